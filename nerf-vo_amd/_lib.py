@@ -1,0 +1,68 @@
+"""ctypes binding of libnerfvo_hip.so (C-ABI declared in include/nerfvo_hip.h).
+
+No torch types cross this boundary: tensors are passed as raw device pointers (``Tensor.data_ptr()``)
+and the stream as ``torch.cuda.current_stream().cuda_stream``.  The product path has NO fallback:
+if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libnerfvo_hip.so"
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/nerfvo_hip.h one to one
+_u32, _u64, _i64, _int = C.c_uint32, C.c_uint64, C.c_int64, C.c_int
+_p = C.c_void_p
+_SIGNATURES = {
+    "nvo_last_error": (C.c_char_p, []),
+    "nvo_version": (_int, []),
+    "nvo_create_encoding": (_int, [_u32, C.c_char_p, C.POINTER(_p)]),
+    "nvo_create_network": (_int, [_u32, _u32, C.c_char_p, C.POINTER(_p)]),
+    "nvo_create_network_with_input_encoding": (_int, [_u32, _u32, C.c_char_p, C.c_char_p, C.POINTER(_p)]),
+    "nvo_destroy": (_int, [_p]),
+    "nvo_n_input_dims": (_u32, [_p]),
+    "nvo_n_output_dims": (_u32, [_p]),
+    "nvo_padded_output_dims": (_u32, [_p]),
+    "nvo_n_params": (_u64, [_p]),
+    "nvo_initial_params": (_int, [_p, _u64, _p]),
+    "nvo_ctx_bytes": (_u64, [_p, _u32]),
+    "nvo_set_option": (_int, [_p, C.c_char_p, _i64]),
+    "nvo_fwd": (_int, [_p, _p, _u32, _p, _p, _p, _p]),
+    "nvo_bwd": (_int, [_p, _p, _u32, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_grid_describe": (_int, [_p, _p, _p]),
+    "nvo_grid_indices": (_int, [_p, _p, _u32, _p, _p]),
+}
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python nerf-vo_amd/build.py`). "
+                "There is no CPU fallback."
+            )
+        handle = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().nvo_last_error()
+        raise RuntimeError(f"nerfvo_hip {what} failed (code {rc}): {msg.decode() if msg else '?'}")

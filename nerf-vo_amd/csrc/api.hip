@@ -1,0 +1,559 @@
+// C-ABI group A: tiny-cuda-nn module boundary (include/nerfvo_hip.h).  Host-side objects only;
+// all device work is in grid.hip / mlp.hip / sh.hip.
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void nvo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* nvo_last_error(void) { return g_err; }
+extern "C" int nvo_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------------------
+// minimal flat JSON object reader (strings, numbers, booleans; nested values are skipped)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct JsonVal {
+    bool is_num = false;
+    double num = 0.0;
+    std::string str;
+};
+typedef std::map<std::string, JsonVal> JsonObj;
+
+struct JsonParser {
+    const char* p;
+    bool ok = true;
+    void ws() { while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') ++p; }
+    std::string string_() {
+        std::string s;
+        if (*p != '"') { ok = false; return s; }
+        ++p;
+        while (*p && *p != '"') {
+            if (*p == '\\' && p[1]) ++p;
+            s.push_back(*p++);
+        }
+        if (*p == '"') ++p; else ok = false;
+        return s;
+    }
+    void skip_nested(char open, char close) {
+        int depth = 0;
+        do {
+            if (*p == '"') { string_(); continue; }
+            if (*p == open) ++depth;
+            if (*p == close) --depth;
+            if (!*p) { ok = false; return; }
+            ++p;
+        } while (depth > 0);
+    }
+    bool parse(JsonObj& out) {
+        ws();
+        if (*p != '{') return false;
+        ++p;
+        while (ok) {
+            ws();
+            if (*p == '}') { ++p; break; }
+            std::string key = string_();
+            ws();
+            if (*p != ':') return false;
+            ++p;
+            ws();
+            JsonVal v;
+            if (*p == '"') {
+                v.str = string_();
+            } else if (*p == '{') {
+                skip_nested('{', '}');
+            } else if (*p == '[') {
+                skip_nested('[', ']');
+            } else if (!strncmp(p, "true", 4)) {
+                v.is_num = true; v.num = 1; v.str = "true"; p += 4;
+            } else if (!strncmp(p, "false", 5)) {
+                v.is_num = true; v.num = 0; v.str = "false"; p += 5;
+            } else if (!strncmp(p, "null", 4)) {
+                p += 4;
+            } else {
+                char* end = nullptr;
+                v.num = strtod(p, &end);
+                if (end == p) return false;
+                v.is_num = true;
+                p = end;
+            }
+            out[key] = v;
+            ws();
+            if (*p == ',') ++p;
+        }
+        return ok;
+    }
+};
+
+bool json_parse(const char* text, JsonObj& out) {
+    if (!text) return false;
+    JsonParser jp{text};
+    return jp.parse(out);
+}
+double json_num(const JsonObj& o, const char* key, double dflt) {
+    auto it = o.find(key);
+    return (it != o.end() && it->second.is_num) ? it->second.num : dflt;
+}
+std::string json_str(const JsonObj& o, const char* key, const char* dflt) {
+    auto it = o.find(key);
+    return (it != o.end() && !it->second.is_num) ? it->second.str : std::string(dflt);
+}
+bool json_has(const JsonObj& o, const char* key) { return o.find(key) != o.end(); }
+
+// PCG32 (O'Neill; the generator tcnn seeds its parameter init with)
+struct Pcg32 {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    explicit Pcg32(uint64_t seed) {
+        state = 0u;
+        inc = (1ULL << 1u) | 1u;
+        next_uint();
+        state += seed;
+        next_uint();
+    }
+    uint32_t next_uint() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    float next_float() {  // [0,1)
+        union { uint32_t u; float f; } x;
+        x.u = (next_uint() >> 9) | 0x3f800000u;
+        return x.f - 1.0f;
+    }
+};
+
+int parse_activation(const std::string& s, int* out) {
+    if (s == "None" || s == "none") { *out = NVO_ACT_NONE; return NVO_OK; }
+    if (s == "ReLU" || s == "relu") { *out = NVO_ACT_RELU; return NVO_OK; }
+    if (s == "Sigmoid" || s == "sigmoid") { *out = NVO_ACT_SIGMOID; return NVO_OK; }
+    nvo_set_error("activation '%s' is not supported (None, ReLU, Sigmoid)", s.c_str());
+    return NVO_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// module objects
+// ---------------------------------------------------------------------------------------------
+struct nvo_module_s {
+    uint32_t n_in = 0, n_out = 0, n_out_padded = 0;
+    uint64_t n_params = 0;
+    virtual ~nvo_module_s() {}
+    virtual uint64_t ctx_bytes(uint32_t batch) const = 0;
+    virtual int init_params(Pcg32& rng, float* out) const = 0;
+    virtual int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
+                    void* ctx) = 0;
+    virtual int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
+                    const void* dout, void* ctx, float* din, float* dparams) = 0;
+    virtual int set_option(const char* key, int64_t value) {
+        nvo_set_error("unknown option '%s'", key);
+        return NVO_ERR_INVALID;
+    }
+};
+
+namespace {
+
+struct GridModule : nvo_module_s {
+    NvoGridLevels g;
+    NvoGridSlices slices;
+    int bwd_mode = 1;
+    bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
+
+    ~GridModule() override { nvo_grid_slices_destroy(&slices); }
+
+    static int create(uint32_t n_input_dims, const JsonObj& cfg, std::unique_ptr<GridModule>* out) {
+        NVO_REQUIRE(n_input_dims == 3, "HashGrid: only 3 input dims are supported (got %u)", n_input_dims);
+        const std::string type = json_str(cfg, "type", "Hash");
+        NVO_REQUIRE(type == "Hash", "grid type '%s' unsupported (Hash only)", type.c_str());
+        const std::string interp = json_str(cfg, "interpolation", "Linear");
+        NVO_REQUIRE(interp == "Linear", "interpolation '%s' unsupported (Linear only)", interp.c_str());
+        const uint32_t n_levels = (uint32_t)json_num(cfg, "n_levels", 16);
+        const uint32_t n_feat = (uint32_t)json_num(cfg, "n_features_per_level", 2);
+        const uint32_t log2_t = (uint32_t)json_num(cfg, "log2_hashmap_size", 19);
+        const uint32_t base = (uint32_t)json_num(cfg, "base_resolution", 16);
+        const float pls = (float)json_num(cfg, "per_level_scale", 2.0);
+        NVO_REQUIRE(n_levels >= 1 && n_levels <= NVO_MAX_LEVELS, "n_levels %u out of range", n_levels);
+        NVO_REQUIRE(n_feat == 2, "n_features_per_level must be 2 (got %u)", n_feat);
+        NVO_REQUIRE(log2_t >= 4 && log2_t <= 24, "log2_hashmap_size %u out of range", log2_t);
+        std::unique_ptr<GridModule> m(new GridModule());
+        const uint32_t entries = nvo_grid_levels_init(&m->g, n_levels, n_feat, log2_t, base, pls);
+        m->n_in = 3;
+        m->n_out = m->n_out_padded = n_levels * n_feat;
+        m->n_params = (uint64_t)entries * n_feat;
+        // The slice table of the LDS backward is a (tiny) device allocation: made lazily at the
+        // first backward so that modules can be created / described on a host without a GPU.
+        const char* env = getenv("NVO_GRID_BWD_MODE");
+        if (env) m->bwd_mode = atoi(env);
+        *out = std::move(m);
+        return NVO_OK;
+    }
+    int ensure_slices() {
+        if (bwd_mode == 1 && slices.n_slices == 0) return nvo_grid_slices_create(g, &slices);
+        return NVO_OK;
+    }
+    uint64_t ctx_bytes(uint32_t) const override { return 16; }
+    int init_params(Pcg32& rng, float* out) const override {
+        for (uint64_t i = 0; i < n_params; ++i) out[i] = rng.next_float() * 2e-4f - 1e-4f;
+        return NVO_OK;
+    }
+    int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
+            void*) override {
+        return nvo_grid_fwd_launch(g, s, B, in, params, out, soa_out, nullptr);
+    }
+    int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void*,
+            const void* dout, void*, float* din, float* dparams) override {
+        if (dparams) {
+            int rc = ensure_slices();
+            if (rc) return rc;
+            rc = nvo_grid_bwd_launch(g, &slices, s, B, in, dout, false, soa_out, dparams, bwd_mode);
+            if (rc) return rc;
+        }
+        if (din) {
+            int rc = nvo_grid_bwd_input_launch(g, s, B, in, params, dout, false, soa_out, din, true);
+            if (rc) return rc;
+        }
+        return NVO_OK;
+    }
+    int set_option(const char* key, int64_t value) override {
+        if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        return nvo_module_s::set_option(key, value);
+    }
+};
+
+struct ShModule : nvo_module_s {
+    uint32_t degree = 4;
+    static int create(uint32_t n_input_dims, const JsonObj& cfg, std::unique_ptr<ShModule>* out) {
+        NVO_REQUIRE(n_input_dims == 3, "SphericalHarmonics needs 3 input dims (got %u)", n_input_dims);
+        std::unique_ptr<ShModule> m(new ShModule());
+        m->degree = (uint32_t)json_num(cfg, "degree", 4);
+        NVO_REQUIRE(m->degree >= 1 && m->degree <= 4, "SphericalHarmonics degree %u not in 1..4", m->degree);
+        m->n_in = 3;
+        m->n_out = m->n_out_padded = m->degree * m->degree;
+        m->n_params = 0;
+        *out = std::move(m);
+        return NVO_OK;
+    }
+    uint64_t ctx_bytes(uint32_t) const override { return 16; }
+    int init_params(Pcg32&, float*) const override { return NVO_OK; }
+    int fwd(hipStream_t s, uint32_t B, const float* in, const void*, void* out, void*) override {
+        return nvo_sh_fwd_launch(s, B, degree, in, out, n_out_padded, n_out_padded);
+    }
+    int bwd(hipStream_t s, uint32_t B, const float* in, const void*, const void*, const void* dout,
+            void*, float* din, float*) override {
+        if (din) return nvo_sh_bwd_input_launch(s, B, degree, in, dout, n_out_padded, din);
+        return NVO_OK;
+    }
+};
+
+struct MlpModule : nvo_module_s {
+    int in_pad = 16, width = 64, n_hidden = 1, out_pad = 16;
+    int act = NVO_ACT_RELU, out_act = NVO_ACT_NONE;
+
+    static int create(uint32_t n_input_dims, uint32_t n_output_dims, const JsonObj& cfg,
+                      std::unique_ptr<MlpModule>* out) {
+        const std::string otype = json_str(cfg, "otype", "FullyFusedMLP");
+        NVO_REQUIRE(otype == "FullyFusedMLP" || otype == "CutlassMLP",
+                    "network otype '%s' unsupported", otype.c_str());
+        std::unique_ptr<MlpModule> m(new MlpModule());
+        m->width = (int)json_num(cfg, "n_neurons", 64);
+        m->n_hidden = (int)json_num(cfg, "n_hidden_layers", 1);
+        int rc = parse_activation(json_str(cfg, "activation", "ReLU"), &m->act);
+        if (rc) return rc;
+        rc = parse_activation(json_str(cfg, "output_activation", "None"), &m->out_act);
+        if (rc) return rc;
+        m->in_pad = (int)nvo_round_up(n_input_dims, 16);
+        m->out_pad = (int)nvo_round_up(n_output_dims, 16);
+        m->n_in = n_input_dims;
+        m->n_out = n_output_dims;
+        m->n_out_padded = (uint32_t)m->out_pad;
+        if (!nvo_mlp_shape_supported(m->in_pad, m->width, m->n_hidden, m->out_pad)) {
+            nvo_set_error("FullyFusedMLP shape (in_pad=%d, n_neurons=%d, n_hidden_layers=%d, out_pad=%d) "
+                          "has no gfx950 kernel instance", m->in_pad, m->width, m->n_hidden, m->out_pad);
+            return NVO_ERR_UNSUPPORTED;
+        }
+        m->n_params = (uint64_t)m->width * m->in_pad + (uint64_t)(m->n_hidden - 1) * m->width * m->width +
+                      (uint64_t)m->out_pad * m->width;
+        *out = std::move(m);
+        return NVO_OK;
+    }
+    uint64_t hidden_bytes(uint32_t B) const { return (uint64_t)n_hidden * B * width * sizeof(_Float16); }
+    uint64_t ctx_bytes(uint32_t B) const override { return nvo_round_up(hidden_bytes(B), 256) + 256; }
+    int init_params(Pcg32& rng, float* out) const override {
+        // Xavier uniform per weight matrix (tcnn FullyFusedMLP::initialize_params)
+        uint64_t o = 0;
+        auto fill = [&](int fan_out, int fan_in) {
+            const float scale = sqrtf(6.0f / (float)(fan_in + fan_out));
+            for (int i = 0; i < fan_out * fan_in; ++i) out[o++] = (rng.next_float() * 2.f - 1.f) * scale;
+        };
+        fill(width, in_pad);
+        for (int l = 0; l < n_hidden - 1; ++l) fill(width, width);
+        fill(out_pad, width);
+        return NVO_OK;
+    }
+    NvoMlpArgs make_args(uint32_t B, const void* in, int in_mode, uint32_t n_in_true,
+                         const void* params, void* out, void* ctx) const {
+        NvoMlpArgs a;
+        memset(&a, 0, sizeof(a));
+        a.batch = B;
+        a.n_in = n_in_true;
+        a.in_mode = in_mode;
+        a.input = in;
+        a.weights = (const _Float16*)params;
+        a.output = (_Float16*)out;
+        a.hidden = (_Float16*)ctx;
+        a.act = act;
+        a.out_act = out_act;
+        return a;
+    }
+    int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
+            void* ctx) override {
+        NvoMlpArgs a = make_args(B, in, NVO_IO_F32_ROWS, n_in, params, out, ctx);
+        return nvo_mlp_fwd_launch(in_pad, width, n_hidden, out_pad, a, s);
+    }
+    int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
+            const void* dout, void* ctx, float* din, float* dparams) override {
+        NVO_REQUIRE(ctx != nullptr, "Network.bwd needs the ctx of the matching fwd");
+        NvoMlpArgs a = make_args(B, in, NVO_IO_F32_ROWS, n_in, params, (void*)out, ctx);
+        a.doutput = (const _Float16*)dout;
+        a.dinput = din;
+        a.din_mode = NVO_IO_F32_ROWS;
+        a.dweights = dparams;
+        if (dparams) NVO_CHECK_HIP(hipMemsetAsync(dparams, 0, sizeof(float) * n_params, s));
+        return nvo_mlp_bwd_launch(in_pad, width, n_hidden, out_pad, a, s);
+    }
+};
+
+// tcnn NetworkWithInputEncoding: params = [network | encoding]; the encoded features stay
+// level-major fp16 in ctx between the two kernels.
+struct NwieModule : nvo_module_s {
+    std::unique_ptr<GridModule> enc;
+    std::unique_ptr<MlpModule> net;
+
+    uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
+    uint64_t ctx_bytes(uint32_t B) const override {
+        // [encoded SoA][d_encoded SoA][mlp hidden]
+        return 2 * enc_bytes(B) + net->ctx_bytes(B);
+    }
+    int init_params(Pcg32& rng, float* out) const override {
+        int rc = net->init_params(rng, out);
+        if (rc) return rc;
+        return enc->init_params(rng, out + net->n_params);
+    }
+    int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
+            void* ctx) override {
+        NVO_REQUIRE(ctx != nullptr, "NetworkWithInputEncoding.fwd needs ctx scratch (also for inference)");
+        char* c = (char*)ctx;
+        void* encoded = c;
+        void* hidden = c + 2 * enc_bytes(B);
+        const _Float16* p = (const _Float16*)params;
+        int rc = nvo_grid_fwd_launch(enc->g, s, B, in, p + net->n_params, encoded, true, nullptr);
+        if (rc) return rc;
+        NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
+        return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
+    }
+    int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
+            const void* dout, void* ctx, float* din, float* dparams) override {
+        NVO_REQUIRE(ctx != nullptr, "NetworkWithInputEncoding.bwd needs the ctx of the matching fwd");
+        char* c = (char*)ctx;
+        void* encoded = c;
+        void* dencoded = c + enc_bytes(B);
+        void* hidden = c + 2 * enc_bytes(B);
+        const _Float16* p = (const _Float16*)params;
+        NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, (void*)out, hidden);
+        a.doutput = (const _Float16*)dout;
+        a.dinput = dencoded;
+        a.din_mode = NVO_IO_HALF2_SOA;
+        a.dweights = dparams;
+        if (dparams) NVO_CHECK_HIP(hipMemsetAsync(dparams, 0, sizeof(float) * net->n_params, s));
+        int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
+        if (rc) return rc;
+        if (dparams) {
+            rc = enc->ensure_slices();
+            if (rc) return rc;
+            rc = nvo_grid_bwd_launch(enc->g, &enc->slices, s, B, in, dencoded, false, true,
+                                     dparams + net->n_params, enc->bwd_mode);
+            if (rc) return rc;
+        }
+        if (din) {
+            rc = nvo_grid_bwd_input_launch(enc->g, s, B, in, p + net->n_params, dencoded, false, true,
+                                           din, true);
+            if (rc) return rc;
+        }
+        return NVO_OK;
+    }
+    int set_option(const char* key, int64_t value) override { return enc->set_option(key, value); }
+};
+
+int create_encoding_impl(uint32_t n_input_dims, const char* json, std::unique_ptr<nvo_module_s>* out,
+                         std::unique_ptr<GridModule>* grid_out) {
+    JsonObj cfg;
+    NVO_REQUIRE(json_parse(json, cfg), "encoding config is not a JSON object: %s", json ? json : "(null)");
+    const std::string otype = json_str(cfg, "otype", "");
+    if (otype == "HashGrid" || otype == "Grid") {
+        std::unique_ptr<GridModule> g;
+        int rc = GridModule::create(n_input_dims, cfg, &g);
+        if (rc) return rc;
+        if (grid_out) *grid_out = std::move(g); else *out = std::move(g);
+        return NVO_OK;
+    }
+    if (otype == "SphericalHarmonics") {
+        NVO_REQUIRE(grid_out == nullptr, "NetworkWithInputEncoding supports HashGrid encodings only");
+        std::unique_ptr<ShModule> m;
+        int rc = ShModule::create(n_input_dims, cfg, &m);
+        if (rc) return rc;
+        *out = std::move(m);
+        return NVO_OK;
+    }
+    nvo_set_error("encoding otype '%s' unsupported (HashGrid, SphericalHarmonics)", otype.c_str());
+    return NVO_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// exported C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int nvo_create_encoding(uint32_t n_input_dims, const char* encoding_json, nvo_module_t* out) {
+    NVO_REQUIRE(out != nullptr, "out is NULL");
+    std::unique_ptr<nvo_module_s> m;
+    int rc = create_encoding_impl(n_input_dims, encoding_json, &m, nullptr);
+    if (rc) return rc;
+    *out = m.release();
+    return NVO_OK;
+}
+
+int nvo_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const char* network_json,
+                       nvo_module_t* out) {
+    NVO_REQUIRE(out != nullptr, "out is NULL");
+    JsonObj cfg;
+    NVO_REQUIRE(json_parse(network_json, cfg), "network config is not a JSON object");
+    std::unique_ptr<MlpModule> m;
+    int rc = MlpModule::create(n_input_dims, n_output_dims, cfg, &m);
+    if (rc) return rc;
+    *out = m.release();
+    return NVO_OK;
+}
+
+int nvo_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims,
+                                           const char* encoding_json, const char* network_json,
+                                           nvo_module_t* out) {
+    NVO_REQUIRE(out != nullptr, "out is NULL");
+    std::unique_ptr<NwieModule> m(new NwieModule());
+    std::unique_ptr<nvo_module_s> unused;
+    int rc = create_encoding_impl(n_input_dims, encoding_json, &unused, &m->enc);
+    if (rc) return rc;
+    m->enc->soa_out = true;
+    JsonObj cfg;
+    NVO_REQUIRE(json_parse(network_json, cfg), "network config is not a JSON object");
+    rc = MlpModule::create(m->enc->n_out, n_output_dims, cfg, &m->net);
+    if (rc) return rc;
+    m->n_in = n_input_dims;
+    m->n_out = n_output_dims;
+    m->n_out_padded = m->net->n_out_padded;
+    m->n_params = m->net->n_params + m->enc->n_params;
+    *out = m.release();
+    return NVO_OK;
+}
+
+int nvo_destroy(nvo_module_t m) {
+    delete m;
+    return NVO_OK;
+}
+
+uint32_t nvo_n_input_dims(nvo_module_t m) { return m ? m->n_in : 0; }
+uint32_t nvo_n_output_dims(nvo_module_t m) { return m ? m->n_out : 0; }
+uint32_t nvo_padded_output_dims(nvo_module_t m) { return m ? m->n_out_padded : 0; }
+uint64_t nvo_n_params(nvo_module_t m) { return m ? m->n_params : 0; }
+uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch) { return m ? m->ctx_bytes(batch) : 0; }
+
+int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out) {
+    NVO_REQUIRE(m && (host_out || m->n_params == 0), "initial_params: NULL argument");
+    Pcg32 rng(seed);
+    return m->init_params(rng, host_out);
+}
+
+int nvo_set_option(nvo_module_t m, const char* key, int64_t value) {
+    NVO_REQUIRE(m && key, "set_option: NULL argument");
+    return m->set_option(key, value);
+}
+
+int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
+            const void* params, void* output, void* ctx) {
+    NVO_REQUIRE(m && output && (input || batch == 0), "fwd: NULL argument");
+    NVO_REQUIRE(params || m->n_params == 0, "fwd: params is NULL");
+    NVO_REQUIRE((batch & 15u) == 0, "fwd: batch (%u) must be a multiple of 16", batch);
+    return m->fwd((hipStream_t)stream, batch, input, params, output, ctx);
+}
+
+int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
+            const void* params, const void* output, const void* dL_doutput, void* ctx,
+            float* dL_dinput, float* dL_dparams) {
+    NVO_REQUIRE(m && dL_doutput && (input || batch == 0), "bwd: NULL argument");
+    NVO_REQUIRE((batch & 15u) == 0, "bwd: batch (%u) must be a multiple of 16", batch);
+    return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput,
+                  dL_dparams);
+}
+
+static GridModule* as_grid(nvo_module_t m) {
+    if (auto* g = dynamic_cast<GridModule*>(m)) return g;
+    if (auto* n = dynamic_cast<NwieModule*>(m)) return n->enc.get();
+    return nullptr;
+}
+
+int nvo_grid_describe(nvo_module_t m, uint32_t* levels_out, float* scales_out) {
+    GridModule* g = as_grid(m);
+    NVO_REQUIRE(g && levels_out && scales_out, "grid_describe: module has no grid encoding");
+    for (uint32_t l = 0; l < g->g.n_levels; ++l) {
+        levels_out[4 * l + 0] = g->g.offset[l];
+        levels_out[4 * l + 1] = g->g.offset[l + 1] - g->g.offset[l];
+        levels_out[4 * l + 2] = g->g.resolution[l];
+        levels_out[4 * l + 3] = g->g.hashed[l];
+        scales_out[l] = g->g.scale[l];
+    }
+    return NVO_OK;
+}
+
+int nvo_grid_indices(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
+                     uint32_t* indices_out) {
+    GridModule* g = as_grid(m);
+    NVO_REQUIRE(g && indices_out, "grid_indices: module has no grid encoding");
+    // The forward kernel needs a table and an output; allocate throw-away ones (debug path only).
+    void* table = nullptr;
+    void* out = nullptr;
+    NVO_CHECK_HIP(hipMalloc(&table, (size_t)g->n_params * 2));
+    NVO_CHECK_HIP(hipMemsetAsync(table, 0, (size_t)g->n_params * 2, (hipStream_t)stream));
+    NVO_CHECK_HIP(hipMalloc(&out, (size_t)g->g.n_levels * batch * 4 + 16));
+    int rc = nvo_grid_fwd_launch(g->g, (hipStream_t)stream, batch, input, table, out, true, indices_out);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(table);
+    (void)hipFree(out);
+    if (rc) return rc;
+    NVO_CHECK_HIP(e);
+    return NVO_OK;
+}
+
+}  // extern "C"

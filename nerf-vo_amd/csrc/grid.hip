@@ -1,0 +1,449 @@
+// Multi-resolution hash-grid encoding for gfx950: forward gather, parameter-gradient scatter and
+// input-gradient kernels.  Replaces tiny-cuda-nn's kernel_grid / kernel_grid_backward /
+// kernel_grid_backward_input (upstream grid.h is not vendored in
+// /root/reference, the arithmetic is restated in oracle/grid.py + oracle/c/nvo_oracle.c).
+//
+// MI355X design notes
+//  * One thread per (sample, level).  The 1-D grid is mapped so that workgroups that the
+//    dispatcher deals to the same XCD (blockIdx % 8, observed round-robin -- speed only, never
+//    correctness) work on the same pair of levels {xcd, xcd+8}: a hashed level's fp16 table is
+//    2 MiB, so one coarse + one fine level stay resident in that XCD's private 4 MiB L2 instead
+//    of the whole 24 MiB table thrashing every L2.
+//  * Encoded features leave the kernel level-major ("SoA": [L][N] half2) so that a wave's store is
+//    256 contiguous bytes; the fused MLP consumes that layout directly.  The tcnn-API path can ask
+//    for sample-major ("AoS": [N][L] half2) instead.
+//  * Interpolation accumulates in fp32 and rounds once to fp16 (tcnn accumulates in fp16).
+//  * Parameter gradients accumulate in fp32 (tcnn: fp16 atomics for F=2).  Two kernels:
+//      - k_grid_bwd_atomic: global float atomics, lane pairs adjacent on one corner (8 B) so a
+//        wave instruction touches 32 distinct 64-B lines, not 64.
+//      - k_grid_bwd_lds:    "slice owner" scatter -- each workgroup owns a 16K-entry slice of one
+//        level's table in LDS (128 KiB of the CU's 160 KiB), re-derives every sample's corner
+//        indices, accumulates hits with LDS atomics and writes the slice back with plain
+//        coalesced stores.  Global atomics on random rows run at ~0.08 TB/s on MI355X
+//        (MI355X_MICROARCH.md, Global float atomics); this path uses none.
+#include "nvo_kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_features,
+                              uint32_t log2_hashmap_size, uint32_t base_resolution,
+                              float per_level_scale) {
+    g->n_levels = n_levels;
+    g->n_features = n_features;
+    const float log2_pls = log2f(per_level_scale);
+    uint32_t offset = 0;
+    for (uint32_t i = 0; i < n_levels; ++i) {
+        const float scale = exp2f((float)i * log2_pls) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        const uint32_t max_params = 0xFFFFFFFFu / 2u;
+        uint32_t params_in_level =
+            powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+        params_in_level = (uint32_t)nvo_round_up(params_in_level, 8u);
+        const uint32_t hash_cap = 1u << log2_hashmap_size;
+        if (params_in_level > hash_cap) params_in_level = hash_cap;
+        g->scale[i] = scale;
+        g->resolution[i] = res;
+        g->offset[i] = offset;
+        g->hashed[i] = ((double)res * (double)res * (double)res > (double)params_in_level) ? 1u : 0u;
+        offset += params_in_level;
+    }
+    for (uint32_t i = n_levels; i <= NVO_MAX_LEVELS; ++i) g->offset[i] = offset;
+    for (uint32_t i = n_levels; i < NVO_MAX_LEVELS; ++i) {
+        g->scale[i] = 0.f;
+        g->resolution[i] = 0;
+        g->hashed[i] = 0;
+    }
+    return offset;
+}
+
+namespace {
+
+constexpr int kGridBlock = 256;
+
+// blockIdx -> (tile, level).  With n_levels a multiple of 8 the blocks that share blockIdx % 8
+// (one XCD under round-robin placement) get levels {xcd, xcd + 8, ...}.
+__device__ __forceinline__ void grid_block_map(uint32_t bid, uint32_t n_levels, uint32_t* tile,
+                                               uint32_t* level) {
+    if ((n_levels & 7u) == 0u) {
+        const uint32_t xcd = bid & 7u;
+        const uint32_t q = bid >> 3;
+        const uint32_t per_xcd = n_levels >> 3;
+        *level = xcd + 8u * (q % per_xcd);
+        *tile = q / per_xcd;
+    } else {
+        *level = bid % n_levels;
+        *tile = bid / n_levels;
+    }
+}
+
+struct Corner {
+    uint32_t px, py, pz;  // cell base
+    float wx, wy, wz;     // fractional position
+};
+
+__device__ __forceinline__ Corner grid_cell(float scale, float x, float y, float z) {
+    // tcnn pos_fract: pos = fma(scale, x, 0.5); cell = floor(pos); frac = pos - cell.
+    Corner c;
+    float fx = fmaf(scale, x, 0.5f), fy = fmaf(scale, y, 0.5f), fz = fmaf(scale, z, 0.5f);
+    float tx = floorf(fx), ty = floorf(fy), tz = floorf(fz);
+    c.px = (uint32_t)(int)tx;
+    c.py = (uint32_t)(int)ty;
+    c.pz = (uint32_t)(int)tz;
+    c.wx = fx - tx;
+    c.wy = fy - ty;
+    c.wz = fz - tz;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// x      : [N][3] f32 (row-major), values expected in [0,1]
+// table  : fp16 parameters, [entries][2]
+// out    : SOA ? [L][N] half2 : [N][L] half2
+// indices: optional debug/parity output, [L][N][8] uint32 (nullptr in production)
+template <bool SOA>
+__global__ void __launch_bounds__(kGridBlock)
+k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
+           const __half2* __restrict__ table, __half2* __restrict__ out,
+           uint32_t* __restrict__ indices) {
+    uint32_t tile, level;
+    grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    const uint32_t i = tile * kGridBlock + threadIdx.x;
+    if (i >= N) return;
+
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const __half2* __restrict__ tab = table + off;
+
+    const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
+                               x[3 * (size_t)i + 2]);
+
+    uint32_t idx[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
+                                c.pz + ((k >> 2) & 1u));
+    }
+    __half2 v[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) v[k] = tab[idx[k]];
+
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                        ((k & 4u) ? c.wz : 1.f - c.wz);
+        const float2 f = __half22float2(v[k]);
+        r0 = fmaf(w, f.x, r0);
+        r1 = fmaf(w, f.y, r1);
+    }
+    const __half2 r = __floats2half2_rn(r0, r1);
+    if (SOA) {
+        out[(size_t)level * N + i] = r;
+    } else {
+        out[(size_t)i * g.n_levels + level] = r;
+    }
+    if (indices) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) indices[((size_t)level * N + i) * 8 + k] = idx[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward w.r.t. parameters, global-atomic form
+// ------------------------------------------------------------------------------------------
+// dy   : SOA ? [L][N] : [N][L] of (half2 | float2), already multiplied by the loss scale
+// grad : fp32 [entries][2], pre-zeroed
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(kGridBlock)
+k_grid_bwd_atomic(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
+                  const DY2* __restrict__ dy, float* __restrict__ grad) {
+    // lane pair (2j, 2j+1) shares one sample; even lane adds feature 0, odd lane feature 1,
+    // so the two 4-byte adds of a corner sit in one 64-B line of one wave instruction.
+    uint32_t tile, level;
+    grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    const uint32_t t = threadIdx.x;
+    const uint32_t i = tile * (kGridBlock / 2) + (t >> 1);
+    if (i >= N) return;
+    const uint32_t feat = t & 1u;
+
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    float* __restrict__ gr = grad + 2 * (size_t)off;
+
+    const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
+                               x[3 * (size_t)i + 2]);
+    const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+    float d;
+    if constexpr (sizeof(DY2) == 4) {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+        d = feat ? f.y : f.x;
+    } else {
+        const float2 f = *reinterpret_cast<const float2*>(&d2);
+        d = feat ? f.y : f.x;
+    }
+    if (d == 0.f) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u),
+                                            c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+        const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                        ((k & 4u) ? c.wz : 1.f - c.wz);
+        atomicAdd(gr + 2 * (size_t)idx + feat, w * d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward w.r.t. parameters, LDS slice-owner form (no global atomics)
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSliceEntries = 16384;             // 16K entries * 2 floats * 4 B = 128 KiB
+constexpr int kLdsBwdBlock = 1024;
+
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(kLdsBwdBlock)
+k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
+               const DY2* __restrict__ dy, float* __restrict__ grad,
+               const uint32_t* __restrict__ slice_level, const uint32_t* __restrict__ slice_first,
+               uint32_t n_chunks) {
+    // blockIdx.x = slice id (level, first entry), blockIdx.y = sample chunk.  n_chunks == 1 ->
+    // plain stores; n_chunks > 1 -> every chunk adds its slice with contiguous (256-B shaped)
+    // float atomics, which run at the full ~1.3 TB/s rate.
+    extern __shared__ float acc[];  // [kSliceEntries][2]
+    const uint32_t level = slice_level[blockIdx.x];
+    const uint32_t first = slice_first[blockIdx.x];
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const float scale = g.scale[level];
+    const uint32_t count = min(kSliceEntries, size - first);
+
+    for (uint32_t e = threadIdx.x; e < 2 * kSliceEntries; e += kLdsBwdBlock) acc[e] = 0.f;
+    __syncthreads();
+
+    const uint32_t per_chunk = (N + n_chunks - 1) / n_chunks;
+    const uint32_t begin = blockIdx.y * per_chunk;
+    const uint32_t end = min(N, begin + per_chunk);
+    for (uint32_t i = begin + threadIdx.x; i < end; i += kLdsBwdBlock) {
+        const Corner c = grid_cell(scale, x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
+                                   x[3 * (size_t)i + 2]);
+        const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+        float2 d;
+        if constexpr (sizeof(DY2) == 4) {
+            d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+        } else {
+            d = *reinterpret_cast<const float2*>(&d2);
+        }
+        if (d.x == 0.f && d.y == 0.f) continue;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u),
+                                                c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+            const uint32_t rel = idx - first;  // unsigned wrap -> huge when idx < first
+            if (rel < count) {
+                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                ((k & 4u) ? c.wz : 1.f - c.wz);
+                atomicAdd(&acc[2 * rel + 0], w * d.x);
+                atomicAdd(&acc[2 * rel + 1], w * d.y);
+            }
+        }
+    }
+    __syncthreads();
+    float* __restrict__ gr = grad + 2 * ((size_t)off + first);
+    if (n_chunks == 1) {
+        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = acc[e];
+    } else {
+        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) {
+            const float v = acc[e];
+            if (v != 0.f) atomicAdd(gr + e, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward w.r.t. the input position (needed for analytic normals and pose gradients)
+// ------------------------------------------------------------------------------------------
+// One thread per (sample, level); per-level partials are combined with float atomics into
+// dx[N][3] (16 adds per element, consecutive lanes -> consecutive 12-B rows).
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(kGridBlock)
+k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
+                 const __half2* __restrict__ table, const DY2* __restrict__ dy,
+                 float* __restrict__ dx) {
+    uint32_t tile, level;
+    grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    const uint32_t i = tile * kGridBlock + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const float scale = g.scale[level];
+    const __half2* __restrict__ tab = table + off;
+
+    const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+    float2 d;
+    if constexpr (sizeof(DY2) == 4) {
+        d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+    } else {
+        d = *reinterpret_cast<const float2*>(&d2);
+    }
+    if (d.x == 0.f && d.y == 0.f) return;
+
+    const Corner c = grid_cell(scale, x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
+                               x[3 * (size_t)i + 2]);
+    float s[8];  // dL/dy . value at each corner
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u),
+                                            c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+        const float2 f = __half22float2(tab[idx]);
+        s[k] = f.x * d.x + f.y * d.y;
+    }
+    const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+    // d/dx: (corner with x-bit) - (corner without), weighted by the other two axes
+    const float gx = scale * (wy0 * wz0 * (s[1] - s[0]) + c.wy * wz0 * (s[3] - s[2]) +
+                              wy0 * c.wz * (s[5] - s[4]) + c.wy * c.wz * (s[7] - s[6]));
+    const float gy = scale * (wx0 * wz0 * (s[2] - s[0]) + c.wx * wz0 * (s[3] - s[1]) +
+                              wx0 * c.wz * (s[6] - s[4]) + c.wx * c.wz * (s[7] - s[5]));
+    const float gz = scale * (wx0 * wy0 * (s[4] - s[0]) + c.wx * wy0 * (s[5] - s[1]) +
+                              wx0 * c.wy * (s[6] - s[2]) + c.wx * c.wy * (s[7] - s[3]));
+    atomicAdd(dx + 3 * (size_t)i + 0, gx);
+    atomicAdd(dx + 3 * (size_t)i + 1, gy);
+    atomicAdd(dx + 3 * (size_t)i + 2, gz);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (C++ linkage, used by api.cpp and the fused pipeline)
+// ---------------------------------------------------------------------------------------------
+int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
+                        const void* table_half, void* out_half, bool soa, uint32_t* indices) {
+    if (N == 0) return NVO_OK;
+    NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
+                g.n_features);
+    const uint32_t tiles = nvo_div_up(N, kGridBlock);
+    const dim3 grid(tiles * g.n_levels), block(kGridBlock);
+    if (soa) {
+        hipLaunchKernelGGL(k_grid_fwd<true>, grid, block, 0, stream, g, N, x,
+                           (const __half2*)table_half, (__half2*)out_half, indices);
+    } else {
+        hipLaunchKernelGGL(k_grid_fwd<false>, grid, block, 0, stream, g, N, x,
+                           (const __half2*)table_half, (__half2*)out_half, indices);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+// Slice tables for the LDS backward live in a small device buffer owned by the module.
+
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
+    uint32_t n = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l)
+        n += nvo_div_up(g.offset[l + 1] - g.offset[l], kSliceEntries);
+    uint32_t* h = (uint32_t*)malloc(sizeof(uint32_t) * 2 * n);
+    uint32_t j = 0;
+    // Largest slices (fine, hashed levels) first so the tail of the launch is the cheap work.
+    for (int l = (int)g.n_levels - 1; l >= 0; --l) {
+        const uint32_t size = g.offset[l + 1] - g.offset[l];
+        for (uint32_t f = 0; f < size; f += kSliceEntries) {
+            h[j] = (uint32_t)l;
+            h[n + j] = f;
+            ++j;
+        }
+    }
+    s->n_slices = n;
+    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(uint32_t) * 2 * n));
+    s->d_first = s->d_level + n;
+    NVO_CHECK_HIP(hipMemcpy(s->d_level, h, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice));
+    free(h);
+    return NVO_OK;
+}
+
+void nvo_grid_slices_destroy(NvoGridSlices* s) {
+    if (s->d_level) (void)hipFree(s->d_level);
+    s->d_level = s->d_first = nullptr;
+    s->n_slices = 0;
+}
+
+// mode: 0 = global atomics, 1 = LDS slice owner.  dy_is_float selects float2 vs half2 input.
+int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
+                        uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
+                        float* grad, int mode) {
+    const size_t grad_bytes = sizeof(float) * 2 * (size_t)g.offset[g.n_levels];
+    if (N == 0) {
+        NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
+        return NVO_OK;
+    }
+    NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
+    if (mode == 1 && slices && slices->n_slices) {
+        // enough sample chunks to put >= ~2 workgroups' worth of waves on every CU
+        uint32_t n_chunks = 1;
+        while (slices->n_slices * n_chunks < 256u && n_chunks < 64u && (N / (n_chunks * 2)) >= 8192u)
+            n_chunks *= 2;
+        if (n_chunks > 1) NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
+        const dim3 grid(slices->n_slices, n_chunks), block(kLdsBwdBlock);
+        const size_t lds = sizeof(float) * 2 * kSliceEntries;
+#define NVO_LAUNCH_LDS(SOA_, T_)                                                              \
+    do {                                                                                      \
+        static bool attr_set = false; /* >64 KiB of dynamic LDS needs an explicit opt-in */   \
+        if (!attr_set) {                                                                      \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_bwd_lds<SOA_, T_>,          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                              (int)lds));                                     \
+            attr_set = true;                                                                  \
+        }                                                                                     \
+        hipLaunchKernelGGL((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
+                           (const T_*)dy, grad, slices->d_level, slices->d_first, n_chunks);  \
+    } while (0)
+        if (soa) {
+            if (dy_is_float) NVO_LAUNCH_LDS(true, float2); else NVO_LAUNCH_LDS(true, __half2);
+        } else {
+            if (dy_is_float) NVO_LAUNCH_LDS(false, float2); else NVO_LAUNCH_LDS(false, __half2);
+        }
+#undef NVO_LAUNCH_LDS
+        NVO_CHECK_LAUNCH();
+        return NVO_OK;
+    }
+    NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
+    const uint32_t tiles = nvo_div_up(N, kGridBlock / 2);
+    const dim3 grid(tiles * g.n_levels), block(kGridBlock);
+#define NVO_LAUNCH_AT(SOA_, T_)                                                               \
+    hipLaunchKernelGGL((k_grid_bwd_atomic<SOA_, T_>), grid, block, 0, stream, g, N, x,        \
+                       (const T_*)dy, grad)
+    if (soa) {
+        if (dy_is_float) NVO_LAUNCH_AT(true, float2); else NVO_LAUNCH_AT(true, __half2);
+    } else {
+        if (dy_is_float) NVO_LAUNCH_AT(false, float2); else NVO_LAUNCH_AT(false, __half2);
+    }
+#undef NVO_LAUNCH_AT
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
+                              const float* x, const void* table_half, const void* dy,
+                              bool dy_is_float, bool soa, float* dx, bool zero_dx) {
+    if (N == 0) return NVO_OK;
+    if (zero_dx) NVO_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * 3 * (size_t)N, stream));
+    const uint32_t tiles = nvo_div_up(N, kGridBlock);
+    const dim3 grid(tiles * g.n_levels), block(kGridBlock);
+#define NVO_LAUNCH_IN(SOA_, T_)                                                               \
+    hipLaunchKernelGGL((k_grid_bwd_input<SOA_, T_>), grid, block, 0, stream, g, N, x,         \
+                       (const __half2*)table_half, (const T_*)dy, dx)
+    if (soa) {
+        if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);
+    } else {
+        if (dy_is_float) NVO_LAUNCH_IN(false, float2); else NVO_LAUNCH_IN(false, __half2);
+    }
+#undef NVO_LAUNCH_IN
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}

@@ -1,0 +1,551 @@
+// Fully fused small-MLP forward / backward on CDNA4 matrix cores (gfx950).
+// Replaces tiny-cuda-nn's kernel_mlp_fused / kernel_mlp_fused_backward + the CUTLASS split-K
+// weight-gradient GEMMs (upstream fully_fused_mlp.cu is not vendored
+// in /root/reference -- restated in oracle/mlp.py).
+//
+// Layout idea ("transposed chain", MI355X-first, no warp-shaped tiling):
+//   Every layer is evaluated as  H_out^T[n][m] = W[n][k] * H_in^T[k][m]  on
+//   v_mfma_f32_16x16x16_f16, with the SAMPLE index m on the MFMA column (lane & 15) and the
+//   feature index in the lane's registers.  The C/D register map of that instruction
+//   (row = 4*(lane>>4)+reg, col = lane&15) is exactly its own B-operand map
+//   (k = 4*(lane>>4)+j, col = lane&15), so a layer's accumulator tile, once activated and packed to
+//   fp16, IS the next layer's B operand: the whole MLP runs in registers, no LDS round trip, no
+//   shuffles.  Weights (row-major [out][in] fp16, tcnn's order) are the A operand and are loaded
+//   into registers once per wave; a wave then streams 16-sample tiles.
+//   Backward runs the same chain with W^T as the A operand (dH_in^T = W^T * dZ^T) and forms
+//   dW[n][k] = sum_m dZ[m][n] H[m][k] on the matrix cores too: both operands need the sample
+//   index in registers, which is a 16x16 transpose of what the chain holds -- done with one
+//   wave-private LDS tile and ds_read_b64_tr_b16 (hardware transposing read).
+//   dW accumulates in fp32 registers across all of a wave's tiles and is flushed once with
+//   row-contiguous float atomics.
+//
+// Numerics: fp16 operands, fp32 accumulate (tcnn accumulates in fp16), fp16 hidden activations.
+#include "nvo_kernels.h"
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+namespace {
+
+constexpr int kMlpBlock = 256;
+constexpr int kWavesPerBlock = kMlpBlock / 64;
+
+__device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_fwd(int act, float v) {
+    if (act == NVO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == NVO_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// derivative expressed through the (saved, fp16-rounded) activation output
+__device__ __forceinline__ float act_bwd_from_out(int act, float out) {
+    if (act == NVO_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+    if (act == NVO_ACT_SIGMOID) return out * (1.f - out);
+    return 1.f;
+}
+
+__device__ __forceinline__ h4 pack_act(int act, f4 v) {
+    h4 r;
+    r[0] = (_Float16)act_fwd(act, v[0]);
+    r[1] = (_Float16)act_fwd(act, v[1]);
+    r[2] = (_Float16)act_fwd(act, v[2]);
+    r[3] = (_Float16)act_fwd(act, v[3]);
+    return r;
+}
+
+// A-operand fragments of W[N_OUT][K_IN] (row-major): f[tn][tk] = W[16tn + (l&15)][16tk + 4g + j]
+template <int N_OUT, int K_IN>
+struct WFrag {
+    h4 f[N_OUT / 16][K_IN / 16];
+    __device__ __forceinline__ void load(const _Float16* __restrict__ W, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk)
+                f[tn][tk] = *reinterpret_cast<const h4*>(W + (size_t)(16 * tn + r) * K_IN + 16 * tk + 4 * g);
+    }
+};
+
+// A-operand fragments of W^T: f[tk][tn] = W[16tn + 4g + j][16tk + (l&15)]   (strided gather, once)
+template <int N_OUT, int K_IN>
+struct WTFrag {
+    h4 f[K_IN / 16][N_OUT / 16];
+    __device__ __forceinline__ void load(const _Float16* __restrict__ W, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+            for (int tn = 0; tn < N_OUT / 16; ++tn) {
+                h4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = W[(size_t)(16 * tn + 4 * g + j) * K_IN + 16 * tk + r];
+                f[tk][tn] = v;
+            }
+    }
+};
+
+// H_out^T tile = W * H_in^T
+template <int N_OUT, int K_IN>
+__device__ __forceinline__ void layer_mm(const WFrag<N_OUT, K_IN>& w, const h4 (&in)[K_IN / 16],
+                                         f4 (&acc)[N_OUT / 16]) {
+#pragma unroll
+    for (int tn = 0; tn < N_OUT / 16; ++tn) {
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk) c = mfma16(w.f[tn][tk], in[tk], c);
+        acc[tn] = c;
+    }
+}
+
+// dH_in^T tile = W^T * dZ^T
+template <int N_OUT, int K_IN>
+__device__ __forceinline__ void layer_mm_t(const WTFrag<N_OUT, K_IN>& wt,
+                                           const h4 (&dz)[N_OUT / 16], f4 (&acc)[K_IN / 16]) {
+#pragma unroll
+    for (int tk = 0; tk < K_IN / 16; ++tk) {
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn) c = mfma16(wt.f[tk][tn], dz[tn], c);
+        acc[tk] = c;
+    }
+}
+
+// Load the B-operand fragments of one 16-sample input tile: x[tk][j] = in[m][16tk + 4g + j]
+template <int IN_PAD>
+__device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, int g,
+                                           h4 (&x)[IN_PAD / 16]) {
+    if (a.in_mode == NVO_IO_F32_ROWS) {
+        const float* __restrict__ p = (const float*)a.input + (size_t)row * a.n_in;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = 16 * tk + 4 * g + j;
+                x[tk][j] = c < a.n_in ? (_Float16)p[c] : (_Float16)1.0f;
+            }
+        }
+    } else if (a.in_mode == NVO_IO_HALF2_SOA) {
+        const h2* __restrict__ p = (const h2*)a.input;
+        const uint32_t n_lv = a.n_in >> 1;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+            const uint32_t lv = 8 * tk + 2 * g;
+            h2 v0 = {(_Float16)0.f, (_Float16)0.f}, v1 = v0;
+            if (lv < n_lv) v0 = p[(size_t)lv * a.batch + row];
+            if (lv + 1 < n_lv) v1 = p[(size_t)(lv + 1) * a.batch + row];
+            x[tk][0] = v0[0];
+            x[tk][1] = v0[1];
+            x[tk][2] = v1[0];
+            x[tk][3] = v1[1];
+        }
+    } else {
+        const _Float16* __restrict__ p = (const _Float16*)a.input + (size_t)row * IN_PAD;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk)
+            x[tk] = *reinterpret_cast<const h4*>(p + 16 * tk + 4 * g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+__global__ void __launch_bounds__(kMlpBlock)
+k_mlp_fwd(NvoMlpArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_tiles = a.batch >> 4;
+
+    WFrag<WIDTH, IN_PAD> w0;
+    WFrag<WIDTH, WIDTH> wh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    WFrag<OUT_PAD, WIDTH> wl;
+    {
+        const _Float16* W = a.weights;
+        w0.load(W, lane);
+        W += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            wh[l].load(W, lane);
+            W += WIDTH * WIDTH;
+        }
+        wl.load(W, lane);
+    }
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 16 + m;
+        h4 x[IN_PAD / 16];
+        load_input<IN_PAD>(a, row, g, x);
+
+        f4 acc[WIDTH / 16];
+        h4 h[WIDTH / 16];
+        layer_mm<WIDTH, IN_PAD>(w0, x, acc);
+#pragma unroll
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(a.act, acc[t]);
+        if (a.hidden) {
+            _Float16* hs = a.hidden + (size_t)row * WIDTH + 4 * g;
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) *reinterpret_cast<h4*>(hs + 16 * t) = h[t];
+        }
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            layer_mm<WIDTH, WIDTH>(wh[l], h, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(a.act, acc[t]);
+            if (a.hidden) {
+                _Float16* hs = a.hidden + ((size_t)(l + 1) * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) *reinterpret_cast<h4*>(hs + 16 * t) = h[t];
+            }
+        }
+        f4 o[OUT_PAD / 16];
+        layer_mm<OUT_PAD, WIDTH>(wl, h, o);
+        _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+        for (int t = 0; t < OUT_PAD / 16; ++t)
+            *reinterpret_cast<h4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// wave-private LDS tile: 16 samples x LD halfs.  Row stride LD+4 halfs (8-B pad) keeps the
+// 8-B alignment ds_read_b64_tr_b16 needs and staggers rows across banks.
+template <int LD>
+struct LdsTile {
+    static constexpr int kStride = LD + 4;
+    _Float16* base;
+    // chain layout -> tile: lane (m,g) owns [m][16t + 4g .. +3]
+    __device__ __forceinline__ void store(int m, int g, int t, h4 v) const {
+        *reinterpret_cast<h4*>(base + m * kStride + 16 * t + 4 * g) = v;
+    }
+    // transposed fragment: element j = tile[4g + j][16t + (lane & 15)]
+    __device__ __forceinline__ h4 load_tr(int lane, int t) const {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const _Float16* addr = base + (4 * g + q) * kStride + 16 * t + 4 * p;
+        fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4_t*)addr);
+        h4 r;
+        __builtin_memcpy(&r, &v, sizeof(r));
+        return r;
+    }
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave complete in issue order; this only stops the compiler from
+    // moving the transposed reads above the tile stores (and vice versa on the next tile).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N_OUT, int K_IN>
+struct DwAcc {
+    f4 a[N_OUT / 16][K_IN / 16];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) a[tn][tk] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // dW[n][k] += sum_m dZ[m][n] H[m][k]   A = dZ^T fragment, B = H fragment (both transposed reads)
+    __device__ __forceinline__ void accumulate(const h4 (&zt)[N_OUT / 16], const h4 (&ht)[K_IN / 16]) {
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) a[tn][tk] = mfma16(zt[tn], ht[tk], a[tn][tk]);
+    }
+    // accumulator (lane, reg r) = dW[16tn + 4g + r][16tk + (lane&15)]
+    __device__ __forceinline__ void flush(float* __restrict__ dW, int lane) const {
+        const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(dW + (size_t)(16 * tn + 4 * g + r) * K_IN + 16 * tk + c, a[tn][tk][r]);
+    }
+};
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+__global__ void __launch_bounds__(kMlpBlock)
+k_mlp_bwd(NvoMlpArgs a) {
+    constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
+                                         : (IN_PAD > OUT_PAD ? IN_PAD : OUT_PAD));
+    __shared__ __attribute__((aligned(16))) _Float16 lds[kWavesPerBlock][2][16 * (MAXW + 4)];
+
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_tiles = a.batch >> 4;
+    const LdsTile<MAXW> tz{&lds[wib][0][0]}, th{&lds[wib][1][0]};
+
+    const bool need_dinput = a.dinput != nullptr;
+
+    // transposed weights for the dH chain (layer 0's only if dL/dinput is wanted)
+    WTFrag<WIDTH, IN_PAD> wt0;
+    WTFrag<WIDTH, WIDTH> wth[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    WTFrag<OUT_PAD, WIDTH> wtl;
+    {
+        const _Float16* W = a.weights;
+        if (need_dinput) wt0.load(W, lane);
+        W += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            wth[l].load(W, lane);
+            W += WIDTH * WIDTH;
+        }
+        wtl.load(W, lane);
+    }
+    DwAcc<WIDTH, IN_PAD> dw0;
+    DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    DwAcc<OUT_PAD, WIDTH> dwl;
+    dw0.zero();
+#pragma unroll
+    for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
+    dwl.zero();
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 16 + m;
+
+        // ---- output layer: dZ_L = dL/dout * out_act'(out)
+        h4 dzl[OUT_PAD / 16];
+        {
+            const _Float16* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
+            const _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) {
+                h4 d = *reinterpret_cast<const h4*>(dp + 16 * t);
+                if (a.out_act != NVO_ACT_NONE) {
+                    const h4 o = *reinterpret_cast<const h4*>(op + 16 * t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        d[j] = (_Float16)((float)d[j] * act_bwd_from_out(a.out_act, (float)o[j]));
+                }
+                dzl[t] = d;
+            }
+        }
+        // last hidden activation H_{N_HIDDEN-1}
+        h4 h[WIDTH / 16];
+        {
+            const _Float16* hp =
+                a.hidden + ((size_t)(N_HIDDEN - 1) * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) h[t] = *reinterpret_cast<const h4*>(hp + 16 * t);
+        }
+        // dW_last += dZ_L^T H
+        {
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) tz.store(m, g, t, dzl[t]);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) th.store(m, g, t, h[t]);
+            wave_lds_sync();
+            h4 zt[OUT_PAD / 16], ht[WIDTH / 16];
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) zt[t] = tz.load_tr(lane, t);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) ht[t] = th.load_tr(lane, t);
+            dwl.accumulate(zt, ht);
+            wave_lds_sync();
+        }
+        // dZ of the last hidden layer
+        h4 dz[WIDTH / 16];
+        {
+            f4 acc[WIDTH / 16];
+            layer_mm_t<OUT_PAD, WIDTH>(wtl, dzl, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(a.act, (float)h[t][j]));
+        }
+        // ---- hidden layers N_HIDDEN-1 .. 1 (weights wh[l-1] map H_{l-1} -> H_l)
+#pragma unroll
+        for (int l = N_HIDDEN - 1; l >= 1; --l) {
+            h4 hp_[WIDTH / 16];  // H_{l-1}
+            {
+                const _Float16* hp = a.hidden + ((size_t)(l - 1) * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t)
+                    hp_[t] = *reinterpret_cast<const h4*>(hp + 16 * t);
+            }
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) {
+                tz.store(m, g, t, dz[t]);
+                th.store(m, g, t, hp_[t]);
+            }
+            wave_lds_sync();
+            {
+                h4 zt[WIDTH / 16], ht[WIDTH / 16];
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) {
+                    zt[t] = tz.load_tr(lane, t);
+                    ht[t] = th.load_tr(lane, t);
+                }
+                dwh[l - 1].accumulate(zt, ht);
+            }
+            wave_lds_sync();
+            f4 acc[WIDTH / 16];
+            layer_mm_t<WIDTH, WIDTH>(wth[l - 1], dz, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(a.act, (float)hp_[t][j]));
+        }
+        // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
+        {
+            h4 x[IN_PAD / 16];
+            load_input<IN_PAD>(a, row, g, x);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) tz.store(m, g, t, dz[t]);
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) th.store(m, g, t, x[t]);
+            wave_lds_sync();
+            h4 zt[WIDTH / 16], xt[IN_PAD / 16];
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) zt[t] = tz.load_tr(lane, t);
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) xt[t] = th.load_tr(lane, t);
+            dw0.accumulate(zt, xt);
+            wave_lds_sync();
+        }
+        if (need_dinput) {
+            f4 acc[IN_PAD / 16];
+            layer_mm_t<WIDTH, IN_PAD>(wt0, dz, acc);
+            if (a.din_mode == NVO_IO_F32_ROWS) {
+                float* __restrict__ p = (float*)a.dinput + (size_t)row * a.n_in;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t c = 16 * tk + 4 * g + j;
+                        if (c < a.n_in) p[c] = acc[tk][j];
+                    }
+            } else if (a.din_mode == NVO_IO_HALF2_SOA) {
+                h2* __restrict__ p = (h2*)a.dinput;
+                const uint32_t n_lv = a.n_in >> 1;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                    const uint32_t lv = 8 * tk + 2 * g;
+                    if (lv < n_lv)
+                        p[(size_t)lv * a.batch + row] = h2{(_Float16)acc[tk][0], (_Float16)acc[tk][1]};
+                    if (lv + 1 < n_lv)
+                        p[(size_t)(lv + 1) * a.batch + row] =
+                            h2{(_Float16)acc[tk][2], (_Float16)acc[tk][3]};
+                }
+            } else {
+                _Float16* __restrict__ p = (_Float16*)a.dinput + (size_t)row * IN_PAD + 4 * g;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                    h4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (_Float16)acc[tk][j];
+                    *reinterpret_cast<h4*>(p + 16 * tk) = v;
+                }
+            }
+        }
+    }
+
+    // ---- flush weight gradients
+    if (a.dweights) {
+        float* dW = a.dweights;
+        dw0.flush(dW, lane);
+        dW += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            dwh[l].flush(dW, lane);
+            dW += WIDTH * WIDTH;
+        }
+        dwl.flush(dW, lane);
+    }
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    const uint32_t n_tiles = a.batch >> 4;
+    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
+                       0, stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+int launch_bwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    const uint32_t n_tiles = a.batch >> 4;
+    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
+                       0, stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+}  // namespace
+
+// Supported shapes (every MLP on the NeRF-VO mapping path):
+//   (in_pad, width, n_hidden, out_pad)
+//   (32, 64, 1, 16) nerfacto base MLP      (64, 64, 2, 16) colour MLP
+//   (32, 64, 3, 64) predicted-normals MLP  (16, 16, 1, 16) proposal density MLP
+//   (16, 64, 1..2, 16), (32, 64, 2, 16), (64, 64, 1, 16) generic tcnn.Network uses
+#define NVO_MLP_SHAPES(X) \
+    X(32, 64, 1, 16)      \
+    X(64, 64, 2, 16)      \
+    X(32, 64, 3, 64)      \
+    X(16, 16, 1, 16)      \
+    X(16, 64, 1, 16)      \
+    X(16, 64, 2, 16)      \
+    X(32, 64, 2, 16)      \
+    X(64, 64, 1, 16)      \
+    X(16, 16, 2, 16)      \
+    X(32, 16, 1, 16)
+
+bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad) {
+#define X(I, W, H, O) \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O) return true;
+    NVO_MLP_SHAPES(X)
+#undef X
+    return false;
+}
+
+int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
+                       hipStream_t stream) {
+    NVO_REQUIRE((a.batch & 15u) == 0, "mlp: batch (%u) must be a multiple of 16", a.batch);
+    if (a.batch == 0) return NVO_OK;
+#define X(I, W, H, O)                                                    \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
+        return launch_fwd<I, W, H, O>(a, stream, 2048);
+    NVO_MLP_SHAPES(X)
+#undef X
+    nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
+                  n_hidden, out_pad);
+    return NVO_ERR_UNSUPPORTED;
+}
+
+int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
+                       hipStream_t stream) {
+    NVO_REQUIRE((a.batch & 15u) == 0, "mlp: batch (%u) must be a multiple of 16", a.batch);
+    if (a.batch == 0) return NVO_OK;
+#define X(I, W, H, O)                                                    \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
+        return launch_bwd<I, W, H, O>(a, stream, 512);
+    NVO_MLP_SHAPES(X)
+#undef X
+    nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
+                  n_hidden, out_pad);
+    return NVO_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,83 @@
+// Shared declarations for the nerfvo HIP library (gfx950 / CDNA4 only).
+//
+// Everything in csrc/ is compiled with `hipcc --offload-arch=gfx950` into ONE shared library,
+// libnerfvo_hip.so, whose exported surface is the C-ABI of include/nerfvo_hip.h.  No torch types
+// cross that boundary: callers hand in raw device pointers + a hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define NVO_OK 0
+#define NVO_ERR_INVALID 1
+#define NVO_ERR_HIP 2
+#define NVO_ERR_UNSUPPORTED 3
+
+#define NVO_WAVE 64
+
+extern "C" const char* nvo_last_error(void);
+void nvo_set_error(const char* fmt, ...);
+
+#define NVO_CHECK_HIP(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            nvo_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return NVO_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define NVO_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            nvo_set_error(__VA_ARGS__);        \
+            return NVO_ERR_INVALID;            \
+        }                                      \
+    } while (0)
+
+#define NVO_CHECK_LAUNCH() NVO_CHECK_HIP(hipGetLastError())
+
+static inline uint32_t nvo_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline uint64_t nvo_round_up(uint64_t a, uint64_t b) { return ((a + b - 1) / b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-resolution grid level table (host-computed once, passed to kernels BY VALUE).
+// Semantics follow tiny-cuda-nn's GridEncodingTemplated constructor and grid_scale /
+// grid_resolution / grid_index helpers (upstream tcnn include/tiny-cuda-nn/encodings/grid.h;
+// NOT vendored in /root/reference -- see SURVEY.md section 2.4 K1 and section 8c).
+// ---------------------------------------------------------------------------------------------
+#define NVO_MAX_LEVELS 32
+
+struct NvoGridLevels {
+    uint32_t n_levels;
+    uint32_t n_features;                    // features per level (2 on every path NeRF-VO uses)
+    uint32_t offset[NVO_MAX_LEVELS + 1];    // entry offset of each level (entries, not scalars)
+    uint32_t resolution[NVO_MAX_LEVELS];    // vertices per axis
+    float scale[NVO_MAX_LEVELS];            // pos = fma(scale, x, 0.5)
+    uint32_t hashed[NVO_MAX_LEVELS];        // 1 -> spatial hash, 0 -> dense stride index
+};
+
+// Fills the table; returns total number of entries.  log2_hashmap_size / base_resolution /
+// per_level_scale have tcnn's meaning.  All float math is done in fp32 with glibc exp2f/log2f/
+// ceilf so that the oracle's C restatement (same libm) reproduces the table bit for bit.
+uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_features,
+                              uint32_t log2_hashmap_size, uint32_t base_resolution,
+                              float per_level_scale);
+
+#ifdef __HIPCC__
+// ---- device helpers shared by grid kernels -------------------------------------------------
+__device__ __forceinline__ uint32_t nvo_grid_index(uint32_t hashed, uint32_t hashmap_size,
+                                                   uint32_t res, uint32_t px, uint32_t py,
+                                                   uint32_t pz) {
+    // tcnn grid_index<3, CoherentPrime>: dense stride index while stride <= hashmap_size,
+    // spatial hash (primes 1, 2654435761, 805459861) when the level does not fit.
+    uint32_t index;
+    if (hashed) {
+        index = px ^ (py * 2654435761u) ^ (pz * 805459861u);
+        return index & (hashmap_size - 1u);  // hashed levels always have power-of-two size
+    }
+    index = px + py * res + pz * res * res;
+    return index % hashmap_size;
+}
+#endif

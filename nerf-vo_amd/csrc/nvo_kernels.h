@@ -1,0 +1,51 @@
+// Internal launcher declarations (C++ linkage) shared between the .hip translation units.
+#pragma once
+#include "nvo_common.h"
+
+// ---- grid.hip -------------------------------------------------------------------------------
+struct NvoGridSlices {
+    uint32_t n_slices = 0;
+    uint32_t* d_level = nullptr;
+    uint32_t* d_first = nullptr;
+};
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s);
+void nvo_grid_slices_destroy(NvoGridSlices* s);
+int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
+                        const void* table_half, void* out_half, bool soa, uint32_t* indices);
+int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
+                        uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
+                        float* grad, int mode);
+int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
+                              const float* x, const void* table_half, const void* dy,
+                              bool dy_is_float, bool soa, float* dx, bool zero_dx);
+
+// ---- sh.hip ---------------------------------------------------------------------------------
+int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
+                      void* out_half, uint32_t out_stride, uint32_t out_width);
+int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
+                            const void* dy_half, uint32_t dy_stride, float* dd01);
+
+// ---- mlp.hip --------------------------------------------------------------------------------
+enum { NVO_ACT_NONE = 0, NVO_ACT_RELU = 1, NVO_ACT_SIGMOID = 2 };
+enum { NVO_IO_F32_ROWS = 0, NVO_IO_HALF2_SOA = 1, NVO_IO_HALF_ROWS = 2 };
+
+struct NvoMlpArgs {
+    uint32_t batch;       // multiple of 16
+    uint32_t n_in;        // true input width (<= IN_PAD)
+    int in_mode;
+    const void* input;
+    const _Float16* weights;  // layer-major, each [out][in] row-major
+    _Float16* output;         // [B][OUT_PAD]
+    _Float16* hidden;         // [N_HIDDEN][B][WIDTH] or nullptr (inference)
+    int act, out_act;
+    // backward only
+    const _Float16* doutput;  // [B][OUT_PAD], loss-scaled
+    void* dinput;             // layout din_mode, nullable
+    int din_mode;
+    float* dweights;          // fp32, same order as weights, accumulated with atomics (pre-zeroed)
+};
+bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
+int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
+                       hipStream_t stream);
+int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
+                       hipStream_t stream);

@@ -1,0 +1,120 @@
+// Real spherical-harmonics direction encoding, degree <= 4 (16 coefficients), forward + input
+// gradient.  Replaces tiny-cuda-nn's kernel_sh / kernel_sh_backward (SURVEY.md section 2.4 K6;
+// upstream spherical_harmonics.h is not vendored -- restated in oracle/sh.py).  Input follows the
+// tcnn convention: d01 = (d + 1) / 2 in [0,1]^3, the kernel maps it back with 2*d01 - 1.
+#include "nvo_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void sh4_eval(float x, float y, float z, uint32_t degree, float* o) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    if (degree <= 1) return;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    if (degree <= 2) return;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if (degree <= 3) return;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// out: [N][out_stride] half; writes n_coeff coefficients then pads up to out_width with 1.0
+__global__ void __launch_bounds__(256)
+k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, __half* __restrict__ out,
+         uint32_t out_stride, uint32_t out_width) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float x = d01[3 * (size_t)i + 0] * 2.f - 1.f;
+    const float y = d01[3 * (size_t)i + 1] * 2.f - 1.f;
+    const float z = d01[3 * (size_t)i + 2] * 2.f - 1.f;
+    float o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0.f;
+    sh4_eval(x, y, z, degree, o);
+    const uint32_t n_coeff = degree * degree;
+    __half* __restrict__ p = out + (size_t)i * out_stride;
+    for (uint32_t k = 0; k < out_width; ++k) p[k] = __float2half(k < n_coeff ? o[k] : 1.0f);
+}
+
+// dL/dd01 = 2 * sum_k dL/dy_k * dy_k/d(x,y,z)
+__global__ void __launch_bounds__(256)
+k_sh_bwd_input(uint32_t N, uint32_t degree, const float* __restrict__ d01,
+               const __half* __restrict__ dy, uint32_t dy_stride, float* __restrict__ dd01) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float x = d01[3 * (size_t)i + 0] * 2.f - 1.f;
+    const float y = d01[3 * (size_t)i + 1] * 2.f - 1.f;
+    const float z = d01[3 * (size_t)i + 2] * 2.f - 1.f;
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    float g[16];
+    const uint32_t n_coeff = degree * degree;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) g[k] = k < n_coeff ? __half2float(dy[(size_t)i * dy_stride + k]) : 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    // degree 2
+    gy += -0.48860251190291987f * g[1];
+    gz += 0.48860251190291987f * g[2];
+    gx += -0.48860251190291987f * g[3];
+    // degree 3
+    gx += 1.0925484305920792f * y * g[4];
+    gy += 1.0925484305920792f * x * g[4];
+    gy += -1.0925484305920792f * z * g[5];
+    gz += -1.0925484305920792f * y * g[5];
+    gz += 2.f * 0.94617469575755997f * z * g[6];
+    gx += -1.0925484305920792f * z * g[7];
+    gz += -1.0925484305920792f * x * g[7];
+    gx += 2.f * 0.54627421529603959f * x * g[8];
+    gy += -2.f * 0.54627421529603959f * y * g[8];
+    // degree 4
+    gx += 0.59004358992664352f * (-6.f * x * y) * g[9];
+    gy += 0.59004358992664352f * (-3.f * x2 + 3.f * y2) * g[9];
+    gx += 2.8906114426405538f * y * z * g[10];
+    gy += 2.8906114426405538f * x * z * g[10];
+    gz += 2.8906114426405538f * x * y * g[10];
+    gy += 0.45704579946446572f * (1.f - 5.f * z2) * g[11];
+    gz += 0.45704579946446572f * (-10.f * y * z) * g[11];
+    gz += 0.3731763325901154f * (15.f * z2 - 3.f) * g[12];
+    gx += 0.45704579946446572f * (1.f - 5.f * z2) * g[13];
+    gz += 0.45704579946446572f * (-10.f * x * z) * g[13];
+    gx += 1.4453057213202769f * (2.f * x * z) * g[14];
+    gy += 1.4453057213202769f * (-2.f * y * z) * g[14];
+    gz += 1.4453057213202769f * (x2 - y2) * g[14];
+    gx += 0.59004358992664352f * (-3.f * x2 + 3.f * y2) * g[15];
+    gy += 0.59004358992664352f * (6.f * x * y) * g[15];
+    dd01[3 * (size_t)i + 0] = 2.f * gx;
+    dd01[3 * (size_t)i + 1] = 2.f * gy;
+    dd01[3 * (size_t)i + 2] = 2.f * gz;
+}
+
+}  // namespace
+
+int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
+                      void* out_half, uint32_t out_stride, uint32_t out_width) {
+    NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
+    if (N == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_sh_fwd, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree, d01,
+                       (__half*)out_half, out_stride, out_width);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
+                            const void* dy_half, uint32_t dy_stride, float* dd01) {
+    NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
+    if (N == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_sh_bwd_input, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
+                       d01, (const __half*)dy_half, dy_stride, dd01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}

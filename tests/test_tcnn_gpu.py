@@ -1,0 +1,265 @@
+"""GPU parity tests: HIP kernels behind the tcnn-compatible surface vs the CPU oracle.
+
+Tolerances (stated per north_star: fp32 tolerance for outputs, bit-exact for hash indices):
+  * hash / dense corner indices: bit-exact (uint32).
+  * encoded features: kernel accumulates in fp32 and rounds once to fp16 -> |err| <= 1 fp16 ulp of
+    the value + tiny fp32 accumulation slack, tested as atol 2e-3*scale.
+  * MLP outputs: fp16 operands, fp32 accumulate, fp16 hidden storage; the oracle rounds at the same
+    points in float64 -> rtol 1e-2, atol 1e-2*scale (a few fp16 ulps amplified through <= 4 layers).
+  * gradients: fp32 accumulation of fp16 products over the batch -> rtol 2e-2 / atol 2e-2*scale.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MAIN = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, max_res=2048)
+PROP0 = dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, max_res=128)
+PROP1 = dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, max_res=256)
+
+
+def _pls(c):
+    return float(np.exp((np.log(c["max_res"]) - np.log(c["base_resolution"])) / (c["n_levels"] - 1)))
+
+
+def _enc_cfg(c):
+    return {"otype": "HashGrid", "n_levels": c["n_levels"], "n_features_per_level": 2,
+            "log2_hashmap_size": c["log2_hashmap_size"], "base_resolution": c["base_resolution"],
+            "per_level_scale": _pls(c)}
+
+
+def _spec(c):
+    from oracle import grid as G
+
+    return G.make_grid_spec(c["n_levels"], 2, c["log2_hashmap_size"], c["base_resolution"], _pls(c))
+
+
+def _points(n, seed, edge_cases=True):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 3), dtype=np.float32)
+    if edge_cases and n >= 16:
+        x[0] = 0.0
+        x[1] = 1.0
+        x[2] = (0.5, 0.5, 0.5)
+        x[3] = (1.0, 0.0, 1.0)
+        x[4] = np.float32(1.0) - np.float32(2.0 ** -24)
+        x[5] = np.float32(2.0 ** -24)
+        x[6] = (0.25, 0.75, 0.125)
+    return x
+
+
+def _assert_close(got, ref, rtol, atol_scale, what):
+    got = got.double().cpu()
+    ref = ref.double().cpu()
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs()
+    bound = atol_scale * scale + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), (
+        f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max().item():.4e} "
+        f"(scale {scale:.4e}); first bad idx {bad.nonzero()[0].tolist()} got {got[bad][0].item():.6e} "
+        f"ref {ref[bad][0].item():.6e}")
+
+
+@pytest.mark.parametrize("cfg", [MAIN, PROP0, PROP1], ids=["main", "prop0", "prop1"])
+def test_grid_indices_bit_exact(device, cfg):
+    import nerf_vo_amd.tinycudann as tcnn
+    from nerf_vo_amd import _lib
+    from oracle import grid as G
+
+    enc = tcnn.Encoding(3, _enc_cfg(cfg))
+    n = 4096
+    x = _points(n, 1)
+    xd = torch.from_numpy(x).to(device)
+    idx = torch.zeros((cfg["n_levels"], n, 8), dtype=torch.int32, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().nvo_grid_indices(enc.native_tcnn_module.handle, stream, n, C.c_void_p(xd.data_ptr()),
+                                           C.c_void_p(idx.data_ptr())), "grid_indices")
+    torch.cuda.synchronize()
+    ref, _ = G.grid_indices_c(_spec(cfg), x)
+    got = idx.cpu().numpy().view(np.uint32)
+    assert (got == ref).all(), f"{int((got != ref).sum())} corner indices differ"
+
+
+@pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
+@pytest.mark.parametrize("bwd_mode", [0, 1], ids=["atomic", "lds"])
+def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import grid as G
+
+    spec = _spec(cfg)
+    enc = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
+    enc.native_tcnn_module.set_option("grid_bwd_mode", bwd_mode)
+    assert enc.n_output_dims == spec.n_output_dims and enc.params.numel() == spec.n_params
+    g = torch.Generator().manual_seed(5)
+    params = (torch.rand(spec.n_params, generator=g) * 2 - 1)
+    with torch.no_grad():
+        enc.params.copy_(params.to(device))
+    n = 1000  # ragged on purpose: padded to 1024 inside the module
+    x = torch.from_numpy(_points(n, 2)).to(device).requires_grad_(True)
+    y = enc(x)
+    assert y.shape == (n, spec.n_output_dims) and y.dtype == torch.float16
+    dy = torch.randn(n, spec.n_output_dims, generator=g).to(device)
+    (y.float() * dy).sum().backward()
+    torch.cuda.synchronize()
+
+    table = params.to(torch.float16).double().view(-1, 2).requires_grad_(True)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = G.grid_encode(spec, xr, table)
+    dy16 = (dy.cpu().float() * 128.0).to(torch.float16).double() / 128.0  # kernel sees fp16(dy*loss_scale)
+    (yr * dy16).sum().backward()
+
+    _assert_close(y, yr, rtol=1e-3, atol_scale=1e-3, what="encoded features")
+    _assert_close(enc.params.grad, table.grad.reshape(-1), rtol=1e-3, atol_scale=1e-4, what="dL/dparams")
+    _assert_close(x.grad, xr.grad, rtol=2e-3, atol_scale=2e-4, what="dL/dx")
+
+
+def test_grid_bwd_lds_matches_atomic_large(device):
+    """Both scatter forms at the full main-field batch (196 608 samples): linearity + agreement."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    enc = tcnn.Encoding(3, _enc_cfg(MAIN)).to(device)
+    n = 4096 * 48
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(n, 3, generator=g).to(device)
+    dy = torch.randn(n, 32, generator=g).to(device)
+    grads = []
+    for mode in (0, 1):
+        enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
+        enc.params.grad = None
+        y = enc(x)
+        (y.float() * dy).sum().backward()
+        grads.append(enc.params.grad.clone())
+    torch.cuda.synchronize()
+    _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
+    # every sample distributes a total weight of 1 per level/feature: sum of grads == sum of dy16
+    dy16 = (dy * 128).half().double() / 128
+    assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0
+
+
+def test_spherical_harmonics(device):
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import sh as S
+
+    for degree in (1, 2, 3, 4):
+        enc = tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": degree}).to(device)
+        g = torch.Generator().manual_seed(degree)
+        d = torch.nn.functional.normalize(torch.randn(1000, 3, generator=g), dim=-1)
+        d01 = ((d + 1) / 2).to(device).requires_grad_(True)
+        y = enc(d01)
+        assert y.shape == (1000, degree * degree)
+        dy = torch.randn(1000, degree * degree, generator=g).to(device)
+        (y.float() * dy).sum().backward()
+        dr = d01.detach().double().cpu().requires_grad_(True)
+        yr = S.sh_encode(dr, degree)
+        dy16 = (dy.cpu() * 128).half().double() / 128
+        (yr * dy16).sum().backward()
+        _assert_close(y, yr, rtol=1e-3, atol_scale=1e-3, what=f"SH degree {degree}")
+        _assert_close(d01.grad, dr.grad, rtol=2e-3, atol_scale=1e-3, what=f"SH degree {degree} dL/dd")
+
+
+MLP_SHAPES = [
+    # n_in, n_out, width, n_hidden, act, out_act
+    (32, 16, 64, 1, "ReLU", "None"),      # nerfacto base MLP
+    (63, 3, 64, 2, "ReLU", "Sigmoid"),    # colour MLP
+    (27, 64, 64, 3, "ReLU", "None"),      # predicted normals MLP
+    (10, 1, 16, 1, "ReLU", "None"),       # proposal density MLP (standalone)
+    (16, 16, 16, 1, "ReLU", "None"),
+]
+
+
+@pytest.mark.parametrize("shape", MLP_SHAPES, ids=[f"{s[0]}-{s[2]}x{s[3]}-{s[1]}" for s in MLP_SHAPES])
+def test_network_fwd_bwd(device, shape):
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import mlp as M
+
+    n_in, n_out, width, n_hidden, act, out_act = shape
+    cfg = {"otype": "FullyFusedMLP", "activation": act, "output_activation": out_act, "n_neurons": width,
+           "n_hidden_layers": n_hidden}
+    net = tcnn.Network(n_in, n_out, cfg).to(device)
+    assert net.params.numel() == M.mlp_n_params(n_in, n_out, width, n_hidden)
+    g = torch.Generator().manual_seed(11)
+    p = torch.randn(net.params.numel(), generator=g) * (1.5 / np.sqrt(width))
+    with torch.no_grad():
+        net.params.copy_(p.to(device))
+    n = 3000  # ragged: padded to 3072
+    x = torch.randn(n, n_in, generator=g).to(device).requires_grad_(True)
+    y = net(x)
+    assert y.shape == (n, n_out) and y.dtype == torch.float16
+    dy = torch.randn(n, n_out, generator=g).to(device)
+    (y.float() * dy).sum().backward()
+    torch.cuda.synchronize()
+
+    pr = p.to(torch.float16).double().requires_grad_(True)
+    ws = M.split_weights(pr, n_in, n_out, width, n_hidden)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = M.mlp_forward(xr, ws, act, out_act, pad_value=1.0)[:, :n_out]
+    dy16 = (dy.cpu() * 128).half().double() / 128
+    (yr * dy16).sum().backward()
+
+    _assert_close(y, yr, rtol=1e-2, atol_scale=5e-3, what="MLP output")
+    _assert_close(x.grad, xr.grad, rtol=2e-2, atol_scale=1e-2, what="MLP dL/dinput")
+    _assert_close(net.params.grad, pr.grad, rtol=2e-2, atol_scale=1e-2, what="MLP dL/dparams")
+
+
+def test_network_identity_layout(device):
+    """A = I style check with an ASYMMETRIC weight: catches row/col swaps in the MFMA fragment maps."""
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import mlp as M
+
+    cfg = {"otype": "FullyFusedMLP", "activation": "None", "output_activation": "None", "n_neurons": 64,
+           "n_hidden_layers": 1}
+    net = tcnn.Network(32, 16, cfg).to(device)
+    w0 = torch.zeros(64, 32)
+    w0[:32, :32] = torch.eye(32)
+    w1 = (torch.arange(16 * 64).float().view(16, 64) % 61 - 30) / 32.0  # asymmetric, exactly fp16
+    with torch.no_grad():
+        net.params.copy_(torch.cat([w0.flatten(), w1.flatten()]).to(device))
+    x = ((torch.arange(128 * 32).float().view(128, 32) % 17) - 8) / 8.0
+    y = net(x.to(device))
+    ref = (x @ w0.t()) @ w1.t()
+    assert torch.equal(y.float().cpu(), ref.half().float()), (y.float().cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("cfg,width", [(MAIN, 64), (PROP0, 16)], ids=["main-64", "prop0-16"])
+def test_network_with_input_encoding(device, cfg, width):
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import grid as G
+    from oracle import mlp as M
+
+    spec = _spec(cfg)
+    n_out = 16 if width == 64 else 1
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width,
+               "n_hidden_layers": 1}
+    model = tcnn.NetworkWithInputEncoding(3, n_out, _enc_cfg(cfg), net_cfg).to(device)
+    n_net = M.mlp_n_params(spec.n_output_dims, n_out, width, 1)
+    assert model.params.numel() == n_net + spec.n_params
+    g = torch.Generator().manual_seed(3)
+    p = torch.cat([torch.randn(n_net, generator=g) * (1.5 / np.sqrt(width)),
+                   torch.rand(spec.n_params, generator=g) * 2 - 1])
+    with torch.no_grad():
+        model.params.copy_(p.to(device))
+    n = 2000
+    x = torch.from_numpy(_points(n, 9)).to(device).requires_grad_(True)
+    y = model(x)
+    dy = torch.randn(n, n_out, generator=g).to(device)
+    (y.float() * dy).sum().backward()
+    torch.cuda.synchronize()
+
+    pr = p.to(torch.float16).double().requires_grad_(True)
+    ws = M.split_weights(pr[:n_net], spec.n_output_dims, n_out, width, 1)
+    table = pr[n_net:].view(-1, 2)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    enc = G.grid_encode(spec, xr, table, quantize_output=True)
+    yr = M.mlp_forward(enc, ws, "ReLU", "None", pad_value=0.0)[:, :n_out]
+    dy16 = (dy.cpu() * 128).half().double() / 128
+    (yr * dy16).sum().backward()
+
+    _assert_close(y, yr, rtol=1e-2, atol_scale=5e-3, what="NWIE output")
+    _assert_close(model.params.grad[:n_net], pr.grad[:n_net], rtol=2e-2, atol_scale=1e-2, what="NWIE dW")
+    # the encoding gradient passes through an fp16 d(encoded) buffer: tolerance 1 fp16 ulp of the scale
+    _assert_close(model.params.grad[n_net:], pr.grad[n_net:], rtol=2e-2, atol_scale=2e-3, what="NWIE dgrid")
+    _assert_close(x.grad, xr.grad, rtol=3e-2, atol_scale=1e-2, what="NWIE dL/dx")
