@@ -51,13 +51,20 @@ def _points(n, seed, edge_cases=True):
     return x
 
 
-def _assert_close(got, ref, rtol, atol_scale, what):
+def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0):
+    """|got-ref| <= atol_scale*max|ref| + rtol*|ref| elementwise.  max_outlier_frac > 0 is only used
+    for gradients that pass through ReLU kinks: a hidden unit whose pre-activation is within fp16
+    rounding of 0 can take a different branch in the kernel and in the float64 oracle, which changes
+    a handful of (sample-local) gradient entries discontinuously."""
     got = got.double().cpu()
     ref = ref.double().cpu()
     scale = max(ref.abs().max().item(), 1e-30)
     err = (got - ref).abs()
     bound = atol_scale * scale + rtol * ref.abs()
     bad = err > bound
+    if max_outlier_frac > 0 and bad.sum().item() <= max_outlier_frac * bad.numel():
+        assert err.max().item() <= 0.05 * scale, f"{what}: outlier too large {err.max().item():.3e} (scale {scale:.3e})"
+        return
     assert not bad.any(), (
         f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max().item():.4e} "
         f"(scale {scale:.4e}); first bad idx {bad.nonzero()[0].tolist()} got {got[bad][0].item():.6e} "
@@ -156,8 +163,11 @@ def test_spherical_harmonics(device):
         dr = d01.detach().double().cpu().requires_grad_(True)
         yr = S.sh_encode(dr, degree)
         dy16 = (dy.cpu() * 128).half().double() / 128
-        (yr * dy16).sum().backward()
         _assert_close(y, yr, rtol=1e-3, atol_scale=1e-3, what=f"SH degree {degree}")
+        if degree == 1:  # constant encoding: the gradient is exactly zero
+            assert (d01.grad == 0).all()
+            continue
+        (yr * dy16).sum().backward()
         _assert_close(d01.grad, dr.grad, rtol=2e-3, atol_scale=1e-3, what=f"SH degree {degree} dL/dd")
 
 
@@ -261,5 +271,6 @@ def test_network_with_input_encoding(device, cfg, width):
     _assert_close(y, yr, rtol=1e-2, atol_scale=5e-3, what="NWIE output")
     _assert_close(model.params.grad[:n_net], pr.grad[:n_net], rtol=2e-2, atol_scale=1e-2, what="NWIE dW")
     # the encoding gradient passes through an fp16 d(encoded) buffer: tolerance 1 fp16 ulp of the scale
-    _assert_close(model.params.grad[n_net:], pr.grad[n_net:], rtol=2e-2, atol_scale=2e-3, what="NWIE dgrid")
+    _assert_close(model.params.grad[n_net:], pr.grad[n_net:], rtol=2e-2, atol_scale=2e-3, what="NWIE dgrid",
+                  max_outlier_frac=1e-5)
     _assert_close(x.grad, xr.grad, rtol=3e-2, atol_scale=1e-2, what="NWIE dL/dx")
