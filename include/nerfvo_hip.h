@@ -92,6 +92,147 @@ int nvo_grid_describe(nvo_module_t m, uint32_t* levels_out, float* scales_out);
 int nvo_grid_indices(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
                      uint32_t* indices_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * B. Ray generation and sampling (nerfstudio PixelSampler gather, RayGenerator /
+ *    Cameras.generate_rays, CameraOptimizer.apply_to_raybundle, UniformLinDispPiecewiseSampler,
+ *    Frustums.get_positions + SceneContraction(L-inf); reference call sites
+ *    /root/reference/nerf_vo/mapping/nerfstudio_utils.py:286-300,90-107).
+ * ---------------------------------------------------------------------------------------------- */
+/* ray_indices: device int64 [R][3] = (camera, y, x); intrinsics: device float [F][4] (fx,fy,cx,cy);
+ * c2w: device float [F][3][4]; corrections: device float [F][3][4] (exp_map_SE3 of the pose
+ * adjustment) or NULL.  Outputs: origins/directions [R][3], directions_norm [R], pixel_area [R]
+ * (nullable), cam_idx int32 [R]. */
+int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+               const float* c2w, const float* corrections, float* origins, float* directions,
+               float* directions_norm, float* pixel_area, int32_t* cam_idx);
+/* images: device float [F][H][W][C] -> out [R][C] */
+int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H,
+                      uint32_t W, uint32_t C, const float* images, float* out);
+/* sbins/tbins: device float [R][S+1]; jitter: device float [R] in [0,1) or NULL (eval bins) */
+int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
+                       const float* jitter, float* sbins, float* tbins);
+/* x01: device float [R*S][3] contracted + normalised sample positions; rows outside (0,1)^3 are
+ * written as zeros (== nerfstudio's `positions * selector`) */
+int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const float* origins,
+                         const float* directions, const float* tbins, float* x01);
+/* out[i] = (d[i] + 1) / 2 for n floats (direction encoding input) */
+int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out);
+/* SH(degree) of (d+1)/2 for R rays -> device fp16 [R][16] (degree 4) */
+int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out_half);
+
+/* ------------------------------------------------------------------------------------------------
+ * C. Per-ray volume rendering, resampling and losses, one wavefront per ray (nerfstudio
+ *    RaySamples.get_weights, PDFSampler, RGB/Accumulation/Depth renderers, interlevel_loss,
+ *    distortion_loss, ds_nerf_depth_loss; multipliers from
+ *    /root/reference/nerf_vo/mapping/nerfstudio.py:71-82, hooks nerfstudio_utils.py:337-350).
+ *    All *_half pointers are device fp16; gradients leave these kernels multiplied by loss_scale.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nvo_weights_pdf_args {
+    uint32_t R, S, S_out;        /* S <= 256; S_out == 0 -> weights only */
+    const void* pre;             /* fp16 [R*S][pre_stride], density pre-activation in column 0 */
+    uint32_t pre_stride;
+    const float* x01;            /* [R*S][3] (selector = x01[.][0] > 0) */
+    const float* sbins;          /* [R][S+1] spacing-domain bins */
+    const float* tbins;          /* [R][S+1] euclidean bins */
+    float density_bias;          /* sigma = exp(pre + density_bias) */
+    float* sigma;                /* [R*S] or NULL */
+    float* weights;              /* [R*S] */
+    float anneal, histogram_padding, near_plane, far_plane;
+    const float* jitter;         /* [R] or NULL */
+    float* sbins_out;            /* [R][S_out+1] */
+    float* tbins_out;
+} nvo_weights_pdf_args;
+int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args);
+
+typedef struct nvo_main_loss_args {
+    uint32_t R, S;               /* S <= 64 */
+    const void* pre;             /* fp16 [R*S][pre_stride] column 0 */
+    uint32_t pre_stride;
+    const void* rgb;             /* fp16 [R*S][rgb_stride] columns 0..2 */
+    uint32_t rgb_stride;
+    const float* x01;
+    const float* sbins;
+    const float* tbins;
+    float density_bias;
+    const float* gt_rgb;         /* [R][3] */
+    const float* gt_depth;       /* [R] z-depth or NULL */
+    const float* directions_norm;/* [R] */
+    float rgb_mult, distortion_mult, depth_mult, depth_sigma;
+    float inv_rays;              /* 1 / global ray count (mean reductions; multi-GPU aware) */
+    float depth_level_div;       /* 1 / number of levels the depth loss averages over */
+    float loss_scale;
+    float* out_rgb;              /* [R][3] */
+    float* out_depth;            /* [R] median depth */
+    float* out_expected_depth;   /* [R] or NULL */
+    float* out_accumulation;     /* [R] */
+    float* weights;              /* [R*S] or NULL */
+    float* losses;               /* [3] rgb, distortion, depth: atomically accumulated */
+    void* dpre;                  /* fp16 [R*S][dpre_stride] column 0; NULL -> inference, no losses */
+    uint32_t dpre_stride;
+    void* drgb;                  /* fp16 [R*S][drgb_stride]: cols 0..2 gradient, others zeroed */
+    uint32_t drgb_stride;
+} nvo_main_loss_args;
+int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
+
+typedef struct nvo_prop_loss_args {
+    uint32_t R, S, S_main;       /* S <= 256, S_main <= 64 */
+    const void* pre;             /* fp16 [R*S][pre_stride] column 0 */
+    uint32_t pre_stride;
+    const float* x01;
+    const float* sbins;
+    const float* tbins;
+    const float* sbins_main;     /* [R][S_main+1] */
+    const float* weights_main;   /* [R*S_main] */
+    float density_bias;
+    const float* gt_depth;       /* nullable */
+    const float* directions_norm;
+    float interlevel_mult, depth_mult, depth_sigma;
+    float inv_rays, depth_level_div, loss_scale;
+    float* losses;               /* [2] interlevel, depth: atomically accumulated */
+    void* dpre;                  /* fp16 [R*S][dpre_stride]: column 0 gradient, others zeroed */
+    uint32_t dpre_stride;
+} nvo_prop_loss_args;
+int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args);
+
+/* ------------------------------------------------------------------------------------------------
+ * D. NerfactoField colour head (nerfstudio fields/nerfacto_field.py get_outputs: concat
+ *    [SH(d) | geo features | appearance embedding] -> tcnn.Network 63->64->64->3 sigmoid).  The
+ *    64-wide input row is assembled inside the MLP kernel, never written to HBM.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nvo_color_args {
+    uint32_t R, S;               /* R*S multiple of 16 */
+    const void* sh;              /* fp16 [R][16] */
+    const void* base_out;        /* fp16 [R*S][16]: col 0 density pre-activation, cols 1..15 geo */
+    const void* embedding;       /* fp16 [F][32] */
+    const int32_t* cam_idx;      /* [R] or NULL -> embedding row 0 for every ray (eval: mean row) */
+    const void* weights;         /* fp16 colour MLP weights: [64][64], [64][64], [16][64] */
+    void* rgb;                   /* fp16 [R*S][16], sigmoid rgb in cols 0..2 */
+    void* hidden;                /* fp16 [2][R*S][64]; NULL for inference */
+    /* backward only */
+    const void* drgb;            /* fp16 [R*S][16] (loss-scaled) */
+    void* d_base_out;            /* fp16 [R*S][16]: cols 1..15 written */
+    float* d_embedding;          /* [F][32] accumulated; nullable */
+    float* d_sh;                 /* [R][16] accumulated; nullable */
+    float* d_weights;            /* accumulated (caller zeroes) */
+} nvo_color_args;
+int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
+int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
+
+/* ------------------------------------------------------------------------------------------------
+ * E. Optimiser (torch.optim.Adam as configured at /root/reference/nerf_vo/mapping/nerfstudio.py:84-100
+ *    + GradScaler's skip-on-non-finite from mixed_precision=True, nerfstudio.py:59).
+ * ---------------------------------------------------------------------------------------------- */
+/* One fused pass over params[n]: updates exp_avg / exp_avg_sq / params and, if params_half != NULL,
+ * the fp16 working copy.  grads are multiplied by grad_scale first (1/loss_scale).  step counts from 1.
+ * skip_flag: device uint32 or NULL; a non-zero value makes the call a no-op. */
+int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
+                  const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
+                  const uint32_t* skip_flag);
+/* *flag = any(!isfinite(grads)) */
+int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag);
+int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
+
 #ifdef __cplusplus
 }
 #endif

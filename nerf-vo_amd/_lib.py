@@ -18,6 +18,44 @@ _lib = None
 # name -> (restype, argtypes); mirrors include/nerfvo_hip.h one to one
 _u32, _u64, _i64, _int = C.c_uint32, C.c_uint64, C.c_int64, C.c_int
 _p = C.c_void_p
+_f = C.c_float
+
+
+class WeightsPdfArgs(C.Structure):
+    """mirror of nvo_weights_pdf_args"""
+    _fields_ = [("R", _u32), ("S", _u32), ("S_out", _u32), ("pre", _p), ("pre_stride", _u32), ("x01", _p),
+                ("sbins", _p), ("tbins", _p), ("density_bias", _f), ("sigma", _p), ("weights", _p),
+                ("anneal", _f), ("histogram_padding", _f), ("near_plane", _f), ("far_plane", _f),
+                ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p)]
+
+
+class MainLossArgs(C.Structure):
+    """mirror of nvo_main_loss_args"""
+    _fields_ = [("R", _u32), ("S", _u32), ("pre", _p), ("pre_stride", _u32), ("rgb", _p), ("rgb_stride", _u32),
+                ("x01", _p), ("sbins", _p), ("tbins", _p), ("density_bias", _f), ("gt_rgb", _p),
+                ("gt_depth", _p), ("directions_norm", _p), ("rgb_mult", _f), ("distortion_mult", _f),
+                ("depth_mult", _f), ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f),
+                ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p), ("out_expected_depth", _p),
+                ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
+                ("drgb", _p), ("drgb_stride", _u32)]
+
+
+class PropLossArgs(C.Structure):
+    """mirror of nvo_prop_loss_args"""
+    _fields_ = [("R", _u32), ("S", _u32), ("S_main", _u32), ("pre", _p), ("pre_stride", _u32), ("x01", _p),
+                ("sbins", _p), ("tbins", _p), ("sbins_main", _p), ("weights_main", _p), ("density_bias", _f),
+                ("gt_depth", _p), ("directions_norm", _p), ("interlevel_mult", _f), ("depth_mult", _f),
+                ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f), ("loss_scale", _f),
+                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32)]
+
+
+class ColorArgs(C.Structure):
+    """mirror of nvo_color_args"""
+    _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
+                ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
+                ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p)]
+
+
 _SIGNATURES = {
     "nvo_last_error": (C.c_char_p, []),
     "nvo_version": (_int, []),
@@ -36,6 +74,24 @@ _SIGNATURES = {
     "nvo_bwd": (_int, [_p, _p, _u32, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_grid_describe": (_int, [_p, _p, _p]),
     "nvo_grid_indices": (_int, [_p, _p, _u32, _p, _p]),
+    # group B
+    "nvo_raygen": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
+    "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
+    "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),
+    "nvo_dirs01": (_int, [_p, _u32, _p, _p]),
+    "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
+    # group C
+    "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),
+    "nvo_main_render_loss": (_int, [_p, C.POINTER(MainLossArgs)]),
+    "nvo_prop_loss": (_int, [_p, C.POINTER(PropLossArgs)]),
+    # group D
+    "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
+    "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
+    # group E
+    "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p]),
+    "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _p]),
+    "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
 }
 
 

@@ -1,0 +1,98 @@
+// Fused Adam step over a flat fp32 parameter range for gfx950: reads grad / m / v / master weight,
+// writes m / v / master weight and the fp16 working copy the kernels consume, in one pass
+// (28 B + 2 B per parameter -- the HBM floor of the optimiser).
+// Semantics = torch.optim.Adam (no AMSGrad, L2 weight decay folded into the gradient) as the
+// reference configures it: AdamOptimizerConfig(lr=1e-2|1e-4, eps=1e-15)
+// (/root/reference/nerf_vo/mapping/nerfstudio.py:84-100); the GradScaler "skip the step when a
+// non-finite gradient was found" behaviour (mixed_precision=True, nerfstudio.py:59) is the
+// optional skip flag.  CPU restatement: oracle/optim.py.
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const float* __restrict__ g,
+       float* __restrict__ m, float* __restrict__ v, float lr, float beta1, float beta2, float eps,
+       float bias1, float bias2_sqrt, float grad_scale, float weight_decay,
+       const uint32_t* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pi = p[i];
+        float gi = g[i] * grad_scale;
+        if (weight_decay != 0.f) gi += weight_decay * pi;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bias2_sqrt + eps;
+        pi -= (lr / bias1) * (mi / denom);
+        p[i] = pi;
+        if (p16) p16[i] = (_Float16)pi;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_nonfinite_flag(uint64_t n, const float* __restrict__ g, uint32_t* __restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = g[i];
+        bad = bad || !(fabsf(x) <= 3.0e38f);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = (_Float16)src[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
+                  const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
+                  const uint32_t* skip_flag) {
+    NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: NULL argument");
+    NVO_REQUIRE(step >= 1, "adam_step: step counts from 1");
+    if (n == 0) return NVO_OK;
+    const float bias1 = 1.f - powf(beta1, (float)step);
+    const float bias2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
+                       (_Float16*)params_half, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bias1,
+                       bias2_sqrt, grad_scale, weight_decay, skip_flag);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag) {
+    NVO_REQUIRE(grads && flag, "nonfinite_flag: NULL argument");
+    NVO_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), (hipStream_t)stream));
+    if (n == 0) return NVO_OK;
+    uint32_t blocks = nvo_div_up(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_nonfinite_flag, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, grads, flag);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half) {
+    NVO_REQUIRE(src && dst_half, "cast_half: NULL argument");
+    if (n == 0) return NVO_OK;
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cast_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src,
+                       (_Float16*)dst_half);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+}  // extern "C"

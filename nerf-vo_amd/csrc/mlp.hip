@@ -21,6 +21,9 @@
 //
 // Numerics: fp16 operands, fp32 accumulate (tcnn accumulates in fp16), fp16 hidden activations.
 #include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+#include <string.h>
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -145,12 +148,37 @@ __device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, in
             x[tk][2] = v1[0];
             x[tk][3] = v1[1];
         }
+    } else if (a.in_mode == NVO_IO_NERFACTO_COLOR) {
+        if constexpr (IN_PAD == 64) {
+            const uint32_t ray = row / a.samples_per_ray;
+            const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
+            const _Float16* __restrict__ sh = a.sh + (size_t)ray * 16;
+            const _Float16* __restrict__ bo = a.base_out + (size_t)row * 16;
+            const _Float16* __restrict__ em = a.embedding + (size_t)cam * 32;
+            x[0] = *reinterpret_cast<const h4*>(sh + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * g + j;                      // feature 16 + q
+                x[1][j] = q < 15 ? bo[1 + q] : em[0];
+                x[2][j] = em[1 + q];                          // feature 32 + q -> embed 1 + q
+                x[3][j] = q < 15 ? em[17 + q] : (_Float16)1.0f;  // feature 48 + q -> embed 17 + q | pad
+            }
+        }
     } else {
         const _Float16* __restrict__ p = (const _Float16*)a.input + (size_t)row * IN_PAD;
 #pragma unroll
         for (int tk = 0; tk < IN_PAD / 16; ++tk)
             x[tk] = *reinterpret_cast<const h4*>(p + 16 * tk + 4 * g);
     }
+}
+
+// sum over the 16 sample lanes (lane & 15) of one lane group
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -446,6 +474,40 @@ k_mlp_bwd(NvoMlpArgs a) {
                         p[(size_t)(lv + 1) * a.batch + row] =
                             h2{(_Float16)acc[tk][2], (_Float16)acc[tk][3]};
                 }
+            } else if (a.din_mode == NVO_IO_NERFACTO_COLOR) {
+                if constexpr (IN_PAD == 64) {
+                    const uint32_t ray = row / a.samples_per_ray;
+                    const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
+                    _Float16* __restrict__ dbo = a.d_base_out + (size_t)row * 16;
+                    // a 16-sample tile lies inside one ray when samples_per_ray % 16 == 0: reduce the
+                    // per-ray quantities over the tile before touching memory
+                    const bool tile_in_ray = (a.samples_per_ray & 15u) == 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = 4 * g + j;
+                        if (q < 15) dbo[1 + q] = (_Float16)acc[1][j];
+                        // embedding columns: e0 <- feature 31, 1+q <- feature 32+q, 17+q <- feature 48+q
+                        float e_lo = acc[2][j];
+                        float e_hi = q < 15 ? acc[3][j] : 0.f;
+                        float e_0 = q == 15 ? acc[1][j] : 0.f;
+                        float s_sh = acc[0][j];
+                        if (tile_in_ray) {
+                            e_lo = group16_sum(e_lo);
+                            e_hi = group16_sum(e_hi);
+                            e_0 = group16_sum(e_0);
+                            s_sh = group16_sum(s_sh);
+                        }
+                        if (!tile_in_ray || m == 0) {
+                            if (a.d_embedding) {
+                                float* de = a.d_embedding + (size_t)cam * 32;
+                                atomicAdd(de + 1 + q, e_lo);
+                                if (q < 15) atomicAdd(de + 17 + q, e_hi);
+                                if (q == 15) atomicAdd(de + 0, e_0);
+                            }
+                            if (a.d_sh) atomicAdd(a.d_sh + (size_t)ray * 16 + q, s_sh);
+                        }
+                    }
+                }
             } else {
                 _Float16* __restrict__ p = (_Float16*)a.dinput + (size_t)row * IN_PAD + 4 * g;
 #pragma unroll
@@ -549,3 +611,53 @@ int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
                   n_hidden, out_pad);
     return NVO_ERR_UNSUPPORTED;
 }
+
+// ---------------------------------------------------------------------------------------------
+// exported: NerfactoField colour head (group D of include/nerfvo_hip.h)
+// ---------------------------------------------------------------------------------------------
+static NvoMlpArgs color_args(const nvo_color_args& c) {
+    NvoMlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.batch = c.R * c.S;
+    a.n_in = 63;
+    a.in_mode = NVO_IO_NERFACTO_COLOR;
+    a.weights = (const _Float16*)c.weights;
+    a.output = (_Float16*)c.rgb;
+    a.hidden = (_Float16*)c.hidden;
+    a.act = NVO_ACT_RELU;
+    a.out_act = NVO_ACT_SIGMOID;
+    a.samples_per_ray = c.S;
+    a.sh = (const _Float16*)c.sh;
+    a.base_out = (const _Float16*)c.base_out;
+    a.embedding = (const _Float16*)c.embedding;
+    a.cam_idx = c.cam_idx;
+    return a;
+}
+
+extern "C" {
+
+int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args) {
+    NVO_REQUIRE(args != nullptr, "color_fwd: args is NULL");
+    const nvo_color_args c = *args;
+    NVO_REQUIRE(c.S >= 1 && c.sh && c.base_out && c.embedding && c.weights && c.rgb, "color_fwd: NULL argument");
+    const NvoMlpArgs a = color_args(c);
+    return nvo_mlp_fwd_launch(64, 64, 2, 16, a, (hipStream_t)stream);
+}
+
+int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
+    NVO_REQUIRE(args != nullptr, "color_bwd: args is NULL");
+    const nvo_color_args c = *args;
+    NVO_REQUIRE(c.S >= 1 && c.sh && c.base_out && c.embedding && c.weights && c.rgb && c.hidden && c.drgb &&
+                c.d_base_out, "color_bwd: NULL argument");
+    NvoMlpArgs a = color_args(c);
+    a.doutput = (const _Float16*)c.drgb;
+    a.dinput = c.d_base_out;
+    a.din_mode = NVO_IO_NERFACTO_COLOR;
+    a.d_base_out = (_Float16*)c.d_base_out;
+    a.d_embedding = c.d_embedding;
+    a.d_sh = c.d_sh;
+    a.dweights = c.d_weights;
+    return nvo_mlp_bwd_launch(64, 64, 2, 16, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -27,7 +27,12 @@ int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, con
 
 // ---- mlp.hip --------------------------------------------------------------------------------
 enum { NVO_ACT_NONE = 0, NVO_ACT_RELU = 1, NVO_ACT_SIGMOID = 2 };
-enum { NVO_IO_F32_ROWS = 0, NVO_IO_HALF2_SOA = 1, NVO_IO_HALF_ROWS = 2 };
+enum {
+    NVO_IO_F32_ROWS = 0,        // [B][n_in] float, columns >= n_in read as 1.0 (identity-encoding pad)
+    NVO_IO_HALF2_SOA = 1,       // [n_in/2][B] half2 (grid encoding output), missing levels read as 0
+    NVO_IO_HALF_ROWS = 2,       // [B][IN_PAD] half
+    NVO_IO_NERFACTO_COLOR = 3,  // 64-wide row assembled on the fly: [SH16(ray) | geo15 | embed32(cam) | 1]
+};
 
 struct NvoMlpArgs {
     uint32_t batch;       // multiple of 16
@@ -43,6 +48,15 @@ struct NvoMlpArgs {
     void* dinput;             // layout din_mode, nullable
     int din_mode;
     float* dweights;          // fp32, same order as weights, accumulated with atomics (pre-zeroed)
+    // NVO_IO_NERFACTO_COLOR only (NerfactoField colour head input, never materialised in HBM)
+    uint32_t samples_per_ray;
+    const _Float16* sh;         // [R][16]  SH of the ray direction
+    const _Float16* base_out;   // [B][16]  base MLP output: col 0 density pre-activation, 1..15 geo
+    const _Float16* embedding;  // [F][32]  appearance embedding (fp16 working copy)
+    const int32_t* cam_idx;     // [R] or nullptr -> row 0 of `embedding` for every ray
+    _Float16* d_base_out;       // [B][16]  cols 1..15 written by the backward
+    float* d_embedding;         // [F][32]  atomically accumulated, nullable
+    float* d_sh;                // [R][16]  atomically accumulated, nullable
 };
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
 int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,

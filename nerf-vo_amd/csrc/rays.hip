@@ -1,0 +1,207 @@
+// Ray-side kernels of the mapping training step for gfx950: pixel gather, pinhole ray generation
+// with SE3 pose correction, piecewise lin-disparity bins, sample positions with L-inf scene
+// contraction.  Replaces the torch-op chains nerfstudio runs per iteration (PixelSampler gather,
+// RayGenerator / Cameras.generate_rays, CameraOptimizer.apply_to_raybundle,
+// UniformLinDispPiecewiseSampler, Frustums.get_positions, SceneContraction) -- SURVEY.md section
+// 2.4 K8/K12, reference call sites /root/reference/nerf_vo/mapping/nerfstudio_utils.py:286-300.
+// CPU restatement: oracle/rays.py.
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+namespace {
+
+// ---- pinhole rays -----------------------------------------------------------------------------
+__device__ __forceinline__ void rot_apply(const float* __restrict__ m /*[3][4]*/, float x, float y,
+                                          float z, float* o) {
+    o[0] = m[0] * x + m[1] * y + m[2] * z;
+    o[1] = m[4] * x + m[5] * y + m[6] * z;
+    o[2] = m[8] * x + m[9] * y + m[10] * z;
+}
+
+__device__ __forceinline__ float norm3(const float* v) {
+    return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+}
+
+// ray_indices: [R][3] int64 (camera, y, x).  corrections: [F][3][4] or nullptr.
+__global__ void __launch_bounds__(256)
+k_raygen(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
+         const float* __restrict__ c2w, const float* __restrict__ corrections,
+         float* __restrict__ origins, float* __restrict__ directions,
+         float* __restrict__ directions_norm, float* __restrict__ pixel_area,
+         int32_t* __restrict__ cam_idx) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t cam = ray_indices[3 * (size_t)r + 0];
+    const float py = (float)ray_indices[3 * (size_t)r + 1] + 0.5f;
+    const float px = (float)ray_indices[3 * (size_t)r + 2] + 0.5f;
+    const float fx = intrinsics[4 * cam + 0], fy = intrinsics[4 * cam + 1];
+    const float cx = intrinsics[4 * cam + 2], cy = intrinsics[4 * cam + 3];
+    const float* __restrict__ m = c2w + 12 * cam;
+
+    float d0[3], dx[3], dy[3];
+    rot_apply(m, (px - cx) / fx, -(py - cy) / fy, -1.f, d0);
+    rot_apply(m, (px + 1.f - cx) / fx, -(py - cy) / fy, -1.f, dx);
+    rot_apply(m, (px - cx) / fx, -(py + 1.f - cy) / fy, -1.f, dy);
+    const float n0 = norm3(d0), nx = norm3(dx), ny = norm3(dy);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d0[k] /= n0;
+        const float ex = d0[k] - dx[k] / nx, ey = d0[k] - dy[k] / ny;
+        a += ex * ex;
+        b += ey * ey;
+    }
+    float o[3] = {m[3], m[7], m[11]};
+    if (corrections) {  // CameraOptimizer.apply_to_raybundle: o += t, d = R d
+        const float* __restrict__ c = corrections + 12 * cam;
+        float d1[3];
+        rot_apply(c, d0[0], d0[1], d0[2], d1);
+        d0[0] = d1[0]; d0[1] = d1[1]; d0[2] = d1[2];
+        o[0] += c[3]; o[1] += c[7]; o[2] += c[11];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[3 * (size_t)r + k] = o[k];
+        directions[3 * (size_t)r + k] = d0[k];
+    }
+    directions_norm[r] = n0;
+    if (pixel_area) pixel_area[r] = sqrtf(a) * sqrtf(b);
+    cam_idx[r] = (int32_t)cam;
+}
+
+// images: [F][H][W][Cn] float -> out [R][Cn]
+__global__ void __launch_bounds__(256)
+k_gather_pixels(uint32_t R, const int64_t* __restrict__ ray_indices, uint32_t H, uint32_t W,
+                uint32_t Cn, const float* __restrict__ images, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * Cn) return;
+    const uint32_t r = i / Cn, c = i - r * Cn;
+    const int64_t cam = ray_indices[3 * (size_t)r + 0], y = ray_indices[3 * (size_t)r + 1],
+                  x = ray_indices[3 * (size_t)r + 2];
+    out[i] = images[(((size_t)cam * H + (size_t)y) * W + (size_t)x) * Cn + c];
+}
+
+// ---- spacing functions (UniformLinDispPiecewiseSampler) ----------------------------------------
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? x * 0.5f : 1.f - 1.f / (2.f * x); }
+__device__ __forceinline__ float spacing_fn_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
+
+// sbins/tbins: [R][S+1].  jitter: [R] in [0,1) (single_jitter) or nullptr (eval: plain linspace).
+__global__ void __launch_bounds__(256)
+k_sample_lindisp(uint32_t R, uint32_t S, float near, float far, const float* __restrict__ jitter,
+                 float* __restrict__ sbins, float* __restrict__ tbins) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * (S + 1)) return;
+    const uint32_t r = i / (S + 1), j = i - r * (S + 1);
+    const float step = 1.0f / (float)S;
+    float b = (float)j * step;
+    if (j == S) b = 1.0f;
+    if (jitter) {
+        const float prev = j > 0 ? (float)(j - 1) * step : 0.f;
+        const float next = (j + 1 == S) ? 1.0f : (float)(j + 1) * step;
+        const float lower = j == 0 ? b : (prev + b) * 0.5f;
+        const float upper = j == S ? b : (b + next) * 0.5f;
+        b = lower + (upper - lower) * jitter[r];
+    }
+    const float s_near = spacing_fn(near), s_far = spacing_fn(far);
+    sbins[i] = b;
+    tbins[i] = spacing_fn_inv(b * s_far + (1.f - b) * s_near);
+}
+
+// ---- sample positions -> contracted, normalised grid coordinates -------------------------------
+// x01: [R*S][3]; rows whose selector is false are written as exact zeros (the selector is then
+// recoverable as x01[.][0] > 0).  contraction: 0 = none (aabb normalisation), 1 = L-inf.
+__global__ void __launch_bounds__(256)
+k_sample_positions(uint32_t R, uint32_t S, const float* __restrict__ origins,
+                   const float* __restrict__ directions, const float* __restrict__ tbins,
+                   float* __restrict__ x01) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * S) return;
+    const uint32_t r = i / S, s = i - r * S;
+    const float mid = (tbins[(size_t)r * (S + 1) + s] + tbins[(size_t)r * (S + 1) + s + 1]) * 0.5f;
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = origins[3 * (size_t)r + k] + directions[3 * (size_t)r + k] * mid;
+    const float mag = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
+    if (!(mag < 1.f)) {
+        const float f = (2.f - 1.f / mag) / mag;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] *= f;
+    }
+    bool sel = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k] = (p[k] + 2.f) * 0.25f;
+        sel = sel && (p[k] > 0.f) && (p[k] < 1.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = sel ? p[k] : 0.f;
+}
+
+// direction encoding input: (d + 1) / 2 per ray
+__global__ void __launch_bounds__(256)
+k_dirs01(uint32_t n, const float* __restrict__ d, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (d[i] + 1.f) * 0.5f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+               const float* c2w, const float* corrections, float* origins, float* directions,
+               float* directions_norm, float* pixel_area, int32_t* cam_idx) {
+    NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && origins && directions &&
+                           directions_norm && cam_idx), "raygen: NULL argument");
+    if (R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_raygen, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       ray_indices, intrinsics, c2w, corrections, origins, directions, directions_norm,
+                       pixel_area, cam_idx);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H,
+                      uint32_t W, uint32_t Cn, const float* images, float* out) {
+    NVO_REQUIRE(R == 0 || (ray_indices && images && out && Cn >= 1), "gather_pixels: NULL argument");
+    if (R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_gather_pixels, dim3(nvo_div_up((uint64_t)R * Cn, 256)), dim3(256), 0,
+                       (hipStream_t)stream, R, ray_indices, H, W, Cn, images, out);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
+                       const float* jitter, float* sbins, float* tbins) {
+    NVO_REQUIRE(S >= 1 && (R == 0 || (sbins && tbins)), "sample_lindisp: bad argument");
+    if (R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_sample_lindisp, dim3(nvo_div_up((uint64_t)R * (S + 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, R, S, near_plane, far_plane, jitter, sbins, tbins);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const float* origins,
+                         const float* directions, const float* tbins, float* x01) {
+    NVO_REQUIRE(S >= 1 && (R == 0 || (origins && directions && tbins && x01)), "sample_positions: bad argument");
+    if (R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, R, S, origins, directions, tbins, x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out) {
+    NVO_REQUIRE(n == 0 || (d && out), "dirs01: NULL argument");
+    if (n == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_dirs01, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d, out);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out_half) {
+    NVO_REQUIRE(R == 0 || (dirs01 && out_half), "sh_encode: NULL argument");
+    return nvo_sh_fwd_launch((hipStream_t)stream, R, degree, dirs01, out_half, 16, 16);
+}
+
+}  // extern "C"

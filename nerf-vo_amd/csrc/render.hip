@@ -1,0 +1,464 @@
+// Per-ray kernels of the mapping training step for gfx950, ONE WAVE (64 lanes) PER RAY:
+//   k_weights_pdf      density activation (trunc_exp) + volume-rendering weights + (optionally)
+//                      histogram-CDF resampling of the next level's bins (PDFSampler)
+//   k_main_render_loss compositing (rgb with last-sample background, accumulation, median and
+//                      expected depth) fused with the rgb / distortion / depth losses and their
+//                      gradients w.r.t. per-sample colour and density pre-activation
+//   k_prop_loss        interlevel (mip-NeRF 360 outer-measure) + depth loss of one proposal level and
+//                      the gradient w.r.t. that level's density pre-activation
+// Prefix / suffix sums over a ray's samples are wavefront scans (shuffle network) with a carry
+// across 64-sample chunks; per-ray scratch lives in the wave's private LDS slice.
+// Replaces nerfstudio's torch-op chains RaySamples.get_weights, PDFSampler, RGBRenderer /
+// AccumulationRenderer / DepthRenderer, interlevel_loss / distortion_loss / ds_nerf_depth_loss
+// (reference hooks /root/reference/nerf_vo/mapping/
+// nerfstudio_utils.py:337-350 and nerfstudio.py:71-82 for the loss multipliers).
+// CPU restatement: oracle/rays.py.
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int kRayBlock = 256;          // 4 waves = 4 rays per workgroup
+constexpr int kRaysPerBlock = kRayBlock / 64;
+constexpr int kMaxS = 256;              // samples per ray handled by the LDS scratch
+constexpr float kLossEps = 1.0e-7f;     // nerfstudio losses.EPS
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (isnan(v)) return 0.f;
+    if (isinf(v)) return v > 0.f ? FLT_MAX : -FLT_MAX;
+    return v;
+}
+
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? x * 0.5f : 1.f - 1.f / (2.f * x); }
+__device__ __forceinline__ float spacing_fn_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
+
+// first index in a[0..n) with a[idx] > v   (torch.searchsorted(..., side="right"))
+__device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Per-ray forward quantities from the density pre-activation; fills LDS arrays w[] and Tr[].
+// sigma = selector * exp(pre + bias); w_i = (1 - exp(-delta_i sigma_i)) * exp(-sum_{j<i} delta_j sigma_j)
+__device__ __forceinline__ void ray_weights(int lane, uint32_t S, const _Float16* __restrict__ pre,
+                                            uint32_t pre_stride, const float* __restrict__ x01,
+                                            const float* __restrict__ tb, float bias,
+                                            float* __restrict__ sigma_out, float* w, float* Tr) {
+    float carry = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        float dd = 0.f, sg = 0.f;
+        if (i < S) {
+            const bool sel = x01[3 * (size_t)i] > 0.f;
+            sg = sel ? __expf((float)pre[(size_t)i * pre_stride] + bias) : 0.f;
+            dd = (tb[i + 1] - tb[i]) * sg;
+            if (sigma_out) sigma_out[i] = sg;
+        }
+        const float incl = wave_incl_scan(dd, lane) + carry;
+        const float T = __expf(-(incl - dd));
+        if (i < S) {
+            w[i] = nan_to_num((1.f - __expf(-dd)) * T);
+            Tr[i] = T;
+        }
+        carry = __shfl(incl, 63, 64);
+    }
+}
+
+// dL/dw (in LDS array g[], overwritten) -> dL/dpre, written as fp16 * loss_scale
+// dL/dsigma_k = delta_k [ g_k (T_k - w_k) - sum_{i>k} g_i w_i ],  dsigma/dpre = exp(clamp(pre+bias,-15,15))
+__device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const _Float16* __restrict__ pre,
+                                                uint32_t pre_stride, const float* __restrict__ x01,
+                                                const float* __restrict__ tb, float bias,
+                                                const float* w, const float* Tr, const float* g,
+                                                float loss_scale, _Float16* __restrict__ dpre,
+                                                uint32_t dpre_stride) {
+    // total of g_i w_i, then inclusive prefix per chunk -> suffix (exclusive) = total - incl
+    float total = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        total += (i < S) ? g[i] * w[i] : 0.f;
+    }
+    total = wave_sum(total);
+    float carry = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const float gw = (i < S) ? g[i] * w[i] : 0.f;
+        const float incl = wave_incl_scan(gw, lane) + carry;
+        if (i < S) {
+            const bool sel = x01[3 * (size_t)i] > 0.f;
+            float d = 0.f;
+            if (sel) {
+                const float x = (float)pre[(size_t)i * pre_stride] + bias;
+                const float delta = tb[i + 1] - tb[i];
+                const float dsig = delta * (g[i] * (Tr[i] - w[i]) - (total - incl));
+                d = dsig * __expf(fminf(fmaxf(x, -15.f), 15.f));
+            }
+            dpre[(size_t)i * dpre_stride] = (_Float16)(d * loss_scale);
+        }
+        carry = __shfl(incl, 63, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights (+ PDF resampling)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kRayBlock)
+k_weights_pdf(nvo_weights_pdf_args a) {
+    __shared__ float lds[kRaysPerBlock][3][kMaxS + 4];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
+    if (r >= a.R) return;
+    float* w = lds[wib][0];
+    float* Tr = lds[wib][1];
+    float* cdf = lds[wib][2];
+    const uint32_t S = a.S;
+    const size_t so = (size_t)r * S;
+    const float* tb = a.tbins + (size_t)r * (S + 1);
+    ray_weights(lane, S, (const _Float16*)a.pre + so * a.pre_stride, a.pre_stride, a.x01 + 3 * so, tb, a.density_bias,
+                a.sigma ? a.sigma + so : nullptr, w, Tr);
+    for (uint32_t i = lane; i < S; i += 64) a.weights[so + i] = w[i];
+    if (a.S_out == 0) return;
+
+    // ---- PDFSampler: annealed weights -> padded pdf -> clamped cdf (cdf[0] = 0)
+    float part = 0.f;
+    for (uint32_t i = lane; i < S; i += 64) {
+        const float wa = (a.anneal == 1.0f ? w[i] : powf(w[i], a.anneal)) + a.histogram_padding;
+        Tr[i] = wa;  // reuse as pdf numerator
+        part += wa;
+    }
+    float sum = wave_sum(part);
+    const float padding = fmaxf(1e-5f - sum, 0.f);
+    sum += padding;
+    const float pad_each = padding / (float)S;
+    float carry = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const float p = (i < S) ? (Tr[i] + pad_each) / sum : 0.f;
+        const float incl = wave_incl_scan(p, lane) + carry;
+        if (i < S) cdf[i + 1] = fminf(1.f, incl);
+        carry = __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const float* sb = a.sbins + (size_t)r * (S + 1);
+    const uint32_t nb = a.S_out + 1;
+    const float inv_nb = 1.0f / (float)nb;
+    const float shift = a.jitter ? a.jitter[r] * inv_nb : 0.5f * inv_nb;
+    const float s_near = spacing_fn(a.near_plane), s_far = spacing_fn(a.far_plane);
+    for (uint32_t j = lane; j < nb; j += 64) {
+        const float u = (float)j * inv_nb + shift;
+        const int inds = upper_bound(cdf, (int)S + 1, u);
+        const int below = min(max(inds - 1, 0), (int)S), above = min(max(inds, 0), (int)S);
+        const float c0 = cdf[below], c1 = cdf[above];
+        float t = (u - c0) / (c1 - c0);
+        if (isnan(t)) t = 0.f;
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        const float b = sb[below] + t * (sb[above] - sb[below]);
+        a.sbins_out[(size_t)r * nb + j] = b;
+        a.tbins_out[(size_t)r * nb + j] = spacing_fn_inv(b * s_far + (1.f - b) * s_near);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main level: render + losses + gradients
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kRayBlock)
+k_main_render_loss(nvo_main_loss_args a) {
+    __shared__ float lds[kRaysPerBlock][4][64 + 4];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
+    if (r >= a.R) return;
+    float* w = lds[wib][0];
+    float* Tr = lds[wib][1];
+    float* g = lds[wib][2];
+    float* ut = lds[wib][3];
+    const uint32_t S = a.S;
+    const size_t so = (size_t)r * S;
+    const float* tb = a.tbins + (size_t)r * (S + 1);
+    const float* sb = a.sbins + (size_t)r * (S + 1);
+    const _Float16* pre = (const _Float16*)a.pre + so * a.pre_stride;
+    const float* x01 = a.x01 + 3 * so;
+    ray_weights(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
+    const bool act = (uint32_t)lane < S;
+    const float wi = act ? w[lane] : 0.f;
+    if (a.weights && act) a.weights[so + lane] = wi;
+
+    // ---- composite
+    float c[3] = {0.f, 0.f, 0.f};
+    if (act) {
+        const _Float16* cp = (const _Float16*)a.rgb + (so + lane) * a.rgb_stride;
+        c[0] = (float)cp[0]; c[1] = (float)cp[1]; c[2] = (float)cp[2];
+    }
+    const float acc = wave_sum(wi);
+    float pix[3], clast[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        clast[k] = __shfl(c[k], (int)S - 1, 64);
+        pix[k] = wave_sum(wi * c[k]) + clast[k] * (1.f - acc);
+    }
+    const float mid = act ? 0.5f * (tb[lane] + tb[lane + 1]) : 0.f;
+    // median depth: first sample whose cumulative weight reaches 0.5 (clamped to the last sample)
+    const float cum = wave_incl_scan(wi, lane);
+    const unsigned long long ballot = __ballot(act && cum >= 0.5f);
+    const int med = ballot ? (int)__builtin_ctzll(ballot) : (int)S - 1;
+    const float depth_med = __shfl(mid, med, 64);
+    if (lane == 0) {
+        a.out_rgb[3 * (size_t)r + 0] = pix[0];
+        a.out_rgb[3 * (size_t)r + 1] = pix[1];
+        a.out_rgb[3 * (size_t)r + 2] = pix[2];
+        a.out_depth[r] = depth_med;
+        a.out_accumulation[r] = acc;
+    }
+    if (a.out_expected_depth) {
+        const float num = wave_sum(wi * mid);
+        if (lane == 0) a.out_expected_depth[r] = num / (acc + 1e-10f);  // clip to [min,max] steps: host
+    }
+    if (!a.dpre) return;
+
+    // ---- losses
+    float dpix[3];
+    float l_rgb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float e = pix[k] - a.gt_rgb[3 * (size_t)r + k];
+        l_rgb += e * e;
+        dpix[k] = a.rgb_mult * 2.f * e * a.inv_rays * (1.f / 3.f);
+    }
+    l_rgb *= a.inv_rays * (1.f / 3.f);
+    // d/dw_i and d/dc_i from the rgb term
+    float gw = 0.f;
+    float dc[3] = {0.f, 0.f, 0.f};
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gw += dpix[k] * (c[k] - clast[k]);
+            dc[k] = dpix[k] * wi;
+        }
+        if ((uint32_t)lane == S - 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dc[k] += dpix[k] * (1.f - acc);
+        }
+    }
+    // distortion (spacing domain): sum_i w_i sum_j w_j |ut_i-ut_j| + sum_i w_i^2 (s_{i+1}-s_i)/3
+    float l_dist = 0.f;
+    if (a.distortion_mult != 0.f) {
+        const float uti = act ? 0.5f * (sb[lane] + sb[lane + 1]) : 0.f;
+        if (act) ut[lane] = uti;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float inner = 0.f;
+        if (act) {
+            for (uint32_t j = 0; j < S; ++j) inner += w[j] * fabsf(uti - ut[j]);
+        }
+        const float ds = act ? (sb[lane + 1] - sb[lane]) : 0.f;
+        l_dist = wave_sum(wi * inner + wi * wi * ds * (1.f / 3.f)) * a.inv_rays;
+        if (act) gw += a.distortion_mult * a.inv_rays * (2.f * inner + 2.f * wi * ds * (1.f / 3.f));
+    }
+    // DS-NeRF depth loss on this level
+    float l_depth = 0.f;
+    if (a.depth_mult != 0.f && a.gt_depth) {
+        const float z = a.gt_depth[r] * a.directions_norm[r];
+        const float mask = z > 0.f ? 1.f : 0.f;
+        float term = 0.f;
+        if (act) {
+            const float len = tb[lane + 1] - tb[lane];
+            const float gss = __expf(-((mid - z) * (mid - z)) / (2.f * a.depth_sigma)) * len * mask;
+            term = -__logf(wi + kLossEps) * gss;
+            gw += a.depth_mult * a.depth_level_div * a.inv_rays * (-gss / (wi + kLossEps));
+        }
+        l_depth = wave_sum(term) * a.inv_rays * a.depth_level_div;
+    }
+    if (lane == 0) {
+        atomicAdd(a.losses + 0, a.rgb_mult * l_rgb);
+        atomicAdd(a.losses + 1, a.distortion_mult * l_dist);
+        atomicAdd(a.losses + 2, a.depth_mult * l_depth);
+    }
+    if (act) g[lane] = gw;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+    if (act) {
+        _Float16* dp = (_Float16*)a.drgb + (so + lane) * a.drgb_stride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] = (_Float16)(dc[k] * a.loss_scale);
+        for (uint32_t k = 3; k < a.drgb_stride; ++k) dp[k] = (_Float16)0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// proposal level: interlevel + depth loss and gradient
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kRayBlock)
+k_prop_loss(nvo_prop_loss_args a) {
+    __shared__ float lds[kRaysPerBlock][4][kMaxS + 4];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
+    if (r >= a.R) return;
+    float* w = lds[wib][0];
+    float* Tr = lds[wib][1];
+    float* g = lds[wib][2];     // dL/dw of this level (built through a difference array)
+    float* cy = lds[wib][3];    // exclusive cumsum of w: cy[0] = 0, cy[j+1] = sum_{<=j} w
+    const uint32_t S = a.S, Sm = a.S_main;
+    const size_t so = (size_t)r * S;
+    const float* tb = a.tbins + (size_t)r * (S + 1);
+    const float* sb = a.sbins + (size_t)r * (S + 1);
+    const _Float16* pre = (const _Float16*)a.pre + so * a.pre_stride;
+    const float* x01 = a.x01 + 3 * so;
+    ray_weights(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float carry = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const float v = (i < S) ? w[i] : 0.f;
+        const float incl = wave_incl_scan(v, lane) + carry;
+        if (i < S) cy[i + 1] = incl;
+        carry = __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cy[0] = 0.f;
+    for (uint32_t i = lane; i < S + 2; i += 64) g[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- interlevel: one main-level interval per lane
+    float l_inter = 0.f;
+    if ((uint32_t)lane < Sm) {
+        const float* cm = a.sbins_main + (size_t)r * (Sm + 1);
+        const float wm = a.weights_main[(size_t)r * Sm + lane];
+        int lo = upper_bound(sb, (int)S, cm[lane]) - 1;          // over interval starts sb[0..S)
+        lo = min(max(lo, 0), (int)S - 1);
+        int hi = upper_bound(sb + 1, (int)S, cm[lane + 1]);      // over interval ends sb[1..S]
+        hi = min(max(hi, 0), (int)S - 1);
+        const float w_outer = cy[hi + 1] - cy[lo];
+        const float diff = wm - w_outer;
+        if (diff > 0.f) {
+            l_inter = diff * diff / (wm + kLossEps);
+            const float coef = a.interlevel_mult * a.inv_rays / (float)Sm;
+            const float gi = -2.f * diff / (wm + kLossEps) * coef;  // d/d(w_outer)
+            atomicAdd(&g[lo], gi);
+            atomicAdd(&g[hi + 1], -gi);
+        }
+    }
+    l_inter = wave_sum(l_inter) * a.inv_rays / (float)Sm;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // difference array -> dL/dw_j (inclusive prefix), plus the depth term
+    float l_depth = 0.f;
+    const bool use_depth = a.depth_mult != 0.f && a.gt_depth;
+    const float z = use_depth ? a.gt_depth[r] * a.directions_norm[r] : 0.f;
+    const float mask = z > 0.f ? 1.f : 0.f;
+    carry = 0.f;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t i = base + lane;
+        const float v = (i < S) ? g[i] : 0.f;
+        const float incl = wave_incl_scan(v, lane) + carry;
+        carry = __shfl(incl, 63, 64);
+        float gi = incl;
+        if (i < S && use_depth) {
+            const float midp = 0.5f * (tb[i] + tb[i + 1]);
+            const float len = tb[i + 1] - tb[i];
+            const float gss = __expf(-((midp - z) * (midp - z)) / (2.f * a.depth_sigma)) * len * mask;
+            l_depth += -__logf(w[i] + kLossEps) * gss;
+            gi += a.depth_mult * a.depth_level_div * a.inv_rays * (-gss / (w[i] + kLossEps));
+        }
+        // all lanes finished reading g[i] of this chunk through the scan before it is overwritten
+        if (i < S) g[i] = gi;
+    }
+    l_depth = wave_sum(l_depth) * a.inv_rays * a.depth_level_div;
+    if (lane == 0) {
+        atomicAdd(a.losses + 0, a.interlevel_mult * l_inter);
+        atomicAdd(a.losses + 1, a.depth_mult * l_depth);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+    for (uint32_t i = lane; i < S; i += 64) {
+        _Float16* dp = (_Float16*)a.dpre + (so + i) * a.dpre_stride;
+        for (uint32_t k = 1; k < a.dpre_stride; ++k) dp[k] = (_Float16)0.f;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// exported entry points (group C of include/nerfvo_hip.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args) {
+    NVO_REQUIRE(args != nullptr, "weights_pdf: args is NULL");
+    const nvo_weights_pdf_args a = *args;
+    NVO_REQUIRE(a.S >= 1 && a.S <= (uint32_t)kMaxS, "weights_pdf: samples per ray %u not in 1..%d", a.S, kMaxS);
+    NVO_REQUIRE(a.S_out <= (uint32_t)kMaxS, "weights_pdf: S_out %u > %d", a.S_out, kMaxS);
+    NVO_REQUIRE(a.S_out == 0 || (a.sbins_out && a.tbins_out), "weights_pdf: output bins are NULL");
+    NVO_REQUIRE(a.pre && a.x01 && a.tbins && a.weights && a.sbins, "weights_pdf: NULL input");
+    if (a.R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_weights_pdf, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+                       (hipStream_t)stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args) {
+    NVO_REQUIRE(args != nullptr, "main_render_loss: args is NULL");
+    const nvo_main_loss_args a = *args;
+    NVO_REQUIRE(a.S >= 1 && a.S <= 64, "main_render_loss: samples per ray %u not in 1..64", a.S);
+    NVO_REQUIRE(a.pre && a.rgb && a.x01 && a.sbins && a.tbins && a.out_rgb && a.out_depth &&
+                a.out_accumulation, "main_render_loss: NULL input/output");
+    NVO_REQUIRE(!a.dpre || (a.drgb && a.losses && a.gt_rgb && a.drgb_stride >= 3),
+                "main_render_loss: training mode needs drgb, losses, gt_rgb");
+    if (a.R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_main_render_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+                       (hipStream_t)stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args) {
+    NVO_REQUIRE(args != nullptr, "prop_loss: args is NULL");
+    const nvo_prop_loss_args a = *args;
+    NVO_REQUIRE(a.S >= 1 && a.S <= (uint32_t)kMaxS && a.S_main >= 1 && a.S_main <= 64,
+                "prop_loss: S=%u (<=%d) S_main=%u (<=64)", a.S, kMaxS, a.S_main);
+    NVO_REQUIRE(a.pre && a.x01 && a.sbins && a.tbins && a.sbins_main && a.weights_main && a.losses &&
+                a.dpre && a.dpre_stride >= 1, "prop_loss: NULL input/output");
+    if (a.R == 0) return NVO_OK;
+    hipLaunchKernelGGL(k_prop_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+                       (hipStream_t)stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+"""Native training / rendering engine of the depth-nerfacto model NeRF-VO maps with.
+
+This is the host-side sequencing of the HIP kernels for ONE optimisation step (and for inference
+rendering): PyTorch only provides device memory, the stream and the RNG; every arithmetic step of
+the hot path is a kernel behind the C-ABI (include/nerfvo_hip.h).  The step mirrors what
+``trainer.train_iteration`` does in the reference (/root/reference/nerf_vo/mapping/nerfstudio.py:151
+with the configuration of :47-103; call stack in SURVEY.md section 3.1/3.3):
+
+    raygen(+pose correction) -> lin-disp bins(256) -> proposal net 0 -> weights+PDF(96)
+    -> proposal net 1 -> weights+PDF(48) -> hash grid + base MLP -> SH + colour MLP
+    -> render + losses (+ per-sample gradients) -> colour/base MLP + grid backward
+    -> [proposal losses + backward when the sampler schedule says so] -> fused Adam
+
+All trainable parameters live in ONE flat fp32 buffer (+ fp16 working copy, gradient, Adam moments)
+so that a multi-GPU step needs exactly one RCCL all-reduce and one optimiser pass per group.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tinycudann.modules import _NativeModule, _create, _ptr, _stream
+
+
+@dataclass
+class GridConfig:
+    n_levels: int
+    log2_hashmap_size: int
+    base_resolution: int
+    max_resolution: int
+    n_features_per_level: int = 2
+
+    @property
+    def per_level_scale(self) -> float:
+        # nerfstudio HashEncoding: growth = exp((ln max_res - ln base_res) / (L - 1))
+        return float(np.exp((np.log(self.max_resolution) - np.log(self.base_resolution)) / (self.n_levels - 1)))
+
+    def tcnn_dict(self) -> dict:
+        return {"otype": "HashGrid", "n_levels": self.n_levels, "n_features_per_level": self.n_features_per_level,
+                "log2_hashmap_size": self.log2_hashmap_size, "base_resolution": self.base_resolution,
+                "per_level_scale": self.per_level_scale}
+
+
+@dataclass
+class EngineConfig:
+    """Values = nerfacto defaults [UPSTREAM, SURVEY.md section 3.3] overridden as the reference does
+    (/root/reference/nerf_vo/mapping/nerfstudio.py:62-82)."""
+    num_images: int = 192
+    num_rays: int = 4096
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    num_proposal_samples: tuple = (256, 96)
+    num_nerf_samples: int = 48
+    main_grid: GridConfig = field(default_factory=lambda: GridConfig(16, 19, 16, 2048))
+    proposal_grids: tuple = (GridConfig(5, 17, 16, 128), GridConfig(5, 17, 16, 256))
+    hidden_dim: int = 64
+    geo_feat_dim: int = 15
+    appearance_embed_dim: int = 32
+    density_bias: float = -1.0            # sigma = trunc_exp(h0 - 1)
+    histogram_padding: float = 0.01
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    proposal_warmup: int = 5000
+    proposal_update_every: int = 5
+    rgb_loss_mult: float = 1.0
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    depth_loss_mult: float = 0.001
+    depth_sigma: float = 0.001
+    loss_scale: float = 128.0
+    lr_fields: float = 1e-2
+    lr_proposal: float = 1e-2
+    lr_camera: float = 1e-4
+    lr_camera_final: float = 1e-5
+    adam_eps: float = 1e-15
+    adam_betas: tuple = (0.9, 0.999)
+    max_num_iterations: int = 8192
+    optimize_poses: bool = False          # BASELINE config[1] "fixed poses"; SE3 gradient path: later round
+    grid_bwd_mode: int = 1                # 1 = LDS slice-owner scatter, 0 = global atomics
+    seed: int = 1337
+
+
+_MLP16 = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 16,
+          "n_hidden_layers": 1}
+
+
+def _call(name: str, *args) -> None:
+    _lib.check(getattr(_lib.lib(), name)(*args), name)
+
+
+class NerfactoEngine:
+    """Owns parameters, optimiser state, scratch and the kernel sequence of one step."""
+
+    LOSS_NAMES = ("rgb_loss", "distortion_loss", "depth_loss", "interlevel_loss", "prop_depth_loss")
+
+    def __init__(self, config: EngineConfig, device: torch.device, world_size: int = 1):
+        if device.type != "cuda":
+            raise RuntimeError("NerfactoEngine needs an MI355X device; there is no CPU fallback")
+        self.cfg = config
+        self.device = device
+        self.world_size = world_size
+        cfg = config
+        self.levels = (*cfg.num_proposal_samples, cfg.num_nerf_samples)
+
+        # ---- native modules (tcnn NetworkWithInputEncoding: params = [mlp | grid])
+        self.prop_nets = [
+            _create("nvo_create_network_with_input_encoding", 3, 1, json.dumps(g.tcnn_dict()).encode(),
+                    json.dumps(_MLP16).encode())
+            for g in cfg.proposal_grids
+        ]
+        base_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                    "n_neurons": cfg.hidden_dim, "n_hidden_layers": 1}
+        self.base_net = _create("nvo_create_network_with_input_encoding", 3, 1 + cfg.geo_feat_dim,
+                                json.dumps(cfg.main_grid.tcnn_dict()).encode(), json.dumps(base_cfg).encode())
+        for m in (*self.prop_nets, self.base_net):
+            m.set_option("grid_bwd_mode", cfg.grid_bwd_mode)
+        color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
+        assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
+        self.n_color = 64 * 64 + 64 * 64 + 16 * 64
+
+        # ---- flat parameter layout: name -> (offset, size, group)
+        segs = []
+        off = 0
+
+        def add(name, size, group):
+            nonlocal off
+            segs.append((name, off, size, group))
+            off += size
+
+        add("field.base", self.base_net.n_params, "fields")
+        add("field.color", self.n_color, "fields")
+        add("field.embedding", cfg.num_images * cfg.appearance_embed_dim, "fields")
+        for i, m in enumerate(self.prop_nets):
+            add(f"proposal.{i}", m.n_params, "proposal_networks")
+        add("camera_opt.pose_adjustment", cfg.num_images * 6, "camera_opt")
+        self.segments = {n: (o, s, g) for n, o, s, g in segs}
+        self.n_params = off
+        self.group_ranges = {}
+        for n, o, s, g in segs:
+            lo, hi = self.group_ranges.get(g, (o, o))
+            self.group_ranges[g] = (min(lo, o), max(hi, o + s))
+
+        dev = device
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.params_half = torch.zeros(self.n_params, dtype=torch.float16, device=dev)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.skip_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.opt_steps = {g: 0 for g in self.group_ranges}
+        self.step = 0
+        self.steps_since_proposal_update = 0
+        self._ws = None
+        self.init_params(cfg.seed)
+
+    # ------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------
+    def view(self, name: str, buf: torch.Tensor | None = None) -> torch.Tensor:
+        o, s, _ = self.segments[name]
+        return (self.params if buf is None else buf)[o:o + s]
+
+    def init_params(self, seed: int) -> None:
+        """tcnn-style init for grids / MLPs (native PCG32 stream), N(0,1) appearance embedding
+        (torch.nn.Embedding default), zero pose adjustment."""
+        host = torch.zeros(self.n_params, dtype=torch.float32)
+        host[self._slice("field.base")] = self.base_net.initial_params(seed)
+        # colour head: Xavier-uniform like a tcnn.Network(63 -> 3, 64 neurons, 2 hidden layers)
+        color = _create("nvo_create_network", 63, 3, json.dumps(
+            {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64,
+             "n_hidden_layers": 2}).encode())
+        assert color.n_params == self.n_color
+        host[self._slice("field.color")] = color.initial_params(seed)
+        g = torch.Generator().manual_seed(seed)
+        host[self._slice("field.embedding")] = torch.randn(self.segments["field.embedding"][1], generator=g)
+        for i, m in enumerate(self.prop_nets):
+            host[self._slice(f"proposal.{i}")] = m.initial_params(seed + 1 + i)
+        self.set_params(host)
+
+    def _slice(self, name: str) -> slice:
+        o, s, _ = self.segments[name]
+        return slice(o, o + s)
+
+    def set_params(self, flat: torch.Tensor) -> None:
+        self.params.copy_(flat.to(self.device, torch.float32))
+        self.sync_half()
+
+    def sync_half(self) -> None:
+        _call("nvo_cast_half", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half))
+
+    def reset_optimizer(self) -> None:
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.opt_steps = {g: 0 for g in self.group_ranges}
+
+    # ------------------------------------------------------------------------------------------
+    # scratch
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self, R: int, training: bool):
+        key = (R, training)
+        if self._ws is not None and self._ws["key"] == key:
+            return self._ws
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        f16 = dict(dtype=torch.float16, device=dev)
+        ws = {"key": key, "R": R}
+        ws["origins"] = torch.empty(R, 3, **f32)
+        ws["directions"] = torch.empty(R, 3, **f32)
+        ws["directions_norm"] = torch.empty(R, **f32)
+        ws["pixel_area"] = torch.empty(R, **f32)
+        ws["cam_idx"] = torch.empty(R, dtype=torch.int32, device=dev)
+        ws["gt_rgb"] = torch.empty(R, 3, **f32)
+        ws["gt_depth"] = torch.empty(R, **f32)
+        ws["dirs01"] = torch.empty(R, 3, **f32)
+        ws["sh"] = torch.empty(R, 16, **f16)
+        ws["out_rgb"] = torch.empty(R, 3, **f32)
+        ws["out_depth"] = torch.empty(R, **f32)
+        ws["out_expected_depth"] = torch.empty(R, **f32)
+        ws["out_accumulation"] = torch.empty(R, **f32)
+        nets = (*self.prop_nets, self.base_net)
+        for k, (S, net) in enumerate(zip(self.levels, nets)):
+            N = R * S
+            assert N % 16 == 0, "rays x samples must be a multiple of 16"
+            ws[f"sbins{k}"] = torch.empty(R, S + 1, **f32)
+            ws[f"tbins{k}"] = torch.empty(R, S + 1, **f32)
+            ws[f"x{k}"] = torch.empty(N, 3, **f32)
+            ws[f"out{k}"] = torch.empty(N, 16, **f16)
+            ws[f"ctx{k}"] = torch.empty(net.ctx_bytes(N), dtype=torch.uint8, device=dev)
+            ws[f"weights{k}"] = torch.empty(N, **f32)
+            if training:
+                ws[f"dout{k}"] = torch.empty(N, 16, **f16)
+        Nm = R * self.levels[-1]
+        ws["rgb"] = torch.empty(Nm, 16, **f16)
+        if training:
+            ws["color_hidden"] = torch.empty(2, Nm, 64, **f16)
+            ws["drgb"] = torch.empty(Nm, 16, **f16)
+        self._ws = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------
+    # forward pieces
+    # ------------------------------------------------------------------------------------------
+    def _param_ptr(self, name: str, buf: torch.Tensor):
+        o, _, _ = self.segments[name]
+        return C.c_void_p(buf.data_ptr() + o * buf.element_size())
+
+    def _density_level(self, ws, k: int, net: _NativeModule, seg: str, stream):
+        """positions -> contracted grid coords -> NetworkWithInputEncoding -> fp16 [N,16] (col 0)."""
+        R, S = ws["R"], self.levels[k]
+        _call("nvo_sample_positions", stream, R, S, _ptr(ws["origins"]), _ptr(ws["directions"]),
+              _ptr(ws[f"tbins{k}"]), _ptr(ws[f"x{k}"]))
+        _call("nvo_fwd", net.handle, stream, R * S, _ptr(ws[f"x{k}"]), self._param_ptr(seg, self.params_half),
+              _ptr(ws[f"out{k}"]), _ptr(ws[f"ctx{k}"]))
+
+    def _weights_pdf(self, ws, k: int, anneal: float, jitter, stream, resample: bool):
+        cfg = self.cfg
+        R, S = ws["R"], self.levels[k]
+        S_out = self.levels[k + 1] if resample else 0
+        a = _lib.WeightsPdfArgs(
+            R=R, S=S, S_out=S_out, pre=ws[f"out{k}"].data_ptr(), pre_stride=16, x01=ws[f"x{k}"].data_ptr(),
+            sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(), density_bias=cfg.density_bias,
+            sigma=None, weights=ws[f"weights{k}"].data_ptr(), anneal=anneal,
+            histogram_padding=cfg.histogram_padding, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+            jitter=None if jitter is None else jitter.data_ptr(),
+            sbins_out=ws[f"sbins{k + 1}"].data_ptr() if resample else None,
+            tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None)
+        _call("nvo_weights_pdf", stream, C.byref(a))
+
+    def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream):
+        """Everything up to (and including) the colour head.  jitters: None or 3 tensors [R]."""
+        cfg = self.cfg
+        R = ws["R"]
+        j = jitters if jitters is not None else (None, None, None)
+        _call("nvo_sample_lindisp", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
+              _ptr(ws["sbins0"]), _ptr(ws["tbins0"]))
+        for k, net in enumerate(self.prop_nets):
+            self._density_level(ws, k, net, f"proposal.{k}", stream)
+            self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True)
+        km = len(self.prop_nets)
+        self._density_level(ws, km, self.base_net, "field.base", stream)
+        _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
+        _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+        ca = self._color_args(ws, training, cam_idx_for_embedding, embedding_ptr)
+        _call("nvo_nerfacto_color_fwd", stream, C.byref(ca))
+        return ca
+
+    def _color_args(self, ws, training, cam_idx, embedding_ptr):
+        km = len(self.prop_nets)
+        return _lib.ColorArgs(
+            R=ws["R"], S=self.levels[-1], sh=ws["sh"].data_ptr(), base_out=ws[f"out{km}"].data_ptr(),
+            embedding=embedding_ptr, cam_idx=None if cam_idx is None else cam_idx.data_ptr(),
+            weights=self._param_ptr("field.color", self.params_half).value, rgb=ws["rgb"].data_ptr(),
+            hidden=ws["color_hidden"].data_ptr() if training else None,
+            drgb=ws["drgb"].data_ptr() if training else None,
+            d_base_out=ws[f"dout{km}"].data_ptr() if training else None,
+            d_embedding=self._param_ptr("field.embedding", self.grads).value if training else None,
+            d_sh=None,
+            d_weights=self._param_ptr("field.color", self.grads).value if training else None)
+
+    def _main_loss_args(self, ws, training: bool, has_depth: bool):
+        cfg = self.cfg
+        km = len(self.prop_nets)
+        R, S = ws["R"], self.levels[-1]
+        inv_rays = 1.0 / (R * self.world_size)
+        n_levels = len(self.levels)
+        return _lib.MainLossArgs(
+            R=R, S=S, pre=ws[f"out{km}"].data_ptr(), pre_stride=16, rgb=ws["rgb"].data_ptr(), rgb_stride=16,
+            x01=ws[f"x{km}"].data_ptr(), sbins=ws[f"sbins{km}"].data_ptr(), tbins=ws[f"tbins{km}"].data_ptr(),
+            density_bias=cfg.density_bias, gt_rgb=ws["gt_rgb"].data_ptr() if training else None,
+            gt_depth=ws["gt_depth"].data_ptr() if (training and has_depth) else None,
+            directions_norm=ws["directions_norm"].data_ptr(), rgb_mult=cfg.rgb_loss_mult,
+            distortion_mult=cfg.distortion_loss_mult, depth_mult=cfg.depth_loss_mult if has_depth else 0.0,
+            depth_sigma=cfg.depth_sigma, inv_rays=inv_rays, depth_level_div=1.0 / n_levels,
+            loss_scale=cfg.loss_scale, out_rgb=ws["out_rgb"].data_ptr(), out_depth=ws["out_depth"].data_ptr(),
+            out_expected_depth=ws["out_expected_depth"].data_ptr(),
+            out_accumulation=ws["out_accumulation"].data_ptr(), weights=ws[f"weights{km}"].data_ptr(),
+            losses=self.losses.data_ptr() if training else None,
+            dpre=ws[f"dout{km}"].data_ptr() if training else None, dpre_stride=16,
+            drgb=ws["drgb"].data_ptr() if training else None, drgb_stride=16)
+
+    # ------------------------------------------------------------------------------------------
+    # schedules (nerfacto callbacks)
+    # ------------------------------------------------------------------------------------------
+    def anneal_at(self, step: int) -> float:
+        n = self.cfg.proposal_weights_anneal_max_num_iters
+        frac = min(max(step / n, 0.0), 1.0)
+        b = self.cfg.proposal_weights_anneal_slope
+        return b * frac / ((b - 1) * frac + 1)
+
+    def proposal_update_due(self, step: int) -> bool:
+        cfg = self.cfg
+        sched = min(max(step / cfg.proposal_warmup * cfg.proposal_update_every, 1.0), float(cfg.proposal_update_every))
+        return self.steps_since_proposal_update > sched or step < 10
+
+    def camera_lr(self, step: int) -> float:
+        """ExponentialDecayScheduler(lr_final=1e-5, max_steps=mapping_iterations) on camera_opt."""
+        cfg = self.cfg
+        t = min(max(step / max(cfg.max_num_iterations, 1), 0.0), 1.0)
+        return math.exp(math.log(cfg.lr_camera) * (1 - t) + math.log(cfg.lr_camera_final) * t)
+
+    # ------------------------------------------------------------------------------------------
+    # one optimisation step
+    # ------------------------------------------------------------------------------------------
+    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths, corrections=None):
+        """ray_indices [R,3] int64 (camera,y,x) -> origins/directions/cam idx + gathered targets."""
+        stream = _stream(self.device)
+        R = ws["R"]
+        H, W = images.shape[1], images.shape[2]
+        _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corrections),
+              _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]),
+              _ptr(ws["cam_idx"]))
+        _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
+        if depths is not None:
+            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 1, _ptr(depths), _ptr(ws["gt_depth"]))
+
+    def load_ray_bundle(self, ws, origins, directions, directions_norm, cam_idx, gt_rgb=None, gt_depth=None):
+        """Inject an existing ray bundle (+ targets) instead of generating rays from pixel indices."""
+        ws["origins"].copy_(origins)
+        ws["directions"].copy_(directions)
+        ws["directions_norm"].copy_(directions_norm.reshape(-1))
+        ws["cam_idx"].copy_(cam_idx.reshape(-1).to(torch.int32))
+        if gt_rgb is not None:
+            ws["gt_rgb"].copy_(gt_rgb)
+        if gt_depth is not None:
+            ws["gt_depth"].copy_(gt_depth.reshape(-1))
+
+    def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
+                         anneal: float | None = None):
+        """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
+        loss_scale) and self.losses; does NOT touch the parameters."""
+        cfg = self.cfg
+        stream = _stream(self.device)
+        step = self.step
+        if anneal is None:
+            anneal = self.anneal_at(step)
+        if update_proposals is None:
+            update_proposals = self.proposal_update_due(step)
+        self.grads.zero_()
+        self.losses.zero_()
+        emb_ptr = self._param_ptr("field.embedding", self.params_half).value
+        ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream)
+        km = len(self.prop_nets)
+        R = ws["R"]
+        la = self._main_loss_args(ws, True, has_depth)
+        _call("nvo_main_render_loss", stream, C.byref(la))
+        _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
+        _call("nvo_bwd", self.base_net.handle, stream, R * self.levels[km], _ptr(ws[f"x{km}"]),
+              self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
+              _ptr(ws[f"ctx{km}"]), None, self._param_ptr("field.base", self.grads))
+        if update_proposals:
+            inv_rays = 1.0 / (R * self.world_size)
+            for k, net in enumerate(self.prop_nets):
+                pa = _lib.PropLossArgs(
+                    R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=16,
+                    x01=ws[f"x{k}"].data_ptr(), sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(),
+                    sbins_main=ws[f"sbins{km}"].data_ptr(), weights_main=ws[f"weights{km}"].data_ptr(),
+                    density_bias=cfg.density_bias, gt_depth=ws["gt_depth"].data_ptr() if has_depth else None,
+                    directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
+                    depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
+                    inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
+                    losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=16)
+                _call("nvo_prop_loss", stream, C.byref(pa))
+                _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
+                      self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
+                      _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), None,
+                      self._param_ptr(f"proposal.{k}", self.grads))
+        return update_proposals
+
+    def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt")) -> None:
+        cfg = self.cfg
+        stream = _stream(self.device)
+        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), _ptr(self.skip_flag))
+        lrs = {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal, "camera_opt": self.camera_lr(self.step)}
+        for g in groups:
+            if g == "camera_opt" and not cfg.optimize_poses:
+                continue
+            lo, hi = self.group_ranges[g]
+            self.opt_steps[g] += 1
+            esz = 4
+            _call("nvo_adam_step", stream, hi - lo, C.c_void_p(self.params.data_ptr() + lo * esz),
+                  C.c_void_p(self.params_half.data_ptr() + lo * 2), C.c_void_p(self.grads.data_ptr() + lo * esz),
+                  C.c_void_p(self.exp_avg.data_ptr() + lo * esz), C.c_void_p(self.exp_avg_sq.data_ptr() + lo * esz),
+                  lrs[g], cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_steps[g],
+                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
+
+    def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None):
+        """One full iteration.  ``all_reduce``: optional callable(flat_grad_tensor) for multi-GPU."""
+        R = ray_indices.shape[0]
+        ws = self._workspace(R, True)
+        if jitters is None:
+            jitters = tuple(torch.rand(R, device=self.device) for _ in range(3))
+        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
+        updated = self.forward_backward(ws, jitters, has_depth=depths is not None)
+        if all_reduce is not None:
+            all_reduce(self.grads)
+        groups = ["fields"] + (["proposal_networks"] if updated else []) + ["camera_opt"]
+        self.optimizer_step(groups)
+        if updated:
+            self.steps_since_proposal_update = 0
+        self.steps_since_proposal_update += 1
+        self.step += 1
+        return updated
+
+    def loss_dict(self) -> dict:
+        vals = self.losses.tolist()
+        d = {"rgb_loss": vals[0], "distortion_loss": vals[1], "depth_loss": vals[2] + vals[4],
+             "interlevel_loss": vals[3]}
+        return d
+
+    # ------------------------------------------------------------------------------------------
+    # inference
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render_rays(self, origins, directions, directions_norm, mean_embedding_half=None):
+        """Eval forward for R rays (R*48 multiple of 16): rgb [R,3] clamped to [0,1], median depth,
+        expected depth, accumulation.  Uses un-jittered bins and the mean appearance embedding
+        (nerfacto use_average_appearance_embedding=True)."""
+        R = origins.shape[0]
+        ws = self._workspace(R, False)
+        ws["origins"].copy_(origins)
+        ws["directions"].copy_(directions)
+        ws["directions_norm"].copy_(directions_norm.reshape(-1))
+        stream = _stream(self.device)
+        if mean_embedding_half is None:
+            emb = self.view("field.embedding").view(self.cfg.num_images, -1)
+            mean_embedding_half = emb.mean(dim=0, keepdim=True).to(torch.float16).contiguous()
+        self._forward(ws, False, 1.0, None, None, mean_embedding_half.data_ptr(), stream)
+        la = self._main_loss_args(ws, False, False)
+        _call("nvo_main_render_loss", stream, C.byref(la))
+        return {"rgb": ws["out_rgb"].clamp(0.0, 1.0), "depth": ws["out_depth"].clone()[:, None],
+                "expected_depth": ws["out_expected_depth"].clone()[:, None],
+                "accumulation": ws["out_accumulation"].clone()[:, None]}
