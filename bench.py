@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the mapping hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE full depth-nerfacto training iteration as NeRF-VO's mapping runs it
+(/root/reference/nerf_vo/mapping/nerfstudio.py:151): pixel sampling -> rays -> proposal sampling
+(256 -> 96 -> 48) -> hash grid + fused MLPs -> compositing + rgb/interlevel/distortion/depth losses
+-> backward -> Adam, on 4096 rays per GPU drawn from a resident synthetic Replica-shaped buffer of
+192 keyframes at 640x480 (BASELINE.json configs[1], fixed poses).  Metric: training ray-samples/s =
+main-field samples whose forward+backward+optimiser update completed per second, whole job.
+Rays shard across ranks (weak scaling); the only exchange is one RCCL all-reduce of the flat
+gradient buffer per step.
+
+Extra JSON objects: "roofline" (dominant kernel, live HIP-event timing) and "cpu_baseline" (the
+torch-CPU oracle of the same step on a bounded sample, rank 0 / N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
+    """ALGORITHMIC bytes one launch of the named kernel moves (DESIGN.md section 'Kernels'; per-unit
+    figures follow SURVEY.md section 8d)."""
+    S = {"L16": cfg.num_nerf_samples}
+    n_main = R * cfg.num_nerf_samples
+    n_p0 = R * cfg.num_proposal_samples[0]
+    n_p1 = R * cfg.num_proposal_samples[1]
+    # per sample: 8 corners x F=2 x fp16 per level gathered (+ x 12 B in, 4 B/level out)
+    if name == "grid_fwd[L16]":
+        return n_main * (16 * 8 * 4 + 12 + 16 * 4)
+    if name == "grid_fwd[L5]":
+        return (n_p0 + n_p1) / 2 * (5 * 8 * 4 + 12 + 5 * 4)
+    if name == "grid_bwd_lds[L16]" or name == "grid_bwd_atomic[L16]":
+        # read-modify-write of every touched fp32 corner pair + x + d(encoded) fp16
+        return n_main * (16 * 8 * 8 * 2 + 12 + 16 * 4)
+    if name == "mlp_bwd[64-64x2-16]":
+        # drgb, rgb, 2 hidden, base_out in; d_base_out out (fp16 rows)
+        return n_main * 2 * (16 + 16 + 128 + 16 + 16)
+    if name == "mlp_fwd[64-64x2-16]":
+        return n_main * 2 * (16 + 128 + 16)
+    if name == "mlp_bwd[32-64x1-16]":
+        return n_main * 2 * (16 + 16 + 64 + 32 + 32)
+    if name == "mlp_fwd[32-64x1-16]":
+        return n_main * 2 * (32 + 64 + 16)
+    if name == "adam":
+        return None  # several launches of different sizes: priced from the parameter count below
+    return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--keyframes", type=int, default=192)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--cpu-baseline-rays", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid-bwd-mode", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=device)
+        dist = dist_mod
+
+    import __graft_entry__ as entry
+
+    if rank == 0:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataManager, DynamicDataManagerConfig, opencv_to_opengl
+    from nerf_vo_amd.parallel import GradientAllReduce
+    from nerf_vo_amd.synthetic import make_sequence
+
+    torch.manual_seed(42 + rank)
+    # ---- resident synthetic keyframe buffer (ingested through the same path the mapper uses)
+    dm = DynamicDataManagerConfig(train_num_rays_per_batch=args.rays, num_frames=args.keyframes,
+                                  frame_height=args.height, frame_width=args.width, use_normals=False).setup(
+        device=device, world_size=world, local_rank=rank)
+    chunk = 24
+    # (render the sequence once, ingest in tracker-sized chunks)
+    seq = make_sequence(args.keyframes, args.height, args.width, device=device)
+    for lo in range(0, args.keyframes, chunk):
+        hi = min(args.keyframes, lo + chunk)
+        dm.train_dataset.update({
+            "keyframe_indices": torch.arange(lo, hi),
+            "camera_intrinsics": seq["camera_intrinsics"][lo:hi],
+            "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"][lo:hi]),
+            "frames_color": seq["frames_color"][lo:hi], "frames_depth": seq["frames_depth"][lo:hi]})
+    del seq
+    ds = dm.train_dataset
+    assert ds.num_active_frames == args.keyframes
+
+    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, grid_bwd_mode=args.grid_bwd_mode)
+    engine = NerfactoEngine(cfg, device, world_size=world)
+    reducer = GradientAllReduce(dist) if dist is not None else None
+    if dist is not None:  # identical initial parameters on every rank
+        dist.broadcast(engine.params, src=0)
+        engine.sync_half()
+    intr = ds.camera_intrinsics
+    c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+
+    def step():
+        ray_indices, _ = dm.next_train(engine.step)
+        engine.train_step(ray_indices, intr, c2w, ds.frames_color, ds.frames_depth, all_reduce=reducer)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    samples_per_step = args.rays * cfg.num_nerf_samples * world
+    value = samples_per_step / (elapsed / args.steps)
+    losses = engine.loss_dict()
+
+    # ---- roofline: same K steps again with per-launch HIP events on the launch stream
+    roofline = None
+    kernel_table = []
+    lib = _lib.lib()
+    prof_steps = min(args.steps, 50)
+    if rank == 0:
+        lib.nvo_profile_enable(1)
+    fence()
+    tp0 = time.perf_counter()
+    for _ in range(prof_steps):  # every rank runs them (the all-reduce is collective)
+        step()
+    fence()
+    ms_prof = (time.perf_counter() - tp0) / prof_steps * 1e3
+    if rank == 0:
+        need = lib.nvo_profile_summary(None, 0)
+        buf = C.create_string_buffer(int(need) + 16)
+        lib.nvo_profile_summary(buf, len(buf))
+        lib.nvo_profile_enable(0)
+        for line in buf.value.decode().strip().splitlines():
+            name, cnt, total = line.rsplit(",", 2)
+            kernel_table.append((name, int(cnt), float(total)))
+        kernel_table.sort(key=lambda r: -r[2])
+        tot = sum(r[2] for r in kernel_table)
+        sys.stderr.write(f"[bench] per-kernel device time over {prof_steps} profiled steps "
+                         f"({ms_prof:.3f} ms/step wall, {tot / prof_steps:.3f} ms/step in kernels):\n")
+        for name, cnt, total in kernel_table:
+            sys.stderr.write(f"[bench]   {name:28s} launches {cnt:5d}  avg {total / cnt * 1e3:9.1f} us  "
+                             f"{100 * total / tot:5.1f} %\n")
+        for name, cnt, total in kernel_table:  # dominant kernel with a byte model
+            b = algorithmic_bytes(name, cfg, args.rays)
+            if b is None:
+                continue
+            avg_s = total / cnt * 1e-3
+            achieved = b / avg_s / 1e9
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
+                        "share_of_step_kernel_time": round(total / tot, 4)}
+            break
+    if dist is not None:
+        dist.barrier()
+
+    # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.bench_cpu import time_cpu_step
+
+        cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)
+
+    if rank == 0:
+        out = {
+            "metric": "training ray-samples/sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Replica-shaped full mapping step, depth-nerfacto "
+                                   "(proposal sampling 256/96/48), fixed poses",
+                       "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
+                       "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
+                       "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
+                       "grid_bwd": "lds" if args.grid_bwd_mode == 1 else "atomic",
+                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
+            "rays_per_sec": args.rays * world / (elapsed / args.steps),
+            "final_losses": losses,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

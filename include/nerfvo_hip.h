@@ -41,6 +41,12 @@ typedef void* nvo_stream_t; /* hipStream_t */
 
 const char* nvo_last_error(void);
 int nvo_version(void);
+/* Per-launch device timing with HIP events recorded on the stream each kernel is enqueued on
+ * (used by bench.py for the roofline numbers).  enable(1) clears previous records and starts
+ * recording, enable(0) stops.  summary() waits for the recorded events and writes
+ * "name,launches,total_ms\n" lines; returns the number of bytes the full text needs. */
+int nvo_profile_enable(int on);
+int64_t nvo_profile_summary(char* buf, uint64_t buf_size);
 
 /* ------------------------------------------------------------------------------------------------
  * A. tiny-cuda-nn module boundary (tcnn bindings/torch: Module::fwd / bwd / initial_params /

@@ -59,6 +59,8 @@ class ColorArgs(C.Structure):
 _SIGNATURES = {
     "nvo_last_error": (C.c_char_p, []),
     "nvo_version": (_int, []),
+    "nvo_profile_enable": (_int, [_int]),
+    "nvo_profile_summary": (_i64, [C.c_char_p, _u64]),
     "nvo_create_encoding": (_int, [_u32, C.c_char_p, C.POINTER(_p)]),
     "nvo_create_network": (_int, [_u32, _u32, C.c_char_p, C.POINTER(_p)]),
     "nvo_create_network_with_input_encoding": (_int, [_u32, _u32, C.c_char_p, C.c_char_p, C.POINTER(_p)]),

@@ -62,6 +62,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: NULL argument");
     NVO_REQUIRE(step >= 1, "adam_step: step counts from 1");
     if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "adam");
     const float bias1 = 1.f - powf(beta1, (float)step);
     const float bias2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     uint32_t blocks = nvo_div_up(n, 256 * 4);
@@ -75,6 +76,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
 
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag) {
     NVO_REQUIRE(grads && flag, "nonfinite_flag: NULL argument");
+    NVO_PROF(stream, "nonfinite_flag");
     NVO_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), (hipStream_t)stream));
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
@@ -87,6 +89,7 @@ int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half) {
     NVO_REQUIRE(src && dst_half, "cast_half: NULL argument");
     if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "cast_half");
     uint32_t blocks = nvo_div_up(n, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_cast_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src,

@@ -29,6 +29,94 @@ extern "C" const char* nvo_last_error(void) { return g_err; }
 extern "C" int nvo_version(void) { return 100; }
 
 // ---------------------------------------------------------------------------------------------
+// per-launch HIP-event profiler: events are recorded on the stream each launcher enqueues on, so
+// the elapsed time is that kernel's (plus its memsets') device time, not host time.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    char name[56];
+    hipEvent_t a, b;
+    bool closed;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool nvo_prof_enabled() { return g_prof_on; }
+
+void nvo_prof_begin(hipStream_t s, const char* fmt, ...) {
+    ProfRec r;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(r.name, sizeof(r.name), fmt, ap);
+    va_end(ap);
+    r.a = prof_event();
+    r.b = prof_event();
+    r.closed = false;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+
+void nvo_prof_end(hipStream_t s) {
+    for (size_t i = g_prof.size(); i-- > 0;) {
+        if (!g_prof[i].closed) {
+            (void)hipEventRecord(g_prof[i].b, s);
+            g_prof[i].closed = true;
+            return;
+        }
+    }
+}
+
+extern "C" int nvo_profile_enable(int on) {
+    for (auto& r : g_prof) {
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return NVO_OK;
+}
+
+// Writes "name,launches,total_ms\n" lines (aggregated by name) into buf; returns bytes needed.
+extern "C" int64_t nvo_profile_summary(char* buf, uint64_t buf_size) {
+    std::map<std::string, std::pair<uint64_t, double>> agg;
+    for (auto& r : g_prof) {
+        if (!r.closed) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        auto& e = agg[r.name];
+        e.first += 1;
+        e.second += ms;
+    }
+    std::string out;
+    char line[160];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s,%llu,%.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first,
+                 kv.second.second);
+        out += line;
+    }
+    if (buf && buf_size > 0) {
+        const size_t n = out.size() < buf_size - 1 ? out.size() : buf_size - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // minimal flat JSON object reader (strings, numbers, booleans; nested values are skipped)
 // ---------------------------------------------------------------------------------------------
 namespace {

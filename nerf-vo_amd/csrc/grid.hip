@@ -16,15 +16,19 @@
 //  * Parameter gradients accumulate in fp32 (tcnn: fp16 atomics for F=2).  Two kernels:
 //      - k_grid_bwd_atomic: global float atomics, lane pairs adjacent on one corner (8 B) so a
 //        wave instruction touches 32 distinct 64-B lines, not 64.
-//      - k_grid_bwd_lds:    "slice owner" scatter -- each workgroup owns a 16K-entry slice of one
-//        level's table in LDS (128 KiB of the CU's 160 KiB), re-derives every sample's corner
-//        indices, accumulates hits with LDS atomics and writes the slice back with plain
+//      - k_grid_bwd_lds:    "slice owner" scatter -- each workgroup owns a slice of one level's
+//        table in LDS (up to all 160 KiB of the CU), re-derives every sample's corner indices,
+//        accumulates hits with LDS atomics (64-bit fixed point where slices are hit often: LDS
+//        integer atomics run 14x the rate of LDS float atomics on gfx950) and writes the slice back with plain
 //        coalesced stores.  Global atomics on random rows run at ~0.08 TB/s on MI355X
 //        (MI355X_MICROARCH.md, Global float atomics); this path uses none.
 #include "nvo_kernels.h"
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_features,
                               uint32_t log2_hashmap_size, uint32_t base_resolution,
@@ -202,67 +206,168 @@ k_grid_bwd_atomic(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 // backward w.r.t. parameters, LDS slice-owner form (no global atomics)
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSliceEntries = 16384;             // 16K entries * 2 floats * 4 B = 128 KiB
+// Two accumulator kinds share one kernel; the host picks one PER LEVEL from the expected hit rate:
+//  * FIXED  -- 64-bit fixed point, 8K-entry slices (128 KiB).  LDS integer atomics retire 4.6 lanes
+//              per clock per CU on MI355X, LDS float atomics 0.33 (lane-serialised; measured with
+//              tools/probes/lds_atomic_probe.hip), so every level whose slices are hit often (dense
+//              levels, small hash tables) accumulates in integers.  Scale 2^26: resolution 1.5e-8 on
+//              the loss-scaled gradient (finer than the fp16 subnormal step tcnn's fp16 accumulation
+//              flushes at), range +-1.4e11.  Integer adds are associative, so a single-chunk item's
+//              result is bitwise reproducible.
+//  * FLOAT  -- fp32, 20K-entry slices (160 KiB = the whole LDS of a CU).  For 2^19-entry hashed
+//              levels a slice receives ~1/26 of the lookups, the kernel is bound by re-deriving the
+//              corner hashes for every (sample, slice) pair, and fewer/larger slices win.
+constexpr uint32_t kSliceFixed = 8192;
+constexpr uint32_t kSliceFloat = 20480;
+constexpr uint32_t kLdsBwdBytes = 160 * 1024;
 constexpr int kLdsBwdBlock = 1024;
+constexpr float kFixScale = 67108864.f;          // 2^26
+constexpr float kFixInv = 1.0f / 67108864.f;
 
-template <bool SOA, typename DY2>
-__global__ void __launch_bounds__(kLdsBwdBlock)
-k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
-               const DY2* __restrict__ dy, float* __restrict__ grad,
-               const uint32_t* __restrict__ slice_level, const uint32_t* __restrict__ slice_first,
-               uint32_t n_chunks) {
-    // blockIdx.x = slice id (level, first entry), blockIdx.y = sample chunk.  n_chunks == 1 ->
-    // plain stores; n_chunks > 1 -> every chunk adds its slice with contiguous (256-B shaped)
-    // float atomics, which run at the full ~1.3 TB/s rate.
-    extern __shared__ float acc[];  // [kSliceEntries][2]
-    const uint32_t level = slice_level[blockIdx.x];
-    const uint32_t first = slice_first[blockIdx.x];
+// float -> 2^26 fixed point through the double "magic number" trick: (double)v * 2^26 + 1.5 * 2^52
+// leaves round-to-nearest(v * 2^26) in the low mantissa bits, so one cvt + one f64 fma + a 64-bit
+// subtract replace the ~20-instruction software float->int64 conversion.  Valid for |v| < 2^25.
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+    const double magic = 6755399441055744.0;  // 1.5 * 2^52
+    const double t = fma((double)v, (double)kFixScale, magic);
+    return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
+}
+
+struct AccFixed {
+    typedef unsigned long long T;
+    static constexpr uint32_t kEntries = kSliceFixed;
+    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1) {
+        atomicAdd(&acc[2 * rel + 0], to_fixed(v0));
+        atomicAdd(&acc[2 * rel + 1], to_fixed(v1));
+    }
+    static __device__ __forceinline__ float get(const T* acc, uint32_t e) { return (float)(long long)acc[e] * kFixInv; }
+};
+struct AccFloat {
+    typedef float T;
+    static constexpr uint32_t kEntries = kSliceFloat;
+    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1) {
+        atomicAdd(&acc[2 * rel + 0], v0);
+        atomicAdd(&acc[2 * rel + 1], v1);
+    }
+    static __device__ __forceinline__ float get(const T* acc, uint32_t e) { return acc[e]; }
+};
+
+// One workgroup per WORK ITEM = (level, slice, sample chunk).  A slice of a large hashed level is
+// hit by a small share of all corner lookups and gets one item that scans every sample and writes
+// its slice with plain stores.  A slice that is hit often (dense levels, small tables) is split into
+// sample chunks of equal expected hit count (table built on the host from the hit share alone,
+// independent of N); chunked items flush with row-contiguous float atomics (256-B shaped, the fast
+// form) into a pre-zeroed range.
+template <typename ACC, bool SOA, typename DY2>
+__device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N,
+                                              const float* __restrict__ x, const DY2* __restrict__ dy,
+                                              float* __restrict__ grad, uint32_t level, uint32_t first,
+                                              uint32_t chunk, uint32_t n_chunks, void* lds_raw) {
+    typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
     const uint32_t res = g.resolution[level];
     const uint32_t hashed = g.hashed[level];
     const float scale = g.scale[level];
-    const uint32_t count = min(kSliceEntries, size - first);
+    const uint32_t count = min(ACC::kEntries, size - first);
 
-    for (uint32_t e = threadIdx.x; e < 2 * kSliceEntries; e += kLdsBwdBlock) acc[e] = 0.f;
+    for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) acc[e] = (typename ACC::T)0;
     __syncthreads();
 
     const uint32_t per_chunk = (N + n_chunks - 1) / n_chunks;
-    const uint32_t begin = blockIdx.y * per_chunk;
+    const uint32_t begin = chunk * per_chunk;
     const uint32_t end = min(N, begin + per_chunk);
-    for (uint32_t i = begin + threadIdx.x; i < end; i += kLdsBwdBlock) {
-        const Corner c = grid_cell(scale, x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
-                                   x[3 * (size_t)i + 2]);
-        const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-        float2 d;
-        if constexpr (sizeof(DY2) == 4) {
-            d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-        } else {
-            d = *reinterpret_cast<const float2*>(&d2);
-        }
-        if (d.x == 0.f && d.y == 0.f) continue;
+    // Samples are taken kUnroll at a time per thread with all of their loads issued up front: the
+    // loop is otherwise one dependent L2 round trip per sample.
+    constexpr uint32_t kUnroll = 4;
+    const uint32_t mask = size - 1u;
+    for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
+        float2 dv[kUnroll];
+        float xv[kUnroll][3];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u),
-                                                c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
-            const uint32_t rel = idx - first;  // unsigned wrap -> huge when idx < first
-            if (rel < count) {
-                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                                ((k & 4u) ? c.wz : 1.f - c.wz);
-                atomicAdd(&acc[2 * rel + 0], w * d.x);
-                atomicAdd(&acc[2 * rel + 1], w * d.y);
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t i = i0 + u * kLdsBwdBlock;
+            dv[u] = make_float2(0.f, 0.f);
+            xv[u][0] = xv[u][1] = xv[u][2] = 0.f;
+            if (i < end) {
+                const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+                if constexpr (sizeof(DY2) == 4) {
+                    dv[u] = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+                } else {
+                    dv[u] = *reinterpret_cast<const float2*>(&d2);
+                }
+                xv[u][0] = x[3 * (size_t)i + 0];
+                xv[u][1] = x[3 * (size_t)i + 1];
+                xv[u][2] = x[3 * (size_t)i + 2];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const float2 d = dv[u];
+            if (d.x == 0.f && d.y == 0.f) continue;
+            const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
+            if (hashed) {
+                // two integer multiplies per sample, the 8 corner hashes are xor combinations;
+                // corners are then visited through a per-lane hit mask
+                const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
+                const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
+                const uint32_t x0 = c.px, x1 = c.px + 1u;
+                const uint32_t a00 = hy0 ^ hz0, a10 = hy1 ^ hz0, a01 = hy0 ^ hz1, a11 = hy1 ^ hz1;
+                uint32_t hits = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t idx = (((k & 1u) ? x1 : x0) ^
+                                          ((k & 4u) ? ((k & 2u) ? a11 : a01) : ((k & 2u) ? a10 : a00))) & mask;
+                    hits |= ((idx - first) < count ? 1u : 0u) << k;
+                }
+                while (hits) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(hits);
+                    hits &= hits - 1u;
+                    const uint32_t idx = (((k & 1u) ? x1 : x0) ^
+                                          ((k & 4u) ? ((k & 2u) ? a11 : a01) : ((k & 2u) ? a10 : a00))) & mask;
+                    const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                    ((k & 4u) ? c.wz : 1.f - c.wz);
+                    ACC::add(acc, idx - first, w * d.x, w * d.y);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u),
+                                                        c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+                    const uint32_t rel = idx - first;  // unsigned wrap -> huge when idx < first
+                    if (rel < count) {
+                        const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                        ((k & 4u) ? c.wz : 1.f - c.wz);
+                        ACC::add(acc, rel, w * d.x, w * d.y);
+                    }
+                }
             }
         }
     }
     __syncthreads();
     float* __restrict__ gr = grad + 2 * ((size_t)off + first);
     if (n_chunks == 1) {
-        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = acc[e];
+        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = ACC::get(acc, e);
     } else {
         for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) {
-            const float v = acc[e];
+            const float v = ACC::get(acc, e);
             if (v != 0.f) atomicAdd(gr + e, v);
         }
+    }
+}
+
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(kLdsBwdBlock)
+k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
+               const DY2* __restrict__ dy, float* __restrict__ grad,
+               const uint4* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | float-mode flag}
+    const uint32_t n_chunks = item.w & 0x7FFFFFFFu;
+    if (item.w >> 31) {
+        grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
+    } else {
+        grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
     }
 }
 
@@ -329,6 +434,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
+    NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
     if (soa) {
@@ -345,25 +451,62 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 // Slice tables for the LDS backward live in a small device buffer owned by the module.
 
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
-    uint32_t n = 0;
-    for (uint32_t l = 0; l < g.n_levels; ++l)
-        n += nvo_div_up(g.offset[l + 1] - g.offset[l], kSliceEntries);
-    uint32_t* h = (uint32_t*)malloc(sizeof(uint32_t) * 2 * n);
-    uint32_t j = 0;
-    // Largest slices (fine, hashed levels) first so the tail of the launch is the cheap work.
+    struct Item { uint32_t level, first, chunk, n_chunks; };
+    // Per level: accumulator kind and slice size.  Large hashed tables (>= 2^18 entries: a 20K-entry
+    // slice sees <= 8 % of the lookups) use fp32 / 20K-entry slices, everything else 64-bit fixed
+    // point / 8K-entry slices.  NVO_GRID_BWD_ACC = "fixed" | "float" forces one kind (experiments).
+    const char* force = getenv("NVO_GRID_BWD_ACC");
+    auto float_mode = [&](uint32_t l) {
+        if (force && !strcmp(force, "fixed")) return false;
+        if (force && !strcmp(force, "float")) return true;
+        return g.hashed[l] && (g.offset[l + 1] - g.offset[l]) >= (1u << 18);
+    };
+    // pass 1: chunk counts from the hit share alone (unit = share of one float slice of a 2^19
+    // table); pass 2: scale them so that the launch has enough (>= target) items to fill 256 CUs
+    // for several rounds.
+    uint32_t target = 1024;
+    if (const char* env = getenv("NVO_GRID_BWD_ITEMS")) target = (uint32_t)atoi(env);
+    auto base_chunks = [&](uint32_t count, uint32_t size) {
+        const double share = (double)count / (double)size * (524288.0 / (double)kSliceFloat);
+        uint32_t n = (uint32_t)(share + 0.5);
+        return n < 1 ? 1u : n;
+    };
+    uint32_t base_total = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
+        const uint32_t size = g.offset[l + 1] - g.offset[l];
+        const uint32_t se = float_mode(l) ? kSliceFloat : kSliceFixed;
+        for (uint32_t f = 0; f < size; f += se) base_total += base_chunks(size - f < se ? size - f : se, size);
+    }
+    const uint32_t factor = base_total >= target ? 1u : (target + base_total - 1) / base_total;
+    // Most expensive first: single-chunk items scan all N samples (long), chunked items scan
+    // N / n_chunks samples with a high hit rate (short but atomic-heavy).
+    std::vector<Item> single, chunked;
     for (int l = (int)g.n_levels - 1; l >= 0; --l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
-        for (uint32_t f = 0; f < size; f += kSliceEntries) {
-            h[j] = (uint32_t)l;
-            h[n + j] = f;
-            ++j;
+        const bool fm = float_mode((uint32_t)l);
+        const uint32_t se = fm ? kSliceFloat : kSliceFixed;
+        for (uint32_t f = 0; f < size; f += se) {
+            const uint32_t count = size - f < se ? size - f : se;
+            uint32_t n_chunks = base_chunks(count, size) * factor;
+            if (n_chunks > 1024) n_chunks = 1024;
+            for (uint32_t c = 0; c < n_chunks; ++c)
+                (n_chunks == 1 ? single : chunked).push_back(Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u)});
         }
     }
-    s->n_slices = n;
-    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(uint32_t) * 2 * n));
-    s->d_first = s->d_level + n;
-    NVO_CHECK_HIP(hipMemcpy(s->d_level, h, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice));
-    free(h);
+    std::vector<Item> all(single);
+    all.insert(all.end(), chunked.begin(), chunked.end());
+    s->n_slices = (uint32_t)all.size();
+    // contiguous run of entries owned by chunked items (needs zeroing before the atomic flush)
+    s->zero_first = 0xFFFFFFFFu;
+    s->zero_last = 0;
+    for (const Item& it : chunked) {
+        const uint32_t lo = g.offset[it.level], hi = g.offset[it.level + 1];
+        if (lo < s->zero_first) s->zero_first = lo;
+        if (hi > s->zero_last) s->zero_last = hi;
+    }
+    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size()));
+    s->d_first = nullptr;
+    NVO_CHECK_HIP(hipMemcpy(s->d_level, all.data(), sizeof(Item) * all.size(), hipMemcpyHostToDevice));
     return NVO_OK;
 }
 
@@ -378,19 +521,21 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                         uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
                         float* grad, int mode) {
     const size_t grad_bytes = sizeof(float) * 2 * (size_t)g.offset[g.n_levels];
+    NVO_PROF(stream, "grid_bwd_%s[L%u]", (mode == 1 && slices && slices->n_slices) ? "lds" : "atomic", g.n_levels);
     if (N == 0) {
         NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
         return NVO_OK;
     }
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     if (mode == 1 && slices && slices->n_slices) {
-        // enough sample chunks to put >= ~2 workgroups' worth of waves on every CU
-        uint32_t n_chunks = 1;
-        while (slices->n_slices * n_chunks < 256u && n_chunks < 64u && (N / (n_chunks * 2)) >= 8192u)
-            n_chunks *= 2;
-        if (n_chunks > 1) NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
-        const dim3 grid(slices->n_slices, n_chunks), block(kLdsBwdBlock);
-        const size_t lds = sizeof(float) * 2 * kSliceEntries;
+        if (slices->zero_last > slices->zero_first) {
+            // chunked (atomically flushed) levels form one contiguous run of entries
+            NVO_CHECK_HIP(hipMemsetAsync(grad + 2 * (size_t)slices->zero_first, 0,
+                                         sizeof(float) * 2 * (size_t)(slices->zero_last - slices->zero_first),
+                                         stream));
+        }
+        const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
+        const size_t lds = kLdsBwdBytes;
 #define NVO_LAUNCH_LDS(SOA_, T_)                                                              \
     do {                                                                                      \
         static bool attr_set = false; /* >64 KiB of dynamic LDS needs an explicit opt-in */   \
@@ -401,7 +546,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         hipLaunchKernelGGL((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, slices->d_level, slices->d_first, n_chunks);  \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level);               \
     } while (0)
         if (soa) {
             if (dy_is_float) NVO_LAUNCH_LDS(true, float2); else NVO_LAUNCH_LDS(true, __half2);
@@ -432,6 +577,7 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
                               const float* x, const void* table_half, const void* dy,
                               bool dy_is_float, bool soa, float* dx, bool zero_dx) {
     if (N == 0) return NVO_OK;
+    NVO_PROF(stream, "grid_bwd_input[L%u]", g.n_levels);
     if (zero_dx) NVO_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * 3 * (size_t)N, stream));
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);

@@ -537,6 +537,7 @@ k_mlp_bwd(NvoMlpArgs a) {
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
 int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    NVO_PROF(stream, "mlp_fwd[%d-%dx%d-%d]", IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -548,6 +549,7 @@ int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
 int launch_bwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    NVO_PROF(stream, "mlp_bwd[%d-%dx%d-%d]", IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;

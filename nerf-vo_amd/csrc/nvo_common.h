@@ -38,6 +38,23 @@ void nvo_set_error(const char* fmt, ...);
 
 #define NVO_CHECK_LAUNCH() NVO_CHECK_HIP(hipGetLastError())
 
+// ---- optional per-launch HIP-event profiler (off by default; see nvo_profile_enable) ----------
+bool nvo_prof_enabled();
+void nvo_prof_begin(hipStream_t s, const char* fmt, ...);
+void nvo_prof_end(hipStream_t s);
+struct NvoProfScope {
+    hipStream_t s;
+    bool on;
+    explicit NvoProfScope(hipStream_t s_) : s(s_), on(nvo_prof_enabled()) {}
+    ~NvoProfScope() {
+        if (on) nvo_prof_end(s);
+    }
+};
+// Brackets everything the enclosing launcher enqueues with a pair of events on ITS stream.
+#define NVO_PROF(stream, ...)                                   \
+    NvoProfScope nvo_prof_scope__((hipStream_t)(stream));       \
+    if (nvo_prof_scope__.on) nvo_prof_begin((hipStream_t)(stream), __VA_ARGS__)
+
 static inline uint32_t nvo_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline uint64_t nvo_round_up(uint64_t a, uint64_t b) { return ((a + b - 1) / b) * b; }
 

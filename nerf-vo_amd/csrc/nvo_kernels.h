@@ -5,8 +5,9 @@
 // ---- grid.hip -------------------------------------------------------------------------------
 struct NvoGridSlices {
     uint32_t n_slices = 0;
-    uint32_t* d_level = nullptr;
+    uint32_t* d_level = nullptr;   // device array of uint4 work items {level, first, chunk, n_chunks}
     uint32_t* d_first = nullptr;
+    uint32_t zero_first = 0, zero_last = 0;  // entry range flushed with atomics (zeroed per launch)
 };
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s);
 void nvo_grid_slices_destroy(NvoGridSlices* s);

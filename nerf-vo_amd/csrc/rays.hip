@@ -154,6 +154,7 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
     NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && origins && directions &&
                            directions_norm && cam_idx), "raygen: NULL argument");
     if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "raygen");
     hipLaunchKernelGGL(k_raygen, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R,
                        ray_indices, intrinsics, c2w, corrections, origins, directions, directions_norm,
                        pixel_area, cam_idx);
@@ -165,6 +166,7 @@ int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
                       uint32_t W, uint32_t Cn, const float* images, float* out) {
     NVO_REQUIRE(R == 0 || (ray_indices && images && out && Cn >= 1), "gather_pixels: NULL argument");
     if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "gather_pixels");
     hipLaunchKernelGGL(k_gather_pixels, dim3(nvo_div_up((uint64_t)R * Cn, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, ray_indices, H, W, Cn, images, out);
     NVO_CHECK_LAUNCH();
@@ -175,6 +177,7 @@ int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_p
                        const float* jitter, float* sbins, float* tbins) {
     NVO_REQUIRE(S >= 1 && (R == 0 || (sbins && tbins)), "sample_lindisp: bad argument");
     if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "sample_lindisp");
     hipLaunchKernelGGL(k_sample_lindisp, dim3(nvo_div_up((uint64_t)R * (S + 1), 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, near_plane, far_plane, jitter, sbins, tbins);
     NVO_CHECK_LAUNCH();
@@ -185,6 +188,7 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
                          const float* directions, const float* tbins, float* x01) {
     NVO_REQUIRE(S >= 1 && (R == 0 || (origins && directions && tbins && x01)), "sample_positions: bad argument");
     if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "sample_positions[S%u]", S);
     hipLaunchKernelGGL(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, origins, directions, tbins, x01);
     NVO_CHECK_LAUNCH();
@@ -194,6 +198,7 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
 int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out) {
     NVO_REQUIRE(n == 0 || (d && out), "dirs01: NULL argument");
     if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "dirs01");
     hipLaunchKernelGGL(k_dirs01, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d, out);
     NVO_CHECK_LAUNCH();
     return NVO_OK;

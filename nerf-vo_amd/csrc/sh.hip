@@ -103,6 +103,7 @@ int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const flo
                       void* out_half, uint32_t out_stride, uint32_t out_width) {
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
+    NVO_PROF(stream, "sh_fwd");
     hipLaunchKernelGGL(k_sh_fwd, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree, d01,
                        (__half*)out_half, out_stride, out_width);
     NVO_CHECK_LAUNCH();
@@ -113,6 +114,7 @@ int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, con
                             const void* dy_half, uint32_t dy_stride, float* dd01) {
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
+    NVO_PROF(stream, "sh_bwd_input");
     hipLaunchKernelGGL(k_sh_bwd_input, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
                        d01, (const __half*)dy_half, dy_stride, dd01);
     NVO_CHECK_LAUNCH();

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Kernel-level timing on the GPU box (HIP-event profiler of the library): hash-grid forward /
+backward variants at the BASELINE batch sizes.  Usage: python tools/kernel_bench.py [--iters 20]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+entry.build()
+import nerf_vo_amd.tinycudann as tcnn  # noqa: E402
+from nerf_vo_amd import _lib  # noqa: E402
+
+
+def pls(b, m, L):
+    return float(np.exp((np.log(m) - np.log(b)) / (L - 1)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    cases = [("main L16 T19", dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=pls(16, 2048, 16)), 4096 * 48),
+             ("prop0 L5 T17", dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, per_level_scale=pls(16, 128, 5)), 4096 * 256),
+             ("prop1 L5 T17", dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, per_level_scale=pls(16, 256, 5)), 4096 * 96)]
+    for label, cfg, n in cases:
+        enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_features_per_level": 2, **cfg}).to(dev)
+        with torch.no_grad():
+            enc.params.uniform_(-1, 1)
+        # ray-coherent positions (48 consecutive samples along a ray), like the training step
+        R = (n + 47) // 48
+        o = (torch.rand(R, 1, 3, device=dev) - 0.5) * 0.5 + 0.5
+        d = torch.nn.functional.normalize(torch.randn(R, 1, 3, device=dev), dim=-1)
+        t = torch.linspace(0, 0.4, 48, device=dev).view(1, 48, 1)
+        x = (o + d * t).clamp(0.001, 0.999).reshape(-1, 3)[:n].contiguous().requires_grad_(False)
+        dy = torch.randn(n, enc.n_output_dims, device=dev)
+        for mode in (0, 1):
+            enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
+            for it in range(args.iters + 3):
+                if it == 3:
+                    torch.cuda.synchronize()
+                    lib.nvo_profile_enable(1)
+                enc.params.grad = None
+                y = enc(x)
+                (y.float() * dy).sum().backward()
+            torch.cuda.synchronize()
+            need = lib.nvo_profile_summary(None, 0)
+            buf = C.create_string_buffer(int(need) + 16)
+            lib.nvo_profile_summary(buf, len(buf))
+            lib.nvo_profile_enable(0)
+            for line in buf.value.decode().strip().splitlines():
+                name, cnt, total = line.rsplit(",", 2)
+                print(f"{label:14s} N={n:8d} mode={mode} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
+
+
+if __name__ == "__main__":
+    main()
