@@ -111,6 +111,10 @@ int nvo_grid_indices(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const 
 int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
                const float* c2w, const float* corrections, float* origins, float* directions,
                float* directions_norm, float* pixel_area, int32_t* cam_idx);
+/* exp_map_SE3 of the camera optimizer (CameraOptimizerConfig(mode='SE3'),
+ * /root/reference/nerf_vo/mapping/nerfstudio.py:64,209-212): tangent device float [n][6]
+ * (translation | rotation) -> out device float [n][3][4] */
+int nvo_se3_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out);
 /* images: device float [F][H][W][C] -> out [R][C] */
 int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H,
                       uint32_t W, uint32_t C, const float* images, float* out);

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "nvo_grid_indices": (_int, [_p, _p, _u32, _p, _p]),
     # group B
     "nvo_raygen": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_se3_exp_map": (_int, [_p, _u32, _p, _p]),
     "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
     "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
     "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),

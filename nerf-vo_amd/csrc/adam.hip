@@ -67,7 +67,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     const float bias2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     uint32_t blocks = nvo_div_up(n, 256 * 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
+    NVO_LAUNCH(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
                        (_Float16*)params_half, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bias1,
                        bias2_sqrt, grad_scale, weight_decay, skip_flag);
     NVO_CHECK_LAUNCH();
@@ -81,7 +81,7 @@ int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_nonfinite_flag, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, grads, flag);
+    NVO_LAUNCH(k_nonfinite_flag, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, grads, flag);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
@@ -92,7 +92,7 @@ int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_h
     NVO_PROF(stream, "cast_half");
     uint32_t blocks = nvo_div_up(n, 256 * 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cast_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src,
+    NVO_LAUNCH(k_cast_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src,
                        (_Float16*)dst_half);
     NVO_CHECK_LAUNCH();
     return NVO_OK;

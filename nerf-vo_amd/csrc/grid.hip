@@ -438,10 +438,10 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
     if (soa) {
-        hipLaunchKernelGGL(k_grid_fwd<true>, grid, block, 0, stream, g, N, x,
+        NVO_LAUNCH(k_grid_fwd<true>, grid, block, 0, stream, g, N, x,
                            (const __half2*)table_half, (__half2*)out_half, indices);
     } else {
-        hipLaunchKernelGGL(k_grid_fwd<false>, grid, block, 0, stream, g, N, x,
+        NVO_LAUNCH(k_grid_fwd<false>, grid, block, 0, stream, g, N, x,
                            (const __half2*)table_half, (__half2*)out_half, indices);
     }
     NVO_CHECK_LAUNCH();
@@ -545,7 +545,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                                               (int)lds));                                     \
             attr_set = true;                                                                  \
         }                                                                                     \
-        hipLaunchKernelGGL((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
+        NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
                            (const T_*)dy, grad, (const uint4*)slices->d_level);               \
     } while (0)
         if (soa) {
@@ -561,7 +561,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
     const uint32_t tiles = nvo_div_up(N, kGridBlock / 2);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_AT(SOA_, T_)                                                               \
-    hipLaunchKernelGGL((k_grid_bwd_atomic<SOA_, T_>), grid, block, 0, stream, g, N, x,        \
+    NVO_LAUNCH((k_grid_bwd_atomic<SOA_, T_>), grid, block, 0, stream, g, N, x,        \
                        (const T_*)dy, grad)
     if (soa) {
         if (dy_is_float) NVO_LAUNCH_AT(true, float2); else NVO_LAUNCH_AT(true, __half2);
@@ -582,7 +582,7 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_IN(SOA_, T_)                                                               \
-    hipLaunchKernelGGL((k_grid_bwd_input<SOA_, T_>), grid, block, 0, stream, g, N, x,         \
+    NVO_LAUNCH((k_grid_bwd_input<SOA_, T_>), grid, block, 0, stream, g, N, x,         \
                        (const __half2*)table_half, (const T_*)dy, dx)
     if (soa) {
         if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);

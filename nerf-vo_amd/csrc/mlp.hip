@@ -541,7 +541,7 @@ int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
+    NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
                        0, stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -553,7 +553,7 @@ int launch_bwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
+    NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
                        0, stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -37,6 +37,14 @@ void nvo_set_error(const char* fmt, ...);
     } while (0)
 
 #define NVO_CHECK_LAUNCH() NVO_CHECK_HIP(hipGetLastError())
+// hipGetLastError() is sticky per thread and also latches errors raised by OTHER users of the runtime
+// in this process (e.g. a benign device query inside PyTorch): clear it before every launch so that
+// the check after the launch reports this launch only.
+#define NVO_LAUNCH(...)                  \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 
 // ---- optional per-launch HIP-event profiler (off by default; see nvo_profile_enable) ----------
 bool nvo_prof_enabled();

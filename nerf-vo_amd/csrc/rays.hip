@@ -144,9 +144,47 @@ k_dirs01(uint32_t n, const float* __restrict__ d, float* __restrict__ out) {
     if (i < n) out[i] = (d[i] + 1.f) * 0.5f;
 }
 
+// exp_map_SE3 of nerfstudio's camera optimizer (cameras/lie_groups.py): tangent [n][6] = (translation
+// | rotation) -> [n][3][4], with the same small-angle Taylor branches (theta < 1e-2).
+__global__ void __launch_bounds__(256)
+k_se3_exp(uint32_t n, const float* __restrict__ tangent, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* t = tangent + 6 * (size_t)i;
+    const float lx = t[0], ly = t[1], lz = t[2], ax = t[3], ay = t[4], az = t[5];
+    const float theta2 = ax * ax + ay * ay + az * az;
+    const float theta = sqrtf(theta2);
+    const bool nz = theta < 1e-2f;
+    const float sine = sinf(theta);
+    const float cosine = nz ? 8.f / (4.f + theta2) - 1.f : cosf(theta);
+    const float sbt = nz ? 0.5f * cosine + 0.5f : sine / theta;
+    const float omc = nz ? 0.5f * sbt : (1.f - cosine) / theta2;
+    float* o = out + 12 * (size_t)i;
+    o[0] = omc * ax * ax + cosine;   o[1] = omc * ax * ay - sbt * az;  o[2] = omc * ax * az + sbt * ay;
+    o[4] = omc * ay * ax + sbt * az; o[5] = omc * ay * ay + cosine;    o[6] = omc * ay * az - sbt * ax;
+    o[8] = omc * az * ax - sbt * ay; o[9] = omc * az * ay + sbt * ax;  o[10] = omc * az * az + cosine;
+    const float sbt_t = nz ? 1.f - theta2 / 6.f : sbt;
+    const float omc_t = nz ? 0.5f - theta2 / 24.f : omc;
+    const float tms = nz ? 1.f / 6.f - theta2 / 120.f : (theta - sine) / (theta2 * theta);
+    const float cx = ay * lz - az * ly, cy = az * lx - ax * lz, cz = ax * ly - ay * lx;  // ang x lin
+    const float dot = ax * lx + ay * ly + az * lz;
+    o[3] = sbt_t * lx + omc_t * cx + tms * ax * dot;
+    o[7] = sbt_t * ly + omc_t * cy + tms * ay * dot;
+    o[11] = sbt_t * lz + omc_t * cz + tms * az * dot;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nvo_se3_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out) {
+    NVO_REQUIRE(n == 0 || (tangent && out), "se3_exp_map: NULL argument");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "se3_exp_map");
+    NVO_LAUNCH(k_se3_exp, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tangent, out);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
 
 int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
                const float* c2w, const float* corrections, float* origins, float* directions,
@@ -155,7 +193,7 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
                            directions_norm && cam_idx), "raygen: NULL argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "raygen");
-    hipLaunchKernelGGL(k_raygen, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+    NVO_LAUNCH(k_raygen, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R,
                        ray_indices, intrinsics, c2w, corrections, origins, directions, directions_norm,
                        pixel_area, cam_idx);
     NVO_CHECK_LAUNCH();
@@ -167,7 +205,7 @@ int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
     NVO_REQUIRE(R == 0 || (ray_indices && images && out && Cn >= 1), "gather_pixels: NULL argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "gather_pixels");
-    hipLaunchKernelGGL(k_gather_pixels, dim3(nvo_div_up((uint64_t)R * Cn, 256)), dim3(256), 0,
+    NVO_LAUNCH(k_gather_pixels, dim3(nvo_div_up((uint64_t)R * Cn, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, ray_indices, H, W, Cn, images, out);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -178,7 +216,7 @@ int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_p
     NVO_REQUIRE(S >= 1 && (R == 0 || (sbins && tbins)), "sample_lindisp: bad argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "sample_lindisp");
-    hipLaunchKernelGGL(k_sample_lindisp, dim3(nvo_div_up((uint64_t)R * (S + 1), 256)), dim3(256), 0,
+    NVO_LAUNCH(k_sample_lindisp, dim3(nvo_div_up((uint64_t)R * (S + 1), 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, near_plane, far_plane, jitter, sbins, tbins);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -189,7 +227,7 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
     NVO_REQUIRE(S >= 1 && (R == 0 || (origins && directions && tbins && x01)), "sample_positions: bad argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "sample_positions[S%u]", S);
-    hipLaunchKernelGGL(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
+    NVO_LAUNCH(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, origins, directions, tbins, x01);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -199,7 +237,7 @@ int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out) {
     NVO_REQUIRE(n == 0 || (d && out), "dirs01: NULL argument");
     if (n == 0) return NVO_OK;
     NVO_PROF(stream, "dirs01");
-    hipLaunchKernelGGL(k_dirs01, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d, out);
+    NVO_LAUNCH(k_dirs01, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d, out);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

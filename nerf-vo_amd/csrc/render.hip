@@ -427,7 +427,7 @@ int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args) {
     NVO_REQUIRE(a.pre && a.x01 && a.tbins && a.weights && a.sbins, "weights_pdf: NULL input");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "weights_pdf[S%u]", a.S);
-    hipLaunchKernelGGL(k_weights_pdf, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+    NVO_LAUNCH(k_weights_pdf, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
                        (hipStream_t)stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -443,7 +443,7 @@ int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args) {
                 "main_render_loss: training mode needs drgb, losses, gt_rgb");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "main_render_loss");
-    hipLaunchKernelGGL(k_main_render_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+    NVO_LAUNCH(k_main_render_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
                        (hipStream_t)stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -458,7 +458,7 @@ int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args) {
                 a.dpre && a.dpre_stride >= 1, "prop_loss: NULL input/output");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "prop_loss[S%u]", a.S);
-    hipLaunchKernelGGL(k_prop_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
+    NVO_LAUNCH(k_prop_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
                        (hipStream_t)stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;

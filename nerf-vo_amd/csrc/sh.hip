@@ -104,7 +104,7 @@ int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const flo
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "sh_fwd");
-    hipLaunchKernelGGL(k_sh_fwd, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree, d01,
+    NVO_LAUNCH(k_sh_fwd, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree, d01,
                        (__half*)out_half, out_stride, out_width);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -115,7 +115,7 @@ int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, con
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "sh_bwd_input");
-    hipLaunchKernelGGL(k_sh_bwd_input, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
+    NVO_LAUNCH(k_sh_bwd_input, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
                        d01, (const __half*)dy_half, dy_stride, dd01);
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -1,0 +1,125 @@
+"""Drop-in counterpart of the reference's mapping method ``Nerfstudio``
+(/root/reference/nerf_vo/mapping/nerfstudio.py:33-217): same constructor arguments, attributes
+(``is_initialized``, ``is_shut_down``, ``step``, ``trainer``, ``config``) and methods (``__call__``,
+``update``, ``train``, ``shut_down``, ``save_snapshot``), same per-call cadence (ingest, then ONE
+training iteration), same snapshot artefacts (checkpoint, dataset.pt,
+matrices/matrices_origin2frame_training.json)."""
+from __future__ import annotations
+
+import argparse
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .dataset import DynamicDataManagerConfig
+from .model import CameraOptimizerConfig, ExtendedNerfactoModelConfig, multiply
+from .trainer import (AdamOptimizerConfig, ExponentialDecaySchedulerConfig, TrainerConfig, TrainingCallbackLocation,
+                      VanillaPipelineConfig, ViewerConfig, profiler)
+
+
+def step_check(step: int, step_size: int, run_at_zero: bool = False) -> bool:
+    """/root/reference/nerf_vo/mapping/mapping_utils.py:9-12"""
+    if step_size == 0:
+        return False
+    return (run_at_zero or step != 0) and step % step_size == 0
+
+
+def set_logging_prefix(metrics: dict, prefix: str) -> dict:
+    return {prefix + str(k): v for k, v in metrics.items()}
+
+
+class Nerfstudio:
+    def __init__(self, args: argparse.Namespace, device: torch.device = torch.device("cuda:0")) -> None:
+        self.args = args
+        self.device = torch.device(device)
+        self.is_initialized = False
+        self.is_shut_down = False
+        self.step = 0
+        self.config = TrainerConfig(
+            project_name="nerf_vo", experiment_name=args.experiment, method_name="extended_nerfacto",
+            output_dir=Path(args.dir_prediction + "/nerfstudio"), relative_model_dir=Path("../../../../snapshots"),
+            save_only_latest_checkpoint=False, steps_per_save=args.mapping_snapshot_iterations,
+            steps_per_eval_batch=512, steps_per_eval_image=512, steps_per_eval_all_images=512,
+            max_num_iterations=args.mapping_iterations, mixed_precision=True,
+            pipeline=VanillaPipelineConfig(
+                datamanager=DynamicDataManagerConfig(
+                    train_num_rays_per_batch=4096, eval_num_rays_per_batch=4096,
+                    camera_optimizer=CameraOptimizerConfig(mode="SE3"), num_frames=args.num_keyframes,
+                    frame_height=args.frame_height, frame_width=args.frame_width,
+                    use_normals="normal" in args.enhancement_module),
+                model=ExtendedNerfactoModelConfig(
+                    interlevel_loss_mult=1.0, distortion_loss_mult=0.002, orientation_loss_mult=0,
+                    pred_normal_loss_mult=0, depth_loss_mult=0.001, normal_loss_mult=0.000005, predict_normals=True,
+                    is_euclidean_depth=False, depth_sigma=0.001, should_decay_sigma=False)),
+            optimizers={
+                "proposal_networks": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None},
+                "fields": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None},
+                "camera_opt": {"optimizer": AdamOptimizerConfig(lr=1e-4, eps=1e-15),
+                               "scheduler": ExponentialDecaySchedulerConfig(lr_final=1e-5,
+                                                                            max_steps=args.mapping_iterations)},
+            },
+            viewer=ViewerConfig(num_rays_per_chunk=1 << 15), vis="viewer")
+        self.config.set_timestamp()
+        self.config.print_to_terminal()
+        self.config.save_config()
+        self.trainer = self.config.setup(device=self.device)
+        self.trainer.setup()
+
+    def __call__(self, input: dict | None) -> None:
+        if self.step == self.config.max_num_iterations:
+            self.shut_down()
+        else:
+            if input is not None:
+                self.update(input=input)
+            if self.is_initialized:
+                self.train()
+
+    def update(self, input: dict) -> None:
+        self.trainer.pipeline.datamanager.train_dataset.update(input=input)
+        if not self.is_initialized:
+            self.trainer._init_viewer_state()
+        self.is_initialized = True  # (no torch.cuda.empty_cache(): allocator churn)
+
+    def train(self) -> None:
+        with self.trainer.train_lock:
+            self.trainer.pipeline.train()
+            for callback in self.trainer.callbacks:
+                callback.run_callback_at_location(self.step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+            loss, loss_dict, metrics_dict = self.trainer.train_iteration(self.step)
+            for callback in self.trainer.callbacks:
+                callback.run_callback_at_location(self.step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        self.trainer._update_viewer_state(self.step)
+        if step_check(self.step, self.config.logging.steps_per_log, run_at_zero=True):
+            self.last_loss_dict = set_logging_prefix(loss_dict, "loss/")
+            self.last_metrics_dict = set_logging_prefix(metrics_dict, "metrics/")
+        if step_check(self.step, self.config.steps_per_save):
+            self.save_snapshot()
+        self.step += 1
+
+    def shut_down(self) -> None:
+        self.save_snapshot()
+        print(f"[nerf_vo_amd] training finished: config {self.config.get_base_dir() / 'config.yml'}, "
+              f"checkpoints {self.trainer.checkpoint_dir}")
+        for callback in self.trainer.callbacks:
+            callback.run_callback_at_location(step=self.step, location=TrainingCallbackLocation.AFTER_TRAIN)
+        profiler.flush_profiler(self.config.logging)
+        self.is_shut_down = True
+
+    def optimized_poses(self) -> np.ndarray:
+        """[n,4,4] camera_optimizer(correction) o camera_to_world for the active frames."""
+        ds = self.trainer.pipeline.datamanager.train_dataset
+        n = ds.num_active_frames
+        mats = np.tile(np.eye(4), (n, 1, 1))
+        corr = self.trainer.pipeline.model.camera_optimizer(torch.arange(n).to(self.device))
+        mats[:, :3] = multiply(corr, ds.cameras.camera_to_worlds[:n].to(self.device)).detach().cpu().numpy()
+        return mats
+
+    def save_snapshot(self) -> None:
+        self.trainer.save_checkpoint(self.step)
+        self.trainer.pipeline.datamanager.train_dataset.save_dataset(dir_prediction=self.args.dir_prediction)
+        mdir = Path(self.args.dir_prediction) / "matrices"
+        mdir.mkdir(parents=True, exist_ok=True)
+        with open(mdir / "matrices_origin2frame_training.json", "w") as file:
+            json.dump(self.optimized_poses().tolist(), file)
