@@ -1,0 +1,69 @@
+"""Multi-process (gloo, world_size 2, CPU) test of the only collective on the path: the sum
+all-reduce of the flat gradient buffer, plus ray sharding helpers."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nerf_vo_amd.parallel import GradientAllReduce
+
+    red = GradientAllReduce(dist, bucket_numel=1000)
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 10_007  # not a multiple of the bucket size
+    grad = torch.randn(n, generator=g)
+    mine = grad.clone()
+    red(grad)
+    # every rank must hold the same sum; rank 0 checks it against a locally recomputed reference
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ref = sum(gathered)
+    ok = torch.allclose(grad, ref, atol=1e-6)
+    # partial reduction: only one segment is reduced, the rest keeps the local value
+    grad2 = mine.clone()
+    red(grad2, segments=[(100, 2500)])
+    ok = ok and torch.allclose(grad2[100:2600], ref[100:2600], atol=1e-6) and torch.equal(grad2[:100], mine[:100]) \
+        and torch.equal(grad2[2600:], mine[2600:])
+    torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_gloo_world2(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(tmp_path / f"r{r}.pt")["ok"], f"rank {r} saw a wrong reduction"
+
+
+def test_single_process_world_is_identity():
+    from nerf_vo_amd.parallel import GradientAllReduce, shard_ray_count
+
+    class _NoDist:
+        @staticmethod
+        def is_initialized():
+            return False
+
+    red = GradientAllReduce(_NoDist())
+    x = torch.arange(10.0)
+    y = x.clone()
+    red(y)
+    assert torch.equal(x, y)
+    assert [shard_ray_count(4096, 8, r) for r in range(8)] == [512] * 8
+    assert sum(shard_ray_count(4099, 8, r) for r in range(8)) == 4099
