@@ -62,6 +62,24 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
     return None
 
 
+def pmc_traffic(name: str):
+    """HBM bytes per launch of the named kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_fetch_write_per_kernel.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of
+    this same command; (FETCH_SIZE + WRITE_SIZE) * 1024, raw -- see the note in that file about the
+    gfx950 FETCH_SIZE calibration).  None when no PMC summary covers the kernel."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")), reverse=True):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        for k in data.get("kernels", []):
+            if k.get("bench_name") == name:
+                return int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path)
+    return None, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,8 +213,10 @@ def main() -> None:
                 continue
             avg_s = total / cnt * 1e-3
             achieved = b / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(name)
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
                         "share_of_step_kernel_time": round(total / tot, 4)}
             break

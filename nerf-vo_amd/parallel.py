@@ -24,8 +24,8 @@ class GradientAllReduce:
     def __call__(self, flat_grad: torch.Tensor, segments=None) -> None:
         """In-place sum over ranks.  ``segments``: optional iterable of (offset, size) ranges to
         reduce (e.g. skip the proposal networks on steps where they are not updated)."""
-        if self.world_size == 1:
-            return
+        if not self.dist.is_initialized():
+            return  # single process without a process group: identity
         ranges = [(0, flat_grad.numel())] if segments is None else list(segments)
         handles = []
         for off, size in ranges:

@@ -57,7 +57,8 @@ def test_encoded_features_match_golden(device, golden):
     table = np.random.default_rng(5).uniform(-1, 1, (enc.params.numel() // 2, 2))
     with torch.no_grad():
         enc.params.copy_(torch.from_numpy(table.reshape(-1)).float().to(device))
-    y = enc(torch.from_numpy(_points(64, 12)).to(device)).float().cpu().numpy()
+    with torch.no_grad():
+        y = enc(torch.from_numpy(_points(64, 12)).to(device)).float().cpu().numpy()
     # the golden features use the un-rounded float64 table; the kernel reads its fp16 copy: |err| <= ~1e-3
     np.testing.assert_allclose(y, golden["g3_features"], atol=2e-3, rtol=2e-3)
 
@@ -68,7 +69,8 @@ def test_sh_and_se3_match_golden(device, golden):
 
     enc = tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 4}).to(device)
     d = torch.from_numpy(golden["g5_dirs"]).float().to(device)
-    y = enc((d + 1) / 2).float().cpu().numpy()
+    with torch.no_grad():
+        y = enc((d + 1) / 2).float().cpu().numpy()
     np.testing.assert_allclose(y, golden["g5_sh4"], atol=2e-3, rtol=2e-3)
 
     tang = torch.from_numpy(golden["g9_tangent"]).float().to(device).contiguous()
