@@ -438,9 +438,11 @@ class NerfactoEngine:
             jitters = tuple(torch.rand(R, device=self.device) for _ in range(3))
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
         updated = self.forward_backward(ws, jitters, has_depth=depths is not None)
-        if all_reduce is not None:
-            all_reduce(self.grads)
         groups = ["fields"] + (["proposal_networks"] if updated else []) + ["camera_opt"]
+        if all_reduce is not None:
+            # one exchange per iteration: the gradient ranges that are non-zero on this step
+            active = [g for g in groups if g != "camera_opt" or self.cfg.optimize_poses]
+            all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)])
         self.optimizer_step(groups)
         if updated:
             self.steps_since_proposal_update = 0

@@ -15,26 +15,44 @@ import torch
 
 
 class GradientAllReduce:
-    def __init__(self, dist_module, bucket_numel: int = 4 * 1024 * 1024, group=None):
+    """``compress="fp16"``: the (loss-scaled) fp32 gradient is cast to fp16, summed by the collective
+    in fp16 and cast back -- half the bytes on the xGMI links (27.7 MB instead of 55.4 MB); the
+    optimiser's non-finite check runs after the reduction, so an fp16 overflow skips the step exactly
+    like a local overflow would.  ``compress=None`` reduces the fp32 buffer in place."""
+
+    def __init__(self, dist_module, bucket_numel: int = 4 * 1024 * 1024, group=None, compress: str | None = None):
         self.dist = dist_module
         self.bucket_numel = int(bucket_numel)
         self.group = group
-        self.world_size = dist_module.get_world_size(group) if dist_module.is_initialized() else 1
+        if compress not in (None, "fp16"):
+            raise ValueError(f"unknown gradient compression {compress!r}")
+        self.compress = compress
+        self._half = None
 
     def __call__(self, flat_grad: torch.Tensor, segments=None) -> None:
         """In-place sum over ranks.  ``segments``: optional iterable of (offset, size) ranges to
         reduce (e.g. skip the proposal networks on steps where they are not updated)."""
         if not self.dist.is_initialized():
             return  # single process without a process group: identity
-        ranges = [(0, flat_grad.numel())] if segments is None else list(segments)
+        ranges = [(0, flat_grad.numel())] if segments is None else [(int(o), int(n)) for o, n in segments]
+        src = flat_grad
+        if self.compress == "fp16":
+            if self._half is None or self._half.numel() != flat_grad.numel() or self._half.device != flat_grad.device:
+                self._half = torch.empty(flat_grad.numel(), dtype=torch.float16, device=flat_grad.device)
+            for off, size in ranges:
+                self._half[off:off + size].copy_(flat_grad[off:off + size])
+            src = self._half
         handles = []
         for off, size in ranges:
             for lo in range(off, off + size, self.bucket_numel):
                 hi = min(off + size, lo + self.bucket_numel)
-                handles.append(self.dist.all_reduce(flat_grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
+                handles.append(self.dist.all_reduce(src[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
                                                     async_op=True))
         for h in handles:
             h.wait()
+        if self.compress == "fp16":
+            for off, size in ranges:
+                flat_grad[off:off + size].copy_(self._half[off:off + size])
 
 
 def shard_ray_count(global_rays: int, world_size: int, rank: int) -> int:

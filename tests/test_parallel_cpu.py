@@ -40,6 +40,12 @@ def _worker(rank, world, port, tmp):
     red(grad2, segments=[(100, 2500)])
     ok = ok and torch.allclose(grad2[100:2600], ref[100:2600], atol=1e-6) and torch.equal(grad2[:100], mine[:100]) \
         and torch.equal(grad2[2600:], mine[2600:])
+    # fp16-compressed exchange: same sum up to fp16 rounding of each rank's contribution
+    red16 = GradientAllReduce(dist, bucket_numel=3000, compress="fp16")
+    grad3 = mine.clone()
+    red16(grad3, segments=[(0, 5000), (5000, n - 5000)])
+    ref16 = sum(t.half().float() for t in gathered)
+    ok = ok and torch.allclose(grad3, ref16, atol=2e-2, rtol=2e-3)
     torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
