@@ -92,6 +92,7 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-bwd-mode", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,9 +153,15 @@ def main() -> None:
     intr = ds.camera_intrinsics
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
 
+    use_graph = not args.no_graph
+
     def step():
-        ray_indices, _ = dm.next_train(engine.step)
-        engine.train_step(ray_indices, intr, c2w, ds.frames_color, ds.frames_depth, all_reduce=reducer)
+        nonlocal use_graph
+        if use_graph:
+            engine.train_step_graphed(ds, all_reduce=reducer)
+        else:
+            ray_indices, _ = dm.next_train(engine.step)
+            engine.train_step(ray_indices, intr, c2w, ds.frames_color, ds.frames_depth, all_reduce=reducer)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -188,8 +195,10 @@ def main() -> None:
         lib.nvo_profile_enable(1)
     fence()
     tp0 = time.perf_counter()
+    use_graph_saved, use_graph = use_graph, False  # launchers (and their event hooks) only run eagerly
     for _ in range(prof_steps):  # every rank runs them (the all-reduce is collective)
         step()
+    use_graph = use_graph_saved
     fence()
     ms_prof = (time.perf_counter() - tp0) / prof_steps * 1e3
     if rank == 0:
@@ -241,6 +250,7 @@ def main() -> None:
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
                        "grid_bwd": "lds" if args.grid_bwd_mode == 1 else "atomic",
+                       "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
                        "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (fp16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             "final_losses": losses,

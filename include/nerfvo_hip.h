@@ -151,6 +151,7 @@ typedef struct nvo_weights_pdf_args {
     const float* jitter;         /* [R] or NULL */
     float* sbins_out;            /* [R][S_out+1] */
     float* tbins_out;
+    const float* anneal_dev;     /* device float or NULL: overrides `anneal` (hipGraph replay) */
 } nvo_weights_pdf_args;
 int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args);
 
@@ -176,7 +177,8 @@ typedef struct nvo_main_loss_args {
     float* out_expected_depth;   /* [R] or NULL */
     float* out_accumulation;     /* [R] */
     float* weights;              /* [R*S] or NULL */
-    float* losses;               /* [3] rgb, distortion, depth: atomically accumulated */
+    float* losses;               /* [64][8] shards; slots 0..2 = rgb, distortion, depth: atomically accumulated,
+                                    the caller zeroes the buffer and sums the 64 shards */
     void* dpre;                  /* fp16 [R*S][dpre_stride] column 0; NULL -> inference, no losses */
     uint32_t dpre_stride;
     void* drgb;                  /* fp16 [R*S][drgb_stride]: cols 0..2 gradient, others zeroed */
@@ -198,7 +200,7 @@ typedef struct nvo_prop_loss_args {
     const float* directions_norm;
     float interlevel_mult, depth_mult, depth_sigma;
     float inv_rays, depth_level_div, loss_scale;
-    float* losses;               /* [2] interlevel, depth: atomically accumulated */
+    float* losses;               /* [64][8] shards (same buffer, base + 3): slots 0..1 = interlevel, depth */
     void* dpre;                  /* fp16 [R*S][dpre_stride]: column 0 gradient, others zeroed */
     uint32_t dpre_stride;
 } nvo_prop_loss_args;
@@ -238,7 +240,12 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
                   const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
-                  const uint32_t* skip_flag);
+                  const uint32_t* skip_flag, const float* hyper_dev);
+/* hyper_dev (nullable): device float[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} overriding the
+ * by-value arguments, so that a captured hipGraph of the step can be replayed with new values. */
+/* dst[i] = host_values[i] for n <= 16 floats; the values travel as kernel arguments (no host buffer
+ * has to stay alive), used to refresh per-step scalars ahead of a graph replay. */
+int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* host_values);
 /* *flag = any(!isfinite(grads)) */
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);

@@ -26,7 +26,7 @@ class WeightsPdfArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("S_out", _u32), ("pre", _p), ("pre_stride", _u32), ("x01", _p),
                 ("sbins", _p), ("tbins", _p), ("density_bias", _f), ("sigma", _p), ("weights", _p),
                 ("anneal", _f), ("histogram_padding", _f), ("near_plane", _f), ("far_plane", _f),
-                ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p)]
+                ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p), ("anneal_dev", _p)]
 
 
 class MainLossArgs(C.Structure):
@@ -92,7 +92,8 @@ _SIGNATURES = {
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
     # group E
-    "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p]),
+    "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
+    "nvo_write_floats": (_int, [_p, _p, _u32, _p]),
     "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
 }

@@ -15,8 +15,13 @@ __global__ void __launch_bounds__(256)
 k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const float* __restrict__ g,
        float* __restrict__ m, float* __restrict__ v, float lr, float beta1, float beta2, float eps,
        float bias1, float bias2_sqrt, float grad_scale, float weight_decay,
-       const uint32_t* __restrict__ skip_flag) {
+       const uint32_t* __restrict__ skip_flag, const float* __restrict__ hyper_dev) {
     if (skip_flag && *skip_flag) return;
+    if (hyper_dev) {  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} kept in device memory (graph replay)
+        lr = hyper_dev[0];
+        bias1 = hyper_dev[1];
+        bias2_sqrt = hyper_dev[2];
+    }
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float pi = p[i];
@@ -58,7 +63,7 @@ extern "C" {
 int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
                   const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
-                  const uint32_t* skip_flag) {
+                  const uint32_t* skip_flag, const float* hyper_dev) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: NULL argument");
     NVO_REQUIRE(step >= 1, "adam_step: step counts from 1");
     if (n == 0) return NVO_OK;
@@ -69,7 +74,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     if (blocks > 2048) blocks = 2048;
     NVO_LAUNCH(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
                        (_Float16*)params_half, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bias1,
-                       bias2_sqrt, grad_scale, weight_decay, skip_flag);
+                       bias2_sqrt, grad_scale, weight_decay, skip_flag, hyper_dev);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
@@ -82,6 +87,21 @@ int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;
     NVO_LAUNCH(k_nonfinite_flag, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, grads, flag);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+struct NvoFloats16 { float v[16]; };
+__global__ void k_write_floats(float* dst, uint32_t n, NvoFloats16 vals) {
+    if (threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
+int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* host_values) {
+    NVO_REQUIRE(dst && host_values && n <= 16, "write_floats: bad argument (n <= 16)");
+    if (n == 0) return NVO_OK;
+    NvoFloats16 vals;
+    for (uint32_t i = 0; i < 16; ++i) vals.v[i] = i < n ? host_values[i] : 0.f;
+    NVO_LAUNCH(k_write_floats, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n, vals);  // values travel by value
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

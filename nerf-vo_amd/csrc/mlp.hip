@@ -303,6 +303,30 @@ struct DwAcc {
                 for (int r = 0; r < 4; ++r)
                     atomicAdd(dW + (size_t)(16 * tn + 4 * g + r) * K_IN + 16 * tk + c, a[tn][tk][r]);
     }
+    // Workgroup-level flush: the block's waves sum their accumulators in LDS (same lane <-> element
+    // map in every wave, so plain read-modify-write phases separated by barriers suffice), then all
+    // threads add the block total to global memory in row order (256 contiguous bytes per wave
+    // instruction -- the fast float-atomic shape -- and 4x fewer adds per address).
+    // MUST be called by every wave of the block (contains __syncthreads()).
+    __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib) const {
+        const int c = lane & 15, g = lane >> 4;
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (wib == w) {
+#pragma unroll
+                for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+                    for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = (16 * tn + 4 * g + r) * K_IN + 16 * tk + c;
+                            red[e] = (w == 0 ? 0.f : red[e]) + a[tn][tk][r];
+                        }
+            }
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
+        __syncthreads();
+    }
 };
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
@@ -521,17 +545,22 @@ k_mlp_bwd(NvoMlpArgs a) {
         }
     }
 
-    // ---- flush weight gradients
+    // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
     if (a.dweights) {
+        __syncthreads();  // every wave is done with its LDS tiles
+        float* red = reinterpret_cast<float*>(&lds[0][0][0]);
+        constexpr int kLdsFloats = (int)(sizeof(lds) / sizeof(float));
+        static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
+                      "dW block reduction does not fit the LDS tiles");
         float* dW = a.dweights;
-        dw0.flush(dW, lane);
+        dw0.flush_block(dW, red, lane, wib);
         dW += WIDTH * IN_PAD;
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            dwh[l].flush(dW, lane);
+            dwh[l].flush_block(dW, red, lane, wib);
             dW += WIDTH * WIDTH;
         }
-        dwl.flush(dW, lane);
+        dwl.flush_block(dW, red, lane, wib);
     }
 }
 

@@ -141,9 +141,10 @@ k_weights_pdf(nvo_weights_pdf_args a) {
     if (a.S_out == 0) return;
 
     // ---- PDFSampler: annealed weights -> padded pdf -> clamped cdf (cdf[0] = 0)
+    const float anneal = a.anneal_dev ? *a.anneal_dev : a.anneal;
     float part = 0.f;
     for (uint32_t i = lane; i < S; i += 64) {
-        const float wa = (a.anneal == 1.0f ? w[i] : powf(w[i], a.anneal)) + a.histogram_padding;
+        const float wa = (anneal == 1.0f ? w[i] : powf(w[i], anneal)) + a.histogram_padding;
         Tr[i] = wa;  // reuse as pdf numerator
         part += wa;
     }
@@ -294,9 +295,12 @@ k_main_render_loss(nvo_main_loss_args a) {
         l_depth = wave_sum(term) * a.inv_rays * a.depth_level_div;
     }
     if (lane == 0) {
-        atomicAdd(a.losses + 0, a.rgb_mult * l_rgb);
-        atomicAdd(a.losses + 1, a.distortion_mult * l_dist);
-        atomicAdd(a.losses + 2, a.depth_mult * l_depth);
+        // 64 shards of 8 floats: thousands of adds to ONE word serialise at the memory side
+        // (~88 same-address atomics per us on MI355X); the host sums the shards.
+        float* shard = a.losses + 8 * (r & 63u);
+        atomicAdd(shard + 0, a.rgb_mult * l_rgb);
+        atomicAdd(shard + 1, a.distortion_mult * l_dist);
+        atomicAdd(shard + 2, a.depth_mult * l_depth);
     }
     if (act) g[lane] = gw;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -397,8 +401,9 @@ k_prop_loss(nvo_prop_loss_args a) {
     }
     l_depth = wave_sum(l_depth) * a.inv_rays * a.depth_level_div;
     if (lane == 0) {
-        atomicAdd(a.losses + 0, a.interlevel_mult * l_inter);
-        atomicAdd(a.losses + 1, a.depth_mult * l_depth);
+        float* shard = a.losses + 8 * (r & 63u);
+        atomicAdd(shard + 0, a.interlevel_mult * l_inter);
+        atomicAdd(shard + 1, a.depth_mult * l_depth);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -152,8 +152,11 @@ class NerfactoEngine:
         self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
-        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)  # sharded accumulators
         self.skip_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
+        self._graphs = {}
+        self._pix_scale = None
         self.opt_steps = {g: 0 for g in self.group_ranges}
         self.step = 0
         self.steps_since_proposal_update = 0
@@ -259,7 +262,7 @@ class NerfactoEngine:
         _call("nvo_fwd", net.handle, stream, R * S, _ptr(ws[f"x{k}"]), self._param_ptr(seg, self.params_half),
               _ptr(ws[f"out{k}"]), _ptr(ws[f"ctx{k}"]))
 
-    def _weights_pdf(self, ws, k: int, anneal: float, jitter, stream, resample: bool):
+    def _weights_pdf(self, ws, k: int, anneal: float, jitter, stream, resample: bool, anneal_dev: int | None = None):
         cfg = self.cfg
         R, S = ws["R"], self.levels[k]
         S_out = self.levels[k + 1] if resample else 0
@@ -270,10 +273,11 @@ class NerfactoEngine:
             histogram_padding=cfg.histogram_padding, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
             jitter=None if jitter is None else jitter.data_ptr(),
             sbins_out=ws[f"sbins{k + 1}"].data_ptr() if resample else None,
-            tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None)
+            tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None, anneal_dev=anneal_dev)
         _call("nvo_weights_pdf", stream, C.byref(a))
 
-    def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream):
+    def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream,
+                 anneal_dev: int | None = None):
         """Everything up to (and including) the colour head.  jitters: None or 3 tensors [R]."""
         cfg = self.cfg
         R = ws["R"]
@@ -282,7 +286,7 @@ class NerfactoEngine:
               _ptr(ws["sbins0"]), _ptr(ws["tbins0"]))
         for k, net in enumerate(self.prop_nets):
             self._density_level(ws, k, net, f"proposal.{k}", stream)
-            self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True)
+            self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True, anneal_dev=anneal_dev)
         km = len(self.prop_nets)
         self._density_level(ws, km, self.base_net, "field.base", stream)
         _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
@@ -372,7 +376,7 @@ class NerfactoEngine:
             ws["gt_depth"].copy_(gt_depth.reshape(-1))
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
-                         anneal: float | None = None):
+                         anneal: float | None = None, anneal_dev: int | None = None):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -385,7 +389,7 @@ class NerfactoEngine:
         self.grads.zero_()
         self.losses.zero_()
         emb_ptr = self._param_ptr("field.embedding", self.params_half).value
-        ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream)
+        ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev)
         km = len(self.prop_nets)
         R = ws["R"]
         la = self._main_loss_args(ws, True, has_depth)
@@ -413,22 +417,138 @@ class NerfactoEngine:
                       self._param_ptr(f"proposal.{k}", self.grads))
         return update_proposals
 
-    def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt")) -> None:
+    _GROUP_ORDER = ("fields", "proposal_networks", "camera_opt")
+
+    def _group_lr(self, g: str) -> float:
+        cfg = self.cfg
+        return {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal,
+                "camera_opt": self.camera_lr(self.step)}[g]
+
+    def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False) -> None:
+        """Non-finite check + fused Adam per group.  ``from_device_scalars``: lr and bias corrections
+        are read from self.dev_scalars (filled by _write_step_scalars) instead of kernel arguments, and
+        the per-group step counters are NOT advanced here -- the form a captured graph replays."""
         cfg = self.cfg
         stream = _stream(self.device)
         _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), _ptr(self.skip_flag))
-        lrs = {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal, "camera_opt": self.camera_lr(self.step)}
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:
                 continue
             lo, hi = self.group_ranges[g]
-            self.opt_steps[g] += 1
+            if not from_device_scalars:
+                self.opt_steps[g] += 1
+            hyper = None
+            if from_device_scalars:
+                gi = self._GROUP_ORDER.index(g)
+                hyper = C.c_void_p(self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi))
             esz = 4
             _call("nvo_adam_step", stream, hi - lo, C.c_void_p(self.params.data_ptr() + lo * esz),
                   C.c_void_p(self.params_half.data_ptr() + lo * 2), C.c_void_p(self.grads.data_ptr() + lo * esz),
                   C.c_void_p(self.exp_avg.data_ptr() + lo * esz), C.c_void_p(self.exp_avg_sq.data_ptr() + lo * esz),
-                  lrs[g], cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_steps[g],
-                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
+                  self._group_lr(g), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, max(self.opt_steps[g], 1),
+                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), hyper)
+
+    # ------------------------------------------------------------------------------------------
+    # hipGraph replay of the step
+    # ------------------------------------------------------------------------------------------
+    def _write_step_scalars(self, anneal: float, groups) -> None:
+        """Per-step scalars (proposal anneal, Adam lr / bias corrections) -> device memory; the values
+        travel as kernel arguments of a tiny eager launch ahead of the graph replay."""
+        cfg = self.cfg
+        vals = [0.0] * 16
+        vals[0] = anneal
+        for gi, g in enumerate(self._GROUP_ORDER):
+            if g in groups:
+                self.opt_steps[g] += 1
+            t = max(self.opt_steps[g], 1)
+            vals[1 + 3 * gi] = self._group_lr(g)
+            vals[2 + 3 * gi] = 1.0 - cfg.adam_betas[0] ** t
+            vals[3 + 3 * gi] = math.sqrt(1.0 - cfg.adam_betas[1] ** t)
+        arr = (C.c_float * 16)(*vals)
+        _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 16, arr)
+
+    def train_step_graphed(self, dataset, all_reduce=None):
+        """One full iteration replayed from a captured hipGraph (torch.cuda.CUDAGraph): pixel sampling,
+        jitters, ray generation, forward, losses, backward and (single-GPU) the optimiser are ONE graph
+        launch, which removes the ~45 inter-kernel launch gaps of the eager step.  Two graphs exist per
+        ray count: with and without the proposal-network update.  With ``all_reduce`` the optimiser is
+        a second graph behind the (eager) collective."""
+        cfg = self.cfg
+        R = cfg.num_rays
+        step = self.step
+        updated = self.proposal_update_due(step)
+        groups = ["fields"] + (["proposal_networks"] if updated else []) + (["camera_opt"] if cfg.optimize_poses else [])
+        has_depth = dataset.frames_depth is not None
+        key = (R, updated, has_depth, all_reduce is not None)
+        if self._pix_scale is None:
+            self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
+            self._pix_scale_host = None
+        extent = (dataset.num_active_frames, dataset.frame_height, dataset.frame_width)
+        if self._pix_scale_host != extent:  # keyframes were added: refresh the sampler range in place
+            self._pix_scale.copy_(torch.tensor(extent, dtype=torch.float32))
+            self._pix_scale_host = extent
+        self._write_step_scalars(self.anneal_at(step), groups)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None)
+            self._graphs[key] = entry
+        entry["main"].replay()
+        if all_reduce is not None:
+            active = [g for g in groups]
+            all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)])
+            entry["opt"].replay()
+        if updated:
+            self.steps_since_proposal_update = 0
+        self.steps_since_proposal_update += 1
+        self.step += 1
+        return updated
+
+    def _capture_step(self, dataset, R, updated, has_depth, groups, split_optimizer):
+        dev = self.device
+        ws = self._workspace(R, True)
+        intr = dataset.camera_intrinsics
+        c2w_full = dataset.camera_extrinsics
+        scale = self._pix_scale
+        c2w = torch.empty(c2w_full.shape[0], 3, 4, device=dev)
+        anneal_ptr = self.dev_scalars.data_ptr()
+
+        def body_main():
+            u = torch.rand((R, 3), device=dev)
+            ray_indices = torch.floor(u * scale).long()
+            c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
+            self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None)
+            jit = torch.rand((3, R), device=dev)
+            self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
+                                  anneal=1.0, anneal_dev=anneal_ptr)
+
+        def body_opt():
+            self.optimizer_step(groups, from_device_scalars=True)
+
+        # warm-up on a side stream (allocations, lazy module state), then capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.params_half.clone())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body_main()
+                body_opt()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half), saved):
+            dst.copy_(src)  # the warm-up steps must not count as training
+        entry = {}
+        g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_main):
+            body_main()
+            if not split_optimizer:
+                body_opt()
+        entry["main"] = g_main
+        if split_optimizer:
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt):
+                body_opt()
+            entry["opt"] = g_opt
+        return entry
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None):
         """One full iteration.  ``all_reduce``: optional callable(flat_grad_tensor) for multi-GPU."""
@@ -451,7 +571,7 @@ class NerfactoEngine:
         return updated
 
     def loss_dict(self) -> dict:
-        vals = self.losses.tolist()
+        vals = self.losses.sum(dim=0).tolist()
         d = {"rgb_loss": vals[0], "distortion_loss": vals[1], "depth_loss": vals[2] + vals[4],
              "interlevel_loss": vals[3]}
         return d

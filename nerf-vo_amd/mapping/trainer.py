@@ -81,6 +81,10 @@ class VanillaPipeline:
                                         num_rays=config.datamanager.train_num_rays_per_batch)
         self.training = True
         self.all_reduce = None  # set by the distributed launcher (nerf_vo_amd.parallel.GradientAllReduce)
+        import os
+
+        # hipGraph replay of the step (default); NVO_NO_GRAPH=1 launches every kernel eagerly
+        self.use_graph = os.environ.get("NVO_NO_GRAPH", "0") != "1"
 
     def train(self):
         self.training = True
@@ -93,12 +97,15 @@ class VanillaPipeline:
     def get_train_loss_dict(self, step: int):
         """One full native iteration (forward, losses, backward, optimiser)."""
         ds = self.datamanager.train_dataset
-        ray_indices, batch = self.datamanager.next_train(step)
         eng = self.model.engine
         eng.step = step
-        c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
-        eng.train_step(ray_indices, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth,
-                       all_reduce=self.all_reduce)
+        if self.use_graph:
+            eng.train_step_graphed(ds, all_reduce=self.all_reduce)
+        else:
+            ray_indices, batch = self.datamanager.next_train(step)
+            c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+            eng.train_step(ray_indices, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth,
+                           all_reduce=self.all_reduce)
         return None, eng.loss_dict(), self.model.get_metrics_dict()
 
 
