@@ -72,7 +72,9 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
     if verbose:
-        print(f"[nerf-vo_amd] built {LIB_PATH} ({LIB_PATH.stat().st_size / 1e6:.1f} MB) from {len(srcs)} sources")
+        # stderr: bench.py must print exactly one JSON line on stdout
+        print(f"[nerf-vo_amd] built {LIB_PATH} ({LIB_PATH.stat().st_size / 1e6:.1f} MB) from {len(srcs)} sources",
+              file=sys.stderr)
     return LIB_PATH
 
 
