@@ -92,6 +92,8 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-bwd-mode", type=int, default=1)
+    ap.add_argument("--optimize-poses", action="store_true",
+                    help="BASELINE configs[2]: SE3 pose-gradient backprop enabled (default: configs[1], fixed poses)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -144,7 +146,8 @@ def main() -> None:
     ds = dm.train_dataset
     assert ds.num_active_frames == args.keyframes
 
-    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, grid_bwd_mode=args.grid_bwd_mode)
+    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, grid_bwd_mode=args.grid_bwd_mode,
+                       optimize_poses=args.optimize_poses)
     engine = NerfactoEngine(cfg, device, world_size=world)
     reducer = GradientAllReduce(dist, compress="fp16") if dist is not None else None
     if dist is not None:  # identical initial parameters on every rank
@@ -244,8 +247,10 @@ def main() -> None:
             "metric": "training ray-samples/sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Replica-shaped full mapping step, depth-nerfacto "
-                                   "(proposal sampling 256/96/48), fixed poses",
+            "config": {"workload": ("BASELINE configs[2]: Replica-shaped full mapping step, depth-nerfacto (proposal "
+                                    "sampling 256/96/48), SE3 pose-gradient backprop enabled" if args.optimize_poses else
+                                    "BASELINE configs[1]: Replica-shaped full mapping step, depth-nerfacto "
+                                    "(proposal sampling 256/96/48), fixed poses"),
                        "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",

@@ -115,6 +115,31 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
  * /root/reference/nerf_vo/mapping/nerfstudio.py:64,209-212): tangent device float [n][6]
  * (translation | rotation) -> out device float [n][3][4] */
 int nvo_se3_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out);
+/* mode 0 = exp_map_SE3 (as above), 1 = exp_map_SO3xR3 (nerfstudio's other camera-optimizer mode:
+ * Rodrigues rotation with |w|^2 clamped at 1e-4, translation = the tangent's first three entries) */
+int nvo_pose_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out, int mode);
+/* Pose-gradient chain of the SE3 camera optimiser (autograd through torch ops in nerfstudio [UPSTREAM];
+ * reference use /root/reference/nerf_vo/mapping/nerfstudio.py:64,208-216).  All gradients carry the
+ * loss scale of their inputs.
+ *  positions_bwd : dx01 [R*S][3] (from nvo_bwd's dL_dinput) -> d_origin/d_dir [R][3], ACCUMULATED
+ *                  (selector, (x+2)/4, L-inf contraction Jacobian, reduction over the ray's samples)
+ *  sh_bwd_input_f32: dy float [R][16] (colour head d_sh) -> dd01 [R][3]
+ *  pose_bwd      : d_origin, d_dir, d_dir01 (nullable, weighted 1/2) -> d_corrections [F][3][4],
+ *                  atomically accumulated (caller zeroes)
+ *  se3_exp_map_bwd: d_corrections -> d_tangent [n][6] (OVERWRITTEN) through exp_map_SE3, plus
+ *                  reg_scale * d/dtangent of (mean|trans| * trans_penalty + mean|rot| * rot_penalty);
+ *                  reg_loss (nullable): the regulariser value is atomically added to *reg_loss */
+int nvo_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t S, const float* origins,
+                      const float* directions, const float* tbins, const float* dx01, float* d_origin,
+                      float* d_dir);
+int nvo_sh_bwd_input_f32(nvo_stream_t stream, uint32_t N, uint32_t degree, const float* dirs01,
+                         const float* dy, float* dd01);
+int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                 const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                 float* d_corrections);
+int nvo_se3_exp_map_bwd(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
+                        float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
+                        float* reg_loss, int mode);
 /* images: device float [F][H][W][C] -> out [R][C] */
 int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H,
                       uint32_t W, uint32_t C, const float* images, float* out);

@@ -79,6 +79,11 @@ _SIGNATURES = {
     # group B
     "nvo_raygen": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_se3_exp_map": (_int, [_p, _u32, _p, _p]),
+    "nvo_pose_exp_map": (_int, [_p, _u32, _p, _p, _int]),
+    "nvo_positions_bwd": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _p]),
+    "nvo_sh_bwd_input_f32": (_int, [_p, _u32, _u32, _p, _p, _p]),
+    "nvo_pose_bwd": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_se3_exp_map_bwd": (_int, [_p, _u32, _p, _p, _f, _f, _f, _p, _p, _int]),
     "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
     "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
     "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),

@@ -147,11 +147,22 @@ k_dirs01(uint32_t n, const float* __restrict__ d, float* __restrict__ out) {
 // exp_map_SE3 of nerfstudio's camera optimizer (cameras/lie_groups.py): tangent [n][6] = (translation
 // | rotation) -> [n][3][4], with the same small-angle Taylor branches (theta < 1e-2).
 __global__ void __launch_bounds__(256)
-k_se3_exp(uint32_t n, const float* __restrict__ tangent, float* __restrict__ out) {
+k_se3_exp(uint32_t n, const float* __restrict__ tangent, float* __restrict__ out, int mode) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* t = tangent + 6 * (size_t)i;
     const float lx = t[0], ly = t[1], lz = t[2], ax = t[3], ay = t[4], az = t[5];
+    if (mode == 1) {
+        // exp_map_SO3xR3: R = I + sin(a)/a K + (1-cos a)/a^2 K^2 with a = sqrt(max(|w|^2, 1e-4)), t = lin
+        const float ang = sqrtf(fmaxf(ax * ax + ay * ay + az * az, 1e-4f));
+        const float f1 = sinf(ang) / ang, f2 = (1.f - cosf(ang)) / (ang * ang);
+        float* o = out + 12 * (size_t)i;
+        o[0] = 1.f + f2 * (-az * az - ay * ay); o[1] = -f1 * az + f2 * ax * ay;         o[2] = f1 * ay + f2 * ax * az;
+        o[4] = f1 * az + f2 * ax * ay;          o[5] = 1.f + f2 * (-az * az - ax * ax); o[6] = -f1 * ax + f2 * ay * az;
+        o[8] = -f1 * ay + f2 * ax * az;         o[9] = f1 * ax + f2 * ay * az;          o[10] = 1.f + f2 * (-ay * ay - ax * ax);
+        o[3] = lx; o[7] = ly; o[11] = lz;
+        return;
+    }
     const float theta2 = ax * ax + ay * ay + az * az;
     const float theta = sqrtf(theta2);
     const bool nz = theta < 1e-2f;
@@ -177,11 +188,21 @@ k_se3_exp(uint32_t n, const float* __restrict__ tangent, float* __restrict__ out
 
 extern "C" {
 
+int nvo_pose_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out, int mode) {
+    NVO_REQUIRE(n == 0 || (tangent && out), "pose_exp_map: NULL argument");
+    NVO_REQUIRE(mode == 0 || mode == 1, "pose_exp_map: mode %d (0 = SE3, 1 = SO3xR3)", mode);
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "pose_exp_map");
+    NVO_LAUNCH(k_se3_exp, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tangent, out, mode);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
 int nvo_se3_exp_map(nvo_stream_t stream, uint32_t n, const float* tangent, float* out) {
     NVO_REQUIRE(n == 0 || (tangent && out), "se3_exp_map: NULL argument");
     if (n == 0) return NVO_OK;
     NVO_PROF(stream, "se3_exp_map");
-    NVO_LAUNCH(k_se3_exp, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tangent, out);
+    NVO_LAUNCH(k_se3_exp, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tangent, out, 0);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -48,9 +48,13 @@ k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, __half* __r
 }
 
 // dL/dd01 = 2 * sum_k dL/dy_k * dy_k/d(x,y,z)
+__device__ __forceinline__ float sh_to_float(__half v) { return __half2float(v); }
+__device__ __forceinline__ float sh_to_float(float v) { return v; }
+
+template <typename DY>
 __global__ void __launch_bounds__(256)
 k_sh_bwd_input(uint32_t N, uint32_t degree, const float* __restrict__ d01,
-               const __half* __restrict__ dy, uint32_t dy_stride, float* __restrict__ dd01) {
+               const DY* __restrict__ dy, uint32_t dy_stride, float* __restrict__ dd01) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float x = d01[3 * (size_t)i + 0] * 2.f - 1.f;
@@ -60,7 +64,7 @@ k_sh_bwd_input(uint32_t N, uint32_t degree, const float* __restrict__ d01,
     float g[16];
     const uint32_t n_coeff = degree * degree;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) g[k] = k < n_coeff ? __half2float(dy[(size_t)i * dy_stride + k]) : 0.f;
+    for (uint32_t k = 0; k < 16; ++k) g[k] = k < n_coeff ? sh_to_float(dy[(size_t)i * dy_stride + k]) : 0.f;
     float gx = 0.f, gy = 0.f, gz = 0.f;
     // degree 2
     gy += -0.48860251190291987f * g[1];
@@ -115,8 +119,21 @@ int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, con
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "sh_bwd_input");
-    NVO_LAUNCH(k_sh_bwd_input, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
+    NVO_LAUNCH(k_sh_bwd_input<__half>, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree,
                        d01, (const __half*)dy_half, dy_stride, dd01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+// dy: float [N][16] (the colour head's per-ray SH gradient) -> dd01 [N][3]
+extern "C" int nvo_sh_bwd_input_f32(void* stream, uint32_t N, uint32_t degree, const float* d01,
+                                    const float* dy, float* dd01) {
+    NVO_REQUIRE(degree >= 1 && degree <= 4, "sh_bwd_input_f32: degree %u not in 1..4", degree);
+    NVO_REQUIRE(N == 0 || (d01 && dy && dd01), "sh_bwd_input_f32: NULL argument");
+    if (N == 0) return NVO_OK;
+    NVO_PROF(stream, "sh_bwd_input");
+    NVO_LAUNCH(k_sh_bwd_input<float>, dim3(nvo_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, degree,
+               d01, dy, 16u, dd01);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -81,7 +81,10 @@ class EngineConfig:
     adam_eps: float = 1e-15
     adam_betas: tuple = (0.9, 0.999)
     max_num_iterations: int = 8192
-    optimize_poses: bool = False          # BASELINE config[1] "fixed poses"; SE3 gradient path: later round
+    optimize_poses: bool = False          # BASELINE configs[1] is "fixed poses"; True = the reference's SE3 optimiser
+    camera_mode: str = "SE3"              # "SE3" (reference's explicit config) | "SO3xR3" (nerfacto model default)
+    camera_trans_l2_penalty: float = 1e-2  # camera_opt_regularizer (nerfstudio >= 1.0 CameraOptimizer [UPSTREAM])
+    camera_rot_l2_penalty: float = 1e-3
     grid_bwd_mode: int = 1                # 1 = LDS slice-owner scatter, 0 = global atomics
     seed: int = 1337
 
@@ -157,6 +160,9 @@ class NerfactoEngine:
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
         self._graphs = {}
         self._pix_scale = None
+        self.corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
+        self.d_corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
+        self._pose_inputs = None  # (intrinsics, c2w) of the rays currently loaded (pose backward)
         self.opt_steps = {g: 0 for g in self.group_ranges}
         self.step = 0
         self.steps_since_proposal_update = 0
@@ -239,6 +245,14 @@ class NerfactoEngine:
             ws[f"weights{k}"] = torch.empty(N, **f32)
             if training:
                 ws[f"dout{k}"] = torch.empty(N, 16, **f16)
+                if self.cfg.optimize_poses:
+                    ws[f"dx{k}"] = torch.empty(N, 3, **f32)
+        if training and self.cfg.optimize_poses:
+            ws["ray_indices"] = torch.zeros(R, 3, dtype=torch.int64, device=dev)
+            ws["d_origin"] = torch.empty(R, 3, **f32)
+            ws["d_dir"] = torch.empty(R, 3, **f32)
+            ws["d_sh"] = torch.empty(R, 16, **f32)
+            ws["d_dirs01"] = torch.empty(R, 3, **f32)
         Nm = R * self.levels[-1]
         ws["rgb"] = torch.empty(Nm, 16, **f16)
         if training:
@@ -305,7 +319,7 @@ class NerfactoEngine:
             drgb=ws["drgb"].data_ptr() if training else None,
             d_base_out=ws[f"dout{km}"].data_ptr() if training else None,
             d_embedding=self._param_ptr("field.embedding", self.grads).value if training else None,
-            d_sh=None,
+            d_sh=ws["d_sh"].data_ptr() if (training and "d_sh" in ws) else None,
             d_weights=self._param_ptr("field.color", self.grads).value if training else None)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool):
@@ -357,6 +371,15 @@ class NerfactoEngine:
         stream = _stream(self.device)
         R = ws["R"]
         H, W = images.shape[1], images.shape[2]
+        if corrections is None and self.cfg.optimize_poses:
+            # CameraOptimizer.forward: exp_map_SE3(pose_adjustment) for every camera, gathered by raygen
+            _call("nvo_pose_exp_map", stream, self.cfg.num_images,
+                  self._param_ptr("camera_opt.pose_adjustment", self.params), _ptr(self.corrections),
+                  self._pose_mode())
+            corrections = self.corrections
+            if "ray_indices" in ws:
+                ws["ray_indices"].copy_(ray_indices)
+            self._pose_inputs = (intrinsics, c2w)
         _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corrections),
               _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]),
               _ptr(ws["cam_idx"]))
@@ -392,12 +415,16 @@ class NerfactoEngine:
         ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev)
         km = len(self.prop_nets)
         R = ws["R"]
+        pose = cfg.optimize_poses and "d_sh" in ws and self._pose_inputs is not None
         la = self._main_loss_args(ws, True, has_depth)
         _call("nvo_main_render_loss", stream, C.byref(la))
+        if pose:
+            ws["d_sh"].zero_()
         _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
         _call("nvo_bwd", self.base_net.handle, stream, R * self.levels[km], _ptr(ws[f"x{km}"]),
               self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
-              _ptr(ws[f"ctx{km}"]), None, self._param_ptr("field.base", self.grads))
+              _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]) if pose else None,
+              self._param_ptr("field.base", self.grads))
         if update_proposals:
             inv_rays = 1.0 / (R * self.world_size)
             for k, net in enumerate(self.prop_nets):
@@ -413,9 +440,39 @@ class NerfactoEngine:
                 _call("nvo_prop_loss", stream, C.byref(pa))
                 _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
                       self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
-                      _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), None,
+                      _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
                       self._param_ptr(f"proposal.{k}", self.grads))
+        if pose:
+            self._pose_backward(ws, update_proposals, stream)
         return update_proposals
+
+    def _pose_backward(self, ws, update_proposals: bool, stream) -> None:
+        """dL/dx01 of every level that ran backward + the SH direction gradient -> dL/dpose_adjustment
+        (written into the camera_opt range of self.grads, loss-scaled like every other gradient)."""
+        cfg = self.cfg
+        R = ws["R"]
+        km = len(self.prop_nets)
+        ws["d_origin"].zero_()
+        ws["d_dir"].zero_()
+        levels = ([0, 1] if update_proposals else []) + [km]
+        for k in levels:
+            _call("nvo_positions_bwd", stream, R, self.levels[k], _ptr(ws["origins"]), _ptr(ws["directions"]),
+                  _ptr(ws[f"tbins{k}"]), _ptr(ws[f"dx{k}"]), _ptr(ws["d_origin"]), _ptr(ws["d_dir"]))
+        _call("nvo_sh_bwd_input_f32", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["d_sh"]), _ptr(ws["d_dirs01"]))
+        self.d_corrections.zero_()
+        intr, c2w = self._pose_inputs
+        _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+              _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
+        # regulariser: its value goes to loss slot 5 of shard 0, its gradient is scaled like the rest
+        reg_scale = cfg.loss_scale / self.world_size
+        _call("nvo_se3_exp_map_bwd", stream, cfg.num_images,
+              self._param_ptr("camera_opt.pose_adjustment", self.params), _ptr(self.d_corrections),
+              cfg.camera_trans_l2_penalty, cfg.camera_rot_l2_penalty, reg_scale,
+              self._param_ptr("camera_opt.pose_adjustment", self.grads),
+              C.c_void_p(self.losses.data_ptr() + 5 * 4), self._pose_mode())
+
+    def _pose_mode(self) -> int:
+        return {"SE3": 0, "SO3xR3": 1}[self.cfg.camera_mode]
 
     _GROUP_ORDER = ("fields", "proposal_networks", "camera_opt")
 
@@ -574,6 +631,8 @@ class NerfactoEngine:
         vals = self.losses.sum(dim=0).tolist()
         d = {"rgb_loss": vals[0], "distortion_loss": vals[1], "depth_loss": vals[2] + vals[4],
              "interlevel_loss": vals[3]}
+        if self.cfg.optimize_poses:
+            d["camera_opt_regularizer"] = vals[5]
         return d
 
     # ------------------------------------------------------------------------------------------

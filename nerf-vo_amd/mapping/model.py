@@ -74,8 +74,9 @@ class CameraOptimizer(torch.nn.Module):
             return torch.eye(4, device=self.engine.device)[None, :3, :4].repeat(indices.shape[0], 1, 1)
         tangent = self.pose_adjustment[indices.to(self.engine.device).long()].contiguous()
         out = torch.empty(tangent.shape[0], 3, 4, device=tangent.device)
-        _lib.check(_lib.lib().nvo_se3_exp_map(_stream(tangent.device), tangent.shape[0], _ptr(tangent), _ptr(out)),
-                   "nvo_se3_exp_map")
+        mode = 1 if self.config.mode == "SO3xR3" else 0
+        _lib.check(_lib.lib().nvo_pose_exp_map(_stream(tangent.device), tangent.shape[0], _ptr(tangent), _ptr(out), mode),
+                   "nvo_pose_exp_map")
         return out
 
     def all_corrections(self) -> torch.Tensor:
@@ -94,7 +95,11 @@ class ExtendedNerfactoModel:
             num_proposal_samples=tuple(config.num_proposal_samples_per_ray),
             num_nerf_samples=config.num_nerf_samples_per_ray, interlevel_loss_mult=config.interlevel_loss_mult,
             distortion_loss_mult=config.distortion_loss_mult, depth_loss_mult=config.depth_loss_mult,
-            depth_sigma=config.depth_sigma, max_num_iterations=max_num_iterations, seed=seed)
+            depth_sigma=config.depth_sigma, max_num_iterations=max_num_iterations, seed=seed,
+            optimize_poses=config.camera_optimizer.mode in ("SE3", "SO3xR3"),
+            camera_mode=config.camera_optimizer.mode if config.camera_optimizer.mode in ("SE3", "SO3xR3") else "SE3",
+            camera_trans_l2_penalty=config.camera_optimizer.trans_l2_penalty,
+            camera_rot_l2_penalty=config.camera_optimizer.rot_l2_penalty)
         self.engine = NerfactoEngine(ecfg, self.device, world_size=world_size)
         self.camera_optimizer = CameraOptimizer(config.camera_optimizer, self.engine)
         self.training = True

@@ -90,6 +90,31 @@ def exp_map_se3(tangent):
     return torch.cat([rot, trans], dim=2)
 
 
+def exp_map_so3xr3(tangent):
+    """nerfstudio cameras/lie_groups.py exp_map_SO3xR3: Rodrigues rotation (|w|^2 clamped at 1e-4) and
+    the translation taken directly from the tangent's first three entries."""
+    log_rot = tangent[:, 3:]
+    nrms = (log_rot * log_rot).sum(1)
+    rot_angles = torch.clamp(nrms, 1e-4).sqrt()
+    inv = 1.0 / rot_angles
+    fac1 = inv * rot_angles.sin()
+    fac2 = inv * inv * (1.0 - rot_angles.cos())
+    n = tangent.shape[0]
+    zeros = torch.zeros(n, dtype=tangent.dtype)
+    skews = torch.stack([
+        torch.stack([zeros, -log_rot[:, 2], log_rot[:, 1]], dim=1),
+        torch.stack([log_rot[:, 2], zeros, -log_rot[:, 0]], dim=1),
+        torch.stack([-log_rot[:, 1], log_rot[:, 0], zeros], dim=1)], dim=1)
+    rot = fac1[:, None, None] * skews + fac2[:, None, None] * (skews @ skews) + torch.eye(3, dtype=tangent.dtype)[None]
+    return torch.cat([rot, tangent[:, :3, None]], dim=2)
+
+
+def camera_opt_regularizer(pose_adjustment, trans_l2_penalty=1e-2, rot_l2_penalty=1e-3):
+    """CameraOptimizer.get_loss_dict (nerfstudio >= 1.0 [UPSTREAM])."""
+    return (pose_adjustment[:, :3].norm(dim=-1).mean() * trans_l2_penalty
+            + pose_adjustment[:, 3:].norm(dim=-1).mean() * rot_l2_penalty)
+
+
 def apply_pose_correction(origins, directions, corrections):
     """CameraOptimizer.apply_to_raybundle: o += t, d = R d (corrections [R,3,4] already gathered)."""
     return origins + corrections[:, :3, 3], torch.einsum("rij,rj->ri", corrections[:, :3, :3], directions)
