@@ -56,7 +56,24 @@ k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ ds
         dst[i] = (_Float16)src[i];
 }
 
+__global__ void __launch_bounds__(256)
+k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+
 }  // namespace
+
+int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    NVO_REQUIRE((bytes & 3u) == 0 && ((uintptr_t)ptr & 3u) == 0, "zero_async: %zu bytes not 4-byte granular", bytes);
+    if (bytes == 0) return NVO_OK;
+    const uint64_t n = bytes / 4;
+    uint32_t blocks = nvo_div_up(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_zero_u32, dim3(blocks), dim3(256), 0, stream, (uint32_t*)ptr, n);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
 
 extern "C" {
 
@@ -82,7 +99,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag) {
     NVO_REQUIRE(grads && flag, "nonfinite_flag: NULL argument");
     NVO_PROF(stream, "nonfinite_flag");
-    NVO_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), (hipStream_t)stream));
+    if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;

@@ -428,7 +428,8 @@ struct MlpModule : nvo_module_s {
         a.dinput = din;
         a.din_mode = NVO_IO_F32_ROWS;
         a.dweights = dparams;
-        if (dparams) NVO_CHECK_HIP(hipMemsetAsync(dparams, 0, sizeof(float) * n_params, s));
+        if (dparams)
+            if (int rc = nvo_zero_async(dparams, sizeof(float) * n_params, s)) return rc;
         return nvo_mlp_bwd_launch(in_pad, width, n_hidden, out_pad, a, s);
     }
 };
@@ -474,7 +475,8 @@ struct NwieModule : nvo_module_s {
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
-        if (dparams) NVO_CHECK_HIP(hipMemsetAsync(dparams, 0, sizeof(float) * net->n_params, s));
+        if (dparams)
+            if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {

@@ -523,16 +523,15 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
     const size_t grad_bytes = sizeof(float) * 2 * (size_t)g.offset[g.n_levels];
     NVO_PROF(stream, "grid_bwd_%s[L%u]", (mode == 1 && slices && slices->n_slices) ? "lds" : "atomic", g.n_levels);
     if (N == 0) {
-        NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
-        return NVO_OK;
+        return nvo_zero_async(grad, grad_bytes, stream);
     }
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     if (mode == 1 && slices && slices->n_slices) {
         if (slices->zero_last > slices->zero_first) {
             // chunked (atomically flushed) levels form one contiguous run of entries
-            NVO_CHECK_HIP(hipMemsetAsync(grad + 2 * (size_t)slices->zero_first, 0,
-                                         sizeof(float) * 2 * (size_t)(slices->zero_last - slices->zero_first),
-                                         stream));
+            if (int rc = nvo_zero_async(grad + 2 * (size_t)slices->zero_first,
+                                        sizeof(float) * 2 * (size_t)(slices->zero_last - slices->zero_first), stream))
+                return rc;
         }
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
         const size_t lds = kLdsBwdBytes;
@@ -557,7 +556,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         NVO_CHECK_LAUNCH();
         return NVO_OK;
     }
-    NVO_CHECK_HIP(hipMemsetAsync(grad, 0, grad_bytes, stream));
+    if (int rc = nvo_zero_async(grad, grad_bytes, stream)) return rc;
     const uint32_t tiles = nvo_div_up(N, kGridBlock / 2);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_AT(SOA_, T_)                                                               \
@@ -578,7 +577,8 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
                               bool dy_is_float, bool soa, float* dx, bool zero_dx) {
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "grid_bwd_input[L%u]", g.n_levels);
-    if (zero_dx) NVO_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * 3 * (size_t)N, stream));
+    if (zero_dx)
+        if (int rc = nvo_zero_async(dx, sizeof(float) * 3 * (size_t)N, stream)) return rc;
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_IN(SOA_, T_)                                                               \

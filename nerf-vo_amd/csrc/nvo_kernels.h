@@ -2,6 +2,12 @@
 #pragma once
 #include "nvo_common.h"
 
+// ---- fill (adam.hip) -------------------------------------------------------------------------
+// Zero `bytes` (multiple of 4) of device memory with a KERNEL.  hipMemsetAsync is avoided on every
+// path that can be captured into a hipGraph: on ROCm 7.2 a captured 4-byte memset node replayed as
+// byte value 0x01 (observed: the optimiser's skip flag read back 0x01010101 after graph replay).
+int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 // ---- grid.hip -------------------------------------------------------------------------------
 struct NvoGridSlices {
     uint32_t n_slices = 0;

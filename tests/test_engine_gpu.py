@@ -294,8 +294,18 @@ def test_graph_replay_matches_eager_semantics(device):
     assert scalars[0][2] == pytest.approx(0.1, rel=1e-5) and scalars[9][2] == pytest.approx(1 - 0.9 ** 10, rel=1e-5)
     assert scalars[5][0] > scalars[1][0] > 0.0  # anneal ramps up
     assert not torch.equal(p0, eng.params)
-    # warm-up inside capture must not have advanced the optimiser: first replay applied exactly step 1
     assert len(eng._graphs) == 2
+    # the optimiser must really have run on every replay: the GradScaler-style skip flag stays 0
+    # (regression: a captured 4-byte hipMemsetAsync replayed as 0x01 bytes and silently disabled Adam)
+    assert int(eng.skip_flag.item()) == 0
+    # same sequence launched eagerly reaches the same loss level
+    eng2 = NerfactoEngine(EngineConfig(num_images=n, num_rays=1024), device)
+    c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+    for it in range(40):
+        idx = torch.floor(torch.rand(1024, 3, device=device) * torch.tensor([n, H, W], device=device)).long()
+        eng2.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth)
+    eager = eng2.loss_dict()["rgb_loss"]
+    assert abs(np.log(losses[-1] / eager)) < 0.35, (losses[-1], eager)
 
 
 @pytest.mark.parametrize("mode", ["SE3", "SO3xR3"])
