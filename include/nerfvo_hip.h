@@ -256,6 +256,31 @@ int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
 
 /* ------------------------------------------------------------------------------------------------
+ * F. Cascaded occupancy grid (instant-ngp testbed: generate_training_samples_nerf,
+ *    ema_grid_samples_nerf, grid_to_bitfield, bitfield_max_pool -- the back-end behind
+ *    `mapping_module: 'instant-ngp'`, /root/reference/nerf_vo/mapping/instant_ngp.py:33-50,104-105;
+ *    nerfacc 0.5.2 traverse_grids / OccGridEstimator, /root/reference/requirements.txt:113).
+ *    Normalised frame: cascade 0 covers [0,1]^3, cascade k covers [0.5 - 2^(k-1), 0.5 + 2^(k-1)]^3;
+ *    128^3 cells per cascade in Morton order; bitfield = device uint8 [n_levels][128^3 / 8].
+ * ---------------------------------------------------------------------------------------------- */
+/* DDA march of R rays (unit directions) with deterministic packing: counts[R], offsets[R+1]
+ * (exclusive scan, offsets[R] = total), then (ray_idx, t, dt)[capacity] written at the offsets.  Rays
+ * whose samples would not fit get count 0.  jitter: device float [R] in [0,1) or NULL.
+ * Step size dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 1024). */
+int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                  const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                  uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
+                  float* dt_out);
+/* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
+ * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
+ * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.
+ * scratch8: 8 bytes of device scratch. */
+int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* fresh, float decay,
+                   float threshold, uint8_t* bitfield, void* scratch8);
+/* centres (or jittered points, jitter device float [128^3][3]) of cascade `level` cells, Morton order */
+int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, float* positions);
+
+/* ------------------------------------------------------------------------------------------------
  * E. Optimiser (torch.optim.Adam as configured at /root/reference/nerf_vo/mapping/nerfstudio.py:84-100
  *    + GradScaler's skip-on-non-finite from mixed_precision=True, nerfstudio.py:59).
  * ---------------------------------------------------------------------------------------------- */

@@ -96,6 +96,10 @@ _SIGNATURES = {
     # group D
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
+    # group F
+    "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p]),
+    "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
+    "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     # group E
     "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
     "nvo_write_floats": (_int, [_p, _p, _u32, _p]),

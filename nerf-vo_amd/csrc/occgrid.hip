@@ -1,0 +1,342 @@
+// Cascaded Morton-bitfield occupancy grid for gfx950: DDA ray marcher with deterministic packed
+// output, density-grid EMA update, bitfield construction + cascade max-pool.
+// Replaces instant-ngp's generate_training_samples_nerf / ema_grid_samples_nerf / grid_to_bitfield /
+// bitfield_max_pool (SURVEY.md section 2.4 K13/K16 -- the `mapping_module: 'instant-ngp'` back-end,
+// /root/reference/nerf_vo/mapping/instant_ngp.py:33-50,104-105) and nerfacc's traverse_grids (K17).
+// CPU restatement: oracle/c/nvo_oracle.c (bit-exact: same IEEE operations in the same order; this
+// file is compiled with -ffp-contract=off).
+//
+// MI355X notes
+//  * The whole 3-cascade bitfield is 768 KiB: it lives in L2 (4 MiB per XCD) after the first touch;
+//    one lane marches one ray (divergent trip counts), a wave = 64 neighbouring rays.
+//  * Packing is deterministic: pass 1 counts the occupied steps per ray, a single-workgroup
+//    wave-scan turns counts into offsets (ballot-free exclusive prefix sum with a carry across 64-lane
+//    chunks), pass 2 re-marches and writes (ray, t, dt) at the ray's offset.  No global atomics, no
+//    dependence on dispatch order; a ray whose samples would exceed the capacity gets count 0 in
+//    the scan (instant-ngp drops such rays too).
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+namespace {
+
+constexpr int kG = 128;
+constexpr uint32_t kCells = 128u * 128u * 128u;
+constexpr uint32_t kMaxSteps = 1024u;
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ float min_step() { return 1.7320508075688772f / 1024.0f; }
+__device__ __forceinline__ float max_step() { return (1.7320508075688772f / 1024.0f) * 128.0f * 1024.0f / 128.0f; }
+__device__ __forceinline__ float calc_dt(float t, float cone_angle) {
+    float dt = t * cone_angle;
+    if (dt < min_step()) dt = min_step();
+    if (dt > max_step()) dt = max_step();
+    return dt;
+}
+__device__ __forceinline__ int mip_from_pos(const float* p, int max_mip) {
+    float m = fabsf(p[0] - 0.5f);
+    if (fabsf(p[1] - 0.5f) > m) m = fabsf(p[1] - 0.5f);
+    if (fabsf(p[2] - 0.5f) > m) m = fabsf(p[2] - 0.5f);
+    int e;
+    frexpf(m, &e);
+    int mip = e + 1;
+    if (mip < 0) mip = 0;
+    if (mip > max_mip) mip = max_mip;
+    return mip;
+}
+__device__ __forceinline__ int mip_from_dt(float dt, const float* p, int max_mip) {
+    int mip = mip_from_pos(p, max_mip);
+    dt *= 2.0f * (float)kG;
+    if (dt < 1.0f) return mip;
+    int e;
+    frexpf(dt, &e);
+    if (e > mip) mip = e;
+    if (mip > max_mip) mip = max_mip;
+    return mip;
+}
+__device__ __forceinline__ uint32_t cell_index(const float* p, int mip) {
+    const float s = scalbnf(1.0f, -mip);
+    int i[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = (p[k] - 0.5f) * s + 0.5f;
+        i[k] = (int)(v * (float)kG);
+        if (i[k] < 0 || i[k] >= kG) return 0xFFFFFFFFu;
+    }
+    return morton3d((uint32_t)i[0], (uint32_t)i[1], (uint32_t)i[2]);
+}
+__device__ __forceinline__ bool occupied(const float* p, const uint8_t* __restrict__ bitfield, int mip) {
+    const uint32_t idx = cell_index(p, mip);
+    if (idx == 0xFFFFFFFFu) return false;
+    return (bitfield[idx / 8 + (size_t)mip * (kCells / 8)] >> (idx % 8)) & 1;
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, const float* p, const float* d,
+                                                       const float* idir, int mip) {
+    const float res = scalbnf((float)kG, -mip);
+    float tmin = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float q = res * (p[k] - 0.5f);
+        const float tk = (floorf(q + 0.5f + 0.5f * sgn(d[k])) - q) * idir[k];
+        if (tk < tmin) tmin = tk;
+    }
+    float dist = tmin / res;
+    if (!(dist > 0.0f)) dist = 0.0f;
+    const float t_target = t + dist;
+    do {
+        t += calc_dt(t, cone_angle);
+    } while (t < t_target);
+    return t;
+}
+
+// WRITE == false: count only.  WRITE == true: write (ray, t, dt) at offsets[r] (rays with capped == 0 skip)
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restrict__ directions,
+            const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
+            const float* __restrict__ jitter, uint32_t* __restrict__ counts,
+            const uint32_t* __restrict__ offsets, uint32_t capacity, int32_t* __restrict__ ray_idx,
+            float* __restrict__ t_out, float* __restrict__ dt_out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int max_mip = n_levels - 1;
+    const float half = 0.5f * (float)(1 << max_mip);
+    const float lo = 0.5f - half, hi = 0.5f + half;
+    float o[3], d[3], idir[3];
+    float tmin = t_near, tmax = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = origins[3 * (size_t)r + k];
+        d[k] = directions[3 * (size_t)r + k];
+        idir[k] = 1.0f / d[k];
+        float t0 = (lo - o[k]) * idir[k], t1 = (hi - o[k]) * idir[k];
+        if (t0 > t1) { const float tt = t0; t0 = t1; t1 = tt; }
+        if (t0 > tmin) tmin = t0;
+        if (t1 < tmax) tmax = t1;
+    }
+    uint32_t base = 0, limit = 0;
+    if (WRITE) {
+        base = offsets[r];
+        limit = counts[r];
+        if (limit == 0 || base + limit > capacity) return;
+    }
+    uint32_t j = 0;
+    if (tmax > tmin) {
+        float t = tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);
+        for (;;) {
+            float p[3];
+            bool inside = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[k] = o[k] + d[k] * t;
+                inside = inside && p[k] >= lo && p[k] <= hi;
+            }
+            if (!inside || j >= kMaxSteps) break;
+            const float dt = calc_dt(t, cone_angle);
+            const int mip = mip_from_dt(dt, p, max_mip);
+            if (occupied(p, bitfield, mip)) {
+                if (WRITE) {
+                    ray_idx[base + j] = (int32_t)r;
+                    t_out[base + j] = t;
+                    dt_out[base + j] = dt;
+                }
+                ++j;
+                t += dt;
+            } else {
+                t = advance_to_next_voxel(t, cone_angle, p, d, idir, mip);
+            }
+        }
+    }
+    if (!WRITE) counts[r] = j;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Single-workgroup exclusive scan of counts[n] -> offsets[n], total in offsets[n]; entries that would
+// push the running total beyond `capacity` are treated as 0 (and zeroed in counts).
+__global__ void __launch_bounds__(1024)
+k_scan_counts(uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t capacity) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < n ? counts[i] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(c, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t prefix = carry_s;
+        for (int w = 0; w < wave; ++w) prefix += wave_tot[w];
+        uint32_t excl = prefix + incl - c;
+        if (i < n) offsets[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = prefix + incl;
+        __syncthreads();
+    }
+    // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024)
+        if (offsets[i] + counts[i] > capacity) counts[i] = 0;
+    if (threadIdx.x == 0) offsets[n] = carry_s;
+}
+
+// instant-ngp ema_grid_samples_nerf: never-seen cells (negative) stay; others max(decay * old, new)
+__global__ void __launch_bounds__(256)
+k_occ_ema(uint64_t n, float* __restrict__ grid, const float* __restrict__ fresh, float decay) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float prev = grid[i];
+    grid[i] = prev < 0.f ? prev : fmaxf(prev * decay, fresh[i]);
+}
+
+// sum of max(v, 0) over cascade 0 (fixed-point so the mean is order independent / reproducible)
+__global__ void __launch_bounds__(256)
+k_occ_sum(const float* __restrict__ grid, unsigned long long* __restrict__ acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = i < kCells ? fmaxf(grid[i], 0.f) : 0.f;
+    // 2^-20 resolution fixed point, block-reduced in LDS integer atomics (fast on gfx950)
+    __shared__ unsigned long long s;
+    if (threadIdx.x == 0) s = 0ull;
+    __syncthreads();
+    atomicAdd(&s, (unsigned long long)(long long)llrintf(v * 1048576.0f));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+
+__global__ void __launch_bounds__(256)
+k_occ_bitfield(const float* __restrict__ grid, int n_levels, float threshold,
+               const unsigned long long* __restrict__ acc, uint8_t* __restrict__ bitfield) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (uint64_t)n_levels * (kCells / 8)) return;
+    const float mean = (float)((double)(*acc) / 1048576.0 / (double)kCells);
+    const float th = mean < threshold ? mean : threshold;
+    uint8_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (grid[b * 8 + j] > th) bits |= (uint8_t)(1u << j);
+    bitfield[b] = bits;
+}
+
+// coarse level `l` |= 2x2x2 max-pool of level l-1 over its inner half (one thread per coarse cell)
+__global__ void __launch_bounds__(256)
+k_occ_maxpool(int l, uint8_t* __restrict__ bitfield) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64u * 64u * 64u) return;
+    const uint32_t x = i & 63u, y = (i >> 6) & 63u, z = i >> 12;
+    const uint8_t* fine = bitfield + (size_t)(l - 1) * (kCells / 8);
+    const uint32_t fi = morton3d(2 * x, 2 * y, 2 * z);  // multiple of 8: one byte = the 2x2x2 block
+    if (fine[fi / 8]) {
+        const uint32_t ci = morton3d(x + 32, y + 32, z + 32);
+        // 8 threads may share a destination byte: set the bit atomically on the enclosing word
+        uint32_t* word = reinterpret_cast<uint32_t*>(bitfield + (size_t)l * (kCells / 8)) + (ci / 32);
+        atomicOr(word, 1u << (ci % 32));
+    }
+}
+
+// cell centres of one cascade in Morton order, normalised frame; jitter [cells][3] in [0,1) or null
+__global__ void __launch_bounds__(256)
+k_occ_cell_positions(int level, const float* __restrict__ jitter, float* __restrict__ pos) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= kCells) return;
+    // inverse Morton
+    uint32_t c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t v = (x >> k) & 0x49249249u;
+        v = (v ^ (v >> 2)) & 0xC30C30C3u;
+        v = (v ^ (v >> 4)) & 0x0F00F00Fu;
+        v = (v ^ (v >> 8)) & 0xFF0000FFu;
+        v = (v ^ (v >> 16)) & 0x0000FFFFu;
+        c[k] = v;
+    }
+    const float scale = scalbnf(1.0f, level);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float u = ((float)c[k] + (jitter ? jitter[3 * (size_t)x + k] : 0.5f)) / (float)kG;
+        pos[3 * (size_t)x + k] = (u - 0.5f) * scale + 0.5f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                  const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                  uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
+                  float* dt_out) {
+    NVO_REQUIRE(n_levels >= 1 && n_levels <= 8, "occ_march: n_levels %d not in 1..8", n_levels);
+    NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts && offsets && ray_idx && t_out && dt_out),
+                "occ_march: NULL argument");
+    if (R == 0) return NVO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        NVO_PROF(stream, "occ_march_count");
+        NVO_LAUNCH(k_occ_march<false>, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
+                   n_levels, cone_angle, t_near, jitter, counts, offsets, capacity, ray_idx, t_out, dt_out);
+        NVO_CHECK_LAUNCH();
+    }
+    {
+        NVO_PROF(stream, "occ_scan");
+        NVO_LAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, R, counts, offsets, capacity);
+        NVO_CHECK_LAUNCH();
+    }
+    {
+        NVO_PROF(stream, "occ_march_write");
+        NVO_LAUNCH(k_occ_march<true>, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
+                   n_levels, cone_angle, t_near, jitter, counts, offsets, capacity, ray_idx, t_out, dt_out);
+        NVO_CHECK_LAUNCH();
+    }
+    return NVO_OK;
+}
+
+int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* fresh, float decay,
+                   float threshold, uint8_t* bitfield, void* scratch8) {
+    NVO_REQUIRE(n_levels >= 1 && n_levels <= 8 && grid && bitfield && scratch8, "occ_update: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    NVO_PROF(stream, "occ_update");
+    const uint64_t n = (uint64_t)n_levels * kCells;
+    if (fresh) {
+        NVO_LAUNCH(k_occ_ema, dim3(nvo_div_up(n, 256)), dim3(256), 0, s, n, grid, fresh, decay);
+        NVO_CHECK_LAUNCH();
+    }
+    if (int rc = nvo_zero_async(scratch8, 8, s)) return rc;
+    NVO_LAUNCH(k_occ_sum, dim3(kCells / 256), dim3(256), 0, s, grid, (unsigned long long*)scratch8);
+    NVO_CHECK_LAUNCH();
+    NVO_LAUNCH(k_occ_bitfield, dim3(nvo_div_up(n / 8, 256)), dim3(256), 0, s, grid, n_levels, threshold,
+               (const unsigned long long*)scratch8, bitfield);
+    NVO_CHECK_LAUNCH();
+    for (int l = 1; l < n_levels; ++l) {
+        NVO_LAUNCH(k_occ_maxpool, dim3(64 * 64 * 64 / 256), dim3(256), 0, s, l, bitfield);
+        NVO_CHECK_LAUNCH();
+    }
+    return NVO_OK;
+}
+
+int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, float* positions) {
+    NVO_REQUIRE(level >= 0 && level < 8 && positions, "occ_cell_positions: bad argument");
+    NVO_PROF(stream, "occ_cell_positions");
+    NVO_LAUNCH(k_occ_cell_positions, dim3(kCells / 256), dim3(256), 0, (hipStream_t)stream, level, jitter, positions);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+}  // extern "C"

@@ -102,6 +102,19 @@ def build():
     e = Rr.exp_map_se3(tang)
     out["g9_exp"] = e.numpy()
     out["g9_multiply"] = Rr.pose_multiply(e[:4], e[4:]).numpy()
+    # G6b occupancy DDA hit lists on a seeded bitfield (bit-exact integer/IEEE path)
+    from oracle import occgrid as O
+    rng_o = np.random.default_rng(51)
+    ogrid = (rng_o.random((3, O.CELLS), dtype=np.float32) ** 6) * 0.08
+    obf = O.grid_to_bitfield(ogrid, 3)
+    oo = (rng_o.random((16, 3), dtype=np.float32) - 0.5) * 0.8 + 0.5
+    od = rng_o.normal(size=(16, 3)).astype(np.float32)
+    od /= np.linalg.norm(od, axis=1, keepdims=True)
+    ojit = rng_o.random(16).astype(np.float32)
+    oc, ot, odt = O.march_rays(oo, od, obf, 3, 1 / 256, 0.0, ojit, max_out=64)
+    out["g6b_occ_origins"], out["g6b_occ_dirs"], out["g6b_occ_jitter"] = oo, od, ojit
+    out["g6b_occ_counts"], out["g6b_occ_t"], out["g6b_occ_dt"] = oc, ot, odt
+    out["g6b_occ_bitfield_popcount"] = np.array([int(np.unpackbits(obf[l]).sum()) for l in range(3)])
     # G10 PSNR (both definitions)
     rng = np.random.default_rng(41)
     a = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)

@@ -1,0 +1,134 @@
+"""GPU: cascaded occupancy grid (Morton bitfield, DDA marcher, EMA/bitfield/max-pool update) vs the C
+oracle -- BIT-EXACT: occupancy hits, per-ray sample counts, the t/dt of every sample, bitfield bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _scene_grid(n_levels, seed):
+    """A blobby density field so that rays cross empty and occupied regions in every cascade."""
+    from oracle import occgrid as O
+
+    rng = np.random.default_rng(seed)
+    grid = (rng.random((n_levels, O.CELLS), dtype=np.float32) ** 6) * 0.08
+    grid[:, ::7] = 0.0
+    grid[0, :1000] = -1.0  # never-visible cells stay negative through the EMA
+    return grid
+
+
+@pytest.mark.parametrize("n_levels,cone", [(3, 1.0 / 256.0), (1, 0.0), (5, 0.004)])
+def test_march_bit_exact(device, n_levels, cone):
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    grid = _scene_grid(n_levels, 1)
+    bf = O.grid_to_bitfield(grid, n_levels)
+    rng = np.random.default_rng(2)
+    R = 512
+    o = (rng.random((R, 3), dtype=np.float32) - 0.5) * 0.9 + 0.5
+    o[:8] = rng.random((8, 3), dtype=np.float32) * 6 - 2.5  # some origins outside every cascade
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[8] = (1.0, 0.0, 0.0)  # axis-aligned ray: infinite inverse direction components
+    jit = rng.random(R).astype(np.float32)
+    cap = R * 1024
+    od, dd, jd = (torch.from_numpy(a).to(device) for a in (o, d, jit))
+    bfd = torch.from_numpy(bf).to(device)
+    counts = torch.zeros(R, dtype=torch.int32, device=device)
+    offsets = torch.zeros(R + 1, dtype=torch.int32, device=device)
+    ridx = torch.full((cap,), -1, dtype=torch.int32, device=device)
+    t = torch.zeros(cap, device=device)
+    dt = torch.zeros(cap, device=device)
+    _lib.check(lib.nvo_occ_march(_stream(), R, _p(od), _p(dd), _p(bfd), n_levels, cone, 0.0, _p(jd), cap, _p(counts),
+                                 _p(offsets), _p(ridx), _p(t), _p(dt)), "occ_march")
+    torch.cuda.synchronize()
+    rc, rt, rdt = O.march_rays(o, d, bf, n_levels, cone, 0.0, jit)
+    got_c = counts.cpu().numpy().astype(np.uint32)
+    assert (got_c == rc).all(), f"{int((got_c != rc).sum())} rays with different sample counts"
+    assert rc.sum() > 1000 and ((rc == 0).any() or n_levels > 3)
+    off = offsets.cpu().numpy().astype(np.int64)
+    assert (off[:-1] == np.concatenate([[0], np.cumsum(rc)[:-1]])).all() and off[-1] == rc.sum()
+    tt, dtt, rr = t.cpu().numpy(), dt.cpu().numpy(), ridx.cpu().numpy()
+    for r in range(R):
+        n = int(rc[r])
+        sl = slice(off[r], off[r] + n)
+        assert (rr[sl] == r).all()
+        assert (tt[sl].view(np.uint32) == rt[r, :n].view(np.uint32)).all(), f"ray {r}: t differs"
+        assert (dtt[sl].view(np.uint32) == rdt[r, :n].view(np.uint32)).all(), f"ray {r}: dt differs"
+
+
+def test_capacity_drops_whole_rays(device):
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    bf = np.full((1, O.CELLS // 8), 0xFF, np.uint8)  # everything occupied
+    R = 64
+    o = np.full((R, 3), 0.5, np.float32)
+    d = np.tile(np.array([[0.6, 0.64, 0.48]], np.float32), (R, 1))
+    cap = 1000
+    tens = [torch.from_numpy(a).to(device) for a in (o, d, bf)]
+    counts = torch.zeros(R, dtype=torch.int32, device=device)
+    offsets = torch.zeros(R + 1, dtype=torch.int32, device=device)
+    ridx = torch.full((cap,), -1, dtype=torch.int32, device=device)
+    t = torch.zeros(cap, device=device)
+    dt = torch.zeros(cap, device=device)
+    _lib.check(lib.nvo_occ_march(_stream(), R, _p(tens[0]), _p(tens[1]), _p(tens[2]), 1, 0.0, 0.0, None, cap,
+                                 _p(counts), _p(offsets), _p(ridx), _p(t), _p(dt)), "occ_march")
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy()
+    per_ray = c[0]
+    assert per_ray > 100 and (c[: cap // per_ray] == per_ray).all() and (c[cap // per_ray:] == 0).all()
+    assert (ridx.cpu().numpy()[: (cap // per_ray) * per_ray] >= 0).all()
+
+
+def test_update_bitfield_and_maxpool_bit_exact(device):
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    for seed, thr in ((3, 0.01), (4, 0.5)):  # second case: mean < threshold decides
+        n_levels = 3
+        grid = _scene_grid(n_levels, seed)
+        fresh = (np.random.default_rng(seed + 10).random((n_levels, O.CELLS), dtype=np.float32) ** 5) * 0.1
+        ref_grid = O.ema_update(grid, fresh, 0.95)
+        ref_bf = O.grid_to_bitfield(ref_grid, n_levels, thr)
+        gd = torch.from_numpy(grid.copy()).to(device)
+        fd = torch.from_numpy(fresh).to(device)
+        bfd = torch.zeros(n_levels, O.CELLS // 8, dtype=torch.uint8, device=device)
+        scratch = torch.zeros(8, dtype=torch.uint8, device=device)
+        _lib.check(lib.nvo_occ_update(_stream(), n_levels, _p(gd), _p(fd), 0.95, thr, _p(bfd), _p(scratch)), "occ_update")
+        torch.cuda.synchronize()
+        assert (gd.cpu().numpy().view(np.uint32) == ref_grid.view(np.uint32)).all()
+        got = bfd.cpu().numpy()
+        assert (got == ref_bf).all(), f"{int((got != ref_bf).sum())} bitfield bytes differ"
+        assert np.unpackbits(got[1]).mean() > np.unpackbits(O.grid_to_bitfield(ref_grid[:1], 1, thr)).mean() * 0.1
+
+
+def test_cell_positions_invert_the_index(device):
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    for level in (0, 2):
+        pos = torch.zeros(O.CELLS, 3, device=device)
+        _lib.check(lib.nvo_occ_cell_positions(_stream(), level, None, _p(pos)), "cell_positions")
+        torch.cuda.synchronize()
+        p = pos.cpu().numpy()
+        sel = np.random.default_rng(0).integers(0, O.CELLS, 2000)
+        u = (p[sel] - 0.5) / (2.0 ** level) + 0.5
+        ijk = np.floor(u * 128).astype(np.uint32)
+        assert (O.morton3d_numpy(ijk[:, 0], ijk[:, 1], ijk[:, 2]) == sel).all()
