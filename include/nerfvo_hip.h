@@ -280,6 +280,61 @@ int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* 
 /* centres (or jittered points, jitter device float [128^3][3]) of cascade `level` cells, Morton order */
 int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, float* positions);
 
+/* Occupancy-grid ("instant-ngp") trainer pieces on PACKED samples (capacity slots, ray_idx < 0 = empty):
+ *  ngp_positions      : x01 = clamp((o + t d - aabb_lo) / (aabb_hi - aabb_lo), 0, 1) per slot
+ *  ngp_rgb_fwd / bwd  : rgb head 32 -> 64 -> 64 -> 3 on [density-net output 16 | SH16(ray)] (linear
+ *                       output; the logistic is applied by the compositing kernel, as upstream)
+ *  ngp_composite_loss : per ray (counts/offsets from nvo_occ_march) front-to-back compositing with
+ *                       density = exp(pre), rgb = sigmoid(y), background blend; L2 rgb + L2 depth
+ *                       losses; per-sample gradients (d_rgb_out fp16 rows, d_density_pre float)
+ *  ngp_thickness      : exp(pre) * sqrt(3)/1024 * 2^level for the density-grid update */
+typedef struct nvo_ngp_rgb_args {
+    uint32_t capacity;           /* multiple of 16 */
+    const void* sh;              /* fp16 [R][16] */
+    const void* density_out;     /* fp16 [capacity][16] */
+    const int32_t* ray_idx;      /* [capacity] */
+    const void* weights;         /* fp16 [64][32], [64][64], [16][64] */
+    void* rgb_out;               /* fp16 [capacity][16] */
+    void* hidden;                /* fp16 [2][capacity][64] or NULL */
+    const void* d_rgb_out;       /* bwd: fp16 [capacity][16] */
+    void* d_density_out;         /* bwd: fp16 [capacity][16] (all columns written) */
+    const float* d_density_pre;  /* bwd: [capacity], added into column 0; nullable */
+    float* d_weights;            /* bwd: accumulated */
+} nvo_ngp_rgb_args;
+int nvo_ngp_rgb_fwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);
+int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);
+
+typedef struct nvo_ngp_loss_args {
+    uint32_t R, capacity;
+    const uint32_t* counts;      /* [R] */
+    const uint32_t* offsets;     /* [R+1] */
+    const int32_t* ray_idx;      /* [capacity] (training only) */
+    const float* t;              /* [capacity] */
+    const float* dt;
+    const void* density_out;     /* fp16 [capacity][density_stride], pre-activation in column 0 */
+    uint32_t density_stride;
+    const void* rgb_out;         /* fp16 [capacity][rgb_stride], pre-sigmoid rgb in columns 0..2 */
+    uint32_t rgb_stride;
+    const float* background;     /* [R][3] or NULL (black) */
+    const float* gt_rgb;         /* [R][3] */
+    const float* gt_depth;       /* [R] or NULL */
+    const float* directions_norm;/* [R] or NULL */
+    float rgb_mult, depth_mult, inv_rays, loss_scale;
+    float* out_rgb;              /* [R][3] nullable */
+    float* out_depth;            /* [R] nullable (expected ray distance) */
+    float* out_accumulation;     /* [R] nullable */
+    float* losses;               /* [64][8] shards: slot 0 rgb, slot 1 depth */
+    void* d_rgb_out;             /* fp16 [capacity][d_rgb_stride]; NULL -> inference */
+    uint32_t d_rgb_stride;
+    float* d_density_pre;        /* [capacity] */
+} nvo_ngp_loss_args;
+int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
+                      const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);
+int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args);
+int nvo_ngp_thickness(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride, int level,
+                      float* out);
+int nvo_fill_i32(nvo_stream_t stream, uint32_t n, int32_t* ptr, int32_t value);
+
 /* ------------------------------------------------------------------------------------------------
  * E. Optimiser (torch.optim.Adam as configured at /root/reference/nerf_vo/mapping/nerfstudio.py:84-100
  *    + GradScaler's skip-on-non-finite from mixed_precision=True, nerfstudio.py:59).

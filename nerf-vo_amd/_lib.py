@@ -17,6 +17,7 @@ _lib = None
 
 # name -> (restype, argtypes); mirrors include/nerfvo_hip.h one to one
 _u32, _u64, _i64, _int = C.c_uint32, C.c_uint64, C.c_int64, C.c_int
+_i32 = C.c_int32
 _p = C.c_void_p
 _f = C.c_float
 
@@ -54,6 +55,22 @@ class ColorArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p)]
+
+
+class NgpRgbArgs(C.Structure):
+    """mirror of nvo_ngp_rgb_args"""
+    _fields_ = [("capacity", _u32), ("sh", _p), ("density_out", _p), ("ray_idx", _p), ("weights", _p), ("rgb_out", _p),
+                ("hidden", _p), ("d_rgb_out", _p), ("d_density_out", _p), ("d_density_pre", _p), ("d_weights", _p)]
+
+
+class NgpLossArgs(C.Structure):
+    """mirror of nvo_ngp_loss_args"""
+    _fields_ = [("R", _u32), ("capacity", _u32), ("counts", _p), ("offsets", _p), ("ray_idx", _p), ("t", _p), ("dt", _p),
+                ("density_out", _p), ("density_stride", _u32), ("rgb_out", _p), ("rgb_stride", _u32),
+                ("background", _p), ("gt_rgb", _p), ("gt_depth", _p), ("directions_norm", _p), ("rgb_mult", _f),
+                ("depth_mult", _f), ("inv_rays", _f), ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p),
+                ("out_accumulation", _p), ("losses", _p), ("d_rgb_out", _p), ("d_rgb_stride", _u32),
+                ("d_density_pre", _p)]
 
 
 _SIGNATURES = {
@@ -100,6 +117,12 @@ _SIGNATURES = {
     "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p]),
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
+    "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
+    "nvo_ngp_rgb_fwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
+    "nvo_ngp_rgb_bwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
+    "nvo_ngp_composite_loss": (_int, [_p, C.POINTER(NgpLossArgs)]),
+    "nvo_ngp_thickness": (_int, [_p, _u32, _p, _u32, _int, _p]),
+    "nvo_fill_i32": (_int, [_p, _u32, _p, _i32]),
     # group E
     "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
     "nvo_write_floats": (_int, [_p, _p, _u32, _p]),
@@ -122,6 +145,13 @@ def lib() -> C.CDLL:
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python nerf-vo_amd/build.py`). "
                 "There is no CPU fallback."
             )
+        # PyTorch bundles its own libamdhip64.so.7 (+ HSA runtime); this library is linked against the
+        # SONAME only.  Whichever copy is loaded first serves the whole process, and mixing the system
+        # HIP runtime with torch's bundled HSA runtime ends in "no ROCm-capable device is detected".
+        # Import torch FIRST so that both sides share torch's runtime (streams and pointers are then
+        # handles of one and the same runtime instance).
+        import torch  # noqa: F401
+
         handle = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here == header/library mismatch

@@ -164,6 +164,13 @@ __device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, in
                 x[3][j] = q < 15 ? em[17 + q] : (_Float16)1.0f;  // feature 48 + q -> embed 17 + q | pad
             }
         }
+    } else if (a.in_mode == NVO_IO_NGP_RGB) {
+        if constexpr (IN_PAD == 32) {
+            const int32_t ray = a.sample_ray[row];
+            x[0] = *reinterpret_cast<const h4*>(a.base_out + (size_t)row * 16 + 4 * g);
+            h4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            x[1] = ray >= 0 ? *reinterpret_cast<const h4*>(a.sh + (size_t)ray * 16 + 4 * g) : z;
+        }
     } else {
         const _Float16* __restrict__ p = (const _Float16*)a.input + (size_t)row * IN_PAD;
 #pragma unroll
@@ -532,6 +539,15 @@ k_mlp_bwd(NvoMlpArgs a) {
                         }
                     }
                 }
+            } else if (a.din_mode == NVO_IO_NGP_RGB) {
+                if constexpr (IN_PAD == 32) {
+                    // d(density-net output): all 16 columns; column 0 also receives dL/d(density pre-activation)
+                    h4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (_Float16)acc[0][j];
+                    if (g == 0 && a.d_extra_col0) v[0] = (_Float16)(acc[0][0] + a.d_extra_col0[row]);
+                    *reinterpret_cast<h4*>(a.d_base_out + (size_t)row * 16 + 4 * g) = v;
+                }
             } else {
                 _Float16* __restrict__ p = (_Float16*)a.dinput + (size_t)row * IN_PAD + 4 * g;
 #pragma unroll
@@ -673,6 +689,45 @@ int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args) {
     NVO_REQUIRE(c.S >= 1 && c.sh && c.base_out && c.embedding && c.weights && c.rgb, "color_fwd: NULL argument");
     const NvoMlpArgs a = color_args(c);
     return nvo_mlp_fwd_launch(64, 64, 2, 16, a, (hipStream_t)stream);
+}
+
+static NvoMlpArgs ngp_rgb_args(const nvo_ngp_rgb_args& c) {
+    NvoMlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.batch = c.capacity;
+    a.n_in = 32;
+    a.in_mode = NVO_IO_NGP_RGB;
+    a.weights = (const _Float16*)c.weights;
+    a.output = (_Float16*)c.rgb_out;
+    a.hidden = (_Float16*)c.hidden;
+    a.act = NVO_ACT_RELU;
+    a.out_act = NVO_ACT_NONE;  // the logistic lives in the compositing kernel, as in instant-ngp
+    a.sh = (const _Float16*)c.sh;
+    a.base_out = (const _Float16*)c.density_out;
+    a.sample_ray = c.ray_idx;
+    return a;
+}
+
+int nvo_ngp_rgb_fwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
+    NVO_REQUIRE(args != nullptr, "ngp_rgb_fwd: args is NULL");
+    const nvo_ngp_rgb_args c = *args;
+    NVO_REQUIRE(c.sh && c.density_out && c.ray_idx && c.weights && c.rgb_out, "ngp_rgb_fwd: NULL argument");
+    return nvo_mlp_fwd_launch(32, 64, 2, 16, ngp_rgb_args(c), (hipStream_t)stream);
+}
+
+int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
+    NVO_REQUIRE(args != nullptr, "ngp_rgb_bwd: args is NULL");
+    const nvo_ngp_rgb_args c = *args;
+    NVO_REQUIRE(c.sh && c.density_out && c.ray_idx && c.weights && c.rgb_out && c.hidden && c.d_rgb_out &&
+                c.d_density_out, "ngp_rgb_bwd: NULL argument");
+    NvoMlpArgs a = ngp_rgb_args(c);
+    a.doutput = (const _Float16*)c.d_rgb_out;
+    a.dinput = c.d_density_out;
+    a.din_mode = NVO_IO_NGP_RGB;
+    a.d_base_out = (_Float16*)c.d_density_out;
+    a.d_extra_col0 = c.d_density_pre;
+    a.dweights = c.d_weights;
+    return nvo_mlp_bwd_launch(32, 64, 2, 16, a, (hipStream_t)stream);
 }
 
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {

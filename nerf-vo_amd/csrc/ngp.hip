@@ -1,0 +1,277 @@
+// Occupancy-grid ("instant-ngp") training back-end for gfx950: per-sample positions for PACKED
+// variable-length rays, front-to-back compositing fused with the rgb / depth L2 losses and their
+// per-sample gradients, density -> optical-thickness conversion for the density-grid update.
+// Replaces instant-ngp's compute_loss_kernel_train_nerf (+ the NeRF-SLAM fork's depth term) and the
+// glue around generate_training_samples_nerf / update_density_grid_nerf (SURVEY.md section 2.4
+// K13-K16; reference call sites /root/reference/nerf_vo/mapping/instant_ngp.py:33-50,87-105 --
+// aabb_scale 4, L2 depth loss, extrinsics optimisation).  Upstream sources are not vendored; the
+// arithmetic is restated in oracle/ngp.py.
+//
+// One WAVE per ray: a ray's samples are contiguous in the packed arrays (nvo_occ_march), lanes stride
+// over them in chunks of 64; transmittance is a multiplicative wave scan with a carry across chunks.
+#include "nvo_kernels.h"
+#include "../../include/nerfvo_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// x01 = (o + t d - aabb_lo) * aabb_inv_size for every packed slot; slots with ray_idx < 0 -> zeros
+__global__ void __launch_bounds__(256)
+k_ngp_positions(uint32_t capacity, const int32_t* __restrict__ ray_idx, const float* __restrict__ t,
+                const float* __restrict__ origins, const float* __restrict__ directions, float aabb_lo,
+                float aabb_inv_size, float* __restrict__ x01) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    const int32_t r = ray_idx[i];
+    float p[3] = {0.f, 0.f, 0.f};
+    if (r >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float w = origins[3 * (size_t)r + k] + directions[3 * (size_t)r + k] * t[i];
+            p[k] = fminf(fmaxf((w - aabb_lo) * aabb_inv_size, 0.f), 1.f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = p[k];
+}
+
+}  // namespace
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_ngp_composite_loss(nvo_ngp_loss_args a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const uint32_t n = a.counts[r];
+    const uint32_t base = a.offsets[r];
+    const _Float16* den = (const _Float16*)a.density_out;
+    const _Float16* col = (const _Float16*)a.rgb_out;
+
+    // ---- pass 1: composite front to back (T = prod (1 - alpha) through a log-space additive scan)
+    float carry = 0.f;  // sum of density * dt of all previous samples
+    float pix[3] = {0.f, 0.f, 0.f};
+    float depth = 0.f, acc = 0.f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t j = c0 + lane;
+        float dd = 0.f, tj = 0.f, rgb[3] = {0.f, 0.f, 0.f};
+        if (j < n) {
+            const size_t s = base + j;
+            const float sigma = __expf((float)den[s * a.density_stride]);
+            dd = sigma * a.dt[s];
+            tj = a.t[s];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb[k] = 1.f / (1.f + __expf(-(float)col[s * a.rgb_stride + k]));
+        }
+        const float incl = wave_incl_scan(dd, lane) + carry;
+        const float T = __expf(-(incl - dd));
+        const float w = (j < n) ? (1.f - __expf(-dd)) * T : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pix[k] += wave_sum(w * rgb[k]);
+        depth += wave_sum(w * tj);
+        acc += wave_sum(w);
+        carry = __shfl(incl, 63, 64);
+    }
+    const float T_final = __expf(-carry);
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (a.background) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bg[k] = a.background[3 * (size_t)r + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pix[k] += T_final * bg[k];
+    if (lane == 0) {
+        if (a.out_rgb) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.out_rgb[3 * (size_t)r + k] = pix[k];
+        }
+        if (a.out_depth) a.out_depth[r] = depth;
+        if (a.out_accumulation) a.out_accumulation[r] = acc;
+    }
+    if (!a.d_rgb_out) return;
+
+    // ---- losses (means over the global ray count)
+    float g_pix[3], l_rgb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float e = pix[k] - a.gt_rgb[3 * (size_t)r + k];
+        l_rgb += e * e;
+        g_pix[k] = 2.f * e * a.inv_rays * (1.f / 3.f) * a.rgb_mult;
+    }
+    l_rgb *= a.inv_rays * (1.f / 3.f) * a.rgb_mult;
+    float g_depth = 0.f, l_depth = 0.f;
+    if (a.gt_depth && a.depth_mult != 0.f) {
+        const float z = a.gt_depth[r] * (a.directions_norm ? a.directions_norm[r] : 1.f);
+        if (z > 0.f) {
+            const float e = depth - z;
+            l_depth = e * e * a.inv_rays * a.depth_mult;
+            g_depth = 2.f * e * a.inv_rays * a.depth_mult;
+        }
+    }
+    if (lane == 0) {
+        float* shard = a.losses + 8 * (r & 63u);
+        atomicAdd(shard + 0, l_rgb);
+        atomicAdd(shard + 1, l_depth);
+    }
+
+    // ---- pass 2: per-sample gradients.  With q_i = w_i (g_pix . rgb_i + g_depth t_i):
+    //   dL/dsigma_i = dt_i [ T_i exp(-dd_i) (g.rgb_i + g_depth t_i) - sum_{j>i} q_j - T_final g.bg ]
+    //   dL/drgb_i   = w_i g_pix
+    float total_q = 0.f;
+    carry = 0.f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {  // total of q
+        const uint32_t j = c0 + lane;
+        float dd = 0.f, q = 0.f;
+        if (j < n) {
+            const size_t s = base + j;
+            dd = __expf((float)den[s * a.density_stride]) * a.dt[s];
+        }
+        const float incl = wave_incl_scan(dd, lane) + carry;
+        if (j < n) {
+            const size_t s = base + j;
+            const float T = __expf(-(incl - dd));
+            const float w = (1.f - __expf(-dd)) * T;
+            float dot = g_depth * a.t[s];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dot += g_pix[k] / (1.f + __expf(-(float)col[s * a.rgb_stride + k]));
+            q = w * dot;
+        }
+        total_q += wave_sum(q);
+        carry = __shfl(incl, 63, 64);
+    }
+    const float g_bg = T_final * (g_pix[0] * bg[0] + g_pix[1] * bg[1] + g_pix[2] * bg[2]);
+    carry = 0.f;
+    float carry_q = 0.f;
+    _Float16* d_rgb = (_Float16*)a.d_rgb_out;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t j = c0 + lane;
+        float dd = 0.f, q = 0.f, w = 0.f, T = 0.f, dot = 0.f, sigma = 0.f, rgb[3] = {0.f, 0.f, 0.f};
+        if (j < n) {
+            const size_t s = base + j;
+            sigma = __expf((float)den[s * a.density_stride]);
+            dd = sigma * a.dt[s];
+        }
+        const float incl = wave_incl_scan(dd, lane) + carry;
+        if (j < n) {
+            const size_t s = base + j;
+            T = __expf(-(incl - dd));
+            w = (1.f - __expf(-dd)) * T;
+            dot = g_depth * a.t[s];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rgb[k] = 1.f / (1.f + __expf(-(float)col[s * a.rgb_stride + k]));
+                dot += g_pix[k] * rgb[k];
+            }
+            q = w * dot;
+        }
+        const float incl_q = wave_incl_scan(q, lane) + carry_q;
+        if (j < n) {
+            const size_t s = base + j;
+            const float suffix = total_q - incl_q;
+            const float dsigma = a.dt[s] * (T * __expf(-dd) * dot - suffix - g_bg);
+            // density = exp(x): dsigma/dx = sigma (clamped like tcnn's Exponential activation backward)
+            a.d_density_pre[s] = dsigma * fminf(sigma, 3.2690173e6f) * a.loss_scale;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)  // rgb = sigmoid(y): drgb/dy = rgb (1 - rgb)
+                d_rgb[s * a.d_rgb_stride + k] = (_Float16)(w * g_pix[k] * rgb[k] * (1.f - rgb[k]) * a.loss_scale);
+            for (uint32_t k = 3; k < a.d_rgb_stride; ++k) d_rgb[s * a.d_rgb_stride + k] = (_Float16)0.f;
+        }
+        carry = __shfl(incl, 63, 64);
+        carry_q = __shfl(incl_q, 63, 64);
+    }
+}
+
+// zero the gradient rows of packed slots that belong to no ray (beyond the last offset / dropped rays)
+__global__ void __launch_bounds__(256)
+k_ngp_clear_invalid(uint32_t capacity, const int32_t* __restrict__ ray_idx, _Float16* __restrict__ d_rgb,
+                    uint32_t d_rgb_stride, float* __restrict__ d_density_pre) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity || ray_idx[i] >= 0) return;
+    for (uint32_t k = 0; k < d_rgb_stride; ++k) d_rgb[(size_t)i * d_rgb_stride + k] = (_Float16)0.f;
+    d_density_pre[i] = 0.f;
+}
+
+// optical thickness of a density-grid cell sample: exp(pre) * sqrt(3)/1024 * 2^level
+__global__ void __launch_bounds__(256)
+k_ngp_thickness(uint32_t n, const _Float16* __restrict__ density_out, uint32_t stride, int level,
+                float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = __expf((float)density_out[(size_t)i * stride]) * scalbnf(1.7320508075688772f / 1024.0f, level);
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_i32(uint32_t n, int32_t* __restrict__ p, int32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
+                      const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01) {
+    NVO_REQUIRE(capacity == 0 || (ray_idx && t && origins && directions && x01), "ngp_positions: NULL argument");
+    NVO_REQUIRE(aabb_hi > aabb_lo, "ngp_positions: empty aabb");
+    if (capacity == 0) return NVO_OK;
+    NVO_PROF(stream, "ngp_positions");
+    NVO_LAUNCH(k_ngp_positions, dim3(nvo_div_up(capacity, 256)), dim3(256), 0, (hipStream_t)stream, capacity, ray_idx,
+               t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args) {
+    NVO_REQUIRE(args != nullptr, "ngp_composite_loss: args is NULL");
+    const nvo_ngp_loss_args a = *args;
+    NVO_REQUIRE(a.counts && a.offsets && a.t && a.dt && a.density_out && a.rgb_out, "ngp_composite_loss: NULL input");
+    NVO_REQUIRE(!a.d_rgb_out || (a.d_density_pre && a.gt_rgb && a.losses && a.ray_idx && a.d_rgb_stride >= 3),
+                "ngp_composite_loss: training mode needs d_density_pre, gt_rgb, losses, ray_idx");
+    if (a.R == 0) return NVO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    NVO_PROF(stream, "ngp_composite_loss");
+    if (a.d_rgb_out) {
+        NVO_LAUNCH(k_ngp_clear_invalid, dim3(nvo_div_up(a.capacity, 256)), dim3(256), 0, s, a.capacity, a.ray_idx,
+                   (_Float16*)a.d_rgb_out, a.d_rgb_stride, a.d_density_pre);
+        NVO_CHECK_LAUNCH();
+    }
+    NVO_LAUNCH(k_ngp_composite_loss, dim3(nvo_div_up(a.R, 4)), dim3(256), 0, s, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ngp_thickness(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride, int level,
+                      float* out) {
+    NVO_REQUIRE(n == 0 || (density_out && out && stride >= 1), "ngp_thickness: bad argument");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "ngp_thickness");
+    NVO_LAUNCH(k_ngp_thickness, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+               (const _Float16*)density_out, stride, level, out);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_fill_i32(nvo_stream_t stream, uint32_t n, int32_t* ptr, int32_t value) {
+    NVO_REQUIRE(n == 0 || ptr, "fill_i32: NULL argument");
+    if (n == 0) return NVO_OK;
+    NVO_LAUNCH(k_fill_i32, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, ptr, value);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+}  // extern "C"

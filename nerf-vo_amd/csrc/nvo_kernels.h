@@ -39,6 +39,7 @@ enum {
     NVO_IO_HALF2_SOA = 1,       // [n_in/2][B] half2 (grid encoding output), missing levels read as 0
     NVO_IO_HALF_ROWS = 2,       // [B][IN_PAD] half
     NVO_IO_NERFACTO_COLOR = 3,  // 64-wide row assembled on the fly: [SH16(ray) | geo15 | embed32(cam) | 1]
+    NVO_IO_NGP_RGB = 4,         // 32-wide row: [density-net output 16 | SH16(ray of the packed sample)]
 };
 
 struct NvoMlpArgs {
@@ -64,6 +65,9 @@ struct NvoMlpArgs {
     _Float16* d_base_out;       // [B][16]  cols 1..15 written by the backward
     float* d_embedding;         // [F][32]  atomically accumulated, nullable
     float* d_sh;                // [R][16]  atomically accumulated, nullable
+    // NVO_IO_NGP_RGB only (instant-ngp rgb head on packed samples)
+    const int32_t* sample_ray;    // [B] ray index of each packed sample (< 0: empty slot)
+    const float* d_extra_col0;    // [B] added to column 0 of d_base_out (dL/d density pre-activation)
 };
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
 int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,

@@ -1,0 +1,295 @@
+"""Occupancy-grid ("instant-ngp") training / rendering engine -- the second mapping back-end of the
+reference (`mapping_module: 'instant-ngp'`, /root/reference/nerf_vo/mapping/instant_ngp.py:19-117,
+which drives NVlabs' testbed through pyngp).
+
+One step = what ``Testbed::frame()`` -> ``train(batch)`` does [UPSTREAM]:
+    rays -> DDA march through the cascaded Morton bitfield (packed samples, deterministic offsets)
+    -> hash grid + density MLP -> SH + rgb MLP -> front-to-back compositing + L2 rgb / depth loss
+    (+ per-sample gradients) -> rgb / density MLP + grid backward -> Adam;
+    every ``density_update_every`` steps the density grid is re-estimated (EMA), thresholded into the
+    bitfield and max-pooled up the cascades.
+Network shapes follow instant-ngp's configs/nerf/base.json: HashGrid(L16, F2, T2^19, base 16),
+density MLP 32->64->16, rgb MLP [16 | SH16]->64->64->3, exponential density, logistic rgb.
+
+Frame convention: the engine works in instant-ngp's normalised frame (cascade 0 = [0,1]^3, scene
+aabb = [0.5 - aabb_scale/2, 0.5 + aabb_scale/2]^3); poses are camera-to-world in that frame, OpenGL
+axes (the mapper mirror converts).  All arithmetic is HIP kernels behind include/nerfvo_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from .engine import GridConfig, _call
+from .tinycudann.modules import _create, _ptr, _stream
+
+CELLS = 128 ** 3
+
+
+@dataclass
+class NgpConfig:
+    num_images: int = 192
+    num_rays: int = 4096
+    capacity: int = 1 << 18               # packed sample slots per step (instant-ngp's target batch)
+    aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
+    cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
+    near_distance: float = 0.1
+    desired_resolution: int = 2048
+    density_update_every: int = 16
+    density_decay: float = 0.95
+    occupancy_threshold: float = 0.01
+    rgb_loss_mult: float = 1.0
+    depth_loss_mult: float = 1.0          # NeRF-SLAM fork's depth term, LossType.L2 (instant_ngp.py:48)
+    loss_scale: float = 128.0
+    lr: float = 1e-2
+    adam_betas: tuple = (0.9, 0.99)
+    adam_eps: float = 1e-15
+    l2_reg: float = 1e-6                  # on MLP weights only
+    random_background: bool = False
+    seed: int = 1337
+
+    @property
+    def n_levels(self) -> int:
+        k = 0
+        while (1 << k) < self.aabb_scale:
+            k += 1
+        return k + 1
+
+    @property
+    def aabb(self) -> tuple:
+        h = 0.5 * self.aabb_scale
+        return (0.5 - h, 0.5 + h)
+
+    @property
+    def grid(self) -> GridConfig:
+        return GridConfig(16, 19, 16, self.desired_resolution * self.aabb_scale)
+
+
+class NgpEngine:
+    def __init__(self, config: NgpConfig, device: torch.device, world_size: int = 1):
+        if device.type != "cuda":
+            raise RuntimeError("NgpEngine needs an MI355X device; there is no CPU fallback")
+        self.cfg = config
+        self.device = device
+        self.world_size = world_size
+        cfg = config
+        net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                   "n_hidden_layers": 1}
+        self.density_net = _create("nvo_create_network_with_input_encoding", 3, 16,
+                                   json.dumps(cfg.grid.tcnn_dict()).encode(), json.dumps(net_cfg).encode())
+        self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
+        self.n_density_mlp = 64 * 32 + 16 * 64
+        self.segments = {"density": (0, self.density_net.n_params), "rgb": (self.density_net.n_params, self.n_rgb)}
+        self.n_params = self.density_net.n_params + self.n_rgb
+        dev = device
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
+        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(self.n_params), z(self.n_params), z(self.n_params), z(self.n_params)
+        self.params_half = z(self.n_params, torch.float16)
+        self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)
+        self.skip_flag = z(1, torch.int32)
+        self.density_grid = z(cfg.n_levels * CELLS)
+        self.bitfield = z(cfg.n_levels * CELLS // 8, torch.uint8)
+        self._scratch8 = z(8, torch.uint8)
+        self.step = 0
+        self.opt_step = 0
+        self._ws = None
+        self.init_params(cfg.seed)
+
+    # ---- parameters --------------------------------------------------------------------------
+    def init_params(self, seed: int) -> None:
+        host = torch.zeros(self.n_params)
+        host[: self.density_net.n_params] = self.density_net.initial_params(seed)
+        rgb = _create("nvo_create_network", 32, 3, json.dumps(
+            {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+             "n_hidden_layers": 2}).encode())
+        assert rgb.n_params == self.n_rgb
+        host[self.density_net.n_params:] = rgb.initial_params(seed + 1)
+        self.set_params(host)
+
+    def set_params(self, flat: torch.Tensor) -> None:
+        self.params.copy_(flat.to(self.device, torch.float32))
+        _call("nvo_cast_half", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half))
+
+    def _pp(self, name: str, buf: torch.Tensor):
+        o, _ = self.segments[name]
+        return C.c_void_p(buf.data_ptr() + o * buf.element_size())
+
+    # ---- scratch -----------------------------------------------------------------------------
+    def _workspace(self, R: int, training: bool):
+        key = (R, training)
+        if self._ws is not None and self._ws["key"] == key:
+            return self._ws
+        dev, cap = self.device, self.cfg.capacity
+        f32 = dict(dtype=torch.float32, device=dev)
+        f16 = dict(dtype=torch.float16, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws = {"key": key, "R": R}
+        for name, shape in (("origins", (R, 3)), ("directions", (R, 3)), ("directions_norm", (R,)), ("pixel_area", (R,)),
+                            ("gt_rgb", (R, 3)), ("gt_depth", (R,)), ("dirs01", (R, 3)), ("out_rgb", (R, 3)),
+                            ("out_depth", (R,)), ("out_accumulation", (R,)), ("t", (cap,)), ("dt", (cap,)),
+                            ("x01", (cap, 3)), ("d_density_pre", (cap,))):
+            ws[name] = torch.zeros(*shape, **f32)
+        ws["cam_idx"] = torch.zeros(R, **i32)
+        ws["counts"] = torch.zeros(R, **i32)
+        ws["offsets"] = torch.zeros(R + 1, **i32)
+        ws["ray_idx"] = torch.full((cap,), -1, **i32)
+        ws["sh"] = torch.zeros(R, 16, **f16)
+        ws["density_out"] = torch.zeros(cap, 16, **f16)
+        ws["rgb_out"] = torch.zeros(cap, 16, **f16)
+        ws["ctx"] = torch.empty(self.density_net.ctx_bytes(cap), dtype=torch.uint8, device=dev)
+        if training:
+            ws["rgb_hidden"] = torch.zeros(2, cap, 64, **f16)
+            ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
+            ws["d_density_out"] = torch.zeros(cap, 16, **f16)
+        self._ws = ws
+        return ws
+
+    # ---- density grid ------------------------------------------------------------------------
+    @torch.no_grad()
+    def update_density_grid(self, jitter: bool = True) -> None:
+        """update_density_grid_nerf: sample every cell of every cascade (jittered), evaluate the density
+        network, EMA the optical thickness into the grid, rebuild bitfield + cascade max-pool."""
+        cfg = self.cfg
+        stream = _stream(self.device)
+        lo, hi = cfg.aabb
+        chunk = 1 << 19
+        fresh = torch.empty(cfg.n_levels * CELLS, device=self.device)
+        pos = torch.empty(CELLS, 3, device=self.device)
+        x01 = torch.empty(chunk, 3, device=self.device)
+        out = torch.empty(chunk, 16, dtype=torch.float16, device=self.device)
+        ctx = torch.empty(self.density_net.ctx_bytes(chunk), dtype=torch.uint8, device=self.device)
+        for level in range(cfg.n_levels):
+            jit = torch.rand(CELLS, 3, device=self.device) if jitter else None
+            _call("nvo_occ_cell_positions", stream, level, _ptr(jit), _ptr(pos))
+            for c0 in range(0, CELLS, chunk):
+                x01.copy_(((pos[c0:c0 + chunk] - lo) / (hi - lo)).clamp_(0.0, 1.0))
+                _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
+                      _ptr(out), _ptr(ctx))
+                _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 16, level,
+                      C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
+        _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
+              cfg.occupancy_threshold, _ptr(self.bitfield), _ptr(self._scratch8))
+
+    # ---- forward / backward ------------------------------------------------------------------
+    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths) -> None:
+        stream = _stream(self.device)
+        R = ws["R"]
+        H, W = images.shape[1], images.shape[2]
+        _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), None, _ptr(ws["origins"]),
+              _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]))
+        _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
+        if depths is not None:
+            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 1, _ptr(depths), _ptr(ws["gt_depth"]))
+
+    def _forward(self, ws, training: bool, jitter, stream) -> None:
+        cfg = self.cfg
+        R, cap = ws["R"], cfg.capacity
+        lo, hi = cfg.aabb
+        _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
+        _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
+              cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
+              _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]))
+        _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
+              _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
+        _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
+              _ptr(ws["density_out"]), _ptr(ws["ctx"]))
+        _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
+        _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+        ra = self._rgb_args(ws, training)
+        _call("nvo_ngp_rgb_fwd", stream, C.byref(ra))
+
+    def _rgb_args(self, ws, training: bool):
+        return _lib.NgpRgbArgs(
+            capacity=self.cfg.capacity, sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
+            ray_idx=ws["ray_idx"].data_ptr(), weights=self._pp("rgb", self.params_half).value,
+            rgb_out=ws["rgb_out"].data_ptr(), hidden=ws["rgb_hidden"].data_ptr() if training else None,
+            d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None,
+            d_density_out=ws["d_density_out"].data_ptr() if training else None,
+            d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
+            d_weights=self._pp("rgb", self.grads).value if training else None)
+
+    def _loss_args(self, ws, training: bool, has_depth: bool, background):
+        cfg = self.cfg
+        R = ws["R"]
+        return _lib.NgpLossArgs(
+            R=R, capacity=cfg.capacity, counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
+            ray_idx=ws["ray_idx"].data_ptr(), t=ws["t"].data_ptr(), dt=ws["dt"].data_ptr(),
+            density_out=ws["density_out"].data_ptr(), density_stride=16, rgb_out=ws["rgb_out"].data_ptr(), rgb_stride=16,
+            background=None if background is None else background.data_ptr(),
+            gt_rgb=ws["gt_rgb"].data_ptr() if training else None,
+            gt_depth=ws["gt_depth"].data_ptr() if (training and has_depth) else None,
+            directions_norm=ws["directions_norm"].data_ptr(), rgb_mult=cfg.rgb_loss_mult,
+            depth_mult=cfg.depth_loss_mult if has_depth else 0.0, inv_rays=1.0 / (R * self.world_size),
+            loss_scale=cfg.loss_scale, out_rgb=ws["out_rgb"].data_ptr(), out_depth=ws["out_depth"].data_ptr(),
+            out_accumulation=ws["out_accumulation"].data_ptr(), losses=self.losses.data_ptr() if training else None,
+            d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None, d_rgb_stride=16,
+            d_density_pre=ws["d_density_pre"].data_ptr() if training else None)
+
+    def forward_backward(self, ws, jitter, has_depth: bool = True, background=None) -> None:
+        stream = _stream(self.device)
+        cap = self.cfg.capacity
+        self.grads.zero_()
+        self.losses.zero_()
+        self._forward(ws, True, jitter, stream)
+        la = self._loss_args(ws, True, has_depth, background)
+        _call("nvo_ngp_composite_loss", stream, C.byref(la))
+        ra = self._rgb_args(ws, True)
+        _call("nvo_ngp_rgb_bwd", stream, C.byref(ra))
+        _call("nvo_bwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
+              _ptr(ws["density_out"]), _ptr(ws["d_density_out"]), _ptr(ws["ctx"]), None, self._pp("density", self.grads))
+
+    def optimizer_step(self) -> None:
+        cfg = self.cfg
+        stream = _stream(self.device)
+        self.opt_step += 1
+        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), _ptr(self.skip_flag))
+        n_grid = self.density_net.n_params - self.n_density_mlp
+        # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only
+        for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
+                              (self.density_net.n_params, self.n_rgb, cfg.l2_reg)):
+            _call("nvo_adam_step", stream, size, C.c_void_p(self.params.data_ptr() + 4 * off),
+                  C.c_void_p(self.params_half.data_ptr() + 2 * off), C.c_void_p(self.grads.data_ptr() + 4 * off),
+                  C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
+                  cfg.lr, cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, wd,
+                  _ptr(self.skip_flag), None)
+
+    def train_step(self, ray_indices, intrinsics, c2w, images, depths, all_reduce=None):
+        R = ray_indices.shape[0]
+        ws = self._workspace(R, True)
+        if self.step % self.cfg.density_update_every == 0:
+            self.update_density_grid()
+        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
+        jitter = torch.rand(R, device=self.device)
+        bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
+        self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg)
+        if all_reduce is not None:
+            all_reduce(self.grads)
+        self.optimizer_step()
+        self.step += 1
+
+    def loss_dict(self) -> dict:
+        vals = self.losses.sum(dim=0).tolist()
+        return {"rgb_loss": vals[0], "depth_loss": vals[1]}
+
+    def samples_last_step(self) -> int:
+        ws = self._ws
+        return int(min(int(ws["offsets"][-1].item()), self.cfg.capacity)) if ws is not None else 0
+
+    @torch.no_grad()
+    def render_rays(self, origins, directions, directions_norm):
+        R = origins.shape[0]
+        ws = self._workspace(R, False)
+        ws["origins"].copy_(origins)
+        ws["directions"].copy_(directions)
+        ws["directions_norm"].copy_(directions_norm.reshape(-1))
+        stream = _stream(self.device)
+        self._forward(ws, False, None, stream)
+        la = self._loss_args(ws, False, False, None)
+        _call("nvo_ngp_composite_loss", stream, C.byref(la))
+        return {"rgb": ws["out_rgb"].clamp(0, 1), "depth": ws["out_depth"].clone()[:, None],
+                "accumulation": ws["out_accumulation"].clone()[:, None]}

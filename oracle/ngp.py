@@ -1,0 +1,83 @@
+"""CPU oracle: one training step of the occupancy-grid ("instant-ngp") back-end (TEST INFRASTRUCTURE;
+parity unpinned).  Restates Testbed::train_nerf_step of NVlabs instant-ngp as forked by NeRF-SLAM
+(reference call sites /root/reference/nerf_vo/mapping/instant_ngp.py:33-50,104-105; SURVEY.md section
+3.4): occupancy marching (oracle/c/nvo_oracle.c), hash grid + density MLP, SH + rgb MLP, exponential
+density / logistic rgb, front-to-back compositing, L2 rgb + L2 depth loss.  torch-CPU float64 with
+autograd; fp16 rounding emulated where the kernels store fp16."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import grid as G
+from . import mlp as M
+from . import occgrid as O
+from . import sh as S
+
+
+def _q16(x):
+    return x + (x.to(torch.float16).to(x.dtype) - x).detach()
+
+
+class NgpOracle:
+    def __init__(self, aabb_scale=4, desired_resolution=2048, cone_angle=1 / 256, near=0.1, rgb_mult=1.0,
+                 depth_mult=1.0, emulate_fp16=True):
+        self.aabb_scale = aabb_scale
+        self.n_levels = int(np.ceil(np.log2(aabb_scale))) + 1 if aabb_scale > 1 else 1
+        pls = float(np.exp((np.log(desired_resolution * aabb_scale) - np.log(16)) / 15))
+        self.spec = G.make_grid_spec(16, 2, 19, 16, pls)
+        self.cone_angle, self.near = cone_angle, near
+        self.rgb_mult, self.depth_mult = rgb_mult, depth_mult
+        self.emulate_fp16 = emulate_fp16
+        self.lo, self.hi = 0.5 - 0.5 * aabb_scale, 0.5 + 0.5 * aabb_scale
+        self.params = {}
+
+    def march(self, origins, directions, bitfield, jitter):
+        return O.march_rays(origins.float().numpy(), directions.float().numpy(), bitfield, self.n_levels,
+                            self.cone_angle, self.near, np.zeros(len(origins)) if jitter is None else jitter.numpy())
+
+    def forward(self, origins, directions, counts, t, dt, background=None):
+        """Packed forward for the samples found by march().  Returns per-ray rgb, depth, accumulation."""
+        P = self.params
+        R = origins.shape[0]
+        ray_idx = np.repeat(np.arange(R), counts.astype(np.int64))
+        tt = torch.from_numpy(np.concatenate([t[r, :counts[r]] for r in range(R)]).astype(np.float32)).double()
+        dd = torch.from_numpy(np.concatenate([dt[r, :counts[r]] for r in range(R)]).astype(np.float32)).double()
+        ri = torch.from_numpy(ray_idx)
+        # the kernel evaluates o + t d in fp32
+        pos = (origins.float()[ri] + directions.float()[ri] * tt.float()[:, None]).double()
+        x01 = ((pos - self.lo) * (1.0 / (self.hi - self.lo))).clamp(0.0, 1.0)
+        enc = G.grid_encode(self.spec, x01, P["grid"], quantize_output=self.emulate_fp16)
+        dws = M.split_weights(P["density_mlp"], 32, 16, 64, 1)
+        dens_out = M.mlp_forward(enc, dws, "ReLU", "None", pad_value=0.0, emulate_fp16=self.emulate_fp16)
+        sh = S.sh_encode((directions + 1.0) / 2.0, 4)
+        if self.emulate_fp16:
+            sh = _q16(sh)
+        rin = torch.cat([dens_out, sh[ri]], dim=-1)
+        rws = M.split_weights(P["rgb_mlp"], 32, 3, 64, 2)
+        rgb_pre = M.mlp_forward(rin, rws, "ReLU", "None", pad_value=1.0, emulate_fp16=self.emulate_fp16)[:, :3]
+        sigma = torch.exp(dens_out[:, 0])
+        rgb = torch.sigmoid(rgb_pre)
+        out_rgb, out_depth, out_acc = [], [], []
+        off = 0
+        for r in range(R):
+            n = int(counts[r])
+            s, c, ts, ds = sigma[off:off + n], rgb[off:off + n], tt[off:off + n], dd[off:off + n]
+            off += n
+            ddens = s * ds
+            T = torch.exp(-(torch.cumsum(ddens, 0) - ddens))
+            w = (1 - torch.exp(-ddens)) * T
+            Tf = torch.exp(-ddens.sum()) if n else torch.ones((), dtype=torch.float64)
+            bg = background[r] if background is not None else torch.zeros(3, dtype=torch.float64)
+            out_rgb.append((w[:, None] * c).sum(0) + Tf * bg)
+            out_depth.append((w * ts).sum())
+            out_acc.append(w.sum())
+        return torch.stack(out_rgb), torch.stack(out_depth), torch.stack(out_acc)
+
+    def loss_dict(self, rgb, depth, gt_rgb, gt_depth, directions_norm):
+        d = {"rgb_loss": self.rgb_mult * torch.mean((rgb - gt_rgb) ** 2)}
+        if gt_depth is not None:
+            z = gt_depth * directions_norm
+            mask = (z > 0).double()
+            d["depth_loss"] = self.depth_mult * torch.mean(((depth - z) ** 2) * mask)
+        return d

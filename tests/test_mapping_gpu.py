@@ -42,3 +42,40 @@ def test_psnr_definitions():
     y[0, 1] = 10
     assert np.mean((x[..., 0] - y[..., 0]) ** 2) == 58.0
     assert calculate_psnr_reference(x, y) > calculate_psnr_float(x, y)
+
+
+def test_instant_ngp_mapper_end_to_end(device, tmp_path):
+    """The `mapping_module: 'instant-ngp'` mirror: ingest -> train -> snapshot -> render, on a synthetic
+    room placed inside cascade 0 of the occupancy grid."""
+    import argparse
+
+    import torch
+
+    from nerf_vo_amd.mapping.instant_ngp_mapper import InstantNGP, InstantNGPRenderer
+    from nerf_vo_amd.mapping.renderer import calculate_psnr_float
+    from nerf_vo_amd.synthetic import make_sequence, replica_intrinsics
+
+    n, H, W, iters = 12, 60, 80, 400
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    poses = seq["camera_extrinsics"].clone()
+    poses[:, :3, 3] += 0.5
+    args = argparse.Namespace(num_keyframes=n, frame_height=H, frame_width=W, mapping_iterations=iters,
+                              mapping_snapshot_iterations=iters, dir_prediction=str(tmp_path))
+    mapper = InstantNGP(args, device=device)
+    mapper.ngp.cfg.num_rays = 1024
+    mapper(input={"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+                  "camera_extrinsics": poses, "frames_color": seq["frames_color"], "frames_depth": seq["frames_depth"],
+                  "last_frame": True})
+    while mapper.step < iters:
+        mapper(input=None)
+    mapper(input=None)
+    assert mapper.is_shut_down and list((tmp_path / "snapshots").glob("snapshot*.pt"))
+    renderer = InstantNGPRenderer(mapping_model=mapper)
+    fx, fy, cx, cy = replica_intrinsics(H, W)
+    color, depth = renderer.render_frame({"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": H, "width": W},
+                                         renderer.get_camera_extrinsics(3))
+    gt = (seq["frames_color"][3].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
+    assert color.shape == (H, W, 3) and color.dtype == np.uint8
+    assert calculate_psnr_float(color, gt) > 17.0
+    gt_depth = seq["frames_depth"][3, 0].cpu().numpy()
+    assert np.abs(depth - gt_depth).mean() < 0.15
