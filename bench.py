@@ -45,7 +45,7 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
         return n_main * (16 * 8 * 4 + 12 + 16 * 4)
     if name == "grid_fwd[L5]":
         return (n_p0 + n_p1) / 2 * (5 * 8 * 4 + 12 + 5 * 4)
-    if name == "grid_bwd_lds[L16]" or name == "grid_bwd_atomic[L16]":
+    if name in ("grid_bwd_lds[L16]", "grid_bwd_atomic[L16]", "grid_bwd_binned[L16]"):
         # read-modify-write of every touched fp32 corner pair + x + d(encoded) fp16
         return n_main * (16 * 8 * 8 * 2 + 12 + 16 * 4)
     if name == "mlp_bwd[64-64x2-16]":
@@ -254,7 +254,7 @@ def main() -> None:
                        "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
-                       "grid_bwd": "lds" if args.grid_bwd_mode == 1 else "atomic",
+                       "grid_bwd": {0: "atomic", 1: "lds", 2: "binned"}[args.grid_bwd_mode],
                        "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
                        "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (fp16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),

@@ -75,7 +75,8 @@ uint64_t nvo_n_params(nvo_module_t m);
 int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out);
 /* Bytes of caller-owned device scratch ("ctx") that one fwd/bwd pair of this batch size needs. */
 uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
-/* Integer options: "grid_bwd_mode" 0 = global float atomics, 1 = LDS slice-owner scatter. */
+/* Integer options: "grid_bwd_mode" 0 = global float atomics, 1 = LDS slice-owner scatter (default),
+ * 2 = binned scatter for hashed levels (count / scan / scatter / accumulate; bitwise reproducible). */
 int nvo_set_option(nvo_module_t m, const char* key, int64_t value);
 
 /* input  : device float [batch][n_input_dims]

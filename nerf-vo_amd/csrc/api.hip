@@ -266,10 +266,20 @@ namespace {
 struct GridModule : nvo_module_s {
     NvoGridLevels g;
     NvoGridSlices slices;
-    int bwd_mode = 1;
+    NvoGridBins bins;
+    int bwd_mode = 1;  // 0 global atomics, 1 LDS slice owner (default, fastest), 2 binned hashed levels + slice owner
     bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
 
-    ~GridModule() override { nvo_grid_slices_destroy(&slices); }
+    ~GridModule() override {
+        nvo_grid_slices_destroy(&slices);
+        nvo_grid_bins_destroy(&bins);
+    }
+    int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
+        int rc = ensure_slices();
+        if (rc) return rc;
+        if (bwd_mode == 2) return nvo_grid_bwd_binned_launch(g, &bins, s, B, in, dout, false, soa, dparams);
+        return nvo_grid_bwd_launch(g, &slices, s, B, in, dout, false, soa, dparams, bwd_mode);
+    }
 
     static int create(uint32_t n_input_dims, const JsonObj& cfg, std::unique_ptr<GridModule>* out) {
         NVO_REQUIRE(n_input_dims == 3, "HashGrid: only 3 input dims are supported (got %u)", n_input_dims);
@@ -299,6 +309,7 @@ struct GridModule : nvo_module_s {
     }
     int ensure_slices() {
         if (bwd_mode == 1 && slices.n_slices == 0) return nvo_grid_slices_create(g, &slices);
+        if (bwd_mode == 2 && bins.n_bins == 0 && bins.dense.n_slices == 0) return nvo_grid_bins_create(g, &bins);
         return NVO_OK;
     }
     uint64_t ctx_bytes(uint32_t) const override { return 16; }
@@ -313,9 +324,7 @@ struct GridModule : nvo_module_s {
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void*,
             const void* dout, void*, float* din, float* dparams) override {
         if (dparams) {
-            int rc = ensure_slices();
-            if (rc) return rc;
-            rc = nvo_grid_bwd_launch(g, &slices, s, B, in, dout, false, soa_out, dparams, bwd_mode);
+            int rc = bwd_params(s, B, in, dout, soa_out, dparams);
             if (rc) return rc;
         }
         if (din) {
@@ -480,10 +489,7 @@ struct NwieModule : nvo_module_s {
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {
-            rc = enc->ensure_slices();
-            if (rc) return rc;
-            rc = nvo_grid_bwd_launch(enc->g, &enc->slices, s, B, in, dencoded, false, true,
-                                     dparams + net->n_params, enc->bwd_mode);
+            rc = enc->bwd_params(s, B, in, dencoded, true, dparams + net->n_params);
             if (rc) return rc;
         }
         if (din) {

@@ -372,6 +372,190 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------
+// backward w.r.t. parameters, BINNED form for hashed levels (mode 2)
+// ------------------------------------------------------------------------------------------
+// The slice-owner kernel above re-derives every sample's corner hashes once per slice of a level
+// (26-64x redundancy).  The binned form derives them a constant three times instead:
+//   k_bin_count   : per (sample, hashed level) count the corner lookups per 8K-entry slice (LDS
+//                   integer histogram per workgroup, one global add per non-empty bin)
+//   k_bin_scan    : exclusive scan of the <= 2048 bin totals (one workgroup)
+//   k_bin_scatter : same histogram -> one range reservation per (workgroup, bin) -> 4-byte records
+//                   (sample << 3 | corner) written in short contiguous runs
+//   k_bin_accumulate: one workgroup per bin walks ITS records only, re-derives weight and entry of
+//                   that single corner, accumulates in 64-bit fixed point in LDS (integer atomics),
+//                   and writes the slice with plain stores -> bitwise reproducible gradients.
+constexpr uint32_t kBinSlice = 8192;
+constexpr int kBinBlock = 256;
+
+template <bool SOA, typename DY2>
+__device__ __forceinline__ bool load_dy_nonzero(const NvoGridLevels& g, const DY2* __restrict__ dy, uint32_t N,
+                                                uint32_t level, uint32_t i, float2* out) {
+    const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+    if constexpr (sizeof(DY2) == 4) {
+        *out = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+    } else {
+        *out = *reinterpret_cast<const float2*>(&d2);
+    }
+    return out->x != 0.f || out->y != 0.f;
+}
+
+__device__ __forceinline__ uint32_t hashed_corner(const Corner& c, uint32_t k, uint32_t mask) {
+    return ((c.px + (k & 1u)) ^ ((c.py + ((k >> 1) & 1u)) * 2654435761u) ^ ((c.pz + ((k >> 2) & 1u)) * 805459861u)) & mask;
+}
+
+// grid = (ceil(N / 256), n_binned_levels).  bin ids of level j start at bin_first[j].
+template <bool SCATTER, bool SOA, typename DY2>
+__global__ void __launch_bounds__(kBinBlock)
+k_bin_count_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
+                    const uint32_t* __restrict__ binned_levels, const uint32_t* __restrict__ bin_first,
+                    uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t* __restrict__ records) {
+    extern __shared__ uint32_t hist[];  // [n_slices] histogram, then [n_slices] block bases (scatter)
+    const uint32_t level = binned_levels[blockIdx.y];
+    const uint32_t bin0 = bin_first[blockIdx.y];
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    const uint32_t n_slices = size / kBinSlice;
+    const uint32_t mask = size - 1u;
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock) hist[b] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kBinBlock + threadIdx.x;
+    uint32_t idx[8];
+    bool live = false;
+    if (i < N) {
+        float2 d;
+        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+        if (live) {
+            const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                idx[k] = hashed_corner(c, k, mask);
+                atomicAdd(&hist[idx[k] / kBinSlice], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock)
+            if (hist[b]) atomicAdd(&counts[bin0 + b], hist[b]);
+        return;
+    }
+    // reserve one contiguous range per bin for this workgroup, then hand out slots inside it
+    uint32_t* block_base = hist + n_slices;
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock) {
+        const uint32_t c = hist[b];
+        block_base[b] = c ? atomicAdd(&cursor[bin0 + b], c) : 0u;
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t b = idx[k] / kBinSlice;
+            const uint32_t slot = atomicAdd(&hist[b], 1u);
+            records[block_base[b] + slot] = (i << 3) | k;
+        }
+    }
+}
+
+// counts[n] -> base[n] (exclusive), cursor[n] = base[n]; base[n] = total.  One workgroup.
+__global__ void __launch_bounds__(1024)
+k_bin_scan(uint32_t n, const uint32_t* __restrict__ counts, uint32_t* __restrict__ base,
+           uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(n, lo + per);
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b) s += counts[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        base[n] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t b = lo; b < hi; ++b) {
+        base[b] = run;
+        cursor[b] = run;
+        run += counts[b];
+    }
+}
+
+// grid = (n_bins, n_chunks): a workgroup walks chunk `blockIdx.y` of ITS bin's records.  Loads are
+// unconditional (indices clamped into the bin) and issued kUnroll deep, so that the record ->
+// (x, dy) dependent chain is paid once per kUnroll records instead of once per record.
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(kLdsBwdBlock)
+k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
+                 const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
+                 const uint32_t* __restrict__ base, const uint32_t* __restrict__ records,
+                 float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
+    const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    const uint32_t mask = size - 1u;
+    const float scale = g.scale[level];
+    const uint32_t n_chunks = gridDim.y;
+    const uint32_t bin_begin = base[blockIdx.x], bin_end = base[blockIdx.x + 1];
+    const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
+    const uint32_t begin = bin_begin + blockIdx.y * per_chunk;
+    const uint32_t end = min(bin_end, begin + per_chunk);
+    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
+    if (begin >= end) {
+        if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
+            for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = 0.f;
+        return;
+    }
+    for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) acc[e] = 0ull;
+    __syncthreads();
+    constexpr uint32_t kUnroll = 8;
+    for (uint32_t r0 = begin + threadIdx.x; r0 < end; r0 += kUnroll * kLdsBwdBlock) {
+        uint32_t rec[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) rec[u] = records[min(r0 + u * kLdsBwdBlock, end - 1u)];
+        float2 dv[kUnroll];
+        float xv[kUnroll][3];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t i = rec[u] >> 3;
+            const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+            if constexpr (sizeof(DY2) == 4) {
+                dv[u] = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+            } else {
+                dv[u] = *reinterpret_cast<const float2*>(&d2);
+            }
+            xv[u][0] = x[3 * (size_t)i + 0];
+            xv[u][1] = x[3 * (size_t)i + 1];
+            xv[u][2] = x[3 * (size_t)i + 2];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t k = rec[u] & 7u;
+            const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
+            const uint32_t idx = hashed_corner(c, k, mask);
+            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                            ((k & 4u) ? c.wz : 1.f - c.wz);
+            if (r0 + u * kLdsBwdBlock < end)  // idx / kBinSlice == slice by construction of the bins
+                AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y);
+        }
+    }
+    __syncthreads();
+    if (n_chunks == 1) {
+        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
+    } else {
+        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) {
+            const float v = AccFixed::get(acc, e);
+            if (v != 0.f) atomicAdd(gr + e, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward w.r.t. the input position (needed for analytic normals and pose gradients)
 // ------------------------------------------------------------------------------------------
 // One thread per (sample, level); per-level partials are combined with float atomics into
@@ -450,7 +634,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 
 // Slice tables for the LDS backward live in a small device buffer owned by the module.
 
-int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask) {
     struct Item { uint32_t level, first, chunk, n_chunks; };
     // Per level: accumulator kind and slice size.  Large hashed tables (>= 2^18 entries: a 20K-entry
     // slice sees <= 8 % of the lookups) use fp32 / 20K-entry slices, everything else 64-bit fixed
@@ -473,6 +657,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
     };
     uint32_t base_total = 0;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
+        if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
         const uint32_t se = float_mode(l) ? kSliceFloat : kSliceFixed;
         for (uint32_t f = 0; f < size; f += se) base_total += base_chunks(size - f < se ? size - f : se, size);
@@ -482,6 +667,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
     // N / n_chunks samples with a high hit rate (short but atomic-heavy).
     std::vector<Item> single, chunked;
     for (int l = (int)g.n_levels - 1; l >= 0; --l) {
+        if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
         const bool fm = float_mode((uint32_t)l);
         const uint32_t se = fm ? kSliceFloat : kSliceFixed;
@@ -504,6 +690,10 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s) {
         if (lo < s->zero_first) s->zero_first = lo;
         if (hi > s->zero_last) s->zero_last = hi;
     }
+    if (all.empty()) {
+        s->d_level = s->d_first = nullptr;
+        return NVO_OK;
+    }
     NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size()));
     s->d_first = nullptr;
     NVO_CHECK_HIP(hipMemcpy(s->d_level, all.data(), sizeof(Item) * all.size(), hipMemcpyHostToDevice));
@@ -514,6 +704,112 @@ void nvo_grid_slices_destroy(NvoGridSlices* s) {
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
     s->n_slices = 0;
+}
+
+int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b) {
+    std::vector<uint32_t> levels, first, bin_level, bin_slice;
+    b->binned_mask = 0;
+    b->max_slices = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
+        const uint32_t size = g.offset[l + 1] - g.offset[l];
+        if (!g.hashed[l] || size < kBinSlice || (size & (size - 1u))) continue;
+        levels.push_back(l);
+        first.push_back((uint32_t)bin_level.size());
+        const uint32_t n_slices = size / kBinSlice;
+        if (n_slices > b->max_slices) b->max_slices = n_slices;
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            bin_level.push_back(l);
+            bin_slice.push_back(s);
+        }
+        b->binned_mask |= 1u << l;
+    }
+    b->n_binned_levels = (uint32_t)levels.size();
+    b->n_bins = (uint32_t)bin_level.size();
+    if (b->n_bins) {
+        const size_t words = 2 * levels.size() + 2 * bin_level.size() + 3 * bin_level.size() + 1;
+        NVO_CHECK_HIP(hipMalloc((void**)&b->d_binned_levels, sizeof(uint32_t) * words));
+        uint32_t* p = b->d_binned_levels;
+        b->d_bin_first = p + levels.size();
+        b->d_bin_level = b->d_bin_first + levels.size();
+        b->d_bin_slice = b->d_bin_level + bin_level.size();
+        b->d_counts = b->d_bin_slice + bin_level.size();
+        b->d_base = b->d_counts + bin_level.size();
+        b->d_cursor = b->d_base + bin_level.size() + 1;
+        NVO_CHECK_HIP(hipMemcpy(b->d_binned_levels, levels.data(), 4 * levels.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(b->d_bin_first, first.data(), 4 * first.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(b->d_bin_level, bin_level.data(), 4 * bin_level.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(b->d_bin_slice, bin_slice.data(), 4 * bin_slice.size(), hipMemcpyHostToDevice));
+    }
+    const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
+    return nvo_grid_slices_create(g, &b->dense, all & ~b->binned_mask);
+}
+
+void nvo_grid_bins_destroy(NvoGridBins* b) {
+    if (b->d_binned_levels) (void)hipFree(b->d_binned_levels);
+    if (b->d_records) (void)hipFree(b->d_records);
+    b->d_binned_levels = b->d_records = nullptr;
+    b->records_cap = 0;
+    b->n_bins = b->n_binned_levels = 0;
+    nvo_grid_slices_destroy(&b->dense);
+}
+
+// mode 2: binned scatter for hashed levels + slice-owner items for the rest
+int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
+                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad) {
+    NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
+    NVO_REQUIRE(N < (1u << 29), "grid_bwd_binned: batch too large for 29-bit sample ids");
+    NVO_PROF(stream, "grid_bwd_binned[L%u]", g.n_levels);
+    if (bins->n_bins) {
+        const size_t need = (size_t)N * 8 * bins->n_binned_levels;
+        if (need > bins->records_cap) {  // grows during warm-up only; never while a graph is captured
+            if (bins->d_records) NVO_CHECK_HIP(hipFree(bins->d_records));
+            NVO_CHECK_HIP(hipMalloc((void**)&bins->d_records, sizeof(uint32_t) * need));
+            bins->records_cap = need;
+        }
+        if (int rc = nvo_zero_async(bins->d_counts, sizeof(uint32_t) * bins->n_bins, stream)) return rc;
+        const dim3 grid(nvo_div_up(N, kBinBlock), bins->n_binned_levels), block(kBinBlock);
+        // few bins (small tables): several workgroups per bin, combined with contiguous float atomics
+        uint32_t acc_chunks = 1;
+        while (bins->n_bins * acc_chunks < 512u && acc_chunks < 64u) acc_chunks *= 2;
+        if (acc_chunks > 1) {
+            for (uint32_t j = 0; j < 32; ++j) {
+                if (!((bins->binned_mask >> j) & 1u)) continue;
+                if (int rc = nvo_zero_async(grad + 2 * (size_t)g.offset[j],
+                                            sizeof(float) * 2 * (size_t)(g.offset[j + 1] - g.offset[j]), stream))
+                    return rc;
+            }
+        }
+        const size_t lds_hist = sizeof(uint32_t) * 2 * bins->max_slices;
+        const size_t lds_acc = sizeof(unsigned long long) * 2 * kBinSlice;
+#define NVO_LAUNCH_BIN(SOA_, T_)                                                                             \
+    do {                                                                                                     \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_bin_accumulate<SOA_, T_>,                       \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));   \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        NVO_LAUNCH((k_bin_count_scatter<false, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy, \
+                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, bins->d_records); \
+        NVO_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, stream, bins->n_bins, bins->d_counts, bins->d_base,   \
+                   bins->d_cursor);                                                                          \
+        NVO_LAUNCH((k_bin_count_scatter<true, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy,  \
+                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, bins->d_records); \
+        NVO_LAUNCH((k_bin_accumulate<SOA_, T_>), dim3(bins->n_bins, acc_chunks), dim3(kLdsBwdBlock), lds_acc, stream, g, N, x, \
+                   (const T_*)dy, bins->d_bin_level, bins->d_bin_slice, bins->d_base, bins->d_records, grad); \
+    } while (0)
+        if (soa) {
+            if (dy_is_float) NVO_LAUNCH_BIN(true, float2); else NVO_LAUNCH_BIN(true, __half2);
+        } else {
+            if (dy_is_float) NVO_LAUNCH_BIN(false, float2); else NVO_LAUNCH_BIN(false, __half2);
+        }
+#undef NVO_LAUNCH_BIN
+        NVO_CHECK_LAUNCH();
+    }
+    if (bins->dense.n_slices) {
+        return nvo_grid_bwd_launch(g, &bins->dense, stream, N, x, dy, dy_is_float, soa, grad, 1);
+    }
+    return NVO_OK;
 }
 
 // mode: 0 = global atomics, 1 = LDS slice owner.  dy_is_float selects float2 vs half2 input.

@@ -15,7 +15,29 @@ struct NvoGridSlices {
     uint32_t* d_first = nullptr;
     uint32_t zero_first = 0, zero_last = 0;  // entry range flushed with atomics (zeroed per launch)
 };
-int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s);
+// level_mask: bit l set -> level l gets slice-owner work items (default: all levels)
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu);
+
+// Binned backward (mode 2): hashed levels go through count/scan/scatter/accumulate, the remaining
+// (dense, small) levels through the slice-owner items in `dense`.
+struct NvoGridBins {
+    uint32_t n_binned_levels = 0, n_bins = 0, max_slices = 0;
+    uint32_t binned_mask = 0;
+    uint32_t* d_binned_levels = nullptr;  // [n_binned_levels]
+    uint32_t* d_bin_first = nullptr;      // [n_binned_levels]
+    uint32_t* d_bin_level = nullptr;      // [n_bins]
+    uint32_t* d_bin_slice = nullptr;      // [n_bins]
+    uint32_t* d_counts = nullptr;         // [n_bins]
+    uint32_t* d_base = nullptr;           // [n_bins + 1]
+    uint32_t* d_cursor = nullptr;         // [n_bins]
+    uint32_t* d_records = nullptr;        // [records_cap]
+    size_t records_cap = 0;
+    NvoGridSlices dense;
+};
+int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b);
+void nvo_grid_bins_destroy(NvoGridBins* b);
+int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
+                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
 void nvo_grid_slices_destroy(NvoGridSlices* s);
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices);

@@ -85,7 +85,7 @@ class EngineConfig:
     camera_mode: str = "SE3"              # "SE3" (reference's explicit config) | "SO3xR3" (nerfacto model default)
     camera_trans_l2_penalty: float = 1e-2  # camera_opt_regularizer (nerfstudio >= 1.0 CameraOptimizer [UPSTREAM])
     camera_rot_l2_penalty: float = 1e-3
-    grid_bwd_mode: int = 1                # 1 = LDS slice-owner scatter, 0 = global atomics
+    grid_bwd_mode: int = 1                # 1 = LDS slice owner (fastest), 2 = binned hashed levels (bitwise reproducible), 0 = global atomics
     seed: int = 1337
 
 

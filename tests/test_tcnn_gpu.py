@@ -92,7 +92,7 @@ def test_grid_indices_bit_exact(device, cfg):
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
-@pytest.mark.parametrize("bwd_mode", [0, 1], ids=["atomic", "lds"])
+@pytest.mark.parametrize("bwd_mode", [0, 1, 2], ids=["atomic", "lds", "binned"])
 def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     import nerf_vo_amd.tinycudann as tcnn
     from oracle import grid as G
@@ -134,7 +134,7 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
     grads = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
         enc.params.grad = None
         y = enc(x)
@@ -142,6 +142,13 @@ def test_grid_bwd_lds_matches_atomic_large(device):
         grads.append(enc.params.grad.clone())
     torch.cuda.synchronize()
     _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
+    _assert_close(grads[2], grads[0], rtol=1e-3, atol_scale=1e-5, what="binned vs atomic dL/dparams")
+    # the binned form accumulates hashed levels in fixed point with a single owner per slice: bitwise reproducible
+    enc.native_tcnn_module.set_option("grid_bwd_mode", 2)
+    enc.params.grad = None
+    (enc(x).float() * dy).sum().backward()
+    hashed_lo = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
+    assert torch.equal(enc.params.grad[hashed_lo:], grads[2][hashed_lo:])
     # every sample distributes a total weight of 1 per level/feature: sum of grads == sum of dy16
     dy16 = (dy * 128).half().double() / 128
     assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0

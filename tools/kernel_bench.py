@@ -41,7 +41,7 @@ def main():
         t = torch.linspace(0, 0.4, 48, device=dev).view(1, 48, 1)
         x = (o + d * t).clamp(0.001, 0.999).reshape(-1, 3)[:n].contiguous().requires_grad_(False)
         dy = torch.randn(n, enc.n_output_dims, device=dev)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
             for it in range(args.iters + 3):
                 if it == 3:
