@@ -97,6 +97,13 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner on
+    # communicator creation) write to fd 1 directly, so fd 1 is pointed at stderr for the whole run and
+    # the result is written to a private duplicate of the original stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,7 +269,8 @@ def main() -> None:
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -344,16 +344,18 @@ int nvo_fill_i32(nvo_stream_t stream, uint32_t n, int32_t* ptr, int32_t value);
  * the fp16 working copy.  grads are multiplied by grad_scale first (1/loss_scale).  step counts from 1.
  * skip_flag: device uint32 or NULL; a non-zero value makes the call a no-op. */
 int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
-                  const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
+                  const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
                   const uint32_t* skip_flag, const float* hyper_dev);
+/* grads: device float[n], or device fp16[n] when grads_are_half != 0 (the buffer a compressed
+ * all-reduce leaves behind: no cast-back pass). */
 /* hyper_dev (nullable): device float[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} overriding the
  * by-value arguments, so that a captured hipGraph of the step can be replayed with new values. */
 /* dst[i] = host_values[i] for n <= 16 floats; the values travel as kernel arguments (no host buffer
  * has to stay alive), used to refresh per-step scalars ahead of a graph replay. */
 int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* host_values);
 /* *flag = any(!isfinite(grads)) */
-int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag);
+int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
 
 #ifdef __cplusplus

@@ -124,9 +124,9 @@ _SIGNATURES = {
     "nvo_ngp_thickness": (_int, [_p, _u32, _p, _u32, _int, _p]),
     "nvo_fill_i32": (_int, [_p, _u32, _p, _i32]),
     # group E
-    "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
+    "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
     "nvo_write_floats": (_int, [_p, _p, _u32, _p]),
-    "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _p]),
+    "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
 }
 

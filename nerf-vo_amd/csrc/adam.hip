@@ -11,39 +11,79 @@
 
 namespace {
 
+__device__ __forceinline__ float load_grad(const float* g, uint64_t i) { return g[i]; }
+__device__ __forceinline__ float load_grad(const _Float16* g, uint64_t i) { return (float)g[i]; }
+
+struct AdamHyper {
+    float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale, weight_decay;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamHyper& h) {
+    float gi = g * h.grad_scale;
+    if (h.weight_decay != 0.f) gi += h.weight_decay * p;
+    m = h.beta1 * m + (1.f - h.beta1) * gi;
+    v = h.beta2 * v + (1.f - h.beta2) * gi * gi;
+    const float denom = sqrtf(v) / h.bias2_sqrt + h.eps;
+    p -= (h.lr / h.bias1) * (m / denom);
+}
+
+// GT = float (local gradient) or _Float16 (the fp16 buffer a compressed all-reduce leaves behind).
+// The body works on 4 consecutive parameters per thread through 16-byte accesses when the range is
+// 16-byte aligned (HBM-bound kernel: 28 B + 2 B per parameter), scalar otherwise / for the tail.
+template <typename GT>
 __global__ void __launch_bounds__(256)
-k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const float* __restrict__ g,
-       float* __restrict__ m, float* __restrict__ v, float lr, float beta1, float beta2, float eps,
-       float bias1, float bias2_sqrt, float grad_scale, float weight_decay,
-       const uint32_t* __restrict__ skip_flag, const float* __restrict__ hyper_dev) {
+k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
+       float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag,
+       const float* __restrict__ hyper_dev, int vec4) {
     if (skip_flag && *skip_flag) return;
     if (hyper_dev) {  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} kept in device memory (graph replay)
-        lr = hyper_dev[0];
-        bias1 = hyper_dev[1];
-        bias2_sqrt = hyper_dev[2];
+        h.lr = hyper_dev[0];
+        h.bias1 = hyper_dev[1];
+        h.bias2_sqrt = hyper_dev[2];
     }
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float pi = p[i];
-        float gi = g[i] * grad_scale;
-        if (weight_decay != 0.f) gi += weight_decay * pi;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t done = 0;
+    if (vec4) {
+        const uint64_t n4 = n >> 2;
+        for (uint64_t q = tid; q < n4; q += stride) {
+            float4 pv = reinterpret_cast<float4*>(p)[q];
+            float4 mv = reinterpret_cast<float4*>(m)[q];
+            float4 vv = reinterpret_cast<float4*>(v)[q];
+            const uint64_t i = q << 2;
+            adam_one(pv.x, mv.x, vv.x, load_grad(g, i + 0), h);
+            adam_one(pv.y, mv.y, vv.y, load_grad(g, i + 1), h);
+            adam_one(pv.z, mv.z, vv.z, load_grad(g, i + 2), h);
+            adam_one(pv.w, mv.w, vv.w, load_grad(g, i + 3), h);
+            reinterpret_cast<float4*>(p)[q] = pv;
+            reinterpret_cast<float4*>(m)[q] = mv;
+            reinterpret_cast<float4*>(v)[q] = vv;
+            if (p16) {
+                p16[i + 0] = (_Float16)pv.x;
+                p16[i + 1] = (_Float16)pv.y;
+                p16[i + 2] = (_Float16)pv.z;
+                p16[i + 3] = (_Float16)pv.w;
+            }
+        }
+        done = n4 << 2;
+    }
+    for (uint64_t i = done + tid; i < n; i += stride) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_one(pi, mi, vi, load_grad(g, i), h);
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bias2_sqrt + eps;
-        pi -= (lr / bias1) * (mi / denom);
-        p[i] = pi;
         if (p16) p16[i] = (_Float16)pi;
     }
 }
 
+template <typename GT>
 __global__ void __launch_bounds__(256)
-k_nonfinite_flag(uint64_t n, const float* __restrict__ g, uint32_t* __restrict__ flag) {
+k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float x = g[i];
+        const float x = load_grad(g, i);
         bad = bad || !(fabsf(x) <= 3.0e38f);
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -78,32 +118,44 @@ int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 extern "C" {
 
 int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_half,
-                  const float* grads, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
+                  const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
                   const uint32_t* skip_flag, const float* hyper_dev) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: NULL argument");
     NVO_REQUIRE(step >= 1, "adam_step: step counts from 1");
     if (n == 0) return NVO_OK;
     NVO_PROF(stream, "adam");
-    const float bias1 = 1.f - powf(beta1, (float)step);
-    const float bias2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    uint32_t blocks = nvo_div_up(n, 256 * 4);
-    if (blocks > 2048) blocks = 2048;
-    NVO_LAUNCH(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
-                       (_Float16*)params_half, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bias1,
-                       bias2_sqrt, grad_scale, weight_decay, skip_flag, hyper_dev);
+    AdamHyper h{lr, beta1, beta2, eps, 1.f - powf(beta1, (float)step), sqrtf(1.f - powf(beta2, (float)step)),
+                grad_scale, weight_decay};
+    const uintptr_t align = (uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
+    const int vec4 = (align & 15u) == 0 && (!params_half || ((uintptr_t)params_half & 7u) == 0) &&
+                     (((uintptr_t)grads & (grads_are_half ? 7u : 15u)) == 0);
+    uint32_t blocks = nvo_div_up(n, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (grads_are_half) {
+        NVO_LAUNCH(k_adam<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
+                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+    } else {
+        NVO_LAUNCH(k_adam<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
+                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+    }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
 
-int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const float* grads, uint32_t* flag) {
+int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag) {
     NVO_REQUIRE(grads && flag, "nonfinite_flag: NULL argument");
     NVO_PROF(stream, "nonfinite_flag");
     if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;
-    NVO_LAUNCH(k_nonfinite_flag, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, grads, flag);
+    if (grads_are_half) {
+        NVO_LAUNCH(k_nonfinite_flag<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n,
+                   (const _Float16*)grads, flag);
+    } else {
+        NVO_LAUNCH(k_nonfinite_flag<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const float*)grads, flag);
+    }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

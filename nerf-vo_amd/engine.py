@@ -481,13 +481,16 @@ class NerfactoEngine:
         return {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal,
                 "camera_opt": self.camera_lr(self.step)}[g]
 
-    def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False) -> None:
+    def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False,
+                       grads_half: torch.Tensor | None = None) -> None:
         """Non-finite check + fused Adam per group.  ``from_device_scalars``: lr and bias corrections
         are read from self.dev_scalars (filled by _write_step_scalars) instead of kernel arguments, and
         the per-group step counters are NOT advanced here -- the form a captured graph replays."""
         cfg = self.cfg
         stream = _stream(self.device)
-        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), _ptr(self.skip_flag))
+        # grads_half: the fp16 buffer a compressed all-reduce left behind -- consumed directly
+        gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (grads_half, 2, 1)
+        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:
                 continue
@@ -500,7 +503,7 @@ class NerfactoEngine:
                 hyper = C.c_void_p(self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi))
             esz = 4
             _call("nvo_adam_step", stream, hi - lo, C.c_void_p(self.params.data_ptr() + lo * esz),
-                  C.c_void_p(self.params_half.data_ptr() + lo * 2), C.c_void_p(self.grads.data_ptr() + lo * esz),
+                  C.c_void_p(self.params_half.data_ptr() + lo * 2), C.c_void_p(gbuf.data_ptr() + lo * gsz), ghalf,
                   C.c_void_p(self.exp_avg.data_ptr() + lo * esz), C.c_void_p(self.exp_avg_sq.data_ptr() + lo * esz),
                   self._group_lr(g), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, max(self.opt_steps[g], 1),
                   1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), hyper)
@@ -537,6 +540,7 @@ class NerfactoEngine:
         groups = ["fields"] + (["proposal_networks"] if updated else []) + (["camera_opt"] if cfg.optimize_poses else [])
         has_depth = dataset.frames_depth is not None
         key = (R, updated, has_depth, all_reduce is not None)
+        self._reducer_compress = getattr(all_reduce, "compress", None)
         if self._pix_scale is None:
             self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
             self._pix_scale_host = None
@@ -551,8 +555,11 @@ class NerfactoEngine:
             self._graphs[key] = entry
         entry["main"].replay()
         if all_reduce is not None:
-            active = [g for g in groups]
-            all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)])
+            segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in groups)]
+            if entry.get("half") is not None:  # compressed exchange: reduce the captured fp16 buffer in place
+                all_reduce.reduce_half(self.grads, entry["half"], segs)
+            else:
+                all_reduce(self.grads, segments=segs)
             entry["opt"].replay()
         if updated:
             self.steps_since_proposal_update = 0
@@ -578,8 +585,12 @@ class NerfactoEngine:
             self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
                                   anneal=1.0, anneal_dev=anneal_ptr)
 
+        half = None
+        if split_optimizer and getattr(self, "_reducer_compress", None) == "fp16":
+            half = torch.zeros(self.n_params, dtype=torch.float16, device=dev)
+
         def body_opt():
-            self.optimizer_step(groups, from_device_scalars=True)
+            self.optimizer_step(groups, from_device_scalars=True, grads_half=half)
 
         # warm-up on a side stream (allocations, lazy module state), then capture
         side = torch.cuda.Stream(device=dev)
@@ -593,7 +604,7 @@ class NerfactoEngine:
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half), saved):
             dst.copy_(src)  # the warm-up steps must not count as training
-        entry = {}
+        entry = {"half": half}
         g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_main):
             body_main()
@@ -619,8 +630,11 @@ class NerfactoEngine:
         if all_reduce is not None:
             # one exchange per iteration: the gradient ranges that are non-zero on this step
             active = [g for g in groups if g != "camera_opt" or self.cfg.optimize_poses]
-            all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)])
-        self.optimizer_step(groups)
+            reduced_half = all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)],
+                                      keep_half=True)
+            self.optimizer_step(groups, grads_half=reduced_half)
+        else:
+            self.optimizer_step(groups)
         if updated:
             self.steps_since_proposal_update = 0
         self.steps_since_proposal_update += 1

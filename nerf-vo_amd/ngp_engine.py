@@ -247,13 +247,13 @@ class NgpEngine:
         cfg = self.cfg
         stream = _stream(self.device)
         self.opt_step += 1
-        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), _ptr(self.skip_flag))
+        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), 0, _ptr(self.skip_flag))
         n_grid = self.density_net.n_params - self.n_density_mlp
         # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only
         for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
                               (self.density_net.n_params, self.n_rgb, cfg.l2_reg)):
             _call("nvo_adam_step", stream, size, C.c_void_p(self.params.data_ptr() + 4 * off),
-                  C.c_void_p(self.params_half.data_ptr() + 2 * off), C.c_void_p(self.grads.data_ptr() + 4 * off),
+                  C.c_void_p(self.params_half.data_ptr() + 2 * off), C.c_void_p(self.grads.data_ptr() + 4 * off), 0,
                   C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
                   cfg.lr, cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, wd,
                   _ptr(self.skip_flag), None)

@@ -29,11 +29,30 @@ class GradientAllReduce:
         self.compress = compress
         self._half = None
 
-    def __call__(self, flat_grad: torch.Tensor, segments=None) -> None:
-        """In-place sum over ranks.  ``segments``: optional iterable of (offset, size) ranges to
-        reduce (e.g. skip the proposal networks on steps where they are not updated)."""
+    def reduce_half(self, flat_grad: torch.Tensor, half: torch.Tensor, segments) -> None:
+        """Compressed exchange into a caller-owned fp16 buffer (the optimiser then consumes ``half``
+        directly -- no cast-back pass).  Used by the graph-replayed step."""
+        ranges = [(int(o), int(n)) for o, n in segments]
+        for off, size in ranges:
+            half[off:off + size].copy_(flat_grad[off:off + size])
         if not self.dist.is_initialized():
-            return  # single process without a process group: identity
+            return
+        handles = []
+        for off, size in ranges:
+            for lo in range(off, off + size, self.bucket_numel):
+                hi = min(off + size, lo + self.bucket_numel)
+                handles.append(self.dist.all_reduce(half[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+        for h in handles:
+            h.wait()
+
+    def __call__(self, flat_grad: torch.Tensor, segments=None, keep_half: bool = False):
+        """In-place sum over ranks.  ``segments``: optional iterable of (offset, size) ranges to
+        reduce (e.g. skip the proposal networks on steps where they are not updated).  With
+        ``keep_half`` and fp16 compression the reduced fp16 buffer is RETURNED instead of being cast
+        back into ``flat_grad`` (the fused Adam reads fp16 gradients directly)."""
+        if not self.dist.is_initialized():
+            return None  # single process without a process group: identity
         ranges = [(0, flat_grad.numel())] if segments is None else [(int(o), int(n)) for o, n in segments]
         src = flat_grad
         if self.compress == "fp16":
@@ -51,8 +70,11 @@ class GradientAllReduce:
         for h in handles:
             h.wait()
         if self.compress == "fp16":
+            if keep_half:
+                return self._half
             for off, size in ranges:
                 flat_grad[off:off + size].copy_(self._half[off:off + size])
+        return None
 
 
 def shard_ray_count(global_rays: int, world_size: int, rank: int) -> int:

@@ -206,8 +206,8 @@ def test_adam_matches_torch_semantics(device):
     for step in range(1, 6):
         grad = torch.randn(n, generator=g) * 128.0
         gd = grad.to(device)
-        _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gd), _ptr(flag))
-        _call("nvo_adam_step", _stream(device), n, _ptr(pd), _ptr(p16), _ptr(gd), _ptr(md), _ptr(vd), 1e-2, 0.9, 0.999,
+        _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gd), 0, _ptr(flag))
+        _call("nvo_adam_step", _stream(device), n, _ptr(pd), _ptr(p16), _ptr(gd), 0, _ptr(md), _ptr(vd), 1e-2, 0.9, 0.999,
               1e-15, step, 1.0 / 128.0, 0.0, _ptr(flag), None)
         pr, mr, vr = adam_reference(pr, grad.double() / 128.0, mr, vr, 1e-2, step)
     torch.cuda.synchronize()
@@ -216,11 +216,23 @@ def test_adam_matches_torch_semantics(device):
     # a non-finite gradient anywhere skips the whole step (GradScaler semantics)
     before = pd.clone()
     gd[12345] = float("inf")
-    _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gd), _ptr(flag))
-    _call("nvo_adam_step", _stream(device), n, _ptr(pd), _ptr(p16), _ptr(gd), _ptr(md), _ptr(vd), 1e-2, 0.9, 0.999,
+    _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gd), 0, _ptr(flag))
+    _call("nvo_adam_step", _stream(device), n, _ptr(pd), _ptr(p16), _ptr(gd), 0, _ptr(md), _ptr(vd), 1e-2, 0.9, 0.999,
           1e-15, 6, 1.0 / 128.0, 0.0, _ptr(flag), None)
     torch.cuda.synchronize()
     assert int(flag.item()) == 1 and torch.equal(before, pd)
+    # fp16 gradient buffer (what a compressed all-reduce hands over) gives the same update as its fp32 cast
+    g16 = (torch.randn(n, generator=g) * 4).half().to(device)
+    pa, pb = pd.clone(), pd.clone()
+    ma, mb, va, vb = md.clone(), md.clone(), vd.clone(), vd.clone()
+    flag.zero_()
+    _call("nvo_adam_step", _stream(device), n, _ptr(pa), None, _ptr(g16), 1, _ptr(ma), _ptr(va), 1e-2, 0.9, 0.999,
+          1e-15, 7, 1.0 / 128.0, 0.0, _ptr(flag), None)
+    g32 = g16.float()
+    _call("nvo_adam_step", _stream(device), n, _ptr(pb), None, _ptr(g32), 0, _ptr(mb), _ptr(vb), 1e-2, 0.9, 0.999,
+          1e-15, 7, 1.0 / 128.0, 0.0, _ptr(flag), None)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
 def test_eval_render_matches_oracle(device):
