@@ -209,6 +209,16 @@ typedef struct nvo_main_loss_args {
     uint32_t dpre_stride;
     void* drgb;                  /* fp16 [R*S][drgb_stride]: cols 0..2 gradient, others zeroed */
     uint32_t drgb_stride;
+    /* analytic normals (nerfacto predict_normals + the reference's monosdf normal-loss hook,
+     * /root/reference/nerf_vo/mapping/nerfstudio_utils.py:337-350).  All nullable / zero -> disabled. */
+    const float* dsigma_dx;      /* [R*S][3] d(density pre-activation)/d(x01) from nvo_bwd(dL_dparams=NULL) with
+                                    dL_doutput = dsigma_scale * e_0; per-sample normal = -normalize(.) and is a
+                                    CONSTANT of the graph (torch.autograd.grad without create_graph) */
+    float dsigma_inv_scale;      /* 1 / dsigma_scale, applied before the 1e-12 normalisation clamp */
+    const float* gt_normal;      /* [R][3] target in the (n+1)/2 colour space the dataset hands out, or NULL */
+    float normal_mult;           /* normal_loss_mult (5e-6 in the reference config) */
+    float* out_normals;          /* [R][3] NormalsRenderer (safe-normalised) -> NormalsShader (n+1)/2, or NULL */
+                                 /* loss slot 6 of the shard receives normal_mult * monosdf_normal_loss */
 } nvo_main_loss_args;
 int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
 

@@ -38,7 +38,9 @@ class MainLossArgs(C.Structure):
                 ("depth_mult", _f), ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f),
                 ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p), ("out_expected_depth", _p),
                 ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
-                ("drgb", _p), ("drgb_stride", _u32)]
+                ("drgb", _p), ("drgb_stride", _u32),
+                ("dsigma_dx", _p), ("dsigma_inv_scale", _f), ("gt_normal", _p), ("normal_mult", _f),
+                ("out_normals", _p)]
 
 
 class PropLossArgs(C.Structure):

@@ -238,6 +238,30 @@ k_main_render_loss(nvo_main_loss_args a) {
         const float num = wave_sum(wi * mid);
         if (lane == 0) a.out_expected_depth[r] = num / (acc + 1e-10f);  // clip to [min,max] steps: host
     }
+    // ---- analytic normals: n_i = -normalize(d pre_i / d x01_i); rendered N = safe_normalize(sum w_i n_i);
+    //      the "normals" output is NormalsShader(N) = (N + 1) / 2
+    float nrm[3] = {0.f, 0.f, 0.f};
+    float Nv[3] = {0.f, 0.f, 0.f}, Nhat[3] = {0.f, 0.f, 0.f};
+    float rN = 0.f;
+    const bool has_normals = a.dsigma_dx != nullptr;
+    if (has_normals) {
+        if (act) {
+            const float* gp = a.dsigma_dx + 3 * (so + lane);
+            const float gx = gp[0] * a.dsigma_inv_scale, gy = gp[1] * a.dsigma_inv_scale,
+                        gz = gp[2] * a.dsigma_inv_scale;
+            const float inv = -1.f / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
+            nrm[0] = gx * inv; nrm[1] = gy * inv; nrm[2] = gz * inv;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Nv[k] = wave_sum(wi * nrm[k]);
+        rN = sqrtf(Nv[0] * Nv[0] + Nv[1] * Nv[1] + Nv[2] * Nv[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Nhat[k] = Nv[k] / (rN + 1e-10f);  // safe_normalize
+        if (a.out_normals && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.out_normals[3 * (size_t)r + k] = 0.5f * (Nhat[k] + 1.f);
+        }
+    }
     if (!a.dpre) return;
 
     // ---- losses
@@ -294,6 +318,50 @@ k_main_render_loss(nvo_main_loss_args a) {
         }
         l_depth = wave_sum(term) * a.inv_rays * a.depth_level_div;
     }
+    // monosdf normal loss on the shaded normals: L1 + (1 - cos) between the L2-normalised vectors
+    float l_normal = 0.f;
+    if (has_normals && a.gt_normal && a.normal_mult != 0.f) {
+        float sh[3], q[3], p[3], dp[3];
+        float rs = 0.f, rq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sh[k] = 0.5f * (Nhat[k] + 1.f);
+            q[k] = a.gt_normal[3 * (size_t)r + k];
+            rs += sh[k] * sh[k];
+            rq += q[k] * q[k];
+        }
+        rs = fmaxf(sqrtf(rs), 1e-12f);
+        rq = fmaxf(sqrtf(rq), 1e-12f);
+        float pdq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = sh[k] / rs;
+            q[k] /= rq;
+            l_normal += fabsf(p[k] - q[k]);
+            pdq += p[k] * q[k];
+        }
+        l_normal = (l_normal + 1.f - pdq) * a.inv_rays;
+        // backward: p = sh / |sh|, sh = (Nhat + 1) / 2, Nhat = Nv / (|Nv| + 1e-10)
+        float pdp = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = p[k] - q[k];
+            dp[k] = a.normal_mult * a.inv_rays * ((e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) - q[k]);
+            pdp += p[k] * dp[k];
+        }
+        float dN[3], NdN = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dN[k] = 0.5f * (dp[k] - p[k] * pdp) / rs;
+            NdN += Nv[k] * dN[k];
+        }
+        const float den = rN + 1e-10f;
+        const float radial = rN > 0.f ? NdN / (rN * den * den) : 0.f;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gw += (dN[k] / den - Nv[k] * radial) * nrm[k];
+        }
+    }
     if (lane == 0) {
         // 64 shards of 8 floats: thousands of adds to ONE word serialise at the memory side
         // (~88 same-address atomics per us on MI355X); the host sums the shards.
@@ -301,6 +369,7 @@ k_main_render_loss(nvo_main_loss_args a) {
         atomicAdd(shard + 0, a.rgb_mult * l_rgb);
         atomicAdd(shard + 1, a.distortion_mult * l_dist);
         atomicAdd(shard + 2, a.depth_mult * l_depth);
+        if (l_normal != 0.f) atomicAdd(shard + 6, a.normal_mult * l_normal);
     }
     if (act) g[lane] = gw;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

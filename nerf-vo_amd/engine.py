@@ -73,6 +73,7 @@ class EngineConfig:
     distortion_loss_mult: float = 0.002
     depth_loss_mult: float = 0.001
     depth_sigma: float = 0.001
+    normal_loss_mult: float = 5e-6        # reference: nerf_vo/mapping/nerfstudio.py:77 (monosdf normal supervision)
     loss_scale: float = 128.0
     lr_fields: float = 1e-2
     lr_proposal: float = 1e-2
@@ -227,6 +228,8 @@ class NerfactoEngine:
         ws["cam_idx"] = torch.empty(R, dtype=torch.int32, device=dev)
         ws["gt_rgb"] = torch.empty(R, 3, **f32)
         ws["gt_depth"] = torch.empty(R, **f32)
+        ws["gt_normal"] = torch.empty(R, 3, **f32)
+        ws["out_normals"] = torch.empty(R, 3, **f32)
         ws["dirs01"] = torch.empty(R, 3, **f32)
         ws["sh"] = torch.empty(R, 16, **f16)
         ws["out_rgb"] = torch.empty(R, 3, **f32)
@@ -276,6 +279,22 @@ class NerfactoEngine:
         _call("nvo_fwd", net.handle, stream, R * S, _ptr(ws[f"x{k}"]), self._param_ptr(seg, self.params_half),
               _ptr(ws[f"out{k}"]), _ptr(ws[f"ctx{k}"]))
 
+    def _analytic_normal_grads(self, ws, stream) -> None:
+        """d(density pre-activation)/d(x01) of the main field -> ws["dsigma_dx"] [R*48,3]: the quantity
+        NerfactoField.get_normals takes with torch.autograd.grad(..., retain_graph=True) (no create_graph,
+        so the normals are constants of the loss graph).  One input-only backward of the base network with
+        dL/doutput = loss_scale * e_0 -- the same kernels the pose gradient uses."""
+        km = len(self.prop_nets)
+        N = ws["R"] * self.levels[km]
+        if "dsigma_dx" not in ws:
+            ws["dsigma_dx"] = torch.empty(N, 3, dtype=torch.float32, device=self.device)
+            seed = torch.zeros(N, 16, dtype=torch.float16, device=self.device)
+            seed[:, 0] = self.cfg.loss_scale
+            ws["dsigma_seed"] = seed
+        _call("nvo_bwd", self.base_net.handle, stream, N, _ptr(ws[f"x{km}"]),
+              self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws["dsigma_seed"]),
+              _ptr(ws[f"ctx{km}"]), _ptr(ws["dsigma_dx"]), None)
+
     def _weights_pdf(self, ws, k: int, anneal: float, jitter, stream, resample: bool, anneal_dev: int | None = None):
         cfg = self.cfg
         R, S = ws["R"], self.levels[k]
@@ -322,7 +341,8 @@ class NerfactoEngine:
             d_sh=ws["d_sh"].data_ptr() if (training and "d_sh" in ws) else None,
             d_weights=self._param_ptr("field.color", self.grads).value if training else None)
 
-    def _main_loss_args(self, ws, training: bool, has_depth: bool):
+    def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
+                        has_gt_normal: bool = False):
         cfg = self.cfg
         km = len(self.prop_nets)
         R, S = ws["R"], self.levels[-1]
@@ -341,7 +361,11 @@ class NerfactoEngine:
             out_accumulation=ws["out_accumulation"].data_ptr(), weights=ws[f"weights{km}"].data_ptr(),
             losses=self.losses.data_ptr() if training else None,
             dpre=ws[f"dout{km}"].data_ptr() if training else None, dpre_stride=16,
-            drgb=ws["drgb"].data_ptr() if training else None, drgb_stride=16)
+            drgb=ws["drgb"].data_ptr() if training else None, drgb_stride=16,
+            dsigma_dx=ws["dsigma_dx"].data_ptr() if normals else None, dsigma_inv_scale=1.0 / cfg.loss_scale,
+            gt_normal=ws["gt_normal"].data_ptr() if (normals and training and has_gt_normal) else None,
+            normal_mult=cfg.normal_loss_mult if (normals and has_gt_normal) else 0.0,
+            out_normals=ws["out_normals"].data_ptr() if normals else None)
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -366,8 +390,10 @@ class NerfactoEngine:
     # ------------------------------------------------------------------------------------------
     # one optimisation step
     # ------------------------------------------------------------------------------------------
-    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths, corrections=None):
-        """ray_indices [R,3] int64 (camera,y,x) -> origins/directions/cam idx + gathered targets."""
+    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths, corrections=None, normals=None):
+        """ray_indices [R,3] int64 (camera,y,x) -> origins/directions/cam idx + gathered targets.
+        ``normals``: optional [n,H,W,3] world-space normal images in the (n+1)/2 colour space
+        (DynamicDataset.get_dataset()['normal_image'])."""
         stream = _stream(self.device)
         R = ws["R"]
         H, W = images.shape[1], images.shape[2]
@@ -386,8 +412,11 @@ class NerfactoEngine:
         _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
         if depths is not None:
             _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 1, _ptr(depths), _ptr(ws["gt_depth"]))
+        if normals is not None:
+            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(normals), _ptr(ws["gt_normal"]))
 
-    def load_ray_bundle(self, ws, origins, directions, directions_norm, cam_idx, gt_rgb=None, gt_depth=None):
+    def load_ray_bundle(self, ws, origins, directions, directions_norm, cam_idx, gt_rgb=None, gt_depth=None,
+                        gt_normal=None):
         """Inject an existing ray bundle (+ targets) instead of generating rays from pixel indices."""
         ws["origins"].copy_(origins)
         ws["directions"].copy_(directions)
@@ -397,9 +426,11 @@ class NerfactoEngine:
             ws["gt_rgb"].copy_(gt_rgb)
         if gt_depth is not None:
             ws["gt_depth"].copy_(gt_depth.reshape(-1))
+        if gt_normal is not None:
+            ws["gt_normal"].copy_(gt_normal)
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
-                         anneal: float | None = None, anneal_dev: int | None = None):
+                         anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -416,7 +447,12 @@ class NerfactoEngine:
         km = len(self.prop_nets)
         R = ws["R"]
         pose = cfg.optimize_poses and "d_sh" in ws and self._pose_inputs is not None
-        la = self._main_loss_args(ws, True, has_depth)
+        # monosdf normal supervision (enhancement 'normal' modes): needs the analytic normals; without a
+        # target the predict_normals heads contribute exactly zero loss and are not evaluated
+        normals = has_normals and cfg.normal_loss_mult > 0.0
+        if normals:
+            self._analytic_normal_grads(ws, stream)
+        la = self._main_loss_args(ws, True, has_depth, normals=normals, has_gt_normal=normals)
         _call("nvo_main_render_loss", stream, C.byref(la))
         if pose:
             ws["d_sh"].zero_()
@@ -539,7 +575,8 @@ class NerfactoEngine:
         updated = self.proposal_update_due(step)
         groups = ["fields"] + (["proposal_networks"] if updated else []) + (["camera_opt"] if cfg.optimize_poses else [])
         has_depth = dataset.frames_depth is not None
-        key = (R, updated, has_depth, all_reduce is not None)
+        has_normals = bool(getattr(dataset, "use_normals", False)) and cfg.normal_loss_mult > 0.0
+        key = (R, updated, has_depth, all_reduce is not None, has_normals)
         self._reducer_compress = getattr(all_reduce, "compress", None)
         if self._pix_scale is None:
             self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -551,7 +588,7 @@ class NerfactoEngine:
         self._write_step_scalars(self.anneal_at(step), groups)
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None)
+            entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None, has_normals)
             self._graphs[key] = entry
         entry["main"].replay()
         if all_reduce is not None:
@@ -567,7 +604,7 @@ class NerfactoEngine:
         self.step += 1
         return updated
 
-    def _capture_step(self, dataset, R, updated, has_depth, groups, split_optimizer):
+    def _capture_step(self, dataset, R, updated, has_depth, groups, split_optimizer, has_normals=False):
         dev = self.device
         ws = self._workspace(R, True)
         intr = dataset.camera_intrinsics
@@ -580,10 +617,11 @@ class NerfactoEngine:
             u = torch.rand((R, 3), device=dev)
             ray_indices = torch.floor(u * scale).long()
             c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
-            self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None)
+            self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
+                           normals=dataset.world_normals01() if has_normals else None)
             jit = torch.rand((3, R), device=dev)
             self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
-                                  anneal=1.0, anneal_dev=anneal_ptr)
+                                  anneal=1.0, anneal_dev=anneal_ptr, has_normals=has_normals)
 
         half = None
         if split_optimizer and getattr(self, "_reducer_compress", None) == "fp16":
@@ -618,14 +656,14 @@ class NerfactoEngine:
             entry["opt"] = g_opt
         return entry
 
-    def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None):
+    def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None, normals=None):
         """One full iteration.  ``all_reduce``: optional callable(flat_grad_tensor) for multi-GPU."""
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
         if jitters is None:
             jitters = tuple(torch.rand(R, device=self.device) for _ in range(3))
-        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
-        updated = self.forward_backward(ws, jitters, has_depth=depths is not None)
+        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths, normals=normals)
+        updated = self.forward_backward(ws, jitters, has_depth=depths is not None, has_normals=normals is not None)
         groups = ["fields"] + (["proposal_networks"] if updated else []) + ["camera_opt"]
         if all_reduce is not None:
             # one exchange per iteration: the gradient ranges that are non-zero on this step
@@ -647,13 +685,15 @@ class NerfactoEngine:
              "interlevel_loss": vals[3]}
         if self.cfg.optimize_poses:
             d["camera_opt_regularizer"] = vals[5]
+        if vals[6] != 0.0:
+            d["normal_loss"] = vals[6]
         return d
 
     # ------------------------------------------------------------------------------------------
     # inference
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def render_rays(self, origins, directions, directions_norm, mean_embedding_half=None):
+    def render_rays(self, origins, directions, directions_norm, mean_embedding_half=None, normals: bool = False):
         """Eval forward for R rays (R*48 multiple of 16): rgb [R,3] clamped to [0,1], median depth,
         expected depth, accumulation.  Uses un-jittered bins and the mean appearance embedding
         (nerfacto use_average_appearance_embedding=True)."""
@@ -667,8 +707,13 @@ class NerfactoEngine:
             emb = self.view("field.embedding").view(self.cfg.num_images, -1)
             mean_embedding_half = emb.mean(dim=0, keepdim=True).to(torch.float16).contiguous()
         self._forward(ws, False, 1.0, None, None, mean_embedding_half.data_ptr(), stream)
-        la = self._main_loss_args(ws, False, False)
+        if normals:
+            self._analytic_normal_grads(ws, stream)
+        la = self._main_loss_args(ws, False, False, normals=normals)
         _call("nvo_main_render_loss", stream, C.byref(la))
-        return {"rgb": ws["out_rgb"].clamp(0.0, 1.0), "depth": ws["out_depth"].clone()[:, None],
-                "expected_depth": ws["out_expected_depth"].clone()[:, None],
-                "accumulation": ws["out_accumulation"].clone()[:, None]}
+        out = {"rgb": ws["out_rgb"].clamp(0.0, 1.0), "depth": ws["out_depth"].clone()[:, None],
+               "expected_depth": ws["out_expected_depth"].clone()[:, None],
+               "accumulation": ws["out_accumulation"].clone()[:, None]}
+        if normals:
+            out["normals"] = ws["out_normals"].clone()
+        return out

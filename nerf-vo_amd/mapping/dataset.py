@@ -96,6 +96,11 @@ class DynamicDataset(torch.utils.data.Dataset):
             data["normal_image"] = self._normal_world01[:n]
         return data
 
+    def world_normals01(self) -> torch.Tensor:
+        """The whole (fixed-address) world-space normal buffer in the (n+1)/2 colour space; rows
+        >= num_active_frames are never sampled."""
+        return self._normal_world01
+
     # ---- ingest -------------------------------------------------------------------------------
     def update(self, input: dict) -> None:
         self.insert_update(self.prepare_update(input))

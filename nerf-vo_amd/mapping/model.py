@@ -95,7 +95,8 @@ class ExtendedNerfactoModel:
             num_proposal_samples=tuple(config.num_proposal_samples_per_ray),
             num_nerf_samples=config.num_nerf_samples_per_ray, interlevel_loss_mult=config.interlevel_loss_mult,
             distortion_loss_mult=config.distortion_loss_mult, depth_loss_mult=config.depth_loss_mult,
-            depth_sigma=config.depth_sigma, max_num_iterations=max_num_iterations, seed=seed,
+            depth_sigma=config.depth_sigma, normal_loss_mult=float(config.normal_loss_mult),
+            max_num_iterations=max_num_iterations, seed=seed,
             optimize_poses=config.camera_optimizer.mode in ("SE3", "SO3xR3"),
             camera_mode=config.camera_optimizer.mode if config.camera_optimizer.mode in ("SE3", "SO3xR3") else "SE3",
             camera_trans_l2_penalty=config.camera_optimizer.trans_l2_penalty,
@@ -105,8 +106,8 @@ class ExtendedNerfactoModel:
         self.training = True
         # Loss terms whose multiplier is 0 in every shipped configuration (orientation / predicted
         # normals, nerfstudio.py:74-75) contribute exactly zero loss and zero gradient; their heads are
-        # not evaluated.  The monosdf normal loss (normal_loss_mult, enhancement 'normal' mode only)
-        # is not part of any shipped config either and is reported as unsupported when requested.
+        # not evaluated.  The monosdf normal loss (normal_loss_mult; enhancement modes containing
+        # 'normal') runs inside the fused render/loss kernel on the analytic normals of the main field.
 
     # ---- module protocol ---------------------------------------------------------------------
     def train(self, mode: bool = True):
@@ -156,7 +157,8 @@ class ExtendedNerfactoModel:
                 o = torch.cat([o, o[-1:].expand(pad, 3)])
                 d = torch.cat([d, d[-1:].expand(pad, 3)])
                 dn = torch.cat([dn, dn[-1:].expand(pad)])
-            res = self.engine.render_rays(o.contiguous(), d.contiguous(), dn.contiguous(), mean_emb)
+            res = self.engine.render_rays(o.contiguous(), d.contiguous(), dn.contiguous(), mean_emb,
+                                          normals=self.config.predict_normals)
             for k, v in res.items():
                 outs.setdefault(k, []).append(v[: hi - lo].clone())
         return {k: torch.cat(v).view(*shape, -1) for k, v in outs.items()}
@@ -170,8 +172,8 @@ class ExtendedNerfactoModel:
         cfg = self.config
         metrics = {"distortion": ld["distortion_loss"] / cfg.distortion_loss_mult if cfg.distortion_loss_mult else 0.0,
                    "depth_loss": ld["depth_loss"] / cfg.depth_loss_mult if cfg.depth_loss_mult else 0.0}
-        if batch is not None and "normal_image" in batch and cfg.normal_loss_mult > 0.0:
-            raise NotImplementedError("monosdf normal supervision (enhancement 'normal' mode) is not built yet")
+        if "normal_loss" in ld and cfg.normal_loss_mult > 0.0:
+            metrics["normal_loss"] = ld["normal_loss"] / cfg.normal_loss_mult
         return metrics
 
     def get_loss_dict(self, outputs=None, batch=None, metrics_dict=None) -> dict:

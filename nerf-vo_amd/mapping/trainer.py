@@ -104,8 +104,9 @@ class VanillaPipeline:
         else:
             ray_indices, batch = self.datamanager.next_train(step)
             c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+            normals = ds.world_normals01() if (ds.use_normals and eng.cfg.normal_loss_mult > 0.0) else None
             eng.train_step(ray_indices, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth,
-                           all_reduce=self.all_reduce)
+                           all_reduce=self.all_reduce, normals=normals)
         return None, eng.loss_dict(), self.model.get_metrics_dict()
 
 

@@ -44,6 +44,7 @@ class OracleConfig:
     distortion_loss_mult: float = 0.002
     depth_loss_mult: float = 0.001
     depth_sigma: float = 0.001
+    normal_loss_mult: float = 5e-6          # ref: nerf_vo/mapping/nerfstudio.py:77
     emulate_fp16: bool = True
     dtype: torch.dtype = torch.float64
 
@@ -91,19 +92,28 @@ class NerfactoOracle:
             self.params[name] = p.to(dt).requires_grad_(True)
 
     # -------------------------------------------------------------------------------------------
-    def _density(self, spec, grid, mlp_flat, width, n_out, origins, directions, tbins):
+    def _density(self, spec, grid, mlp_flat, width, n_out, origins, directions, tbins, want_normals=False):
         cfg = self.cfg
         pos = Rr.sample_positions(origins, directions, tbins)
         x01, selector = Rr.normalized_positions(pos)
+        if want_normals and not x01.requires_grad:
+            x01 = x01.detach().requires_grad_(True)   # NerfactoField.get_density: _sample_locations.requires_grad = True
         flat = x01.reshape(-1, 3)
         enc = G.grid_encode(spec, flat, grid, quantize_output=cfg.emulate_fp16)
         ws = M.split_weights(mlp_flat, spec.n_output_dims, n_out, width, 1)
         out = M.mlp_forward(enc, ws, "ReLU", "None", pad_value=0.0, emulate_fp16=cfg.emulate_fp16)
         pre = out[:, 0].reshape(tbins.shape[0], -1)
         density = Rr.trunc_exp(pre + cfg.density_bias) * selector.to(pre.dtype)
+        if want_normals:
+            # NerfactoField.get_normals [UPSTREAM]: autograd.grad(density_before_activation, sample_locations,
+            # grad_outputs=ones, retain_graph=True) -- no create_graph, the normals are constants
+            (gx,) = torch.autograd.grad(pre, x01, grad_outputs=torch.ones_like(pre), retain_graph=True)
+            normals = -torch.nn.functional.normalize(gx, dim=-1)
+            return density, out, normals.detach()
         return density, out
 
-    def forward(self, origins, directions, directions_norm, cam_idx, jitters, anneal=1.0, training=True):
+    def forward(self, origins, directions, directions_norm, cam_idx, jitters, anneal=1.0, training=True,
+                normals=False, sample_normals_override=None):
         """Returns dict with per-level (sbins, tbins, weights), rgb per sample, rendered outputs."""
         cfg = self.cfg
         P = self.params
@@ -123,7 +133,9 @@ class NerfactoOracle:
             annealed = torch.pow(w.detach(), anneal)
             sb, tb = Rr.sample_pdf(sb, annealed, n_next[k], cfg.near_plane, cfg.far_plane,
                                    None if j[k + 1] is None else j[k + 1].reshape(R, 1), cfg.histogram_padding)
-        dens, base_out = self._density(self.main_spec, P["base_grid"], P["base_mlp"], 64, 16, origins, directions, tb)
+        res = self._density(self.main_spec, P["base_grid"], P["base_mlp"], 64, 16, origins, directions, tb,
+                            want_normals=normals)
+        dens, base_out = res[0], res[1]
         Sm = cfg.num_nerf_samples
         geo = base_out[:, 1:16]
         d01 = (directions + 1.0) / 2.0
@@ -155,11 +167,18 @@ class NerfactoOracle:
             expected = torch.sum(w * steps, dim=-1, keepdim=True) / (acc + 1e-10)
         if not training:
             out_rgb = out_rgb.clamp(0.0, 1.0)
-        return {"rgb": out_rgb, "depth": depth, "accumulation": acc, "expected_depth": expected,
-                "weights_list": weights_list, "sbins_list": sbins_list, "tbins_list": tbins_list,
-                "rgb_samples": rgb, "base_out": base_out, "directions_norm": directions_norm}
+        out = {"rgb": out_rgb, "depth": depth, "accumulation": acc, "expected_depth": expected,
+               "weights_list": weights_list, "sbins_list": sbins_list, "tbins_list": tbins_list,
+               "rgb_samples": rgb, "base_out": base_out, "directions_norm": directions_norm}
+        if normals:
+            # sample_normals_override: tests inject the kernel's own per-sample normals to check the
+            # render + loss arithmetic independently of the fp16 backward that produced them
+            sn = res[2] if sample_normals_override is None else sample_normals_override
+            out["sample_normals"] = res[2]
+            out["normals"] = Rr.render_normals_shaded(w, sn)
+        return out
 
-    def loss_dict(self, outputs, gt_rgb, gt_depth):
+    def loss_dict(self, outputs, gt_rgb, gt_depth, gt_normal=None):
         cfg = self.cfg
         wl, sl, tl = outputs["weights_list"], outputs["sbins_list"], outputs["tbins_list"]
         d = {"rgb_loss": cfg.rgb_loss_mult * torch.mean((outputs["rgb"] - gt_rgb) ** 2)}
@@ -171,6 +190,9 @@ class NerfactoOracle:
             for w, tb in zip(wl, tl):
                 dl = dl + Rr.ds_nerf_depth_loss(w, tb, term, cfg.depth_sigma) / len(wl)
             d["depth_loss"] = cfg.depth_loss_mult * dl
+        if gt_normal is not None and cfg.normal_loss_mult > 0 and "normals" in outputs:
+            # reference hook: nerf_vo/mapping/nerfstudio_utils.py:337-350
+            d["normal_loss"] = cfg.normal_loss_mult * Rr.monosdf_normal_loss(outputs["normals"], gt_normal)
         return d
 
     def zero_grad(self):

@@ -320,6 +320,16 @@ def ds_nerf_depth_loss(weights, tbins, termination_depth, sigma):
     return torch.mean(loss)
 
 
+def render_normals_shaded(weights, sample_normals):
+    """NormalsRenderer (sum_i w_i n_i, then safe_normalize = v / (|v| + 1e-10)) followed by NormalsShader
+    ((n + 1) / 2) -- what nerfacto stores in outputs['normals'] [UPSTREAM] and what the reference's
+    normal-loss hook compares with the (n+1)/2-mapped targets of DynamicDataset.get_dataset
+    (ref: nerf_vo/mapping/nerfstudio_utils.py:145-153, 337-350)."""
+    n = torch.sum(weights[..., None] * sample_normals, dim=-2)
+    n = n / (torch.linalg.norm(n, dim=-1, keepdim=True) + 1e-10)
+    return (n + 1.0) / 2.0
+
+
 def monosdf_normal_loss(normal_pred, normal_gt):
     normal_gt = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)
     normal_pred = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)

@@ -122,6 +122,16 @@ def build():
     out["g10_a"], out["g10_b"] = a, bb
     out["g10_psnr_reference"] = Rr.psnr_reference(a, bb)
     out["g10_psnr_float"] = Rr.psnr_float(a, bb)
+    # G7b rendered normals (NormalsRenderer + NormalsShader) and the normal loss on them; own generator so
+    # that the vectors above keep their values
+    g2 = torch.Generator().manual_seed(77)
+    sn = torch.nn.functional.normalize(torch.randn(8, 96, 3, generator=g2, dtype=torch.float64), dim=-1)
+    out["g7b_sample_normals"] = sn.numpy()
+    shaded = Rr.render_normals_shaded(wts, sn)
+    out["g7b_normals_shaded"] = shaded.numpy()
+    gtn = (torch.nn.functional.normalize(torch.randn(8, 3, generator=g2, dtype=torch.float64), dim=-1) + 1) / 2
+    out["g7b_gt_normal"] = gtn.numpy()
+    out["g8b_monosdf_on_shaded"] = float(Rr.monosdf_normal_loss(shaded, gtn))
     return out
 
 

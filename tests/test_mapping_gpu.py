@@ -40,6 +40,19 @@ def test_synthetic_mapping_end_to_end(device, tmp_path):
     torch.cuda.synchronize()
 
 
+def test_synthetic_mapping_with_normal_supervision(device, tmp_path):
+    """enhancement modes containing 'normal' (reference: nerf_vo/mapping/nerfstudio.py:68-69, use_normals):
+    the dataset hands out (R^-1 n + 1)/2 targets and the step adds normal_loss_mult * monosdf_normal_loss;
+    runs through the hipGraph replay path like every other mapper step."""
+    from run_synthetic_mapping import run
+
+    res = run(keyframes=8, height=60, width=80, iterations=150, eval_frames=1, chunk=8, quiet=True,
+              out_dir=str(tmp_path), enhancement="depth-normal")
+    ld = res["final_losses"]
+    assert "normal_loss" in ld and np.isfinite(ld["normal_loss"]) and 0.0 < ld["normal_loss"] < 5e-6 * 6.0, ld
+    assert np.isfinite(res["psnr_float_mse"]) and res["psnr_float_mse"] > 12.0, res
+
+
 def test_psnr_definitions():
     from nerf_vo_amd.mapping.renderer import calculate_psnr_float, calculate_psnr_reference
     from oracle.rays import psnr_float, psnr_reference

@@ -21,7 +21,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chunk=8, device="cuda:0", quiet=False,
-        out_dir=None):
+        out_dir=None, enhancement="depth"):
     entry.build()
     from nerf_vo_amd.mapping.dataset import opencv_to_opengl
     from nerf_vo_amd.mapping.nerfstudio_mapper import Nerfstudio
@@ -33,7 +33,7 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
     args = argparse.Namespace(
         experiment="synthetic", dir_prediction=out_dir, mapping_snapshot_iterations=iterations,
         mapping_iterations=iterations, num_keyframes=keyframes, frame_height=height, frame_width=width,
-        enhancement_module="depth")
+        enhancement_module=enhancement)
     mapper = Nerfstudio(args, device=dev)
     seq = make_sequence(keyframes, height, width, device=dev)
     iters_between = max(int(iterations / keyframes), 1)
@@ -45,6 +45,7 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
             "keyframe_indices": torch.arange(lo, hi), "camera_intrinsics": seq["camera_intrinsics"][lo:hi],
             "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"][lo:hi]),
             "frames_color": seq["frames_color"][lo:hi], "frames_depth": seq["frames_depth"][lo:hi],
+            **({"frames_normal": seq["frames_normal"][lo:hi]} if "normal" in enhancement else {}),
             "last_frame": hi == keyframes})
         for _ in range(iters_between * (hi - lo) - 1):
             if mapper.step < iterations:
