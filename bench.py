@@ -45,9 +45,12 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
         return n_main * (16 * 8 * 4 + 12 + 16 * 4)
     if name == "grid_fwd[L5]":
         return (n_p0 + n_p1) / 2 * (5 * 8 * 4 + 12 + 5 * 4)
-    if name in ("grid_bwd_lds[L16]", "grid_bwd_atomic[L16]", "grid_bwd_binned[L16]"):
+    bwd_kinds = ("grid_bwd_lds", "grid_bwd_atomic", "grid_bwd_binned", "grid_bwd_stream")
+    if name in tuple(k + "[L16]" for k in bwd_kinds):
         # read-modify-write of every touched fp32 corner pair + x + d(encoded) fp16
         return n_main * (16 * 8 * 8 * 2 + 12 + 16 * 4)
+    if name in tuple(k + "[L5]" for k in bwd_kinds):  # one launch per proposal net: average of the two
+        return (n_p0 + n_p1) / 2 * (5 * 8 * 8 * 2 + 12 + 5 * 4)
     if name == "mlp_bwd[64-64x2-16]":
         # drgb, rgb, 2 hidden, base_out in; d_base_out out (fp16 rows)
         return n_main * 2 * (16 + 16 + 128 + 16 + 16)
@@ -91,7 +94,10 @@ def main() -> None:
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--grid-bwd-mode", type=int, default=1)
+    ap.add_argument("--grid-bwd-mode", type=int, nargs="+", default=None,
+                    help="hash-grid backward kernel: one value for all networks or three (main, proposal 0, "
+                         "proposal 1); 3 = streamed binned, 1 = LDS slice owner, 2 = binned, 0 = global atomics; "
+                         "default = EngineConfig's")
     ap.add_argument("--optimize-poses", action="store_true",
                     help="BASELINE configs[2]: SE3 pose-gradient backprop enabled (default: configs[1], fixed poses)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -153,8 +159,10 @@ def main() -> None:
     ds = dm.train_dataset
     assert ds.num_active_frames == args.keyframes
 
-    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, grid_bwd_mode=args.grid_bwd_mode,
-                       optimize_poses=args.optimize_poses)
+    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses)
+    if args.grid_bwd_mode is not None:
+        cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
+    bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
     engine = NerfactoEngine(cfg, device, world_size=world)
     reducer = GradientAllReduce(dist, compress="fp16") if dist is not None else None
     if dist is not None:  # identical initial parameters on every rank
@@ -261,7 +269,7 @@ def main() -> None:
                        "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
-                       "grid_bwd": {0: "atomic", 1: "lds", 2: "binned"}[args.grid_bwd_mode],
+                       "grid_bwd": [{0: "atomic", 1: "lds", 2: "binned", 3: "stream"}[int(m)] for m in bwd_modes],
                        "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
                        "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (fp16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),

@@ -54,7 +54,13 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-bool nvo_prof_enabled() { return g_prof_on; }
+bool nvo_prof_detail() {
+    static const bool on = [] { const char* e = getenv("NVO_PROF_DETAIL"); return e && atoi(e) != 0; }();
+    return on;
+}
+static int g_prof_mute = 0;
+void nvo_prof_mute(int delta) { g_prof_mute += delta; }
+bool nvo_prof_enabled() { return g_prof_on && (g_prof_mute == 0 || nvo_prof_detail()); }
 
 void nvo_prof_begin(hipStream_t s, const char* fmt, ...) {
     ProfRec r;
@@ -267,17 +273,20 @@ struct GridModule : nvo_module_s {
     NvoGridLevels g;
     NvoGridSlices slices;
     NvoGridBins bins;
+    NvoGridStream stream_bins;
     int bwd_mode = 1;  // 0 global atomics, 1 LDS slice owner (default, fastest), 2 binned hashed levels + slice owner
     bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
 
     ~GridModule() override {
         nvo_grid_slices_destroy(&slices);
         nvo_grid_bins_destroy(&bins);
+        nvo_grid_stream_destroy(&stream_bins);
     }
     int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
         int rc = ensure_slices();
         if (rc) return rc;
         if (bwd_mode == 2) return nvo_grid_bwd_binned_launch(g, &bins, s, B, in, dout, false, soa, dparams);
+        if (bwd_mode == 3) return nvo_grid_bwd_stream_launch(g, &stream_bins, s, B, in, dout, false, soa, dparams);
         return nvo_grid_bwd_launch(g, &slices, s, B, in, dout, false, soa, dparams, bwd_mode);
     }
 
@@ -310,6 +319,7 @@ struct GridModule : nvo_module_s {
     int ensure_slices() {
         if (bwd_mode == 1 && slices.n_slices == 0) return nvo_grid_slices_create(g, &slices);
         if (bwd_mode == 2 && bins.n_bins == 0 && bins.dense.n_slices == 0) return nvo_grid_bins_create(g, &bins);
+        if (bwd_mode == 3 && !stream_bins.created) return nvo_grid_stream_create(g, &stream_bins);
         return NVO_OK;
     }
     uint64_t ctx_bytes(uint32_t) const override { return 16; }
@@ -335,6 +345,12 @@ struct GridModule : nvo_module_s {
     }
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        if (!strcmp(key, "grid_stream_tile")) { stream_bins.tile = (uint32_t)value; return NVO_OK; }
+        if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
+            nvo_grid_stream_destroy(&stream_bins);
+            stream_bins.owner_max_slices = (uint32_t)value;
+            return NVO_OK;
+        }
         return nvo_module_s::set_option(key, value);
     }
 };

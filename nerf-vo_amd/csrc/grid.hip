@@ -556,6 +556,303 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
 }
 
 // ------------------------------------------------------------------------------------------
+// backward w.r.t. parameters, STREAMED binned form (mode 3) -- every level, no global atomics in the
+// sort, no gathers and no hash re-derivation in the accumulate
+// ------------------------------------------------------------------------------------------
+// Mode 2's accumulate pass is bound by the dependent random gathers of x / dy behind every 4-byte
+// record, mode 1 by re-deriving every corner hash once per slice.  Here:
+//   k_st_count   : tile of 1024 samples x one level -> LDS histogram over the level's 8K-entry bins ->
+//                  counts[bin][tile] with plain stores
+//   k_st_scan_tiles : per bin, exclusive scan over the tiles (in place) + bin total
+//   k_st_scan_bins  : exclusive scan of the bin totals -> base[]; builds the accumulate work items
+//                  (bin, chunk, n_chunks) from the ACTUAL record counts, so a heavily hit bin (dense coarse
+//                  levels, clustered samples) is split over several workgroups
+//   k_st_scatter : same tile decomposition; the pass that holds x, dy and the interpolation weights in
+//                  registers writes SELF-CONTAINED 8-byte records {entry-in-bin (13 bit), w*dy.x, w*dy.y}.
+//                  The index bits ride in the low mantissa bits of the two fp32 values (6 + 7), which keep
+//                  17 / 16 mantissa bits after round-to-nearest -- 64x finer than the fp16 dy they are
+//                  computed from (tcnn forms the same product in fp16).  Records are staged in LDS sorted
+//                  by bin and leave the workgroup in runs that are contiguous per bin.
+//   k_st_zero    : zero the slices of multi-chunk bins (their chunks combine with float atomics)
+//   k_st_accumulate : a pure stream -- coalesced record loads + LDS 64-bit integer atomics, then plain
+//                  stores (single-chunk bins: bitwise reproducible) or row-contiguous float atomics.
+// samples per tile = threads per workgroup (template parameter TILE of count / scatter; both passes
+// must use the same value: the scatter offsets are the scanned per-tile counts)
+constexpr uint32_t kStChunkRecords = 32768;        // target records per accumulate work item
+constexpr uint32_t kStMaxChunks = 256;
+
+__device__ __forceinline__ uint2 rec_pack(uint32_t rel, float v0, float v1) {
+    const uint32_t a = __float_as_uint(v0) + 0x20u;  // round to nearest at bit 6
+    const uint32_t b = __float_as_uint(v1) + 0x40u;  // ... at bit 7
+    return make_uint2((a & ~0x3Fu) | (rel & 0x3Fu), (b & ~0x7Fu) | (rel >> 6));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// grid = (n_tiles, n_levels).  counts[(bin_first[level] + b) * n_tiles + tile]
+template <int TILE, bool SOA, typename DY2>
+__global__ void __launch_bounds__(TILE)
+k_st_count(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
+           const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
+           uint32_t* __restrict__ counts) {
+    constexpr uint32_t kStBlock = TILE;
+    extern __shared__ uint32_t hist[];
+    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
+    const uint32_t bin0 = bin_first[blockIdx.y];
+    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) hist[b] = 0u;
+    __syncthreads();
+    const uint32_t i = tile * kStBlock + threadIdx.x;
+    if (i < N) {
+        float2 d;
+        if (load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d)) {
+            const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
+                                                    c.pz + ((k >> 2) & 1u));
+                atomicAdd(&hist[idx / kBinSlice], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) counts[(size_t)(bin0 + b) * n_tiles + tile] = hist[b];
+}
+
+// grid = n_bins, block = 256: counts[bin][0..n_tiles) -> exclusive offsets in place, totals[bin]
+__global__ void __launch_bounds__(256)
+k_st_scan_tiles(uint32_t n_tiles, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = counts + (size_t)blockIdx.x * n_tiles;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 256) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t c = t < n_tiles ? row[t] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(c, lane);
+        if (lane == 63) wave_tot[wib] = incl;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int w = 0; w < wib; ++w) pre += wave_tot[w];
+        if (t < n_tiles) row[t] = pre + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = pre + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// One workgroup.  totals[n] -> base[n + 1] (exclusive; base[n] = grand total); item list from the actual
+// counts: items[j] = {bin, chunk, n_chunks, 0}; n_items[0] = number of items.
+__global__ void __launch_bounds__(1024)
+k_st_scan_bins(uint32_t n, const uint32_t* __restrict__ totals, uint32_t* __restrict__ base,
+               uint4* __restrict__ items, uint32_t* __restrict__ n_items, uint32_t* __restrict__ bin_chunks,
+               uint32_t max_items) {
+    __shared__ uint32_t wtot[16], wtot2[16];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t s = 0, s2 = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = totals[b];
+        s += c;
+        s2 += min(kStMaxChunks, max(1u, (c + kStChunkRecords - 1u) / kStChunkRecords));
+    }
+    const uint32_t incl = wave_incl_scan_u32(s, lane), incl2 = wave_incl_scan_u32(s2, lane);
+    if (lane == 63) {
+        wtot[wib] = incl;
+        wtot2[wib] = incl2;
+    }
+    __syncthreads();
+    uint32_t run = incl - s, run2 = incl2 - s2;
+    for (int w = 0; w < wib; ++w) {
+        run += wtot[w];
+        run2 += wtot2[w];
+    }
+    if (threadIdx.x == 1023) {
+        base[n] = run + s;
+        n_items[0] = min(run2 + s2, max_items);
+    }
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = totals[b];
+        base[b] = run;
+        run += c;
+        const uint32_t nc = min(kStMaxChunks, max(1u, (c + kStChunkRecords - 1u) / kStChunkRecords));
+        bin_chunks[b] = nc;
+        for (uint32_t j = 0; j < nc; ++j)
+            if (run2 + j < max_items) items[run2 + j] = make_uint4(b, j, nc, 0u);
+        run2 += nc;
+    }
+}
+
+// grid = (n_tiles, n_levels); LDS: stage[8192] uint2 | dst[8192] u32 | hist | loff | gbase
+template <int TILE, bool SOA, typename DY2>
+__global__ void __launch_bounds__(TILE)
+k_st_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
+             const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
+             const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ base,
+             uint2* __restrict__ records) {
+    constexpr uint32_t kStBlock = TILE;
+    constexpr uint32_t kStRecords = TILE * 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(stage + kStRecords);
+    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
+    const uint32_t bin0 = bin_first[blockIdx.y];
+    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
+    uint32_t* hist = dst + kStRecords;
+    uint32_t* loff = hist + n_slices;
+    uint32_t* gbase = loff + n_slices;
+    __shared__ uint32_t total_s;
+    // the global offset of this tile's run in every bin does not depend on the histogram: requested first,
+    // so its latency overlaps the x / dy loads instead of following them
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) {
+        hist[b] = 0u;
+        gbase[b] = base[bin0 + b] + tile_off[(size_t)(bin0 + b) * n_tiles + tile];
+    }
+    __syncthreads();
+    const uint32_t i = tile * kStBlock + threadIdx.x;
+    uint32_t idx[8], slot[8];
+    float2 d = make_float2(0.f, 0.f);
+    Corner c = {};
+    bool live = false;
+    if (i < N) {
+        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+        if (live) {
+            c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
+                                        c.pz + ((k >> 2) & 1u));
+                slot[k] = atomicAdd(&hist[idx[k] / kBinSlice], 1u);  // rank inside (tile, bin)
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
+        const int lane = (int)threadIdx.x;
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < n_slices; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const uint32_t cnt = b < n_slices ? hist[b] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt, lane);
+            if (b < n_slices) loff[b] = carry + incl - cnt;
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) total_s = carry;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t b = idx[k] / kBinSlice;
+            const uint32_t pos = loff[b] + slot[k];
+            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                            ((k & 4u) ? c.wz : 1.f - c.wz);
+            stage[pos] = rec_pack(idx[k] & (kBinSlice - 1u), w * d.x, w * d.y);
+            dst[pos] = gbase[b] + slot[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    for (uint32_t t = threadIdx.x; t < total; t += kStBlock) records[dst[t]] = stage[t];
+}
+
+// entries of the slice a bin owns
+__device__ __forceinline__ uint32_t st_bin_entries(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    return min(kBinSlice, size - slice * kBinSlice);
+}
+
+// grid = n_bins: slices of multi-chunk bins are combined with float atomics and must start at zero
+__global__ void __launch_bounds__(256)
+k_st_zero(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
+          const uint32_t* __restrict__ bin_chunks, float* __restrict__ grad) {
+    if (bin_chunks[blockIdx.x] <= 1u) return;
+    const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
+    const uint32_t n = 2 * st_bin_entries(g, level, slice);
+    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
+    for (uint32_t e = threadIdx.x; e < n; e += 256) gr[e] = 0.f;
+}
+
+// grid = max_items (blocks past n_items exit): pure streaming accumulate of one chunk of one bin
+__global__ void __launch_bounds__(kLdsBwdBlock)
+k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
+                const uint32_t* __restrict__ base, const uint4* __restrict__ items,
+                const uint32_t* __restrict__ n_items, const uint2* __restrict__ records, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_items[0]) return;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
+    const uint4 item = items[blockIdx.x];
+    const uint32_t bin = item.x, chunk = item.y, n_chunks = item.z;
+    const uint32_t level = bin_level[bin], slice = bin_slice[bin];
+    const uint32_t entries = st_bin_entries(g, level, slice);
+    const uint32_t bin_begin = base[bin], bin_end = base[bin + 1];
+    const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
+    const uint32_t begin = bin_begin + chunk * per_chunk;
+    const uint32_t end = min(bin_end, begin + per_chunk);
+    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
+    if (begin >= end) {
+        if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
+            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = 0.f;
+        return;
+    }
+    {
+        uint4* z = reinterpret_cast<uint4*>(lds_raw);
+        for (uint32_t e = threadIdx.x; e < entries; e += kLdsBwdBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    // Record pairs (16-byte loads), kUnroll of them per thread in flight at once: a chunk of <= 32K records
+    // is requested in ONE round trip (the loop is otherwise one dependent HBM latency per iteration with a
+    // single workgroup per CU -- 128 KiB of LDS -- to hide it).
+    constexpr uint32_t kUnroll = 16;
+    const uint4* __restrict__ rec2 = reinterpret_cast<const uint4*>(records);
+    const uint32_t pair_begin = begin >> 1, pair_end = (end + 1u) >> 1;
+    for (uint32_t p0 = pair_begin + threadIdx.x; p0 < pair_end; p0 += kUnroll * kLdsBwdBlock) {
+        uint4 rec[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t p = p0 + u * kLdsBwdBlock;
+            rec[u] = p < pair_end ? rec2[p] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {
+            const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
+            if (r >= begin && r < end) {
+                const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
+                AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu));
+            }
+            if (r + 1u >= begin && r + 1u < end) {
+                const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
+                AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu));
+            }
+        }
+    }
+    __syncthreads();
+    if (n_chunks == 1) {
+        for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
+    } else {
+        for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
+            const float v = AccFixed::get(acc, e);
+            if (v != 0.f) atomicAdd(gr + e, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward w.r.t. the input position (needed for analytic normals and pose gradients)
 // ------------------------------------------------------------------------------------------
 // One thread per (sample, level); per-level partials are combined with float atomics into
@@ -758,6 +1055,7 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
                                const float* x, const void* dy, bool dy_is_float, bool soa, float* grad) {
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     NVO_REQUIRE(N < (1u << 29), "grid_bwd_binned: batch too large for 29-bit sample ids");
+    NVO_REQUIRE((uint64_t)N * 8 * bins->n_binned_levels < 0xFFFFFFFFull, "grid_bwd_binned: too many records");
     NVO_PROF(stream, "grid_bwd_binned[L%u]", g.n_levels);
     if (bins->n_bins) {
         const size_t need = (size_t)N * 8 * bins->n_binned_levels;
@@ -809,6 +1107,150 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
     if (bins->dense.n_slices) {
         return nvo_grid_bwd_launch(g, &bins->dense, stream, N, x, dy, dy_is_float, soa, grad, 1);
     }
+    return NVO_OK;
+}
+
+// ---- mode 3 host side ---------------------------------------------------------------------------
+int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
+    // Levels with many 8K-entry bins are streamed; levels with <= kStOwnerSlices slices (the coarse dense
+    // ones: almost every lookup hits every slice, the redundancy of the slice-owner form is small and the
+    // per-bin record lists would be long and conflict-heavy) keep slice-owner work items.
+    std::vector<uint32_t> levels, first, bin_level, bin_slice;
+    st->max_slices = 0;
+    st->streamed_mask = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
+        const uint32_t size = g.offset[l + 1] - g.offset[l];
+        const uint32_t n_slices = (size + kBinSlice - 1u) / kBinSlice;
+        if (n_slices <= st->owner_max_slices) continue;
+        levels.push_back(l);
+        first.push_back((uint32_t)bin_level.size());
+        if (n_slices > st->max_slices) st->max_slices = n_slices;
+        for (uint32_t sl = 0; sl < n_slices; ++sl) {
+            bin_level.push_back(l);
+            bin_slice.push_back(sl);
+        }
+        st->streamed_mask |= 1u << l;
+    }
+    first.push_back((uint32_t)bin_level.size());
+    st->n_levels = (uint32_t)levels.size();
+    st->n_bins = (uint32_t)bin_level.size();
+    const size_t nb = st->n_bins;
+    if (nb) {
+        const size_t words = levels.size() + first.size() + 2 * nb + nb /*totals*/ + (nb + 1) /*base*/ + nb /*chunks*/ + 4;
+        NVO_CHECK_HIP(hipMalloc((void**)&st->d_meta, sizeof(uint32_t) * words));
+        st->d_levels = st->d_meta;
+        st->d_bin_first = st->d_levels + levels.size();
+        st->d_bin_level = st->d_bin_first + first.size();
+        st->d_bin_slice = st->d_bin_level + nb;
+        st->d_totals = st->d_bin_slice + nb;
+        st->d_base = st->d_totals + nb;
+        st->d_bin_chunks = st->d_base + nb + 1;
+        st->d_n_items = st->d_bin_chunks + nb;
+        NVO_CHECK_HIP(hipMemcpy(st->d_levels, levels.data(), 4 * levels.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(st->d_bin_first, first.data(), 4 * first.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(st->d_bin_level, bin_level.data(), 4 * nb, hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(st->d_bin_slice, bin_slice.data(), 4 * nb, hipMemcpyHostToDevice));
+    }
+    st->created = true;
+    const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
+    return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask);
+}
+
+void nvo_grid_stream_destroy(NvoGridStream* st) {
+    if (st->d_meta) (void)hipFree(st->d_meta);
+    if (st->d_work) (void)hipFree(st->d_work);
+    st->d_meta = nullptr;
+    st->d_work = nullptr;
+    st->work_bytes = 0;
+    st->n_bins = 0;
+    st->created = false;
+    nvo_grid_slices_destroy(&st->owner);
+}
+
+int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
+                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad) {
+    NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
+    NVO_REQUIRE((uint64_t)N * 8 * g.n_levels < 0xFFFFFFFFull, "grid_bwd_stream: too many records for 32-bit offsets");
+    if (N == 0) return nvo_zero_async(grad, sizeof(float) * 2 * (size_t)g.offset[g.n_levels], stream);
+    NVO_PROF(stream, "grid_bwd_stream[L%u]", g.n_levels);
+    const uint32_t tile = st->tile;
+    NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
+    const uint32_t n_tiles = nvo_div_up(N, tile);
+    if (st->owner.n_slices) {  // coarse levels: slice-owner items (disjoint gradient ranges)
+        NvoProfMute mute;
+        if (int rc = nvo_grid_bwd_launch(g, &st->owner, stream, N, x, dy, dy_is_float, soa, grad, 1)) return rc;
+    }
+    if (st->n_bins == 0) return NVO_OK;
+    const size_t n_records = (size_t)N * 8 * st->n_levels;
+    const uint32_t max_items = st->n_bins + (uint32_t)(n_records / kStChunkRecords) + 1u;
+    // scratch: records | counts[n_bins][n_tiles] | items[max_items]   (grows during warm-up only; never
+    // while a graph is being captured)
+    const size_t rec_bytes = nvo_round_up(n_records * sizeof(uint2), 256);
+    const size_t cnt_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
+    const size_t item_bytes = (size_t)max_items * sizeof(uint4);
+    const size_t need = rec_bytes + cnt_bytes + item_bytes;
+    if (need > st->work_bytes) {
+        if (st->d_work) NVO_CHECK_HIP(hipFree(st->d_work));
+        NVO_CHECK_HIP(hipMalloc((void**)&st->d_work, need));
+        st->work_bytes = need;
+    }
+    uint2* records = reinterpret_cast<uint2*>(st->d_work);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(st->d_work + rec_bytes);
+    uint4* items = reinterpret_cast<uint4*>(st->d_work + rec_bytes + cnt_bytes);
+    const dim3 grid(n_tiles, st->n_levels);
+    const size_t lds_hist = sizeof(uint32_t) * st->max_slices;
+    const size_t lds_stage = (size_t)tile * 8 * 12 + sizeof(uint32_t) * 3 * st->max_slices;
+    const size_t lds_acc = sizeof(unsigned long long) * 2 * kBinSlice;
+#define NVO_LAUNCH_ST(TILE_, SOA_, T_)                                                                       \
+    do {                                                                                                     \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_st_scatter<TILE_, SOA_, T_>,                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                              (int)((size_t)TILE_ * 96 + 12 * 4096)));                       \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_st_accumulate,                                  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));   \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "st_count[L%u]", g.n_levels);                                               \
+            NVO_LAUNCH((k_st_count<TILE_, SOA_, T_>), grid, dim3(TILE_), lds_hist, stream, g, N, x, (const T_*)dy, \
+                       st->d_levels, st->d_bin_first, counts);                                                 \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "st_scan[L%u]", g.n_levels);                                                \
+            NVO_LAUNCH(k_st_scan_tiles, dim3(st->n_bins), dim3(256), 0, stream, n_tiles, counts, st->d_totals); \
+            NVO_LAUNCH(k_st_scan_bins, dim3(1), dim3(1024), 0, stream, st->n_bins, st->d_totals, st->d_base, \
+                       items, st->d_n_items, st->d_bin_chunks, max_items);                                   \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "st_scatter[L%u]", g.n_levels);                                             \
+            NVO_LAUNCH((k_st_scatter<TILE_, SOA_, T_>), grid, dim3(TILE_), lds_stage, stream, g, N, x, (const T_*)dy, \
+                       st->d_levels, st->d_bin_first, counts, st->d_base, records);                            \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "st_accumulate[L%u]", g.n_levels);                                          \
+            NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
+                       st->d_bin_chunks, grad);                                                              \
+            NVO_LAUNCH(k_st_accumulate, dim3(max_items), dim3(kLdsBwdBlock), lds_acc, stream, g, st->d_bin_level, \
+                       st->d_bin_slice, st->d_base, items, st->d_n_items, records, grad);                    \
+        }                                                                                                    \
+    } while (0)
+#define NVO_LAUNCH_ST_T(SOA_, T_)                                                 \
+    do {                                                                          \
+        if (tile == 256) NVO_LAUNCH_ST(256, SOA_, T_);                            \
+        else if (tile == 512) NVO_LAUNCH_ST(512, SOA_, T_);                       \
+        else NVO_LAUNCH_ST(1024, SOA_, T_);                                       \
+    } while (0)
+    NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
+    if (soa) {
+        if (dy_is_float) NVO_LAUNCH_ST_T(true, float2); else NVO_LAUNCH_ST_T(true, __half2);
+    } else {
+        if (dy_is_float) NVO_LAUNCH_ST_T(false, float2); else NVO_LAUNCH_ST_T(false, __half2);
+    }
+#undef NVO_LAUNCH_ST_T
+#undef NVO_LAUNCH_ST
+    NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
 

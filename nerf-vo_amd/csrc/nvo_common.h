@@ -53,7 +53,7 @@ void nvo_prof_end(hipStream_t s);
 struct NvoProfScope {
     hipStream_t s;
     bool on;
-    explicit NvoProfScope(hipStream_t s_) : s(s_), on(nvo_prof_enabled()) {}
+    explicit NvoProfScope(hipStream_t s_, bool enable = true) : s(s_), on(enable && nvo_prof_enabled()) {}
     ~NvoProfScope() {
         if (on) nvo_prof_end(s);
     }
@@ -62,6 +62,21 @@ struct NvoProfScope {
 #define NVO_PROF(stream, ...)                                   \
     NvoProfScope nvo_prof_scope__((hipStream_t)(stream));       \
     if (nvo_prof_scope__.on) nvo_prof_begin((hipStream_t)(stream), __VA_ARGS__)
+
+// While an NvoProfMute is alive, NVO_PROF scopes of nested launchers are not recorded (their time is part
+// of the enclosing scope) unless NVO_PROF_DETAIL=1.
+void nvo_prof_mute(int delta);
+struct NvoProfMute {
+    NvoProfMute() { nvo_prof_mute(+1); }
+    ~NvoProfMute() { nvo_prof_mute(-1); }
+};
+
+// Sub-scope inside a launcher that already has an NVO_PROF scope: recorded only with NVO_PROF_DETAIL=1 in
+// the environment (the per-launcher totals would otherwise count the time twice).
+bool nvo_prof_detail();
+#define NVO_PROF_SUB(stream, ...)                                                      \
+    NvoProfScope nvo_prof_sub__((hipStream_t)(stream), nvo_prof_detail());             \
+    if (nvo_prof_sub__.on) nvo_prof_begin((hipStream_t)(stream), __VA_ARGS__)
 
 static inline uint32_t nvo_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline uint64_t nvo_round_up(uint64_t a, uint64_t b) { return ((a + b - 1) / b) * b; }
@@ -102,7 +117,11 @@ __device__ __forceinline__ uint32_t nvo_grid_index(uint32_t hashed, uint32_t has
         index = px ^ (py * 2654435761u) ^ (pz * 805459861u);
         return index & (hashmap_size - 1u);  // hashed levels always have power-of-two size
     }
+    // Dense levels: index < res^3 <= hashmap_size except for the +1 corners of positions at the upper
+    // domain face (x == 1), so the modulo (a ~40-instruction software division on the GPU) sits behind
+    // a branch that is almost never taken.
     index = px + py * res + pz * res * res;
-    return index % hashmap_size;
+    if (index >= hashmap_size) index %= hashmap_size;
+    return index;
 }
 #endif

@@ -38,6 +38,32 @@ int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b);
 void nvo_grid_bins_destroy(NvoGridBins* b);
 int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
                                const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
+
+// Streamed binned backward (mode 3): levels with many 8K-entry bins go through count / scan / scatter of
+// self-contained 8-byte records / streaming accumulate; the coarse levels keep slice-owner items.
+struct NvoGridStream {
+    bool created = false;
+    uint32_t n_levels = 0, n_bins = 0, max_slices = 0;
+    uint32_t streamed_mask = 0;
+    uint32_t owner_max_slices = 5;    // levels with at most this many 8K-entry slices stay slice-owner
+    uint32_t tile = 512;              // samples per count / scatter workgroup (256 | 512 | 1024)
+    uint32_t* d_meta = nullptr;       // one allocation holding the arrays below
+    uint32_t* d_levels = nullptr;     // [n_levels] streamed level ids
+    uint32_t* d_bin_first = nullptr;  // [n_levels + 1]
+    uint32_t* d_bin_level = nullptr;  // [n_bins]
+    uint32_t* d_bin_slice = nullptr;  // [n_bins]
+    uint32_t* d_totals = nullptr;     // [n_bins]
+    uint32_t* d_base = nullptr;       // [n_bins + 1]
+    uint32_t* d_bin_chunks = nullptr; // [n_bins]
+    uint32_t* d_n_items = nullptr;    // [1]
+    unsigned char* d_work = nullptr;  // records | counts | items (sized for the largest batch seen)
+    size_t work_bytes = 0;
+    NvoGridSlices owner;
+};
+int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);
+void nvo_grid_stream_destroy(NvoGridStream* st);
+int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
+                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
 void nvo_grid_slices_destroy(NvoGridSlices* s);
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices);

@@ -86,7 +86,10 @@ class EngineConfig:
     camera_mode: str = "SE3"              # "SE3" (reference's explicit config) | "SO3xR3" (nerfacto model default)
     camera_trans_l2_penalty: float = 1e-2  # camera_opt_regularizer (nerfstudio >= 1.0 CameraOptimizer [UPSTREAM])
     camera_rot_l2_penalty: float = 1e-3
-    grid_bwd_mode: int = 1                # 1 = LDS slice owner (fastest), 2 = binned hashed levels (bitwise reproducible), 0 = global atomics
+    # hash-grid parameter-gradient kernel per network (main field, proposal 0, proposal 1):
+    # 3 = streamed binned (self-contained records; coarse levels slice-owner), 1 = LDS slice owner,
+    # 2 = binned with gathers, 0 = global atomics.  An int applies to all three.
+    grid_bwd_mode: int | tuple = (3, 1, 1)
     seed: int = 1337
 
 
@@ -122,8 +125,9 @@ class NerfactoEngine:
                     "n_neurons": cfg.hidden_dim, "n_hidden_layers": 1}
         self.base_net = _create("nvo_create_network_with_input_encoding", 3, 1 + cfg.geo_feat_dim,
                                 json.dumps(cfg.main_grid.tcnn_dict()).encode(), json.dumps(base_cfg).encode())
-        for m in (*self.prop_nets, self.base_net):
-            m.set_option("grid_bwd_mode", cfg.grid_bwd_mode)
+        modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
+        for m, mode in zip((self.base_net, *self.prop_nets), modes):
+            m.set_option("grid_bwd_mode", int(mode))
         color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
         assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
         self.n_color = 64 * 64 + 64 * 64 + 16 * 64

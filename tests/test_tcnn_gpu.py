@@ -92,7 +92,7 @@ def test_grid_indices_bit_exact(device, cfg):
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
-@pytest.mark.parametrize("bwd_mode", [0, 1, 2], ids=["atomic", "lds", "binned"])
+@pytest.mark.parametrize("bwd_mode", [0, 1, 2, 3], ids=["atomic", "lds", "binned", "streamed"])
 def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     import nerf_vo_amd.tinycudann as tcnn
     from oracle import grid as G
@@ -134,7 +134,7 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
     grads = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
         enc.params.grad = None
         y = enc(x)
@@ -143,6 +143,13 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     torch.cuda.synchronize()
     _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
     _assert_close(grads[2], grads[0], rtol=1e-3, atol_scale=1e-5, what="binned vs atomic dL/dparams")
+    # streamed records carry w*dy rounded to 16-17 mantissa bits (2^-17 relative per contribution)
+    _assert_close(grads[3], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed vs atomic dL/dparams")
+    enc.native_tcnn_module.set_option("grid_bwd_mode", 3)
+    enc.params.grad = None
+    (enc(x).float() * dy).sum().backward()
+    assert torch.equal(enc.params.grad[2 * (4096 + 12168 + 29792 + 79512 + 205384):],
+                       grads[3][2 * (4096 + 12168 + 29792 + 79512 + 205384):]), "streamed form is not reproducible"
     # the binned form accumulates hashed levels in fixed point with a single owner per slice: bitwise reproducible
     enc.native_tcnn_module.set_option("grid_bwd_mode", 2)
     enc.params.grad = None

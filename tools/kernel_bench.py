@@ -24,13 +24,18 @@ def pls(b, m, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--modes", type=int, nargs="+", default=[0, 1, 2, 3])
+    ap.add_argument("--tiles", type=int, nargs="+", default=[512], help="mode 3: samples per count/scatter tile")
+    ap.add_argument("--masks", type=str, nargs="+", default=["5"], help="mode 3: owner_max_slices values")
+    ap.add_argument("--cases", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     cases = [("main L16 T19", dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=pls(16, 2048, 16)), 4096 * 48),
              ("prop0 L5 T17", dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, per_level_scale=pls(16, 128, 5)), 4096 * 256),
              ("prop1 L5 T17", dict(n_levels=5, log2_hashmap_size=17, base_resolution=16, per_level_scale=pls(16, 256, 5)), 4096 * 96)]
-    for label, cfg, n in cases:
+    for label, cfg, n in [cases[c] for c in args.cases]:
         enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_features_per_level": 2, **cfg}).to(dev)
         with torch.no_grad():
             enc.params.uniform_(-1, 1)
@@ -40,9 +45,20 @@ def main():
         d = torch.nn.functional.normalize(torch.randn(R, 1, 3, device=dev), dim=-1)
         t = torch.linspace(0, 0.4, 48, device=dev).view(1, 48, 1)
         x = (o + d * t).clamp(0.001, 0.999).reshape(-1, 3)[:n].contiguous().requires_grad_(False)
+        if args.random_x:
+            x = torch.rand(n, 3, device=dev)
         dy = torch.randn(n, enc.n_output_dims, device=dev)
-        for mode in (0, 1, 2):
+        variants = []
+        for mode in args.modes:
+            if mode == 3:
+                variants += [(3, t, int(m, 0)) for t in args.tiles for m in args.masks]
+            else:
+                variants.append((mode, 0, 0xFFFFFFFF))
+        for mode, tile, mask in variants:
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
+            if mode == 3:
+                enc.native_tcnn_module.set_option("grid_stream_tile", tile)
+                enc.native_tcnn_module.set_option("grid_stream_owner_slices", mask)
             for it in range(args.iters + 3):
                 if it == 3:
                     torch.cuda.synchronize()
@@ -57,7 +73,10 @@ def main():
             lib.nvo_profile_enable(0)
             for line in buf.value.decode().strip().splitlines():
                 name, cnt, total = line.rsplit(",", 2)
-                print(f"{label:14s} N={n:8d} mode={mode} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
+                if name.startswith("grid_fwd"):
+                    continue
+                tag = f"mode={mode}" + (f" tile={tile} owner<={mask}" if mode == 3 else "")
+                print(f"{label:14s} N={n:8d} {tag:32s} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
 
 
 if __name__ == "__main__":
