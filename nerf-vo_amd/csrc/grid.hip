@@ -281,6 +281,11 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     // loop is otherwise one dependent L2 round trip per sample.
     constexpr uint32_t kUnroll = 4;
     const uint32_t mask = size - 1u;
+    const uint32_t res2 = res * res;
+    // (hashed levels) both x corners of a (y, z) pair share a slice when the slice size is a power of two
+    // that exceeds every x coordinate
+    const bool pair_bins = hashed && (ACC::kEntries & (ACC::kEntries - 1u)) == 0u && res + 1u < ACC::kEntries &&
+                           (first & (ACC::kEntries - 1u)) == 0u && count == ACC::kEntries;
     for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
         float2 dv[kUnroll];
         float xv[kUnroll][3];
@@ -306,40 +311,52 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             const float2 d = dv[u];
             if (d.x == 0.f && d.y == 0.f) continue;
             const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
+            const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+            const float wyz[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
             if (hashed) {
-                // two integer multiplies per sample, the 8 corner hashes are xor combinations;
-                // corners are then visited through a per-lane hit mask
+                // two integer multiplies per sample; the 4 (y, z) corner pairs are xor combinations
                 const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
                 const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
-                const uint32_t x0 = c.px, x1 = c.px + 1u;
-                const uint32_t a00 = hy0 ^ hz0, a10 = hy1 ^ hz0, a01 = hy0 ^ hz1, a11 = hy1 ^ hz1;
-                uint32_t hits = 0;
+                const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+                if (pair_bins) {
+                    // power-of-two slices and px + 1 < slice size: the x coordinate only touches index bits
+                    // below the slice bits, so both x corners of a (y, z) pair are in the SAME slice and one
+                    // test on the (y, z) hash decides both
 #pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t idx = (((k & 1u) ? x1 : x0) ^
-                                          ((k & 4u) ? ((k & 2u) ? a11 : a01) : ((k & 2u) ? a10 : a00))) & mask;
-                    hits |= ((idx - first) < count ? 1u : 0u) << k;
-                }
-                while (hits) {
-                    const uint32_t k = (uint32_t)__builtin_ctz(hits);
-                    hits &= hits - 1u;
-                    const uint32_t idx = (((k & 1u) ? x1 : x0) ^
-                                          ((k & 4u) ? ((k & 2u) ? a11 : a01) : ((k & 2u) ? a10 : a00))) & mask;
-                    const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                                    ((k & 4u) ? c.wz : 1.f - c.wz);
-                    ACC::add(acc, idx - first, w * d.x, w * d.y);
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t h = a[j] & mask;
+                        if ((h & ~(ACC::kEntries - 1u)) == first) {
+                            const float wj = wyz[j];
+                            const uint32_t lo = h & (ACC::kEntries - 1u);
+                            ACC::add(acc, lo ^ c.px, wx0 * wj * d.x, wx0 * wj * d.y);
+                            ACC::add(acc, lo ^ (c.px + 1u), c.wx * wj * d.x, c.wx * wj * d.y);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t r0 = ((c.px ^ a[j]) & mask) - first, r1 = (((c.px + 1u) ^ a[j]) & mask) - first;
+                        const float wj = wyz[j];
+                        if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y);
+                        if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y);
+                    }
                 }
             } else {
+                // dense stride index: one base + adds; the wrap (positions on the upper domain face only) sits
+                // behind a branch that is almost never taken
+                const uint32_t base = c.px + c.py * res + c.pz * res2;
 #pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u),
-                                                        c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
-                    const uint32_t rel = idx - first;  // unsigned wrap -> huge when idx < first
-                    if (rel < count) {
-                        const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                                        ((k & 4u) ? c.wz : 1.f - c.wz);
-                        ACC::add(acc, rel, w * d.x, w * d.y);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    uint32_t i0 = base + ((j & 1u) ? res : 0u) + ((j & 2u) ? res2 : 0u);
+                    uint32_t i1 = i0 + 1u;
+                    if (i1 >= size) {
+                        i0 %= size;
+                        i1 %= size;
                     }
+                    const uint32_t r0 = i0 - first, r1 = i1 - first;  // unsigned wrap -> huge when below the slice
+                    const float wj = wyz[j];
+                    if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y);
+                    if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y);
                 }
             }
         }
@@ -788,67 +805,72 @@ k_st_zero(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_
     for (uint32_t e = threadIdx.x; e < n; e += 256) gr[e] = 0.f;
 }
 
-// grid = max_items (blocks past n_items exit): pure streaming accumulate of one chunk of one bin
+// PERSISTENT: grid = one workgroup per CU, each loops over the work items (blockIdx.x, + gridDim.x, ...).
+// A 1024-thread workgroup with 128 KiB of LDS has a CU to itself and costs ~6 us just to be dispatched
+// and drained on MI355X (measured: the kernel with an empty body took 44 us for 1775 workgroups), so
+// one-item-per-workgroup launches were dispatch-bound.
 __global__ void __launch_bounds__(kLdsBwdBlock)
 k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
                 const uint32_t* __restrict__ base, const uint4* __restrict__ items,
                 const uint32_t* __restrict__ n_items, const uint2* __restrict__ records, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (blockIdx.x >= n_items[0]) return;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
-    const uint4 item = items[blockIdx.x];
-    const uint32_t bin = item.x, chunk = item.y, n_chunks = item.z;
-    const uint32_t level = bin_level[bin], slice = bin_slice[bin];
-    const uint32_t entries = st_bin_entries(g, level, slice);
-    const uint32_t bin_begin = base[bin], bin_end = base[bin + 1];
-    const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
-    const uint32_t begin = bin_begin + chunk * per_chunk;
-    const uint32_t end = min(bin_end, begin + per_chunk);
-    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
-    if (begin >= end) {
-        if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = 0.f;
-        return;
-    }
-    {
-        uint4* z = reinterpret_cast<uint4*>(lds_raw);
-        for (uint32_t e = threadIdx.x; e < entries; e += kLdsBwdBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    __syncthreads();
-    // Record pairs (16-byte loads), kUnroll of them per thread in flight at once: a chunk of <= 32K records
-    // is requested in ONE round trip (the loop is otherwise one dependent HBM latency per iteration with a
-    // single workgroup per CU -- 128 KiB of LDS -- to hide it).
-    constexpr uint32_t kUnroll = 16;
     const uint4* __restrict__ rec2 = reinterpret_cast<const uint4*>(records);
-    const uint32_t pair_begin = begin >> 1, pair_end = (end + 1u) >> 1;
-    for (uint32_t p0 = pair_begin + threadIdx.x; p0 < pair_end; p0 += kUnroll * kLdsBwdBlock) {
-        uint4 rec[kUnroll];
+    const uint32_t total_items = n_items[0];
+    for (uint32_t it = blockIdx.x; it < total_items; it += gridDim.x) {
+        const uint4 item = items[it];
+        const uint32_t bin = item.x, chunk = item.y, n_chunks = item.z;
+        const uint32_t level = bin_level[bin], slice = bin_slice[bin];
+        const uint32_t entries = st_bin_entries(g, level, slice);
+        const uint32_t bin_begin = base[bin], bin_end = base[bin + 1];
+        const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
+        const uint32_t begin = bin_begin + chunk * per_chunk;
+        const uint32_t end = min(bin_end, begin + per_chunk);
+        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
+        if (begin >= end) {  // uniform per workgroup
+            if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
+                for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = 0.f;
+            continue;
+        }
+        {
+            uint4* z = reinterpret_cast<uint4*>(lds_raw);
+            for (uint32_t e = threadIdx.x; e < entries; e += kLdsBwdBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        // Record pairs (16-byte loads), kUnroll of them per thread in flight at once: a chunk of <= 32K
+        // records is requested in one round trip.
+        constexpr uint32_t kUnroll = 16;
+        const uint32_t pair_begin = begin >> 1, pair_end = (end + 1u) >> 1;
+        for (uint32_t p0 = pair_begin + threadIdx.x; p0 < pair_end; p0 += kUnroll * kLdsBwdBlock) {
+            uint4 rec[kUnroll];
 #pragma unroll
-        for (uint32_t u = 0; u < kUnroll; ++u) {
-            const uint32_t p = p0 + u * kLdsBwdBlock;
-            rec[u] = p < pair_end ? rec2[p] : make_uint4(0u, 0u, 0u, 0u);
-        }
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const uint32_t p = p0 + u * kLdsBwdBlock;
+                rec[u] = p < pair_end ? rec2[p] : make_uint4(0u, 0u, 0u, 0u);
+            }
 #pragma unroll
-        for (uint32_t u = 0; u < kUnroll; ++u) {
-            const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
-            if (r >= begin && r < end) {
-                const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
-                AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu));
-            }
-            if (r + 1u >= begin && r + 1u < end) {
-                const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
-                AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu));
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
+                if (r >= begin && r < end) {
+                    const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
+                    AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu));
+                }
+                if (r + 1u >= begin && r + 1u < end) {
+                    const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
+                    AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu));
+                }
             }
         }
-    }
-    __syncthreads();
-    if (n_chunks == 1) {
-        for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
-    } else {
-        for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
-            const float v = AccFixed::get(acc, e);
-            if (v != 0.f) atomicAdd(gr + e, v);
+        __syncthreads();
+        if (n_chunks == 1) {
+            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
+        } else {
+            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
+                const float v = AccFixed::get(acc, e);
+                if (v != 0.f) atomicAdd(gr + e, v);
+            }
         }
+        __syncthreads();  // the next item zeroes the accumulators
     }
 }
 
@@ -931,7 +953,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 
 // Slice tables for the LDS backward live in a small device buffer owned by the module.
 
-int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask) {
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask, uint32_t target) {
     struct Item { uint32_t level, first, chunk, n_chunks; };
     // Per level: accumulator kind and slice size.  Large hashed tables (>= 2^18 entries: a 20K-entry
     // slice sees <= 8 % of the lookups) use fp32 / 20K-entry slices, everything else 64-bit fixed
@@ -945,7 +967,6 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     // pass 1: chunk counts from the hit share alone (unit = share of one float slice of a 2^19
     // table); pass 2: scale them so that the launch has enough (>= target) items to fill 256 CUs
     // for several rounds.
-    uint32_t target = 1024;
     if (const char* env = getenv("NVO_GRID_BWD_ITEMS")) target = (uint32_t)atoi(env);
     auto base_chunks = [&](uint32_t count, uint32_t size) {
         const double share = (double)count / (double)size * (524288.0 / (double)kSliceFloat);
@@ -1153,7 +1174,9 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     }
     st->created = true;
     const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
-    return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask);
+    // 512 items: measured optimum for the coarse-only launch (the atomic flush of a chunk costs as much as
+    // scanning ~2K samples; a two-stage store + reduce form was measured slower)
+    return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask, 512);
 }
 
 void nvo_grid_stream_destroy(NvoGridStream* st) {
@@ -1173,6 +1196,11 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     NVO_REQUIRE((uint64_t)N * 8 * g.n_levels < 0xFFFFFFFFull, "grid_bwd_stream: too many records for 32-bit offsets");
     if (N == 0) return nvo_zero_async(grad, sizeof(float) * 2 * (size_t)g.offset[g.n_levels], stream);
     NVO_PROF(stream, "grid_bwd_stream[L%u]", g.n_levels);
+    static const uint32_t n_cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return (uint32_t)(n > 0 ? n : 256);
+    }();
     const uint32_t tile = st->tile;
     NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
     const uint32_t n_tiles = nvo_div_up(N, tile);
@@ -1232,8 +1260,8 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_PROF_SUB(stream, "st_accumulate[L%u]", g.n_levels);                                          \
             NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                        st->d_bin_chunks, grad);                                                              \
-            NVO_LAUNCH(k_st_accumulate, dim3(max_items), dim3(kLdsBwdBlock), lds_acc, stream, g, st->d_bin_level, \
-                       st->d_bin_slice, st->d_base, items, st->d_n_items, records, grad);                    \
+            NVO_LAUNCH(k_st_accumulate, dim3(max_items < n_cus ? max_items : n_cus), dim3(kLdsBwdBlock), lds_acc, \
+                       stream, g, st->d_bin_level, st->d_bin_slice, st->d_base, items, st->d_n_items, records, grad); \
         }                                                                                                    \
     } while (0)
 #define NVO_LAUNCH_ST_T(SOA_, T_)                                                 \

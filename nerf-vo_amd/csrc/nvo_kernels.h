@@ -15,8 +15,10 @@ struct NvoGridSlices {
     uint32_t* d_first = nullptr;
     uint32_t zero_first = 0, zero_last = 0;  // entry range flushed with atomics (zeroed per launch)
 };
-// level_mask: bit l set -> level l gets slice-owner work items (default: all levels)
-int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu);
+// level_mask: bit l set -> level l gets slice-owner work items (default: all levels); target_items: the
+// chunk counts are scaled until the launch has about this many work items
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu,
+                           uint32_t target_items = 1024);
 
 // Binned backward (mode 2): hashed levels go through count/scan/scatter/accumulate, the remaining
 // (dense, small) levels through the slice-owner items in `dense`.
