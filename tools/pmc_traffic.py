@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) of the
+bench command into profiles/<round>_pmc_fetch_write_per_kernel.json: HBM-side KB per launch for every
+kernel of the library, plus the sums bench.py's `roofline.traffic` reads (`bench_name` rows).
+
+Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [steps_profiled]"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    agg = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                m = re.search(r"(k_\w+)", row["Kernel_Name"])
+                if not m:
+                    continue
+                key = (m.group(1), int(row["Grid_Size"]))
+                agg[key][0] += float(row["Counter_Value"])
+                agg[key][1] += 1
+    return agg
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out_path = sys.argv[3]
+    kernels = []
+    for key in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(key, [0.0, 0])
+        w, nw = write.get(key, [0.0, 0])
+        n = max(nf, nw, 1)
+        kernels.append({"kernel": key[0], "grid_size": key[1], "launches": n,
+                        "FETCH_SIZE_KB_per_launch": round(f / max(nf, 1), 1),
+                        "WRITE_SIZE_KB_per_launch": round(w / max(nw, 1), 1)})
+    # bench rows: the streamed main-grid backward is several kernels per step (+ the slice-owner launch of its
+    # coarse levels = the k_grid_bwd_lds launch with the smallest grid)
+    st = [k for k in kernels if k["kernel"].startswith("k_st_")]
+    lds = sorted((k for k in kernels if k["kernel"] == "k_grid_bwd_lds"), key=lambda k: k["grid_size"])
+    rows = []
+    if st:
+        parts = st + (lds[:1] if lds else [])
+        steps = max(k["launches"] for k in parts if k["kernel"] == "k_st_scatter")
+        rows.append({"bench_name": "grid_bwd_stream[L16]", "launches": steps, "parts": [f'{k["kernel"]}/{k["grid_size"]}' for k in parts],
+                     "FETCH_SIZE_KB_per_launch": round(sum(k["FETCH_SIZE_KB_per_launch"] * k["launches"] for k in parts) / steps, 1),
+                     "WRITE_SIZE_KB_per_launch": round(sum(k["WRITE_SIZE_KB_per_launch"] * k["launches"] for k in parts) / steps, 1)})
+        lds = lds[1:]
+    if lds:
+        n = sum(k["launches"] for k in lds)
+        rows.append({"bench_name": "grid_bwd_lds[L5]" if st else "grid_bwd_lds[L16]", "launches": n,
+                     "parts": [f'{k["kernel"]}/{k["grid_size"]}' for k in lds],
+                     "FETCH_SIZE_KB_per_launch": round(sum(k["FETCH_SIZE_KB_per_launch"] * k["launches"] for k in lds) / n, 1),
+                     "WRITE_SIZE_KB_per_launch": round(sum(k["WRITE_SIZE_KB_per_launch"] * k["launches"] for k in lds) / n, 1)})
+    note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
+            "`python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`; raw counter unit KB; per launch = sum / launches. "
+            "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x, other access "
+            "widths are uncalibrated; the values are reported raw.")
+    json.dump({"note": note, "kernels": rows + kernels}, open(out_path, "w"), indent=1)
+    for r in rows:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()
