@@ -90,6 +90,9 @@ class EngineConfig:
     # 3 = streamed binned (self-contained records; coarse levels slice-owner), 1 = LDS slice owner,
     # 2 = binned with gathers, 0 = global atomics.  An int applies to all three.
     grid_bwd_mode: int | tuple = (3, 1, 1)
+    # run the proposal-network losses + backward on a second HIP stream beside the main-field backward
+    # (they only share read-only inputs; forked after the render/loss kernel, joined before the optimiser)
+    overlap_proposal_backward: bool = True
     seed: int = 1337
 
 
@@ -164,6 +167,7 @@ class NerfactoEngine:
         self.skip_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
         self._graphs = {}
+        self._side_stream = None
         self._pix_scale = None
         self.corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
         self.d_corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
@@ -458,6 +462,19 @@ class NerfactoEngine:
             self._analytic_normal_grads(ws, stream)
         la = self._main_loss_args(ws, True, has_depth, normals=normals, has_gt_normal=normals)
         _call("nvo_main_render_loss", stream, C.byref(la))
+        side = None
+        if update_proposals and cfg.overlap_proposal_backward:
+            # fork: everything the proposal backward reads (main-level weights / bins) exists now
+            cur = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                # ONE side stream for both proposal networks: a stream each was measured slower
+                # (1.10 vs 1.01 ms/step) -- three LDS-heavy scatter kernels at once thrash
+                self._side_stream = [torch.cuda.Stream(device=self.device)]
+            side = self._side_stream
+            for st in side:
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    self._proposal_backward(ws, has_depth, pose, _stream(self.device))
         if pose:
             ws["d_sh"].zero_()
         _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
@@ -465,26 +482,38 @@ class NerfactoEngine:
               self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
               _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]) if pose else None,
               self._param_ptr("field.base", self.grads))
-        if update_proposals:
-            inv_rays = 1.0 / (R * self.world_size)
-            for k, net in enumerate(self.prop_nets):
-                pa = _lib.PropLossArgs(
-                    R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=16,
-                    x01=ws[f"x{k}"].data_ptr(), sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(),
-                    sbins_main=ws[f"sbins{km}"].data_ptr(), weights_main=ws[f"weights{km}"].data_ptr(),
-                    density_bias=cfg.density_bias, gt_depth=ws["gt_depth"].data_ptr() if has_depth else None,
-                    directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
-                    depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
-                    inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
-                    losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=16)
-                _call("nvo_prop_loss", stream, C.byref(pa))
-                _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
-                      self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
-                      _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
-                      self._param_ptr(f"proposal.{k}", self.grads))
+        if update_proposals and side is None:
+            self._proposal_backward(ws, has_depth, pose, stream)
+        if side is not None:
+            for st in side:
+                torch.cuda.current_stream(self.device).wait_stream(st)  # join
         if pose:
             self._pose_backward(ws, update_proposals, stream)
         return update_proposals
+
+    def _proposal_backward(self, ws, has_depth: bool, pose: bool, stream, levels=None) -> None:
+        """Interlevel + depth loss of both proposal levels and their network backward."""
+        cfg = self.cfg
+        R = ws["R"]
+        km = len(self.prop_nets)
+        inv_rays = 1.0 / (R * self.world_size)
+        for k, net in enumerate(self.prop_nets):
+            if levels is not None and k not in levels:
+                continue
+            pa = _lib.PropLossArgs(
+                R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=16,
+                x01=ws[f"x{k}"].data_ptr(), sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(),
+                sbins_main=ws[f"sbins{km}"].data_ptr(), weights_main=ws[f"weights{km}"].data_ptr(),
+                density_bias=cfg.density_bias, gt_depth=ws["gt_depth"].data_ptr() if has_depth else None,
+                directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
+                depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
+                inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
+                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=16)
+            _call("nvo_prop_loss", stream, C.byref(pa))
+            _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
+                  self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
+                  _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
+                  self._param_ptr(f"proposal.{k}", self.grads))
 
     def _pose_backward(self, ws, update_proposals: bool, stream) -> None:
         """dL/dx01 of every level that ran backward + the SH direction gradient -> dL/dpose_adjustment
