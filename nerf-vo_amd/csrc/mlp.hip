@@ -21,6 +21,8 @@
 //
 // Numerics: fp16 operands, fp32 accumulate (tcnn accumulates in fp16), fp16 hidden activations.
 #include "nvo_kernels.h"
+
+#include <stdlib.h>
 #include "../../include/nerfvo_hip.h"
 
 #include <string.h>
@@ -623,6 +625,28 @@ int launch_bwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
     X(16, 16, 2, 16)      \
     X(32, 16, 1, 16)
 
+// workgroup caps (tuning knobs; the defaults are the measured optima on MI355X)
+static uint32_t env_blocks(const char* name, uint32_t dflt) {
+    const char* e = getenv(name);
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt;
+}
+
+// Every wave loads the whole weight set into registers before its first tile, so the cap trades that
+// per-wave setup (and, backward, the per-workgroup dW flush) against parallelism.  Measured on MI355X
+// (bench.py per-kernel table, N = 196 608 / 1 M rows): colour head 64-64x2-16 forward 35.7 us at 512
+// workgroups vs 55 us at 2048, backward 101 us at 256 vs 116 us at 512; base 32-64x1-16 forward 17.8 us at
+// 1024 vs 20.6 us at 2048; the 16-wide proposal MLP wants many (2048+ forward, 512 backward).
+static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
+    const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
+    if (weight_halfs >= 8192) return 512;
+    if (weight_halfs >= 2048) return 1024;
+    return 2048;
+}
+static uint32_t bwd_block_cap(int in_pad, int width, int n_hidden) {
+    const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
+    return weight_halfs >= 8192 ? 256 : 512;
+}
+
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad) {
 #define X(I, W, H, O) \
     if (in_pad == I && width == W && n_hidden == H && out_pad == O) return true;
@@ -637,7 +661,7 @@ int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
     if (a.batch == 0) return NVO_OK;
 #define X(I, W, H, O)                                                    \
     if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
-        return launch_fwd<I, W, H, O>(a, stream, 2048);
+        return launch_fwd<I, W, H, O>(a, stream, env_blocks("NVO_MLP_FWD_BLOCKS", fwd_block_cap(I, W, H)));
     NVO_MLP_SHAPES(X)
 #undef X
     nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
@@ -651,7 +675,7 @@ int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
     if (a.batch == 0) return NVO_OK;
 #define X(I, W, H, O)                                                    \
     if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
-        return launch_bwd<I, W, H, O>(a, stream, 512);
+        return launch_bwd<I, W, H, O>(a, stream, env_blocks("NVO_MLP_BWD_BLOCKS", bwd_block_cap(I, W, H)));
     NVO_MLP_SHAPES(X)
 #undef X
     nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
