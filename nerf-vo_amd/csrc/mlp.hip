@@ -94,6 +94,30 @@ struct WTFrag {
                 f[tk][tn] = v;
             }
     }
+    // Same fragments through LDS: the workgroup copies W row-major (coalesced 8-byte loads) into `stage`
+    // (row stride K_IN + 4 halfs) and every wave takes its transposed fragments with ds_read_b64_tr_b16.
+    // The direct form above costs 4 two-byte gathers per fragment with every lane on its own cache line
+    // (144 load instructions x 64 lines per wave for the colour head) -- the dominant per-wave setup cost.
+    // MUST be called by all threads of the workgroup (barriers); `stage` holds >= N_OUT * (K_IN + 4) halfs.
+    __device__ __forceinline__ void load_lds(const _Float16* __restrict__ W, _Float16* stage, int lane) {
+        constexpr int kStride = K_IN + 4;
+        __syncthreads();  // previous users of the staging area are done
+        for (int e = threadIdx.x; e < N_OUT * K_IN / 4; e += blockDim.x) {
+            const int n = (4 * e) / K_IN, k = (4 * e) % K_IN;
+            *reinterpret_cast<h4*>(stage + n * kStride + k) = *reinterpret_cast<const h4*>(W + (size_t)n * K_IN + k);
+        }
+        __syncthreads();
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+            for (int tn = 0; tn < N_OUT / 16; ++tn) {
+                const _Float16* addr = stage + (16 * tn + 4 * g + q) * kStride + 16 * tk + 4 * pp;
+                fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4_t*)addr);
+                __builtin_memcpy(&f[tk][tn], &v, sizeof(h4));
+            }
+    }
 };
 
 // H_out^T tile = W * H_in^T
@@ -361,14 +385,20 @@ k_mlp_bwd(NvoMlpArgs a) {
     WTFrag<OUT_PAD, WIDTH> wtl;
     {
         const _Float16* W = a.weights;
-        if (need_dinput) wt0.load(W, lane);
+        _Float16* stage = &lds[0][0][0];  // the wave tiles are idle until the first sample tile
+        static_assert(WIDTH * (IN_PAD + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
+                      WIDTH * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
+                      OUT_PAD * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4),
+                      "weight staging does not fit the LDS tiles");
+        if (need_dinput) wt0.load_lds(W, stage, lane);
         W += WIDTH * IN_PAD;
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            wth[l].load(W, lane);
+            wth[l].load_lds(W, stage, lane);
             W += WIDTH * WIDTH;
         }
-        wtl.load(W, lane);
+        wtl.load_lds(W, stage, lane);
+        __syncthreads();
     }
     DwAcc<WIDTH, IN_PAD> dw0;
     DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
