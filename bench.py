@@ -214,9 +214,13 @@ def main() -> None:
     fence()
     tp0 = time.perf_counter()
     use_graph_saved, use_graph = use_graph, False  # launchers (and their event hooks) only run eagerly
+    # per-kernel durations are taken with every kernel alone on the GPU: the timed region above overlaps the
+    # proposal backward with the main-field backward on a second stream, which would inflate both here
+    overlap_saved, cfg.overlap_proposal_backward = cfg.overlap_proposal_backward, False
     for _ in range(prof_steps):  # every rank runs them (the all-reduce is collective)
         step()
     use_graph = use_graph_saved
+    cfg.overlap_proposal_backward = overlap_saved
     fence()
     ms_prof = (time.perf_counter() - tp0) / prof_steps * 1e3
     if rank == 0:

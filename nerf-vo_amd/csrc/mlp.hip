@@ -147,10 +147,11 @@ __device__ __forceinline__ void layer_mm_t(const WTFrag<N_OUT, K_IN>& wt,
 }
 
 // Load the B-operand fragments of one 16-sample input tile: x[tk][j] = in[m][16tk + 4g + j]
-template <int IN_PAD>
+template <int IN_PAD, int IO>
 __device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, int g,
-                                           h4 (&x)[IN_PAD / 16]) {
-    if (a.in_mode == NVO_IO_F32_ROWS) {
+                                           h4 (&x)[IN_PAD / 16], uint32_t cam = 0u) {
+    // cam: (NVO_IO_NERFACTO_COLOR only) appearance-embedding row of this sample's ray, loaded by the caller
+    if constexpr (IO == NVO_IO_F32_ROWS) {
         const float* __restrict__ p = (const float*)a.input + (size_t)row * a.n_in;
 #pragma unroll
         for (int tk = 0; tk < IN_PAD / 16; ++tk) {
@@ -160,7 +161,7 @@ __device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, in
                 x[tk][j] = c < a.n_in ? (_Float16)p[c] : (_Float16)1.0f;
             }
         }
-    } else if (a.in_mode == NVO_IO_HALF2_SOA) {
+    } else if constexpr (IO == NVO_IO_HALF2_SOA) {
         const h2* __restrict__ p = (const h2*)a.input;
         const uint32_t n_lv = a.n_in >> 1;
 #pragma unroll
@@ -174,23 +175,27 @@ __device__ __forceinline__ void load_input(const NvoMlpArgs& a, uint32_t row, in
             x[tk][2] = v1[0];
             x[tk][3] = v1[1];
         }
-    } else if (a.in_mode == NVO_IO_NERFACTO_COLOR) {
+    } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
         if constexpr (IN_PAD == 64) {
+            // row = [SH16(ray) | geo15 = base_out[1..15] | embed32(cam) | 1]; features 16.. are the source rows
+            // shifted by one half, fetched as aligned 8-byte pieces (v0 = src[4g..4g+3], v1 = src[4g+4..4g+7])
             const uint32_t ray = row / a.samples_per_ray;
-            const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
             const _Float16* __restrict__ sh = a.sh + (size_t)ray * 16;
             const _Float16* __restrict__ bo = a.base_out + (size_t)row * 16;
             const _Float16* __restrict__ em = a.embedding + (size_t)cam * 32;
             x[0] = *reinterpret_cast<const h4*>(sh + 4 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = 4 * g + j;                      // feature 16 + q
-                x[1][j] = q < 15 ? bo[1 + q] : em[0];
-                x[2][j] = em[1 + q];                          // feature 32 + q -> embed 1 + q
-                x[3][j] = q < 15 ? em[17 + q] : (_Float16)1.0f;  // feature 48 + q -> embed 17 + q | pad
-            }
+            const h4 b0 = *reinterpret_cast<const h4*>(bo + 4 * g);
+            const h4 b1 = *reinterpret_cast<const h4*>(bo + (g < 3 ? 4 * g + 4 : 12));  // g == 3: unused lane value
+            const h4 e0 = *reinterpret_cast<const h4*>(em + 4 * g);
+            const h4 e1 = *reinterpret_cast<const h4*>(em + 4 * g + 4);
+            const h4 e2 = *reinterpret_cast<const h4*>(em + 16 + 4 * g);
+            const h4 e3 = *reinterpret_cast<const h4*>(em + (g < 3 ? 20 + 4 * g : 28));
+            const _Float16 em0 = em[0];
+            x[1] = h4{b0[1], b0[2], b0[3], g < 3 ? b1[0] : em0};          // features 16 + 4g + j
+            x[2] = h4{e0[1], e0[2], e0[3], e1[0]};                        // embed 1 + 4g + j
+            x[3] = h4{e2[1], e2[2], e2[3], g < 3 ? e3[0] : (_Float16)1.0f};  // embed 17 + 4g + j | pad
         }
-    } else if (a.in_mode == NVO_IO_NGP_RGB) {
+    } else if constexpr (IO == NVO_IO_NGP_RGB) {
         if constexpr (IN_PAD == 32) {
             const int32_t ray = a.sample_ray[row];
             x[0] = *reinterpret_cast<const h4*>(a.base_out + (size_t)row * 16 + 4 * g);
@@ -217,9 +222,11 @@ __device__ __forceinline__ float group16_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU>
 __global__ void __launch_bounds__(kMlpBlock)
 k_mlp_fwd(NvoMlpArgs a) {
+    // hidden activation: compile-time ReLU (every network on the NeRF-VO path) or the run-time switch
+    const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -244,13 +251,17 @@ k_mlp_fwd(NvoMlpArgs a) {
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
         h4 x[IN_PAD / 16];
-        load_input<IN_PAD>(a, row, g, x);
+        uint32_t cam = 0;
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+        }
+        load_input<IN_PAD, IO>(a, row, g, x, cam);
 
         f4 acc[WIDTH / 16];
         h4 h[WIDTH / 16];
         layer_mm<WIDTH, IN_PAD>(w0, x, acc);
 #pragma unroll
-        for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(a.act, acc[t]);
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(hidden_act, acc[t]);
         if (a.hidden) {
             _Float16* hs = a.hidden + (size_t)row * WIDTH + 4 * g;
 #pragma unroll
@@ -260,7 +271,7 @@ k_mlp_fwd(NvoMlpArgs a) {
         for (int l = 0; l < N_HIDDEN - 1; ++l) {
             layer_mm<WIDTH, WIDTH>(wh[l], h, acc);
 #pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(a.act, acc[t]);
+            for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(hidden_act, acc[t]);
             if (a.hidden) {
                 _Float16* hs = a.hidden + ((size_t)(l + 1) * a.batch + row) * WIDTH + 4 * g;
 #pragma unroll
@@ -362,9 +373,10 @@ struct DwAcc {
     }
 };
 
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU>
 __global__ void __launch_bounds__(kMlpBlock)
 k_mlp_bwd(NvoMlpArgs a) {
+    const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
     constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
                                          : (IN_PAD > OUT_PAD ? IN_PAD : OUT_PAD));
     __shared__ __attribute__((aligned(16))) _Float16 lds[kWavesPerBlock][2][16 * (MAXW + 4)];
@@ -408,34 +420,66 @@ k_mlp_bwd(NvoMlpArgs a) {
     for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
     dwl.zero();
 
+    // Every global input of a tile (dL/dout, out, all hidden activations, the input row) is requested in one
+    // go, and the NEXT tile's inputs are requested before the current tile is computed: with the dW
+    // accumulators in registers a wave has its SIMD to itself (346 registers for the colour head), so memory
+    // latency can only be hidden inside the wave.  Before this the tile loop paid three dependent HBM round
+    // trips per tile (measured: 64 % of the wave cycles in s_waitcnt, 6.9 us per 16-sample tile).
+    struct TileIn {
+        h4 dzl[OUT_PAD / 16], out[OUT_PAD / 16];
+        h4 hs[N_HIDDEN][WIDTH / 16];
+        h4 x[IN_PAD / 16];
+    };
+    // output-activation derivative as arithmetic on wave-uniform coefficients (no per-element branches):
+    // factor = 1 + c_sig * (o (1 - o) - 1) + c_relu * (step(o) - 1)
+    const float c_sig = a.out_act == NVO_ACT_SIGMOID ? 1.f : 0.f, c_relu = a.out_act == NVO_ACT_RELU ? 1.f : 0.f;
+    auto load_tile = [&](uint32_t tile, TileIn& t) {
+        const uint32_t row = tile * 16 + m;
+        // the camera index heads a dependent chain (index -> embedding row): requested first, so that waiting
+        // for it does not also wait for the other loads of this tile
+        uint32_t cam = 0;
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+        }
+        const _Float16* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
+        const _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+        for (int i = 0; i < OUT_PAD / 16; ++i) {
+            t.dzl[i] = *reinterpret_cast<const h4*>(dp + 16 * i);
+            t.out[i] = *reinterpret_cast<const h4*>(op + 16 * i);
+        }
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN; ++l) {
+            const _Float16* hp = a.hidden + ((size_t)l * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+            for (int i = 0; i < WIDTH / 16; ++i) t.hs[l][i] = *reinterpret_cast<const h4*>(hp + 16 * i);
+        }
+        load_input<IN_PAD, IO>(a, row, g, t.x, cam);
+    };
+    TileIn cur;
+    if (wave < n_tiles) load_tile(wave, cur);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
+        TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
+        load_tile(min(tile + n_waves, n_tiles - 1u), nxt);
 
         // ---- output layer: dZ_L = dL/dout * out_act'(out)
         h4 dzl[OUT_PAD / 16];
-        {
-            const _Float16* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
-            const _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
 #pragma unroll
-            for (int t = 0; t < OUT_PAD / 16; ++t) {
-                h4 d = *reinterpret_cast<const h4*>(dp + 16 * t);
-                if (a.out_act != NVO_ACT_NONE) {
-                    const h4 o = *reinterpret_cast<const h4*>(op + 16 * t);
+        for (int t = 0; t < OUT_PAD / 16; ++t) {
+            h4 d = cur.dzl[t];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        d[j] = (_Float16)((float)d[j] * act_bwd_from_out(a.out_act, (float)o[j]));
-                }
-                dzl[t] = d;
+            for (int j = 0; j < 4; ++j) {
+                const float o = (float)cur.out[t][j];
+                const float f = 1.f + c_sig * (o * (1.f - o) - 1.f) + c_relu * ((o > 0.f ? 1.f : 0.f) - 1.f);
+                d[j] = (_Float16)((float)d[j] * f);
             }
+            dzl[t] = d;
         }
         // last hidden activation H_{N_HIDDEN-1}
         h4 h[WIDTH / 16];
-        {
-            const _Float16* hp =
-                a.hidden + ((size_t)(N_HIDDEN - 1) * a.batch + row) * WIDTH + 4 * g;
 #pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) h[t] = *reinterpret_cast<const h4*>(hp + 16 * t);
-        }
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
         // dW_last += dZ_L^T H
         {
 #pragma unroll
@@ -460,18 +504,14 @@ k_mlp_bwd(NvoMlpArgs a) {
             for (int t = 0; t < WIDTH / 16; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(a.act, (float)h[t][j]));
+                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(hidden_act, (float)h[t][j]));
         }
         // ---- hidden layers N_HIDDEN-1 .. 1 (weights wh[l-1] map H_{l-1} -> H_l)
 #pragma unroll
         for (int l = N_HIDDEN - 1; l >= 1; --l) {
             h4 hp_[WIDTH / 16];  // H_{l-1}
-            {
-                const _Float16* hp = a.hidden + ((size_t)(l - 1) * a.batch + row) * WIDTH + 4 * g;
 #pragma unroll
-                for (int t = 0; t < WIDTH / 16; ++t)
-                    hp_[t] = *reinterpret_cast<const h4*>(hp + 16 * t);
-            }
+            for (int t = 0; t < WIDTH / 16; ++t) hp_[t] = cur.hs[l - 1][t];
 #pragma unroll
             for (int t = 0; t < WIDTH / 16; ++t) {
                 tz.store(m, g, t, dz[t]);
@@ -494,12 +534,13 @@ k_mlp_bwd(NvoMlpArgs a) {
             for (int t = 0; t < WIDTH / 16; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(a.act, (float)hp_[t][j]));
+                    dz[t][j] = (_Float16)(acc[t][j] * act_bwd_from_out(hidden_act, (float)hp_[t][j]));
         }
         // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
         {
             h4 x[IN_PAD / 16];
-            load_input<IN_PAD>(a, row, g, x);
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) x[t] = cur.x[t];
 #pragma unroll
             for (int t = 0; t < WIDTH / 16; ++t) tz.store(m, g, t, dz[t]);
 #pragma unroll
@@ -516,7 +557,7 @@ k_mlp_bwd(NvoMlpArgs a) {
         if (need_dinput) {
             f4 acc[IN_PAD / 16];
             layer_mm_t<WIDTH, IN_PAD>(wt0, dz, acc);
-            if (a.din_mode == NVO_IO_F32_ROWS) {
+            if constexpr (IO == NVO_IO_F32_ROWS) {
                 float* __restrict__ p = (float*)a.dinput + (size_t)row * a.n_in;
 #pragma unroll
                 for (int tk = 0; tk < IN_PAD / 16; ++tk)
@@ -525,7 +566,7 @@ k_mlp_bwd(NvoMlpArgs a) {
                         const uint32_t c = 16 * tk + 4 * g + j;
                         if (c < a.n_in) p[c] = acc[tk][j];
                     }
-            } else if (a.din_mode == NVO_IO_HALF2_SOA) {
+            } else if constexpr (IO == NVO_IO_HALF2_SOA) {
                 h2* __restrict__ p = (h2*)a.dinput;
                 const uint32_t n_lv = a.n_in >> 1;
 #pragma unroll
@@ -537,7 +578,7 @@ k_mlp_bwd(NvoMlpArgs a) {
                         p[(size_t)(lv + 1) * a.batch + row] =
                             h2{(_Float16)acc[tk][2], (_Float16)acc[tk][3]};
                 }
-            } else if (a.din_mode == NVO_IO_NERFACTO_COLOR) {
+            } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
                 if constexpr (IN_PAD == 64) {
                     const uint32_t ray = row / a.samples_per_ray;
                     const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
@@ -571,7 +612,7 @@ k_mlp_bwd(NvoMlpArgs a) {
                         }
                     }
                 }
-            } else if (a.din_mode == NVO_IO_NGP_RGB) {
+            } else if constexpr (IO == NVO_IO_NGP_RGB) {
                 if constexpr (IN_PAD == 32) {
                     // d(density-net output): all 16 columns; column 0 also receives dL/d(density pre-activation)
                     h4 v;
@@ -591,6 +632,7 @@ k_mlp_bwd(NvoMlpArgs a) {
                 }
             }
         }
+        cur = nxt;
     }
 
     // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
@@ -612,28 +654,79 @@ k_mlp_bwd(NvoMlpArgs a) {
     }
 }
 
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
-int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_fwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
     NVO_PROF(stream, "mlp_fwd[%d-%dx%d-%d]", IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
-    NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
-                       0, stream, a);
+    if (a.act == NVO_ACT_RELU) {
+        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    } else {
+        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+// The IO layout is a compile-time parameter of the kernels (run-time mode switches inside the tile loop cost
+// branches and, worse, full `s_waitcnt vmcnt(0)` drains at every join, which defeats the input prefetch).
+// Row-major fp32 / level-major half2 / row-major half exist for every shape, the two fused heads only for theirs.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+int launch_fwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    switch (a.in_mode) {
+        case NVO_IO_F32_ROWS: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_F32_ROWS>(a, stream, max_blocks);
+        case NVO_IO_HALF2_SOA: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF2_SOA>(a, stream, max_blocks);
+        case NVO_IO_HALF_ROWS: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF_ROWS>(a, stream, max_blocks);
+        case NVO_IO_NERFACTO_COLOR:
+            if constexpr (IN_PAD == 64 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NERFACTO_COLOR>(a, stream, max_blocks);
+            break;
+        case NVO_IO_NGP_RGB:
+            if constexpr (IN_PAD == 32 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NGP_RGB>(a, stream, max_blocks);
+            break;
+    }
+    nvo_set_error("mlp: IO mode %d is not available for shape %d-%dx%d-%d", a.in_mode, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    return NVO_ERR_UNSUPPORTED;
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_bwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
+    NVO_PROF(stream, "mlp_bwd[%d-%dx%d-%d]", IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    const uint32_t n_tiles = a.batch >> 4;
+    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (a.act == NVO_ACT_RELU) {
+        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    } else {
+        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
 int launch_bwd(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) {
-    NVO_PROF(stream, "mlp_bwd[%d-%dx%d-%d]", IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
-    const uint32_t n_tiles = a.batch >> 4;
-    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
-    if (blocks > max_blocks) blocks = max_blocks;
-    NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD>), dim3(blocks), dim3(kMlpBlock),
-                       0, stream, a);
-    NVO_CHECK_LAUNCH();
-    return NVO_OK;
+    if (a.dinput != nullptr && a.din_mode != a.in_mode) {
+        nvo_set_error("mlp: dinput layout (%d) must equal the input layout (%d)", a.din_mode, a.in_mode);
+        return NVO_ERR_UNSUPPORTED;
+    }
+    switch (a.in_mode) {
+        case NVO_IO_F32_ROWS: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_F32_ROWS>(a, stream, max_blocks);
+        case NVO_IO_HALF2_SOA: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF2_SOA>(a, stream, max_blocks);
+        case NVO_IO_HALF_ROWS: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF_ROWS>(a, stream, max_blocks);
+        case NVO_IO_NERFACTO_COLOR:
+            if constexpr (IN_PAD == 64 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NERFACTO_COLOR>(a, stream, max_blocks);
+            break;
+        case NVO_IO_NGP_RGB:
+            if constexpr (IN_PAD == 32 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NGP_RGB>(a, stream, max_blocks);
+            break;
+    }
+    nvo_set_error("mlp: IO mode %d is not available for shape %d-%dx%d-%d", a.in_mode, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    return NVO_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -664,17 +757,19 @@ static uint32_t env_blocks(const char* name, uint32_t dflt) {
 // Every wave loads the whole weight set into registers before its first tile, so the cap trades that
 // per-wave setup (and, backward, the per-workgroup dW flush) against parallelism.  Measured on MI355X
 // (bench.py per-kernel table, N = 196 608 / 1 M rows): colour head 64-64x2-16 forward 35.7 us at 512
-// workgroups vs 55 us at 2048, backward 101 us at 256 vs 116 us at 512; base 32-64x1-16 forward 17.8 us at
-// 1024 vs 20.6 us at 2048; the 16-wide proposal MLP wants many (2048+ forward, 512 backward).
+// workgroups vs 55 us at 2048; base 32-64x1-16 forward 17.8 us at 1024 vs 20.6 us at 2048; the 16-wide
+// proposal MLP wants many forward workgroups (2048+).
 static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
     const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
     if (weight_halfs >= 8192) return 512;
     if (weight_halfs >= 2048) return 1024;
     return 2048;
 }
-static uint32_t bwd_block_cap(int in_pad, int width, int n_hidden) {
-    const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
-    return weight_halfs >= 8192 ? 256 : 512;
+static uint32_t bwd_block_cap(int, int, int) {
+    // one workgroup per CU: with the tile inputs software-pipelined every shape is fastest at 256 (colour head
+    // 74 us vs 107 us at 512; base 30.6 vs 37.7; proposal 49.5 vs 53.4) -- fewer dW flushes, and the dW
+    // accumulators leave the wide shapes one wave per SIMD anyway
+    return 256;
 }
 
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad) {
