@@ -92,7 +92,7 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const _Flo
                                                 const float* __restrict__ tb, float bias,
                                                 const float* w, const float* Tr, const float* g,
                                                 float loss_scale, _Float16* __restrict__ dpre,
-                                                uint32_t dpre_stride) {
+                                                uint32_t dpre_stride, bool zero_row = false) {
     // total of g_i w_i, then inclusive prefix per chunk -> suffix (exclusive) = total - incl
     float total = 0.f;
     for (uint32_t base = 0; base < S; base += 64) {
@@ -114,7 +114,17 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const _Flo
                 const float dsig = delta * (g[i] * (Tr[i] - w[i]) - (total - incl));
                 d = dsig * __expf(fminf(fmaxf(x, -15.f), 15.f));
             }
-            dpre[(size_t)i * dpre_stride] = (_Float16)(d * loss_scale);
+            if (zero_row && dpre_stride == 16) {
+                // whole 32-byte row {d, 0 x 15} as two 16-byte stores (the MLP backward reads all 16 columns)
+                const _Float16 h = (_Float16)(d * loss_scale);
+                uint4 lo = make_uint4(0u, 0u, 0u, 0u);
+                lo.x = (uint32_t)__builtin_bit_cast(unsigned short, h);
+                uint4* row = reinterpret_cast<uint4*>(dpre + (size_t)i * 16);
+                row[0] = lo;
+                row[1] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                dpre[(size_t)i * dpre_stride] = (_Float16)(d * loss_scale);
+            }
         }
         carry = __shfl(incl, 63, 64);
     }
@@ -377,7 +387,17 @@ k_main_render_loss(nvo_main_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
                     (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
-    if (act) {
+    if (act && a.drgb_stride == 16) {
+        // the colour MLP backward reads all 16 columns: one 32-byte row {dr, dg, db, 0 x 13} as two 16-byte stores
+        const _Float16 h0 = (_Float16)(dc[0] * a.loss_scale), h1 = (_Float16)(dc[1] * a.loss_scale),
+                       h2v = (_Float16)(dc[2] * a.loss_scale);
+        uint4 lo = make_uint4(0u, 0u, 0u, 0u);
+        lo.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+        lo.y = (uint32_t)__builtin_bit_cast(unsigned short, h2v);
+        uint4* row = reinterpret_cast<uint4*>((_Float16*)a.drgb + (so + lane) * 16);
+        row[0] = lo;
+        row[1] = make_uint4(0u, 0u, 0u, 0u);
+    } else if (act) {
         _Float16* dp = (_Float16*)a.drgb + (so + lane) * a.drgb_stride;
 #pragma unroll
         for (int k = 0; k < 3; ++k) dp[k] = (_Float16)(dc[k] * a.loss_scale);
@@ -478,10 +498,12 @@ k_prop_loss(nvo_prop_loss_args a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
-    for (uint32_t i = lane; i < S; i += 64) {
-        _Float16* dp = (_Float16*)a.dpre + (so + i) * a.dpre_stride;
-        for (uint32_t k = 1; k < a.dpre_stride; ++k) dp[k] = (_Float16)0.f;
+                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride, true);
+    if (a.dpre_stride != 16) {
+        for (uint32_t i = lane; i < S; i += 64) {
+            _Float16* dp = (_Float16*)a.dpre + (so + i) * a.dpre_stride;
+            for (uint32_t k = 1; k < a.dpre_stride; ++k) dp[k] = (_Float16)0.f;
+        }
     }
 }
 
