@@ -410,7 +410,7 @@ k_main_render_loss(nvo_main_loss_args a) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kRayBlock)
 k_prop_loss(nvo_prop_loss_args a) {
-    __shared__ float lds[kRaysPerBlock][4][kMaxS + 4];
+    __shared__ float lds[kRaysPerBlock][5][kMaxS + 4];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
     if (r >= a.R) return;
@@ -421,7 +421,13 @@ k_prop_loss(nvo_prop_loss_args a) {
     const uint32_t S = a.S, Sm = a.S_main;
     const size_t so = (size_t)r * S;
     const float* tb = a.tbins + (size_t)r * (S + 1);
-    const float* sb = a.sbins + (size_t)r * (S + 1);
+    // the two binary searches per main interval walk this level's spacing bins: staged in LDS, each probe
+    // is an LDS read instead of a dependent global load
+    float* sb = lds[wib][4];
+    {
+        const float* sbg = a.sbins + (size_t)r * (S + 1);
+        for (uint32_t i = lane; i < S + 1; i += 64) sb[i] = sbg[i];
+    }
     const _Float16* pre = (const _Float16*)a.pre + so * a.pre_stride;
     const float* x01 = a.x01 + 3 * so;
     ray_weights(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
