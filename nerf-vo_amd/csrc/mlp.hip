@@ -248,14 +248,21 @@ k_mlp_fwd(NvoMlpArgs a) {
         wl.load(W, lane);
     }
 
-    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+    // the next tile's input row is requested before the current tile is computed (see k_mlp_bwd)
+    auto load_x = [&](uint32_t tile, h4 (&xo)[IN_PAD / 16]) {
         const uint32_t row = tile * 16 + m;
-        h4 x[IN_PAD / 16];
         uint32_t cam = 0;
         if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
             if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
         }
-        load_input<IN_PAD, IO>(a, row, g, x, cam);
+        load_input<IN_PAD, IO>(a, row, g, xo, cam);
+    };
+    h4 x[IN_PAD / 16];
+    if (wave < n_tiles) load_x(wave, x);
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 16 + m;
+        h4 xn[IN_PAD / 16];
+        load_x(min(tile + n_waves, n_tiles - 1u), xn);
 
         f4 acc[WIDTH / 16];
         h4 h[WIDTH / 16];
@@ -284,6 +291,8 @@ k_mlp_fwd(NvoMlpArgs a) {
 #pragma unroll
         for (int t = 0; t < OUT_PAD / 16; ++t)
             *reinterpret_cast<h4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
+#pragma unroll
+        for (int t = 0; t < IN_PAD / 16; ++t) x[t] = xn[t];
     }
 }
 
