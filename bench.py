@@ -94,6 +94,10 @@ def main() -> None:
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--psnr", choices=("off", "small", "replica"), default="small",
+                    help="second half of the BASELINE metric (render PSNR): an end-to-end run of the mapper mirror on "
+                         "the synthetic room, held-out views rendered by the native renderer.  small = 48 keyframes "
+                         "320x240, 1500 iterations (~5 s); replica = 192 keyframes 640x480, 8192 iterations")
     ap.add_argument("--grid-bwd-mode", type=int, nargs="+", default=None,
                     help="hash-grid backward kernel: one value for all networks or three (main, proposal 0, "
                          "proposal 1); 3 = streamed binned, 1 = LDS slice owner, 2 = binned, 0 = global atomics; "
@@ -261,6 +265,23 @@ def main() -> None:
 
         cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)
 
+    # ---- render PSNR (rank 0, N=1): outside the timed region, a separate small end-to-end mapping run
+    render_psnr = None
+    if rank == 0 and world == 1 and args.psnr != "off":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from run_synthetic_mapping import run as run_mapping
+
+        kw = (dict(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6) if args.psnr == "small" else
+              dict(keyframes=192, height=480, width=640, iterations=8192, eval_frames=6))
+        res = run_mapping(quiet=True, **kw)
+        render_psnr = {"psnr_float_mse_db": round(res["psnr_float_mse"], 3),
+                       "psnr_reference_uint8wrap_db": round(res["psnr_reference_uint8wrap"], 3),
+                       "depth_l1": round(res["depth_l1"], 4), "held_out_views": kw["eval_frames"],
+                       "config": f'{kw["keyframes"]} keyframes {kw["width"]}x{kw["height"]}, {kw["iterations"]} iterations '
+                                 "through the Nerfstudio mapper interface (incremental keyframe ingest, SE3 pose "
+                                 "refinement on), synthetic textured room",
+                       "train_ray_samples_per_sec": res["ray_samples_per_sec"]}
+
     if rank == 0:
         out = {
             "metric": "training ray-samples/sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
@@ -280,6 +301,7 @@ def main() -> None:
             "final_losses": losses,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "render_psnr": render_psnr,
         }
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
