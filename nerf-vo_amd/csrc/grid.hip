@@ -626,13 +626,21 @@ k_st_count(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* 
     const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
     const uint32_t size = g.offset[level + 1] - g.offset[level];
     const uint32_t res = g.resolution[level], hashed = g.hashed[level];
+    const uint32_t i = tile * kStBlock + threadIdx.x;
+    float2 d = make_float2(0.f, 0.f);
+    float xs[3] = {0.f, 0.f, 0.f};
+    bool live = false;
+    if (i < N) {  // dy and x in one round trip (see k_st_scatter)
+        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+        xs[0] = x[3 * (size_t)i + 0];
+        xs[1] = x[3 * (size_t)i + 1];
+        xs[2] = x[3 * (size_t)i + 2];
+    }
     for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) hist[b] = 0u;
     __syncthreads();
-    const uint32_t i = tile * kStBlock + threadIdx.x;
-    if (i < N) {
-        float2 d;
-        if (load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d)) {
-            const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+    {
+        if (live) {
+            const Corner c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
                 const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
@@ -734,22 +742,29 @@ k_st_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
     uint32_t* loff = hist + n_slices;
     uint32_t* gbase = loff + n_slices;
     __shared__ uint32_t total_s;
-    // the global offset of this tile's run in every bin does not depend on the histogram: requested first,
-    // so its latency overlaps the x / dy loads instead of following them
+    // every global input of the workgroup is requested up front, in ONE round trip: dy and x of this thread's
+    // sample (x unconditionally -- loading it only for dy != 0 chains two latencies) and the global offset of
+    // this tile's run in every bin, which does not depend on the histogram
+    const uint32_t i = tile * kStBlock + threadIdx.x;
+    float2 d = make_float2(0.f, 0.f);
+    float xs[3] = {0.f, 0.f, 0.f};
+    bool live = false;
+    if (i < N) {
+        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+        xs[0] = x[3 * (size_t)i + 0];
+        xs[1] = x[3 * (size_t)i + 1];
+        xs[2] = x[3 * (size_t)i + 2];
+    }
     for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) {
         hist[b] = 0u;
         gbase[b] = base[bin0 + b] + tile_off[(size_t)(bin0 + b) * n_tiles + tile];
     }
     __syncthreads();
-    const uint32_t i = tile * kStBlock + threadIdx.x;
     uint32_t idx[8], slot[8];
-    float2 d = make_float2(0.f, 0.f);
     Corner c = {};
-    bool live = false;
-    if (i < N) {
-        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+    {
         if (live) {
-            c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+            c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
                 idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
