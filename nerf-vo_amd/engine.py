@@ -626,8 +626,8 @@ class NerfactoEngine:
         entry["main"].replay()
         if all_reduce is not None:
             segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in groups)]
-            if entry.get("half") is not None:  # compressed exchange: reduce the captured fp16 buffer in place
-                all_reduce.reduce_half(self.grads, entry["half"], segs)
+            if entry.get("half") is not None:  # compressed exchange: the fp16 cast is part of the main graph
+                all_reduce.reduce_half(self.grads, entry["half"], segs, already_cast=True)
             else:
                 all_reduce(self.grads, segments=segs)
             entry["opt"].replay()
@@ -655,10 +655,15 @@ class NerfactoEngine:
             jit = torch.rand((3, R), device=dev)
             self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
                                   anneal=1.0, anneal_dev=anneal_ptr, has_normals=has_normals)
+            if half is not None:  # fp16 copy of the ranges the collective will exchange
+                for lo, hi in cast_ranges:
+                    _call("nvo_cast_half", _stream(dev), hi - lo, C.c_void_p(self.grads.data_ptr() + 4 * lo),
+                          C.c_void_p(half.data_ptr() + 2 * lo))
 
         half = None
         if split_optimizer and getattr(self, "_reducer_compress", None) == "fp16":
             half = torch.zeros(self.n_params, dtype=torch.float16, device=dev)
+        cast_ranges = [self.group_ranges[g] for g in groups]
 
         def body_opt():
             self.optimizer_step(groups, from_device_scalars=True, grads_half=half)
