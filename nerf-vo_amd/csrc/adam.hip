@@ -77,13 +77,39 @@ k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* 
     }
 }
 
+// A pure streaming read: 16-byte loads, four of them in flight per thread (the scalar grid-stride form ran at
+// 2.6 TB/s).  Non-finite <=> exponent field all ones; checked on the raw bits.
 template <typename GT>
 __global__ void __launch_bounds__(256)
 k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
+    constexpr uint32_t kPer = 16 / sizeof(GT);  // elements per 16-byte load
+    const uint64_t n_vec = (((uintptr_t)g & 15u) == 0u) ? n / kPer : 0u;
+    const uint4* __restrict__ gv = reinterpret_cast<const uint4*>(g);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float x = load_grad(g, i);
+    auto check = [&](uint4 q) {
+        if constexpr (sizeof(GT) == 4) {
+            bad = bad || (q.x & 0x7F800000u) == 0x7F800000u || (q.y & 0x7F800000u) == 0x7F800000u ||
+                  (q.z & 0x7F800000u) == 0x7F800000u || (q.w & 0x7F800000u) == 0x7F800000u;
+        } else {
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bad = bad || (w[k] & 0x7C00u) == 0x7C00u || (w[k] & 0x7C000000u) == 0x7C000000u;
+        }
+    };
+    uint64_t i = tid;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+        const uint4 a = gv[i], b = gv[i + stride], c = gv[i + 2 * stride], d = gv[i + 3 * stride];
+        check(a);
+        check(b);
+        check(c);
+        check(d);
+    }
+    for (; i < n_vec; i += stride) check(gv[i]);
+    for (uint64_t j = n_vec * kPer + tid; j < n; j += stride) {  // unaligned base or tail
+        const float x = load_grad(g, j);
         bad = bad || !(fabsf(x) <= 3.0e38f);
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -92,8 +118,15 @@ k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ fl
 __global__ void __launch_bounds__(256)
 k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ dst) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        dst[i] = (_Float16)src[i];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = (((uintptr_t)src & 15u) | ((uintptr_t)dst & 7u)) == 0u;
+    const uint64_t n_vec = aligned ? n / 4 : 0u;
+    for (uint64_t i = tid; i < n_vec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+        reinterpret_cast<h4v*>(dst)[i] = h4v{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+    for (uint64_t i = n_vec * 4 + tid; i < n; i += stride) dst[i] = (_Float16)src[i];
 }
 
 __global__ void __launch_bounds__(256)
