@@ -147,6 +147,17 @@ int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
 /* sbins/tbins: device float [R][S+1]; jitter: device float [R] in [0,1) or NULL (eval bins) */
 int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
                        const float* jitter, float* sbins, float* tbins);
+
+/* Fused forms (fewer launches per step; identical arithmetic):
+ *   nvo_lindisp_positions = nvo_sample_lindisp + nvo_sample_positions of those bins
+ *   nvo_gather_targets    = nvo_gather_pixels of colour [F][H][W][3], depth [F][H][W] (nullable) and
+ *                           normals [F][H][W][3] (nullable) + nvo_dirs01 (nullable) in one launch */
+int nvo_lindisp_positions(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
+                          const float* jitter, const float* origins, const float* directions, float* sbins,
+                          float* tbins, float* x01);
+int nvo_gather_targets(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H, uint32_t W,
+                       const float* images, const float* depths, const float* normals, const float* directions,
+                       float* gt_rgb, float* gt_depth, float* gt_normal, float* dirs01);
 /* x01: device float [R*S][3] contracted + normalised sample positions; rows outside (0,1)^3 are
  * written as zeros (== nerfstudio's `positions * selector`) */
 int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const float* origins,
@@ -178,6 +189,11 @@ typedef struct nvo_weights_pdf_args {
     float* sbins_out;            /* [R][S_out+1] */
     float* tbins_out;
     const float* anneal_dev;     /* device float or NULL: overrides `anneal` (hipGraph replay) */
+    /* optional fusion of nvo_sample_positions for the resampled level: all three non-NULL -> the contracted
+     * positions of the S_out new samples are written too */
+    const float* origins;        /* [R][3] */
+    const float* directions;     /* [R][3] */
+    float* x01_out;              /* [R*S_out][3] */
 } nvo_weights_pdf_args;
 int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args);
 

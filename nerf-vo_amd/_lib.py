@@ -27,7 +27,8 @@ class WeightsPdfArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("S_out", _u32), ("pre", _p), ("pre_stride", _u32), ("x01", _p),
                 ("sbins", _p), ("tbins", _p), ("density_bias", _f), ("sigma", _p), ("weights", _p),
                 ("anneal", _f), ("histogram_padding", _f), ("near_plane", _f), ("far_plane", _f),
-                ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p), ("anneal_dev", _p)]
+                ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p), ("anneal_dev", _p),
+                ("origins", _p), ("directions", _p), ("x01_out", _p)]
 
 
 class MainLossArgs(C.Structure):
@@ -105,6 +106,8 @@ _SIGNATURES = {
     "nvo_se3_exp_map_bwd": (_int, [_p, _u32, _p, _p, _f, _f, _f, _p, _p, _int]),
     "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
     "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
+    "nvo_lindisp_positions": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "nvo_gather_targets": (_int, [_p, _u32, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),
     "nvo_dirs01": (_int, [_p, _u32, _p, _p]),
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),

@@ -106,6 +106,28 @@ uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_fe
                               float per_level_scale);
 
 #ifdef __HIPCC__
+// ---- sample position -> contracted, normalised grid coordinate (nerfacto: Frustums.get_positions,
+// SceneContraction(L-inf), (x + 2) / 4, selector mask -> masked positions are zeroed) ----------------------
+__device__ __forceinline__ void nvo_contract_position01(const float o[3], const float d[3], float mid, float out[3]) {
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = o[k] + d[k] * mid;
+    const float mag = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
+    if (!(mag < 1.f)) {
+        const float f = (2.f - 1.f / mag) / mag;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] *= f;
+    }
+    bool sel = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k] = (p[k] + 2.f) * 0.25f;
+        sel = sel && (p[k] > 0.f) && (p[k] < 1.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = sel ? p[k] : 0.f;
+}
+
 // ---- device helpers shared by grid kernels -------------------------------------------------
 __device__ __forceinline__ uint32_t nvo_grid_index(uint32_t hashed, uint32_t hashmap_size,
                                                    uint32_t res, uint32_t px, uint32_t py,

@@ -118,23 +118,79 @@ k_sample_positions(uint32_t R, uint32_t S, const float* __restrict__ origins,
     if (i >= R * S) return;
     const uint32_t r = i / S, s = i - r * S;
     const float mid = (tbins[(size_t)r * (S + 1) + s] + tbins[(size_t)r * (S + 1) + s + 1]) * 0.5f;
+    const float o[3] = {origins[3 * (size_t)r], origins[3 * (size_t)r + 1], origins[3 * (size_t)r + 2]};
+    const float d[3] = {directions[3 * (size_t)r], directions[3 * (size_t)r + 1], directions[3 * (size_t)r + 2]};
     float p[3];
+    nvo_contract_position01(o, d, mid, p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = origins[3 * (size_t)r + k] + directions[3 * (size_t)r + k] * mid;
-    const float mag = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
-    if (!(mag < 1.f)) {
-        const float f = (2.f - 1.f / mag) / mag;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] *= f;
+    for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = p[k];
+}
+
+// Fused first sampler level: lin-disp bins AND the sample positions of those bins in one launch
+// (thread per (ray, sample); the thread of the last sample also writes the closing bin edge).
+__device__ __forceinline__ float lindisp_bin(uint32_t j, uint32_t S, const float* jitter, uint32_t r) {
+    const float step = 1.0f / (float)S;
+    float b = (float)j * step;
+    if (j == S) b = 1.0f;
+    if (jitter) {
+        const float prev = j > 0 ? (float)(j - 1) * step : 0.f;
+        const float next = (j + 1 == S) ? 1.0f : (float)(j + 1) * step;
+        const float lower = j == 0 ? b : (prev + b) * 0.5f;
+        const float upper = j == S ? b : (b + next) * 0.5f;
+        b = lower + (upper - lower) * jitter[r];
     }
-    bool sel = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        p[k] = (p[k] + 2.f) * 0.25f;
-        sel = sel && (p[k] > 0.f) && (p[k] < 1.f);
+    return b;
+}
+
+__global__ void __launch_bounds__(256)
+k_lindisp_positions(uint32_t R, uint32_t S, float near, float far, const float* __restrict__ jitter,
+                    const float* __restrict__ origins, const float* __restrict__ directions,
+                    float* __restrict__ sbins, float* __restrict__ tbins, float* __restrict__ x01) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * S) return;
+    const uint32_t r = i / S, j = i - r * S;
+    const float s_near = spacing_fn(near), s_far = spacing_fn(far);
+    const float b0 = lindisp_bin(j, S, jitter, r), b1 = lindisp_bin(j + 1, S, jitter, r);
+    const float t0 = spacing_fn_inv(b0 * s_far + (1.f - b0) * s_near);
+    const float t1 = spacing_fn_inv(b1 * s_far + (1.f - b1) * s_near);
+    sbins[(size_t)r * (S + 1) + j] = b0;
+    tbins[(size_t)r * (S + 1) + j] = t0;
+    if (j + 1 == S) {
+        sbins[(size_t)r * (S + 1) + S] = b1;
+        tbins[(size_t)r * (S + 1) + S] = t1;
     }
+    const float o[3] = {origins[3 * (size_t)r], origins[3 * (size_t)r + 1], origins[3 * (size_t)r + 2]};
+    const float d[3] = {directions[3 * (size_t)r], directions[3 * (size_t)r + 1], directions[3 * (size_t)r + 2]};
+    float p[3];
+    nvo_contract_position01(o, d, (t0 + t1) * 0.5f, p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = sel ? p[k] : 0.f;
+    for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = p[k];
+}
+
+// Fused ray setup: ray generation + gather of the colour / depth / normal targets + the (d + 1) / 2
+// direction-encoding input, one thread per ray.
+__global__ void __launch_bounds__(256)
+k_gather_targets(uint32_t R, const int64_t* __restrict__ ray_indices, uint32_t H, uint32_t W,
+                 const float* __restrict__ images, const float* __restrict__ depths,
+                 const float* __restrict__ normals, const float* __restrict__ directions,
+                 float* __restrict__ gt_rgb, float* __restrict__ gt_depth, float* __restrict__ gt_normal,
+                 float* __restrict__ dirs01) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t cam = ray_indices[3 * (size_t)r + 0], y = ray_indices[3 * (size_t)r + 1],
+                  x = ray_indices[3 * (size_t)r + 2];
+    const size_t pix = ((size_t)cam * H + (size_t)y) * W + (size_t)x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gt_rgb[3 * (size_t)r + k] = images[3 * pix + k];
+    if (depths) gt_depth[r] = depths[pix];
+    if (normals) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gt_normal[3 * (size_t)r + k] = normals[3 * pix + k];
+    }
+    if (dirs01) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dirs01[3 * (size_t)r + k] = (directions[3 * (size_t)r + k] + 1.f) * 0.5f;
+    }
 }
 
 // direction encoding input: (d + 1) / 2 per ray
@@ -250,6 +306,33 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
     NVO_PROF(stream, "sample_positions[S%u]", S);
     NVO_LAUNCH(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, origins, directions, tbins, x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_lindisp_positions(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
+                          const float* jitter, const float* origins, const float* directions, float* sbins,
+                          float* tbins, float* x01) {
+    NVO_REQUIRE(S >= 1 && (R == 0 || (origins && directions && sbins && tbins && x01)), "lindisp_positions: bad argument");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "lindisp_positions[S%u]", S);
+    NVO_LAUNCH(k_lindisp_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0, (hipStream_t)stream, R, S,
+               near_plane, far_plane, jitter, origins, directions, sbins, tbins, x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_gather_targets(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H, uint32_t W,
+                       const float* images, const float* depths, const float* normals, const float* directions,
+                       float* gt_rgb, float* gt_depth, float* gt_normal, float* dirs01) {
+    NVO_REQUIRE(R == 0 || (ray_indices && images && gt_rgb), "gather_targets: NULL argument");
+    NVO_REQUIRE(!depths || gt_depth, "gather_targets: gt_depth is NULL");
+    NVO_REQUIRE(!normals || gt_normal, "gather_targets: gt_normal is NULL");
+    NVO_REQUIRE(!dirs01 || directions, "gather_targets: directions is NULL");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "gather_targets");
+    NVO_LAUNCH(k_gather_targets, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices, H, W,
+               images, depths, normals, directions, gt_rgb, gt_depth, gt_normal, dirs01);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

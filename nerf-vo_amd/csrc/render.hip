@@ -189,8 +189,23 @@ k_weights_pdf(nvo_weights_pdf_args a) {
         if (isnan(t)) t = 0.f;
         t = fminf(fmaxf(t, 0.f), 1.f);
         const float b = sb[below] + t * (sb[above] - sb[below]);
+        const float tv = spacing_fn_inv(b * s_far + (1.f - b) * s_near);
         a.sbins_out[(size_t)r * nb + j] = b;
-        a.tbins_out[(size_t)r * nb + j] = spacing_fn_inv(b * s_far + (1.f - b) * s_near);
+        a.tbins_out[(size_t)r * nb + j] = tv;
+        if (a.x01_out) w[j] = tv;  // the weights are in global memory already: reuse their LDS row
+    }
+    if (a.x01_out) {  // fused nvo_sample_positions of the resampled level
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float o[3] = {a.origins[3 * (size_t)r], a.origins[3 * (size_t)r + 1], a.origins[3 * (size_t)r + 2]};
+        const float d[3] = {a.directions[3 * (size_t)r], a.directions[3 * (size_t)r + 1], a.directions[3 * (size_t)r + 2]};
+        for (uint32_t j = lane; j < a.S_out; j += 64) {
+            float p[3];
+            nvo_contract_position01(o, d, (w[j] + w[j + 1]) * 0.5f, p);
+            float* xo = a.x01_out + 3 * ((size_t)r * a.S_out + j);
+            xo[0] = p[0]; xo[1] = p[1]; xo[2] = p[2];
+        }
     }
 }
 
@@ -527,6 +542,7 @@ int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args) {
     NVO_REQUIRE(a.S_out <= (uint32_t)kMaxS, "weights_pdf: S_out %u > %d", a.S_out, kMaxS);
     NVO_REQUIRE(a.S_out == 0 || (a.sbins_out && a.tbins_out), "weights_pdf: output bins are NULL");
     NVO_REQUIRE(a.pre && a.x01 && a.tbins && a.weights && a.sbins, "weights_pdf: NULL input");
+    NVO_REQUIRE(!a.x01_out || (a.origins && a.directions && a.S_out > 0), "weights_pdf: x01_out needs origins, directions and S_out");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "weights_pdf[S%u]", a.S);
     NVO_LAUNCH(k_weights_pdf, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,

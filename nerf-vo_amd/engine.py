@@ -281,9 +281,7 @@ class NerfactoEngine:
 
     def _density_level(self, ws, k: int, net: _NativeModule, seg: str, stream):
         """positions -> contracted grid coords -> NetworkWithInputEncoding -> fp16 [N,16] (col 0)."""
-        R, S = ws["R"], self.levels[k]
-        _call("nvo_sample_positions", stream, R, S, _ptr(ws["origins"]), _ptr(ws["directions"]),
-              _ptr(ws[f"tbins{k}"]), _ptr(ws[f"x{k}"]))
+        R, S = ws["R"], self.levels[k]  # ws[f"x{k}"] was written by the sampler kernel of this level
         _call("nvo_fwd", net.handle, stream, R * S, _ptr(ws[f"x{k}"]), self._param_ptr(seg, self.params_half),
               _ptr(ws[f"out{k}"]), _ptr(ws[f"ctx{k}"]))
 
@@ -314,7 +312,10 @@ class NerfactoEngine:
             histogram_padding=cfg.histogram_padding, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
             jitter=None if jitter is None else jitter.data_ptr(),
             sbins_out=ws[f"sbins{k + 1}"].data_ptr() if resample else None,
-            tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None, anneal_dev=anneal_dev)
+            tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None, anneal_dev=anneal_dev,
+            origins=ws["origins"].data_ptr() if resample else None,
+            directions=ws["directions"].data_ptr() if resample else None,
+            x01_out=ws[f"x{k + 1}"].data_ptr() if resample else None)
         _call("nvo_weights_pdf", stream, C.byref(a))
 
     def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream,
@@ -323,14 +324,16 @@ class NerfactoEngine:
         cfg = self.cfg
         R = ws["R"]
         j = jitters if jitters is not None else (None, None, None)
-        _call("nvo_sample_lindisp", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
-              _ptr(ws["sbins0"]), _ptr(ws["tbins0"]))
+        _call("nvo_lindisp_positions", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
+              _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["sbins0"]), _ptr(ws["tbins0"]), _ptr(ws["x0"]))
         for k, net in enumerate(self.prop_nets):
             self._density_level(ws, k, net, f"proposal.{k}", stream)
             self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True, anneal_dev=anneal_dev)
         km = len(self.prop_nets)
         self._density_level(ws, km, self.base_net, "field.base", stream)
-        _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
+        if not ws.get("dirs01_ready", False):
+            _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
+        ws["dirs01_ready"] = False
         _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
         ca = self._color_args(ws, training, cam_idx_for_embedding, embedding_ptr)
         _call("nvo_nerfacto_color_fwd", stream, C.byref(ca))
@@ -417,11 +420,11 @@ class NerfactoEngine:
         _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corrections),
               _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]),
               _ptr(ws["cam_idx"]))
-        _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
-        if depths is not None:
-            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 1, _ptr(depths), _ptr(ws["gt_depth"]))
-        if normals is not None:
-            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(normals), _ptr(ws["gt_normal"]))
+        # colour / depth / normal targets and the direction-encoding input in one launch
+        _call("nvo_gather_targets", stream, R, _ptr(ray_indices), H, W, _ptr(images), _ptr(depths), _ptr(normals),
+              _ptr(ws["directions"]), _ptr(ws["gt_rgb"]), _ptr(ws["gt_depth"]), _ptr(ws["gt_normal"]),
+              _ptr(ws["dirs01"]))
+        ws["dirs01_ready"] = True
 
     def load_ray_bundle(self, ws, origins, directions, directions_norm, cam_idx, gt_rgb=None, gt_depth=None,
                         gt_normal=None):
