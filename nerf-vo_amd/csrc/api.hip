@@ -464,6 +464,7 @@ struct MlpModule : nvo_module_s {
 struct NwieModule : nvo_module_s {
     std::unique_ptr<GridModule> enc;
     std::unique_ptr<MlpModule> net;
+    int compact_out = 0;  // option "compact_output": output / dL_doutput are [B] halfs (column 0 only)
 
     uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
     uint64_t ctx_bytes(uint32_t B) const override {
@@ -485,6 +486,7 @@ struct NwieModule : nvo_module_s {
         int rc = nvo_grid_fwd_launch(enc->g, s, B, in, p + net->n_params, encoded, true, nullptr);
         if (rc) return rc;
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
+        a.compact_out = compact_out;
         return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
@@ -497,6 +499,7 @@ struct NwieModule : nvo_module_s {
         const _Float16* p = (const _Float16*)params;
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, (void*)out, hidden);
         a.doutput = (const _Float16*)dout;
+        a.compact_out = compact_out;
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
@@ -515,7 +518,13 @@ struct NwieModule : nvo_module_s {
         }
         return NVO_OK;
     }
-    int set_option(const char* key, int64_t value) override { return enc->set_option(key, value); }
+    int set_option(const char* key, int64_t value) override {
+        if (!strcmp(key, "compact_output")) {
+            compact_out = value != 0;
+            return NVO_OK;
+        }
+        return enc->set_option(key, value);
+    }
 };
 
 int create_encoding_impl(uint32_t n_input_dims, const char* json, std::unique_ptr<nvo_module_s>* out,

@@ -222,7 +222,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU>
+// COMPACT: only output column 0 exists in memory ([B] halfs instead of [B][OUT_PAD]): the density networks of
+// the proposal sampler produce one number per sample, and a 32-byte row per sample costs 16x the traffic in
+// this kernel, in the per-ray kernels that read it with a 32-byte stride, and again in the backward.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT>
 __global__ void __launch_bounds__(kMlpBlock)
 k_mlp_fwd(NvoMlpArgs a) {
     // hidden activation: compile-time ReLU (every network on the NeRF-VO path) or the run-time switch
@@ -287,10 +290,15 @@ k_mlp_fwd(NvoMlpArgs a) {
         }
         f4 o[OUT_PAD / 16];
         layer_mm<OUT_PAD, WIDTH>(wl, h, o);
-        _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+        if constexpr (COMPACT) {
+            const h4 v = pack_act(a.out_act, o[0]);
+            if (g == 0) a.output[row] = v[0];  // 16 lanes -> 32 contiguous bytes per tile
+        } else {
+            _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
 #pragma unroll
-        for (int t = 0; t < OUT_PAD / 16; ++t)
-            *reinterpret_cast<h4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
+            for (int t = 0; t < OUT_PAD / 16; ++t)
+                *reinterpret_cast<h4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
+        }
 #pragma unroll
         for (int t = 0; t < IN_PAD / 16; ++t) x[t] = xn[t];
     }
@@ -382,7 +390,7 @@ struct DwAcc {
     }
 };
 
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU>
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT>
 __global__ void __launch_bounds__(kMlpBlock)
 k_mlp_bwd(NvoMlpArgs a) {
     const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
@@ -450,12 +458,26 @@ k_mlp_bwd(NvoMlpArgs a) {
         if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
             if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
         }
-        const _Float16* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
-        const _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+        if constexpr (COMPACT) {
+            const _Float16 z = (_Float16)0.f;
+            const _Float16 dv = a.doutput[row], ov = a.output[row];  // every lane group reads, g == 0 keeps
 #pragma unroll
-        for (int i = 0; i < OUT_PAD / 16; ++i) {
-            t.dzl[i] = *reinterpret_cast<const h4*>(dp + 16 * i);
-            t.out[i] = *reinterpret_cast<const h4*>(op + 16 * i);
+            for (int i = 0; i < OUT_PAD / 16; ++i) {
+                t.dzl[i] = h4{z, z, z, z};
+                t.out[i] = h4{z, z, z, z};
+            }
+            if (g == 0) {
+                t.dzl[0][0] = dv;
+                t.out[0][0] = ov;
+            }
+        } else {
+            const _Float16* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
+            const _Float16* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+            for (int i = 0; i < OUT_PAD / 16; ++i) {
+                t.dzl[i] = *reinterpret_cast<const h4*>(dp + 16 * i);
+                t.out[i] = *reinterpret_cast<const h4*>(op + 16 * i);
+            }
         }
 #pragma unroll
         for (int l = 0; l < N_HIDDEN; ++l) {
@@ -669,10 +691,21 @@ int launch_fwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) 
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
+    if (a.compact_out) {
+        if constexpr (IO == NVO_IO_HALF2_SOA && OUT_PAD == 16) {
+            if (a.act == NVO_ACT_RELU) {
+                NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                NVO_CHECK_LAUNCH();
+                return NVO_OK;
+            }
+        }
+        nvo_set_error("mlp: compact (column 0) output needs the level-major half2 input layout and ReLU");
+        return NVO_ERR_UNSUPPORTED;
+    }
     if (a.act == NVO_ACT_RELU) {
-        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
     } else {
-        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+        NVO_LAUNCH((k_mlp_fwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -706,10 +739,21 @@ int launch_bwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) 
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
+    if (a.compact_out) {
+        if constexpr (IO == NVO_IO_HALF2_SOA && OUT_PAD == 16) {
+            if (a.act == NVO_ACT_RELU) {
+                NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                NVO_CHECK_LAUNCH();
+                return NVO_OK;
+            }
+        }
+        nvo_set_error("mlp: compact (column 0) output needs the level-major half2 input layout and ReLU");
+        return NVO_ERR_UNSUPPORTED;
+    }
     if (a.act == NVO_ACT_RELU) {
-        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
     } else {
-        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+        NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -98,11 +98,12 @@ struct NvoMlpArgs {
     int in_mode;
     const void* input;
     const _Float16* weights;  // layer-major, each [out][in] row-major
-    _Float16* output;         // [B][OUT_PAD]
+    _Float16* output;         // [B][OUT_PAD]   (compact_out: [B], column 0 only)
+    int compact_out;          // 1: output / doutput hold column 0 only (level-major half2 input, ReLU nets)
     _Float16* hidden;         // [N_HIDDEN][B][WIDTH] or nullptr (inference)
     int act, out_act;
     // backward only
-    const _Float16* doutput;  // [B][OUT_PAD], loss-scaled
+    const _Float16* doutput;  // [B][OUT_PAD], loss-scaled   (compact_out: [B])
     void* dinput;             // layout din_mode, nullable
     int din_mode;
     float* dweights;          // fp32, same order as weights, accumulated with atomics (pre-zeroed)

@@ -128,6 +128,8 @@ class NerfactoEngine:
                     "n_neurons": cfg.hidden_dim, "n_hidden_layers": 1}
         self.base_net = _create("nvo_create_network_with_input_encoding", 3, 1 + cfg.geo_feat_dim,
                                 json.dumps(cfg.main_grid.tcnn_dict()).encode(), json.dumps(base_cfg).encode())
+        for m in self.prop_nets:  # one density per sample: [N] halfs instead of [N][16] rows
+            m.set_option("compact_output", 1)
         modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
@@ -251,11 +253,12 @@ class NerfactoEngine:
             ws[f"sbins{k}"] = torch.empty(R, S + 1, **f32)
             ws[f"tbins{k}"] = torch.empty(R, S + 1, **f32)
             ws[f"x{k}"] = torch.empty(N, 3, **f32)
-            ws[f"out{k}"] = torch.empty(N, 16, **f16)
+            compact = k < len(self.prop_nets)  # proposal density nets: column 0 only
+            ws[f"out{k}"] = torch.empty(N, **f16) if compact else torch.empty(N, 16, **f16)
             ws[f"ctx{k}"] = torch.empty(net.ctx_bytes(N), dtype=torch.uint8, device=dev)
             ws[f"weights{k}"] = torch.empty(N, **f32)
             if training:
-                ws[f"dout{k}"] = torch.empty(N, 16, **f16)
+                ws[f"dout{k}"] = torch.empty(N, **f16) if compact else torch.empty(N, 16, **f16)
                 if self.cfg.optimize_poses:
                     ws[f"dx{k}"] = torch.empty(N, 3, **f32)
         if training and self.cfg.optimize_poses:
@@ -306,7 +309,8 @@ class NerfactoEngine:
         R, S = ws["R"], self.levels[k]
         S_out = self.levels[k + 1] if resample else 0
         a = _lib.WeightsPdfArgs(
-            R=R, S=S, S_out=S_out, pre=ws[f"out{k}"].data_ptr(), pre_stride=16, x01=ws[f"x{k}"].data_ptr(),
+            R=R, S=S, S_out=S_out, pre=ws[f"out{k}"].data_ptr(), pre_stride=1 if ws[f"out{k}"].dim() == 1 else 16,
+            x01=ws[f"x{k}"].data_ptr(),
             sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(), density_bias=cfg.density_bias,
             sigma=None, weights=ws[f"weights{k}"].data_ptr(), anneal=anneal,
             histogram_padding=cfg.histogram_padding, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
@@ -504,14 +508,14 @@ class NerfactoEngine:
             if levels is not None and k not in levels:
                 continue
             pa = _lib.PropLossArgs(
-                R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=16,
+                R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=1,
                 x01=ws[f"x{k}"].data_ptr(), sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(),
                 sbins_main=ws[f"sbins{km}"].data_ptr(), weights_main=ws[f"weights{km}"].data_ptr(),
                 density_bias=cfg.density_bias, gt_depth=ws["gt_depth"].data_ptr() if has_depth else None,
                 directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
                 depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
                 inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
-                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=16)
+                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=1)
             _call("nvo_prop_loss", stream, C.byref(pa))
             _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
                   self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
