@@ -465,6 +465,7 @@ struct NwieModule : nvo_module_s {
     std::unique_ptr<GridModule> enc;
     std::unique_ptr<MlpModule> net;
     int compact_out = 0;  // option "compact_output": output / dL_doutput are [B] halfs (column 0 only)
+    int recompute_hidden = 0;  // option "recompute_hidden": the forward does not store the hidden layer
 
     uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
     uint64_t ctx_bytes(uint32_t B) const override {
@@ -487,6 +488,7 @@ struct NwieModule : nvo_module_s {
         if (rc) return rc;
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
         a.compact_out = compact_out;
+        if (recompute_hidden) a.hidden = nullptr;
         return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
@@ -500,6 +502,7 @@ struct NwieModule : nvo_module_s {
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, (void*)out, hidden);
         a.doutput = (const _Float16*)dout;
         a.compact_out = compact_out;
+        a.recompute_hidden = recompute_hidden;
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
@@ -521,6 +524,12 @@ struct NwieModule : nvo_module_s {
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "compact_output")) {
             compact_out = value != 0;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "recompute_hidden")) {
+            NVO_REQUIRE(value == 0 || (net->n_hidden == 1 && net->act == NVO_ACT_RELU),
+                        "recompute_hidden needs a single hidden layer with ReLU");
+            recompute_hidden = value != 0;
             return NVO_OK;
         }
         return enc->set_option(key, value);

@@ -100,6 +100,7 @@ struct NvoMlpArgs {
     const _Float16* weights;  // layer-major, each [out][in] row-major
     _Float16* output;         // [B][OUT_PAD]   (compact_out: [B], column 0 only)
     int compact_out;          // 1: output / doutput hold column 0 only (level-major half2 input, ReLU nets)
+    int recompute_hidden;     // 1 (backward): `hidden` is not read, the single hidden layer is recomputed
     _Float16* hidden;         // [N_HIDDEN][B][WIDTH] or nullptr (inference)
     int act, out_act;
     // backward only

@@ -130,6 +130,8 @@ class NerfactoEngine:
                                 json.dumps(cfg.main_grid.tcnn_dict()).encode(), json.dumps(base_cfg).encode())
         for m in self.prop_nets:  # one density per sample: [N] halfs instead of [N][16] rows
             m.set_option("compact_output", 1)
+        for m in (*self.prop_nets, self.base_net):  # single hidden layer: recomputed in the backward, never stored
+            m.set_option("recompute_hidden", 1)
         modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
