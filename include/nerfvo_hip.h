@@ -271,7 +271,9 @@ typedef struct nvo_color_args {
     const int32_t* cam_idx;      /* [R] or NULL -> embedding row 0 for every ray (eval: mean row) */
     const void* weights;         /* fp16 colour MLP weights: [64][64], [64][64], [16][64] */
     void* rgb;                   /* fp16 [R*S][16], sigmoid rgb in cols 0..2 */
-    void* hidden;                /* fp16 [2][R*S][64]; NULL for inference */
+    void* hidden;                /* fp16 [2][R*S][64] or NULL: with NULL the forward stores no activations and the
+                                    backward recomputes both hidden layers (bit-identical; 256 B/sample less traffic
+                                    each way) */
     /* backward only */
     const void* drgb;            /* fp16 [R*S][16] (loss-scaled) */
     void* d_base_out;            /* fp16 [R*S][16]: cols 1..15 written */

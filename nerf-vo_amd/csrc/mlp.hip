@@ -397,7 +397,7 @@ struct DwAcc {
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP>
 __global__ void __launch_bounds__(kMlpBlock)
 k_mlp_bwd(NvoMlpArgs a) {
-    static_assert(!RECOMP || (N_HIDDEN == 1 && RELU), "hidden recomputation: one hidden layer, ReLU");
+    static_assert(!RECOMP || RELU, "hidden recomputation: ReLU networks");
     const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
     constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
                                          : (IN_PAD > OUT_PAD ? IN_PAD : OUT_PAD));
@@ -434,8 +434,13 @@ k_mlp_bwd(NvoMlpArgs a) {
         wtl.load_lds(W, stage, lane);
         __syncthreads();
     }
-    WFrag<WIDTH, IN_PAD> w0f;  // forward weights of the first layer (hidden recomputation only)
-    if constexpr (RECOMP) w0f.load(a.weights, lane);
+    WFrag<WIDTH, IN_PAD> w0f;  // forward weights (hidden recomputation only)
+    WFrag<WIDTH, WIDTH> whf[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    if constexpr (RECOMP) {
+        w0f.load(a.weights, lane);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load(a.weights + WIDTH * IN_PAD + l * WIDTH * WIDTH, lane);
+    }
     DwAcc<WIDTH, IN_PAD> dw0;
     DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
     DwAcc<OUT_PAD, WIDTH> dwl;
@@ -518,15 +523,20 @@ k_mlp_bwd(NvoMlpArgs a) {
         }
         // last hidden activation H_{N_HIDDEN-1}
         h4 h[WIDTH / 16];
-        if constexpr (RECOMP) {
+        if constexpr (RECOMP) {  // forward chain again: identical MFMA order and fp16 rounding
             f4 hacc[WIDTH / 16];
             layer_mm<WIDTH, IN_PAD>(w0f, cur.x, hacc);
 #pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(NVO_ACT_RELU, hacc[t]);
-        } else {
+            for (int t = 0; t < WIDTH / 16; ++t) cur.hs[0][t] = pack_act(NVO_ACT_RELU, hacc[t]);
 #pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
+            for (int l = 1; l < N_HIDDEN; ++l) {
+                layer_mm<WIDTH, WIDTH>(whf[l - 1], cur.hs[l - 1], hacc);
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) cur.hs[l][t] = pack_act(NVO_ACT_RELU, hacc[t]);
+            }
         }
+#pragma unroll
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
         // dW_last += dZ_L^T H
         {
 #pragma unroll
@@ -756,19 +766,26 @@ int launch_bwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) 
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
     if (a.compact_out || a.recompute_hidden) {
-        if constexpr (IO == NVO_IO_HALF2_SOA && OUT_PAD == 16) {
-            if (a.act == NVO_ACT_RELU) {
-                if constexpr (N_HIDDEN == 1) {
-                    if (a.recompute_hidden) {
-                        if (a.compact_out) {
-                            NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
-                        } else {
-                            NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
-                        }
-                        NVO_CHECK_LAUNCH();
-                        return NVO_OK;
-                    }
+        // instantiated where the NeRF-VO path uses them: level-major input (networks behind a hash grid; compact
+        // only there, recomputation for their single-hidden-layer shapes) and the fused colour head
+        constexpr bool kSoa = IO == NVO_IO_HALF2_SOA && OUT_PAD == 16;
+        constexpr bool kRecompOk = (kSoa && N_HIDDEN == 1) || IO == NVO_IO_NERFACTO_COLOR;
+        if (a.act == NVO_ACT_RELU) {
+            if constexpr (kRecompOk) {
+                if (a.recompute_hidden && !a.compact_out) {
+                    NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                    NVO_CHECK_LAUNCH();
+                    return NVO_OK;
                 }
+            }
+            if constexpr (kSoa && N_HIDDEN == 1) {
+                if (a.recompute_hidden && a.compact_out) {
+                    NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                    NVO_CHECK_LAUNCH();
+                    return NVO_OK;
+                }
+            }
+            if constexpr (kSoa) {
                 if (a.compact_out && !a.recompute_hidden) {
                     NVO_LAUNCH((k_mlp_bwd<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
                     NVO_CHECK_LAUNCH();
@@ -776,8 +793,7 @@ int launch_bwd_io(const NvoMlpArgs& a, hipStream_t stream, uint32_t max_blocks) 
                 }
             }
         }
-        nvo_set_error("mlp: compact output / hidden recomputation need the level-major half2 input layout, ReLU and "
-                      "(for recomputation) a single hidden layer");
+        nvo_set_error("mlp: compact output / hidden recomputation are not available for this shape, layout or activation");
         return NVO_ERR_UNSUPPORTED;
     }
     if (a.act == NVO_ACT_RELU) {
@@ -965,7 +981,7 @@ int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
     NVO_REQUIRE(args != nullptr, "color_bwd: args is NULL");
     const nvo_color_args c = *args;
-    NVO_REQUIRE(c.S >= 1 && c.sh && c.base_out && c.embedding && c.weights && c.rgb && c.hidden && c.drgb &&
+    NVO_REQUIRE(c.S >= 1 && c.sh && c.base_out && c.embedding && c.weights && c.rgb && c.drgb &&
                 c.d_base_out, "color_bwd: NULL argument");
     NvoMlpArgs a = color_args(c);
     a.doutput = (const _Float16*)c.drgb;
@@ -975,6 +991,7 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
     a.d_embedding = c.d_embedding;
     a.d_sh = c.d_sh;
     a.dweights = c.d_weights;
+    a.recompute_hidden = c.hidden == nullptr;  // no stored activations: both hidden layers are recomputed
     return nvo_mlp_bwd_launch(64, 64, 2, 16, a, (hipStream_t)stream);
 }
 

@@ -272,7 +272,7 @@ class NerfactoEngine:
         Nm = R * self.levels[-1]
         ws["rgb"] = torch.empty(Nm, 16, **f16)
         if training:
-            ws["color_hidden"] = torch.empty(2, Nm, 64, **f16)
+            # colour head: no stored hidden activations (recomputed in the backward)
             ws["drgb"] = torch.empty(Nm, 16, **f16)
         self._ws = ws
         return ws
@@ -351,7 +351,7 @@ class NerfactoEngine:
             R=ws["R"], S=self.levels[-1], sh=ws["sh"].data_ptr(), base_out=ws[f"out{km}"].data_ptr(),
             embedding=embedding_ptr, cam_idx=None if cam_idx is None else cam_idx.data_ptr(),
             weights=self._param_ptr("field.color", self.params_half).value, rgb=ws["rgb"].data_ptr(),
-            hidden=ws["color_hidden"].data_ptr() if training else None,
+            hidden=None,
             drgb=ws["drgb"].data_ptr() if training else None,
             d_base_out=ws[f"dout{km}"].data_ptr() if training else None,
             d_embedding=self._param_ptr("field.embedding", self.grads).value if training else None,
