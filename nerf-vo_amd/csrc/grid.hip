@@ -641,11 +641,18 @@ k_st_count(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* 
     {
         if (live) {
             const Corner c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
+            // the two x corners of a (y, z) pair almost always share a bin (hashed levels: x only touches the
+            // index bits below the bin bits; dense levels: neighbouring entries): one LDS atomic for both
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                const uint32_t idx = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
-                                                    c.pz + ((k >> 2) & 1u));
-                atomicAdd(&hist[idx / kBinSlice], 1u);
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t b0 = nvo_grid_index(hashed, size, res, c.px, c.py + (j & 1u), c.pz + (j >> 1)) / kBinSlice;
+                const uint32_t b1 = nvo_grid_index(hashed, size, res, c.px + 1u, c.py + (j & 1u), c.pz + (j >> 1)) / kBinSlice;
+                if (b0 == b1) {
+                    atomicAdd(&hist[b0], 2u);
+                } else {
+                    atomicAdd(&hist[b0], 1u);
+                    atomicAdd(&hist[b1], 1u);
+                }
             }
         }
     }
@@ -766,10 +773,21 @@ k_st_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
         if (live) {
             c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
+            for (uint32_t k = 0; k < 8; ++k)
                 idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
                                         c.pz + ((k >> 2) & 1u));
-                slot[k] = atomicAdd(&hist[idx[k] / kBinSlice], 1u);  // rank inside (tile, bin)
+            // rank inside (tile, bin); one LDS atomic per x-corner pair when both corners share the bin
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t b0 = idx[2 * j] / kBinSlice, b1 = idx[2 * j + 1] / kBinSlice;
+                if (b0 == b1) {
+                    const uint32_t r0 = atomicAdd(&hist[b0], 2u);
+                    slot[2 * j] = r0;
+                    slot[2 * j + 1] = r0 + 1u;
+                } else {
+                    slot[2 * j] = atomicAdd(&hist[b0], 1u);
+                    slot[2 * j + 1] = atomicAdd(&hist[b1], 1u);
+                }
             }
         }
     }
