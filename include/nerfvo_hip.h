@@ -359,6 +359,13 @@ typedef struct nvo_ngp_loss_args {
 } nvo_ngp_loss_args;
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);
+/* Extrinsics optimisation of the occupancy-grid back-end (`optimize_extrinsics = True`,
+ * /root/reference/nerf_vo/mapping/instant_ngp.py:47): dL/dx01 [capacity][3] of the packed samples (from
+ * nvo_bwd's dL_dinput) -> per-ray dL/dorigin, dL/ddirection [R][3] (overwritten), which nvo_pose_bwd /
+ * nvo_se3_exp_map_bwd turn into the camera-offset gradient. */
+int nvo_ngp_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t capacity, const int32_t* counts,
+                          const int32_t* offsets, const float* t, const float* origins, const float* directions,
+                          float aabb_lo, float aabb_hi, const float* dx01, float* d_origin, float* d_dir);
 int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args);
 int nvo_ngp_thickness(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride, int level,
                       float* out);

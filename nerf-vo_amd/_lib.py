@@ -123,6 +123,7 @@ _SIGNATURES = {
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
+    "nvo_ngp_positions_bwd": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "nvo_ngp_rgb_fwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
     "nvo_ngp_rgb_bwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
     "nvo_ngp_composite_loss": (_int, [_p, C.POINTER(NgpLossArgs)]),

@@ -48,6 +48,53 @@ k_ngp_positions(uint32_t capacity, const int32_t* __restrict__ ray_idx, const fl
     for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = p[k];
 }
 
+// Backward of k_ngp_positions for the extrinsics optimiser: dL/dx01 of the packed samples -> per-ray
+// dL/dorigin and dL/ddirection (x01 = clamp((o + t d - lo) / size, 0, 1): the clamp passes the gradient
+// strictly inside the box).  One wave per ray over its packed range [offsets[r], offsets[r] + counts[r]).
+__global__ void __launch_bounds__(256)
+k_ngp_positions_bwd(uint32_t R, uint32_t capacity, const int32_t* __restrict__ counts,
+                    const int32_t* __restrict__ offsets, const float* __restrict__ t,
+                    const float* __restrict__ origins, const float* __restrict__ directions, float aabb_lo,
+                    float aabb_inv_size, const float* __restrict__ dx01, float* __restrict__ d_origin,
+                    float* __restrict__ d_dir) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const uint32_t off = (uint32_t)offsets[r];
+    uint32_t n = (uint32_t)counts[r];
+    if (off >= capacity) n = 0;
+    else if (off + n > capacity) n = capacity - off;  // samples beyond the packed capacity were dropped
+    const float o[3] = {origins[3 * (size_t)r], origins[3 * (size_t)r + 1], origins[3 * (size_t)r + 2]};
+    const float d[3] = {directions[3 * (size_t)r], directions[3 * (size_t)r + 1], directions[3 * (size_t)r + 2]};
+    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+    for (uint32_t s = lane; s < n; s += 64) {
+        const float ts = t[off + s];
+        const float* gx = dx01 + 3 * (size_t)(off + s);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = (o[k] + d[k] * ts - aabb_lo) * aabb_inv_size;
+            const float g = (x > 0.f && x < 1.f) ? gx[k] * aabb_inv_size : 0.f;
+            go[k] += g;
+            gd[k] += g * ts;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            go[k] += __shfl_xor(go[k], sh, 64);
+            gd[k] += __shfl_xor(gd[k], sh, 64);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d_origin[3 * (size_t)r + k] = go[k];
+            d_dir[3 * (size_t)r + k] = gd[k];
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -232,6 +279,20 @@ int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray
     NVO_PROF(stream, "ngp_positions");
     NVO_LAUNCH(k_ngp_positions, dim3(nvo_div_up(capacity, 256)), dim3(256), 0, (hipStream_t)stream, capacity, ray_idx,
                t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ngp_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t capacity, const int32_t* counts,
+                          const int32_t* offsets, const float* t, const float* origins, const float* directions,
+                          float aabb_lo, float aabb_hi, const float* dx01, float* d_origin, float* d_dir) {
+    NVO_REQUIRE(R == 0 || (counts && offsets && t && origins && directions && dx01 && d_origin && d_dir),
+                "ngp_positions_bwd: NULL argument");
+    NVO_REQUIRE(aabb_hi > aabb_lo, "ngp_positions_bwd: empty box");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "ngp_positions_bwd");
+    NVO_LAUNCH(k_ngp_positions_bwd, dim3(nvo_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, R, capacity, counts,
+               offsets, t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), dx01, d_origin, d_dir);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -51,6 +51,13 @@ class NgpConfig:
     adam_eps: float = 1e-15
     l2_reg: float = 1e-6                  # on MLP weights only
     random_background: bool = False
+    # training.optimize_extrinsics = True (/root/reference/nerf_vo/mapping/instant_ngp.py:47): per-image pose
+    # offsets (rotation vector + translation, applied like nerfstudio's SO3xR3 camera optimiser) trained from
+    # the position gradients of the packed samples.  Learning rate / L2 pull toward zero follow instant-ngp's
+    # defaults (extrinsic_learning_rate 1e-3, extrinsic_l2_reg 1e-4) [UPSTREAM, unpinned].
+    optimize_extrinsics: bool = True
+    extrinsic_lr: float = 1e-3
+    extrinsic_l2_reg: float = 1e-4
     seed: int = 1337
 
     @property
@@ -98,6 +105,14 @@ class NgpEngine:
         self.step = 0
         self.opt_step = 0
         self._ws = None
+        # camera offsets [F][6] = (translation, rotation vector) and their optimiser state
+        F6 = cfg.num_images * 6
+        self.pose_adjustment, self.pose_grads = z(F6), z(F6)
+        self.pose_exp_avg, self.pose_exp_avg_sq = z(F6), z(F6)
+        self._pose_half = z(F6, torch.float16)  # the fused Adam always writes a half copy
+        self.corrections = z(cfg.num_images * 12)
+        self.d_corrections = z(cfg.num_images * 12)
+        self._pose_inputs = None
         self.init_params(cfg.seed)
 
     # ---- parameters --------------------------------------------------------------------------
@@ -146,6 +161,11 @@ class NgpEngine:
             ws["rgb_hidden"] = torch.zeros(2, cap, 64, **f16)
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
             ws["d_density_out"] = torch.zeros(cap, 16, **f16)
+            if self.cfg.optimize_extrinsics:
+                ws["dx01"] = torch.zeros(cap, 3, **f32)
+                ws["d_origin"] = torch.zeros(R, 3, **f32)
+                ws["d_dir"] = torch.zeros(R, 3, **f32)
+                ws["ray_indices"] = torch.zeros(R, 3, dtype=torch.int64, device=dev)
         self._ws = ws
         return ws
 
@@ -180,7 +200,14 @@ class NgpEngine:
         stream = _stream(self.device)
         R = ws["R"]
         H, W = images.shape[1], images.shape[2]
-        _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), None, _ptr(ws["origins"]),
+        corr = None
+        self._pose_inputs = None
+        if self.cfg.optimize_extrinsics and "ray_indices" in ws:
+            _call("nvo_pose_exp_map", stream, self.cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.corrections), 1)
+            corr = self.corrections
+            ws["ray_indices"].copy_(ray_indices)
+            self._pose_inputs = (intrinsics, c2w)
+        _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corr), _ptr(ws["origins"]),
               _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]))
         _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
         if depths is not None:
@@ -240,8 +267,31 @@ class NgpEngine:
         _call("nvo_ngp_composite_loss", stream, C.byref(la))
         ra = self._rgb_args(ws, True)
         _call("nvo_ngp_rgb_bwd", stream, C.byref(ra))
+        pose = self.cfg.optimize_extrinsics and self._pose_inputs is not None and "dx01" in ws
         _call("nvo_bwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
-              _ptr(ws["density_out"]), _ptr(ws["d_density_out"]), _ptr(ws["ctx"]), None, self._pp("density", self.grads))
+              _ptr(ws["density_out"]), _ptr(ws["d_density_out"]), _ptr(ws["ctx"]), _ptr(ws["dx01"]) if pose else None,
+              self._pp("density", self.grads))
+        if pose:
+            self._pose_backward(ws, stream)
+
+    def _pose_backward(self, ws, stream) -> None:
+        """Position gradients of the packed samples -> per-ray dL/do, dL/dd -> per-camera correction gradient ->
+        dL/d(offset) (+ the L2 pull toward zero); the direction-encoding path is not differentiated (instant-ngp
+        trains the extrinsics from the position gradient alone)."""
+        cfg = self.cfg
+        lo, hi = cfg.aabb
+        R = ws["R"]
+        _call("nvo_ngp_positions_bwd", stream, R, cfg.capacity, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["t"]),
+              _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["dx01"]), _ptr(ws["d_origin"]),
+              _ptr(ws["d_dir"]))
+        self.d_corrections.zero_()
+        intr, c2w = self._pose_inputs
+        _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+              _ptr(ws["d_dir"]), None, _ptr(self.d_corrections))
+        self.pose_grads.zero_()
+        _call("nvo_se3_exp_map_bwd", stream, cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.d_corrections),
+              cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, cfg.loss_scale / self.world_size, _ptr(self.pose_grads),
+              C.c_void_p(self.losses.data_ptr() + 5 * 4), 1)
 
     def optimizer_step(self) -> None:
         cfg = self.cfg
@@ -257,6 +307,11 @@ class NgpEngine:
                   C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
                   cfg.lr, cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, wd,
                   _ptr(self.skip_flag), None)
+        if cfg.optimize_extrinsics and self._pose_inputs is not None:
+            n6 = cfg.num_images * 6
+            _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
+                  _ptr(self.pose_exp_avg), _ptr(self.pose_exp_avg_sq), cfg.extrinsic_lr, cfg.adam_betas[0],
+                  cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), None)
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, all_reduce=None):
         R = ray_indices.shape[0]
@@ -269,12 +324,25 @@ class NgpEngine:
         self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg)
         if all_reduce is not None:
             all_reduce(self.grads)
+            if self.cfg.optimize_extrinsics and self._pose_inputs is not None:
+                all_reduce(self.pose_grads)
         self.optimizer_step()
         self.step += 1
 
+    @torch.no_grad()
+    def camera_corrections(self) -> torch.Tensor:
+        """[F,3,4] pose corrections (rotation | translation) the extrinsics optimiser has learnt so far
+        (counterpart of instant-ngp's nerf.training.get_camera_extrinsics offsets)."""
+        _call("nvo_pose_exp_map", _stream(self.device), self.cfg.num_images, _ptr(self.pose_adjustment),
+              _ptr(self.corrections), 1)
+        return self.corrections.view(self.cfg.num_images, 3, 4).clone()
+
     def loss_dict(self) -> dict:
         vals = self.losses.sum(dim=0).tolist()
-        return {"rgb_loss": vals[0], "depth_loss": vals[1]}
+        d = {"rgb_loss": vals[0], "depth_loss": vals[1]}
+        if self.cfg.optimize_extrinsics and vals[5] != 0.0:
+            d["extrinsic_regularizer"] = vals[5]
+        return d
 
     def samples_last_step(self) -> int:
         ws = self._ws

@@ -36,8 +36,10 @@ class NgpOracle:
         return O.march_rays(origins.float().numpy(), directions.float().numpy(), bitfield, self.n_levels,
                             self.cone_angle, self.near, np.zeros(len(origins)) if jitter is None else jitter.numpy())
 
-    def forward(self, origins, directions, counts, t, dt, background=None):
-        """Packed forward for the samples found by march().  Returns per-ray rgb, depth, accumulation."""
+    def forward(self, origins, directions, counts, t, dt, background=None, sh_directions=None):
+        """Packed forward for the samples found by march().  Returns per-ray rgb, depth, accumulation.
+        ``sh_directions``: directions used for the SH encoding (default: ``directions``); the extrinsics
+        optimiser differentiates the sample positions only, its test passes a detached copy here."""
         P = self.params
         R = origins.shape[0]
         ray_idx = np.repeat(np.arange(R), counts.astype(np.int64))
@@ -50,7 +52,7 @@ class NgpOracle:
         enc = G.grid_encode(self.spec, x01, P["grid"], quantize_output=self.emulate_fp16)
         dws = M.split_weights(P["density_mlp"], 32, 16, 64, 1)
         dens_out = M.mlp_forward(enc, dws, "ReLU", "None", pad_value=0.0, emulate_fp16=self.emulate_fp16)
-        sh = S.sh_encode((directions + 1.0) / 2.0, 4)
+        sh = S.sh_encode(((directions if sh_directions is None else sh_directions) + 1.0) / 2.0, 4)
         if self.emulate_fp16:
             sh = _q16(sh)
         rin = torch.cat([dens_out, sh[ri]], dim=-1)

@@ -103,6 +103,70 @@ def test_ngp_step_matches_oracle(device):
     _assert_close(gr[nd:nden], orc.params["grid"].grad.reshape(-1), what="d hash grid", **tol)
 
 
+def test_ngp_extrinsics_gradient_matches_oracle(device):
+    """optimize_extrinsics (reference: nerf_vo/mapping/instant_ngp.py:47): dL/d(camera offset) through the
+    packed samples' positions vs autograd in the oracle (positions only: the SH directions are detached, as
+    the kernel path does).  Tolerance as the nerfacto pose-gradient test: the chain passes through fp16
+    d(encoded) buffers: rtol 5e-2, atol 3e-2 * max|ref|."""
+    from oracle import occgrid as O
+    from oracle import rays as Rr
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    eng = _engine(device, extrinsic_l2_reg=0.0)
+    rng = np.random.default_rng(3)
+    grid = (rng.random((eng.cfg.n_levels, O.CELLS), dtype=np.float32) ** 8) * 0.05
+    eng.density_grid.copy_(torch.from_numpy(grid.reshape(-1)).to(device))
+    _call("nvo_occ_update", _stream(device), eng.cfg.n_levels, _ptr(eng.density_grid), None, 0.95, 0.01,
+          _ptr(eng.bitfield), _ptr(eng._scratch8))
+    bf = eng.bitfield.cpu().numpy().reshape(eng.cfg.n_levels, -1)
+
+    F, H, W, R = 4, 24, 32, 96
+    g = torch.Generator().manual_seed(6)
+    pose = torch.randn(F, 6, generator=g) * 0.02
+    pose[2] = 0.0
+    eng.pose_adjustment.copy_(pose.reshape(-1).to(device))
+    intr = torch.tensor([[30.0, 28.0, 15.7, 11.6]]).repeat(F, 1)
+    rot = torch.linalg.qr(torch.randn(F, 3, 3, generator=g))[0]
+    c2w = torch.cat([rot, (torch.rand(F, 3, 1, generator=g) - 0.5) * 0.4 + 0.5], dim=2)
+    idx = torch.stack([torch.randint(0, F, (R,), generator=g), torch.randint(0, H, (R,), generator=g),
+                       torch.randint(0, W, (R,), generator=g)], dim=1)
+    images = torch.rand(F, H, W, 3, generator=g)
+    depths = torch.rand(F, H, W, 1, generator=g) * 0.8
+    jitter = torch.rand(R, generator=g)
+
+    ws = eng._workspace(R, True)
+    eng.load_rays(ws, idx.to(device), intr.to(device), c2w.to(device).contiguous(), images.to(device), depths.to(device))
+    eng.forward_backward(ws, jitter.to(device), has_depth=True, background=None)
+    torch.cuda.synchronize()
+    got = (eng.pose_grads / eng.cfg.loss_scale).view(F, 6).double().cpu()
+
+    orc = _oracle(eng)
+    pose_r = pose.double().requires_grad_(True)
+    ro, rd, rn, _ = Rr.generate_rays(idx, intr.double(), c2w.double())
+    corr = Rr.exp_map_so3xr3(pose_r)[idx[:, 0]]
+    ro2, rd2 = Rr.apply_pose_correction(ro, rd, corr)
+    _assert_close(ws["origins"], ro2.detach(), rtol=1e-5, atol_scale=1e-6, what="corrected origins")
+    _assert_close(ws["directions"], rd2.detach(), rtol=1e-5, atol_scale=1e-6, what="corrected directions")
+    # the marcher runs on the kernel's fp32 rays (bit-exact packed samples are covered by the test above)
+    o32, d32 = ws["origins"].cpu(), ws["directions"].cpu()
+    counts, t, dt = orc.march(o32, d32, bf, jitter)
+    assert (ws["counts"].cpu().numpy().astype(np.uint32) == counts).all() and counts.sum() > 300
+    rgb, depth, acc = orc.forward(ro2, rd2, counts, t, dt, background=None, sh_directions=rd2.detach())
+    gt_rgb = images[idx[:, 0], idx[:, 1], idx[:, 2]].double()
+    gt_depth = depths[idx[:, 0], idx[:, 1], idx[:, 2], 0].double()
+    ld = orc.loss_dict(rgb, depth, gt_rgb, gt_depth, rn.reshape(-1).detach())
+    sum(ld.values()).backward()
+    ref = pose_r.grad
+    assert ref.abs().max() > 0
+    _assert_close(got, ref, rtol=5e-2, atol_scale=3e-2, what="dL/d(camera offset), occupancy-grid back-end")
+    before = eng.pose_adjustment.clone()
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert not torch.equal(before, eng.pose_adjustment)
+    assert eng.camera_corrections().shape == (F, 3, 4)
+
+
 def test_density_grid_update_and_training(device):
     """update_density_grid() must mark cells from the network's own density; 60 steps on a synthetic
     sequence must reduce the loss and keep the packed batch inside the capacity."""
