@@ -393,6 +393,25 @@ int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* h
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
 
+/* ------------------------------------------------------------------------------------------------
+ * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of
+ *    /root/reference/nerf_vo/enhancement/enhancement_module.py:61-99 and dpvo_remove_outliers :131-146).
+ *    patches: DPVO patches [K][M][3][P][P] = (x/4, y/4, inverse depth); noise [K][M] in [0,1) (the reference's
+ *    torch.rand tie-breaker, drawn by the caller); frames_depth [K][H][W] monocular depth.
+ *    out_depth = clip(frames_depth * scale_k + shift_k, 0, 5); may alias frames_depth.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nvo_depth_align_args {
+    uint32_t K, M, P, H, W;
+    const float* patches;
+    const float* noise;
+    const float* frames_depth;
+    float* out_depth;
+    void* scratch;               /* nvo_depth_align_scratch_bytes(K, M) */
+    float* scale_shift_out;      /* optional [K][2] */
+} nvo_depth_align_args;
+uint64_t nvo_depth_align_scratch_bytes(uint32_t K, uint32_t M);
+int nvo_depth_align(nvo_stream_t stream, const nvo_depth_align_args* args);
+
 #ifdef __cplusplus
 }
 #endif

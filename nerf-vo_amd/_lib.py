@@ -60,6 +60,12 @@ class ColorArgs(C.Structure):
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p)]
 
 
+class DepthAlignArgs(C.Structure):
+    """mirror of nvo_depth_align_args"""
+    _fields_ = [("K", _u32), ("M", _u32), ("P", _u32), ("H", _u32), ("W", _u32), ("patches", _p), ("noise", _p),
+                ("frames_depth", _p), ("out_depth", _p), ("scratch", _p), ("scale_shift_out", _p)]
+
+
 class NgpRgbArgs(C.Structure):
     """mirror of nvo_ngp_rgb_args"""
     _fields_ = [("capacity", _u32), ("sh", _p), ("density_out", _p), ("ray_idx", _p), ("weights", _p), ("rgb_out", _p),
@@ -123,6 +129,8 @@ _SIGNATURES = {
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
+    "nvo_depth_align_scratch_bytes": (_u64, [_u32, _u32]),
+    "nvo_depth_align": (_int, [_p, C.POINTER(DepthAlignArgs)]),
     "nvo_ngp_positions_bwd": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "nvo_ngp_rgb_fwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
     "nvo_ngp_rgb_bwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
