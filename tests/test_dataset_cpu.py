@@ -153,3 +153,45 @@ def test_synthetic_sequence_shapes_and_geometry():
     assert (fx, round(fy, 3), round(cx, 3), round(cy, 3)) == (320.0, 423.529, 319.733, 239.647)
     rot = seq["camera_extrinsics"][:, :3, :3]
     assert torch.allclose(rot @ rot.transpose(1, 2), torch.eye(3).expand(4, 3, 3), atol=1e-5)
+
+
+# ---- host logic pinned by the reference itself (tests/golden/make_golden_host.py imports /root/reference) ----
+def _host_golden():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_golden.json")))
+
+
+def test_mapping_module_cadence_matches_reference():
+    """MappingModule.step (ref: nerf_vo/mapping/mapping_module.py:35-55): which ticks train, which are skipped."""
+    from nerf_vo_amd.mapping.mapping_module import MappingModule
+
+    class Fake:
+        def __init__(self, stop):
+            self.calls, self.is_shut_down, self.stop = [], False, stop
+
+        def __call__(self, input):
+            self.calls.append(input is not None)
+            if len(self.calls) >= self.stop:
+                self.is_shut_down = True
+
+    for case in _host_golden()["cadence"]:
+        mod = MappingModule(Fake(case["shut_down_after"]), case["mapping_iterations"], case["num_keyframes"])
+        rows = []
+        for item in case["schedule"]:
+            inp = None if item == 0 else {"last_frame": item == 2}
+            n = len(mod.method.calls)
+            _, skip = mod.step(inp)
+            rows.append([item, int(len(mod.method.calls) > n), int(skip), int(mod.shutdown)])
+        assert rows == case["rows"]
+
+
+def test_replica_intrinsics_match_reference_scaling():
+    """synthetic.replica_intrinsics vs scale_camera_intrinsics(datasets/replica.json) of the reference
+    (ref: nerf_vo/data/data_utils.py:24-34)."""
+    from nerf_vo_amd.synthetic import replica_intrinsics
+
+    for row in _host_golden()["intrinsics"]:
+        fx, fy, cx, cy = replica_intrinsics(row["height"], row["width"])
+        assert (fx, fy, cx, cy) == (row["fx"], row["fy"], row["cx"], row["cy"])
