@@ -67,6 +67,26 @@ def build():
                "cx": native["cx"], "cy": native["cy"]}
         r = scale_camera_intrinsics(dict(cam), height=h, width=w)
         out["intrinsics"].append({"height": h, "width": w, "fx": r["fx"], "fy": r["fy"], "cx": r["cx"], "cy": r["cy"]})
+    # PSNR: evaluation/evaluation_utils.py cannot be imported (needs cv2), but calculate_psnr (:289-306) is plain
+    # numpy: its definition is executed from the reference file AT GENERATION TIME (nothing is copied into the
+    # repository) and applied per colour channel, which is what calculate_psnr_color (:309-318) does with
+    # cv2.split + the mean of the three values.
+    import ast
+
+    import numpy as np
+    src = open("/root/reference/evaluation/evaluation_utils.py").read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "calculate_psnr")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "evaluation_utils.py", "exec"), ns)
+    rng = np.random.default_rng(5)
+    out["psnr"] = []
+    for shape, spread in (((24, 32, 3), 30), ((17, 9, 3), 3), ((8, 8, 3), 200)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-spread, spread + 1, shape), 0, 255).astype(np.uint8)
+        with np.errstate(over="ignore"):
+            per_channel = [float(ns["calculate_psnr"](a[..., c], b[..., c])) for c in range(3)]
+        out["psnr"].append({"a": a.tolist(), "b": b.tolist(), "per_channel": per_channel,
+                            "color": sum(per_channel) / 3.0})
     return out
 
 

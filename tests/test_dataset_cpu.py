@@ -195,3 +195,17 @@ def test_replica_intrinsics_match_reference_scaling():
     for row in _host_golden()["intrinsics"]:
         fx, fy, cx, cy = replica_intrinsics(row["height"], row["width"])
         assert (fx, fy, cx, cy) == (row["fx"], row["fy"], row["cx"], row["cy"])
+
+
+def test_psnr_reference_definition_matches_reference_function():
+    """calculate_psnr_reference (product) and oracle.rays.psnr_reference vs the reference's own calculate_psnr
+    evaluated per channel (ref: evaluation/evaluation_utils.py:289-318), uint8 wrap-around included."""
+    import numpy as np
+
+    from nerf_vo_amd.mapping.renderer import calculate_psnr_reference
+    from oracle.rays import psnr_reference
+
+    for row in _host_golden()["psnr"]:
+        a, b = np.asarray(row["a"], dtype=np.uint8), np.asarray(row["b"], dtype=np.uint8)
+        assert calculate_psnr_reference(a, b) == pytest.approx(row["color"], rel=1e-12)
+        assert psnr_reference(a, b) == pytest.approx(row["color"], rel=1e-12)
