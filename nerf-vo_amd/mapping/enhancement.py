@@ -50,9 +50,13 @@ class DpvoDepthEnhancement:
     dpvo_patches, last_frame) -> adds frames_depth (+ frames_normal), scales colours to [0,1] and flips the pose
     axes for the nerfstudio mapper (:113-114)."""
 
-    def __init__(self, method, removal_window: int = 28, mapping_module: str = "nerfstudio"):
+    def __init__(self, method, removal_window: int = 28, mapping_module: str = "nerfstudio",
+                 tracking_module: str = "dpvo"):
+        # method=None + tracking_module='droid-slam' is the reference's enhancement 'none' branch (:105-112):
+        # DROID-SLAM's dense inverse depth and its covariance are passed through
         self.method = method
         self.mapping_module = mapping_module
+        self.tracking_module = tracking_module
         n = removal_window - 2  # ref: enhancement_module.py:32-37
         self.buffer_camera_intrinsics = deque(maxlen=n)
         self.buffer_frames_color = deque(maxlen=n)
@@ -68,6 +72,18 @@ class DpvoDepthEnhancement:
         out["camera_intrinsics"] = input["camera_intrinsics"].clone()
         out["camera_extrinsics"] = input["camera_extrinsics"].clone()
         out["frames_color"] = input["frames_color"] / 255.0
+        if self.method is None:
+            if self.tracking_module != "droid-slam":
+                raise NotImplementedError
+            out["frames_depth"] = 1 / out.pop("droid_slam_inverse_depth")[:, None, :, :]
+            out["frames_depth_covariance"] = out.pop("droid_slam_depth_covariance").clone()[:, None, :, :]
+            if self.mapping_module == "nerfstudio":
+                out["camera_extrinsics"][:, :3, 1:3] *= -1
+            if out.get("last_frame", False):
+                self.shutdown = True
+            return out, False
+        if self.tracking_module != "dpvo":
+            raise NotImplementedError
         frames_depth, frames_normal = self.method(frames_color=out["frames_color"].clone())
         if frames_depth is None:
             raise NotImplementedError
