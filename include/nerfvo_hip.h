@@ -148,6 +148,12 @@ int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
 int nvo_sample_lindisp(nvo_stream_t stream, uint32_t R, uint32_t S, float near_plane, float far_plane,
                        const float* jitter, float* sbins, float* tbins);
 
+/* Pixel sampler + sampler jitters of one step (PixelSampler + single_jitter): ray_indices [R][3] int64 uniform in
+ * [0, extent_dev[c]) (extent_dev = device float {active frames, H, W}), jitter [n_jitter][R] uniform in [0,1).
+ * Counter-based: values are a hash of (seed, step_dev[0], element) -- stateless, hipGraph-replay safe. */
+int nvo_sample_pixels(nvo_stream_t stream, uint32_t R, uint32_t seed, const float* step_dev, const float* extent_dev,
+                      int64_t* ray_indices, float* jitter, uint32_t n_jitter);
+
 /* Fused forms (fewer launches per step; identical arithmetic):
  *   nvo_lindisp_positions = nvo_sample_lindisp + nvo_sample_positions of those bins
  *   nvo_gather_targets    = nvo_gather_pixels of colour [F][H][W][3], depth [F][H][W] (nullable) and
@@ -391,6 +397,8 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
 int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* host_values);
 /* *flag = any(!isfinite(grads)) */
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
+/* same check OR-ed into an already initialised flag (several disjoint gradient ranges, one flag) */
+int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
 
 /* ------------------------------------------------------------------------------------------------

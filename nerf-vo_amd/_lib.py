@@ -112,6 +112,7 @@ _SIGNATURES = {
     "nvo_se3_exp_map_bwd": (_int, [_p, _u32, _p, _p, _f, _f, _f, _p, _p, _int]),
     "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
     "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
+    "nvo_sample_pixels": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _u32]),
     "nvo_lindisp_positions": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p, _p, _p, _p]),
     "nvo_gather_targets": (_int, [_p, _u32, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),
@@ -141,6 +142,7 @@ _SIGNATURES = {
     "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),
     "nvo_write_floats": (_int, [_p, _p, _u32, _p]),
     "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _int, _p]),
+    "nvo_nonfinite_flag_or": (_int, [_p, _u64, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
 }
 

@@ -176,10 +176,23 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     return NVO_OK;
 }
 
+static int nonfinite_launch(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag,
+                            bool reset);
+
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag) {
+    return nonfinite_launch(stream, n, grads, grads_are_half, flag, true);
+}
+
+int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag) {
+    return nonfinite_launch(stream, n, grads, grads_are_half, flag, false);
+}
+
+static int nonfinite_launch(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag,
+                            bool reset) {
     NVO_REQUIRE(grads && flag, "nonfinite_flag: NULL argument");
     NVO_PROF(stream, "nonfinite_flag");
-    if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
+    if (reset)
+        if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;

@@ -167,6 +167,36 @@ k_lindisp_positions(uint32_t R, uint32_t S, float near, float far, const float* 
     for (int k = 0; k < 3; ++k) x01[3 * (size_t)i + k] = p[k];
 }
 
+// Pixel sampler + per-ray sampler jitters of one step in one launch (PixelSampler: uniform (camera, y, x);
+// the proposal sampler's single_jitter: one uniform per ray and level).  Counter-based generator: every
+// value is a hash of (seed, step, element), so the kernel is stateless and replays correctly from a
+// hipGraph -- the step counter is read from device memory.  Statistical quality only matters, not the
+// stream: no parity test depends on RNG streams.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float hash_uniform(uint32_t seed, uint32_t step, uint32_t stream, uint32_t i) {
+    const uint32_t h = pcg_hash(pcg_hash(pcg_hash(seed ^ (stream * 0x9E3779B9u)) + step) + i);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_pixels(uint32_t R, uint32_t seed, const float* __restrict__ step_dev, const float* __restrict__ extent,
+                int64_t* __restrict__ ray_indices, float* __restrict__ jitter, uint32_t n_jitter) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const uint32_t step = (uint32_t)step_dev[0];
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const float e = extent[c];
+        const float v = floorf(hash_uniform(seed, step, c, r) * e);
+        ray_indices[3 * (size_t)r + c] = (int64_t)fminf(v, e - 1.f);
+    }
+    for (uint32_t j = 0; j < n_jitter; ++j) jitter[(size_t)j * R + r] = hash_uniform(seed, step, 3u + j, r);
+}
+
 // Fused ray setup: ray generation + gather of the colour / depth / normal targets + the (d + 1) / 2
 // direction-encoding input, one thread per ray.
 __global__ void __launch_bounds__(256)
@@ -306,6 +336,17 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
     NVO_PROF(stream, "sample_positions[S%u]", S);
     NVO_LAUNCH(k_sample_positions, dim3(nvo_div_up((uint64_t)R * S, 256)), dim3(256), 0,
                        (hipStream_t)stream, R, S, origins, directions, tbins, x01);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_sample_pixels(nvo_stream_t stream, uint32_t R, uint32_t seed, const float* step_dev, const float* extent_dev,
+                      int64_t* ray_indices, float* jitter, uint32_t n_jitter) {
+    NVO_REQUIRE(R == 0 || (step_dev && extent_dev && ray_indices && (n_jitter == 0 || jitter)), "sample_pixels: NULL argument");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "sample_pixels");
+    NVO_LAUNCH(k_sample_pixels, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, seed, step_dev,
+               extent_dev, ray_indices, jitter, n_jitter);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -457,7 +457,13 @@ class NerfactoEngine:
             anneal = self.anneal_at(step)
         if update_proposals is None:
             update_proposals = self.proposal_update_due(step)
-        self.grads.zero_()
+        # Only what is ACCUMULATED into needs zeroing (colour-head dW, appearance-embedding gradient): every other
+        # gradient range is overwritten by its producer (grid slices by plain stores, MLP dW zeroed by nvo_bwd,
+        # pose gradient by the exp-map backward).  Ranges of groups that do not train this step keep stale values
+        # and are neither reduced, checked nor applied.
+        for name in ("field.color", "field.embedding"):
+            o, sz, _ = self.segments[name]
+            self.grads[o:o + sz].zero_()
         self.losses.zero_()
         emb_ptr = self._param_ptr("field.embedding", self.params_half).value
         ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev)
@@ -568,7 +574,18 @@ class NerfactoEngine:
         stream = _stream(self.device)
         # grads_half: the fp16 buffer a compressed all-reduce left behind -- consumed directly
         gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (grads_half, 2, 1)
-        _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        # one flag over the gradient ranges of the groups that train this step (ranges of idle groups hold stale
+        # values); adjacent ranges are checked in one launch
+        active = [self.group_ranges[g] for g in groups if g != "camera_opt" or cfg.optimize_poses]
+        merged = []
+        for lo, hi in sorted(active):
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        for i, (lo, hi) in enumerate(merged):
+            _call("nvo_nonfinite_flag" if i == 0 else "nvo_nonfinite_flag_or", stream, hi - lo,
+                  C.c_void_p(gbuf.data_ptr() + lo * gsz), ghalf, _ptr(self.skip_flag))
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:
                 continue
@@ -595,6 +612,7 @@ class NerfactoEngine:
         cfg = self.cfg
         vals = [0.0] * 16
         vals[0] = anneal
+        vals[10] = float(self.step)  # counter of the stateless pixel / jitter sampler
         for gi, g in enumerate(self._GROUP_ORDER):
             if g in groups:
                 self.opt_steps[g] += 1
@@ -655,13 +673,17 @@ class NerfactoEngine:
         c2w = torch.empty(c2w_full.shape[0], 3, 4, device=dev)
         anneal_ptr = self.dev_scalars.data_ptr()
 
+        ray_indices = torch.zeros((R, 3), dtype=torch.int64, device=dev)
+        jit = torch.zeros((3, R), dtype=torch.float32, device=dev)
+        rng_seed = int(torch.initial_seed() & 0xFFFFFFFF)  # follows torch.manual_seed (per rank in multi-GPU runs)
+        step_ptr = C.c_void_p(self.dev_scalars.data_ptr() + 4 * 10)
+
         def body_main():
-            u = torch.rand((R, 3), device=dev)
-            ray_indices = torch.floor(u * scale).long()
+            # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
+            _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
             c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
             self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
                            normals=dataset.world_normals01() if has_normals else None)
-            jit = torch.rand((3, R), device=dev)
             self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
                                   anneal=1.0, anneal_dev=anneal_ptr, has_normals=has_normals)
             if half is not None:  # fp16 copy of the ranges the collective will exchange
