@@ -274,6 +274,7 @@ struct GridModule : nvo_module_s {
     NvoGridSlices slices;
     NvoGridBins bins;
     NvoGridStream stream_bins;
+    NvoGridInputScratch input_scratch;  // per-level partials of the input backward (allocated at first use)
     int bwd_mode = 1;  // 0 global atomics, 1 LDS slice owner (default, fastest), 2 binned hashed levels + slice owner
     bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
 
@@ -281,6 +282,7 @@ struct GridModule : nvo_module_s {
         nvo_grid_slices_destroy(&slices);
         nvo_grid_bins_destroy(&bins);
         nvo_grid_stream_destroy(&stream_bins);
+        if (input_scratch.ptr) (void)hipFree(input_scratch.ptr);
     }
     int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
         int rc = ensure_slices();
@@ -338,7 +340,7 @@ struct GridModule : nvo_module_s {
             if (rc) return rc;
         }
         if (din) {
-            int rc = nvo_grid_bwd_input_launch(g, s, B, in, params, dout, false, soa_out, din, true);
+            int rc = nvo_grid_bwd_input_launch(g, s, B, in, params, dout, false, soa_out, din, true, &input_scratch);
             if (rc) return rc;
         }
         return NVO_OK;
@@ -516,7 +518,7 @@ struct NwieModule : nvo_module_s {
         }
         if (din) {
             rc = nvo_grid_bwd_input_launch(enc->g, s, B, in, p + net->n_params, dencoded, false, true,
-                                           din, true);
+                                           din, true, &enc->input_scratch);
             if (rc) return rc;
         }
         return NVO_OK;

@@ -912,15 +912,18 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
 // ------------------------------------------------------------------------------------------
 // One thread per (sample, level); per-level partials are combined with float atomics into
 // dx[N][3] (16 adds per element, consecutive lanes -> consecutive 12-B rows).
+// partial != nullptr: the per-level contribution is STORED to partial[level][i][3] (summed over the levels by
+// k_sum_levels) instead of being added into dx with float atomics (16 x 3 atomics per sample).
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                  const __half2* __restrict__ table, const DY2* __restrict__ dy,
-                 float* __restrict__ dx) {
+                 float* __restrict__ dx, float* __restrict__ partial) {
     uint32_t tile, level;
     grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
     const uint32_t i = tile * kGridBlock + threadIdx.x;
     if (i >= N) return;
+    float* __restrict__ pout = partial ? partial + 3 * ((size_t)level * N + i) : nullptr;
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
     const uint32_t res = g.resolution[level];
@@ -935,7 +938,10 @@ k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     } else {
         d = *reinterpret_cast<const float2*>(&d2);
     }
-    if (d.x == 0.f && d.y == 0.f) return;
+    if (d.x == 0.f && d.y == 0.f) {
+        if (pout) pout[0] = pout[1] = pout[2] = 0.f;
+        return;
+    }
 
     const Corner c = grid_cell(scale, x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
                                x[3 * (size_t)i + 2]);
@@ -955,9 +961,25 @@ k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                               wx0 * c.wz * (s[6] - s[4]) + c.wx * c.wz * (s[7] - s[5]));
     const float gz = scale * (wx0 * wy0 * (s[4] - s[0]) + c.wx * wy0 * (s[5] - s[1]) +
                               wx0 * c.wy * (s[6] - s[2]) + c.wx * c.wy * (s[7] - s[3]));
+    if (pout) {
+        pout[0] = gx;
+        pout[1] = gy;
+        pout[2] = gz;
+        return;
+    }
     atomicAdd(dx + 3 * (size_t)i + 0, gx);
     atomicAdd(dx + 3 * (size_t)i + 1, gy);
     atomicAdd(dx + 3 * (size_t)i + 2, gz);
+}
+
+// dx[e] (+)= sum over levels of partial[level][e], e over N * 3 floats
+__global__ void __launch_bounds__(256)
+k_sum_levels(uint32_t n_levels, size_t n, const float* __restrict__ partial, float* __restrict__ dx, int accumulate) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = accumulate ? dx[e] : 0.f;
+    for (uint32_t l = 0; l < n_levels; ++l) s += partial[(size_t)l * n + e];
+    dx[e] = s;
 }
 
 }  // namespace
@@ -1373,22 +1395,37 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
 
 int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
                               const float* x, const void* table_half, const void* dy,
-                              bool dy_is_float, bool soa, float* dx, bool zero_dx) {
+                              bool dy_is_float, bool soa, float* dx, bool zero_dx, NvoGridInputScratch* scratch) {
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "grid_bwd_input[L%u]", g.n_levels);
-    if (zero_dx)
+    float* partial = nullptr;
+    if (scratch) {  // two-stage form: per-level partials + a sum kernel, no float atomics, no zeroing of dx
+        const size_t need = (size_t)g.n_levels * N * 3;
+        if (need > scratch->floats) {  // grows during warm-up only; never while a graph is being captured
+            if (scratch->ptr) NVO_CHECK_HIP(hipFree(scratch->ptr));
+            NVO_CHECK_HIP(hipMalloc((void**)&scratch->ptr, sizeof(float) * need));
+            scratch->floats = need;
+        }
+        partial = scratch->ptr;
+    } else if (zero_dx) {
         if (int rc = nvo_zero_async(dx, sizeof(float) * 3 * (size_t)N, stream)) return rc;
+    }
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_IN(SOA_, T_)                                                               \
     NVO_LAUNCH((k_grid_bwd_input<SOA_, T_>), grid, block, 0, stream, g, N, x,         \
-                       (const __half2*)table_half, (const T_*)dy, dx)
+                       (const __half2*)table_half, (const T_*)dy, dx, partial)
     if (soa) {
         if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);
     } else {
         if (dy_is_float) NVO_LAUNCH_IN(false, float2); else NVO_LAUNCH_IN(false, __half2);
     }
 #undef NVO_LAUNCH_IN
+    if (partial) {
+        const size_t n = (size_t)N * 3;
+        NVO_LAUNCH(k_sum_levels, dim3(nvo_div_up(n, 256)), dim3(256), 0, stream, g.n_levels, n, partial, dx,
+                   zero_dx ? 0 : 1);
+    }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

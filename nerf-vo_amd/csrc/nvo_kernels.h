@@ -72,9 +72,15 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
                         uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
                         float* grad, int mode);
+// scratch (optional, module-owned): per-level partial gradients [L][N][3] of the two-stage input backward
+struct NvoGridInputScratch {
+    float* ptr = nullptr;
+    size_t floats = 0;
+};
 int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
                               const float* x, const void* table_half, const void* dy,
-                              bool dy_is_float, bool soa, float* dx, bool zero_dx);
+                              bool dy_is_float, bool soa, float* dx, bool zero_dx,
+                              NvoGridInputScratch* scratch = nullptr);
 
 // ---- sh.hip ---------------------------------------------------------------------------------
 int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
