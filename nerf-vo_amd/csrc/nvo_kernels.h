@@ -47,7 +47,7 @@ struct NvoGridStream {
     bool created = false;
     uint32_t n_levels = 0, n_bins = 0, max_slices = 0;
     uint32_t streamed_mask = 0;
-    uint32_t owner_max_slices = 5;    // levels with at most this many 8K-entry slices stay slice-owner
+    uint32_t owner_max_slices = 12;   // levels with at most this many 8K-entry slices stay slice-owner (measured optimum)
     uint32_t tile = 512;              // samples per count / scatter workgroup (256 | 512 | 1024)
     uint32_t* d_meta = nullptr;       // one allocation holding the arrays below
     uint32_t* d_levels = nullptr;     // [n_levels] streamed level ids
