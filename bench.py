@@ -94,10 +94,10 @@ def main() -> None:
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--psnr", choices=("off", "small", "replica"), default="small",
+    ap.add_argument("--psnr", choices=("off", "small", "replica"), default="replica",
                     help="second half of the BASELINE metric (render PSNR): an end-to-end run of the mapper mirror on "
                          "the synthetic room, held-out views rendered by the native renderer.  small = 48 keyframes "
-                         "320x240, 1500 iterations (~5 s); replica = 192 keyframes 640x480, 8192 iterations")
+                         "320x240, 1500 iterations (~5 s); replica = 192 keyframes 640x480, 8192 iterations (~10 s on MI355X)")
     ap.add_argument("--grid-bwd-mode", type=int, nargs="+", default=None,
                     help="hash-grid backward kernel: one value for all networks or three (main, proposal 0, "
                          "proposal 1); 3 = streamed binned, 1 = LDS slice owner, 2 = binned, 0 = global atomics; "
