@@ -319,7 +319,9 @@ struct GridModule : nvo_module_s {
         return NVO_OK;
     }
     int ensure_slices() {
-        if (bwd_mode == 1 && slices.n_slices == 0) return nvo_grid_slices_create(g, &slices);
+        // 32-bit accumulators: half the slices per level -> fewer, longer items are the measured optimum
+        if (bwd_mode == 1 && slices.n_slices == 0)
+            return nvo_grid_slices_create(g, &slices, 0xFFFFFFFFu, slices.acc_bits == 32 ? 512u : 1024u);
         if (bwd_mode == 2 && bins.n_bins == 0 && bins.dense.n_slices == 0) return nvo_grid_bins_create(g, &bins);
         if (bwd_mode == 3 && !stream_bins.created) return nvo_grid_stream_create(g, &stream_bins);
         return NVO_OK;
@@ -348,6 +350,14 @@ struct GridModule : nvo_module_s {
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
         if (!strcmp(key, "grid_stream_tile")) { stream_bins.tile = (uint32_t)value; return NVO_OK; }
+        if (!strcmp(key, "grid_acc_bits")) {  // accumulators of the slice-owner items: 64 (default) | 32
+            NVO_REQUIRE(value == 32 || value == 64, "grid_acc_bits must be 32 or 64");
+            nvo_grid_slices_destroy(&slices);
+            nvo_grid_stream_destroy(&stream_bins);
+            slices.acc_bits = (uint32_t)value;
+            stream_bins.owner.acc_bits = (uint32_t)value;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
             nvo_grid_stream_destroy(&stream_bins);
             stream_bins.owner_max_slices = (uint32_t)value;

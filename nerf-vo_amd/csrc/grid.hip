@@ -233,23 +233,50 @@ __device__ __forceinline__ unsigned long long to_fixed(float v) {
     return (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(magic));
 }
 
+// Per-item scale context of the accumulators (only AccFixed32 uses it): s = fixed-point scale per feature,
+// inv = its reciprocal.
+struct AccScale {
+    float s0, s1, inv0, inv1;
+};
+
 struct AccFixed {
     typedef unsigned long long T;
     static constexpr uint32_t kEntries = kSliceFixed;
-    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1) {
+    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1, const AccScale&) {
         atomicAdd(&acc[2 * rel + 0], to_fixed(v0));
         atomicAdd(&acc[2 * rel + 1], to_fixed(v1));
     }
-    static __device__ __forceinline__ float get(const T* acc, uint32_t e) { return (float)(long long)acc[e] * kFixInv; }
+    static __device__ __forceinline__ float get(const T* acc, uint32_t e, const AccScale&) {
+        return (float)(long long)acc[e] * kFixInv;
+    }
 };
 struct AccFloat {
     typedef float T;
     static constexpr uint32_t kEntries = kSliceFloat;
-    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1) {
+    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1, const AccScale&) {
         atomicAdd(&acc[2 * rel + 0], v0);
         atomicAdd(&acc[2 * rel + 1], v1);
     }
-    static __device__ __forceinline__ float get(const T* acc, uint32_t e) { return acc[e]; }
+    static __device__ __forceinline__ float get(const T* acc, uint32_t e, const AccScale&) { return acc[e]; }
+};
+// 32-bit fixed point with a DATA-DERIVED, overflow-proof scale: every contribution to an entry is w * dy with
+// trilinear weights 0 <= w <= 1 that sum to 1 over a sample's corners, so |sum| <= L1_f = sum_i |dy_f(i)| of
+// the level for any entry; scale_f = 2^29 / L1_f keeps every partial sum (rounding slack included) inside
+// int32.  Resolution L1_f / 2^29 -- relative ~1e-5..1e-4 for a typical entry of a coarse level, i.e. finer
+// than the fp16 accumulation of the reference (2^-11 per add) though coarser than the 64-bit form.  Half the
+// LDS per entry => 16K-entry slices => half the slices of a level (half the redundant scans), a 2-instruction
+// conversion instead of cvt_f64 + fma_f64 + 64-bit subtract, and 32-bit LDS atomics.  Integer adds are
+// associative: results are bitwise reproducible for single-chunk items.
+struct AccFixed32 {
+    typedef int T;
+    static constexpr uint32_t kEntries = 16384;
+    static __device__ __forceinline__ void add(T* acc, uint32_t rel, float v0, float v1, const AccScale& sc) {
+        atomicAdd(&acc[2 * rel + 0], __float2int_rn(v0 * sc.s0));
+        atomicAdd(&acc[2 * rel + 1], __float2int_rn(v1 * sc.s1));
+    }
+    static __device__ __forceinline__ float get(const T* acc, uint32_t e, const AccScale& sc) {
+        return (float)acc[e] * ((e & 1u) ? sc.inv1 : sc.inv0);
+    }
 };
 
 // One workgroup per WORK ITEM = (level, slice, sample chunk).  A slice of a large hashed level is
@@ -262,7 +289,8 @@ template <typename ACC, bool SOA, typename DY2>
 __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N,
                                               const float* __restrict__ x, const DY2* __restrict__ dy,
                                               float* __restrict__ grad, uint32_t level, uint32_t first,
-                                              uint32_t chunk, uint32_t n_chunks, void* lds_raw) {
+                                              uint32_t chunk, uint32_t n_chunks, void* lds_raw,
+                                              const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f}) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -328,8 +356,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                         if ((h & ~(ACC::kEntries - 1u)) == first) {
                             const float wj = wyz[j];
                             const uint32_t lo = h & (ACC::kEntries - 1u);
-                            ACC::add(acc, lo ^ c.px, wx0 * wj * d.x, wx0 * wj * d.y);
-                            ACC::add(acc, lo ^ (c.px + 1u), c.wx * wj * d.x, c.wx * wj * d.y);
+                            ACC::add(acc, lo ^ c.px, wx0 * wj * d.x, wx0 * wj * d.y, sc);
+                            ACC::add(acc, lo ^ (c.px + 1u), c.wx * wj * d.x, c.wx * wj * d.y, sc);
                         }
                     }
                 } else {
@@ -337,8 +365,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                     for (uint32_t j = 0; j < 4; ++j) {
                         const uint32_t r0 = ((c.px ^ a[j]) & mask) - first, r1 = (((c.px + 1u) ^ a[j]) & mask) - first;
                         const float wj = wyz[j];
-                        if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y);
-                        if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y);
+                        if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y, sc);
+                        if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y, sc);
                     }
                 }
             } else {
@@ -355,8 +383,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                     }
                     const uint32_t r0 = i0 - first, r1 = i1 - first;  // unsigned wrap -> huge when below the slice
                     const float wj = wyz[j];
-                    if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y);
-                    if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y);
+                    if (r0 < count) ACC::add(acc, r0, wx0 * wj * d.x, wx0 * wj * d.y, sc);
+                    if (r1 < count) ACC::add(acc, r1, c.wx * wj * d.x, c.wx * wj * d.y, sc);
                 }
             }
         }
@@ -364,12 +392,42 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     __syncthreads();
     float* __restrict__ gr = grad + 2 * ((size_t)off + first);
     if (n_chunks == 1) {
-        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = ACC::get(acc, e);
+        for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = ACC::get(acc, e, sc);
     } else {
         for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) {
-            const float v = ACC::get(acc, e);
+            const float v = ACC::get(acc, e, sc);
             if (v != 0.f) atomicAdd(gr + e, v);
         }
+    }
+}
+
+// L1 norm of dy per (level, feature) as 2^8 fixed point in u64 (deterministic: fixed per-thread order, integer
+// atomics between workgroups).  grid = (blocks, n_levels); half2 dy only.
+template <bool SOA>
+__global__ void __launch_bounds__(256)
+k_dy_l1(NvoGridLevels g, uint32_t N, const __half2* __restrict__ dy, unsigned long long* __restrict__ l1) {
+    __shared__ float red[2][4];
+    const uint32_t level = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const float2 d = __half22float2(SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level]);
+        a += fabsf(d.x);
+        b += fabsf(d.y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        // round UP to the 2^-8 grid: the sum must not under-estimate (it bounds every accumulator)
+        atomicAdd(&l1[2 * level + threadIdx.x], (unsigned long long)ceilf(t * 256.f) + 1ull);
     }
 }
 
@@ -377,12 +435,20 @@ template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
-               const uint4* __restrict__ items) {
+               const uint4* __restrict__ items, const unsigned long long* __restrict__ l1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | float-mode flag}
-    const uint32_t n_chunks = item.w & 0x7FFFFFFFu;
+    const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
+    const uint32_t n_chunks = item.w & 0x3FFFFFFFu;
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
+    } else if ((item.w >> 30) & 1u) {
+        const float l1x = (float)l1[2 * item.x] * (1.f / 256.f), l1y = (float)l1[2 * item.x + 1] * (1.f / 256.f);
+        AccScale sc;
+        sc.s0 = l1x > 0.f ? 536870912.f / l1x : 0.f;  // 2^29 / L1
+        sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
+        sc.inv0 = l1x * (1.f / 536870912.f);
+        sc.inv1 = l1y * (1.f / 536870912.f);
+        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
     }
@@ -558,15 +624,15 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
             const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
                             ((k & 4u) ? c.wz : 1.f - c.wz);
             if (r0 + u * kLdsBwdBlock < end)  // idx / kBinSlice == slice by construction of the bins
-                AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y);
+                AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y, AccScale{});
         }
     }
     __syncthreads();
     if (n_chunks == 1) {
-        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
+        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e, AccScale{});
     } else {
         for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) {
-            const float v = AccFixed::get(acc, e);
+            const float v = AccFixed::get(acc, e, AccScale{});
             if (v != 0.f) atomicAdd(gr + e, v);
         }
     }
@@ -886,20 +952,20 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
                 const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
                 if (r >= begin && r < end) {
                     const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
-                    AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu));
+                    AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu), AccScale{});
                 }
                 if (r + 1u >= begin && r + 1u < end) {
                     const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
-                    AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu));
+                    AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu), AccScale{});
                 }
             }
         }
         __syncthreads();
         if (n_chunks == 1) {
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e);
+            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e, AccScale{});
         } else {
             for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
-                const float v = AccFixed::get(acc, e);
+                const float v = AccFixed::get(acc, e, AccScale{});
                 if (v != 0.f) atomicAdd(gr + e, v);
             }
         }
@@ -1009,12 +1075,15 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 // Slice tables for the LDS backward live in a small device buffer owned by the module.
 
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask, uint32_t target) {
+    static_assert(2 * AccFixed32::kEntries * sizeof(int) <= kLdsBwdBytes, "32-bit slice does not fit the LDS");
     struct Item { uint32_t level, first, chunk, n_chunks; };
     // Per level: accumulator kind and slice size.  Large hashed tables (>= 2^18 entries: a 20K-entry
     // slice sees <= 8 % of the lookups) use fp32 / 20K-entry slices, everything else 64-bit fixed
     // point / 8K-entry slices.  NVO_GRID_BWD_ACC = "fixed" | "float" forces one kind (experiments).
     const char* force = getenv("NVO_GRID_BWD_ACC");
+    const bool acc32 = s->acc_bits == 32;  // 32-bit fixed point with the L1-derived scale, every level
     auto float_mode = [&](uint32_t l) {
+        if (acc32) return false;
         if (force && !strcmp(force, "fixed")) return false;
         if (force && !strcmp(force, "float")) return true;
         return g.hashed[l] && (g.offset[l + 1] - g.offset[l]) >= (1u << 18);
@@ -1032,7 +1101,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
-        const uint32_t se = float_mode(l) ? kSliceFloat : kSliceFixed;
+        const uint32_t se = acc32 ? AccFixed32::kEntries : (float_mode(l) ? kSliceFloat : kSliceFixed);
         for (uint32_t f = 0; f < size; f += se) base_total += base_chunks(size - f < se ? size - f : se, size);
     }
     const uint32_t factor = base_total >= target ? 1u : (target + base_total - 1) / base_total;
@@ -1043,13 +1112,14 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
         const bool fm = float_mode((uint32_t)l);
-        const uint32_t se = fm ? kSliceFloat : kSliceFixed;
+        const uint32_t se = acc32 ? AccFixed32::kEntries : (fm ? kSliceFloat : kSliceFixed);
         for (uint32_t f = 0; f < size; f += se) {
             const uint32_t count = size - f < se ? size - f : se;
             uint32_t n_chunks = base_chunks(count, size) * factor;
             if (n_chunks > 1024) n_chunks = 1024;
             for (uint32_t c = 0; c < n_chunks; ++c)
-                (n_chunks == 1 ? single : chunked).push_back(Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u)});
+                (n_chunks == 1 ? single : chunked).push_back(
+                    Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u)});
         }
     }
     std::vector<Item> all(single);
@@ -1067,7 +1137,9 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         s->d_level = s->d_first = nullptr;
         return NVO_OK;
     }
-    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size()));
+    // [items | L1 norms (u64 [levels][2], used by the 32-bit accumulators)]
+    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size() + sizeof(unsigned long long) * 2 * NVO_MAX_LEVELS));
+    s->d_l1 = reinterpret_cast<unsigned long long*>(s->d_level + 4 * all.size());
     s->d_first = nullptr;
     NVO_CHECK_HIP(hipMemcpy(s->d_level, all.data(), sizeof(Item) * all.size(), hipMemcpyHostToDevice));
     return NVO_OK;
@@ -1076,6 +1148,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
 void nvo_grid_slices_destroy(NvoGridSlices* s) {
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
+    s->d_l1 = nullptr;
     s->n_slices = 0;
 }
 
@@ -1356,6 +1429,18 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         }
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
         const size_t lds = kLdsBwdBytes;
+        if (slices->acc_bits == 32) {
+            NVO_REQUIRE(!dy_is_float, "grid: 32-bit accumulators need fp16 dL/dy (set grid_acc_bits to 64)");
+            if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
+            uint32_t bx = nvo_div_up(N, 256 * 8);
+            if (bx > 256) bx = 256;
+            if (bx < 1) bx = 1;
+            if (soa) {
+                NVO_LAUNCH(k_dy_l1<true>, dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const __half2*)dy, slices->d_l1);
+            } else {
+                NVO_LAUNCH(k_dy_l1<false>, dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const __half2*)dy, slices->d_l1);
+            }
+        }
 #define NVO_LAUNCH_LDS(SOA_, T_)                                                              \
     do {                                                                                      \
         static bool attr_set = false; /* >64 KiB of dynamic LDS needs an explicit opt-in */   \
@@ -1366,7 +1451,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, (const uint4*)slices->d_level);               \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1);  \
     } while (0)
         if (soa) {
             if (dy_is_float) NVO_LAUNCH_LDS(true, float2); else NVO_LAUNCH_LDS(true, __half2);

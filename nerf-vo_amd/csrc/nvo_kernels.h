@@ -14,6 +14,8 @@ struct NvoGridSlices {
     uint32_t* d_level = nullptr;   // device array of uint4 work items {level, first, chunk, n_chunks}
     uint32_t* d_first = nullptr;
     uint32_t zero_first = 0, zero_last = 0;  // entry range flushed with atomics (zeroed per launch)
+    uint32_t acc_bits = 64;                  // 32: int32 accumulators with the L1-derived scale (set before create)
+    unsigned long long* d_l1 = nullptr;      // [levels][2] L1 norms of dy (inside the d_level allocation)
 };
 // level_mask: bit l set -> level l gets slice-owner work items (default: all levels); target_items: the
 // chunk counts are scaled until the launch has about this many work items

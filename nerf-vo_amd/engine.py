@@ -93,6 +93,7 @@ class EngineConfig:
     # run the proposal-network losses + backward on a second HIP stream beside the main-field backward
     # (they only share read-only inputs; forked after the render/loss kernel, joined before the optimiser)
     overlap_proposal_backward: bool = True
+    proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
     seed: int = 1337
 
 
@@ -135,6 +136,10 @@ class NerfactoEngine:
         modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
+        # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
+        # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
+        for m in self.prop_nets:
+            m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
         color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
         assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
         self.n_color = 64 * 64 + 64 * 64 + 16 * 64

@@ -124,6 +124,45 @@ def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     _assert_close(x.grad, xr.grad, rtol=2e-3, atol_scale=2e-4, what="dL/dx")
 
 
+@pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
+@pytest.mark.parametrize("bwd_mode", [1, 3], ids=["lds", "streamed"])
+def test_grid_bwd_32bit_accumulators(device, cfg, bwd_mode):
+    """grid_acc_bits=32: int32 accumulators with the overflow-proof L1-derived scale (resolution L1 / 2^29 per
+    level and feature).  Same oracle comparison as the 64-bit form with the absolute tolerance widened to that
+    resolution x sqrt(contributions): atol 2e-4 * max|ref|; the result is reproducible bit for bit."""
+    import nerf_vo_amd.tinycudann as tcnn
+    from oracle import grid as G
+
+    spec = _spec(cfg)
+    enc = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
+    enc.native_tcnn_module.set_option("grid_acc_bits", 32)
+    enc.native_tcnn_module.set_option("grid_bwd_mode", bwd_mode)
+    g = torch.Generator().manual_seed(5)
+    params = (torch.rand(spec.n_params, generator=g) * 2 - 1)
+    with torch.no_grad():
+        enc.params.copy_(params.to(device))
+    n = 4096
+    x = torch.from_numpy(_points(n, 2)).to(device)
+    dy = torch.randn(n, spec.n_output_dims, generator=g).to(device) * torch.logspace(-3, 1, spec.n_output_dims)[None].to(device)
+    grads = []
+    for _ in range(2):
+        enc.params.grad = None
+        (enc(x).float() * dy).sum().backward()
+        grads.append(enc.params.grad.clone())
+    torch.cuda.synchronize()
+    if bwd_mode == 1:
+        assert torch.equal(grads[0], grads[1]) or (grads[0] - grads[1]).abs().max() <= 1e-6 * grads[0].abs().max()
+    table = params.to(torch.float16).double().view(-1, 2).requires_grad_(True)
+    yr = G.grid_encode(spec, x.double().cpu(), table)
+    dy16 = (dy.cpu().float() * 128.0).to(torch.float16).double() / 128.0
+    (yr * dy16).sum().backward()
+    ref = table.grad.reshape(-1)
+    # per level: the resolution scales with that level's own L1, so compare level by level
+    for l in range(spec.n_levels):
+        lo, hi = 2 * int(spec.levels[l, 0]), 2 * int(spec.levels[l, 0] + spec.levels[l, 1])
+        _assert_close(grads[0][lo:hi], ref[lo:hi], rtol=1e-3, atol_scale=2e-4, what=f"dL/dparams level {l} (32-bit)")
+
+
 def test_grid_bwd_lds_matches_atomic_large(device):
     """Both scatter forms at the full main-field batch (196 608 samples): linearity + agreement."""
     import nerf_vo_amd.tinycudann as tcnn

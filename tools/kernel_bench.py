@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--tiles", type=int, nargs="+", default=[512], help="mode 3: samples per count/scatter tile")
     ap.add_argument("--masks", type=str, nargs="+", default=["5"], help="mode 3: owner_max_slices values")
     ap.add_argument("--cases", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--acc-bits", type=int, default=64, help="accumulators of the slice-owner items (32 | 64)")
     ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -54,6 +55,7 @@ def main():
                 variants += [(3, t, int(m, 0)) for t in args.tiles for m in args.masks]
             else:
                 variants.append((mode, 0, 0xFFFFFFFF))
+        enc.native_tcnn_module.set_option("grid_acc_bits", args.acc_bits)
         for mode, tile, mask in variants:
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
             if mode == 3:
