@@ -443,3 +443,103 @@ def test_pose_gradients_match_oracle(device, mode):
     eng.optimizer_step()
     torch.cuda.synchronize()
     assert not torch.equal(before, eng.view("camera_opt.pose_adjustment"))
+
+
+def test_fused_sampler_kernels_match_unfused(device):
+    """nvo_lindisp_positions / nvo_gather_targets / positions inside nvo_weights_pdf are fusions of kernels that
+    still exist on their own: the fused outputs must be identical (same arithmetic, same rounding)."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    st = _stream(device)
+    g = torch.Generator().manual_seed(3)
+    R, S = 96, 256
+    o = ((torch.rand(R, 3, generator=g) - 0.5) * 1.5).to(device)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    jit = torch.rand(R, generator=g).to(device)
+    sb_a, tb_a = torch.empty(R, S + 1, device=device), torch.empty(R, S + 1, device=device)
+    x_a = torch.empty(R * S, 3, device=device)
+    _call("nvo_sample_lindisp", st, R, S, 0.05, 1000.0, _ptr(jit), _ptr(sb_a), _ptr(tb_a))
+    _call("nvo_sample_positions", st, R, S, _ptr(o), _ptr(d), _ptr(tb_a), _ptr(x_a))
+    sb_b, tb_b, x_b = torch.empty_like(sb_a), torch.empty_like(tb_a), torch.empty_like(x_a)
+    _call("nvo_lindisp_positions", st, R, S, 0.05, 1000.0, _ptr(jit), _ptr(o), _ptr(d), _ptr(sb_b), _ptr(tb_b), _ptr(x_b))
+    torch.cuda.synchronize()
+    assert torch.equal(sb_a, sb_b) and torch.equal(tb_a, tb_b) and torch.equal(x_a, x_b)
+
+    # weights_pdf with and without the fused positions of the resampled level
+    S_out = 96
+    pre = (torch.randn(R * S, generator=g) * 2).to(torch.float16).to(device)
+    w = torch.empty(R * S, device=device)
+    outs = []
+    for fused in (False, True):
+        sbo, tbo = torch.empty(R, S_out + 1, device=device), torch.empty(R, S_out + 1, device=device)
+        xo = torch.zeros(R * S_out, 3, device=device)
+        a = _lib.WeightsPdfArgs(
+            R=R, S=S, S_out=S_out, pre=pre.data_ptr(), pre_stride=1, x01=x_a.data_ptr(), sbins=sb_a.data_ptr(),
+            tbins=tb_a.data_ptr(), density_bias=-1.0, sigma=None, weights=w.data_ptr(), anneal=0.7,
+            histogram_padding=0.01, near_plane=0.05, far_plane=1000.0, jitter=jit.data_ptr(),
+            sbins_out=sbo.data_ptr(), tbins_out=tbo.data_ptr(), anneal_dev=None,
+            origins=o.data_ptr() if fused else None, directions=d.data_ptr() if fused else None,
+            x01_out=xo.data_ptr() if fused else None)
+        _call("nvo_weights_pdf", st, C.byref(a))
+        if not fused:
+            _call("nvo_sample_positions", st, R, S_out, _ptr(o), _ptr(d), _ptr(tbo), _ptr(xo))
+        torch.cuda.synchronize()
+        outs.append((sbo, tbo, xo))
+    for p, q in zip(*outs):
+        assert torch.equal(p, q)
+
+    # one gather for colour / depth / normal targets + dirs01
+    F, H, W = 5, 12, 16
+    idx = torch.stack([torch.randint(0, F, (R,), generator=g), torch.randint(0, H, (R,), generator=g),
+                       torch.randint(0, W, (R,), generator=g)], dim=1).to(device)
+    img, dep, nrm = torch.rand(F, H, W, 3, generator=g).to(device), torch.rand(F, H, W, 1, generator=g).to(device), \
+        torch.rand(F, H, W, 3, generator=g).to(device)
+    rgb, dd, nn, d01 = (torch.empty(R, 3, device=device), torch.empty(R, device=device), torch.empty(R, 3, device=device),
+                        torch.empty(R, 3, device=device))
+    _call("nvo_gather_targets", st, R, _ptr(idx), H, W, _ptr(img), _ptr(dep), _ptr(nrm), _ptr(d), _ptr(rgb), _ptr(dd),
+          _ptr(nn), _ptr(d01))
+    torch.cuda.synchronize()
+    assert torch.equal(rgb, img[idx[:, 0], idx[:, 1], idx[:, 2]]) and torch.equal(dd, dep[idx[:, 0], idx[:, 1], idx[:, 2], 0])
+    assert torch.equal(nn, nrm[idx[:, 0], idx[:, 1], idx[:, 2]]) and torch.equal(d01, (d + 1.0) * 0.5)
+
+
+def test_pixel_sampler_kernel(device):
+    """nvo_sample_pixels: indices inside the extents, jitters in [0,1), uniform enough, reproducible for a
+    (seed, step) pair, different across steps / seeds (no parity on RNG streams: SURVEY.md 8a row a3)."""
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    st = _stream(device)
+    R = 1 << 16
+    extent = torch.tensor([37.0, 480.0, 640.0], device=device)
+    step = torch.zeros(1, device=device)
+
+    def draw(seed, s):
+        step.fill_(float(s))
+        idx = torch.empty(R, 3, dtype=torch.int64, device=device)
+        jit = torch.empty(3, R, device=device)
+        _call("nvo_sample_pixels", st, R, seed, _ptr(step), _ptr(extent), _ptr(idx), _ptr(jit), 3)
+        torch.cuda.synchronize()
+        return idx, jit
+
+    idx, jit = draw(1234, 7)
+    assert (idx >= 0).all() and (idx[:, 0] < 37).all() and (idx[:, 1] < 480).all() and (idx[:, 2] < 640).all()
+    assert (jit >= 0).all() and (jit < 1).all()
+    for c, e in enumerate((37, 480, 640)):  # mean / variance of a discrete uniform, 5-sigma bands
+        v = idx[:, c].double()
+        assert abs(v.mean().item() - (e - 1) / 2) < 5 * (e / 12 ** 0.5) / R ** 0.5 + 0.05
+    assert abs(jit.mean().item() - 0.5) < 5 / (12 * 3 * R) ** 0.5
+    counts = torch.bincount(idx[:, 0], minlength=37).double()
+    assert ((counts - R / 37).abs() < 6 * (R / 37) ** 0.5).all()
+    # channels / streams are not copies of each other
+    assert (torch.corrcoef(torch.stack([idx[:, 1].double(), idx[:, 2].double(), jit[0].double(), jit[1].double()]))
+            - torch.eye(4, device=device, dtype=torch.double)).abs().max() < 0.03
+    idx2, jit2 = draw(1234, 7)
+    assert torch.equal(idx, idx2) and torch.equal(jit, jit2)
+    idx3, _ = draw(1234, 8)
+    idx4, _ = draw(1235, 7)
+    assert (idx3 != idx).any(dim=1).double().mean() > 0.99 and (idx4 != idx).any(dim=1).double().mean() > 0.99
