@@ -864,7 +864,8 @@ static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
     if (weight_halfs >= 2048) return 1024;
     return 2048;
 }
-static uint32_t bwd_block_cap(int, int, int) {
+static uint32_t bwd_block_cap(int in_pad, int width, int n_hidden) {
+    if (width * in_pad + (n_hidden - 1) * width * width < 2048) return 512;  // 16-wide proposal MLP: 34 vs 37 us
     // one workgroup per CU: with the tile inputs software-pipelined every shape is fastest at 256 (colour head
     // 74 us vs 107 us at 512; base 30.6 vs 37.7; proposal 49.5 vs 53.4) -- fewer dW flushes, and the dW
     // accumulators leave the wide shapes one wave per SIMD anyway
