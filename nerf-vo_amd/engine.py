@@ -716,7 +716,9 @@ class NerfactoEngine:
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half), saved):
             dst.copy_(src)  # the warm-up steps must not count as training
-        entry = {"half": half}
+        # the graph addresses these buffers by pointer: they must outlive this call (a freed block would be handed
+        # to the next small allocation and every replay would scribble over it)
+        entry = {"half": half, "buffers": (c2w, ray_indices, jit, scale)}
         g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_main):
             body_main()

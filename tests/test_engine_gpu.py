@@ -377,6 +377,20 @@ def test_graph_replay_matches_eager_semantics(device):
     # the optimiser must really have run on every replay: the GradScaler-style skip flag stays 0
     # (regression: a captured 4-byte hipMemsetAsync replayed as 0x01 bytes and silently disabled Adam)
     assert int(eng.skip_flag.item()) == 0
+    # the buffers the graphs address by pointer must stay owned by the engine (regression: the captured pose /
+    # pixel-index / jitter buffers were locals of the capture function; once freed, the caching allocator handed
+    # the same blocks to later allocations and every replay overwrote them -- long mapping runs collapsed)
+    torch.cuda.synchronize()
+    sentinels = []
+    for _ in range(8):
+        sentinels += [torch.full((1024, 3), 7, dtype=torch.int64, device=device),
+                      torch.full((3, 1024), 7.0, device=device), torch.full((n, 3, 4), 7.0, device=device),
+                      torch.full((3,), 7.0, device=device)]
+    for it in range(4):
+        eng.train_step_graphed(ds)
+    torch.cuda.synchronize()
+    assert all(bool((t == 7).all()) for t in sentinels), "a graph replay wrote into memory the engine no longer owns"
+    del sentinels
     # same sequence launched eagerly reaches the same loss level
     eng2 = NerfactoEngine(EngineConfig(num_images=n, num_rays=1024), device)
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()

@@ -21,7 +21,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chunk=8, device="cuda:0", quiet=False,
-        out_dir=None, enhancement="depth"):
+        out_dir=None, enhancement="depth", log_every=0):
     entry.build()
     from nerf_vo_amd.mapping.dataset import opencv_to_opengl
     from nerf_vo_amd.mapping.nerfstudio_mapper import Nerfstudio
@@ -50,8 +50,14 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
         for _ in range(iters_between * (hi - lo) - 1):
             if mapper.step < iterations:
                 mapper(input=None)
+                if log_every and mapper.step % log_every == 0:
+                    ld = mapper.trainer.pipeline.model.engine.loss_dict()
+                    print(f"it {mapper.step:5d} " + " ".join(f"{k}={v:.3e}" for k, v in ld.items()), file=sys.stderr, flush=True)
     while mapper.step < iterations:
         mapper(input=None)
+        if log_every and mapper.step % log_every == 0:
+            ld = mapper.trainer.pipeline.model.engine.loss_dict()
+            print(f"it {mapper.step:5d} " + " ".join(f"{k}={v:.3e}" for k, v in ld.items()), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
     mapper(input=None)  # step == max_num_iterations -> shut_down (snapshot)
@@ -65,8 +71,10 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
     ds = mapper.trainer.pipeline.datamanager.train_dataset
     norm = ds.normalization_matrix.to(dev)
     psnr_ref, psnr_flt, depth_l1 = [], [], []
-    for k in range(eval_frames):
-        idx = 1 + 2 * int(k * keyframes / eval_frames)
+    psnr_train, depth_l1_train = [], []
+    for k in range(2 * eval_frames):
+        held_out = k < eval_frames
+        idx = (1 if held_out else 0) + 2 * int((k % eval_frames) * keyframes / eval_frames)
         pose_cv = all_poses[idx:idx + 1]
         color_gt, depth_gt, _ = render_room(pose_cv, height, width, intr)
         gt = (color_gt[0].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
@@ -75,6 +83,10 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
         pose_std = pose_gl.clone()
         pose_std[:3, 1:3] *= -1  # renderer expects the standard (OpenCV) convention
         color, depth = renderer.render_frame(intr_d, pose_std.cpu().numpy())
+        if not held_out:  # keyframe poses: separates generalisation from fit
+            psnr_train.append(calculate_psnr_float(color, gt))
+            depth_l1_train.append(float(np.abs(depth - depth_gt[0, 0].cpu().numpy()).mean()))
+            continue
         psnr_ref.append(calculate_psnr_reference(color, gt))
         psnr_flt.append(calculate_psnr_float(color, gt))
         depth_l1.append(float(np.abs(depth - depth_gt[0, 0].cpu().numpy()).mean()))
@@ -83,7 +95,8 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
         "train_seconds": train_s, "iterations_per_sec": iterations / train_s,
         "ray_samples_per_sec": iterations * 4096 * 48 / train_s,
         "psnr_reference_uint8wrap": float(np.mean(psnr_ref)), "psnr_float_mse": float(np.mean(psnr_flt)),
-        "depth_l1": float(np.mean(depth_l1)), "final_losses": mapper.trainer.pipeline.model.engine.loss_dict(),
+        "depth_l1": float(np.mean(depth_l1)), "psnr_float_mse_keyframe_views": float(np.mean(psnr_train)),
+        "depth_l1_keyframe_views": float(np.mean(depth_l1_train)), "final_losses": mapper.trainer.pipeline.model.engine.loss_dict(),
         "snapshot_dir": out_dir,
     }
     if not quiet:
@@ -98,5 +111,6 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--iterations", type=int, default=1500)
     ap.add_argument("--eval-frames", type=int, default=6)
+    ap.add_argument("--log-every", type=int, default=0)
     a = ap.parse_args()
-    run(a.keyframes, a.height, a.width, a.iterations, a.eval_frames)
+    run(a.keyframes, a.height, a.width, a.iterations, a.eval_frames, log_every=a.log_every)
