@@ -45,7 +45,10 @@ def _texture(p: torch.Tensor, normal_axis: torch.Tensor) -> torch.Tensor:
     """Smooth + checker texture of the hit point, different per wall."""
     f = 6.0
     base = 0.5 + 0.5 * torch.sin(p * f + normal_axis[..., None].float() * 1.3)
-    checker = ((torch.floor(p[..., 0] * 4) + torch.floor(p[..., 1] * 4) + torch.floor(p[..., 2] * 4)) % 2)[..., None]
+    # the checker is evaluated in the two in-wall coordinates only: the coordinate along the wall normal is +-1 up
+    # to rounding, and floor(4 * (+-1 +- eps)) would flip per pixel (salt noise no view-consistent model can fit)
+    in_wall = torch.ones_like(p).scatter_(-1, normal_axis[..., None], 0.0)
+    checker = ((torch.floor(p * 4) * in_wall).sum(dim=-1) % 2)[..., None]
     return (0.75 * base + 0.25 * checker).clamp(0.0, 1.0)
 
 
