@@ -96,3 +96,39 @@ def make_sequence(num_keyframes: int = 192, height: int = 480, width: int = 640,
         "frames_depth": depth.clamp(0.0, depth_clip),
         "frames_normal": normal,
     }
+
+
+class SyntheticEvaluationDataset:
+    """The analytic room behind the dataset interface the reference's evaluation code reads
+    (/root/reference/evaluation/renderer.py:66-76,81,239-258; evaluator.py:95-98): ground-truth poses in the
+    standard (OpenCV) convention, ``camera_intrinsics`` as a dict with ``depth_scale``, ``evaluation_frames``
+    (every frame that is not a keyframe stride), and ``frames_color`` / ``frames_depth`` per mode."""
+
+    def __init__(self, num_frames: int = 96, height: int = 120, width: int = 160, evaluation_stride: int = 5,
+                 depth_scale: float = 6553.5):
+        fx, fy, cx, cy = replica_intrinsics(height, width)
+        self.camera_intrinsics = {"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": height, "width": width,
+                                  "depth_scale": depth_scale}
+        self.num_frames = num_frames
+        self.camera_extrinsics = orbit_poses_opencv(num_frames).double().numpy()
+        self.evaluation_frames = list(range(2, num_frames, evaluation_stride))
+
+    def render(self, pose_cv) -> tuple:
+        """(uint8 [H,W,3] colour, float [H,W] z-depth) of the room from a standard-convention c2w pose."""
+        ci = self.camera_intrinsics
+        pose = torch.as_tensor(pose_cv, dtype=torch.float32)[None]
+        color, depth, _ = render_room(pose, ci["height"], ci["width"], (ci["fx"], ci["fy"], ci["cx"], ci["cy"]))
+        return ((color[0].permute(1, 2, 0).numpy() * 255).astype("uint8"), depth[0, 0].double().numpy())
+
+    def _indices(self, mode: str, keyframes) -> list:
+        if mode == "keyframes":
+            return list(keyframes)
+        if mode == "evaluation_frames":
+            return list(self.evaluation_frames)
+        return list(range(self.num_frames))
+
+    def frames_color(self, mode: str = "evaluation_frames", keyframes=None) -> list:
+        return [self.render(self.camera_extrinsics[i])[0] for i in self._indices(mode, keyframes)]
+
+    def frames_depth(self, mode: str = "evaluation_frames", keyframes=None) -> list:
+        return [self.render(self.camera_extrinsics[i])[1] for i in self._indices(mode, keyframes)]

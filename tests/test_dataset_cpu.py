@@ -1,6 +1,8 @@
 """CPU tests of the host logic around the hot path: keyframe ingest semantics of the DynamicDataset
 mirror (/root/reference/nerf_vo/mapping/nerfstudio_utils.py:157-228), the mapper cadence helpers and
 the synthetic sequence generator."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,3 +211,34 @@ def test_psnr_reference_definition_matches_reference_function():
         a, b = np.asarray(row["a"], dtype=np.uint8), np.asarray(row["b"], dtype=np.uint8)
         assert calculate_psnr_reference(a, b) == pytest.approx(row["color"], rel=1e-12)
         assert psnr_reference(a, b) == pytest.approx(row["color"], rel=1e-12)
+
+
+def test_runtime_log_csv_matches_reference_format(tmp_path):
+    """PerformanceTracker tuples -> RuntimeLog -> runtime_<process>.csv, byte-identical to what the reference's
+    ``pd.DataFrame(rows).to_csv(path, index=False)`` writes for the same rows (logging_module.py:21-25,46-57)."""
+    import queue
+
+    import pandas as pd
+
+    from nerf_vo_amd.runtime_log import PerformanceTracker, RuntimeLog
+
+    q = queue.Queue()
+    expected = {"mapping": [], "tracking": []}
+    for step in range(5):
+        for name in ("mapping", "tracking"):
+            with PerformanceTracker(process_name=name, logging_queue=q, step=step) as tracker:
+                sum(range(1000 * (step + 1)))
+            tracker.submit()
+            assert tracker.runtime >= 0.0
+            expected[name].append({"step": step, "runtime": tracker.runtime})
+    q.put(("mapping", "loss", 3, 0.5))  # non-runtime fields are ignored (wandb is commented out upstream)
+    q.put(("logging", "shutdown", 0, 0.0))
+    log = RuntimeLog()
+    log.step(log.drain(q))
+    assert log.shutdown and q.empty()
+    written = log.shut_down(str(tmp_path))
+    assert sorted(os.path.basename(p) for p in written) == ["runtime_mapping.csv", "runtime_tracking.csv"]
+    for name, rows in expected.items():
+        pd.DataFrame(rows).to_csv(tmp_path / f"ref_{name}.csv", index=False)
+        assert (tmp_path / f"runtime_{name}.csv").read_text() == (tmp_path / f"ref_{name}.csv").read_text()
+    PerformanceTracker("x", None, 0).submit()  # no queue: a no-op, like the reference
