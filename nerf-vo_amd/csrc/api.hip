@@ -358,6 +358,10 @@ struct GridModule : nvo_module_s {
             stream_bins.owner.acc_bits = (uint32_t)value;
             return NVO_OK;
         }
+        if (!strcmp(key, "grid_stream_overlap")) {  // 0: slice-owner levels and record pipeline back to back
+            stream_bins.overlap = value != 0;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
             nvo_grid_stream_destroy(&stream_bins);
             stream_bins.owner_max_slices = (uint32_t)value;

@@ -1301,6 +1301,12 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_slice, bin_slice.data(), 4 * nb, hipMemcpyHostToDevice));
     }
     st->created = true;
+    if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
+    if (!st->aux) {
+        NVO_CHECK_HIP(hipStreamCreateWithFlags(&st->aux, hipStreamNonBlocking));
+        NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+        NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+    }
     const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
     // 512 items: measured optimum for the coarse-only launch (the atomic flush of a chunk costs as much as
     // scanning ~2K samples; a two-stage store + reduce form was measured slower)
@@ -1315,6 +1321,14 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     st->work_bytes = 0;
     st->n_bins = 0;
     st->created = false;
+    if (st->aux) {
+        (void)hipStreamSynchronize(st->aux);
+        (void)hipStreamDestroy(st->aux);
+        (void)hipEventDestroy(st->ev_fork);
+        (void)hipEventDestroy(st->ev_join);
+        st->aux = nullptr;
+        st->ev_fork = st->ev_join = nullptr;
+    }
     nvo_grid_slices_destroy(&st->owner);
 }
 
@@ -1332,9 +1346,17 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     const uint32_t tile = st->tile;
     NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
     const uint32_t n_tiles = nvo_div_up(N, tile);
+    // fork: with the per-kernel profiler on, everything stays on the caller's stream (its events live there)
+    const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !nvo_prof_enabled();
     if (st->owner.n_slices) {  // coarse levels: slice-owner items (disjoint gradient ranges)
         NvoProfMute mute;
-        if (int rc = nvo_grid_bwd_launch(g, &st->owner, stream, N, x, dy, dy_is_float, soa, grad, 1)) return rc;
+        if (fork) {
+            NVO_CHECK_HIP(hipEventRecord(st->ev_fork, stream));
+            NVO_CHECK_HIP(hipStreamWaitEvent(st->aux, st->ev_fork, 0));
+        }
+        if (int rc = nvo_grid_bwd_launch(g, &st->owner, fork ? st->aux : stream, N, x, dy, dy_is_float, soa, grad, 1))
+            return rc;
+        if (fork) NVO_CHECK_HIP(hipEventRecord(st->ev_join, st->aux));
     }
     if (st->n_bins == 0) return NVO_OK;
     const size_t n_records = (size_t)N * 8 * st->n_levels;
@@ -1407,6 +1429,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
 #undef NVO_LAUNCH_ST_T
 #undef NVO_LAUNCH_ST
     NVO_CHECK_LAUNCH();
+    if (fork) NVO_CHECK_HIP(hipStreamWaitEvent(stream, st->ev_join, 0));  // join
     return NVO_OK;
 }
 
