@@ -314,6 +314,10 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     // that exceeds every x coordinate
     const bool pair_bins = hashed && (ACC::kEntries & (ACC::kEntries - 1u)) == 0u && res + 1u < ACC::kEntries &&
                            (first & (ACC::kEntries - 1u)) == 0u && count == ACC::kEntries;
+    // Integer accumulators cannot carry inf / NaN: a non-finite dy (fp16 overflow of the scaled loss gradient) is
+    // remembered here and poisons the slice's first gradient entry after the flush, so that the optimiser's
+    // non-finite check sees it exactly as it would with floating-point accumulation.
+    bool bad = false;
     for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
         float2 dv[kUnroll];
         float xv[kUnroll][3];
@@ -337,6 +341,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {
             const float2 d = dv[u];
+            bad |= !(fabsf(d.x) < INFINITY) | !(fabsf(d.y) < INFINITY);
             if (d.x == 0.f && d.y == 0.f) continue;
             const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
             const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
@@ -399,6 +404,9 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             if (v != 0.f) atomicAdd(gr + e, v);
         }
     }
+    // (no LDS to spare for a block-wide vote: one atomic per affected wave, after every plain store has retired)
+    __syncthreads();
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));
 }
 
 // L1 norm of dy per (level, feature) as 2^8 fixed point in u64 (deterministic: fixed per-thread order, integer
@@ -597,6 +605,7 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
     for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) acc[e] = 0ull;
     __syncthreads();
     constexpr uint32_t kUnroll = 8;
+    bool bad = false;  // non-finite dy: see grid_bwd_item
     for (uint32_t r0 = begin + threadIdx.x; r0 < end; r0 += kUnroll * kLdsBwdBlock) {
         uint32_t rec[kUnroll];
 #pragma unroll
@@ -623,8 +632,10 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
             const uint32_t idx = hashed_corner(c, k, mask);
             const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
                             ((k & 4u) ? c.wz : 1.f - c.wz);
-            if (r0 + u * kLdsBwdBlock < end)  // idx / kBinSlice == slice by construction of the bins
+            if (r0 + u * kLdsBwdBlock < end) {  // idx / kBinSlice == slice by construction of the bins
+                bad |= !(fabsf(dv[u].x) < INFINITY) | !(fabsf(dv[u].y) < INFINITY);
                 AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y, AccScale{});
+            }
         }
     }
     __syncthreads();
@@ -636,6 +647,8 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
             if (v != 0.f) atomicAdd(gr + e, v);
         }
     }
+    __syncthreads();
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -939,6 +952,7 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
         // Record pairs (16-byte loads), kUnroll of them per thread in flight at once: a chunk of <= 32K
         // records is requested in one round trip.
         constexpr uint32_t kUnroll = 16;
+        bool bad = false;  // a record of a non-finite w * dy has an all-ones exponent whatever rides in its mantissa
         const uint32_t pair_begin = begin >> 1, pair_end = (end + 1u) >> 1;
         for (uint32_t p0 = pair_begin + threadIdx.x; p0 < pair_end; p0 += kUnroll * kLdsBwdBlock) {
             uint4 rec[kUnroll];
@@ -952,10 +966,12 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
                 const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
                 if (r >= begin && r < end) {
                     const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
+                    bad |= ((rec[u].x & 0x7F800000u) == 0x7F800000u) | ((rec[u].y & 0x7F800000u) == 0x7F800000u);
                     AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu), AccScale{});
                 }
                 if (r + 1u >= begin && r + 1u < end) {
                     const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
+                    bad |= ((rec[u].z & 0x7F800000u) == 0x7F800000u) | ((rec[u].w & 0x7F800000u) == 0x7F800000u);
                     AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu), AccScale{});
                 }
             }
@@ -969,7 +985,8 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
                 if (v != 0.f) atomicAdd(gr + e, v);
             }
         }
-        __syncthreads();  // the next item zeroes the accumulators
+        __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
+        if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
     }
 }
 

@@ -163,6 +163,37 @@ def test_grid_bwd_32bit_accumulators(device, cfg, bwd_mode):
         _assert_close(grads[0][lo:hi], ref[lo:hi], rtol=1e-3, atol_scale=2e-4, what=f"dL/dparams level {l} (32-bit)")
 
 
+@pytest.mark.parametrize("bad_value", [float("inf"), float("-inf"), float("nan")], ids=["inf", "-inf", "nan"])
+@pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
+def test_grid_bwd_propagates_nonfinite(device, cfg, bad_value):
+    """A non-finite dy (fp16 overflow of the loss-scaled gradient) must surface as a non-finite parameter gradient in
+    EVERY scatter form, so that the optimiser's GradScaler-style check skips the step -- integer LDS accumulators
+    cannot carry inf / NaN by themselves (regression: they turned it into a finite garbage update)."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    enc = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
+    spec = _spec(cfg)
+    n = 20000
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(n, 3, generator=g).to(device)
+    for level in (0, spec.n_levels - 1):
+        dy = torch.randn(n, 2 * spec.n_levels, generator=g).to(device)
+        dy[12345, 2 * level + 1] = bad_value
+        for mode, bits in ((0, 64), (1, 64), (1, 32), (2, 64), (3, 64), (3, 32)):
+            enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
+            enc.native_tcnn_module.set_option("grid_acc_bits", bits)
+            enc.params.grad = None
+            (enc(x).float() * dy).sum().backward()
+            grad = enc.params.grad
+            lo, cnt = int(spec.levels[level, 0]), int(spec.levels[level, 1])
+            assert not bool(torch.isfinite(grad[2 * lo:2 * (lo + cnt)]).all()), \
+                f"mode {mode} ({bits}-bit): non-finite dy at level {level} vanished from the gradient"
+            # the other levels are untouched by the poison
+            other = torch.cat([grad[:2 * lo], grad[2 * (lo + cnt):]])
+            assert bool(torch.isfinite(other).all())
+    enc.native_tcnn_module.set_option("grid_acc_bits", 64)
+
+
 def test_grid_bwd_lds_matches_atomic_large(device):
     """Both scatter forms at the full main-field batch (196 608 samples): linearity + agreement."""
     import nerf_vo_amd.tinycudann as tcnn
