@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--h", type=int, default=120)
     ap.add_argument("--w", type=int, default=160)
     ap.add_argument("--poses", type=int, default=1)
+    ap.add_argument("--loss-scale", type=float, default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -39,7 +40,8 @@ def main():
                              "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]),
                              "frames_color": seq["frames_color"], "frames_depth": seq["frames_depth"]})
     ds = dm.train_dataset
-    eng = NerfactoEngine(EngineConfig(num_images=a.kf, optimize_poses=bool(a.poses), max_num_iterations=a.iters), dev)
+    extra = {} if a.loss_scale is None else {"loss_scale": a.loss_scale}
+    eng = NerfactoEngine(EngineConfig(num_images=a.kf, optimize_poses=bool(a.poses), max_num_iterations=a.iters, **extra), dev)
     for it in range(a.iters):
         eng.train_step_graphed(ds)
     print("final train losses", eng.loss_dict(), flush=True)
