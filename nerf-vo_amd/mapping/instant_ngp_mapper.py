@@ -1,28 +1,30 @@
 """Drop-in counterpart of the reference's second mapping method ``InstantNGP``
-(/root/reference/nerf_vo/mapping/instant_ngp.py:19-117) and of ``InstantNGPRenderer``
-(/root/reference/evaluation/nerf_renderer.py:221-319), over the native occupancy-grid engine
-(nerf_vo_amd.ngp_engine) instead of pyngp.Testbed.
+(/root/reference/nerf_vo/mapping/instant_ngp.py:19-117) and of ``InstantNGPRenderer`` /
+``NeRFSLAMNGPRenderer`` (/root/reference/evaluation/nerf_renderer.py:221-344).  Both drive the testbed facade
+``nerf_vo_amd.pyngp`` through exactly the calls the reference makes on NVlabs' ``pyngp`` -- the facade, not these
+classes, is the drop-in boundary: the reference's own two files run against it unchanged.
 
-Same constructor, attributes (``is_initialized``, ``is_shut_down``, ``step``) and methods
+Same constructor, attributes (``is_initialized``, ``is_shut_down``, ``step``, ``ngp``) and methods
 (``__call__``, ``update``, ``train``, ``shut_down``, ``save_snapshot``); same ingest transformations
-(NCHW -> NHWC, sRGB -> linear colours at :64-67, unit depth covariance, intrinsics of the first frame,
-poses taken as camera-to-world 3x4 with nerf_scale 1 / nerf_offset 0, aabb_scale 4).  Differences:
-keyframe data stays on the device (the reference round-trips through host numpy lists, :87-100);
-snapshots are torch files, not .msgpack; extrinsics optimisation inside the NGP trainer
-(optimize_extrinsics, :47) is not built yet."""
+(NCHW -> NHWC, sRGB -> linear colours + unit alpha at :64-74, unit depth covariance, intrinsics of the first
+frame of the packet, poses taken as camera-to-world 3x4 in the NeRF / OpenGL convention the enhancement stage
+emits, nerf_scale 1 / nerf_offset 0, aabb_scale 4, extrinsics optimisation on, L2 depth loss).  One difference:
+keyframe data is handed to the facade as device tensors (the reference round-trips every packet through host
+numpy lists, :87-100; the facade accepts both)."""
 from __future__ import annotations
 
 import argparse
 import math
-from pathlib import Path
+import os
 
 import numpy as np
 import torch
 
-from ..ngp_engine import NgpConfig, NgpEngine
-from .cameras import Cameras, CameraType
+from .. import pyngp
 from .nerfstudio_mapper import step_check
 from .renderer import NeRFRenderer
+
+file_instant_ngp_config = "nerf_vo/thirdparty/nerf_slam/thirdparty/instant-ngp/configs/nerf/base.json"
 
 
 class InstantNGP:
@@ -32,17 +34,18 @@ class InstantNGP:
         self.is_initialized = False
         self.is_shut_down = False
         self.step = 0
-        n, h, w = args.num_keyframes, args.frame_height, args.frame_width
-        self.ngp = NgpEngine(NgpConfig(num_images=n, aabb_scale=4, depth_loss_mult=1.0), self.device)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.images = torch.zeros(n, h, w, 3, **f32)          # linear colours
-        self.depths = torch.zeros(n, h, w, 1, **f32)
-        self.depths_cov = torch.ones(n, h, w, 1, **f32)
-        self.poses = torch.eye(4, **f32)[:3].repeat(n, 1, 1)  # camera-to-world, OpenGL axes
-        self.intrinsics = torch.zeros(n, 4, **f32)
-        self.n_images_for_training = 0
-        self.generator = torch.Generator(device=self.device)
-        self.generator.manual_seed(42)
+
+        self.ngp = pyngp.Testbed(pyngp.TestbedMode.Nerf, self.device.index or 0)
+        bounding_box = pyngp.BoundingBox(np.array([-np.inf, -np.inf, -np.inf]), np.array([np.inf, np.inf, np.inf]))
+        self.ngp.create_empty_nerf_dataset(n_images=args.num_keyframes, nerf_scale=1.0,
+                                           nerf_offset=np.array([0.0, 0.0, 0.0]), aabb_scale=4,
+                                           render_aabb=bounding_box)
+        self.ngp.nerf.training.n_images_for_training = 0
+        self.ngp.reload_network_from_file(file_instant_ngp_config)
+        self.ngp.shall_train = True
+        self.ngp.nerf.training.optimize_extrinsics = True
+        self.ngp.nerf.training.depth_loss_type = pyngp.LossType.L2
+        self.ngp.frame()
 
     def __call__(self, input: dict | None) -> None:
         if self.step == self.args.mapping_iterations:
@@ -54,28 +57,27 @@ class InstantNGP:
                 self.train()
 
     def update(self, input: dict) -> None:
-        idx = input["keyframe_indices"].to(self.device).long()
         color = input["frames_color"].to(self.device).permute(0, 2, 3, 1)
         # sRGB -> linear, exactly as the reference does before handing images to the testbed
         color = torch.where(color > 0.04045, torch.pow((color + 0.055) / 1.055, 2.4), color / 12.92)
-        pose = input["camera_extrinsics"].to(self.device)[:, :3].clone()
-        pose[:, :3, 1:3] *= -1  # OpenCV camera axes -> OpenGL (what the native ray generator expects)
-        self.images[idx] = color
-        self.depths[idx] = input["frames_depth"].to(self.device).permute(0, 2, 3, 1)
+        color = torch.cat((color, torch.ones_like(color[..., :1])), dim=3)
+        depth = input["frames_depth"].to(self.device).permute(0, 2, 3, 1)
         if "frames_depth_covariance" in input:
-            self.depths_cov[idx] = input["frames_depth_covariance"].to(self.device).permute(0, 2, 3, 1)
-        self.poses[idx] = pose
-        # the reference passes ONE focal length / principal point (first frame of the packet)
-        self.intrinsics[idx] = input["camera_intrinsics"].to(self.device)[0]
-        self.n_images_for_training = max(self.n_images_for_training, int(idx.max()) + 1)
-        self.is_initialized = True
+            depth_cov = input["frames_depth_covariance"].to(self.device).permute(0, 2, 3, 1)
+        else:
+            depth_cov = torch.ones_like(depth)
+        self.ngp.nerf.training.update_training_images(
+            frame_ids=input["keyframe_indices"].contiguous().cpu().numpy().tolist(),
+            poses=input["camera_extrinsics"].to(self.device)[:, :3].contiguous(),
+            images=color.contiguous(), depths=depth.contiguous(), depths_cov=depth_cov.contiguous(),
+            resolution=np.array([self.args.frame_width, self.args.frame_height]),
+            principal_point=input["camera_intrinsics"][0, 2:].cpu().numpy(),
+            focal_length=input["camera_intrinsics"][0, :2].cpu().numpy(),
+            depth_scale=1.0, depth_cov_scale=1.0)
+        self.is_initialized = True  # (no torch.cuda.empty_cache(): allocator churn)
 
     def train(self) -> None:
-        n, h, w = self.n_images_for_training, self.args.frame_height, self.args.frame_width
-        scale = torch.tensor([n, h, w], device=self.device)
-        u = torch.rand((self.ngp.cfg.num_rays, 3), device=self.device, generator=self.generator)
-        ray_indices = torch.floor(u * scale).long()
-        self.ngp.train_step(ray_indices, self.intrinsics, self.poses, self.images, self.depths)
+        self.ngp.frame()
         if step_check(self.step, self.args.mapping_snapshot_iterations):
             self.save_snapshot()
         self.step += 1
@@ -85,62 +87,70 @@ class InstantNGP:
         self.is_shut_down = True
 
     def save_snapshot(self) -> None:
-        d = Path(self.args.dir_prediction) / "snapshots"
-        d.mkdir(parents=True, exist_ok=True)
-        e = self.ngp
-        torch.save({"step": self.step, "params": e.params, "exp_avg": e.exp_avg, "exp_avg_sq": e.exp_avg_sq,
-                    "opt_step": e.opt_step, "density_grid": e.density_grid, "bitfield": e.bitfield,
-                    "poses": self.poses[: self.n_images_for_training], "config": vars(e.cfg)},
-                   d / f"snapshot{self.step:06d}.pt")
-
-    def get_camera_extrinsics(self, frame_idx: int) -> np.ndarray:
-        """3x4 camera-to-world of a training frame (OpenGL axes), the testbed call the renderer uses."""
-        return self.poses[frame_idx].detach().cpu().numpy()
+        self.ngp.save_snapshot(self.args.dir_prediction + f"/snapshots/snapshot{self.step:06d}.msgpack", False)
 
 
 class InstantNGPRenderer(NeRFRenderer):
-    """render_frame(intrinsics, extrinsics) -> (uint8 sRGB colour, depth) like the reference: linear
-    render -> sRGB transfer -> clip -> *255 + 0.5."""
+    """render_frame(intrinsics, extrinsics) -> (uint8 sRGB colour, z-depth): linear render -> un-premultiply ->
+    sRGB transfer -> clip -> *255 + 0.5, through the same testbed calls as the reference."""
 
     def load_nerf_from_snapshot(self, dir_prediction: str) -> None:
-        raise NotImplementedError("offline snapshot reload is a 'next' row (SURVEY.md section 8f, f4)")
+        dir_snapshots = dir_prediction + "/snapshots"
+        files = sorted(f for f in os.listdir(dir_snapshots) if ".msgpack" in f) if os.path.exists(dir_snapshots) else []
+        if not files:
+            raise FileNotFoundError(f"Could not find snapshot in {dir_snapshots}")
+        self.load_ngp_from_snapshot(file_snapshot=os.path.join(dir_snapshots, files[-1]))
+
+    def load_ngp_from_snapshot(self, file_snapshot: str) -> None:
+        self.ngp = pyngp.Testbed(pyngp.TestbedMode.Nerf, 0)
+        self.ngp.load_snapshot(path=file_snapshot)
 
     def load_nerf_from_mapping_model(self, mapping_model) -> None:
-        self.mapper = mapping_model
         self.ngp = mapping_model.ngp
 
     def get_camera_extrinsics(self, frame_index: int) -> np.ndarray:
         m = np.eye(4)
-        m[:3] = self.mapper.get_camera_extrinsics(frame_index)
-        m[0:3, 1:3] *= -1  # OpenGL -> standard convention
+        m[:3] = self.ngp.nerf.training.get_camera_extrinsics(frame_idx=frame_index)
+        m = m[[1, 2, 0, 3]]   # NGP row order -> NeRF
+        m[0:3, 1:3] *= -1     # NeRF (y up, -z forward) -> standard (y down, z forward)
         return m
 
-    def render_frame(self, camera_intrinsics: dict, camera_extrinsics: np.ndarray, rays_per_chunk: int = 2048):
-        ext = np.array(camera_extrinsics, dtype=np.float64, copy=True)
-        ext[0:3, 1:3] *= -1  # standard -> OpenGL
-        dev = self.ngp.device
-        cams = Cameras(fx=camera_intrinsics["fx"], fy=camera_intrinsics["fy"], cx=camera_intrinsics["cx"],
-                       cy=camera_intrinsics["cy"], height=camera_intrinsics["height"], width=camera_intrinsics["width"],
-                       camera_to_worlds=torch.tensor(ext, dtype=torch.float32).unsqueeze(0)[:, :3],
-                       camera_type=CameraType.PERSPECTIVE).to(dev)
-        bundle = cams.generate_rays(camera_indices=0, keep_shape=True)
-        H, W = camera_intrinsics["height"], camera_intrinsics["width"]
-        o = bundle.origins.reshape(-1, 3)
-        d = bundle.directions.reshape(-1, 3)
-        dn = bundle.metadata["directions_norm"].reshape(-1)
-        rgb, depth = [], []
-        for lo in range(0, o.shape[0], rays_per_chunk):
-            hi = min(o.shape[0], lo + rays_per_chunk)
-            oo, dd, nn = o[lo:hi], d[lo:hi], dn[lo:hi]
-            if hi - lo < rays_per_chunk:
-                pad = rays_per_chunk - (hi - lo)
-                oo = torch.cat([oo, oo[-1:].expand(pad, 3)])
-                dd = torch.cat([dd, dd[-1:].expand(pad, 3)])
-                nn = torch.cat([nn, nn[-1:].expand(pad)])
-            out = self.ngp.render_rays(oo.contiguous(), dd.contiguous(), nn.contiguous())
-            rgb.append(out["rgb"][: hi - lo].clone())
-            depth.append((out["depth"][: hi - lo, 0] / nn[: hi - lo]).clone())  # ray distance -> z-depth
-        lin = torch.cat(rgb).view(H, W, 3).cpu().numpy()
+    def render_frame(self, camera_intrinsics: dict, camera_extrinsics: np.ndarray) -> tuple:
+        color = self.render_frame_color(camera_intrinsics=camera_intrinsics, camera_extrinsics=camera_extrinsics.copy())
+        depth = self.render_frame_depth(camera_intrinsics=camera_intrinsics, camera_extrinsics=camera_extrinsics.copy())
+        return color, depth
+
+    def render_frame_color(self, camera_intrinsics: dict, camera_extrinsics: np.ndarray) -> np.ndarray:
+        self._set_rendering_defaults(camera_intrinsics)
+        self._set_camera_extrinsics(camera_extrinsics)
+        self.ngp.render_mode = pyngp.Shade
+        color = self.ngp.render(width=camera_intrinsics["width"], height=camera_intrinsics["height"], spp=1, linear=True)
+        color[..., 0:3] = np.divide(color[..., 0:3], color[..., 3:4], out=np.zeros_like(color[..., 0:3]),
+                                    where=color[..., 3:4] != 0)
+        lin = color[..., 0:3]
         srgb = np.where(lin > 0.0031308, 1.055 * (np.maximum(lin, 1e-12) ** (1.0 / 2.4)) - 0.055, 12.92 * lin)
-        color = (np.clip(srgb, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
-        return color, torch.cat(depth).view(H, W).cpu().numpy()
+        return (np.clip(srgb, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+
+    def render_frame_depth(self, camera_intrinsics: dict, camera_extrinsics: np.ndarray) -> np.ndarray:
+        self._set_rendering_defaults(camera_intrinsics)
+        self._set_camera_extrinsics(camera_extrinsics)
+        self.ngp.render_mode = pyngp.Depth
+        return self.ngp.render(width=camera_intrinsics["width"], height=camera_intrinsics["height"], spp=1,
+                               linear=True)[..., 0]
+
+    def _set_rendering_defaults(self, camera_intrinsics: dict) -> None:
+        self.ngp.nerf.sharpen = 0.0
+        self.ngp.exposure = 0.0
+        self.ngp.fov_axis = 0
+        self.ngp.fov = (2 * math.atan(0.5 * camera_intrinsics["width"] / camera_intrinsics["fx"])) * 180 / np.pi
+        self.ngp.nerf.render_with_lens_distortion = True
+        self.ngp.nerf.render_min_transmittance = 1e-4
+
+    def _set_camera_extrinsics(self, camera_extrinsics: np.ndarray) -> None:
+        camera_extrinsics = np.array(camera_extrinsics, dtype=np.float64, copy=True)
+        camera_extrinsics[0:3, 1:3] *= -1              # standard -> NeRF convention
+        self.ngp.set_nerf_camera_matrix(camera_extrinsics[[2, 0, 1]])  # NeRF -> NGP row order
+
+
+class NeRFSLAMNGPRenderer(InstantNGPRenderer):
+    """Same renderer; the reference's subclass only locates the NeRF-SLAM build of pyngp (nerf_renderer.py:322-344)."""

@@ -1,0 +1,352 @@
+"""``pyngp``-shaped facade over the native occupancy-grid engine (SURVEY.md section 8 row f3 / section 8b "alt
+outer" boundary): the subset of NVlabs' testbed bindings that the reference touches, with the same names, argument
+meaning and call order, so that its ``InstantNGP`` mapping method
+(/root/reference/nerf_vo/mapping/instant_ngp.py:19-117) and ``InstantNGPRenderer`` / ``NeRFSLAMNGPRenderer``
+(/root/reference/evaluation/nerf_renderer.py:221-344) run against it unchanged (``import nerf_vo_amd.pyngp as
+pyngp``; INTEGRATION.md shows the two-line binding).
+
+What the reference calls, and what answers here:
+    pyngp.TestbedMode.Nerf, pyngp.Testbed(mode, 0)            -> Testbed
+    pyngp.BoundingBox(min, max), pyngp.LossType.L2             -> plain value types
+    create_empty_nerf_dataset(n_images, nerf_scale, nerf_offset, aabb_scale, render_aabb)
+    nerf.training.{n_images_for_training, optimize_extrinsics, depth_loss_type}
+    nerf.training.update_training_images(frame_ids, poses, images, depths, depths_cov, resolution,
+                                         principal_point, focal_length, depth_scale, depth_cov_scale)
+    nerf.training.get_camera_extrinsics(frame_idx)             -> 3x4, optimised pose, "NGP" row order (below)
+    reload_network_from_file(path), shall_train, frame()
+    save_snapshot(path, include_optimizer_state) / load_snapshot(path)
+    render_mode = pyngp.Shade | pyngp.Depth, exposure, fov_axis, fov, nerf.{sharpen, render_with_lens_distortion,
+    render_min_transmittance}, set_nerf_camera_matrix(3x4), render(width, height, spp, linear) -> float32 [H,W,4]
+
+Pose conventions.  ``update_training_images`` receives camera-to-world matrices in the NeRF / OpenGL convention (y
+up, camera looks down -z), exactly what the mapping input carries.  The reference converts poses it READS with
+``m[[1, 2, 0, 3]]`` + a y/z column flip (nerf_renderer.py:244-251) and poses it SETS with the column flip +
+``m[[2, 0, 1]]`` (:311-316): both are consistent with one "NGP" form, the OpenGL matrix with its rows cycled
+(row 0 <- z, row 1 <- x, row 2 <- y), and that is the form ``get_camera_extrinsics`` returns and
+``set_nerf_camera_matrix`` accepts.  (instant-ngp's own ``nerf_matrix_to_ngp`` is [UPSTREAM] and absent from the
+reference tree; this facade is pinned to the reference's call sites, which is all its callers can observe.)
+
+Differences from the CUDA testbed, all outside what the reference observes: training data may be handed over as
+device tensors (no host round trip); snapshots are msgpack containers with this module's own schema (the upstream
+.msgpack layout is [UPSTREAM]); ``render`` always uses spp = 1 rays through pixel centres; marching cubes is out
+of scope.  There is no CPU fallback: the engine needs the HIP library and an MI355X.
+"""
+from __future__ import annotations
+
+import enum
+import json
+import math
+import os
+import types
+
+import numpy as np
+import torch
+
+from .mapping.cameras import Cameras, CameraType
+from .mapping.model import multiply
+from .ngp_engine import NgpConfig, NgpEngine
+
+_TO_NGP_ROWS = [2, 0, 1]    # OpenGL c2w rows -> "NGP" row order
+_FROM_NGP_ROWS = [1, 2, 0]  # and back
+
+
+class TestbedMode(enum.Enum):
+    Nerf = 0
+    Sdf = 1
+    Image = 2
+    Volume = 3
+
+
+class LossType(enum.Enum):
+    L2 = 0
+    L1 = 1
+    Mape = 2
+    Smape = 3
+    Huber = 4
+    LogL1 = 5
+    RelativeL2 = 6
+
+
+class RenderMode(enum.Enum):
+    AO = 0
+    Shade = 1
+    Normals = 2
+    Positions = 3
+    Depth = 4
+
+
+Shade = RenderMode.Shade
+Depth = RenderMode.Depth
+
+
+class BoundingBox:
+    def __init__(self, min=None, max=None) -> None:  # noqa: A002 (pyngp's argument names)
+        self.min = np.full(3, np.inf) if min is None else np.asarray(min, dtype=np.float64)
+        self.max = np.full(3, -np.inf) if max is None else np.asarray(max, dtype=np.float64)
+
+
+def _as_device_tensor(items, device) -> torch.Tensor:
+    """list of numpy arrays / tensors (what the reference passes) or one stacked tensor -> float32 on device."""
+    if isinstance(items, torch.Tensor):
+        return items.to(device=device, dtype=torch.float32)
+    if len(items) and isinstance(items[0], torch.Tensor):
+        return torch.stack([t.to(device=device, dtype=torch.float32) for t in items])
+    return torch.as_tensor(np.stack([np.asarray(a, dtype=np.float32) for a in items]), device=device)
+
+
+class _Training:
+    def __init__(self, testbed: "Testbed") -> None:
+        self._tb = testbed
+        self.n_images_for_training = 0
+        self.optimize_extrinsics = False  # instant-ngp's default; the reference switches it on
+        self.depth_loss_type = LossType.L2
+        self.depth_supervision_lambda = 1.0
+
+    def update_training_images(self, frame_ids, poses, images, depths, depths_cov, resolution, principal_point,
+                               focal_length, depth_scale: float = 1.0, depth_cov_scale: float = 1.0) -> None:
+        tb = self._tb
+        width, height = int(resolution[0]), int(resolution[1])
+        tb._ensure_engine(height, width)
+        dev = tb.device
+        idx = torch.as_tensor(list(frame_ids), dtype=torch.long, device=dev)
+        if idx.numel() == 0:
+            return
+        if int(idx.max()) >= tb._n_images or int(idx.min()) < 0:
+            raise RuntimeError(f"update_training_images: frame id outside the dataset of {tb._n_images} images")
+        rgba = _as_device_tensor(images, dev)
+        if rgba.shape[1:3] != (height, width):
+            raise RuntimeError(f"update_training_images: images are {tuple(rgba.shape[1:3])}, resolution says {(height, width)}")
+        tb._images[idx] = rgba[..., :3]  # linear RGB; the alpha the reference appends is 1 everywhere
+        tb._depths[idx] = _as_device_tensor(depths, dev).reshape(-1, height, width, 1) * float(depth_scale)
+        tb._depths_cov[idx] = _as_device_tensor(depths_cov, dev).reshape(-1, height, width, 1) * float(depth_cov_scale)
+        pose = _as_device_tensor(poses, dev)[:, :3, :4]
+        pose = pose.clone()
+        pose[:, :, 3] = pose[:, :, 3] * tb._nerf_scale + torch.as_tensor(tb._nerf_offset, dtype=torch.float32, device=dev)
+        tb._poses[idx] = pose
+        intr = torch.tensor([float(focal_length[0]), float(focal_length[1]), float(principal_point[0]),
+                             float(principal_point[1])], dtype=torch.float32, device=dev)
+        tb._intrinsics[idx] = intr
+        self.n_images_for_training = max(self.n_images_for_training, int(idx.max()) + 1)
+
+    def get_camera_extrinsics(self, frame_idx: int) -> np.ndarray:
+        tb = self._tb
+        if tb._engine is None:
+            raise RuntimeError("get_camera_extrinsics: no training images have been set")
+        pose = tb._poses[frame_idx]
+        if self.optimize_extrinsics:
+            pose = multiply(tb._engine.camera_corrections()[frame_idx], pose)
+        return pose.detach().cpu().numpy().astype(np.float64)[_TO_NGP_ROWS]
+
+
+class Testbed:
+    def __init__(self, mode: TestbedMode = TestbedMode.Nerf, device_index: int = 0) -> None:
+        if mode != TestbedMode.Nerf:
+            raise NotImplementedError("only TestbedMode.Nerf is on the hot path (SURVEY.md section 8)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyngp.Testbed needs an MI355X device; there is no CPU fallback")
+        self.device = torch.device(f"cuda:{int(device_index)}")
+        self.mode = mode
+        self.nerf = types.SimpleNamespace(training=_Training(self), sharpen=0.0, render_with_lens_distortion=False,
+                                          render_min_transmittance=0.01)
+        self.shall_train = False
+        self.render_mode = Shade
+        self.exposure = 0.0
+        self.fov_axis = 0
+        self.fov = 50.625
+        self.training_step = 0
+        self.loss = 0.0
+        self._n_images = 0
+        self._nerf_scale, self._nerf_offset, self._aabb_scale = 0.33, np.full(3, 0.5), 1  # instant-ngp defaults
+        self.render_aabb = BoundingBox()
+        self._network_config: dict = {}
+        self._engine: NgpEngine | None = None
+        self._camera = np.eye(4)[:3][_TO_NGP_ROWS]
+        self._generator = torch.Generator(device=self.device)
+        self._generator.manual_seed(42)
+
+    # ---- dataset / network set-up ------------------------------------------------------------------------
+    def create_empty_nerf_dataset(self, n_images: int, nerf_scale: float = 0.33, nerf_offset=(0.5, 0.5, 0.5),
+                                  aabb_scale: int = 1, render_aabb: BoundingBox | None = None) -> None:
+        if self._engine is not None:
+            raise RuntimeError("create_empty_nerf_dataset: the dataset already holds images")
+        self._n_images = int(n_images)
+        self._nerf_scale = float(nerf_scale)
+        self._nerf_offset = np.asarray(nerf_offset, dtype=np.float64)
+        self._aabb_scale = int(aabb_scale)
+        if render_aabb is not None:
+            self.render_aabb = render_aabb
+        self.nerf.training.n_images_for_training = 0
+
+    def reload_network_from_file(self, path: str = "") -> None:
+        """instant-ngp's configs/nerf/base.json is what the reference loads (instant_ngp.py:16,44) and what the
+        engine implements; the file lives in a submodule that may be absent, so a missing path keeps the built-in
+        base configuration.  From a present file the optimiser / encoding scalars are honoured."""
+        self._network_config = {}
+        if path and os.path.exists(path):
+            with open(path) as fh:
+                self._network_config = json.load(fh)
+        if self._engine is not None:
+            self._engine.init_params(self._engine.cfg.seed)
+
+    def _config(self) -> NgpConfig:
+        cfg = NgpConfig(num_images=self._n_images, aabb_scale=self._aabb_scale,
+                        depth_loss_mult=self.nerf.training.depth_supervision_lambda,
+                        optimize_extrinsics=bool(self.nerf.training.optimize_extrinsics))
+        opt = self._network_config.get("optimizer", {})
+        while "nested" in opt:  # base.json wraps Adam in ExponentialDecay / Ema
+            opt = opt["nested"]
+        if opt.get("otype", "Adam") == "Adam":
+            cfg.lr = float(opt.get("learning_rate", cfg.lr))
+            cfg.adam_betas = (float(opt.get("beta1", cfg.adam_betas[0])), float(opt.get("beta2", cfg.adam_betas[1])))
+            cfg.adam_eps = float(opt.get("epsilon", cfg.adam_eps))
+            cfg.l2_reg = float(opt.get("l2_reg", cfg.l2_reg))
+        return cfg
+
+    def _ensure_engine(self, height: int, width: int) -> None:
+        if self._engine is not None:
+            if (height, width) != self._resolution:
+                raise RuntimeError("update_training_images: all training images must share one resolution")
+            return
+        if self._n_images <= 0:
+            raise RuntimeError("create_empty_nerf_dataset must be called first")
+        if self.nerf.training.depth_loss_type != LossType.L2:
+            raise NotImplementedError("only LossType.L2 depth supervision is built (instant_ngp.py:48)")
+        self._engine = NgpEngine(self._config(), self.device)
+        self._resolution = (height, width)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        n = self._n_images
+        self._images = torch.zeros(n, height, width, 3, **f32)
+        self._depths = torch.zeros(n, height, width, 1, **f32)
+        self._depths_cov = torch.ones(n, height, width, 1, **f32)
+        self._poses = torch.eye(4, **f32)[:3].repeat(n, 1, 1)
+        self._intrinsics = torch.zeros(n, 4, **f32)
+
+    # ---- training --------------------------------------------------------------------------------------
+    def frame(self) -> bool:
+        """One testbed frame = one training step when ``shall_train`` and images are present (the reference calls
+        it once before any image exists, instant_ngp.py:50: a no-op)."""
+        n = int(self.nerf.training.n_images_for_training)
+        if not self.shall_train or self._engine is None or n <= 0:
+            return True
+        eng = self._engine
+        eng.cfg.optimize_extrinsics = bool(self.nerf.training.optimize_extrinsics)
+        h, w = self._resolution
+        scale = torch.tensor([n, h, w], device=self.device)
+        u = torch.rand((eng.cfg.num_rays, 3), device=self.device, generator=self._generator)
+        eng.train_step(torch.floor(u * scale).long(), self._intrinsics, self._poses, self._images, self._depths)
+        self.training_step = eng.step
+        return True
+
+    # ---- snapshots -------------------------------------------------------------------------------------
+    _SNAPSHOT_FORMAT = "nerf_vo_amd.pyngp.v1"
+
+    def save_snapshot(self, path: str, include_optimizer_state: bool = False) -> None:
+        import msgpack
+
+        if self._engine is None:
+            raise RuntimeError("save_snapshot: nothing has been trained")
+        e = self._engine
+
+        def raw(t: torch.Tensor) -> bytes:
+            return t.detach().contiguous().cpu().numpy().tobytes()
+
+        n = int(self.nerf.training.n_images_for_training)
+        cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(e.cfg).items()}
+        snap = {"format": self._SNAPSHOT_FORMAT, "config": cfg, "step": e.step, "opt_step": e.opt_step,
+                "resolution": list(self._resolution), "n_images": self._n_images, "n_images_for_training": n,
+                "nerf_scale": self._nerf_scale, "nerf_offset": self._nerf_offset.tolist(),
+                "optimize_extrinsics": bool(self.nerf.training.optimize_extrinsics),
+                "params": raw(e.params), "density_grid": raw(e.density_grid), "bitfield": raw(e.bitfield),
+                "poses": raw(self._poses), "intrinsics": raw(self._intrinsics), "pose_adjustment": raw(e.pose_adjustment)}
+        if include_optimizer_state:
+            snap["optimizer"] = {"exp_avg": raw(e.exp_avg), "exp_avg_sq": raw(e.exp_avg_sq),
+                                 "pose_exp_avg": raw(e.pose_exp_avg), "pose_exp_avg_sq": raw(e.pose_exp_avg_sq)}
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "wb") as fh:
+            fh.write(msgpack.packb(snap, use_bin_type=True))
+
+    def load_snapshot(self, path: str) -> None:
+        import msgpack
+
+        with open(path, "rb") as fh:
+            snap = msgpack.unpackb(fh.read(), raw=False)
+        if snap.get("format") != self._SNAPSHOT_FORMAT:
+            raise RuntimeError(f"load_snapshot: {path} is not a {self._SNAPSHOT_FORMAT} snapshot")
+        cfg = dict(snap["config"])
+        cfg["adam_betas"] = tuple(cfg["adam_betas"])
+        self._n_images = int(snap["n_images"])
+        self._nerf_scale, self._nerf_offset = float(snap["nerf_scale"]), np.asarray(snap["nerf_offset"])
+        self._aabb_scale = int(cfg["aabb_scale"])
+        self.nerf.training.optimize_extrinsics = bool(snap["optimize_extrinsics"])
+        self._engine = None
+        h, w = snap["resolution"]
+        self._ensure_engine(int(h), int(w))
+        e = self._engine
+        e.cfg = NgpConfig(**cfg)
+
+        def put(dst: torch.Tensor, blob: bytes) -> None:
+            src = torch.frombuffer(bytearray(blob), dtype=dst.dtype)
+            if src.numel() != dst.numel():
+                raise RuntimeError("load_snapshot: buffer size does not match the configuration")
+            dst.copy_(src.view(dst.shape))
+
+        e.set_params(torch.frombuffer(bytearray(snap["params"]), dtype=torch.float32))
+        put(e.density_grid, snap["density_grid"])
+        put(e.bitfield, snap["bitfield"])
+        put(self._poses, snap["poses"])
+        put(self._intrinsics, snap["intrinsics"])
+        put(e.pose_adjustment, snap["pose_adjustment"])
+        if "optimizer" in snap:
+            for name in ("exp_avg", "exp_avg_sq", "pose_exp_avg", "pose_exp_avg_sq"):
+                put(getattr(e, name), snap["optimizer"][name])
+        e.step, e.opt_step = int(snap["step"]), int(snap["opt_step"])
+        self.training_step = e.step
+        self.nerf.training.n_images_for_training = int(snap["n_images_for_training"])
+
+    # ---- rendering -------------------------------------------------------------------------------------
+    def set_nerf_camera_matrix(self, camera_matrix) -> None:
+        m = np.asarray(camera_matrix, dtype=np.float64)
+        if m.shape != (3, 4):
+            raise RuntimeError(f"set_nerf_camera_matrix expects a 3x4 matrix, got {m.shape}")
+        self._camera = m.copy()
+
+    def render(self, width: int, height: int, spp: int = 1, linear: bool = True, rays_per_chunk: int = 2048) -> np.ndarray:
+        """float32 [height, width, 4].  Shade: alpha-premultiplied linear RGB + alpha (the reference divides by
+        alpha, nerf_renderer.py:274-277); Depth: z-depth in every channel (it reads channel 0, :296).  Pinhole with
+        the focal length of ``fov`` along ``fov_axis``, square pixels and a centred principal point, like the
+        testbed's free camera.  (2048 rays per launch: the engine's packed-sample capacity of 2^18 then leaves 128
+        marched samples per ray; rays beyond the capacity would be dropped whole.)"""
+        if self._engine is None:
+            raise RuntimeError("render: no network has been trained or loaded")
+        if not linear:
+            raise NotImplementedError("render(linear=False): the reference always asks for linear output")
+        focal = 0.5 * (width if self.fov_axis == 0 else height) / math.tan(0.5 * math.radians(self.fov))
+        c2w = torch.tensor(self._camera[_FROM_NGP_ROWS], dtype=torch.float32).unsqueeze(0)
+        cams = Cameras(fx=focal, fy=focal, cx=0.5 * width, cy=0.5 * height, height=height, width=width,
+                       camera_to_worlds=c2w, camera_type=CameraType.PERSPECTIVE).to(self.device)
+        bundle = cams.generate_rays(camera_indices=0, keep_shape=True)
+        o = bundle.origins.reshape(-1, 3)
+        d = bundle.directions.reshape(-1, 3)
+        dn = bundle.metadata["directions_norm"].reshape(-1)
+        chunks = []
+        for lo in range(0, o.shape[0], rays_per_chunk):
+            hi = min(o.shape[0], lo + rays_per_chunk)
+            oo, dd, nn = o[lo:hi], d[lo:hi], dn[lo:hi]
+            if hi - lo < rays_per_chunk:  # one scratch shape: pad the tail chunk
+                pad = rays_per_chunk - (hi - lo)
+                oo = torch.cat([oo, oo[-1:].expand(pad, 3)])
+                dd = torch.cat([dd, dd[-1:].expand(pad, 3)])
+                nn = torch.cat([nn, nn[-1:].expand(pad)])
+            out = self._engine.render_rays(oo.contiguous(), dd.contiguous(), nn.contiguous())
+            if self.render_mode == Depth:
+                z = (out["depth"][: hi - lo, 0] / nn[: hi - lo])[:, None]  # distance along the ray -> z-depth
+                chunks.append(z.expand(-1, 4).clone())
+            elif self.render_mode == Shade:
+                rgb = out["rgb"][: hi - lo] * (2.0 ** self.exposure)
+                chunks.append(torch.cat([rgb, out["accumulation"][: hi - lo]], dim=1))
+            else:
+                raise NotImplementedError(f"render_mode {self.render_mode}: the reference uses Shade and Depth")
+        return torch.cat(chunks).view(height, width, 4).cpu().numpy()
+
+    def compute_and_save_marching_cubes_mesh(self, *args, **kwargs) -> None:
+        raise NotImplementedError("mesh extraction is out of scope (SURVEY.md section 2.2)")

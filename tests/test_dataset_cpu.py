@@ -242,3 +242,19 @@ def test_runtime_log_csv_matches_reference_format(tmp_path):
         pd.DataFrame(rows).to_csv(tmp_path / f"ref_{name}.csv", index=False)
         assert (tmp_path / f"runtime_{name}.csv").read_text() == (tmp_path / f"ref_{name}.csv").read_text()
     PerformanceTracker("x", None, 0).submit()  # no queue: a no-op, like the reference
+
+
+def test_pyngp_facade_surface_and_loud_failure_without_gpu():
+    """The testbed facade exposes the names the reference touches (instant_ngp.py:33-48, nerf_renderer.py:263-316) and
+    refuses to run without an MI355X instead of falling back to anything."""
+    from nerf_vo_amd import pyngp
+
+    assert pyngp.TestbedMode.Nerf and pyngp.LossType.L2 and pyngp.Shade != pyngp.Depth
+    box = pyngp.BoundingBox(np.array([-np.inf] * 3), np.array([np.inf] * 3))
+    assert box.min.shape == (3,) and np.isinf(box.max).all()
+    for name in ("create_empty_nerf_dataset", "reload_network_from_file", "frame", "save_snapshot", "load_snapshot",
+                 "set_nerf_camera_matrix", "render", "compute_and_save_marching_cubes_mesh"):
+        assert callable(getattr(pyngp.Testbed, name))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            pyngp.Testbed(pyngp.TestbedMode.Nerf, 0)

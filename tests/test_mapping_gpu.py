@@ -72,37 +72,56 @@ def test_psnr_definitions():
 
 
 def test_instant_ngp_mapper_end_to_end(device, tmp_path):
-    """The `mapping_module: 'instant-ngp'` mirror: ingest -> train -> snapshot -> render, on a synthetic
-    room placed inside cascade 0 of the occupancy grid."""
+    """The `mapping_module: 'instant-ngp'` mirror over the pyngp facade: ingest -> train -> msgpack snapshot ->
+    render (online and from the reloaded snapshot), on a synthetic room placed inside cascade 0 of the occupancy
+    grid.  Square-pixel intrinsics (120x68 keeps Replica's aspect): the testbed's free camera has one focal length."""
     import argparse
 
     import torch
 
-    from nerf_vo_amd.mapping.instant_ngp_mapper import InstantNGP, InstantNGPRenderer
+    from nerf_vo_amd import pyngp
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.mapping.instant_ngp_mapper import InstantNGP, InstantNGPRenderer, NeRFSLAMNGPRenderer
     from nerf_vo_amd.mapping.renderer import calculate_psnr_float
     from nerf_vo_amd.synthetic import make_sequence, replica_intrinsics
 
-    n, H, W, iters = 12, 60, 80, 400
+    n, H, W, iters = 12, 68, 120, 400
     seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
     poses = seq["camera_extrinsics"].clone()
     poses[:, :3, 3] += 0.5
     args = argparse.Namespace(num_keyframes=n, frame_height=H, frame_width=W, mapping_iterations=iters,
                               mapping_snapshot_iterations=iters, dir_prediction=str(tmp_path))
     mapper = InstantNGP(args, device=device)
-    mapper.ngp.cfg.num_rays = 1024
+    assert isinstance(mapper.ngp, pyngp.Testbed) and mapper.ngp.training_step == 0  # frame() before any image: no-op
     mapper(input={"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
-                  "camera_extrinsics": poses, "frames_color": seq["frames_color"], "frames_depth": seq["frames_depth"],
-                  "last_frame": True})
+                  "camera_extrinsics": opencv_to_opengl(poses), "frames_color": seq["frames_color"],
+                  "frames_depth": seq["frames_depth"], "last_frame": True})
     while mapper.step < iters:
         mapper(input=None)
     mapper(input=None)
-    assert mapper.is_shut_down and list((tmp_path / "snapshots").glob("snapshot*.pt"))
+    assert mapper.is_shut_down and mapper.ngp.training_step == iters
+    assert list((tmp_path / "snapshots").glob("snapshot*.msgpack"))
     renderer = InstantNGPRenderer(mapping_model=mapper)
     fx, fy, cx, cy = replica_intrinsics(H, W)
-    color, depth = renderer.render_frame({"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": H, "width": W},
-                                         renderer.get_camera_extrinsics(3))
+    intr = {"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": H, "width": W}
+    # training poses read back through the testbed are the ingested ones up to the learnt extrinsics offsets
+    pose3 = renderer.get_camera_extrinsics(3)
+    np.testing.assert_allclose(pose3[:3, :3], poses[3, :3, :3].cpu().numpy(), atol=0.02)
+    np.testing.assert_allclose(pose3[:3, 3], poses[3, :3, 3].cpu().numpy(), atol=0.02)
+    color, depth = renderer.render_frame(intr, pose3)
     gt = (seq["frames_color"][3].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
     assert color.shape == (H, W, 3) and color.dtype == np.uint8
     assert calculate_psnr_float(color, gt) > 17.0
     gt_depth = seq["frames_depth"][3, 0].cpu().numpy()
     assert np.abs(depth - gt_depth).mean() < 0.15
+    # offline: a fresh testbed restored from the snapshot renders the same frame bit for bit
+    offline = NeRFSLAMNGPRenderer(dir_prediction=str(tmp_path))
+    np.testing.assert_array_equal(offline.get_camera_extrinsics(3), pose3)
+    color2, depth2 = offline.render_frame(intr, pose3)
+    assert np.array_equal(color2, color) and np.array_equal(depth2, depth)
+    # misuse fails loudly
+    with pytest.raises(RuntimeError):
+        mapper.ngp.nerf.training.update_training_images(
+            frame_ids=[n], poses=opencv_to_opengl(poses)[:1, :3], images=torch.zeros(1, H, W, 4), depths=torch.zeros(1, H, W, 1),
+            depths_cov=torch.ones(1, H, W, 1), resolution=np.array([W, H]), principal_point=np.array([cx, cy]),
+            focal_length=np.array([fx, fy]))
