@@ -104,6 +104,8 @@ def main() -> None:
                          "default = EngineConfig's")
     ap.add_argument("--optimize-poses", action="store_true",
                     help="BASELINE configs[2]: SE3 pose-gradient backprop enabled (default: configs[1], fixed poses)")
+    ap.add_argument("--late-steps", type=int, default=100,
+                    help="extra timed steps late in the proposal-update schedule (reported as late_schedule; 0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -258,6 +260,28 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
 
+    # ---- informational: the same K-step measurement late in the schedule.  `value` above is taken over steps
+    # [warmup, warmup + K) of a fresh run, where nerfacto refreshes its proposal networks every 2nd step; past the
+    # 5000-step proposal warm-up they are refreshed every 6th step (the reference trains 8192 steps per sequence).
+    late = None
+    if args.late_steps > 0:
+        engine.step = 6000
+        for _ in range(12):
+            step()
+        fence()
+        tl0 = time.perf_counter()
+        for _ in range(args.late_steps):
+            step()
+        fence()
+        t_late = time.perf_counter() - tl0
+        if dist is not None:
+            t = torch.tensor([t_late], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_late = float(t.item())
+        late = {"first_step": 6012, "steps": args.late_steps, "ms_per_step": t_late / args.late_steps * 1e3,
+                "value": samples_per_step / (t_late / args.late_steps),
+                "note": "proposal networks refreshed every 6th step (schedule past the 5000-step warm-up)"}
+
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -299,6 +323,7 @@ def main() -> None:
                        "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (fp16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             "final_losses": losses,
+            "late_schedule": late,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "render_psnr": render_psnr,
