@@ -326,29 +326,56 @@ struct GridModule : nvo_module_s {
         if (bwd_mode == 3 && !stream_bins.created) return nvo_grid_stream_create(g, &stream_bins);
         return NVO_OK;
     }
-    uint64_t ctx_bytes(uint32_t) const override { return 16; }
+    // option "prepare_input_gradients" (tcnn's forward flag of the same name): the forward also stores
+    // d(out)/d(cell coordinate) in ctx ([L][3][B] half2) and the backward w.r.t. the input streams it instead of
+    // gathering the 8 corners of every (sample, level) again.  The ctx of a forward run with the option off (or
+    // with another batch size) is never read as dy/dx: the matching backward then takes the gather form.
+    int prepare_input_gradients = 0;
+    bool dydx_valid = false;
+    uint32_t dydx_batch = 0;
+    uint64_t dydx_bytes(uint32_t B) const { return nvo_round_up((uint64_t)g.n_levels * 3 * B * 4, 256); }
+    // shared by the stand-alone encoding and NetworkWithInputEncoding (dydx: where in ITS ctx the block lives)
+    int fwd_encode(hipStream_t s, uint32_t B, const float* in, const void* table, void* out, bool soa, void* dydx) {
+        dydx_valid = dydx != nullptr;
+        dydx_batch = B;
+        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx);
+    }
+    int bwd_input(hipStream_t s, uint32_t B, const float* in, const void* table, const void* dout, bool soa,
+                  float* din, const void* dydx) {
+        if (dydx && dydx_valid && dydx_batch == B)
+            return nvo_grid_bwd_input_dydx_launch(g, s, B, dydx, dout, false, soa, din, true);
+        return nvo_grid_bwd_input_launch(g, s, B, in, table, dout, false, soa, din, true, &input_scratch);
+    }
+    uint64_t ctx_bytes(uint32_t B) const override { return 16 + (prepare_input_gradients ? dydx_bytes(B) : 0); }
     int init_params(Pcg32& rng, float* out) const override {
         for (uint64_t i = 0; i < n_params; ++i) out[i] = rng.next_float() * 2e-4f - 1e-4f;
         return NVO_OK;
     }
     int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
-            void*) override {
-        return nvo_grid_fwd_launch(g, s, B, in, params, out, soa_out, nullptr);
+            void* ctx) override {
+        void* dydx = (prepare_input_gradients && ctx) ? (char*)ctx + 16 : nullptr;
+        return fwd_encode(s, B, in, params, out, soa_out, dydx);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void*,
-            const void* dout, void*, float* din, float* dparams) override {
+            const void* dout, void* ctx, float* din, float* dparams) override {
         if (dparams) {
             int rc = bwd_params(s, B, in, dout, soa_out, dparams);
             if (rc) return rc;
         }
         if (din) {
-            int rc = nvo_grid_bwd_input_launch(g, s, B, in, params, dout, false, soa_out, din, true, &input_scratch);
+            const void* dydx = (prepare_input_gradients && ctx) ? (const char*)ctx + 16 : nullptr;
+            int rc = bwd_input(s, B, in, params, dout, soa_out, din, dydx);
             if (rc) return rc;
         }
         return NVO_OK;
     }
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        if (!strcmp(key, "prepare_input_gradients")) {  // changes ctx_bytes(): set before the ctx scratch is sized
+            prepare_input_gradients = value != 0;
+            dydx_valid = false;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_stream_tile")) { stream_bins.tile = (uint32_t)value; return NVO_OK; }
         if (!strcmp(key, "grid_acc_bits")) {  // accumulators of the slice-owner items: 64 (default) | 32
             NVO_REQUIRE(value == 32 || value == 64, "grid_acc_bits must be 32 or 64");
@@ -485,9 +512,10 @@ struct NwieModule : nvo_module_s {
 
     uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
     uint64_t ctx_bytes(uint32_t B) const override {
-        // [encoded SoA][d_encoded SoA][mlp hidden]
-        return 2 * enc_bytes(B) + net->ctx_bytes(B);
+        // [encoded SoA][d_encoded SoA][mlp hidden][dy/dx of the encoding (option prepare_input_gradients)]
+        return dydx_offset(B) + (enc->prepare_input_gradients ? enc->dydx_bytes(B) : 0);
     }
+    uint64_t dydx_offset(uint32_t B) const { return nvo_round_up(2 * enc_bytes(B) + net->ctx_bytes(B), 256); }
     int init_params(Pcg32& rng, float* out) const override {
         int rc = net->init_params(rng, out);
         if (rc) return rc;
@@ -500,7 +528,8 @@ struct NwieModule : nvo_module_s {
         void* encoded = c;
         void* hidden = c + 2 * enc_bytes(B);
         const _Float16* p = (const _Float16*)params;
-        int rc = nvo_grid_fwd_launch(enc->g, s, B, in, p + net->n_params, encoded, true, nullptr);
+        void* dydx = enc->prepare_input_gradients ? c + dydx_offset(B) : nullptr;
+        int rc = enc->fwd_encode(s, B, in, p + net->n_params, encoded, true, dydx);
         if (rc) return rc;
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
         a.compact_out = compact_out;
@@ -531,8 +560,8 @@ struct NwieModule : nvo_module_s {
             if (rc) return rc;
         }
         if (din) {
-            rc = nvo_grid_bwd_input_launch(enc->g, s, B, in, p + net->n_params, dencoded, false, true,
-                                           din, true, &enc->input_scratch);
+            const void* dydx = enc->prepare_input_gradients ? c + dydx_offset(B) : nullptr;
+            rc = enc->bwd_input(s, B, in, p + net->n_params, dencoded, true, din, dydx);
             if (rc) return rc;
         }
         return NVO_OK;

@@ -107,11 +107,16 @@ __device__ __forceinline__ Corner grid_cell(float scale, float x, float y, float
 // table  : fp16 parameters, [entries][2]
 // out    : SOA ? [L][N] half2 : [N][L] half2
 // indices: optional debug/parity output, [L][N][8] uint32 (nullptr in production)
-template <bool SOA>
+// dydx   : (DYDX) d(out)/d(cell coordinate) per level and axis, [L][3][N] half2 (feature pair) -- what tcnn's
+//          forward stores when input gradients were requested (prepare_input_gradients): the backward w.r.t. the
+//          input then is a coalesced stream instead of a second pass of 8 gathers per (sample, level).  Kept in
+//          CELL units (the level's scale is applied by the consumer) so that it has the magnitude of a table
+//          difference and fits fp16 like the table itself.
+template <bool SOA, bool DYDX>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
            const __half2* __restrict__ table, __half2* __restrict__ out,
-           uint32_t* __restrict__ indices) {
+           uint32_t* __restrict__ indices, __half2* __restrict__ dydx) {
     uint32_t tile, level;
     grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
     const uint32_t i = tile * kGridBlock + threadIdx.x;
@@ -150,6 +155,26 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         out[(size_t)level * N + i] = r;
     } else {
         out[(size_t)i * g.n_levels + level] = r;
+    }
+    if constexpr (DYDX) {
+        float2 f[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) f[k] = __half22float2(v[k]);
+        const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+        // d/d(axis): (corner with the axis bit) - (corner without), weighted by the other two axes
+        const float ax[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
+        const float ay[4] = {wx0 * wz0, c.wx * wz0, wx0 * c.wz, c.wx * c.wz};
+        const float az[4] = {wx0 * wy0, c.wx * wy0, wx0 * c.wy, c.wx * c.wy};
+        const float gx0 = ax[0] * (f[1].x - f[0].x) + ax[1] * (f[3].x - f[2].x) + ax[2] * (f[5].x - f[4].x) + ax[3] * (f[7].x - f[6].x);
+        const float gx1 = ax[0] * (f[1].y - f[0].y) + ax[1] * (f[3].y - f[2].y) + ax[2] * (f[5].y - f[4].y) + ax[3] * (f[7].y - f[6].y);
+        const float gy0 = ay[0] * (f[2].x - f[0].x) + ay[1] * (f[3].x - f[1].x) + ay[2] * (f[6].x - f[4].x) + ay[3] * (f[7].x - f[5].x);
+        const float gy1 = ay[0] * (f[2].y - f[0].y) + ay[1] * (f[3].y - f[1].y) + ay[2] * (f[6].y - f[4].y) + ay[3] * (f[7].y - f[5].y);
+        const float gz0 = az[0] * (f[4].x - f[0].x) + az[1] * (f[5].x - f[1].x) + az[2] * (f[6].x - f[2].x) + az[3] * (f[7].x - f[3].x);
+        const float gz1 = az[0] * (f[4].y - f[0].y) + az[1] * (f[5].y - f[1].y) + az[2] * (f[6].y - f[2].y) + az[3] * (f[7].y - f[3].y);
+        __half2* __restrict__ o = dydx + (size_t)level * 3 * N + i;
+        o[0] = __floats2half2_rn(gx0, gx1);
+        o[N] = __floats2half2_rn(gy0, gy1);
+        o[2 * (size_t)N] = __floats2half2_rn(gz0, gz1);
     }
     if (indices) {
 #pragma unroll
@@ -1055,6 +1080,41 @@ k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     atomicAdd(dx + 3 * (size_t)i + 2, gz);
 }
 
+// Input backward from the dy/dx the forward stored: one thread per sample streams L x (dy, 3 x dydx) half2 values,
+// all coalesced.  dx[i][axis] (+)= sum_l scale_l * (dy_l . dydx_l,axis).
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(256)
+k_grid_bwd_input_dydx(NvoGridLevels g, uint32_t N, const __half2* __restrict__ dydx, const DY2* __restrict__ dy,
+                      float* __restrict__ dx, int accumulate) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (uint32_t level = 0; level < g.n_levels; ++level) {
+        const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+        float2 d;
+        if constexpr (sizeof(DY2) == 4) {
+            d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
+        } else {
+            d = *reinterpret_cast<const float2*>(&d2);
+        }
+        const __half2* __restrict__ p = dydx + (size_t)level * 3 * N + i;
+        const float2 gx = __half22float2(p[0]), gy = __half22float2(p[N]), gz = __half22float2(p[2 * (size_t)N]);
+        const float sc = g.scale[level];
+        a0 = fmaf(sc, d.x * gx.x + d.y * gx.y, a0);
+        a1 = fmaf(sc, d.x * gy.x + d.y * gy.y, a1);
+        a2 = fmaf(sc, d.x * gz.x + d.y * gz.y, a2);
+    }
+    float* __restrict__ o = dx + 3 * (size_t)i;
+    if (accumulate) {
+        a0 += o[0];
+        a1 += o[1];
+        a2 += o[2];
+    }
+    o[0] = a0;
+    o[1] = a1;
+    o[2] = a2;
+}
+
 // dx[e] (+)= sum over levels of partial[level][e], e over N * 3 floats
 __global__ void __launch_bounds__(256)
 k_sum_levels(uint32_t n_levels, size_t n, const float* __restrict__ partial, float* __restrict__ dx, int accumulate) {
@@ -1071,20 +1131,22 @@ k_sum_levels(uint32_t n_levels, size_t n, const float* __restrict__ partial, flo
 // host launchers (C++ linkage, used by api.cpp and the fused pipeline)
 // ---------------------------------------------------------------------------------------------
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
-                        const void* table_half, void* out_half, bool soa, uint32_t* indices) {
+                        const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half) {
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     const uint32_t tiles = nvo_div_up(N, kGridBlock);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
+#define NVO_LAUNCH_FWD(SOA_, DYDX_)                                                                   \
+    NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
+               (__half2*)out_half, indices, (__half2*)dydx_half)
     if (soa) {
-        NVO_LAUNCH(k_grid_fwd<true>, grid, block, 0, stream, g, N, x,
-                           (const __half2*)table_half, (__half2*)out_half, indices);
+        if (dydx_half) NVO_LAUNCH_FWD(true, true); else NVO_LAUNCH_FWD(true, false);
     } else {
-        NVO_LAUNCH(k_grid_fwd<false>, grid, block, 0, stream, g, N, x,
-                           (const __half2*)table_half, (__half2*)out_half, indices);
+        if (dydx_half) NVO_LAUNCH_FWD(false, true); else NVO_LAUNCH_FWD(false, false);
     }
+#undef NVO_LAUNCH_FWD
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
@@ -1514,6 +1576,24 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         if (dy_is_float) NVO_LAUNCH_AT(false, float2); else NVO_LAUNCH_AT(false, __half2);
     }
 #undef NVO_LAUNCH_AT
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
+                                   const void* dy, bool dy_is_float, bool soa, float* dx, bool zero_dx) {
+    if (N == 0) return NVO_OK;
+    NVO_PROF(stream, "grid_bwd_input_dydx[L%u]", g.n_levels);
+    const dim3 grid(nvo_div_up(N, 256)), block(256);
+#define NVO_LAUNCH_IN(SOA_, T_)                                                                              \
+    NVO_LAUNCH((k_grid_bwd_input_dydx<SOA_, T_>), grid, block, 0, stream, g, N, (const __half2*)dydx_half,   \
+               (const T_*)dy, dx, zero_dx ? 0 : 1)
+    if (soa) {
+        if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);
+    } else {
+        if (dy_is_float) NVO_LAUNCH_IN(false, float2); else NVO_LAUNCH_IN(false, __half2);
+    }
+#undef NVO_LAUNCH_IN
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

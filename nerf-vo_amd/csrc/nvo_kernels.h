@@ -77,8 +77,12 @@ void nvo_grid_stream_destroy(NvoGridStream* st);
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
                                const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
 void nvo_grid_slices_destroy(NvoGridSlices* s);
+// dydx_half (optional): [L][3][N] half2, d(out)/d(cell coordinate) for nvo_grid_bwd_input_dydx_launch
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
-                        const void* table_half, void* out_half, bool soa, uint32_t* indices);
+                        const void* table_half, void* out_half, bool soa, uint32_t* indices,
+                        void* dydx_half = nullptr);
+int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
+                                   const void* dy, bool dy_is_float, bool soa, float* dx, bool zero_dx);
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
                         uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
                         float* grad, int mode);

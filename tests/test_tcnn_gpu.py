@@ -194,6 +194,47 @@ def test_grid_bwd_propagates_nonfinite(device, cfg, bad_value):
     enc.native_tcnn_module.set_option("grid_acc_bits", 64)
 
 
+@pytest.mark.parametrize("kind", ["encoding", "network_with_input_encoding"])
+@pytest.mark.parametrize("cfg", [MAIN, PROP1], ids=["main", "prop1"])
+def test_stored_input_gradients_match_gather(device, cfg, kind):
+    """Option prepare_input_gradients (tcnn's forward flag): the forward stores d(encoded)/d(position) as fp16 in cell
+    units and the input backward streams it.  Same outputs bit for bit, same parameter gradients; the input gradient
+    equals the gather form up to the fp16 rounding of the stored derivative (2^-11 per level term; the gather form
+    itself is checked against the oracle in test_grid_encoding_fwd_bwd): atol 2e-3 * max|dx|, rtol 2e-3."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    if kind == "encoding":
+        m = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
+        n_out = 2 * cfg["n_levels"]
+    else:
+        m = tcnn.NetworkWithInputEncoding(3, 16, _enc_cfg(cfg), {"otype": "FullyFusedMLP", "activation": "ReLU",
+                                                                 "output_activation": "None", "n_neurons": 64,
+                                                                 "n_hidden_layers": 1}).to(device)
+        n_out = 16
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        m.params.copy_(((torch.rand(m.params.numel(), generator=g) - 0.5) * 0.8).to(device))
+    n = 30000 + 37  # ragged
+    x0 = torch.rand(n, 3, generator=g)
+    x0[:4] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [1.0, 0.0, 0.25]])
+    dy = torch.randn(n, n_out, generator=g).to(device)
+    res = []
+    for stored in (0, 1, 0):
+        m.native_tcnn_module.set_option("prepare_input_gradients", stored)
+        x = x0.to(device).requires_grad_(True)
+        m.params.grad = None
+        y = m(x)
+        (y.float() * dy).sum().backward()
+        res.append((y.detach().clone(), x.grad.clone(), m.params.grad.clone()))
+    (y0, dx0, dp0), (y1, dx1, dp1), (y2, dx2, _) = res
+    assert torch.equal(y0, y1), "the option must not change the forward output"
+    # (parameter gradients: same kernels; the default slice-owner scatter is reproducible to fp32 rounding only)
+    _assert_close(dp1, dp0, rtol=1e-3, atol_scale=2e-4, what="dL/dparams with the option on")
+    assert torch.equal(dx0, dx2), "switching the option off again must restore the gather form exactly"
+    _assert_close(dx1, dx0, rtol=2e-3, atol_scale=2e-3, what="dL/dx from stored dy/dx vs gather")
+    assert float(dx0.abs().max()) > 0
+
+
 def test_grid_bwd_lds_matches_atomic_large(device):
     """Both scatter forms at the full main-field batch (196 608 samples): linearity + agreement."""
     import nerf_vo_amd.tinycudann as tcnn
