@@ -223,10 +223,12 @@ def main() -> None:
     # per-kernel durations are taken with every kernel alone on the GPU: the timed region above overlaps the
     # proposal backward with the main-field backward on a second stream, which would inflate both here
     overlap_saved, cfg.overlap_proposal_backward = cfg.overlap_proposal_backward, False
+    overlap_pose_saved, cfg.overlap_pose_backward = cfg.overlap_pose_backward, False
     for _ in range(prof_steps):  # every rank runs them (the all-reduce is collective)
         step()
     use_graph = use_graph_saved
     cfg.overlap_proposal_backward = overlap_saved
+    cfg.overlap_pose_backward = overlap_pose_saved
     fence()
     ms_prof = (time.perf_counter() - tp0) / prof_steps * 1e3
     if rank == 0:

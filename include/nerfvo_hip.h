@@ -91,6 +91,15 @@ int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
 int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
             const void* params, const void* output, const void* dL_doutput, void* ctx,
             float* dL_dinput, float* dL_dparams);
+/* nvo_bwd with the two halves of a NetworkWithInputEncoding backward on two streams: after the network
+ * backward, dL_dinput is produced in `stream` order (complete for later work on `stream` when the call returns)
+ * while the parameter backward of the input encoding -- the long scatter -- is enqueued on `params_stream`,
+ * forked from `stream` at that point.  The CALLER joins: whatever consumes dL_dparams must wait for
+ * `params_stream`.  Lets the consumers of dL_dinput (pose / normal gradient chains) run beside the scatter.
+ * params_stream == NULL or == stream, or a module without an input encoding: identical to nvo_bwd. */
+int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream, uint32_t batch,
+                 const float* input, const void* params, const void* output, const void* dL_doutput, void* ctx,
+                 float* dL_dinput, float* dL_dparams);
 
 /* Parity/debug: the per-level table geometry and the 8 corner indices the encoder uses.
  * levels_out: host uint32 [n_levels][4] = {offset, size, resolution, hashed}; scales_out: host

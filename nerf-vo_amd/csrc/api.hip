@@ -536,8 +536,17 @@ struct NwieModule : nvo_module_s {
         if (recompute_hidden) a.hidden = nullptr;
         return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
     }
+    hipEvent_t ev_fork = nullptr;  // nvo_bwd_fork: network backward done -> the encoding's parameter backward may start
+    ~NwieModule() override {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
             const void* dout, void* ctx, float* din, float* dparams) override {
+        return bwd_on(s, s, B, in, params, out, dout, ctx, din, dparams);
+    }
+    // sp: stream of the encoding's parameter backward (== s: everything in order on one stream)
+    int bwd_on(hipStream_t s, hipStream_t sp, uint32_t B, const float* in, const void* params, const void* out,
+               const void* dout, void* ctx, float* din, float* dparams) {
         NVO_REQUIRE(ctx != nullptr, "NetworkWithInputEncoding.bwd needs the ctx of the matching fwd");
         char* c = (char*)ctx;
         void* encoded = c;
@@ -556,7 +565,12 @@ struct NwieModule : nvo_module_s {
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {
-            rc = enc->bwd_params(s, B, in, dencoded, true, dparams + net->n_params);
+            if (sp != s) {  // fork (the first call happens in an eager warm-up step, never under graph capture)
+                if (!ev_fork) NVO_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                NVO_CHECK_HIP(hipEventRecord(ev_fork, s));
+                NVO_CHECK_HIP(hipStreamWaitEvent(sp, ev_fork, 0));
+            }
+            rc = enc->bwd_params(sp, B, in, dencoded, true, dparams + net->n_params);
             if (rc) return rc;
         }
         if (din) {
@@ -691,6 +705,18 @@ int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
     NVO_REQUIRE((batch & 15u) == 0, "bwd: batch (%u) must be a multiple of 16", batch);
     return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput,
                   dL_dparams);
+}
+
+int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream, uint32_t batch,
+                 const float* input, const void* params, const void* output, const void* dL_doutput, void* ctx,
+                 float* dL_dinput, float* dL_dparams) {
+    NVO_REQUIRE(m && dL_doutput && (input || batch == 0), "bwd_fork: NULL argument");
+    NVO_REQUIRE((batch & 15u) == 0, "bwd_fork: batch (%u) must be a multiple of 16", batch);
+    auto* n = dynamic_cast<NwieModule*>(m);
+    if (!n || !params_stream || params_stream == stream || !dL_dparams || !dL_dinput)
+        return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput, dL_dparams);
+    return n->bwd_on((hipStream_t)stream, (hipStream_t)params_stream, batch, input, params, output, dL_doutput, ctx,
+                     dL_dinput, dL_dparams);
 }
 
 static GridModule* as_grid(nvo_module_t m) {

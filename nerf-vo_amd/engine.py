@@ -98,6 +98,8 @@ class EngineConfig:
     # need gradients (pose optimisation, analytic normals); the input backward then streams it (112 -> ~20 us) instead
     # of gathering the corners again.  None = on iff optimize_poses.
     store_input_gradients: bool | None = None
+    # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
+    overlap_pose_backward: bool = True
     seed: int = 1337
 
 
@@ -185,6 +187,7 @@ class NerfactoEngine:
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
         self._graphs = {}
         self._side_stream = None
+        self._scatter_stream = None
         self._pix_scale = None
         self.corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
         self.d_corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
@@ -506,10 +509,22 @@ class NerfactoEngine:
         if pose:
             ws["d_sh"].zero_()
         _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
-        _call("nvo_bwd", self.base_net.handle, stream, R * self.levels[km], _ptr(ws[f"x{km}"]),
-              self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
-              _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]) if pose else None,
-              self._param_ptr("field.base", self.grads))
+        scatter_stream = None
+        if pose and cfg.overlap_pose_backward:
+            # the pose chain below only needs dL/dx of the main field: the long parameter scatter of its hash grid
+            # runs beside it on another stream (forked inside the call, joined at the end of this function)
+            if self._scatter_stream is None:
+                self._scatter_stream = torch.cuda.Stream(device=self.device)
+            scatter_stream = self._scatter_stream
+            _call("nvo_bwd_fork", self.base_net.handle, stream, C.c_void_p(scatter_stream.cuda_stream),
+                  R * self.levels[km], _ptr(ws[f"x{km}"]), self._param_ptr("field.base", self.params_half),
+                  _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]), _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]),
+                  self._param_ptr("field.base", self.grads))
+        else:
+            _call("nvo_bwd", self.base_net.handle, stream, R * self.levels[km], _ptr(ws[f"x{km}"]),
+                  self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
+                  _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]) if pose else None,
+                  self._param_ptr("field.base", self.grads))
         if update_proposals and side is None:
             self._proposal_backward(ws, has_depth, pose, stream)
         if side is not None:
@@ -517,6 +532,8 @@ class NerfactoEngine:
                 torch.cuda.current_stream(self.device).wait_stream(st)  # join
         if pose:
             self._pose_backward(ws, update_proposals, stream)
+        if scatter_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(scatter_stream)  # join
         return update_proposals
 
     def _proposal_backward(self, ws, has_depth: bool, pose: bool, stream, levels=None) -> None:
