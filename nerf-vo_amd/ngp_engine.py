@@ -89,6 +89,10 @@ class NgpEngine:
                    "n_hidden_layers": 1}
         self.density_net = _create("nvo_create_network_with_input_encoding", 3, 16,
                                    json.dumps(cfg.grid.tcnn_dict()).encode(), json.dumps(net_cfg).encode())
+        # streamed binned scatter for the 2^19 hashed levels (as the nerfacto main field: 650 -> ~250 us at 2^18
+        # samples); with extrinsics optimisation the forward stores d(encoded)/d(position) for a streamed input backward
+        self.density_net.set_option("grid_bwd_mode", 3)
+        self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
         self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
         self.n_density_mlp = 64 * 32 + 16 * 64
         self.segments = {"density": (0, self.density_net.n_params), "rgb": (self.density_net.n_params, self.n_rgb)}

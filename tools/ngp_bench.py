@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Step time of the occupancy-grid ("instant-ngp") trainer through the pyngp facade on the synthetic room.
+python tools/ngp_bench.py [--steps 300] [--extrinsics 0|1]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+entry.build()
+from nerf_vo_amd import pyngp  # noqa: E402
+from nerf_vo_amd.mapping.dataset import opencv_to_opengl  # noqa: E402
+from nerf_vo_amd.synthetic import make_sequence  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--keyframes", type=int, default=48)
+    ap.add_argument("--extrinsics", type=int, default=1)
+    ap.add_argument("--profile", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    H, W = 272, 480
+    seq = make_sequence(a.keyframes, H, W, device=dev, scene_scale=0.2)
+    poses = seq["camera_extrinsics"].clone()
+    poses[:, :3, 3] += 0.5
+    tb = pyngp.Testbed(pyngp.TestbedMode.Nerf, 0)
+    tb.create_empty_nerf_dataset(n_images=a.keyframes, nerf_scale=1.0, nerf_offset=np.zeros(3), aabb_scale=4)
+    tb.reload_network_from_file("")
+    tb.shall_train = True
+    tb.nerf.training.optimize_extrinsics = bool(a.extrinsics)
+    color = seq["frames_color"].permute(0, 2, 3, 1)
+    color = torch.cat([color, torch.ones_like(color[..., :1])], dim=3)
+    depth = seq["frames_depth"].permute(0, 2, 3, 1)
+    tb.nerf.training.update_training_images(
+        frame_ids=list(range(a.keyframes)), poses=opencv_to_opengl(poses)[:, :3], images=color.contiguous(),
+        depths=depth.contiguous(), depths_cov=torch.ones_like(depth), resolution=np.array([W, H]),
+        principal_point=seq["camera_intrinsics"][0, 2:].cpu().numpy(), focal_length=seq["camera_intrinsics"][0, :2].cpu().numpy())
+    for _ in range(a.warmup):
+        tb.frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tb.frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    eng = tb._engine
+    if a.profile:
+        import ctypes as C
+
+        from nerf_vo_amd import _lib
+        lib = _lib.lib()
+        lib.nvo_profile_enable(1)
+        for _ in range(32):
+            tb.frame()
+        torch.cuda.synchronize()
+        need = lib.nvo_profile_summary(None, 0)
+        buf = C.create_string_buffer(int(need) + 16)
+        lib.nvo_profile_summary(buf, len(buf))
+        lib.nvo_profile_enable(0)
+        rows = []
+        for line in buf.value.decode().strip().splitlines():
+            name, cnt, total = line.rsplit(",", 2)
+            rows.append((name, int(cnt), float(total)))
+        rows.sort(key=lambda r: -r[2])
+        tot = sum(r[2] for r in rows)
+        print(f"kernel time {tot / 32:.3f} ms/step over 32 steps")
+        for name, cnt, total in rows[:24]:
+            print(f"  {name:30s} launches {cnt:4d} avg {total / cnt * 1e3:9.1f} us  {100 * total / tot:5.1f} %")
+    n = eng.samples_last_step()
+    print(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
+          f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
+
+
+if __name__ == "__main__":
+    main()
