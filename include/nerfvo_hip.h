@@ -397,6 +397,24 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
                   const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, uint32_t step, float grad_scale, float weight_decay,
                   const uint32_t* skip_flag, const float* hyper_dev);
+/* The same update for up to 4 parameter groups of ONE flat buffer in one launch (the optimisers of
+ * /root/reference/nerf_vo/mapping/nerfstudio.py:84-100 differ only in learning rate and step count).
+ * offset / n are in elements of the flat buffers; hyper_dev: optional device float[3] = {lr, 1 - beta1^t,
+ * sqrt(1 - beta2^t)} that overrides lr / step (graph replay). */
+typedef struct nvo_adam_group {
+    uint64_t offset, n;
+    float lr;
+    uint32_t step;
+    const float* hyper_dev;
+} nvo_adam_group;
+int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                         void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
+                         float beta1, float beta2, float eps, float grad_scale, float weight_decay,
+                         const uint32_t* skip_flag);
+/* nvo_nonfinite_flag over up to 4 ranges (element offsets / sizes, host arrays) of one gradient buffer in one
+ * launch; the flag is reset first. */
+int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                              const void* grads, int grads_are_half, uint32_t* flag);
 /* grads: device float[n], or device fp16[n] when grads_are_half != 0 (the buffer a compressed
  * all-reduce leaves behind: no cast-back pass). */
 /* hyper_dev (nullable): device float[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} overriding the

@@ -60,6 +60,12 @@ class ColorArgs(C.Structure):
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p)]
 
 
+class AdamGroup(C.Structure):
+    """nvo_adam_group (include/nerfvo_hip.h)"""
+    _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
+                ("hyper_dev", C.c_void_p)]
+
+
 class DepthAlignArgs(C.Structure):
     """mirror of nvo_depth_align_args"""
     _fields_ = [("K", _u32), ("M", _u32), ("P", _u32), ("H", _u32), ("W", _u32), ("patches", _p), ("noise", _p),
@@ -144,6 +150,8 @@ _SIGNATURES = {
     "nvo_write_floats": (_int, [_p, _p, _u32, _p]),
     "nvo_nonfinite_flag": (_int, [_p, _u64, _p, _int, _p]),
     "nvo_nonfinite_flag_or": (_int, [_p, _u64, _p, _int, _p]),
+    "nvo_adam_step_groups": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p]),
+    "nvo_nonfinite_flag_ranges": (_int, [_p, _u32, _p, _p, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
 }
 

@@ -31,18 +31,11 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, 
 // The body works on 4 consecutive parameters per thread through 16-byte accesses when the range is
 // 16-byte aligned (HBM-bound kernel: 28 B + 2 B per parameter), scalar otherwise / for the tail.
 template <typename GT>
-__global__ void __launch_bounds__(256)
-k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
-       float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag,
-       const float* __restrict__ hyper_dev, int vec4) {
-    if (skip_flag && *skip_flag) return;
-    if (hyper_dev) {  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} kept in device memory (graph replay)
-        h.lr = hyper_dev[0];
-        h.bias1 = hyper_dev[1];
-        h.bias2_sqrt = hyper_dev[2];
-    }
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16,
+                                           const GT* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                           const AdamHyper& h, int vec4, uint32_t block_id, uint32_t n_blocks) {
+    const uint64_t stride = (uint64_t)n_blocks * blockDim.x;
+    const uint64_t tid = (uint64_t)block_id * blockDim.x + threadIdx.x;
     uint64_t done = 0;
     if (vec4) {
         const uint64_t n4 = n >> 2;
@@ -77,16 +70,63 @@ k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* 
     }
 }
 
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
+       float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag,
+       const float* __restrict__ hyper_dev, int vec4) {
+    if (skip_flag && *skip_flag) return;
+    if (hyper_dev) {  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} kept in device memory (graph replay)
+        h.lr = hyper_dev[0];
+        h.bias1 = hyper_dev[1];
+        h.bias2_sqrt = hyper_dev[2];
+    }
+    adam_range<GT>(n, p, p16, g, m, v, h, vec4, blockIdx.x, gridDim.x);
+}
+
+// Several parameter groups (own range, learning rate and step count each) of ONE flat buffer in one launch: the
+// groups of a training step differ only in those scalars, and a launch per group costs ~8 us of dispatch for what
+// may be a thousand parameters (the camera group).  Blocks [first_block[k], first_block[k + 1]) serve group k.
+constexpr uint32_t kAdamMaxGroups = 4;
+struct AdamGroups {
+    uint32_t n_groups;
+    uint32_t first_block[kAdamMaxGroups + 1];
+    uint64_t offset[kAdamMaxGroups], n[kAdamMaxGroups];
+    float lr[kAdamMaxGroups], bias1[kAdamMaxGroups], bias2_sqrt[kAdamMaxGroups];
+    const float* hyper_dev[kAdamMaxGroups];
+    int vec4[kAdamMaxGroups];
+};
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_adam_groups(AdamGroups gr, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
+              float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag) return;
+    uint32_t k = 0;
+    while (k + 1 < gr.n_groups && blockIdx.x >= gr.first_block[k + 1]) ++k;
+    h.lr = gr.lr[k];
+    h.bias1 = gr.bias1[k];
+    h.bias2_sqrt = gr.bias2_sqrt[k];
+    if (gr.hyper_dev[k]) {
+        h.lr = gr.hyper_dev[k][0];
+        h.bias1 = gr.hyper_dev[k][1];
+        h.bias2_sqrt = gr.hyper_dev[k][2];
+    }
+    const uint64_t o = gr.offset[k];
+    adam_range<GT>(gr.n[k], p + o, p16 ? p16 + o : nullptr, g + o, m + o, v + o, h, gr.vec4[k],
+                   blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k]);
+}
+
 // A pure streaming read: 16-byte loads, four of them in flight per thread (the scalar grid-stride form ran at
 // 2.6 TB/s).  Non-finite <=> exponent field all ones; checked on the raw bits.
 template <typename GT>
-__global__ void __launch_bounds__(256)
-k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
+__device__ __forceinline__ bool nonfinite_range(uint64_t n, const GT* __restrict__ g, uint32_t block_id,
+                                                uint32_t n_blocks) {
     constexpr uint32_t kPer = 16 / sizeof(GT);  // elements per 16-byte load
     const uint64_t n_vec = (((uintptr_t)g & 15u) == 0u) ? n / kPer : 0u;
     const uint4* __restrict__ gv = reinterpret_cast<const uint4*>(g);
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)n_blocks * blockDim.x;
+    const uint64_t tid = (uint64_t)block_id * blockDim.x + threadIdx.x;
     bool bad = false;
     auto check = [&](uint4 q) {
         if constexpr (sizeof(GT) == 4) {
@@ -112,6 +152,30 @@ k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ fl
         const float x = load_grad(g, j);
         bad = bad || !(fabsf(x) <= 3.0e38f);
     }
+    return bad;
+}
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_nonfinite_flag(uint64_t n, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
+    const bool bad = nonfinite_range<GT>(n, g, blockIdx.x, gridDim.x);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+struct FlagRanges {
+    uint32_t n_ranges;
+    uint32_t first_block[kAdamMaxGroups + 1];
+    uint64_t offset[kAdamMaxGroups], n[kAdamMaxGroups];
+};
+
+// several ranges of one gradient buffer in one launch; RESETS the flag first is the launcher's job
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_nonfinite_flag_ranges(FlagRanges r, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
+    uint32_t k = 0;
+    while (k + 1 < r.n_ranges && blockIdx.x >= r.first_block[k + 1]) ++k;
+    const bool bad = nonfinite_range<GT>(r.n[k], g + r.offset[k], blockIdx.x - r.first_block[k],
+                                         r.first_block[k + 1] - r.first_block[k]);
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
@@ -171,6 +235,84 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     } else {
         NVO_LAUNCH(k_adam<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
                    (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                         void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
+                         float beta1, float beta2, float eps, float grad_scale, float weight_decay,
+                         const uint32_t* skip_flag) {
+    NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq && groups, "adam_step_groups: NULL argument");
+    NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "adam_step_groups: 1..%u groups (got %u)", kAdamMaxGroups,
+                n_groups);
+    NVO_PROF(stream, "adam");
+    AdamGroups gr{};
+    uint32_t k = 0, blocks_total = 0;
+    const size_t gsz = grads_are_half ? 2 : 4;
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        if (groups[i].n == 0) continue;
+        NVO_REQUIRE(groups[i].step >= 1, "adam_step_groups: step counts from 1");
+        const uint64_t o = groups[i].offset;
+        gr.offset[k] = o;
+        gr.n[k] = groups[i].n;
+        gr.lr[k] = groups[i].lr;
+        gr.bias1[k] = 1.f - powf(beta1, (float)groups[i].step);
+        gr.bias2_sqrt[k] = sqrtf(1.f - powf(beta2, (float)groups[i].step));
+        gr.hyper_dev[k] = groups[i].hyper_dev;
+        const uintptr_t align = (uintptr_t)(params + o) | (uintptr_t)(exp_avg + o) | (uintptr_t)(exp_avg_sq + o);
+        gr.vec4[k] = (align & 15u) == 0 && (!params_half || (((uintptr_t)params_half + 2 * o) & 7u) == 0) &&
+                     ((((uintptr_t)grads + gsz * o) & (grads_are_half ? 7u : 15u)) == 0);
+        uint32_t blocks = nvo_div_up(groups[i].n, 256 * 8);
+        if (blocks > 4096) blocks = 4096;
+        gr.first_block[k] = blocks_total;
+        blocks_total += blocks;
+        ++k;
+    }
+    if (k == 0) return NVO_OK;
+    gr.n_groups = k;
+    for (uint32_t i = k; i <= kAdamMaxGroups; ++i) gr.first_block[i] = blocks_total;
+    AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
+    if (grads_are_half) {
+        NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
+                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag);
+    } else {
+        NVO_LAUNCH(k_adam_groups<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
+                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                              const void* grads, int grads_are_half, uint32_t* flag) {
+    NVO_REQUIRE(grads && flag && offsets && sizes, "nonfinite_flag_ranges: NULL argument");
+    NVO_REQUIRE(n_ranges >= 1 && n_ranges <= kAdamMaxGroups, "nonfinite_flag_ranges: 1..%u ranges (got %u)",
+                kAdamMaxGroups, n_ranges);
+    NVO_PROF(stream, "nonfinite_flag");
+    if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
+    FlagRanges r{};
+    uint32_t k = 0, blocks_total = 0;
+    for (uint32_t i = 0; i < n_ranges; ++i) {
+        if (sizes[i] == 0) continue;
+        r.offset[k] = offsets[i];
+        r.n[k] = sizes[i];
+        uint32_t blocks = nvo_div_up(sizes[i], 256 * 8);
+        if (blocks > 2048) blocks = 2048;
+        r.first_block[k] = blocks_total;
+        blocks_total += blocks;
+        ++k;
+    }
+    if (k == 0) return NVO_OK;
+    r.n_ranges = k;
+    for (uint32_t i = k; i <= kAdamMaxGroups; ++i) r.first_block[i] = blocks_total;
+    if (grads_are_half) {
+        NVO_LAUNCH(k_nonfinite_flag_ranges<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r,
+                   (const _Float16*)grads, flag);
+    } else {
+        NVO_LAUNCH(k_nonfinite_flag_ranges<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r,
+                   (const float*)grads, flag);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -366,7 +366,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {
             const float2 d = dv[u];
-            bad |= !(fabsf(d.x) < INFINITY) | !(fabsf(d.y) < INFINITY);
+            bad = bad || !(fabsf(d.x) < INFINITY) || !(fabsf(d.y) < INFINITY);
             if (d.x == 0.f && d.y == 0.f) continue;
             const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
             const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
@@ -658,7 +658,7 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
             const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
                             ((k & 4u) ? c.wz : 1.f - c.wz);
             if (r0 + u * kLdsBwdBlock < end) {  // idx / kBinSlice == slice by construction of the bins
-                bad |= !(fabsf(dv[u].x) < INFINITY) | !(fabsf(dv[u].y) < INFINITY);
+                bad = bad || !(fabsf(dv[u].x) < INFINITY) || !(fabsf(dv[u].y) < INFINITY);
                 AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y, AccScale{});
             }
         }

@@ -613,9 +613,12 @@ class NerfactoEngine:
                 merged[-1][1] = max(merged[-1][1], hi)
             else:
                 merged.append([lo, hi])
-        for i, (lo, hi) in enumerate(merged):
-            _call("nvo_nonfinite_flag" if i == 0 else "nvo_nonfinite_flag_or", stream, hi - lo,
-                  C.c_void_p(gbuf.data_ptr() + lo * gsz), ghalf, _ptr(self.skip_flag))
+        # one launch for the flag (all active ranges) and one for Adam (all active groups: they differ in learning
+        # rate and step count only)
+        offs = (C.c_uint64 * len(merged))(*[lo for lo, _ in merged])
+        sizes = (C.c_uint64 * len(merged))(*[hi - lo for lo, hi in merged])
+        _call("nvo_nonfinite_flag_ranges", stream, len(merged), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        batch = []
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:
                 continue
@@ -625,13 +628,13 @@ class NerfactoEngine:
             hyper = None
             if from_device_scalars:
                 gi = self._GROUP_ORDER.index(g)
-                hyper = C.c_void_p(self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi))
-            esz = 4
-            _call("nvo_adam_step", stream, hi - lo, C.c_void_p(self.params.data_ptr() + lo * esz),
-                  C.c_void_p(self.params_half.data_ptr() + lo * 2), C.c_void_p(gbuf.data_ptr() + lo * gsz), ghalf,
-                  C.c_void_p(self.exp_avg.data_ptr() + lo * esz), C.c_void_p(self.exp_avg_sq.data_ptr() + lo * esz),
-                  self._group_lr(g), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, max(self.opt_steps[g], 1),
-                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), hyper)
+                hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi)
+            batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=max(self.opt_steps[g], 1),
+                                        hyper_dev=hyper))
+        arr = (_lib.AdamGroup * len(batch))(*batch)
+        _call("nvo_adam_step_groups", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+              ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
 
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step

@@ -235,6 +235,71 @@ def test_adam_matches_torch_semantics(device):
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
+def test_grouped_adam_equals_per_group_launches(device):
+    """nvo_adam_step_groups / nvo_nonfinite_flag_ranges (one launch for the groups of a step) against one
+    nvo_adam_step / nvo_nonfinite_flag(_or) launch per group: bit-identical parameters, moments and fp16 copies,
+    including odd (unaligned) group boundaries, device-side hyper-parameters and the skip flag."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import _call, _ptr, _stream
+
+    st = _stream(device)
+    n = 300_007
+    bounds = [(0, 250_000), (250_000, 299_001), (299_001, 300_007)]  # the last two starts are not 16-byte aligned
+    lrs, steps = (1e-2, 5e-3, 1e-4), (7, 3, 11)
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g).to(device)
+    m0, v0 = (torch.rand(n, generator=g) * 0.1).to(device), (torch.rand(n, generator=g) * 0.01).to(device)
+    grads = (torch.randn(n, generator=g) * 128.0).to(device)
+    hyper = torch.tensor([3e-3, 1 - 0.9 ** 5, (1 - 0.999 ** 5) ** 0.5], device=device)  # overrides group 1
+    for half in (0, 1):
+        gbuf = grads.half() if half else grads
+        esz = 2 if half else 4
+        out = []
+        for grouped in (False, True):
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+            p16 = torch.zeros(n, dtype=torch.float16, device=device)
+            flag = torch.ones(1, dtype=torch.int32, device=device)  # must be reset by the first flag launch
+            if grouped:
+                offs = (C.c_uint64 * 2)(0, bounds[2][0])
+                sizes = (C.c_uint64 * 2)(bounds[1][1], bounds[2][1] - bounds[2][0])
+                _call("nvo_nonfinite_flag_ranges", st, 2, offs, sizes, _ptr(gbuf), half, _ptr(flag))
+                arr = (_lib.AdamGroup * 3)(*[
+                    _lib.AdamGroup(offset=lo, n=hi - lo, lr=lrs[i], step=steps[i],
+                                   hyper_dev=hyper.data_ptr() if i == 1 else None)
+                    for i, (lo, hi) in enumerate(bounds)])
+                _call("nvo_adam_step_groups", st, 3, arr, _ptr(p), _ptr(p16), _ptr(gbuf), half, _ptr(m), _ptr(v), 0.9,
+                      0.999, 1e-15, 1.0 / 128.0, 0.0, _ptr(flag))
+            else:
+                _call("nvo_nonfinite_flag", st, bounds[1][1], _ptr(gbuf), half, _ptr(flag))
+                _call("nvo_nonfinite_flag_or", st, bounds[2][1] - bounds[2][0],
+                      C.c_void_p(gbuf.data_ptr() + esz * bounds[2][0]), half, _ptr(flag))
+                for i, (lo, hi) in enumerate(bounds):
+                    _call("nvo_adam_step", st, hi - lo, C.c_void_p(p.data_ptr() + 4 * lo), C.c_void_p(p16.data_ptr() + 2 * lo),
+                          C.c_void_p(gbuf.data_ptr() + esz * lo), half, C.c_void_p(m.data_ptr() + 4 * lo),
+                          C.c_void_p(v.data_ptr() + 4 * lo), lrs[i], 0.9, 0.999, 1e-15, steps[i], 1.0 / 128.0, 0.0, _ptr(flag),
+                          _ptr(hyper) if i == 1 else None)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 0
+            out.append((p, m, v, p16))
+        for a, b in zip(*out):
+            assert torch.equal(a, b)
+        assert not torch.equal(out[0][0], p0)
+    # a non-finite value in the second range raises the flag and the grouped step becomes a no-op
+    bad = grads.clone()
+    bad[bounds[2][0] + 5] = float("nan")
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    offs, sizes = (C.c_uint64 * 2)(0, bounds[2][0]), (C.c_uint64 * 2)(bounds[1][1], bounds[2][1] - bounds[2][0])
+    _call("nvo_nonfinite_flag_ranges", st, 2, offs, sizes, _ptr(bad), 0, _ptr(flag))
+    p = p0.clone()
+    arr = (_lib.AdamGroup * 1)(_lib.AdamGroup(offset=0, n=n, lr=1e-2, step=1, hyper_dev=None))
+    _call("nvo_adam_step_groups", st, 1, arr, _ptr(p), None, _ptr(bad), 0, _ptr(m0.clone()), _ptr(v0.clone()), 0.9, 0.999,
+          1e-15, 1.0 / 128.0, 0.0, _ptr(flag))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and torch.equal(p, p0)
+
+
 def test_normal_supervision_matches_oracle(device):
     """monosdf normal loss on the analytic normals (reference hook nerf_vo/mapping/nerfstudio_utils.py:337-350;
     enhancement modes containing 'normal').  Every other loss multiplier is zeroed so that the gradient
