@@ -410,11 +410,14 @@ typedef struct nvo_adam_group {
 int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
                          void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
                          float beta1, float beta2, float eps, float grad_scale, float weight_decay,
-                         const uint32_t* skip_flag);
-/* nvo_nonfinite_flag over up to 4 ranges (element offsets / sizes, host arrays) of one gradient buffer in one
- * launch; the flag is reset first. */
+                         const uint32_t* skip_flags);
+/* skip_flags: device uint32 [n_groups] or NULL; group i is a no-op when skip_flags[i] != 0 -- GradScaler.step
+ * decides per optimiser (nerfstudio's optimizer_scaler_step_all calls it once per parameter group).
+ *
+ * nvo_nonfinite_flag over up to 4 ranges (element offsets / sizes, host arrays) of one gradient buffer in one
+ * launch: flags[i] (device uint32 [n_ranges], reset first) is raised iff range i holds an inf / NaN. */
 int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
-                              const void* grads, int grads_are_half, uint32_t* flag);
+                              const void* grads, int grads_are_half, uint32_t* flags);
 /* grads: device float[n], or device fp16[n] when grads_are_half != 0 (the buffer a compressed
  * all-reduce leaves behind: no cast-back pass). */
 /* hyper_dev (nullable): device float[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} overriding the

@@ -95,15 +95,17 @@ struct AdamGroups {
     float lr[kAdamMaxGroups], bias1[kAdamMaxGroups], bias2_sqrt[kAdamMaxGroups];
     const float* hyper_dev[kAdamMaxGroups];
     int vec4[kAdamMaxGroups];
+    uint32_t slot[kAdamMaxGroups];  // index of the group in the caller's arrays (its skip flag)
 };
 
 template <typename GT>
 __global__ void __launch_bounds__(256)
 k_adam_groups(AdamGroups gr, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
-              float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag) {
-    if (skip_flag && *skip_flag) return;
+              float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flags) {
     uint32_t k = 0;
     while (k + 1 < gr.n_groups && blockIdx.x >= gr.first_block[k + 1]) ++k;
+    // GradScaler.step decides per optimiser: a group is skipped iff ITS gradients held a non-finite value
+    if (skip_flags && skip_flags[gr.slot[k]]) return;
     h.lr = gr.lr[k];
     h.bias1 = gr.bias1[k];
     h.bias2_sqrt = gr.bias2_sqrt[k];
@@ -166,17 +168,18 @@ struct FlagRanges {
     uint32_t n_ranges;
     uint32_t first_block[kAdamMaxGroups + 1];
     uint64_t offset[kAdamMaxGroups], n[kAdamMaxGroups];
+    uint32_t slot[kAdamMaxGroups];  // index of the range in the caller's arrays (its flag word)
 };
 
-// several ranges of one gradient buffer in one launch; RESETS the flag first is the launcher's job
+// several ranges of one gradient buffer in one launch, one flag word per range (reset by the launcher)
 template <typename GT>
 __global__ void __launch_bounds__(256)
-k_nonfinite_flag_ranges(FlagRanges r, const GT* __restrict__ g, uint32_t* __restrict__ flag) {
+k_nonfinite_flag_ranges(FlagRanges r, const GT* __restrict__ g, uint32_t* __restrict__ flags) {
     uint32_t k = 0;
     while (k + 1 < r.n_ranges && blockIdx.x >= r.first_block[k + 1]) ++k;
     const bool bad = nonfinite_range<GT>(r.n[k], g + r.offset[k], blockIdx.x - r.first_block[k],
                                          r.first_block[k + 1] - r.first_block[k]);
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + r.slot[k], 1u);
 }
 
 __global__ void __launch_bounds__(256)
@@ -243,7 +246,7 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
 int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
                          void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
                          float beta1, float beta2, float eps, float grad_scale, float weight_decay,
-                         const uint32_t* skip_flag) {
+                         const uint32_t* skip_flags) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq && groups, "adam_step_groups: NULL argument");
     NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "adam_step_groups: 1..%u groups (got %u)", kAdamMaxGroups,
                 n_groups);
@@ -261,6 +264,7 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
         gr.bias1[k] = 1.f - powf(beta1, (float)groups[i].step);
         gr.bias2_sqrt[k] = sqrtf(1.f - powf(beta2, (float)groups[i].step));
         gr.hyper_dev[k] = groups[i].hyper_dev;
+        gr.slot[k] = i;
         const uintptr_t align = (uintptr_t)(params + o) | (uintptr_t)(exp_avg + o) | (uintptr_t)(exp_avg_sq + o);
         gr.vec4[k] = (align & 15u) == 0 && (!params_half || (((uintptr_t)params_half + 2 * o) & 7u) == 0) &&
                      ((((uintptr_t)grads + gsz * o) & (grads_are_half ? 7u : 15u)) == 0);
@@ -276,28 +280,30 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
     AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
     if (grads_are_half) {
         NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag);
+                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags);
     } else {
         NVO_LAUNCH(k_adam_groups<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag);
+                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
 
 int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
-                              const void* grads, int grads_are_half, uint32_t* flag) {
+                              const void* grads, int grads_are_half, uint32_t* flags) {
+    uint32_t* flag = flags;
     NVO_REQUIRE(grads && flag && offsets && sizes, "nonfinite_flag_ranges: NULL argument");
     NVO_REQUIRE(n_ranges >= 1 && n_ranges <= kAdamMaxGroups, "nonfinite_flag_ranges: 1..%u ranges (got %u)",
                 kAdamMaxGroups, n_ranges);
     NVO_PROF(stream, "nonfinite_flag");
-    if (int rc = nvo_zero_async(flag, sizeof(uint32_t), (hipStream_t)stream)) return rc;
+    if (int rc = nvo_zero_async(flag, sizeof(uint32_t) * n_ranges, (hipStream_t)stream)) return rc;
     FlagRanges r{};
     uint32_t k = 0, blocks_total = 0;
     for (uint32_t i = 0; i < n_ranges; ++i) {
         if (sizes[i] == 0) continue;
         r.offset[k] = offsets[i];
         r.n[k] = sizes[i];
+        r.slot[k] = i;
         uint32_t blocks = nvo_div_up(sizes[i], 256 * 8);
         if (blocks > 2048) blocks = 2048;
         r.first_block[k] = blocks_total;

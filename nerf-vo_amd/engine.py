@@ -183,7 +183,7 @@ class NerfactoEngine:
         self.exp_avg = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)  # sharded accumulators
-        self.skip_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.skip_flag = torch.zeros(4, dtype=torch.int32, device=dev)  # one word per parameter group of the step
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
         self._graphs = {}
         self._side_stream = None
@@ -597,27 +597,19 @@ class NerfactoEngine:
 
     def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False,
                        grads_half: torch.Tensor | None = None) -> None:
-        """Non-finite check + fused Adam per group.  ``from_device_scalars``: lr and bias corrections
+        """Non-finite check + fused Adam, per group (one launch each for all groups).  ``from_device_scalars``: lr and bias corrections
         are read from self.dev_scalars (filled by _write_step_scalars) instead of kernel arguments, and
         the per-group step counters are NOT advanced here -- the form a captured graph replays."""
         cfg = self.cfg
         stream = _stream(self.device)
         # grads_half: the fp16 buffer a compressed all-reduce left behind -- consumed directly
         gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (grads_half, 2, 1)
-        # one flag over the gradient ranges of the groups that train this step (ranges of idle groups hold stale
-        # values); adjacent ranges are checked in one launch
-        active = [self.group_ranges[g] for g in groups if g != "camera_opt" or cfg.optimize_poses]
-        merged = []
-        for lo, hi in sorted(active):
-            if merged and lo <= merged[-1][1]:
-                merged[-1][1] = max(merged[-1][1], hi)
-            else:
-                merged.append([lo, hi])
-        # one launch for the flag (all active ranges) and one for Adam (all active groups: they differ in learning
-        # rate and step count only)
-        offs = (C.c_uint64 * len(merged))(*[lo for lo, _ in merged])
-        sizes = (C.c_uint64 * len(merged))(*[hi - lo for lo, hi in merged])
-        _call("nvo_nonfinite_flag_ranges", stream, len(merged), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
+        # hold stale values and are neither checked nor applied), all in one launch
+        active = [g for g in groups if g != "camera_opt" or cfg.optimize_poses]
+        offs = (C.c_uint64 * len(active))(*[self.group_ranges[g][0] for g in active])
+        sizes = (C.c_uint64 * len(active))(*[self.group_ranges[g][1] - self.group_ranges[g][0] for g in active])
+        _call("nvo_nonfinite_flag_ranges", stream, len(active), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
         batch = []
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:

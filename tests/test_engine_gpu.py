@@ -237,8 +237,8 @@ def test_adam_matches_torch_semantics(device):
 
 def test_grouped_adam_equals_per_group_launches(device):
     """nvo_adam_step_groups / nvo_nonfinite_flag_ranges (one launch for the groups of a step) against one
-    nvo_adam_step / nvo_nonfinite_flag(_or) launch per group: bit-identical parameters, moments and fp16 copies,
-    including odd (unaligned) group boundaries, device-side hyper-parameters and the skip flag."""
+    nvo_adam_step launch per group: bit-identical parameters, moments and fp16 copies, including odd (unaligned) group
+    boundaries and device-side hyper-parameters; and the per-group skip flags (GradScaler.step decides per optimiser)."""
     import ctypes as C
 
     from nerf_vo_amd import _lib
@@ -260,11 +260,11 @@ def test_grouped_adam_equals_per_group_launches(device):
         for grouped in (False, True):
             p, m, v = p0.clone(), m0.clone(), v0.clone()
             p16 = torch.zeros(n, dtype=torch.float16, device=device)
-            flag = torch.ones(1, dtype=torch.int32, device=device)  # must be reset by the first flag launch
+            flag = torch.ones(4, dtype=torch.int32, device=device)  # must be reset by the flag launch
             if grouped:
-                offs = (C.c_uint64 * 2)(0, bounds[2][0])
-                sizes = (C.c_uint64 * 2)(bounds[1][1], bounds[2][1] - bounds[2][0])
-                _call("nvo_nonfinite_flag_ranges", st, 2, offs, sizes, _ptr(gbuf), half, _ptr(flag))
+                offs = (C.c_uint64 * 3)(*[lo for lo, _ in bounds])
+                sizes = (C.c_uint64 * 3)(*[hi - lo for lo, hi in bounds])
+                _call("nvo_nonfinite_flag_ranges", st, 3, offs, sizes, _ptr(gbuf), half, _ptr(flag))
                 arr = (_lib.AdamGroup * 3)(*[
                     _lib.AdamGroup(offset=lo, n=hi - lo, lr=lrs[i], step=steps[i],
                                    hyper_dev=hyper.data_ptr() if i == 1 else None)
@@ -272,32 +272,37 @@ def test_grouped_adam_equals_per_group_launches(device):
                 _call("nvo_adam_step_groups", st, 3, arr, _ptr(p), _ptr(p16), _ptr(gbuf), half, _ptr(m), _ptr(v), 0.9,
                       0.999, 1e-15, 1.0 / 128.0, 0.0, _ptr(flag))
             else:
-                _call("nvo_nonfinite_flag", st, bounds[1][1], _ptr(gbuf), half, _ptr(flag))
-                _call("nvo_nonfinite_flag_or", st, bounds[2][1] - bounds[2][0],
-                      C.c_void_p(gbuf.data_ptr() + esz * bounds[2][0]), half, _ptr(flag))
+                flag[1:] = 0  # the single-range launcher owns (and resets) one word only
+                _call("nvo_nonfinite_flag", st, n, _ptr(gbuf), half, _ptr(flag))
                 for i, (lo, hi) in enumerate(bounds):
                     _call("nvo_adam_step", st, hi - lo, C.c_void_p(p.data_ptr() + 4 * lo), C.c_void_p(p16.data_ptr() + 2 * lo),
                           C.c_void_p(gbuf.data_ptr() + esz * lo), half, C.c_void_p(m.data_ptr() + 4 * lo),
                           C.c_void_p(v.data_ptr() + 4 * lo), lrs[i], 0.9, 0.999, 1e-15, steps[i], 1.0 / 128.0, 0.0, _ptr(flag),
                           _ptr(hyper) if i == 1 else None)
             torch.cuda.synchronize()
-            assert int(flag.item()) == 0
+            assert int(flag[:3].sum().item()) == 0
             out.append((p, m, v, p16))
         for a, b in zip(*out):
             assert torch.equal(a, b)
         assert not torch.equal(out[0][0], p0)
-    # a non-finite value in the second range raises the flag and the grouped step becomes a no-op
+    # GradScaler.step semantics: a non-finite value in ONE group skips that group only
     bad = grads.clone()
-    bad[bounds[2][0] + 5] = float("nan")
-    flag = torch.zeros(1, dtype=torch.int32, device=device)
-    offs, sizes = (C.c_uint64 * 2)(0, bounds[2][0]), (C.c_uint64 * 2)(bounds[1][1], bounds[2][1] - bounds[2][0])
-    _call("nvo_nonfinite_flag_ranges", st, 2, offs, sizes, _ptr(bad), 0, _ptr(flag))
-    p = p0.clone()
-    arr = (_lib.AdamGroup * 1)(_lib.AdamGroup(offset=0, n=n, lr=1e-2, step=1, hyper_dev=None))
-    _call("nvo_adam_step_groups", st, 1, arr, _ptr(p), None, _ptr(bad), 0, _ptr(m0.clone()), _ptr(v0.clone()), 0.9, 0.999,
-          1e-15, 1.0 / 128.0, 0.0, _ptr(flag))
+    bad[bounds[1][0] + 5] = float("nan")
+    flag = torch.zeros(4, dtype=torch.int32, device=device)
+    offs = (C.c_uint64 * 3)(*[lo for lo, _ in bounds])
+    sizes = (C.c_uint64 * 3)(*[hi - lo for lo, hi in bounds])
+    _call("nvo_nonfinite_flag_ranges", st, 3, offs, sizes, _ptr(bad), 0, _ptr(flag))
+    p, m, v = p0.clone(), m0.clone(), v0.clone()
+    arr = (_lib.AdamGroup * 3)(*[_lib.AdamGroup(offset=lo, n=hi - lo, lr=lrs[i], step=steps[i], hyper_dev=None)
+                                 for i, (lo, hi) in enumerate(bounds)])
+    _call("nvo_adam_step_groups", st, 3, arr, _ptr(p), None, _ptr(bad), 0, _ptr(m), _ptr(v), 0.9, 0.999, 1e-15,
+          1.0 / 128.0, 0.0, _ptr(flag))
     torch.cuda.synchronize()
-    assert int(flag.item()) == 1 and torch.equal(p, p0)
+    assert flag[:3].tolist() == [0, 1, 0]
+    lo, hi = bounds[1]
+    assert torch.equal(p[lo:hi], p0[lo:hi]) and torch.equal(m[lo:hi], m0[lo:hi]), "the poisoned group must not move"
+    assert not torch.equal(p[:lo], p0[:lo]) and not torch.equal(p[hi:], p0[hi:]), "the other groups must step"
+    assert bool(torch.isfinite(p).all())
 
 
 def test_normal_supervision_matches_oracle(device):
@@ -441,7 +446,7 @@ def test_graph_replay_matches_eager_semantics(device):
     assert len(eng._graphs) == 2
     # the optimiser must really have run on every replay: the GradScaler-style skip flag stays 0
     # (regression: a captured 4-byte hipMemsetAsync replayed as 0x01 bytes and silently disabled Adam)
-    assert int(eng.skip_flag.item()) == 0
+    assert int(eng.skip_flag.sum().item()) == 0
     # the buffers the graphs address by pointer must stay owned by the engine (regression: the captured pose /
     # pixel-index / jitter buffers were locals of the capture function; once freed, the caching allocator handed
     # the same blocks to later allocations and every replay overwrote them -- long mapping runs collapsed)

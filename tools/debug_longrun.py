@@ -50,7 +50,7 @@ def main():
             if a.poses:
                 pa = eng.view("camera_opt.pose_adjustment").view(a.kf, 6)
                 extra = f" |pose_adj| max {pa.abs().max().item():.4f}"
-            print(f"it {it:5d} " + " ".join(f"{k}={v:.3e}" for k, v in ld.items()) + f" skip={int(eng.skip_flag.item())}" + extra, flush=True)
+            print(f"it {it:5d} " + " ".join(f"{k}={v:.3e}" for k, v in ld.items()) + f" skip={int(eng.skip_flag.sum().item())}" + extra, flush=True)
 
 
 if __name__ == "__main__":
