@@ -170,7 +170,7 @@ def main() -> None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
     engine = NerfactoEngine(cfg, device, world_size=world)
-    reducer = GradientAllReduce(dist, compress="fp16") if dist is not None else None
+    reducer = GradientAllReduce(dist, compress="bf16") if dist is not None else None
     if dist is not None:  # identical initial parameters on every rank
         dist.broadcast(engine.params, src=0)
         engine.sync_half()
@@ -322,7 +322,7 @@ def main() -> None:
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
                        "grid_bwd": [{0: "atomic", 1: "lds", 2: "binned", 3: "stream"}[int(m)] for m in bwd_modes],
                        "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
-                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (fp16-compressed flat gradient)/step" if world > 1 else "single GPU"},
+                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (bf16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             "final_losses": losses,
             "late_schedule": late,

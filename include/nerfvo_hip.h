@@ -429,6 +429,9 @@ int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* h
 int nvo_nonfinite_flag(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
 /* same check OR-ed into an already initialised flag (several disjoint gradient ranges, one flag) */
 int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, int grads_are_half, uint32_t* flag);
+/* fp32 -> bfloat16 (round to nearest even; inf / NaN preserved): the compressed form of the gradient exchange.
+ * Everywhere a `grads_are_half` argument appears, 0 = fp32, 1 = fp16, 2 = bfloat16. */
+int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
 
 /* ------------------------------------------------------------------------------------------------

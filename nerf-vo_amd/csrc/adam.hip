@@ -13,6 +13,16 @@ namespace {
 
 __device__ __forceinline__ float load_grad(const float* g, uint64_t i) { return g[i]; }
 __device__ __forceinline__ float load_grad(const _Float16* g, uint64_t i) { return (float)g[i]; }
+// bfloat16 = the upper half of an fp32: same exponent range, 8 significant bits.  The compressed gradient exchange
+// uses it rather than fp16 because Adam (eps 1e-15) turns ANY non-zero gradient into a full-size step, so the
+// tiny gradients of rarely hit hash-grid entries must not flush to zero (fp16 underflows below 6e-8).
+struct Bf16 { uint16_t bits; };
+__device__ __forceinline__ float load_grad(const Bf16* g, uint64_t i) { return __uint_as_float((uint32_t)g[i].bits << 16); }
+__device__ __forceinline__ uint16_t to_bf16(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));  // inf / NaN stay so
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // round to nearest even
+}
 
 struct AdamHyper {
     float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale, weight_decay;
@@ -27,7 +37,7 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, 
     p -= (h.lr / h.bias1) * (m / denom);
 }
 
-// GT = float (local gradient) or _Float16 (the fp16 buffer a compressed all-reduce leaves behind).
+// GT = float (local gradient), _Float16 or Bf16 (the 2-byte buffer a compressed all-reduce leaves behind).
 // The body works on 4 consecutive parameters per thread through 16-byte accesses when the range is
 // 16-byte aligned (HBM-bound kernel: 28 B + 2 B per parameter), scalar otherwise / for the tail.
 template <typename GT>
@@ -135,10 +145,11 @@ __device__ __forceinline__ bool nonfinite_range(uint64_t n, const GT* __restrict
             bad = bad || (q.x & 0x7F800000u) == 0x7F800000u || (q.y & 0x7F800000u) == 0x7F800000u ||
                   (q.z & 0x7F800000u) == 0x7F800000u || (q.w & 0x7F800000u) == 0x7F800000u;
         } else {
+            constexpr uint32_t lo = sizeof(GT) == 2 && __is_same(GT, Bf16) ? 0x7F80u : 0x7C00u;  // exponent field
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                bad = bad || (w[k] & 0x7C00u) == 0x7C00u || (w[k] & 0x7C000000u) == 0x7C000000u;
+                bad = bad || (w[k] & lo) == lo || (w[k] & (lo << 16)) == (lo << 16);
         }
     };
     uint64_t i = tid;
@@ -197,6 +208,20 @@ k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ ds
 }
 
 __global__ void __launch_bounds__(256)
+k_cast_bf16(uint64_t n, const float* __restrict__ src, uint16_t* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = (((uintptr_t)src & 15u) | ((uintptr_t)dst & 7u)) == 0u;
+    const uint64_t n_vec = aligned ? n / 4 : 0u;
+    for (uint64_t i = tid; i < n_vec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2((uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16),
+                                                      (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16));
+    }
+    for (uint64_t i = n_vec * 4 + tid; i < n; i += stride) dst[i] = to_bf16(src[i]);
+}
+
+__global__ void __launch_bounds__(256)
 k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
@@ -232,7 +257,10 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
                      (((uintptr_t)grads & (grads_are_half ? 7u : 15u)) == 0);
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 4096) blocks = 4096;
-    if (grads_are_half) {
+    if (grads_are_half == 2) {
+        NVO_LAUNCH(k_adam<Bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
+                   (_Float16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+    } else if (grads_are_half) {
         NVO_LAUNCH(k_adam<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
                    (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
     } else {
@@ -278,7 +306,10 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
     gr.n_groups = k;
     for (uint32_t i = k; i <= kAdamMaxGroups; ++i) gr.first_block[i] = blocks_total;
     AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
-    if (grads_are_half) {
+    if (grads_are_half == 2) {
+        NVO_LAUNCH(k_adam_groups<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
+                   (_Float16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags);
+    } else if (grads_are_half) {
         NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
                    (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags);
     } else {
@@ -313,7 +344,10 @@ int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint
     if (k == 0) return NVO_OK;
     r.n_ranges = k;
     for (uint32_t i = k; i <= kAdamMaxGroups; ++i) r.first_block[i] = blocks_total;
-    if (grads_are_half) {
+    if (grads_are_half == 2) {
+        NVO_LAUNCH(k_nonfinite_flag_ranges<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r,
+                   (const Bf16*)grads, flag);
+    } else if (grads_are_half) {
         NVO_LAUNCH(k_nonfinite_flag_ranges<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r,
                    (const _Float16*)grads, flag);
     } else {
@@ -344,7 +378,9 @@ static int nonfinite_launch(nvo_stream_t stream, uint64_t n, const void* grads, 
     if (n == 0) return NVO_OK;
     uint32_t blocks = nvo_div_up(n, 256 * 8);
     if (blocks > 2048) blocks = 2048;
-    if (grads_are_half) {
+    if (grads_are_half == 2) {
+        NVO_LAUNCH(k_nonfinite_flag<Bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const Bf16*)grads, flag);
+    } else if (grads_are_half) {
         NVO_LAUNCH(k_nonfinite_flag<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n,
                    (const _Float16*)grads, flag);
     } else {
@@ -365,6 +401,17 @@ int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* h
     NvoFloats16 vals;
     for (uint32_t i = 0; i < 16; ++i) vals.v[i] = i < n ? host_values[i] : 0.f;
     NVO_LAUNCH(k_write_floats, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n, vals);  // values travel by value
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16) {
+    NVO_REQUIRE(src && dst_bf16, "cast_bf16: NULL argument");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "cast_bf16");
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_cast_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src, (uint16_t*)dst_bf16);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

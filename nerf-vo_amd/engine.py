@@ -602,8 +602,9 @@ class NerfactoEngine:
         the per-group step counters are NOT advanced here -- the form a captured graph replays."""
         cfg = self.cfg
         stream = _stream(self.device)
-        # grads_half: the fp16 buffer a compressed all-reduce left behind -- consumed directly
-        gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (grads_half, 2, 1)
+        # grads_half: the 2-byte (bf16 | fp16) buffer a compressed all-reduce left behind -- consumed directly
+        gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (
+            grads_half, 2, 2 if grads_half.dtype == torch.bfloat16 else 1)
         # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
         # hold stale values and are neither checked nor applied), all in one launch
         active = [g for g in groups if g != "camera_opt" or cfg.optimize_poses]
@@ -678,7 +679,7 @@ class NerfactoEngine:
         entry["main"].replay()
         if all_reduce is not None:
             segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in groups)]
-            if entry.get("half") is not None:  # compressed exchange: the fp16 cast is part of the main graph
+            if entry.get("half") is not None:  # compressed exchange: the 2-byte cast is part of the main graph
                 all_reduce.reduce_half(self.grads, entry["half"], segs, already_cast=True)
             else:
                 all_reduce(self.grads, segments=segs)
@@ -711,14 +712,16 @@ class NerfactoEngine:
                            normals=dataset.world_normals01() if has_normals else None)
             self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
                                   anneal=1.0, anneal_dev=anneal_ptr, has_normals=has_normals)
-            if half is not None:  # fp16 copy of the ranges the collective will exchange
+            if half is not None:  # 2-byte copy of the ranges the collective will exchange
+                cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"
                 for lo, hi in cast_ranges:
-                    _call("nvo_cast_half", _stream(dev), hi - lo, C.c_void_p(self.grads.data_ptr() + 4 * lo),
+                    _call(cast, _stream(dev), hi - lo, C.c_void_p(self.grads.data_ptr() + 4 * lo),
                           C.c_void_p(half.data_ptr() + 2 * lo))
 
         half = None
-        if split_optimizer and getattr(self, "_reducer_compress", None) == "fp16":
-            half = torch.zeros(self.n_params, dtype=torch.float16, device=dev)
+        compress = getattr(self, "_reducer_compress", None)
+        if split_optimizer and compress in ("bf16", "fp16"):
+            half = torch.zeros(self.n_params, dtype=torch.bfloat16 if compress == "bf16" else torch.float16, device=dev)
         cast_ranges = [self.group_ranges[g] for g in groups]
 
         def body_opt():

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One rank of the 2-process data-parallel check (tests/test_distributed_gpu.py): both ranks share cuda:0 and
+exchange gradients over gloo (RCCL needs one device per rank; the code path above the collective is the same).
+Usage: dist_engine_worker.py <rank> <world> <port> <workdir> <compress: none|fp16>"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+entry.build()
+from nerf_vo_amd.engine import EngineConfig, NerfactoEngine  # noqa: E402
+from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl  # noqa: E402
+from nerf_vo_amd.parallel import GradientAllReduce  # noqa: E402
+from nerf_vo_amd.synthetic import make_sequence  # noqa: E402
+
+
+def main():
+    rank, world, port, workdir, compress = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    plan = torch.load(os.path.join(workdir, "plan.pt"))
+    n, H, W, R = plan["n"], plan["H"], plan["W"], plan["R"]
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=dev, use_normals=False)
+    seq = make_sequence(n, H, W, device=dev)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+    torch.manual_seed(100 + rank)  # rank-specific sampler stream of the graphed step
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"]), dev, world_size=world)
+    eng.set_params(plan["params"].to(dev))  # identical initial parameters on every rank
+    reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress)
+    c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+    for k in range(plan["eager_steps"]):
+        idx = plan["rays"][k][rank].to(dev)
+        jit = tuple(j.to(dev) for j in plan["jitters"][k][rank])
+        eng.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit, all_reduce=reducer)
+    torch.cuda.synchronize()
+    after_eager = eng.params.detach().cpu().clone()
+    for _ in range(plan["graph_steps"]):
+        eng.train_step_graphed(ds, all_reduce=reducer)
+    torch.cuda.synchronize()
+    torch.save({"after_eager": after_eager, "after_graph": eng.params.detach().cpu(), "losses": eng.loss_dict(),
+                "skip": eng.skip_flag.cpu()}, os.path.join(workdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

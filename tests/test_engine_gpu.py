@@ -233,6 +233,33 @@ def test_adam_matches_torch_semantics(device):
           1e-15, 7, 1.0 / 128.0, 0.0, _ptr(flag), None)
     torch.cuda.synchronize()
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    # bfloat16 gradient buffer (the compressed exchange bench.py uses): nvo_cast_bf16 rounds to nearest even exactly like
+    # torch, keeps inf / NaN, and the optimiser consumes the buffer like its fp32 cast
+    src = torch.cat([torch.randn(n - 6, generator=g) * torch.logspace(-30, 3, n - 6),
+                     torch.tensor([float("inf"), float("-inf"), float("nan"), 0.0, -0.0, 1e-40])]).to(device)
+    dst = torch.empty(n, dtype=torch.bfloat16, device=device)
+    _call("nvo_cast_bf16", _stream(device), n, _ptr(src), _ptr(dst))
+    torch.cuda.synchronize()
+    ref16 = src.to(torch.bfloat16)
+    finite = torch.isfinite(src)
+    assert torch.equal(dst[finite].view(torch.int16), ref16[finite].view(torch.int16))
+    assert torch.equal(torch.isinf(dst), torch.isinf(src)) and torch.equal(torch.isnan(dst), torch.isnan(src))
+    gb = (torch.randn(n, generator=g) * torch.logspace(-12, 1, n)).to(torch.bfloat16).to(device)
+    pa, pb = pd.clone(), pd.clone()
+    ma, mb, va, vb = md.clone(), md.clone(), vd.clone(), vd.clone()
+    flag.zero_()
+    _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gb), 2, _ptr(flag))
+    _call("nvo_adam_step", _stream(device), n, _ptr(pa), None, _ptr(gb), 2, _ptr(ma), _ptr(va), 1e-2, 0.9, 0.999,
+          1e-15, 8, 1.0 / 128.0, 0.0, _ptr(flag), None)
+    gb32 = gb.float()
+    _call("nvo_adam_step", _stream(device), n, _ptr(pb), None, _ptr(gb32), 0, _ptr(mb), _ptr(vb), 1e-2, 0.9, 0.999,
+          1e-15, 8, 1.0 / 128.0, 0.0, _ptr(flag), None)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    gb[777] = float("inf")
+    _call("nvo_nonfinite_flag", _stream(device), n, _ptr(gb), 2, _ptr(flag))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
 
 
 def test_grouped_adam_equals_per_group_launches(device):

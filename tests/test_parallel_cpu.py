@@ -46,6 +46,13 @@ def _worker(rank, world, port, tmp):
     red16(grad3, segments=[(0, 5000), (5000, n - 5000)])
     ref16 = sum(t.half().float() for t in gathered)
     ok = ok and torch.allclose(grad3, ref16, atol=2e-2, rtol=2e-3)
+    # bf16-compressed exchange (what bench.py uses): 8 significant bits, fp32's exponent range -- tiny values survive
+    redb = GradientAllReduce(dist, compress="bf16")
+    tiny = mine.clone() * 1e-12
+    back = redb(tiny.clone(), keep_half=True)
+    refb = sum((t * 1e-12).to(torch.bfloat16).float() for t in gathered)
+    ok = ok and back.dtype == torch.bfloat16 and torch.allclose(back.float(), refb, rtol=2e-2, atol=0.0) \
+        and float((back.float() == 0).float().mean()) < 1e-3
     torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
