@@ -26,20 +26,22 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("compress", ["none", "bf16", "fp16"])
-def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress):
+@pytest.mark.parametrize("compress,poses", [("none", False), ("bf16", False), ("bf16", True), ("fp16", False)],
+                         ids=["none", "bf16", "bf16-pose-optimisation", "fp16"])
+def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, poses):
     from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
     from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
     from nerf_vo_amd.synthetic import make_sequence
 
     n, H, W, R, world, eager_steps, graph_steps = 6, 60, 80, 512, 2, 3, 4
     g = torch.Generator().manual_seed(77)
-    ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=world * R), device)  # the concatenated batch, one process
+    # the concatenated batch, one process
+    ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=world * R, optimize_poses=poses), device)
     params0 = ref.params.detach().cpu().clone()
     scale = torch.tensor([n, H, W])
     rays = [[torch.floor(torch.rand(R, 3, generator=g) * scale).long() for _ in range(world)] for _ in range(eager_steps)]
     jitters = [[tuple(torch.rand(R, generator=g) for _ in range(3)) for _ in range(world)] for _ in range(eager_steps)]
-    torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": rays, "jitters": jitters, "poses": False,
+    torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": rays, "jitters": jitters, "poses": poses,
                 "eager_steps": eager_steps, "graph_steps": graph_steps}, tmp_path / "plan.pt")
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
