@@ -259,6 +259,23 @@ def main() -> None:
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
                         "share_of_step_kernel_time": round(total / tot, 4)}
             break
+    # MFMA utilisation of the fused-MLP kernels alone: FLOP model 2*N*(I*W + (H-1)*W*W + W*O)
+    # for a forward; a backward = input gradient + weight gradient + (these networks store no hidden activations)
+    # the recomputed forward = 3x.  N = main-field samples per launch; dense fp16 MFMA peak 2.5 PFLOP/s.
+    mlp_mfma = []
+    if rank == 0:
+        import re as _re
+
+        n_main = args.rays * cfg.num_nerf_samples
+        for name, cnt, total in kernel_table:
+            m = _re.fullmatch(r"mlp_(fwd|bwd)\[(\d+)-(\d+)x(\d+)-(\d+)\]", name)
+            if not m or int(m.group(3)) != 64:  # the 16-wide proposal networks run on two batch sizes: not modelled
+                continue
+            i_, w_, h_, o_ = (int(m.group(k)) for k in (2, 3, 4, 5))
+            flop = 2.0 * n_main * (i_ * w_ + (h_ - 1) * w_ * w_ + w_ * o_) * (1 if m.group(1) == "fwd" else 3)
+            tflops = flop / (total / cnt * 1e-3) / 1e12
+            mlp_mfma.append({"kernel": name, "avg_launch_us": round(total / cnt * 1e3, 2), "achieved": round(tflops, 1),
+                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tflops / 2500.0, 4)})
     if dist is not None:
         dist.barrier()
 
@@ -324,6 +341,10 @@ def main() -> None:
                        "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
                        "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (bf16-compressed flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
+            # main + both proposal levels: every field evaluation a ray costs
+            "field_evals_per_sec": args.rays * world * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples))
+            / (elapsed / args.steps),
+            "mlp_mfma": mlp_mfma,
             "final_losses": losses,
             "late_schedule": late,
             "roofline": roofline,
