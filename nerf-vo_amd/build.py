@@ -47,12 +47,15 @@ def _compile(src: Path) -> Path:
     stamp = _stamp(src)
     if obj.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
         return obj
-    cmd = [HIPCC, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+    tmp = obj.with_name(f"{obj.name}.{os.getpid()}.tmp")  # concurrent builders (multi-process tests) never see a torn file
+    cmd = [HIPCC, *CXXFLAGS, "-c", str(src), "-o", str(tmp)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
     if res.stderr.strip():
         sys.stderr.write(res.stderr)
+    os.replace(tmp, obj)
     stamp_file.write_text(stamp)
     return obj
 
@@ -67,10 +70,13 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         objs = list(ex.map(_compile, srcs))
     newest_obj = max(o.stat().st_mtime for o in objs)
     if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest_obj:
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB_PATH)]
+        tmp = LIB_PATH.with_name(f"{LIB_PATH.name}.{os.getpid()}.tmp")
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
+            tmp.unlink(missing_ok=True)
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+        os.replace(tmp, LIB_PATH)  # atomic: a process that already mapped the old library keeps its inode
     if verbose:
         # stderr: bench.py must print exactly one JSON line on stdout
         print(f"[nerf-vo_amd] built {LIB_PATH} ({LIB_PATH.stat().st_size / 1e6:.1f} MB) from {len(srcs)} sources",
