@@ -170,7 +170,24 @@ def main() -> None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
     engine = NerfactoEngine(cfg, device, world_size=world)
-    reducer = GradientAllReduce(dist, compress="bf16") if dist is not None else None
+    compress = None
+    if dist is not None:
+        # bf16 is the faithful 2-byte wire format (nerf_vo_amd/parallel.py); should this RCCL build refuse the dtype,
+        # every rank sees the same error here and the exchange falls back to fp16 instead of ending the run
+        compress = os.environ.get("NVO_GRAD_COMPRESS", "bf16")
+        if compress == "bf16":
+            try:
+                probe = torch.ones(64, dtype=torch.bfloat16, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(device)
+                if float(probe[0]) != float(world):
+                    raise RuntimeError("bf16 all-reduce returned a wrong sum")
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write(f"[bench] bf16 all-reduce unavailable ({exc}); using fp16 compression\n")
+                compress = "fp16"
+        if compress == "none":
+            compress = None
+    reducer = GradientAllReduce(dist, compress=compress) if dist is not None else None
     if dist is not None:  # identical initial parameters on every rank
         dist.broadcast(engine.params, src=0)
         engine.sync_half()
@@ -339,7 +356,7 @@ def main() -> None:
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
                        "grid_bwd": [{0: "atomic", 1: "lds", 2: "binned", 3: "stream"}[int(m)] for m in bwd_modes],
                        "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
-                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce (bf16-compressed flat gradient)/step" if world > 1 else "single GPU"},
+                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce ({compress or 'fp32'} flat gradient)/step" if world > 1 else "single GPU"},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             # main + both proposal levels: every field evaluation a ray costs
             "field_evals_per_sec": args.rays * world * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples))
