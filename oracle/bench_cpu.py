@@ -2,8 +2,8 @@
 step (forward + losses + autograd backward + Adam on every parameter) on the GPU box's host cores.
 
 The reference's own CPU path (nerfstudio ``implementation="torch"``) cannot be imported here
-(SURVEY.md section 8c), so this is kind "port".  The sample is bounded: a reduced ray batch for a
-couple of steps (about 10-30 s of CPU work); throughput is reported in the metric's unit
+(SURVEY.md section 8c), so this is kind "port".  The sample is bounded: a reduced ray batch (256 rays) for
+8 timed steps after one warm-up (about 12 s of CPU work at ~1.4 s/step); throughput is reported in the metric's unit
 (main-field ray-samples/s).  float32, all host threads.
 """
 from __future__ import annotations
@@ -16,7 +16,7 @@ import torch
 from .nerfacto import NerfactoOracle, OracleConfig, adam_reference
 
 
-def time_cpu_step(num_rays: int = 256, num_images: int = 8, steps: int = 2, warmup: int = 1,
+def time_cpu_step(num_rays: int = 256, num_images: int = 8, steps: int = 8, warmup: int = 1,
                   max_threads: int = 16) -> dict:
     # torch-CPU scales poorly past a few dozen threads on these small gather/scatter ops (256 threads
     # on the GPU box's host ran 40x SLOWER than 16); "cores" reports the threads actually used.
