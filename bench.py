@@ -169,7 +169,7 @@ def main() -> None:
     if args.grid_bwd_mode is not None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
-    engine = NerfactoEngine(cfg, device, world_size=world)
+    engine = NerfactoEngine(cfg, device, world_size=world, rank=rank)
     compress = None
     if dist is not None:
         # bf16 is the faithful 2-byte wire format (nerf_vo_amd/parallel.py); should this RCCL build refuse the dtype,

@@ -181,6 +181,8 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
 int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out);
 /* SH(degree) of (d+1)/2 for R rays -> device fp16 [R][16] (degree 4) */
 int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out_half);
+/* same with the output format chosen: out_bf16 = 0 -> fp16, 1 -> bfloat16 */
+int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16);
 
 /* ------------------------------------------------------------------------------------------------
  * C. Per-ray volume rendering, resampling and losses, one wavefront per ray (nerfstudio
@@ -209,6 +211,7 @@ typedef struct nvo_weights_pdf_args {
     const float* origins;        /* [R][3] */
     const float* directions;     /* [R][3] */
     float* x01_out;              /* [R*S_out][3] */
+    int act_bf16;                /* 0: the 16-bit tensors above are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
 } nvo_weights_pdf_args;
 int nvo_weights_pdf(nvo_stream_t stream, const nvo_weights_pdf_args* args);
 
@@ -250,6 +253,7 @@ typedef struct nvo_main_loss_args {
     float normal_mult;           /* normal_loss_mult (5e-6 in the reference config) */
     float* out_normals;          /* [R][3] NormalsRenderer (safe-normalised) -> NormalsShader (n+1)/2, or NULL */
                                  /* loss slot 6 of the shard receives normal_mult * monosdf_normal_loss */
+    int act_bf16;                /* 0: pre / rgb / dpre / drgb are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
 } nvo_main_loss_args;
 int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
 
@@ -270,6 +274,7 @@ typedef struct nvo_prop_loss_args {
     float* losses;               /* [64][8] shards (same buffer, base + 3): slots 0..1 = interlevel, depth */
     void* dpre;                  /* fp16 [R*S][dpre_stride]: column 0 gradient, others zeroed */
     uint32_t dpre_stride;
+    int act_bf16;                /* 0: pre / dpre are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
 } nvo_prop_loss_args;
 int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args);
 
@@ -295,6 +300,8 @@ typedef struct nvo_color_args {
     float* d_embedding;          /* [F][32] accumulated; nullable */
     float* d_sh;                 /* [R][16] accumulated; nullable */
     float* d_weights;            /* accumulated (caller zeroes) */
+    int act_bf16;                /* 0: every "fp16" tensor above is fp16 (v_mfma_..._f16), 1: all of them are bfloat16
+                                    and the network runs on v_mfma_f32_16x16x16_bf16 (BASELINE configs[4]) */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
@@ -433,6 +440,17 @@ int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, in
  * Everywhere a `grads_are_half` argument appears, 0 = fp32, 1 = fp16, 2 = bfloat16. */
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
+/* bf16 MLP mode (BASELINE configs[4]: "MFMA bf16 MLP + fp32 hash accumulate"): the 16-bit working copy of the flat
+ * parameter buffer is bfloat16 inside up to 4 element ranges [bf16_lo[k], bf16_hi[k]) (the fused-MLP weights and the
+ * appearance embedding; bounds multiples of 4) and fp16 elsewhere (the hash tables).  Host arrays.
+ * nvo_adam_step_groups_mixed == nvo_adam_step_groups with that format for the copy it writes. */
+int nvo_cast_working_copy(nvo_stream_t stream, uint64_t n, const float* src, void* dst16, uint32_t n_bf16_ranges,
+                          const uint64_t* bf16_lo, const uint64_t* bf16_hi);
+int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                               void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                               float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                               float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                               const uint64_t* bf16_lo, const uint64_t* bf16_hi);
 
 /* ------------------------------------------------------------------------------------------------
  * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of

@@ -28,7 +28,7 @@ class WeightsPdfArgs(C.Structure):
                 ("sbins", _p), ("tbins", _p), ("density_bias", _f), ("sigma", _p), ("weights", _p),
                 ("anneal", _f), ("histogram_padding", _f), ("near_plane", _f), ("far_plane", _f),
                 ("jitter", _p), ("sbins_out", _p), ("tbins_out", _p), ("anneal_dev", _p),
-                ("origins", _p), ("directions", _p), ("x01_out", _p)]
+                ("origins", _p), ("directions", _p), ("x01_out", _p), ("act_bf16", _int)]
 
 
 class MainLossArgs(C.Structure):
@@ -41,7 +41,7 @@ class MainLossArgs(C.Structure):
                 ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
                 ("drgb", _p), ("drgb_stride", _u32),
                 ("dsigma_dx", _p), ("dsigma_inv_scale", _f), ("gt_normal", _p), ("normal_mult", _f),
-                ("out_normals", _p)]
+                ("out_normals", _p), ("act_bf16", _int)]
 
 
 class PropLossArgs(C.Structure):
@@ -50,14 +50,14 @@ class PropLossArgs(C.Structure):
                 ("sbins", _p), ("tbins", _p), ("sbins_main", _p), ("weights_main", _p), ("density_bias", _f),
                 ("gt_depth", _p), ("directions_norm", _p), ("interlevel_mult", _f), ("depth_mult", _f),
                 ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f), ("loss_scale", _f),
-                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32)]
+                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32), ("act_bf16", _int)]
 
 
 class ColorArgs(C.Structure):
     """mirror of nvo_color_args"""
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
-                ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p)]
+                ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int)]
 
 
 class AdamGroup(C.Structure):
@@ -125,6 +125,7 @@ _SIGNATURES = {
     "nvo_sample_positions": (_int, [_p, _u32, _u32, _p, _p, _p, _p]),
     "nvo_dirs01": (_int, [_p, _u32, _p, _p]),
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
+    "nvo_sh_encode_t": (_int, [_p, _u32, _u32, _p, _p, _int]),
     # group C
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),
     "nvo_main_render_loss": (_int, [_p, C.POINTER(MainLossArgs)]),
@@ -153,6 +154,8 @@ _SIGNATURES = {
     "nvo_adam_step_groups": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p]),
     "nvo_nonfinite_flag_ranges": (_int, [_p, _u32, _p, _p, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
+    "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
+    "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_cast_bf16": (_int, [_p, _u64, _p, _p]),
 }
 

@@ -9,6 +9,8 @@
 #include "nvo_kernels.h"
 #include "../../include/nerfvo_hip.h"
 
+#include <string.h>
+
 namespace {
 
 __device__ __forceinline__ float load_grad(const float* g, uint64_t i) { return g[i]; }
@@ -28,6 +30,22 @@ struct AdamHyper {
     float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale, weight_decay;
 };
 
+// Format of the 16-bit working copy the kernels read: fp16 everywhere except inside up to 4 element ranges
+// [lo, hi) of the flat buffer, which are bfloat16 (bf16 MLP mode: the fused-MLP weights and the appearance
+// embedding; the hash tables stay fp16 -- 11 significant bits for entries that are interpolated in fp32).
+// Range bounds are multiples of 4 (checked on the host), so a 4-element vector never straddles a boundary.
+constexpr uint32_t kMaxBf16Ranges = 4;
+struct Copy16Fmt {
+    uint32_t n;
+    uint64_t lo[kMaxBf16Ranges], hi[kMaxBf16Ranges];
+    __device__ __forceinline__ bool is_bf16(uint64_t i) const {
+        bool r = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kMaxBf16Ranges; ++k) r = r || (k < n && i >= lo[k] && i < hi[k]);
+        return r;
+    }
+};
+
 __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamHyper& h) {
     float gi = g * h.grad_scale;
     if (h.weight_decay != 0.f) gi += h.weight_decay * p;
@@ -40,10 +58,12 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, 
 // GT = float (local gradient), _Float16 or Bf16 (the 2-byte buffer a compressed all-reduce leaves behind).
 // The body works on 4 consecutive parameters per thread through 16-byte accesses when the range is
 // 16-byte aligned (HBM-bound kernel: 28 B + 2 B per parameter), scalar otherwise / for the tail.
+// base: index of p[0] in the flat buffer (what Copy16Fmt's ranges refer to)
 template <typename GT>
-__device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16,
+__device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, nvo_h16* __restrict__ p16,
                                            const GT* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                           const AdamHyper& h, int vec4, uint32_t block_id, uint32_t n_blocks) {
+                                           const AdamHyper& h, int vec4, uint32_t block_id, uint32_t n_blocks,
+                                           const Copy16Fmt& fmt, uint64_t base) {
     const uint64_t stride = (uint64_t)n_blocks * blockDim.x;
     const uint64_t tid = (uint64_t)block_id * blockDim.x + threadIdx.x;
     uint64_t done = 0;
@@ -62,10 +82,8 @@ __device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, _F
             reinterpret_cast<float4*>(m)[q] = mv;
             reinterpret_cast<float4*>(v)[q] = vv;
             if (p16) {
-                p16[i + 0] = (_Float16)pv.x;
-                p16[i + 1] = (_Float16)pv.y;
-                p16[i + 2] = (_Float16)pv.z;
-                p16[i + 3] = (_Float16)pv.w;
+                const bool bf = fmt.is_bf16(base + i);
+                *reinterpret_cast<uint2*>(p16 + i) = make_uint2(nvo_cvt16x2(pv.x, pv.y, bf), nvo_cvt16x2(pv.z, pv.w, bf));
             }
         }
         done = n4 << 2;
@@ -76,13 +94,13 @@ __device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, _F
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-        if (p16) p16[i] = (_Float16)pi;
+        if (p16) p16[i] = nvo_cvt16(pi, fmt.is_bf16(base + i));
     }
 }
 
 template <typename GT>
 __global__ void __launch_bounds__(256)
-k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
+k_adam(uint64_t n, float* __restrict__ p, nvo_h16* __restrict__ p16, const GT* __restrict__ g,
        float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flag,
        const float* __restrict__ hyper_dev, int vec4) {
     if (skip_flag && *skip_flag) return;
@@ -91,7 +109,7 @@ k_adam(uint64_t n, float* __restrict__ p, _Float16* __restrict__ p16, const GT* 
         h.bias1 = hyper_dev[1];
         h.bias2_sqrt = hyper_dev[2];
     }
-    adam_range<GT>(n, p, p16, g, m, v, h, vec4, blockIdx.x, gridDim.x);
+    adam_range<GT>(n, p, p16, g, m, v, h, vec4, blockIdx.x, gridDim.x, Copy16Fmt{}, 0);
 }
 
 // Several parameter groups (own range, learning rate and step count each) of ONE flat buffer in one launch: the
@@ -110,8 +128,9 @@ struct AdamGroups {
 
 template <typename GT>
 __global__ void __launch_bounds__(256)
-k_adam_groups(AdamGroups gr, float* __restrict__ p, _Float16* __restrict__ p16, const GT* __restrict__ g,
-              float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flags) {
+k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, const GT* __restrict__ g,
+              float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flags,
+              Copy16Fmt fmt) {
     uint32_t k = 0;
     while (k + 1 < gr.n_groups && blockIdx.x >= gr.first_block[k + 1]) ++k;
     // GradScaler.step decides per optimiser: a group is skipped iff ITS gradients held a non-finite value
@@ -126,7 +145,7 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, _Float16* __restrict__ p16, 
     }
     const uint64_t o = gr.offset[k];
     adam_range<GT>(gr.n[k], p + o, p16 ? p16 + o : nullptr, g + o, m + o, v + o, h, gr.vec4[k],
-                   blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k]);
+                   blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k], fmt, o);
 }
 
 // A pure streaming read: 16-byte loads, four of them in flight per thread (the scalar grid-stride form ran at
@@ -207,6 +226,14 @@ k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ ds
     for (uint64_t i = n_vec * 4 + tid; i < n; i += stride) dst[i] = (_Float16)src[i];
 }
 
+// fp32 -> 16-bit working copy in the mixed format of Copy16Fmt
+__global__ void __launch_bounds__(256)
+k_cast_working_copy(uint64_t n, const float* __restrict__ src, nvo_h16* __restrict__ dst, Copy16Fmt fmt) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = nvo_cvt16(src[i], fmt.is_bf16(i));
+}
+
 __global__ void __launch_bounds__(256)
 k_cast_bf16(uint64_t n, const float* __restrict__ src, uint16_t* __restrict__ dst) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -259,15 +286,28 @@ int nvo_adam_step(nvo_stream_t stream, uint64_t n, float* params, void* params_h
     if (blocks > 4096) blocks = 4096;
     if (grads_are_half == 2) {
         NVO_LAUNCH(k_adam<Bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
-                   (_Float16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
     } else if (grads_are_half) {
         NVO_LAUNCH(k_adam<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
-                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
     } else {
         NVO_LAUNCH(k_adam<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params,
-                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
+                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flag, hyper_dev, vec4);
     }
     NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+static int make_copy_fmt(uint32_t n_ranges, const uint64_t* lo, const uint64_t* hi, Copy16Fmt* fmt) {
+    NVO_REQUIRE(n_ranges <= kMaxBf16Ranges && (n_ranges == 0 || (lo && hi)), "working copy: at most %u bf16 ranges",
+                kMaxBf16Ranges);
+    memset(fmt, 0, sizeof(*fmt));
+    fmt->n = n_ranges;
+    for (uint32_t k = 0; k < n_ranges; ++k) {
+        NVO_REQUIRE((lo[k] & 3u) == 0 && (hi[k] & 3u) == 0 && lo[k] <= hi[k], "working copy: bf16 range %u is not 4-aligned", k);
+        fmt->lo[k] = lo[k];
+        fmt->hi[k] = hi[k];
+    }
     return NVO_OK;
 }
 
@@ -275,7 +315,33 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
                          void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
                          float beta1, float beta2, float eps, float grad_scale, float weight_decay,
                          const uint32_t* skip_flags) {
+    return nvo_adam_step_groups_mixed(stream, n_groups, groups, params, params_half, grads, grads_are_half, exp_avg,
+                                      exp_avg_sq, beta1, beta2, eps, grad_scale, weight_decay, skip_flags, 0, nullptr,
+                                      nullptr);
+}
+
+int nvo_cast_working_copy(nvo_stream_t stream, uint64_t n, const float* src, void* dst16, uint32_t n_bf16_ranges,
+                          const uint64_t* bf16_lo, const uint64_t* bf16_hi) {
+    NVO_REQUIRE(src && dst16, "cast_working_copy: NULL argument");
+    Copy16Fmt fmt;
+    if (int rc = make_copy_fmt(n_bf16_ranges, bf16_lo, bf16_hi, &fmt)) return rc;
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "cast_half");
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_cast_working_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src, (nvo_h16*)dst16, fmt);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                               void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                               float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                               float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                               const uint64_t* bf16_lo, const uint64_t* bf16_hi) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq && groups, "adam_step_groups: NULL argument");
+    Copy16Fmt fmt;
+    if (int rc = make_copy_fmt(n_bf16_ranges, bf16_lo, bf16_hi, &fmt)) return rc;
     NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "adam_step_groups: 1..%u groups (got %u)", kAdamMaxGroups,
                 n_groups);
     NVO_PROF(stream, "adam");
@@ -308,13 +374,13 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
     AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
     if (grads_are_half == 2) {
         NVO_LAUNCH(k_adam_groups<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (_Float16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags);
+                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
     } else if (grads_are_half) {
         NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (_Float16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags);
+                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
     } else {
         NVO_LAUNCH(k_adam_groups<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (_Float16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags);
+                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -277,6 +277,10 @@ struct GridModule : nvo_module_s {
     NvoGridInputScratch input_scratch;  // per-level partials of the input backward (allocated at first use)
     int bwd_mode = 1;  // 0 global atomics, 1 LDS slice owner (default, fastest), 2 binned hashed levels + slice owner
     bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
+    // option "bf16": the encoded features and their gradient are bfloat16 instead of fp16 (the format of the network
+    // behind the encoding).  The table itself stays fp16, interpolation and gradient accumulation stay fp32.
+    bool bf16 = false;
+    int dy_fmt() const { return bf16 ? NVO_DY_BF16 : NVO_DY_HALF; }
 
     ~GridModule() override {
         nvo_grid_slices_destroy(&slices);
@@ -287,9 +291,9 @@ struct GridModule : nvo_module_s {
     int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
         int rc = ensure_slices();
         if (rc) return rc;
-        if (bwd_mode == 2) return nvo_grid_bwd_binned_launch(g, &bins, s, B, in, dout, false, soa, dparams);
-        if (bwd_mode == 3) return nvo_grid_bwd_stream_launch(g, &stream_bins, s, B, in, dout, false, soa, dparams);
-        return nvo_grid_bwd_launch(g, &slices, s, B, in, dout, false, soa, dparams, bwd_mode);
+        if (bwd_mode == 2) return nvo_grid_bwd_binned_launch(g, &bins, s, B, in, dout, dy_fmt(), soa, dparams);
+        if (bwd_mode == 3) return nvo_grid_bwd_stream_launch(g, &stream_bins, s, B, in, dout, dy_fmt(), soa, dparams);
+        return nvo_grid_bwd_launch(g, &slices, s, B, in, dout, dy_fmt(), soa, dparams, bwd_mode);
     }
 
     static int create(uint32_t n_input_dims, const JsonObj& cfg, std::unique_ptr<GridModule>* out) {
@@ -338,13 +342,13 @@ struct GridModule : nvo_module_s {
     int fwd_encode(hipStream_t s, uint32_t B, const float* in, const void* table, void* out, bool soa, void* dydx) {
         dydx_valid = dydx != nullptr;
         dydx_batch = B;
-        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx);
+        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16);
     }
     int bwd_input(hipStream_t s, uint32_t B, const float* in, const void* table, const void* dout, bool soa,
                   float* din, const void* dydx) {
         if (dydx && dydx_valid && dydx_batch == B)
-            return nvo_grid_bwd_input_dydx_launch(g, s, B, dydx, dout, false, soa, din, true);
-        return nvo_grid_bwd_input_launch(g, s, B, in, table, dout, false, soa, din, true, &input_scratch);
+            return nvo_grid_bwd_input_dydx_launch(g, s, B, dydx, dout, dy_fmt(), soa, din, true);
+        return nvo_grid_bwd_input_launch(g, s, B, in, table, dout, dy_fmt(), soa, din, true, &input_scratch);
     }
     uint64_t ctx_bytes(uint32_t B) const override { return 16 + (prepare_input_gradients ? dydx_bytes(B) : 0); }
     int init_params(Pcg32& rng, float* out) const override {
@@ -371,6 +375,7 @@ struct GridModule : nvo_module_s {
     }
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "prepare_input_gradients")) {  // changes ctx_bytes(): set before the ctx scratch is sized
             prepare_input_gradients = value != 0;
             dydx_valid = false;
@@ -400,6 +405,11 @@ struct GridModule : nvo_module_s {
 
 struct ShModule : nvo_module_s {
     uint32_t degree = 4;
+    bool bf16 = false;  // option "bf16": bfloat16 output
+    int set_option(const char* key, int64_t value) override {
+        if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        return nvo_module_s::set_option(key, value);
+    }
     static int create(uint32_t n_input_dims, const JsonObj& cfg, std::unique_ptr<ShModule>* out) {
         NVO_REQUIRE(n_input_dims == 3, "SphericalHarmonics needs 3 input dims (got %u)", n_input_dims);
         std::unique_ptr<ShModule> m(new ShModule());
@@ -414,10 +424,11 @@ struct ShModule : nvo_module_s {
     uint64_t ctx_bytes(uint32_t) const override { return 16; }
     int init_params(Pcg32&, float*) const override { return NVO_OK; }
     int fwd(hipStream_t s, uint32_t B, const float* in, const void*, void* out, void*) override {
-        return nvo_sh_fwd_launch(s, B, degree, in, out, n_out_padded, n_out_padded);
+        return nvo_sh_fwd_launch(s, B, degree, in, out, n_out_padded, n_out_padded, bf16);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void*, const void*, const void* dout,
             void*, float* din, float*) override {
+        NVO_REQUIRE(!(din && bf16), "SphericalHarmonics: the input gradient of the bf16 form is not built");
         if (din) return nvo_sh_bwd_input_launch(s, B, degree, in, dout, n_out_padded, din);
         return NVO_OK;
     }
@@ -426,6 +437,13 @@ struct ShModule : nvo_module_s {
 struct MlpModule : nvo_module_s {
     int in_pad = 16, width = 64, n_hidden = 1, out_pad = 16;
     int act = NVO_ACT_RELU, out_act = NVO_ACT_NONE;
+    // option "bf16": weights, hidden activations, output and dL/doutput are bfloat16 and the layers run on
+    // v_mfma_f32_16x16x16_bf16 (mlp_bf16.hip) instead of fp16 / v_mfma_f32_16x16x16_f16; accumulation is fp32 in both
+    int bf16 = 0;
+    int set_option(const char* key, int64_t value) override {
+        if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        return nvo_module_s::set_option(key, value);
+    }
 
     static int create(uint32_t n_input_dims, uint32_t n_output_dims, const JsonObj& cfg,
                       std::unique_ptr<MlpModule>* out) {
@@ -481,6 +499,7 @@ struct MlpModule : nvo_module_s {
         a.hidden = (_Float16*)ctx;
         a.act = act;
         a.out_act = out_act;
+        a.bf16 = bf16;
         return a;
     }
     int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
@@ -584,6 +603,10 @@ struct NwieModule : nvo_module_s {
         if (!strcmp(key, "compact_output")) {
             compact_out = value != 0;
             return NVO_OK;
+        }
+        if (!strcmp(key, "bf16")) {  // network in bfloat16, encoding output / gradient in bfloat16, table fp16
+            net->bf16 = value != 0;
+            return enc->set_option(key, value);
         }
         if (!strcmp(key, "recompute_hidden")) {
             NVO_REQUIRE(value == 0 || (net->n_hidden == 1 && net->act == NVO_ACT_RELU),

@@ -81,6 +81,16 @@ __device__ __forceinline__ void grid_block_map(uint32_t bid, uint32_t n_levels, 
     }
 }
 
+// dL/d(encoded) pair of one (sample, level): fp16 (tcnn's precision), fp32, or bfloat16 (bf16 MLP mode)
+struct Bf2 {
+    uint32_t raw;
+};
+__device__ __forceinline__ float2 dy2f(__half2 v) { return __half22float2(v); }
+__device__ __forceinline__ float2 dy2f(float2 v) { return v; }
+__device__ __forceinline__ float2 dy2f(Bf2 v) {
+    return make_float2(__uint_as_float(v.raw << 16), __uint_as_float(v.raw & 0xFFFF0000u));
+}
+
 struct Corner {
     uint32_t px, py, pz;  // cell base
     float wx, wy, wz;     // fractional position
@@ -116,7 +126,7 @@ template <bool SOA, bool DYDX>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
            const __half2* __restrict__ table, __half2* __restrict__ out,
-           uint32_t* __restrict__ indices, __half2* __restrict__ dydx) {
+           uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16) {
     uint32_t tile, level;
     grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
     const uint32_t i = tile * kGridBlock + threadIdx.x;
@@ -150,11 +160,13 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         r0 = fmaf(w, f.x, r0);
         r1 = fmaf(w, f.y, r1);
     }
-    const __half2 r = __floats2half2_rn(r0, r1);
+    // fp32 interpolation, ONE rounding to the network's input format (fp16, or bfloat16 in the bf16 MLP mode)
+    const uint32_t r = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
     if (SOA) {
-        out[(size_t)level * N + i] = r;
+        o32[(size_t)level * N + i] = r;
     } else {
-        out[(size_t)i * g.n_levels + level] = r;
+        o32[(size_t)i * g.n_levels + level] = r;
     }
     if constexpr (DYDX) {
         float2 f[8];
@@ -209,14 +221,8 @@ k_grid_bwd_atomic(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
                                x[3 * (size_t)i + 2]);
     const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-    float d;
-    if constexpr (sizeof(DY2) == 4) {
-        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-        d = feat ? f.y : f.x;
-    } else {
-        const float2 f = *reinterpret_cast<const float2*>(&d2);
-        d = feat ? f.y : f.x;
-    }
+    const float2 f = dy2f(d2);
+    const float d = feat ? f.y : f.x;
     if (d == 0.f) return;
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k) {
@@ -353,11 +359,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             xv[u][0] = xv[u][1] = xv[u][2] = 0.f;
             if (i < end) {
                 const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-                if constexpr (sizeof(DY2) == 4) {
-                    dv[u] = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-                } else {
-                    dv[u] = *reinterpret_cast<const float2*>(&d2);
-                }
+                dv[u] = dy2f(d2);
                 xv[u][0] = x[3 * (size_t)i + 0];
                 xv[u][1] = x[3 * (size_t)i + 1];
                 xv[u][2] = x[3 * (size_t)i + 2];
@@ -436,14 +438,14 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
 
 // L1 norm of dy per (level, feature) as 2^8 fixed point in u64 (deterministic: fixed per-thread order, integer
 // atomics between workgroups).  grid = (blocks, n_levels); half2 dy only.
-template <bool SOA>
+template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(256)
-k_dy_l1(NvoGridLevels g, uint32_t N, const __half2* __restrict__ dy, unsigned long long* __restrict__ l1) {
+k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long long* __restrict__ l1) {
     __shared__ float red[2][4];
     const uint32_t level = blockIdx.y;
     float a = 0.f, b = 0.f;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const float2 d = __half22float2(SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level]);
+        const float2 d = dy2f(SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level]);
         a += fabsf(d.x);
         b += fabsf(d.y);
     }
@@ -507,11 +509,7 @@ template <bool SOA, typename DY2>
 __device__ __forceinline__ bool load_dy_nonzero(const NvoGridLevels& g, const DY2* __restrict__ dy, uint32_t N,
                                                 uint32_t level, uint32_t i, float2* out) {
     const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-    if constexpr (sizeof(DY2) == 4) {
-        *out = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-    } else {
-        *out = *reinterpret_cast<const float2*>(&d2);
-    }
+    *out = dy2f(d2);
     return out->x != 0.f || out->y != 0.f;
 }
 
@@ -641,11 +639,7 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
         for (uint32_t u = 0; u < kUnroll; ++u) {
             const uint32_t i = rec[u] >> 3;
             const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-            if constexpr (sizeof(DY2) == 4) {
-                dv[u] = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-            } else {
-                dv[u] = *reinterpret_cast<const float2*>(&d2);
-            }
+            dv[u] = dy2f(d2);
             xv[u][0] = x[3 * (size_t)i + 0];
             xv[u][1] = x[3 * (size_t)i + 1];
             xv[u][2] = x[3 * (size_t)i + 2];
@@ -1040,12 +1034,7 @@ k_grid_bwd_input(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     const __half2* __restrict__ tab = table + off;
 
     const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-    float2 d;
-    if constexpr (sizeof(DY2) == 4) {
-        d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-    } else {
-        d = *reinterpret_cast<const float2*>(&d2);
-    }
+    const float2 d = dy2f(d2);
     if (d.x == 0.f && d.y == 0.f) {
         if (pout) pout[0] = pout[1] = pout[2] = 0.f;
         return;
@@ -1091,12 +1080,7 @@ k_grid_bwd_input_dydx(NvoGridLevels g, uint32_t N, const __half2* __restrict__ d
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (uint32_t level = 0; level < g.n_levels; ++level) {
         const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-        float2 d;
-        if constexpr (sizeof(DY2) == 4) {
-            d = __half22float2(*reinterpret_cast<const __half2*>(&d2));
-        } else {
-            d = *reinterpret_cast<const float2*>(&d2);
-        }
+        const float2 d = dy2f(d2);
         const __half2* __restrict__ p = dydx + (size_t)level * 3 * N + i;
         const float2 gx = __half22float2(p[0]), gy = __half22float2(p[N]), gz = __half22float2(p[2 * (size_t)N]);
         const float sc = g.scale[level];
@@ -1130,8 +1114,17 @@ k_sum_levels(uint32_t n_levels, size_t n, const float* __restrict__ partial, flo
 // ---------------------------------------------------------------------------------------------
 // host launchers (C++ linkage, used by api.cpp and the fused pipeline)
 // ---------------------------------------------------------------------------------------------
+// dy_fmt (NVO_DY_*) -> element type of the dL/d(encoded) pairs
+#define NVO_DY_DISPATCH(M, SOA_)                          \
+    do {                                                  \
+        if (dy_fmt == NVO_DY_FLOAT) M(SOA_, float2);      \
+        else if (dy_fmt == NVO_DY_BF16) M(SOA_, Bf2);     \
+        else M(SOA_, __half2);                            \
+    } while (0)
+
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
-                        const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half) {
+                        const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half,
+                        bool out_bf16) {
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
@@ -1140,7 +1133,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
 #define NVO_LAUNCH_FWD(SOA_, DYDX_)                                                                   \
     NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
-               (__half2*)out_half, indices, (__half2*)dydx_half)
+               (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0)
     if (soa) {
         if (dydx_half) NVO_LAUNCH_FWD(true, true); else NVO_LAUNCH_FWD(true, false);
     } else {
@@ -1280,7 +1273,7 @@ void nvo_grid_bins_destroy(NvoGridBins* b) {
 
 // mode 2: binned scatter for hashed levels + slice-owner items for the rest
 int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad) {
+                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad) {
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     NVO_REQUIRE(N < (1u << 29), "grid_bwd_binned: batch too large for 29-bit sample ids");
     NVO_REQUIRE((uint64_t)N * 8 * bins->n_binned_levels < 0xFFFFFFFFull, "grid_bwd_binned: too many records");
@@ -1325,15 +1318,15 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
                    (const T_*)dy, bins->d_bin_level, bins->d_bin_slice, bins->d_base, bins->d_records, grad); \
     } while (0)
         if (soa) {
-            if (dy_is_float) NVO_LAUNCH_BIN(true, float2); else NVO_LAUNCH_BIN(true, __half2);
+            NVO_DY_DISPATCH(NVO_LAUNCH_BIN, true);
         } else {
-            if (dy_is_float) NVO_LAUNCH_BIN(false, float2); else NVO_LAUNCH_BIN(false, __half2);
+            NVO_DY_DISPATCH(NVO_LAUNCH_BIN, false);
         }
 #undef NVO_LAUNCH_BIN
         NVO_CHECK_LAUNCH();
     }
     if (bins->dense.n_slices) {
-        return nvo_grid_bwd_launch(g, &bins->dense, stream, N, x, dy, dy_is_float, soa, grad, 1);
+        return nvo_grid_bwd_launch(g, &bins->dense, stream, N, x, dy, dy_fmt, soa, grad, 1);
     }
     return NVO_OK;
 }
@@ -1412,7 +1405,7 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
 }
 
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad) {
+                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad) {
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     NVO_REQUIRE((uint64_t)N * 8 * g.n_levels < 0xFFFFFFFFull, "grid_bwd_stream: too many records for 32-bit offsets");
     if (N == 0) return nvo_zero_async(grad, sizeof(float) * 2 * (size_t)g.offset[g.n_levels], stream);
@@ -1433,7 +1426,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_CHECK_HIP(hipEventRecord(st->ev_fork, stream));
             NVO_CHECK_HIP(hipStreamWaitEvent(st->aux, st->ev_fork, 0));
         }
-        if (int rc = nvo_grid_bwd_launch(g, &st->owner, fork ? st->aux : stream, N, x, dy, dy_is_float, soa, grad, 1))
+        if (int rc = nvo_grid_bwd_launch(g, &st->owner, fork ? st->aux : stream, N, x, dy, dy_fmt, soa, grad, 1))
             return rc;
         if (fork) NVO_CHECK_HIP(hipEventRecord(st->ev_join, st->aux));
     }
@@ -1501,9 +1494,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     } while (0)
     NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
     if (soa) {
-        if (dy_is_float) NVO_LAUNCH_ST_T(true, float2); else NVO_LAUNCH_ST_T(true, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_ST_T, true);
     } else {
-        if (dy_is_float) NVO_LAUNCH_ST_T(false, float2); else NVO_LAUNCH_ST_T(false, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_ST_T, false);
     }
 #undef NVO_LAUNCH_ST_T
 #undef NVO_LAUNCH_ST
@@ -1512,9 +1505,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     return NVO_OK;
 }
 
-// mode: 0 = global atomics, 1 = LDS slice owner.  dy_is_float selects float2 vs half2 input.
+// mode: 0 = global atomics, 1 = LDS slice owner.  dy_fmt selects float2 vs half2 input.
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
-                        uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
+                        uint32_t N, const float* x, const void* dy, int dy_fmt, bool soa,
                         float* grad, int mode) {
     const size_t grad_bytes = sizeof(float) * 2 * (size_t)g.offset[g.n_levels];
     NVO_PROF(stream, "grid_bwd_%s[L%u]", (mode == 1 && slices && slices->n_slices) ? "lds" : "atomic", g.n_levels);
@@ -1532,16 +1525,19 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
         const size_t lds = kLdsBwdBytes;
         if (slices->acc_bits == 32) {
-            NVO_REQUIRE(!dy_is_float, "grid: 32-bit accumulators need fp16 dL/dy (set grid_acc_bits to 64)");
+            NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
             uint32_t bx = nvo_div_up(N, 256 * 8);
             if (bx > 256) bx = 256;
             if (bx < 1) bx = 1;
+#define NVO_LAUNCH_L1(SOA_, T_) \
+    NVO_LAUNCH((k_dy_l1<SOA_, T_>), dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const T_*)dy, slices->d_l1)
             if (soa) {
-                NVO_LAUNCH(k_dy_l1<true>, dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const __half2*)dy, slices->d_l1);
+                if (dy_fmt == NVO_DY_BF16) NVO_LAUNCH_L1(true, Bf2); else NVO_LAUNCH_L1(true, __half2);
             } else {
-                NVO_LAUNCH(k_dy_l1<false>, dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const __half2*)dy, slices->d_l1);
+                if (dy_fmt == NVO_DY_BF16) NVO_LAUNCH_L1(false, Bf2); else NVO_LAUNCH_L1(false, __half2);
             }
+#undef NVO_LAUNCH_L1
         }
 #define NVO_LAUNCH_LDS(SOA_, T_)                                                              \
     do {                                                                                      \
@@ -1556,9 +1552,9 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                            (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1);  \
     } while (0)
         if (soa) {
-            if (dy_is_float) NVO_LAUNCH_LDS(true, float2); else NVO_LAUNCH_LDS(true, __half2);
+            NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);
         } else {
-            if (dy_is_float) NVO_LAUNCH_LDS(false, float2); else NVO_LAUNCH_LDS(false, __half2);
+            NVO_DY_DISPATCH(NVO_LAUNCH_LDS, false);
         }
 #undef NVO_LAUNCH_LDS
         NVO_CHECK_LAUNCH();
@@ -1571,9 +1567,9 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
     NVO_LAUNCH((k_grid_bwd_atomic<SOA_, T_>), grid, block, 0, stream, g, N, x,        \
                        (const T_*)dy, grad)
     if (soa) {
-        if (dy_is_float) NVO_LAUNCH_AT(true, float2); else NVO_LAUNCH_AT(true, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_AT, true);
     } else {
-        if (dy_is_float) NVO_LAUNCH_AT(false, float2); else NVO_LAUNCH_AT(false, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_AT, false);
     }
 #undef NVO_LAUNCH_AT
     NVO_CHECK_LAUNCH();
@@ -1581,7 +1577,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
 }
 
 int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
-                                   const void* dy, bool dy_is_float, bool soa, float* dx, bool zero_dx) {
+                                   const void* dy, int dy_fmt, bool soa, float* dx, bool zero_dx) {
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "grid_bwd_input_dydx[L%u]", g.n_levels);
     const dim3 grid(nvo_div_up(N, 256)), block(256);
@@ -1589,9 +1585,9 @@ int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, u
     NVO_LAUNCH((k_grid_bwd_input_dydx<SOA_, T_>), grid, block, 0, stream, g, N, (const __half2*)dydx_half,   \
                (const T_*)dy, dx, zero_dx ? 0 : 1)
     if (soa) {
-        if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_IN, true);
     } else {
-        if (dy_is_float) NVO_LAUNCH_IN(false, float2); else NVO_LAUNCH_IN(false, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_IN, false);
     }
 #undef NVO_LAUNCH_IN
     NVO_CHECK_LAUNCH();
@@ -1600,7 +1596,7 @@ int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, u
 
 int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
                               const float* x, const void* table_half, const void* dy,
-                              bool dy_is_float, bool soa, float* dx, bool zero_dx, NvoGridInputScratch* scratch) {
+                              int dy_fmt, bool soa, float* dx, bool zero_dx, NvoGridInputScratch* scratch) {
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "grid_bwd_input[L%u]", g.n_levels);
     float* partial = nullptr;
@@ -1621,9 +1617,9 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
     NVO_LAUNCH((k_grid_bwd_input<SOA_, T_>), grid, block, 0, stream, g, N, x,         \
                        (const __half2*)table_half, (const T_*)dy, dx, partial)
     if (soa) {
-        if (dy_is_float) NVO_LAUNCH_IN(true, float2); else NVO_LAUNCH_IN(true, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_IN, true);
     } else {
-        if (dy_is_float) NVO_LAUNCH_IN(false, float2); else NVO_LAUNCH_IN(false, __half2);
+        NVO_DY_DISPATCH(NVO_LAUNCH_IN, false);
     }
 #undef NVO_LAUNCH_IN
     if (partial) {

@@ -1,0 +1,923 @@
+// Kernel bodies of the fully fused MLP, compiled once per 16-bit element type:
+//   mlp.hip       #define NVO_MLP_BF16 0  ->  T = _Float16, v_mfma_f32_16x16x16_f16   (tcnn's precision)
+//   mlp_bf16.hip  #define NVO_MLP_BF16 1  ->  T = __bf16,   v_mfma_f32_16x16x16_bf16  (BASELINE configs[4])
+// Everything the network streams -- weights, inputs from the encoding, hidden activations, outputs and all of
+// their gradients -- is T in memory; accumulation is fp32 in both.  See mlp.hip for the design notes.
+#pragma once
+#include "nvo_kernels.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef NVO_MLP_BF16
+#error "define NVO_MLP_BF16 (0 | 1) before including mlp_impl.h"
+#endif
+#if NVO_MLP_BF16
+#define NVO_MLP_NAME(x) x##_bf16
+#define NVO_MLP_TAG ":bf16"
+#else
+#define NVO_MLP_NAME(x) x##_f16
+#define NVO_MLP_TAG ""
+#endif
+
+namespace {
+
+#if NVO_MLP_BF16
+typedef __bf16 T;
+#else
+typedef _Float16 T;
+#endif
+typedef T T4 __attribute__((ext_vector_type(4)));
+typedef T T2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef NvoMlpArgsT<T> Args;
+
+
+constexpr int kMlpBlock = 256;
+constexpr int kWavesPerBlock = kMlpBlock / 64;
+
+// one MFMA 16x16x16 (K = 16: 4 operand elements per lane); fp16 and bf16 share the register layout
+__device__ __forceinline__ f4 mfma16(T4 a, T4 b, f4 c) {
+#if NVO_MLP_BF16
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    s4 as, bs;
+    __builtin_memcpy(&as, &a, sizeof(as));
+    __builtin_memcpy(&bs, &b, sizeof(bs));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as, bs, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ float act_fwd(int act, float v) {
+    if (act == NVO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == NVO_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// derivative expressed through the (saved, fp16-rounded) activation output
+__device__ __forceinline__ float act_bwd_from_out(int act, float out) {
+    if (act == NVO_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+    if (act == NVO_ACT_SIGMOID) return out * (1.f - out);
+    return 1.f;
+}
+
+__device__ __forceinline__ T4 pack_act(int act, f4 v) {
+    T4 r;
+    r[0] = (T)act_fwd(act, v[0]);
+    r[1] = (T)act_fwd(act, v[1]);
+    r[2] = (T)act_fwd(act, v[2]);
+    r[3] = (T)act_fwd(act, v[3]);
+    return r;
+}
+
+// A-operand fragments of W[N_OUT][K_IN] (row-major): f[tn][tk] = W[16tn + (l&15)][16tk + 4g + j]
+template <int N_OUT, int K_IN>
+struct WFrag {
+    T4 f[N_OUT / 16][K_IN / 16];
+    __device__ __forceinline__ void load(const T* __restrict__ W, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk)
+                f[tn][tk] = *reinterpret_cast<const T4*>(W + (size_t)(16 * tn + r) * K_IN + 16 * tk + 4 * g);
+    }
+};
+
+// A-operand fragments of W^T: f[tk][tn] = W[16tn + 4g + j][16tk + (l&15)]   (strided gather, once)
+template <int N_OUT, int K_IN>
+struct WTFrag {
+    T4 f[K_IN / 16][N_OUT / 16];
+    __device__ __forceinline__ void load(const T* __restrict__ W, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+            for (int tn = 0; tn < N_OUT / 16; ++tn) {
+                T4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = W[(size_t)(16 * tn + 4 * g + j) * K_IN + 16 * tk + r];
+                f[tk][tn] = v;
+            }
+    }
+    // Same fragments through LDS: the workgroup copies W row-major (coalesced 8-byte loads) into `stage`
+    // (row stride K_IN + 4 halfs) and every wave takes its transposed fragments with ds_read_b64_tr_b16.
+    // The direct form above costs 4 two-byte gathers per fragment with every lane on its own cache line
+    // (144 load instructions x 64 lines per wave for the colour head) -- the dominant per-wave setup cost.
+    // MUST be called by all threads of the workgroup (barriers); `stage` holds >= N_OUT * (K_IN + 4) halfs.
+    __device__ __forceinline__ void load_lds(const T* __restrict__ W, T* stage, int lane) {
+        constexpr int kStride = K_IN + 4;
+        __syncthreads();  // previous users of the staging area are done
+        for (int e = threadIdx.x; e < N_OUT * K_IN / 4; e += blockDim.x) {
+            const int n = (4 * e) / K_IN, k = (4 * e) % K_IN;
+            *reinterpret_cast<T4*>(stage + n * kStride + k) = *reinterpret_cast<const T4*>(W + (size_t)n * K_IN + k);
+        }
+        __syncthreads();
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+            for (int tn = 0; tn < N_OUT / 16; ++tn) {
+                const T* addr = stage + (16 * tn + 4 * g + q) * kStride + 16 * tk + 4 * pp;
+                fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4_t*)addr);
+                __builtin_memcpy(&f[tk][tn], &v, sizeof(T4));
+            }
+    }
+};
+
+// H_out^T tile = W * H_in^T
+template <int N_OUT, int K_IN>
+__device__ __forceinline__ void layer_mm(const WFrag<N_OUT, K_IN>& w, const T4 (&in)[K_IN / 16],
+                                         f4 (&acc)[N_OUT / 16]) {
+#pragma unroll
+    for (int tn = 0; tn < N_OUT / 16; ++tn) {
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk) c = mfma16(w.f[tn][tk], in[tk], c);
+        acc[tn] = c;
+    }
+}
+
+// dH_in^T tile = W^T * dZ^T
+template <int N_OUT, int K_IN>
+__device__ __forceinline__ void layer_mm_t(const WTFrag<N_OUT, K_IN>& wt,
+                                           const T4 (&dz)[N_OUT / 16], f4 (&acc)[K_IN / 16]) {
+#pragma unroll
+    for (int tk = 0; tk < K_IN / 16; ++tk) {
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn) c = mfma16(wt.f[tk][tn], dz[tn], c);
+        acc[tk] = c;
+    }
+}
+
+// Load the B-operand fragments of one 16-sample input tile: x[tk][j] = in[m][16tk + 4g + j]
+template <int IN_PAD, int IO>
+__device__ __forceinline__ void load_input(const Args& a, uint32_t row, int g,
+                                           T4 (&x)[IN_PAD / 16], uint32_t cam = 0u) {
+    // cam: (NVO_IO_NERFACTO_COLOR only) appearance-embedding row of this sample's ray, loaded by the caller
+    if constexpr (IO == NVO_IO_F32_ROWS) {
+        const float* __restrict__ p = (const float*)a.input + (size_t)row * a.n_in;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = 16 * tk + 4 * g + j;
+                x[tk][j] = c < a.n_in ? (T)p[c] : (T)1.0f;
+            }
+        }
+    } else if constexpr (IO == NVO_IO_HALF2_SOA) {
+        const T2* __restrict__ p = (const T2*)a.input;
+        const uint32_t n_lv = a.n_in >> 1;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+            const uint32_t lv = 8 * tk + 2 * g;
+            T2 v0 = {(T)0.f, (T)0.f}, v1 = v0;
+            if (lv < n_lv) v0 = p[(size_t)lv * a.batch + row];
+            if (lv + 1 < n_lv) v1 = p[(size_t)(lv + 1) * a.batch + row];
+            x[tk][0] = v0[0];
+            x[tk][1] = v0[1];
+            x[tk][2] = v1[0];
+            x[tk][3] = v1[1];
+        }
+    } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+        if constexpr (IN_PAD == 64) {
+            // row = [SH16(ray) | geo15 = base_out[1..15] | embed32(cam) | 1]; features 16.. are the source rows
+            // shifted by one half, fetched as aligned 8-byte pieces (v0 = src[4g..4g+3], v1 = src[4g+4..4g+7])
+            const uint32_t ray = row / a.samples_per_ray;
+            const T* __restrict__ sh = a.sh + (size_t)ray * 16;
+            const T* __restrict__ bo = a.base_out + (size_t)row * 16;
+            const T* __restrict__ em = a.embedding + (size_t)cam * 32;
+            x[0] = *reinterpret_cast<const T4*>(sh + 4 * g);
+            const T4 b0 = *reinterpret_cast<const T4*>(bo + 4 * g);
+            const T4 b1 = *reinterpret_cast<const T4*>(bo + (g < 3 ? 4 * g + 4 : 12));  // g == 3: unused lane value
+            const T4 e0 = *reinterpret_cast<const T4*>(em + 4 * g);
+            const T4 e1 = *reinterpret_cast<const T4*>(em + 4 * g + 4);
+            const T4 e2 = *reinterpret_cast<const T4*>(em + 16 + 4 * g);
+            const T4 e3 = *reinterpret_cast<const T4*>(em + (g < 3 ? 20 + 4 * g : 28));
+            const T em0 = em[0];
+            x[1] = T4{b0[1], b0[2], b0[3], g < 3 ? b1[0] : em0};          // features 16 + 4g + j
+            x[2] = T4{e0[1], e0[2], e0[3], e1[0]};                        // embed 1 + 4g + j
+            x[3] = T4{e2[1], e2[2], e2[3], g < 3 ? e3[0] : (T)1.0f};  // embed 17 + 4g + j | pad
+        }
+    } else if constexpr (IO == NVO_IO_NGP_RGB) {
+        if constexpr (IN_PAD == 32) {
+            const int32_t ray = a.sample_ray[row];
+            x[0] = *reinterpret_cast<const T4*>(a.base_out + (size_t)row * 16 + 4 * g);
+            T4 z = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+            x[1] = ray >= 0 ? *reinterpret_cast<const T4*>(a.sh + (size_t)ray * 16 + 4 * g) : z;
+        }
+    } else {
+        const T* __restrict__ p = (const T*)a.input + (size_t)row * IN_PAD;
+#pragma unroll
+        for (int tk = 0; tk < IN_PAD / 16; ++tk)
+            x[tk] = *reinterpret_cast<const T4*>(p + 16 * tk + 4 * g);
+    }
+}
+
+// sum over the 16 sample lanes (lane & 15) of one lane group
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+// COMPACT: only output column 0 exists in memory ([B] halfs instead of [B][OUT_PAD]): the density networks of
+// the proposal sampler produce one number per sample, and a 32-byte row per sample costs 16x the traffic in
+// this kernel, in the per-ray kernels that read it with a 32-byte stride, and again in the backward.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT>
+__global__ void __launch_bounds__(kMlpBlock)
+NVO_MLP_NAME(k_mlp_fwd)(Args a) {
+    // hidden activation: compile-time ReLU (every network on the NeRF-VO path) or the run-time switch
+    const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_tiles = a.batch >> 4;
+
+    WFrag<WIDTH, IN_PAD> w0;
+    WFrag<WIDTH, WIDTH> wh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    WFrag<OUT_PAD, WIDTH> wl;
+    {
+        const T* W = a.weights;
+        w0.load(W, lane);
+        W += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            wh[l].load(W, lane);
+            W += WIDTH * WIDTH;
+        }
+        wl.load(W, lane);
+    }
+
+    // the next tile's input row is requested before the current tile is computed (see NVO_MLP_NAME(k_mlp_bwd))
+    auto load_x = [&](uint32_t tile, T4 (&xo)[IN_PAD / 16]) {
+        const uint32_t row = tile * 16 + m;
+        uint32_t cam = 0;
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+        }
+        load_input<IN_PAD, IO>(a, row, g, xo, cam);
+    };
+    T4 x[IN_PAD / 16];
+    if (wave < n_tiles) load_x(wave, x);
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 16 + m;
+        T4 xn[IN_PAD / 16];
+        load_x(min(tile + n_waves, n_tiles - 1u), xn);
+
+        f4 acc[WIDTH / 16];
+        T4 h[WIDTH / 16];
+        layer_mm<WIDTH, IN_PAD>(w0, x, acc);
+#pragma unroll
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(hidden_act, acc[t]);
+        if (a.hidden) {
+            T* hs = a.hidden + (size_t)row * WIDTH + 4 * g;
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) *reinterpret_cast<T4*>(hs + 16 * t) = h[t];
+        }
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            layer_mm<WIDTH, WIDTH>(wh[l], h, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) h[t] = pack_act(hidden_act, acc[t]);
+            if (a.hidden) {
+                T* hs = a.hidden + ((size_t)(l + 1) * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) *reinterpret_cast<T4*>(hs + 16 * t) = h[t];
+            }
+        }
+        f4 o[OUT_PAD / 16];
+        layer_mm<OUT_PAD, WIDTH>(wl, h, o);
+        if constexpr (COMPACT) {
+            const T4 v = pack_act(a.out_act, o[0]);
+            if (g == 0) a.output[row] = v[0];  // 16 lanes -> 32 contiguous bytes per tile
+        } else {
+            T* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t)
+                *reinterpret_cast<T4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < IN_PAD / 16; ++t) x[t] = xn[t];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// wave-private LDS tile: 16 samples x LD halfs.  Row stride LD+4 halfs (8-B pad) keeps the
+// 8-B alignment ds_read_b64_tr_b16 needs and staggers rows across banks.
+template <int LD>
+struct LdsTile {
+    static constexpr int kStride = LD + 4;
+    T* base;
+    // chain layout -> tile: lane (m,g) owns [m][16t + 4g .. +3]
+    __device__ __forceinline__ void store(int m, int g, int t, T4 v) const {
+        *reinterpret_cast<T4*>(base + m * kStride + 16 * t + 4 * g) = v;
+    }
+    // transposed fragment: element j = tile[4g + j][16t + (lane & 15)]
+    __device__ __forceinline__ T4 load_tr(int lane, int t) const {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const T* addr = base + (4 * g + q) * kStride + 16 * t + 4 * p;
+        fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4_t*)addr);
+        T4 r;
+        __builtin_memcpy(&r, &v, sizeof(r));
+        return r;
+    }
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave complete in issue order; this only stops the compiler from
+    // moving the transposed reads above the tile stores (and vice versa on the next tile).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N_OUT, int K_IN>
+struct DwAcc {
+    f4 a[N_OUT / 16][K_IN / 16];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) a[tn][tk] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // dW[n][k] += sum_m dZ[m][n] H[m][k]   A = dZ^T fragment, B = H fragment (both transposed reads)
+    __device__ __forceinline__ void accumulate(const T4 (&zt)[N_OUT / 16], const T4 (&ht)[K_IN / 16]) {
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) a[tn][tk] = mfma16(zt[tn], ht[tk], a[tn][tk]);
+    }
+    // accumulator (lane, reg r) = dW[16tn + 4g + r][16tk + (lane&15)]
+    __device__ __forceinline__ void flush(float* __restrict__ dW, int lane) const {
+        const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(dW + (size_t)(16 * tn + 4 * g + r) * K_IN + 16 * tk + c, a[tn][tk][r]);
+    }
+    // Workgroup-level flush: the block's waves sum their accumulators in LDS (same lane <-> element
+    // map in every wave, so plain read-modify-write phases separated by barriers suffice), then all
+    // threads add the block total to global memory in row order (256 contiguous bytes per wave
+    // instruction -- the fast float-atomic shape -- and 4x fewer adds per address).
+    // MUST be called by every wave of the block (contains __syncthreads()).
+    __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib) const {
+        const int c = lane & 15, g = lane >> 4;
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (wib == w) {
+#pragma unroll
+                for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+                    for (int tk = 0; tk < K_IN / 16; ++tk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = (16 * tn + 4 * g + r) * K_IN + 16 * tk + c;
+                            red[e] = (w == 0 ? 0.f : red[e]) + a[tn][tk][r];
+                        }
+            }
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
+        __syncthreads();
+    }
+};
+
+// RECOMP (single-hidden-layer ReLU networks): the hidden activation is not read back from memory but
+// recomputed from the input row with the same MFMA sequence and the same fp16 rounding as the forward (so it
+// is bit-identical) -- the forward then does not store it at all.  64..128 bytes per sample less traffic in
+// each direction for one to eight extra MFMAs per 16-sample tile.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP>
+__global__ void __launch_bounds__(kMlpBlock)
+NVO_MLP_NAME(k_mlp_bwd)(Args a) {
+    static_assert(!RECOMP || RELU, "hidden recomputation: ReLU networks");
+    const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
+    constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
+                                         : (IN_PAD > OUT_PAD ? IN_PAD : OUT_PAD));
+    __shared__ __attribute__((aligned(16))) T lds[kWavesPerBlock][2][16 * (MAXW + 4)];
+
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_tiles = a.batch >> 4;
+    const LdsTile<MAXW> tz{&lds[wib][0][0]}, th{&lds[wib][1][0]};
+
+    const bool need_dinput = a.dinput != nullptr;
+
+    // transposed weights for the dH chain (layer 0's only if dL/dinput is wanted)
+    WTFrag<WIDTH, IN_PAD> wt0;
+    WTFrag<WIDTH, WIDTH> wth[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    WTFrag<OUT_PAD, WIDTH> wtl;
+    {
+        const T* W = a.weights;
+        T* stage = &lds[0][0][0];  // the wave tiles are idle until the first sample tile
+        static_assert(WIDTH * (IN_PAD + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
+                      WIDTH * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
+                      OUT_PAD * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4),
+                      "weight staging does not fit the LDS tiles");
+        if (need_dinput) wt0.load_lds(W, stage, lane);
+        W += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            wth[l].load_lds(W, stage, lane);
+            W += WIDTH * WIDTH;
+        }
+        wtl.load_lds(W, stage, lane);
+        __syncthreads();
+    }
+    WFrag<WIDTH, IN_PAD> w0f;  // forward weights (hidden recomputation only)
+    WFrag<WIDTH, WIDTH> whf[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    if constexpr (RECOMP) {
+        w0f.load(a.weights, lane);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load(a.weights + WIDTH * IN_PAD + l * WIDTH * WIDTH, lane);
+    }
+    DwAcc<WIDTH, IN_PAD> dw0;
+    DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    DwAcc<OUT_PAD, WIDTH> dwl;
+    dw0.zero();
+#pragma unroll
+    for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
+    dwl.zero();
+
+    // Every global input of a tile (dL/dout, out, all hidden activations, the input row) is requested in one
+    // go, and the NEXT tile's inputs are requested before the current tile is computed: with the dW
+    // accumulators in registers a wave has its SIMD to itself (346 registers for the colour head), so memory
+    // latency can only be hidden inside the wave.  Before this the tile loop paid three dependent HBM round
+    // trips per tile (measured: 64 % of the wave cycles in s_waitcnt, 6.9 us per 16-sample tile).
+    struct TileIn {
+        T4 dzl[OUT_PAD / 16], out[OUT_PAD / 16];
+        T4 hs[N_HIDDEN][WIDTH / 16];
+        T4 x[IN_PAD / 16];
+    };
+    // output-activation derivative as arithmetic on wave-uniform coefficients (no per-element branches):
+    // factor = 1 + c_sig * (o (1 - o) - 1) + c_relu * (step(o) - 1)
+    const float c_sig = a.out_act == NVO_ACT_SIGMOID ? 1.f : 0.f, c_relu = a.out_act == NVO_ACT_RELU ? 1.f : 0.f;
+    auto load_tile = [&](uint32_t tile, TileIn& t) {
+        const uint32_t row = tile * 16 + m;
+        // the camera index heads a dependent chain (index -> embedding row): requested first, so that waiting
+        // for it does not also wait for the other loads of this tile
+        uint32_t cam = 0;
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+        }
+        if constexpr (COMPACT) {
+            const T z = (T)0.f;
+            const T dv = a.doutput[row], ov = a.output[row];  // every lane group reads, g == 0 keeps
+#pragma unroll
+            for (int i = 0; i < OUT_PAD / 16; ++i) {
+                t.dzl[i] = T4{z, z, z, z};
+                t.out[i] = T4{z, z, z, z};
+            }
+            if (g == 0) {
+                t.dzl[0][0] = dv;
+                t.out[0][0] = ov;
+            }
+        } else {
+            const T* dp = a.doutput + (size_t)row * OUT_PAD + 4 * g;
+            const T* op = a.output + (size_t)row * OUT_PAD + 4 * g;
+#pragma unroll
+            for (int i = 0; i < OUT_PAD / 16; ++i) {
+                t.dzl[i] = *reinterpret_cast<const T4*>(dp + 16 * i);
+                t.out[i] = *reinterpret_cast<const T4*>(op + 16 * i);
+            }
+        }
+        if constexpr (!RECOMP) {
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN; ++l) {
+                const T* hp = a.hidden + ((size_t)l * a.batch + row) * WIDTH + 4 * g;
+#pragma unroll
+                for (int i = 0; i < WIDTH / 16; ++i) t.hs[l][i] = *reinterpret_cast<const T4*>(hp + 16 * i);
+            }
+        }
+        load_input<IN_PAD, IO>(a, row, g, t.x, cam);
+    };
+    TileIn cur;
+    if (wave < n_tiles) load_tile(wave, cur);
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t row = tile * 16 + m;
+        TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
+        load_tile(min(tile + n_waves, n_tiles - 1u), nxt);
+
+        // ---- output layer: dZ_L = dL/dout * out_act'(out)
+        T4 dzl[OUT_PAD / 16];
+#pragma unroll
+        for (int t = 0; t < OUT_PAD / 16; ++t) {
+            T4 d = cur.dzl[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o = (float)cur.out[t][j];
+                const float f = 1.f + c_sig * (o * (1.f - o) - 1.f) + c_relu * ((o > 0.f ? 1.f : 0.f) - 1.f);
+                d[j] = (T)((float)d[j] * f);
+            }
+            dzl[t] = d;
+        }
+        // last hidden activation H_{N_HIDDEN-1}
+        T4 h[WIDTH / 16];
+        if constexpr (RECOMP) {  // forward chain again: identical MFMA order and fp16 rounding
+            f4 hacc[WIDTH / 16];
+            layer_mm<WIDTH, IN_PAD>(w0f, cur.x, hacc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) cur.hs[0][t] = pack_act(NVO_ACT_RELU, hacc[t]);
+#pragma unroll
+            for (int l = 1; l < N_HIDDEN; ++l) {
+                layer_mm<WIDTH, WIDTH>(whf[l - 1], cur.hs[l - 1], hacc);
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) cur.hs[l][t] = pack_act(NVO_ACT_RELU, hacc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
+        // dW_last += dZ_L^T H
+        {
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) tz.store(m, g, t, dzl[t]);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) th.store(m, g, t, h[t]);
+            wave_lds_sync();
+            T4 zt[OUT_PAD / 16], ht[WIDTH / 16];
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) zt[t] = tz.load_tr(lane, t);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) ht[t] = th.load_tr(lane, t);
+            dwl.accumulate(zt, ht);
+            wave_lds_sync();
+        }
+        // dZ of the last hidden layer
+        T4 dz[WIDTH / 16];
+        {
+            f4 acc[WIDTH / 16];
+            layer_mm_t<OUT_PAD, WIDTH>(wtl, dzl, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dz[t][j] = (T)(acc[t][j] * act_bwd_from_out(hidden_act, (float)h[t][j]));
+        }
+        // ---- hidden layers N_HIDDEN-1 .. 1 (weights wh[l-1] map H_{l-1} -> H_l)
+#pragma unroll
+        for (int l = N_HIDDEN - 1; l >= 1; --l) {
+            T4 hp_[WIDTH / 16];  // H_{l-1}
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) hp_[t] = cur.hs[l - 1][t];
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) {
+                tz.store(m, g, t, dz[t]);
+                th.store(m, g, t, hp_[t]);
+            }
+            wave_lds_sync();
+            {
+                T4 zt[WIDTH / 16], ht[WIDTH / 16];
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) {
+                    zt[t] = tz.load_tr(lane, t);
+                    ht[t] = th.load_tr(lane, t);
+                }
+                dwh[l - 1].accumulate(zt, ht);
+            }
+            wave_lds_sync();
+            f4 acc[WIDTH / 16];
+            layer_mm_t<WIDTH, WIDTH>(wth[l - 1], dz, acc);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dz[t][j] = (T)(acc[t][j] * act_bwd_from_out(hidden_act, (float)hp_[t][j]));
+        }
+        // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
+        {
+            T4 x[IN_PAD / 16];
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) x[t] = cur.x[t];
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) tz.store(m, g, t, dz[t]);
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) th.store(m, g, t, x[t]);
+            wave_lds_sync();
+            T4 zt[WIDTH / 16], xt[IN_PAD / 16];
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) zt[t] = tz.load_tr(lane, t);
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) xt[t] = th.load_tr(lane, t);
+            dw0.accumulate(zt, xt);
+            wave_lds_sync();
+        }
+        if (need_dinput) {
+            f4 acc[IN_PAD / 16];
+            layer_mm_t<WIDTH, IN_PAD>(wt0, dz, acc);
+            if constexpr (IO == NVO_IO_F32_ROWS) {
+                float* __restrict__ p = (float*)a.dinput + (size_t)row * a.n_in;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t c = 16 * tk + 4 * g + j;
+                        if (c < a.n_in) p[c] = acc[tk][j];
+                    }
+            } else if constexpr (IO == NVO_IO_HALF2_SOA) {
+                T2* __restrict__ p = (T2*)a.dinput;
+                const uint32_t n_lv = a.n_in >> 1;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                    const uint32_t lv = 8 * tk + 2 * g;
+                    if (lv < n_lv)
+                        p[(size_t)lv * a.batch + row] = T2{(T)acc[tk][0], (T)acc[tk][1]};
+                    if (lv + 1 < n_lv)
+                        p[(size_t)(lv + 1) * a.batch + row] =
+                            T2{(T)acc[tk][2], (T)acc[tk][3]};
+                }
+            } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+                if constexpr (IN_PAD == 64) {
+                    const uint32_t ray = row / a.samples_per_ray;
+                    const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
+                    T* __restrict__ dbo = a.d_base_out + (size_t)row * 16;
+                    // a 16-sample tile lies inside one ray when samples_per_ray % 16 == 0: reduce the
+                    // per-ray quantities over the tile before touching memory
+                    const bool tile_in_ray = (a.samples_per_ray & 15u) == 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = 4 * g + j;
+                        if (q < 15) dbo[1 + q] = (T)acc[1][j];
+                        // embedding columns: e0 <- feature 31, 1+q <- feature 32+q, 17+q <- feature 48+q
+                        float e_lo = acc[2][j];
+                        float e_hi = q < 15 ? acc[3][j] : 0.f;
+                        float e_0 = q == 15 ? acc[1][j] : 0.f;
+                        float s_sh = acc[0][j];
+                        if (tile_in_ray) {
+                            e_lo = group16_sum(e_lo);
+                            e_hi = group16_sum(e_hi);
+                            e_0 = group16_sum(e_0);
+                            s_sh = group16_sum(s_sh);
+                        }
+                        if (!tile_in_ray || m == 0) {
+                            if (a.d_embedding) {
+                                float* de = a.d_embedding + (size_t)cam * 32;
+                                atomicAdd(de + 1 + q, e_lo);
+                                if (q < 15) atomicAdd(de + 17 + q, e_hi);
+                                if (q == 15) atomicAdd(de + 0, e_0);
+                            }
+                            if (a.d_sh) atomicAdd(a.d_sh + (size_t)ray * 16 + q, s_sh);
+                        }
+                    }
+                }
+            } else if constexpr (IO == NVO_IO_NGP_RGB) {
+                if constexpr (IN_PAD == 32) {
+                    // d(density-net output): all 16 columns; column 0 also receives dL/d(density pre-activation)
+                    T4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (T)acc[0][j];
+                    if (g == 0 && a.d_extra_col0) v[0] = (T)(acc[0][0] + a.d_extra_col0[row]);
+                    *reinterpret_cast<T4*>(a.d_base_out + (size_t)row * 16 + 4 * g) = v;
+                }
+            } else {
+                T* __restrict__ p = (T*)a.dinput + (size_t)row * IN_PAD + 4 * g;
+#pragma unroll
+                for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                    T4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (T)acc[tk][j];
+                    *reinterpret_cast<T4*>(p + 16 * tk) = v;
+                }
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
+    if (a.dweights) {
+        __syncthreads();  // every wave is done with its LDS tiles
+        float* red = reinterpret_cast<float*>(&lds[0][0][0]);
+        constexpr int kLdsFloats = (int)(sizeof(lds) / sizeof(float));
+        static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
+                      "dW block reduction does not fit the LDS tiles");
+        float* dW = a.dweights;
+        dw0.flush_block(dW, red, lane, wib);
+        dW += WIDTH * IN_PAD;
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) {
+            dwh[l].flush_block(dW, red, lane, wib);
+            dW += WIDTH * WIDTH;
+        }
+        dwl.flush_block(dW, red, lane, wib);
+    }
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_fwd_io(const Args& a, hipStream_t stream, uint32_t max_blocks) {
+    NVO_PROF(stream, "mlp_fwd[%d-%dx%d-%d]" NVO_MLP_TAG, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    const uint32_t n_tiles = a.batch >> 4;
+    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (a.compact_out) {
+        if constexpr (IO == NVO_IO_HALF2_SOA && OUT_PAD == 16) {
+            if (a.act == NVO_ACT_RELU) {
+                NVO_LAUNCH((NVO_MLP_NAME(k_mlp_fwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                NVO_CHECK_LAUNCH();
+                return NVO_OK;
+            }
+        }
+        nvo_set_error("mlp: compact (column 0) output needs the level-major half2 input layout and ReLU");
+        return NVO_ERR_UNSUPPORTED;
+    }
+    if (a.act == NVO_ACT_RELU) {
+        NVO_LAUNCH((NVO_MLP_NAME(k_mlp_fwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    } else {
+        NVO_LAUNCH((NVO_MLP_NAME(k_mlp_fwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+// The IO layout is a compile-time parameter of the kernels (run-time mode switches inside the tile loop cost
+// branches and, worse, full `s_waitcnt vmcnt(0)` drains at every join, which defeats the input prefetch).
+// Row-major fp32 / level-major half2 / row-major half exist for every shape, the two fused heads only for theirs.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+int launch_fwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
+    switch (a.in_mode) {
+        case NVO_IO_F32_ROWS: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_F32_ROWS>(a, stream, max_blocks);
+        case NVO_IO_HALF2_SOA: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF2_SOA>(a, stream, max_blocks);
+        case NVO_IO_HALF_ROWS: return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF_ROWS>(a, stream, max_blocks);
+        case NVO_IO_NERFACTO_COLOR:
+            if constexpr (IN_PAD == 64 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NERFACTO_COLOR>(a, stream, max_blocks);
+            break;
+        case NVO_IO_NGP_RGB:
+            if constexpr (IN_PAD == 32 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NGP_RGB>(a, stream, max_blocks);
+            break;
+    }
+    nvo_set_error("mlp: IO mode %d is not available for shape %d-%dx%d-%d", a.in_mode, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    return NVO_ERR_UNSUPPORTED;
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_bwd_io(const Args& a, hipStream_t stream, uint32_t max_blocks) {
+    NVO_PROF(stream, "mlp_bwd[%d-%dx%d-%d]" NVO_MLP_TAG, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    const uint32_t n_tiles = a.batch >> 4;
+    uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (a.compact_out || a.recompute_hidden) {
+        // instantiated where the NeRF-VO path uses them: level-major input (networks behind a hash grid; compact
+        // only there, recomputation for their single-hidden-layer shapes) and the fused colour head
+        constexpr bool kSoa = IO == NVO_IO_HALF2_SOA && OUT_PAD == 16;
+        constexpr bool kRecompOk = (kSoa && N_HIDDEN == 1) || IO == NVO_IO_NERFACTO_COLOR;
+        if (a.act == NVO_ACT_RELU) {
+            if constexpr (kRecompOk) {
+                if (a.recompute_hidden && !a.compact_out) {
+                    NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                    NVO_CHECK_LAUNCH();
+                    return NVO_OK;
+                }
+            }
+            if constexpr (kSoa && N_HIDDEN == 1) {
+                if (a.recompute_hidden && a.compact_out) {
+                    NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                    NVO_CHECK_LAUNCH();
+                    return NVO_OK;
+                }
+            }
+            if constexpr (kSoa) {
+                if (a.compact_out && !a.recompute_hidden) {
+                    NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+                    NVO_CHECK_LAUNCH();
+                    return NVO_OK;
+                }
+            }
+        }
+        nvo_set_error("mlp: compact output / hidden recomputation are not available for this shape, layout or activation");
+        return NVO_ERR_UNSUPPORTED;
+    }
+    if (a.act == NVO_ACT_RELU) {
+        NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    } else {
+        NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, false, false, false>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD>
+int launch_bwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
+    if (a.dinput != nullptr && a.din_mode != a.in_mode) {
+        nvo_set_error("mlp: dinput layout (%d) must equal the input layout (%d)", a.din_mode, a.in_mode);
+        return NVO_ERR_UNSUPPORTED;
+    }
+    switch (a.in_mode) {
+        case NVO_IO_F32_ROWS: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_F32_ROWS>(a, stream, max_blocks);
+        case NVO_IO_HALF2_SOA: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF2_SOA>(a, stream, max_blocks);
+        case NVO_IO_HALF_ROWS: return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_HALF_ROWS>(a, stream, max_blocks);
+        case NVO_IO_NERFACTO_COLOR:
+            if constexpr (IN_PAD == 64 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NERFACTO_COLOR>(a, stream, max_blocks);
+            break;
+        case NVO_IO_NGP_RGB:
+            if constexpr (IN_PAD == 32 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
+                return launch_bwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NGP_RGB>(a, stream, max_blocks);
+            break;
+    }
+    nvo_set_error("mlp: IO mode %d is not available for shape %d-%dx%d-%d", a.in_mode, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
+    return NVO_ERR_UNSUPPORTED;
+}
+
+
+}  // namespace
+
+
+// Supported shapes (every MLP on the NeRF-VO mapping path):
+//   (in_pad, width, n_hidden, out_pad)
+//   (32, 64, 1, 16) nerfacto base MLP      (64, 64, 2, 16) colour MLP
+//   (32, 64, 3, 64) predicted-normals MLP  (16, 16, 1, 16) proposal density MLP
+//   (16, 64, 1..2, 16), (32, 64, 2, 16), (64, 64, 1, 16) generic tcnn.Network uses
+#define NVO_MLP_SHAPES(X) \
+    X(32, 64, 1, 16)      \
+    X(64, 64, 2, 16)      \
+    X(32, 64, 3, 64)      \
+    X(16, 16, 1, 16)      \
+    X(16, 64, 1, 16)      \
+    X(16, 64, 2, 16)      \
+    X(32, 64, 2, 16)      \
+    X(64, 64, 1, 16)      \
+    X(16, 16, 2, 16)      \
+    X(32, 16, 1, 16)
+
+// workgroup caps (tuning knobs; the defaults are the measured optima on MI355X)
+static uint32_t env_blocks(const char* name, uint32_t dflt) {
+    const char* e = getenv(name);
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt;
+}
+
+// Every wave loads the whole weight set into registers before its first tile, so the cap trades that
+// per-wave setup (and, backward, the per-workgroup dW flush) against parallelism.  Measured on MI355X
+// (bench.py per-kernel table, N = 196 608 / 1 M rows): colour head 64-64x2-16 forward 35.7 us at 512
+// workgroups vs 55 us at 2048; base 32-64x1-16 forward 17.8 us at 1024 vs 20.6 us at 2048; the 16-wide
+// proposal MLP wants many forward workgroups (2048+).
+static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
+    const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
+    if (weight_halfs >= 8192) return 512;
+    if (weight_halfs >= 2048) return 1024;
+    return 2048;
+}
+static uint32_t bwd_block_cap(int in_pad, int width, int n_hidden) {
+    if (width * in_pad + (n_hidden - 1) * width * width < 2048) return 512;  // 16-wide proposal MLP: 34 vs 37 us
+    // one workgroup per CU: with the tile inputs software-pipelined every shape is fastest at 256 (colour head
+    // 74 us vs 107 us at 512; base 30.6 vs 37.7; proposal 49.5 vs 53.4) -- fewer dW flushes, and the dW
+    // accumulators leave the wide shapes one wave per SIMD anyway
+    return 256;
+}
+
+static bool mlp_shape_supported_impl(int in_pad, int width, int n_hidden, int out_pad) {
+#define X(I, W, H, O) \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O) return true;
+    NVO_MLP_SHAPES(X)
+#undef X
+    return false;
+}
+
+int NVO_MLP_NAME(nvo_mlp_fwd_launch)(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a0,
+                                     hipStream_t stream) {
+    const Args& a = reinterpret_cast<const Args&>(a0);
+    NVO_REQUIRE((a.batch & 15u) == 0, "mlp: batch (%u) must be a multiple of 16", a.batch);
+    if (a.batch == 0) return NVO_OK;
+#define X(I, W, H, O)                                                    \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
+        return launch_fwd<I, W, H, O>(a, stream, env_blocks("NVO_MLP_FWD_BLOCKS", fwd_block_cap(I, W, H)));
+    NVO_MLP_SHAPES(X)
+#undef X
+    nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
+                  n_hidden, out_pad);
+    return NVO_ERR_UNSUPPORTED;
+}
+
+int NVO_MLP_NAME(nvo_mlp_bwd_launch)(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a0,
+                                     hipStream_t stream) {
+    const Args& a = reinterpret_cast<const Args&>(a0);
+    NVO_REQUIRE((a.batch & 15u) == 0, "mlp: batch (%u) must be a multiple of 16", a.batch);
+    if (a.batch == 0) return NVO_OK;
+#define X(I, W, H, O)                                                    \
+    if (in_pad == I && width == W && n_hidden == H && out_pad == O)      \
+        return launch_bwd<I, W, H, O>(a, stream, env_blocks("NVO_MLP_BWD_BLOCKS", bwd_block_cap(I, W, H)));
+    NVO_MLP_SHAPES(X)
+#undef X
+    nvo_set_error("mlp: unsupported shape in_pad=%d width=%d n_hidden=%d out_pad=%d", in_pad, width,
+                  n_hidden, out_pad);
+    return NVO_ERR_UNSUPPORTED;
+}
+

@@ -106,6 +106,26 @@ uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_fe
                               float per_level_scale);
 
 #ifdef __HIPCC__
+// ---- 16-bit activation storage chosen at run time (wave-uniform flag): fp16 (tcnn's precision) or bfloat16
+// (EngineConfig.mlp_dtype = "bf16", BASELINE configs[4]).  Used by the kernels around the fused MLP, where one
+// select per element is noise; the MLP kernels themselves are compiled per type (mlp_impl.h).
+typedef unsigned short nvo_h16;  // raw bits of a _Float16 or a __bf16
+__device__ __forceinline__ float nvo_ld16(const nvo_h16* p, bool bf) {
+    const nvo_h16 raw = *p;
+    return bf ? __uint_as_float((uint32_t)raw << 16) : (float)__builtin_bit_cast(_Float16, raw);
+}
+__device__ __forceinline__ nvo_h16 nvo_cvt16(float v, bool bf) {  // round to nearest even in both formats
+    return bf ? __builtin_bit_cast(nvo_h16, (__bf16)v) : __builtin_bit_cast(nvo_h16, (_Float16)v);
+}
+__device__ __forceinline__ uint32_t nvo_cvt16x2(float a, float b, bool bf) {
+    return (uint32_t)nvo_cvt16(a, bf) | ((uint32_t)nvo_cvt16(b, bf) << 16);
+}
+__device__ __forceinline__ float2 nvo_ld16x2(uint32_t raw, bool bf) {
+    if (bf) return make_float2(__uint_as_float(raw << 16), __uint_as_float(raw & 0xFFFF0000u));
+    return make_float2((float)__builtin_bit_cast(_Float16, (nvo_h16)(raw & 0xFFFFu)),
+                       (float)__builtin_bit_cast(_Float16, (nvo_h16)(raw >> 16)));
+}
+
 // ---- sample position -> contracted, normalised grid coordinate (nerfacto: Frustums.get_positions,
 // SceneContraction(L-inf), (x + 2) / 4, selector mask -> masked positions are zeroed) ----------------------
 __device__ __forceinline__ void nvo_contract_position01(const float o[3], const float d[3], float mid, float out[3]) {

@@ -9,6 +9,8 @@
 int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream);
 
 // ---- grid.hip -------------------------------------------------------------------------------
+// format of the dL/d(encoded) pairs handed to the backward launchers (`dy_fmt`)
+enum { NVO_DY_HALF = 0, NVO_DY_FLOAT = 1, NVO_DY_BF16 = 2 };
 struct NvoGridSlices {
     uint32_t n_slices = 0;
     uint32_t* d_level = nullptr;   // device array of uint4 work items {level, first, chunk, n_chunks}
@@ -41,7 +43,7 @@ struct NvoGridBins {
 int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b);
 void nvo_grid_bins_destroy(NvoGridBins* b);
 int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
+                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad);
 
 // Streamed binned backward (mode 3): levels with many 8K-entry bins go through count / scan / scatter of
 // self-contained 8-byte records / streaming accumulate; the coarse levels keep slice-owner items.
@@ -75,16 +77,17 @@ struct NvoGridStream {
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);
 void nvo_grid_stream_destroy(NvoGridStream* st);
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, bool dy_is_float, bool soa, float* grad);
+                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad);
 void nvo_grid_slices_destroy(NvoGridSlices* s);
 // dydx_half (optional): [L][3][N] half2, d(out)/d(cell coordinate) for nvo_grid_bwd_input_dydx_launch
+// out_bf16: the encoded features leave as bfloat16 pairs instead of fp16 pairs (bf16 MLP mode)
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices,
-                        void* dydx_half = nullptr);
+                        void* dydx_half = nullptr, bool out_bf16 = false);
 int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
-                                   const void* dy, bool dy_is_float, bool soa, float* dx, bool zero_dx);
+                                   const void* dy, int dy_fmt, bool soa, float* dx, bool zero_dx);
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
-                        uint32_t N, const float* x, const void* dy, bool dy_is_float, bool soa,
+                        uint32_t N, const float* x, const void* dy, int dy_fmt, bool soa,
                         float* grad, int mode);
 // scratch (optional, module-owned): per-level partial gradients [L][N][3] of the two-stage input backward
 struct NvoGridInputScratch {
@@ -93,12 +96,12 @@ struct NvoGridInputScratch {
 };
 int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
                               const float* x, const void* table_half, const void* dy,
-                              bool dy_is_float, bool soa, float* dx, bool zero_dx,
+                              int dy_fmt, bool soa, float* dx, bool zero_dx,
                               NvoGridInputScratch* scratch = nullptr);
 
 // ---- sh.hip ---------------------------------------------------------------------------------
 int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
-                      void* out_half, uint32_t out_stride, uint32_t out_width);
+                      void* out_half, uint32_t out_stride, uint32_t out_width, bool out_bf16 = false);
 int nvo_sh_bwd_input_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
                             const void* dy_half, uint32_t dy_stride, float* dd01);
 
@@ -112,36 +115,47 @@ enum {
     NVO_IO_NGP_RGB = 4,         // 32-wide row: [density-net output 16 | SH16(ray of the packed sample)]
 };
 
-struct NvoMlpArgs {
+// E: the 16-bit element type of everything the network streams (_Float16 | __bf16).  The layout does not depend
+// on E (pointers only), so host code fills an NvoMlpArgs (= NvoMlpArgsT<_Float16>) whatever `bf16` says and the
+// bf16 kernels reinterpret it.
+template <typename E>
+struct NvoMlpArgsT {
     uint32_t batch;       // multiple of 16
     uint32_t n_in;        // true input width (<= IN_PAD)
     int in_mode;
     const void* input;
-    const _Float16* weights;  // layer-major, each [out][in] row-major
-    _Float16* output;         // [B][OUT_PAD]   (compact_out: [B], column 0 only)
+    const E* weights;  // layer-major, each [out][in] row-major
+    E* output;         // [B][OUT_PAD]   (compact_out: [B], column 0 only)
+    int bf16;                 // 0: E = _Float16 (tcnn's precision), 1: E = __bf16 (mlp_bf16.hip)
     int compact_out;          // 1: output / doutput hold column 0 only (level-major half2 input, ReLU nets)
     int recompute_hidden;     // 1 (backward): `hidden` is not read, the single hidden layer is recomputed
-    _Float16* hidden;         // [N_HIDDEN][B][WIDTH] or nullptr (inference)
+    E* hidden;         // [N_HIDDEN][B][WIDTH] or nullptr (inference)
     int act, out_act;
     // backward only
-    const _Float16* doutput;  // [B][OUT_PAD], loss-scaled   (compact_out: [B])
+    const E* doutput;  // [B][OUT_PAD], loss-scaled   (compact_out: [B])
     void* dinput;             // layout din_mode, nullable
     int din_mode;
     float* dweights;          // fp32, same order as weights, accumulated with atomics (pre-zeroed)
     // NVO_IO_NERFACTO_COLOR only (NerfactoField colour head input, never materialised in HBM)
     uint32_t samples_per_ray;
-    const _Float16* sh;         // [R][16]  SH of the ray direction
-    const _Float16* base_out;   // [B][16]  base MLP output: col 0 density pre-activation, 1..15 geo
-    const _Float16* embedding;  // [F][32]  appearance embedding (fp16 working copy)
+    const E* sh;         // [R][16]  SH of the ray direction
+    const E* base_out;   // [B][16]  base MLP output: col 0 density pre-activation, 1..15 geo
+    const E* embedding;  // [F][32]  appearance embedding (fp16 working copy)
     const int32_t* cam_idx;     // [R] or nullptr -> row 0 of `embedding` for every ray
-    _Float16* d_base_out;       // [B][16]  cols 1..15 written by the backward
+    E* d_base_out;       // [B][16]  cols 1..15 written by the backward
     float* d_embedding;         // [F][32]  atomically accumulated, nullable
     float* d_sh;                // [R][16]  atomically accumulated, nullable
     // NVO_IO_NGP_RGB only (instant-ngp rgb head on packed samples)
     const int32_t* sample_ray;    // [B] ray index of each packed sample (< 0: empty slot)
     const float* d_extra_col0;    // [B] added to column 0 of d_base_out (dL/d density pre-activation)
 };
+typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
+// per-element-type entry points (mlp.hip / mlp_bf16.hip); nvo_mlp_{fwd,bwd}_launch dispatch on a.bf16
+int nvo_mlp_fwd_launch_f16(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a, hipStream_t stream);
+int nvo_mlp_bwd_launch_f16(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a, hipStream_t stream);
+int nvo_mlp_fwd_launch_bf16(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a, hipStream_t stream);
+int nvo_mlp_bwd_launch_bf16(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a, hipStream_t stream);
 int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
                        hipStream_t stream);
 int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,

@@ -392,4 +392,9 @@ int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float*
     return nvo_sh_fwd_launch((hipStream_t)stream, R, degree, dirs01, out_half, 16, 16);
 }
 
+int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16) {
+    NVO_REQUIRE(R == 0 || (dirs01 && out), "sh_encode_t: NULL argument");
+    return nvo_sh_fwd_launch((hipStream_t)stream, R, degree, dirs01, out, 16, 16, out_bf16 != 0);
+}
+
 }  // extern "C"

@@ -61,7 +61,7 @@ __device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
 
 // Per-ray forward quantities from the density pre-activation; fills LDS arrays w[] and Tr[].
 // sigma = selector * exp(pre + bias); w_i = (1 - exp(-delta_i sigma_i)) * exp(-sum_{j<i} delta_j sigma_j)
-__device__ __forceinline__ void ray_weights(int lane, uint32_t S, const _Float16* __restrict__ pre,
+__device__ __forceinline__ void ray_weights(int lane, uint32_t S, const nvo_h16* __restrict__ pre, bool bf,
                                             uint32_t pre_stride, const float* __restrict__ x01,
                                             const float* __restrict__ tb, float bias,
                                             float* __restrict__ sigma_out, float* w, float* Tr) {
@@ -71,7 +71,7 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const _Float16
         float dd = 0.f, sg = 0.f;
         if (i < S) {
             const bool sel = x01[3 * (size_t)i] > 0.f;
-            sg = sel ? __expf((float)pre[(size_t)i * pre_stride] + bias) : 0.f;
+            sg = sel ? __expf(nvo_ld16(pre + (size_t)i * pre_stride, bf) + bias) : 0.f;
             dd = (tb[i + 1] - tb[i]) * sg;
             if (sigma_out) sigma_out[i] = sg;
         }
@@ -87,11 +87,11 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const _Float16
 
 // dL/dw (in LDS array g[], overwritten) -> dL/dpre, written as fp16 * loss_scale
 // dL/dsigma_k = delta_k [ g_k (T_k - w_k) - sum_{i>k} g_i w_i ],  dsigma/dpre = exp(clamp(pre+bias,-15,15))
-__device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const _Float16* __restrict__ pre,
+__device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const nvo_h16* __restrict__ pre, bool bf,
                                                 uint32_t pre_stride, const float* __restrict__ x01,
                                                 const float* __restrict__ tb, float bias,
                                                 const float* w, const float* Tr, const float* g,
-                                                float loss_scale, _Float16* __restrict__ dpre,
+                                                float loss_scale, nvo_h16* __restrict__ dpre,
                                                 uint32_t dpre_stride, bool zero_row = false) {
     // total of g_i w_i, then inclusive prefix per chunk -> suffix (exclusive) = total - incl
     float total = 0.f;
@@ -109,21 +109,20 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const _Flo
             const bool sel = x01[3 * (size_t)i] > 0.f;
             float d = 0.f;
             if (sel) {
-                const float x = (float)pre[(size_t)i * pre_stride] + bias;
+                const float x = nvo_ld16(pre + (size_t)i * pre_stride, bf) + bias;
                 const float delta = tb[i + 1] - tb[i];
                 const float dsig = delta * (g[i] * (Tr[i] - w[i]) - (total - incl));
                 d = dsig * __expf(fminf(fmaxf(x, -15.f), 15.f));
             }
             if (zero_row && dpre_stride == 16) {
                 // whole 32-byte row {d, 0 x 15} as two 16-byte stores (the MLP backward reads all 16 columns)
-                const _Float16 h = (_Float16)(d * loss_scale);
                 uint4 lo = make_uint4(0u, 0u, 0u, 0u);
-                lo.x = (uint32_t)__builtin_bit_cast(unsigned short, h);
+                lo.x = (uint32_t)nvo_cvt16(d * loss_scale, bf);
                 uint4* row = reinterpret_cast<uint4*>(dpre + (size_t)i * 16);
                 row[0] = lo;
                 row[1] = make_uint4(0u, 0u, 0u, 0u);
             } else {
-                dpre[(size_t)i * dpre_stride] = (_Float16)(d * loss_scale);
+                dpre[(size_t)i * dpre_stride] = nvo_cvt16(d * loss_scale, bf);
             }
         }
         carry = __shfl(incl, 63, 64);
@@ -145,7 +144,7 @@ k_weights_pdf(nvo_weights_pdf_args a) {
     const uint32_t S = a.S;
     const size_t so = (size_t)r * S;
     const float* tb = a.tbins + (size_t)r * (S + 1);
-    ray_weights(lane, S, (const _Float16*)a.pre + so * a.pre_stride, a.pre_stride, a.x01 + 3 * so, tb, a.density_bias,
+    ray_weights(lane, S, (const nvo_h16*)a.pre + so * a.pre_stride, a.act_bf16 != 0, a.pre_stride, a.x01 + 3 * so, tb, a.density_bias,
                 a.sigma ? a.sigma + so : nullptr, w, Tr);
     for (uint32_t i = lane; i < S; i += 64) a.weights[so + i] = w[i];
     if (a.S_out == 0) return;
@@ -226,9 +225,10 @@ k_main_render_loss(nvo_main_loss_args a) {
     const size_t so = (size_t)r * S;
     const float* tb = a.tbins + (size_t)r * (S + 1);
     const float* sb = a.sbins + (size_t)r * (S + 1);
-    const _Float16* pre = (const _Float16*)a.pre + so * a.pre_stride;
+    const nvo_h16* pre = (const nvo_h16*)a.pre + so * a.pre_stride;
+    const bool bf = a.act_bf16 != 0;
     const float* x01 = a.x01 + 3 * so;
-    ray_weights(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
+    ray_weights(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
     const bool act = (uint32_t)lane < S;
     const float wi = act ? w[lane] : 0.f;
     if (a.weights && act) a.weights[so + lane] = wi;
@@ -236,8 +236,8 @@ k_main_render_loss(nvo_main_loss_args a) {
     // ---- composite
     float c[3] = {0.f, 0.f, 0.f};
     if (act) {
-        const _Float16* cp = (const _Float16*)a.rgb + (so + lane) * a.rgb_stride;
-        c[0] = (float)cp[0]; c[1] = (float)cp[1]; c[2] = (float)cp[2];
+        const nvo_h16* cp = (const nvo_h16*)a.rgb + (so + lane) * a.rgb_stride;
+        c[0] = nvo_ld16(cp, bf); c[1] = nvo_ld16(cp + 1, bf); c[2] = nvo_ld16(cp + 2, bf);
     }
     const float acc = wave_sum(wi);
     float pix[3], clast[3];
@@ -400,23 +400,21 @@ k_main_render_loss(nvo_main_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+    ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
     if (act && a.drgb_stride == 16) {
         // the colour MLP backward reads all 16 columns: one 32-byte row {dr, dg, db, 0 x 13} as two 16-byte stores
-        const _Float16 h0 = (_Float16)(dc[0] * a.loss_scale), h1 = (_Float16)(dc[1] * a.loss_scale),
-                       h2v = (_Float16)(dc[2] * a.loss_scale);
         uint4 lo = make_uint4(0u, 0u, 0u, 0u);
-        lo.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
-        lo.y = (uint32_t)__builtin_bit_cast(unsigned short, h2v);
-        uint4* row = reinterpret_cast<uint4*>((_Float16*)a.drgb + (so + lane) * 16);
+        lo.x = nvo_cvt16x2(dc[0] * a.loss_scale, dc[1] * a.loss_scale, bf);
+        lo.y = (uint32_t)nvo_cvt16(dc[2] * a.loss_scale, bf);
+        uint4* row = reinterpret_cast<uint4*>((nvo_h16*)a.drgb + (so + lane) * 16);
         row[0] = lo;
         row[1] = make_uint4(0u, 0u, 0u, 0u);
     } else if (act) {
-        _Float16* dp = (_Float16*)a.drgb + (so + lane) * a.drgb_stride;
+        nvo_h16* dp = (nvo_h16*)a.drgb + (so + lane) * a.drgb_stride;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dp[k] = (_Float16)(dc[k] * a.loss_scale);
-        for (uint32_t k = 3; k < a.drgb_stride; ++k) dp[k] = (_Float16)0.f;
+        for (int k = 0; k < 3; ++k) dp[k] = nvo_cvt16(dc[k] * a.loss_scale, bf);
+        for (uint32_t k = 3; k < a.drgb_stride; ++k) dp[k] = (nvo_h16)0;
     }
 }
 
@@ -443,9 +441,10 @@ k_prop_loss(nvo_prop_loss_args a) {
         const float* sbg = a.sbins + (size_t)r * (S + 1);
         for (uint32_t i = lane; i < S + 1; i += 64) sb[i] = sbg[i];
     }
-    const _Float16* pre = (const _Float16*)a.pre + so * a.pre_stride;
+    const nvo_h16* pre = (const nvo_h16*)a.pre + so * a.pre_stride;
+    const bool bf = a.act_bf16 != 0;
     const float* x01 = a.x01 + 3 * so;
-    ray_weights(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
+    ray_weights(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, nullptr, w, Tr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -518,12 +517,12 @@ k_prop_loss(nvo_prop_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    ray_weights_bwd(lane, S, pre, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                    (_Float16*)a.dpre + so * a.dpre_stride, a.dpre_stride, true);
+    ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride, true);
     if (a.dpre_stride != 16) {
         for (uint32_t i = lane; i < S; i += 64) {
-            _Float16* dp = (_Float16*)a.dpre + (so + i) * a.dpre_stride;
-            for (uint32_t k = 1; k < a.dpre_stride; ++k) dp[k] = (_Float16)0.f;
+            nvo_h16* dp = (nvo_h16*)a.dpre + (so + i) * a.dpre_stride;
+            for (uint32_t k = 1; k < a.dpre_stride; ++k) dp[k] = (nvo_h16)0;
         }
     }
 }

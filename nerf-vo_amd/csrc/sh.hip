@@ -29,10 +29,10 @@ __device__ __forceinline__ void sh4_eval(float x, float y, float z, uint32_t deg
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
-// out: [N][out_stride] half; writes n_coeff coefficients then pads up to out_width with 1.0
+// out: [N][out_stride] fp16 (bf = 0) or bfloat16 (bf = 1); writes n_coeff coefficients then pads up to out_width with 1.0
 __global__ void __launch_bounds__(256)
-k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, __half* __restrict__ out,
-         uint32_t out_stride, uint32_t out_width) {
+k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, nvo_h16* __restrict__ out,
+         uint32_t out_stride, uint32_t out_width, int bf) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float x = d01[3 * (size_t)i + 0] * 2.f - 1.f;
@@ -43,8 +43,8 @@ k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, __half* __r
     for (int k = 0; k < 16; ++k) o[k] = 0.f;
     sh4_eval(x, y, z, degree, o);
     const uint32_t n_coeff = degree * degree;
-    __half* __restrict__ p = out + (size_t)i * out_stride;
-    for (uint32_t k = 0; k < out_width; ++k) p[k] = __float2half(k < n_coeff ? o[k] : 1.0f);
+    nvo_h16* __restrict__ p = out + (size_t)i * out_stride;
+    for (uint32_t k = 0; k < out_width; ++k) p[k] = nvo_cvt16(k < n_coeff ? o[k] : 1.0f, bf != 0);
 }
 
 // dL/dd01 = 2 * sum_k dL/dy_k * dy_k/d(x,y,z)
@@ -104,12 +104,12 @@ k_sh_bwd_input(uint32_t N, uint32_t degree, const float* __restrict__ d01,
 }  // namespace
 
 int nvo_sh_fwd_launch(hipStream_t stream, uint32_t N, uint32_t degree, const float* d01,
-                      void* out_half, uint32_t out_stride, uint32_t out_width) {
+                      void* out_half, uint32_t out_stride, uint32_t out_width, bool out_bf16) {
     NVO_REQUIRE(degree >= 1 && degree <= 4, "SphericalHarmonics: degree %u not in 1..4", degree);
     if (N == 0) return NVO_OK;
     NVO_PROF(stream, "sh_fwd");
     NVO_LAUNCH(k_sh_fwd, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, N, degree, d01,
-                       (__half*)out_half, out_stride, out_width);
+                       (nvo_h16*)out_half, out_stride, out_width, out_bf16 ? 1 : 0);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

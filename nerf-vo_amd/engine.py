@@ -100,6 +100,11 @@ class EngineConfig:
     store_input_gradients: bool | None = None
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
+    # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
+    # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
+    # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
+    # "MFMA bf16 MLP + fp32 hash accumulate"; reference: mixed_precision=True, nerf_vo/mapping/nerfstudio.py:59)
+    mlp_dtype: str = "f16"
     seed: int = 1337
 
 
@@ -116,14 +121,19 @@ class NerfactoEngine:
 
     LOSS_NAMES = ("rgb_loss", "distortion_loss", "depth_loss", "interlevel_loss", "prop_depth_loss")
 
-    def __init__(self, config: EngineConfig, device: torch.device, world_size: int = 1):
+    def __init__(self, config: EngineConfig, device: torch.device, world_size: int = 1, rank: int = 0):
         if device.type != "cuda":
             raise RuntimeError("NerfactoEngine needs an MI355X device; there is no CPU fallback")
         self.cfg = config
         self.device = device
         self.world_size = world_size
+        self.rank = int(rank)  # mixed into the stateless pixel / jitter sampler: every rank draws its own rays
         cfg = config
         self.levels = (*cfg.num_proposal_samples, cfg.num_nerf_samples)
+        if cfg.mlp_dtype not in ("f16", "bf16"):
+            raise ValueError(f"mlp_dtype must be 'f16' or 'bf16' (got {cfg.mlp_dtype!r})")
+        self.bf16 = cfg.mlp_dtype == "bf16"
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float16
 
         # ---- native modules (tcnn NetworkWithInputEncoding: params = [mlp | grid])
         self.prop_nets = [
@@ -142,6 +152,7 @@ class NerfactoEngine:
         modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
+            m.set_option("bf16", int(self.bf16))
         # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
         for m in self.prop_nets:
@@ -176,8 +187,23 @@ class NerfactoEngine:
             lo, hi = self.group_ranges.get(g, (o, o))
             self.group_ranges[g] = (min(lo, o), max(hi, o + s))
 
+        # bf16 mode: which element ranges of the 16-bit working copy are bfloat16 (fused-MLP weights + appearance
+        # embedding); everything else -- the hash tables (and the unused copy of the poses) -- stays fp16
+        self.bf16_ranges = []
+        if self.bf16:
+            n_base_mlp = self.base_net.n_params - self._grid_params(self.base_net)
+            o = self.segments["field.base"][0]
+            self.bf16_ranges.append((o, o + n_base_mlp))
+            self.bf16_ranges.append((self.segments["field.color"][0], sum(self.segments["field.embedding"][:2])))
+            for i, m in enumerate(self.prop_nets):
+                o = self.segments[f"proposal.{i}"][0]
+                self.bf16_ranges.append((o, o + m.n_params - self._grid_params(m)))
+        self._bf16_lo = (C.c_uint64 * max(len(self.bf16_ranges), 1))(*[lo for lo, _ in self.bf16_ranges])
+        self._bf16_hi = (C.c_uint64 * max(len(self.bf16_ranges), 1))(*[hi for _, hi in self.bf16_ranges])
         dev = device
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        # 16-bit working copy the kernels read: fp16, except the bf16_ranges in bf16 mode (raw bits; decode with
+        # working_copy_float())
         self.params_half = torch.zeros(self.n_params, dtype=torch.float16, device=dev)
         self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
@@ -195,7 +221,7 @@ class NerfactoEngine:
         self.opt_steps = {g: 0 for g in self.group_ranges}
         self.step = 0
         self.steps_since_proposal_update = 0
-        self._ws = None
+        self._ws = {}  # (ray count, training) -> scratch; never evicted (captured graphs address it by pointer)
         self.init_params(cfg.seed)
 
     # ------------------------------------------------------------------------------------------
@@ -230,8 +256,28 @@ class NerfactoEngine:
         self.params.copy_(flat.to(self.device, torch.float32))
         self.sync_half()
 
+    @staticmethod
+    def _grid_params(net: _NativeModule) -> int:
+        levels = (C.c_uint32 * (4 * 32))()
+        scales = (C.c_float * 32)()
+        _call("nvo_grid_describe", net.handle, levels, scales)
+        entries, l = 0, 0
+        while l < 32 and levels[4 * l + 1] > 0:
+            entries += levels[4 * l + 1]
+            l += 1
+        return 2 * entries
+
     def sync_half(self) -> None:
-        _call("nvo_cast_half", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half))
+        _call("nvo_cast_working_copy", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half),
+              len(self.bf16_ranges), self._bf16_lo, self._bf16_hi)
+
+    def working_copy_float(self) -> torch.Tensor:
+        """The values the kernels actually consume (the 16-bit working copy decoded to fp32): fp16 everywhere in
+        f16 mode; in bf16 mode bfloat16 inside bf16_ranges and fp16 elsewhere."""
+        out = self.params_half.float()
+        for lo, hi in self.bf16_ranges:
+            out[lo:hi] = self.params_half[lo:hi].view(torch.bfloat16).float()
+        return out
 
     def reset_optimizer(self) -> None:
         self.exp_avg.zero_()
@@ -243,11 +289,11 @@ class NerfactoEngine:
     # ------------------------------------------------------------------------------------------
     def _workspace(self, R: int, training: bool):
         key = (R, training)
-        if self._ws is not None and self._ws["key"] == key:
-            return self._ws
+        if key in self._ws:
+            return self._ws[key]
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        f16 = dict(dtype=torch.float16, device=dev)
+        f16 = dict(dtype=self.act_dtype, device=dev)  # 16-bit activations / gradients (fp16 | bf16)
         ws = {"key": key, "R": R}
         ws["origins"] = torch.empty(R, 3, **f32)
         ws["directions"] = torch.empty(R, 3, **f32)
@@ -290,7 +336,7 @@ class NerfactoEngine:
         if training:
             # colour head: no stored hidden activations (recomputed in the backward)
             ws["drgb"] = torch.empty(Nm, 16, **f16)
-        self._ws = ws
+        self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------------------------------
@@ -315,7 +361,7 @@ class NerfactoEngine:
         N = ws["R"] * self.levels[km]
         if "dsigma_dx" not in ws:
             ws["dsigma_dx"] = torch.empty(N, 3, dtype=torch.float32, device=self.device)
-            seed = torch.zeros(N, 16, dtype=torch.float16, device=self.device)
+            seed = torch.zeros(N, 16, dtype=self.act_dtype, device=self.device)
             seed[:, 0] = self.cfg.loss_scale
             ws["dsigma_seed"] = seed
         _call("nvo_bwd", self.base_net.handle, stream, N, _ptr(ws[f"x{km}"]),
@@ -337,7 +383,7 @@ class NerfactoEngine:
             tbins_out=ws[f"tbins{k + 1}"].data_ptr() if resample else None, anneal_dev=anneal_dev,
             origins=ws["origins"].data_ptr() if resample else None,
             directions=ws["directions"].data_ptr() if resample else None,
-            x01_out=ws[f"x{k + 1}"].data_ptr() if resample else None)
+            x01_out=ws[f"x{k + 1}"].data_ptr() if resample else None, act_bf16=int(self.bf16))
         _call("nvo_weights_pdf", stream, C.byref(a))
 
     def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream,
@@ -356,7 +402,7 @@ class NerfactoEngine:
         if not ws.get("dirs01_ready", False):
             _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
         ws["dirs01_ready"] = False
-        _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+        _call("nvo_sh_encode_t", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]), int(self.bf16))
         ca = self._color_args(ws, training, cam_idx_for_embedding, embedding_ptr)
         _call("nvo_nerfacto_color_fwd", stream, C.byref(ca))
         return ca
@@ -372,7 +418,8 @@ class NerfactoEngine:
             d_base_out=ws[f"dout{km}"].data_ptr() if training else None,
             d_embedding=self._param_ptr("field.embedding", self.grads).value if training else None,
             d_sh=ws["d_sh"].data_ptr() if (training and "d_sh" in ws) else None,
-            d_weights=self._param_ptr("field.color", self.grads).value if training else None)
+            d_weights=self._param_ptr("field.color", self.grads).value if training else None,
+            act_bf16=int(self.bf16))
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -398,7 +445,7 @@ class NerfactoEngine:
             dsigma_dx=ws["dsigma_dx"].data_ptr() if normals else None, dsigma_inv_scale=1.0 / cfg.loss_scale,
             gt_normal=ws["gt_normal"].data_ptr() if (normals and training and has_gt_normal) else None,
             normal_mult=cfg.normal_loss_mult if (normals and has_gt_normal) else 0.0,
-            out_normals=ws["out_normals"].data_ptr() if normals else None)
+            out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16))
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -553,7 +600,8 @@ class NerfactoEngine:
                 directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
                 depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
                 inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
-                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=1)
+                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=1,
+                act_bf16=int(self.bf16))
             _call("nvo_prop_loss", stream, C.byref(pa))
             _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
                   self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
@@ -625,9 +673,9 @@ class NerfactoEngine:
             batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=max(self.opt_steps[g], 1),
                                         hyper_dev=hyper))
         arr = (_lib.AdamGroup * len(batch))(*batch)
-        _call("nvo_adam_step_groups", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+        _call("nvo_adam_step_groups_mixed", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
               ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
-              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi)
 
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step
@@ -701,7 +749,9 @@ class NerfactoEngine:
 
         ray_indices = torch.zeros((R, 3), dtype=torch.int64, device=dev)
         jit = torch.zeros((3, R), dtype=torch.float32, device=dev)
-        rng_seed = int(torch.initial_seed() & 0xFFFFFFFF)  # follows torch.manual_seed (per rank in multi-GPU runs)
+        # follows torch.manual_seed; the rank is mixed in so that data-parallel ranks never draw the same rays even when
+        # every process was seeded identically (same multiplier as the data manager's rank-offset generator)
+        rng_seed = int((torch.initial_seed() + 1000003 * self.rank) & 0xFFFFFFFF)
         step_ptr = C.c_void_p(self.dev_scalars.data_ptr() + 4 * 10)
 
         def body_main():
@@ -741,7 +791,7 @@ class NerfactoEngine:
             dst.copy_(src)  # the warm-up steps must not count as training
         # the graph addresses these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
-        entry = {"half": half, "buffers": (c2w, ray_indices, jit, scale)}
+        entry = {"half": half, "buffers": (c2w, ray_indices, jit, scale), "ws": ws}
         g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_main):
             body_main()
@@ -778,8 +828,10 @@ class NerfactoEngine:
         self.step += 1
         return updated
 
-    def loss_dict(self) -> dict:
-        vals = self.losses.sum(dim=0).tolist()
+    def loss_dict(self, totals: torch.Tensor | None = None) -> dict:
+        """Loss terms of the last step as Python floats (ONE device sync).  ``totals``: a snapshot taken earlier
+        with loss_totals()."""
+        vals = (self.losses.sum(dim=0) if totals is None else totals).tolist()
         d = {"rgb_loss": vals[0], "distortion_loss": vals[1], "depth_loss": vals[2] + vals[4],
              "interlevel_loss": vals[3]}
         if self.cfg.optimize_poses:
@@ -787,6 +839,10 @@ class NerfactoEngine:
         if vals[6] != 0.0:
             d["normal_loss"] = vals[6]
         return d
+
+    def loss_totals(self) -> torch.Tensor:
+        """[8] device tensor: the sharded loss accumulators of the last step summed (enqueued, no host sync)."""
+        return self.losses.sum(dim=0)
 
     # ------------------------------------------------------------------------------------------
     # inference
@@ -804,7 +860,10 @@ class NerfactoEngine:
         stream = _stream(self.device)
         if mean_embedding_half is None:
             emb = self.view("field.embedding").view(self.cfg.num_images, -1)
-            mean_embedding_half = emb.mean(dim=0, keepdim=True).to(torch.float16).contiguous()
+            mean_embedding_half = emb.mean(dim=0, keepdim=True)
+        if mean_embedding_half.dtype != self.act_dtype:  # (callers may hand in fp32 / fp16: the colour head reads
+            mean_embedding_half = mean_embedding_half.float().to(self.act_dtype)  # its operand format)
+        mean_embedding_half = mean_embedding_half.contiguous()
         self._forward(ws, False, 1.0, None, None, mean_embedding_half.data_ptr(), stream)
         if normals:
             self._analytic_normal_grads(ws, stream)

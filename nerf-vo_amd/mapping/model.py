@@ -44,6 +44,7 @@ class DepthNerfactoModelConfig:
     depth_sigma: float = 0.01
     should_decay_sigma: bool = False
     eval_num_rays_per_chunk: int = 1 << 15
+    mlp_dtype: str = "f16"  # "bf16": fused MLPs on bf16 MFMA, hash tables fp16 + fp32 accumulate (BASELINE configs[4])
     camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
 
 
@@ -52,8 +53,8 @@ class ExtendedNerfactoModelConfig(DepthNerfactoModelConfig):
     normal_loss_mult: float = 1e-5
 
     def setup(self, num_train_data: int, device, world_size: int = 1, max_num_iterations: int = 8192,
-              num_rays: int = 4096, seed: int = 1337):
-        return ExtendedNerfactoModel(self, num_train_data, device, world_size, max_num_iterations, num_rays, seed)
+              num_rays: int = 4096, seed: int = 1337, rank: int = 0):
+        return ExtendedNerfactoModel(self, num_train_data, device, world_size, max_num_iterations, num_rays, seed, rank)
 
 
 class CameraOptimizer(torch.nn.Module):
@@ -85,7 +86,7 @@ class CameraOptimizer(torch.nn.Module):
 
 class ExtendedNerfactoModel:
     def __init__(self, config: ExtendedNerfactoModelConfig, num_train_data: int, device, world_size: int = 1,
-                 max_num_iterations: int = 8192, num_rays: int = 4096, seed: int = 1337):
+                 max_num_iterations: int = 8192, num_rays: int = 4096, seed: int = 1337, rank: int = 0):
         if config.is_euclidean_depth:
             raise NotImplementedError("is_euclidean_depth=True is not used by the reference (nerfstudio.py:79)")
         self.config = config
@@ -96,12 +97,12 @@ class ExtendedNerfactoModel:
             num_nerf_samples=config.num_nerf_samples_per_ray, interlevel_loss_mult=config.interlevel_loss_mult,
             distortion_loss_mult=config.distortion_loss_mult, depth_loss_mult=config.depth_loss_mult,
             depth_sigma=config.depth_sigma, normal_loss_mult=float(config.normal_loss_mult),
-            max_num_iterations=max_num_iterations, seed=seed,
+            max_num_iterations=max_num_iterations, seed=seed, mlp_dtype=config.mlp_dtype,
             optimize_poses=config.camera_optimizer.mode in ("SE3", "SO3xR3"),
             camera_mode=config.camera_optimizer.mode if config.camera_optimizer.mode in ("SE3", "SO3xR3") else "SE3",
             camera_trans_l2_penalty=config.camera_optimizer.trans_l2_penalty,
             camera_rot_l2_penalty=config.camera_optimizer.rot_l2_penalty)
-        self.engine = NerfactoEngine(ecfg, self.device, world_size=world_size)
+        self.engine = NerfactoEngine(ecfg, self.device, world_size=world_size, rank=rank)
         self.camera_optimizer = CameraOptimizer(config.camera_optimizer, self.engine)
         self.training = True
         # Loss terms whose multiplier is 0 in every shipped configuration (orientation / predicted
@@ -147,7 +148,7 @@ class ExtendedNerfactoModel:
         n = origins.shape[0]
         chunk = min(self.config.eval_num_rays_per_chunk, max(n, 1))
         emb = self.engine.view("field.embedding").view(self.engine.cfg.num_images, -1)
-        mean_emb = emb.mean(dim=0, keepdim=True).to(torch.float16).contiguous()
+        mean_emb = emb.mean(dim=0, keepdim=True).contiguous()  # the engine casts it to the colour head's operand format
         outs: dict[str, list] = {}
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
@@ -167,8 +168,8 @@ class ExtendedNerfactoModel:
         return self.get_outputs_for_camera_ray_bundle(ray_bundle)
 
     # ---- training-time dictionaries (filled by the last native step) --------------------------
-    def get_metrics_dict(self, outputs=None, batch=None) -> dict:
-        ld = self.engine.loss_dict()
+    def get_metrics_dict(self, outputs=None, batch=None, loss_dict: dict | None = None) -> dict:
+        ld = self.engine.loss_dict() if loss_dict is None else loss_dict
         cfg = self.config
         metrics = {"distortion": ld["distortion_loss"] / cfg.distortion_loss_mult if cfg.distortion_loss_mult else 0.0,
                    "depth_loss": ld["depth_loss"] / cfg.depth_loss_mult if cfg.depth_loss_mult else 0.0}

@@ -15,6 +15,33 @@ from .dataset import DynamicDataManagerConfig
 from .model import ExtendedNerfactoModelConfig
 
 
+class LazyLossDict(dict):
+    """What ``train_iteration`` hands back for loss_dict / metrics_dict: a dict whose values are read from the device
+    on FIRST ACCESS.  The reference only looks at them on logging steps (/root/reference/nerf_vo/mapping/nerfstudio.py:
+    161-168); materialising them every iteration costs a full device sync per step and stalls the graph replay."""
+
+    def __init__(self, fill):
+        super().__init__()
+        self._fill = fill
+
+    def _load(self):
+        if self._fill is not None:
+            fill, self._fill = self._fill, None
+            super().update(fill())
+
+    def _wrap(name):  # noqa: N805
+        def method(self, *a, **k):
+            self._load()
+            return getattr(dict, name)(self, *a, **k)
+        method.__name__ = name
+        return method
+
+    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "keys", "values", "items",
+               "get", "copy", "pop", "setdefault", "update", "__setitem__", "__delitem__"):
+        locals()[_n] = _wrap(_n)
+    del _n, _wrap
+
+
 class TrainingCallbackLocation(enum.Enum):
     BEFORE_TRAIN_ITERATION = 1
     AFTER_TRAIN_ITERATION = 2
@@ -78,7 +105,7 @@ class VanillaPipeline:
                                                     local_rank=local_rank)
         self.model = config.model.setup(num_train_data=config.datamanager.num_frames, device=self.device,
                                         world_size=world_size, max_num_iterations=max_num_iterations,
-                                        num_rays=config.datamanager.train_num_rays_per_batch)
+                                        num_rays=config.datamanager.train_num_rays_per_batch, rank=local_rank)
         self.training = True
         self.all_reduce = None  # set by the distributed launcher (nerf_vo_amd.parallel.GradientAllReduce)
         import os
@@ -107,7 +134,10 @@ class VanillaPipeline:
             normals = ds.world_normals01() if (ds.use_normals and eng.cfg.normal_loss_mult > 0.0) else None
             eng.train_step(ray_indices, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth,
                            all_reduce=self.all_reduce, normals=normals)
-        return None, eng.loss_dict(), self.model.get_metrics_dict()
+        totals = eng.loss_totals()  # device snapshot of this step's loss terms; read back only if somebody looks
+        loss_dict = LazyLossDict(lambda: eng.loss_dict(totals))
+        metrics = LazyLossDict(lambda: self.model.get_metrics_dict(loss_dict=dict(loss_dict)))
+        return totals[:7].sum(), loss_dict, metrics
 
 
 @dataclass
@@ -205,9 +235,8 @@ class Trainer:
         return None
 
     def train_iteration(self, step: int):
-        _, loss_dict, metrics_dict = self.pipeline.get_train_loss_dict(step)
-        loss = sum(loss_dict.values())
-        return loss, loss_dict, metrics_dict
+        # loss: 0-dim device tensor (as in nerfstudio); the dictionaries are read from the device on first access
+        return self.pipeline.get_train_loss_dict(step)
 
     def save_checkpoint(self, step: int) -> None:
         self.checkpoint_dir.mkdir(parents=True, exist_ok=True)

@@ -21,7 +21,9 @@ def preferred_precision() -> torch.dtype:
 
 
 def default_loss_scale(precision: torch.dtype = torch.float16) -> float:
-    return 128.0 if precision == torch.float16 else 1.0
+    # bf16 does not need the scale for range, but the hash-grid backward accumulates in fixed point sized for the
+    # SCALED gradient, so both 16-bit formats use tcnn's fp16 default
+    return 128.0 if precision in (torch.float16, torch.bfloat16) else 1.0
 
 
 def free_temporary_memory() -> None:
@@ -72,10 +74,12 @@ class _NativeModule:
     def set_option(self, key: str, value: int) -> None:
         _lib.check(_lib.lib().nvo_set_option(self.handle, key.encode(), int(value)), f"set_option({key})")
 
+    out_dtype = torch.float16  # torch.bfloat16 once the "bf16" option is set (Module.__init__)
+
     def fwd(self, x: torch.Tensor, params: torch.Tensor, save_ctx: bool):
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         batch = x.shape[0]
-        out = torch.empty((batch, self.padded_output_dims), dtype=torch.float16, device=x.device)
+        out = torch.empty((batch, self.padded_output_dims), dtype=self.out_dtype, device=x.device)
         ctx = None
         if save_ctx or self.needs_ctx_for_inference:
             ctx = torch.empty(self.ctx_bytes(batch), dtype=torch.uint8, device=x.device)
@@ -102,9 +106,12 @@ class _NativeModule:
 
 class _module_function(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, native: _NativeModule, x: torch.Tensor, params: torch.Tensor, loss_scale: float):
+    def forward(ctx, native: _NativeModule, x: torch.Tensor, master: torch.Tensor, params: torch.Tensor,
+                loss_scale: float):
+        """master: the fp32 parameters (what receives the gradient); params: their 16-bit working copy in the
+        format the kernels read (not differentiated)."""
         ctx.set_materialize_grads(False)
-        needs_grad = x.requires_grad or params.requires_grad
+        needs_grad = x.requires_grad or master.requires_grad
         native_ctx, output = native.fwd(x, params, save_ctx=needs_grad)
         ctx.save_for_backward(x, params, output)
         ctx.native = native
@@ -115,26 +122,33 @@ class _module_function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, doutput):
         if doutput is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x, params, output = ctx.saved_tensors
         if ctx.native_ctx is None:
             raise RuntimeError("tcnn module backward called but forward ran without gradient tracking")
-        scaled = (doutput.to(torch.float32) * ctx.loss_scale).to(torch.float16).contiguous()
+        scaled = (doutput.to(torch.float32) * ctx.loss_scale).to(ctx.native.out_dtype).contiguous()
         need_dx = ctx.needs_input_grad[1]
         need_dp = ctx.needs_input_grad[2] and ctx.native.n_params > 0
         dx, dp = ctx.native.bwd(ctx.native_ctx, x, params, output, scaled, need_dx, need_dp)
         if dx is not None:
             dx = dx / ctx.loss_scale
         if dp is not None:
-            dp = (dp / ctx.loss_scale).to(params.dtype)
-        return None, dx, dp, None
+            dp = dp / ctx.loss_scale  # fp32, accumulated in fp32 by the kernels (tcnn hands back fp16 here)
+        return None, dx, dp, None, None
 
 
 class Module(torch.nn.Module):
-    def __init__(self, seed: int = 1337):
+    """``dtype``: torch.float16 (default, tcnn's precision) or torch.bfloat16 -- an extension over tcnn: outputs,
+    hidden activations and MLP weights in bfloat16 on v_mfma_f32_16x16x16_bf16 (hash tables stay fp16 with fp32
+    interpolation / gradient accumulation)."""
+
+    def __init__(self, seed: int = 1337, dtype=None):
         super().__init__()
+        dtype = torch.float16 if dtype is None else dtype
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError("nerf_vo_amd tcnn modules compute in fp16 or bf16 (fp32 accumulate) only")
+        self.dtype = dtype
         self.native_tcnn_module = self._native_tcnn_module()
-        self.dtype = torch.float16
         self.seed = seed
         initial_params = self.native_tcnn_module.initial_params(seed)
         self.params = torch.nn.Parameter(initial_params, requires_grad=True)
@@ -154,10 +168,21 @@ class Module(torch.nn.Module):
         output = _module_function.apply(
             self.native_tcnn_module,
             x_padded.to(torch.float).contiguous(),
-            self.params.to(self.dtype).contiguous(),
+            self.params,
+            self._working_copy(),
             self.loss_scale,
         )
         return output[:batch_size, : self.n_output_dims]
+
+    def _working_copy(self) -> torch.Tensor:
+        """16-bit copy of the parameters in the format the kernels read (raw bits for mixed layouts)."""
+        return self.params.detach().to(self.dtype).contiguous()
+
+    def _configure_native(self, m: _NativeModule) -> _NativeModule:
+        if self.dtype == torch.bfloat16:
+            m.set_option("bf16", 1)
+            m.out_dtype = torch.bfloat16
+        return m
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -166,6 +191,7 @@ class Module(torch.nn.Module):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("dtype", torch.float16)
         self.native_tcnn_module = self._native_tcnn_module()
 
     def extra_repr(self) -> str:
@@ -182,33 +208,44 @@ def _create(fn_name: str, *args) -> _NativeModule:
 class NetworkWithInputEncoding(Module):
     """Input encoding followed by a fully fused MLP; params = [network | encoding] (tcnn order)."""
 
-    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, dtype=None):
         self.n_input_dims = n_input_dims
         self.n_output_dims = n_output_dims
         self.encoding_config = dict(encoding_config)
         self.network_config = dict(network_config)
-        super().__init__(seed=seed)
+        super().__init__(seed=seed, dtype=dtype)
 
     def _native_tcnn_module(self):
         m = _create(
             "nvo_create_network_with_input_encoding", self.n_input_dims, self.n_output_dims,
             json.dumps(self.encoding_config).encode(), json.dumps(self.network_config).encode())
         m.needs_ctx_for_inference = True
-        return m
+        enc = _create("nvo_create_encoding", self.n_input_dims, json.dumps(self.encoding_config).encode())
+        self._n_network_params = m.n_params - enc.n_params  # params = [network | encoding]
+        del enc
+        return self._configure_native(m)
+
+    def _working_copy(self) -> torch.Tensor:
+        if self.dtype == torch.float16:
+            return super()._working_copy()
+        # bf16: network weights bfloat16, hash table fp16 -- one raw 16-bit buffer
+        p = self.params.detach()
+        k = self._n_network_params
+        return torch.cat([p[:k].to(torch.bfloat16).view(torch.int16), p[k:].to(torch.float16).view(torch.int16)])
 
 
 class Network(Module):
     """Fully fused MLP on raw (identity-encoded, 1-padded) inputs."""
 
-    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
+    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337, dtype=None):
         self.n_input_dims = n_input_dims
         self.n_output_dims = n_output_dims
         self.network_config = dict(network_config)
-        super().__init__(seed=seed)
+        super().__init__(seed=seed, dtype=dtype)
 
     def _native_tcnn_module(self):
-        return _create("nvo_create_network", self.n_input_dims, self.n_output_dims,
-                       json.dumps(self.network_config).encode())
+        return self._configure_native(_create("nvo_create_network", self.n_input_dims, self.n_output_dims,
+                                              json.dumps(self.network_config).encode()))
 
 
 class Encoding(Module):
@@ -217,10 +254,12 @@ class Encoding(Module):
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):
         self.n_input_dims = n_input_dims
         self.encoding_config = dict(encoding_config)
-        if dtype is not None and dtype != torch.float16:
-            raise NotImplementedError("nerf_vo_amd tcnn.Encoding computes in fp16 only")
-        super().__init__(seed=seed)
+        super().__init__(seed=seed, dtype=dtype)
         self.n_output_dims = self.native_tcnn_module.n_output_dims
 
     def _native_tcnn_module(self):
-        return _create("nvo_create_encoding", self.n_input_dims, json.dumps(self.encoding_config).encode())
+        return self._configure_native(_create("nvo_create_encoding", self.n_input_dims,
+                                              json.dumps(self.encoding_config).encode()))
+
+    def _working_copy(self) -> torch.Tensor:
+        return self.params.detach().to(torch.float16).contiguous()  # the table is fp16 in both output formats

@@ -153,5 +153,7 @@ def grid_encode(spec: GridSpec, x: torch.Tensor, table: torch.Tensor, quantize_o
         outs.append(acc)
     y = torch.cat(outs, dim=1)
     if quantize_output:
-        y = y + (y.to(torch.float16).to(dt) - y).detach()  # straight-through fp16 rounding
+        from .quant import q16
+
+        y = q16(y)  # straight-through rounding to the network's input format (fp16 | bf16, quant.py)
     return y

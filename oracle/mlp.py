@@ -42,9 +42,7 @@ def _act(name: str, x: torch.Tensor) -> torch.Tensor:
     raise ValueError(name)
 
 
-def _q16(x: torch.Tensor) -> torch.Tensor:
-    """fp16 rounding with a straight-through gradient (models the kernel's fp16 storage points)."""
-    return x + (x.to(torch.float16).to(x.dtype) - x).detach()
+from .quant import q16 as _q16  # 16-bit storage emulation in the ACTIVE format (fp16 | bf16), see quant.py
 
 
 def mlp_forward(x: torch.Tensor, weights, activation="ReLU", output_activation="None", pad_value=1.0,

@@ -49,8 +49,7 @@ class OracleConfig:
     dtype: torch.dtype = torch.float64
 
 
-def _q16(x):
-    return x + (x.to(torch.float16).to(x.dtype) - x).detach()
+from .quant import q16 as _q16  # 16-bit storage emulation in the ACTIVE format (fp16 | bf16), see quant.py
 
 
 class NerfactoOracle:

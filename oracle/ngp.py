@@ -15,8 +15,7 @@ from . import occgrid as O
 from . import sh as S
 
 
-def _q16(x):
-    return x + (x.to(torch.float16).to(x.dtype) - x).detach()
+from .quant import q16 as _q16  # 16-bit storage emulation in the ACTIVE format (fp16 | bf16), see quant.py
 
 
 class NgpOracle:

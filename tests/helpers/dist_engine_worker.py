@@ -30,8 +30,9 @@ def main():
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
-    torch.manual_seed(100 + rank)  # rank-specific sampler stream of the graphed step
-    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"]), dev, world_size=world)
+    torch.manual_seed(100)  # SAME seed on every rank: the engine itself must give each rank its own sampler stream
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"]), dev, world_size=world,
+                         rank=rank)
     eng.set_params(plan["params"].to(dev))  # identical initial parameters on every rank
     reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress)
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
@@ -44,8 +45,9 @@ def main():
     for _ in range(plan["graph_steps"]):
         eng.train_step_graphed(ds, all_reduce=reducer)
     torch.cuda.synchronize()
+    drawn = next(iter(eng._graphs.values()))["buffers"][1].cpu()  # pixel indices of the last graph-replayed step
     torch.save({"after_eager": after_eager, "after_graph": eng.params.detach().cpu(), "losses": eng.loss_dict(),
-                "skip": eng.skip_flag.cpu()}, os.path.join(workdir, f"rank{rank}.pt"))
+                "skip": eng.skip_flag.cpu(), "ray_indices": drawn}, os.path.join(workdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

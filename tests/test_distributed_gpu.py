@@ -63,6 +63,10 @@ def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, po
     assert torch.equal(r0["after_eager"], r1["after_eager"]) and torch.equal(r0["after_graph"], r1["after_graph"])
     assert not torch.equal(r0["after_eager"], params0) and not torch.equal(r0["after_graph"], r0["after_eager"])
     assert int(r0["skip"].sum()) == 0 and np.isfinite(list(r0["losses"].values())).all()
+    # every process called torch.manual_seed with the SAME value: the ranks must still draw different rays (otherwise
+    # the summed gradient is one rank's gradient and data parallelism silently adds nothing)
+    same = float((r0["ray_indices"] == r1["ray_indices"]).all(dim=1).float().mean())
+    assert same < 0.01, f"{same:.1%} of the two ranks' pixel samples coincide"
     # (2) same trajectory as ONE process training on the concatenated batch
     ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
     seq = make_sequence(n, H, W, device=device)
