@@ -136,7 +136,7 @@ def test_full_step_matches_oracle(device, dtype):
         return eng.grads[o:o + s] / ls
 
     nb = _mlp_count("field.base")
-    tol = dict(rtol=3e-2 * K, atol_scale=1.5e-2 * K, max_outlier_frac=1e-4 * K)
+    tol = dict(rtol=3e-2 * K, atol_scale=1.5e-2 * K, max_outlier_frac=1e-4 * K, max_outlier=0.05 if K == 1.0 else 0.2)
     _assert_close(gseg("field.color"), orc.params["color_mlp"].grad, what="d colour MLP", **tol)
     _assert_close(gseg("field.embedding"), orc.params["embedding"].grad.reshape(-1), what="d embedding", **tol)
     _assert_close(gseg("field.base")[:nb], orc.params["base_mlp"].grad, what="d base MLP", **tol)

@@ -51,11 +51,12 @@ def _points(n, seed, edge_cases=True):
     return x
 
 
-def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0):
+def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0, max_outlier=0.05):
     """|got-ref| <= atol_scale*max|ref| + rtol*|ref| elementwise.  max_outlier_frac > 0 is only used
     for gradients that pass through ReLU kinks: a hidden unit whose pre-activation is within fp16
     rounding of 0 can take a different branch in the kernel and in the float64 oracle, which changes
-    a handful of (sample-local) gradient entries discontinuously."""
+    a handful of (sample-local) gradient entries discontinuously; such an entry may be off by at most
+    max_outlier * max|ref| (0.05; the bf16 tests allow 0.2 -- 8x wider rounding band around every kink)."""
     got = got.double().cpu()
     ref = ref.double().cpu()
     scale = max(ref.abs().max().item(), 1e-30)
@@ -63,7 +64,7 @@ def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0):
     bound = atol_scale * scale + rtol * ref.abs()
     bad = err > bound
     if max_outlier_frac > 0 and bad.sum().item() <= max_outlier_frac * bad.numel():
-        assert err.max().item() <= 0.05 * scale, f"{what}: outlier too large {err.max().item():.3e} (scale {scale:.3e})"
+        assert err.max().item() <= max_outlier * scale, f"{what}: outlier too large {err.max().item():.3e} (scale {scale:.3e})"
         return
     assert not bad.any(), (
         f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max().item():.4e} "
