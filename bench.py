@@ -32,6 +32,19 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
+WORKLOADS = {
+    "replica": dict(keyframes=192, height=480, width=640, mlp_dtype="f16", normals=False,
+                    name="BASELINE configs[1]: Replica-shaped full mapping step, depth-nerfacto (proposal sampling "
+                         "256/96/48), fixed poses"),
+    "replica360": dict(keyframes=192, height=360, width=640, mlp_dtype="f16", normals=False,
+                       name="BASELINE configs[1] at the reference's Replica training resolution 360x640 "
+                            "(configs/nerf_vo_replica.yaml:16-17)"),
+    "scannet": dict(keyframes=512, height=240, width=320, mlp_dtype="bf16", normals=True,
+                    name="BASELINE configs[4] (one GPU of it): ScanNet-shaped mapping step, 512 keyframes 240x320 "
+                         "(configs/nerf_vo_scannet.yaml:15-17), depth + monosdf normal supervision, bf16 MFMA MLPs + "
+                         "fp32 hash accumulate"),
+}
+
 
 def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
     """ALGORITHMIC bytes one launch of the named kernel moves (DESIGN.md section 'Kernels'; per-unit
@@ -47,10 +60,12 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
         return (n_p0 + n_p1) / 2 * (5 * 8 * 4 + 12 + 5 * 4)
     bwd_kinds = ("grid_bwd_lds", "grid_bwd_atomic", "grid_bwd_binned", "grid_bwd_stream")
     if name in tuple(k + "[L16]" for k in bwd_kinds):
-        # read-modify-write of every touched fp32 corner pair + x + d(encoded) fp16
-        return n_main * (16 * 8 * 8 * 2 + 12 + 16 * 4)
+        # scatter RMW 2 x 512 B (16 levels x 8 corners x 4 B, read + write) + 12 B position
+        # + 64 B d(encoded) = 1100 B / sample.  (The kernels accumulate fp32 pairs -- twice the RMW bytes of the
+        # fp16 table 8d prices -- which the contract does not credit: see roofline.algorithmic_bytes_fp32_rmw.)
+        return n_main * (16 * 8 * 4 * 2 + 12 + 16 * 4)
     if name in tuple(k + "[L5]" for k in bwd_kinds):  # one launch per proposal net: average of the two
-        return (n_p0 + n_p1) / 2 * (5 * 8 * 8 * 2 + 12 + 5 * 4)
+        return (n_p0 + n_p1) / 2 * (5 * 8 * 4 * 2 + 12 + 5 * 4)
     if name == "mlp_bwd[64-64x2-16]":
         # drgb, rgb, 2 hidden, base_out in; d_base_out out (fp16 rows)
         return n_main * 2 * (16 + 16 + 128 + 16 + 16)
@@ -88,10 +103,19 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--keyframes", type=int, default=192)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="replica",
+                    help="replica = BASELINE configs[1] (192 keyframes 640x480, fp16 MLPs); replica360 = the same at the "
+                         "reference's own Replica training resolution 360x640 (configs/nerf_vo_replica.yaml:16-17); scannet = "
+                         "BASELINE configs[4] (512 keyframes 240x320 per configs/nerf_vo_scannet.yaml:15-17, depth + normal "
+                         "supervision, bf16 MFMA MLPs + fp32 hash accumulate)")
+    ap.add_argument("--keyframes", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--mlp-dtype", choices=("f16", "bf16"), default=None)
     ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--cpu-baseline", choices=("configs0", "sample", "off"), default="configs0",
+                    help="configs0 = BASELINE configs[0] as written: one 640x480 keyframe, 4096 rays, fp32 torch-CPU, all "
+                         "host cores, 3 timed steps after 1 warm-up (about 1-2 min of CPU); sample = 256-ray sample (about 12 s)")
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--psnr", choices=("off", "small", "replica"), default="replica",
@@ -108,6 +132,14 @@ def main() -> None:
                     help="extra timed steps late in the proposal-update schedule (reported as late_schedule; 0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.keyframes = args.keyframes or wl["keyframes"]
+    args.height = args.height or wl["height"]
+    args.width = args.width or wl["width"]
+    args.mlp_dtype = args.mlp_dtype or wl["mlp_dtype"]
+    use_normals = wl["normals"]
+    if args.no_cpu_baseline:
+        args.cpu_baseline = "off"
 
     # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner on
     # communicator creation) write to fd 1 directly, so fd 1 is pointed at stderr for the whole run and
@@ -149,7 +181,7 @@ def main() -> None:
     torch.manual_seed(42 + rank)
     # ---- resident synthetic keyframe buffer (ingested through the same path the mapper uses)
     dm = DynamicDataManagerConfig(train_num_rays_per_batch=args.rays, num_frames=args.keyframes,
-                                  frame_height=args.height, frame_width=args.width, use_normals=False).setup(
+                                  frame_height=args.height, frame_width=args.width, use_normals=use_normals).setup(
         device=device, world_size=world, local_rank=rank)
     chunk = 24
     # (render the sequence once, ingest in tracker-sized chunks)
@@ -160,12 +192,14 @@ def main() -> None:
             "keyframe_indices": torch.arange(lo, hi),
             "camera_intrinsics": seq["camera_intrinsics"][lo:hi],
             "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"][lo:hi]),
-            "frames_color": seq["frames_color"][lo:hi], "frames_depth": seq["frames_depth"][lo:hi]})
+            "frames_color": seq["frames_color"][lo:hi], "frames_depth": seq["frames_depth"][lo:hi],
+            **({"frames_normal": seq["frames_normal"][lo:hi]} if use_normals else {})})
     del seq
     ds = dm.train_dataset
     assert ds.num_active_frames == args.keyframes
 
-    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses)
+    cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses,
+                       mlp_dtype=args.mlp_dtype)
     if args.grid_bwd_mode is not None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
@@ -202,7 +236,8 @@ def main() -> None:
             engine.train_step_graphed(ds, all_reduce=reducer)
         else:
             ray_indices, _ = dm.next_train(engine.step)
-            engine.train_step(ray_indices, intr, c2w, ds.frames_color, ds.frames_depth, all_reduce=reducer)
+            engine.train_step(ray_indices, intr, c2w, ds.frames_color, ds.frames_depth, all_reduce=reducer,
+                              normals=ds.world_normals01() if use_normals else None)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -274,7 +309,16 @@ def main() -> None:
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
+                        "bytes_model": "SURVEY.md 8d per-unit bytes x units per launch (DESIGN.md section 3)",
                         "share_of_step_kernel_time": round(total / tot, 4)}
+            if name.startswith("grid_bwd"):
+                # informational: what the kernel really read-modify-writes (fp32 gradient pairs, 2x the 8d figure)
+                lv = 16 if name.endswith("[L16]") else 5
+                units = b / (lv * 8 * 4 * 2 + 12 + lv * 4)
+                b32 = units * (lv * 8 * 8 * 2 + 12 + lv * 4)
+                roofline["fp32_rmw_variant"] = {"algorithmic_bytes_per_launch": int(b32),
+                                                "achieved": round(b32 / avg_s / 1e9, 2),
+                                                "frac": round(b32 / avg_s / 1e9 / HBM_PEAK_GBS, 5)}
             break
     # MFMA utilisation of the fused-MLP kernels alone: FLOP model 2*N*(I*W + (H-1)*W*W + W*O)
     # for a forward; a backward = input gradient + weight gradient + (these networks store no hidden activations)
@@ -320,14 +364,18 @@ def main() -> None:
 
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and args.cpu_baseline != "off":
         from oracle.bench_cpu import time_cpu_step
 
-        cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)
+        if args.cpu_baseline == "configs0":  # BASELINE configs[0] as written
+            cpu_baseline = time_cpu_step(num_rays=4096, num_images=1, steps=3, warmup=1, keyframe=(480, 640),
+                                         max_threads=None)
+        else:  # explicitly labelled fallback: a 256-ray sample of the same step
+            cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)
 
     # ---- render PSNR (rank 0, N=1): outside the timed region, a separate small end-to-end mapping run
     render_psnr = None
-    if rank == 0 and world == 1 and args.psnr != "off":
+    if rank == 0 and world == 1 and args.psnr != "off" and args.workload == "replica":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from run_synthetic_mapping import run as run_mapping
 
@@ -346,11 +394,12 @@ def main() -> None:
         out = {
             "metric": "training ray-samples/sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.mlp_dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: Replica-shaped full mapping step, depth-nerfacto (proposal "
-                                    "sampling 256/96/48), SE3 pose-gradient backprop enabled" if args.optimize_poses else
-                                    "BASELINE configs[1]: Replica-shaped full mapping step, depth-nerfacto "
-                                    "(proposal sampling 256/96/48), fixed poses"),
+                                    "sampling 256/96/48), SE3 pose-gradient backprop enabled"
+                                    if (args.optimize_poses and args.workload == "replica") else
+                                    wl["name"] + (", SE3 pose-gradient backprop enabled" if args.optimize_poses else "")),
+                       "normal_supervision": use_normals,
                        "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
