@@ -199,7 +199,7 @@ def main() -> None:
     assert ds.num_active_frames == args.keyframes
 
     cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses,
-                       mlp_dtype=args.mlp_dtype)
+                       mlp_dtype=args.mlp_dtype, expect_normals=use_normals)
     if args.grid_bwd_mode is not None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3

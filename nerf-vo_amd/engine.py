@@ -96,10 +96,16 @@ class EngineConfig:
     proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
     # Main grid: the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients) whenever positions
     # need gradients (pose optimisation, analytic normals); the input backward then streams it (112 -> ~20 us) instead
-    # of gathering the corners again.  None = on iff optimize_poses.
+    # of gathering the corners again.  None = on iff optimize_poses or expect_normals.
     store_input_gradients: bool | None = None
+    # the data manager delivers normal images (enhancement modes containing 'normal'): the analytic-normal pass needs
+    # d(density)/d(position) every step, so the main grid's forward stores its input gradients
+    expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
+    # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling) while the fields gradient is
+    # still being all-reduced (train_step_graphed; bit-identical to the un-pipelined order)
+    pipeline_sampling_prefix: bool = True
     # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
     # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
@@ -159,7 +165,7 @@ class NerfactoEngine:
             m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
         store = cfg.store_input_gradients
         if store is None:
-            store = bool(cfg.optimize_poses)
+            store = bool(cfg.optimize_poses or cfg.expect_normals)
         self.base_net.set_option("prepare_input_gradients", int(bool(store)))
         color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
         assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
@@ -211,6 +217,8 @@ class NerfactoEngine:
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)  # sharded accumulators
         self.skip_flag = torch.zeros(4, dtype=torch.int32, device=dev)  # one word per parameter group of the step
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
+        self.dev_sampling = torch.zeros(4, dtype=torch.float32, device=dev)  # [anneal, sampler step counter]
+        self._pending_head = None  # multi-GPU: stamp of the sampling prefix already launched for the next step
         self._graphs = {}
         self._side_stream = None
         self._scatter_stream = None
@@ -386,9 +394,10 @@ class NerfactoEngine:
             x01_out=ws[f"x{k + 1}"].data_ptr() if resample else None, act_bf16=int(self.bf16))
         _call("nvo_weights_pdf", stream, C.byref(a))
 
-    def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream,
-                 anneal_dev: int | None = None):
-        """Everything up to (and including) the colour head.  jitters: None or 3 tensors [R]."""
+    def _forward_head(self, ws, anneal: float, jitters, stream, anneal_dev: int | None = None) -> None:
+        """Proposal sampling: lin-disp bins -> proposal net 0 -> PDF resample -> proposal net 1 -> PDF resample ->
+        positions of the main-field samples.  Reads the PROPOSAL networks' parameters only (what the multi-GPU step
+        exploits: this prefix of step k+1 runs while the fields gradient of step k is still being reduced)."""
         cfg = self.cfg
         R = ws["R"]
         j = jitters if jitters is not None else (None, None, None)
@@ -397,6 +406,14 @@ class NerfactoEngine:
         for k, net in enumerate(self.prop_nets):
             self._density_level(ws, k, net, f"proposal.{k}", stream)
             self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True, anneal_dev=anneal_dev)
+
+    def _forward(self, ws, training: bool, anneal: float, jitters, cam_idx_for_embedding, embedding_ptr, stream,
+                 anneal_dev: int | None = None, skip_head: bool = False):
+        """Everything up to (and including) the colour head.  jitters: None or 3 tensors [R].  skip_head: the
+        proposal-sampling prefix already ran (``_forward_head``)."""
+        R = ws["R"]
+        if not skip_head:
+            self._forward_head(ws, anneal, jitters, stream, anneal_dev=anneal_dev)
         km = len(self.prop_nets)
         self._density_level(ws, km, self.base_net, "field.base", stream)
         if not ws.get("dirs01_ready", False):
@@ -510,7 +527,8 @@ class NerfactoEngine:
             ws["gt_normal"].copy_(gt_normal)
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
-                         anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False):
+                         anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False,
+                         skip_head: bool = False):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -529,7 +547,8 @@ class NerfactoEngine:
             self.grads[o:o + sz].zero_()
         self.losses.zero_()
         emb_ptr = self._param_ptr("field.embedding", self.params_half).value
-        ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev)
+        ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev,
+                           skip_head=skip_head)
         km = len(self.prop_nets)
         R = ws["R"]
         pose = cfg.optimize_poses and "d_sh" in ws and self._pose_inputs is not None
@@ -680,13 +699,18 @@ class NerfactoEngine:
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step
     # ------------------------------------------------------------------------------------------
+    def _write_sampling_scalars(self, step: int) -> None:
+        """[proposal-weight anneal, counter of the stateless pixel / jitter sampler] of ``step`` -> device memory (read
+        by the sampling prefix of the captured step); the values travel as kernel arguments of a tiny eager launch."""
+        arr = (C.c_float * 2)(self.anneal_at(step), float(step))
+        _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_sampling), 2, arr)
+
     def _write_step_scalars(self, anneal: float, groups) -> None:
-        """Per-step scalars (proposal anneal, Adam lr / bias corrections) -> device memory; the values
-        travel as kernel arguments of a tiny eager launch ahead of the graph replay."""
+        """Adam lr / bias corrections of this step -> device memory (read by the captured optimiser); advances the
+        step counters of ``groups``.  (Slot 0 mirrors the anneal for inspection; the kernels read dev_sampling.)"""
         cfg = self.cfg
         vals = [0.0] * 16
         vals[0] = anneal
-        vals[10] = float(self.step)  # counter of the stateless pixel / jitter sampler
         for gi, g in enumerate(self._GROUP_ORDER):
             if g in groups:
                 self.opt_steps[g] += 1
@@ -698,11 +722,23 @@ class NerfactoEngine:
         _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 16, arr)
 
     def train_step_graphed(self, dataset, all_reduce=None):
-        """One full iteration replayed from a captured hipGraph (torch.cuda.CUDAGraph): pixel sampling,
-        jitters, ray generation, forward, losses, backward and (single-GPU) the optimiser are ONE graph
-        launch, which removes the ~45 inter-kernel launch gaps of the eager step.  Two graphs exist per
-        ray count: with and without the proposal-network update.  With ``all_reduce`` the optimiser is
-        a second graph behind the (eager) collective."""
+        """One full iteration replayed from captured hipGraphs (torch.cuda.CUDAGraph).
+
+        Single GPU: pixel sampling, jitters, ray generation, forward, losses, backward and the optimiser are ONE graph
+        launch, which removes the ~45 inter-kernel launch gaps of the eager step (two graphs per ray count: with and
+        without the proposal-network update).
+
+        With ``all_reduce`` (one process per GPU) the step is four graphs around two collectives, software-pipelined
+        across iterations WITHOUT changing any value:
+
+            head_k  : pixel sampling -> rays -> proposal sampling      (reads proposal-network + pose parameters only)
+            body_k  : main field forward, losses, every backward, 2-byte cast of the gradients
+            reduce A: proposal networks (+ camera poses) -- small -- then opt_A (their Adam)
+            reduce B: fields (24.5 MB as bf16), ASYNC on the collective's stream ...
+            head_k+1:   ... while the compute stream already runs the next iteration's sampling prefix, which depends
+                        on nothing reduce B / opt_B produce (~130 us of the ~250 us exchange hidden)
+            opt_B   : Adam of the fields group once reduce B has landed.
+        """
         cfg = self.cfg
         R = cfg.num_rays
         step = self.step
@@ -719,49 +755,80 @@ class NerfactoEngine:
         if self._pix_scale_host != extent:  # keyframes were added: refresh the sampler range in place
             self._pix_scale.copy_(torch.tensor(extent, dtype=torch.float32))
             self._pix_scale_host = extent
-        self._write_step_scalars(self.anneal_at(step), groups)
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None, has_normals)
             self._graphs[key] = entry
-        entry["main"].replay()
-        if all_reduce is not None:
-            segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in groups)]
-            if entry.get("half") is not None:  # compressed exchange: the 2-byte cast is part of the main graph
-                all_reduce.reduce_half(self.grads, entry["half"], segs, already_cast=True)
-            else:
-                all_reduce(self.grads, segments=segs)
-            entry["opt"].replay()
+        if all_reduce is None:
+            self._write_sampling_scalars(step)
+            self._write_step_scalars(self.anneal_at(step), groups)
+            entry["main"].replay()
+        else:
+            stamp = (step, key, getattr(dataset, "version", 0), extent)
+            if self._pending_head != stamp:  # not launched ahead (first step, new keyframes, externally set step)
+                self._write_sampling_scalars(step)
+                entry["head"].replay()
+            self._pending_head = None
+            entry["body"].replay()
+            self._write_step_scalars(self.anneal_at(step), groups)
+            half = entry.get("half")
+
+            def reduce(gs, async_op=False):
+                segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in gs)]
+                if half is not None:  # compressed exchange: the 2-byte cast is part of the body graph
+                    return all_reduce.reduce_half(self.grads, half, segs, already_cast=True, async_op=async_op)
+                return all_reduce(self.grads, segments=segs, async_op=async_op)
+
+            first = [g for g in groups if g != "fields"]
+            if first:
+                reduce(first)
+                entry["opt_a"].replay()
+            pending = reduce(["fields"], async_op=True)
         if updated:
             self.steps_since_proposal_update = 0
         self.steps_since_proposal_update += 1
         self.step += 1
+        if all_reduce is not None:
+            if cfg.pipeline_sampling_prefix:
+                nstep = self.step
+                nkey = (R, self.proposal_update_due(nstep), has_depth, True, has_normals)
+                nentry = self._graphs.get(nkey)
+                if nentry is not None:  # (a key that still has to be captured runs un-pipelined once)
+                    self._write_sampling_scalars(nstep)
+                    nentry["head"].replay()
+                    self._pending_head = (nstep, nkey, getattr(dataset, "version", 0), extent)
+            all_reduce.wait(pending)
+            entry["opt_b"].replay()
         return updated
 
-    def _capture_step(self, dataset, R, updated, has_depth, groups, split_optimizer, has_normals=False):
+    def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False):
         dev = self.device
         ws = self._workspace(R, True)
         intr = dataset.camera_intrinsics
         c2w_full = dataset.camera_extrinsics
         scale = self._pix_scale
         c2w = torch.empty(c2w_full.shape[0], 3, 4, device=dev)
-        anneal_ptr = self.dev_scalars.data_ptr()
+        anneal_ptr = self.dev_sampling.data_ptr()
 
         ray_indices = torch.zeros((R, 3), dtype=torch.int64, device=dev)
         jit = torch.zeros((3, R), dtype=torch.float32, device=dev)
         # follows torch.manual_seed; the rank is mixed in so that data-parallel ranks never draw the same rays even when
         # every process was seeded identically (same multiplier as the data manager's rank-offset generator)
         rng_seed = int((torch.initial_seed() + 1000003 * self.rank) & 0xFFFFFFFF)
-        step_ptr = C.c_void_p(self.dev_scalars.data_ptr() + 4 * 10)
+        step_ptr = C.c_void_p(self.dev_sampling.data_ptr() + 4)
+        jits = (jit[0], jit[1], jit[2])
 
-        def body_main():
+        def body_head():
             # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
             _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
             c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
             self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
                            normals=dataset.world_normals01() if has_normals else None)
-            self.forward_backward(ws, (jit[0], jit[1], jit[2]), has_depth=has_depth, update_proposals=updated,
-                                  anneal=1.0, anneal_dev=anneal_ptr, has_normals=has_normals)
+            self._forward_head(ws, 1.0, jits, _stream(dev), anneal_dev=anneal_ptr)
+
+        def body_rest():
+            self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
+                                  anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True)
             if half is not None:  # 2-byte copy of the ranges the collective will exchange
                 cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"
                 for lo, hi in cast_ranges:
@@ -770,12 +837,16 @@ class NerfactoEngine:
 
         half = None
         compress = getattr(self, "_reducer_compress", None)
-        if split_optimizer and compress in ("bf16", "fp16"):
+        if split and compress in ("bf16", "fp16"):
             half = torch.zeros(self.n_params, dtype=torch.bfloat16 if compress == "bf16" else torch.float16, device=dev)
         cast_ranges = [self.group_ranges[g] for g in groups]
+        # multi-GPU: the small groups (proposal networks, camera poses) are reduced and stepped FIRST -- the next
+        # iteration's sampling prefix needs them -- the fields group last (train_step_graphed)
+        groups_a = [g for g in groups if g != "fields"] if split else []
+        groups_b = ["fields"] if split else list(groups)
 
-        def body_opt():
-            self.optimizer_step(groups, from_device_scalars=True, grads_half=half)
+        def body_opt(gs):
+            self.optimizer_step(gs, from_device_scalars=True, grads_half=half)
 
         # warm-up on a side stream (allocations, lazy module state), then capture
         side = torch.cuda.Stream(device=dev)
@@ -783,26 +854,37 @@ class NerfactoEngine:
         saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.params_half.clone())
         with torch.cuda.stream(side):
             for _ in range(2):
-                body_main()
-                body_opt()
+                body_head()
+                body_rest()
+                if groups_a:
+                    body_opt(groups_a)
+                body_opt(groups_b)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half), saved):
             dst.copy_(src)  # the warm-up steps must not count as training
-        # the graph addresses these buffers by pointer: they must outlive this call (a freed block would be handed
+        # the graphs address these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
         entry = {"half": half, "buffers": (c2w, ray_indices, jit, scale), "ws": ws}
-        g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_main):
-            body_main()
-            if not split_optimizer:
-                body_opt()
-        entry["main"] = g_main
-        if split_optimizer:
-            g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt):
-                body_opt()
-            entry["opt"] = g_opt
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            return g
+
+        if not split:
+            def whole():
+                body_head()
+                body_rest()
+                body_opt(groups_b)
+            entry["main"] = capture(whole)
+        else:
+            entry["head"] = capture(body_head)
+            entry["body"] = capture(body_rest)
+            if groups_a:
+                entry["opt_a"] = capture(lambda: body_opt(groups_a))
+            entry["opt_b"] = capture(lambda: body_opt(groups_b))
         return entry
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None, normals=None):

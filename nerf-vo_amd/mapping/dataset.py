@@ -136,6 +136,9 @@ class DynamicDataset(torch.utils.data.Dataset):
         return out
 
     def insert_update(self, input: dict) -> None:
+        # bumped on every ingest: a step prefix launched ahead of time (engine pipelining) is re-done when it saw
+        # an older state of the buffer
+        self.version = getattr(self, "version", 0) + 1
         dev = self.device
         idx = input["indices"].to(dev)
         key = input["keyframe_indices"].to(dev)

@@ -53,8 +53,9 @@ class ExtendedNerfactoModelConfig(DepthNerfactoModelConfig):
     normal_loss_mult: float = 1e-5
 
     def setup(self, num_train_data: int, device, world_size: int = 1, max_num_iterations: int = 8192,
-              num_rays: int = 4096, seed: int = 1337, rank: int = 0):
-        return ExtendedNerfactoModel(self, num_train_data, device, world_size, max_num_iterations, num_rays, seed, rank)
+              num_rays: int = 4096, seed: int = 1337, rank: int = 0, use_normals: bool = False):
+        return ExtendedNerfactoModel(self, num_train_data, device, world_size, max_num_iterations, num_rays, seed, rank,
+                                     use_normals)
 
 
 class CameraOptimizer(torch.nn.Module):
@@ -86,7 +87,8 @@ class CameraOptimizer(torch.nn.Module):
 
 class ExtendedNerfactoModel:
     def __init__(self, config: ExtendedNerfactoModelConfig, num_train_data: int, device, world_size: int = 1,
-                 max_num_iterations: int = 8192, num_rays: int = 4096, seed: int = 1337, rank: int = 0):
+                 max_num_iterations: int = 8192, num_rays: int = 4096, seed: int = 1337, rank: int = 0,
+                 use_normals: bool = False):
         if config.is_euclidean_depth:
             raise NotImplementedError("is_euclidean_depth=True is not used by the reference (nerfstudio.py:79)")
         self.config = config
@@ -98,6 +100,7 @@ class ExtendedNerfactoModel:
             distortion_loss_mult=config.distortion_loss_mult, depth_loss_mult=config.depth_loss_mult,
             depth_sigma=config.depth_sigma, normal_loss_mult=float(config.normal_loss_mult),
             max_num_iterations=max_num_iterations, seed=seed, mlp_dtype=config.mlp_dtype,
+            expect_normals=bool(use_normals) and float(config.normal_loss_mult) > 0.0,
             optimize_poses=config.camera_optimizer.mode in ("SE3", "SO3xR3"),
             camera_mode=config.camera_optimizer.mode if config.camera_optimizer.mode in ("SE3", "SO3xR3") else "SE3",
             camera_trans_l2_penalty=config.camera_optimizer.trans_l2_penalty,

@@ -105,7 +105,8 @@ class VanillaPipeline:
                                                     local_rank=local_rank)
         self.model = config.model.setup(num_train_data=config.datamanager.num_frames, device=self.device,
                                         world_size=world_size, max_num_iterations=max_num_iterations,
-                                        num_rays=config.datamanager.train_num_rays_per_batch, rank=local_rank)
+                                        num_rays=config.datamanager.train_num_rays_per_batch, rank=local_rank,
+                                        use_normals=bool(getattr(config.datamanager, "use_normals", False)))
         self.training = True
         self.all_reduce = None  # set by the distributed launcher (nerf_vo_amd.parallel.GradientAllReduce)
         import os

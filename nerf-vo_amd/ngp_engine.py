@@ -175,9 +175,11 @@ class NgpEngine:
 
     # ---- density grid ------------------------------------------------------------------------
     @torch.no_grad()
-    def update_density_grid(self, jitter: bool = True) -> None:
+    def update_density_grid(self, jitter: bool = True, all_reduce=None) -> None:
         """update_density_grid_nerf: sample every cell of every cascade (jittered), evaluate the density
-        network, EMA the optical thickness into the grid, rebuild bitfield + cascade max-pool."""
+        network, EMA the optical thickness into the grid, rebuild bitfield + cascade max-pool.
+        ``all_reduce`` (multi-GPU): the fresh estimates are MAX-reduced over the ranks before the update, so the
+        density grid and bitfield stay identical everywhere (parallel.GradientAllReduce.reduce_max)."""
         cfg = self.cfg
         stream = _stream(self.device)
         lo, hi = cfg.aabb
@@ -196,6 +198,8 @@ class NgpEngine:
                       _ptr(out), _ptr(ctx))
                 _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 16, level,
                       C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
+        if all_reduce is not None:
+            all_reduce.reduce_max(fresh)
         _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
               cfg.occupancy_threshold, _ptr(self.bitfield), _ptr(self._scratch8))
 
@@ -321,7 +325,7 @@ class NgpEngine:
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
         if self.step % self.cfg.density_update_every == 0:
-            self.update_density_grid()
+            self.update_density_grid(all_reduce=all_reduce)
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
         jitter = torch.rand(R, device=self.device)
         bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None

@@ -47,26 +47,45 @@ class GradientAllReduce:
                 out.append((off, size))
         return out
 
-    def reduce_half(self, flat_grad: torch.Tensor, half: torch.Tensor, segments, already_cast: bool = False) -> None:
+    def reduce_half(self, flat_grad: torch.Tensor, half: torch.Tensor, segments, already_cast: bool = False,
+                    async_op: bool = False):
         """Compressed exchange into a caller-owned fp16 buffer (the optimiser then consumes ``half``
         directly -- no cast-back pass).  Used by the graph-replayed step, whose captured graph already
-        holds the fp32 -> fp16 cast (``already_cast``)."""
+        holds the fp32 -> fp16 cast (``already_cast``).  ``async_op``: return the pending handles instead of
+        waiting (hand them to ``wait``) -- the collective then runs beside whatever the caller enqueues next."""
         ranges = self._merge(segments)
         if not already_cast:
             for off, size in ranges:
                 half[off:off + size].copy_(flat_grad[off:off + size])
         if not self.dist.is_initialized():
-            return
+            return []
         handles = []
         for off, size in ranges:
             for lo in range(off, off + size, self.bucket_numel):
                 hi = min(off + size, lo + self.bucket_numel)
                 handles.append(self.dist.all_reduce(half[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
                                                     async_op=True))
-        for h in handles:
+        if async_op:
+            return handles
+        self.wait(handles)
+        return []
+
+    @staticmethod
+    def wait(handles) -> None:
+        """RCCL: the CURRENT STREAM waits for the collective (the host does not block); gloo: the host waits."""
+        for h in handles or ():
             h.wait()
 
-    def __call__(self, flat_grad: torch.Tensor, segments=None, keep_half: bool = False):
+    def reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place elementwise MAX over ranks: the occupancy-grid back-end's density estimates.
+        Every rank evaluates the density network at its OWN jittered point per grid cell; the maximum over ranks is
+        what instant-ngp's `max(decayed old, new)` update wants (more samples per cell), and it keeps the density
+        grid -- hence the bitfield every rank marches through -- identical on all ranks."""
+        if self.dist.is_initialized():
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def __call__(self, flat_grad: torch.Tensor, segments=None, keep_half: bool = False, async_op: bool = False):
         """In-place sum over ranks.  ``segments``: optional iterable of (offset, size) ranges to
         reduce (e.g. skip the proposal networks on steps where they are not updated).  With
         ``keep_half`` and compression the reduced 2-byte buffer is RETURNED instead of being cast
@@ -87,6 +106,8 @@ class GradientAllReduce:
                 hi = min(off + size, lo + self.bucket_numel)
                 handles.append(self.dist.all_reduce(src[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
                                                     async_op=True))
+        if async_op and self.compress is None:
+            return handles
         for h in handles:
             h.wait()
         if self.compress is not None:

@@ -31,7 +31,8 @@ def main():
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
     torch.manual_seed(100)  # SAME seed on every rank: the engine itself must give each rank its own sampler stream
-    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"]), dev, world_size=world,
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"],
+                                      pipeline_sampling_prefix=plan.get("pipeline", True)), dev, world_size=world,
                          rank=rank)
     eng.set_params(plan["params"].to(dev))  # identical initial parameters on every rank
     reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress)

@@ -26,6 +26,51 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _run_ranks(workdir, world, compress):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "dist_engine_worker.py"), str(r),
+                               str(world), str(port), str(workdir), compress], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    return [torch.load(workdir / f"rank{r}.pt") for r in range(world)]
+
+
+@pytest.mark.parametrize("poses", [False, True], ids=["fixed-poses", "pose-optimisation"])
+def test_pipelined_sampling_prefix_is_bit_identical(device, tmp_path, poses):
+    """The multi-GPU step launches the NEXT iteration's sampling prefix (rays -> proposal sampling) while the fields
+    gradient of the current one is still in the collective, and reduces / steps the small groups (proposal networks,
+    camera poses) first.  That reordering must not change a single bit: 12 graph-replayed steps (update and
+    non-update iterations, keyed graph switches) with the prefix pipelined vs launched in program order."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+
+    n, H, W, R, world = 6, 60, 80, 512, 2
+    ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=poses), device)
+    params0 = ref.params.detach().cpu().clone()
+    del ref
+    res = {}
+    for pipeline in (True, False):
+        wd = tmp_path / f"pipe{int(pipeline)}"
+        wd.mkdir()
+        torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": [], "jitters": [], "poses": poses,
+                    "eager_steps": 0, "graph_steps": 12, "pipeline": pipeline}, wd / "plan.pt")
+        res[pipeline] = _run_ranks(wd, world, "bf16")
+    a, b = res[True], res[False]
+    assert torch.equal(a[0]["after_graph"], a[1]["after_graph"]), "ranks diverged with the pipelined prefix"
+    assert torch.equal(a[0]["after_graph"], b[0]["after_graph"]), "pipelining the sampling prefix changed the result"
+    assert not torch.equal(a[0]["after_graph"], params0) and int(a[0]["skip"].sum()) == 0
+    assert a[0]["losses"] == b[0]["losses"]
+
+
 @pytest.mark.parametrize("compress,poses", [("none", False), ("bf16", False), ("bf16", True), ("fp16", False)],
                          ids=["none", "bf16", "bf16-pose-optimisation", "fp16"])
 def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, poses):
@@ -43,22 +88,7 @@ def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, po
     jitters = [[tuple(torch.rand(R, generator=g) for _ in range(3)) for _ in range(world)] for _ in range(eager_steps)]
     torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": rays, "jitters": jitters, "poses": poses,
                 "eager_steps": eager_steps, "graph_steps": graph_steps}, tmp_path / "plan.pt")
-    port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "dist_engine_worker.py"), str(r),
-                               str(world), str(port), str(tmp_path), compress], env=env, stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=300)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(out.decode(errors="replace"))
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
-    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    r0, r1 = _run_ranks(tmp_path, world, compress)
     # (1) replicated state never diverges
     assert torch.equal(r0["after_eager"], r1["after_eager"]) and torch.equal(r0["after_graph"], r1["after_graph"])
     assert not torch.equal(r0["after_eager"], params0) and not torch.equal(r0["after_graph"], r0["after_eager"])

@@ -53,6 +53,23 @@ def _worker(rank, world, port, tmp):
     refb = sum((t * 1e-12).to(torch.bfloat16).float() for t in gathered)
     ok = ok and back.dtype == torch.bfloat16 and torch.allclose(back.float(), refb, rtol=2e-2, atol=0.0) \
         and float((back.float() == 0).float().mean()) < 1e-3
+    # asynchronous form (the multi-GPU step overlaps the fields reduction with the next sampling prefix): handles out,
+    # same sum after wait(); compressed variant through the caller-owned 2-byte buffer
+    grad4 = mine.clone()
+    handles = red(grad4, segments=[(0, n)], async_op=True)
+    ok = ok and len(handles) > 0
+    red.wait(handles)
+    ok = ok and torch.allclose(grad4, ref, atol=1e-6)
+    half = mine.to(torch.bfloat16)
+    handles = redb.reduce_half(mine, half, [(0, 4000), (6000, n - 6000)], already_cast=True, async_op=True)
+    redb.wait(handles)
+    refh = sum(t.to(torch.bfloat16).float() for t in gathered)
+    ok = ok and torch.allclose(half[:4000].float(), refh[:4000], rtol=2e-2, atol=1e-2) \
+        and torch.equal(half[4000:6000], mine[4000:6000].to(torch.bfloat16))
+    # MAX reduction of the occupancy-grid density estimates: identical on every rank, elementwise maximum
+    dens = mine.abs().clone()
+    red.reduce_max(dens)
+    ok = ok and torch.equal(dens, torch.stack([t.abs() for t in gathered]).max(dim=0).values)
     torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
