@@ -46,11 +46,14 @@ def _run_ranks(workdir, world, compress):
 
 
 @pytest.mark.parametrize("poses", [False, True], ids=["fixed-poses", "pose-optimisation"])
-def test_pipelined_sampling_prefix_is_bit_identical(device, tmp_path, poses):
+def test_pipelined_sampling_prefix_keeps_the_trajectory(device, tmp_path, poses):
     """The multi-GPU step launches the NEXT iteration's sampling prefix (rays -> proposal sampling) while the fields
     gradient of the current one is still in the collective, and reduces / steps the small groups (proposal networks,
-    camera poses) first.  That reordering must not change a single bit: 12 graph-replayed steps (update and
-    non-update iterations, keyed graph switches) with the prefix pipelined vs launched in program order."""
+    camera poses) first.  The reordering must not change what is computed.  The step is not bitwise reproducible run
+    to run (float atomics in the MLP weight-gradient flush and in multi-chunk grid slices), so the yardstick is the
+    run-to-run noise itself: 12 graph-replayed steps (update and non-update iterations, graph switches) in program
+    order TWICE give the noise floor; the pipelined run must sit within 3x of it (a prefix that read a stale parameter
+    would draw different samples -- orders of magnitude above the floor)."""
     from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
 
     n, H, W, R, world = 6, 60, 80, 512, 2
@@ -58,17 +61,24 @@ def test_pipelined_sampling_prefix_is_bit_identical(device, tmp_path, poses):
     params0 = ref.params.detach().cpu().clone()
     del ref
     res = {}
-    for pipeline in (True, False):
-        wd = tmp_path / f"pipe{int(pipeline)}"
+    for tag, pipeline in (("pipe", True), ("serial", False), ("serial2", False)):
+        wd = tmp_path / tag
         wd.mkdir()
         torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": [], "jitters": [], "poses": poses,
                     "eager_steps": 0, "graph_steps": 12, "pipeline": pipeline}, wd / "plan.pt")
-        res[pipeline] = _run_ranks(wd, world, "bf16")
-    a, b = res[True], res[False]
-    assert torch.equal(a[0]["after_graph"], a[1]["after_graph"]), "ranks diverged with the pipelined prefix"
-    assert torch.equal(a[0]["after_graph"], b[0]["after_graph"]), "pipelining the sampling prefix changed the result"
-    assert not torch.equal(a[0]["after_graph"], params0) and int(a[0]["skip"].sum()) == 0
-    assert a[0]["losses"] == b[0]["losses"]
+        res[tag] = _run_ranks(wd, world, "bf16")
+    for tag, r in res.items():
+        assert torch.equal(r[0]["after_graph"], r[1]["after_graph"]), f"ranks diverged ({tag})"
+        assert int(r[0]["skip"].sum()) == 0 and not torch.equal(r[0]["after_graph"], params0)
+        assert torch.equal(r[0]["ray_indices"], res["serial"][0]["ray_indices"]), "the sampler stream moved"
+    upd = {tag: (r[0]["after_graph"] - params0).double() for tag, r in res.items()}
+    scale = float(upd["serial"].abs().sum())
+    noise = float((upd["serial2"] - upd["serial"]).abs().sum()) / scale
+    diff = float((upd["pipe"] - upd["serial"]).abs().sum()) / scale
+    print(f"relative L1 of the 12-step update: run-to-run {noise:.3e}, pipelined vs program order {diff:.3e}")
+    assert diff <= 3.0 * noise + 1e-7, f"pipelined prefix changed the trajectory: {diff:.3e} vs noise floor {noise:.3e}"
+    for k, v in res["serial"][0]["losses"].items():
+        assert abs(res["pipe"][0]["losses"][k] - v) <= 0.05 * abs(v) + 1e-9, (k, res["pipe"][0]["losses"][k], v)
 
 
 @pytest.mark.parametrize("compress,poses", [("none", False), ("bf16", False), ("bf16", True), ("fp16", False)],

@@ -92,15 +92,22 @@ def test_grid_indices_bit_exact(device, cfg):
     assert (got == ref).all(), f"{int((got != ref).sum())} corner indices differ"
 
 
+def _set_bwd_mode(enc, bwd_mode):
+    """0 atomics | 1 slice owner | 2 binned | 3 streamed (globally sorted records) | 4 streamed, tile-local records"""
+    enc.native_tcnn_module.set_option("grid_bwd_mode", min(bwd_mode, 3))
+    if bwd_mode >= 3:
+        enc.native_tcnn_module.set_option("grid_stream_layout", int(bwd_mode == 4))
+
+
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
-@pytest.mark.parametrize("bwd_mode", [0, 1, 2, 3], ids=["atomic", "lds", "binned", "streamed"])
+@pytest.mark.parametrize("bwd_mode", [0, 1, 2, 3, 4], ids=["atomic", "lds", "binned", "streamed", "streamed-tile-local"])
 def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     import nerf_vo_amd.tinycudann as tcnn
     from oracle import grid as G
 
     spec = _spec(cfg)
     enc = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
-    enc.native_tcnn_module.set_option("grid_bwd_mode", bwd_mode)
+    _set_bwd_mode(enc, bwd_mode)
     assert enc.n_output_dims == spec.n_output_dims and enc.params.numel() == spec.n_params
     g = torch.Generator().manual_seed(5)
     params = (torch.rand(spec.n_params, generator=g) * 2 - 1)
@@ -246,13 +253,19 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
     grads = []
-    for mode in (0, 1, 2, 3):
-        enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
+    for mode in (0, 1, 2, 3, 4):
+        _set_bwd_mode(enc, mode)
         enc.params.grad = None
         y = enc(x)
         (y.float() * dy).sum().backward()
         grads.append(enc.params.grad.clone())
     torch.cuda.synchronize()
+    # tile-local record layout: the same records summed in 64-bit fixed point -> bit-identical to the sorted layout
+    # wherever a bin has a single accumulate item (every hashed level)
+    hashed0 = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
+    assert torch.equal(grads[4][hashed0:], grads[3][hashed0:]), "tile-local layout differs from the sorted layout"
+    _assert_close(grads[4], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed (tile-local) vs atomic dL/dparams")
+    _set_bwd_mode(enc, 3)
     _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
     _assert_close(grads[2], grads[0], rtol=1e-3, atol_scale=1e-5, what="binned vs atomic dL/dparams")
     # streamed records carry w*dy rounded to 16-17 mantissa bits (2^-17 relative per contribution)

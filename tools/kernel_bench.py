@@ -26,8 +26,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--modes", type=int, nargs="+", default=[0, 1, 2, 3])
     ap.add_argument("--tiles", type=int, nargs="+", default=[512], help="mode 3: samples per count/scatter tile")
-    ap.add_argument("--masks", type=str, nargs="+", default=["5"], help="mode 3: owner_max_slices values")
+    ap.add_argument("--masks", type=str, nargs="+", default=["12"], help="mode 3: owner_max_slices values")
     ap.add_argument("--cases", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--layouts", type=int, nargs="+", default=[0, 1], help="mode 3: record layout (0 sorted, 1 tile-local)")
     ap.add_argument("--acc-bits", type=int, default=64, help="accumulators of the slice-owner items (32 | 64)")
     ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
     args = ap.parse_args()
@@ -52,15 +53,16 @@ def main():
         variants = []
         for mode in args.modes:
             if mode == 3:
-                variants += [(3, t, int(m, 0)) for t in args.tiles for m in args.masks]
+                variants += [(3, t, int(m, 0), lay) for t in args.tiles for m in args.masks for lay in args.layouts]
             else:
-                variants.append((mode, 0, 0xFFFFFFFF))
+                variants.append((mode, 0, 0xFFFFFFFF, 0))
         enc.native_tcnn_module.set_option("grid_acc_bits", args.acc_bits)
-        for mode, tile, mask in variants:
+        for mode, tile, mask, layout in variants:
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
             if mode == 3:
                 enc.native_tcnn_module.set_option("grid_stream_tile", tile)
                 enc.native_tcnn_module.set_option("grid_stream_owner_slices", mask)
+                enc.native_tcnn_module.set_option("grid_stream_layout", layout)
             for it in range(args.iters + 3):
                 if it == 3:
                     torch.cuda.synchronize()
@@ -77,7 +79,7 @@ def main():
                 name, cnt, total = line.rsplit(",", 2)
                 if name.startswith("grid_fwd"):
                     continue
-                tag = f"mode={mode}" + (f" tile={tile} owner<={mask}" if mode == 3 else "")
+                tag = f"mode={mode}" + (f" tile={tile} owner<={mask} layout={layout}" if mode == 3 else "")
                 print(f"{label:14s} N={n:8d} {tag:32s} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
 
 
