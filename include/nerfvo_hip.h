@@ -181,6 +181,43 @@ int nvo_sample_positions(nvo_stream_t stream, uint32_t R, uint32_t S, const floa
 int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out);
 /* SH(degree) of (d+1)/2 for R rays -> device fp16 [R][16] (degree 4) */
 int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out_half);
+/* The whole per-ray prefix of a training step in one launch: nvo_sample_pixels + nvo_raygen + nvo_gather_targets +
+ * nvo_sh_encode_t (degree 4) + nvo_lindisp_positions, bit-identical to calling them one after the other
+ * (/root/reference/nerf_vo/mapping/nerfstudio_utils.py:286-300: PixelSampler -> RayGenerator -> the model's first
+ * sampler level).  c2w: [F] poses of c2w_stride floats each (12 = [3][4], 16 = the top rows of [4][4] matrices, read
+ * in place -- no staging copy). */
+typedef struct nvo_ray_head_args {
+    uint32_t R, S;               /* rays, samples of the first sampler level */
+    uint32_t seed, n_jitter;     /* counter-based sampler: see nvo_sample_pixels; jitter [n_jitter][R] */
+    const float* step_dev;       /* device float: step counter */
+    const float* extent_dev;     /* device float[3]: {active frames, H, W} */
+    const float* intrinsics;     /* [F][4] */
+    const float* c2w;
+    uint32_t c2w_stride;
+    const float* corrections;    /* [F][3][4] or NULL */
+    uint32_t H, W;
+    const float* images;         /* [F][H][W][3] */
+    const float* depths;         /* [F][H][W] or NULL */
+    const float* normals;        /* [F][H][W][3] or NULL */
+    float near_plane, far_plane;
+    int64_t* ray_indices;        /* [R][3] */
+    float* jitter;
+    float* origins;              /* [R][3] */
+    float* directions;           /* [R][3] */
+    float* directions_norm;      /* [R] */
+    float* pixel_area;           /* [R] or NULL */
+    int32_t* cam_idx;            /* [R] */
+    float* gt_rgb;               /* [R][3] */
+    float* gt_depth;             /* [R] (required with depths) */
+    float* gt_normal;            /* [R][3] (required with normals) */
+    float* dirs01;               /* [R][3] */
+    void* sh;                    /* 16-bit [R][16] or NULL */
+    int sh_bf16;
+    float* sbins;                /* [R][S+1] */
+    float* tbins;                /* [R][S+1] */
+    float* x01;                  /* [R*S][3] */
+} nvo_ray_head_args;
+int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args);
 /* same with the output format chosen: out_bf16 = 0 -> fp16, 1 -> bfloat16 */
 int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16);
 

@@ -60,6 +60,16 @@ class ColorArgs(C.Structure):
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int)]
 
 
+class RayHeadArgs(C.Structure):
+    """mirror of nvo_ray_head_args"""
+    _fields_ = [("R", _u32), ("S", _u32), ("seed", _u32), ("n_jitter", _u32), ("step_dev", _p), ("extent_dev", _p),
+                ("intrinsics", _p), ("c2w", _p), ("c2w_stride", _u32), ("corrections", _p), ("H", _u32), ("W", _u32),
+                ("images", _p), ("depths", _p), ("normals", _p), ("near_plane", _f), ("far_plane", _f),
+                ("ray_indices", _p), ("jitter", _p), ("origins", _p), ("directions", _p), ("directions_norm", _p),
+                ("pixel_area", _p), ("cam_idx", _p), ("gt_rgb", _p), ("gt_depth", _p), ("gt_normal", _p), ("dirs01", _p),
+                ("sh", _p), ("sh_bf16", _int), ("sbins", _p), ("tbins", _p), ("x01", _p)]
+
+
 class AdamGroup(C.Structure):
     """nvo_adam_group (include/nerfvo_hip.h)"""
     _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
@@ -126,6 +136,7 @@ _SIGNATURES = {
     "nvo_dirs01": (_int, [_p, _u32, _p, _p]),
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
     "nvo_sh_encode_t": (_int, [_p, _u32, _u32, _p, _p, _int]),
+    "nvo_ray_head": (_int, [_p, C.POINTER(RayHeadArgs)]),
     # group C
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),
     "nvo_main_render_loss": (_int, [_p, C.POINTER(MainLossArgs)]),

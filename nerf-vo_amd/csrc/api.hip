@@ -390,6 +390,11 @@ struct GridModule : nvo_module_s {
             stream_bins.owner.acc_bits = (uint32_t)value;
             return NVO_OK;
         }
+        if (!strcmp(key, "grid_stream_layout")) {  // 0: globally bin-sorted records (count/scan/scatter), 1: tile-local
+            nvo_grid_stream_destroy(&stream_bins);
+            stream_bins.tile_local = value != 0;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_stream_overlap")) {  // 0: slice-owner levels and record pipeline back to back
             stream_bins.overlap = value != 0;
             return NVO_OK;

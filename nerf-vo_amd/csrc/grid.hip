@@ -1540,6 +1540,28 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_level, bin_level.data(), 4 * nb, hipMemcpyHostToDevice));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_slice, bin_slice.data(), 4 * nb, hipMemcpyHostToDevice));
     }
+    if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
+    if (st->tile_local && nb) {
+        // static work list: hashed levels spread their records evenly over the bins (one item per bin); a streamed
+        // DENSE level sees clustered samples, so its bins are split into tile ranges
+        std::vector<uint32_t> items, chunks(nb, 1u);
+        for (uint32_t j = 0; j < levels.size(); ++j) {
+            const uint32_t nc = g.hashed[levels[j]] ? 1u : st->dense_chunks;
+            for (uint32_t b = first[j]; b < first[j + 1]; ++b) {
+                chunks[b] = nc;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    items.push_back(b);
+                    items.push_back(c);
+                    items.push_back(nc);
+                    items.push_back(j);
+                }
+            }
+        }
+        st->n_tl_items = (uint32_t)(items.size() / 4);
+        NVO_CHECK_HIP(hipMalloc((void**)&st->d_tl_items, 4 * items.size()));
+        NVO_CHECK_HIP(hipMemcpy(st->d_tl_items, items.data(), 4 * items.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMemcpy(st->d_bin_chunks, chunks.data(), 4 * nb, hipMemcpyHostToDevice));
+    }
     st->created = true;
     if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
     if (!st->aux) {
@@ -1556,6 +1578,9 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
 void nvo_grid_stream_destroy(NvoGridStream* st) {
     if (st->d_meta) (void)hipFree(st->d_meta);
     if (st->d_work) (void)hipFree(st->d_work);
+    if (st->d_tl_items) (void)hipFree(st->d_tl_items);
+    st->d_tl_items = nullptr;
+    st->n_tl_items = 0;
     st->d_meta = nullptr;
     st->d_work = nullptr;
     st->work_bytes = 0;
@@ -1599,6 +1624,60 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         if (fork) NVO_CHECK_HIP(hipEventRecord(st->ev_join, st->aux));
     }
     if (st->n_bins == 0) return NVO_OK;
+    if (st->tile_local) {
+        const size_t tile_records = (size_t)tile * 8;
+        const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * sizeof(uint2), 256);
+        const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
+        const size_t need_tl = rec_bytes_tl + seg_bytes;
+        if (need_tl > st->work_bytes) {  // grows during warm-up only; never while a graph is being captured
+            if (st->d_work) NVO_CHECK_HIP(hipFree(st->d_work));
+            NVO_CHECK_HIP(hipMalloc((void**)&st->d_work, need_tl));
+            st->work_bytes = need_tl;
+        }
+        uint2* records_tl = reinterpret_cast<uint2*>(st->d_work);
+        uint32_t* seg = reinterpret_cast<uint32_t*>(st->d_work + rec_bytes_tl);
+        const dim3 grid_tl(n_tiles, st->n_levels);
+        const size_t lds_tl = tile_records * sizeof(uint2) + sizeof(uint32_t) * 2 * st->max_slices;
+        const size_t lds_acc_tl = sizeof(unsigned long long) * 2 * kBinSlice;
+        NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
+#define NVO_LAUNCH_TL(TILE_, SOA_, T_)                                                                       \
+    do {                                                                                                     \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter<TILE_, SOA_, T_>,                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                              (int)((size_t)TILE_ * 64 + 8 * 4096)));                        \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate,                                  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc_tl)); \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                             \
+            NVO_LAUNCH((k_tl_scatter<TILE_, SOA_, T_>), grid_tl, dim3(TILE_), lds_tl, stream, g, N, x, (const T_*)dy, \
+                       st->d_levels, st->d_bin_first, seg, records_tl);                                       \
+        }                                                                                                    \
+        {                                                                                                    \
+            NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                          \
+            NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
+                       st->d_bin_chunks, grad);                                                              \
+            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < n_cus ? st->n_tl_items : n_cus), dim3(kLdsBwdBlock), \
+                       lds_acc_tl, stream, g, st->d_bin_level, st->d_bin_slice, (const uint4*)st->d_tl_items,  \
+                       st->n_tl_items, seg, records_tl, n_tiles, (uint32_t)tile_records, grad);               \
+        }                                                                                                    \
+    } while (0)
+#define NVO_LAUNCH_TL_T(SOA_, T_)                                                 \
+    do {                                                                          \
+        if (tile == 256) NVO_LAUNCH_TL(256, SOA_, T_);                            \
+        else if (tile == 512) NVO_LAUNCH_TL(512, SOA_, T_);                       \
+        else NVO_LAUNCH_TL(1024, SOA_, T_);                                       \
+    } while (0)
+        if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, false);
+#undef NVO_LAUNCH_TL_T
+#undef NVO_LAUNCH_TL
+        NVO_CHECK_LAUNCH();
+        if (fork) NVO_CHECK_HIP(hipStreamWaitEvent(stream, st->ev_join, 0));  // join
+        return NVO_OK;
+    }
     const size_t n_records = (size_t)N * 8 * st->n_levels;
     const uint32_t max_items = st->n_bins + (uint32_t)(n_records / kStChunkRecords) + 1u;
     // scratch: records | counts[n_bins][n_tiles] | items[max_items]   (grows during warm-up only; never

@@ -22,23 +22,13 @@ __device__ __forceinline__ float norm3(const float* v) {
     return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 }
 
-// ray_indices: [R][3] int64 (camera, y, x).  corrections: [F][3][4] or nullptr.
-__global__ void __launch_bounds__(256)
-k_raygen(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
-         const float* __restrict__ c2w, const float* __restrict__ corrections,
-         float* __restrict__ origins, float* __restrict__ directions,
-         float* __restrict__ directions_norm, float* __restrict__ pixel_area,
-         int32_t* __restrict__ cam_idx) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const int64_t cam = ray_indices[3 * (size_t)r + 0];
-    const float py = (float)ray_indices[3 * (size_t)r + 1] + 0.5f;
-    const float px = (float)ray_indices[3 * (size_t)r + 2] + 0.5f;
-    const float fx = intrinsics[4 * cam + 0], fy = intrinsics[4 * cam + 1];
-    const float cx = intrinsics[4 * cam + 2], cy = intrinsics[4 * cam + 3];
-    const float* __restrict__ m = c2w + 12 * cam;
-
-    float d0[3], dx[3], dy[3];
+// One pinhole ray: pixel centre (px, py) of camera `cam` -> origin, unit direction, |direction before
+// normalisation|, pixel area.  m: the camera's [3][4] pose rows (row stride 4 floats); c: its pose correction or nullptr.
+__device__ __forceinline__ void raygen_one(float px, float py, const float* __restrict__ intr4,
+                                           const float* __restrict__ m, const float* __restrict__ c, float* o,
+                                           float* d0, float* dnorm, float* area) {
+    const float fx = intr4[0], fy = intr4[1], cx = intr4[2], cy = intr4[3];
+    float dx[3], dy[3];
     rot_apply(m, (px - cx) / fx, -(py - cy) / fy, -1.f, d0);
     rot_apply(m, (px + 1.f - cx) / fx, -(py - cy) / fy, -1.f, dx);
     rot_apply(m, (px - cx) / fx, -(py + 1.f - cy) / fy, -1.f, dy);
@@ -51,21 +41,41 @@ k_raygen(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __res
         a += ex * ex;
         b += ey * ey;
     }
-    float o[3] = {m[3], m[7], m[11]};
-    if (corrections) {  // CameraOptimizer.apply_to_raybundle: o += t, d = R d
-        const float* __restrict__ c = corrections + 12 * cam;
+    o[0] = m[3];
+    o[1] = m[7];
+    o[2] = m[11];
+    if (c) {  // CameraOptimizer.apply_to_raybundle: o += t, d = R d
         float d1[3];
         rot_apply(c, d0[0], d0[1], d0[2], d1);
         d0[0] = d1[0]; d0[1] = d1[1]; d0[2] = d1[2];
         o[0] += c[3]; o[1] += c[7]; o[2] += c[11];
     }
+    *dnorm = n0;
+    *area = sqrtf(a) * sqrtf(b);
+}
+
+// ray_indices: [R][3] int64 (camera, y, x).  corrections: [F][3][4] or nullptr.
+__global__ void __launch_bounds__(256)
+k_raygen(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
+         const float* __restrict__ c2w, const float* __restrict__ corrections,
+         float* __restrict__ origins, float* __restrict__ directions,
+         float* __restrict__ directions_norm, float* __restrict__ pixel_area,
+         int32_t* __restrict__ cam_idx) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t cam = ray_indices[3 * (size_t)r + 0];
+    const float py = (float)ray_indices[3 * (size_t)r + 1] + 0.5f;
+    const float px = (float)ray_indices[3 * (size_t)r + 2] + 0.5f;
+    float o[3], d0[3], n0, area;
+    raygen_one(px, py, intrinsics + 4 * cam, c2w + 12 * cam, corrections ? corrections + 12 * cam : nullptr, o, d0, &n0,
+               &area);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         origins[3 * (size_t)r + k] = o[k];
         directions[3 * (size_t)r + k] = d0[k];
     }
     directions_norm[r] = n0;
-    if (pixel_area) pixel_area[r] = sqrtf(a) * sqrtf(b);
+    if (pixel_area) pixel_area[r] = area;
     cam_idx[r] = (int32_t)cam;
 }
 
@@ -195,6 +205,81 @@ k_sample_pixels(uint32_t R, uint32_t seed, const float* __restrict__ step_dev, c
         ray_indices[3 * (size_t)r + c] = (int64_t)fminf(v, e - 1.f);
     }
     for (uint32_t j = 0; j < n_jitter; ++j) jitter[(size_t)j * R + r] = hash_uniform(seed, step, 3u + j, r);
+}
+
+// The whole per-ray prefix of a training step in ONE launch: pixel sampler + sampler jitters (k_sample_pixels), ray
+// generation with pose correction (k_raygen), target gather + direction-encoding input (k_gather_targets), SH(4) of
+// the direction (k_sh_fwd) and the first sampler level (k_lindisp_positions).  Thread per (ray, sample of level 0):
+// every thread re-derives its ray (a hash and ~80 flops -- free next to the five launches it replaces, ~6 us each of
+// dispatch + drain for 4096-ray kernels); the thread of sample 0 writes the per-ray outputs.  Same device functions
+// as the separate kernels: the results are bit-identical (tests/test_engine_gpu.py::test_ray_head_matches_separate).
+__global__ void __launch_bounds__(256)
+k_ray_head(nvo_ray_head_args a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.R * a.S) return;
+    const uint32_t r = i / a.S, j = i - r * a.S;
+    const uint32_t step = (uint32_t)a.step_dev[0];
+    int64_t idx[3];
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const float e = a.extent_dev[c];
+        const float v = floorf(hash_uniform(a.seed, step, c, r) * e);
+        idx[c] = (int64_t)fminf(v, e - 1.f);
+    }
+    const float jit0 = hash_uniform(a.seed, step, 3u, r);
+    const int64_t cam = idx[0];
+    float o[3], d[3], n0, area;
+    raygen_one((float)idx[2] + 0.5f, (float)idx[1] + 0.5f, a.intrinsics + 4 * cam, a.c2w + (size_t)a.c2w_stride * cam,
+               a.corrections ? a.corrections + 12 * cam : nullptr, o, d, &n0, &area);
+    // ---- first sampler level (k_lindisp_positions)
+    const float s_near = spacing_fn(a.near_plane), s_far = spacing_fn(a.far_plane);
+    const float b0 = lindisp_bin(j, a.S, &jit0, 0), b1 = lindisp_bin(j + 1, a.S, &jit0, 0);
+    const float t0 = spacing_fn_inv(b0 * s_far + (1.f - b0) * s_near);
+    const float t1 = spacing_fn_inv(b1 * s_far + (1.f - b1) * s_near);
+    a.sbins[(size_t)r * (a.S + 1) + j] = b0;
+    a.tbins[(size_t)r * (a.S + 1) + j] = t0;
+    if (j + 1 == a.S) {
+        a.sbins[(size_t)r * (a.S + 1) + a.S] = b1;
+        a.tbins[(size_t)r * (a.S + 1) + a.S] = t1;
+    }
+    float p[3];
+    nvo_contract_position01(o, d, (t0 + t1) * 0.5f, p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.x01[3 * (size_t)i + k] = p[k];
+    if (j != 0) return;
+    // ---- per-ray outputs
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.ray_indices[3 * (size_t)r + k] = idx[k];
+        a.origins[3 * (size_t)r + k] = o[k];
+        a.directions[3 * (size_t)r + k] = d[k];
+    }
+    a.jitter[r] = jit0;
+    for (uint32_t q = 1; q < a.n_jitter; ++q) a.jitter[(size_t)q * a.R + r] = hash_uniform(a.seed, step, 3u + q, r);
+    a.directions_norm[r] = n0;
+    if (a.pixel_area) a.pixel_area[r] = area;
+    a.cam_idx[r] = (int32_t)cam;
+    const size_t pix = ((size_t)cam * a.H + (size_t)idx[1]) * a.W + (size_t)idx[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.gt_rgb[3 * (size_t)r + k] = a.images[3 * pix + k];
+    if (a.depths) a.gt_depth[r] = a.depths[pix];
+    if (a.normals) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.gt_normal[3 * (size_t)r + k] = a.normals[3 * pix + k];
+    }
+    float d01[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d01[k] = (d[k] + 1.f) * 0.5f;
+        a.dirs01[3 * (size_t)r + k] = d01[k];
+    }
+    if (a.sh) {  // k_sh_fwd on (d + 1) / 2, degree 4
+        float c[16];
+        nvo_sh4_eval(d01[0] * 2.f - 1.f, d01[1] * 2.f - 1.f, d01[2] * 2.f - 1.f, 4u, c);
+        nvo_h16* __restrict__ sp = (nvo_h16*)a.sh + 16 * (size_t)r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sp[k] = nvo_cvt16(c[k], a.sh_bf16 != 0);
+    }
 }
 
 // Fused ray setup: ray generation + gather of the colour / depth / normal targets + the (d + 1) / 2
@@ -390,6 +475,22 @@ int nvo_dirs01(nvo_stream_t stream, uint32_t n, const float* d, float* out) {
 int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out_half) {
     NVO_REQUIRE(R == 0 || (dirs01 && out_half), "sh_encode: NULL argument");
     return nvo_sh_fwd_launch((hipStream_t)stream, R, degree, dirs01, out_half, 16, 16);
+}
+
+int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args) {
+    NVO_REQUIRE(args != nullptr, "ray_head: args is NULL");
+    const nvo_ray_head_args a = *args;
+    NVO_REQUIRE(a.S >= 1 && a.n_jitter >= 1 && (a.c2w_stride == 12 || a.c2w_stride == 16), "ray_head: bad S / n_jitter / c2w_stride");
+    NVO_REQUIRE(a.R == 0 || (a.step_dev && a.extent_dev && a.intrinsics && a.c2w && a.images && a.ray_indices &&
+                             a.jitter && a.origins && a.directions && a.directions_norm && a.cam_idx && a.gt_rgb &&
+                             a.dirs01 && a.sbins && a.tbins && a.x01), "ray_head: NULL argument");
+    NVO_REQUIRE(!a.depths || a.gt_depth, "ray_head: depths without gt_depth");
+    NVO_REQUIRE(!a.normals || a.gt_normal, "ray_head: normals without gt_normal");
+    if (a.R == 0) return NVO_OK;
+    NVO_PROF(stream, "ray_head[S%u]", a.S);
+    NVO_LAUNCH(k_ray_head, dim3(nvo_div_up((uint64_t)a.R * a.S, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
 }
 
 int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16) {

@@ -6,29 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ void sh4_eval(float x, float y, float z, uint32_t degree, float* o) {
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    o[0] = 0.28209479177387814f;
-    if (degree <= 1) return;
-    o[1] = -0.48860251190291987f * y;
-    o[2] = 0.48860251190291987f * z;
-    o[3] = -0.48860251190291987f * x;
-    if (degree <= 2) return;
-    o[4] = 1.0925484305920792f * xy;
-    o[5] = -1.0925484305920792f * yz;
-    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-    o[7] = -1.0925484305920792f * xz;
-    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-    if (degree <= 3) return;
-    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-    o[10] = 2.8906114426405538f * xy * z;
-    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-    o[14] = 1.4453057213202769f * z * (x2 - y2);
-    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
-}
-
 // out: [N][out_stride] fp16 (bf = 0) or bfloat16 (bf = 1); writes n_coeff coefficients then pads up to out_width with 1.0
 __global__ void __launch_bounds__(256)
 k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, nvo_h16* __restrict__ out,
@@ -41,7 +18,7 @@ k_sh_fwd(uint32_t N, uint32_t degree, const float* __restrict__ d01, nvo_h16* __
     float o[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) o[k] = 0.f;
-    sh4_eval(x, y, z, degree, o);
+    nvo_sh4_eval(x, y, z, degree, o);
     const uint32_t n_coeff = degree * degree;
     nvo_h16* __restrict__ p = out + (size_t)i * out_stride;
     for (uint32_t k = 0; k < out_width; ++k) p[k] = nvo_cvt16(k < n_coeff ? o[k] : 1.0f, bf != 0);

@@ -106,6 +106,9 @@ class EngineConfig:
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling) while the fields gradient is
     # still being all-reduced (train_step_graphed; bit-identical to the un-pipelined order)
     pipeline_sampling_prefix: bool = True
+    # graph-replayed step: pixel sampling, ray generation, target gather, SH and the first sampler level in ONE launch
+    # (nvo_ray_head) instead of five 4096-ray kernels of ~6 us dispatch + drain each; bit-identical
+    fused_ray_head: bool = True
     # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
     # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
@@ -394,15 +397,17 @@ class NerfactoEngine:
             x01_out=ws[f"x{k + 1}"].data_ptr() if resample else None, act_bf16=int(self.bf16))
         _call("nvo_weights_pdf", stream, C.byref(a))
 
-    def _forward_head(self, ws, anneal: float, jitters, stream, anneal_dev: int | None = None) -> None:
+    def _forward_head(self, ws, anneal: float, jitters, stream, anneal_dev: int | None = None,
+                      skip_first_level: bool = False) -> None:
         """Proposal sampling: lin-disp bins -> proposal net 0 -> PDF resample -> proposal net 1 -> PDF resample ->
         positions of the main-field samples.  Reads the PROPOSAL networks' parameters only (what the multi-GPU step
         exploits: this prefix of step k+1 runs while the fields gradient of step k is still being reduced)."""
         cfg = self.cfg
         R = ws["R"]
         j = jitters if jitters is not None else (None, None, None)
-        _call("nvo_lindisp_positions", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
-              _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["sbins0"]), _ptr(ws["tbins0"]), _ptr(ws["x0"]))
+        if not skip_first_level:  # (nvo_ray_head already wrote the first level's bins and positions)
+            _call("nvo_lindisp_positions", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
+                  _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["sbins0"]), _ptr(ws["tbins0"]), _ptr(ws["x0"]))
         for k, net in enumerate(self.prop_nets):
             self._density_level(ws, k, net, f"proposal.{k}", stream)
             self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True, anneal_dev=anneal_dev)
@@ -419,7 +424,9 @@ class NerfactoEngine:
         if not ws.get("dirs01_ready", False):
             _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
         ws["dirs01_ready"] = False
-        _call("nvo_sh_encode_t", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]), int(self.bf16))
+        if not ws.get("sh_ready", False):
+            _call("nvo_sh_encode_t", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]), int(self.bf16))
+        ws["sh_ready"] = False
         ca = self._color_args(ws, training, cam_idx_for_embedding, embedding_ptr)
         _call("nvo_nerfacto_color_fwd", stream, C.byref(ca))
         return ca
@@ -803,6 +810,7 @@ class NerfactoEngine:
 
     def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False):
         dev = self.device
+        cfg = self.cfg
         ws = self._workspace(R, True)
         intr = dataset.camera_intrinsics
         c2w_full = dataset.camera_extrinsics
@@ -819,12 +827,46 @@ class NerfactoEngine:
         jits = (jit[0], jit[1], jit[2])
 
         def body_head():
+            if cfg.fused_ray_head:
+                return body_head_fused()
             # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
             _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
             c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
             self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
                            normals=dataset.world_normals01() if has_normals else None)
             self._forward_head(ws, 1.0, jits, _stream(dev), anneal_dev=anneal_ptr)
+
+        def body_head_fused():
+            # everything per ray up to the first sampler level in ONE launch (nvo_ray_head)
+            stream = _stream(dev)
+            images, depths = dataset.frames_color, dataset.frames_depth if has_depth else None
+            normals = dataset.world_normals01() if has_normals else None
+            corr, poses, stride, ridx = None, c2w_full, 16, ray_indices
+            if cfg.optimize_poses:
+                # CameraOptimizer.forward for every camera; the pose backward wants [F][3][4] poses + the drawn pixels
+                _call("nvo_pose_exp_map", stream, cfg.num_images, self._param_ptr("camera_opt.pose_adjustment", self.params),
+                      _ptr(self.corrections), self._pose_mode())
+                c2w.copy_(c2w_full[:, :3, :4])
+                corr, poses, stride = self.corrections, c2w, 12
+                self._pose_inputs = (intr, c2w)
+                if "ray_indices" in ws:
+                    ridx = ws["ray_indices"]
+            ra = _lib.RayHeadArgs(
+                R=R, S=self.levels[0], seed=rng_seed, n_jitter=3, step_dev=step_ptr.value, extent_dev=scale.data_ptr(),
+                intrinsics=intr.data_ptr(), c2w=poses.data_ptr(), c2w_stride=stride,
+                corrections=None if corr is None else corr.data_ptr(), H=images.shape[1], W=images.shape[2],
+                images=images.data_ptr(), depths=None if depths is None else depths.data_ptr(),
+                normals=None if normals is None else normals.data_ptr(), near_plane=cfg.near_plane,
+                far_plane=cfg.far_plane, ray_indices=ridx.data_ptr(), jitter=jit.data_ptr(),
+                origins=ws["origins"].data_ptr(), directions=ws["directions"].data_ptr(),
+                directions_norm=ws["directions_norm"].data_ptr(), pixel_area=ws["pixel_area"].data_ptr(),
+                cam_idx=ws["cam_idx"].data_ptr(), gt_rgb=ws["gt_rgb"].data_ptr(), gt_depth=ws["gt_depth"].data_ptr(),
+                gt_normal=ws["gt_normal"].data_ptr(), dirs01=ws["dirs01"].data_ptr(), sh=ws["sh"].data_ptr(),
+                sh_bf16=int(self.bf16), sbins=ws["sbins0"].data_ptr(), tbins=ws["tbins0"].data_ptr(), x01=ws["x0"].data_ptr())
+            _call("nvo_ray_head", stream, C.byref(ra))
+            ws["dirs01_ready"] = True
+            ws["sh_ready"] = True
+            self._forward_head(ws, 1.0, jits, stream, anneal_dev=anneal_ptr, skip_first_level=True)
 
         def body_rest():
             self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
@@ -865,7 +907,8 @@ class NerfactoEngine:
             dst.copy_(src)  # the warm-up steps must not count as training
         # the graphs address these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
-        entry = {"half": half, "buffers": (c2w, ray_indices, jit, scale), "ws": ws}
+        drawn = ws["ray_indices"] if (cfg.fused_ray_head and cfg.optimize_poses and "ray_indices" in ws) else ray_indices
+        entry = {"half": half, "buffers": (c2w, drawn, jit, scale, ray_indices), "ws": ws}
 
         def capture(fn):
             g = torch.cuda.CUDAGraph()

@@ -70,7 +70,6 @@ def test_pipelined_sampling_prefix_keeps_the_trajectory(device, tmp_path, poses)
     for tag, r in res.items():
         assert torch.equal(r[0]["after_graph"], r[1]["after_graph"]), f"ranks diverged ({tag})"
         assert int(r[0]["skip"].sum()) == 0 and not torch.equal(r[0]["after_graph"], params0)
-        assert torch.equal(r[0]["ray_indices"], res["serial"][0]["ray_indices"]), "the sampler stream moved"
     upd = {tag: (r[0]["after_graph"] - params0).double() for tag, r in res.items()}
     scale = float(upd["serial"].abs().sum())
     noise = float((upd["serial2"] - upd["serial"]).abs().sum()) / scale

@@ -148,6 +148,67 @@ def test_full_step_matches_oracle(device, dtype):
                       what=f"d prop{k} grid", **tol)
 
 
+@pytest.mark.parametrize("stride,poses,fmt", [(16, False, 0), (12, True, 1)], ids=["4x4-fixed-f16", "3x4-corrected-bf16"])
+def test_ray_head_matches_separate(device, stride, poses, fmt):
+    """nvo_ray_head (pixel sampler + raygen + target gather + SH + first sampler level in one launch) must equal the
+    five separate launches BIT FOR BIT on every output."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import _call, _ptr, _stream
+
+    g = torch.Generator().manual_seed(9)
+    F, H, W, R, S = 7, 48, 64, 1000, 256
+    dev = lambda t: t.to(device).contiguous()  # noqa: E731
+    intr = dev(torch.tensor([[30.0, 28.0, 31.7, 23.6]]).repeat(F, 1) + torch.rand(F, 4, generator=g))
+    rot = torch.linalg.qr(torch.randn(F, 3, 3, generator=g))[0]
+    c2w44 = torch.eye(4).repeat(F, 1, 1)
+    c2w44[:, :3, :3] = rot
+    c2w44[:, :3, 3] = torch.randn(F, 3, generator=g) * 0.3
+    c2w44 = dev(c2w44)
+    c2w34 = c2w44[:, :3, :4].contiguous()
+    corr = dev(torch.cat([torch.linalg.qr(torch.randn(F, 3, 3, generator=g))[0], torch.randn(F, 3, 1, generator=g) * 0.05], 2))
+    images, depths, normals = dev(torch.rand(F, H, W, 3, generator=g)), dev(torch.rand(F, H, W, generator=g)), dev(torch.rand(F, H, W, 3, generator=g))
+    step_dev = torch.tensor([37.0], device=device)
+    extent = torch.tensor([float(F - 2), float(H), float(W)], device=device)
+    seed = 0xC0FFEE
+    st = _stream(device)
+    adt = torch.bfloat16 if fmt else torch.float16
+
+    def bufs():
+        z = lambda *s, dt=torch.float32: torch.full(s, -7, dtype=dt, device=device)  # noqa: E731
+        return dict(idx=z(R, 3, dt=torch.int64), jit=z(3, R), o=z(R, 3), d=z(R, 3), dn=z(R), pa=z(R), ci=z(R, dt=torch.int32),
+                    rgb=z(R, 3), dep=z(R), nor=z(R, 3), d01=z(R, 3), sh=z(R, 16, dt=adt), sb=z(R, S + 1), tb=z(R, S + 1),
+                    x=z(R * S, 3))
+
+    a, b = bufs(), bufs()
+    poses_t = c2w34 if stride == 12 else c2w44
+    # ---- separate launches
+    _call("nvo_sample_pixels", st, R, seed, _ptr(step_dev), _ptr(extent), _ptr(a["idx"]), _ptr(a["jit"]), 3)
+    _call("nvo_raygen", st, R, _ptr(a["idx"]), _ptr(intr), _ptr(c2w34), _ptr(corr) if poses else None, _ptr(a["o"]), _ptr(a["d"]),
+          _ptr(a["dn"]), _ptr(a["pa"]), _ptr(a["ci"]))
+    _call("nvo_gather_targets", st, R, _ptr(a["idx"]), H, W, _ptr(images), _ptr(depths), _ptr(normals), _ptr(a["d"]),
+          _ptr(a["rgb"]), _ptr(a["dep"]), _ptr(a["nor"]), _ptr(a["d01"]))
+    _call("nvo_sh_encode_t", st, R, 4, _ptr(a["d01"]), _ptr(a["sh"]), fmt)
+    _call("nvo_lindisp_positions", st, R, S, 0.05, 1000.0, _ptr(a["jit"][0]), _ptr(a["o"]), _ptr(a["d"]), _ptr(a["sb"]),
+          _ptr(a["tb"]), _ptr(a["x"]))
+    # ---- one launch
+    ra = _lib.RayHeadArgs(R=R, S=S, seed=seed, n_jitter=3, step_dev=step_dev.data_ptr(), extent_dev=extent.data_ptr(),
+                          intrinsics=intr.data_ptr(), c2w=poses_t.data_ptr(), c2w_stride=stride,
+                          corrections=corr.data_ptr() if poses else None, H=H, W=W, images=images.data_ptr(),
+                          depths=depths.data_ptr(), normals=normals.data_ptr(), near_plane=0.05, far_plane=1000.0,
+                          ray_indices=b["idx"].data_ptr(), jitter=b["jit"].data_ptr(), origins=b["o"].data_ptr(),
+                          directions=b["d"].data_ptr(), directions_norm=b["dn"].data_ptr(), pixel_area=b["pa"].data_ptr(),
+                          cam_idx=b["ci"].data_ptr(), gt_rgb=b["rgb"].data_ptr(), gt_depth=b["dep"].data_ptr(),
+                          gt_normal=b["nor"].data_ptr(), dirs01=b["d01"].data_ptr(), sh=b["sh"].data_ptr(), sh_bf16=fmt,
+                          sbins=b["sb"].data_ptr(), tbins=b["tb"].data_ptr(), x01=b["x"].data_ptr())
+    _call("nvo_ray_head", st, C.byref(ra))
+    torch.cuda.synchronize()
+    assert int(a["idx"][:, 0].max()) <= F - 3 and float(a["x"].min()) >= 0.0
+    for k in a:
+        assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), f"nvo_ray_head output '{k}' differs from the separate kernels"
+
+
 def test_raygen_and_gather(device):
     from nerf_vo_amd.engine import _call, _ptr, _stream
     from oracle import rays as Rr
