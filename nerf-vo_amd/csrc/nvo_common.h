@@ -115,6 +115,10 @@ __device__ __forceinline__ float nvo_ld16(const nvo_h16* p, bool bf) {
     return bf ? __uint_as_float((uint32_t)raw << 16) : (float)__builtin_bit_cast(_Float16, raw);
 }
 __device__ __forceinline__ nvo_h16 nvo_cvt16(float v, bool bf) {  // round to nearest even in both formats
+    // The value is made opaque first: when `v` is a visible fp32 product the backend otherwise selects
+    // v_fma_mixlo_f16 (product kept exact, ONE rounding to fp16), and whether it can see the product depends on the
+    // surrounding kernel -- fused and unfused launch sequences must round identically (fp32 first, then 16 bit).
+    asm("" : "+v"(v));
     return bf ? __builtin_bit_cast(nvo_h16, (__bf16)v) : __builtin_bit_cast(nvo_h16, (_Float16)v);
 }
 __device__ __forceinline__ uint32_t nvo_cvt16x2(float a, float b, bool bf) {

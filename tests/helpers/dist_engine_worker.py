@@ -43,12 +43,51 @@ def main():
         eng.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit, all_reduce=reducer)
     torch.cuda.synchronize()
     after_eager = eng.params.detach().cpu().clone()
+    prefix_mismatch, prefix_checked = [], 0
     for _ in range(plan["graph_steps"]):
         eng.train_step_graphed(ds, all_reduce=reducer)
+        if plan.get("verify_prefix") and eng._pending_head is not None:
+            # The sampling prefix of the NEXT step has been launched ahead of this step's fields reduction + Adam.  It
+            # is deterministic in its inputs (no float atomics before the losses), so replaying it once more now --
+            # after everything of this step has landed -- must reproduce every buffer it writes BIT FOR BIT; a prefix
+            # that raced with the exchange or read a parameter the late optimiser graph still had to write would not.
+            torch.cuda.synchronize()
+            ws = eng._workspace(R, True)
+            km = len(eng.prop_nets)
+            names = ["origins", "directions", "gt_rgb", "gt_depth", "cam_idx", "sh"] + [
+                f"{b}{k}" for k in range(km + 1) for b in ("x", "sbins", "tbins")] + [
+                f"{b}{k}" for k in range(km) for b in ("out", "weights")]
+            before = {k: ws[k].clone() for k in names}
+            eng._graphs[eng._pending_head[1]]["head"].replay()
+            torch.cuda.synchronize()
+            prefix_checked += 1
+            prefix_mismatch += [k for k in names if not torch.equal(before[k].view(torch.uint8), ws[k].view(torch.uint8))]
     torch.cuda.synchronize()
+    ab = None
+    if plan.get("ab_pipeline"):
+        # A/B from ONE bit-identical state (the graphs of both step kinds exist by now): the same few steps with the
+        # sampling prefix launched ahead, and twice in program order (the second gives the run-to-run noise of the
+        # step's float atomics).  Starting from identical parameters / moments / counters keeps chaotic amplification
+        # out of the comparison, which 12-step trajectories from separate processes could not.
+        snap = ([t.clone() for t in (eng.params, eng.params_half, eng.exp_avg, eng.exp_avg_sq)], dict(eng.opt_steps),
+                eng.step, eng.steps_since_proposal_update)
+
+        def run(pipeline: bool):
+            for dst, src in zip((eng.params, eng.params_half, eng.exp_avg, eng.exp_avg_sq), snap[0]):
+                dst.copy_(src)
+            eng.opt_steps.update(snap[1])
+            eng.step, eng.steps_since_proposal_update, eng._pending_head = snap[2], snap[3], None
+            eng.cfg.pipeline_sampling_prefix = pipeline
+            for _ in range(plan["ab_pipeline"]):
+                eng.train_step_graphed(ds, all_reduce=reducer)
+            torch.cuda.synchronize()
+            return (eng.params.detach() - snap[0][0]).double().cpu()
+
+        ab = {"pipe": run(True), "serial": run(False), "serial2": run(False)}
     drawn = next(iter(eng._graphs.values()))["buffers"][1].cpu()  # pixel indices of the last graph-replayed step
     torch.save({"after_eager": after_eager, "after_graph": eng.params.detach().cpu(), "losses": eng.loss_dict(),
-                "skip": eng.skip_flag.cpu(), "ray_indices": drawn}, os.path.join(workdir, f"rank{rank}.pt"))
+                "skip": eng.skip_flag.cpu(), "ray_indices": drawn, "prefix_checked": prefix_checked,
+                "prefix_mismatch": sorted(set(prefix_mismatch)), "ab": ab}, os.path.join(workdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -49,35 +49,40 @@ def _run_ranks(workdir, world, compress):
 def test_pipelined_sampling_prefix_keeps_the_trajectory(device, tmp_path, poses):
     """The multi-GPU step launches the NEXT iteration's sampling prefix (rays -> proposal sampling) while the fields
     gradient of the current one is still in the collective, and reduces / steps the small groups (proposal networks,
-    camera poses) first.  The reordering must not change what is computed.  The step is not bitwise reproducible run
-    to run (float atomics in the MLP weight-gradient flush and in multi-chunk grid slices), so the yardstick is the
-    run-to-run noise itself: 12 graph-replayed steps (update and non-update iterations, graph switches) in program
-    order TWICE give the noise floor; the pipelined run must sit within 3x of it (a prefix that read a stale parameter
-    would draw different samples -- orders of magnitude above the floor)."""
+    camera poses) first.  The reordering must not change what is computed.
+
+    Sharp check (bitwise): the prefix is deterministic in its inputs, so the worker replays the prefix that was launched
+    ahead ONCE MORE after the late optimiser graph has landed and compares every buffer it writes bit for bit -- a
+    prefix that raced with the exchange, or read a parameter the late graph still had to write, would differ.
+
+    Second check (write-after-read hazards of the reordering): from ONE bit-identical state (parameters, moments,
+    counters restored inside the same processes) 4 steps are run with the prefix launched ahead and twice in program
+    order; the second program-order run gives the noise of the step's float atomics (MLP weight-gradient flush,
+    multi-chunk grid slices).  Identical start states keep chaotic amplification out of the yardstick -- 12-step
+    trajectories of separate process pairs measured noise samples from 1.4e-5 to 5e-4 on the same build."""
     from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
 
     n, H, W, R, world = 6, 60, 80, 512, 2
     ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=poses), device)
     params0 = ref.params.detach().cpu().clone()
     del ref
-    res = {}
-    for tag, pipeline in (("pipe", True), ("serial", False), ("serial2", False)):
-        wd = tmp_path / tag
-        wd.mkdir()
-        torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": [], "jitters": [], "poses": poses,
-                    "eager_steps": 0, "graph_steps": 12, "pipeline": pipeline}, wd / "plan.pt")
-        res[tag] = _run_ranks(wd, world, "bf16")
-    for tag, r in res.items():
-        assert torch.equal(r[0]["after_graph"], r[1]["after_graph"]), f"ranks diverged ({tag})"
-        assert int(r[0]["skip"].sum()) == 0 and not torch.equal(r[0]["after_graph"], params0)
-    upd = {tag: (r[0]["after_graph"] - params0).double() for tag, r in res.items()}
-    scale = float(upd["serial"].abs().sum())
-    noise = float((upd["serial2"] - upd["serial"]).abs().sum()) / scale
-    diff = float((upd["pipe"] - upd["serial"]).abs().sum()) / scale
-    print(f"relative L1 of the 12-step update: run-to-run {noise:.3e}, pipelined vs program order {diff:.3e}")
-    assert diff <= 3.0 * noise + 1e-7, f"pipelined prefix changed the trajectory: {diff:.3e} vs noise floor {noise:.3e}"
-    for k, v in res["serial"][0]["losses"].items():
-        assert abs(res["pipe"][0]["losses"][k] - v) <= 0.05 * abs(v) + 1e-9, (k, res["pipe"][0]["losses"][k], v)
+    torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": [], "jitters": [], "poses": poses,
+                "eager_steps": 0, "graph_steps": 12, "pipeline": True, "verify_prefix": True, "ab_pipeline": 4},
+               tmp_path / "plan.pt")
+    res = _run_ranks(tmp_path, world, "bf16")
+    for r in res:
+        assert r["prefix_checked"] >= 8, "the pipelined run never launched a prefix ahead"
+        assert not r["prefix_mismatch"], f"prefix launched ahead differs from its replay in program order: {r['prefix_mismatch']}"
+    assert torch.equal(res[0]["after_graph"], res[1]["after_graph"]), "ranks diverged"
+    assert int(res[0]["skip"].sum()) == 0 and not torch.equal(res[0]["after_graph"], params0)
+    ab = res[0]["ab"]
+    for k in ab:
+        assert torch.equal(ab[k], res[1]["ab"][k]), f"ranks diverged in the A/B run ({k})"
+    scale = float(ab["serial"].abs().sum())
+    noise = float((ab["serial2"] - ab["serial"]).abs().sum()) / scale
+    diff = float((ab["pipe"] - ab["serial"]).abs().sum()) / scale
+    print(f"relative L1 of a 4-step update from one state: run-to-run {noise:.3e}, pipelined vs program order {diff:.3e}")
+    assert scale > 0 and diff <= 5.0 * noise + 1e-6, f"pipelined prefix changed the update: {diff:.3e} vs noise {noise:.3e}"
 
 
 @pytest.mark.parametrize("compress,poses", [("none", False), ("bf16", False), ("bf16", True), ("fp16", False)],
