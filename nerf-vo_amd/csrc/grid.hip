@@ -277,8 +277,13 @@ struct AccFixed {
         atomicAdd(&acc[2 * rel + 0], to_fixed(v0));
         atomicAdd(&acc[2 * rel + 1], to_fixed(v1));
     }
+    // int64 -> float through double (cvt_f64_i32 + cvt_f64_u32 + one f64 fma + cvt_f32_f64: 4 instructions instead of
+    // the ~12 of the software int64 -> float conversion; the double holds every |sum| < 2^53 -- 1.3e8 in gradient
+    // units -- exactly, so the one rounding to float is the correctly rounded conversion)
     static __device__ __forceinline__ float get(const T* acc, uint32_t e, const AccScale&) {
-        return (float)(long long)acc[e] * kFixInv;
+        const unsigned long long v = acc[e];
+        const double d = fma((double)(int)(uint32_t)(v >> 32), 4294967296.0, (double)(uint32_t)v);
+        return (float)d * kFixInv;
     }
 };
 struct AccFloat {
@@ -1012,7 +1017,8 @@ k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const u
 // ---- tile-local record layout (NvoGridStream::tile_local) -------------------------------------------------
 // The count / scan passes above exist only to give every (tile, bin) run its place in ONE globally bin-sorted
 // record array.  Here the runs stay where they are produced: tile t of streamed level j owns the fixed region
-// records[(j * n_tiles + t) * TILE * 8 ...], sorted by bin inside, and seg[bin][tile] = start | count << 16 says
+// records[(j * n_tiles + t) * TILE * 8 ...], sorted by bin inside, and seg[bin][tile] = start | count << 16 (| bit 31:
+// the tile saw a non-finite dy) says
 // where bin's run sits in it.  The scatter is then a single pass whose output is a straight copy of its LDS
 // staging area (no per-record destination), and the accumulate work items (bin, tile range) are STATIC: a bin's
 // workgroup walks its ~58-record (464-byte) runs, one wave per run, several runs in flight per wave.
@@ -1066,7 +1072,11 @@ k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
             }
         }
     }
-    __syncthreads();
+    // Integer accumulators cannot carry inf / NaN: a non-finite dy of this (tile, level) is flagged in bit 31 of every
+    // segment word the tile writes, and the accumulate pass poisons the slices that see the flag (the optimiser's
+    // non-finite check decides per parameter group, so the whole level being poisoned changes nothing)
+    const uint32_t bad_bit =
+        __syncthreads_or(live && !(fabsf(d.x) < INFINITY && fabsf(d.y) < INFINITY)) ? 0x80000000u : 0u;
     if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
         const int lane = (int)threadIdx.x;
         uint32_t carry = 0;
@@ -1076,7 +1086,7 @@ k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
             const uint32_t incl = wave_incl_scan_u32(cnt, lane);
             if (b < n_slices) {
                 loff[b] = carry + incl - cnt;
-                seg[(size_t)(bin0 + b) * n_tiles + tile] = (carry + incl - cnt) | (cnt << 16);
+                seg[(size_t)(bin0 + b) * n_tiles + tile] = (carry + incl - cnt) | (cnt << 16) | bad_bit;
             }
             carry += __shfl(incl, 63, 64);
         }
@@ -1100,80 +1110,167 @@ k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
     for (uint32_t t = threadIdx.x; t < (total + 1u) / 2u; t += kStBlock) dst[t] = src[t];
 }
 
-// PERSISTENT like k_st_accumulate; items = {bin, chunk, n_chunks, streamed-level index}: the chunk walks tiles
-// [chunk * per, (chunk + 1) * per) of its bin.
-__global__ void __launch_bounds__(kLdsBwdBlock)
-k_tl_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
-                const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
+// PERSISTENT like k_st_accumulate; items = {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}:
+// the chunk walks tiles [chunk * per, (chunk + 1) * per) of its bin.
+//
+// One 1024-thread workgroup with 128 KiB of accumulators has a CU to itself, so nothing hides a dependent round trip
+// but the workgroup's own loads: measured with the loads alone (atomics off), a straightforward item -- header ->
+// bin tables -> segment words -> runs in two batches, the second half of every run in a serial tail -- cost 28 us.
+// Hence: the header is self-contained (no bin-table hop); the NEXT item's header and segment words are requested
+// while the current item streams; every wave owns a contiguous block of the item's tiles (all waves stream, whatever
+// the tile count, and a wave's segment words are one contiguous read); and a wave reads its runs as one
+// concatenated record stream, all of whose loads are in flight at once (see the loop).
+constexpr uint32_t kTlWin = 26;  // wave loads per pass: 24 runs x 64 records of a hashed level + slack
+constexpr int kTlBlock = 1024;
+
+struct TlItem {
+    uint32_t bin, chunk, n_chunks, lvl, level, slice, t0, t1;
+};
+__device__ __forceinline__ TlItem tl_decode(uint4 h, uint32_t n_tiles) {
+    TlItem I;
+    I.bin = h.x;
+    I.chunk = h.y & 0xFFFFu;
+    I.n_chunks = h.y >> 16;
+    I.lvl = h.z & 0xFFu;
+    I.level = h.z >> 8;
+    I.slice = h.w;
+    const uint32_t per = (n_tiles + I.n_chunks - 1u) / I.n_chunks;
+    I.t0 = min(n_tiles, I.chunk * per);
+    I.t1 = min(n_tiles, I.t0 + per);
+    return I;
+}
+
+__global__ void __launch_bounds__(kTlBlock)
+k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                 const uint2* __restrict__ records, uint32_t n_tiles, uint32_t tile_records, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
-    const int lane = threadIdx.x & 63;
-    const uint32_t wib = threadIdx.x >> 6;
-    constexpr uint32_t kWaves = kLdsBwdBlock / 64;
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint4 item = items[it];
-        const uint32_t bin = item.x, chunk = item.y, n_chunks = item.z, lvl = item.w;
-        const uint32_t level = bin_level[bin], slice = bin_slice[bin];
-        const uint32_t entries = st_bin_entries(g, level, slice);
-        const uint32_t per = (n_tiles + n_chunks - 1) / n_chunks;
-        const uint32_t t0 = chunk * per, t1 = min(n_tiles, t0 + per);
-        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
+    const uint32_t lane = threadIdx.x & 63u;
+    // the wave index as a SCALAR: everything derived from it (tile block, run counts, loop bounds, the lane a segment
+    // word is read from) then lives in SGPRs -- left in a VGPR, the compiler treated the run loops as divergent
+    // (exec-masked loops, ds_bpermute for every segment word, 64-bit vector address arithmetic per run)
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr uint32_t kWaves = kTlBlock / 64;
+    uint32_t it = blockIdx.x;
+    if (it >= n_items) return;
+    // Wave w owns the contiguous tile block [t0 + w * per_wave, ...) of an item: its segment words (lane j: the wave's
+    // j-th tile; first block of 64 tiles) are one contiguous read.
+    auto seg_first = [&](const TlItem& I) -> uint32_t {
+        const uint32_t n_span = I.t1 - I.t0;
+        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
+        const uint32_t first = min(n_span, wib * per_wave);
+        const uint32_t n_mine = min(per_wave, n_span - first);
+        return lane < min(64u, n_mine) ? seg[(size_t)I.bin * n_tiles + I.t0 + first + lane] : 0u;
+    };
+    TlItem cur = tl_decode(items[it], n_tiles);
+    uint32_t segw = seg_first(cur);
+    for (;;) {
+        const uint32_t it_next = it + gridDim.x;
+        const bool has_next = it_next < n_items;
+        const uint4 head_next = items[has_next ? it_next : it];  // in flight while the accumulators are zeroed
+        const uint32_t entries = st_bin_entries(g, cur.level, cur.slice);
+        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * kBinSlice);
         {
             uint4* z = reinterpret_cast<uint4*>(lds_raw);
-            for (uint32_t e = threadIdx.x; e < entries; e += kLdsBwdBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t e = threadIdx.x; e < entries; e += kTlBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
-        const uint32_t* __restrict__ seg_row = seg + (size_t)bin * n_tiles;
-        const uint2* __restrict__ rec_lvl = records + (size_t)lvl * n_tiles * tile_records;
-        bool bad = false;  // a record of a non-finite w * dy has an all-ones exponent whatever rides in its mantissa
+        const uint2* __restrict__ rec_lvl = records + (size_t)cur.lvl * n_tiles * tile_records;
+        const uint32_t n_span = cur.t1 - cur.t0;
+        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
+        const uint32_t tile_first = cur.t0 + min(n_span, wib * per_wave);
+        const uint32_t n_mine = min(per_wave, cur.t1 - tile_first);
+        bool bad = false;  // (flagged by the scatter pass in bit 31 of the segment words)
         auto add = [&](uint2 r) {
             const uint32_t rel = (r.x & 0x3Fu) | ((r.y & 0x7Fu) << 6);
-            bad |= ((r.x & 0x7F800000u) == 0x7F800000u) | ((r.y & 0x7F800000u) == 0x7F800000u);
             AccFixed::add(acc, rel, __uint_as_float(r.x & ~0x3Fu), __uint_as_float(r.y & ~0x7Fu), AccScale{});
         };
-        // each wave takes blocks of 64 tiles: lane l fetches the segment word of tile tb + l, then the wave walks the
-        // runs kUnroll at a time (the first 64 records of kUnroll runs are requested before any is consumed)
-        constexpr uint32_t kUnroll = 8;
-        for (uint32_t tb = t0 + wib * 64u; tb < t1; tb += kWaves * 64u) {
-            const uint32_t n_here = min(64u, t1 - tb);
-            const uint32_t segw = (uint32_t)lane < n_here ? seg_row[tb + lane] : 0u;
-            for (uint32_t k0 = 0; k0 < n_here; k0 += kUnroll) {
-                uint2 rec[kUnroll];
-                uint32_t cnt[kUnroll];
+        TlItem nxt = cur;
+        uint32_t segw_next = 0u;
+        bool next_requested = false;
+        for (uint32_t j0 = 0; j0 < n_mine; j0 += 64u) {
+            const uint32_t n_here = min(64u, n_mine - j0);
+            if (j0 > 0u)  // (more than 64 tiles per wave: > 1024 tiles in the chunk)
+                segw = lane < n_here ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+            // The wave's runs (lane j: run of its j-th tile) are read as ONE concatenated stream of `total` records:
+            // wave load q fetches virtual records [64 q, 64 q + 64), whichever runs they fall in.  Every load is full
+            // (no per-run tails, no masked half loads) and all kTlWin loads of a pass -- a whole item's share for this
+            // wave when the level is hashed -- are requested back to back with UNCONDITIONAL loads (straight-line code:
+            // the compiler waits with counted vmcnt(N); loads behind `lane < count` branches made it wait for vmcnt(0)
+            // at every join).
+            const uint32_t cnt = lane < n_here ? (segw >> 16) & 0x7FFFu : 0u;
+            bad |= lane < n_here && (segw >> 31) != 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            // index (in records, from rec_lvl) of the run's first record minus its position in the stream: a lane whose
+            // virtual record v lies in run j reads rec_lvl[base_j + v]   (mod 2^32 arithmetic)
+            const uint32_t base = (tile_first + j0 + lane) * tile_records + (segw & 0xFFFFu) - (incl - cnt);
+            uint32_t r_s = 0u;  // (scalar) first run that reaches into the current window
+            for (uint32_t q0 = 0; q0 * 64u < total; q0 += kTlWin) {
+                uint2 rec[kTlWin];
 #pragma unroll
-                for (uint32_t u = 0; u < kUnroll; ++u) {
-                    const uint32_t k = k0 + u;
-                    const uint32_t sw = k < n_here ? (uint32_t)__shfl((int)segw, (int)k, 64) : 0u;
-                    cnt[u] = sw >> 16;
-                    const uint2* __restrict__ run = rec_lvl + (size_t)(tb + k) * tile_records + (sw & 0xFFFFu);
-                    rec[u] = (uint32_t)lane < cnt[u] ? run[lane] : make_uint2(0u, 0u);
+                for (uint32_t u = 0; u < kTlWin; ++u) {
+                    const uint32_t w0 = (q0 + u) * 64u;  // uniform
+                    const uint32_t v = w0 + lane;
+                    uint32_t my_base = 0u;
+                    if (w0 < total) {
+                        // ~9 vector instructions per window: the run index lives in an SGPR, the lanes only compare
+                        // against the (scalar) start of each further run that begins inside the window
+                        uint32_t end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r_s);
+                        while (end_r <= w0) end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)++r_s);
+                        my_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r_s);
+                        for (uint32_t r = r_s; end_r < w0 + 64u && r < 63u;) {
+                            ++r;
+                            const uint32_t b_r = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r);
+                            my_base = v >= end_r ? b_r : my_base;  // (end of run r - 1 = start of run r)
+                            end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r);
+                        }
+                    }
+                    rec[u] = rec_lvl[v < total ? my_base + v : 0u];
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < kUnroll; ++u)
-                    if ((uint32_t)lane < cnt[u]) add(rec[u]);
-#pragma unroll
-                for (uint32_t u = 0; u < kUnroll; ++u) {  // runs longer than one wave (dense levels, clustered samples)
-                    if (cnt[u] > 64u) {
-                        const uint32_t k = k0 + u;
-                        const uint32_t sw = (uint32_t)__shfl((int)segw, (int)k, 64);
-                        const uint2* __restrict__ run = rec_lvl + (size_t)(tb + k) * tile_records + (sw & 0xFFFFu);
-                        for (uint32_t r = 64u + lane; r < cnt[u]; r += 64u) add(run[r]);
+                if (!next_requested) {  // the next item's segment words ride behind this item's loads
+                    next_requested = true;
+                    if (has_next) {
+                        nxt = tl_decode(head_next, n_tiles);
+                        segw_next = seg_first(nxt);
                     }
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < kTlWin; ++u)
+                    if ((q0 + u) * 64u + lane < total) add(rec[u]);
             }
         }
+        if (!next_requested && has_next) {  // (a wave without records in this item)
+            nxt = tl_decode(head_next, n_tiles);
+            segw_next = seg_first(nxt);
+        }
         __syncthreads();
-        if (n_chunks == 1) {
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e, AccScale{});
-        } else {
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
-                const float v = AccFixed::get(acc, e, AccScale{});
-                if (v != 0.f) atomicAdd(gr + e, v);
+        {
+            // flush: 4 consecutive gradient scalars per thread and step (two 16-byte LDS reads, one 16-byte store)
+            const uint32_t n4 = entries >> 1;  // 2 * entries scalars / 4
+            float4* __restrict__ gr4 = reinterpret_cast<float4*>(gr);
+            if (cur.n_chunks == 1u) {
+                for (uint32_t e = threadIdx.x; e < n4; e += kTlBlock) {
+                    float4 v;
+                    v.x = AccFixed::get(acc, 4 * e + 0, AccScale{});
+                    v.y = AccFixed::get(acc, 4 * e + 1, AccScale{});
+                    v.z = AccFixed::get(acc, 4 * e + 2, AccScale{});
+                    v.w = AccFixed::get(acc, 4 * e + 3, AccScale{});
+                    gr4[e] = v;
+                }
+            } else {
+                for (uint32_t e = threadIdx.x; e < 2 * entries; e += kTlBlock) {
+                    const float v = AccFixed::get(acc, e, AccScale{});
+                    if (v != 0.f) atomicAdd(gr + e, v);
+                }
             }
         }
         __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
-        if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
+        if (__ballot(bad) != 0ull && lane == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
+        if (!has_next) break;
+        it = it_next;
+        cur = nxt;
+        segw = segw_next;
     }
 }
 
@@ -1545,15 +1642,25 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         // static work list: hashed levels spread their records evenly over the bins (one item per bin); a streamed
         // DENSE level sees clustered samples, so its bins are split into tile ranges
         std::vector<uint32_t> items, chunks(nb, 1u);
+        const bool spread = !(getenv("NVO_TL_ORDER") && atoi(getenv("NVO_TL_ORDER")) == 0);
+        if (const char* e = getenv("NVO_TL_DENSE_CHUNKS")) st->dense_chunks = (uint32_t)atoi(e);
         for (uint32_t j = 0; j < levels.size(); ++j) {
             const uint32_t nc = g.hashed[levels[j]] ? 1u : st->dense_chunks;
-            for (uint32_t b = first[j]; b < first[j + 1]; ++b) {
+            const uint32_t nbj = first[j + 1] - first[j];
+            for (uint32_t q = 0; q < nbj; ++q) {
+                // The persistent workgroups of ONE XCD take the items congruent to it modulo 8.  A bin's runs start
+                // near bin * 512 B inside every 32 KiB tile region, so bins that are 8 apart would put all 32
+                // workgroups of an XCD on the same few L2 channels: deal the bins so that an XCD gets CONSECUTIVE
+                // bins (8 x 8 transpose of the order inside each group of 64).
+                uint32_t bq = q;
+                if (spread && nbj >= 64 && q < (nbj & ~63u)) bq = (q & ~63u) | ((q & 7u) << 3) | ((q >> 3) & 7u);
+                const uint32_t b = first[j] + bq;
                 chunks[b] = nc;
-                for (uint32_t c = 0; c < nc; ++c) {
+                for (uint32_t c = 0; c < nc; ++c) {  // self-contained header (k_tl_accumulate: tl_decode)
                     items.push_back(b);
-                    items.push_back(c);
-                    items.push_back(nc);
-                    items.push_back(j);
+                    items.push_back(c | (nc << 16));
+                    items.push_back(j | (levels[j] << 8));
+                    items.push_back(bin_slice[b]);
                 }
             }
         }
@@ -1660,9 +1767,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                          \
             NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                        st->d_bin_chunks, grad);                                                              \
-            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < n_cus ? st->n_tl_items : n_cus), dim3(kLdsBwdBlock), \
-                       lds_acc_tl, stream, g, st->d_bin_level, st->d_bin_slice, (const uint4*)st->d_tl_items,  \
-                       st->n_tl_items, seg, records_tl, n_tiles, (uint32_t)tile_records, grad);               \
+            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < n_cus ? st->n_tl_items : n_cus), dim3(kTlBlock), \
+                       lds_acc_tl, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, records_tl, \
+                       n_tiles, (uint32_t)tile_records, grad);                                               \
         }                                                                                                    \
     } while (0)
 #define NVO_LAUNCH_TL_T(SOA_, T_)                                                 \

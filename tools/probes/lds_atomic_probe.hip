@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(1024) k(const uint32_t* __restrict__ idx, int 
             if (MODE == 2) atomicAdd((unsigned long long*)&lds[2 * a], 1ull);
             if (MODE == 3) { atomicAdd((float*)&lds[2 * a], 1.0f); atomicAdd((float*)&lds[2 * a + 1], 2.0f); }
             if (MODE == 4) lds[2 * a] = h;  // plain store for reference
+            if (MODE == 5) unsafeAtomicAdd((double*)&lds[2 * a], 1.0);
+            if (MODE == 6) { unsafeAtomicAdd((float*)&lds[2 * a], 1.0f); }
         }
     }
     __syncthreads();
@@ -60,6 +62,8 @@ int main() {
         run<1>("ds_add_u32", d_idx, d_out, active);
         run<2>("ds_add_u64", d_idx, d_out, active);
         run<3>("2x ds_add_f32 (pair)", d_idx, d_out, active);
+        run<5>("ds_add_f64", d_idx, d_out, active);
+        run<6>("ds_add_f32 (unsafe)", d_idx, d_out, active);
     }
     return 0;
 }
