@@ -477,6 +477,12 @@ int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, in
  * Everywhere a `grads_are_half` argument appears, 0 = fp32, 1 = fp16, 2 = bfloat16. */
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
+/* Exponential moving average of the weights, the "Ema" optimiser wrapper of instant-ngp's configs/nerf/base.json
+ * (decay 0.95) that pyngp.Testbed trains with (/root/reference/nerf_vo/mapping/instant_ngp.py:45 loads that file):
+ * ema = (ema * decay * (1 - decay^(step-1)) + params * (1 - decay)) / (1 - decay^step), step counting from 1; the
+ * optional fp16 copy (ema_half) is what inference reads.  skip_flag as in nvo_adam_step. */
+int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                   uint32_t step, const uint32_t* skip_flag);
 /* bf16 MLP mode (BASELINE configs[4]: "MFMA bf16 MLP + fp32 hash accumulate"): the 16-bit working copy of the flat
  * parameter buffer is bfloat16 inside up to 4 element ranges [bf16_lo[k], bf16_hi[k]) (the fused-MLP weights and the
  * appearance embedding; bounds multiples of 4) and fp16 elsewhere (the hash tables).  Host arrays.

@@ -248,6 +248,22 @@ k_cast_bf16(uint64_t n, const float* __restrict__ src, uint16_t* __restrict__ ds
     for (uint64_t i = n_vec * 4 + tid; i < n; i += stride) dst[i] = to_bf16(src[i]);
 }
 
+// tcnn EmaOptimizer::step [UPSTREAM, restated]: the debiased exponential moving average of the weights,
+//   ema_t = (ema_{t-1} * decay * (1 - decay^(t-1)) + w_t * (1 - decay)) / (1 - decay^t),
+// kept in fp32 with a 16-bit copy for inference.  skip_flag (the optimiser's): non-zero = the step was skipped, the
+// average keeps its value.
+__global__ void __launch_bounds__(256)
+k_ema_update(uint64_t n, const float* __restrict__ params, float* __restrict__ ema, _Float16* __restrict__ ema_half,
+             float keep, float take, float inv_debias, const uint32_t* __restrict__ skip_flag) {
+    if (skip_flag && skip_flag[0] != 0u) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float e = (ema[i] * keep + params[i] * take) * inv_debias;
+        ema[i] = e;
+        if (ema_half) ema_half[i] = (_Float16)e;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -478,6 +494,23 @@ int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_b
     uint32_t blocks = nvo_div_up(n, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     NVO_LAUNCH(k_cast_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src, (uint16_t*)dst_bf16);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                   uint32_t step, const uint32_t* skip_flag) {
+    NVO_REQUIRE(params && ema, "ema_update: NULL argument");
+    NVO_REQUIRE(step >= 1 && decay >= 0.f && decay < 1.f, "ema_update: step counts from 1, 0 <= decay < 1");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "ema_update");
+    const double d = (double)decay;
+    const float keep = (float)(d * (1.0 - pow(d, (double)step - 1.0)));
+    const float inv_debias = (float)(1.0 / (1.0 - pow(d, (double)step)));
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_ema_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params, ema, (_Float16*)ema_half, keep,
+               1.0f - decay, inv_debias, skip_flag);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -319,9 +319,14 @@ int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const f
     static float2* march_scratch = nullptr;
     static size_t march_scratch_rays = 0;
     if (R > march_scratch_rays) {
+        // (power-of-two growth: the adaptive ray batch of the occupancy-grid trainer changes R every few steps)
+        size_t rays = march_scratch_rays ? march_scratch_rays : 4096;
+        while (rays < R) rays *= 2;
         if (march_scratch) NVO_CHECK_HIP(hipFree(march_scratch));
-        NVO_CHECK_HIP(hipMalloc((void**)&march_scratch, sizeof(float2) * (size_t)R * kMaxSteps));
-        march_scratch_rays = R;
+        march_scratch = nullptr;
+        march_scratch_rays = 0;
+        NVO_CHECK_HIP(hipMalloc((void**)&march_scratch, sizeof(float2) * rays * kMaxSteps));
+        march_scratch_rays = rays;
     }
     {
         NVO_PROF(stream, "occ_march");

@@ -58,6 +58,17 @@ class NgpConfig:
     optimize_extrinsics: bool = True
     extrinsic_lr: float = 1e-3
     extrinsic_l2_reg: float = 1e-4
+    # "optimizer": {"otype": "Ema", "decay": 0.95, "nested": Adam} of instant-ngp's configs/nerf/base.json (the file the
+    # reference loads, instant_ngp.py:45) [UPSTREAM tcnn EmaOptimizer]: inference reads the debiased moving average of
+    # the weights, training the raw ones.  0 switches it off.
+    ema_decay: float = 0.95
+    # Testbed::train adapts the rays per batch so that the marched samples meet the target batch (1 << 18):
+    # rays <- rays * target / measured, rounded up to the batch granularity (128), every `density_update_every` steps
+    # (upstream does it where it reads the loss back, every 16 steps) [UPSTREAM NerfCounters::update_after_training].
+    # num_rays is the first batch; rays beyond the packed capacity are dropped for that step, as upstream.
+    adaptive_rays: bool = True
+    min_rays: int = 128
+    max_rays: int = 1 << 16               # (upstream clamps at 1 << 18; the march scratch is rays x 1024 steps x 8 B)
     seed: int = 1337
 
     @property
@@ -101,6 +112,12 @@ class NgpEngine:
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
         self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(self.n_params), z(self.n_params), z(self.n_params), z(self.n_params)
         self.params_half = z(self.n_params, torch.float16)
+        # moving average of the weights (inference copy) -- allocated on first use
+        self.params_ema = None
+        self.params_ema_half = None
+        self.ema_step = 0
+        self.rays_per_batch = int(cfg.num_rays)
+        self._measured = []  # device scalars: marched samples of the steps since the last adaptation
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)
         self.skip_flag = z(1, torch.int32)
         self.density_grid = z(cfg.n_levels * CELLS)
@@ -133,6 +150,13 @@ class NgpEngine:
     def set_params(self, flat: torch.Tensor) -> None:
         self.params.copy_(flat.to(self.device, torch.float32))
         _call("nvo_cast_half", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half))
+        self.params_ema = self.params_ema_half = None  # the average restarts from the new weights
+        self.ema_step = 0
+
+    def inference_params_half(self) -> torch.Tensor:
+        """The 16-bit weights inference reads: the moving average once it exists (tcnn: the optimiser's
+        custom_weights()), the raw working copy otherwise."""
+        return self.params_ema_half if (self.params_ema_half is not None and self.ema_step > 0) else self.params_half
 
     def _pp(self, name: str, buf: torch.Tensor):
         o, _ = self.segments[name]
@@ -140,14 +164,18 @@ class NgpEngine:
 
     # ---- scratch -----------------------------------------------------------------------------
     def _workspace(self, R: int, training: bool):
+        """Scratch for up to R_cap >= R rays (power of two: the adaptive batch changes R every few steps; the kernels
+        take R as an argument and only touch the first R rows)."""
+        ws = self._ws
+        if ws is not None and ws["training"] == training and R <= ws["R_cap"]:
+            return self._ray_views(ws, R)
+        R_req, R = R, max(4096, 1 << max(0, (R - 1).bit_length()))
         key = (R, training)
-        if self._ws is not None and self._ws["key"] == key:
-            return self._ws
         dev, cap = self.device, self.cfg.capacity
         f32 = dict(dtype=torch.float32, device=dev)
         f16 = dict(dtype=torch.float16, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        ws = {"key": key, "R": R}
+        ws = {"key": key, "R": R_req, "R_cap": R, "training": training}
         for name, shape in (("origins", (R, 3)), ("directions", (R, 3)), ("directions_norm", (R,)), ("pixel_area", (R,)),
                             ("gt_rgb", (R, 3)), ("gt_depth", (R,)), ("dirs01", (R, 3)), ("out_rgb", (R, 3)),
                             ("out_depth", (R,)), ("out_accumulation", (R,)), ("t", (cap,)), ("dt", (cap,)),
@@ -170,7 +198,19 @@ class NgpEngine:
                 ws["d_origin"] = torch.zeros(R, 3, **f32)
                 ws["d_dir"] = torch.zeros(R, 3, **f32)
                 ws["ray_indices"] = torch.zeros(R, 3, dtype=torch.int64, device=dev)
+        ws["_per_ray"] = {k: ws[k] for k in self._PER_RAY if k in ws}
         self._ws = ws
+        return self._ray_views(ws, R_req)
+
+    _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "dirs01", "out_rgb",
+                "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices")
+
+    @staticmethod
+    def _ray_views(ws, R: int):
+        """ws[name] = the first R rows of every per-ray buffer (same storage, same base address)."""
+        ws["R"] = R
+        for k, full in ws["_per_ray"].items():
+            ws[k] = full[:R + 1] if k == "offsets" else full[:R]
         return ws
 
     # ---- density grid ------------------------------------------------------------------------
@@ -225,13 +265,15 @@ class NgpEngine:
         cfg = self.cfg
         R, cap = ws["R"], cfg.capacity
         lo, hi = cfg.aabb
+        # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
+        self._fwd_half = self.params_half if training else self.inference_params_half()
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
               _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]))
         _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
               _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
-        _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
+        _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),
               _ptr(ws["density_out"]), _ptr(ws["ctx"]))
         _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
         _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
@@ -241,7 +283,8 @@ class NgpEngine:
     def _rgb_args(self, ws, training: bool):
         return _lib.NgpRgbArgs(
             capacity=self.cfg.capacity, sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
-            ray_idx=ws["ray_idx"].data_ptr(), weights=self._pp("rgb", self.params_half).value,
+            ray_idx=ws["ray_idx"].data_ptr(),
+            weights=self._pp("rgb", self.params_half if training else self.inference_params_half()).value,
             rgb_out=ws["rgb_out"].data_ptr(), hidden=ws["rgb_hidden"].data_ptr() if training else None,
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None,
             d_density_out=ws["d_density_out"].data_ptr() if training else None,
@@ -315,6 +358,13 @@ class NgpEngine:
                   C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
                   cfg.lr, cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, wd,
                   _ptr(self.skip_flag), None)
+        if cfg.ema_decay > 0.0:
+            if self.params_ema is None:
+                self.params_ema = torch.zeros_like(self.params)
+                self.params_ema_half = torch.zeros_like(self.params_half)
+            self.ema_step += 1
+            _call("nvo_ema_update", stream, self.n_params, _ptr(self.params), _ptr(self.params_ema),
+                  _ptr(self.params_ema_half), cfg.ema_decay, self.ema_step, _ptr(self.skip_flag))
         if cfg.optimize_extrinsics and self._pose_inputs is not None:
             n6 = cfg.num_images * 6
             _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
@@ -336,6 +386,22 @@ class NgpEngine:
                 all_reduce(self.pose_grads)
         self.optimizer_step()
         self.step += 1
+        if self.cfg.adaptive_rays:
+            self._adapt_rays(ws, R)
+
+    def _adapt_rays(self, ws, R: int) -> None:
+        """rays_per_batch <- rays * target / measured samples per step (mean since the last adaptation), rounded up to
+        128, every `density_update_every` steps -- ONE host read-back per 16 steps, where upstream reads its loss."""
+        cfg = self.cfg
+        self._measured.append(ws["counts"].sum())  # marched (uncapped) samples of this step, device scalar
+        if self.step % cfg.density_update_every != 0:
+            return
+        measured = float(torch.stack(self._measured).float().mean().item())
+        self._measured = []
+        if measured <= 0.0:
+            return
+        want = int(math.ceil(R * cfg.capacity / measured / 128.0)) * 128
+        self.rays_per_batch = max(cfg.min_rays, min(cfg.max_rays, want))
 
     @torch.no_grad()
     def camera_corrections(self) -> torch.Tensor:

@@ -232,7 +232,9 @@ class Testbed:
         eng.cfg.optimize_extrinsics = bool(self.nerf.training.optimize_extrinsics)
         h, w = self._resolution
         scale = torch.tensor([n, h, w], device=self.device)
-        u = torch.rand((eng.cfg.num_rays, 3), device=self.device, generator=self._generator)
+        # (Testbed::train adapts the rays per batch to the marched-sample target; NgpEngine.rays_per_batch)
+        u = torch.rand((eng.rays_per_batch if eng.cfg.adaptive_rays else eng.cfg.num_rays, 3), device=self.device,
+                       generator=self._generator)
         eng.train_step(torch.floor(u * scale).long(), self._intrinsics, self._poses, self._images, self._depths)
         self.training_step = eng.step
         return True
@@ -258,6 +260,10 @@ class Testbed:
                 "optimize_extrinsics": bool(self.nerf.training.optimize_extrinsics),
                 "params": raw(e.params), "density_grid": raw(e.density_grid), "bitfield": raw(e.bitfield),
                 "poses": raw(self._poses), "intrinsics": raw(self._intrinsics), "pose_adjustment": raw(e.pose_adjustment)}
+        if e.params_ema is not None and e.ema_step > 0:  # what inference reads (moving average of the weights)
+            snap["params_ema"] = raw(e.params_ema)
+            snap["ema_step"] = e.ema_step
+        snap["rays_per_batch"] = e.rays_per_batch
         if include_optimizer_state:
             snap["optimizer"] = {"exp_avg": raw(e.exp_avg), "exp_avg_sq": raw(e.exp_avg_sq),
                                  "pose_exp_avg": raw(e.pose_exp_avg), "pose_exp_avg_sq": raw(e.pose_exp_avg_sq)}
@@ -291,6 +297,11 @@ class Testbed:
             dst.copy_(src.view(dst.shape))
 
         e.set_params(torch.frombuffer(bytearray(snap["params"]), dtype=torch.float32))
+        if "params_ema" in snap:
+            e.params_ema = torch.frombuffer(bytearray(snap["params_ema"]), dtype=torch.float32).to(self.device)
+            e.params_ema_half = e.params_ema.to(torch.float16)
+            e.ema_step = int(snap["ema_step"])
+        e.rays_per_batch = int(snap.get("rays_per_batch", e.cfg.num_rays))
         put(e.density_grid, snap["density_grid"])
         put(e.bitfield, snap["bitfield"])
         put(self._poses, snap["poses"])

@@ -196,3 +196,74 @@ def test_density_grid_update_and_training(device):
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-10:])
     assert int(eng.skip_flag.item()) == 0
+
+
+def test_weight_ema_matches_tcnn_formula(device):
+    """nvo_ema_update vs the debiased moving average of tcnn's EmaOptimizer (restated): ema_t = (ema_{t-1} * d *
+    (1 - d^(t-1)) + w_t * (1 - d)) / (1 - d^t); a raised skip flag leaves the average untouched."""
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    n, d = 10007, 0.95
+    g = torch.Generator().manual_seed(1)
+    ema = torch.zeros(n, device=device)
+    ema_half = torch.zeros(n, dtype=torch.float16, device=device)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    ref = torch.zeros(n, dtype=torch.float64)
+    for t in range(1, 41):
+        w = torch.randn(n, generator=g)
+        _call("nvo_ema_update", _stream(device), n, _ptr(w.to(device)), _ptr(ema), _ptr(ema_half), d, t, _ptr(flag))
+        ref = (ref * d * (1 - d ** (t - 1)) + w.double() * (1 - d)) / (1 - d ** t)
+        if t == 1:
+            assert torch.allclose(ema.cpu(), w, rtol=1e-6, atol=1e-7)  # the first average IS the weights
+    torch.cuda.synchronize()
+    assert torch.allclose(ema.cpu().double(), ref, rtol=2e-5, atol=2e-6)
+    assert torch.equal(ema_half.cpu(), ema.cpu().half())
+    before = ema.clone()
+    flag.fill_(1)
+    _call("nvo_ema_update", _stream(device), n, _ptr(torch.randn(n, generator=g).to(device)), _ptr(ema), _ptr(ema_half), d, 41,
+          _ptr(flag))
+    torch.cuda.synchronize()
+    assert torch.equal(before, ema)
+
+
+def test_adaptive_ray_batch_and_ema_inference(device):
+    """The ray batch adapts toward the packed-sample target (NerfCounters::update_after_training [UPSTREAM]): after a
+    few adaptations the marched samples per step sit within 25 % of the capacity, whatever batch the run started
+    with; inference reads the moving average of the weights, training the raw ones."""
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W = 8, 60, 80
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    c2w = opencv_to_opengl(seq["camera_extrinsics"])
+    c2w[:, :3, 3] += 0.5
+    c2w = c2w[:, :3, :4].contiguous()
+    images = seq["frames_color"].permute(0, 2, 3, 1).contiguous()
+    depths = seq["frames_depth"].permute(0, 2, 3, 1).contiguous()
+    scale = torch.tensor([n, H, W], device=device)
+    for start in (256, 8192):
+        eng = NgpEngine(NgpConfig(num_images=n, num_rays=start, capacity=1 << 16), device)
+        seen = []
+        for it in range(96):
+            R = eng.rays_per_batch
+            assert R % 128 == 0 and eng.cfg.min_rays <= R <= eng.cfg.max_rays
+            idx = torch.floor(torch.rand(R, 3, device=device) * scale).long()
+            eng.train_step(idx, seq["camera_intrinsics"], c2w, images, depths)
+            seen.append((R, int(eng._ws["counts"].sum().item())))
+        assert eng.rays_per_batch != start, "the batch never adapted"
+        tail = np.mean([m for _, m in seen[-16:]])
+        assert 0.75 * eng.cfg.capacity <= tail <= 1.25 * eng.cfg.capacity, (start, seen[-16:])
+        assert int(eng.skip_flag.item()) == 0
+    # EMA: exists, differs from the raw weights, and is what render_rays evaluates
+    assert eng.ema_step == 96 and eng.inference_params_half() is eng.params_ema_half
+    assert not torch.equal(eng.params_ema_half, eng.params_half)
+    o = torch.tensor([[0.5, 0.5, 0.5]], device=device).repeat(64, 1)
+    dirs = torch.nn.functional.normalize(torch.randn(64, 3, device=device), dim=-1)
+    out_ema = eng.render_rays(o, dirs, torch.ones(64, device=device))["rgb"].clone()
+    eng.cfg.ema_decay, saved = 0.0, (eng.params_ema, eng.params_ema_half)
+    eng.params_ema = eng.params_ema_half = None
+    out_raw = eng.render_rays(o, dirs, torch.ones(64, device=device))["rgb"].clone()
+    eng.params_ema, eng.params_ema_half = saved
+    assert torch.isfinite(out_ema).all() and not torch.equal(out_ema, out_raw)
