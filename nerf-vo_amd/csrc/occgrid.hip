@@ -79,8 +79,10 @@ __device__ __forceinline__ bool occupied(const float* p, const uint8_t* __restri
     return (bitfield[idx / 8 + (size_t)mip * (kCells / 8)] >> (idx % 8)) & 1;
 }
 __device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
-__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, const float* p, const float* d,
-                                                       const float* idir, int mip) {
+// instant-ngp advance_to_next_voxel, first half: the ray parameter at which the ray leaves the cell of cascade `mip`
+// that holds p.  The march then steps along its FIXED progression t <- t + calc_dt(t) until t >= that target (at least
+// one step), i.e. the sample positions of a ray do not depend on the occupancy, only which of them are visited.
+__device__ __forceinline__ float voxel_exit_target(float t, const float* p, const float* d, const float* idir, int mip) {
     const float res = scalbnf((float)kG, -mip);
     float tmin = 3.0e38f;
 #pragma unroll
@@ -91,7 +93,11 @@ __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle
     }
     float dist = tmin / res;
     if (!(dist > 0.0f)) dist = 0.0f;
-    const float t_target = t + dist;
+    return t + dist;
+}
+__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, const float* p, const float* d,
+                                                       const float* idir, int mip) {
+    const float t_target = voxel_exit_target(t, p, d, idir, mip);
     do {
         t += calc_dt(t, cone_angle);
     } while (t < t_target);
@@ -166,6 +172,99 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
     }
     if (staged) flush(j);
     counts[r] = j;
+}
+
+// ONE WAVE PER RAY (the default).  A ray's candidate positions are the fixed progression t_0, t_1 = t_0 + calc_dt(t_0), ...
+// whatever the occupancy (see voxel_exit_target), so a wave tests 64 consecutive candidates at once -- one bitfield
+// round trip per 64 candidates instead of one per candidate, and 4096 waves instead of 64 for a 4096-ray batch (the
+// ray-per-lane form above keeps 960 of the chip's 1024 SIMDs idle and is a chain of ~1000 dependent loads) -- and then
+// replays the sequential visiting order on wave-wide ballots: the next visited candidate is the first one at or past
+// the current skip target; an occupied one is accepted and steps to its successor (a whole run of occupied candidates
+// is accepted with one mask operation), an empty one raises the skip target to the exit of its cell.  The accepted
+// samples leave through a popcount prefix over the ballot: coalesced stores in ray order, no atomics, and every
+// (t, dt) is bit-identical to the sequential march (the progression itself is evaluated with the same fp32 recurrence).
+__global__ void __launch_bounds__(256)
+k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __restrict__ directions,
+                 const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
+                 const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (r >= R) return;
+    const int max_mip = n_levels - 1;
+    const float half = 0.5f * (float)(1 << max_mip);
+    const float lo = 0.5f - half, hi = 0.5f + half;
+    float o[3], d[3], idir[3];
+    float tmin = t_near, tmax = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = origins[3 * (size_t)r + k];
+        d[k] = directions[3 * (size_t)r + k];
+        idir[k] = 1.0f / d[k];
+        float t0 = (lo - o[k]) * idir[k], t1 = (hi - o[k]) * idir[k];
+        if (t0 > t1) { const float tt = t0; t0 = t1; t1 = tt; }
+        if (t0 > tmin) tmin = t0;
+        if (t1 < tmax) tmax = t1;
+    }
+    float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
+    uint32_t j = 0;  // accepted so far (uniform)
+    if (tmax > tmin) {
+        float t = tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);  // candidate 0 of the current block
+        float skip_to = -3.0e38f;  // (uniform) candidates before this ray parameter are stepped over
+        bool done = false;
+        // (16384 blocks = 2^20 candidates: an exit every wave reaches even for a degenerate ray whose skip target is
+        // not finite -- a regular ray leaves a cascade-2 box after ~1000 candidates)
+        for (uint32_t block = 0; !done && block < 16384u; ++block) {
+            // lane k keeps the k-th value of the progression; every lane evaluates the same recurrence
+            float my_t = t;
+            for (uint32_t k = 0; k < 64u; ++k) {
+                if (lane == k) my_t = t;
+                t += calc_dt(t, cone_angle);
+            }
+            float p[3];
+            bool inside = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[k] = o[k] + d[k] * my_t;
+                inside = inside && p[k] >= lo && p[k] <= hi;
+            }
+            const float dt = calc_dt(my_t, cone_angle);
+            const int mip = mip_from_dt(dt, p, max_mip);
+            const bool occ = inside && occupied(p, bitfield, mip);
+            const float exit_t = (inside && !occ) ? voxel_exit_target(my_t, p, d, idir, mip) : 0.f;
+            const unsigned long long in_mask = __ballot(inside), occ_mask = __ballot(occ);
+            unsigned long long accept = 0ull;
+            uint32_t pos = 0;
+            while (pos < 64u) {
+                const unsigned long long cand = __ballot(my_t >= skip_to) & (~0ull << pos);
+                if (cand == 0ull) break;  // the rest of the block is stepped over
+                const uint32_t k = (uint32_t)__builtin_ctzll(cand);
+                if (!((in_mask >> k) & 1ull) || j >= kMaxSteps) {  // left the box / sample budget of the ray spent
+                    done = true;
+                    break;
+                }
+                if ((occ_mask >> k) & 1ull) {
+                    // an occupied candidate steps to its successor: the whole run of occupied candidates is visited
+                    const unsigned long long stop = ~occ_mask & (~0ull << k);
+                    uint32_t u = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                    const uint32_t room = kMaxSteps - j;
+                    if (u - k > room) u = k + room;
+                    accept |= (u >= 64u ? ~0ull : ((1ull << u) - 1ull)) & (~0ull << k);
+                    j += u - k;
+                    pos = u;
+                    skip_to = -3.0e38f;
+                } else {
+                    skip_to = __shfl(exit_t, (int)k, 64);
+                    pos = k + 1u;
+                }
+            }
+            if ((accept >> lane) & 1ull) {
+                const uint32_t before = (uint32_t)__popcll(accept & ((1ull << lane) - 1ull));
+                const uint32_t first = j - (uint32_t)__popcll(accept);
+                run[first + before] = make_float2(my_t, dt);
+            }
+        }
+    }
+    if (lane == 0u) counts[r] = j;
 }
 
 // one wave per ray: scratch run -> packed arrays at the scanned offset (rays dropped by the capacity clamp have
@@ -330,8 +429,14 @@ int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const f
     }
     {
         NVO_PROF(stream, "occ_march");
-        NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
-                   n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+        static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
+        if (ray_per_lane) {  // (A/B switch: the sequential form, one ray per lane)
+            NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
+                       n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+        } else {
+            NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
+                       n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+        }
         NVO_CHECK_LAUNCH();
     }
     {
