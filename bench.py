@@ -83,8 +83,10 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
 def pmc_traffic(name: str):
     """HBM bytes per launch of the named kernel from the committed rocprofv3 PMC summary
     (profiles/*_pmc_fetch_write_per_kernel.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of
-    this same command; (FETCH_SIZE + WRITE_SIZE) * 1024, raw -- see the note in that file about the
-    gfx950 FETCH_SIZE calibration).  None when no PMC summary covers the kernel."""
+    this same command; (FETCH_SIZE corrected for gfx950's half-counted coalesced streaming reads + WRITE_SIZE) *
+    1024 -- see the note in that file).  The counters cannot be collected inside a timed run (a --pmc pass
+    serialises the kernels), so the figure comes from the latest committed pass of the same command and names its
+    source file.  None when no PMC summary covers the kernel."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")), reverse=True):
@@ -94,7 +96,8 @@ def pmc_traffic(name: str):
             continue
         for k in data.get("kernels", []):
             if k.get("bench_name") == name:
-                return int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path)
+                fetch = k.get("FETCH_SIZE_KB_corrected", k["FETCH_SIZE_KB_per_launch"])  # gfx950 streaming-read correction
+                return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path)
     return None, None
 
 

@@ -41,28 +41,43 @@ def main():
         kernels.append({"kernel": key[0], "grid_size": key[1], "launches": n,
                         "FETCH_SIZE_KB_per_launch": round(f / max(nf, 1), 1),
                         "WRITE_SIZE_KB_per_launch": round(w / max(nw, 1), 1)})
+    # gfx950: FETCH_SIZE reports exactly HALF the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section:
+    # 16 B per lane; calibrated here for 8 B per lane too -- tools/probes/read_bw_probe under --pmc FETCH_SIZE reports
+    # 70 688 KB for a 141 312 KB buffer at both widths, profiles/r2_pmc_probe_calibration.txt).  The kernels below read
+    # nothing but such streams; every other kernel's reads (4-byte gathers, strided rows) are uncalibrated and stay raw.
+    STREAM_READERS = {"k_tl_accumulate", "k_st_accumulate", "k_adam_groups", "k_adam", "k_nonfinite_flag_ranges",
+                      "k_nonfinite_flag", "k_read"}
+    for k in kernels:
+        k["FETCH_SIZE_KB_corrected"] = round(k["FETCH_SIZE_KB_per_launch"] * (2.0 if k["kernel"] in STREAM_READERS else 1.0), 1)
     # bench rows: the streamed main-grid backward is several kernels per step (+ the slice-owner launch of its
     # coarse levels = the k_grid_bwd_lds launch with the smallest grid)
-    st = [k for k in kernels if k["kernel"].startswith("k_st_")]
+    st = [k for k in kernels if k["kernel"].startswith(("k_st_", "k_tl_"))]
     lds = sorted((k for k in kernels if k["kernel"] == "k_grid_bwd_lds"), key=lambda k: k["grid_size"])
     rows = []
+
+    def total(parts, field, steps):
+        return round(sum(k[field] * k["launches"] for k in parts) / steps, 1)
+
     if st:
         parts = st + (lds[:1] if lds else [])
-        steps = max(k["launches"] for k in parts if k["kernel"] == "k_st_scatter")
+        steps = max(k["launches"] for k in parts if k["kernel"] in ("k_st_scatter", "k_tl_scatter"))
         rows.append({"bench_name": "grid_bwd_stream[L16]", "launches": steps, "parts": [f'{k["kernel"]}/{k["grid_size"]}' for k in parts],
-                     "FETCH_SIZE_KB_per_launch": round(sum(k["FETCH_SIZE_KB_per_launch"] * k["launches"] for k in parts) / steps, 1),
-                     "WRITE_SIZE_KB_per_launch": round(sum(k["WRITE_SIZE_KB_per_launch"] * k["launches"] for k in parts) / steps, 1)})
+                     "FETCH_SIZE_KB_per_launch": total(parts, "FETCH_SIZE_KB_per_launch", steps),
+                     "FETCH_SIZE_KB_corrected": total(parts, "FETCH_SIZE_KB_corrected", steps),
+                     "WRITE_SIZE_KB_per_launch": total(parts, "WRITE_SIZE_KB_per_launch", steps)})
         lds = lds[1:]
     if lds:
         n = sum(k["launches"] for k in lds)
         rows.append({"bench_name": "grid_bwd_lds[L5]" if st else "grid_bwd_lds[L16]", "launches": n,
                      "parts": [f'{k["kernel"]}/{k["grid_size"]}' for k in lds],
-                     "FETCH_SIZE_KB_per_launch": round(sum(k["FETCH_SIZE_KB_per_launch"] * k["launches"] for k in lds) / n, 1),
-                     "WRITE_SIZE_KB_per_launch": round(sum(k["WRITE_SIZE_KB_per_launch"] * k["launches"] for k in lds) / n, 1)})
+                     "FETCH_SIZE_KB_per_launch": total(lds, "FETCH_SIZE_KB_per_launch", n),
+                     "FETCH_SIZE_KB_corrected": total(lds, "FETCH_SIZE_KB_corrected", n),
+                     "WRITE_SIZE_KB_per_launch": total(lds, "WRITE_SIZE_KB_per_launch", n)})
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
-            "`python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`; raw counter unit KB; per launch = sum / launches. "
-            "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x, other access "
-            "widths are uncalibrated; the values are reported raw.")
+            "`python3 bench.py --steps 20 --warmup 5 --psnr off --cpu-baseline off --late-steps 0`; raw counter unit KB; "
+            "per launch = sum / launches.  FETCH_SIZE_KB_corrected = raw x 2 for the kernels whose reads are pure coalesced "
+            "streams (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of such reads; calibrated with "
+            "tools/probes/read_bw_probe at 8 and 16 B per lane), raw for every other kernel (uncalibrated access widths).")
     json.dump({"note": note, "kernels": rows + kernels}, open(out_path, "w"), indent=1)
     for r in rows:
         print(r)
