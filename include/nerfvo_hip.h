@@ -75,8 +75,23 @@ uint64_t nvo_n_params(nvo_module_t m);
 int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out);
 /* Bytes of caller-owned device scratch ("ctx") that one fwd/bwd pair of this batch size needs. */
 uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
-/* Integer options: "grid_bwd_mode" 0 = global float atomics, 1 = LDS slice-owner scatter (default),
- * 2 = binned scatter for hashed levels (count / scan / scatter / accumulate; bitwise reproducible). */
+/* Integer options (tuning knobs: none changes results beyond summation order).
+ *   "grid_bwd_mode"   parameter-gradient kernel of a hash-grid encoding:
+ *                       0 = global float atomics, 1 = LDS slice-owner scatter (module default),
+ *                       2 = binned scatter for hashed levels with gathers (count / scan / scatter / accumulate),
+ *                       3 = streamed binned scatter of self-contained 8-byte records, coarse levels slice-owner
+ *                           (what the engine selects for the main field)
+ *   "grid_stream_layout"        (mode 3) 1 = tile-local records, no count / scan passes (default); 0 = globally sorted
+ *   "grid_stream_tile"          (mode 3) samples per scatter workgroup: 256 | 512 (default) | 1024
+ *   "grid_stream_owner_slices"  (mode 3) levels with at most this many 8K-entry slices stay slice-owner (default 12)
+ *   "grid_stream_overlap"       (mode 3) 1 = coarse-level launch on an auxiliary stream beside the record pipeline
+ *   "grid_acc_bits"             accumulators of the slice-owner items: 64 (2^26 fixed point, default) | 32 (int32 with
+ *                               a data-derived overflow-proof scale; needs 16-bit dL/dy)
+ *   "prepare_input_gradients"   the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients); set
+ *                               before the ctx scratch is sized -- it changes nvo_ctx_bytes()
+ *   "bf16"                      16-bit format of everything the network streams: 0 = fp16 (default), 1 = bfloat16
+ *   "compact_output"            (networks with one output) only column 0 exists in memory: [batch] instead of [batch][16]
+ *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones */
 int nvo_set_option(nvo_module_t m, const char* key, int64_t value);
 
 /* input  : device float [batch][n_input_dims]
