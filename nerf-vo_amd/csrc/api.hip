@@ -533,6 +533,12 @@ struct NwieModule : nvo_module_s {
     std::unique_ptr<MlpModule> net;
     int compact_out = 0;  // option "compact_output": output / dL_doutput are [B] halfs (column 0 only)
     int recompute_hidden = 0;  // option "recompute_hidden": the forward does not store the hidden layer
+    // option "fuse_encoding": the forward evaluates the hash grid inside the MLP kernel's operand load
+    // (NVO_IO_GRID_FUSED) -- one launch, no feature round trip between two kernels.  Meant for grids whose tables fit
+    // every XCD's L2 (the proposal networks: 1.5 MB): the stand-alone k_grid_fwd keeps a level's table on ONE XCD,
+    // which a fused kernel cannot.  Bit-identical outputs.
+    int fuse_encoding = 0;
+    NvoGridLevels* d_levels = nullptr;  // device copy of enc->g for the fused kernel
 
     uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
     uint64_t ctx_bytes(uint32_t B) const override {
@@ -553,6 +559,19 @@ struct NwieModule : nvo_module_s {
         void* hidden = c + 2 * enc_bytes(B);
         const _Float16* p = (const _Float16*)params;
         void* dydx = enc->prepare_input_gradients ? c + dydx_offset(B) : nullptr;
+        if (fuse_encoding && !dydx && net->n_hidden == 1 && net->in_pad <= 32 && net->out_pad == 16) {
+            if (!d_levels) {  // (first call = an eager warm-up step, never under graph capture)
+                NVO_CHECK_HIP(hipMalloc((void**)&d_levels, sizeof(NvoGridLevels)));
+                NVO_CHECK_HIP(hipMemcpy(d_levels, &enc->g, sizeof(NvoGridLevels), hipMemcpyHostToDevice));
+            }
+            NvoMlpArgs a = net->make_args(B, in, NVO_IO_GRID_FUSED, enc->n_out, p, out, hidden);
+            a.compact_out = compact_out;
+            if (recompute_hidden) a.hidden = nullptr;
+            a.grid = d_levels;
+            a.grid_table = p + net->n_params;
+            a.enc_out = encoded;  // the backward (and the recomputed hidden layer) read the features from ctx
+            return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
+        }
         int rc = enc->fwd_encode(s, B, in, p + net->n_params, encoded, true, dydx);
         if (rc) return rc;
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
@@ -563,6 +582,7 @@ struct NwieModule : nvo_module_s {
     hipEvent_t ev_fork = nullptr;  // nvo_bwd_fork: network backward done -> the encoding's parameter backward may start
     ~NwieModule() override {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (d_levels) (void)hipFree(d_levels);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
             const void* dout, void* ctx, float* din, float* dparams) override {
@@ -612,6 +632,10 @@ struct NwieModule : nvo_module_s {
         if (!strcmp(key, "bf16")) {  // network in bfloat16, encoding output / gradient in bfloat16, table fp16
             net->bf16 = value != 0;
             return enc->set_option(key, value);
+        }
+        if (!strcmp(key, "fuse_encoding")) {
+            fuse_encoding = value != 0;
+            return NVO_OK;
         }
         if (!strcmp(key, "recompute_hidden")) {
             NVO_REQUIRE(value == 0 || (net->n_hidden == 1 && net->act == NVO_ACT_RELU),

@@ -1462,6 +1462,9 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     std::vector<Item> all(single);
     all.insert(all.end(), chunked.begin(), chunked.end());
     s->n_slices = (uint32_t)all.size();
+    s->lds_bytes = 128 * 1024;
+    for (const Item& it : all)
+        if (it.n_chunks >> 31) s->lds_bytes = kLdsBwdBytes;
     // contiguous run of entries owned by chunked items (needs zeroing before the atomic flush)
     s->zero_first = 0xFFFFFFFFu;
     s->zero_last = 0;
@@ -1877,7 +1880,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                 return rc;
         }
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
-        const size_t lds = kLdsBwdBytes;
+        const size_t lds = slices->lds_bytes;
         if (slices->acc_bits == 32) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
@@ -1899,7 +1902,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         if (!attr_set) {                                                                      \
             NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_bwd_lds<SOA_, T_>,          \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                              (int)lds));                                     \
+                                              (int)kLdsBwdBytes));                            \
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \

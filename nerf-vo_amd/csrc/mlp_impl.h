@@ -219,6 +219,78 @@ __device__ __forceinline__ void load_input(const Args& a, uint32_t row, int g,
     }
 }
 
+// ---- NVO_IO_GRID_FUSED: the hash-grid gather of the two levels a lane feeds into each 16-feature tile --------------
+// (lane group g of K-tile tk holds features 16 tk + 4 g .. + 3 = levels 8 tk + 2 g and 8 tk + 2 g + 1 of sample m.)
+// Split in two so that the gathers of the NEXT tile are in flight while the current tile runs through the MFMA chain:
+// grid_issue computes the corner indices and requests the 8 table entries per level; grid_finish interpolates in fp32
+// in exactly the order of k_grid_fwd (bit-identical features), rounds once to E and optionally stores the pair.
+template <int IN_PAD>
+struct GridGather {
+    uint32_t v[IN_PAD / 16][2][8];  // raw half2 table entries
+    float w[IN_PAD / 16][2][3];     // fractional position per axis
+    uint32_t row;
+};
+template <int IN_PAD>
+__device__ __forceinline__ void grid_issue(const Args& a, uint32_t row, int g, GridGather<IN_PAD>& gg) {
+    const NvoGridLevels& G = *a.grid;
+    const float* __restrict__ xp = (const float*)a.input + 3 * (size_t)row;
+    const float px = xp[0], py = xp[1], pz = xp[2];
+    const uint32_t* __restrict__ table = (const uint32_t*)a.grid_table;
+    gg.row = row;
+#pragma unroll
+    for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t lv = 8 * tk + 2 * g + h;
+            if (lv < G.n_levels) {
+                // tcnn pos_fract: pos = fma(scale, x, 0.5); cell = floor(pos); frac = pos - cell   (= grid.hip grid_cell)
+                const float sc = G.scale[lv];
+                const float fx = fmaf(sc, px, 0.5f), fy = fmaf(sc, py, 0.5f), fz = fmaf(sc, pz, 0.5f);
+                const float tx = floorf(fx), ty = floorf(fy), tz = floorf(fz);
+                const uint32_t cx = (uint32_t)(int)tx, cy = (uint32_t)(int)ty, cz = (uint32_t)(int)tz;
+                gg.w[tk][h][0] = fx - tx;
+                gg.w[tk][h][1] = fy - ty;
+                gg.w[tk][h][2] = fz - tz;
+                const uint32_t off = G.offset[lv], size = G.offset[lv + 1] - off;
+                const uint32_t res = G.resolution[lv], hashed = G.hashed[lv];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k)
+                    gg.v[tk][h][k] = table[off + nvo_grid_index(hashed, size, res, cx + (k & 1u), cy + ((k >> 1) & 1u),
+                                                               cz + ((k >> 2) & 1u))];
+            }
+        }
+    }
+}
+template <int IN_PAD>
+__device__ __forceinline__ void grid_finish(const Args& a, int g, const GridGather<IN_PAD>& gg, T4 (&x)[IN_PAD / 16]) {
+    const uint32_t n_levels = a.grid->n_levels;
+#pragma unroll
+    for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+        T pair[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t lv = 8 * tk + 2 * g + h;
+            pair[h][0] = pair[h][1] = (T)0.f;
+            if (lv < n_levels) {
+                const float wx = gg.w[tk][h][0], wy = gg.w[tk][h][1], wz = gg.w[tk][h][2];
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const float w = ((k & 1u) ? wx : 1.f - wx) * ((k & 2u) ? wy : 1.f - wy) * ((k & 4u) ? wz : 1.f - wz);
+                    const float2 f = nvo_ld16x2(gg.v[tk][h][k], false);  // the tables are fp16 in both modes
+                    r0 = fmaf(w, f.x, r0);
+                    r1 = fmaf(w, f.y, r1);
+                }
+                const uint32_t packed = nvo_cvt16x2(r0, r1, NVO_MLP_BF16 != 0);  // ONE rounding, as k_grid_fwd
+                pair[h][0] = __builtin_bit_cast(T, (nvo_h16)(packed & 0xFFFFu));
+                pair[h][1] = __builtin_bit_cast(T, (nvo_h16)(packed >> 16));
+                if (a.enc_out) reinterpret_cast<uint32_t*>(a.enc_out)[(size_t)lv * a.batch + gg.row] = packed;
+            }
+        }
+        x[tk] = T4{pair[0][0], pair[0][1], pair[1][0], pair[1][1]};
+    }
+}
+
 // sum over the 16 sample lanes (lane & 15) of one lane group
 __device__ __forceinline__ float group16_sum(float v) {
     v += __shfl_xor(v, 1, 64);
@@ -270,11 +342,26 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
         load_input<IN_PAD, IO>(a, row, g, xo, cam);
     };
     T4 x[IN_PAD / 16];
-    if (wave < n_tiles) load_x(wave, x);
+    if constexpr (IO == NVO_IO_GRID_FUSED) {
+        if (wave < n_tiles) {
+            GridGather<IN_PAD> g0;
+            grid_issue<IN_PAD>(a, wave * 16 + m, g, g0);
+            grid_finish<IN_PAD>(a, g, g0, x);
+        }
+    } else {
+        if (wave < n_tiles) load_x(wave, x);
+    }
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
         T4 xn[IN_PAD / 16];
-        load_x(min(tile + n_waves, n_tiles - 1u), xn);
+        GridGather<IO == NVO_IO_GRID_FUSED ? IN_PAD : 16> gn;
+        const bool has_next = tile + n_waves < n_tiles;
+        if constexpr (IO == NVO_IO_GRID_FUSED) {
+            // the next tile's 16 table gathers per lane are in flight while this tile runs through the MFMA chain
+            if (has_next) grid_issue<IN_PAD>(a, (tile + n_waves) * 16 + m, g, gn);
+        } else {
+            load_x(min(tile + n_waves, n_tiles - 1u), xn);
+        }
 
         f4 acc[WIDTH / 16];
         T4 h[WIDTH / 16];
@@ -308,8 +395,12 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
             for (int t = 0; t < OUT_PAD / 16; ++t)
                 *reinterpret_cast<T4*>(op + 16 * t) = pack_act(a.out_act, o[t]);
         }
+        if constexpr (IO == NVO_IO_GRID_FUSED) {
+            if (has_next) grid_finish<IN_PAD>(a, g, gn, x);
+        } else {
 #pragma unroll
-        for (int t = 0; t < IN_PAD / 16; ++t) x[t] = xn[t];
+            for (int t = 0; t < IN_PAD / 16; ++t) x[t] = xn[t];
+        }
     }
 }
 
@@ -727,7 +818,7 @@ int launch_fwd_io(const Args& a, hipStream_t stream, uint32_t max_blocks) {
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
     if (a.compact_out) {
-        if constexpr (IO == NVO_IO_HALF2_SOA && OUT_PAD == 16) {
+        if constexpr ((IO == NVO_IO_HALF2_SOA || IO == NVO_IO_GRID_FUSED) && OUT_PAD == 16) {
             if (a.act == NVO_ACT_RELU) {
                 NVO_LAUNCH((NVO_MLP_NAME(k_mlp_fwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
                 NVO_CHECK_LAUNCH();
@@ -762,6 +853,10 @@ int launch_fwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
         case NVO_IO_NGP_RGB:
             if constexpr (IN_PAD == 32 && WIDTH == 64 && N_HIDDEN == 2 && OUT_PAD == 16)
                 return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_NGP_RGB>(a, stream, max_blocks);
+            break;
+        case NVO_IO_GRID_FUSED:
+            if constexpr (IN_PAD <= 32 && N_HIDDEN == 1 && OUT_PAD == 16)
+                return launch_fwd_io<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, NVO_IO_GRID_FUSED>(a, stream, max_blocks);
             break;
     }
     nvo_set_error("mlp: IO mode %d is not available for shape %d-%dx%d-%d", a.in_mode, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);

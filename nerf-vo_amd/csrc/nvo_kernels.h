@@ -18,6 +18,9 @@ struct NvoGridSlices {
     uint32_t zero_first = 0, zero_last = 0;  // entry range flushed with atomics (zeroed per launch)
     uint32_t acc_bits = 64;                  // 32: int32 accumulators with the L1-derived scale (set before create)
     unsigned long long* d_l1 = nullptr;      // [levels][2] L1 norms of dy (inside the d_level allocation)
+    // dynamic LDS the launch asks for: 160 KiB only when an item accumulates in fp32 (20K-entry slices), else 128 KiB
+    // -- which leaves 32 KiB of a CU's LDS to a concurrently running kernel (the record scatter of mode 3)
+    uint32_t lds_bytes = 160 * 1024;
 };
 // level_mask: bit l set -> level l gets slice-owner work items (default: all levels); target_items: the
 // chunk counts are scaled until the launch has about this many work items
@@ -120,6 +123,9 @@ enum {
     NVO_IO_HALF_ROWS = 2,       // [B][IN_PAD] half
     NVO_IO_NERFACTO_COLOR = 3,  // 64-wide row assembled on the fly: [SH16(ray) | geo15 | embed32(cam) | 1]
     NVO_IO_NGP_RGB = 4,         // 32-wide row: [density-net output 16 | SH16(ray of the packed sample)]
+    NVO_IO_GRID_FUSED = 5,      // (forward only) the hash-grid encoding is evaluated inside the operand load: positions
+                                // in, LDS-free register chain out; the encoded features never make the round trip
+                                // through HBM between two kernels (they are still stored once when a backward follows)
 };
 
 // E: the 16-bit element type of everything the network streams (_Float16 | __bf16).  The layout does not depend
@@ -155,6 +161,10 @@ struct NvoMlpArgsT {
     // NVO_IO_NGP_RGB only (instant-ngp rgb head on packed samples)
     const int32_t* sample_ray;    // [B] ray index of each packed sample (< 0: empty slot)
     const float* d_extra_col0;    // [B] added to column 0 of d_base_out (dL/d density pre-activation)
+    // NVO_IO_GRID_FUSED only: input = positions [B][3] float
+    const NvoGridLevels* grid;    // DEVICE copy of the level table
+    const void* grid_table;       // fp16 [entries][2]
+    void* enc_out;                // [L][B] pairs of E (what a separate encoding kernel would have written), nullable
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

@@ -109,6 +109,13 @@ class EngineConfig:
     # graph-replayed step: pixel sampling, ray generation, target gather, SH and the first sampler level in ONE launch
     # (nvo_ray_head) instead of five 4096-ray kernels of ~6 us dispatch + drain each; bit-identical
     fused_ray_head: bool = True
+    # proposal networks: evaluate the hash grid inside the MLP kernel's operand load (module option fuse_encoding:
+    # one launch per level instead of two, no feature round trip between them; bit-identical).  MEASURED SLOWER and
+    # therefore off: 51.5 us per launch against 35 + 8.2 us for the two kernels (0.760 vs 0.740 ms per step) -- a lane
+    # group of the MFMA operand layout owns two levels, so with 5 levels the groups gather 2 / 2 / 1 / 0 levels, and
+    # the stand-alone gather has a thread per (sample, level).  (Never for the main field: its 16 level tables, 24 MiB,
+    # only stay L2-resident because k_grid_fwd pins each level to one XCD.)
+    fuse_proposal_encoding: bool = False
     # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
     # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
@@ -166,6 +173,7 @@ class NerfactoEngine:
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
         for m in self.prop_nets:
             m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
+            m.set_option("fuse_encoding", int(cfg.fuse_proposal_encoding))
         store = cfg.store_input_gradients
         if store is None:
             store = bool(cfg.optimize_poses or cfg.expect_normals)

@@ -431,3 +431,45 @@ def test_network_with_input_encoding(device, cfg, width, dtype):
     _assert_close(model.params.grad[n_net:], pr.grad[n_net:], rtol=2e-2 * k, atol_scale=2e-3 * k, what="NWIE dgrid",
                   max_outlier_frac=1e-5 * k)
     _assert_close(x.grad, xr.grad, rtol=3e-2 * k, atol_scale=1e-2 * k, what="NWIE dL/dx")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg,width,compact", [(MAIN, 64, False), (PROP0, 16, True), (PROP1, 16, False)],
+                         ids=["main-64", "prop0-16-compact", "prop1-16"])
+def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dtype):
+    """option fuse_encoding: the hash grid evaluated inside the MLP kernel's operand load (NVO_IO_GRID_FUSED) must give
+    the SAME bits as the two-kernel form -- output, the encoded features it leaves in ctx for the backward, and hence
+    every gradient."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    n_out = 16 if width == 64 else 1
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width,
+               "n_hidden_layers": 1}
+    g = torch.Generator().manual_seed(21)
+    n = 16 * 301  # several tiles per wave and a ragged last wave
+    x = torch.from_numpy(_points(n, 4)).to(device)
+    x[0] = 0.0
+    x[1] = 1.0  # both domain faces (dense-index wrap)
+    dy = torch.randn(n, n_out, generator=g).to(device)
+    res = []
+    params = None
+    for fused in (0, 1):
+        model = tcnn.NetworkWithInputEncoding(3, n_out, _enc_cfg(cfg), net_cfg, dtype=tdt).to(device)
+        if params is None:
+            params = torch.cat([torch.randn(model.params.numel(), generator=g) * 0.3]).to(device)
+        with torch.no_grad():
+            model.params.copy_(params)
+        model.native_tcnn_module.set_option("fuse_encoding", fused)
+        if compact:
+            model.native_tcnn_module.set_option("recompute_hidden", 1)
+        xx = x.clone().requires_grad_(True)
+        y = model(xx)
+        (y.float() * dy).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), model.params.grad.clone(), xx.grad.clone()))
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16)), "fused forward output differs"
+    assert torch.equal(res[0][2], res[1][2]), "dL/dx differs (the encoded features left in ctx differ)"
+    # the weight gradient is flushed with float atomics (order-dependent in the last bits); the grid gradient of the
+    # default slice-owner scatter is deterministic for single-chunk slices -- both must agree to rounding
+    _assert_close(res[1][1], res[0][1], rtol=1e-4, atol_scale=1e-6, what="dL/dparams, fused vs two-kernel forward")
