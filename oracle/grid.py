@@ -119,7 +119,8 @@ def grid_indices_numpy(spec: GridSpec, x: np.ndarray) -> np.ndarray:
                 if hashed:
                     idx = (p[0] * PRIMES[0]) ^ (p[1] * PRIMES[1]) ^ (p[2] * PRIMES[2])
                 else:
-                    idx = p[0] + p[1] * np.uint32(res) + p[2] * np.uint32(res * res)
+                    # (uint32 stride arithmetic like tcnn's grid_index: res * res wraps for res >= 65536)
+                    idx = p[0] + p[1] * np.uint32(res & 0xFFFFFFFF) + p[2] * np.uint32((res * res) & 0xFFFFFFFF)
                 out[l, :, k] = idx % np.uint32(size)
     return out
 
