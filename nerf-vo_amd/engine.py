@@ -774,6 +774,15 @@ class NerfactoEngine:
         if entry is None:
             entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None, has_normals)
             self._graphs[key] = entry
+            # Capture the sibling variant (with / without the proposal-network update) right away: the first ten steps
+            # all refresh the proposal networks, so the other graph would otherwise be captured -- two eager warm-up
+            # steps + the capture, a few ms -- in the middle of training (step 10), e.g. inside a timed window.
+            sib = (R, not updated, has_depth, all_reduce is not None, has_normals)
+            if sib not in self._graphs:
+                sib_groups = ["fields"] + ([] if updated else ["proposal_networks"]) + (
+                    ["camera_opt"] if cfg.optimize_poses else [])
+                self._graphs[sib] = self._capture_step(dataset, R, not updated, has_depth, sib_groups,
+                                                       all_reduce is not None, has_normals)
         if all_reduce is None:
             self._write_sampling_scalars(step)
             self._write_step_scalars(self.anneal_at(step), groups)
