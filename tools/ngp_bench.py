@@ -77,6 +77,27 @@ def main():
     n = eng.samples_last_step()
     print(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
           f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
+    if a.profile:
+        # one JSON line in the shape of bench.py's (occupancy-grid back-end; SURVEY.md section 8d bytes: 588 B per
+        # packed sample for the gather, 1100 B for the scatter)
+        import json
+
+        per = {name: total / cnt * 1e-3 for name, cnt, total in rows}  # seconds per launch
+        cap = eng.cfg.capacity
+        roof = None
+        for name, bytes_per_sample in (("grid_bwd_stream[L16]", 1100), ("grid_fwd[L16]", 588)):
+            if name in per:
+                b = cap * bytes_per_sample
+                roof = roof or {"kernel": name, "bound": "hbm", "achieved": round(b / per[name] / 1e9, 1), "peak": 8000.0,
+                                "unit": "GB/s", "frac": round(b / per[name] / 1e9 / 8000.0, 4), "traffic": None,
+                                "avg_launch_us": round(per[name] * 1e6, 1), "algorithmic_bytes_per_launch": b}
+        print(json.dumps({"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
+                          "unit": "samples/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "rays_per_batch": eng.rays_per_batch,
+                          "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H}, aabb_scale 4, "
+                                                 f"capacity {cap} packed samples, extrinsics optimisation "
+                                                 f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch"},
+                          "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof}))
 
 
 if __name__ == "__main__":
