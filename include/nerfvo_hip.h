@@ -91,8 +91,15 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *                               before the ctx scratch is sized -- it changes nvo_ctx_bytes()
  *   "bf16"                      16-bit format of everything the network streams: 0 = fp16 (default), 1 = bfloat16
  *   "compact_output"            (networks with one output) only column 0 exists in memory: [batch] instead of [batch][16]
- *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones */
+ *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones
+ *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
+ *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
+ *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges
+ *                               lists -- with nvo_zero_ranges, ONE launch for all networks of a training step */
 int nvo_set_option(nvo_module_t m, const char* key, int64_t value);
+/* The device ranges nvo_bwd(m, ..., dL_dparams) clears before accumulating (see option "external_zero").  Returns
+ * the number of ranges written to ptrs_out / bytes_out (<= capacity), or a negative error code. */
+int nvo_bwd_zero_ranges(nvo_module_t m, float* dL_dparams, void** ptrs_out, uint64_t* bytes_out, uint32_t capacity);
 
 /* input  : device float [batch][n_input_dims]
  * params : device fp16 [n_params]   (NetworkWithInputEncoding: network weights first, then grid)
@@ -492,6 +499,8 @@ int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, in
  * Everywhere a `grads_are_half` argument appears, 0 = fp32, 1 = fp16, 2 = bfloat16. */
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
+/* Clears up to 24 device ranges (host arrays of pointers / byte counts, 4-byte granular) with one launch. */
+int nvo_zero_ranges(nvo_stream_t stream, uint32_t n_ranges, void* const* ptrs, const uint64_t* bytes);
 /* Exponential moving average of the weights, the "Ema" optimiser wrapper of instant-ngp's configs/nerf/base.json
  * (decay 0.95) that pyngp.Testbed trains with (/root/reference/nerf_vo/mapping/instant_ngp.py:45 loads that file):
  * ema = (ema * decay * (1 - decay^(step-1)) + params * (1 - decay)) / (1 - decay^step), step counting from 1; the

@@ -165,6 +165,8 @@ _SIGNATURES = {
     "nvo_adam_step_groups": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p]),
     "nvo_nonfinite_flag_ranges": (_int, [_p, _u32, _p, _p, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
+    "nvo_zero_ranges": (_int, [_p, _u32, _p, _p]),
+    "nvo_bwd_zero_ranges": (_int, [_p, _p, _p, _p, _u32]),
     "nvo_ema_update": (_int, [_p, _u64, _p, _p, _p, _f, _u32, _p]),
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),

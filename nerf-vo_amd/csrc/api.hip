@@ -265,6 +265,12 @@ struct nvo_module_s {
         nvo_set_error("unknown option '%s'", key);
         return NVO_ERR_INVALID;
     }
+    // device ranges bwd() clears before it accumulates into them, for a given dL_dparams (nvo_bwd_zero_ranges); with
+    // option "external_zero" the caller clears them instead (one launch for all networks of a training step)
+    virtual int zero_ranges(float* /*dparams*/, NvoZeroRanges* /*out*/) {
+        nvo_set_error("this module's backward has no externalisable zeroing");
+        return NVO_ERR_UNSUPPORTED;
+    }
 };
 
 namespace {
@@ -287,6 +293,30 @@ struct GridModule : nvo_module_s {
         nvo_grid_bins_destroy(&bins);
         nvo_grid_stream_destroy(&stream_bins);
         if (input_scratch.ptr) (void)hipFree(input_scratch.ptr);
+    }
+    bool external_zero = false;
+    int grid_zero_ranges(float* dparams, NvoZeroRanges* out) {
+        int rc = ensure_slices();
+        if (rc) return rc;
+        if (bwd_mode == 1) {
+            nvo_grid_slices_zero_ranges(g, &slices, dparams, out);
+            return NVO_OK;
+        }
+        if (bwd_mode == 3 && nvo_grid_stream_zero_ranges(g, &stream_bins, dparams, out)) return NVO_OK;
+        nvo_set_error("grid_bwd_mode %d (this layout) zeroes data-dependent ranges: external_zero is unavailable", bwd_mode);
+        return NVO_ERR_UNSUPPORTED;
+    }
+    int zero_ranges(float* dparams, NvoZeroRanges* out) override { return grid_zero_ranges(dparams, out); }
+    int set_external_zero(bool on) {
+        if (on) {  // only where grid_zero_ranges can describe the zeroing
+            NvoZeroRanges probe;
+            if (int rc = grid_zero_ranges(nullptr, &probe)) return rc;
+        }
+        external_zero = on;
+        slices.external_zero = on;
+        stream_bins.external_zero = on;
+        stream_bins.owner.external_zero = on;
+        return NVO_OK;
     }
     int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
         int rc = ensure_slices();
@@ -375,6 +405,7 @@ struct GridModule : nvo_module_s {
     }
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        if (!strcmp(key, "external_zero")) return set_external_zero(value != 0);
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "prepare_input_gradients")) {  // changes ctx_bytes(): set before the ctx scratch is sized
             prepare_input_gradients = value != 0;
@@ -447,6 +478,7 @@ struct MlpModule : nvo_module_s {
     int bf16 = 0;
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        if (!strcmp(key, "external_zero")) { external_zero = value != 0; return NVO_OK; }
         return nvo_module_s::set_option(key, value);
     }
 
@@ -520,9 +552,14 @@ struct MlpModule : nvo_module_s {
         a.dinput = din;
         a.din_mode = NVO_IO_F32_ROWS;
         a.dweights = dparams;
-        if (dparams)
+        if (dparams && !external_zero)
             if (int rc = nvo_zero_async(dparams, sizeof(float) * n_params, s)) return rc;
         return nvo_mlp_bwd_launch(in_pad, width, n_hidden, out_pad, a, s);
+    }
+    bool external_zero = false;
+    int zero_ranges(float* dparams, NvoZeroRanges* out) override {
+        out->push_back({dparams, sizeof(float) * n_params});
+        return NVO_OK;
     }
 };
 
@@ -579,6 +616,10 @@ struct NwieModule : nvo_module_s {
         if (recompute_hidden) a.hidden = nullptr;
         return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
     }
+    int zero_ranges(float* dparams, NvoZeroRanges* out) override {
+        if (int rc = net->zero_ranges(dparams, out)) return rc;
+        return enc->grid_zero_ranges(dparams ? dparams + net->n_params : nullptr, out);
+    }
     hipEvent_t ev_fork = nullptr;  // nvo_bwd_fork: network backward done -> the encoding's parameter backward may start
     ~NwieModule() override {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -604,7 +645,7 @@ struct NwieModule : nvo_module_s {
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
-        if (dparams)
+        if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
@@ -635,6 +676,11 @@ struct NwieModule : nvo_module_s {
         }
         if (!strcmp(key, "fuse_encoding")) {
             fuse_encoding = value != 0;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "external_zero")) {
+            if (int rc = enc->set_external_zero(value != 0)) return rc;
+            net->external_zero = value != 0;
             return NVO_OK;
         }
         if (!strcmp(key, "recompute_hidden")) {
@@ -740,6 +786,21 @@ int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out) {
 int nvo_set_option(nvo_module_t m, const char* key, int64_t value) {
     NVO_REQUIRE(m && key, "set_option: NULL argument");
     return m->set_option(key, value);
+}
+
+int nvo_bwd_zero_ranges(nvo_module_t m, float* dL_dparams, void** ptrs_out, uint64_t* bytes_out, uint32_t capacity) {
+    NVO_REQUIRE(m && dL_dparams && ptrs_out && bytes_out, "bwd_zero_ranges: NULL argument");
+    NvoZeroRanges r;
+    if (int rc = m->zero_ranges(dL_dparams, &r)) return rc < 0 ? rc : -rc;
+    if (r.size() > capacity) {
+        nvo_set_error("bwd_zero_ranges: %zu ranges, capacity %u", r.size(), capacity);
+        return NVO_ERR_INVALID < 0 ? NVO_ERR_INVALID : -NVO_ERR_INVALID;
+    }
+    for (size_t i = 0; i < r.size(); ++i) {
+        ptrs_out[i] = r[i].first;
+        bytes_out[i] = r[i].second;
+    }
+    return (int)r.size();
 }
 
 int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,

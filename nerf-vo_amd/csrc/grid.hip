@@ -1492,6 +1492,23 @@ void nvo_grid_slices_destroy(NvoGridSlices* s) {
     s->n_slices = 0;
 }
 
+void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s, float* grad, NvoZeroRanges* out) {
+    if (s->zero_last > s->zero_first)
+        out->push_back({grad + 2 * (size_t)s->zero_first, sizeof(float) * 2 * (size_t)(s->zero_last - s->zero_first)});
+    if (s->acc_bits == 32 && s->d_l1) out->push_back({s->d_l1, sizeof(unsigned long long) * 2 * g.n_levels});
+}
+
+bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out) {
+    if (!st->tile_local) return false;  // the sorted layout decides per launch which bins are chunked
+    nvo_grid_slices_zero_ranges(g, &st->owner, grad, out);
+    // streamed DENSE levels: their bins are split into tile ranges that combine with float atomics (k_st_zero)
+    if (st->dense_chunks > 1)
+        for (uint32_t l = 0; l < g.n_levels; ++l)
+            if (((st->streamed_mask >> l) & 1u) && !g.hashed[l])
+                out->push_back({grad + 2 * (size_t)g.offset[l], sizeof(float) * 2 * (size_t)(g.offset[l + 1] - g.offset[l])});
+    return true;
+}
+
 int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b) {
     std::vector<uint32_t> levels, first, bin_level, bin_slice;
     b->binned_mask = 0;
@@ -1768,8 +1785,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         }                                                                                                    \
         {                                                                                                    \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                          \
-            NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
-                       st->d_bin_chunks, grad);                                                              \
+            if (!st->external_zero)                                                                          \
+                NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
+                           st->d_bin_chunks, grad);                                                          \
             NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < n_cus ? st->n_tl_items : n_cus), dim3(kTlBlock), \
                        lds_acc_tl, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, records_tl, \
                        n_tiles, (uint32_t)tile_records, grad);                                               \
@@ -1873,7 +1891,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
     }
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
     if (mode == 1 && slices && slices->n_slices) {
-        if (slices->zero_last > slices->zero_first) {
+        if (slices->zero_last > slices->zero_first && !slices->external_zero) {
             // chunked (atomically flushed) levels form one contiguous run of entries
             if (int rc = nvo_zero_async(grad + 2 * (size_t)slices->zero_first,
                                         sizeof(float) * 2 * (size_t)(slices->zero_last - slices->zero_first), stream))
@@ -1883,7 +1901,8 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         const size_t lds = slices->lds_bytes;
         if (slices->acc_bits == 32) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
-            if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
+            if (!slices->external_zero)
+                if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
             uint32_t bx = nvo_div_up(N, 256 * 8);
             if (bx > 256) bx = 256;
             if (bx < 1) bx = 1;

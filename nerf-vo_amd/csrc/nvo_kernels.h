@@ -21,7 +21,14 @@ struct NvoGridSlices {
     // dynamic LDS the launch asks for: 160 KiB only when an item accumulates in fp32 (20K-entry slices), else 128 KiB
     // -- which leaves 32 KiB of a CU's LDS to a concurrently running kernel (the record scatter of mode 3)
     uint32_t lds_bytes = 160 * 1024;
+    // The caller zeroes what the launch would zero (nvo_bwd_zero_ranges / option external_zero): a training step then
+    // clears every accumulate-into buffer of all its networks with ONE launch instead of ~6 dependent 5-us launches.
+    bool external_zero = false;
 };
+#include <utility>
+#include <vector>
+typedef std::vector<std::pair<void*, size_t>> NvoZeroRanges;
+void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s, float* grad, NvoZeroRanges* out);
 // level_mask: bit l set -> level l gets slice-owner work items (default: all levels); target_items: the
 // chunk counts are scaled until the launch has about this many work items
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu,
@@ -83,7 +90,10 @@ struct NvoGridStream {
     uint32_t n_tl_items = 0;
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool external_zero = false;  // (tile-local layout only) see NvoGridSlices::external_zero
 };
+// false: this configuration zeroes data-dependent ranges (globally sorted layout) and cannot hand the zeroing over
+bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out);
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);
 void nvo_grid_stream_destroy(NvoGridStream* st);
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,

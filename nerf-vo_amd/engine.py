@@ -178,6 +178,7 @@ class NerfactoEngine:
         if store is None:
             store = bool(cfg.optimize_poses or cfg.expect_normals)
         self.base_net.set_option("prepare_input_gradients", int(bool(store)))
+        self._zero_plan = None  # built lazily (needs the flat gradient buffer): _step_zero_ranges()
         color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
         assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
         self.n_color = 64 * 64 + 64 * 64 + 16 * 64
@@ -227,8 +228,10 @@ class NerfactoEngine:
         self.exp_avg_sq = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)  # sharded accumulators
         self.skip_flag = torch.zeros(4, dtype=torch.int32, device=dev)  # one word per parameter group of the step
-        self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)  # [anneal | (lr, bias1, bias2_sqrt) x 3]
-        self.dev_sampling = torch.zeros(4, dtype=torch.float32, device=dev)  # [anneal, sampler step counter]
+        # [anneal | (lr, bias1, bias2_sqrt) x 3 | ... | anneal, sampler step counter]: the sampling scalars are the last
+        # two slots of the same buffer, so a single-GPU step refreshes everything with ONE tiny launch
+        self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.dev_sampling = self.dev_scalars[14:16]
         self._pending_head = None  # multi-GPU: stamp of the sampling prefix already launched for the next step
         self._graphs = {}
         self._side_stream = None
@@ -557,10 +560,8 @@ class NerfactoEngine:
         # gradient range is overwritten by its producer (grid slices by plain stores, MLP dW zeroed by nvo_bwd,
         # pose gradient by the exp-map backward).  Ranges of groups that do not train this step keep stale values
         # and are neither reduced, checked nor applied.
-        for name in ("field.color", "field.embedding"):
-            o, sz, _ = self.segments[name]
-            self.grads[o:o + sz].zero_()
-        self.losses.zero_()
+        pose_active = cfg.optimize_poses and "d_sh" in ws and self._pose_inputs is not None
+        self._zero_step_buffers(ws, bool(update_proposals), bool(pose_active), stream)
         emb_ptr = self._param_ptr("field.embedding", self.params_half).value
         ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev,
                            skip_head=skip_head)
@@ -587,8 +588,6 @@ class NerfactoEngine:
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     self._proposal_backward(ws, has_depth, pose, _stream(self.device))
-        if pose:
-            ws["d_sh"].zero_()
         _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
         scatter_stream = None
         if pose and cfg.overlap_pose_backward:
@@ -616,6 +615,46 @@ class NerfactoEngine:
         if scatter_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(scatter_stream)  # join
         return update_proposals
+
+    def _net_zero_ranges(self, net, seg: str):
+        """What nvo_bwd of ``net`` clears before it accumulates (MLP weight gradient, atomically flushed grid ranges,
+        scale scratch), handed over to the step's single zero launch: module option external_zero."""
+        cap = 16
+        ptrs = (C.c_void_p * cap)()
+        sizes = (C.c_uint64 * cap)()
+        n = _lib.lib().nvo_bwd_zero_ranges(net.handle, self._param_ptr(seg, self.grads), ptrs, sizes, cap)
+        if n < 0:
+            raise RuntimeError(f"nvo_bwd_zero_ranges({seg}): {_lib.lib().nvo_last_error().decode()}")
+        net.set_option("external_zero", 1)
+        return [(int(ptrs[i]), int(sizes[i])) for i in range(n)]
+
+    def _zero_step_buffers(self, ws, update_proposals: bool, pose: bool, stream) -> None:
+        """Everything a step ACCUMULATES into is cleared by ONE launch at its start (colour-head dW, appearance-embedding
+        gradient, loss shards, the MLP weight gradients and atomically flushed grid ranges of the networks that run
+        backward, the pose-chain reductions).  It used to be ~9 launches (three torch fills + the zeroing inside every
+        nvo_bwd), each ~5 us of dependent dispatch + drain in the replayed graph: 30-40 us per step.  Every other
+        gradient range is overwritten by its producer; ranges of groups that do not train this step keep stale values
+        and are neither reduced, checked nor applied."""
+        if self._zero_plan is None:
+            plan = {"always": [], "proposals": [], "pose": {}}
+            for name in ("field.color", "field.embedding"):
+                o, sz, _ = self.segments[name]
+                plan["always"].append((self.grads.data_ptr() + 4 * o, 4 * sz))
+            plan["always"].append((self.losses.data_ptr(), self.losses.numel() * 4))
+            plan["always"] += self._net_zero_ranges(self.base_net, "field.base")
+            for k, net in enumerate(self.prop_nets):
+                plan["proposals"] += self._net_zero_ranges(net, f"proposal.{k}")
+            self._zero_plan = plan
+        ranges = list(self._zero_plan["always"])
+        if update_proposals:
+            ranges += self._zero_plan["proposals"]
+        if pose:
+            for name in ("d_sh", "d_origin", "d_dir"):
+                ranges.append((ws[name].data_ptr(), ws[name].numel() * 4))
+            ranges.append((self.d_corrections.data_ptr(), self.d_corrections.numel() * 4))
+        ptrs = (C.c_void_p * len(ranges))(*[p for p, _ in ranges])
+        sizes = (C.c_uint64 * len(ranges))(*[b for _, b in ranges])
+        _call("nvo_zero_ranges", stream, len(ranges), ptrs, sizes)
 
     def _proposal_backward(self, ws, has_depth: bool, pose: bool, stream, levels=None) -> None:
         """Interlevel + depth loss of both proposal levels and their network backward."""
@@ -648,14 +687,11 @@ class NerfactoEngine:
         cfg = self.cfg
         R = ws["R"]
         km = len(self.prop_nets)
-        ws["d_origin"].zero_()
-        ws["d_dir"].zero_()
         levels = ([0, 1] if update_proposals else []) + [km]
         for k in levels:
             _call("nvo_positions_bwd", stream, R, self.levels[k], _ptr(ws["origins"]), _ptr(ws["directions"]),
                   _ptr(ws[f"tbins{k}"]), _ptr(ws[f"dx{k}"]), _ptr(ws["d_origin"]), _ptr(ws["d_dir"]))
         _call("nvo_sh_bwd_input_f32", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["d_sh"]), _ptr(ws["d_dirs01"]))
-        self.d_corrections.zero_()
         intr, c2w = self._pose_inputs
         _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
               _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
@@ -720,7 +756,7 @@ class NerfactoEngine:
         arr = (C.c_float * 2)(self.anneal_at(step), float(step))
         _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_sampling), 2, arr)
 
-    def _write_step_scalars(self, anneal: float, groups) -> None:
+    def _write_step_scalars(self, anneal: float, groups, sampling_step: int | None = None) -> None:
         """Adam lr / bias corrections of this step -> device memory (read by the captured optimiser); advances the
         step counters of ``groups``.  (Slot 0 mirrors the anneal for inspection; the kernels read dev_sampling.)"""
         cfg = self.cfg
@@ -733,8 +769,13 @@ class NerfactoEngine:
             vals[1 + 3 * gi] = self._group_lr(g)
             vals[2 + 3 * gi] = 1.0 - cfg.adam_betas[0] ** t
             vals[3 + 3 * gi] = math.sqrt(1.0 - cfg.adam_betas[1] ** t)
-        arr = (C.c_float * 16)(*vals)
-        _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 16, arr)
+        if sampling_step is not None:  # (single GPU: the sampling scalars ride in the same launch)
+            vals[14], vals[15] = self.anneal_at(sampling_step), float(sampling_step)
+            arr = (C.c_float * 16)(*vals)
+            _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 16, arr)
+        else:  # (multi GPU: slots 14-15 belong to the sampling prefix that may already run ahead)
+            arr = (C.c_float * 14)(*vals[:14])
+            _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 14, arr)
 
     def train_step_graphed(self, dataset, all_reduce=None):
         """One full iteration replayed from captured hipGraphs (torch.cuda.CUDAGraph).
@@ -784,8 +825,7 @@ class NerfactoEngine:
                 self._graphs[sib] = self._capture_step(dataset, R, not updated, has_depth, sib_groups,
                                                        all_reduce is not None, has_normals)
         if all_reduce is None:
-            self._write_sampling_scalars(step)
-            self._write_step_scalars(self.anneal_at(step), groups)
+            self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
             entry["main"].replay()
         else:
             stamp = (step, key, getattr(dataset, "version", 0), extent)
