@@ -484,6 +484,10 @@ int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_
  * launch: flags[i] (device uint32 [n_ranges], reset first) is raised iff range i holds an inf / NaN. */
 int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
                               const void* grads, int grads_are_half, uint32_t* flags);
+/* The same without resetting the flag words first (they were cleared earlier, e.g. by the step's nvo_zero_ranges):
+ * one launch less in front of the optimiser. */
+int nvo_nonfinite_flag_ranges_or(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                              const void* grads, int grads_are_half, uint32_t* flags);
 /* grads: device float[n], or device fp16[n] when grads_are_half != 0 (the buffer a compressed
  * all-reduce leaves behind: no cast-back pass). */
 /* hyper_dev (nullable): device float[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} overriding the

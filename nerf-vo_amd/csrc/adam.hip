@@ -428,14 +428,28 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
     return NVO_OK;
 }
 
+static int nonfinite_ranges_launch(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                                   const void* grads, int grads_are_half, uint32_t* flags, bool reset);
+
 int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
                               const void* grads, int grads_are_half, uint32_t* flags) {
+    return nonfinite_ranges_launch(stream, n_ranges, offsets, sizes, grads, grads_are_half, flags, true);
+}
+
+int nvo_nonfinite_flag_ranges_or(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                                 const void* grads, int grads_are_half, uint32_t* flags) {
+    return nonfinite_ranges_launch(stream, n_ranges, offsets, sizes, grads, grads_are_half, flags, false);
+}
+
+static int nonfinite_ranges_launch(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
+                                   const void* grads, int grads_are_half, uint32_t* flags, bool reset) {
     uint32_t* flag = flags;
     NVO_REQUIRE(grads && flag && offsets && sizes, "nonfinite_flag_ranges: NULL argument");
     NVO_REQUIRE(n_ranges >= 1 && n_ranges <= kAdamMaxGroups, "nonfinite_flag_ranges: 1..%u ranges (got %u)",
                 kAdamMaxGroups, n_ranges);
     NVO_PROF(stream, "nonfinite_flag");
-    if (int rc = nvo_zero_async(flag, sizeof(uint32_t) * n_ranges, (hipStream_t)stream)) return rc;
+    if (reset)
+        if (int rc = nvo_zero_async(flag, sizeof(uint32_t) * n_ranges, (hipStream_t)stream)) return rc;
     FlagRanges r{};
     uint32_t k = 0, blocks_total = 0;
     for (uint32_t i = 0; i < n_ranges; ++i) {

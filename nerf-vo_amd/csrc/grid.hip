@@ -449,10 +449,32 @@ k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long l
     __shared__ float red[2][4];
     const uint32_t level = blockIdx.y;
     float a = 0.f, b = 0.f;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const float2 d = dy2f(SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level]);
-        a += fabsf(d.x);
-        b += fabsf(d.y);
+    if (SOA && (N & 3u) == 0u && (((uintptr_t)dy) & 15u) == 0u) {
+        // level-major layout: a level's pairs are one contiguous stream -- 16-byte loads (4 samples), two in flight
+        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(dy + (size_t)level * N);
+        const uint32_t n4 = N >> 2, stride = gridDim.x * 256;
+        auto acc4 = [&](uint4 q) {
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float2 d = dy2f(__builtin_bit_cast(DY2, w[k]));
+                a += fabsf(d.x);
+                b += fabsf(d.y);
+            }
+        };
+        uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {
+            const uint4 q0 = p[i], q1 = p[i + stride];
+            acc4(q0);
+            acc4(q1);
+        }
+        if (i < n4) acc4(p[i]);
+    } else {
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+            const float2 d = dy2f(SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level]);
+            a += fabsf(d.x);
+            b += fabsf(d.y);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1903,7 +1925,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (!slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
-            uint32_t bx = nvo_div_up(N, 256 * 8);
+            uint32_t bx = nvo_div_up(N, 256 * 16);
             if (bx > 256) bx = 256;
             if (bx < 1) bx = 1;
 #define NVO_LAUNCH_L1(SOA_, T_) \

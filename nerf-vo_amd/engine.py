@@ -641,6 +641,7 @@ class NerfactoEngine:
                 o, sz, _ = self.segments[name]
                 plan["always"].append((self.grads.data_ptr() + 4 * o, 4 * sz))
             plan["always"].append((self.losses.data_ptr(), self.losses.numel() * 4))
+            plan["always"].append((self.skip_flag.data_ptr(), self.skip_flag.numel() * 4))
             plan["always"] += self._net_zero_ranges(self.base_net, "field.base")
             for k, net in enumerate(self.prop_nets):
                 plan["proposals"] += self._net_zero_ranges(net, f"proposal.{k}")
@@ -714,7 +715,7 @@ class NerfactoEngine:
                 "camera_opt": self.camera_lr(self.step)}[g]
 
     def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False,
-                       grads_half: torch.Tensor | None = None) -> None:
+                       grads_half: torch.Tensor | None = None, flags_cleared: bool = False) -> None:
         """Non-finite check + fused Adam, per group (one launch each for all groups).  ``from_device_scalars``: lr and bias corrections
         are read from self.dev_scalars (filled by _write_step_scalars) instead of kernel arguments, and
         the per-group step counters are NOT advanced here -- the form a captured graph replays."""
@@ -728,7 +729,9 @@ class NerfactoEngine:
         active = [g for g in groups if g != "camera_opt" or cfg.optimize_poses]
         offs = (C.c_uint64 * len(active))(*[self.group_ranges[g][0] for g in active])
         sizes = (C.c_uint64 * len(active))(*[self.group_ranges[g][1] - self.group_ranges[g][0] for g in active])
-        _call("nvo_nonfinite_flag_ranges", stream, len(active), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        # (flags_cleared: the step's single zero launch already cleared the flag words -- one launch less)
+        _call("nvo_nonfinite_flag_ranges_or" if flags_cleared else "nvo_nonfinite_flag_ranges", stream, len(active), offs,
+              sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
         batch = []
         for g in groups:
             if g == "camera_opt" and not cfg.optimize_poses:
@@ -945,7 +948,9 @@ class NerfactoEngine:
         groups_b = ["fields"] if split else list(groups)
 
         def body_opt(gs):
-            self.optimizer_step(gs, from_device_scalars=True, grads_half=half)
+            # single graph: ONE optimiser call per step, and the flag words were cleared by the step's zero launch
+            # (split graphs run two optimiser calls that share flag slot 0: they reset their own)
+            self.optimizer_step(gs, from_device_scalars=True, grads_half=half, flags_cleared=not split)
 
         # warm-up on a side stream (allocations, lazy module state), then capture
         side = torch.cuda.Stream(device=dev)
