@@ -406,6 +406,10 @@ struct GridModule : nvo_module_s {
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
         if (!strcmp(key, "external_zero")) return set_external_zero(value != 0);
+        if (!strcmp(key, "grid_compact_live")) {  // slice-owner items scan only the samples with a non-zero gradient
+            slices.compact_live = value != 0;
+            return NVO_OK;
+        }
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "prepare_input_gradients")) {  // changes ctx_bytes(): set before the ctx scratch is sized
             prepare_input_gradients = value != 0;

@@ -326,7 +326,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               const float* __restrict__ x, const DY2* __restrict__ dy,
                                               float* __restrict__ grad, uint32_t level, uint32_t first,
                                               uint32_t chunk, uint32_t n_chunks, void* lds_raw,
-                                              const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f}) {
+                                              const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
+                                              const uint32_t* __restrict__ live = nullptr) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -334,13 +335,27 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     const uint32_t hashed = g.hashed[level];
     const float scale = g.scale[level];
     const uint32_t count = min(ACC::kEntries, size - first);
+    // live != nullptr: live[0] = number of samples with a non-zero gradient, live[1 + j] = their ids; the chunks then
+    // partition that list.  (A list that holds most of the samples is not worth the indirection: identity scan.)
+    const uint32_t n_live = live ? live[0] : N;
+    const bool listed = live != nullptr && n_live < N - (N >> 2);
+    const uint32_t n_scan = listed ? n_live : N;
+    // A short list does not need all of a slice's chunks: an item costs ~10 us of zeroing / flushing / barriers
+    // whatever it scans (measured: with 95 % of the samples dead the launch only got 15 % faster), so only as many
+    // chunks stay active as have a full pass (4096 samples) to scan; the others leave at once.  The slice of a
+    // chunked item is flushed with atomics into a pre-zeroed range, which any number of active chunks satisfies.
+    uint32_t n_act = n_chunks;
+    if (listed && n_chunks > 1u) {
+        n_act = max(1u, min(n_chunks, n_scan / 4096u));
+        if (chunk >= n_act) return;
+    }
 
     for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) acc[e] = (typename ACC::T)0;
     __syncthreads();
 
-    const uint32_t per_chunk = (N + n_chunks - 1) / n_chunks;
-    const uint32_t begin = chunk * per_chunk;
-    const uint32_t end = min(N, begin + per_chunk);
+    const uint32_t per_chunk = (n_scan + n_act - 1) / n_act;
+    const uint32_t begin = min(n_scan, chunk * per_chunk);
+    const uint32_t end = min(n_scan, begin + per_chunk);
     // Samples are taken kUnroll at a time per thread with all of their loads issued up front: the
     // loop is otherwise one dependent L2 round trip per sample.
     constexpr uint32_t kUnroll = 4;
@@ -357,12 +372,18 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
         float2 dv[kUnroll];
         float xv[kUnroll][3];
+        uint32_t sid[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; ++u) {  // (one extra round trip per pass when the list is used)
+            const uint32_t j = i0 + u * kLdsBwdBlock;
+            sid[u] = j < end ? (listed ? live[1u + j] : j) : 0u;
+        }
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {
-            const uint32_t i = i0 + u * kLdsBwdBlock;
+            const uint32_t i = sid[u];
             dv[u] = make_float2(0.f, 0.f);
             xv[u][0] = xv[u][1] = xv[u][2] = 0.f;
-            if (i < end) {
+            if (i0 + u * kLdsBwdBlock < end) {
                 const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
                 dv[u] = dy2f(d2);
                 xv[u][0] = x[3 * (size_t)i + 0];
@@ -497,12 +518,14 @@ template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
-               const uint4* __restrict__ items, const unsigned long long* __restrict__ l1) {
+               const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
+               const uint32_t* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x3FFFFFFFu;
     if (item.w >> 31) {
-        grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
+        grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live);
     } else if ((item.w >> 30) & 1u) {
         const float l1x = (float)l1[2 * item.x] * (1.f / 256.f), l1y = (float)l1[2 * item.x + 1] * (1.f / 256.f);
         AccScale sc;
@@ -510,9 +533,59 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
-        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc);
+        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc, live);
     } else {
-        grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw);
+        grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live);
+    }
+}
+
+// List of the samples whose dL/dy is non-zero on any level (NvoGridSlices::compact_live): out[0] = count (zeroed by
+// the launcher), out[1 + k] = sample id.  Workgroup-aggregated append; the order of the workgroups is not
+// deterministic, which only moves samples between the chunks of an item (integer accumulation is order-free, chunked
+// items combine with float atomics either way).
+template <bool SOA, typename DY2>
+__global__ void __launch_bounds__(1024)
+k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ out) {
+    // one workgroup per 4096 consecutive samples, ONE global atomic per workgroup (a wave-level append put 16 K atomics
+    // on one address for a 1 M-sample batch: the single counter serialised them -- +40 us per launch)
+    constexpr uint32_t kPer = 4;
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t block_base;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * (1024u * kPer);
+    bool live[kPer];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t i = first + q * 1024u + threadIdx.x;
+        live[q] = false;
+        if (i < N) {
+            for (uint32_t l = 0; l < g.n_levels; ++l) {
+                const float2 d = dy2f(SOA ? dy[(size_t)l * N + i] : dy[(size_t)i * g.n_levels + l]);
+                live[q] = live[q] || d.x != 0.f || d.y != 0.f;  // (NaN != 0: non-finite gradients stay listed)
+            }
+        }
+        mine += (uint32_t)__popcll(__ballot(live[q]));  // (wave total of pass q, same in every lane)
+    }
+    if (lane == 0u) wave_cnt[wib] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = wave_cnt[w];
+            wave_cnt[w] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(out, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = block_base + wave_cnt[wib];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const unsigned long long m = __ballot(live[q]);
+        if (live[q]) out[1u + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = first + q * 1024u + threadIdx.x;
+        pos += (uint32_t)__popcll(m);
     }
 }
 
@@ -1508,6 +1581,9 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
 }
 
 void nvo_grid_slices_destroy(NvoGridSlices* s) {
+    if (s->d_live) (void)hipFree(s->d_live);
+    s->d_live = nullptr;
+    s->live_cap = 0;
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
     s->d_l1 = nullptr;
@@ -1921,6 +1997,22 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         }
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
         const size_t lds = slices->lds_bytes;
+        const uint32_t* live = nullptr;
+        if (slices->compact_live) {
+            if ((size_t)N + 1 > slices->live_cap) {  // grows during warm-up only; never while a graph is being captured
+                if (slices->d_live) NVO_CHECK_HIP(hipFree(slices->d_live));
+                slices->d_live = nullptr;
+                slices->live_cap = 0;
+                NVO_CHECK_HIP(hipMalloc((void**)&slices->d_live, sizeof(uint32_t) * ((size_t)N + 1)));
+                slices->live_cap = (size_t)N + 1;
+            }
+            if (int rc = nvo_zero_async(slices->d_live, sizeof(uint32_t), stream)) return rc;
+#define NVO_LAUNCH_LIVE(SOA_, T_) \
+    NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, slices->d_live)
+            if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
+#undef NVO_LAUNCH_LIVE
+            live = slices->d_live;
+        }
         if (slices->acc_bits == 32) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (!slices->external_zero)
@@ -1947,7 +2039,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1);  \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

@@ -607,6 +607,27 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         const uint32_t row = tile * 16 + m;
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
         load_tile(min(tile + n_waves, n_tiles - 1u), nxt);
+        if constexpr (COMPACT && IO == NVO_IO_HALF2_SOA) {
+            // A tile whose 16 dL/dout values are all EXACTLY zero contributes nothing to any dW and its dX is zero: skip
+            // the chain.  (The proposal networks of a nerfacto run: from a few hundred steps on 80-93 % of level 0's
+            // tiles and 46-68 % of level 1's -- the interlevel loss is zero wherever the proposal weights stay under
+            // the bound and fp16 flushes what is left below 6e-8 -- DESIGN.md section 7.1.)
+            if (__ballot((float)cur.dzl[0][0] != 0.f) == 0ull) {
+                if (need_dinput) {
+                    T2* __restrict__ p = (T2*)a.dinput;
+                    const uint32_t n_lv = a.n_in >> 1;
+                    const T z = (T)0.f;
+#pragma unroll
+                    for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                        const uint32_t lv = 8 * tk + 2 * g;
+                        if (lv < n_lv) p[(size_t)lv * a.batch + row] = T2{z, z};
+                        if (lv + 1 < n_lv) p[(size_t)(lv + 1) * a.batch + row] = T2{z, z};
+                    }
+                }
+                cur = nxt;
+                continue;
+            }
+        }
 
         // ---- output layer: dZ_L = dL/dout * out_act'(out)
         T4 dzl[OUT_PAD / 16];

@@ -24,6 +24,13 @@ struct NvoGridSlices {
     // The caller zeroes what the launch would zero (nvo_bwd_zero_ranges / option external_zero): a training step then
     // clears every accumulate-into buffer of all its networks with ONE launch instead of ~6 dependent 5-us launches.
     bool external_zero = false;
+    // option grid_compact_live: the samples whose dL/dy is non-zero on ANY level are listed first (k_live_samples) and
+    // the items scan that list instead of all N samples.  For the proposal networks of a nerfacto run 87-98 % of the
+    // samples carry an exactly zero gradient from a few hundred steps on, and every one of them
+    // was loaded and tested once per slice (25 slice scans for a proposal grid).
+    bool compact_live = false;
+    mutable uint32_t* d_live = nullptr;   // [1 + N]: count, then the live sample ids (grows with N, warm-up only)
+    mutable size_t live_cap = 0;
 };
 #include <utility>
 #include <vector>

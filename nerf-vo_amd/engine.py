@@ -116,6 +116,9 @@ class EngineConfig:
     # the stand-alone gather has a thread per (sample, level).  (Never for the main field: its 16 level tables, 24 MiB,
     # only stay L2-resident because k_grid_fwd pins each level to one XCD.)
     fuse_proposal_encoding: bool = False
+    # proposal grids: the slice-owner scatter scans a list of the samples with a non-zero gradient instead of all of
+    # them (option grid_compact_live; 87-98 % of the proposal samples have dL/dy == 0 from a few hundred steps on)
+    compact_live_proposal_samples: bool = True
     # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
     # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
@@ -174,6 +177,8 @@ class NerfactoEngine:
         for m in self.prop_nets:
             m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
             m.set_option("fuse_encoding", int(cfg.fuse_proposal_encoding))
+            # most proposal samples carry an exactly zero gradient after a few hundred steps: scan the live ones only
+            m.set_option("grid_compact_live", int(cfg.compact_live_proposal_samples))
         store = cfg.store_input_gradients
         if store is None:
             store = bool(cfg.optimize_poses or cfg.expect_normals)

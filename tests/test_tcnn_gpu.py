@@ -473,3 +473,66 @@ def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dt
     # the weight gradient is flushed with float atomics (order-dependent in the last bits); the grid gradient of the
     # default slice-owner scatter is deterministic for single-chunk slices -- both must agree to rounding
     _assert_close(res[1][1], res[0][1], rtol=1e-4, atol_scale=1e-6, what="dL/dparams, fused vs two-kernel forward")
+
+
+def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0):
+    """A proposal-shaped NetworkWithInputEncoding driven through the raw C-ABI the way the engine drives it."""
+    import json
+
+    from nerf_vo_amd.tinycudann.modules import _create
+
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 16,
+               "n_hidden_layers": 1}
+    m = _create("nvo_create_network_with_input_encoding", 3, 1, json.dumps(_enc_cfg(cfg)).encode(), json.dumps(net_cfg).encode())
+    m.set_option("grid_bwd_mode", 1)
+    m.set_option("grid_acc_bits", acc_bits)
+    m.set_option("grid_compact_live", compact_live)
+    if compact:
+        m.set_option("compact_output", 1)
+        m.set_option("recompute_hidden", 1)
+    return m
+
+
+@pytest.mark.parametrize("zero_frac", [0.0, 0.9, 1.0], ids=["all-live", "90pct-zero", "all-zero"])
+def test_zero_gradient_samples_are_skipped_exactly(device, zero_frac):
+    """Proposal-network backward with most dL/dout EXACTLY zero, clustered in runs along the rays as in training: the
+    compact-output kernel skips all-zero 16-sample tiles and the slice-owner scatter scans the list of live samples
+    (option grid_compact_live).  Reference: the same network with full-width [B][16] output rows (no tile skipping
+    in that instantiation) and the scan over all samples.  dL/dx must agree to the last bit, the gradients up to the
+    order of the float atomics that flush multi-chunk slices and the MLP weight gradient."""
+    from nerf_vo_amd.engine import _call, _ptr, _stream
+
+    g = torch.Generator().manual_seed(17)
+    N = 16 * 1024
+    x = torch.from_numpy(_points(N, 6)).to(device)
+    st = _stream(device)
+    dout = torch.randn(N, generator=g)
+    keep = (torch.rand(N // 64, generator=g) >= zero_frac).repeat_interleave(64)  # runs of 64 samples live or dead
+    dout = (dout * keep).to(device)
+    res = {}
+    for tag, compact, live in (("ref", False, 0), ("skip", True, 1)):
+        m = _raw_nwie(device, PROP0, compact, compact_live=live)
+        if "params" not in res:
+            res["params"] = (torch.randn(m.n_params, generator=g) * 0.3).to(device)
+        ph = res["params"].half()
+        ctx = torch.empty(m.ctx_bytes(N), dtype=torch.uint8, device=device)
+        out = torch.empty(N if compact else (N, 16), dtype=torch.float16, device=device)
+        _call("nvo_fwd", m.handle, st, N, _ptr(x), _ptr(ph), _ptr(out), _ptr(ctx))
+        if compact:
+            dy = (dout * 128).half()
+        else:
+            dy = torch.zeros(N, 16, dtype=torch.float16, device=device)
+            dy[:, 0] = (dout * 128).half()
+        dx = torch.full((N, 3), 7.0, device=device)
+        dp = torch.full((m.n_params,), 7.0, device=device)
+        _call("nvo_bwd", m.handle, st, N, _ptr(x), _ptr(ph), _ptr(out), _ptr(dy), _ptr(ctx), _ptr(dx), _ptr(dp))
+        torch.cuda.synchronize()
+        res[tag] = (out.float().view(N, -1)[:, 0].clone(), dx.clone(), dp.clone())
+    n_net = 16 * 16 + 16 * 16
+    assert torch.equal(res["ref"][0], res["skip"][0])
+    assert torch.equal(res["ref"][1], res["skip"][1]), "dL/dx differs"
+    # (multi-chunk slices and the MLP weight gradient are flushed with float atomics: equal up to summation order)
+    _assert_close(res["skip"][2][n_net:], res["ref"][2][n_net:], rtol=1e-4, atol_scale=1e-6, what="grid gradient, live list")
+    _assert_close(res["skip"][2][:n_net], res["ref"][2][:n_net], rtol=1e-4, atol_scale=1e-6, what="dW with skipped tiles")
+    if zero_frac == 1.0:
+        assert float(res["skip"][2].abs().max()) == 0.0 and float(res["skip"][1].abs().max()) == 0.0
