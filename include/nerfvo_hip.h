@@ -92,6 +92,7 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *   "bf16"                      16-bit format of everything the network streams: 0 = fp16 (default), 1 = bfloat16
  *   "compact_output"            (networks with one output) only column 0 exists in memory: [batch] instead of [batch][16]
  *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones
+ *   "grid_compact_live"         (mode 1) the slice-owner items scan a list of the samples whose dL/dy is non-zero
  *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
  *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
  *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges
