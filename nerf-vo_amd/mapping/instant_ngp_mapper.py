@@ -138,6 +138,13 @@ class InstantNGPRenderer(NeRFRenderer):
         return self.ngp.render(width=camera_intrinsics["width"], height=camera_intrinsics["height"], spp=1,
                                linear=True)[..., 0]
 
+    def render_mesh(self, file_mesh: str, resolution, lower_bound, upper_bound) -> None:
+        """ref: evaluation/nerf_renderer.py:296-300"""
+        from .. import pyngp
+
+        bounding_box = pyngp.BoundingBox(lower_bound, upper_bound)
+        self.ngp.compute_and_save_marching_cubes_mesh(file_mesh, resolution, bounding_box)
+
     def _set_rendering_defaults(self, camera_intrinsics: dict) -> None:
         self.ngp.nerf.sharpen = 0.0
         self.ngp.exposure = 0.0

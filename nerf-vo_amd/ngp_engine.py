@@ -411,6 +411,31 @@ class NgpEngine:
               _ptr(self.corrections), 1)
         return self.corrections.view(self.cfg.num_images, 3, 4).clone()
 
+    @torch.no_grad()
+    def density_at(self, positions: torch.Tensor) -> torch.Tensor:
+        """Density (exponential activation of the density network's first output, instant-ngp's nerf activation) at
+        positions [M, 3] of the engine's normalised frame, evaluated with the inference weights.  Points outside the
+        scene box read 0.  Used by mesh extraction; not on the training path."""
+        cfg = self.cfg
+        lo, hi = cfg.aabb
+        stream = _stream(self.device)
+        M = positions.shape[0]
+        chunk = 1 << 18
+        x01 = torch.empty(chunk, 3, device=self.device)
+        out = torch.empty(chunk, 16, dtype=torch.float16, device=self.device)
+        ctx = torch.empty(self.density_net.ctx_bytes(chunk), dtype=torch.uint8, device=self.device)
+        res = torch.empty(M, device=self.device)
+        ph = self.inference_params_half()
+        for c0 in range(0, M, chunk):
+            p = positions[c0:c0 + chunk].to(self.device, torch.float32)
+            n = p.shape[0]
+            x01.zero_()
+            x01[:n] = ((p - lo) / (hi - lo)).clamp_(0.0, 1.0)
+            _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", ph), _ptr(out), _ptr(ctx))
+            inside = ((p >= lo) & (p <= hi)).all(dim=1)
+            res[c0:c0 + n] = torch.where(inside, torch.exp(out[:n, 0].float().clamp(max=15.0)), torch.zeros((), device=self.device))
+        return res
+
     def loss_dict(self) -> dict:
         vals = self.losses.sum(dim=0).tolist()
         d = {"rgb_loss": vals[0], "depth_loss": vals[1]}

@@ -28,8 +28,8 @@ reference tree; this facade is pinned to the reference's call sites, which is al
 
 Differences from the CUDA testbed, all outside what the reference observes: training data may be handed over as
 device tensors (no host round trip); snapshots are msgpack containers with this module's own schema (the upstream
-.msgpack layout is [UPSTREAM]); ``render`` always uses spp = 1 rays through pixel centres; marching cubes is out
-of scope.  There is no CPU fallback: the engine needs the HIP library and an MI355X.
+.msgpack layout is [UPSTREAM]); ``render`` always uses spp = 1 rays through pixel centres; the mesh of
+``compute_and_save_marching_cubes_mesh`` is extracted with marching tetrahedra (meshing.py).  There is no CPU fallback: the engine needs the HIP library and an MI355X.
 """
 from __future__ import annotations
 
@@ -359,5 +359,35 @@ class Testbed:
                 raise NotImplementedError(f"render_mode {self.render_mode}: the reference uses Shade and Depth")
         return torch.cat(chunks).view(height, width, 4).cpu().numpy()
 
-    def compute_and_save_marching_cubes_mesh(self, *args, **kwargs) -> None:
-        raise NotImplementedError("mesh extraction is out of scope (SURVEY.md section 2.2)")
+    def compute_and_save_marching_cubes_mesh(self, filename: str, resolution=(256, 256, 256), aabb: BoundingBox | None = None,
+                                             thresh: float = 2.5, generate_uvs_for_obj_file: bool = False) -> None:
+        """Density iso-surface at ``thresh`` (instant-ngp's default 2.5) over ``aabb`` (dataset / world coordinates, as
+        the reference passes it: nerf_renderer.py:296-300; empty or infinite -> the scene box) sampled on a
+        ``resolution`` grid, written as .obj or .ply.  The surface is extracted with marching tetrahedra
+        (nerf_vo_amd/meshing.py) instead of upstream's marching-cubes tables: same iso-surface, another triangulation.
+        Vertices are written in the same dataset coordinates the box is given in."""
+        from .meshing import marching_tetrahedra, write_mesh
+
+        if self._engine is None:
+            raise RuntimeError("compute_and_save_marching_cubes_mesh: no network has been trained or loaded")
+        if generate_uvs_for_obj_file:
+            raise NotImplementedError("generate_uvs_for_obj_file: the reference never asks for texture coordinates")
+        res = [int(r) for r in (np.asarray(resolution).reshape(-1).tolist() * 3)[:3]]
+        e = self._engine
+        lo_n, hi_n = e.cfg.aabb  # scene box of the engine's normalised frame
+        scale, off = float(self._nerf_scale), np.asarray(self._nerf_offset, dtype=np.float64)
+        box = aabb if aabb is not None else BoundingBox()
+        lo = np.asarray(box.min, dtype=np.float64)
+        hi = np.asarray(box.max, dtype=np.float64)
+        world_lo, world_hi = (np.full(3, lo_n) - off) / scale, (np.full(3, hi_n) - off) / scale
+        if not (np.isfinite(lo).all() and np.isfinite(hi).all() and (hi > lo).all()):
+            lo, hi = world_lo, world_hi
+        lo, hi = np.maximum(lo, world_lo), np.minimum(hi, world_hi)
+        axes = [torch.linspace(float(lo[k]), float(hi[k]), res[k], device=self.device) for k in range(3)]
+        gx, gy, gz = torch.meshgrid(*axes, indexing="ij")
+        world = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3)
+        unit = world * scale + torch.as_tensor(off, dtype=torch.float32, device=self.device)
+        dens = e.density_at(unit).view(*res)
+        verts, faces = marching_tetrahedra(dens, lo, hi, float(thresh))
+        os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+        write_mesh(filename, verts, faces)

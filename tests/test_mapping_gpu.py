@@ -129,6 +129,19 @@ def test_instant_ngp_mapper_end_to_end(device, tmp_path):
     np.testing.assert_array_equal(offline.get_camera_extrinsics(3), pose3)
     color2, depth2 = offline.render_frame(intr, pose3)
     assert np.array_equal(color2, color) and np.array_equal(depth2, depth)
+    # mesh of the density field (ref: evaluation/nerf_renderer.py:296-300): a closed-ish surface inside the scene box,
+    # written in dataset coordinates
+    offline.render_mesh(str(tmp_path / "mesh.ply"), np.array([96, 96, 96]), np.array([-np.inf] * 3), np.array([np.inf] * 3))
+    raw = open(tmp_path / "mesh.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    nv = int(head.split(b"element vertex ")[1].split()[0])
+    nf = int(head.split(b"element face ")[1].split()[0])
+    assert nv > 500 and nf > 1000 and len(body) == nv * 12 + nf * 13
+    verts = np.frombuffer(body[: nv * 12], dtype="<f4").reshape(-1, 3)
+    # (aabb_scale 4 around the unit cube's centre 0.5; nerf_scale 1, nerf_offset 0: dataset == engine coordinates)
+    assert np.isfinite(verts).all() and verts.min() >= -1.5 - 1e-4 and verts.max() <= 2.5 + 1e-4
+    # a part of the surface lies where the cameras look: within the room (scene_scale 0.2 around 0.5)
+    assert (np.linalg.norm(verts - 0.5, axis=1) < 0.6).mean() > 0.05
     # misuse fails loudly
     with pytest.raises(RuntimeError):
         mapper.ngp.nerf.training.update_training_images(
