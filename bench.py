@@ -134,6 +134,7 @@ def main() -> None:
     ap.add_argument("--late-steps", type=int, default=100,
                     help="extra timed steps late in the proposal-update schedule (reported as late_schedule; 0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     args.keyframes = args.keyframes or wl["keyframes"]
@@ -203,6 +204,8 @@ def main() -> None:
 
     cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses,
                        mlp_dtype=args.mlp_dtype, expect_normals=use_normals)
+    if args.proposal_streams is not None:
+        cfg.proposal_backward_streams = args.proposal_streams
     if args.grid_bwd_mode is not None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3

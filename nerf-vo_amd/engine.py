@@ -93,6 +93,7 @@ class EngineConfig:
     # run the proposal-network losses + backward on a second HIP stream beside the main-field backward
     # (they only share read-only inputs; forked after the render/loss kernel, joined before the optimiser)
     overlap_proposal_backward: bool = True
+    proposal_backward_streams: int = 1    # 2 = one side stream per proposal network (measured: see DESIGN.md section 5.0)
     proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
     # Main grid: the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients) whenever positions
     # need gradients (pose optimisation, analytic normals); the input backward then streams it (112 -> ~20 us) instead
@@ -585,14 +586,17 @@ class NerfactoEngine:
             # fork: everything the proposal backward reads (main-level weights / bins) exists now
             cur = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
-                # ONE side stream for both proposal networks: a stream each was measured slower
-                # (1.10 vs 1.01 ms/step) -- three LDS-heavy scatter kernels at once thrash
-                self._side_stream = [torch.cuda.Stream(device=self.device)]
+                # ONE side stream for both proposal networks (round 1: a stream each measured slower, 1.10 vs 1.01
+                # ms/step -- three LDS-heavy scatter kernels at once thrash); cfg.proposal_backward_streams = 2 keeps
+                # the experiment available
+                self._side_stream = [torch.cuda.Stream(device=self.device)
+                                     for _ in range(max(1, min(2, int(cfg.proposal_backward_streams))))]
             side = self._side_stream
-            for st in side:
+            for si, st in enumerate(side):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    self._proposal_backward(ws, has_depth, pose, _stream(self.device))
+                    self._proposal_backward(ws, has_depth, pose, _stream(self.device),
+                                            levels=None if len(side) == 1 else [si])
         _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
         scatter_stream = None
         if pose and cfg.overlap_pose_backward:
