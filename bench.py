@@ -282,7 +282,24 @@ def main() -> None:
     # proposal backward with the main-field backward on a second stream, which would inflate both here
     overlap_saved, cfg.overlap_proposal_backward = cfg.overlap_proposal_backward, False
     overlap_pose_saved, cfg.overlap_pose_backward = cfg.overlap_pose_backward, False
+    # Eager launches with an event pair each are host-bound (the host needs longer per step than the GPU does), so a
+    # multi-kernel scope such as grid_bwd_stream would time the idle gaps between its kernels as well.  A spin of
+    # about one step's host time at the head of every profiled step lets the host run ahead: the scopes then see
+    # their kernels back to back, which is what rocprofv3's per-kernel durations add up to.
+    spin_cycles = 0
+    if hasattr(torch.cuda, "_sleep"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1_000_000)
+        torch.cuda.synchronize(device)
+        e0.record()
+        torch.cuda._sleep(1_000_000)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms_per_mcycle = max(e0.elapsed_time(e1), 1e-3)
+        spin_cycles = int(1_000_000 * min(2.0, max(0.3, 1.5 * ms_per_step)) / ms_per_mcycle)
     for _ in range(prof_steps):  # every rank runs them (the all-reduce is collective)
+        if spin_cycles:
+            torch.cuda._sleep(spin_cycles)
         step()
     use_graph = use_graph_saved
     cfg.overlap_proposal_backward = overlap_saved

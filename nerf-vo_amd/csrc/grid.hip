@@ -327,7 +327,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               float* __restrict__ grad, uint32_t level, uint32_t first,
                                               uint32_t chunk, uint32_t n_chunks, void* lds_raw,
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
-                                              const uint32_t* __restrict__ live = nullptr) {
+                                              const uint32_t* __restrict__ live = nullptr, bool merge = false) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -353,7 +353,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) acc[e] = (typename ACC::T)0;
     __syncthreads();
 
-    const uint32_t per_chunk = (n_scan + n_act - 1) / n_act;
+    // (chunk boundaries on multiples of 8 samples: the run-merging scan loads 8 consecutive samples per lane)
+    const uint32_t per_chunk = ((n_scan + n_act - 1) / n_act + 7u) & ~7u;
     const uint32_t begin = min(n_scan, chunk * per_chunk);
     const uint32_t end = min(n_scan, begin + per_chunk);
     // Samples are taken kUnroll at a time per thread with all of their loads issued up front: the
@@ -369,6 +370,97 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     // remembered here and poisons the slice's first gradient entry after the flush, so that the optimiser's
     // non-finite check sees it exactly as it would with floating-point accumulation.
     bool bad = false;
+    if (merge && !hashed) {
+        // Run-merging scan of a DENSE level (option grid_bwd_runs).  Consecutive samples are neighbours on a ray and a
+        // coarse cell holds a run of them: a lane takes 8 CONSECUTIVE samples (a wave 512, all 8 loads in flight at
+        // once), sums the 8 x 2 corner contributions of the current cell in fp32 registers and goes to the LDS
+        // accumulators once per run -- index arithmetic, slice tests, float -> fixed conversions and atomics per RUN
+        // instead of per sample, and the lanes of one atomic instruction are 8 samples apart instead of adjacent
+        // (the per-sample form had 2/3 of its LDS cycles in same-address conflicts).  A run whose 8 corners all
+        // miss the slice costs the cell computation only.
+        constexpr uint32_t kRun = 8;
+        float a0[8], a1[8];
+        uint32_t cx = 0, cy = 0, cz = 0, cbase = 0;
+        bool open = false, hit = false;
+        const uint32_t span = 1u + res + res2;  // largest corner offset from the cell's base index
+        auto flush = [&]() {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t i0 = cbase + ((j & 1u) ? res : 0u) + ((j & 2u) ? res2 : 0u);
+                uint32_t i1 = i0 + 1u;
+                if (i1 >= size) {
+                    i0 %= size;
+                    i1 %= size;
+                }
+                const uint32_t r0 = i0 - first, r1 = i1 - first;  // unsigned wrap -> huge when below the slice
+                if (r0 < count) ACC::add(acc, r0, a0[2 * j], a1[2 * j], sc);
+                if (r1 < count) ACC::add(acc, r1, a0[2 * j + 1], a1[2 * j + 1], sc);
+            }
+        };
+        auto visit = [&](float px, float py, float pz, float2 d) {
+            bad = bad || !(fabsf(d.x) < INFINITY) || !(fabsf(d.y) < INFINITY);
+            if (d.x == 0.f && d.y == 0.f) return;
+            const Corner c = grid_cell(scale, px, py, pz);
+            if (!open || c.px != cx || c.py != cy || c.pz != cz) {
+                if (open && hit) flush();
+                cx = c.px;
+                cy = c.py;
+                cz = c.pz;
+                open = true;
+                cbase = c.px + c.py * res + c.pz * res2;
+                // corners lie in [cbase, cbase + span] (or wrap, upper domain face only: treated as a hit)
+                hit = cbase + span >= size || (cbase + span >= first && cbase < first + count);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+            }
+            if (!hit) return;
+            const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+            const float wyz[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const float w0 = wx0 * wyz[j], w1 = c.wx * wyz[j];
+                a0[2 * j] += w0 * d.x;
+                a1[2 * j] += w0 * d.y;
+                a0[2 * j + 1] += w1 * d.x;
+                a1[2 * j + 1] += w1 * d.y;
+            }
+        };
+        bool vec = false;
+        if constexpr (SOA && sizeof(DY2) == 4) {
+            vec = !listed && (N & 3u) == 0u && (((uintptr_t)dy) & 15u) == 0u && (((uintptr_t)x) & 15u) == 0u;
+        }
+        for (uint32_t b0 = begin + threadIdx.x * kRun; b0 < end; b0 += kLdsBwdBlock * kRun) {
+            open = false;
+            hit = false;
+            bool done = false;
+            if constexpr (SOA && sizeof(DY2) == 4) {
+                if (vec && b0 + kRun <= end) {
+                    const float4* __restrict__ xp = reinterpret_cast<const float4*>(x + 3 * (size_t)b0);
+                    const uint4* __restrict__ dp = reinterpret_cast<const uint4*>(dy + (size_t)level * N + b0);
+                    const float4 p0 = xp[0], p1 = xp[1], p2 = xp[2], p3 = xp[3], p4 = xp[4], p5 = xp[5];
+                    const uint4 q0 = dp[0], q1 = dp[1];
+                    visit(p0.x, p0.y, p0.z, dy2f(__builtin_bit_cast(DY2, q0.x)));
+                    visit(p0.w, p1.x, p1.y, dy2f(__builtin_bit_cast(DY2, q0.y)));
+                    visit(p1.z, p1.w, p2.x, dy2f(__builtin_bit_cast(DY2, q0.z)));
+                    visit(p2.y, p2.z, p2.w, dy2f(__builtin_bit_cast(DY2, q0.w)));
+                    visit(p3.x, p3.y, p3.z, dy2f(__builtin_bit_cast(DY2, q1.x)));
+                    visit(p3.w, p4.x, p4.y, dy2f(__builtin_bit_cast(DY2, q1.y)));
+                    visit(p4.z, p4.w, p5.x, dy2f(__builtin_bit_cast(DY2, q1.z)));
+                    visit(p5.y, p5.z, p5.w, dy2f(__builtin_bit_cast(DY2, q1.w)));
+                    done = true;
+                }
+            }
+            if (!done) {
+                const uint32_t stop = min(end, b0 + kRun);
+                for (uint32_t j = b0; j < stop; ++j) {
+                    const uint32_t i = listed ? live[1u + j] : j;
+                    const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+                    visit(x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2], dy2f(d2));
+                }
+            }
+            if (open && hit) flush();
+        }
+    } else
     for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
         float2 dv[kUnroll];
         float xv[kUnroll][3];
@@ -522,10 +614,11 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const uint32_t* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
-    const uint32_t n_chunks = item.w & 0x3FFFFFFFu;
+    const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
+    const bool merge = (item.w >> 29) & 1u;
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge);
     } else if ((item.w >> 30) & 1u) {
         const float l1x = (float)l1[2 * item.x] * (1.f / 256.f), l1y = (float)l1[2 * item.x + 1] * (1.f / 256.f);
         AccScale sc;
@@ -533,10 +626,11 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
-        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc, live);
+        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc, live,
+                                            merge);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge);
     }
 }
 
@@ -1506,7 +1600,8 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
 
 // Slice tables for the LDS backward live in a small device buffer owned by the module.
 
-int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask, uint32_t target) {
+int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask, uint32_t target,
+                           bool env_items) {
     static_assert(2 * AccFixed32::kEntries * sizeof(int) <= kLdsBwdBytes, "32-bit slice does not fit the LDS");
     struct Item { uint32_t level, first, chunk, n_chunks; };
     // Per level: accumulator kind and slice size.  Large hashed tables (>= 2^18 entries: a 20K-entry
@@ -1523,12 +1618,13 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     // pass 1: chunk counts from the hit share alone (unit = share of one float slice of a 2^19
     // table); pass 2: scale them so that the launch has enough (>= target) items to fill 256 CUs
     // for several rounds.
-    if (const char* env = getenv("NVO_GRID_BWD_ITEMS")) target = (uint32_t)atoi(env);
+    if (const char* env = env_items ? getenv("NVO_GRID_BWD_ITEMS") : nullptr) target = (uint32_t)atoi(env);
     auto base_chunks = [&](uint32_t count, uint32_t size) {
         const double share = (double)count / (double)size * (524288.0 / (double)kSliceFloat);
         uint32_t n = (uint32_t)(share + 0.5);
         return n < 1 ? 1u : n;
     };
+    if (const char* e = getenv("NVO_GRID_RUNS")) s->runs = atoi(e) != 0;  // A/B switch for measurements
     uint32_t base_total = 0;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         if (!((level_mask >> l) & 1u)) continue;
@@ -1536,7 +1632,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         const uint32_t se = acc32 ? AccFixed32::kEntries : (float_mode(l) ? kSliceFloat : kSliceFixed);
         for (uint32_t f = 0; f < size; f += se) base_total += base_chunks(size - f < se ? size - f : se, size);
     }
-    const uint32_t factor = base_total >= target ? 1u : (target + base_total - 1) / base_total;
+    const uint32_t factor = (base_total == 0 || base_total >= target) ? 1u : (target + base_total - 1) / base_total;
     // Most expensive first: single-chunk items scan all N samples (long), chunked items scan
     // N / n_chunks samples with a high hit rate (short but atomic-heavy).
     std::vector<Item> single, chunked;
@@ -1551,7 +1647,8 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
             if (n_chunks > 1024) n_chunks = 1024;
             for (uint32_t c = 0; c < n_chunks; ++c)
                 (n_chunks == 1 ? single : chunked).push_back(
-                    Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u)});
+                    Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u) |
+                                                (s->runs && !g.hashed[l] ? 0x20000000u : 0u)});
         }
     }
     std::vector<Item> all(single);
@@ -1722,6 +1819,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     std::vector<uint32_t> levels, first, bin_level, bin_slice;
     st->max_slices = 0;
     st->streamed_mask = 0;
+    if (const char* e = getenv("NVO_GRID_OWNER_SLICES")) st->owner_max_slices = (uint32_t)atoi(e);  // measurements
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
         const uint32_t n_slices = (size + kBinSlice - 1u) / kBinSlice;
@@ -1795,9 +1893,12 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
     }
     const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
-    // 512 items: measured optimum for the coarse-only launch (the atomic flush of a chunk costs as much as
-    // scanning ~2K samples; a two-stage store + reduce form was measured slower)
-    return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask, 512);
+    // (a two-stage store + reduce form of the flush was measured slower)
+    // measured optima for the coarse-only launch: 512 items (the atomic flush of a chunk costs as much as scanning ~2K
+    // samples), 256 with the run-merging scan (cheaper scan, same flush)
+    uint32_t owner_items = st->owner.runs ? 256 : 512;
+    if (const char* e = getenv("NVO_GRID_OWNER_ITEMS")) owner_items = (uint32_t)atoi(e);  // measurements
+    return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask, owner_items, false);
 }
 
 void nvo_grid_stream_destroy(NvoGridStream* st) {
@@ -1983,12 +2084,13 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                         uint32_t N, const float* x, const void* dy, int dy_fmt, bool soa,
                         float* grad, int mode) {
     const size_t grad_bytes = sizeof(float) * 2 * (size_t)g.offset[g.n_levels];
-    NVO_PROF(stream, "grid_bwd_%s[L%u]", (mode == 1 && slices && slices->n_slices) ? "lds" : "atomic", g.n_levels);
+    const bool owner_form = mode == 1 && slices && slices->n_slices;
+    NVO_PROF(stream, "grid_bwd_%s[L%u]", owner_form ? "lds" : "atomic", g.n_levels);
     if (N == 0) {
         return nvo_zero_async(grad, grad_bytes, stream);
     }
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
-    if (mode == 1 && slices && slices->n_slices) {
+    if (owner_form) {
         if (slices->zero_last > slices->zero_first && !slices->external_zero) {
             // chunked (atomically flushed) levels form one contiguous run of entries
             if (int rc = nvo_zero_async(grad + 2 * (size_t)slices->zero_first,

@@ -31,6 +31,10 @@ struct NvoGridSlices {
     bool compact_live = false;
     mutable uint32_t* d_live = nullptr;   // [1 + N]: count, then the live sample ids (grows with N, warm-up only)
     mutable size_t live_cap = 0;
+    // option grid_bwd_runs (set before create): the items of DENSE levels scan with run merging -- a lane takes 8
+    // consecutive samples, sums the corner contributions in registers while the cell stays the same and goes to the LDS
+    // accumulators once per run (consecutive samples are neighbours on a ray, so a coarse cell holds a run of them)
+    bool runs = false;
 };
 #include <utility>
 #include <vector>
@@ -39,7 +43,7 @@ void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s,
 // level_mask: bit l set -> level l gets slice-owner work items (default: all levels); target_items: the
 // chunk counts are scaled until the launch has about this many work items
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu,
-                           uint32_t target_items = 1024);
+                           uint32_t target_items = 1024, bool env_items = true);
 
 // Binned backward (mode 2): hashed levels go through count/scan/scatter/accumulate, the remaining
 // (dense, small) levels through the slice-owner items in `dense`.

@@ -95,6 +95,8 @@ class EngineConfig:
     overlap_proposal_backward: bool = True
     proposal_backward_streams: int = 1    # 2 = one side stream per proposal network (measured: see DESIGN.md section 5.0)
     proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
+    # dense levels of (main, proposal 0, proposal 1): run-merging scan in the slice-owner items (option grid_bwd_runs)
+    grid_bwd_runs: tuple = (True, True, True)
     # Main grid: the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients) whenever positions
     # need gradients (pose optimisation, analytic normals); the input backward then streams it (112 -> ~20 us) instead
     # of gathering the corners again.  None = on iff optimize_poses or expect_normals.
@@ -173,6 +175,8 @@ class NerfactoEngine:
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
+        for m, runs in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs):
+            m.set_option("grid_bwd_runs", int(bool(runs)))
         # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
         for m in self.prop_nets:

@@ -93,14 +93,21 @@ def test_grid_indices_bit_exact(device, cfg):
 
 
 def _set_bwd_mode(enc, bwd_mode):
-    """0 atomics | 1 slice owner | 2 binned | 3 streamed (globally sorted records) | 4 streamed, tile-local records"""
-    enc.native_tcnn_module.set_option("grid_bwd_mode", min(bwd_mode, 3))
-    if bwd_mode >= 3:
-        enc.native_tcnn_module.set_option("grid_stream_layout", int(bwd_mode == 4))
+    """0 atomics | 1 slice owner | 2 binned | 3 streamed (globally sorted records) | 4 streamed, tile-local records |
+    5 slice owner with run-merged dense levels | 6 streamed tile-local with run-merged coarse levels"""
+    m = enc.native_tcnn_module
+    m.set_option("grid_bwd_runs", int(bwd_mode >= 5))
+    m.set_option("grid_bwd_mode", {5: 1, 6: 3}.get(bwd_mode, min(bwd_mode, 3)))
+    if bwd_mode >= 3 and bwd_mode != 5:
+        m.set_option("grid_stream_layout", int(bwd_mode in (4, 6)))
+
+
+BWD_MODES = [0, 1, 2, 3, 4, 5, 6]
+BWD_MODE_IDS = ["atomic", "lds", "binned", "streamed", "streamed-tile-local", "lds-runs", "streamed-tile-local-runs"]
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
-@pytest.mark.parametrize("bwd_mode", [0, 1, 2, 3, 4], ids=["atomic", "lds", "binned", "streamed", "streamed-tile-local"])
+@pytest.mark.parametrize("bwd_mode", BWD_MODES, ids=BWD_MODE_IDS)
 def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     import nerf_vo_amd.tinycudann as tcnn
     from oracle import grid as G
@@ -253,13 +260,18 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
     grads = []
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5, 6):
         _set_bwd_mode(enc, mode)
         enc.params.grad = None
         y = enc(x)
         (y.float() * dy).sum().backward()
         grads.append(enc.params.grad.clone())
     torch.cuda.synchronize()
+    # run-merged coarse levels (uniform random points are the worst case: no two consecutive samples share a cell)
+    _assert_close(grads[5], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds + run-merged dense levels vs atomic dL/dparams")
+    _assert_close(grads[6], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed + run-merged coarse levels vs atomic")
+    assert torch.equal(grads[6][2 * (4096 + 12168 + 29792 + 79512 + 205384):],
+                       grads[4][2 * (4096 + 12168 + 29792 + 79512 + 205384):]), "hashed levels must not change"
     # tile-local record layout: the same records summed in 64-bit fixed point -> bit-identical to the sorted layout
     # wherever a bin has a single accumulate item (every hashed level)
     hashed0 = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
@@ -475,7 +487,7 @@ def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dt
     _assert_close(res[1][1], res[0][1], rtol=1e-4, atol_scale=1e-6, what="dL/dparams, fused vs two-kernel forward")
 
 
-def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0):
+def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0, runs=0):
     """A proposal-shaped NetworkWithInputEncoding driven through the raw C-ABI the way the engine drives it."""
     import json
 
@@ -487,6 +499,7 @@ def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0):
     m.set_option("grid_bwd_mode", 1)
     m.set_option("grid_acc_bits", acc_bits)
     m.set_option("grid_compact_live", compact_live)
+    m.set_option("grid_bwd_runs", runs)
     if compact:
         m.set_option("compact_output", 1)
         m.set_option("recompute_hidden", 1)
@@ -536,3 +549,54 @@ def test_zero_gradient_samples_are_skipped_exactly(device, zero_frac):
     _assert_close(res["skip"][2][:n_net], res["ref"][2][:n_net], rtol=1e-4, atol_scale=1e-6, what="dW with skipped tiles")
     if zero_frac == 1.0:
         assert float(res["skip"][2].abs().max()) == 0.0 and float(res["skip"][1].abs().max()) == 0.0
+
+
+def _ray_points(n_rays, n_samples, seed):
+    """Samples along rays through the unit cube, ray-major (the order the samplers emit)."""
+    rng = np.random.default_rng(seed)
+    o = rng.random((n_rays, 1, 3), dtype=np.float32) * 0.2 + 0.4
+    d = rng.standard_normal((n_rays, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = np.sort(rng.random((n_rays, n_samples, 1), dtype=np.float32), axis=1) * 0.55
+    return np.clip(o + t * d, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("live", [0, 1], ids=["all-samples", "live-list"])
+@pytest.mark.parametrize("acc_bits", [64, 32])
+@pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
+def test_run_merged_dense_levels_match_slice_owner(device, cfg, acc_bits, live):
+    """Option grid_bwd_runs on ray-ordered samples (the case it is built for: a coarse cell holds a run of consecutive
+    samples), level-major dL/dy as the fused networks hand it over (16-byte vector loads), some samples with an exactly
+    zero gradient.  Reference: the same slice-owner items scanning sample by sample.  Both sum fp32 products; the
+    run-merged form adds the products of a run in fp32 registers before the one conversion to fixed point, so the
+    agreement is to fp32 rounding of the run sums (64-bit accumulators) or to the int32 quantum L1 / 2^29 per
+    addend (32-bit accumulators)."""
+    from nerf_vo_amd.engine import _call, _ptr, _stream
+
+    g = torch.Generator().manual_seed(23)
+    n_rays, S = 256, 48
+    N = n_rays * S
+    x = torch.from_numpy(_ray_points(n_rays, S, 11)).to(device)
+    st = _stream(device)
+    dout = torch.randn(N, generator=g) * (torch.rand(N, generator=g) > 0.25)
+    dout = dout.to(device)
+    res = {}
+    params = None
+    for tag, runs in (("owner", 0), ("runs", 1)):
+        m = _raw_nwie(device, cfg, True, acc_bits=acc_bits, runs=runs, compact_live=live)
+        if params is None:
+            params = (torch.randn(m.n_params, generator=g) * 0.3).to(device)
+        ph = params.half()
+        ctx = torch.empty(m.ctx_bytes(N), dtype=torch.uint8, device=device)
+        out = torch.empty(N, dtype=torch.float16, device=device)
+        _call("nvo_fwd", m.handle, st, N, _ptr(x), _ptr(ph), _ptr(out), _ptr(ctx))
+        dy = (dout * 128).half()
+        dx = torch.zeros((N, 3), device=device)
+        dp = torch.full((m.n_params,), 7.0, device=device)
+        _call("nvo_bwd", m.handle, st, N, _ptr(x), _ptr(ph), _ptr(out), _ptr(dy), _ptr(ctx), _ptr(dx), _ptr(dp))
+        torch.cuda.synchronize()
+        res[tag] = dp.clone()
+    n_net = 16 * 16 + 16 * 16
+    assert float(res["owner"][n_net:].abs().max()) > 0
+    tol = dict(rtol=1e-5, atol_scale=1e-6) if acc_bits == 64 else dict(rtol=1e-3, atol_scale=1e-4)
+    _assert_close(res["runs"][n_net:], res["owner"][n_net:], what="grid gradient, run-merged", **tol)
