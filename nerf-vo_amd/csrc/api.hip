@@ -428,6 +428,12 @@ struct GridModule : nvo_module_s {
             stream_bins.owner.acc_bits = (uint32_t)value;
             return NVO_OK;
         }
+        if (!strcmp(key, "grid_bwd_batch")) {  // expected batch size of the backward launches (0 = unknown)
+            nvo_grid_slices_destroy(&slices);
+            nvo_grid_stream_destroy(&stream_bins);
+            slices.batch_hint = stream_bins.owner.batch_hint = (uint32_t)value;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_bwd_runs")) {  // slice-owner items of dense levels: run-merging scan (on rebuild)
             nvo_grid_slices_destroy(&slices);
             nvo_grid_stream_destroy(&stream_bins);
@@ -440,6 +446,7 @@ struct GridModule : nvo_module_s {
             return NVO_OK;
         }
         if (!strcmp(key, "grid_stream_overlap")) {  // 0: slice-owner levels and record pipeline back to back
+            nvo_grid_stream_destroy(&stream_bins);  // (the owner's slice size depends on it)
             stream_bins.overlap = value != 0;
             return NVO_OK;
         }

@@ -327,14 +327,15 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               float* __restrict__ grad, uint32_t level, uint32_t first,
                                               uint32_t chunk, uint32_t n_chunks, void* lds_raw,
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
-                                              const uint32_t* __restrict__ live = nullptr, bool merge = false) {
+                                              const uint32_t* __restrict__ live = nullptr, bool merge = false,
+                                              uint32_t slice_cap = ACC::kEntries) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
     const uint32_t res = g.resolution[level];
     const uint32_t hashed = g.hashed[level];
     const float scale = g.scale[level];
-    const uint32_t count = min(ACC::kEntries, size - first);
+    const uint32_t count = min(slice_cap, size - first);  // slice_cap <= ACC::kEntries
     // live != nullptr: live[0] = number of samples with a non-zero gradient, live[1 + j] = their ids; the chunks then
     // partition that list.  (A list that holds most of the samples is not worth the indirection: identity scan.)
     const uint32_t n_live = live ? live[0] : N;
@@ -410,8 +411,10 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                 cbase = c.px + c.py * res + c.pz * res2;
                 // corners lie in [cbase, cbase + span] (or wrap, upper domain face only: treated as a hit)
                 hit = cbase + span >= size || (cbase + span >= first && cbase < first + count);
+                if (hit) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+                    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+                }
             }
             if (!hit) return;
             const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
@@ -616,21 +619,22 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
     const bool merge = (item.w >> 29) & 1u;
+    const uint32_t level = item.x & 0xFFu, cap = item.x >> 8;  // cap: entries per slice of this level
     if (item.w >> 31) {
-        grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge);
+        grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap);
     } else if ((item.w >> 30) & 1u) {
-        const float l1x = (float)l1[2 * item.x] * (1.f / 256.f), l1y = (float)l1[2 * item.x + 1] * (1.f / 256.f);
+        const float l1x = (float)l1[2 * level] * (1.f / 256.f), l1y = (float)l1[2 * level + 1] * (1.f / 256.f);
         AccScale sc;
         sc.s0 = l1x > 0.f ? 536870912.f / l1x : 0.f;  // 2^29 / L1
         sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
-        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge);
+        grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
+                                            merge, cap);
     } else {
-        grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, item.x, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge);
+        grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap);
     }
 }
 
@@ -1615,6 +1619,13 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         if (force && !strcmp(force, "float")) return true;
         return g.hashed[l] && (g.offset[l + 1] - g.offset[l]) >= (1u << 18);
     };
+    // entries per slice of a level; fixed_cap (< 8192, dense levels only) shrinks the 64-bit fixed-point slices so that
+    // the launch leaves LDS to a kernel running beside it (mode 3: the record scatter, see NvoGridStream::overlap)
+    auto slice_entries = [&](uint32_t l) {
+        if (acc32) return AccFixed32::kEntries;
+        if (float_mode(l)) return kSliceFloat;
+        return (s->fixed_cap && !g.hashed[l]) ? (s->fixed_cap < kSliceFixed ? s->fixed_cap : kSliceFixed) : kSliceFixed;
+    };
     // pass 1: chunk counts from the hit share alone (unit = share of one float slice of a 2^19
     // table); pass 2: scale them so that the launch has enough (>= target) items to fill 256 CUs
     // for several rounds.
@@ -1629,10 +1640,30 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
-        const uint32_t se = acc32 ? AccFixed32::kEntries : (float_mode(l) ? kSliceFloat : kSliceFixed);
+        const uint32_t se = slice_entries(l);
         for (uint32_t f = 0; f < size; f += se) base_total += base_chunks(size - f < se ? size - f : se, size);
     }
     const uint32_t factor = (base_total == 0 || base_total >= target) ? 1u : (target + base_total - 1) / base_total;
+    // one-round rule (see NvoGridSlices::batch_hint)
+    uint32_t even_chunks = 0;
+    if (s->runs && s->batch_hint) {
+        uint32_t n_total = 0;
+        for (uint32_t l = 0; l < g.n_levels; ++l) {
+            if (!((level_mask >> l) & 1u)) continue;
+            const uint32_t size = g.offset[l + 1] - g.offset[l];
+            const uint32_t se = slice_entries(l);
+            n_total += (size + se - 1) / se;
+        }
+        int dev = 0, n_cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (const char* e = getenv("NVO_GRID_ROUND_CUS")) n_cus = atoi(e);  // measurements
+        if (n_total && n_total <= (uint32_t)n_cus) {
+            const uint64_t pass = (uint64_t)kLdsBwdBlock * 8;
+            const uint32_t per = (uint32_t)n_cus / n_total;
+            const uint32_t k = (uint32_t)((s->batch_hint + pass * per - 1) / (pass * per));
+            even_chunks = (uint32_t)((s->batch_hint + pass * k - 1) / (pass * k));
+        }
+    }
     // Most expensive first: single-chunk items scan all N samples (long), chunked items scan
     // N / n_chunks samples with a high hit rate (short but atomic-heavy).
     std::vector<Item> single, chunked;
@@ -1640,28 +1671,30 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         if (!((level_mask >> l) & 1u)) continue;
         const uint32_t size = g.offset[l + 1] - g.offset[l];
         const bool fm = float_mode((uint32_t)l);
-        const uint32_t se = acc32 ? AccFixed32::kEntries : (fm ? kSliceFloat : kSliceFixed);
+        const uint32_t se = slice_entries((uint32_t)l);
         for (uint32_t f = 0; f < size; f += se) {
             const uint32_t count = size - f < se ? size - f : se;
-            uint32_t n_chunks = base_chunks(count, size) * factor;
+            uint32_t n_chunks = even_chunks ? even_chunks : base_chunks(count, size) * factor;
             if (n_chunks > 1024) n_chunks = 1024;
             for (uint32_t c = 0; c < n_chunks; ++c)
                 (n_chunks == 1 ? single : chunked).push_back(
-                    Item{(uint32_t)l, f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u) |
+                    Item{(uint32_t)l | (se << 8), f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u) |
                                                 (s->runs && !g.hashed[l] ? 0x20000000u : 0u)});
         }
     }
     std::vector<Item> all(single);
     all.insert(all.end(), chunked.begin(), chunked.end());
     s->n_slices = (uint32_t)all.size();
-    s->lds_bytes = 128 * 1024;
-    for (const Item& it : all)
-        if (it.n_chunks >> 31) s->lds_bytes = kLdsBwdBytes;
+    s->lds_bytes = 0;
+    for (const Item& it : all) {  // (every accumulator kind holds 2 values per entry)
+        const uint32_t bytes = (it.level >> 8) * 2u * ((it.n_chunks >> 31) ? 4u : ((it.n_chunks >> 30) & 1u) ? 4u : 8u);
+        if (bytes > s->lds_bytes) s->lds_bytes = bytes;
+    }
     // contiguous run of entries owned by chunked items (needs zeroing before the atomic flush)
     s->zero_first = 0xFFFFFFFFu;
     s->zero_last = 0;
     for (const Item& it : chunked) {
-        const uint32_t lo = g.offset[it.level], hi = g.offset[it.level + 1];
+        const uint32_t lo = g.offset[it.level & 0xFFu], hi = g.offset[(it.level & 0xFFu) + 1];
         if (lo < s->zero_first) s->zero_first = lo;
         if (hi > s->zero_last) s->zero_last = hi;
     }
@@ -1819,6 +1852,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     std::vector<uint32_t> levels, first, bin_level, bin_slice;
     st->max_slices = 0;
     st->streamed_mask = 0;
+    if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
     if (const char* e = getenv("NVO_GRID_OWNER_SLICES")) st->owner_max_slices = (uint32_t)atoi(e);  // measurements
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
@@ -1886,7 +1920,6 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_chunks, chunks.data(), 4 * nb, hipMemcpyHostToDevice));
     }
     st->created = true;
-    if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
     if (!st->aux) {
         NVO_CHECK_HIP(hipStreamCreateWithFlags(&st->aux, hipStreamNonBlocking));
         NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
@@ -1896,6 +1929,9 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     // (a two-stage store + reduce form of the flush was measured slower)
     // measured optima for the coarse-only launch: 512 items (the atomic flush of a chunk costs as much as scanning ~2K
     // samples), 256 with the run-merging scan (cheaper scan, same flush)
+    // 8000-entry slices: 125 KiB of LDS, which leaves room for a 512-sample scatter workgroup (32.5 KiB) on the same CU
+    st->owner.fixed_cap = st->overlap ? 8000u : 0u;
+    if (const char* e = getenv("NVO_GRID_OWNER_CAP")) st->owner.fixed_cap = (uint32_t)atoi(e);  // measurements
     uint32_t owner_items = st->owner.runs ? 256 : 512;
     if (const char* e = getenv("NVO_GRID_OWNER_ITEMS")) owner_items = (uint32_t)atoi(e);  // measurements
     return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask, owner_items, false);
@@ -1938,7 +1974,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
     const uint32_t n_tiles = nvo_div_up(N, tile);
     // fork: with the per-kernel profiler on, everything stays on the caller's stream (its events live there)
-    const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !nvo_prof_enabled();
+    const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !(nvo_prof_enabled() && nvo_prof_detail());
     if (st->owner.n_slices) {  // coarse levels: slice-owner items (disjoint gradient ranges)
         NvoProfMute mute;
         if (fork) {

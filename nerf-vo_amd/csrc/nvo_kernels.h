@@ -35,6 +35,12 @@ struct NvoGridSlices {
     // consecutive samples, sums the corner contributions in registers while the cell stays the same and goes to the LDS
     // accumulators once per run (consecutive samples are neighbours on a ray, so a coarse cell holds a run of them)
     bool runs = false;
+    // option grid_bwd_batch (set before create): the batch size the launches will see.  With it (and runs) every slice
+    // gets the same number of chunks, chosen so that ALL items of the launch are resident at once (one item per CU)
+    // and a chunk is a whole number of 8192-sample passes (1024 lanes x 8 consecutive samples): an item costs ~8 us of
+    // dispatch, zeroing and flushing whatever it scans, so one round of long items beats several rounds of short ones.
+    uint32_t batch_hint = 0;
+    uint32_t fixed_cap = 0;  // (set before create) entries per 64-bit fixed-point slice of a dense level; 0 = 8192
 };
 #include <utility>
 #include <vector>

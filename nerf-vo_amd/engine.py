@@ -175,8 +175,10 @@ class NerfactoEngine:
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
-        for m, runs in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs):
+        batches = (cfg.num_nerf_samples, *cfg.num_proposal_samples)
+        for m, runs, per_ray in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs, batches):
             m.set_option("grid_bwd_runs", int(bool(runs)))
+            m.set_option("grid_bwd_batch", int(cfg.num_rays * per_ray))
         # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
         for m in self.prop_nets:
