@@ -93,6 +93,11 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *   "compact_output"            (networks with one output) only column 0 exists in memory: [batch] instead of [batch][16]
  *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones
  *   "grid_compact_live"         (mode 1) the slice-owner items scan a list of the samples whose dL/dy is non-zero
+ *   "grid_bwd_runs"             (modes 1 and 3) slice-owner items of DENSE levels scan with run merging: a lane takes 8
+ *                               consecutive samples and goes to the LDS accumulators once per run of samples that
+ *                               share a cell (consecutive samples are neighbours on a ray); off = per-sample scan
+ *   "grid_bwd_batch"            batch size the backward launches will see (0 = unknown): with "grid_bwd_runs" the
+ *                               slices are chunked so that all items of a launch are resident at once
  *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
  *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
  *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges
