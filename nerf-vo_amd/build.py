@@ -22,6 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result", "-ffp-contract=off"]
+CXXFLAGS += os.environ.get("NVO_EXTRA_CXXFLAGS", "").split()  # e.g. -DNVO_MLP_PHASE (per-phase cycle counters, debugging)
 
 
 def _sources() -> list[Path]:

@@ -194,15 +194,17 @@ __device__ __forceinline__ void load_input(const Args& a, uint32_t row, int g,
             const T* __restrict__ em = a.embedding + (size_t)cam * 32;
             x[0] = *reinterpret_cast<const T4*>(sh + 4 * g);
             const T4 b0 = *reinterpret_cast<const T4*>(bo + 4 * g);
-            const T4 b1 = *reinterpret_cast<const T4*>(bo + (g < 3 ? 4 * g + 4 : 12));  // g == 3: unused lane value
+            // (only what is used is requested: a wider load whose upper part is dead hands the dead registers back to
+            // the allocator while the load is still in flight, and their first reuse then waits for the whole prefetch)
+            const T b1 = bo[g < 3 ? 4 * g + 4 : 12];  // g == 3: unused lane value
             const T4 e0 = *reinterpret_cast<const T4*>(em + 4 * g);
-            const T4 e1 = *reinterpret_cast<const T4*>(em + 4 * g + 4);
+            const T e1 = em[4 * g + 4];
             const T4 e2 = *reinterpret_cast<const T4*>(em + 16 + 4 * g);
-            const T4 e3 = *reinterpret_cast<const T4*>(em + (g < 3 ? 20 + 4 * g : 28));
+            const T e3 = em[g < 3 ? 20 + 4 * g : 28];
             const T em0 = em[0];
-            x[1] = T4{b0[1], b0[2], b0[3], g < 3 ? b1[0] : em0};          // features 16 + 4g + j
-            x[2] = T4{e0[1], e0[2], e0[3], e1[0]};                        // embed 1 + 4g + j
-            x[3] = T4{e2[1], e2[2], e2[3], g < 3 ? e3[0] : (T)1.0f};  // embed 17 + 4g + j | pad
+            x[1] = T4{b0[1], b0[2], b0[3], g < 3 ? b1 : em0};          // features 16 + 4g + j
+            x[2] = T4{e0[1], e0[2], e0[3], e1};                        // embed 1 + 4g + j
+            x[3] = T4{e2[1], e2[2], e2[3], g < 3 ? e3 : (T)1.0f};  // embed 17 + 4g + j | pad
         }
     } else if constexpr (IO == NVO_IO_NGP_RGB) {
         if constexpr (IN_PAD == 32) {
@@ -292,11 +294,18 @@ __device__ __forceinline__ void grid_finish(const Args& a, int g, const GridGath
 }
 
 // sum over the 16 sample lanes (lane & 15) of one lane group
+// Sum over the 16 lanes of a DPP row (= the 16 samples of a tile), every lane receives the total.  Row rotations are
+// DPP modifiers of the add itself; __shfl_xor compiles to ds_bpermute_b32, an LDS round trip per step -- 64 dependent
+// ones per tile in the colour head's epilogue, which with one wave per SIMD was 38 % of the tile loop (tools/mlp_phase.py).
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_row_mov<0x128>(v);  // row_ror:8
+    v += dpp_row_mov<0x124>(v);  // row_ror:4
+    v += dpp_row_mov<0x122>(v);  // row_ror:2
+    v += dpp_row_mov<0x121>(v);  // row_ror:1
     return v;
 }
 
@@ -333,14 +342,18 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
     }
 
     // the next tile's input row is requested before the current tile is computed (see NVO_MLP_NAME(k_mlp_bwd))
-    auto load_x = [&](uint32_t tile, T4 (&xo)[IN_PAD / 16]) {
-        const uint32_t row = tile * 16 + m;
-        uint32_t cam = 0;
+    // (colour head) the camera index heads a dependent chain (index -> embedding row): requested one tile before the
+    // tile's other inputs, so that the address of the embedding row never waits for a round trip inside the loop
+    auto load_cam = [&](uint32_t tile) -> uint32_t {
         if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
-            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+            if (a.cam_idx) return (uint32_t)a.cam_idx[(tile * 16 + m) / a.samples_per_ray];
         }
-        load_input<IN_PAD, IO>(a, row, g, xo, cam);
+        return 0u;
     };
+    auto load_x = [&](uint32_t tile, T4 (&xo)[IN_PAD / 16], uint32_t cam) {
+        load_input<IN_PAD, IO>(a, tile * 16 + m, g, xo, cam);
+    };
+    uint32_t cam_nxt = 0;
     T4 x[IN_PAD / 16];
     if constexpr (IO == NVO_IO_GRID_FUSED) {
         if (wave < n_tiles) {
@@ -349,7 +362,10 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
             grid_finish<IN_PAD>(a, g, g0, x);
         }
     } else {
-        if (wave < n_tiles) load_x(wave, x);
+        if (wave < n_tiles) {
+            load_x(wave, x, load_cam(wave));
+            cam_nxt = load_cam(min(wave + n_waves, n_tiles - 1u));
+        }
     }
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
@@ -360,7 +376,8 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
             // the next tile's 16 table gathers per lane are in flight while this tile runs through the MFMA chain
             if (has_next) grid_issue<IN_PAD>(a, (tile + n_waves) * 16 + m, g, gn);
         } else {
-            load_x(min(tile + n_waves, n_tiles - 1u), xn);
+            load_x(min(tile + n_waves, n_tiles - 1u), xn, cam_nxt);
+            cam_nxt = load_cam(min(tile + 2u * n_waves, n_tiles - 1u));
         }
 
         f4 acc[WIDTH / 16];
@@ -558,18 +575,24 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         T4 dzl[OUT_PAD / 16], out[OUT_PAD / 16];
         T4 hs[N_HIDDEN][WIDTH / 16];
         T4 x[IN_PAD / 16];
+        uint32_t cam;  // (colour head) appearance-embedding row of this lane's sample
     };
     // output-activation derivative as arithmetic on wave-uniform coefficients (no per-element branches):
     // factor = 1 + c_sig * (o (1 - o) - 1) + c_relu * (step(o) - 1)
     const float c_sig = a.out_act == NVO_ACT_SIGMOID ? 1.f : 0.f, c_relu = a.out_act == NVO_ACT_RELU ? 1.f : 0.f;
-    auto load_tile = [&](uint32_t tile, TileIn& t) {
-        const uint32_t row = tile * 16 + m;
-        // the camera index heads a dependent chain (index -> embedding row): requested first, so that waiting
-        // for it does not also wait for the other loads of this tile
-        uint32_t cam = 0;
+    // The camera index heads a dependent chain (index -> embedding row).  With ONE wave per SIMD a dependent round trip
+    // inside the tile loop stalls the whole SIMD (it used to: once in load_tile for the embedding address and once more
+    // in the epilogue for the gradient's address -- half of the 55 % of wave cycles the counters showed in s_waitcnt),
+    // so the index is requested a tile earlier than the tile's other inputs and carried along with them.
+    auto load_cam = [&](uint32_t tile) -> uint32_t {
         if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
-            if (a.cam_idx) cam = (uint32_t)a.cam_idx[row / a.samples_per_ray];
+            if (a.cam_idx) return (uint32_t)a.cam_idx[(tile * 16 + m) / a.samples_per_ray];
         }
+        return 0u;
+    };
+    auto load_tile = [&](uint32_t tile, TileIn& t, uint32_t cam) {
+        const uint32_t row = tile * 16 + m;
+        t.cam = cam;
         if constexpr (COMPACT) {
             const T z = (T)0.f;
             const T dv = a.doutput[row], ov = a.output[row];  // every lane group reads, g == 0 keeps
@@ -602,11 +625,20 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         load_input<IN_PAD, IO>(a, row, g, t.x, cam);
     };
     TileIn cur;
-    if (wave < n_tiles) load_tile(wave, cur);
+    uint32_t cam_nxt = 0;
+    if (wave < n_tiles) {
+        load_tile(wave, cur, load_cam(wave));
+        cam_nxt = load_cam(min(wave + n_waves, n_tiles - 1u));
+    }
+    // Nothing issued before the loop may still be pending when it starts: the compiler's waits for such loads (weight
+    // fragments, the first tile) would sit INSIDE the loop as s_waitcnt vmcnt(N) with N counted along the entry path,
+    // and in steady state such a count also drains the previous tile's stores and float atomics.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
-        load_tile(min(tile + n_waves, n_tiles - 1u), nxt);
+        load_tile(min(tile + n_waves, n_tiles - 1u), nxt, cam_nxt);
+        cam_nxt = load_cam(min(tile + 2u * n_waves, n_tiles - 1u));
         if constexpr (COMPACT && IO == NVO_IO_HALF2_SOA) {
             // A tile whose 16 dL/dout values are all EXACTLY zero contributes nothing to any dW and its dX is zero: skip
             // the chain.  (The proposal networks of a nerfacto run: from a few hundred steps on 80-93 % of level 0's
@@ -759,27 +791,32 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
                 if constexpr (IN_PAD == 64) {
                     const uint32_t ray = row / a.samples_per_ray;
-                    const uint32_t cam = a.cam_idx ? (uint32_t)a.cam_idx[ray] : 0u;
+                    const uint32_t cam = cur.cam;
                     T* __restrict__ dbo = a.d_base_out + (size_t)row * 16;
                     // a 16-sample tile lies inside one ray when samples_per_ray % 16 == 0: reduce the
                     // per-ray quantities over the tile before touching memory
                     const bool tile_in_ray = (a.samples_per_ray & 15u) == 0u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int q = 4 * g + j;
-                        if (q < 15) dbo[1 + q] = (T)acc[1][j];
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * g + j < 15) dbo[1 + 4 * g + j] = (T)acc[1][j];
+                    if (tile_in_ray) {
+                        // After the row reduction every lane of a 16-lane row holds the sums; lane m < 4 keeps column
+                        // j = m, so one atomic instruction covers 16 consecutive floats (one 64-byte request) where a
+                        // per-j form issues four instructions with 4 lanes each.
                         // embedding columns: e0 <- feature 31, 1+q <- feature 32+q, 17+q <- feature 48+q
-                        float e_lo = acc[2][j];
-                        float e_hi = q < 15 ? acc[3][j] : 0.f;
-                        float e_0 = q == 15 ? acc[1][j] : 0.f;
-                        float s_sh = acc[0][j];
-                        if (tile_in_ray) {
-                            e_lo = group16_sum(e_lo);
-                            e_hi = group16_sum(e_hi);
-                            e_0 = group16_sum(e_0);
-                            s_sh = group16_sum(s_sh);
+                        float e_lo = 0.f, e_hi = 0.f, s_sh = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = group16_sum(acc[2][j]);
+                            const float hi = group16_sum(4 * g + j < 15 ? acc[3][j] : 0.f);
+                            const float sh = group16_sum(acc[0][j]);
+                            e_lo = m == j ? lo : e_lo;
+                            e_hi = m == j ? hi : e_hi;
+                            s_sh = m == j ? sh : s_sh;
                         }
-                        if (!tile_in_ray || m == 0) {
+                        const float e_0 = group16_sum(g == 3 ? acc[1][3] : 0.f);  // q == 15 only
+                        if (m < 4) {
+                            const int q = 4 * g + m;
                             if (a.d_embedding) {
                                 float* de = a.d_embedding + (size_t)cam * 32;
                                 atomicAdd(de + 1 + q, e_lo);
@@ -787,6 +824,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                                 if (q == 15) atomicAdd(de + 0, e_0);
                             }
                             if (a.d_sh) atomicAdd(a.d_sh + (size_t)ray * 16 + q, s_sh);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = 4 * g + j;
+                            if (a.d_embedding) {
+                                float* de = a.d_embedding + (size_t)cam * 32;
+                                atomicAdd(de + 1 + q, acc[2][j]);
+                                if (q < 15) atomicAdd(de + 17 + q, acc[3][j]);
+                                if (q == 15) atomicAdd(de + 0, acc[1][j]);
+                            }
+                            if (a.d_sh) atomicAdd(a.d_sh + (size_t)ray * 16 + q, acc[0][j]);
                         }
                     }
                 }
