@@ -64,6 +64,11 @@ static NvoMlpArgs color_args(const nvo_color_args& c) {
     return a;
 }
 
+#ifdef NVO_MLP_PHASE
+extern "C" int nvo_debug_mlp_phase(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(nvo_mlp_phase_cycles_f16), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" {
 
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args) {

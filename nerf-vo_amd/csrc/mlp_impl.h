@@ -116,6 +116,11 @@ struct WTFrag {
             *reinterpret_cast<T4*>(stage + n * kStride + k) = *reinterpret_cast<const T4*>(W + (size_t)n * K_IN + k);
         }
         __syncthreads();
+        read_staged(stage, lane);
+    }
+    // the fragment reads alone: `stage` holds W row-major with row stride K_IN + 4 (see RowStage)
+    __device__ __forceinline__ void read_staged(const T* stage, int lane) {
+        constexpr int kStride = K_IN + 4;
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
 #pragma unroll
         for (int tk = 0; tk < K_IN / 16; ++tk)
@@ -126,6 +131,28 @@ struct WTFrag {
                     (__attribute__((address_space(3))) fp16x4_t*)addr);
                 __builtin_memcpy(&f[tk][tn], &v, sizeof(T4));
             }
+    }
+};
+
+// One matrix on its way global -> registers -> LDS staging (row stride K_IN + 4 halfs).  Split in two so that a kernel
+// can have the loads of ALL its matrices in flight before the first LDS store waits for one of them.
+template <int N_OUT, int K_IN>
+struct RowStage {
+    static constexpr int kT4 = N_OUT * K_IN / 4, kTrips = (kT4 + kMlpBlock - 1) / kMlpBlock, kHalfs = N_OUT * (K_IN + 4);
+    T4 v[kTrips];
+    __device__ __forceinline__ void issue(const T* __restrict__ W) {
+#pragma unroll
+        for (int i = 0; i < kTrips; ++i) {
+            const int e = (int)threadIdx.x + i * kMlpBlock;
+            v[i] = *reinterpret_cast<const T4*>(W + 4 * (size_t)(e < kT4 ? e : 0));
+        }
+    }
+    __device__ __forceinline__ void store(T* stage) const {
+#pragma unroll
+        for (int i = 0; i < kTrips; ++i) {
+            const int e = (int)threadIdx.x + i * kMlpBlock;
+            if (e < kT4) *reinterpret_cast<T4*>(stage + ((4 * e) / K_IN) * (K_IN + 4) + (4 * e) % K_IN) = v[i];
+        }
     }
 };
 
@@ -502,10 +529,31 @@ struct DwAcc {
             }
             __syncthreads();
         }
+        // (every block adds to the same addresses in the same order; starting each block at its own offset was measured
+        // SLOWER -- 57.5 vs 56.1 us for the colour head -- the L2 handles the convoy better than a spread)
         for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
         __syncthreads();
     }
 };
+
+// -DNVO_MLP_PHASE (debugging aid, never in the product build; NVO_EXTRA_CXXFLAGS of nerf_vo_amd/build.py): wave 0 of
+// the colour-head backward sums the shader cycles it spends in each phase of the tile loop (s_memtime) and leaves them
+// in nvo_mlp_phase_cycles (read by tools/mlp_phase.py through nvo_debug_mlp_phase).
+#ifdef NVO_MLP_PHASE
+__device__ unsigned long long NVO_MLP_NAME(nvo_mlp_phase_cycles)[16];
+#define NVO_PH_DECL unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t_ = __builtin_amdgcn_s_memtime()
+#define NVO_PH_START const unsigned long long ph_start_ = __builtin_amdgcn_s_memtime()
+#define NVO_PH(k)                                                     \
+    do {                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        ph_[k] += t_ - ph_t_;                                         \
+        ph_t_ = t_;                                                   \
+    } while (0)
+#else
+#define NVO_PH_DECL
+#define NVO_PH_START
+#define NVO_PH(k)
+#endif
 
 // RECOMP (single-hidden-layer ReLU networks): the hidden activation is not read back from memory but
 // recomputed from the input row with the same MFMA sequence and the same fp16 rounding as the forward (so it
@@ -515,10 +563,16 @@ template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, b
 __global__ void __launch_bounds__(kMlpBlock)
 NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     static_assert(!RECOMP || RELU, "hidden recomputation: ReLU networks");
+    NVO_PH_START;
     const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
     constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
                                          : (IN_PAD > OUT_PAD ? IN_PAD : OUT_PAD));
-    __shared__ __attribute__((aligned(16))) T lds[kWavesPerBlock][2][16 * (MAXW + 4)];
+    // LDS: two 16-row tiles per wave (transposes); before the first tile the same bytes stage ALL weight matrices
+    constexpr int kTileHalfs = 16 * (MAXW + 4);
+    constexpr int kStageHalfs = RowStage<WIDTH, IN_PAD>::kHalfs + (N_HIDDEN - 1) * RowStage<WIDTH, WIDTH>::kHalfs +
+                                RowStage<OUT_PAD, WIDTH>::kHalfs;
+    constexpr int kLdsHalfs = kWavesPerBlock * 2 * kTileHalfs > kStageHalfs ? kWavesPerBlock * 2 * kTileHalfs : kStageHalfs;
+    __shared__ __attribute__((aligned(16))) T lds[kLdsHalfs];
 
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
@@ -526,7 +580,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     const uint32_t wave = blockIdx.x * kWavesPerBlock + wib;
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
     const uint32_t n_tiles = a.batch >> 4;
-    const LdsTile<MAXW> tz{&lds[wib][0][0]}, th{&lds[wib][1][0]};
+    const LdsTile<MAXW> tz{lds + (2 * wib) * kTileHalfs}, th{lds + (2 * wib + 1) * kTileHalfs};
 
     const bool need_dinput = a.dinput != nullptr;
 
@@ -534,29 +588,43 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     WTFrag<WIDTH, IN_PAD> wt0;
     WTFrag<WIDTH, WIDTH> wth[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
     WTFrag<OUT_PAD, WIDTH> wtl;
-    {
-        const T* W = a.weights;
-        T* stage = &lds[0][0][0];  // the wave tiles are idle until the first sample tile
-        static_assert(WIDTH * (IN_PAD + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
-                      WIDTH * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4) &&
-                      OUT_PAD * (WIDTH + 4) <= kWavesPerBlock * 2 * 16 * (MAXW + 4),
-                      "weight staging does not fit the LDS tiles");
-        if (need_dinput) wt0.load_lds(W, stage, lane);
-        W += WIDTH * IN_PAD;
-#pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            wth[l].load_lds(W, stage, lane);
-            W += WIDTH * WIDTH;
-        }
-        wtl.load_lds(W, stage, lane);
-        __syncthreads();
-    }
+    // Prologue in ONE memory round trip: the row-major copies of every matrix (for the transposed fragments), the
+    // forward fragments of the recomputation and the first tile's camera index are all requested before anything
+    // waits.  (It used to be a round trip per matrix -- copy, barrier, fragment reads, barrier -- then the forward
+    // fragments, then camera index -> embedding row: ~18 K cycles of the colour head's 110 K, tools/mlp_phase.py.)
     WFrag<WIDTH, IN_PAD> w0f;  // forward weights (hidden recomputation only)
     WFrag<WIDTH, WIDTH> whf[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
-    if constexpr (RECOMP) {
-        w0f.load(a.weights, lane);
+    uint32_t cam_first = 0;
+    {
+        const T* W = a.weights;
+        RowStage<WIDTH, IN_PAD> s0;
+        RowStage<WIDTH, WIDTH> sh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+        RowStage<OUT_PAD, WIDTH> sl;
+        if (need_dinput) s0.issue(W);
 #pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load(a.weights + WIDTH * IN_PAD + l * WIDTH * WIDTH, lane);
+        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].issue(W + WIDTH * IN_PAD + l * WIDTH * WIDTH);
+        sl.issue(W + WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH);
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx && wave < n_tiles) cam_first = (uint32_t)a.cam_idx[(wave * 16 + m) / a.samples_per_ray];
+        }
+        if constexpr (RECOMP) {
+            w0f.load(W, lane);
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load(W + WIDTH * IN_PAD + l * WIDTH * WIDTH, lane);
+        }
+        T* stage = lds;  // the wave tiles are idle until the first sample tile
+        T* stage_h = stage + RowStage<WIDTH, IN_PAD>::kHalfs;
+        T* stage_l = stage_h + (N_HIDDEN - 1) * RowStage<WIDTH, WIDTH>::kHalfs;
+        if (need_dinput) s0.store(stage);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].store(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs);
+        sl.store(stage_l);
+        __syncthreads();
+        if (need_dinput) wt0.read_staged(stage, lane);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) wth[l].read_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
+        wtl.read_staged(stage_l, lane);
+        __syncthreads();  // the staging bytes become the wave tiles
     }
     DwAcc<WIDTH, IN_PAD> dw0;
     DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
@@ -627,18 +695,24 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     TileIn cur;
     uint32_t cam_nxt = 0;
     if (wave < n_tiles) {
-        load_tile(wave, cur, load_cam(wave));
+        load_tile(wave, cur, cam_first);
         cam_nxt = load_cam(min(wave + n_waves, n_tiles - 1u));
     }
     // Nothing issued before the loop may still be pending when it starts: the compiler's waits for such loads (weight
     // fragments, the first tile) would sit INSIDE the loop as s_waitcnt vmcnt(N) with N counted along the entry path,
     // and in steady state such a count also drains the previous tile's stores and float atomics.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    NVO_PH_DECL;
+#ifdef NVO_MLP_PHASE
+    ph_[10] = ph_t_ - ph_start_;  // prologue: weight staging, fragment loads, first tile
+#endif
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
+        NVO_PH(9);
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
         load_tile(min(tile + n_waves, n_tiles - 1u), nxt, cam_nxt);
         cam_nxt = load_cam(min(tile + 2u * n_waves, n_tiles - 1u));
+        NVO_PH(0);
         if constexpr (COMPACT && IO == NVO_IO_HALF2_SOA) {
             // A tile whose 16 dL/dout values are all EXACTLY zero contributes nothing to any dW and its dX is zero: skip
             // the chain.  (The proposal networks of a nerfacto run: from a few hundred steps on 80-93 % of level 0's
@@ -690,6 +764,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         }
 #pragma unroll
         for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
+        NVO_PH(1);
         // dW_last += dZ_L^T H
         {
 #pragma unroll
@@ -705,6 +780,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             dwl.accumulate(zt, ht);
             wave_lds_sync();
         }
+        NVO_PH(2);
         // dZ of the last hidden layer
         T4 dz[WIDTH / 16];
         {
@@ -716,6 +792,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                 for (int j = 0; j < 4; ++j)
                     dz[t][j] = (T)(acc[t][j] * act_bwd_from_out(hidden_act, (float)h[t][j]));
         }
+        NVO_PH(3);
         // ---- hidden layers N_HIDDEN-1 .. 1 (weights wh[l-1] map H_{l-1} -> H_l)
 #pragma unroll
         for (int l = N_HIDDEN - 1; l >= 1; --l) {
@@ -746,6 +823,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                 for (int j = 0; j < 4; ++j)
                     dz[t][j] = (T)(acc[t][j] * act_bwd_from_out(hidden_act, (float)hp_[t][j]));
         }
+        NVO_PH(4);
         // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
         {
             T4 x[IN_PAD / 16];
@@ -764,9 +842,11 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             dw0.accumulate(zt, xt);
             wave_lds_sync();
         }
+        NVO_PH(5);
         if (need_dinput) {
             f4 acc[IN_PAD / 16];
             layer_mm_t<WIDTH, IN_PAD>(wt0, dz, acc);
+            NVO_PH(6);
             if constexpr (IO == NVO_IO_F32_ROWS) {
                 float* __restrict__ p = (float*)a.dinput + (size_t)row * a.n_in;
 #pragma unroll
@@ -859,13 +939,14 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                 }
             }
         }
+        NVO_PH(7);
         cur = nxt;
+        NVO_PH(8);
     }
-
     // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
     if (a.dweights) {
         __syncthreads();  // every wave is done with its LDS tiles
-        float* red = reinterpret_cast<float*>(&lds[0][0][0]);
+        float* red = reinterpret_cast<float*>(lds);
         constexpr int kLdsFloats = (int)(sizeof(lds) / sizeof(float));
         static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
                       "dW block reduction does not fit the LDS tiles");
@@ -879,6 +960,13 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         }
         dwl.flush_block(dW, red, lane, wib);
     }
+#ifdef NVO_MLP_PHASE
+    NVO_PH(11);  // dW flush (block reduction through LDS + float atomics)
+    if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+        if (wave == 0 && lane == 0)
+            for (int k = 0; k < 12; ++k) NVO_MLP_NAME(nvo_mlp_phase_cycles)[k] = ph_[k];
+    }
+#endif
 }
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>

@@ -19,7 +19,8 @@ from nerf_vo_amd.synthetic import make_sequence  # noqa: E402
 
 NAMES = ["issue next tile's loads", "output layer + forward recompute", "dW_last (transposes + MFMA)", "dZ last hidden",
          "hidden layers (transposes, dW, chain)", "dW0 (transposes + MFMA)", "dX chain", "epilogue (stores, atomics)",
-         "cur = nxt (wait for the prefetch)", "loop overhead"]
+         "cur = nxt (wait for the prefetch)", "loop overhead", "PROLOGUE (weights, first tile), whole kernel",
+         "dW FLUSH (LDS reduction + atomics), whole kernel"]
 
 
 def main():
@@ -44,6 +45,8 @@ def main():
     print(f"wave 0: {tot} cycles in the tile loop, {tiles} tiles -> {tot / tiles:.0f} cycles per tile")
     for k in (9, 0, 1, 2, 3, 4, 5, 6, 7, 8):
         print(f"  {NAMES[k]:42s} {out[k] / tiles:9.0f} cycles/tile  {100.0 * out[k] / tot:5.1f} %")
+    for k in (10, 11):
+        print(f"  {NAMES[k]:50s} {out[k]:9d} cycles")
 
 
 if __name__ == "__main__":
