@@ -24,8 +24,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kMaxPatches = 1024;  // patches per frame held in LDS
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = nvo_wave_sum(v);  // DPP form (nvo_common.h)
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[wave] = v;

@@ -592,11 +592,8 @@ k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long l
             b += fabsf(d.y);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off, 64);
-        b += __shfl_xor(b, off, 64);
-    }
+    a = nvo_wave_sum(a);
+    b = nvo_wave_sum(b);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = a;
         red[1][threadIdx.x >> 6] = b;
@@ -900,14 +897,7 @@ __device__ __forceinline__ uint2 rec_pack(uint32_t rel, float v0, float v1) {
     return make_uint2((a & ~0x3Fu) | (rel & 0x3Fu), (b & ~0x7Fu) | (rel >> 6));
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return nvo_wave_incl_scan(v); }  // DPP
 
 // grid = (n_tiles, n_levels).  counts[(bin_first[level] + b) * n_tiles + tile]
 template <int TILE, bool SOA, typename DY2>
@@ -1096,7 +1086,7 @@ k_st_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
             const uint32_t cnt = b < n_slices ? hist[b] : 0u;
             const uint32_t incl = wave_incl_scan_u32(cnt, lane);
             if (b < n_slices) loff[b] = carry + incl - cnt;
-            carry += __shfl(incl, 63, 64);
+            carry += nvo_wave_bcast(incl, 63);
         }
         if (lane == 0) total_s = carry;
     }
@@ -1281,7 +1271,7 @@ k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
                 loff[b] = carry + incl - cnt;
                 seg[(size_t)(bin0 + b) * n_tiles + tile] = (carry + incl - cnt) | (cnt << 16) | bad_bit;
             }
-            carry += __shfl(incl, 63, 64);
+            carry += nvo_wave_bcast(incl, 63);
         }
         if (lane == 0) total_s = carry;
     }

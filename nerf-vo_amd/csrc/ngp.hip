@@ -14,19 +14,9 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
+// (DPP forms, nvo_common.h)
+__device__ __forceinline__ float wave_sum(float v) { return nvo_wave_sum(v); }
+__device__ __forceinline__ float wave_incl_scan(float v, int) { return nvo_wave_incl_scan(v); }
 
 // x01 = (o + t d - aabb_lo) * aabb_inv_size for every packed slot; slots with ray_idx < 0 -> zeros
 __global__ void __launch_bounds__(256)
@@ -80,11 +70,8 @@ k_ngp_positions_bwd(uint32_t R, uint32_t capacity, const int32_t* __restrict__ c
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) {
-            go[k] += __shfl_xor(go[k], sh, 64);
-            gd[k] += __shfl_xor(gd[k], sh, 64);
-        }
+        go[k] = nvo_wave_sum(go[k]);
+        gd[k] = nvo_wave_sum(gd[k]);
     }
     if (lane == 0) {
 #pragma unroll
@@ -131,7 +118,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         for (int k = 0; k < 3; ++k) pix[k] += wave_sum(w * rgb[k]);
         depth += wave_sum(w * tj);
         acc += wave_sum(w);
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
     const float T_final = __expf(-carry);
     float bg[3] = {0.f, 0.f, 0.f};
@@ -198,7 +185,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
             q = w * dot;
         }
         total_q += wave_sum(q);
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
     const float g_bg = T_final * (g_pix[0] * bg[0] + g_pix[1] * bg[1] + g_pix[2] * bg[2]);
     carry = 0.f;
@@ -237,8 +224,8 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
                 d_rgb[s * a.d_rgb_stride + k] = (_Float16)(w * g_pix[k] * rgb[k] * (1.f - rgb[k]) * a.loss_scale);
             for (uint32_t k = 3; k < a.d_rgb_stride; ++k) d_rgb[s * a.d_rgb_stride + k] = (_Float16)0.f;
         }
-        carry = __shfl(incl, 63, 64);
-        carry_q = __shfl(incl_q, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
+        carry_q = nvo_wave_bcast(incl_q, 63);
     }
 }
 

@@ -177,6 +177,58 @@ __device__ __forceinline__ void nvo_sh4_eval(float x, float y, float z, uint32_t
 }
 
 
+// ---- wave64 cross-lane primitives as DPP modifiers -------------------------------------------------
+// __shfl / __shfl_up / __shfl_xor compile to ds_bpermute_b32: an LDS round trip (~100+ cycles) per step, six dependent
+// ones per scan or reduction.  The per-ray kernels are one wave per ray and do little else between their scans, so the
+// steps are written as DPP row shifts / row broadcasts (gfx9 family: row_shr:n inside a row of 16, row_bcast:15 / :31
+// across rows), which ride on the add itself.  Identity 0: a lane without a source adds 0.
+#if defined(__HIPCC__)
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float nvo_dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t nvo_dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ float nvo_wave_incl_scan(float v) {
+    v += nvo_dpp_f32<0x111>(v);          // row_shr:1
+    v += nvo_dpp_f32<0x112>(v);          // row_shr:2
+    v += nvo_dpp_f32<0x114>(v);          // row_shr:4
+    v += nvo_dpp_f32<0x118>(v);          // row_shr:8   -> inclusive scan inside every row of 16
+    v += nvo_dpp_f32<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+    v += nvo_dpp_f32<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t nvo_wave_incl_scan(uint32_t v) {
+    v += nvo_dpp_u32<0x111>(v);
+    v += nvo_dpp_u32<0x112>(v);
+    v += nvo_dpp_u32<0x114>(v);
+    v += nvo_dpp_u32<0x118>(v);
+    v += nvo_dpp_u32<0x142, 0xA>(v);
+    v += nvo_dpp_u32<0x143, 0xC>(v);
+    return v;
+}
+// value of one lane (wave-uniform index) in every lane
+__device__ __forceinline__ float nvo_wave_bcast(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src_lane)));
+}
+__device__ __forceinline__ uint32_t nvo_wave_bcast(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src_lane));
+}
+// sum over the 64 lanes, in every lane
+__device__ __forceinline__ float nvo_wave_sum(float v) {
+    v += nvo_dpp_f32<0x128>(v);          // row_ror:8
+    v += nvo_dpp_f32<0x124>(v);          // row_ror:4
+    v += nvo_dpp_f32<0x122>(v);          // row_ror:2
+    v += nvo_dpp_f32<0x121>(v);          // row_ror:1   -> every lane holds its row's total
+    v += nvo_dpp_f32<0x142, 0xA>(v);     // rows 1, 3 += rows 0, 2
+    v += nvo_dpp_f32<0x143, 0xC>(v);     // rows 2, 3 += row 1 (= rows 0 + 1): lane 63 holds the total
+    return nvo_wave_bcast(v, 63);
+}
+#endif
+
 // ---- device helpers shared by grid kernels -------------------------------------------------
 __device__ __forceinline__ uint32_t nvo_grid_index(uint32_t hashed, uint32_t hashmap_size,
                                                    uint32_t res, uint32_t px, uint32_t py,

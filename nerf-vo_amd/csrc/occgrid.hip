@@ -253,7 +253,7 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
                     pos = u;
                     skip_to = -3.0e38f;
                 } else {
-                    skip_to = __shfl(exit_t, (int)k, 64);
+                    skip_to = nvo_wave_bcast(exit_t, (int)k);
                     pos = k + 1u;
                 }
             }
@@ -285,14 +285,7 @@ k_occ_compact(uint32_t R, const uint32_t* __restrict__ counts, const uint32_t* _
     }
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return nvo_wave_incl_scan(v); }  // DPP
 
 // Single-workgroup exclusive scan of counts[n] -> offsets[n], total in offsets[n]; entries that would
 // push the running total beyond `capacity` are treated as 0 (and zeroed in counts).

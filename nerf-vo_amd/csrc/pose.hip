@@ -15,9 +15,7 @@
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return nvo_wave_sum(v);  // DPP form (nvo_common.h)
 }
 
 // One wave per ray: lanes stride over the ray's samples.

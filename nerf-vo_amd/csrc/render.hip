@@ -25,20 +25,9 @@ constexpr int kRaysPerBlock = kRayBlock / 64;
 constexpr int kMaxS = 256;              // samples per ray handled by the LDS scratch
 constexpr float kLossEps = 1.0e-7f;     // nerfstudio losses.EPS
 
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+// (DPP forms, nvo_common.h: the shuffle forms were six dependent LDS round trips each)
+__device__ __forceinline__ float wave_incl_scan(float v, int) { return nvo_wave_incl_scan(v); }
+__device__ __forceinline__ float wave_sum(float v) { return nvo_wave_sum(v); }
 
 __device__ __forceinline__ float nan_to_num(float v) {
     if (isnan(v)) return 0.f;
@@ -81,7 +70,7 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const nvo_h16*
             w[i] = nan_to_num((1.f - __expf(-dd)) * T);
             Tr[i] = T;
         }
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
 }
 
@@ -125,7 +114,7 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const nvo_
                 dpre[(size_t)i * dpre_stride] = nvo_cvt16(d * loss_scale, bf);
             }
         }
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
 }
 
@@ -167,7 +156,7 @@ k_weights_pdf(nvo_weights_pdf_args a) {
         const float p = (i < S) ? (Tr[i] + pad_each) / sum : 0.f;
         const float incl = wave_incl_scan(p, lane) + carry;
         if (i < S) cdf[i + 1] = fminf(1.f, incl);
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -243,7 +232,7 @@ k_main_render_loss(nvo_main_loss_args a) {
     float pix[3], clast[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        clast[k] = __shfl(c[k], (int)S - 1, 64);
+        clast[k] = nvo_wave_bcast(c[k], (int)S - 1);
         pix[k] = wave_sum(wi * c[k]) + clast[k] * (1.f - acc);
     }
     const float mid = act ? 0.5f * (tb[lane] + tb[lane + 1]) : 0.f;
@@ -251,7 +240,7 @@ k_main_render_loss(nvo_main_loss_args a) {
     const float cum = wave_incl_scan(wi, lane);
     const unsigned long long ballot = __ballot(act && cum >= 0.5f);
     const int med = ballot ? (int)__builtin_ctzll(ballot) : (int)S - 1;
-    const float depth_med = __shfl(mid, med, 64);
+    const float depth_med = nvo_wave_bcast(mid, med);
     if (lane == 0) {
         a.out_rgb[3 * (size_t)r + 0] = pix[0];
         a.out_rgb[3 * (size_t)r + 1] = pix[1];
@@ -455,7 +444,7 @@ k_prop_loss(nvo_prop_loss_args a) {
         const float v = (i < S) ? w[i] : 0.f;
         const float incl = wave_incl_scan(v, lane) + carry;
         if (i < S) cy[i + 1] = incl;
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
     }
     if (lane == 0) cy[0] = 0.f;
     for (uint32_t i = lane; i < S + 2; i += 64) g[i] = 0.f;
@@ -496,7 +485,7 @@ k_prop_loss(nvo_prop_loss_args a) {
         const uint32_t i = base + lane;
         const float v = (i < S) ? g[i] : 0.f;
         const float incl = wave_incl_scan(v, lane) + carry;
-        carry = __shfl(incl, 63, 64);
+        carry = nvo_wave_bcast(incl, 63);
         float gi = incl;
         if (i < S && use_depth) {
             const float midp = 0.5f * (tb[i] + tb[i + 1]);
