@@ -55,15 +55,32 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const nvo_h16*
                                             const float* __restrict__ tb, float bias,
                                             float* __restrict__ sigma_out, float* w, float* Tr) {
     float carry = 0.f;
+    // One wave walks the ray in chunks of 64 samples with a carry between them: the NEXT chunk's inputs are requested
+    // (unconditionally, at a clamped index: a load behind a divergent branch makes the join wait for everything in
+    // flight) before the current chunk is scanned, so a 256-sample ray pays one memory round trip instead of four.
+    struct In { float x0, pr, t0, t1; };
+    auto fetch = [&](uint32_t base) {
+        const uint32_t i = min(base + (uint32_t)lane, S - 1u);
+        In v;
+        v.x0 = x01[3 * (size_t)i];
+        v.pr = nvo_ld16(pre + (size_t)i * pre_stride, bf);
+        v.t0 = tb[i];
+        v.t1 = tb[i + 1];
+        return v;
+    };
+    In cur = fetch(0);
     for (uint32_t base = 0; base < S; base += 64) {
         const uint32_t i = base + lane;
+        In nxt = cur;
+        if (base + 64 < S) nxt = fetch(base + 64);  // (wave-uniform; single-chunk rays request nothing twice)
         float dd = 0.f, sg = 0.f;
         if (i < S) {
-            const bool sel = x01[3 * (size_t)i] > 0.f;
-            sg = sel ? __expf(nvo_ld16(pre + (size_t)i * pre_stride, bf) + bias) : 0.f;
-            dd = (tb[i + 1] - tb[i]) * sg;
+            const bool sel = cur.x0 > 0.f;
+            sg = sel ? __expf(cur.pr + bias) : 0.f;
+            dd = (cur.t1 - cur.t0) * sg;
             if (sigma_out) sigma_out[i] = sg;
         }
+        cur = nxt;
         const float incl = wave_incl_scan(dd, lane) + carry;
         const float T = __expf(-(incl - dd));
         if (i < S) {
