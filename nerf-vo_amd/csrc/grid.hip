@@ -148,8 +148,24 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                                 c.pz + ((k >> 2) & 1u));
     }
     __half2 v[8];
+    if (!hashed) {
+        // dense level: the two x corners of a (y, z) pair are neighbours in memory -- one 8-byte load instead of two
+        // 4-byte gathers (dword alignment suffices); a pair that straddles the table's wrap takes two loads
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) v[k] = tab[idx[k]];
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (idx[2 * j + 1] == idx[2 * j] + 1u) {
+                const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(tab) + idx[2 * j]);
+                v[2 * j] = __builtin_bit_cast(__half2, q.x);
+                v[2 * j + 1] = __builtin_bit_cast(__half2, q.y);
+            } else {
+                v[2 * j] = tab[idx[2 * j]];
+                v[2 * j + 1] = tab[idx[2 * j + 1]];
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = tab[idx[k]];
+    }
 
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
