@@ -657,7 +657,10 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 // items combine with float atomics either way).
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(1024)
-k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ out) {
+k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ out,
+               unsigned long long* __restrict__ l1) {
+    // l1 != nullptr (32-bit accumulators, <= 8 levels): the per-level L1 norms of dy that k_dy_l1 computes are summed
+    // in the same pass -- both kernels read every dy once, and each cost ~14 us per 1 M-sample launch
     // one workgroup per 4096 consecutive samples, ONE global atomic per workgroup (a wave-level append put 16 K atomics
     // on one address for a 1 M-sample batch: the single counter serialised them -- +40 us per launch)
     constexpr uint32_t kPer = 4;
@@ -667,20 +670,56 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
     const uint32_t first = blockIdx.x * (1024u * kPer);
     bool live[kPer];
     uint32_t mine = 0;
+    constexpr uint32_t kL1Levels = 8;
+    float la[kL1Levels], lb[kL1Levels];
+#pragma unroll
+    for (uint32_t l = 0; l < kL1Levels; ++l) la[l] = lb[l] = 0.f;
+    __shared__ float l1_red[16][kL1Levels][2];
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) {
         const uint32_t i = first + q * 1024u + threadIdx.x;
         live[q] = false;
         if (i < N) {
-            for (uint32_t l = 0; l < g.n_levels; ++l) {
-                const float2 d = dy2f(SOA ? dy[(size_t)l * N + i] : dy[(size_t)i * g.n_levels + l]);
-                live[q] = live[q] || d.x != 0.f || d.y != 0.f;  // (NaN != 0: non-finite gradients stay listed)
+            if (l1) {
+#pragma unroll
+                for (uint32_t l = 0; l < kL1Levels; ++l) {
+                    if (l < g.n_levels) {
+                        const float2 d = dy2f(SOA ? dy[(size_t)l * N + i] : dy[(size_t)i * g.n_levels + l]);
+                        live[q] = live[q] || d.x != 0.f || d.y != 0.f;
+                        la[l] += fabsf(d.x);
+                        lb[l] += fabsf(d.y);
+                    }
+                }
+            } else {
+                for (uint32_t l = 0; l < g.n_levels; ++l) {
+                    const float2 d = dy2f(SOA ? dy[(size_t)l * N + i] : dy[(size_t)i * g.n_levels + l]);
+                    live[q] = live[q] || d.x != 0.f || d.y != 0.f;  // (NaN != 0: non-finite gradients stay listed)
+                }
             }
         }
         mine += (uint32_t)__popcll(__ballot(live[q]));  // (wave total of pass q, same in every lane)
     }
+    if (l1) {
+#pragma unroll
+        for (uint32_t l = 0; l < kL1Levels; ++l) {
+            if (l < g.n_levels) {  // (wave-uniform)
+                const float a = nvo_wave_sum(la[l]), b = nvo_wave_sum(lb[l]);
+                if (lane == 0u) {
+                    l1_red[wib][l][0] = a;
+                    l1_red[wib][l][1] = b;
+                }
+            }
+        }
+    }
     if (lane == 0u) wave_cnt[wib] = mine;
     __syncthreads();
+    if (l1 && threadIdx.x < 2u * g.n_levels) {
+        const uint32_t l = threadIdx.x >> 1, f = threadIdx.x & 1u;
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += l1_red[w][l][f];
+        // round UP to the 2^-8 grid: the sum must not under-estimate (it bounds every accumulator) -- as k_dy_l1
+        atomicAdd(&l1[2 * l + f], (unsigned long long)ceilf(t * 256.f) + 1ull);
+    }
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < 16; ++w) {
@@ -2142,6 +2181,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
         const size_t lds = slices->lds_bytes;
         const uint32_t* live = nullptr;
+        bool l1_fused = false;
         if (slices->compact_live) {
             if ((size_t)N + 1 > slices->live_cap) {  // grows during warm-up only; never while a graph is being captured
                 if (slices->d_live) NVO_CHECK_HIP(hipFree(slices->d_live));
@@ -2151,13 +2191,18 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                 slices->live_cap = (size_t)N + 1;
             }
             if (int rc = nvo_zero_async(slices->d_live, sizeof(uint32_t), stream)) return rc;
-#define NVO_LAUNCH_LIVE(SOA_, T_) \
-    NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, slices->d_live)
+            // (32-bit accumulators, <= 8 levels: the L1 norms of dy ride in the same pass)
+            l1_fused = slices->acc_bits == 32 && g.n_levels <= 8 && dy_fmt != NVO_DY_FLOAT;
+            if (l1_fused && !slices->external_zero)
+                if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
+#define NVO_LAUNCH_LIVE(SOA_, T_)                                                                                    \
+    NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, \
+               slices->d_live, l1_fused ? slices->d_l1 : nullptr)
             if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
 #undef NVO_LAUNCH_LIVE
             live = slices->d_live;
         }
-        if (slices->acc_bits == 32) {
+        if (slices->acc_bits == 32 && !l1_fused) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (!slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;

@@ -544,8 +544,11 @@ def test_zero_gradient_samples_are_skipped_exactly(device, zero_frac):
     n_net = 16 * 16 + 16 * 16
     assert torch.equal(res["ref"][0], res["skip"][0])
     assert torch.equal(res["ref"][1], res["skip"][1]), "dL/dx differs"
-    # (multi-chunk slices and the MLP weight gradient are flushed with float atomics: equal up to summation order)
-    _assert_close(res["skip"][2][n_net:], res["ref"][2][n_net:], rtol=1e-4, atol_scale=1e-6, what="grid gradient, live list")
+    # (multi-chunk slices and the MLP weight gradient are flushed with float atomics: equal up to summation order.  The
+    # grid gradient accumulates in int32 with the scale 2^29 / L1(dy): with the live list the L1 norms are summed inside
+    # k_live_samples, without it by k_dy_l1 -- another summation order, a scale that differs in its last bits, hence
+    # every addend rounded to the integer grid independently in the two runs: quantum L1 / 2^29 per addend.)
+    _assert_close(res["skip"][2][n_net:], res["ref"][2][n_net:], rtol=1e-3, atol_scale=2e-5, what="grid gradient, live list")
     _assert_close(res["skip"][2][:n_net], res["ref"][2][:n_net], rtol=1e-4, atol_scale=1e-6, what="dW with skipped tiles")
     if zero_frac == 1.0:
         assert float(res["skip"][2].abs().max()) == 0.0 and float(res["skip"][1].abs().max()) == 0.0
