@@ -83,7 +83,7 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *                           (what the engine selects for the main field)
  *   "grid_stream_layout"        (mode 3) 1 = tile-local records, no count / scan passes (default); 0 = globally sorted
  *   "grid_stream_tile"          (mode 3) samples per scatter workgroup: 256 | 512 (default) | 1024
- *   "grid_stream_owner_slices"  (mode 3) levels with at most this many 8K-entry slices stay slice-owner (default 12)
+ *   "grid_stream_owner_slices"  (mode 3) levels with at most this many 4K-entry bins stay slice-owner (default 24)
  *   "grid_stream_overlap"       (mode 3) 1 = coarse-level launch on an auxiliary stream beside the record pipeline
  *   "grid_acc_bits"             accumulators of the slice-owner items: 64 (2^26 fixed point, default) | 32 (int32 with
  *                               a data-derived overflow-proof scale; needs 16-bit dL/dy)

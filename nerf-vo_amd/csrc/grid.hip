@@ -744,7 +744,7 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
 // ------------------------------------------------------------------------------------------
 // The slice-owner kernel above re-derives every sample's corner hashes once per slice of a level
 // (26-64x redundancy).  The binned form derives them a constant three times instead:
-//   k_bin_count   : per (sample, hashed level) count the corner lookups per 8K-entry slice (LDS
+//   k_bin_count   : per (sample, hashed level) count the corner lookups per kBinSlice-entry slice (LDS
 //                   integer histogram per workgroup, one global add per non-empty bin)
 //   k_bin_scan    : exclusive scan of the <= 2048 bin totals (one workgroup)
 //   k_bin_scatter : same histogram -> one range reservation per (workgroup, bin) -> 4-byte records
@@ -752,7 +752,11 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
 //   k_bin_accumulate: one workgroup per bin walks ITS records only, re-derives weight and entry of
 //                   that single corner, accumulates in 64-bit fixed point in LDS (integer atomics),
 //                   and writes the slice with plain stores -> bitwise reproducible gradients.
-constexpr uint32_t kBinSlice = 8192;
+// Entries per bin of the binned / streamed forms.  4096 (64 KiB of 64-bit accumulator pairs) since the end of round 2:
+// TWO accumulate workgroups fit a CU, and while one of them only loads its records the other one converts / adds /
+// flushes -- with 8192-entry bins (one 128 KiB workgroup per CU) every CU of the chip was in the same phase at the same
+// time (k_tl_accumulate 77 -> 70 us).
+constexpr uint32_t kBinSlice = 4096;
 constexpr int kBinBlock = 256;
 
 template <bool SOA, typename DY2>
@@ -926,7 +930,7 @@ k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
 // ------------------------------------------------------------------------------------------
 // Mode 2's accumulate pass is bound by the dependent random gathers of x / dy behind every 4-byte
 // record, mode 1 by re-deriving every corner hash once per slice.  Here:
-//   k_st_count   : tile of 1024 samples x one level -> LDS histogram over the level's 8K-entry bins ->
+//   k_st_count   : tile of 1024 samples x one level -> LDS histogram over the level's kBinSlice-entry bins ->
 //                  counts[bin][tile] with plain stores
 //   k_st_scan_tiles : per bin, exclusive scan over the tiles (in place) + bin total
 //   k_st_scan_bins  : exclusive scan of the bin totals -> base[]; builds the accumulate work items
@@ -1359,7 +1363,7 @@ k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2
 // the tile count, and a wave's segment words are one contiguous read); and a wave reads its runs as one
 // concatenated record stream, all of whose loads are in flight at once (see the loop).
 constexpr uint32_t kTlWin = 26;  // wave loads per pass: 24 runs x 64 records of a hashed level + slack
-constexpr int kTlBlock = 1024;
+constexpr int kTlBlock = 512;  // two workgroups per CU (2 x 64 KiB of accumulators): their phases overlap
 
 struct TlItem {
     uint32_t bin, chunk, n_chunks, lvl, level, slice, t0, t1;
@@ -1891,7 +1895,7 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
 
 // ---- mode 3 host side ---------------------------------------------------------------------------
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
-    // Levels with many 8K-entry bins are streamed; levels with <= kStOwnerSlices slices (the coarse dense
+    // Levels with many kBinSlice-entry bins are streamed; levels with <= kStOwnerSlices slices (the coarse dense
     // ones: almost every lookup hits every slice, the redundancy of the slice-owner form is small and the
     // per-bin record lists would be long and conflict-heavy) keep slice-owner work items.
     std::vector<uint32_t> levels, first, bin_level, bin_slice;
@@ -2068,7 +2072,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             if (!st->external_zero)                                                                          \
                 NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                            st->d_bin_chunks, grad);                                                          \
-            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < n_cus ? st->n_tl_items : n_cus), dim3(kTlBlock), \
+            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlock), \
                        lds_acc_tl, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, records_tl, \
                        n_tiles, (uint32_t)tile_records, grad);                                               \
         }                                                                                                    \

@@ -72,13 +72,13 @@ void nvo_grid_bins_destroy(NvoGridBins* b);
 int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
                                const float* x, const void* dy, int dy_fmt, bool soa, float* grad);
 
-// Streamed binned backward (mode 3): levels with many 8K-entry bins go through count / scan / scatter of
+// Streamed binned backward (mode 3): levels with many 4K-entry bins go through count / scan / scatter of
 // self-contained 8-byte records / streaming accumulate; the coarse levels keep slice-owner items.
 struct NvoGridStream {
     bool created = false;
     uint32_t n_levels = 0, n_bins = 0, max_slices = 0;
     uint32_t streamed_mask = 0;
-    uint32_t owner_max_slices = 12;   // levels with at most this many 8K-entry slices stay slice-owner (measured optimum)
+    uint32_t owner_max_slices = 24;   // levels with at most this many 4K-entry bins stay slice-owner (measured optimum: levels 0-3 of the main grid)
     uint32_t tile = 512;              // samples per count / scatter workgroup (256 | 512 | 1024)
     uint32_t* d_meta = nullptr;       // one allocation holding the arrays below
     uint32_t* d_levels = nullptr;     // [n_levels] streamed level ids
