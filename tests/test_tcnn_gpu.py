@@ -587,6 +587,8 @@ def test_run_merged_dense_levels_match_slice_owner(device, cfg, acc_bits, live):
     params = None
     for tag, runs in (("owner", 0), ("runs", 1)):
         m = _raw_nwie(device, cfg, True, acc_bits=acc_bits, runs=runs, compact_live=live)
+        if runs:  # a batch hint that does NOT match the launch (the chunking is a tuning input, never a contract)
+            m.set_option("grid_bwd_batch", 3 * N + 16)
         if params is None:
             params = (torch.randn(m.n_params, generator=g) * 0.3).to(device)
         ph = params.half()
