@@ -122,91 +122,115 @@ __device__ __forceinline__ Corner grid_cell(float scale, float x, float y, float
 //          input then is a coalesced stream instead of a second pass of 8 gathers per (sample, level).  Kept in
 //          CELL units (the level's scale is applied by the consumer) so that it has the magnitude of a table
 //          difference and fits fp16 like the table itself.
-template <bool SOA, bool DYDX>
+// SPT samples per thread (tile = SPT * kGridBlock samples, sample s of a thread is kGridBlock apart from sample s - 1:
+// coalescing as before): the kernel is two dependent memory round trips per (sample, level) -- position, then the
+// corner gathers -- and at full occupancy its time is (rounds of resident workgroups) x (that latency); with the gathers
+// of SPT samples in flight per thread the rounds shrink by SPT.
+template <bool SOA, bool DYDX, int SPT>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
            const __half2* __restrict__ table, __half2* __restrict__ out,
            uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16) {
     uint32_t tile, level;
     grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
-    const uint32_t i = tile * kGridBlock + threadIdx.x;
-    if (i >= N) return;
+    const uint32_t i_first = tile * (kGridBlock * SPT) + threadIdx.x;
+    if (i_first >= N) return;
 
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
     const uint32_t res = g.resolution[level];
     const uint32_t hashed = g.hashed[level];
     const __half2* __restrict__ tab = table + off;
+    const float scale = g.scale[level];
 
-    const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1],
-                               x[3 * (size_t)i + 2]);
-
-    uint32_t idx[8];
+    // every load is unconditional (a sample past the end reads sample N - 1 again and stores nothing): loads behind a
+    // divergent branch would make the join wait for everything in flight
+    uint32_t i[SPT];
+    float px[SPT][3];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
-                                c.pz + ((k >> 2) & 1u));
+    for (int s = 0; s < SPT; ++s) {
+        i[s] = i_first + (uint32_t)s * kGridBlock;
+        const uint32_t ic = min(i[s], N - 1u);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) px[s][k] = x[3 * (size_t)ic + k];
     }
-    __half2 v[8];
-    if (!hashed) {
-        // dense level: the two x corners of a (y, z) pair are neighbours in memory -- one 8-byte load instead of two
-        // 4-byte gathers (dword alignment suffices); a pair that straddles the table's wrap takes two loads
+    Corner c[SPT];
+    uint32_t idx[SPT][8];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (idx[2 * j + 1] == idx[2 * j] + 1u) {
-                const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(tab) + idx[2 * j]);
-                v[2 * j] = __builtin_bit_cast(__half2, q.x);
-                v[2 * j + 1] = __builtin_bit_cast(__half2, q.y);
-            } else {
-                v[2 * j] = tab[idx[2 * j]];
-                v[2 * j + 1] = tab[idx[2 * j + 1]];
+    for (int s = 0; s < SPT; ++s) {
+        c[s] = grid_cell(scale, px[s][0], px[s][1], px[s][2]);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            idx[s][k] = nvo_grid_index(hashed, size, res, c[s].px + (k & 1u), c[s].py + ((k >> 1) & 1u),
+                                       c[s].pz + ((k >> 2) & 1u));
+    }
+    __half2 v[SPT][8];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        if (!hashed) {
+            // dense level: the two x corners of a (y, z) pair are neighbours in memory -- one 8-byte load instead of two
+            // 4-byte gathers (dword alignment suffices); a pair that straddles the table's wrap takes two loads
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (idx[s][2 * j + 1] == idx[s][2 * j] + 1u) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(tab) + idx[s][2 * j]);
+                    v[s][2 * j] = __builtin_bit_cast(__half2, q.x);
+                    v[s][2 * j + 1] = __builtin_bit_cast(__half2, q.y);
+                } else {
+                    v[s][2 * j] = tab[idx[s][2 * j]];
+                    v[s][2 * j + 1] = tab[idx[s][2 * j + 1]];
+                }
             }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) v[s][k] = tab[idx[s][k]];
         }
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) v[k] = tab[idx[k]];
     }
-
-    float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-        const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                        ((k & 4u) ? c.wz : 1.f - c.wz);
-        const float2 f = __half22float2(v[k]);
-        r0 = fmaf(w, f.x, r0);
-        r1 = fmaf(w, f.y, r1);
-    }
-    // fp32 interpolation, ONE rounding to the network's input format (fp16, or bfloat16 in the bf16 MLP mode)
-    const uint32_t r = nvo_cvt16x2(r0, r1, out_bf16 != 0);
-    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
-    if (SOA) {
-        o32[(size_t)level * N + i] = r;
-    } else {
-        o32[(size_t)i * g.n_levels + level] = r;
-    }
-    if constexpr (DYDX) {
-        float2 f[8];
+    for (int s = 0; s < SPT; ++s) {
+        if (i[s] >= N) continue;
+        const Corner& cc = c[s];
+        float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) f[k] = __half22float2(v[k]);
-        const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
-        // d/d(axis): (corner with the axis bit) - (corner without), weighted by the other two axes
-        const float ax[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
-        const float ay[4] = {wx0 * wz0, c.wx * wz0, wx0 * c.wz, c.wx * c.wz};
-        const float az[4] = {wx0 * wy0, c.wx * wy0, wx0 * c.wy, c.wx * c.wy};
-        const float gx0 = ax[0] * (f[1].x - f[0].x) + ax[1] * (f[3].x - f[2].x) + ax[2] * (f[5].x - f[4].x) + ax[3] * (f[7].x - f[6].x);
-        const float gx1 = ax[0] * (f[1].y - f[0].y) + ax[1] * (f[3].y - f[2].y) + ax[2] * (f[5].y - f[4].y) + ax[3] * (f[7].y - f[6].y);
-        const float gy0 = ay[0] * (f[2].x - f[0].x) + ay[1] * (f[3].x - f[1].x) + ay[2] * (f[6].x - f[4].x) + ay[3] * (f[7].x - f[5].x);
-        const float gy1 = ay[0] * (f[2].y - f[0].y) + ay[1] * (f[3].y - f[1].y) + ay[2] * (f[6].y - f[4].y) + ay[3] * (f[7].y - f[5].y);
-        const float gz0 = az[0] * (f[4].x - f[0].x) + az[1] * (f[5].x - f[1].x) + az[2] * (f[6].x - f[2].x) + az[3] * (f[7].x - f[3].x);
-        const float gz1 = az[0] * (f[4].y - f[0].y) + az[1] * (f[5].y - f[1].y) + az[2] * (f[6].y - f[2].y) + az[3] * (f[7].y - f[3].y);
-        __half2* __restrict__ o = dydx + (size_t)level * 3 * N + i;
-        o[0] = __floats2half2_rn(gx0, gx1);
-        o[N] = __floats2half2_rn(gy0, gy1);
-        o[2 * (size_t)N] = __floats2half2_rn(gz0, gz1);
-    }
-    if (indices) {
+        for (uint32_t k = 0; k < 8; ++k) {
+            const float w = ((k & 1u) ? cc.wx : 1.f - cc.wx) * ((k & 2u) ? cc.wy : 1.f - cc.wy) *
+                            ((k & 4u) ? cc.wz : 1.f - cc.wz);
+            const float2 f = __half22float2(v[s][k]);
+            r0 = fmaf(w, f.x, r0);
+            r1 = fmaf(w, f.y, r1);
+        }
+        // fp32 interpolation, ONE rounding to the network's input format (fp16, or bfloat16 in the bf16 MLP mode)
+        const uint32_t r = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+        uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
+        if (SOA) {
+            o32[(size_t)level * N + i[s]] = r;
+        } else {
+            o32[(size_t)i[s] * g.n_levels + level] = r;
+        }
+        if constexpr (DYDX) {
+            float2 f[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) indices[((size_t)level * N + i) * 8 + k] = idx[k];
+            for (uint32_t k = 0; k < 8; ++k) f[k] = __half22float2(v[s][k]);
+            const float wx0 = 1.f - cc.wx, wy0 = 1.f - cc.wy, wz0 = 1.f - cc.wz;
+            // d/d(axis): (corner with the axis bit) - (corner without), weighted by the other two axes
+            const float ax[4] = {wy0 * wz0, cc.wy * wz0, wy0 * cc.wz, cc.wy * cc.wz};
+            const float ay[4] = {wx0 * wz0, cc.wx * wz0, wx0 * cc.wz, cc.wx * cc.wz};
+            const float az[4] = {wx0 * wy0, cc.wx * wy0, wx0 * cc.wy, cc.wx * cc.wy};
+            const float gx0 = ax[0] * (f[1].x - f[0].x) + ax[1] * (f[3].x - f[2].x) + ax[2] * (f[5].x - f[4].x) + ax[3] * (f[7].x - f[6].x);
+            const float gx1 = ax[0] * (f[1].y - f[0].y) + ax[1] * (f[3].y - f[2].y) + ax[2] * (f[5].y - f[4].y) + ax[3] * (f[7].y - f[6].y);
+            const float gy0 = ay[0] * (f[2].x - f[0].x) + ay[1] * (f[3].x - f[1].x) + ay[2] * (f[6].x - f[4].x) + ay[3] * (f[7].x - f[5].x);
+            const float gy1 = ay[0] * (f[2].y - f[0].y) + ay[1] * (f[3].y - f[1].y) + ay[2] * (f[6].y - f[4].y) + ay[3] * (f[7].y - f[5].y);
+            const float gz0 = az[0] * (f[4].x - f[0].x) + az[1] * (f[5].x - f[1].x) + az[2] * (f[6].x - f[2].x) + az[3] * (f[7].x - f[3].x);
+            const float gz1 = az[0] * (f[4].y - f[0].y) + az[1] * (f[5].y - f[1].y) + az[2] * (f[6].y - f[2].y) + az[3] * (f[7].y - f[3].y);
+            __half2* __restrict__ o = dydx + (size_t)level * 3 * N + i[s];
+            o[0] = __floats2half2_rn(gx0, gx1);
+            o[N] = __floats2half2_rn(gy0, gy1);
+            o[2 * (size_t)N] = __floats2half2_rn(gz0, gz1);
+        }
+        if (indices) {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) indices[((size_t)level * N + i[s]) * 8 + k] = idx[s][k];
+        }
     }
 }
 
@@ -1636,17 +1660,26 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
-    const uint32_t tiles = nvo_div_up(N, kGridBlock);
+    static const int spt_env = [] { const char* e = getenv("NVO_GRID_FWD_SPT"); return e ? atoi(e) : 2; }();
+    const int spt = (dydx_half || spt_env < 2) ? 1 : (spt_env >= 4 ? 4 : 2);  // samples per thread
+    const uint32_t tiles = nvo_div_up(N, kGridBlock * spt);
     const dim3 grid(tiles * g.n_levels), block(kGridBlock);
-#define NVO_LAUNCH_FWD(SOA_, DYDX_)                                                                   \
-    NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
+#define NVO_LAUNCH_FWD_S(SOA_, DYDX_, SPT_)                                                                  \
+    NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_, SPT_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
                (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0)
+#define NVO_LAUNCH_FWD(SOA_, DYDX_)                                        \
+    do {                                                                   \
+        if (DYDX_ || spt == 1) NVO_LAUNCH_FWD_S(SOA_, DYDX_, 1);           \
+        else if (spt == 2) NVO_LAUNCH_FWD_S(SOA_, false, 2);               \
+        else NVO_LAUNCH_FWD_S(SOA_, false, 4);                             \
+    } while (0)
     if (soa) {
         if (dydx_half) NVO_LAUNCH_FWD(true, true); else NVO_LAUNCH_FWD(true, false);
     } else {
         if (dydx_half) NVO_LAUNCH_FWD(false, true); else NVO_LAUNCH_FWD(false, false);
     }
 #undef NVO_LAUNCH_FWD
+#undef NVO_LAUNCH_FWD_S
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
