@@ -178,6 +178,10 @@ int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, co
 int nvo_se3_exp_map_bwd(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
                         float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
                         float* reg_loss, int mode);
+/* reg_scale_dev (nullable): device float that multiplies reg_scale (the dynamic loss scale of the step) */
+int nvo_se3_exp_map_bwd_scaled(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
+                               float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
+                               float* reg_loss, int mode, const float* reg_scale_dev);
 /* images: device float [F][H][W][C] -> out [R][C] */
 int nvo_gather_pixels(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, uint32_t H,
                       uint32_t W, uint32_t C, const float* images, float* out);
@@ -319,6 +323,8 @@ typedef struct nvo_main_loss_args {
     float* out_normals;          /* [R][3] NormalsRenderer (safe-normalised) -> NormalsShader (n+1)/2, or NULL */
                                  /* loss slot 6 of the shard receives normal_mult * monosdf_normal_loss */
     int act_bf16;                /* 0: pre / rgb / dpre / drgb are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
+    const float* loss_scale_dev; /* nullable: device float that REPLACES loss_scale (dynamic loss scaling: the
+                                    GradScaler state lives on the device so that a captured step stays valid) */
 } nvo_main_loss_args;
 int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
 
@@ -337,9 +343,10 @@ typedef struct nvo_prop_loss_args {
     float interlevel_mult, depth_mult, depth_sigma;
     float inv_rays, depth_level_div, loss_scale;
     float* losses;               /* [64][8] shards (same buffer, base + 3): slots 0..1 = interlevel, depth */
-    void* dpre;                  /* fp16 [R*S][dpre_stride]: column 0 gradient, others zeroed */
+    void* dpre;                  /* fp16 [R*S][dpre_stride]: column 0 gradient, others zeroed; NULL = loss VALUES only */
     uint32_t dpre_stride;
     int act_bf16;                /* 0: pre / dpre are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
+    const float* loss_scale_dev; /* nullable: device float that REPLACES loss_scale */
 } nvo_prop_loss_args;
 int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args);
 
@@ -382,11 +389,14 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
 /* DDA march of R rays (unit directions) with deterministic packing: counts[R], offsets[R+1]
  * (exclusive scan, offsets[R] = total), then (ray_idx, t, dt)[capacity] written at the offsets.  Rays
  * whose samples would not fit get count 0.  jitter: device float [R] in [0,1) or NULL.
- * Step size dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 1024). */
+ * Step size dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 1024).
+ * scratch: CALLER-owned device staging area of at least nvo_occ_march_scratch_bytes(R) bytes (ray-major runs of the
+ * single march; the native side allocates nothing, so a captured launch never holds a pointer it could lose). */
+uint64_t nvo_occ_march_scratch_bytes(uint32_t R);
 int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
                   const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                   uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
-                  float* dt_out);
+                  float* dt_out, void* scratch, uint64_t scratch_bytes);
 /* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
  * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
  * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.
@@ -478,6 +488,15 @@ typedef struct nvo_adam_group {
     float lr;
     uint32_t step;
     const float* hyper_dev;
+    /* step_dev (nullable): device uint32 = number of steps APPLIED to this group so far; the bias corrections are
+     * computed from *step_dev + 1 on the device (`step` and hyper_dev[1..2] are ignored) and nvo_opt_commit advances
+     * the counter behind the launch iff the group was not skipped -- torch.optim.Adam's state['step'] under
+     * GradScaler.step, which does not count skipped steps. */
+    const uint32_t* step_dev;
+    /* which word of skip_flags belongs to this group: the group's index in `groups` unless flag_slot_set != 0 (a step
+     * that runs its groups in two launches keeps ONE flag word per group that way) */
+    uint32_t flag_slot;
+    uint32_t flag_slot_set;
 } nvo_adam_group;
 int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
                          void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,
@@ -528,6 +547,25 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
                                float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
                                float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
                                const uint64_t* bf16_lo, const uint64_t* bf16_hi);
+/* The same with the loss scale read from the device: loss_scale_dev (nullable) = device float, grad_scale is then
+ * 1 / *loss_scale_dev (dynamic loss scaling, the reference trains with mixed_precision=True i.e. torch's GradScaler:
+ * /root/reference/nerf_vo/mapping/nerfstudio.py:59). */
+int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                                void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                                float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                                float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                                const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev);
+/* What GradScaler.step / GradScaler.update leave behind, on the device (one tiny launch behind the optimiser launches
+ * of a step, capturable): for every group i in active_mask (bit i), applied[i] += 1 iff skip_flags[i] == 0; and, when
+ * scale != NULL, the loss scale backs off (x backoff_factor, not below min_scale) if ANY group of scale_mask was
+ * skipped and grows (x growth_factor, not above max_scale) after growth_interval consecutive clean steps (torch
+ * defaults: init 65536, growth 2, backoff 0.5, interval 2000).  (Two masks: a step that runs its optimisers in two
+ * launches commits each launch's counters behind it and updates the scale once, from all of the step's groups.)
+ * applied / skip_flags: device uint32 [n_groups] (nullable); scale: device float, growth_tracker: device uint32 (both
+ * nullable together). */
+int nvo_opt_commit(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                   const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale);
 
 /* ------------------------------------------------------------------------------------------------
  * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of

@@ -41,7 +41,7 @@ class MainLossArgs(C.Structure):
                 ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
                 ("drgb", _p), ("drgb_stride", _u32),
                 ("dsigma_dx", _p), ("dsigma_inv_scale", _f), ("gt_normal", _p), ("normal_mult", _f),
-                ("out_normals", _p), ("act_bf16", _int)]
+                ("out_normals", _p), ("act_bf16", _int), ("loss_scale_dev", _p)]
 
 
 class PropLossArgs(C.Structure):
@@ -50,7 +50,7 @@ class PropLossArgs(C.Structure):
                 ("sbins", _p), ("tbins", _p), ("sbins_main", _p), ("weights_main", _p), ("density_bias", _f),
                 ("gt_depth", _p), ("directions_norm", _p), ("interlevel_mult", _f), ("depth_mult", _f),
                 ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f), ("loss_scale", _f),
-                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32), ("act_bf16", _int)]
+                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32), ("act_bf16", _int), ("loss_scale_dev", _p)]
 
 
 class ColorArgs(C.Structure):
@@ -73,7 +73,8 @@ class RayHeadArgs(C.Structure):
 class AdamGroup(C.Structure):
     """nvo_adam_group (include/nerfvo_hip.h)"""
     _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
-                ("hyper_dev", C.c_void_p)]
+                ("hyper_dev", C.c_void_p), ("step_dev", C.c_void_p), ("flag_slot", C.c_uint32),
+                ("flag_slot_set", C.c_uint32)]
 
 
 class DepthAlignArgs(C.Structure):
@@ -127,6 +128,7 @@ _SIGNATURES = {
     "nvo_sh_bwd_input_f32": (_int, [_p, _u32, _u32, _p, _p, _p]),
     "nvo_pose_bwd": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_se3_exp_map_bwd": (_int, [_p, _u32, _p, _p, _f, _f, _f, _p, _p, _int]),
+    "nvo_se3_exp_map_bwd_scaled": (_int, [_p, _u32, _p, _p, _f, _f, _f, _p, _p, _int, _p]),
     "nvo_gather_pixels": (_int, [_p, _u32, _p, _u32, _u32, _u32, _p, _p]),
     "nvo_sample_lindisp": (_int, [_p, _u32, _u32, _f, _f, _p, _p, _p]),
     "nvo_sample_pixels": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _u32]),
@@ -145,7 +147,8 @@ _SIGNATURES = {
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
     # group F
-    "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p]),
+    "nvo_occ_march_scratch_bytes": (_u64, [_u32]),
+    "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64]),
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
@@ -171,6 +174,8 @@ _SIGNATURES = {
     "nvo_ema_update": (_int, [_p, _u64, _p, _p, _p, _f, _u32, _p]),
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
+    "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),
+    "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f]),
     "nvo_cast_bf16": (_int, [_p, _u64, _p, _p]),
 }
 

@@ -5,7 +5,7 @@
 // reference configures it: AdamOptimizerConfig(lr=1e-2|1e-4, eps=1e-15)
 // (/root/reference/nerf_vo/mapping/nerfstudio.py:84-100); the GradScaler "skip the step when a
 // non-finite gradient was found" behaviour (mixed_precision=True, nerfstudio.py:59) is the
-// optional skip flag.  CPU restatement: oracle/optim.py.
+// optional skip flag.  CPU restatement: oracle/nerfacto.py::adam_reference.
 #include "nvo_kernels.h"
 #include "../../include/nerfvo_hip.h"
 
@@ -122,15 +122,16 @@ struct AdamGroups {
     uint64_t offset[kAdamMaxGroups], n[kAdamMaxGroups];
     float lr[kAdamMaxGroups], bias1[kAdamMaxGroups], bias2_sqrt[kAdamMaxGroups];
     const float* hyper_dev[kAdamMaxGroups];
+    const uint32_t* step_dev[kAdamMaxGroups];  // applied-step counter on the device (nvo_adam_group::step_dev)
     int vec4[kAdamMaxGroups];
-    uint32_t slot[kAdamMaxGroups];  // index of the group in the caller's arrays (its skip flag)
+    uint32_t slot[kAdamMaxGroups];  // index of the group's skip flag
 };
 
 template <typename GT>
 __global__ void __launch_bounds__(256)
 k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, const GT* __restrict__ g,
               float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flags,
-              Copy16Fmt fmt) {
+              Copy16Fmt fmt, const float* __restrict__ loss_scale_dev) {
     uint32_t k = 0;
     while (k + 1 < gr.n_groups && blockIdx.x >= gr.first_block[k + 1]) ++k;
     // GradScaler.step decides per optimiser: a group is skipped iff ITS gradients held a non-finite value
@@ -143,6 +144,15 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
         h.bias1 = gr.hyper_dev[k][1];
         h.bias2_sqrt = gr.hyper_dev[k][2];
     }
+    if (gr.step_dev[k]) {
+        // torch.optim.Adam under GradScaler.step: state['step'] counts the APPLIED steps only -- the counter lives on the
+        // device and nvo_opt_commit advances it behind this launch iff the group was not skipped (double: 1 - 0.999^t
+        // loses 3 digits in fp32 for small t)
+        const double t = (double)(*gr.step_dev[k]) + 1.0;
+        h.bias1 = (float)(1.0 - pow((double)h.beta1, t));
+        h.bias2_sqrt = (float)sqrt(1.0 - pow((double)h.beta2, t));
+    }
+    if (loss_scale_dev) h.grad_scale = 1.0f / *loss_scale_dev;  // dynamic loss scale (GradScaler state on the device)
     const uint64_t o = gr.offset[k];
     adam_range<GT>(gr.n[k], p + o, p16 ? p16 + o : nullptr, g + o, m + o, v + o, h, gr.vec4[k],
                    blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k], fmt, o);
@@ -270,6 +280,35 @@ k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
 }
 
+// GradScaler.update() + the optimisers' step counters, on the device (one thread): group i of `active_mask` advances its
+// applied-step counter iff its skip flag is clear; the loss scale backs off when ANY active group saw a non-finite
+// gradient and grows after `interval` clean steps (torch.cuda.amp.GradScaler: init 65536, x2 / 2000 steps, x0.5).
+__global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+                             const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
+                             uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
+                             float min_scale, float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool any_bad = false;
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        const bool bad = skip_flags && skip_flags[i] != 0u;
+        if ((scale_mask >> i) & 1u) any_bad = any_bad || bad;
+        if (((active_mask >> i) & 1u) && applied && !bad) applied[i] += 1u;
+    }
+    if (scale) {
+        float sc = *scale;
+        uint32_t tr = *growth_tracker;
+        if (any_bad) {
+            sc = fmaxf(sc * backoff, min_scale);
+            tr = 0u;
+        } else if (++tr >= interval) {
+            sc = fminf(sc * growth, max_scale);
+            tr = 0u;
+        }
+        *scale = sc;
+        *growth_tracker = tr;
+    }
+}
+
 constexpr uint32_t kZeroMaxRanges = 24;
 struct ZeroRanges {
     uint32_t n;
@@ -381,6 +420,30 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
                                float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
                                float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
                                const uint64_t* bf16_lo, const uint64_t* bf16_hi) {
+    return nvo_adam_step_groups_scaled(stream, n_groups, groups, params, params_half, grads, grads_are_half, exp_avg,
+                                       exp_avg_sq, beta1, beta2, eps, grad_scale, weight_decay, skip_flags,
+                                       n_bf16_ranges, bf16_lo, bf16_hi, nullptr);
+}
+
+int nvo_opt_commit(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                   const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale) {
+    NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "opt_commit: 1..%u groups (got %u)", kAdamMaxGroups, n_groups);
+    NVO_REQUIRE(applied || scale, "opt_commit: nothing to update");
+    NVO_REQUIRE(!scale || (growth_tracker && growth_interval >= 1 && growth_factor >= 1.f && backoff_factor > 0.f &&
+                           backoff_factor <= 1.f && min_scale > 0.f && max_scale >= min_scale),
+                "opt_commit: bad loss-scale schedule");
+    NVO_LAUNCH(k_opt_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, n_groups, active_mask, scale_mask, applied, skip_flags, scale,
+               growth_tracker, growth_factor, backoff_factor, growth_interval, min_scale, max_scale);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                                void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                                float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                                float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                                const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq && groups, "adam_step_groups: NULL argument");
     Copy16Fmt fmt;
     if (int rc = make_copy_fmt(n_bf16_ranges, bf16_lo, bf16_hi, &fmt)) return rc;
@@ -392,15 +455,18 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
     const size_t gsz = grads_are_half ? 2 : 4;
     for (uint32_t i = 0; i < n_groups; ++i) {
         if (groups[i].n == 0) continue;
-        NVO_REQUIRE(groups[i].step >= 1, "adam_step_groups: step counts from 1");
+        NVO_REQUIRE(groups[i].step >= 1 || groups[i].step_dev, "adam_step_groups: step counts from 1");
+        NVO_REQUIRE(groups[i].flag_slot < kAdamMaxGroups, "adam_step_groups: flag_slot %u out of range", groups[i].flag_slot);
         const uint64_t o = groups[i].offset;
         gr.offset[k] = o;
         gr.n[k] = groups[i].n;
         gr.lr[k] = groups[i].lr;
-        gr.bias1[k] = 1.f - powf(beta1, (float)groups[i].step);
-        gr.bias2_sqrt[k] = sqrtf(1.f - powf(beta2, (float)groups[i].step));
+        gr.bias1[k] = 1.f - powf(beta1, (float)(groups[i].step ? groups[i].step : 1u));
+        gr.bias2_sqrt[k] = sqrtf(1.f - powf(beta2, (float)(groups[i].step ? groups[i].step : 1u)));
         gr.hyper_dev[k] = groups[i].hyper_dev;
-        gr.slot[k] = i;
+        gr.step_dev[k] = groups[i].step_dev;
+        // flag word of the group: its index in the caller's array unless the caller pins one (flag_slot + 1)
+        gr.slot[k] = groups[i].flag_slot_set ? groups[i].flag_slot : i;
         const uintptr_t align = (uintptr_t)(params + o) | (uintptr_t)(exp_avg + o) | (uintptr_t)(exp_avg_sq + o);
         gr.vec4[k] = (align & 15u) == 0 && (!params_half || (((uintptr_t)params_half + 2 * o) & 7u) == 0) &&
                      ((((uintptr_t)grads + gsz * o) & (grads_are_half ? 7u : 15u)) == 0);
@@ -416,13 +482,13 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
     AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
     if (grads_are_half == 2) {
         NVO_LAUNCH(k_adam_groups<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
+                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
     } else if (grads_are_half) {
         NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
+                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
     } else {
         NVO_LAUNCH(k_adam_groups<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt);
+                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

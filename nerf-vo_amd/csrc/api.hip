@@ -29,6 +29,43 @@ extern "C" const char* nvo_last_error(void) { return g_err; }
 extern "C" int nvo_version(void) { return 100; }
 
 // ---------------------------------------------------------------------------------------------
+// graph-capture-safe growable scratch (nvo_common.h)
+// ---------------------------------------------------------------------------------------------
+int nvo_scratch_reserve(NvoScratch* s, size_t need, hipStream_t stream, const char* what) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    // (the legacy NULL stream cannot be captured, and querying it while ANOTHER stream captures is an error)
+    if (stream != nullptr) NVO_CHECK_HIP(hipStreamIsCapturing(stream, &cs));
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    if (need > s->bytes) {
+        NVO_REQUIRE(!capturing,
+                    "%s: scratch would have to grow from %zu to %zu bytes while a hipGraph is being captured "
+                    "(hipMalloc cannot be captured): launch once eagerly at this batch size before capturing",
+                    what, s->bytes, need);
+        if (s->ptr) {
+            if (s->captured) {  // a captured graph still addresses the old block: keep it alive
+                NVO_REQUIRE(s->n_retired < 8, "%s: scratch grew %u times after a graph capture", what, s->n_retired);
+                s->retired[s->n_retired++] = s->ptr;
+            } else {
+                NVO_CHECK_HIP(hipFree(s->ptr));
+            }
+        }
+        s->ptr = nullptr;
+        s->bytes = 0;
+        s->captured = false;
+        NVO_CHECK_HIP(hipMalloc(&s->ptr, need));
+        s->bytes = need;
+    }
+    if (capturing) s->captured = true;
+    return NVO_OK;
+}
+
+void nvo_scratch_destroy(NvoScratch* s) {
+    if (s->ptr) (void)hipFree(s->ptr);
+    for (uint32_t i = 0; i < s->n_retired; ++i) (void)hipFree(s->retired[i]);
+    *s = NvoScratch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-launch HIP-event profiler: events are recorded on the stream each launcher enqueues on, so
 // the elapsed time is that kernel's (plus its memsets') device time, not host time.
 // ---------------------------------------------------------------------------------------------
@@ -292,7 +329,7 @@ struct GridModule : nvo_module_s {
         nvo_grid_slices_destroy(&slices);
         nvo_grid_bins_destroy(&bins);
         nvo_grid_stream_destroy(&stream_bins);
-        if (input_scratch.ptr) (void)hipFree(input_scratch.ptr);
+        nvo_scratch_destroy(&input_scratch);
     }
     bool external_zero = false;
     int grid_zero_ranges(float* dparams, NvoZeroRanges* out) {

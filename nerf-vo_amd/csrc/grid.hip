@@ -1793,9 +1793,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
 }
 
 void nvo_grid_slices_destroy(NvoGridSlices* s) {
-    if (s->d_live) (void)hipFree(s->d_live);
-    s->d_live = nullptr;
-    s->live_cap = 0;
+    nvo_scratch_destroy(&s->live);
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
     s->d_l1 = nullptr;
@@ -1859,9 +1857,8 @@ int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b) {
 
 void nvo_grid_bins_destroy(NvoGridBins* b) {
     if (b->d_binned_levels) (void)hipFree(b->d_binned_levels);
-    if (b->d_records) (void)hipFree(b->d_records);
-    b->d_binned_levels = b->d_records = nullptr;
-    b->records_cap = 0;
+    nvo_scratch_destroy(&b->records);
+    b->d_binned_levels = nullptr;
     b->n_bins = b->n_binned_levels = 0;
     nvo_grid_slices_destroy(&b->dense);
 }
@@ -1875,11 +1872,8 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
     NVO_PROF(stream, "grid_bwd_binned[L%u]", g.n_levels);
     if (bins->n_bins) {
         const size_t need = (size_t)N * 8 * bins->n_binned_levels;
-        if (need > bins->records_cap) {  // grows during warm-up only; never while a graph is captured
-            if (bins->d_records) NVO_CHECK_HIP(hipFree(bins->d_records));
-            NVO_CHECK_HIP(hipMalloc((void**)&bins->d_records, sizeof(uint32_t) * need));
-            bins->records_cap = need;
-        }
+        if (int rc = nvo_scratch_reserve(&bins->records, sizeof(uint32_t) * need, stream, "grid_bwd_binned records")) return rc;
+        uint32_t* const d_records = static_cast<uint32_t*>(bins->records.ptr);
         if (int rc = nvo_zero_async(bins->d_counts, sizeof(uint32_t) * bins->n_bins, stream)) return rc;
         const dim3 grid(nvo_div_up(N, kBinBlock), bins->n_binned_levels), block(kBinBlock);
         // few bins (small tables): several workgroups per bin, combined with contiguous float atomics
@@ -1904,13 +1898,13 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
             attr_set = true;                                                                                 \
         }                                                                                                    \
         NVO_LAUNCH((k_bin_count_scatter<false, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy, \
-                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, bins->d_records); \
+                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, d_records); \
         NVO_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, stream, bins->n_bins, bins->d_counts, bins->d_base,   \
                    bins->d_cursor);                                                                          \
         NVO_LAUNCH((k_bin_count_scatter<true, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy,  \
-                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, bins->d_records); \
+                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, d_records); \
         NVO_LAUNCH((k_bin_accumulate<SOA_, T_>), dim3(bins->n_bins, acc_chunks), dim3(kLdsBwdBlock), lds_acc, stream, g, N, x, \
-                   (const T_*)dy, bins->d_bin_level, bins->d_bin_slice, bins->d_base, bins->d_records, grad); \
+                   (const T_*)dy, bins->d_bin_level, bins->d_bin_slice, bins->d_base, d_records, grad); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_BIN, true);
@@ -2021,13 +2015,11 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
 
 void nvo_grid_stream_destroy(NvoGridStream* st) {
     if (st->d_meta) (void)hipFree(st->d_meta);
-    if (st->d_work) (void)hipFree(st->d_work);
+    nvo_scratch_destroy(&st->work);
     if (st->d_tl_items) (void)hipFree(st->d_tl_items);
     st->d_tl_items = nullptr;
     st->n_tl_items = 0;
     st->d_meta = nullptr;
-    st->d_work = nullptr;
-    st->work_bytes = 0;
     st->n_bins = 0;
     st->created = false;
     if (st->aux) {
@@ -2073,13 +2065,10 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * sizeof(uint2), 256);
         const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
         const size_t need_tl = rec_bytes_tl + seg_bytes;
-        if (need_tl > st->work_bytes) {  // grows during warm-up only; never while a graph is being captured
-            if (st->d_work) NVO_CHECK_HIP(hipFree(st->d_work));
-            NVO_CHECK_HIP(hipMalloc((void**)&st->d_work, need_tl));
-            st->work_bytes = need_tl;
-        }
-        uint2* records_tl = reinterpret_cast<uint2*>(st->d_work);
-        uint32_t* seg = reinterpret_cast<uint32_t*>(st->d_work + rec_bytes_tl);
+        if (int rc = nvo_scratch_reserve(&st->work, need_tl, stream, "grid_bwd_stream records")) return rc;
+        unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
+        uint2* records_tl = reinterpret_cast<uint2*>(d_work);
+        uint32_t* seg = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl);
         const dim3 grid_tl(n_tiles, st->n_levels);
         const size_t lds_tl = tile_records * sizeof(uint2) + sizeof(uint32_t) * 2 * st->max_slices;
         const size_t lds_acc_tl = sizeof(unsigned long long) * 2 * kBinSlice;
@@ -2125,20 +2114,16 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     }
     const size_t n_records = (size_t)N * 8 * st->n_levels;
     const uint32_t max_items = st->n_bins + (uint32_t)(n_records / kStChunkRecords) + 1u;
-    // scratch: records | counts[n_bins][n_tiles] | items[max_items]   (grows during warm-up only; never
-    // while a graph is being captured)
+    // scratch: records | counts[n_bins][n_tiles] | items[max_items]   (graph-safe growth: NvoScratch)
     const size_t rec_bytes = nvo_round_up(n_records * sizeof(uint2), 256);
     const size_t cnt_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
     const size_t item_bytes = (size_t)max_items * sizeof(uint4);
     const size_t need = rec_bytes + cnt_bytes + item_bytes;
-    if (need > st->work_bytes) {
-        if (st->d_work) NVO_CHECK_HIP(hipFree(st->d_work));
-        NVO_CHECK_HIP(hipMalloc((void**)&st->d_work, need));
-        st->work_bytes = need;
-    }
-    uint2* records = reinterpret_cast<uint2*>(st->d_work);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(st->d_work + rec_bytes);
-    uint4* items = reinterpret_cast<uint4*>(st->d_work + rec_bytes + cnt_bytes);
+    if (int rc = nvo_scratch_reserve(&st->work, need, stream, "grid_bwd_stream records")) return rc;
+    unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
+    uint2* records = reinterpret_cast<uint2*>(d_work);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(d_work + rec_bytes);
+    uint4* items = reinterpret_cast<uint4*>(d_work + rec_bytes + cnt_bytes);
     const dim3 grid(n_tiles, st->n_levels);
     const size_t lds_hist = sizeof(uint32_t) * st->max_slices;
     const size_t lds_stage = (size_t)tile * 8 * 12 + sizeof(uint32_t) * 3 * st->max_slices;
@@ -2220,24 +2205,20 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         const uint32_t* live = nullptr;
         bool l1_fused = false;
         if (slices->compact_live) {
-            if ((size_t)N + 1 > slices->live_cap) {  // grows during warm-up only; never while a graph is being captured
-                if (slices->d_live) NVO_CHECK_HIP(hipFree(slices->d_live));
-                slices->d_live = nullptr;
-                slices->live_cap = 0;
-                NVO_CHECK_HIP(hipMalloc((void**)&slices->d_live, sizeof(uint32_t) * ((size_t)N + 1)));
-                slices->live_cap = (size_t)N + 1;
-            }
-            if (int rc = nvo_zero_async(slices->d_live, sizeof(uint32_t), stream)) return rc;
+            if (int rc = nvo_scratch_reserve(&slices->live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list"))
+                return rc;
+            uint32_t* const d_live = static_cast<uint32_t*>(slices->live.ptr);
+            if (int rc = nvo_zero_async(d_live, sizeof(uint32_t), stream)) return rc;
             // (32-bit accumulators, <= 8 levels: the L1 norms of dy ride in the same pass)
             l1_fused = slices->acc_bits == 32 && g.n_levels <= 8 && dy_fmt != NVO_DY_FLOAT;
             if (l1_fused && !slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
 #define NVO_LAUNCH_LIVE(SOA_, T_)                                                                                    \
     NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, \
-               slices->d_live, l1_fused ? slices->d_l1 : nullptr)
+               d_live, l1_fused ? slices->d_l1 : nullptr)
             if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
 #undef NVO_LAUNCH_LIVE
-            live = slices->d_live;
+            live = d_live;
         }
         if (slices->acc_bits == 32 && !l1_fused) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
@@ -2318,12 +2299,8 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
     float* partial = nullptr;
     if (scratch) {  // two-stage form: per-level partials + a sum kernel, no float atomics, no zeroing of dx
         const size_t need = (size_t)g.n_levels * N * 3;
-        if (need > scratch->floats) {  // grows during warm-up only; never while a graph is being captured
-            if (scratch->ptr) NVO_CHECK_HIP(hipFree(scratch->ptr));
-            NVO_CHECK_HIP(hipMalloc((void**)&scratch->ptr, sizeof(float) * need));
-            scratch->floats = need;
-        }
-        partial = scratch->ptr;
+        if (int rc = nvo_scratch_reserve(scratch, sizeof(float) * need, stream, "grid_bwd_input partials")) return rc;
+        partial = static_cast<float*>(scratch->ptr);
     } else if (zero_dx) {
         if (int rc = nvo_zero_async(dx, sizeof(float) * 3 * (size_t)N, stream)) return rc;
     }

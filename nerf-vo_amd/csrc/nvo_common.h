@@ -78,6 +78,23 @@ bool nvo_prof_detail();
     NvoProfScope nvo_prof_sub__((hipStream_t)(stream), nvo_prof_detail());             \
     if (nvo_prof_sub__.on) nvo_prof_begin((hipStream_t)(stream), __VA_ARGS__)
 
+// ---- graph-capture-safe growable device scratch -----------------------------------------------
+// Module-owned scratch that grows with the largest batch seen.  A captured hipGraph addresses the block by POINTER, so
+// once a launch that uses it has been captured the block must never be freed while the module lives: a larger batch
+// later (an eager step or a render at another ray count between two replays) gets a NEW block and the old one is
+// RETIRED -- kept allocated until the module is destroyed -- instead of hipFree'd.  Growing while a capture is in
+// progress is refused (hipMalloc is not capturable): run one eager warm-up launch at that size first.
+struct NvoScratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    bool captured = false;     // a captured launch addresses `ptr`
+    void* retired[8] = {};     // blocks captured graphs may still address (freed by nvo_scratch_destroy)
+    uint32_t n_retired = 0;
+};
+// Makes s->ptr hold at least `need` bytes for a launch on `stream`; `what` names the buffer in error messages.
+int nvo_scratch_reserve(NvoScratch* s, size_t need, hipStream_t stream, const char* what);
+void nvo_scratch_destroy(NvoScratch* s);
+
 static inline uint32_t nvo_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline uint64_t nvo_round_up(uint64_t a, uint64_t b) { return ((a + b - 1) / b) * b; }
 

@@ -29,8 +29,7 @@ struct NvoGridSlices {
     // samples carry an exactly zero gradient from a few hundred steps on, and every one of them
     // was loaded and tested once per slice (25 slice scans for a proposal grid).
     bool compact_live = false;
-    mutable uint32_t* d_live = nullptr;   // [1 + N]: count, then the live sample ids (grows with N, warm-up only)
-    mutable size_t live_cap = 0;
+    mutable NvoScratch live;              // [1 + N] uint32: count, then the live sample ids (grows with N; graph-safe)
     // option grid_bwd_runs (set before create): the items of DENSE levels scan with run merging -- a lane takes 8
     // consecutive samples, sums the corner contributions in registers while the cell stays the same and goes to the LDS
     // accumulators once per run (consecutive samples are neighbours on a ray, so a coarse cell holds a run of them)
@@ -63,8 +62,7 @@ struct NvoGridBins {
     uint32_t* d_counts = nullptr;         // [n_bins]
     uint32_t* d_base = nullptr;           // [n_bins + 1]
     uint32_t* d_cursor = nullptr;         // [n_bins]
-    uint32_t* d_records = nullptr;        // [records_cap]
-    size_t records_cap = 0;
+    NvoScratch records;                   // [N * 8 * n_binned_levels] uint32 (grows with N; graph-safe)
     NvoGridSlices dense;
 };
 int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b);
@@ -89,8 +87,7 @@ struct NvoGridStream {
     uint32_t* d_base = nullptr;       // [n_bins + 1]
     uint32_t* d_bin_chunks = nullptr; // [n_bins]
     uint32_t* d_n_items = nullptr;    // [1]
-    unsigned char* d_work = nullptr;  // records | counts | items (sized for the largest batch seen)
-    size_t work_bytes = 0;
+    NvoScratch work;                  // records | counts | items (sized for the largest batch seen; graph-safe growth)
     NvoGridSlices owner;
     // The slice-owner items of the coarse levels and the record pipeline of the streamed levels touch disjoint
     // gradient ranges, so they CAN run side by side (the former on this auxiliary stream, forked from / joined to the
@@ -127,10 +124,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                         uint32_t N, const float* x, const void* dy, int dy_fmt, bool soa,
                         float* grad, int mode);
 // scratch (optional, module-owned): per-level partial gradients [L][N][3] of the two-stage input backward
-struct NvoGridInputScratch {
-    float* ptr = nullptr;
-    size_t floats = 0;
-};
+typedef NvoScratch NvoGridInputScratch;
 int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N,
                               const float* x, const void* table_half, const void* dy,
                               int dy_fmt, bool soa, float* dx, bool zero_dx,

@@ -398,28 +398,23 @@ k_occ_cell_positions(int level, const float* __restrict__ jitter, float* __restr
 
 extern "C" {
 
+uint64_t nvo_occ_march_scratch_bytes(uint32_t R) { return (uint64_t)sizeof(float2) * R * kMaxSteps; }
+
 int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
                   const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                   uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
-                  float* dt_out) {
+                  float* dt_out, void* scratch, uint64_t scratch_bytes) {
     NVO_REQUIRE(n_levels >= 1 && n_levels <= 8, "occ_march: n_levels %d not in 1..8", n_levels);
     NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts && offsets && ray_idx && t_out && dt_out),
                 "occ_march: NULL argument");
     if (R == 0) return NVO_OK;
+    // ray-major staging area of the single march: CALLER-owned (it used to be a process-global block that was freed
+    // and re-allocated whenever a larger R arrived -- a captured graph would have kept the dangling pointer)
+    NVO_REQUIRE(scratch && scratch_bytes >= nvo_occ_march_scratch_bytes(R),
+                "occ_march: scratch of %llu bytes is too small for %u rays (nvo_occ_march_scratch_bytes: %llu)",
+                (unsigned long long)scratch_bytes, R, (unsigned long long)nvo_occ_march_scratch_bytes(R));
     hipStream_t s = (hipStream_t)stream;
-    // ray-major staging area of the single march (grows during warm-up only; never while a graph is captured)
-    static float2* march_scratch = nullptr;
-    static size_t march_scratch_rays = 0;
-    if (R > march_scratch_rays) {
-        // (power-of-two growth: the adaptive ray batch of the occupancy-grid trainer changes R every few steps)
-        size_t rays = march_scratch_rays ? march_scratch_rays : 4096;
-        while (rays < R) rays *= 2;
-        if (march_scratch) NVO_CHECK_HIP(hipFree(march_scratch));
-        march_scratch = nullptr;
-        march_scratch_rays = 0;
-        NVO_CHECK_HIP(hipMalloc((void**)&march_scratch, sizeof(float2) * rays * kMaxSteps));
-        march_scratch_rays = rays;
-    }
+    float2* march_scratch = static_cast<float2*>(scratch);
     {
         NVO_PROF(stream, "occ_march");
         static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;

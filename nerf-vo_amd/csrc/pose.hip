@@ -184,9 +184,10 @@ __device__ __forceinline__ Dual dfun(const Dual& a, float value, float derivativ
 __global__ void __launch_bounds__(64)
 k_se3_exp_bwd(uint32_t n, const float* __restrict__ tangent, const float* __restrict__ d_corr,
               float trans_penalty, float rot_penalty, float reg_scale, float* __restrict__ d_tangent,
-              int mode) {
+              int mode, const float* __restrict__ reg_scale_dev) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (reg_scale_dev) reg_scale *= *reg_scale_dev;  // dynamic loss scale (device float)
     const float* t = tangent + 6 * (size_t)i;
     Dual l[3] = {dvar(t[0], 0), dvar(t[1], 1), dvar(t[2], 2)};
     Dual a[3] = {dvar(t[3], 3), dvar(t[4], 4), dvar(t[5], 5)};
@@ -301,12 +302,19 @@ int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, co
 int nvo_se3_exp_map_bwd(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
                         float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
                         float* reg_loss, int mode) {
+    return nvo_se3_exp_map_bwd_scaled(stream, n, tangent, d_corrections, trans_penalty, rot_penalty, reg_scale, d_tangent,
+                                      reg_loss, mode, nullptr);
+}
+
+int nvo_se3_exp_map_bwd_scaled(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
+                               float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
+                               float* reg_loss, int mode, const float* reg_scale_dev) {
     NVO_REQUIRE(n == 0 || (tangent && d_corrections && d_tangent), "se3_exp_map_bwd: NULL argument");
     NVO_REQUIRE(mode == 0 || mode == 1, "se3_exp_map_bwd: mode %d (0 = SE3, 1 = SO3xR3)", mode);
     if (n == 0) return NVO_OK;
     NVO_PROF(stream, "se3_exp_map_bwd");
     NVO_LAUNCH(k_se3_exp_bwd, dim3(nvo_div_up(n, 64)), dim3(64), 0, (hipStream_t)stream, n, tangent,
-               d_corrections, trans_penalty, rot_penalty, reg_scale, d_tangent, mode);
+               d_corrections, trans_penalty, rot_penalty, reg_scale, d_tangent, mode, reg_scale_dev);
     NVO_CHECK_LAUNCH();
     if (reg_loss) {
         NVO_LAUNCH(k_pose_regularizer, dim3(1), dim3(256), 0, (hipStream_t)stream, n, tangent, trans_penalty,

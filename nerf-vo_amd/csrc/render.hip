@@ -223,6 +223,7 @@ k_main_render_loss(nvo_main_loss_args a) {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
     if (r >= a.R) return;
+    if (a.loss_scale_dev) a.loss_scale = *a.loss_scale_dev;  // dynamic loss scale (GradScaler state on the device)
     float* w = lds[wib][0];
     float* Tr = lds[wib][1];
     float* g = lds[wib][2];
@@ -433,6 +434,7 @@ k_prop_loss(nvo_prop_loss_args a) {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
     if (r >= a.R) return;
+    if (a.loss_scale_dev) a.loss_scale = *a.loss_scale_dev;
     float* w = lds[wib][0];
     float* Tr = lds[wib][1];
     float* g = lds[wib][2];     // dL/dw of this level (built through a difference array)
@@ -520,6 +522,9 @@ k_prop_loss(nvo_prop_loss_args a) {
         atomicAdd(shard + 0, a.interlevel_mult * l_inter);
         atomicAdd(shard + 1, a.depth_mult * l_depth);
     }
+    // value-only call (dpre == NULL): nerfstudio evaluates the interlevel / proposal-level depth terms on EVERY step,
+    // also on those where the proposal networks do not train -- the loss values without the gradient pass
+    if (a.dpre == nullptr) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -578,7 +583,7 @@ int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args) {
     NVO_REQUIRE(a.S >= 1 && a.S <= (uint32_t)kMaxS && a.S_main >= 1 && a.S_main <= 64,
                 "prop_loss: S=%u (<=%d) S_main=%u (<=64)", a.S, kMaxS, a.S_main);
     NVO_REQUIRE(a.pre && a.x01 && a.sbins && a.tbins && a.sbins_main && a.weights_main && a.losses &&
-                a.dpre && a.dpre_stride >= 1, "prop_loss: NULL input/output");
+                (a.dpre == nullptr || a.dpre_stride >= 1), "prop_loss: NULL input/output");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "prop_loss[S%u]", a.S);
     NVO_LAUNCH(k_prop_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,

@@ -75,6 +75,17 @@ class EngineConfig:
     depth_sigma: float = 0.001
     normal_loss_mult: float = 5e-6        # reference: nerf_vo/mapping/nerfstudio.py:77 (monosdf normal supervision)
     loss_scale: float = 128.0
+    # torch.cuda.amp.GradScaler dynamics (the reference trains with mixed_precision=True,
+    # /root/reference/nerf_vo/mapping/nerfstudio.py:59 -- nerfstudio wraps the step in GradScaler(): init 65536, x2 after
+    # 2000 consecutive clean steps, x0.5 when any optimiser saw a non-finite gradient).  The state (scale, growth
+    # tracker, per-group applied-step counters) lives on the device, so the captured step stays valid.  False = tcnn's
+    # static loss scale (`loss_scale`) + skip-on-non-finite.
+    dynamic_loss_scale: bool = False
+    loss_scale_init: float = 65536.0
+    loss_scale_growth: float = 2.0
+    loss_scale_backoff: float = 0.5
+    loss_scale_interval: int = 2000
+    loss_scale_max: float = 16777216.0    # 2^24: keeps the fixed-point grid accumulators (|v| < 2^25) in range in bf16 mode
     lr_fields: float = 1e-2
     lr_proposal: float = 1e-2
     lr_camera: float = 1e-4
@@ -127,6 +138,15 @@ class EngineConfig:
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
     # "MFMA bf16 MLP + fp32 hash accumulate"; reference: mixed_precision=True, nerf_vo/mapping/nerfstudio.py:59)
     mlp_dtype: str = "f16"
+    # nerfstudio evaluates the interlevel and proposal-level depth losses on EVERY step and returns them in loss_dict
+    # (/root/reference/nerf_vo/mapping/nerfstudio.py:151-152), also on the steps where the proposal networks do not
+    # train; here they are produced by the proposal backward, which only runs on update steps.  "logging": on the
+    # steps the reference looks at its loss_dict (step % log_every == 0, nerfstudio.py:161-168) a value-only pass of
+    # the proposal loss kernel fills them in (~40 us on those steps); "always": on every non-update step (exact a1
+    # return values on every step); "never": the terms read 0 on non-update steps.  Gradients are identical in all
+    # three (nerfstudio computes these values under no_grad on such steps).
+    proposal_loss_values: str = "logging"
+    log_every: int = 10                   # LoggingConfig.steps_per_log of the trainer mirror
     seed: int = 1337
 
 
@@ -252,7 +272,13 @@ class NerfactoEngine:
         self.corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
         self.d_corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
         self._pose_inputs = None  # (intrinsics, c2w) of the rays currently loaded (pose backward)
-        self.opt_steps = {g: 0 for g in self.group_ranges}
+        # GradScaler-shaped optimiser state ON THE DEVICE: [applied steps x 4 groups | loss scale (float bits) | growth
+        # tracker | pad]; slot of a group = its index in _GROUP_ORDER (also its skip-flag word)
+        self.opt_state = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.dev_applied = self.opt_state[0:4]
+        self.dev_loss_scale = self.opt_state[4:5].view(torch.float32)
+        self.dev_growth_tracker = self.opt_state[5:6]
+        self.dev_loss_scale.fill_(cfg.loss_scale_init if cfg.dynamic_loss_scale else cfg.loss_scale)
         self.step = 0
         self.steps_since_proposal_update = 0
         self._ws = {}  # (ray count, training) -> scratch; never evicted (captured graphs address it by pointer)
@@ -317,6 +343,27 @@ class NerfactoEngine:
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.opt_steps = {g: 0 for g in self.group_ranges}
+
+    @property
+    def opt_steps(self) -> dict:
+        """Steps APPLIED to each parameter group so far (torch.optim.Adam's state['step']: a step GradScaler skipped
+        does not count).  The counters live on the device (nvo_opt_commit advances them); reading them synchronises."""
+        vals = self.dev_applied.tolist()
+        return {g: int(vals[self._GROUP_ORDER.index(g)]) for g in self.group_ranges}
+
+    @opt_steps.setter
+    def opt_steps(self, steps: dict) -> None:
+        vals = self.dev_applied.tolist()
+        for g, n in steps.items():
+            vals[self._GROUP_ORDER.index(g)] = int(n)
+        self.dev_applied.copy_(torch.tensor(vals, dtype=torch.int32))
+
+    def current_loss_scale(self) -> float:
+        """The loss scale the next step will use (device read-back; static unless cfg.dynamic_loss_scale)."""
+        return float(self.dev_loss_scale.item())
+
+    def _loss_scale_ptr(self):
+        return self.dev_loss_scale.data_ptr() if self.cfg.dynamic_loss_scale else None
 
     # ------------------------------------------------------------------------------------------
     # scratch
@@ -492,7 +539,8 @@ class NerfactoEngine:
             dsigma_dx=ws["dsigma_dx"].data_ptr() if normals else None, dsigma_inv_scale=1.0 / cfg.loss_scale,
             gt_normal=ws["gt_normal"].data_ptr() if (normals and training and has_gt_normal) else None,
             normal_mult=cfg.normal_loss_mult if (normals and has_gt_normal) else 0.0,
-            out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16))
+            out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16),
+            loss_scale_dev=self._loss_scale_ptr() if training else None)
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -558,7 +606,7 @@ class NerfactoEngine:
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
                          anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False,
-                         skip_head: bool = False):
+                         skip_head: bool = False, proposal_values: bool | None = None):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -568,6 +616,8 @@ class NerfactoEngine:
             anneal = self.anneal_at(step)
         if update_proposals is None:
             update_proposals = self.proposal_update_due(step)
+        if proposal_values is None:
+            proposal_values = self.proposal_values_due(step, bool(update_proposals))
         # Only what is ACCUMULATED into needs zeroing (colour-head dW, appearance-embedding gradient): every other
         # gradient range is overwritten by its producer (grid slices by plain stores, MLP dW zeroed by nvo_bwd,
         # pose gradient by the exp-map backward).  Ranges of groups that do not train this step keep stale values
@@ -622,6 +672,8 @@ class NerfactoEngine:
                   self._param_ptr("field.base", self.grads))
         if update_proposals and side is None:
             self._proposal_backward(ws, has_depth, pose, stream)
+        if proposal_values and not update_proposals:
+            self._proposal_backward(ws, has_depth, False, stream, values_only=True)
         if side is not None:
             for st in side:
                 torch.cuda.current_stream(self.device).wait_stream(st)  # join
@@ -672,8 +724,16 @@ class NerfactoEngine:
         sizes = (C.c_uint64 * len(ranges))(*[b for _, b in ranges])
         _call("nvo_zero_ranges", stream, len(ranges), ptrs, sizes)
 
-    def _proposal_backward(self, ws, has_depth: bool, pose: bool, stream, levels=None) -> None:
-        """Interlevel + depth loss of both proposal levels and their network backward."""
+    def proposal_values_due(self, step: int, updated: bool) -> bool:
+        """A non-update step on which loss_dict must still carry the interlevel / proposal-level depth VALUES."""
+        mode = self.cfg.proposal_loss_values
+        if updated or mode == "never":
+            return False
+        return mode == "always" or step % max(1, int(self.cfg.log_every)) == 0
+
+    def _proposal_backward(self, ws, has_depth: bool, pose: bool, stream, levels=None, values_only: bool = False) -> None:
+        """Interlevel + depth loss of both proposal levels and their network backward (``values_only``: the loss
+        VALUES alone -- what nerfstudio reports on steps where the proposal networks do not train)."""
         cfg = self.cfg
         R = ws["R"]
         km = len(self.prop_nets)
@@ -689,9 +749,11 @@ class NerfactoEngine:
                 directions_norm=ws["directions_norm"].data_ptr(), interlevel_mult=cfg.interlevel_loss_mult,
                 depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
                 inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
-                losses=self.losses.data_ptr() + 3 * 4, dpre=ws[f"dout{k}"].data_ptr(), dpre_stride=1,
-                act_bf16=int(self.bf16))
+                losses=self.losses.data_ptr() + 3 * 4, dpre=None if values_only else ws[f"dout{k}"].data_ptr(),
+                dpre_stride=1, act_bf16=int(self.bf16), loss_scale_dev=self._loss_scale_ptr())
             _call("nvo_prop_loss", stream, C.byref(pa))
+            if values_only:
+                continue
             _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
                   self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
                   _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
@@ -712,12 +774,13 @@ class NerfactoEngine:
         _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
               _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
         # regulariser: its value goes to loss slot 5 of shard 0, its gradient is scaled like the rest
-        reg_scale = cfg.loss_scale / self.world_size
-        _call("nvo_se3_exp_map_bwd", stream, cfg.num_images,
+        dyn = cfg.dynamic_loss_scale
+        reg_scale = (1.0 if dyn else cfg.loss_scale) / self.world_size
+        _call("nvo_se3_exp_map_bwd_scaled", stream, cfg.num_images,
               self._param_ptr("camera_opt.pose_adjustment", self.params), _ptr(self.d_corrections),
               cfg.camera_trans_l2_penalty, cfg.camera_rot_l2_penalty, reg_scale,
               self._param_ptr("camera_opt.pose_adjustment", self.grads),
-              C.c_void_p(self.losses.data_ptr() + 5 * 4), self._pose_mode())
+              C.c_void_p(self.losses.data_ptr() + 5 * 4), self._pose_mode(), _ptr(self.dev_loss_scale) if dyn else None)
 
     def _pose_mode(self) -> int:
         return {"SE3": 0, "SO3xR3": 1}[self.cfg.camera_mode]
@@ -730,40 +793,72 @@ class NerfactoEngine:
                 "camera_opt": self.camera_lr(self.step)}[g]
 
     def optimizer_step(self, groups=("fields", "proposal_networks", "camera_opt"), from_device_scalars=False,
-                       grads_half: torch.Tensor | None = None, flags_cleared: bool = False) -> None:
-        """Non-finite check + fused Adam, per group (one launch each for all groups).  ``from_device_scalars``: lr and bias corrections
-        are read from self.dev_scalars (filled by _write_step_scalars) instead of kernel arguments, and
-        the per-group step counters are NOT advanced here -- the form a captured graph replays."""
+                       grads_half: torch.Tensor | None = None, flags_cleared: bool = False, step_groups=None,
+                       shard: tuple | None = None, check: bool = True) -> None:
+        """Non-finite check + fused Adam + commit, per group (one launch each for all groups).  GradScaler semantics
+        (/root/reference/nerf_vo/mapping/nerfstudio.py:59, mixed_precision=True): a group whose gradients hold a non-finite
+        value is skipped and its step counter does not advance (the counters live on the device: dev_applied); with
+        cfg.dynamic_loss_scale the scale backs off / grows like torch's GradScaler.update().
+        ``from_device_scalars``: the learning rates are read from self.dev_scalars (filled by _write_step_scalars)
+        instead of kernel arguments -- the form a captured graph replays.
+        ``step_groups``: all groups this STEP trains (default: ``groups``) -- a step that runs its optimisers in two
+        calls hands it to the LAST one, which then updates the loss scale from all of the step's flags.
+        ``shard``: (rank, world) -- this rank's 1/world slice of the FIELDS group only (sharded optimiser: the other ranks
+        step the other slices and the 16-bit working copy is all-gathered afterwards).
+        ``check``: False when the caller already raised the flag words (sharded exchange: they travel with the gradient)."""
         cfg = self.cfg
         stream = _stream(self.device)
         # grads_half: the 2-byte (bf16 | fp16) buffer a compressed all-reduce left behind -- consumed directly
         gbuf, gsz, ghalf = (self.grads, 4, 0) if grads_half is None else (
             grads_half, 2, 2 if grads_half.dtype == torch.bfloat16 else 1)
-        # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
-        # hold stale values and are neither checked nor applied), all in one launch
         active = [g for g in groups if g != "camera_opt" or cfg.optimize_poses]
-        offs = (C.c_uint64 * len(active))(*[self.group_ranges[g][0] for g in active])
-        sizes = (C.c_uint64 * len(active))(*[self.group_ranges[g][1] - self.group_ranges[g][0] for g in active])
-        # (flags_cleared: the step's single zero launch already cleared the flag words -- one launch less)
-        _call("nvo_nonfinite_flag_ranges_or" if flags_cleared else "nvo_nonfinite_flag_ranges", stream, len(active), offs,
-              sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
-        batch = []
-        for g in groups:
-            if g == "camera_opt" and not cfg.optimize_poses:
-                continue
+        order = self._GROUP_ORDER
+
+        def span(g):
             lo, hi = self.group_ranges[g]
-            if not from_device_scalars:
-                self.opt_steps[g] += 1
-            hyper = None
-            if from_device_scalars:
-                gi = self._GROUP_ORDER.index(g)
-                hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi)
-            batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=max(self.opt_steps[g], 1),
-                                        hyper_dev=hyper))
+            if shard is not None and g == "fields":
+                rank, world = shard
+                per = (hi - lo) // world
+                assert per * world == hi - lo, "fields group is padded to a multiple of 8 x 64 elements"
+                lo, hi = lo + rank * per, lo + (rank + 1) * per
+            return lo, hi
+
+        if check:
+            # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
+            # hold stale values and are neither checked nor applied), all in one launch; flag word = the group's slot
+            offs = (C.c_uint64 * len(order))(*[span(g)[0] if g in active else 0 for g in order])
+            sizes = (C.c_uint64 * len(order))(*[span(g)[1] - span(g)[0] if g in active else 0 for g in order])
+            # (flags_cleared: the step's single zero launch already cleared the flag words -- one launch less)
+            if not flags_cleared:
+                slots = [order.index(g) for g in active]
+                for sl in slots:  # only the words of the groups checked here (another call may own the others)
+                    _call("nvo_zero_ranges", stream, 1, (C.c_void_p * 1)(self.skip_flag.data_ptr() + 4 * sl), (C.c_uint64 * 1)(4))
+            _call("nvo_nonfinite_flag_ranges_or", stream, len(order), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        batch = []
+        mask = 0
+        for g in active:
+            lo, hi = span(g)
+            gi = order.index(g)
+            mask |= 1 << gi
+            hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None
+            batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=0, hyper_dev=hyper,
+                                        step_dev=self.dev_applied.data_ptr() + 4 * gi, flag_slot=gi, flag_slot_set=1))
+        if not batch:
+            return
         arr = (_lib.AdamGroup * len(batch))(*batch)
-        _call("nvo_adam_step_groups_mixed", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+        dyn = cfg.dynamic_loss_scale
+        _call("nvo_adam_step_groups_scaled", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
               ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
-              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi)
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
+              _ptr(self.dev_loss_scale) if dyn else None)
+        scale_mask = 0
+        if dyn and "fields" in active:  # the fields group is stepped last in every launch order
+            for g in (step_groups if step_groups is not None else active):
+                if g != "camera_opt" or cfg.optimize_poses:
+                    scale_mask |= 1 << order.index(g)
+        _call("nvo_opt_commit", stream, len(order), mask, scale_mask, _ptr(self.dev_applied), _ptr(self.skip_flag),
+              _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
+              cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max)
 
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step
@@ -775,18 +870,13 @@ class NerfactoEngine:
         _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_sampling), 2, arr)
 
     def _write_step_scalars(self, anneal: float, groups, sampling_step: int | None = None) -> None:
-        """Adam lr / bias corrections of this step -> device memory (read by the captured optimiser); advances the
-        step counters of ``groups``.  (Slot 0 mirrors the anneal for inspection; the kernels read dev_sampling.)"""
-        cfg = self.cfg
+        """Learning rates of this step -> device memory (read by the captured optimiser; the Adam bias corrections are
+        computed on the device from the applied-step counters).  (Slot 0 mirrors the anneal for inspection; the
+        kernels read dev_sampling.)"""
         vals = [0.0] * 16
         vals[0] = anneal
         for gi, g in enumerate(self._GROUP_ORDER):
-            if g in groups:
-                self.opt_steps[g] += 1
-            t = max(self.opt_steps[g], 1)
             vals[1 + 3 * gi] = self._group_lr(g)
-            vals[2 + 3 * gi] = 1.0 - cfg.adam_betas[0] ** t
-            vals[3 + 3 * gi] = math.sqrt(1.0 - cfg.adam_betas[1] ** t)
         if sampling_step is not None:  # (single GPU: the sampling scalars ride in the same launch)
             vals[14], vals[15] = self.anneal_at(sampling_step), float(sampling_step)
             arr = (C.c_float * 16)(*vals)
@@ -820,7 +910,8 @@ class NerfactoEngine:
         groups = ["fields"] + (["proposal_networks"] if updated else []) + (["camera_opt"] if cfg.optimize_poses else [])
         has_depth = dataset.frames_depth is not None
         has_normals = bool(getattr(dataset, "use_normals", False)) and cfg.normal_loss_mult > 0.0
-        key = (R, updated, has_depth, all_reduce is not None, has_normals)
+        values = self.proposal_values_due(step, updated)
+        key = (R, updated, has_depth, all_reduce is not None, has_normals, values)
         self._reducer_compress = getattr(all_reduce, "compress", None)
         if self._pix_scale is None:
             self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -831,17 +922,22 @@ class NerfactoEngine:
             self._pix_scale_host = extent
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._capture_step(dataset, R, updated, has_depth, groups, all_reduce is not None, has_normals)
-            self._graphs[key] = entry
-            # Capture the sibling variant (with / without the proposal-network update) right away: the first ten steps
-            # all refresh the proposal networks, so the other graph would otherwise be captured -- two eager warm-up
-            # steps + the capture, a few ms -- in the middle of training (step 10), e.g. inside a timed window.
-            sib = (R, not updated, has_depth, all_reduce is not None, has_normals)
-            if sib not in self._graphs:
-                sib_groups = ["fields"] + ([] if updated else ["proposal_networks"]) + (
+            # Capture EVERY variant of the step right away (with / without the proposal-network update, and the
+            # non-update step that still evaluates the proposal loss values): the first ten steps all refresh the
+            # proposal networks, so the other graphs would otherwise be captured -- two eager warm-up steps + the
+            # capture, a few ms -- in the middle of training (step 10), e.g. inside a timed window.
+            mode = cfg.proposal_loss_values
+            variants = [(True, False)] + ([(False, False)] if mode != "always" else []) + (
+                [(False, True)] if mode != "never" else [])
+            for v_upd, v_val in variants:
+                vkey = (R, v_upd, has_depth, all_reduce is not None, has_normals, v_val)
+                if vkey in self._graphs:
+                    continue
+                v_groups = ["fields"] + (["proposal_networks"] if v_upd else []) + (
                     ["camera_opt"] if cfg.optimize_poses else [])
-                self._graphs[sib] = self._capture_step(dataset, R, not updated, has_depth, sib_groups,
-                                                       all_reduce is not None, has_normals)
+                self._graphs[vkey] = self._capture_step(dataset, R, v_upd, has_depth, v_groups, all_reduce is not None,
+                                                        has_normals, v_val)
+            entry = self._graphs[key]
         if all_reduce is None:
             self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
             entry["main"].replay()
@@ -873,7 +969,8 @@ class NerfactoEngine:
         if all_reduce is not None:
             if cfg.pipeline_sampling_prefix:
                 nstep = self.step
-                nkey = (R, self.proposal_update_due(nstep), has_depth, True, has_normals)
+                nupd = self.proposal_update_due(nstep)
+                nkey = (R, nupd, has_depth, True, has_normals, self.proposal_values_due(nstep, nupd))
                 nentry = self._graphs.get(nkey)
                 if nentry is not None:  # (a key that still has to be captured runs un-pipelined once)
                     self._write_sampling_scalars(nstep)
@@ -883,7 +980,7 @@ class NerfactoEngine:
             entry["opt_b"].replay()
         return updated
 
-    def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False):
+    def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False, values=False):
         dev = self.device
         cfg = self.cfg
         ws = self._workspace(R, True)
@@ -945,7 +1042,7 @@ class NerfactoEngine:
 
         def body_rest():
             self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
-                                  anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True)
+                                  anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True, proposal_values=values)
             if half is not None:  # 2-byte copy of the ranges the collective will exchange
                 cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"
                 for lo, hi in cast_ranges:
@@ -963,14 +1060,18 @@ class NerfactoEngine:
         groups_b = ["fields"] if split else list(groups)
 
         def body_opt(gs):
-            # single graph: ONE optimiser call per step, and the flag words were cleared by the step's zero launch
-            # (split graphs run two optimiser calls that share flag slot 0: they reset their own)
-            self.optimizer_step(gs, from_device_scalars=True, grads_half=half, flags_cleared=not split)
+            # every group owns ONE flag word (its slot) and the step's zero launch cleared them all, so neither the
+            # single optimiser call of the one-graph step nor the two calls of the split step reset anything
+            self.optimizer_step(gs, from_device_scalars=True, grads_half=half, flags_cleared=True, step_groups=groups)
 
         # warm-up on a side stream (allocations, lazy module state), then capture
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.params_half.clone())
+        saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.params_half.clone(),
+                 self.opt_state.clone())
+        # the warm-up runs on real step scalars (learning rates, anneal, sampler counter): all-zero scalars used to
+        # put lr / bias1 = 0 / 0 = NaN into every parameter of the first warm-up step
+        self._write_step_scalars(self.anneal_at(self.step), groups, sampling_step=self.step)
         with torch.cuda.stream(side):
             for _ in range(2):
                 body_head()
@@ -980,8 +1081,8 @@ class NerfactoEngine:
                 body_opt(groups_b)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half), saved):
-            dst.copy_(src)  # the warm-up steps must not count as training
+        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
+            dst.copy_(src)  # the warm-up steps must not count as training (nor as applied optimiser steps)
         # the graphs address these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
         drawn = ws["ray_indices"] if (cfg.fused_ray_head and cfg.optimize_poses and "ray_indices" in ws) else ray_indices

@@ -129,7 +129,9 @@ class ExtendedNerfactoModel:
         e = self.engine
         return {"params": e.params.detach().clone(), "exp_avg": e.exp_avg.clone(), "exp_avg_sq": e.exp_avg_sq.clone(),
                 "opt_steps": dict(e.opt_steps), "step": e.step,
-                "steps_since_proposal_update": e.steps_since_proposal_update}
+                "steps_since_proposal_update": e.steps_since_proposal_update,
+                # GradScaler state (torch: scaler.state_dict() -> scale, _growth_tracker)
+                "scaler": {"scale": e.current_loss_scale(), "growth_tracker": int(e.dev_growth_tracker.item())}}
 
     def load_state_dict(self, state: dict) -> None:
         e = self.engine
@@ -139,6 +141,9 @@ class ExtendedNerfactoModel:
         e.opt_steps = dict(state["opt_steps"])
         e.step = int(state["step"])
         e.steps_since_proposal_update = int(state["steps_since_proposal_update"])
+        if "scaler" in state and e.cfg.dynamic_loss_scale:
+            e.dev_loss_scale.fill_(float(state["scaler"]["scale"]))
+            e.dev_growth_tracker.fill_(int(state["scaler"]["growth_tracker"]))
 
     # ---- inference ---------------------------------------------------------------------------
     @torch.no_grad()

@@ -189,6 +189,8 @@ class NgpEngine:
         ws["density_out"] = torch.zeros(cap, 16, **f16)
         ws["rgb_out"] = torch.zeros(cap, 16, **f16)
         ws["ctx"] = torch.empty(self.density_net.ctx_bytes(cap), dtype=torch.uint8, device=dev)
+        # staging area of the march (ray-major runs of accepted samples): owned here, not by the native side
+        ws["march_scratch"] = torch.empty(int(_lib.lib().nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=dev)
         if training:
             ws["rgb_hidden"] = torch.zeros(2, cap, 64, **f16)
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
@@ -270,7 +272,8 @@ class NgpEngine:
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
-              _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]))
+              _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), _ptr(ws["march_scratch"]),
+              ws["march_scratch"].numel())
         _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
               _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
         _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),

@@ -25,22 +25,26 @@ def main():
     dev = torch.device("cuda:0")
     plan = torch.load(os.path.join(workdir, "plan.pt"))
     n, H, W, R = plan["n"], plan["H"], plan["W"], plan["R"]
-    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=dev, use_normals=False)
+    normals = bool(plan.get("normals", False))  # BASELINE configs[4]: monosdf normal supervision (+ bf16 MLPs)
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=dev, use_normals=normals)
     seq = make_sequence(n, H, W, device=dev)
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
-               "frames_depth": seq["frames_depth"]})
+               "frames_depth": seq["frames_depth"], **({"frames_normal": seq["frames_normal"]} if normals else {})})
     torch.manual_seed(100)  # SAME seed on every rank: the engine itself must give each rank its own sampler stream
     eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=plan["poses"],
-                                      pipeline_sampling_prefix=plan.get("pipeline", True)), dev, world_size=world,
-                         rank=rank)
+                                      pipeline_sampling_prefix=plan.get("pipeline", True),
+                                      mlp_dtype=plan.get("mlp_dtype", "f16"), expect_normals=normals,
+                                      **plan.get("engine_overrides", {})), dev,
+                         world_size=world, rank=rank)
     eng.set_params(plan["params"].to(dev))  # identical initial parameters on every rank
     reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress)
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
     for k in range(plan["eager_steps"]):
         idx = plan["rays"][k][rank].to(dev)
         jit = tuple(j.to(dev) for j in plan["jitters"][k][rank])
-        eng.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit, all_reduce=reducer)
+        eng.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit, all_reduce=reducer,
+                       normals=ds.world_normals01() if normals else None)
     torch.cuda.synchronize()
     after_eager = eng.params.detach().cpu().clone()
     prefix_mismatch, prefix_checked = [], 0
@@ -75,7 +79,7 @@ def main():
         def run(pipeline: bool):
             for dst, src in zip((eng.params, eng.params_half, eng.exp_avg, eng.exp_avg_sq), snap[0]):
                 dst.copy_(src)
-            eng.opt_steps.update(snap[1])
+            eng.opt_steps = snap[1]
             eng.step, eng.steps_since_proposal_update, eng._pending_head = snap[2], snap[3], None
             eng.cfg.pipeline_sampling_prefix = pipeline
             for _ in range(plan["ab_pipeline"]):

@@ -26,10 +26,10 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_ranks(workdir, world, compress):
+def _run_ranks(workdir, world, compress, worker="dist_engine_worker.py"):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "dist_engine_worker.py"), str(r),
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", worker), str(r),
                                str(world), str(port), str(workdir), compress], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
@@ -89,9 +89,12 @@ def test_pipelined_sampling_prefix_keeps_the_trajectory(device, tmp_path, poses)
     assert scale > 0 and diff <= max(50.0 * noise, 1e-4), f"pipelined prefix changed the update: {diff:.3e} vs noise {noise:.3e}"
 
 
-@pytest.mark.parametrize("compress,poses", [("none", False), ("bf16", False), ("bf16", True), ("fp16", False)],
-                         ids=["none", "bf16", "bf16-pose-optimisation", "fp16"])
-def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, poses):
+@pytest.mark.parametrize("compress,poses,mlp_dtype,normals",
+                         [("none", False, "f16", False), ("bf16", False, "f16", False), ("bf16", True, "f16", False),
+                          ("fp16", False, "f16", False), ("bf16", False, "bf16", True)],
+                         ids=["none", "bf16", "bf16-pose-optimisation", "fp16", "configs4-bf16-mlp-normals"])
+def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, poses, mlp_dtype, normals):
+    """Last id = BASELINE configs[4] on two ranks: bf16 MFMA MLPs + monosdf normal supervision, bf16 gradient exchange."""
     from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
     from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
     from nerf_vo_amd.synthetic import make_sequence
@@ -99,33 +102,37 @@ def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, po
     n, H, W, R, world, eager_steps, graph_steps = 6, 60, 80, 512, 2, 3, 4
     g = torch.Generator().manual_seed(77)
     # the concatenated batch, one process
-    ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=world * R, optimize_poses=poses), device)
+    ref = NerfactoEngine(EngineConfig(num_images=n, num_rays=world * R, optimize_poses=poses, mlp_dtype=mlp_dtype,
+                                      expect_normals=normals), device)
     params0 = ref.params.detach().cpu().clone()
     scale = torch.tensor([n, H, W])
     rays = [[torch.floor(torch.rand(R, 3, generator=g) * scale).long() for _ in range(world)] for _ in range(eager_steps)]
     jitters = [[tuple(torch.rand(R, generator=g) for _ in range(3)) for _ in range(world)] for _ in range(eager_steps)]
     torch.save({"n": n, "H": H, "W": W, "R": R, "params": params0, "rays": rays, "jitters": jitters, "poses": poses,
-                "eager_steps": eager_steps, "graph_steps": graph_steps}, tmp_path / "plan.pt")
+                "eager_steps": eager_steps, "graph_steps": graph_steps, "mlp_dtype": mlp_dtype, "normals": normals},
+               tmp_path / "plan.pt")
     r0, r1 = _run_ranks(tmp_path, world, compress)
     # (1) replicated state never diverges
     assert torch.equal(r0["after_eager"], r1["after_eager"]) and torch.equal(r0["after_graph"], r1["after_graph"])
     assert not torch.equal(r0["after_eager"], params0) and not torch.equal(r0["after_graph"], r0["after_eager"])
     assert int(r0["skip"].sum()) == 0 and np.isfinite(list(r0["losses"].values())).all()
+    assert ("normal_loss" in r0["losses"]) == normals
     # every process called torch.manual_seed with the SAME value: the ranks must still draw different rays (otherwise
     # the summed gradient is one rank's gradient and data parallelism silently adds nothing)
     same = float((r0["ray_indices"] == r1["ray_indices"]).all(dim=1).float().mean())
     assert same < 0.01, f"{same:.1%} of the two ranks' pixel samples coincide"
     # (2) same trajectory as ONE process training on the concatenated batch
-    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=normals)
     seq = make_sequence(n, H, W, device=device)
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
-               "frames_depth": seq["frames_depth"]})
+               "frames_depth": seq["frames_depth"], **({"frames_normal": seq["frames_normal"]} if normals else {})})
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
     for k in range(eager_steps):
         idx = torch.cat(rays[k]).to(device)
         jit = tuple(torch.cat([jitters[k][r][j] for r in range(world)]).to(device) for j in range(3))
-        ref.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit)
+        ref.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, jitters=jit,
+                       normals=ds.world_normals01() if normals else None)
     torch.cuda.synchronize()
     upd_ref = (ref.params.detach().cpu() - params0).double()
     upd_two = (r0["after_eager"] - params0).double()
@@ -140,3 +147,32 @@ def test_two_rank_step_matches_concatenated_batch(device, tmp_path, compress, po
     # have turned into full-size steps: kept as an option, measured here, NOT what bench.py uses.
     tol = {"none": 5e-3, "bf16": 2e-2, "fp16": 0.5}[compress]  # measured: 2.9e-3 / 6.2e-3 / 1.95e-1
     assert rel < tol, f"two-rank update differs from the concatenated-batch update by {rel:.3e} (relative L1)"
+
+
+def test_ngp_density_grid_stays_identical_across_ranks(device, tmp_path):
+    """Occupancy-grid back-end on two ranks ("all-reduce(max) of the density-grid EMA ... or
+    identical deterministic updates on every rank").  Each rank jitters its own point per grid cell and draws its own
+    rays; with ``reduce_max`` of the fresh estimates and the summed gradients, the density grid, the Morton bitfield
+    and every parameter (camera offsets included) are BIT-identical on both ranks after every grid update -- and they
+    are NOT without the reduction (the control run), so the assertion has teeth."""
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+
+    n, H, W, R, world = 8, 60, 80, 512, 2
+    ref = NgpEngine(NgpConfig(num_images=n, num_rays=R, capacity=1 << 16), device)
+    params0 = ref.params.detach().cpu().clone()
+    del ref
+    torch.save({"n": n, "H": H, "W": W, "R": R, "steps": 9, "update_every": 4, "params": params0}, tmp_path / "plan.pt")
+    r0, r1 = _run_ranks(tmp_path, world, "1", worker="dist_ngp_worker.py")
+    assert len(r0["grids"]) == 3
+    assert not torch.equal(r0["rays"], r1["rays"]), "both ranks drew the same rays"
+    for k, (g0, g1, b0, b1) in enumerate(zip(r0["grids"], r1["grids"], r0["bits"], r1["bits"])):
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)), f"density grid differs after update {k}"
+        assert torch.equal(b0, b1), f"bitfield differs after update {k}"
+        occ = float(np.unpackbits(b0.numpy()).mean())
+        assert 0.0 < occ <= 1.0
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["pose"], r1["pose"]), "replicated state diverged"
+    assert not torch.equal(r0["params"], params0) and int(r0["skip"].sum()) == 0
+    assert np.isfinite(list(r0["losses"].values())).all()
+    # control: without the exchange the ranks' grids differ (own jitters, own gradients)
+    c0, c1 = _run_ranks(tmp_path, world, "0", worker="dist_ngp_worker.py")
+    assert not torch.equal(c0["grids"][0], c1["grids"][0])

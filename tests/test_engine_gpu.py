@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_tcnn_gpu import _assert_close
+from test_tcnn_gpu import BF16_K, _assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,7 @@ def test_full_step_matches_oracle(device, dtype):
     below is multiplied by K = 8 in that mode."""
     from oracle.quant import activation_format
 
-    K = 1.0 if dtype == "f16" else 8.0
+    K = 1.0 if dtype == "f16" else BF16_K
     eng = _make_engine(device, mlp_dtype=dtype)
     orc = _oracle_from_engine(eng)
     R = 256
@@ -406,15 +406,20 @@ def test_grouped_adam_equals_per_group_launches(device):
     assert bool(torch.isfinite(p).all())
 
 
-def test_normal_supervision_matches_oracle(device):
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_normal_supervision_matches_oracle(device, dtype):
     """monosdf normal loss on the analytic normals (reference hook nerf_vo/mapping/nerfstudio_utils.py:337-350;
     enhancement modes containing 'normal').  Every other loss multiplier is zeroed so that the gradient
-    compared is the normal term's alone.  Tolerances: per-sample normals come from an fp16 MLP backward
-    (oracle: float64) -> direction agreement cos > 0.999 on >= 98 % of the samples; with the kernel's own
+    compared is the normal term's alone.  Tolerances: per-sample normals come from a 16-bit MLP backward
+    (oracle: float64) -> direction agreement cos > 0.999 (bf16: 1 - 8e-3) on >= 98 % of the samples; with the kernel's own
     per-sample normals injected into the oracle the rendered normals agree to 2e-3 absolute (97 % of rays), the loss to
-    1 % and the gradients to the tolerance of the full-step test."""  # noqa
+    1 % and the gradients to the tolerance of the full-step test.  bf16 = BASELINE configs[4] (bf16 MFMA MLPs + normal
+    supervision): every tolerance x BF16_K = 8 = 2^(11 - 8), the ratio of the two formats' rounding steps."""  # noqa
+    from oracle.quant import activation_format
+
+    K = 1.0 if dtype == "f16" else BF16_K
     eng = _make_engine(device, rgb_loss_mult=0.0, distortion_loss_mult=0.0, depth_loss_mult=0.0,
-                       interlevel_loss_mult=0.0, normal_loss_mult=1.0)
+                       interlevel_loss_mult=0.0, normal_loss_mult=1.0, mlp_dtype=dtype)
     orc = _oracle_from_engine(eng)
     orc.cfg.rgb_loss_mult = orc.cfg.distortion_loss_mult = orc.cfg.depth_loss_mult = 0.0
     orc.cfg.interlevel_loss_mult = 0.0
@@ -432,29 +437,32 @@ def test_normal_supervision_matches_oracle(device):
     gx = ws["dsigma_dx"].double().cpu()
     got_sn = -torch.nn.functional.normalize(gx, dim=-1).view(R, -1, 3)
 
-    out = orc.forward(origins.double(), directions.double(), dnorm.double(), cam, tuple(j.double() for j in jit),
-                      anneal=1.0, training=True, normals=True, sample_normals_override=got_sn)
+    with activation_format(dtype):
+        out = orc.forward(origins.double(), directions.double(), dnorm.double(), cam, tuple(j.double() for j in jit),
+                          anneal=1.0, training=True, normals=True, sample_normals_override=got_sn)
+    cos_min = 1.0 - 1e-3 * K
     cos = (got_sn * out["sample_normals"]).sum(-1)
     sel = out["weights_list"][-1] > 1e-4  # samples that matter for the render
-    frac = (cos[sel] > 0.999).double().mean().item()
-    assert frac >= 0.98, f"analytic normals agree (cos>0.999) on only {frac:.4f} of the weighted samples"
+    frac = (cos[sel] > cos_min).double().mean().item()
+    assert frac >= 0.98, f"analytic normals agree (cos>{cos_min}) on only {frac:.4f} of the weighted samples"
 
     # the normalised sum is ill-conditioned on rays whose per-sample normals cancel (|sum w n| << 1):
     # 2e-3 on >= 97 % of the rays, 3e-2 everywhere
     err = (ws["out_normals"].double().cpu() - out["normals"]).abs().max(dim=-1).values
-    assert (err < 2e-3).double().mean() >= 0.97 and err.max() < 3e-2, \
-        f"rendered normals: max err {err.max():.3e}, frac<2e-3 {(err < 2e-3).double().mean():.3f}"
-    ld = orc.loss_dict(out, gt_rgb.double(), None, gt_normal.double())
-    ld["normal_loss"].backward()
+    assert (err < 2e-3 * K).double().mean() >= 0.97 and err.max() < min(3e-2 * K, 0.15), \
+        f"rendered normals: max err {err.max():.3e}, frac<{2e-3 * K} {(err < 2e-3 * K).double().mean():.3f}"
+    with activation_format(dtype):
+        ld = orc.loss_dict(out, gt_rgb.double(), None, gt_normal.double())
+        ld["normal_loss"].backward()
     got = eng.loss_dict()
     ref = float(ld["normal_loss"])
-    assert abs(got["normal_loss"] - ref) <= 1e-2 * abs(ref), f"normal_loss got {got['normal_loss']:.6e} ref {ref:.6e}"
+    assert abs(got["normal_loss"] - ref) <= 1e-2 * K * abs(ref), f"normal_loss got {got['normal_loss']:.6e} ref {ref:.6e}"
 
     ls = eng.cfg.loss_scale
     o, sz, _ = eng.segments["field.base"]
     nb = _mlp_count("field.base")
     gb = eng.grads[o:o + sz] / ls
-    tol = dict(rtol=3e-2, atol_scale=1.5e-2, max_outlier_frac=1e-4)
+    tol = dict(rtol=3e-2 * K, atol_scale=1.5e-2 * K, max_outlier_frac=1e-4 * K, max_outlier=0.05 if K == 1.0 else 0.2)
     assert orc.params["base_mlp"].grad.abs().max() > 0
     _assert_close(gb[:nb], orc.params["base_mlp"].grad, what="d base MLP (normal loss)", **tol)
     _assert_close(gb[nb:], orc.params["base_grid"].grad.reshape(-1), what="d main grid (normal loss)", **tol)
@@ -464,13 +472,14 @@ def test_normal_supervision_matches_oracle(device):
     torch.cuda.synchronize()
     wse = eng._workspace(R, False)
     sn_e = -torch.nn.functional.normalize(wse["dsigma_dx"].double().cpu(), dim=-1).view(R, -1, 3)
-    refe = orc.forward(origins.double(), directions.double(), dnorm.double(), cam, None, anneal=1.0, training=False,
-                       normals=True, sample_normals_override=sn_e)
+    with activation_format(dtype):
+        refe = orc.forward(origins.double(), directions.double(), dnorm.double(), cam, None, anneal=1.0, training=False,
+                           normals=True, sample_normals_override=sn_e)
     cos_e = (sn_e * refe["sample_normals"]).sum(-1)[refe["weights_list"][-1] > 1e-4]
-    assert (cos_e > 0.999).double().mean() >= 0.98
+    assert (cos_e > cos_min).double().mean() >= 0.98
     d = (res["normals"].double().cpu() - refe["normals"]).abs().max(dim=-1).values
-    assert (d < 2e-3).double().mean() >= 0.97 and d.max() < 3e-2, \
-        f"eval normals: max err {d.max():.3e}, frac<2e-3 {(d < 2e-3).double().mean():.3f}"
+    assert (d < 2e-3 * K).double().mean() >= 0.97 and d.max() < min(3e-2 * K, 0.15), \
+        f"eval normals: max err {d.max():.3e}, frac<{2e-3 * K} {(d < 2e-3 * K).double().mean():.3f}"
 
 
 def test_eval_render_matches_oracle(device):
@@ -544,7 +553,7 @@ def test_graph_replay_matches_eager_semantics(device):
     assert scalars[0][2] == pytest.approx(0.1, rel=1e-5) and scalars[9][2] == pytest.approx(1 - 0.9 ** 10, rel=1e-5)
     assert scalars[5][0] > scalars[1][0] > 0.0  # anneal ramps up
     assert not torch.equal(p0, eng.params)
-    assert len(eng._graphs) == 2
+    assert len(eng._graphs) == 3  # update step, plain step, plain step that also evaluates the proposal loss values
     # the optimiser must really have run on every replay: the GradScaler-style skip flag stays 0
     # (regression: a captured 4-byte hipMemsetAsync replayed as 0x01 bytes and silently disabled Adam)
     assert int(eng.skip_flag.sum().item()) == 0
@@ -588,6 +597,122 @@ def test_graph_replay_matches_eager_semantics(device):
         eng2.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth)
     eager = eng2.loss_dict()["rgb_loss"]
     assert abs(np.log(losses[-1] / eager)) < 0.35, (losses[-1], eager)
+
+
+def test_gradscaler_step_and_update_semantics(device):
+    """GradScaler.step / GradScaler.update as the reference trains with them (mixed_precision=True,
+    /root/reference/nerf_vo/mapping/nerfstudio.py:59), restated here and run against the engine's device-side state:
+      * a group whose gradient holds an inf / NaN is skipped ALONE, its moments and parameters do not move, and its Adam
+        step counter (torch: state['step'], which feeds the bias corrections) does NOT advance;
+      * the other groups step with the unscaled gradient;
+      * the loss scale halves after a step in which ANY optimiser was skipped and doubles after `growth_interval`
+        consecutive clean steps; the growth tracker restarts at every back-off.
+    The parameters are compared with torch.optim.Adam fed the unscaled gradients on the clean steps only."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+
+    cfg = EngineConfig(num_images=NUM_IMAGES, optimize_poses=True, dynamic_loss_scale=True, loss_scale_init=1024.0,
+                       loss_scale_interval=3)
+    eng = NerfactoEngine(cfg, device)
+    g = torch.Generator().manual_seed(3)
+    p0 = (torch.randn(eng.n_params, generator=g) * 0.1)
+    eng.set_params(p0)
+    ref_p = {k: torch.nn.Parameter(p0[lo:hi].clone().to(device)) for k, (lo, hi) in eng.group_ranges.items()}
+    lrs = {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal}
+    bad_plan = {2: ["proposal_networks"], 5: ["fields"], 6: ["fields", "camera_opt"]}  # step -> poisoned groups
+    scale, tracker = 1024.0, 0
+    applied = {k: 0 for k in eng.group_ranges}
+    opt = {}
+    for step in range(12):
+        eng.step = step
+        raw = torch.randn(eng.n_params, generator=g) * 1e-3
+        grads = (raw * scale).to(device)
+        for k in bad_plan.get(step, []):
+            lo, hi = eng.group_ranges[k]
+            grads[lo + 7] = float("inf") if step % 2 else float("nan")
+        eng.grads.copy_(grads)
+        eng.skip_flag.zero_()
+        assert eng.current_loss_scale() == scale
+        eng.optimizer_step(flags_cleared=True)
+        torch.cuda.synchronize()
+        found = bad_plan.get(step, [])
+        for k, (lo, hi) in eng.group_ranges.items():
+            if k in found:
+                continue
+            applied[k] += 1
+            if k not in opt:
+                lr0 = lrs.get(k, eng.camera_lr(step))
+                opt[k] = torch.optim.Adam([ref_p[k]], lr=lr0, eps=cfg.adam_eps, betas=cfg.adam_betas)
+            if k == "camera_opt":
+                opt[k].param_groups[0]["lr"] = eng.camera_lr(step)
+            ref_p[k].grad = raw[lo:hi].to(device)
+            opt[k].step()
+        if found:
+            scale, tracker = scale * 0.5, 0
+        else:
+            tracker += 1
+            if tracker == 3:
+                scale, tracker = scale * 2.0, 0
+        assert eng.opt_steps == applied, (step, eng.opt_steps, applied)
+        assert eng.current_loss_scale() == scale and int(eng.dev_growth_tracker.item()) == tracker, (step, scale)
+        flags = eng.skip_flag.tolist()
+        assert [bool(flags[eng._GROUP_ORDER.index(k)]) for k in eng._GROUP_ORDER] == [k in found for k in eng._GROUP_ORDER]
+    for k, (lo, hi) in eng.group_ranges.items():
+        _assert_close(eng.params[lo:hi], ref_p[k].detach(), rtol=2e-5, atol_scale=2e-6, what=f"params of group {k}")
+    assert bool(torch.isfinite(eng.params).all()) and bool(torch.isfinite(eng.exp_avg_sq).all())
+
+
+def test_native_scratch_survives_larger_batches_between_replays(device):
+    """Graph-capture safety of the NATIVE scratch (record stream of the streamed grid backward, live-sample list,
+    per-level partials of the input backward): captured graphs address those blocks by pointer, and a larger batch
+    between two replays used to hipFree + hipMalloc them.  Now a block a captured launch addresses is retired, not
+    freed (csrc/nvo_common.h NvoScratch).  Run A: 8 replays.  Run B: 4 replays, then -- with the training state saved
+    and restored around it -- an eager step at 4x the ray count and a render with analytic normals at 8x (both grow every
+    native scratch block), then 4 more replays.  B must land where A does up to the float-atomic noise of the step
+    (measured ~1e-6 relative L1 of the update; a graph that kept a dangling pointer faults or trains on garbage)."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 1024
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=True)
+    seq = make_sequence(n, H, W, device=device)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"], "frames_normal": seq["frames_normal"]})
+    c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
+
+    def run(interrupt: bool):
+        torch.manual_seed(11)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=True, expect_normals=True), device)
+        p0 = eng.params.clone()
+        for _ in range(4):
+            eng.train_step_graphed(ds)
+        if interrupt:
+            torch.cuda.synchronize()
+            saved = ([t.clone() for t in (eng.params, eng.params_half, eng.exp_avg, eng.exp_avg_sq)], dict(eng.opt_steps),
+                     eng.step, eng.steps_since_proposal_update)
+            idx = torch.floor(torch.rand(4 * R, 3, device=device) * torch.tensor([n, H, W], device=device)).long()
+            eng.train_step(idx, ds.camera_intrinsics, c2w, ds.frames_color, ds.frames_depth, normals=ds.world_normals01())
+            o = torch.zeros(8 * R, 3, device=device)
+            d = torch.nn.functional.normalize(torch.randn(8 * R, 3, device=device), dim=-1)
+            eng.render_rays(o, d, torch.ones(8 * R, device=device), normals=True)
+            torch.cuda.synchronize()
+            for dst, src in zip((eng.params, eng.params_half, eng.exp_avg, eng.exp_avg_sq), saved[0]):
+                dst.copy_(src)
+            eng.opt_steps = saved[1]
+            eng.step, eng.steps_since_proposal_update = saved[2], saved[3]
+            junk = [torch.full((1 << 20,), float("nan"), device=device) for _ in range(8)]
+        for _ in range(4):
+            eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        assert int(eng.skip_flag.sum()) == 0 and bool(torch.isfinite(eng.params).all())
+        return (eng.params - p0).double().cpu(), eng.loss_dict()
+
+    upd_a, loss_a = run(False)
+    upd_b, loss_b = run(True)
+    rel = float((upd_a - upd_b).abs().sum() / upd_a.abs().sum())
+    assert rel < 5e-3, f"replays after a larger eager batch diverged from the uninterrupted run: {rel:.3e}"
+    assert abs(loss_a["rgb_loss"] - loss_b["rgb_loss"]) <= 2e-2 * loss_a["rgb_loss"], (loss_a, loss_b)
 
 
 @pytest.mark.parametrize("mode", ["SE3", "SO3xR3"])

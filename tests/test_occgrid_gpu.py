@@ -52,8 +52,9 @@ def test_march_bit_exact(device, n_levels, cone):
     ridx = torch.full((cap,), -1, dtype=torch.int32, device=device)
     t = torch.zeros(cap, device=device)
     dt = torch.zeros(cap, device=device)
+    scratch = torch.empty(int(lib.nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=device)
     _lib.check(lib.nvo_occ_march(_stream(), R, _p(od), _p(dd), _p(bfd), n_levels, cone, 0.0, _p(jd), cap, _p(counts),
-                                 _p(offsets), _p(ridx), _p(t), _p(dt)), "occ_march")
+                                 _p(offsets), _p(ridx), _p(t), _p(dt), _p(scratch), scratch.numel()), "occ_march")
     torch.cuda.synchronize()
     rc, rt, rdt = O.march_rays(o, d, bf, n_levels, cone, 0.0, jit)
     got_c = counts.cpu().numpy().astype(np.uint32)
@@ -86,8 +87,12 @@ def test_capacity_drops_whole_rays(device):
     ridx = torch.full((cap,), -1, dtype=torch.int32, device=device)
     t = torch.zeros(cap, device=device)
     dt = torch.zeros(cap, device=device)
+    scratch = torch.empty(int(lib.nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=device)
     _lib.check(lib.nvo_occ_march(_stream(), R, _p(tens[0]), _p(tens[1]), _p(tens[2]), 1, 0.0, 0.0, None, cap,
-                                 _p(counts), _p(offsets), _p(ridx), _p(t), _p(dt)), "occ_march")
+                                 _p(counts), _p(offsets), _p(ridx), _p(t), _p(dt), _p(scratch), scratch.numel()), "occ_march")
+    # an undersized staging area is refused, not overrun
+    assert lib.nvo_occ_march(_stream(), R, _p(tens[0]), _p(tens[1]), _p(tens[2]), 1, 0.0, 0.0, None, cap, _p(counts),
+                             _p(offsets), _p(ridx), _p(t), _p(dt), _p(scratch), scratch.numel() - 8) != 0
     torch.cuda.synchronize()
     c = counts.cpu().numpy()
     per_ray = c[0]

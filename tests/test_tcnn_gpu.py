@@ -51,6 +51,11 @@ def _points(n, seed, edge_cases=True):
     return x
 
 
+# bf16 keeps 8 significant bits where fp16 keeps 11: one rounding step is 2^(11-8) = 8x wider, and every tolerance of a
+# test that runs in both formats is multiplied by this ONE factor in bf16 mode
+BF16_K = 8.0
+
+
 def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0, max_outlier=0.05):
     """|got-ref| <= atol_scale*max|ref| + rtol*|ref| elementwise.  max_outlier_frac > 0 is only used
     for gradients that pass through ReLU kinks: a hidden unit whose pre-activation is within fp16
@@ -344,7 +349,7 @@ def test_network_fwd_bwd(device, shape, dtype):
     from oracle.quant import activation_format, q16
 
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
-    k = 1.0 if dtype == "f16" else 8.0
+    k = 1.0 if dtype == "f16" else BF16_K
     n_in, n_out, width, n_hidden, act, out_act = shape
     cfg = {"otype": "FullyFusedMLP", "activation": act, "output_activation": out_act, "n_neurons": width,
            "n_hidden_layers": n_hidden}
@@ -405,7 +410,7 @@ def test_network_with_input_encoding(device, cfg, width, dtype):
     from oracle.quant import activation_format, q16
 
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
-    k = 1.0 if dtype == "f16" else 8.0
+    k = 1.0 if dtype == "f16" else BF16_K
     spec = _spec(cfg)
     n_out = 16 if width == 64 else 1
     net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width,
