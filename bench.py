@@ -227,7 +227,10 @@ def main() -> None:
                 compress = "fp16"
         if compress == "none":
             compress = None
-    reducer = GradientAllReduce(dist, compress=compress) if dist is not None else None
+    # sharded optimiser (reduce-scatter -> Adam on this rank's slice -> all-gather of the working copy): the default
+    # whenever the exchange is compressed; NVO_SHARD_OPT=0 = all-reduce + replicated optimiser
+    shard_opt = compress is not None and os.environ.get("NVO_SHARD_OPT", "1") != "0"
+    reducer = GradientAllReduce(dist, compress=compress, shard_optimizer=shard_opt) if dist is not None else None
     if dist is not None:  # identical initial parameters on every rank
         dist.broadcast(engine.params, src=0)
         engine.sync_half()
@@ -414,6 +417,25 @@ def main() -> None:
                        "train_ray_samples_per_sec": res["ray_samples_per_sec"]}
 
     if rank == 0:
+        captured = any(e.get("captured_collectives") for e in engine._graphs.values())
+        if not use_graph:
+            launch_desc = "eager"
+        elif dist is None:
+            launch_desc = "hipGraph replay: ONE graph per step (variants: with / without proposal update, value-only proposal losses)"
+        elif captured:
+            launch_desc = ("hipGraph replay: ONE graph per step with the RCCL collectives captured inside "
+                           "(body -> exchange -> next sampling prefix)")
+        else:
+            launch_desc = "hipGraph replay: compute segments (body / opt_a / head0 / opt_b / head1) around eager collectives"
+        if dist is None:
+            parallelism = "single GPU (no process group)"
+        else:
+            wire = compress or "fp32"
+            parallelism = (f"rays sharded x{world} (torch.distributed, backend nccl = RCCL), per step: all-reduce of the "
+                           f"proposal / pose gradients + " +
+                           (f"reduce-scatter ({wire}) of the fields gradient -> Adam on the rank's 1/{world} slice -> "
+                            f"all-gather of the 16-bit working copy" if shard_opt else
+                            f"all-reduce ({wire}) of the fields gradient, replicated Adam"))
         out = {
             "metric": "training ray-samples/sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -427,8 +449,7 @@ def main() -> None:
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
                        "grid_bwd": [{0: "atomic", 1: "lds", 2: "binned", 3: "stream"}[int(m)] for m in bwd_modes],
-                       "launch": "hipGraph replay (2 graphs: with/without proposal update)" if use_graph else "eager",
-                       "parallelism": f"rays sharded x{world}, 1 RCCL all-reduce ({compress or 'fp32'} flat gradient)/step" if world > 1 else "single GPU"},
+                       "launch": launch_desc, "parallelism": parallelism},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             # main + both proposal levels: every field evaluation a ray costs
             "field_evals_per_sec": args.rays * world * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples))

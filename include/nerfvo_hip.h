@@ -528,6 +528,16 @@ int nvo_nonfinite_flag_or(nvo_stream_t stream, uint64_t n, const void* grads, in
  * Everywhere a `grads_are_half` argument appears, 0 = fp32, 1 = fp16, 2 = bfloat16. */
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16);
 int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_half);
+/* Sharded gradient exchange (multi-GPU: reduce-scatter -> Adam on this rank's 1/world slice -> all-gather of the 16-bit
+ * working copy).  src[0, n) is cast to the wire format (1 = fp16, 2 = bf16) as `world` chunks of n / world elements,
+ * each followed by `pad` FLAG slots: wire16[(i / per) * (per + pad) + i % per].  *flag (device uint32, OR-ed) is raised
+ * when src holds an inf / NaN, and every pad slot receives *flag ? 1 : 0 -- after the SUM reduce-scatter of the wire
+ * buffer, rank r reads the number of ranks that overflowed from the pad of ITS chunk, so all ranks skip the group
+ * together (GradScaler.step semantics) without a second collective: nvo_flag_from_wire ORs (slot != 0) into *flag.
+ * n multiple of 4 * world; pad a positive multiple of 4; wire16 holds world * (n / world + pad) elements. */
+int nvo_cast_shards(nvo_stream_t stream, uint64_t n, uint32_t world, uint32_t pad, const float* src, void* wire16,
+                    int wire_fmt, uint32_t* flag);
+int nvo_flag_from_wire(nvo_stream_t stream, const void* wire_slot16, uint32_t* flag);
 /* Clears up to 24 device ranges (host arrays of pointers / byte counts, 4-byte granular) with one launch. */
 int nvo_zero_ranges(nvo_stream_t stream, uint32_t n_ranges, void* const* ptrs, const uint64_t* bytes);
 /* Exponential moving average of the weights, the "Ema" optimiser wrapper of instant-ngp's configs/nerf/base.json

@@ -258,6 +258,50 @@ k_cast_bf16(uint64_t n, const float* __restrict__ src, uint16_t* __restrict__ ds
     for (uint64_t i = n_vec * 4 + tid; i < n; i += stride) dst[i] = to_bf16(src[i]);
 }
 
+// ---- sharded gradient exchange (reduce-scatter -> Adam on this rank's 1/W slice -> all-gather of the working copy) ----
+// The fp32 gradient range [0, n) is cast to the 2-byte wire format as W chunks of `per` elements, each followed by `pad`
+// FLAG slots: wire[(i / per) * (per + pad) + i % per] = cvt(src[i]).  A non-finite source value raises *flag (the rank's
+// LOCAL overflow flag).  k_flag_to_wire then writes flag ? 1 : 0 into every chunk's pad slots, so that after the SUM
+// reduce-scatter rank r finds the number of ranks that overflowed in the pad of ITS chunk -- every rank learns the same
+// verdict without a second collective (GradScaler.step must skip the whole group everywhere or nowhere).
+template <bool BF>
+__global__ void __launch_bounds__(256)
+k_cast_shards(uint64_t n, uint64_t per, uint32_t pad, const float* __restrict__ src, uint16_t* __restrict__ dst,
+              uint32_t* __restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    auto cvt = [](float x) -> uint16_t {
+        if (BF) return to_bf16(x);
+        return __builtin_bit_cast(uint16_t, (_Float16)x);
+    };
+    // per and pad are multiples of 4 (checked on the host): a 4-vector never straddles a chunk
+    for (uint64_t q = tid; q < n / 4; q += stride) {
+        const uint64_t i = q * 4;
+        const float4 v = reinterpret_cast<const float4*>(src)[q];
+        // (what does not survive the cast -- beyond 65504 on an fp16 wire -- counts as an overflow as well)
+        const float lim = BF ? 3.0e38f : 65504.0f;
+        bad = bad || !(fabsf(v.x) <= lim) || !(fabsf(v.y) <= lim) || !(fabsf(v.z) <= lim) || !(fabsf(v.w) <= lim);
+        const uint64_t o = (i / per) * (per + pad) + (i % per);
+        *reinterpret_cast<uint2*>(dst + o) = make_uint2((uint32_t)cvt(v.x) | ((uint32_t)cvt(v.y) << 16),
+                                                        (uint32_t)cvt(v.z) | ((uint32_t)cvt(v.w) << 16));
+    }
+    if (flag && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+template <bool BF>
+__global__ void k_flag_to_wire(const uint32_t* __restrict__ flag, uint16_t* __restrict__ wire, uint64_t per, uint32_t pad,
+                               uint32_t world) {
+    const uint16_t one = BF ? (uint16_t)0x3F80u : (uint16_t)0x3C00u;
+    const uint16_t v = *flag ? one : (uint16_t)0;
+    for (uint32_t t = threadIdx.x; t < world * pad; t += blockDim.x)
+        wire[(uint64_t)(t / pad) * (per + pad) + per + (t % pad)] = v;
+}
+
+__global__ void k_flag_from_wire(const uint16_t* __restrict__ slot, uint32_t* __restrict__ flag) {
+    if (threadIdx.x == 0 && (slot[0] & 0x7FFFu) != 0u) atomicOr(flag, 1u);  // any non-zero count (or a NaN) = overflow
+}
+
 // tcnn EmaOptimizer::step [UPSTREAM, restated]: the debiased exponential moving average of the weights,
 //   ema_t = (ema_{t-1} * decay * (1 - decay^(t-1)) + w_t * (1 - decay)) / (1 - decay^t),
 // kept in fp32 with a 16-bit copy for inference.  skip_flag (the optimiser's): non-zero = the step was skipped, the
@@ -600,6 +644,37 @@ int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_b
     uint32_t blocks = nvo_div_up(n, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     NVO_LAUNCH(k_cast_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, src, (uint16_t*)dst_bf16);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_cast_shards(nvo_stream_t stream, uint64_t n, uint32_t world, uint32_t pad, const float* src, void* wire16,
+                    int wire_fmt, uint32_t* flag) {
+    NVO_REQUIRE(src && wire16 && flag, "cast_shards: NULL argument");
+    NVO_REQUIRE(world >= 1 && n % ((uint64_t)world * 4) == 0 && pad % 4 == 0 && pad >= 4,
+                "cast_shards: n (%llu) must be a multiple of 4 x world (%u), pad (%u) a positive multiple of 4",
+                (unsigned long long)n, world, pad);
+    NVO_REQUIRE(wire_fmt == 1 || wire_fmt == 2, "cast_shards: wire format 1 (fp16) or 2 (bf16)");
+    NVO_REQUIRE((((uintptr_t)src & 15u) | ((uintptr_t)wire16 & 7u)) == 0, "cast_shards: unaligned buffers");
+    if (n == 0) return NVO_OK;
+    const uint64_t per = n / world;
+    NVO_PROF(stream, "cast_shards");
+    uint32_t blocks = nvo_div_up(n, 256 * 4 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (wire_fmt == 2) {
+        NVO_LAUNCH(k_cast_shards<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, per, pad, src, (uint16_t*)wire16, flag);
+        NVO_LAUNCH(k_flag_to_wire<true>, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, (uint16_t*)wire16, per, pad, world);
+    } else {
+        NVO_LAUNCH(k_cast_shards<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, per, pad, src, (uint16_t*)wire16, flag);
+        NVO_LAUNCH(k_flag_to_wire<false>, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, (uint16_t*)wire16, per, pad, world);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_flag_from_wire(nvo_stream_t stream, const void* wire_slot16, uint32_t* flag) {
+    NVO_REQUIRE(wire_slot16 && flag, "flag_from_wire: NULL argument");
+    NVO_LAUNCH(k_flag_from_wire, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)wire_slot16, flag);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -227,6 +227,9 @@ class NerfactoEngine:
         add("field.base", self.base_net.n_params, "fields")
         add("field.color", self.n_color, "fields")
         add("field.embedding", cfg.num_images * cfg.appearance_embed_dim, "fields")
+        # the fields group splits into 1 / 2 / 4 / 8 equal, 16-byte aligned shards (sharded optimiser of the multi-GPU
+        # step); the padding parameters never receive a gradient and stay zero
+        add("field.pad", (-off) % 512, "fields")
         for i, m in enumerate(self.prop_nets):
             add(f"proposal.{i}", m.n_params, "proposal_networks")
         add("camera_opt.pose_adjustment", cfg.num_images * 6, "camera_opt")
@@ -338,6 +341,21 @@ class NerfactoEngine:
         for lo, hi in self.bf16_ranges:
             out[lo:hi] = self.params_half[lo:hi].view(torch.bfloat16).float()
         return out
+
+    @torch.no_grad()
+    def sync_sharded_state(self, all_reduce) -> None:
+        """Sharded optimiser (multi-GPU, all_reduce.shard_optimizer): every rank holds the CURRENT fp32 master weights
+        and Adam moments of its own 1/W slice of the fields group only (the 16-bit working copy the kernels read is
+        complete everywhere).  Call this before anything that needs the full fp32 state on one rank -- a checkpoint,
+        sync_half(), a switch back to the replicated optimiser: the slices are all-gathered in fp32."""
+        if all_reduce is None or not getattr(all_reduce, "shard_optimizer", False) or all_reduce.world == 1:
+            return
+        lo, hi = self.group_ranges["fields"]
+        per = (hi - lo) // all_reduce.world
+        r = all_reduce.rank
+        for buf in (self.params, self.exp_avg, self.exp_avg_sq):
+            full = buf[lo:hi]
+            all_reduce.all_gather(full, full[r * per:(r + 1) * per].clone())
 
     def reset_optimizer(self) -> None:
         self.exp_avg.zero_()
@@ -468,10 +486,12 @@ class NerfactoEngine:
         _call("nvo_weights_pdf", stream, C.byref(a))
 
     def _forward_head(self, ws, anneal: float, jitters, stream, anneal_dev: int | None = None,
-                      skip_first_level: bool = False) -> None:
+                      skip_first_level: bool = False, levels=None) -> None:
         """Proposal sampling: lin-disp bins -> proposal net 0 -> PDF resample -> proposal net 1 -> PDF resample ->
         positions of the main-field samples.  Reads the PROPOSAL networks' parameters only (what the multi-GPU step
-        exploits: this prefix of step k+1 runs while the fields gradient of step k is still being reduced)."""
+        exploits: this prefix of step k+1 runs while the fields gradient of step k is still being exchanged).
+        ``levels``: the proposal levels to run (default: all) -- the multi-GPU step runs level 0 beside the
+        reduce-scatter and level 1 beside the all-gather."""
         cfg = self.cfg
         R = ws["R"]
         j = jitters if jitters is not None else (None, None, None)
@@ -479,6 +499,8 @@ class NerfactoEngine:
             _call("nvo_lindisp_positions", stream, R, self.levels[0], cfg.near_plane, cfg.far_plane, _ptr(j[0]),
                   _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(ws["sbins0"]), _ptr(ws["tbins0"]), _ptr(ws["x0"]))
         for k, net in enumerate(self.prop_nets):
+            if levels is not None and k not in levels:
+                continue
             self._density_level(ws, k, net, f"proposal.{k}", stream)
             self._weights_pdf(ws, k, anneal, j[k + 1], stream, resample=True, anneal_dev=anneal_dev)
 
@@ -889,20 +911,24 @@ class NerfactoEngine:
         """One full iteration replayed from captured hipGraphs (torch.cuda.CUDAGraph).
 
         Single GPU: pixel sampling, jitters, ray generation, forward, losses, backward and the optimiser are ONE graph
-        launch, which removes the ~45 inter-kernel launch gaps of the eager step (two graphs per ray count: with and
-        without the proposal-network update).
+        launch, which removes the ~45 inter-kernel launch gaps of the eager step (one graph per step variant: with /
+        without the proposal-network update, with the value-only proposal losses).
 
-        With ``all_reduce`` (one process per GPU) the step is four graphs around two collectives, software-pipelined
+        With ``all_reduce`` (one process per GPU; nerf_vo_amd.parallel.GradientAllReduce) the step is software-pipelined
         across iterations WITHOUT changing any value:
 
-            head_k  : pixel sampling -> rays -> proposal sampling      (reads proposal-network + pose parameters only)
-            body_k  : main field forward, losses, every backward, 2-byte cast of the gradients
-            reduce A: proposal networks (+ camera poses) -- small -- then opt_A (their Adam)
-            reduce B: fields (24.5 MB as bf16), ASYNC on the collective's stream ...
-            head_k+1:   ... while the compute stream already runs the next iteration's sampling prefix, which depends
-                        on nothing reduce B / opt_B produce (~130 us of the ~250 us exchange hidden)
-            opt_B   : Adam of the fields group once reduce B has landed.
-        """
+            body_k   : main field forward, losses, every backward, the 2-byte cast of the gradients (+ overflow flags)
+            reduce A : proposal networks (+ camera poses) -- small, all-reduce -- then opt_A (their replicated Adam)
+            reduce B : fields (24.5 MB as bf16): reduce-scatter, ASYNC on the collective's stream ...
+            head_k+1 :   ... while the compute stream already runs the next iteration's sampling prefix up to proposal
+                         level 0 (reads proposal-network + pose parameters only)
+            opt_B    : Adam of the fields group on this rank's 1/W slice
+            gather B : all-gather of the 16-bit working copy of the fields group, beside proposal level 1 of head_k+1.
+
+        (``all_reduce.shard_optimizer`` False: reduce B is an all-reduce and opt_B the replicated Adam, no gather.)
+        With RCCL the collectives are CAPTURED with the kernels -- the whole iteration, next prefix included, is ONE
+        graph launch per step; with a backend that cannot be captured (gloo in the tests) or NVO_DIST_CAPTURE=0 the
+        compute segments are separate graphs around eager collectives."""
         cfg = self.cfg
         R = cfg.num_rays
         step = self.step
@@ -912,7 +938,7 @@ class NerfactoEngine:
         has_normals = bool(getattr(dataset, "use_normals", False)) and cfg.normal_loss_mult > 0.0
         values = self.proposal_values_due(step, updated)
         key = (R, updated, has_depth, all_reduce is not None, has_normals, values)
-        self._reducer_compress = getattr(all_reduce, "compress", None)
+        self._reducer = all_reduce
         if self._pix_scale is None:
             self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
             self._pix_scale_host = None
@@ -942,42 +968,22 @@ class NerfactoEngine:
             self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
             entry["main"].replay()
         else:
-            stamp = (step, key, getattr(dataset, "version", 0), extent)
+            stamp = (step, getattr(dataset, "version", 0), extent)
             if self._pending_head != stamp:  # not launched ahead (first step, new keyframes, externally set step)
                 self._write_sampling_scalars(step)
                 entry["head"].replay()
             self._pending_head = None
-            entry["body"].replay()
+            pipeline = bool(cfg.pipeline_sampling_prefix)
             self._write_step_scalars(self.anneal_at(step), groups)
-            half = entry.get("half")
-
-            def reduce(gs, async_op=False):
-                segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in gs)]
-                if half is not None:  # compressed exchange: the 2-byte cast is part of the body graph
-                    return all_reduce.reduce_half(self.grads, half, segs, already_cast=True, async_op=async_op)
-                return all_reduce(self.grads, segments=segs, async_op=async_op)
-
-            first = [g for g in groups if g != "fields"]
-            if first:
-                reduce(first)
-                entry["opt_a"].replay()
-            pending = reduce(["fields"], async_op=True)
+            if pipeline:  # the sampling scalars of the NEXT iteration: its prefix runs inside this one
+                self._write_sampling_scalars(step + 1)
+            entry["run"](pipeline)
+            if pipeline:
+                self._pending_head = (step + 1, getattr(dataset, "version", 0), extent)
         if updated:
             self.steps_since_proposal_update = 0
         self.steps_since_proposal_update += 1
         self.step += 1
-        if all_reduce is not None:
-            if cfg.pipeline_sampling_prefix:
-                nstep = self.step
-                nupd = self.proposal_update_due(nstep)
-                nkey = (R, nupd, has_depth, True, has_normals, self.proposal_values_due(nstep, nupd))
-                nentry = self._graphs.get(nkey)
-                if nentry is not None:  # (a key that still has to be captured runs un-pipelined once)
-                    self._write_sampling_scalars(nstep)
-                    nentry["head"].replay()
-                    self._pending_head = (nstep, nkey, getattr(dataset, "version", 0), extent)
-            all_reduce.wait(pending)
-            entry["opt_b"].replay()
         return updated
 
     def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False, values=False):
@@ -998,19 +1004,24 @@ class NerfactoEngine:
         step_ptr = C.c_void_p(self.dev_sampling.data_ptr() + 4)
         jits = (jit[0], jit[1], jit[2])
 
-        def body_head():
+        def body_head(levels=None):
+            """Sampling prefix.  levels: None = all of it; (0,) = rays + proposal level 0; (1,) = proposal level 1."""
+            first = levels is None or 0 in levels
             if cfg.fused_ray_head:
-                return body_head_fused()
-            # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
-            _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
-            c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
-            self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
-                           normals=dataset.world_normals01() if has_normals else None)
-            self._forward_head(ws, 1.0, jits, _stream(dev), anneal_dev=anneal_ptr)
+                return body_head_fused(levels, first)
+            if first:
+                # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
+                _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
+                c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
+                self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
+                               normals=dataset.world_normals01() if has_normals else None)
+            self._forward_head(ws, 1.0, jits, _stream(dev), anneal_dev=anneal_ptr, skip_first_level=not first, levels=levels)
 
-        def body_head_fused():
+        def body_head_fused(levels, first):
             # everything per ray up to the first sampler level in ONE launch (nvo_ray_head)
             stream = _stream(dev)
+            if not first:
+                return self._forward_head(ws, 1.0, jits, stream, anneal_dev=anneal_ptr, skip_first_level=True, levels=levels)
             images, depths = dataset.frames_color, dataset.frames_depth if has_depth else None
             normals = dataset.world_normals01() if has_normals else None
             corr, poses, stride, ridx = None, c2w_full, 16, ray_indices
@@ -1038,31 +1049,102 @@ class NerfactoEngine:
             _call("nvo_ray_head", stream, C.byref(ra))
             ws["dirs01_ready"] = True
             ws["sh_ready"] = True
-            self._forward_head(ws, 1.0, jits, stream, anneal_dev=anneal_ptr, skip_first_level=True)
+            self._forward_head(ws, 1.0, jits, stream, anneal_dev=anneal_ptr, skip_first_level=True, levels=levels)
+
+        # ---- the exchange (multi-GPU) -------------------------------------------------------------------------
+        red = getattr(self, "_reducer", None) if split else None
+        compress = getattr(red, "compress", None)
+        half = wire = shard_out = None
+        world, rank = (red.world, red.rank) if red is not None else (1, 0)
+        sharded = bool(split and getattr(red, "shard_optimizer", False) and compress in ("bf16", "fp16"))
+        wire_dt = torch.bfloat16 if compress == "bf16" else torch.float16
+        f_lo, f_hi = self.group_ranges["fields"]
+        per = (f_hi - f_lo) // max(world, 1)
+        kPad = 8  # flag slots behind every chunk of the wire buffer (16 bytes: chunks stay 16-byte aligned)
+        if split and compress in ("bf16", "fp16"):
+            if not hasattr(self, "_wire_half") or self._wire_half.dtype != wire_dt:
+                self._wire_half = torch.zeros(self.n_params, dtype=wire_dt, device=dev)
+            half = self._wire_half  # (shared by the step variants: they never run concurrently)
+            if sharded:
+                assert per * world == f_hi - f_lo and per % 8 == 0, "fields group must split into 16-byte aligned shards"
+                if not hasattr(self, "_wire_fields") or self._wire_fields.numel() != world * (per + kPad) or self._wire_fields.dtype != wire_dt:
+                    self._wire_fields = torch.zeros(world * (per + kPad), dtype=wire_dt, device=dev)
+                    self._shard_out = torch.zeros(per + kPad, dtype=wire_dt, device=dev)
+                wire, shard_out = self._wire_fields, self._shard_out
+        # multi-GPU: the small groups (proposal networks, camera poses) are reduced and stepped FIRST -- the next
+        # iteration's sampling prefix needs them -- the fields group last
+        groups_a = [g for g in groups if g != "fields"] if split else []
+        groups_b = ["fields"] if split else list(groups)
+        fields_slot = self._GROUP_ORDER.index("fields")
+        fields_flag = C.c_void_p(self.skip_flag.data_ptr() + 4 * fields_slot)
 
         def body_rest():
             self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
                                   anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True, proposal_values=values)
-            if half is not None:  # 2-byte copy of the ranges the collective will exchange
-                cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"
-                for lo, hi in cast_ranges:
-                    _call(cast, _stream(dev), hi - lo, C.c_void_p(self.grads.data_ptr() + 4 * lo),
-                          C.c_void_p(half.data_ptr() + 2 * lo))
-
-        half = None
-        compress = getattr(self, "_reducer_compress", None)
-        if split and compress in ("bf16", "fp16"):
-            half = torch.zeros(self.n_params, dtype=torch.bfloat16 if compress == "bf16" else torch.float16, device=dev)
-        cast_ranges = [self.group_ranges[g] for g in groups]
-        # multi-GPU: the small groups (proposal networks, camera poses) are reduced and stepped FIRST -- the next
-        # iteration's sampling prefix needs them -- the fields group last (train_step_graphed)
-        groups_a = [g for g in groups if g != "fields"] if split else []
-        groups_b = ["fields"] if split else list(groups)
+            if half is None:
+                return
+            cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"
+            for g in (groups_a if sharded else groups):  # 2-byte copy of the ranges the all-reduce will exchange
+                lo, hi = self.group_ranges[g]
+                _call(cast, _stream(dev), hi - lo, C.c_void_p(self.grads.data_ptr() + 4 * lo),
+                      C.c_void_p(half.data_ptr() + 2 * lo))
+            if sharded:  # fields: W chunks + flag slots; the cast raises this rank's overflow flag on the way
+                _call("nvo_cast_shards", _stream(dev), f_hi - f_lo, world, kPad, C.c_void_p(self.grads.data_ptr() + 4 * f_lo),
+                      _ptr(wire), 2 if wire_dt == torch.bfloat16 else 1, fields_flag)
 
         def body_opt(gs):
             # every group owns ONE flag word (its slot) and the step's zero launch cleared them all, so neither the
             # single optimiser call of the one-graph step nor the two calls of the split step reset anything
+            if sharded and gs == ["fields"]:
+                # the reduced chunk carries the number of ranks whose gradient overflowed in its first flag slot
+                _call("nvo_flag_from_wire", _stream(dev), C.c_void_p(shard_out.data_ptr() + 2 * per), fields_flag)
+                # (the kernels index the gradient by flat element offset: rebase the pointer of this rank's chunk)
+                class _Rebased:  # noqa: N801 - minimal tensor stand-in for optimizer_step
+                    dtype = shard_out.dtype
+
+                    @staticmethod
+                    def data_ptr():
+                        return shard_out.data_ptr() - 2 * (f_lo + rank * per)
+                self.optimizer_step(gs, from_device_scalars=True, grads_half=_Rebased, flags_cleared=True, step_groups=groups,
+                                    shard=(rank, world), check=False)
+                return
             self.optimizer_step(gs, from_device_scalars=True, grads_half=half, flags_cleared=True, step_groups=groups)
+
+        def reduce_a():
+            segs = [(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in groups_a)]
+            if half is not None:
+                red.reduce_half(self.grads, half, segs, already_cast=True)
+            else:
+                red(self.grads, segments=segs)
+
+        def reduce_b_start():
+            if sharded:
+                return red.reduce_scatter(shard_out, wire, async_op=True)
+            if half is not None:
+                return red.reduce_half(self.grads, half, [(f_lo, f_hi - f_lo)], already_cast=True, async_op=True)
+            return red(self.grads, segments=[(f_lo, f_hi - f_lo)], async_op=True)
+
+        def gather_b_start():
+            # every rank stepped its slice of the fp32 master and wrote the 16-bit working copy of that slice
+            full = self.params_half[f_lo:f_hi]
+            return red.all_gather(full, full[rank * per:(rank + 1) * per], async_op=True)
+
+        def program(pipeline: bool, seg):
+            """The iteration behind the sampling prefix; seg(name, fn) runs a COMPUTE segment (captured on its own in
+            the eager-collective mode, inline when the whole program is captured)."""
+            seg("body", body_rest)
+            if groups_a:
+                reduce_a()
+                seg("opt_a", lambda: body_opt(groups_a))
+            pending = reduce_b_start()
+            if pipeline:
+                seg("head0", lambda: body_head((0,)))
+            red.wait(pending)
+            seg("opt_b", lambda: body_opt(groups_b))
+            pending = gather_b_start() if sharded else []
+            if pipeline:
+                seg("head1", lambda: body_head((1,)))
+            red.wait(pending)
 
         # warm-up on a side stream (allocations, lazy module state), then capture
         side = torch.cuda.Stream(device=dev)
@@ -1075,10 +1157,11 @@ class NerfactoEngine:
         with torch.cuda.stream(side):
             for _ in range(2):
                 body_head()
-                body_rest()
-                if groups_a:
-                    body_opt(groups_a)
-                body_opt(groups_b)
+                if split:
+                    program(False, lambda name, fn: fn())
+                else:
+                    body_rest()
+                    body_opt(groups_b)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
@@ -1086,11 +1169,12 @@ class NerfactoEngine:
         # the graphs address these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
         drawn = ws["ray_indices"] if (cfg.fused_ray_head and cfg.optimize_poses and "ray_indices" in ws) else ray_indices
-        entry = {"half": half, "buffers": (c2w, drawn, jit, scale, ray_indices), "ws": ws}
+        entry = {"half": half, "buffers": (c2w, drawn, jit, scale, ray_indices), "ws": ws, "sharded": sharded,
+                 "captured_collectives": False}
 
-        def capture(fn):
+        def capture(fn, **kw):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **kw):
                 fn()
             return g
 
@@ -1100,12 +1184,44 @@ class NerfactoEngine:
                 body_rest()
                 body_opt(groups_b)
             entry["main"] = capture(whole)
-        else:
-            entry["head"] = capture(body_head)
-            entry["body"] = capture(body_rest)
-            if groups_a:
-                entry["opt_a"] = capture(lambda: body_opt(groups_a))
-            entry["opt_b"] = capture(lambda: body_opt(groups_b))
+            return entry
+
+        entry["head"] = capture(body_head)
+        import os
+
+        want = os.environ.get("NVO_DIST_CAPTURE", "auto")
+        backend = red.dist.get_backend(red.group) if red.dist.is_initialized() else "none"
+        if want != "0" and (backend == "nccl" or want == "1"):
+            # RCCL collectives issued under capture become nodes of the graph (the process group's stream joins the
+            # capture through its event dependencies): the whole iteration is then ONE graph launch.  thread_local: the
+            # process group's watchdog thread polls events with calls a global-mode capture would be invalidated by.
+            try:
+                whole_g = {p: capture(lambda p=p: program(p, lambda name, fn: fn()), capture_error_mode="thread_local")
+                           for p in (False, True)}
+                entry["captured_collectives"] = True
+                entry["run"] = lambda pipeline: whole_g[bool(pipeline)].replay()
+                entry["whole"] = whole_g
+                return entry
+            except Exception as exc:  # noqa: BLE001 - fall back to eager collectives between captured segments
+                import sys
+
+                sys.stderr.write(f"[nerf_vo_amd] collectives could not be captured ({type(exc).__name__}: {exc}); "
+                                 "using eager collectives between captured compute segments\n")
+                torch.cuda.synchronize(dev)
+                for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
+                    dst.copy_(src)
+        segs = {}
+
+        def seg_capture(name, fn):
+            segs[name] = capture(fn)
+
+        # capture every compute segment once (the collectives in between run eagerly, here and at replay)
+        program(True, lambda name, fn: (seg_capture(name, fn), segs[name].replay()))
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
+            dst.copy_(src)
+        entry["segments"] = segs
+        entry["run"] = lambda pipeline: program(bool(pipeline), lambda name, fn: segs[name].replay())
         return entry
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None, normals=None):

@@ -38,7 +38,8 @@ def main():
                                       **plan.get("engine_overrides", {})), dev,
                          world_size=world, rank=rank)
     eng.set_params(plan["params"].to(dev))  # identical initial parameters on every rank
-    reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress)
+    reducer = GradientAllReduce(dist, compress=None if compress == "none" else compress,
+                                shard_optimizer=bool(plan.get("shard_optimizer", False)))
     c2w = ds.camera_extrinsics[:, :3, :4].contiguous()
     for k in range(plan["eager_steps"]):
         idx = plan["rays"][k][rank].to(dev)
@@ -62,11 +63,19 @@ def main():
                 f"{b}{k}" for k in range(km + 1) for b in ("x", "sbins", "tbins")] + [
                 f"{b}{k}" for k in range(km) for b in ("out", "weights")]
             before = {k: ws[k].clone() for k in names}
-            eng._graphs[eng._pending_head[1]]["head"].replay()
+            next(iter(eng._graphs.values()))["head"].replay()  # (the sampling prefix is the same in every step variant)
             torch.cuda.synchronize()
             prefix_checked += 1
             prefix_mismatch += [k for k in names if not torch.equal(before[k].view(torch.uint8), ws[k].view(torch.uint8))]
     torch.cuda.synchronize()
+    sharded_state = None
+    if plan.get("shard_optimizer"):
+        # sharded optimiser: the fp32 master / moments of the fields group are current on their owner only, the
+        # 16-bit working copy everywhere -- record both views, then gather the fp32 state
+        sharded_state = {"params_half": eng.params_half.cpu().clone(), "own_master": eng.params.cpu().clone()}
+        eng.sync_sharded_state(reducer)
+        torch.cuda.synchronize()
+        sharded_state["captured_collectives"] = bool(next(iter(eng._graphs.values())).get("captured_collectives")) if eng._graphs else False
     ab = None
     if plan.get("ab_pipeline"):
         # A/B from ONE bit-identical state (the graphs of both step kinds exist by now): the same few steps with the
@@ -91,7 +100,8 @@ def main():
     drawn = next(iter(eng._graphs.values()))["buffers"][1].cpu()  # pixel indices of the last graph-replayed step
     torch.save({"after_eager": after_eager, "after_graph": eng.params.detach().cpu(), "losses": eng.loss_dict(),
                 "skip": eng.skip_flag.cpu(), "ray_indices": drawn, "prefix_checked": prefix_checked,
-                "prefix_mismatch": sorted(set(prefix_mismatch)), "ab": ab}, os.path.join(workdir, f"rank{rank}.pt"))
+                "prefix_mismatch": sorted(set(prefix_mismatch)), "ab": ab, "sharded_state": sharded_state,
+                "opt_steps": eng.opt_steps, "exp_avg": eng.exp_avg.cpu()}, os.path.join(workdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -70,6 +70,29 @@ def _worker(rank, world, port, tmp):
     dens = mine.abs().clone()
     red.reduce_max(dens)
     ok = ok and torch.equal(dens, torch.stack([t.abs() for t in gathered]).max(dim=0).values)
+    # sharded exchange: reduce-scatter of a wire buffer of `world` chunks (+ flag slots), all-gather of the owners' slices
+    # IN PLACE (the shard is a slice of the full buffer, as the optimiser writes it)
+    reds = GradientAllReduce(dist, compress="bf16", shard_optimizer=True)
+    per, pad = 1000, 8
+    wire = torch.zeros(world * (per + pad), dtype=torch.bfloat16)
+    for c in range(world):
+        wire[c * (per + pad):c * (per + pad) + per] = mine[c * per:(c + 1) * per].to(torch.bfloat16)
+        wire[c * (per + pad) + per:(c + 1) * (per + pad)] = 1.0 if rank == 1 else 0.0  # rank 1 "overflowed"
+    out = torch.zeros(per + pad, dtype=torch.bfloat16)
+    reds.wait(reds.reduce_scatter(out, wire, async_op=True))
+    ref_chunk = sum(t[rank * per:(rank + 1) * per].to(torch.bfloat16).float() for t in gathered)
+    ok = ok and torch.allclose(out[:per].float(), ref_chunk, rtol=2e-2, atol=1e-2) and float(out[per]) == 1.0
+    full = torch.zeros(world * per, dtype=torch.bfloat16)
+    full[rank * per:(rank + 1) * per] = out[:per]
+    reds.wait(reds.all_gather(full, full[rank * per:(rank + 1) * per], async_op=True))
+    chunks = [torch.zeros(per, dtype=torch.bfloat16) for _ in range(world)]
+    dist.all_gather(chunks, out[:per].clone())
+    ok = ok and torch.equal(full, torch.cat(chunks)) and reds.world == world and reds.rank == rank
+    try:
+        GradientAllReduce(dist, shard_optimizer=True)
+        ok = False  # the sharded optimiser needs a 2-byte wire format
+    except ValueError:
+        pass
     torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
