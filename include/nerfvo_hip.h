@@ -175,6 +175,11 @@ int nvo_sh_bwd_input_f32(nvo_stream_t stream, uint32_t N, uint32_t degree, const
 int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
                  const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
                  float* d_corrections);
+/* deterministic form: per-ray contributions [R][12] go through per_ray_scratch and are summed per camera in a FIXED
+ * order (n_cameras rows of d_corrections) instead of float atomics */
+int nvo_pose_bwd_det(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                     const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                     float* d_corrections, float* per_ray_scratch, uint32_t n_cameras);
 int nvo_se3_exp_map_bwd(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,
                         float trans_penalty, float rot_penalty, float reg_scale, float* d_tangent,
                         float* reg_loss, int mode);
@@ -374,9 +379,16 @@ typedef struct nvo_color_args {
     float* d_weights;            /* accumulated (caller zeroes) */
     int act_bf16;                /* 0: every "fp16" tensor above is fp16 (v_mfma_..._f16), 1: all of them are bfloat16
                                     and the network runs on v_mfma_f32_16x16x16_bf16 (BASELINE configs[4]) */
+    /* deterministic mode (backward; det_scratch NULL = off): the weight gradient and the per-camera embedding / per-ray
+     * SH-direction gradients are summed in FIXED orders through this caller-owned scratch instead of float atomics --
+     * bitwise reproducible results, a few launches more.  Needs S % 16 == 0 and cam_idx. */
+    void* det_scratch;           /* nvo_color_det_scratch_bytes(R, S) */
+    uint64_t det_scratch_bytes;
+    uint32_t n_cameras;          /* rows of d_embedding (deterministic mode only) */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
+uint64_t nvo_color_det_scratch_bytes(uint32_t R, uint32_t S);
 
 /* ------------------------------------------------------------------------------------------------
  * F. Cascaded occupancy grid (instant-ngp testbed: generate_training_samples_nerf,
@@ -488,11 +500,11 @@ typedef struct nvo_adam_group {
     float lr;
     uint32_t step;
     const float* hyper_dev;
-    /* step_dev (nullable): device uint32 = number of steps APPLIED to this group so far; the bias corrections are
-     * computed from *step_dev + 1 on the device (`step` and hyper_dev[1..2] are ignored) and nvo_opt_commit advances
-     * the counter behind the launch iff the group was not skipped -- torch.optim.Adam's state['step'] under
-     * GradScaler.step, which does not count skipped steps. */
-    const uint32_t* step_dev;
+    /* bias_dev (nullable): device float[2] = {1 - beta1^t, sqrt(1 - beta2^t)} of the group's NEXT applied step, kept
+     * by nvo_opt_commit next to its applied-step counter (`step` and hyper_dev[1..2] are then ignored): the counter
+     * advances iff the group was not skipped -- torch.optim.Adam's state['step'] under GradScaler.step, which does not
+     * count skipped steps. */
+    const float* bias_dev;
     /* which word of skip_flags belongs to this group: the group's index in `groups` unless flag_slot_set != 0 (a step
      * that runs its groups in two launches keeps ONE flag word per group that way) */
     uint32_t flag_slot;
@@ -575,7 +587,10 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
  * nullable together). */
 int nvo_opt_commit(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
                    const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
-                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale);
+                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                   float beta1, float beta2);
+/* bias (nullable): device float [n_groups][2]; a group whose counter advances to t gets {1 - beta1^(t+1),
+ * sqrt(1 - beta2^(t+1))} -- what nvo_adam_group::bias_dev of its next step reads. */
 
 /* ------------------------------------------------------------------------------------------------
  * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of

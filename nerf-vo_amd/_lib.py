@@ -57,7 +57,8 @@ class ColorArgs(C.Structure):
     """mirror of nvo_color_args"""
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
-                ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int)]
+                ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int), ("det_scratch", _p),
+                ("det_scratch_bytes", _u64), ("n_cameras", _u32)]
 
 
 class RayHeadArgs(C.Structure):
@@ -73,7 +74,7 @@ class RayHeadArgs(C.Structure):
 class AdamGroup(C.Structure):
     """nvo_adam_group (include/nerfvo_hip.h)"""
     _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
-                ("hyper_dev", C.c_void_p), ("step_dev", C.c_void_p), ("flag_slot", C.c_uint32),
+                ("hyper_dev", C.c_void_p), ("bias_dev", C.c_void_p), ("flag_slot", C.c_uint32),
                 ("flag_slot_set", C.c_uint32)]
 
 
@@ -146,6 +147,8 @@ _SIGNATURES = {
     # group D
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
+    "nvo_color_det_scratch_bytes": (_u64, [_u32, _u32]),
+    "nvo_pose_bwd_det": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _u32]),
     # group F
     "nvo_occ_march_scratch_bytes": (_u64, [_u32]),
     "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64]),
@@ -175,7 +178,7 @@ _SIGNATURES = {
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),
-    "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f]),
+    "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f]),
     "nvo_cast_bf16": (_int, [_p, _u64, _p, _p]),
     "nvo_cast_shards": (_int, [_p, _u64, _u32, _u32, _p, _p, _int, _p]),
     "nvo_flag_from_wire": (_int, [_p, _p, _p]),

@@ -122,7 +122,7 @@ struct AdamGroups {
     uint64_t offset[kAdamMaxGroups], n[kAdamMaxGroups];
     float lr[kAdamMaxGroups], bias1[kAdamMaxGroups], bias2_sqrt[kAdamMaxGroups];
     const float* hyper_dev[kAdamMaxGroups];
-    const uint32_t* step_dev[kAdamMaxGroups];  // applied-step counter on the device (nvo_adam_group::step_dev)
+    const float* bias_dev[kAdamMaxGroups];  // {1 - beta1^t, sqrt(1 - beta2^t)} kept by nvo_opt_commit (nvo_adam_group::bias_dev)
     int vec4[kAdamMaxGroups];
     uint32_t slot[kAdamMaxGroups];  // index of the group's skip flag
 };
@@ -144,13 +144,12 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
         h.bias1 = gr.hyper_dev[k][1];
         h.bias2_sqrt = gr.hyper_dev[k][2];
     }
-    if (gr.step_dev[k]) {
-        // torch.optim.Adam under GradScaler.step: state['step'] counts the APPLIED steps only -- the counter lives on the
-        // device and nvo_opt_commit advances it behind this launch iff the group was not skipped (double: 1 - 0.999^t
-        // loses 3 digits in fp32 for small t)
-        const double t = (double)(*gr.step_dev[k]) + 1.0;
-        h.bias1 = (float)(1.0 - pow((double)h.beta1, t));
-        h.bias2_sqrt = (float)sqrt(1.0 - pow((double)h.beta2, t));
+    if (gr.bias_dev[k]) {
+        // torch.optim.Adam under GradScaler.step: state['step'] counts the APPLIED steps only -- the counter and the
+        // bias corrections of the NEXT applied step live on the device; nvo_opt_commit advances them behind this launch
+        // iff the group was not skipped
+        h.bias1 = gr.bias_dev[k][0];
+        h.bias2_sqrt = gr.bias_dev[k][1];
     }
     if (loss_scale_dev) h.grad_scale = 1.0f / *loss_scale_dev;  // dynamic loss scale (GradScaler state on the device)
     const uint64_t o = gr.offset[k];
@@ -330,13 +329,21 @@ k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
 __global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
                              const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
                              uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
-                             float min_scale, float max_scale) {
+                             float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     bool any_bad = false;
     for (uint32_t i = 0; i < n_groups; ++i) {
         const bool bad = skip_flags && skip_flags[i] != 0u;
         if ((scale_mask >> i) & 1u) any_bad = any_bad || bad;
-        if (((active_mask >> i) & 1u) && applied && !bad) applied[i] += 1u;
+        if (((active_mask >> i) & 1u) && applied && !bad) {
+            const uint32_t done = applied[i] + 1u;
+            applied[i] = done;
+            if (bias) {  // bias corrections of the group's NEXT applied step (double: 1 - 0.999^t loses digits in fp32)
+                const double t = (double)done + 1.0;
+                bias[2 * i + 0] = (float)(1.0 - pow((double)beta1, t));
+                bias[2 * i + 1] = (float)sqrt(1.0 - pow((double)beta2, t));
+            }
+        }
     }
     if (scale) {
         float sc = *scale;
@@ -379,7 +386,81 @@ k_zero_ranges(ZeroRanges r) {
     }
 }
 
+// ---- deterministic reductions (EngineConfig.deterministic): fixed summation orders instead of float atomics ----
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float* __restrict__ partial, uint32_t n_blocks, uint64_t n, float* __restrict__ dst) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float acc = 0.f;
+    for (uint32_t b = 0; b < n_blocks; ++b) acc += partial[(uint64_t)b * n + e];
+    dst[e] += acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_reduce_by_camera(uint32_t R, uint32_t K, const float* __restrict__ rows, uint32_t row_stride, const void* __restrict__ cam,
+                   int cam_i64x3, float* __restrict__ out) {
+    // one workgroup per camera: 8 sub-sequences (rays r = s, s + 8, ...) of 32 lanes (columns), each summed in ray
+    // order, then combined s = 0..7 -- every order is fixed, so the result does not depend on scheduling
+    __shared__ float part[8][32];
+    const uint32_t c = blockIdx.x, k = threadIdx.x & 31u, sub = threadIdx.x >> 5;
+    float acc = 0.f;
+    for (uint32_t r = sub; r < R; r += 8u) {
+        const int64_t cr = cam_i64x3 ? reinterpret_cast<const int64_t*>(cam)[3 * (size_t)r]
+                                     : (int64_t)reinterpret_cast<const int32_t*>(cam)[r];
+        if (cr == (int64_t)c && k < K) acc += rows[(size_t)r * row_stride + k];
+    }
+    part[sub][k] = acc;
+    __syncthreads();
+    if (sub == 0 && k < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][k];
+        out[(size_t)c * K + k] += t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_color_tiles_to_rays(uint32_t R, uint32_t tiles_per_ray, const float* __restrict__ tile_partial,
+                      float* __restrict__ per_ray, float* __restrict__ d_sh) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 48u) return;
+    const uint32_t r = i / 48u, k = i % 48u;
+    float acc = 0.f;
+    for (uint32_t t = 0; t < tiles_per_ray; ++t) acc += tile_partial[((size_t)r * tiles_per_ray + t) * 48u + k];
+    per_ray[i] = acc;
+    if (d_sh && k >= 32u) d_sh[(size_t)r * 16u + (k - 32u)] += acc;
+}
+
 }  // namespace
+
+int nvo_reduce_partials(hipStream_t stream, const float* partial, uint32_t n_blocks, uint64_t n, float* dst) {
+    NVO_REQUIRE(partial && dst, "reduce_partials: NULL argument");
+    if (n == 0 || n_blocks == 0) return NVO_OK;
+    NVO_PROF(stream, "reduce_partials");
+    NVO_LAUNCH(k_reduce_partials, dim3(nvo_div_up(n, 256)), dim3(256), 0, stream, partial, n_blocks, n, dst);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_reduce_by_camera(hipStream_t stream, uint32_t R, uint32_t K, const float* rows, uint32_t row_stride,
+                         const void* cam, int cam_i64x3, uint32_t F, float* out) {
+    NVO_REQUIRE(rows && cam && out && K >= 1 && K <= 32, "reduce_by_camera: bad argument (K <= 32)");
+    if (R == 0 || F == 0) return NVO_OK;
+    NVO_PROF(stream, "reduce_by_camera");
+    NVO_LAUNCH(k_reduce_by_camera, dim3(F), dim3(256), 0, stream, R, K, rows, row_stride, cam, cam_i64x3, out);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_color_tiles_to_rays(hipStream_t stream, uint32_t R, uint32_t tiles_per_ray, const float* tile_partial,
+                            float* per_ray, float* d_sh) {
+    NVO_REQUIRE(tile_partial && per_ray && tiles_per_ray >= 1, "color_tiles_to_rays: bad argument");
+    if (R == 0) return NVO_OK;
+    NVO_LAUNCH(k_color_tiles_to_rays, dim3(nvo_div_up((uint64_t)R * 48, 256)), dim3(256), 0, stream, R, tiles_per_ray,
+               tile_partial, per_ray, d_sh);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
 
 int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
     NVO_REQUIRE((bytes & 3u) == 0 && ((uintptr_t)ptr & 3u) == 0, "zero_async: %zu bytes not 4-byte granular", bytes);
@@ -471,14 +552,15 @@ int nvo_adam_step_groups_mixed(nvo_stream_t stream, uint32_t n_groups, const nvo
 
 int nvo_opt_commit(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
                    const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
-                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale) {
+                   float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                   float beta1, float beta2) {
     NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "opt_commit: 1..%u groups (got %u)", kAdamMaxGroups, n_groups);
     NVO_REQUIRE(applied || scale, "opt_commit: nothing to update");
     NVO_REQUIRE(!scale || (growth_tracker && growth_interval >= 1 && growth_factor >= 1.f && backoff_factor > 0.f &&
                            backoff_factor <= 1.f && min_scale > 0.f && max_scale >= min_scale),
                 "opt_commit: bad loss-scale schedule");
     NVO_LAUNCH(k_opt_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, n_groups, active_mask, scale_mask, applied, skip_flags, scale,
-               growth_tracker, growth_factor, backoff_factor, growth_interval, min_scale, max_scale);
+               growth_tracker, growth_factor, backoff_factor, growth_interval, min_scale, max_scale, bias, beta1, beta2);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
@@ -499,7 +581,7 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
     const size_t gsz = grads_are_half ? 2 : 4;
     for (uint32_t i = 0; i < n_groups; ++i) {
         if (groups[i].n == 0) continue;
-        NVO_REQUIRE(groups[i].step >= 1 || groups[i].step_dev, "adam_step_groups: step counts from 1");
+        NVO_REQUIRE(groups[i].step >= 1 || groups[i].bias_dev, "adam_step_groups: step counts from 1");
         NVO_REQUIRE(groups[i].flag_slot < kAdamMaxGroups, "adam_step_groups: flag_slot %u out of range", groups[i].flag_slot);
         const uint64_t o = groups[i].offset;
         gr.offset[k] = o;
@@ -508,7 +590,7 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
         gr.bias1[k] = 1.f - powf(beta1, (float)(groups[i].step ? groups[i].step : 1u));
         gr.bias2_sqrt[k] = sqrtf(1.f - powf(beta2, (float)(groups[i].step ? groups[i].step : 1u)));
         gr.hyper_dev[k] = groups[i].hyper_dev;
-        gr.step_dev[k] = groups[i].step_dev;
+        gr.bias_dev[k] = groups[i].bias_dev;
         // flag word of the group: its index in the caller's array unless the caller pins one (flag_slot + 1)
         gr.slot[k] = groups[i].flag_slot_set ? groups[i].flag_slot : i;
         const uintptr_t align = (uintptr_t)(params + o) | (uintptr_t)(exp_avg + o) | (uintptr_t)(exp_avg_sq + o);

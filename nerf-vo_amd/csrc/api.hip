@@ -451,6 +451,12 @@ struct GridModule : nvo_module_s {
             return NVO_OK;
         }
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        if (!strcmp(key, "deterministic")) {  // bitwise reproducible parameter gradient (see NvoGridSlices::deterministic)
+            nvo_grid_slices_destroy(&slices);
+            nvo_grid_stream_destroy(&stream_bins);
+            slices.deterministic = stream_bins.deterministic = stream_bins.owner.deterministic = value != 0;
+            return NVO_OK;
+        }
         if (!strcmp(key, "prepare_input_gradients")) {  // changes ctx_bytes(): set before the ctx scratch is sized
             prepare_input_gradients = value != 0;
             dydx_valid = false;
@@ -533,9 +539,23 @@ struct MlpModule : nvo_module_s {
     // option "bf16": weights, hidden activations, output and dL/doutput are bfloat16 and the layers run on
     // v_mfma_f32_16x16x16_bf16 (mlp_bf16.hip) instead of fp16 / v_mfma_f32_16x16x16_f16; accumulation is fp32 in both
     int bf16 = 0;
+    // option "deterministic": the weight gradient is summed over the workgroups in a fixed order (block totals stored
+    // to this scratch + a reduce launch) instead of float atomics
+    bool deterministic = false;
+    NvoScratch dw_scratch;
+    ~MlpModule() override { nvo_scratch_destroy(&dw_scratch); }
+    int det_partials(hipStream_t s, uint32_t B, NvoMlpArgs* a) {
+        if (!deterministic || !a->dweights) return NVO_OK;
+        const size_t bytes = sizeof(float) * (size_t)nvo_mlp_bwd_blocks(in_pad, width, n_hidden, B) *
+                             nvo_mlp_n_weights(in_pad, width, n_hidden, out_pad);
+        if (int rc = nvo_scratch_reserve(&dw_scratch, bytes, s, "mlp dW block totals")) return rc;
+        a->dw_partial = static_cast<float*>(dw_scratch.ptr);
+        return NVO_OK;
+    }
     int set_option(const char* key, int64_t value) override {
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "external_zero")) { external_zero = value != 0; return NVO_OK; }
+        if (!strcmp(key, "deterministic")) { deterministic = value != 0; return NVO_OK; }
         return nvo_module_s::set_option(key, value);
     }
 
@@ -611,6 +631,7 @@ struct MlpModule : nvo_module_s {
         a.dweights = dparams;
         if (dparams && !external_zero)
             if (int rc = nvo_zero_async(dparams, sizeof(float) * n_params, s)) return rc;
+        if (int rc = det_partials(s, B, &a)) return rc;
         return nvo_mlp_bwd_launch(in_pad, width, n_hidden, out_pad, a, s);
     }
     bool external_zero = false;
@@ -704,6 +725,7 @@ struct NwieModule : nvo_module_s {
         a.dweights = dparams;
         if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
+        if (int rc0 = net->det_partials(s, B, &a)) return rc0;
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {
@@ -734,6 +756,10 @@ struct NwieModule : nvo_module_s {
         if (!strcmp(key, "fuse_encoding")) {
             fuse_encoding = value != 0;
             return NVO_OK;
+        }
+        if (!strcmp(key, "deterministic")) {  // network weight gradient AND hash-grid gradient bitwise reproducible
+            net->deterministic = value != 0;
+            return enc->set_option(key, value);
         }
         if (!strcmp(key, "external_zero")) {
             if (int rc = enc->set_external_zero(value != 0)) return rc;

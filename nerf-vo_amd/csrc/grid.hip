@@ -1696,7 +1696,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     const char* force = getenv("NVO_GRID_BWD_ACC");
     const bool acc32 = s->acc_bits == 32;  // 32-bit fixed point with the L1-derived scale, every level
     auto float_mode = [&](uint32_t l) {
-        if (acc32) return false;
+        if (acc32 || s->deterministic) return false;  // (LDS float atomics retire in no fixed order)
         if (force && !strcmp(force, "fixed")) return false;
         if (force && !strcmp(force, "float")) return true;
         return g.hashed[l] && (g.offset[l + 1] - g.offset[l]) >= (1u << 18);
@@ -1758,6 +1758,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
             const uint32_t count = size - f < se ? size - f : se;
             uint32_t n_chunks = even_chunks ? even_chunks : base_chunks(count, size) * factor;
             if (n_chunks > 1024) n_chunks = 1024;
+            if (s->deterministic) n_chunks = 1;  // chunks of a slice meet in float atomics: one owner instead
             for (uint32_t c = 0; c < n_chunks; ++c)
                 (n_chunks == 1 ? single : chunked).push_back(
                     Item{(uint32_t)l | (se << 8), f, c, n_chunks | (fm ? 0x80000000u : 0u) | (acc32 ? 0x40000000u : 0u) |
@@ -1970,6 +1971,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         std::vector<uint32_t> items, chunks(nb, 1u);
         const bool spread = !(getenv("NVO_TL_ORDER") && atoi(getenv("NVO_TL_ORDER")) == 0);
         if (const char* e = getenv("NVO_TL_DENSE_CHUNKS")) st->dense_chunks = (uint32_t)atoi(e);
+        if (st->deterministic) st->dense_chunks = 1;  // the tile ranges of a bin meet in float atomics: one item per bin
         for (uint32_t j = 0; j < levels.size(); ++j) {
             const uint32_t nc = g.hashed[levels[j]] ? 1u : st->dense_chunks;
             const uint32_t nbj = first[j + 1] - first[j];
@@ -2204,7 +2206,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         const size_t lds = slices->lds_bytes;
         const uint32_t* live = nullptr;
         bool l1_fused = false;
-        if (slices->compact_live) {
+        if (slices->compact_live && !slices->deterministic) {  // (the list's append order would change the run sums)
             if (int rc = nvo_scratch_reserve(&slices->live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list"))
                 return rc;
             uint32_t* const d_live = static_cast<uint32_t*>(slices->live.ptr);

@@ -41,6 +41,15 @@ int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
                   : nvo_mlp_bwd_launch_f16(in_pad, width, n_hidden, out_pad, a, stream);
 }
 
+uint32_t nvo_mlp_bwd_blocks(int in_pad, int width, int n_hidden, uint32_t batch) {
+    uint32_t blocks = nvo_div_up(batch >> 4, kWavesPerBlock);
+    const uint32_t cap = env_blocks("NVO_MLP_BWD_BLOCKS", bwd_block_cap(in_pad, width, n_hidden));
+    return blocks > cap ? cap : blocks;
+}
+uint64_t nvo_mlp_n_weights(int in_pad, int width, int n_hidden, int out_pad) {
+    return (uint64_t)width * in_pad + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)out_pad * width;
+}
+
 // ---------------------------------------------------------------------------------------------
 // exported: NerfactoField colour head (group D of include/nerfvo_hip.h)
 // ---------------------------------------------------------------------------------------------
@@ -132,7 +141,29 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
     a.d_sh = c.d_sh;
     a.dweights = c.d_weights;
     a.recompute_hidden = c.hidden == nullptr;  // no stored activations: both hidden layers are recomputed
+    if (c.det_scratch) {
+        // deterministic mode: [dW block totals | per-tile embedding / SH sums | per-ray sums], all summed in fixed orders
+        NVO_REQUIRE((c.S & 15u) == 0 && c.cam_idx && c.d_weights, "color_bwd: the deterministic form needs S %% 16 == 0, cam_idx, d_weights");
+        NVO_REQUIRE(c.det_scratch_bytes >= nvo_color_det_scratch_bytes(c.R, c.S), "color_bwd: deterministic scratch too small");
+        const uint32_t n_tiles = (c.R * c.S) >> 4;
+        float* dw_partial = static_cast<float*>(c.det_scratch);
+        float* tile_partial = dw_partial + (size_t)nvo_mlp_bwd_blocks(64, 64, 2, c.R * c.S) * nvo_mlp_n_weights(64, 64, 2, 16);
+        float* per_ray = tile_partial + (size_t)n_tiles * 48;
+        a.dw_partial = dw_partial;
+        a.tile_partial = tile_partial;
+        if (int rc = nvo_mlp_bwd_launch(64, 64, 2, 16, a, (hipStream_t)stream)) return rc;
+        if (int rc = nvo_color_tiles_to_rays((hipStream_t)stream, c.R, c.S >> 4, tile_partial, per_ray, c.d_sh)) return rc;
+        if (c.d_embedding)
+            return nvo_reduce_by_camera((hipStream_t)stream, c.R, 32, per_ray, 48, c.cam_idx, 0, c.n_cameras, c.d_embedding);
+        return NVO_OK;
+    }
     return nvo_mlp_bwd_launch(64, 64, 2, 16, a, (hipStream_t)stream);
+}
+
+uint64_t nvo_color_det_scratch_bytes(uint32_t R, uint32_t S) {
+    const uint64_t n = (uint64_t)R * S;
+    return sizeof(float) * ((uint64_t)nvo_mlp_bwd_blocks(64, 64, 2, (uint32_t)n) * nvo_mlp_n_weights(64, 64, 2, 16) +
+                            (n >> 4) * 48 + (uint64_t)R * 48);
 }
 
 }  // extern "C"

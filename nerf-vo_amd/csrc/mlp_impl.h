@@ -513,7 +513,8 @@ struct DwAcc {
     // threads add the block total to global memory in row order (256 contiguous bytes per wave
     // instruction -- the fast float-atomic shape -- and 4x fewer adds per address).
     // MUST be called by every wave of the block (contains __syncthreads()).
-    __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib) const {
+    __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib,
+                                                float* __restrict__ partial = nullptr) const {
         const int c = lane & 15, g = lane >> 4;
         for (int w = 0; w < kWavesPerBlock; ++w) {
             if (wib == w) {
@@ -531,7 +532,11 @@ struct DwAcc {
         }
         // (every block adds to the same addresses in the same order; starting each block at its own offset was measured
         // SLOWER -- 57.5 vs 56.1 us for the colour head -- the L2 handles the convoy better than a spread)
-        for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
+        if (partial) {  // deterministic mode: the block total is STORED; a second launch sums the blocks in order
+            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) partial[e] = red[e];
+        } else {
+            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
+        }
         __syncthreads();
     }
 };
@@ -895,7 +900,16 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                             s_sh = m == j ? sh : s_sh;
                         }
                         const float e_0 = group16_sum(g == 3 ? acc[1][3] : 0.f);  // q == 15 only
-                        if (m < 4) {
+                        if (m < 4 && a.tile_partial) {
+                            // deterministic mode: the tile's sums are stored, nvo_color_tiles_to_rays /
+                            // nvo_reduce_by_camera add them up in a fixed order
+                            const int q = 4 * g + m;
+                            float* tp = a.tile_partial + (size_t)tile * 48;
+                            tp[1 + q] = e_lo;
+                            if (q < 15) tp[17 + q] = e_hi;
+                            if (q == 15) tp[0] = e_0;
+                            tp[32 + q] = s_sh;
+                        } else if (m < 4) {
                             const int q = 4 * g + m;
                             if (a.d_embedding) {
                                 float* de = a.d_embedding + (size_t)cam * 32;
@@ -951,14 +965,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
                       "dW block reduction does not fit the LDS tiles");
         float* dW = a.dweights;
-        dw0.flush_block(dW, red, lane, wib);
+        constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
+        float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
+        dw0.flush_block(dW, red, lane, wib, part);
         dW += WIDTH * IN_PAD;
+        if (part) part += WIDTH * IN_PAD;
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            dwh[l].flush_block(dW, red, lane, wib);
+            dwh[l].flush_block(dW, red, lane, wib, part);
             dW += WIDTH * WIDTH;
+            if (part) part += WIDTH * WIDTH;
         }
-        dwl.flush_block(dW, red, lane, wib);
+        dwl.flush_block(dW, red, lane, wib, part);
     }
 #ifdef NVO_MLP_PHASE
     NVO_PH(11);  // dW flush (block reduction through LDS + float atomics)
@@ -1022,11 +1040,24 @@ int launch_fwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
 }
 
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks);
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
 int launch_bwd_io(const Args& a, hipStream_t stream, uint32_t max_blocks) {
     NVO_PROF(stream, "mlp_bwd[%d-%dx%d-%d]" NVO_MLP_TAG, IN_PAD, WIDTH, N_HIDDEN, OUT_PAD);
     const uint32_t n_tiles = a.batch >> 4;
     uint32_t blocks = nvo_div_up(n_tiles, kWavesPerBlock);
     if (blocks > max_blocks) blocks = max_blocks;
+    if (int rc = launch_bwd_io_kernel<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO>(a, stream, blocks)) return rc;
+    if (a.dw_partial && a.dweights) {  // deterministic mode: sum the workgroups' block totals in workgroup order
+        constexpr uint64_t kWeights = (uint64_t)WIDTH * IN_PAD + (uint64_t)(N_HIDDEN - 1) * WIDTH * WIDTH + (uint64_t)OUT_PAD * WIDTH;
+        return nvo_reduce_partials(stream, a.dw_partial, blocks, kWeights, a.dweights);
+    }
+    return NVO_OK;
+}
+
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO>
+int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
     if (a.compact_out || a.recompute_hidden) {
         // instantiated where the NeRF-VO path uses them: level-major input (networks behind a hash grid; compact
         // only there, recomputation for their single-hidden-layer shapes) and the fused colour head

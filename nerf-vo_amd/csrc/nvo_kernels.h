@@ -40,6 +40,10 @@ struct NvoGridSlices {
     // dispatch, zeroing and flushing whatever it scans, so one round of long items beats several rounds of short ones.
     uint32_t batch_hint = 0;
     uint32_t fixed_cap = 0;  // (set before create) entries per 64-bit fixed-point slice of a dense level; 0 = 8192
+    // (set before create) deterministic mode: every slice is ONE work item (no chunks meeting in float atomics), integer
+    // accumulators on every level (LDS float atomics retire in no fixed order), no live-sample list (its append order
+    // changes the run sums).  The gradient is then bitwise reproducible; the launch is several times slower.
+    bool deterministic = false;
 };
 #include <utility>
 #include <vector>
@@ -105,6 +109,7 @@ struct NvoGridStream {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool external_zero = false;  // (tile-local layout only) see NvoGridSlices::external_zero
+    bool deterministic = false;  // (set before create) one accumulate item per bin on dense levels too; owner: see there
 };
 // false: this configuration zeroes data-dependent ranges (globally sorted layout) and cannot hand the zeroing over
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out);
@@ -186,6 +191,12 @@ struct NvoMlpArgsT {
     const NvoGridLevels* grid;    // DEVICE copy of the level table
     const void* grid_table;       // fp16 [entries][2]
     void* enc_out;                // [L][B] pairs of E (what a separate encoding kernel would have written), nullable
+    // deterministic mode (backward; nullable): every workgroup STORES its dW block total to dw_partial[block][n_weights]
+    // and a second launch sums the blocks in a fixed order (the default adds them with float atomics, whose order
+    // varies); NVO_IO_NERFACTO_COLOR: the per-tile sums of the embedding / SH-direction gradients go to
+    // tile_partial[tile][48] = {embedding 32 | d_sh 16} instead of float atomics (nvo_color_tile_reduce sums them)
+    float* dw_partial;
+    float* tile_partial;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
@@ -198,3 +209,17 @@ int nvo_mlp_fwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
                        hipStream_t stream);
 int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const NvoMlpArgs& a,
                        hipStream_t stream);
+// workgroups the backward of this shape launches for `batch` rows (rows of dw_partial) and its weight count
+uint32_t nvo_mlp_bwd_blocks(int in_pad, int width, int n_hidden, uint32_t batch);
+uint64_t nvo_mlp_n_weights(int in_pad, int width, int n_hidden, int out_pad);
+
+// ---- deterministic reductions (adam.hip) ---------------------------------------------------------
+// dst[e] += sum_b partial[b][e], b ascending
+int nvo_reduce_partials(hipStream_t stream, const float* partial, uint32_t n_blocks, uint64_t n, float* dst);
+// out[c][k] += sum over rows r with cam(r) == c, r ascending within 8 interleaved sub-sequences that are combined in a
+// fixed order.  cam: int32 [R] (cam_i64x3 = 0) or int64 [R][3] column 0 (= 1); rows [R][row_stride], K <= 32 columns
+int nvo_reduce_by_camera(hipStream_t stream, uint32_t R, uint32_t K, const float* rows, uint32_t row_stride,
+                         const void* cam, int cam_i64x3, uint32_t F, float* out);
+// colour head: tile_partial [R * tiles_per_ray][48] -> per_ray [R][48] (tiles ascending); d_sh[r] = per_ray[r][32..48)
+int nvo_color_tiles_to_rays(hipStream_t stream, uint32_t R, uint32_t tiles_per_ray, const float* tile_partial,
+                            float* per_ray, float* d_sh);

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256)
 k_pose_bwd(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
            const float* __restrict__ c2w, const float* __restrict__ d_origin,
            const float* __restrict__ d_dir, const float* __restrict__ d_dir01,
-           float* __restrict__ d_corr) {
+           float* __restrict__ d_corr, float* __restrict__ per_ray) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int64_t cam = ray_indices[3 * (size_t)r + 0];
@@ -110,6 +110,16 @@ k_pose_bwd(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __r
     for (int k = 0; k < 3; ++k) {
         d0[k] /= n0;
         gd[k] = d_dir[3 * (size_t)r + k] + (d_dir01 ? 0.5f * d_dir01[3 * (size_t)r + k] : 0.f);
+    }
+    if (per_ray) {  // deterministic form: stored per ray, summed per camera in a fixed order by nvo_reduce_by_camera
+        float* g = per_ray + 12 * (size_t)r;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[4 * i + j] = gd[i] * d0[j];
+            g[4 * i + 3] = d_origin[3 * (size_t)r + i];
+        }
+        return;
     }
     float* g = d_corr + 12 * cam;
 #pragma unroll
@@ -294,9 +304,22 @@ int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, co
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "pose_bwd");
     NVO_LAUNCH(k_pose_bwd, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices,
-               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections);
+               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, (float*)nullptr);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
+}
+
+int nvo_pose_bwd_det(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                     const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                     float* d_corrections, float* per_ray_scratch, uint32_t n_cameras) {
+    NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && d_origin && d_dir && d_corrections && per_ray_scratch),
+                "pose_bwd_det: NULL argument");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "pose_bwd");
+    NVO_LAUNCH(k_pose_bwd, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices,
+               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, per_ray_scratch);
+    NVO_CHECK_LAUNCH();
+    return nvo_reduce_by_camera((hipStream_t)stream, R, 12, per_ray_scratch, 12, ray_indices, 1, n_cameras, d_corrections);
 }
 
 int nvo_se3_exp_map_bwd(nvo_stream_t stream, uint32_t n, const float* tangent, const float* d_corrections,

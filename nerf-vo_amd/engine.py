@@ -146,6 +146,13 @@ class EngineConfig:
     # return values on every step); "never": the terms read 0 on non-update steps.  Gradients are identical in all
     # three (nerfstudio computes these values under no_grad on such steps).
     proposal_loss_values: str = "logging"
+    # Bitwise reproducible training (debugging aid; several times slower): every float-atomic reduction of the step is
+    # replaced by a fixed summation order -- MLP weight gradients (per-workgroup block totals + an ordered reduce),
+    # the colour head's per-camera embedding / per-ray SH gradients, the per-camera pose gradient, and the hash grids
+    # (ONE owner work item per slice / bin instead of sample chunks that meet in float atomics, integer accumulators
+    # everywhere, no live-sample list).  Two runs from the same state then produce bit-identical parameters; only the
+    # REPORTED loss values (64 float-atomic shards) may differ in their last bits.
+    deterministic: bool = False
     log_every: int = 10                   # LoggingConfig.steps_per_log of the trainer mirror
     seed: int = 1337
 
@@ -195,6 +202,7 @@ class NerfactoEngine:
         for m, mode in zip((self.base_net, *self.prop_nets), modes):
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
+            m.set_option("deterministic", int(bool(cfg.deterministic)))
         batches = (cfg.num_nerf_samples, *cfg.num_proposal_samples)
         for m, runs, per_ray in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs, batches):
             m.set_option("grid_bwd_runs", int(bool(runs)))
@@ -277,11 +285,13 @@ class NerfactoEngine:
         self._pose_inputs = None  # (intrinsics, c2w) of the rays currently loaded (pose backward)
         # GradScaler-shaped optimiser state ON THE DEVICE: [applied steps x 4 groups | loss scale (float bits) | growth
         # tracker | pad]; slot of a group = its index in _GROUP_ORDER (also its skip-flag word)
-        self.opt_state = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.opt_state = torch.zeros(16, dtype=torch.int32, device=dev)
         self.dev_applied = self.opt_state[0:4]
         self.dev_loss_scale = self.opt_state[4:5].view(torch.float32)
         self.dev_growth_tracker = self.opt_state[5:6]
+        self.dev_bias = self.opt_state[8:16].view(torch.float32)  # [group][2]: bias corrections of the next applied step
         self.dev_loss_scale.fill_(cfg.loss_scale_init if cfg.dynamic_loss_scale else cfg.loss_scale)
+        self._write_bias([0, 0, 0, 0])
         self.step = 0
         self.steps_since_proposal_update = 0
         self._ws = {}  # (ray count, training) -> scratch; never evicted (captured graphs address it by pointer)
@@ -375,6 +385,16 @@ class NerfactoEngine:
         for g, n in steps.items():
             vals[self._GROUP_ORDER.index(g)] = int(n)
         self.dev_applied.copy_(torch.tensor(vals, dtype=torch.int32))
+        self._write_bias(vals)
+
+    def _write_bias(self, applied) -> None:
+        """Bias corrections of every group's NEXT applied step (t = applied + 1), as nvo_opt_commit keeps them."""
+        b1, b2 = self.cfg.adam_betas
+        vals = []
+        for n in applied:
+            t = int(n) + 1
+            vals += [1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)]
+        self.dev_bias.copy_(torch.tensor(vals, dtype=torch.float32))
 
     def current_loss_scale(self) -> float:
         """The loss scale the next step will use (device read-back; static unless cfg.dynamic_loss_scale)."""
@@ -435,6 +455,10 @@ class NerfactoEngine:
         if training:
             # colour head: no stored hidden activations (recomputed in the backward)
             ws["drgb"] = torch.empty(Nm, 16, **f16)
+            if self.cfg.deterministic:  # scratch of the fixed-order reductions (colour head, pose gradient)
+                ws["color_det"] = torch.empty(int(_lib.lib().nvo_color_det_scratch_bytes(R, self.levels[-1])),
+                                              dtype=torch.uint8, device=dev)
+                ws["pose_det"] = torch.empty(R, 12, **f32)
         self._ws[key] = ws
         return ws
 
@@ -535,7 +559,10 @@ class NerfactoEngine:
             d_embedding=self._param_ptr("field.embedding", self.grads).value if training else None,
             d_sh=ws["d_sh"].data_ptr() if (training and "d_sh" in ws) else None,
             d_weights=self._param_ptr("field.color", self.grads).value if training else None,
-            act_bf16=int(self.bf16))
+            act_bf16=int(self.bf16),
+            det_scratch=ws["color_det"].data_ptr() if (training and "color_det" in ws) else None,
+            det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
+            n_cameras=self.cfg.num_images)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -793,8 +820,12 @@ class NerfactoEngine:
                   _ptr(ws[f"tbins{k}"]), _ptr(ws[f"dx{k}"]), _ptr(ws["d_origin"]), _ptr(ws["d_dir"]))
         _call("nvo_sh_bwd_input_f32", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["d_sh"]), _ptr(ws["d_dirs01"]))
         intr, c2w = self._pose_inputs
-        _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
-              _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
+        if "pose_det" in ws:  # deterministic mode: per-ray contributions summed per camera in a fixed order
+            _call("nvo_pose_bwd_det", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+                  _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections), _ptr(ws["pose_det"]), cfg.num_images)
+        else:
+            _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+                  _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
         # regulariser: its value goes to loss slot 5 of shard 0, its gradient is scaled like the rest
         dyn = cfg.dynamic_loss_scale
         reg_scale = (1.0 if dyn else cfg.loss_scale) / self.world_size
@@ -864,7 +895,7 @@ class NerfactoEngine:
             mask |= 1 << gi
             hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None
             batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=0, hyper_dev=hyper,
-                                        step_dev=self.dev_applied.data_ptr() + 4 * gi, flag_slot=gi, flag_slot_set=1))
+                                        bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
         if not batch:
             return
         arr = (_lib.AdamGroup * len(batch))(*batch)
@@ -880,7 +911,8 @@ class NerfactoEngine:
                     scale_mask |= 1 << order.index(g)
         _call("nvo_opt_commit", stream, len(order), mask, scale_mask, _ptr(self.dev_applied), _ptr(self.skip_flag),
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
-              cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max)
+              cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max,
+              _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
 
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step
