@@ -493,6 +493,12 @@ struct GridModule : nvo_module_s {
             stream_bins.overlap = value != 0;
             return NVO_OK;
         }
+        if (!strcmp(key, "grid_stream_acc_bits")) {  // record pass of the streamed levels: 64 | 32 (packed, 8192-entry bins)
+            NVO_REQUIRE(value == 32 || value == 64, "grid_stream_acc_bits must be 32 or 64");
+            nvo_grid_stream_destroy(&stream_bins);
+            stream_bins.acc_bits = (uint32_t)value;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
             nvo_grid_stream_destroy(&stream_bins);
             stream_bins.owner_max_slices = (uint32_t)value;

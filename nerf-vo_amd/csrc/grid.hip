@@ -235,6 +235,104 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------
+// forward for SMALL grids (the proposal networks: 5 levels, 2^17-entry tables): coarse dense levels served from LDS
+// ------------------------------------------------------------------------------------------
+// k_grid_fwd on a proposal grid runs at the L1's tag-lookup rate, not at any bandwidth: 27 M line accesses per 1 M-sample
+// launch, 90 % of them hits (profiles/r2_pmc_grid_fwd.txt) -- a random gather costs the vector L1 one tag look-up per
+// LANE whatever it hits.  The two coarsest levels (16 KiB + 79 / 128 KiB) fit a CU's 160 KiB of LDS, whose banked
+// gather costs ~8 cycles per wave instruction instead of 64.  One 1024-thread workgroup per CU stages them once and
+// walks its share of the samples with a thread per SAMPLE (all levels: the position is loaded once instead of once per
+// level, and a lane keeps 16-20 global gathers of the remaining levels in flight); on the hashed levels the two x
+// corners of a (y, z) pair are ONE aligned 8-byte load whenever the cell's x index is even (then idx1 == idx0 ^ 1).
+// L1 accesses per sample: 28 -> 16 (levels dense/dense/dense/hash/hash), 32 -> 18 (dense/dense/hash/hash/hash).
+// Same fp32 interpolation, same order, one rounding: bit-identical to k_grid_fwd.
+constexpr int kSmallBlock = 1024;
+
+template <int NLDS, int NG>
+__global__ void __launch_bounds__(kSmallBlock)
+k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                 __half2* __restrict__ out, int out_bf16, uint32_t per_block) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const uint32_t* __restrict__ tab32 = reinterpret_cast<const uint32_t*>(table);
+    {   // stage the leading NLDS levels (contiguous from entry 0; level offsets are multiples of 8 entries)
+        const uint32_t n4 = g.offset[NLDS] >> 2;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+        for (uint32_t e = threadIdx.x; e < n4; e += kSmallBlock) dst[e] = src[e];
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.x * per_block;
+    const uint32_t last = min(N, first + per_block);
+    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
+    for (uint32_t i = first + threadIdx.x; i < last; i += kSmallBlock) {
+        const float px = x[3 * (size_t)i + 0], py = x[3 * (size_t)i + 1], pz = x[3 * (size_t)i + 2];
+        // ---- global levels first: every gather of the sample is requested before anything is consumed
+        Corner cg[NG];
+        uint32_t vg[NG][8];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const uint32_t level = NLDS + q;
+            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+            const uint32_t hashed = g.hashed[level];
+            const uint32_t* __restrict__ tl = tab32 + off;
+            cg[q] = grid_cell(g.scale[level], px, py, pz);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t cy = cg[q].py + (j & 1u), cz = cg[q].pz + (j >> 1);
+                const uint32_t i0 = nvo_grid_index(hashed, size, res, cg[q].px, cy, cz);
+                const uint32_t i1 = nvo_grid_index(hashed, size, res, cg[q].px + 1u, cy, cz);
+                if (hashed ? ((cg[q].px & 1u) == 0u) : false) {
+                    // even cell x: idx1 == idx0 ^ 1 -- both corners sit in one aligned 8-byte pair
+                    const uint2 pr = *reinterpret_cast<const uint2*>(tl + (i0 & ~1u));
+                    vg[q][2 * j] = (i0 & 1u) ? pr.y : pr.x;
+                    vg[q][2 * j + 1] = (i0 & 1u) ? pr.x : pr.y;
+                } else if (!hashed && i1 == i0 + 1u) {
+                    // dense level: x neighbours are neighbours in memory (dword alignment suffices)
+                    const uint2 pr = *reinterpret_cast<const uint2*>(tl + i0);
+                    vg[q][2 * j] = pr.x;
+                    vg[q][2 * j + 1] = pr.y;
+                } else {
+                    vg[q][2 * j] = tl[i0];
+                    vg[q][2 * j + 1] = tl[i1];
+                }
+            }
+        }
+        // ---- LDS levels while the gathers fly
+#pragma unroll
+        for (int l = 0; l < NLDS; ++l) {
+            const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+            const uint32_t* tl = lds_tab + off;
+            const Corner c = grid_cell(g.scale[l], px, py, pz);
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                ((k & 4u) ? c.wz : 1.f - c.wz);
+                const float2 f = __half22float2(__builtin_bit_cast(__half2, tl[idx]));
+                r0 = fmaf(w, f.x, r0);
+                r1 = fmaf(w, f.y, r1);
+            }
+            o32[(size_t)l * N + i] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Corner& c = cg[q];
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                ((k & 4u) ? c.wz : 1.f - c.wz);
+                const float2 f = __half22float2(__builtin_bit_cast(__half2, vg[q][k]));
+                r0 = fmaf(w, f.x, r0);
+                r1 = fmaf(w, f.y, r1);
+            }
+            o32[(size_t)(NLDS + q) * N + i] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward w.r.t. parameters, global-atomic form
 // ------------------------------------------------------------------------------------------
 // dy   : SOA ? [L][N] : [N][L] of (half2 | float2), already multiplied by the loss scale
@@ -1540,6 +1638,330 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
     }
 }
 
+// ---- tile-local layout, PACKED accumulators (NvoGridStream::acc_bits == 32; round 3) ---------------------------
+// k_tl_accumulate spends an entry's two features in two 64-bit LDS atomics on 16 bytes of accumulator.  Here an entry is
+// ONE 64-bit word holding two 32-bit fixed-point sums, lo = feature 0 and hi = feature 1, updated by ONE atomic add of
+// X = a + b * 2^32 (two's complement: the low half's borrow rides into the high half and comes back out when the
+// sums are separated: lo = (int32)X, hi = (X - lo) >> 32 -- exact while both sums stay inside int32).  Half the LDS
+// atomics, half the zeroing and flushing, and 8 bytes per entry: a bin holds 8192 entries in the 64 KiB that 4096 needed,
+// so a bin's runs are twice as long (~64 records = one full wave load) and there are half as many items.
+// The fixed-point scale must be data-derived and overflow-proof.  |sum over an entry| <= L1(bin) = sum of |w * dy| over
+// every record of the bin, and the SCATTER can deliver that bound for free: its rank atomic (one LDS atomic per x-corner
+// pair that returns the pair's position inside its (tile, bin) run) becomes a 64-bit add whose upper fields sum the
+// records' magnitudes, quantised UP against the tile's max |dy|:
+//     hist64[bin] += count | q0 << 16 | q1 << 40,   q_f = ceil(|v_f| * 1023 / M_f)  (<= 1024; <= 4096 records per tile)
+// The tile writes L1_f(tile, bin) <= S_f * M_f / 1023, rounded UP to bf16, next to its segment word; the accumulate item
+// sums the words of its tiles (fixed order) and scales by 2^29 / L1.  Everything that feeds the scale is integer or
+// fixed-order arithmetic, so single-chunk bins stay bitwise reproducible.
+constexpr uint32_t kBinP = 8192;
+constexpr int kTlBlockP = 512;
+
+__device__ __forceinline__ uint32_t st_bin_entries_p(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    return min(kBinP, size - slice * kBinP);
+}
+
+__global__ void __launch_bounds__(256)
+k_st_zero_p(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
+            const uint32_t* __restrict__ bin_chunks, float* __restrict__ grad) {
+    if (bin_chunks[blockIdx.x] <= 1u) return;
+    const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
+    const uint32_t n = 2 * st_bin_entries_p(g, level, slice);
+    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinP);
+    for (uint32_t e = threadIdx.x; e < n; e += 256) gr[e] = 0.f;
+}
+
+// maximum over the 64 lanes of a NON-NEGATIVE value, in every lane (DPP steps as nvo_wave_sum: a lane without a source
+// reads 0, the identity for non-negative values)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, nvo_dpp_f32<0x128>(v));
+    v = fmaxf(v, nvo_dpp_f32<0x124>(v));
+    v = fmaxf(v, nvo_dpp_f32<0x122>(v));
+    v = fmaxf(v, nvo_dpp_f32<0x121>(v));
+    v = fmaxf(v, nvo_dpp_f32<0x142, 0xA>(v));
+    v = fmaxf(v, nvo_dpp_f32<0x143, 0xC>(v));
+    return nvo_wave_bcast(v, 63);
+}
+
+__device__ __forceinline__ uint32_t bf16_up(float v) {  // smallest bfloat16 >= v, v >= 0 and finite
+    const uint32_t u = __float_as_uint(v) + 0xFFFFu;
+    return u >> 16;
+}
+
+template <int TILE, bool SOA, typename DY2>
+__global__ void __launch_bounds__(TILE)
+k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
+               const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
+               uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint2* __restrict__ records) {
+    constexpr uint32_t kStBlock = TILE;
+    constexpr uint32_t kStRecords = TILE * 8;
+    constexpr uint32_t kWaves = TILE / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
+    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
+    const uint32_t bin0 = bin_first[blockIdx.y];
+    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
+    const uint32_t size = g.offset[level + 1] - g.offset[level];
+    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(stage + kStRecords);
+    uint32_t* loff = reinterpret_cast<uint32_t*>(hist + n_slices);
+    __shared__ uint32_t total_s;
+    __shared__ float wmax[kWaves][2];
+    const uint32_t i = tile * kStBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    float2 d = make_float2(0.f, 0.f);
+    float xs[3] = {0.f, 0.f, 0.f};
+    bool live = false;
+    if (i < N) {  // dy and x in one round trip
+        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
+        xs[0] = x[3 * (size_t)i + 0];
+        xs[1] = x[3 * (size_t)i + 1];
+        xs[2] = x[3 * (size_t)i + 2];
+    }
+    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) hist[b] = 0ull;
+    {   // tile maxima of |dy| per feature (non-finite values are flagged below and poison the level: treat them as 0 here)
+        const bool fin = fabsf(d.x) < INFINITY && fabsf(d.y) < INFINITY;
+        float m0 = fin ? fabsf(d.x) : 0.f, m1 = fin ? fabsf(d.y) : 0.f;
+        m0 = wave_max_nonneg(m0);
+        m1 = wave_max_nonneg(m1);
+        if (lane == 0) {
+            wmax[wib][0] = m0;
+            wmax[wib][1] = m1;
+        }
+    }
+    __syncthreads();
+    float M0 = 0.f, M1 = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        M0 = fmaxf(M0, wmax[w][0]);
+        M1 = fmaxf(M1, wmax[w][1]);
+    }
+    const float q0s = M0 > 0.f ? 1023.f / M0 : 0.f, q1s = M1 > 0.f ? 1023.f / M1 : 0.f;
+    uint32_t idx[8], slot[8];
+    float v0[8], v1[8];
+    const bool finite = fabsf(d.x) < INFINITY && fabsf(d.y) < INFINITY;
+    if (live) {
+        const Corner c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                            ((k & 4u) ? c.wz : 1.f - c.wz);
+            v0[k] = w * d.x;
+            v1[k] = w * d.y;
+        }
+        // magnitude of a record in units of M / 1023, rounded UP (+1 covers the rounding of the product); <= 1024
+        auto quant = [&](float v, float qs) -> unsigned long long {
+            return finite ? (unsigned long long)min(1024u, (uint32_t)(fabsf(v) * qs) + 1u) : 0ull;
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {  // rank inside (tile, bin) + magnitude sums: ONE LDS atomic per x-corner pair
+            const uint32_t b0 = idx[2 * j] / kBinP, b1 = idx[2 * j + 1] / kBinP;
+            const unsigned long long m_a = (quant(v0[2 * j], q0s) << 16) | (quant(v1[2 * j], q1s) << 40);
+            const unsigned long long m_b = (quant(v0[2 * j + 1], q0s) << 16) | (quant(v1[2 * j + 1], q1s) << 40);
+            if (b0 == b1) {
+                const uint32_t r0 = (uint32_t)(atomicAdd(&hist[b0], 2ull + m_a + m_b) & 0xFFFFull);
+                slot[2 * j] = r0;
+                slot[2 * j + 1] = r0 + 1u;
+            } else {
+                slot[2 * j] = (uint32_t)(atomicAdd(&hist[b0], 1ull + m_a) & 0xFFFFull);
+                slot[2 * j + 1] = (uint32_t)(atomicAdd(&hist[b1], 1ull + m_b) & 0xFFFFull);
+            }
+        }
+    }
+    const uint32_t bad_bit = __syncthreads_or(live && !finite) ? 0x80000000u : 0u;
+    if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < n_slices; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const unsigned long long h = b < n_slices ? hist[b] : 0ull;
+            const uint32_t cnt = (uint32_t)(h & 0xFFFFull);
+            const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+            if (b < n_slices) {
+                loff[b] = carry + incl - cnt;
+                seg[(size_t)(bin0 + b) * n_tiles + tile] = (carry + incl - cnt) | (cnt << 16) | bad_bit;
+                const float l0 = (float)((uint32_t)(h >> 16) & 0xFFFFFFu) * (M0 * (1.f / 1023.f));
+                const float l1 = (float)(uint32_t)(h >> 40) * (M1 * (1.f / 1023.f));
+                segl1[(size_t)(bin0 + b) * n_tiles + tile] = bf16_up(l0 * 1.0001f) | (bf16_up(l1 * 1.0001f) << 16);
+            }
+            carry += nvo_wave_bcast(incl, 63);
+        }
+        if (lane == 0) total_s = carry;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            stage[loff[idx[k] / kBinP] + slot[k]] = rec_pack(idx[k] & (kBinP - 1u), v0[k], v1[k]);
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(records + ((size_t)blockIdx.y * n_tiles + tile) * kStRecords);
+    const uint4* src = reinterpret_cast<const uint4*>(stage);
+    for (uint32_t t = threadIdx.x; t < (total + 1u) / 2u; t += kStBlock) dst[t] = src[t];
+}
+
+__global__ void __launch_bounds__(kTlBlockP)
+k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
+                  const uint32_t* __restrict__ segl1, const uint2* __restrict__ records, uint32_t n_tiles,
+                  uint32_t tile_records, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
+    constexpr uint32_t kWaves = kTlBlockP / 64;
+    __shared__ float wpart[kWaves][2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t it = blockIdx.x;
+    if (it >= n_items) return;
+    auto words_first = [&](const TlItem& I, uint32_t* l1w) -> uint32_t {
+        const uint32_t n_span = I.t1 - I.t0;
+        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
+        const uint32_t first = min(n_span, wib * per_wave);
+        const uint32_t n_mine = min(per_wave, n_span - first);
+        const bool mine = lane < min(64u, n_mine);
+        const size_t o = (size_t)I.bin * n_tiles + I.t0 + first + lane;
+        *l1w = mine ? segl1[o] : 0u;
+        return mine ? seg[o] : 0u;
+    };
+    TlItem cur = tl_decode(items[it], n_tiles);
+    uint32_t l1w = 0u;
+    uint32_t segw = words_first(cur, &l1w);
+    for (;;) {
+        const uint32_t it_next = it + gridDim.x;
+        const bool has_next = it_next < n_items;
+        const uint4 head_next = items[has_next ? it_next : it];  // in flight while the accumulators are zeroed
+        const uint32_t entries = st_bin_entries_p(g, cur.level, cur.slice);
+        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * kBinP);
+        {
+            uint4* z = reinterpret_cast<uint4*>(lds_raw);  // one uint4 = two entries
+            for (uint32_t e = threadIdx.x; e < (entries + 1u) / 2u; e += kTlBlockP) z[e] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint2* __restrict__ rec_lvl = records + (size_t)cur.lvl * n_tiles * tile_records;
+        const uint32_t n_span = cur.t1 - cur.t0;
+        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
+        const uint32_t tile_first = cur.t0 + min(n_span, wib * per_wave);
+        const uint32_t n_mine = min(per_wave, cur.t1 - tile_first);
+        // ---- the bin's L1 bound: this wave's tiles (lane j: tile j; further blocks of 64 tiles in order), then the waves
+        {
+            float a0 = __uint_as_float(l1w << 16), a1 = __uint_as_float(l1w & 0xFFFF0000u);
+            for (uint32_t j0 = 64u; j0 < n_mine; j0 += 64u) {
+                const uint32_t w2 = lane < min(64u, n_mine - j0) ? segl1[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+                a0 += __uint_as_float(w2 << 16);
+                a1 += __uint_as_float(w2 & 0xFFFF0000u);
+            }
+            a0 = nvo_wave_sum(a0);
+            a1 = nvo_wave_sum(a1);
+            if (lane == 0) {
+                wpart[wib][0] = a0;
+                wpart[wib][1] = a1;
+            }
+        }
+        __syncthreads();  // accumulators zeroed, L1 partials visible
+        float L0 = 0.f, L1 = 0.f;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) {
+            L0 += wpart[w][0];
+            L1 += wpart[w][1];
+        }
+        // |sum over an entry| <= L; rounding of each add <= 0.5: n <= 2^20 records leave 2^29 + 2^19 < 2^31
+        const float s0 = L0 > 0.f ? 536870912.f / L0 : 0.f, s1 = L1 > 0.f ? 536870912.f / L1 : 0.f;
+        const float inv0 = L0 * (1.f / 536870912.f), inv1 = L1 * (1.f / 536870912.f);
+        bool bad = false;
+        auto add = [&](uint2 r) {
+            const uint32_t rel = (r.x & 0x3Fu) | ((r.y & 0x7Fu) << 6);
+            const int a = __float2int_rn(__uint_as_float(r.x & ~0x3Fu) * s0);
+            const int b = __float2int_rn(__uint_as_float(r.y & ~0x7Fu) * s1);
+            const long long X = (long long)a + ((long long)b << 32);
+            atomicAdd(&acc[rel], (unsigned long long)X);
+        };
+        TlItem nxt = cur;
+        uint32_t segw_next = 0u, l1w_next = 0u;
+        bool next_requested = false;
+        for (uint32_t j0 = 0; j0 < n_mine; j0 += 64u) {
+            const uint32_t n_here = min(64u, n_mine - j0);
+            if (j0 > 0u) segw = lane < n_here ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+            const uint32_t cnt = lane < n_here ? (segw >> 16) & 0x7FFFu : 0u;
+            bad |= lane < n_here && (segw >> 31) != 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t base = (tile_first + j0 + lane) * tile_records + (segw & 0xFFFFu) - (incl - cnt);
+            uint32_t r_s = 0u;  // (scalar) first run that reaches into the current window
+            for (uint32_t q0 = 0; q0 * 64u < total; q0 += kTlWin) {
+                uint2 rec[kTlWin];
+#pragma unroll
+                for (uint32_t u = 0; u < kTlWin; ++u) {
+                    const uint32_t w0 = (q0 + u) * 64u;  // uniform
+                    const uint32_t v = w0 + lane;
+                    uint32_t my_base = 0u;
+                    if (w0 < total) {
+                        uint32_t end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r_s);
+                        while (end_r <= w0) end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)++r_s);
+                        my_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r_s);
+                        for (uint32_t r = r_s; end_r < w0 + 64u && r < 63u;) {
+                            ++r;
+                            const uint32_t b_r = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r);
+                            my_base = v >= end_r ? b_r : my_base;
+                            end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r);
+                        }
+                    }
+                    rec[u] = rec_lvl[v < total ? my_base + v : 0u];
+                }
+                if (!next_requested) {  // the next item's segment / L1 words ride behind this item's loads
+                    next_requested = true;
+                    if (has_next) {
+                        nxt = tl_decode(head_next, n_tiles);
+                        segw_next = words_first(nxt, &l1w_next);
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kTlWin; ++u)
+                    if ((q0 + u) * 64u + lane < total) add(rec[u]);
+            }
+        }
+        if (!next_requested && has_next) {  // (a wave without records in this item)
+            nxt = tl_decode(head_next, n_tiles);
+            segw_next = words_first(nxt, &l1w_next);
+        }
+        __syncthreads();
+        {
+            // flush: two entries (four gradient scalars) per thread and step: one 16-byte LDS read, one 16-byte store
+            const uint32_t n2 = entries >> 1;  // (entries of a bin are a multiple of 8)
+            float4* __restrict__ gr4 = reinterpret_cast<float4*>(gr);
+            const ulonglong2* acc2 = reinterpret_cast<const ulonglong2*>(acc);
+            auto split = [&](unsigned long long w, float* f0, float* f1) {
+                const long long X = (long long)w;
+                const int lo = (int)X;
+                const int hi = (int)((X - (long long)lo) >> 32);
+                *f0 = (float)lo * inv0;
+                *f1 = (float)hi * inv1;
+            };
+            if (cur.n_chunks == 1u) {
+                for (uint32_t e = threadIdx.x; e < n2; e += kTlBlockP) {
+                    const ulonglong2 w = acc2[e];
+                    float4 v;
+                    split(w.x, &v.x, &v.y);
+                    split(w.y, &v.z, &v.w);
+                    gr4[e] = v;
+                }
+            } else {
+                for (uint32_t e = threadIdx.x; e < entries; e += kTlBlockP) {
+                    float f0, f1;
+                    split(acc[e], &f0, &f1);
+                    if (f0 != 0.f) atomicAdd(gr + 2 * e, f0);
+                    if (f1 != 0.f) atomicAdd(gr + 2 * e + 1, f1);
+                }
+            }
+        }
+        __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
+        if (__ballot(bad) != 0ull && lane == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
+        if (!has_next) break;
+        it = it_next;
+        cur = nxt;
+        segw = segw_next;
+        l1w = l1w_next;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward w.r.t. the input position (needed for analytic normals and pose gradients)
 // ------------------------------------------------------------------------------------------
@@ -1660,6 +2082,29 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
+    // small grids (the proposal networks): the two coarsest dense levels from LDS, a thread per sample (k_grid_fwd_small)
+    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 1; }();
+    if (small_env && soa && !indices && !dydx_half && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
+        (size_t)g.offset[2] * 4 <= 152 * 1024 && (g.offset[2] & 3u) == 0u && (((uintptr_t)table_half) & 15u) == 0u) {
+        static const uint32_t n_cus = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return (uint32_t)(n > 0 ? n : 256);
+        }();
+        const size_t lds = (size_t)g.offset[2] * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              152 * 1024));
+            attr_set = true;
+        }
+        // one workgroup per CU, a whole number of 1024-sample passes each
+        const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock);
+        NVO_LAUNCH((k_grid_fwd_small<2, 3>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
+                   (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
+        NVO_CHECK_LAUNCH();
+        return NVO_OK;
+    }
     static const int spt_env = [] { const char* e = getenv("NVO_GRID_FWD_SPT"); return e ? atoi(e) : 2; }();
     const int spt = (dydx_half || spt_env < 2) ? 1 : (spt_env >= 4 ? 4 : 2);  // samples per thread
     const uint32_t tiles = nvo_div_up(N, kGridBlock * spt);
@@ -1931,10 +2376,17 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     st->streamed_mask = 0;
     if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
     if (const char* e = getenv("NVO_GRID_OWNER_SLICES")) st->owner_max_slices = (uint32_t)atoi(e);  // measurements
+    if (const char* e = getenv("NVO_TL_ACC_BITS")) st->acc_bits = (uint32_t)atoi(e);  // A/B switch for measurements
+    if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
+    if (!st->tile_local) st->acc_bits = 64;  // (the packed accumulators exist for the tile-local layout only)
+    // entries per bin: 4096 x 16 B (two 64-bit sums per entry) or 8192 x 8 B (two 32-bit sums in one word) = 64 KiB
+    const uint32_t bin_entries = st->acc_bits == 32 ? kBinP : kBinSlice;
+    st->bin_entries = bin_entries;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
-        const uint32_t n_slices = (size + kBinSlice - 1u) / kBinSlice;
-        if (n_slices <= st->owner_max_slices) continue;
+        // (which levels stay slice-owner is decided in 4096-entry units, whatever the bin size)
+        if ((size + kBinSlice - 1u) / kBinSlice <= st->owner_max_slices) continue;
+        const uint32_t n_slices = (size + bin_entries - 1u) / bin_entries;
         levels.push_back(l);
         first.push_back((uint32_t)bin_level.size());
         if (n_slices > st->max_slices) st->max_slices = n_slices;
@@ -1964,7 +2416,6 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_level, bin_level.data(), 4 * nb, hipMemcpyHostToDevice));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_slice, bin_slice.data(), 4 * nb, hipMemcpyHostToDevice));
     }
-    if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
     if (st->tile_local && nb) {
         // static work list: hashed levels spread their records evenly over the bins (one item per bin); a streamed
         // DENSE level sees clustered samples, so its bins are split into tile ranges
@@ -2066,7 +2517,8 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         const size_t tile_records = (size_t)tile * 8;
         const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * sizeof(uint2), 256);
         const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
-        const size_t need_tl = rec_bytes_tl + seg_bytes;
+        const bool packed = st->acc_bits == 32;
+        const size_t need_tl = rec_bytes_tl + seg_bytes * (packed ? 2 : 1);
         if (int rc = nvo_scratch_reserve(&st->work, need_tl, stream, "grid_bwd_stream records")) return rc;
         unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
         uint2* records_tl = reinterpret_cast<uint2*>(d_work);
@@ -2107,7 +2559,40 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         else if (tile == 512) NVO_LAUNCH_TL(512, SOA_, T_);                       \
         else NVO_LAUNCH_TL(1024, SOA_, T_);                                       \
     } while (0)
-        if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, false);
+        if (packed) {
+            // two 32-bit fixed-point sums per 64-bit accumulator word, 8192-entry bins (k_tl_scatter_p / k_tl_accumulate_p)
+            NVO_REQUIRE(tile == 512, "grid_bwd_stream: the packed accumulators are built for 512-sample tiles");
+            uint32_t* segl1 = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl + seg_bytes);
+            const size_t lds_p = tile_records * sizeof(uint2) + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
+            const size_t lds_acc_p = sizeof(unsigned long long) * kBinP;
+#define NVO_LAUNCH_TLP(SOA_, T_)                                                                              \
+    do {                                                                                                      \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) {                                                                                      \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<512, SOA_, T_>,                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(512 * 64 + 12 * 4096))); \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p,                                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc_p));   \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        {                                                                                                     \
+            NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
+            NVO_LAUNCH((k_tl_scatter_p<512, SOA_, T_>), grid_tl, dim3(512), lds_p, stream, g, N, x, (const T_*)dy, \
+                       st->d_levels, st->d_bin_first, seg, segl1, records_tl);                                 \
+        }                                                                                                     \
+        {                                                                                                     \
+            NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
+            if (!st->external_zero)                                                                           \
+                NVO_LAUNCH(k_st_zero_p, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
+                           st->d_bin_chunks, grad);                                                           \
+            NVO_LAUNCH(k_tl_accumulate_p, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlockP), \
+                       lds_acc_p, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1, records_tl, \
+                       n_tiles, (uint32_t)tile_records, grad);                                                \
+        }                                                                                                     \
+    } while (0)
+            if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
+#undef NVO_LAUNCH_TLP
+        } else if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, false);
 #undef NVO_LAUNCH_TL_T
 #undef NVO_LAUNCH_TL
         NVO_CHECK_LAUNCH();

@@ -103,6 +103,11 @@ struct NvoGridStream {
     // count / scan passes): every (tile, level) keeps its bin-sorted records in a fixed region + a [bin][tile] segment
     // table; accumulate items are static (grid.hip).  Measured on the full step: 0.744 vs 0.769 ms.
     bool tile_local = true;
+    // (tile-local layout) accumulators of the record pass: 64 = two 64-bit fixed-point sums per entry, 4096-entry bins;
+    // 32 = two 32-bit fixed-point sums in ONE 64-bit word (one LDS atomic per record), 8192-entry bins, overflow-proof
+    // scale from per-(tile, bin) L1 bounds the scatter delivers with its rank atomics (grid.hip, k_tl_scatter_p)
+    uint32_t acc_bits = 64;
+    uint32_t bin_entries = 4096;      // (set by create)
     uint32_t dense_chunks = 8;        // tile-range chunks per bin of a streamed DENSE level (clustered samples)
     uint32_t* d_tl_items = nullptr;   // uint4 {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}
     uint32_t n_tl_items = 0;

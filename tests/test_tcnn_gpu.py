@@ -101,14 +101,17 @@ def _set_bwd_mode(enc, bwd_mode):
     """0 atomics | 1 slice owner | 2 binned | 3 streamed (globally sorted records) | 4 streamed, tile-local records |
     5 slice owner with run-merged dense levels | 6 streamed tile-local with run-merged coarse levels"""
     m = enc.native_tcnn_module
-    m.set_option("grid_bwd_runs", int(bwd_mode >= 5))
-    m.set_option("grid_bwd_mode", {5: 1, 6: 3}.get(bwd_mode, min(bwd_mode, 3)))
+    m.set_option("grid_bwd_runs", int(bwd_mode in (5, 6, 7)))
+    m.set_option("grid_bwd_mode", {5: 1, 6: 3, 7: 3}.get(bwd_mode, min(bwd_mode, 3)))
     if bwd_mode >= 3 and bwd_mode != 5:
-        m.set_option("grid_stream_layout", int(bwd_mode in (4, 6)))
+        m.set_option("grid_stream_layout", int(bwd_mode in (4, 6, 7)))
+        # 7: tile-local records accumulated as two 32-bit fixed-point sums per 64-bit word, 8192-entry bins (round 3)
+        m.set_option("grid_stream_acc_bits", 32 if bwd_mode == 7 else 64)
 
 
-BWD_MODES = [0, 1, 2, 3, 4, 5, 6]
-BWD_MODE_IDS = ["atomic", "lds", "binned", "streamed", "streamed-tile-local", "lds-runs", "streamed-tile-local-runs"]
+BWD_MODES = [0, 1, 2, 3, 4, 5, 6, 7]
+BWD_MODE_IDS = ["atomic", "lds", "binned", "streamed", "streamed-tile-local", "lds-runs", "streamed-tile-local-runs",
+                "streamed-tile-local-packed32"]
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
@@ -265,13 +268,21 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
     grads = []
-    for mode in (0, 1, 2, 3, 4, 5, 6):
+    for mode in (0, 1, 2, 3, 4, 5, 6, 7):
         _set_bwd_mode(enc, mode)
         enc.params.grad = None
         y = enc(x)
         (y.float() * dy).sum().backward()
         grads.append(enc.params.grad.clone())
     torch.cuda.synchronize()
+    # packed 32-bit fixed-point accumulators (one 64-bit LDS atomic per record, scale 2^29 / L1 of the bin): each add
+    # rounds to L1(bin) / 2^29 -- finer than the 16-17 mantissa bits the records carry -- and the sums are integers
+    _assert_close(grads[7], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed (tile-local, packed 32-bit) vs atomic")
+    _set_bwd_mode(enc, 7)
+    enc.params.grad = None
+    (enc(x).float() * dy).sum().backward()
+    hashed7 = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
+    assert torch.equal(enc.params.grad[hashed7:], grads[7][hashed7:]), "packed form is not bitwise reproducible"
     # run-merged coarse levels (uniform random points are the worst case: no two consecutive samples share a cell)
     _assert_close(grads[5], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds + run-merged dense levels vs atomic dL/dparams")
     _assert_close(grads[6], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed + run-merged coarse levels vs atomic")

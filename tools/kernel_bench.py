@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--layouts", type=int, nargs="+", default=[0, 1], help="mode 3: record layout (0 sorted, 1 tile-local)")
     ap.add_argument("--acc-bits", type=int, default=64, help="accumulators of the slice-owner items (32 | 64)")
     ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
+    ap.add_argument("--stream-acc-bits", type=int, nargs="+", default=[64],
+                    help="mode 3, tile-local layout: accumulators of the record pass (64 | 32 = packed, 8192-entry bins)")
+    ap.add_argument("--runs", type=int, default=1, help="run-merging scan of the slice-owner items (grid_bwd_runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.lib()
@@ -53,16 +56,20 @@ def main():
         variants = []
         for mode in args.modes:
             if mode == 3:
-                variants += [(3, t, int(m, 0), lay) for t in args.tiles for m in args.masks for lay in args.layouts]
+                variants += [(3, t, int(m, 0), lay, ab) for t in args.tiles for m in args.masks for lay in args.layouts
+                             for ab in (args.stream_acc_bits if lay == 1 else [64])]
             else:
-                variants.append((mode, 0, 0xFFFFFFFF, 0))
+                variants.append((mode, 0, 0xFFFFFFFF, 0, 64))
         enc.native_tcnn_module.set_option("grid_acc_bits", args.acc_bits)
-        for mode, tile, mask, layout in variants:
+        enc.native_tcnn_module.set_option("grid_bwd_runs", args.runs)
+        enc.native_tcnn_module.set_option("grid_bwd_batch", n)
+        for mode, tile, mask, layout, sab in variants:
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
             if mode == 3:
                 enc.native_tcnn_module.set_option("grid_stream_tile", tile)
                 enc.native_tcnn_module.set_option("grid_stream_owner_slices", mask)
                 enc.native_tcnn_module.set_option("grid_stream_layout", layout)
+                enc.native_tcnn_module.set_option("grid_stream_acc_bits", sab)
             for it in range(args.iters + 3):
                 if it == 3:
                     torch.cuda.synchronize()
@@ -79,7 +86,7 @@ def main():
                 name, cnt, total = line.rsplit(",", 2)
                 if name.startswith("grid_fwd"):
                     continue
-                tag = f"mode={mode}" + (f" tile={tile} owner<={mask} layout={layout}" if mode == 3 else "")
+                tag = f"mode={mode}" + (f" tile={tile} owner<={mask} layout={layout} acc={sab}" if mode == 3 else "")
                 print(f"{label:14s} N={n:8d} {tag:32s} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
 
 
