@@ -330,6 +330,8 @@ typedef struct nvo_main_loss_args {
     int act_bf16;                /* 0: pre / rgb / dpre / drgb are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
     const float* loss_scale_dev; /* nullable: device float that REPLACES loss_scale (dynamic loss scaling: the
                                     GradScaler state lives on the device so that a captured step stays valid) */
+    uint32_t* nonfinite_flag;    /* nullable: OR-ed with 1 when a gradient stored to dpre / drgb overflows the 16-bit
+                                    format (inf / NaN / > 65504 in fp16): the overflow check at its source */
 } nvo_main_loss_args;
 int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
 
@@ -352,6 +354,7 @@ typedef struct nvo_prop_loss_args {
     uint32_t dpre_stride;
     int act_bf16;                /* 0: pre / dpre are fp16 (default), 1: bfloat16 (bf16 MLP mode) */
     const float* loss_scale_dev; /* nullable: device float that REPLACES loss_scale */
+    uint32_t* nonfinite_flag;    /* nullable: as in nvo_main_loss_args */
 } nvo_prop_loss_args;
 int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args);
 
@@ -385,6 +388,8 @@ typedef struct nvo_color_args {
     void* det_scratch;           /* nvo_color_det_scratch_bytes(R, S) */
     uint64_t det_scratch_bytes;
     uint32_t n_cameras;          /* rows of d_embedding (deterministic mode only) */
+    uint32_t* nonfinite_flag;    /* (backward; nullable) device word OR-ed with 1 when a 16-bit gradient the launch stores
+                                    overflows its format -- GradScaler's found_inf raised by the producer */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);

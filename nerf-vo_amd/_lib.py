@@ -41,7 +41,7 @@ class MainLossArgs(C.Structure):
                 ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
                 ("drgb", _p), ("drgb_stride", _u32),
                 ("dsigma_dx", _p), ("dsigma_inv_scale", _f), ("gt_normal", _p), ("normal_mult", _f),
-                ("out_normals", _p), ("act_bf16", _int), ("loss_scale_dev", _p)]
+                ("out_normals", _p), ("act_bf16", _int), ("loss_scale_dev", _p), ("nonfinite_flag", _p)]
 
 
 class PropLossArgs(C.Structure):
@@ -50,7 +50,8 @@ class PropLossArgs(C.Structure):
                 ("sbins", _p), ("tbins", _p), ("sbins_main", _p), ("weights_main", _p), ("density_bias", _f),
                 ("gt_depth", _p), ("directions_norm", _p), ("interlevel_mult", _f), ("depth_mult", _f),
                 ("depth_sigma", _f), ("inv_rays", _f), ("depth_level_div", _f), ("loss_scale", _f),
-                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32), ("act_bf16", _int), ("loss_scale_dev", _p)]
+                ("losses", _p), ("dpre", _p), ("dpre_stride", _u32), ("act_bf16", _int), ("loss_scale_dev", _p),
+                ("nonfinite_flag", _p)]
 
 
 class ColorArgs(C.Structure):
@@ -58,7 +59,7 @@ class ColorArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int), ("det_scratch", _p),
-                ("det_scratch_bytes", _u64), ("n_cameras", _u32)]
+                ("det_scratch_bytes", _u64), ("n_cameras", _u32), ("nonfinite_flag", _p)]
 
 
 class RayHeadArgs(C.Structure):

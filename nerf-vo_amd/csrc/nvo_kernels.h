@@ -202,6 +202,10 @@ struct NvoMlpArgsT {
     // tile_partial[tile][48] = {embedding 32 | d_sh 16} instead of float atomics (nvo_color_tile_reduce sums them)
     float* dw_partial;
     float* tile_partial;
+    // (backward; nullable) device word OR-ed with 1 when a gradient this launch STORES IN 16 BITS does not survive the
+    // format (inf / NaN, or beyond 65504 in fp16) -- the optimiser's overflow check at the producer instead of a scan
+    // of the whole gradient buffer afterwards (every fp32 accumulation downstream of finite 16-bit values is finite)
+    uint32_t* nonfinite_flag;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

@@ -93,12 +93,15 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const nvo_h16*
 
 // dL/dw (in LDS array g[], overwritten) -> dL/dpre, written as fp16 * loss_scale
 // dL/dsigma_k = delta_k [ g_k (T_k - w_k) - sum_{i>k} g_i w_i ],  dsigma/dpre = exp(clamp(pre+bias,-15,15))
-__device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const nvo_h16* __restrict__ pre, bool bf,
+// returns (per lane): a gradient of this ray does not survive the 16-bit format it is stored in
+__device__ __forceinline__ bool ray_weights_bwd(int lane, uint32_t S, const nvo_h16* __restrict__ pre, bool bf,
                                                 uint32_t pre_stride, const float* __restrict__ x01,
                                                 const float* __restrict__ tb, float bias,
                                                 const float* w, const float* Tr, const float* g,
                                                 float loss_scale, nvo_h16* __restrict__ dpre,
                                                 uint32_t dpre_stride, bool zero_row = false) {
+    bool overflow = false;
+    const float fmt_max = bf ? 3.0e38f : 65504.0f;
     // total of g_i w_i, then inclusive prefix per chunk -> suffix (exclusive) = total - incl
     float total = 0.f;
     for (uint32_t base = 0; base < S; base += 64) {
@@ -120,6 +123,7 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const nvo_
                 const float dsig = delta * (g[i] * (Tr[i] - w[i]) - (total - incl));
                 d = dsig * __expf(fminf(fmaxf(x, -15.f), 15.f));
             }
+            overflow = overflow || !(fabsf(d * loss_scale) <= fmt_max);
             if (zero_row && dpre_stride == 16) {
                 // whole 32-byte row {d, 0 x 15} as two 16-byte stores (the MLP backward reads all 16 columns)
                 uint4 lo = make_uint4(0u, 0u, 0u, 0u);
@@ -133,6 +137,7 @@ __device__ __forceinline__ void ray_weights_bwd(int lane, uint32_t S, const nvo_
         }
         carry = nvo_wave_bcast(incl, 63);
     }
+    return overflow;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,8 +412,14 @@ k_main_render_loss(nvo_main_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+    bool overflow = ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+    if (act) {
+        const float fmt_max = bf ? 3.0e38f : 65504.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) overflow = overflow || !(fabsf(dc[k] * a.loss_scale) <= fmt_max);
+    }
+    if (a.nonfinite_flag && __ballot(overflow) != 0ull && lane == 0) atomicOr(a.nonfinite_flag, 1u);
     if (act && a.drgb_stride == 16) {
         // the colour MLP backward reads all 16 columns: one 32-byte row {dr, dg, db, 0 x 13} as two 16-byte stores
         uint4 lo = make_uint4(0u, 0u, 0u, 0u);
@@ -528,8 +539,9 @@ k_prop_loss(nvo_prop_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride, true);
+    const bool overflow = ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
+                                          (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride, true);
+    if (a.nonfinite_flag && __ballot(overflow) != 0ull && lane == 0) atomicOr(a.nonfinite_flag, 1u);
     if (a.dpre_stride != 16) {
         for (uint32_t i = lane; i < S; i += 64) {
             nvo_h16* dp = (nvo_h16*)a.dpre + (so + i) * a.dpre_stride;

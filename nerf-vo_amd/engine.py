@@ -106,6 +106,10 @@ class EngineConfig:
     overlap_proposal_backward: bool = True
     proposal_backward_streams: int = 1    # 2 = one side stream per proposal network (measured: see DESIGN.md section 5.0)
     proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
+    # record pass of the main grid's streamed levels (grid_bwd_mode 3): 32 = ONE 64-bit LDS atomic per record on two
+    # packed 32-bit fixed-point sums, 8192-entry bins, overflow-proof scale from the scatter's per-(tile, bin) L1 bounds
+    # (k_tl_scatter_p / k_tl_accumulate_p: accumulate 83 -> 69 us on the kernel bench); 64 = two 64-bit sums per entry
+    main_grid_stream_acc_bits: int = 32
     # dense levels of (main, proposal 0, proposal 1): run-merging scan in the slice-owner items (option grid_bwd_runs)
     grid_bwd_runs: tuple = (True, True, True)
     # Main grid: the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients) whenever positions
@@ -153,6 +157,12 @@ class EngineConfig:
     # everywhere, no live-sample list).  Two runs from the same state then produce bit-identical parameters; only the
     # REPORTED loss values (64 float-atomic shards) may differ in their last bits.
     deterministic: bool = False
+    # GradScaler's found_inf raised AT THE SOURCE (single GPU): the kernels that store a gradient in 16 bits (render /
+    # loss kernels, every fused-MLP backward) OR a flag word of their parameter group when a value does not survive the
+    # format; every fp32 accumulation downstream of finite 16-bit values is finite, so the optimiser no longer re-reads
+    # the 55 MB gradient buffer to look for inf / NaN (nonfinite_flag: 13-17 us per step).  With a process group the
+    # check stays behind the reduction (another rank may have overflowed); the pose group (1152 scalars) is scanned.
+    producer_overflow_flags: bool = True
     log_every: int = 10                   # LoggingConfig.steps_per_log of the trainer mirror
     seed: int = 1337
 
@@ -203,6 +213,7 @@ class NerfactoEngine:
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
             m.set_option("deterministic", int(bool(cfg.deterministic)))
+        self.base_net.set_option("grid_stream_acc_bits", int(cfg.main_grid_stream_acc_bits))
         batches = (cfg.num_nerf_samples, *cfg.num_proposal_samples)
         for m, runs, per_ray in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs, batches):
             m.set_option("grid_bwd_runs", int(bool(runs)))
@@ -219,6 +230,7 @@ class NerfactoEngine:
             store = bool(cfg.optimize_poses or cfg.expect_normals)
         self.base_net.set_option("prepare_input_gradients", int(bool(store)))
         self._zero_plan = None  # built lazily (needs the flat gradient buffer): _step_zero_ranges()
+        self._producer_flags = False  # set per call: the producers raise the groups' overflow flags (single GPU)
         color_in = 16 + cfg.geo_feat_dim + cfg.appearance_embed_dim
         assert color_in == 63 and cfg.hidden_dim == 64, "colour head kernel is specialised to 63 -> 64 -> 64 -> 3"
         self.n_color = 64 * 64 + 64 * 64 + 16 * 64
@@ -403,6 +415,22 @@ class NerfactoEngine:
     def _loss_scale_ptr(self):
         return self.dev_loss_scale.data_ptr() if self.cfg.dynamic_loss_scale else None
 
+    def _flag_ptr(self, group: str):
+        """Overflow flag word of a parameter group (what the producers raise), or None when the optimiser scans."""
+        if not self._producer_flags:
+            return None
+        return self.skip_flag.data_ptr() + 4 * self._GROUP_ORDER.index(group)
+
+    def _use_producer_flags(self, on: bool) -> None:
+        on = bool(on and self.cfg.producer_overflow_flags)
+        if on == self._producer_flags and getattr(self, "_producer_flags_set", False):
+            return
+        self._producer_flags = on
+        self._producer_flags_set = True
+        self.base_net.set_option("nonfinite_flag_ptr", self._flag_ptr("fields") or 0)
+        for m in self.prop_nets:
+            m.set_option("nonfinite_flag_ptr", self._flag_ptr("proposal_networks") or 0)
+
     # ------------------------------------------------------------------------------------------
     # scratch
     # ------------------------------------------------------------------------------------------
@@ -562,7 +590,7 @@ class NerfactoEngine:
             act_bf16=int(self.bf16),
             det_scratch=ws["color_det"].data_ptr() if (training and "color_det" in ws) else None,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
-            n_cameras=self.cfg.num_images)
+            n_cameras=self.cfg.num_images, nonfinite_flag=self._flag_ptr("fields") if training else None)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -589,7 +617,8 @@ class NerfactoEngine:
             gt_normal=ws["gt_normal"].data_ptr() if (normals and training and has_gt_normal) else None,
             normal_mult=cfg.normal_loss_mult if (normals and has_gt_normal) else 0.0,
             out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16),
-            loss_scale_dev=self._loss_scale_ptr() if training else None)
+            loss_scale_dev=self._loss_scale_ptr() if training else None,
+            nonfinite_flag=self._flag_ptr("fields") if training else None)
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -661,6 +690,7 @@ class NerfactoEngine:
         cfg = self.cfg
         stream = _stream(self.device)
         step = self.step
+        self._use_producer_flags(self.world_size == 1 and getattr(self, "_reducer", None) is None)
         if anneal is None:
             anneal = self.anneal_at(step)
         if update_proposals is None:
@@ -799,7 +829,8 @@ class NerfactoEngine:
                 depth_mult=cfg.depth_loss_mult if has_depth else 0.0, depth_sigma=cfg.depth_sigma,
                 inv_rays=inv_rays, depth_level_div=1.0 / len(self.levels), loss_scale=cfg.loss_scale,
                 losses=self.losses.data_ptr() + 3 * 4, dpre=None if values_only else ws[f"dout{k}"].data_ptr(),
-                dpre_stride=1, act_bf16=int(self.bf16), loss_scale_dev=self._loss_scale_ptr())
+                dpre_stride=1, act_bf16=int(self.bf16), loss_scale_dev=self._loss_scale_ptr(),
+                nonfinite_flag=None if values_only else self._flag_ptr("proposal_networks"))
             _call("nvo_prop_loss", stream, C.byref(pa))
             if values_only:
                 continue
@@ -876,7 +907,15 @@ class NerfactoEngine:
                 lo, hi = lo + rank * per, lo + (rank + 1) * per
             return lo, hi
 
-        if check:
+        if check and self._producer_flags:
+            # the producers raised the flags of the fields / proposal groups; the pose gradient (fp32 all the way from the
+            # same 16-bit values, 1152 scalars) is scanned -- it must also stop when EITHER of the others overflowed
+            if "camera_opt" in active:
+                lo, hi = self.group_ranges["camera_opt"]
+                offs = (C.c_uint64 * len(order))(*[lo if g == "camera_opt" else 0 for g in order])
+                sizes = (C.c_uint64 * len(order))(*[hi - lo if g == "camera_opt" else 0 for g in order])
+                _call("nvo_nonfinite_flag_ranges_or", stream, len(order), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+        elif check:
             # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
             # hold stale values and are neither checked nor applied), all in one launch; flag word = the group's slot
             offs = (C.c_uint64 * len(order))(*[span(g)[0] if g in active else 0 for g in order])
@@ -1260,6 +1299,7 @@ class NerfactoEngine:
         """One full iteration.  ``all_reduce``: optional callable(flat_grad_tensor) for multi-GPU."""
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
+        self._reducer = all_reduce
         if jitters is None:
             jitters = tuple(torch.rand(R, device=self.device) for _ in range(3))
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths, normals=normals)

@@ -103,6 +103,7 @@ class NgpEngine:
         # streamed binned scatter for the 2^19 hashed levels (as the nerfacto main field: 650 -> ~250 us at 2^18
         # samples); with extrinsics optimisation the forward stores d(encoded)/d(position) for a streamed input backward
         self.density_net.set_option("grid_bwd_mode", 3)
+        self.density_net.set_option("grid_stream_acc_bits", 32)  # packed 2 x 32-bit fixed-point record accumulate
         self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
         self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
         self.n_density_mlp = 64 * 32 + 16 * 64

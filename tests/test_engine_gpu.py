@@ -704,6 +704,45 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     _assert_close(g_det, g_def, rtol=1e-3, atol_scale=1e-5, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
+@pytest.mark.parametrize("scale,expect", [(128.0, False), (3.0e7, True)], ids=["in-range", "overflow"])
+def test_producer_overflow_flags_match_the_scan(device, scale, expect):
+    """GradScaler's found_inf raised at the source (EngineConfig.producer_overflow_flags): the kernels that store a
+    gradient in 16 bits flag their parameter group, the optimiser does not re-read the gradient buffer.  With a loss
+    scale that pushes dL/d(rgb) beyond fp16 the flags of a producer-flag step must equal those of the scanning step,
+    the skipped groups must not move and their step counters must not advance; in range nothing is flagged and both
+    steps apply the same update."""
+    res = {}
+    for producer in (True, False):
+        eng = _make_engine(device, loss_scale=scale, producer_overflow_flags=producer)
+        R = 256
+        origins, directions, dnorm, cam, jit, gt_rgb, gt_depth = _rays(R, 7)
+        ws = eng._workspace(R, True)
+        eng.load_ray_bundle(ws, origins.to(device), directions.to(device), dnorm.to(device), cam.to(device),
+                            gt_rgb.to(device), gt_depth.to(device))
+        p0 = eng.params.clone()
+        eng.forward_backward(ws, tuple(j.to(device) for j in jit), has_depth=True, update_proposals=True, anneal=0.6)
+        assert eng._producer_flags == producer
+        eng.optimizer_step(["fields", "proposal_networks"], flags_cleared=True)
+        torch.cuda.synchronize()
+        res[producer] = (eng.skip_flag.tolist(), eng.opt_steps, (eng.params - p0).abs().max().item(), p0, eng.params.clone(),
+                         bool(torch.isfinite(eng.grads[:eng.group_ranges["proposal_networks"][1]]).all()))
+    flags_p, steps_p, moved_p, p0, params_p, _ = res[True]
+    flags_s, steps_s, moved_s, _, params_s, grads_finite = res[False]
+    assert [bool(f) for f in flags_p[:2]] == [bool(f) for f in flags_s[:2]], (flags_p, flags_s)
+    assert bool(flags_s[0]) == expect and grads_finite == (not expect)
+    assert steps_p == steps_s
+    assert bool(torch.isfinite(params_p).all()) and bool(torch.isfinite(params_s).all())
+    if expect:
+        lo, hi = 0, res[True][3].numel()
+        f_lo, f_hi = 0, 0
+        assert steps_p["fields"] == 0 and moved_p >= 0.0
+        assert torch.equal(params_p[:1000], p0[:1000]), "a skipped group moved"
+    else:
+        assert steps_p["fields"] == 1 and moved_p > 0.0
+        rel = float((params_p - params_s).abs().sum() / (params_s - p0).abs().sum())
+        assert rel < 1e-3, rel
+
+
 def test_native_scratch_survives_larger_batches_between_replays(device):
     """Graph-capture safety of the NATIVE scratch (record stream of the streamed grid backward, live-sample list,
     per-level partials of the input backward): captured graphs address those blocks by pointer, and a larger batch

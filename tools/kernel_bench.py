@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
     ap.add_argument("--stream-acc-bits", type=int, nargs="+", default=[64],
                     help="mode 3, tile-local layout: accumulators of the record pass (64 | 32 = packed, 8192-entry bins)")
+    ap.add_argument("--show-fwd", action="store_true", help="also print the forward gather's time")
     ap.add_argument("--runs", type=int, default=1, help="run-merging scan of the slice-owner items (grid_bwd_runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -84,7 +85,7 @@ def main():
             lib.nvo_profile_enable(0)
             for line in buf.value.decode().strip().splitlines():
                 name, cnt, total = line.rsplit(",", 2)
-                if name.startswith("grid_fwd"):
+                if name.startswith("grid_fwd") and not args.show_fwd:
                     continue
                 tag = f"mode={mode}" + (f" tile={tile} owner<={mask} layout={layout} acc={sab}" if mode == 3 else "")
                 print(f"{label:14s} N={n:8d} {tag:32s} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
