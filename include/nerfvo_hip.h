@@ -75,7 +75,9 @@ uint64_t nvo_n_params(nvo_module_t m);
 int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out);
 /* Bytes of caller-owned device scratch ("ctx") that one fwd/bwd pair of this batch size needs. */
 uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
-/* Integer options (tuning knobs: none changes results beyond summation order).
+/* Integer options (tuning knobs: none changes results beyond summation order / the rounding of fixed-point
+ * accumulators; which forms are bitwise reproducible run to run is said per option -- "deterministic" makes all of
+ * them so).
  *   "grid_bwd_mode"   parameter-gradient kernel of a hash-grid encoding:
  *                       0 = global float atomics, 1 = LDS slice-owner scatter (module default),
  *                       2 = binned scatter for hashed levels with gathers (count / scan / scatter / accumulate),
@@ -92,7 +94,22 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *   "bf16"                      16-bit format of everything the network streams: 0 = fp16 (default), 1 = bfloat16
  *   "compact_output"            (networks with one output) only column 0 exists in memory: [batch] instead of [batch][16]
  *   "recompute_hidden"          the backward recomputes the hidden activations instead of reading stored ones
- *   "grid_compact_live"         (mode 1) the slice-owner items scan a list of the samples whose dL/dy is non-zero
+ *   "grid_compact_live"         (mode 1) the slice-owner items scan a list of the samples whose dL/dy is non-zero.  The
+ *                               list is appended per workgroup in dispatch order: with "grid_bwd_runs" the fp32 sums of
+ *                               a lane's 8 list-consecutive samples then depend on that order, so results are NOT
+ *                               bitwise reproducible (without it only the chunk a sample falls in changes, which
+ *                               integer accumulation does not see); "deterministic" switches the list off
+ *   "grid_stream_acc_bits"      (mode 3, tile-local layout) accumulators of the record pass: 64 = two 64-bit fixed-point
+ *                               sums per entry, 4096-entry bins; 32 = two 32-bit fixed-point sums in ONE 64-bit word
+ *                               (one LDS atomic per record), 8192-entry bins, scale 2^29 / L1(bin) from bounds the
+ *                               scatter delivers with its rank atomics; both bitwise reproducible on hashed levels
+ *   "deterministic"             bitwise reproducible gradients: every slice / bin has ONE owner work item (no sample
+ *                               chunks meeting in float atomics), integer accumulators on every level, no live list;
+ *                               networks sum their weight gradient over the workgroups in a fixed order.  Several
+ *                               times slower; a debugging aid (EngineConfig.deterministic)
+ *   "nonfinite_flag_ptr"        (hash-grid modes 1 and 3 / tile-local) device address of a uint32 the parameter backward
+ *                               ORs with 1 when it meets a non-finite dL/dy (0 = off): GradScaler's found_inf raised
+ *                               where the 16-bit gradient chain ends, instead of a scan of the gradient buffer
  *   "grid_bwd_runs"             (modes 1 and 3) slice-owner items of DENSE levels scan with run merging: a lane takes 8
  *                               consecutive samples and goes to the LDS accumulators once per run of samples that
  *                               share a cell (consecutive samples are neighbours on a ray); off = per-sample scan
@@ -388,8 +405,6 @@ typedef struct nvo_color_args {
     void* det_scratch;           /* nvo_color_det_scratch_bytes(R, S) */
     uint64_t det_scratch_bytes;
     uint32_t n_cameras;          /* rows of d_embedding (deterministic mode only) */
-    uint32_t* nonfinite_flag;    /* (backward; nullable) device word OR-ed with 1 when a 16-bit gradient the launch stores
-                                    overflows its format -- GradScaler's found_inf raised by the producer */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
@@ -563,6 +578,10 @@ int nvo_zero_ranges(nvo_stream_t stream, uint32_t n_ranges, void* const* ptrs, c
  * optional fp16 copy (ema_half) is what inference reads.  skip_flag as in nvo_adam_step. */
 int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
                    uint32_t step, const uint32_t* skip_flag);
+/* The same with the step count on the device: *step_dev = averages applied so far; the call uses t = *step_dev + 1 and
+ * advances the counter iff the step was not skipped (the debias factor never runs ahead of the average). */
+int nvo_ema_update_dev(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                       uint32_t* step_dev, const uint32_t* skip_flag);
 /* bf16 MLP mode (BASELINE configs[4]: "MFMA bf16 MLP + fp32 hash accumulate"): the 16-bit working copy of the flat
  * parameter buffer is bfloat16 inside up to 4 element ranges [bf16_lo[k], bf16_hi[k]) (the fused-MLP weights and the
  * appearance embedding; bounds multiples of 4) and fp16 elsewhere (the hash tables).  Host arrays.

@@ -317,6 +317,32 @@ k_ema_update(uint64_t n, const float* __restrict__ params, float* __restrict__ e
     }
 }
 
+// the same with the step count kept on the device: *step_dev = number of averages APPLIED so far; a skipped optimiser
+// step leaves both the average and the counter alone (k_ema_commit), so the debias factor 1 / (1 - decay^t) never runs
+// ahead of the average it normalises
+__global__ void __launch_bounds__(256)
+k_ema_update_dev(uint64_t n, const float* __restrict__ params, float* __restrict__ ema, _Float16* __restrict__ ema_half,
+                 float decay, const uint32_t* __restrict__ step_dev, const uint32_t* __restrict__ skip_flag) {
+    if (skip_flag && skip_flag[0] != 0u) return;
+    __shared__ float fac[2];
+    if (threadIdx.x == 0) {
+        const double d = (double)decay, t = (double)(*step_dev) + 1.0;
+        fac[0] = (float)(d * (1.0 - pow(d, t - 1.0)));
+        fac[1] = (float)(1.0 / (1.0 - pow(d, t)));
+    }
+    __syncthreads();
+    const float keep = fac[0], inv_debias = fac[1], take = 1.0f - decay;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float e = (ema[i] * keep + params[i] * take) * inv_debias;
+        ema[i] = e;
+        if (ema_half) ema_half[i] = (_Float16)e;
+    }
+}
+__global__ void k_ema_commit(uint32_t* __restrict__ step_dev, const uint32_t* __restrict__ skip_flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip_flag && skip_flag[0] != 0u)) *step_dev += 1u;
+}
+
 __global__ void __launch_bounds__(256)
 k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -802,6 +828,21 @@ int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* 
     if (blocks > 2048) blocks = 2048;
     NVO_LAUNCH(k_ema_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params, ema, (_Float16*)ema_half, keep,
                1.0f - decay, inv_debias, skip_flag);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ema_update_dev(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                       uint32_t* step_dev, const uint32_t* skip_flag) {
+    NVO_REQUIRE(params && ema && step_dev, "ema_update_dev: NULL argument");
+    NVO_REQUIRE(decay >= 0.f && decay < 1.f, "ema_update_dev: 0 <= decay < 1");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "ema_update");
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_ema_update_dev, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params, ema, (_Float16*)ema_half, decay,
+               (const uint32_t*)step_dev, skip_flag);
+    NVO_LAUNCH(k_ema_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, skip_flag);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

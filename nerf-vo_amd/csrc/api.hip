@@ -451,6 +451,10 @@ struct GridModule : nvo_module_s {
             return NVO_OK;
         }
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        if (!strcmp(key, "nonfinite_flag_ptr")) {  // device address of the overflow flag the backward raises (0 = none)
+            slices.nf_flag = stream_bins.owner.nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value);
+            return NVO_OK;
+        }
         if (!strcmp(key, "deterministic")) {  // bitwise reproducible parameter gradient (see NvoGridSlices::deterministic)
             nvo_grid_slices_destroy(&slices);
             nvo_grid_stream_destroy(&stream_bins);
@@ -562,13 +566,8 @@ struct MlpModule : nvo_module_s {
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "external_zero")) { external_zero = value != 0; return NVO_OK; }
         if (!strcmp(key, "deterministic")) { deterministic = value != 0; return NVO_OK; }
-        if (!strcmp(key, "nonfinite_flag_ptr")) {  // device address of the overflow flag word the backward raises (0 = none)
-            nonfinite_flag = reinterpret_cast<uint32_t*>((uintptr_t)value);
-            return NVO_OK;
-        }
         return nvo_module_s::set_option(key, value);
     }
-    uint32_t* nonfinite_flag = nullptr;
 
     static int create(uint32_t n_input_dims, uint32_t n_output_dims, const JsonObj& cfg,
                       std::unique_ptr<MlpModule>* out) {
@@ -643,7 +642,6 @@ struct MlpModule : nvo_module_s {
         if (dparams && !external_zero)
             if (int rc = nvo_zero_async(dparams, sizeof(float) * n_params, s)) return rc;
         if (int rc = det_partials(s, B, &a)) return rc;
-        a.nonfinite_flag = nonfinite_flag;
         return nvo_mlp_bwd_launch(in_pad, width, n_hidden, out_pad, a, s);
     }
     bool external_zero = false;
@@ -738,7 +736,6 @@ struct NwieModule : nvo_module_s {
         if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         if (int rc0 = net->det_partials(s, B, &a)) return rc0;
-        a.nonfinite_flag = net->nonfinite_flag;
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {
@@ -774,7 +771,7 @@ struct NwieModule : nvo_module_s {
             net->deterministic = value != 0;
             return enc->set_option(key, value);
         }
-        if (!strcmp(key, "nonfinite_flag_ptr")) return net->set_option(key, value);
+        if (!strcmp(key, "nonfinite_flag_ptr")) return enc->set_option(key, value);
         if (!strcmp(key, "external_zero")) {
             if (int rc = enc->set_external_zero(value != 0)) return rc;
             net->external_zero = value != 0;

@@ -466,7 +466,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               uint32_t chunk, uint32_t n_chunks, void* lds_raw,
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
                                               const uint32_t* __restrict__ live = nullptr, bool merge = false,
-                                              uint32_t slice_cap = ACC::kEntries) {
+                                              uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -692,7 +692,10 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     }
     // (no LDS to spare for a block-wide vote: one atomic per affected wave, after every plain store has retired)
     __syncthreads();
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) {
+        atomicAdd(gr, __builtin_nanf(""));
+        if (nf_flag) atomicOr(nf_flag, 1u);  // (the optimiser's overflow flag, raised at the source)
+    }
 }
 
 // L1 norm of dy per (level, feature) as 2^8 fixed point in u64 (deterministic: fixed per-thread order, integer
@@ -749,7 +752,7 @@ __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
                const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
-               const uint32_t* __restrict__ live) {
+               const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
@@ -757,7 +760,7 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     const uint32_t level = item.x & 0xFFu, cap = item.x >> 8;  // cap: entries per slice of this level
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag);
     } else if ((item.w >> 30) & 1u) {
         const float l1x = (float)l1[2 * level] * (1.f / 256.f), l1y = (float)l1[2 * level + 1] * (1.f / 256.f);
         AccScale sc;
@@ -766,17 +769,20 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
         grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge, cap);
+                                            merge, cap, nf_flag);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag);
     }
 }
 
 // List of the samples whose dL/dy is non-zero on any level (NvoGridSlices::compact_live): out[0] = count (zeroed by
 // the launcher), out[1 + k] = sample id.  Workgroup-aggregated append; the order of the workgroups is not
-// deterministic, which only moves samples between the chunks of an item (integer accumulation is order-free, chunked
-// items combine with float atomics either way).
+// deterministic.  For the per-sample scan that only moves samples between the chunks of an item (integer accumulation
+// is order-free, chunked items combine with float atomics either way); with the run-merging scan (grid_bwd_runs) a lane
+// sums 8 LIST-consecutive samples in fp32 before the conversion, so which samples share a run -- hence the rounding of
+// the run sums -- follows the append order: compact_live + runs is not bitwise reproducible run to run (the
+// deterministic mode therefore scans all samples).
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(1024)
 k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ out,
@@ -1506,7 +1512,8 @@ __device__ __forceinline__ TlItem tl_decode(uint4 h, uint32_t n_tiles) {
 
 __global__ void __launch_bounds__(kTlBlock)
 k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
-                const uint2* __restrict__ records, uint32_t n_tiles, uint32_t tile_records, float* __restrict__ grad) {
+                const uint2* __restrict__ records, uint32_t n_tiles, uint32_t tile_records, float* __restrict__ grad,
+                uint32_t* __restrict__ nf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1630,7 +1637,10 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
             }
         }
         __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
-        if (__ballot(bad) != 0ull && lane == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
+        if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
+            atomicAdd(gr, __builtin_nanf(""));
+            if (nf_flag) atomicOr(nf_flag, 1u);
+        }
         if (!has_next) break;
         it = it_next;
         cur = nxt;
@@ -1804,7 +1814,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
 __global__ void __launch_bounds__(kTlBlockP)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint2* __restrict__ records, uint32_t n_tiles,
-                  uint32_t tile_records, float* __restrict__ grad) {
+                  uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
@@ -1953,7 +1963,10 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             }
         }
         __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
-        if (__ballot(bad) != 0ull && lane == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
+        if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
+            atomicAdd(gr, __builtin_nanf(""));
+            if (nf_flag) atomicOr(nf_flag, 1u);
+        }
         if (!has_next) break;
         it = it_next;
         cur = nxt;
@@ -2550,7 +2563,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
                            st->d_bin_chunks, grad);                                                          \
             NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlock), \
                        lds_acc_tl, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, records_tl, \
-                       n_tiles, (uint32_t)tile_records, grad);                                               \
+                       n_tiles, (uint32_t)tile_records, grad, st->owner.nf_flag);                            \
         }                                                                                                    \
     } while (0)
 #define NVO_LAUNCH_TL_T(SOA_, T_)                                                 \
@@ -2587,7 +2600,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
                            st->d_bin_chunks, grad);                                                           \
             NVO_LAUNCH(k_tl_accumulate_p, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlockP), \
                        lds_acc_p, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1, records_tl, \
-                       n_tiles, (uint32_t)tile_records, grad);                                                \
+                       n_tiles, (uint32_t)tile_records, grad, st->owner.nf_flag);                             \
         }                                                                                                     \
     } while (0)
             if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
@@ -2733,7 +2746,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live); \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

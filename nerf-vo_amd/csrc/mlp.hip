@@ -141,7 +141,6 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
     a.d_sh = c.d_sh;
     a.dweights = c.d_weights;
     a.recompute_hidden = c.hidden == nullptr;  // no stored activations: both hidden layers are recomputed
-    a.nonfinite_flag = c.nonfinite_flag;
     if (c.det_scratch) {
         // deterministic mode: [dW block totals | per-tile embedding / SH sums | per-ray sums], all summed in fixed orders
         NVO_REQUIRE((c.S & 15u) == 0 && c.cam_idx && c.d_weights, "color_bwd: the deterministic form needs S %% 16 == 0, cam_idx, d_weights");

@@ -588,8 +588,6 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     const LdsTile<MAXW> tz{lds + (2 * wib) * kTileHalfs}, th{lds + (2 * wib + 1) * kTileHalfs};
 
     const bool need_dinput = a.dinput != nullptr;
-    bool nf = false;  // a 16-bit gradient of this wave overflowed its format (a.nonfinite_flag)
-    constexpr float kFmtMax = NVO_MLP_BF16 ? 3.0e38f : 65504.0f;
 
     // transposed weights for the dH chain (layer 0's only if dL/dinput is wanted)
     WTFrag<WIDTH, IN_PAD> wt0;
@@ -831,12 +829,6 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                     dz[t][j] = (T)(acc[t][j] * act_bwd_from_out(hidden_act, (float)hp_[t][j]));
         }
         NVO_PH(4);
-        if (a.nonfinite_flag) {  // the first layer's dZ as it is stored in 16 bits (feeds dW0 and dX)
-#pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nf = nf || !(fabsf((float)dz[t][j]) <= kFmtMax);
-        }
         // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
         {
             T4 x[IN_PAD / 16];
@@ -860,12 +852,6 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             f4 acc[IN_PAD / 16];
             layer_mm_t<WIDTH, IN_PAD>(wt0, dz, acc);
             NVO_PH(6);
-            if (a.nonfinite_flag && IO != NVO_IO_F32_ROWS) {  // dX leaves in 16 bits: what does not fit is an overflow
-#pragma unroll
-                for (int tk = 0; tk < IN_PAD / 16; ++tk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nf = nf || !(fabsf(acc[tk][j]) <= kFmtMax);
-            }
             if constexpr (IO == NVO_IO_F32_ROWS) {
                 float* __restrict__ p = (float*)a.dinput + (size_t)row * a.n_in;
 #pragma unroll
@@ -971,7 +957,6 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         cur = nxt;
         NVO_PH(8);
     }
-    if (a.nonfinite_flag && __ballot(nf) != 0ull && lane == 0) atomicOr(a.nonfinite_flag, 1u);
     // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
     if (a.dweights) {
         __syncthreads();  // every wave is done with its LDS tiles

@@ -44,6 +44,10 @@ struct NvoGridSlices {
     // accumulators on every level (LDS float atomics retire in no fixed order), no live-sample list (its append order
     // changes the run sums).  The gradient is then bitwise reproducible; the launch is several times slower.
     bool deterministic = false;
+    // (nullable) device word OR-ed with 1 when an item meets a non-finite dL/dy (it also poisons its slice's first
+    // gradient entry): the optimiser's overflow flag raised at the source -- the k_tl_accumulate passes of a stream
+    // layout use their owner's word
+    uint32_t* nf_flag = nullptr;
 };
 #include <utility>
 #include <vector>
@@ -202,10 +206,6 @@ struct NvoMlpArgsT {
     // tile_partial[tile][48] = {embedding 32 | d_sh 16} instead of float atomics (nvo_color_tile_reduce sums them)
     float* dw_partial;
     float* tile_partial;
-    // (backward; nullable) device word OR-ed with 1 when a gradient this launch STORES IN 16 BITS does not survive the
-    // format (inf / NaN, or beyond 65504 in fp16) -- the optimiser's overflow check at the producer instead of a scan
-    // of the whole gradient buffer afterwards (every fp32 accumulation downstream of finite 16-bit values is finite)
-    uint32_t* nonfinite_flag;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

@@ -157,11 +157,16 @@ class EngineConfig:
     # everywhere, no live-sample list).  Two runs from the same state then produce bit-identical parameters; only the
     # REPORTED loss values (64 float-atomic shards) may differ in their last bits.
     deterministic: bool = False
-    # GradScaler's found_inf raised AT THE SOURCE (single GPU): the kernels that store a gradient in 16 bits (render /
-    # loss kernels, every fused-MLP backward) OR a flag word of their parameter group when a value does not survive the
-    # format; every fp32 accumulation downstream of finite 16-bit values is finite, so the optimiser no longer re-reads
-    # the 55 MB gradient buffer to look for inf / NaN (nonfinite_flag: 13-17 us per step).  With a process group the
-    # check stays behind the reduction (another rank may have overflowed); the pose group (1152 scalars) is scanned.
+    # GradScaler's found_inf raised AT THE SOURCE (single GPU).  Every gradient of the step descends from the 16-bit
+    # dL/d(pre-activation) / dL/d(rgb) the loss kernels store, through 16-bit buffers (d_base_out, dL/d(encoded)) into
+    # fp32 accumulations; an fp32 sum of finite 16-bit products cannot overflow, so a non-finite gradient exists iff a
+    # 16-bit value on that chain is non-finite -- and a non-finite value propagates down the chain to its end, the
+    # hash-grid backward.  The loss kernels (the roots) and the grid backward (the leaves, which already had to detect
+    # it for their integer accumulators) OR the flag word of their parameter group; the optimiser no longer re-reads the
+    # 55 MB gradient buffer (nonfinite_flag: 13-17 us per step).  (Instrumenting the fused-MLP backward as well was
+    # measured: +4.5 / +4.6 / +1.7 us on its three launches -- as much as the scan saved -- and is not needed.)  With a
+    # process group the check stays behind the reduction (another rank may have overflowed); the pose group (1152
+    # scalars) is scanned.
     producer_overflow_flags: bool = True
     log_every: int = 10                   # LoggingConfig.steps_per_log of the trainer mirror
     seed: int = 1337
@@ -422,7 +427,9 @@ class NerfactoEngine:
         return self.skip_flag.data_ptr() + 4 * self._GROUP_ORDER.index(group)
 
     def _use_producer_flags(self, on: bool) -> None:
-        on = bool(on and self.cfg.producer_overflow_flags)
+        modes = self.cfg.grid_bwd_mode if isinstance(self.cfg.grid_bwd_mode, (tuple, list)) else (self.cfg.grid_bwd_mode,) * 3
+        # (the leaves of the gradient chain that raise the flag are the slice-owner / tile-local grid kernels)
+        on = bool(on and self.cfg.producer_overflow_flags and all(int(m) in (1, 3) for m in modes))
         if on == self._producer_flags and getattr(self, "_producer_flags_set", False):
             return
         self._producer_flags = on
@@ -435,13 +442,25 @@ class NerfactoEngine:
     # scratch
     # ------------------------------------------------------------------------------------------
     def _workspace(self, R: int, training: bool):
+        """Scratch of one ray count.  TRAINING workspaces are kept for good (captured graphs address them by pointer).
+        INFERENCE has ONE workspace, sized for the largest chunk seen so far: a smaller chunk (the remainder of an
+        image, another resolution) uses the first R rows of every buffer -- the kernels take R as an argument --
+        instead of a permanent 1-2 GB workspace per distinct chunk size."""
         key = (R, training)
         if key in self._ws:
             return self._ws[key]
+        if not training:
+            old = self._ws.get("inference")
+            if old is not None and old["R_cap"] >= R:
+                old["R"] = R
+                return old
+            if old is not None:  # grow: nothing captured ever addresses the inference scratch
+                del self._ws["inference"]
+                old.clear()
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         f16 = dict(dtype=self.act_dtype, device=dev)  # 16-bit activations / gradients (fp16 | bf16)
-        ws = {"key": key, "R": R}
+        ws = {"key": key, "R": R, "R_cap": R}
         ws["origins"] = torch.empty(R, 3, **f32)
         ws["directions"] = torch.empty(R, 3, **f32)
         ws["directions_norm"] = torch.empty(R, **f32)
@@ -487,7 +506,7 @@ class NerfactoEngine:
                 ws["color_det"] = torch.empty(int(_lib.lib().nvo_color_det_scratch_bytes(R, self.levels[-1])),
                                               dtype=torch.uint8, device=dev)
                 ws["pose_det"] = torch.empty(R, 12, **f32)
-        self._ws[key] = ws
+        self._ws[key if training else "inference"] = ws
         return ws
 
     # ------------------------------------------------------------------------------------------
@@ -511,8 +530,9 @@ class NerfactoEngine:
         km = len(self.prop_nets)
         N = ws["R"] * self.levels[km]
         if "dsigma_dx" not in ws:
-            ws["dsigma_dx"] = torch.empty(N, 3, dtype=torch.float32, device=self.device)
-            seed = torch.zeros(N, 16, dtype=self.act_dtype, device=self.device)
+            n_cap = ws["R_cap"] * self.levels[km]
+            ws["dsigma_dx"] = torch.empty(n_cap, 3, dtype=torch.float32, device=self.device)
+            seed = torch.zeros(n_cap, 16, dtype=self.act_dtype, device=self.device)
             seed[:, 0] = self.cfg.loss_scale
             ws["dsigma_seed"] = seed
         _call("nvo_bwd", self.base_net.handle, stream, N, _ptr(ws[f"x{km}"]),
@@ -590,7 +610,7 @@ class NerfactoEngine:
             act_bf16=int(self.bf16),
             det_scratch=ws["color_det"].data_ptr() if (training and "color_det" in ws) else None,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
-            n_cameras=self.cfg.num_images, nonfinite_flag=self._flag_ptr("fields") if training else None)
+            n_cameras=self.cfg.num_images)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -1345,9 +1365,9 @@ class NerfactoEngine:
         (nerfacto use_average_appearance_embedding=True)."""
         R = origins.shape[0]
         ws = self._workspace(R, False)
-        ws["origins"].copy_(origins)
-        ws["directions"].copy_(directions)
-        ws["directions_norm"].copy_(directions_norm.reshape(-1))
+        ws["origins"][:R].copy_(origins)
+        ws["directions"][:R].copy_(directions)
+        ws["directions_norm"][:R].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
         if mean_embedding_half is None:
             emb = self.view("field.embedding").view(self.cfg.num_images, -1)
@@ -1360,9 +1380,9 @@ class NerfactoEngine:
             self._analytic_normal_grads(ws, stream)
         la = self._main_loss_args(ws, False, False, normals=normals)
         _call("nvo_main_render_loss", stream, C.byref(la))
-        out = {"rgb": ws["out_rgb"].clamp(0.0, 1.0), "depth": ws["out_depth"].clone()[:, None],
-               "expected_depth": ws["out_expected_depth"].clone()[:, None],
-               "accumulation": ws["out_accumulation"].clone()[:, None]}
+        out = {"rgb": ws["out_rgb"][:R].clamp(0.0, 1.0), "depth": ws["out_depth"][:R].clone()[:, None],
+               "expected_depth": ws["out_expected_depth"][:R].clone()[:, None],
+               "accumulation": ws["out_accumulation"][:R].clone()[:, None]}
         if normals:
-            out["normals"] = ws["out_normals"].clone()
+            out["normals"] = ws["out_normals"][:R].clone()
         return out

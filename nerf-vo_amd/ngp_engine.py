@@ -116,7 +116,10 @@ class NgpEngine:
         # moving average of the weights (inference copy) -- allocated on first use
         self.params_ema = None
         self.params_ema_half = None
-        self.ema_step = 0
+        # number of averages applied, ON THE DEVICE: a step the overflow check skipped advances neither the average nor
+        # its debias factor (ema_step reads it back)
+        self._ema_step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ema_started = False
         self.rays_per_batch = int(cfg.num_rays)
         self._measured = []  # device scalars: marched samples of the steps since the last adaptation
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)
@@ -157,7 +160,17 @@ class NgpEngine:
     def inference_params_half(self) -> torch.Tensor:
         """The 16-bit weights inference reads: the moving average once it exists (tcnn: the optimiser's
         custom_weights()), the raw working copy otherwise."""
-        return self.params_ema_half if (self.params_ema_half is not None and self.ema_step > 0) else self.params_half
+        return self.params_ema_half if (self.params_ema_half is not None and self._ema_started) else self.params_half
+
+    @property
+    def ema_step(self) -> int:
+        """Averages applied so far (device counter; reading it synchronises)."""
+        return int(self._ema_step_dev.item())
+
+    @ema_step.setter
+    def ema_step(self, value: int) -> None:
+        self._ema_step_dev.fill_(int(value))
+        self._ema_started = int(value) > 0
 
     def _pp(self, name: str, buf: torch.Tensor):
         o, _ = self.segments[name]
@@ -223,6 +236,10 @@ class NgpEngine:
         network, EMA the optical thickness into the grid, rebuild bitfield + cascade max-pool.
         ``all_reduce`` (multi-GPU): the fresh estimates are MAX-reduced over the ranks before the update, so the
         density grid and bitfield stay identical everywhere (parallel.GradientAllReduce.reduce_max)."""
+        # (The density network is evaluated with the RAW training weights, not the EMA copy inference reads: upstream's
+        # update_density_grid_nerf calls m_nerf_network->density(..., use_inference_params = false) [UPSTREAM, unpinned --
+        # the submodule is not vendored].  Marching therefore follows the weights being trained, shading at inference
+        # the averaged ones, exactly as in the testbed.)
         cfg = self.cfg
         stream = _stream(self.device)
         lo, hi = cfg.aabb
@@ -366,9 +383,11 @@ class NgpEngine:
             if self.params_ema is None:
                 self.params_ema = torch.zeros_like(self.params)
                 self.params_ema_half = torch.zeros_like(self.params_half)
-            self.ema_step += 1
-            _call("nvo_ema_update", stream, self.n_params, _ptr(self.params), _ptr(self.params_ema),
-                  _ptr(self.params_ema_half), cfg.ema_decay, self.ema_step, _ptr(self.skip_flag))
+            # (Should the very first step be skipped, inference would read an all-zero average for one step: instant-ngp
+            # has the same window; the debias factor itself is exact -- it follows the device counter.)
+            self._ema_started = True
+            _call("nvo_ema_update_dev", stream, self.n_params, _ptr(self.params), _ptr(self.params_ema),
+                  _ptr(self.params_ema_half), cfg.ema_decay, _ptr(self._ema_step_dev), _ptr(self.skip_flag))
         if cfg.optimize_extrinsics and self._pose_inputs is not None:
             n6 = cfg.num_images * 6
             _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
