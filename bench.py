@@ -97,8 +97,9 @@ def pmc_traffic(name: str):
         for k in data.get("kernels", []):
             if k.get("bench_name") == name:
                 fetch = k.get("FETCH_SIZE_KB_corrected", k["FETCH_SIZE_KB_per_launch"])  # gfx950 streaming-read correction
-                return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path)
-    return None, None
+                raw = int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024)
+                return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path), raw
+    return None, None, None
 
 
 def main() -> None:
@@ -134,6 +135,10 @@ def main() -> None:
     ap.add_argument("--late-steps", type=int, default=100,
                     help="extra timed steps late in the proposal-update schedule (reported as late_schedule; 0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="proposal backward on the main stream instead of a side stream (profiling: every kernel alone)")
+    ap.add_argument("--no-kernel-table", action="store_true",
+                    help="skip the eager per-kernel HIP-event pass (rocprofv3 runs: only graph-replayed steps in the trace)")
     ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -206,6 +211,9 @@ def main() -> None:
                        mlp_dtype=args.mlp_dtype, expect_normals=use_normals)
     if args.proposal_streams is not None:
         cfg.proposal_backward_streams = args.proposal_streams
+    if args.no_overlap:
+        cfg.overlap_proposal_backward = False
+        cfg.overlap_pose_backward = False
     if args.grid_bwd_mode is not None:
         cfg.grid_bwd_mode = args.grid_bwd_mode[0] if len(args.grid_bwd_mode) == 1 else tuple(args.grid_bwd_mode)
     bwd_modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
@@ -275,8 +283,8 @@ def main() -> None:
     roofline = None
     kernel_table = []
     lib = _lib.lib()
-    prof_steps = min(args.steps, 50)
-    if rank == 0:
+    prof_steps = 0 if args.no_kernel_table else min(args.steps, 50)
+    if rank == 0 and prof_steps:
         lib.nvo_profile_enable(1)
     fence()
     tp0 = time.perf_counter()
@@ -308,8 +316,8 @@ def main() -> None:
     cfg.overlap_proposal_backward = overlap_saved
     cfg.overlap_pose_backward = overlap_pose_saved
     fence()
-    ms_prof = (time.perf_counter() - tp0) / prof_steps * 1e3
-    if rank == 0:
+    ms_prof = (time.perf_counter() - tp0) / max(prof_steps, 1) * 1e3
+    if rank == 0 and prof_steps:
         need = lib.nvo_profile_summary(None, 0)
         buf = C.create_string_buffer(int(need) + 16)
         lib.nvo_profile_summary(buf, len(buf))
@@ -330,10 +338,13 @@ def main() -> None:
                 continue
             avg_s = total / cnt * 1e-3
             achieved = b / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(name)
+            traffic, traffic_src, traffic_raw = pmc_traffic(name)
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src,
+                        # uncorrected counters (FETCH_SIZE under-reports coalesced streams on gfx950; the x2 correction of
+                        # the record pass is an estimate for its access pattern: the truth lies between the two)
+                        "traffic_raw": traffic_raw,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
                         "bytes_model": "SURVEY.md 8d per-unit bytes x units per launch (DESIGN.md section 3)",
                         "share_of_step_kernel_time": round(total / tot, 4)}

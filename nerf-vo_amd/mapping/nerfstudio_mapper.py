@@ -52,7 +52,12 @@ class Nerfstudio:
                 model=ExtendedNerfactoModelConfig(
                     interlevel_loss_mult=1.0, distortion_loss_mult=0.002, orientation_loss_mult=0,
                     pred_normal_loss_mult=0, depth_loss_mult=0.001, normal_loss_mult=0.000005, predict_normals=True,
-                    is_euclidean_depth=False, depth_sigma=0.001, should_decay_sigma=False)),
+                    is_euclidean_depth=False, depth_sigma=0.001, should_decay_sigma=False,
+                    # (not in the reference's argument set: optional switches of this build, off unless given)
+                    deterministic=bool(getattr(args, "deterministic", False)),
+                    dynamic_loss_scale=bool(getattr(args, "dynamic_loss_scale", False)),
+                    **({"camera_optimizer": CameraOptimizerConfig(mode=args.camera_optimizer_mode)}
+                       if getattr(args, "camera_optimizer_mode", None) else {}))),
             optimizers={
                 "proposal_networks": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None},
                 "fields": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None},

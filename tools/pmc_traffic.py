@@ -45,8 +45,11 @@ def main():
     # 16 B per lane; calibrated here for 8 B per lane too -- tools/probes/read_bw_probe under --pmc FETCH_SIZE reports
     # 70 688 KB for a 141 312 KB buffer at both widths, profiles/r2_pmc_probe_calibration.txt).  The kernels below read
     # nothing but such streams; every other kernel's reads (4-byte gathers, strided rows) are uncalibrated and stay raw.
-    STREAM_READERS = {"k_tl_accumulate", "k_st_accumulate", "k_adam_groups", "k_adam", "k_nonfinite_flag_ranges",
-                      "k_nonfinite_flag", "k_read"}
+    # (k_tl_accumulate / _p read ~256-512-byte record runs at arbitrary 8-byte offsets plus 4-byte segment words -- NOT
+    # the pattern the probe calibrated.  Their x2 figure is therefore an ESTIMATE; the raw value is reported beside it
+    # -- bench.py: roofline.traffic (estimate) and roofline.traffic_raw -- and the truth lies between the two.)
+    STREAM_READERS = {"k_tl_accumulate", "k_tl_accumulate_p", "k_st_accumulate", "k_adam_groups", "k_adam",
+                      "k_nonfinite_flag_ranges", "k_nonfinite_flag", "k_read"}
     for k in kernels:
         k["FETCH_SIZE_KB_corrected"] = round(k["FETCH_SIZE_KB_per_launch"] * (2.0 if k["kernel"] in STREAM_READERS else 1.0), 1)
     # bench rows: the streamed main-grid backward is several kernels per step (+ the slice-owner launch of its
@@ -73,11 +76,15 @@ def main():
                      "FETCH_SIZE_KB_per_launch": total(lds, "FETCH_SIZE_KB_per_launch", n),
                      "FETCH_SIZE_KB_corrected": total(lds, "FETCH_SIZE_KB_corrected", n),
                      "WRITE_SIZE_KB_per_launch": total(lds, "WRITE_SIZE_KB_per_launch", n)})
-    note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
+    commit = os.environ.get("NVO_COMMIT", "")
+    note = ((f"commit {commit}; " if commit else "") +
+            "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
             "`python3 bench.py --steps 20 --warmup 5 --psnr off --cpu-baseline off --late-steps 0`; raw counter unit KB; "
             "per launch = sum / launches.  FETCH_SIZE_KB_corrected = raw x 2 for the kernels whose reads are pure coalesced "
             "streams (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of such reads; calibrated with "
-            "tools/probes/read_bw_probe at 8 and 16 B per lane), raw for every other kernel (uncalibrated access widths).")
+            "tools/probes/read_bw_probe at 8 and 16 B per lane), raw for every other kernel (uncalibrated access widths); "
+            "for k_tl_accumulate(_p) -- record runs at 8-byte granularity, not the calibrated pattern -- the corrected "
+            "figure is an estimate, the raw one a lower bound.")
     json.dump({"note": note, "kernels": rows + kernels}, open(out_path, "w"), indent=1)
     for r in rows:
         print(r)
