@@ -702,9 +702,16 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
 // atomics between workgroups).  grid = (blocks, n_levels); half2 dy only.
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(256)
-k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long long* __restrict__ l1) {
+k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long long* __restrict__ l1, uint32_t level_mask) {
     __shared__ float red[2][4];
-    const uint32_t level = blockIdx.y;
+    // blockIdx.y counts the levels of level_mask (the levels that have slice-owner items: the stream form keeps only
+    // its coarse levels there, and the norms of the others would be read for nothing)
+    uint32_t level = 0;
+    for (uint32_t seen = 0, l = 0; l < g.n_levels; ++l)
+        if ((level_mask >> l) & 1u) {
+            if (seen == blockIdx.y) level = l;
+            ++seen;
+        }
     float a = 0.f, b = 0.f;
     if (SOA && (N & 3u) == 0u && (((uintptr_t)dy) & 15u) == 0u) {
         // level-major layout: a level's pairs are one contiguous stream -- 16-byte loads (4 samples), two in flight
@@ -2170,6 +2177,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     // table); pass 2: scale them so that the launch has enough (>= target) items to fill 256 CUs
     // for several rounds.
     if (const char* env = env_items ? getenv("NVO_GRID_BWD_ITEMS") : nullptr) target = (uint32_t)atoi(env);
+    s->level_mask = level_mask;
     auto base_chunks = [&](uint32_t count, uint32_t size) {
         const double share = (double)count / (double)size * (524288.0 / (double)kSliceFloat);
         uint32_t n = (uint32_t)(share + 0.5);
@@ -2474,6 +2482,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     // 8000-entry slices: 125 KiB of LDS, which leaves room for a 512-sample scatter workgroup (32.5 KiB) on the same CU
     st->owner.fixed_cap = st->overlap ? 8000u : 0u;
     if (const char* e = getenv("NVO_GRID_OWNER_CAP")) st->owner.fixed_cap = (uint32_t)atoi(e);  // measurements
+    if (const char* e = getenv("NVO_STREAM_OWNER_ACC_BITS")) st->owner.acc_bits = (uint32_t)atoi(e);  // measurements
     uint32_t owner_items = st->owner.runs ? 256 : 512;
     if (const char* e = getenv("NVO_GRID_OWNER_ITEMS")) owner_items = (uint32_t)atoi(e);  // measurements
     return nvo_grid_slices_create(g, &st->owner, all & ~st->streamed_mask, owner_items, false);
@@ -2727,8 +2736,11 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             uint32_t bx = nvo_div_up(N, 256 * 16);
             if (bx > 256) bx = 256;
             if (bx < 1) bx = 1;
+            const uint32_t all_levels = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
+            const uint32_t l1_mask = slices->level_mask & all_levels;
 #define NVO_LAUNCH_L1(SOA_, T_) \
-    NVO_LAUNCH((k_dy_l1<SOA_, T_>), dim3(bx, g.n_levels), dim3(256), 0, stream, g, N, (const T_*)dy, slices->d_l1)
+    NVO_LAUNCH((k_dy_l1<SOA_, T_>), dim3(bx, (uint32_t)__builtin_popcount(l1_mask)), dim3(256), 0, stream, g, N, (const T_*)dy, \
+               slices->d_l1, l1_mask)
             if (soa) {
                 if (dy_fmt == NVO_DY_BF16) NVO_LAUNCH_L1(true, Bf2); else NVO_LAUNCH_L1(true, __half2);
             } else {

@@ -406,12 +406,14 @@ class NerfactoEngine:
 
     def _write_bias(self, applied) -> None:
         """Bias corrections of every group's NEXT applied step (t = applied + 1), as nvo_opt_commit keeps them."""
-        b1, b2 = self.cfg.adam_betas
+        # (the kernel receives the betas as fp32 and raises them in double: do exactly that here, or a restored state
+        # would differ from the device's own by an ulp of the bias correction)
+        b1, b2 = (float(np.float32(b)) for b in self.cfg.adam_betas)
         vals = []
         for n in applied:
             t = int(n) + 1
             vals += [1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)]
-        self.dev_bias.copy_(torch.tensor(vals, dtype=torch.float32))
+        self.dev_bias.copy_(torch.tensor(vals, dtype=torch.float64).to(torch.float32))
 
     def current_loss_scale(self) -> float:
         """The loss scale the next step will use (device read-back; static unless cfg.dynamic_loss_scale)."""
@@ -1065,9 +1067,9 @@ class NerfactoEngine:
                 entry["head"].replay()
             self._pending_head = None
             pipeline = bool(cfg.pipeline_sampling_prefix)
-            self._write_step_scalars(self.anneal_at(step), groups)
-            if pipeline:  # the sampling scalars of the NEXT iteration: its prefix runs inside this one
-                self._write_sampling_scalars(step + 1)
+            # learning rates of THIS iteration and, when its prefix runs inside this one, the sampling scalars of the
+            # NEXT iteration: one tiny launch
+            self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step + 1 if pipeline else None)
             entry["run"](pipeline)
             if pipeline:
                 self._pending_head = (step + 1, getattr(dataset, "version", 0), extent)
