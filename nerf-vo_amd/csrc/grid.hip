@@ -248,7 +248,7 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 // Same fp32 interpolation, same order, one rounding: bit-identical to k_grid_fwd.
 constexpr int kSmallBlock = 1024;
 
-template <int NLDS, int NG>
+template <int NLDS, int NG, int SPT>
 __global__ void __launch_bounds__(kSmallBlock)
 k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
                  __half2* __restrict__ out, int out_bf16, uint32_t per_block) {
@@ -264,70 +264,91 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
     const uint32_t first = blockIdx.x * per_block;
     const uint32_t last = min(N, first + per_block);
     uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
-    for (uint32_t i = first + threadIdx.x; i < last; i += kSmallBlock) {
-        const float px = x[3 * (size_t)i + 0], py = x[3 * (size_t)i + 1], pz = x[3 * (size_t)i + 2];
-        // ---- global levels first: every gather of the sample is requested before anything is consumed
-        Corner cg[NG];
-        uint32_t vg[NG][8];
+    // SPT samples per thread and pass (kSmallBlock apart: coalescing as with one): with one 1024-thread workgroup per CU
+    // the launch is latency-bound (PMC: waves wait 59 % of their cycles) -- twice the gathers in flight per wave
+    for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += kSmallBlock * SPT) {
+        uint32_t is[SPT];
+        float pos[SPT][3];
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            const uint32_t level = NLDS + q;
-            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
-            const uint32_t hashed = g.hashed[level];
-            const uint32_t* __restrict__ tl = tab32 + off;
-            cg[q] = grid_cell(g.scale[level], px, py, pz);
+        for (int s = 0; s < SPT; ++s) {
+            is[s] = i0 + (uint32_t)s * kSmallBlock;
+            const uint32_t ic = min(is[s], last - 1u);  // (unconditional loads; a sample past the end stores nothing)
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t cy = cg[q].py + (j & 1u), cz = cg[q].pz + (j >> 1);
-                const uint32_t i0 = nvo_grid_index(hashed, size, res, cg[q].px, cy, cz);
-                const uint32_t i1 = nvo_grid_index(hashed, size, res, cg[q].px + 1u, cy, cz);
-                if (hashed ? ((cg[q].px & 1u) == 0u) : false) {
-                    // even cell x: idx1 == idx0 ^ 1 -- both corners sit in one aligned 8-byte pair
-                    const uint2 pr = *reinterpret_cast<const uint2*>(tl + (i0 & ~1u));
-                    vg[q][2 * j] = (i0 & 1u) ? pr.y : pr.x;
-                    vg[q][2 * j + 1] = (i0 & 1u) ? pr.x : pr.y;
-                } else if (!hashed && i1 == i0 + 1u) {
-                    // dense level: x neighbours are neighbours in memory (dword alignment suffices)
-                    const uint2 pr = *reinterpret_cast<const uint2*>(tl + i0);
-                    vg[q][2 * j] = pr.x;
-                    vg[q][2 * j + 1] = pr.y;
-                } else {
-                    vg[q][2 * j] = tl[i0];
-                    vg[q][2 * j + 1] = tl[i1];
+            for (int k = 0; k < 3; ++k) pos[s][k] = x[3 * (size_t)ic + k];
+        }
+        // ---- global levels first: every gather of the samples is requested before anything is consumed
+        Corner cg[SPT][NG];
+        uint32_t vg[SPT][NG][8];
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const uint32_t level = NLDS + q;
+                const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+                const uint32_t hashed = g.hashed[level];
+                const uint32_t* __restrict__ tl = tab32 + off;
+                cg[s][q] = grid_cell(g.scale[level], pos[s][0], pos[s][1], pos[s][2]);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t cy = cg[s][q].py + (j & 1u), cz = cg[s][q].pz + (j >> 1);
+                    const uint32_t i0c = nvo_grid_index(hashed, size, res, cg[s][q].px, cy, cz);
+                    const uint32_t i1c = nvo_grid_index(hashed, size, res, cg[s][q].px + 1u, cy, cz);
+                    if (hashed ? ((cg[s][q].px & 1u) == 0u) : false) {
+                        // even cell x: idx1 == idx0 ^ 1 -- both corners sit in one aligned 8-byte pair
+                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + (i0c & ~1u));
+                        vg[s][q][2 * j] = (i0c & 1u) ? pr.y : pr.x;
+                        vg[s][q][2 * j + 1] = (i0c & 1u) ? pr.x : pr.y;
+                    } else if (!hashed && i1c == i0c + 1u) {
+                        // dense level: x neighbours are neighbours in memory (dword alignment suffices)
+                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + i0c);
+                        vg[s][q][2 * j] = pr.x;
+                        vg[s][q][2 * j + 1] = pr.y;
+                    } else {
+                        vg[s][q][2 * j] = tl[i0c];
+                        vg[s][q][2 * j + 1] = tl[i1c];
+                    }
                 }
             }
         }
         // ---- LDS levels while the gathers fly
 #pragma unroll
-        for (int l = 0; l < NLDS; ++l) {
-            const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
-            const uint32_t* tl = lds_tab + off;
-            const Corner c = grid_cell(g.scale[l], px, py, pz);
-            float r0 = 0.f, r1 = 0.f;
+        for (int s = 0; s < SPT; ++s) {
+            if (is[s] >= last) continue;
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
-                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                                ((k & 4u) ? c.wz : 1.f - c.wz);
-                const float2 f = __half22float2(__builtin_bit_cast(__half2, tl[idx]));
-                r0 = fmaf(w, f.x, r0);
-                r1 = fmaf(w, f.y, r1);
+            for (int l = 0; l < NLDS; ++l) {
+                const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+                const uint32_t* tl = lds_tab + off;
+                const Corner c = grid_cell(g.scale[l], pos[s][0], pos[s][1], pos[s][2]);
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+                    const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                    ((k & 4u) ? c.wz : 1.f - c.wz);
+                    const float2 f = __half22float2(__builtin_bit_cast(__half2, tl[idx]));
+                    r0 = fmaf(w, f.x, r0);
+                    r1 = fmaf(w, f.y, r1);
+                }
+                o32[(size_t)l * N + is[s]] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
             }
-            o32[(size_t)l * N + i] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
         }
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            const Corner& c = cg[q];
-            float r0 = 0.f, r1 = 0.f;
+        for (int s = 0; s < SPT; ++s) {
+            if (is[s] >= last) continue;
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                                ((k & 4u) ? c.wz : 1.f - c.wz);
-                const float2 f = __half22float2(__builtin_bit_cast(__half2, vg[q][k]));
-                r0 = fmaf(w, f.x, r0);
-                r1 = fmaf(w, f.y, r1);
+            for (int q = 0; q < NG; ++q) {
+                const Corner& c = cg[s][q];
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                    ((k & 4u) ? c.wz : 1.f - c.wz);
+                    const float2 f = __half22float2(__builtin_bit_cast(__half2, vg[s][q][k]));
+                    r0 = fmaf(w, f.x, r0);
+                    r1 = fmaf(w, f.y, r1);
+                }
+                o32[(size_t)(NLDS + q) * N + is[s]] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
             }
-            o32[(size_t)(NLDS + q) * N + i] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
         }
     }
 }
@@ -2103,7 +2124,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     // small grids (the proposal networks): the two coarsest dense levels from LDS, a thread per sample (k_grid_fwd_small)
-    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 1; }();
+    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 2; }();  // 0 off | 1 | 2 samples per thread
     if (small_env && soa && !indices && !dydx_half && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
         (size_t)g.offset[2] * 4 <= 152 * 1024 && (g.offset[2] & 3u) == 0u && (((uintptr_t)table_half) & 15u) == 0u) {
         static const uint32_t n_cus = [] {
@@ -2114,14 +2135,21 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
         const size_t lds = (size_t)g.offset[2] * 4;
         static bool attr_set = false;
         if (!attr_set) {
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              152 * 1024));
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               152 * 1024));
             attr_set = true;
         }
-        // one workgroup per CU, a whole number of 1024-sample passes each
-        const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock);
-        NVO_LAUNCH((k_grid_fwd_small<2, 3>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
-                   (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
+        // one workgroup per CU, a whole number of passes each
+        const uint32_t spt = small_env >= 2 ? 2u : 1u;
+        const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock * spt);
+        if (spt == 2)
+            NVO_LAUNCH((k_grid_fwd_small<2, 3, 2>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
+                       (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
+        else
+            NVO_LAUNCH((k_grid_fwd_small<2, 3, 1>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
+                       (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
         NVO_CHECK_LAUNCH();
         return NVO_OK;
     }

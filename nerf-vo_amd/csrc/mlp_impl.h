@@ -1130,6 +1130,7 @@ int launch_bwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
 //   (32, 64, 1, 16) nerfacto base MLP      (64, 64, 2, 16) colour MLP
 //   (32, 64, 3, 64) predicted-normals MLP  (16, 16, 1, 16) proposal density MLP
 //   (16, 64, 1..2, 16), (32, 64, 2, 16), (64, 64, 1, 16) generic tcnn.Network uses
+//   (16 | 32, 32, 1..2, 16) tcnn's n_neurons = 32 (not on the NeRF-VO path; the tcnn surface beyond nerfacto)
 #define NVO_MLP_SHAPES(X) \
     X(32, 64, 1, 16)      \
     X(64, 64, 2, 16)      \
@@ -1140,7 +1141,11 @@ int launch_bwd(const Args& a, hipStream_t stream, uint32_t max_blocks) {
     X(32, 64, 2, 16)      \
     X(64, 64, 1, 16)      \
     X(16, 16, 2, 16)      \
-    X(32, 16, 1, 16)
+    X(32, 16, 1, 16)      \
+    X(16, 32, 1, 16)      \
+    X(16, 32, 2, 16)      \
+    X(32, 32, 1, 16)      \
+    X(32, 32, 2, 16)
 
 // workgroup caps (tuning knobs; the defaults are the measured optima on MI355X)
 static uint32_t env_blocks(const char* name, uint32_t dflt) {

@@ -345,6 +345,8 @@ MLP_SHAPES = [
     (27, 64, 64, 3, "ReLU", "None"),      # predicted normals MLP
     (10, 1, 16, 1, "ReLU", "None"),       # proposal density MLP (standalone)
     (16, 16, 16, 1, "ReLU", "None"),
+    (27, 3, 32, 2, "ReLU", "Sigmoid"),    # tcnn n_neurons = 32 (not on the NeRF-VO path)
+    (16, 16, 32, 1, "ReLU", "None"),
 ]
 
 

@@ -63,7 +63,7 @@ def main():
 
     if st:
         parts = st + (lds[:1] if lds else [])
-        steps = max(k["launches"] for k in parts if k["kernel"] in ("k_st_scatter", "k_tl_scatter"))
+        steps = max(k["launches"] for k in parts if k["kernel"] in ("k_st_scatter", "k_tl_scatter", "k_tl_scatter_p"))
         rows.append({"bench_name": "grid_bwd_stream[L16]", "launches": steps, "parts": [f'{k["kernel"]}/{k["grid_size"]}' for k in parts],
                      "FETCH_SIZE_KB_per_launch": total(parts, "FETCH_SIZE_KB_per_launch", steps),
                      "FETCH_SIZE_KB_corrected": total(parts, "FETCH_SIZE_KB_corrected", steps),
