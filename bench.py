@@ -418,14 +418,25 @@ def main() -> None:
 
         kw = (dict(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6) if args.psnr == "small" else
               dict(keyframes=192, height=480, width=640, iterations=8192, eval_frames=6))
-        res = run_mapping(quiet=True, **kw)
-        render_psnr = {"psnr_float_mse_db": round(res["psnr_float_mse"], 3),
-                       "psnr_reference_uint8wrap_db": round(res["psnr_reference_uint8wrap"], 3),
-                       "depth_l1": round(res["depth_l1"], 4), "held_out_views": kw["eval_frames"],
+        # Both runs use the DETERMINISTIC mode with a fixed seed (bitwise reproducible training: DESIGN.md section 3.7), so
+        # the figures below are the same on every box and every run -- the depth L1 of such a run is heavy-tailed (a few
+        # floaters move it 0.03 ... 0.22 between seeds, with or without float atomics, with or without pose refinement:
+        # section 5.3).  The training THROUGHPUT is the timed region above, not these runs (deterministic mode is ~2x slower).
+        def psnr_run(mode):
+            res = run_mapping(quiet=True, deterministic=True, seed=42, camera_optimizer_mode=mode, **kw)
+            return {"psnr_float_mse_db": round(res["psnr_float_mse"], 3),
+                    "psnr_reference_uint8wrap_db": round(res["psnr_reference_uint8wrap"], 3),
+                    "depth_l1": round(res["depth_l1"], 4),
+                    "psnr_float_mse_keyframe_views_db": round(res["psnr_float_mse_keyframe_views"], 3)}
+
+        # BASELINE configs[1] is "fixed poses": the headline figure trains with the camera optimiser off; the second run is
+        # the mapper exactly as the reference configures it (SE3 refinement on: it perturbs poses that are already exact
+        # here, which costs ~6 dB at held-out GROUND-TRUTH poses)
+        render_psnr = {**psnr_run("off"), "held_out_views": kw["eval_frames"],
                        "config": f'{kw["keyframes"]} keyframes {kw["width"]}x{kw["height"]}, {kw["iterations"]} iterations '
-                                 "through the Nerfstudio mapper interface (incremental keyframe ingest, SE3 pose "
-                                 "refinement on), synthetic textured room",
-                       "train_ray_samples_per_sec": res["ray_samples_per_sec"]}
+                                 "through the Nerfstudio mapper interface (incremental keyframe ingest), fixed poses "
+                                 "(BASELINE configs[1]), synthetic textured room; deterministic mode, seed 42",
+                       "with_se3_pose_refinement": psnr_run("SE3")}
 
     if rank == 0:
         captured = any(e.get("captured_collectives") for e in engine._graphs.values())

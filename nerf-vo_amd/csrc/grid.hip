@@ -2124,7 +2124,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     // small grids (the proposal networks): the two coarsest dense levels from LDS, a thread per sample (k_grid_fwd_small)
-    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 2; }();  // 0 off | 1 | 2 samples per thread
+    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 1; }();  // 0 off | 1 | 2 samples per thread (2 measured slower: 35.0 vs 33.6 us)
     if (small_env && soa && !indices && !dydx_half && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
         (size_t)g.offset[2] * 4 <= 152 * 1024 && (g.offset[2] & 3u) == 0u && (((uintptr_t)table_half) & 15u) == 0u) {
         static const uint32_t n_cus = [] {
