@@ -81,6 +81,36 @@ __device__ __forceinline__ void grid_block_map(uint32_t bid, uint32_t n_levels, 
     }
 }
 
+// XCD-BALANCED block map of the forward (round 3).  grid_block_map gives XCD x the levels {x, x + 8}: with 5 dense and 11
+// hashed levels, XCDs 5-7 gather from TWO 2 MiB hashed tables while XCDs 0-4 have one hashed and one (cheap) dense level
+// -- the busy three run at their L2-gather ceiling (2.9 TB/s each) and the others idle almost half the launch.  The plan
+// below keeps what the pinning buys (an XCD's private 4 MiB L2 holds at most TWO hashed tables) and evens out the work:
+// XCD x owns one hashed level completely, the remaining hashed levels are cut into tile ranges so that every XCD gets a
+// piece of exactly ONE further table, and the dense levels' tiles fill the XCDs up to the same cost.  Placement of
+// block b on XCD b % 8 is an observation, not a contract: it affects speed only.
+constexpr int kPlanUnits = 8;
+struct GridFwdPlan {
+    uint32_t enabled;
+    uint32_t n_units[8];
+    uint32_t level[8][kPlanUnits];
+    uint32_t tile0[8][kPlanUnits];
+    uint32_t n_tiles[8][kPlanUnits];
+};
+
+__device__ __forceinline__ bool grid_plan_map(const GridFwdPlan& p, uint32_t bid, uint32_t* tile, uint32_t* level) {
+    const uint32_t xcd = bid & 7u;
+    uint32_t q = bid >> 3;
+    for (uint32_t u = 0; u < p.n_units[xcd]; ++u) {
+        if (q < p.n_tiles[xcd][u]) {
+            *tile = p.tile0[xcd][u] + q;
+            *level = p.level[xcd][u];
+            return true;
+        }
+        q -= p.n_tiles[xcd][u];
+    }
+    return false;
+}
+
 // dL/d(encoded) pair of one (sample, level): fp16 (tcnn's precision), fp32, or bfloat16 (bf16 MLP mode)
 struct Bf2 {
     uint32_t raw;
@@ -130,9 +160,13 @@ template <bool SOA, bool DYDX, int SPT>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
            const __half2* __restrict__ table, __half2* __restrict__ out,
-           uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16) {
+           uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16, GridFwdPlan plan) {
     uint32_t tile, level;
-    grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    if (plan.enabled) {
+        if (!grid_plan_map(plan, blockIdx.x, &tile, &level)) return;
+    } else {
+        grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    }
     const uint32_t i_first = tile * (kGridBlock * SPT) + threadIdx.x;
     if (i_first >= N) return;
 
@@ -2116,6 +2150,82 @@ k_sum_levels(uint32_t n_levels, size_t n, const float* __restrict__ partial, flo
         else M(SOA_, __half2);                            \
     } while (0)
 
+// Builds the XCD-balanced plan (see GridFwdPlan); returns the blocks per XCD (grid = 8 x that), plan->enabled = 0 when
+// the level set does not fit the scheme (fewer than 8 hashed levels, too many pieces).
+static uint32_t grid_fwd_plan_build(const NvoGridLevels& g, uint32_t tiles, GridFwdPlan* plan) {
+    static const float dense_cost = [] { const char* e = getenv("NVO_GRID_FWD_DENSE_COST"); return e ? (float)atof(e) : 0.4f; }();
+    std::vector<uint32_t> hashed, dense;
+    for (uint32_t l = 0; l < g.n_levels; ++l) (g.hashed[l] ? hashed : dense).push_back(l);
+    if (hashed.size() < 8 || hashed.size() > 16) return 0;
+    float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto push = [&](uint32_t xcd, uint32_t level, uint32_t t0, uint32_t n, float cost) -> bool {
+        if (n == 0) return true;
+        uint32_t& k = plan->n_units[xcd];
+        if (k >= (uint32_t)kPlanUnits) return false;
+        plan->level[xcd][k] = level;
+        plan->tile0[xcd][k] = t0;
+        plan->n_tiles[xcd][k] = n;
+        ++k;
+        load[xcd] += cost * (float)n;
+        return true;
+    };
+    // one whole hashed level per XCD (the finest first: they miss L1 most)
+    for (uint32_t x = 0; x < 8; ++x)
+        if (!push(x, hashed[hashed.size() - 1 - x], 0, tiles, 1.f)) return 0;
+    // the remaining hashed levels in pieces: every XCD gets tiles of exactly ONE further table
+    const uint32_t n_rest = (uint32_t)hashed.size() - 8;
+    if (n_rest) {
+        const uint32_t piece = nvo_div_up((uint64_t)n_rest * tiles, 8);
+        uint32_t lv = 0, t0 = 0;
+        for (uint32_t x = 0; x < 8 && lv < n_rest; ++x) {
+            const uint32_t n = tiles - t0 < piece ? tiles - t0 : piece;
+            if (!push(x, hashed[lv], t0, n, 1.f)) return 0;
+            t0 += n;
+            if (t0 >= tiles) {
+                ++lv;
+                t0 = 0;
+            }
+        }
+        // (what the one-table-per-XCD rule left over goes to the XCD that already holds that table)
+        while (lv < n_rest) {
+            uint32_t owner = 7;
+            for (uint32_t x = 0; x < 8; ++x)
+                for (uint32_t u = 0; u < plan->n_units[x]; ++u)
+                    if (plan->level[x][u] == hashed[lv]) owner = x;
+            if (!push(owner, hashed[lv], t0, tiles - t0, 1.f)) return 0;
+            ++lv;
+            t0 = 0;
+        }
+    }
+    // dense levels: tile ranges to the least loaded XCD until every XCD carries the same cost
+    float total = 0.f;
+    for (int x = 0; x < 8; ++x) total += load[x];
+    total += dense_cost * (float)(dense.size() * tiles);
+    const float target = total / 8.f;
+    for (uint32_t l : dense) {
+        uint32_t t0 = 0;
+        while (t0 < tiles) {
+            uint32_t best = 0;
+            for (uint32_t x = 1; x < 8; ++x)
+                if (load[x] < load[best]) best = x;
+            float room = (target - load[best]) / dense_cost;
+            uint32_t n = room < 8.f ? 8u : (uint32_t)room;
+            if (n > tiles - t0) n = tiles - t0;
+            if (plan->n_units[best] + 1 >= (uint32_t)kPlanUnits) n = tiles - t0;  // last free slot: take the rest
+            if (!push(best, l, t0, n, dense_cost)) return 0;
+            t0 += n;
+        }
+    }
+    uint32_t max_blocks = 0;
+    for (uint32_t x = 0; x < 8; ++x) {
+        uint32_t b = 0;
+        for (uint32_t u = 0; u < plan->n_units[x]; ++u) b += plan->n_tiles[x][u];
+        if (b > max_blocks) max_blocks = b;
+    }
+    plan->enabled = 1;
+    return max_blocks;
+}
+
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half,
                         bool out_bf16) {
@@ -2156,10 +2266,17 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     static const int spt_env = [] { const char* e = getenv("NVO_GRID_FWD_SPT"); return e ? atoi(e) : 2; }();
     const int spt = (dydx_half || spt_env < 2) ? 1 : (spt_env >= 4 ? 4 : 2);  // samples per thread
     const uint32_t tiles = nvo_div_up(N, kGridBlock * spt);
-    const dim3 grid(tiles * g.n_levels), block(kGridBlock);
+    dim3 grid(tiles * g.n_levels), block(kGridBlock);
+    GridFwdPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    static const int balance_env = [] { const char* e = getenv("NVO_GRID_FWD_BALANCE"); return e ? atoi(e) : 1; }();
+    if (balance_env && (g.n_levels & 7u) == 0u) {
+        const uint32_t blocks_per_xcd = grid_fwd_plan_build(g, tiles, &plan);
+        if (plan.enabled) grid = dim3(8u * blocks_per_xcd);
+    }
 #define NVO_LAUNCH_FWD_S(SOA_, DYDX_, SPT_)                                                                  \
     NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_, SPT_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
-               (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0)
+               (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0, plan)
 #define NVO_LAUNCH_FWD(SOA_, DYDX_)                                        \
     do {                                                                   \
         if (DYDX_ || spt == 1) NVO_LAUNCH_FWD_S(SOA_, DYDX_, 1);           \
