@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_features,
@@ -1566,7 +1567,7 @@ __device__ __forceinline__ TlItem tl_decode(uint4 h, uint32_t n_tiles) {
     I.lvl = h.z & 0xFFu;
     I.level = h.z >> 8;
     I.slice = h.w;
-    const uint32_t per = (n_tiles + I.n_chunks - 1u) / I.n_chunks;
+    const uint32_t per = I.n_chunks ? (n_tiles + I.n_chunks - 1u) / I.n_chunks : 0u;  // (n_chunks == 0: padding item)
     I.t0 = min(n_tiles, I.chunk * per);
     I.t1 = min(n_tiles, I.t0 + per);
     return I;
@@ -1725,21 +1726,24 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
 // The tile writes L1_f(tile, bin) <= S_f * M_f / 1023, rounded UP to bf16, next to its segment word; the accumulate item
 // sums the words of its tiles (fixed order) and scales by 2^29 / L1.  Everything that feeds the scale is integer or
 // fixed-order arithmetic, so single-chunk bins stay bitwise reproducible.
-constexpr uint32_t kBinP = 8192;
+constexpr uint32_t kBinP = 8192;   // largest bin of the packed form (13-bit entry index in a record)
+constexpr uint32_t kBinPSmall = 6176;  // 85 bins per 2^19 table: 11 hashed levels = 935 items = two even rounds of 512 workgroups
 constexpr int kTlBlockP = 512;
 
+template <uint32_t BIN>
 __device__ __forceinline__ uint32_t st_bin_entries_p(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
     const uint32_t size = g.offset[level + 1] - g.offset[level];
-    return min(kBinP, size - slice * kBinP);
+    return min(BIN, size - slice * BIN);
 }
 
+template <uint32_t BIN>
 __global__ void __launch_bounds__(256)
 k_st_zero_p(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
             const uint32_t* __restrict__ bin_chunks, float* __restrict__ grad) {
     if (bin_chunks[blockIdx.x] <= 1u) return;
     const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
-    const uint32_t n = 2 * st_bin_entries_p(g, level, slice);
-    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinP);
+    const uint32_t n = 2 * st_bin_entries_p<BIN>(g, level, slice);
+    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * BIN);
     for (uint32_t e = threadIdx.x; e < n; e += 256) gr[e] = 0.f;
 }
 
@@ -1760,7 +1764,7 @@ __device__ __forceinline__ uint32_t bf16_up(float v) {  // smallest bfloat16 >= 
     return u >> 16;
 }
 
-template <int TILE, bool SOA, typename DY2>
+template <int TILE, bool SOA, typename DY2, uint32_t BIN>
 __global__ void __launch_bounds__(TILE)
 k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
@@ -1828,7 +1832,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
         };
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {  // rank inside (tile, bin) + magnitude sums: ONE LDS atomic per x-corner pair
-            const uint32_t b0 = idx[2 * j] / kBinP, b1 = idx[2 * j + 1] / kBinP;
+            const uint32_t b0 = idx[2 * j] / BIN, b1 = idx[2 * j + 1] / BIN;
             const unsigned long long m_a = (quant(v0[2 * j], q0s) << 16) | (quant(v1[2 * j], q1s) << 40);
             const unsigned long long m_b = (quant(v0[2 * j + 1], q0s) << 16) | (quant(v1[2 * j + 1], q1s) << 40);
             if (b0 == b1) {
@@ -1864,7 +1868,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     if (live) {
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            stage[loff[idx[k] / kBinP] + slot[k]] = rec_pack(idx[k] & (kBinP - 1u), v0[k], v1[k]);
+            stage[loff[idx[k] / BIN] + slot[k]] = rec_pack(idx[k] % BIN, v0[k], v1[k]);
     }
     __syncthreads();
     const uint32_t total = total_s;
@@ -1873,6 +1877,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     for (uint32_t t = threadIdx.x; t < (total + 1u) / 2u; t += kStBlock) dst[t] = src[t];
 }
 
+template <uint32_t BIN>
 __global__ void __launch_bounds__(kTlBlockP)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint2* __restrict__ records, uint32_t n_tiles,
@@ -1897,13 +1902,20 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
     };
     TlItem cur = tl_decode(items[it], n_tiles);
     uint32_t l1w = 0u;
-    uint32_t segw = words_first(cur, &l1w);
+    uint32_t segw = cur.n_chunks ? words_first(cur, &l1w) : 0u;
     for (;;) {
         const uint32_t it_next = it + gridDim.x;
         const bool has_next = it_next < n_items;
         const uint4 head_next = items[has_next ? it_next : it];  // in flight while the accumulators are zeroed
-        const uint32_t entries = st_bin_entries_p(g, cur.level, cur.slice);
-        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * kBinP);
+        if (cur.n_chunks == 0u) {  // padding of the balanced work list (n_chunks == 0): nothing to do in this round
+            if (!has_next) break;
+            it = it_next;
+            cur = tl_decode(head_next, n_tiles);
+            segw = cur.n_chunks ? words_first(cur, &l1w) : 0u;
+            continue;
+        }
+        const uint32_t entries = st_bin_entries_p<BIN>(g, cur.level, cur.slice);
+        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * BIN);
         {
             uint4* z = reinterpret_cast<uint4*>(lds_raw);  // one uint4 = two entries
             for (uint32_t e = threadIdx.x; e < (entries + 1u) / 2u; e += kTlBlockP) z[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -1982,7 +1994,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     next_requested = true;
                     if (has_next) {
                         nxt = tl_decode(head_next, n_tiles);
-                        segw_next = words_first(nxt, &l1w_next);
+                        if (nxt.n_chunks) segw_next = words_first(nxt, &l1w_next);
                     }
                 }
 #pragma unroll
@@ -1992,7 +2004,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         }
         if (!next_requested && has_next) {  // (a wave without records in this item)
             nxt = tl_decode(head_next, n_tiles);
-            segw_next = words_first(nxt, &l1w_next);
+            if (nxt.n_chunks) segw_next = words_first(nxt, &l1w_next);
         }
         __syncthreads();
         {
@@ -2546,7 +2558,9 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
     if (!st->tile_local) st->acc_bits = 64;  // (the packed accumulators exist for the tile-local layout only)
     // entries per bin: 4096 x 16 B (two 64-bit sums per entry) or 8192 x 8 B (two 32-bit sums in one word) = 64 KiB
-    const uint32_t bin_entries = st->acc_bits == 32 ? kBinP : kBinSlice;
+    uint32_t bin_p = kBinPSmall;
+    if (const char* e = getenv("NVO_TL_BIN")) bin_p = (uint32_t)atoi(e) == kBinP ? kBinP : kBinPSmall;  // measurements
+    const uint32_t bin_entries = st->acc_bits == 32 ? bin_p : kBinSlice;
     st->bin_entries = bin_entries;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
@@ -2608,6 +2622,46 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
                     items.push_back(bin_slice[b]);
                 }
             }
+        }
+        st->n_tl_slots = 0;
+        if (st->acc_bits == 32 && !(getenv("NVO_TL_BALANCE") && atoi(getenv("NVO_TL_BALANCE")) == 0)) {
+            // BALANCED work list for the persistent accumulate (2 workgroups per CU, workgroup w walks items w, w + slots,
+            // ...).  Dealt round-robin, 935 hashed-level items + 272 cheap dense-level chunks gave some workgroups two
+            // hashed items and a chunk, others one hashed item: the launch lasted as long as the former.  Longest-
+            // processing-time-first over the slots (cost of an item ~ its expected records: 1 / bins of its level /
+            // chunks), then laid out round by round with PADDING items (n_chunks = 0) where a slot has nothing left.
+            int dev = 0, n_cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint32_t slots = 2u * (uint32_t)(n_cus > 0 ? n_cus : 256);
+            const uint32_t n_it = (uint32_t)(items.size() / 4);
+            std::vector<std::pair<float, uint32_t>> order;
+            for (uint32_t i = 0; i < n_it; ++i) {
+                const uint32_t j = items[4 * i + 2] & 0xFFu, nc = items[4 * i + 1] >> 16;
+                order.push_back({1.f / (float)(first[j + 1] - first[j]) / (float)nc, i});
+            }
+            std::stable_sort(order.begin(), order.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first; });
+            std::vector<float> load(slots, 0.f);
+            std::vector<std::vector<uint32_t>> mine(slots);
+            uint32_t cursor = 0;
+            for (const auto& oc : order) {
+                // least-loaded slot (linear scan: a few hundred slots, ~1200 items, once per module); ties go round-robin
+                uint32_t best = cursor % slots;
+                for (uint32_t q = 0; q < slots; ++q) {
+                    const uint32_t sidx = (cursor + q) % slots;
+                    if (load[sidx] < load[best]) best = sidx;
+                }
+                mine[best].push_back(oc.second);
+                load[best] += oc.first;
+                ++cursor;
+            }
+            size_t rounds = 0;
+            for (const auto& m : mine) rounds = m.size() > rounds ? m.size() : rounds;
+            std::vector<uint32_t> laid(4 * rounds * slots, 0u);  // all-zero header = padding (n_chunks == 0)
+            for (uint32_t w = 0; w < slots; ++w)
+                for (size_t r = 0; r < mine[w].size(); ++r)
+                    for (int k = 0; k < 4; ++k) laid[4 * (r * slots + w) + k] = items[4 * mine[w][r] + k];
+            items.swap(laid);
+            st->n_tl_slots = slots;
         }
         st->n_tl_items = (uint32_t)(items.size() / 4);
         NVO_CHECK_HIP(hipMalloc((void**)&st->d_tl_items, 4 * items.size()));
@@ -2731,34 +2785,41 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_REQUIRE(tile == 512, "grid_bwd_stream: the packed accumulators are built for 512-sample tiles");
             uint32_t* segl1 = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl + seg_bytes);
             const size_t lds_p = tile_records * sizeof(uint2) + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
-            const size_t lds_acc_p = sizeof(unsigned long long) * kBinP;
-#define NVO_LAUNCH_TLP(SOA_, T_)                                                                              \
+            const size_t lds_acc_p = sizeof(unsigned long long) * st->bin_entries;
+            const uint32_t acc_grid = st->n_tl_slots ? st->n_tl_slots : (st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus);
+#define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_)                                                                      \
     do {                                                                                                      \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<512, SOA_, T_>,                     \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<512, SOA_, T_, BIN_>,               \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(512 * 64 + 12 * 4096))); \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p,                                 \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc_p));   \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p<BIN_>,                           \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * BIN_)));  \
             attr_set = true;                                                                                  \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
-            NVO_LAUNCH((k_tl_scatter_p<512, SOA_, T_>), grid_tl, dim3(512), lds_p, stream, g, N, x, (const T_*)dy, \
+            NVO_LAUNCH((k_tl_scatter_p<512, SOA_, T_, BIN_>), grid_tl, dim3(512), lds_p, stream, g, N, x, (const T_*)dy, \
                        st->d_levels, st->d_bin_first, seg, segl1, records_tl);                                 \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
             if (!st->external_zero)                                                                           \
-                NVO_LAUNCH(k_st_zero_p, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
+                NVO_LAUNCH(k_st_zero_p<BIN_>, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                            st->d_bin_chunks, grad);                                                           \
-            NVO_LAUNCH(k_tl_accumulate_p, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlockP), \
-                       lds_acc_p, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1, records_tl, \
-                       n_tiles, (uint32_t)tile_records, grad, st->owner.nf_flag);                             \
+            NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
+                       (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1, records_tl, n_tiles,         \
+                       (uint32_t)tile_records, grad, st->owner.nf_flag);                                      \
         }                                                                                                     \
+    } while (0)
+#define NVO_LAUNCH_TLP(SOA_, T_)                                                           \
+    do {                                                                                   \
+        if (st->bin_entries == kBinP) NVO_LAUNCH_TLP_B(SOA_, T_, kBinP);                   \
+        else NVO_LAUNCH_TLP_B(SOA_, T_, kBinPSmall);                                       \
     } while (0)
             if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
 #undef NVO_LAUNCH_TLP
+#undef NVO_LAUNCH_TLP_B
         } else if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, false);
 #undef NVO_LAUNCH_TL_T
 #undef NVO_LAUNCH_TL
