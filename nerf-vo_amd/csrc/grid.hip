@@ -1727,7 +1727,7 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
 // sums the words of its tiles (fixed order) and scales by 2^29 / L1.  Everything that feeds the scale is integer or
 // fixed-order arithmetic, so single-chunk bins stay bitwise reproducible.
 constexpr uint32_t kBinP = 8192;   // largest bin of the packed form (13-bit entry index in a record)
-constexpr uint32_t kBinPSmall = 6176;  // 85 bins per 2^19 table: 11 hashed levels = 935 items = two even rounds of 512 workgroups
+constexpr uint32_t kBinPSmall = 6176;  // (experiment, NVO_TL_BIN=6176: 85 bins per 2^19 table; measured slower)
 constexpr int kTlBlockP = 512;
 
 template <uint32_t BIN>
@@ -2558,8 +2558,11 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
     if (!st->tile_local) st->acc_bits = 64;  // (the packed accumulators exist for the tile-local layout only)
     // entries per bin: 4096 x 16 B (two 64-bit sums per entry) or 8192 x 8 B (two 32-bit sums in one word) = 64 KiB
-    uint32_t bin_p = kBinPSmall;
-    if (const char* e = getenv("NVO_TL_BIN")) bin_p = (uint32_t)atoi(e) == kBinP ? kBinP : kBinPSmall;  // measurements
+    // (6176-entry bins -- 85 per 2^19 table, 935 hashed items = two even rounds of 512 workgroups on paper -- measured
+    // SLOWER: 139.0 / 146.1 us for the stage against 132.8 / 127.3 with 8192-entry bins (dealt / balanced work list):
+    // the shorter runs cost more than the evener rounds save)
+    uint32_t bin_p = kBinP;
+    if (const char* e = getenv("NVO_TL_BIN")) bin_p = (uint32_t)atoi(e) == kBinPSmall ? kBinPSmall : kBinP;  // measurements
     const uint32_t bin_entries = st->acc_bits == 32 ? bin_p : kBinSlice;
     st->bin_entries = bin_entries;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
@@ -2626,8 +2629,9 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         st->n_tl_slots = 0;
         if (st->acc_bits == 32 && !(getenv("NVO_TL_BALANCE") && atoi(getenv("NVO_TL_BALANCE")) == 0)) {
             // BALANCED work list for the persistent accumulate (2 workgroups per CU, workgroup w walks items w, w + slots,
-            // ...).  Dealt round-robin, 935 hashed-level items + 272 cheap dense-level chunks gave some workgroups two
-            // hashed items and a chunk, others one hashed item: the launch lasted as long as the former.  Longest-
+            // ...).  Dealt round-robin, 704 hashed-level items + 208 cheap dense-level chunks gave some workgroups two
+            // hashed items and a chunk, others one hashed item: the launch lasted as long as the former (132.8 -> 127.3
+            // us for the stage with the list below: the chunks now go to the workgroups with one hashed item).  Longest-
             // processing-time-first over the slots (cost of an item ~ its expected records: 1 / bins of its level /
             // chunks), then laid out round by round with PADDING items (n_chunks = 0) where a slot has nothing left.
             int dev = 0, n_cus = 256;
