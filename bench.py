@@ -140,6 +140,8 @@ def main() -> None:
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the eager per-kernel HIP-event pass (rocprofv3 runs: only graph-replayed steps in the trace)")
     ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
+    ap.add_argument("--pipeline-single-gpu", action="store_true",
+                    help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     args.keyframes = args.keyframes or wl["keyframes"]
@@ -211,6 +213,8 @@ def main() -> None:
                        mlp_dtype=args.mlp_dtype, expect_normals=use_normals)
     if args.proposal_streams is not None:
         cfg.proposal_backward_streams = args.proposal_streams
+    if args.pipeline_single_gpu:
+        cfg.pipeline_single_gpu = True
     if args.no_overlap:
         cfg.overlap_proposal_backward = False
         cfg.overlap_pose_backward = False
@@ -442,6 +446,9 @@ def main() -> None:
         captured = any(e.get("captured_collectives") for e in engine._graphs.values())
         if not use_graph:
             launch_desc = "eager"
+        elif dist is None and any(e.get("pipelined") for e in engine._graphs.values()):
+            launch_desc = ("hipGraph replay: ONE graph per step = body -> Adam(proposal, poses) -> [Adam(fields) || sampling "
+                           "prefix of the next step] (variants: with / without proposal update, value-only proposal losses)")
         elif dist is None:
             launch_desc = "hipGraph replay: ONE graph per step (variants: with / without proposal update, value-only proposal losses)"
         elif captured:

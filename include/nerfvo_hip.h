@@ -192,6 +192,12 @@ int nvo_sh_bwd_input_f32(nvo_stream_t stream, uint32_t N, uint32_t degree, const
 int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
                  const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
                  float* d_corrections);
+/* same sum for a KNOWN camera count (camera index < n_cameras): when at least 64 rays meet on a camera on average, each
+ * workgroup adds into its own camera table in LDS and flushes the non-zero words once -- one global float atomic per
+ * workgroup and word instead of one per ray and word (n_cameras <= 1024; otherwise this is nvo_pose_bwd) */
+int nvo_pose_bwd_cams(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                      const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                      float* d_corrections, uint32_t n_cameras);
 /* deterministic form: per-ray contributions [R][12] go through per_ray_scratch and are summed per camera in a FIXED
  * order (n_cameras rows of d_corrections) instead of float atomics */
 int nvo_pose_bwd_det(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,

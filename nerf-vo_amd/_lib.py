@@ -149,6 +149,7 @@ _SIGNATURES = {
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_color_det_scratch_bytes": (_u64, [_u32, _u32]),
+    "nvo_pose_bwd_cams": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _u32]),
     "nvo_pose_bwd_det": (_int, [_p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _u32]),
     # group F
     "nvo_occ_march_scratch_bytes": (_u64, [_u32]),

@@ -122,9 +122,16 @@ class EngineConfig:
     expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
-    # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling) while the fields gradient is
-    # still being all-reduced (train_step_graphed; bit-identical to the un-pipelined order)
+    # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
+    # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
+    # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
+    # hold the NEXT step's rays.
     pipeline_sampling_prefix: bool = True
+    # the same software pipelining on ONE GPU: the graph ends with [Adam of the fields group || next sampling prefix].
+    # Bit-identical, and MEASURED NEUTRAL (0.617 vs 0.608 ms/step; even the prefix beside the whole main backward
+    # gains only 2 %): the Adam stream saturates HBM and the prefix's gathers then wait longer for their misses -- the
+    # chip has no idle resource for a second kernel to use.  Off by default; kept for the test of the launch order.
+    pipeline_single_gpu: bool = False
     # graph-replayed step: pixel sampling, ray generation, target gather, SH and the first sampler level in ONE launch
     # (nvo_ray_head) instead of five 4096-ray kernels of ~6 us dispatch + drain each; bit-identical
     fused_ray_head: bool = True
@@ -296,7 +303,7 @@ class NerfactoEngine:
         # two slots of the same buffer, so a single-GPU step refreshes everything with ONE tiny launch
         self.dev_scalars = torch.zeros(16, dtype=torch.float32, device=dev)
         self.dev_sampling = self.dev_scalars[14:16]
-        self._pending_head = None  # multi-GPU: stamp of the sampling prefix already launched for the next step
+        self._pending_head = None  # stamp of the sampling prefix already launched for the next step (pipelined graphs)
         self._graphs = {}
         self._side_stream = None
         self._scatter_stream = None
@@ -347,6 +354,7 @@ class NerfactoEngine:
         return slice(o, o + s)
 
     def set_params(self, flat: torch.Tensor) -> None:
+        self._pending_head = None  # (a sampling prefix launched ahead read the old proposal networks)
         self.params.copy_(flat.to(self.device, torch.float32))
         self.sync_half()
 
@@ -676,6 +684,7 @@ class NerfactoEngine:
         stream = _stream(self.device)
         R = ws["R"]
         H, W = images.shape[1], images.shape[2]
+        self._pending_head = None  # (a prefix launched ahead by a pipelined graph is overwritten here)
         if corrections is None and self.cfg.optimize_poses:
             # CameraOptimizer.forward: exp_map_SE3(pose_adjustment) for every camera, gathered by raygen
             _call("nvo_pose_exp_map", stream, self.cfg.num_images,
@@ -693,10 +702,13 @@ class NerfactoEngine:
               _ptr(ws["directions"]), _ptr(ws["gt_rgb"]), _ptr(ws["gt_depth"]), _ptr(ws["gt_normal"]),
               _ptr(ws["dirs01"]))
         ws["dirs01_ready"] = True
+        ws["sh_ready"] = False  # (may be left set by the capture of a pipelined graph, which ends with a sampling prefix)
 
     def load_ray_bundle(self, ws, origins, directions, directions_norm, cam_idx, gt_rgb=None, gt_depth=None,
                         gt_normal=None):
         """Inject an existing ray bundle (+ targets) instead of generating rays from pixel indices."""
+        self._pending_head = None
+        ws["dirs01_ready"] = ws["sh_ready"] = False
         ws["origins"].copy_(origins)
         ws["directions"].copy_(directions)
         ws["directions_norm"].copy_(directions_norm.reshape(-1))
@@ -881,8 +893,8 @@ class NerfactoEngine:
             _call("nvo_pose_bwd_det", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
                   _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections), _ptr(ws["pose_det"]), cfg.num_images)
         else:
-            _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
-                  _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections))
+            _call("nvo_pose_bwd_cams", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+                  _ptr(ws["d_dir"]), _ptr(ws["d_dirs01"]), _ptr(self.d_corrections), cfg.num_images)
         # regulariser: its value goes to loss slot 5 of shard 0, its gradient is scaled like the rest
         dyn = cfg.dynamic_loss_scale
         reg_scale = (1.0 if dyn else cfg.loss_scale) / self.world_size
@@ -1061,9 +1073,19 @@ class NerfactoEngine:
                 self._graphs[vkey] = self._capture_step(dataset, R, v_upd, has_depth, v_groups, all_reduce is not None,
                                                         has_normals, v_val)
             entry = self._graphs[key]
-        if all_reduce is None:
+        if all_reduce is None and not entry.get("pipelined"):
+            self._pending_head = None
             self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
             entry["main"].replay()
+        elif all_reduce is None:
+            # single GPU, pipelined: this graph ends with [Adam of the fields group || sampling prefix of step + 1]
+            stamp = (step, getattr(dataset, "version", 0), extent)
+            if self._pending_head != stamp:  # not launched ahead (first step, new keyframes, eager work in between)
+                self._write_sampling_scalars(step)
+                entry["head"].replay()
+            self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step + 1)
+            entry["main"].replay()
+            self._pending_head = (step + 1, getattr(dataset, "version", 0), extent)
         else:
             stamp = (step, getattr(dataset, "version", 0), extent)
             if self._pending_head != stamp:  # not launched ahead (first step, new keyframes, externally set step)
@@ -1087,14 +1109,21 @@ class NerfactoEngine:
         dev = self.device
         cfg = self.cfg
         ws = self._workspace(R, True)
+        self._pending_head = None  # (the warm-up steps below overwrite a prefix launched ahead)
         intr = dataset.camera_intrinsics
         c2w_full = dataset.camera_extrinsics
         scale = self._pix_scale
-        c2w = torch.empty(c2w_full.shape[0], 3, 4, device=dev)
         anneal_ptr = self.dev_sampling.data_ptr()
-
-        ray_indices = torch.zeros((R, 3), dtype=torch.int64, device=dev)
-        jit = torch.zeros((3, R), dtype=torch.float32, device=dev)
+        # ONE set of pose / drawn-pixel / jitter buffers for all step variants of this ray count: a pipelined graph runs
+        # the NEXT step's prefix, and that step may replay another variant
+        if not hasattr(self, "_step_buffers"):
+            self._step_buffers = {}
+        bkey = (R, int(c2w_full.shape[0]))
+        if bkey not in self._step_buffers:
+            self._step_buffers[bkey] = (torch.empty(c2w_full.shape[0], 3, 4, device=dev),
+                                        torch.zeros((R, 3), dtype=torch.int64, device=dev),
+                                        torch.zeros((3, R), dtype=torch.float32, device=dev))
+        c2w, ray_indices, jit = self._step_buffers[bkey]
         # follows torch.manual_seed; the rank is mixed in so that data-parallel ranks never draw the same rays even when
         # every process was seeded identically (same multiplier as the data manager's rank-offset generator)
         rng_seed = int((torch.initial_seed() + 1000003 * self.rank) & 0xFFFFFFFF)
@@ -1170,8 +1199,9 @@ class NerfactoEngine:
                 wire, shard_out = self._wire_fields, self._shard_out
         # multi-GPU: the small groups (proposal networks, camera poses) are reduced and stepped FIRST -- the next
         # iteration's sampling prefix needs them -- the fields group last
-        groups_a = [g for g in groups if g != "fields"] if split else []
-        groups_b = ["fields"] if split else list(groups)
+        pipe1 = (not split) and bool(cfg.pipeline_single_gpu)  # single GPU: [fields Adam || next prefix]
+        groups_a = [g for g in groups if g != "fields"] if (split or pipe1) else []
+        groups_b = ["fields"] if (split or pipe1) else list(groups)
         fields_slot = self._GROUP_ORDER.index("fields")
         fields_flag = C.c_void_p(self.skip_flag.data_ptr() + 4 * fields_slot)
 
@@ -1258,6 +1288,8 @@ class NerfactoEngine:
                     program(False, lambda name, fn: fn())
                 else:
                     body_rest()
+                    if groups_a:
+                        body_opt(groups_a)
                     body_opt(groups_b)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -1275,12 +1307,30 @@ class NerfactoEngine:
                 fn()
             return g
 
-        if not split:
+        if not split and not pipe1:
             def whole():
                 body_head()
                 body_rest()
                 body_opt(groups_b)
             entry["main"] = capture(whole)
+            return entry
+        if pipe1:
+            opt_stream = torch.cuda.Stream(device=dev)
+
+            def whole_pipelined():
+                body_rest()
+                if groups_a:  # proposal networks / poses first: the next prefix reads them
+                    body_opt(groups_a)
+                cur = torch.cuda.current_stream(dev)
+                opt_stream.wait_stream(cur)
+                with torch.cuda.stream(opt_stream):
+                    body_opt(groups_b)
+                body_head()
+                cur.wait_stream(opt_stream)
+            entry["head"] = capture(body_head)
+            entry["main"] = capture(whole_pipelined)
+            entry["pipelined"] = True
+            entry["streams"] = (opt_stream,)
             return entry
 
         entry["head"] = capture(body_head)

@@ -358,8 +358,8 @@ class NgpEngine:
               _ptr(ws["d_dir"]))
         self.d_corrections.zero_()
         intr, c2w = self._pose_inputs
-        _call("nvo_pose_bwd", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
-              _ptr(ws["d_dir"]), None, _ptr(self.d_corrections))
+        _call("nvo_pose_bwd_cams", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
+              _ptr(ws["d_dir"]), None, _ptr(self.d_corrections), cfg.num_images)
         self.pose_grads.zero_()
         _call("nvo_se3_exp_map_bwd", stream, cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.d_corrections),
               cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, cfg.loss_scale / self.world_size, _ptr(self.pose_grads),

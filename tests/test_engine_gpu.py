@@ -704,6 +704,56 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     _assert_close(g_det, g_def, rtol=1e-3, atol_scale=1e-5, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
+def test_pipelined_prefix_is_bit_identical_on_one_gpu(device):
+    """EngineConfig.pipeline_single_gpu: the graph ends with [Adam of the fields group || sampling prefix of the NEXT
+    step] -- the launch order the multi-GPU step uses around its exchange, on one GPU.  The reordering must not change
+    a single bit of the parameters: same seed, deterministic mode, with and without the pipelining, across the
+    proposal-update schedule (the next step may replay another graph variant), a keyframe ingest (the prefix launched
+    ahead saw the old buffer and has to be redone) and an eager step in between (which overwrites the workspace).
+    (The reported loss VALUES are summed with float atomics in every mode: compared to 1e-5.)"""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 8, 60, 80, 512
+    seq = make_sequence(n, H, W, device=device)
+
+    def ingest(ds, lo, hi):
+        ds.update({"keyframe_indices": torch.arange(lo, hi), "camera_intrinsics": seq["camera_intrinsics"][lo:hi],
+                   "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"][lo:hi]),
+                   "frames_color": seq["frames_color"][lo:hi], "frames_depth": seq["frames_depth"][lo:hi]})
+
+    def run(pipeline: bool):
+        torch.manual_seed(3)
+        ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+        ingest(ds, 0, 5)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=True, deterministic=True,
+                                          pipeline_single_gpu=pipeline), device)
+        gen = torch.Generator(device=device).manual_seed(9)
+        losses = []
+        for it in range(26):
+            if it == 14:
+                ingest(ds, 5, 8)
+            if it == 20:  # an eager step on the same workspace between two replays
+                extent = torch.tensor([ds.num_active_frames, H, W], device=device)
+                idx = torch.floor(torch.rand(R, 3, device=device, generator=gen) * extent).long()
+                eng.train_step(idx, ds.camera_intrinsics, ds.camera_extrinsics[:, :3, :4].contiguous(), ds.frames_color,
+                               ds.frames_depth)
+            eng.train_step_graphed(ds)
+            losses.append(eng.loss_totals().clone())
+        torch.cuda.synchronize()
+        assert int(eng.skip_flag.sum()) == 0
+        pipelined = any(e.get("pipelined") for e in eng._graphs.values())
+        return eng.params.clone(), eng.exp_avg_sq.clone(), torch.stack(losses), pipelined
+
+    a, b = run(True), run(False)
+    assert a[3] and not b[3]
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-12), "losses differ between the two launch orders"
+    for name, x, y in (("params", a[0], b[0]), ("exp_avg_sq", a[1], b[1])):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), \
+            f"{name}: {int((x != y).sum())} of {x.numel()} entries differ between the pipelined and the plain graph"
+
+
 @pytest.mark.parametrize("scale,expect", [(128.0, False), (1.0e10, True)], ids=["in-range", "overflow"])
 def test_producer_overflow_flags_match_the_scan(device, scale, expect):
     """GradScaler's found_inf raised at the source (EngineConfig.producer_overflow_flags): the kernels that store a
@@ -799,6 +849,42 @@ def test_native_scratch_survives_larger_batches_between_replays(device):
         f"replays after a larger eager batch diverged from the uninterrupted run: relative L1 "
         f"{float((upd_a - upd_b).abs().sum() / upd_a.abs().sum()):.3e}")
     assert abs(loss_a["rgb_loss"] - loss_b["rgb_loss"]) <= 1e-4 * loss_a["rgb_loss"], (loss_a, loss_b)
+
+
+@pytest.mark.parametrize("R,F", [(7552, 48), (4096, 192), (1500, 1)], ids=["ngp-48cams-table", "nerfacto-192cams-plain", "one-camera-table"])
+def test_pose_bwd_lds_table_matches_global_atomics(device, R, F):
+    """nvo_pose_bwd_cams (per-workgroup camera table in LDS, flushed once) vs nvo_pose_bwd (one global float atomic per
+    ray and word) vs a float64 torch restatement of the sum: dL/dcorrection[cam] = [dL/dd (x) d_raw | dL/do].  Both
+    kernels add floats in no fixed order: rtol 1e-4 of the largest entry."""
+    from nerf_vo_amd.engine import _call, _ptr, _stream
+
+    g = torch.Generator().manual_seed(R + F)
+    H, W = 48, 64
+    idx = torch.stack([torch.randint(0, F, (R,), generator=g), torch.randint(0, H, (R,), generator=g),
+                       torch.randint(0, W, (R,), generator=g)], dim=1).to(device)
+    intr = torch.tensor([[60.0, 61.0, W / 2, H / 2]]).repeat(F, 1) + torch.rand(F, 4, generator=g)
+    rot = torch.linalg.qr(torch.randn(F, 3, 3, generator=g)).Q
+    c2w = torch.cat([rot, torch.randn(F, 3, 1, generator=g)], dim=2).contiguous()
+    d_o, d_d, d_d01 = (torch.randn(R, 3, generator=g) for _ in range(3))
+    dev = [t.to(device).contiguous() for t in (intr, c2w, d_o, d_d, d_d01)]
+    out = {}
+    for name in ("nvo_pose_bwd", "nvo_pose_bwd_cams"):
+        acc = torch.zeros(F, 3, 4, device=device)
+        extra = (F,) if name.endswith("cams") else ()
+        _call(name, _stream(device), R, _ptr(idx), _ptr(dev[0]), _ptr(dev[1]), _ptr(dev[2]), _ptr(dev[3]), _ptr(dev[4]),
+              _ptr(acc), *extra)
+        out[name] = acc.cpu().double()
+    cam, py, px = idx[:, 0].cpu(), idx[:, 1].cpu().double() + 0.5, idx[:, 2].cpu().double() + 0.5
+    it = intr.double()[cam]
+    raw = torch.stack([(px - it[:, 2]) / it[:, 0], -(py - it[:, 3]) / it[:, 1], -torch.ones(R, dtype=torch.float64)], dim=1)
+    d0 = torch.einsum("rij,rj->ri", c2w.double()[cam][:, :, :3], raw)
+    d0 = d0 / d0.norm(dim=1, keepdim=True)
+    gd = d_d.double() + 0.5 * d_d01.double()
+    per_ray = torch.cat([gd[:, :, None] * d0[:, None, :], d_o.double()[:, :, None]], dim=2)  # [R][3][4]
+    ref = torch.zeros(F, 3, 4, dtype=torch.float64).index_add_(0, cam, per_ray)
+    tol = 1e-4 * float(ref.abs().max())
+    for name, got in out.items():
+        assert float((got - ref).abs().max()) <= tol, (name, float((got - ref).abs().max()), tol)
 
 
 @pytest.mark.parametrize("mode", ["SE3", "SO3xR3"])

@@ -234,6 +234,13 @@ def test_configs4_graphed_step_at_full_size(device):
     torch.cuda.synchronize()
     key = next(k for k in eng._graphs if k[1])  # the variant that just ran (with the proposal update)
     assert key[4] is True, "the captured step does not carry normal supervision"
+    if eng._graphs[key].get("pipelined"):
+        # the graph already ran the sampling prefix of step 1 beside the optimiser: draw step 0's rays again (the
+        # sampler is a stateless function of (seed, step)) so that the eager step below sees the same pixels
+        eng._write_sampling_scalars(0)
+        eng._graphs[key]["head"].replay()
+        eng._pending_head = None
+        torch.cuda.synchronize()
     _, drawn, jit, _, _ = eng._graphs[key]["buffers"]
     idx, jit = drawn.clone(), jit.clone()
     assert int(idx.min()) >= 0 and bool((idx.max(dim=0).values < torch.tensor([n, H, W], device=device)).all())
