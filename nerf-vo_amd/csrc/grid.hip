@@ -522,7 +522,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               uint32_t chunk, uint32_t n_chunks, void* lds_raw,
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
                                               const uint32_t* __restrict__ live = nullptr, bool merge = false,
-                                              uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr) {
+                                              uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr,
+                                              const uint32_t* __restrict__ live_n = nullptr) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -530,9 +531,9 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     const uint32_t hashed = g.hashed[level];
     const float scale = g.scale[level];
     const uint32_t count = min(slice_cap, size - first);  // slice_cap <= ACC::kEntries
-    // live != nullptr: live[0] = number of samples with a non-zero gradient, live[1 + j] = their ids; the chunks then
+    // live != nullptr: *live_n = number of samples with a non-zero gradient, live[j] = their ids; the chunks then
     // partition that list.  (A list that holds most of the samples is not worth the indirection: identity scan.)
-    const uint32_t n_live = live ? live[0] : N;
+    const uint32_t n_live = live ? *live_n : N;
     const bool listed = live != nullptr && n_live < N - (N >> 2);
     const uint32_t n_scan = listed ? n_live : N;
     // A short list does not need all of a slice's chunks: an item costs ~10 us of zeroing / flushing / barriers
@@ -650,7 +651,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             if (!done) {
                 const uint32_t stop = min(end, b0 + kRun);
                 for (uint32_t j = b0; j < stop; ++j) {
-                    const uint32_t i = listed ? live[1u + j] : j;
+                    const uint32_t i = listed ? live[j] : j;
                     const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
                     visit(x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2], dy2f(d2));
                 }
@@ -665,7 +666,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {  // (one extra round trip per pass when the list is used)
             const uint32_t j = i0 + u * kLdsBwdBlock;
-            sid[u] = j < end ? (listed ? live[1u + j] : j) : 0u;
+            sid[u] = j < end ? (listed ? live[j] : j) : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {
@@ -815,7 +816,7 @@ __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
                const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
-               const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag) {
+               const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
@@ -823,7 +824,7 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     const uint32_t level = item.x & 0xFFu, cap = item.x >> 8;  // cap: entries per slice of this level
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
     } else if ((item.w >> 30) & 1u) {
         const float l1x = (float)l1[2 * level] * (1.f / 256.f), l1y = (float)l1[2 * level + 1] * (1.f / 256.f);
         AccScale sc;
@@ -832,15 +833,16 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
         grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge, cap, nf_flag);
+                                            merge, cap, nf_flag, live_n);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
     }
 }
 
-// List of the samples whose dL/dy is non-zero on any level (NvoGridSlices::compact_live): out[0] = count (zeroed by
-// the launcher), out[1 + k] = sample id.  Workgroup-aggregated append; the order of the workgroups is not
+// List of the samples whose dL/dy is non-zero on any level (NvoGridSlices::compact_live): *count = their number (a word
+// of the module's permanent state, zeroed by the launcher or -- external_zero -- by the step's single zero launch),
+// out[k] = sample id.  Workgroup-aggregated append; the order of the workgroups is not
 // deterministic.  For the per-sample scan that only moves samples between the chunks of an item (integer accumulation
 // is order-free, chunked items combine with float atomics either way); with the run-merging scan (grid_bwd_runs) a lane
 // sums 8 LIST-consecutive samples in fp32 before the conversion, so which samples share a run -- hence the rounding of
@@ -848,8 +850,8 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 // deterministic mode therefore scans all samples).
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(1024)
-k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ out,
-               unsigned long long* __restrict__ l1) {
+k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ count,
+               uint32_t* __restrict__ out, unsigned long long* __restrict__ l1) {
     // l1 != nullptr (32-bit accumulators, <= 8 levels): the per-level L1 norms of dy that k_dy_l1 computes are summed
     // in the same pass -- both kernels read every dy once, and each cost ~14 us per 1 M-sample launch
     // one workgroup per 4096 consecutive samples, ONE global atomic per workgroup (a wave-level append put 16 K atomics
@@ -918,14 +920,14 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
             wave_cnt[w] = tot;
             tot += c;
         }
-        block_base = tot ? atomicAdd(out, tot) : 0u;
+        block_base = tot ? atomicAdd(count, tot) : 0u;
     }
     __syncthreads();
     uint32_t pos = block_base + wave_cnt[wib];
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) {
         const unsigned long long m = __ballot(live[q]);
-        if (live[q]) out[1u + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = first + q * 1024u + threadIdx.x;
+        if (live[q]) out[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = first + q * 1024u + threadIdx.x;
         pos += (uint32_t)__popcll(m);
     }
 }
@@ -2408,9 +2410,11 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         s->d_level = s->d_first = nullptr;
         return NVO_OK;
     }
-    // [items | L1 norms (u64 [levels][2], used by the 32-bit accumulators)]
-    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size() + sizeof(unsigned long long) * 2 * NVO_MAX_LEVELS));
-    s->d_l1 = reinterpret_cast<unsigned long long*>(s->d_level + 4 * all.size());
+    // [items | length of the live-sample list (one u64 slot) | L1 norms (u64 [levels][2], used by the 32-bit accumulators)]
+    NVO_CHECK_HIP(hipMalloc((void**)&s->d_level, sizeof(Item) * all.size() + sizeof(unsigned long long) * (1 + 2 * NVO_MAX_LEVELS)));
+    s->d_live_n = reinterpret_cast<uint32_t*>(s->d_level + 4 * all.size());
+    NVO_CHECK_HIP(hipMemset(s->d_live_n, 0, sizeof(unsigned long long)));
+    s->d_l1 = reinterpret_cast<unsigned long long*>(s->d_live_n) + 1;
     s->d_first = nullptr;
     NVO_CHECK_HIP(hipMemcpy(s->d_level, all.data(), sizeof(Item) * all.size(), hipMemcpyHostToDevice));
     return NVO_OK;
@@ -2421,13 +2425,16 @@ void nvo_grid_slices_destroy(NvoGridSlices* s) {
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
     s->d_l1 = nullptr;
+    s->d_live_n = nullptr;
     s->n_slices = 0;
 }
 
 void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s, float* grad, NvoZeroRanges* out) {
     if (s->zero_last > s->zero_first)
         out->push_back({grad + 2 * (size_t)s->zero_first, sizeof(float) * 2 * (size_t)(s->zero_last - s->zero_first)});
-    if (s->acc_bits == 32 && s->d_l1) out->push_back({s->d_l1, sizeof(unsigned long long) * 2 * g.n_levels});
+    // the live-list length and, behind it, the L1 norms of the 32-bit accumulators: one range
+    if (s->d_live_n)
+        out->push_back({s->d_live_n, sizeof(unsigned long long) * (1 + (s->acc_bits == 32 ? 2 * g.n_levels : 0))});
 }
 
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out) {
@@ -2927,14 +2934,15 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             if (int rc = nvo_scratch_reserve(&slices->live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list"))
                 return rc;
             uint32_t* const d_live = static_cast<uint32_t*>(slices->live.ptr);
-            if (int rc = nvo_zero_async(d_live, sizeof(uint32_t), stream)) return rc;
+            if (!slices->external_zero)  // (otherwise cleared by the step's zero launch: nvo_grid_slices_zero_ranges)
+                if (int rc = nvo_zero_async(slices->d_live_n, sizeof(uint32_t), stream)) return rc;
             // (32-bit accumulators, <= 8 levels: the L1 norms of dy ride in the same pass)
             l1_fused = slices->acc_bits == 32 && g.n_levels <= 8 && dy_fmt != NVO_DY_FLOAT;
             if (l1_fused && !slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
 #define NVO_LAUNCH_LIVE(SOA_, T_)                                                                                    \
     NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, \
-               d_live, l1_fused ? slices->d_l1 : nullptr)
+               slices->d_live_n, d_live, l1_fused ? slices->d_l1 : nullptr)
             if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
 #undef NVO_LAUNCH_LIVE
             live = d_live;
@@ -2968,7 +2976,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag); \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag, slices->d_live_n); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

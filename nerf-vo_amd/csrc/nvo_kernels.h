@@ -19,6 +19,7 @@ struct NvoGridSlices {
     uint32_t acc_bits = 64;                  // 32: int32 accumulators with the L1-derived scale (set before create)
     uint32_t level_mask = 0xFFFFFFFFu;       // (set by create) levels that have items: the L1 pre-pass reads only those
     unsigned long long* d_l1 = nullptr;      // [levels][2] L1 norms of dy (inside the d_level allocation)
+    uint32_t* d_live_n = nullptr;            // length of the live-sample list (inside the d_level allocation, before d_l1)
     // dynamic LDS the launch asks for: 160 KiB only when an item accumulates in fp32 (20K-entry slices), else 128 KiB
     // -- which leaves 32 KiB of a CU's LDS to a concurrently running kernel (the record scatter of mode 3)
     uint32_t lds_bytes = 160 * 1024;
