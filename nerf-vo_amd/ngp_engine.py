@@ -104,6 +104,11 @@ class NgpEngine:
         # samples); with extrinsics optimisation the forward stores d(encoded)/d(position) for a streamed input backward
         self.density_net.set_option("grid_bwd_mode", 3)
         self.density_net.set_option("grid_stream_acc_bits", 32)  # packed 2 x 32-bit fixed-point record accumulate
+        # the coarse (dense) levels that stay slice-owner: int32 accumulators with the L1-derived scale, run-merging scan,
+        # chunk table sized for the packed capacity -- what the nerfacto main grid uses (76 -> ~35 us)
+        self.density_net.set_option("grid_acc_bits", 32)
+        self.density_net.set_option("grid_bwd_runs", 1)
+        self.density_net.set_option("grid_bwd_batch", int(cfg.capacity))
         self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
         self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
         self.n_density_mlp = 64 * 32 + 16 * 64
