@@ -1731,6 +1731,7 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
 constexpr uint32_t kBinP = 8192;   // largest bin of the packed form (13-bit entry index in a record)
 constexpr uint32_t kBinPSmall = 6176;  // (experiment, NVO_TL_BIN=6176: 85 bins per 2^19 table; measured slower)
 constexpr int kTlBlockP = 512;
+constexpr uint32_t kTlWinP = 14;  // wave loads of pair records per pass (a hashed item's 48 runs x ~32 pairs per wave = 24 loads)
 
 template <uint32_t BIN>
 __device__ __forceinline__ uint32_t st_bin_entries_p(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
@@ -1766,22 +1767,40 @@ __device__ __forceinline__ uint32_t bf16_up(float v) {  // smallest bfloat16 >= 
     return u >> 16;
 }
 
+// PAIR records (12 bytes).  Both x corners of a (y, z) pair of a cell fall into the same bin (hashed levels: their
+// indices differ by the xor mask px ^ (px + 1), which stays below the bin size; dense levels: they are neighbours), so
+// one record carries the pair: u_f = w_y w_z dy_f (the two features, fp32 with the low 6 / 7 mantissa bits replaced by
+// the first corner's 13-bit entry offset, as the per-corner records of k_tl_scatter), the x weight as a 16-bit fraction
+// and a 4-bit code for the second corner's offset (0..12: rel ^ ((2 << code) - 1), 15: rel + 1, 14: no second corner).
+// The accumulate item splits u into (1 - w) u and w u.  Three quarters of the record bytes and half the records of the
+// per-corner form; a pair that does straddle two bins (a dense level's bin boundary, resolutions beyond the bin size)
+// is written as two single-corner records.
+constexpr uint32_t kPairSingle = 14u, kPairNext = 15u;
+struct PairRec {
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ PairRec pair_pack(uint32_t rel, float u0, float u1, uint32_t wq, uint32_t code) {
+    const uint32_t a = __float_as_uint(u0) + 0x20u;  // round to nearest at bit 6
+    const uint32_t b = __float_as_uint(u1) + 0x40u;  // ... at bit 7
+    return PairRec{(a & ~0x3Fu) | (rel & 0x3Fu), (b & ~0x7Fu) | (rel >> 6), (wq & 0xFFFFu) | (code << 16)};
+}
+
 template <int TILE, bool SOA, typename DY2, uint32_t BIN>
 __global__ void __launch_bounds__(TILE)
 k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
-               uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint2* __restrict__ records) {
+               uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint32_t* __restrict__ records) {
     constexpr uint32_t kStBlock = TILE;
-    constexpr uint32_t kStRecords = TILE * 8;
+    constexpr uint32_t kStRecords = TILE * 8;  // capacity: every pair split into two single-corner records
     constexpr uint32_t kWaves = TILE / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(lds_raw);  // [kStRecords][3]
     const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
     const uint32_t bin0 = bin_first[blockIdx.y];
     const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
     const uint32_t size = g.offset[level + 1] - g.offset[level];
     const uint32_t res = g.resolution[level], hashed = g.hashed[level];
-    unsigned long long* hist = reinterpret_cast<unsigned long long*>(stage + kStRecords);
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(stage + 3 * kStRecords);
     uint32_t* loff = reinterpret_cast<uint32_t*>(hist + n_slices);
     __shared__ uint32_t total_s;
     __shared__ float wmax[kWaves][2];
@@ -1815,35 +1834,47 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
         M1 = fmaxf(M1, wmax[w][1]);
     }
     const float q0s = M0 > 0.f ? 1023.f / M0 : 0.f, q1s = M1 > 0.f ? 1023.f / M1 : 0.f;
-    uint32_t idx[8], slot[8];
-    float v0[8], v1[8];
+    // per (y, z) pair j: one pair record (n_rec = 1) or two single-corner records (n_rec = 2)
+    uint32_t bin_a[4], bin_b[4], slot_a[4], slot_b[4];
+    PairRec rec_a[4], rec_b[4];
+    bool split[4];
     const bool finite = fabsf(d.x) < INFINITY && fabsf(d.y) < INFINITY;
     if (live) {
         const Corner c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
-            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                            ((k & 4u) ? c.wz : 1.f - c.wz);
-            v0[k] = w * d.x;
-            v1[k] = w * d.y;
-        }
+        const uint32_t wq = min(65535u, (uint32_t)__float2int_rn(c.wx * 65536.f));
+        const float fb = (float)wq * (1.f / 65536.f), fa = 1.f - fb;
         // magnitude of a record in units of M / 1023, rounded UP (+1 covers the rounding of the product); <= 1024
         auto quant = [&](float v, float qs) -> unsigned long long {
             return finite ? (unsigned long long)min(1024u, (uint32_t)(fabsf(v) * qs) + 1u) : 0ull;
         };
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {  // rank inside (tile, bin) + magnitude sums: ONE LDS atomic per x-corner pair
-            const uint32_t b0 = idx[2 * j] / BIN, b1 = idx[2 * j + 1] / BIN;
-            const unsigned long long m_a = (quant(v0[2 * j], q0s) << 16) | (quant(v1[2 * j], q1s) << 40);
-            const unsigned long long m_b = (quant(v0[2 * j + 1], q0s) << 16) | (quant(v1[2 * j + 1], q1s) << 40);
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t cy = c.py + (j & 1u), cz = c.pz + (j >> 1);
+            const uint32_t i0 = nvo_grid_index(hashed, size, res, c.px, cy, cz);
+            const uint32_t i1 = nvo_grid_index(hashed, size, res, c.px + 1u, cy, cz);
+            const float wyz = ((j & 1u) ? c.wy : 1.f - c.wy) * ((j & 2u) ? c.wz : 1.f - c.wz);
+            const float u0 = wyz * d.x, u1 = wyz * d.y;
+            const uint32_t b0 = i0 / BIN, b1 = i1 / BIN, r0 = i0 % BIN, r1 = i1 % BIN;
+            bin_a[j] = b0;
+            bin_b[j] = b1;
+            // second corner's offset from the first: xor with a low mask (hashed levels) or + 1 (dense levels)
+            const uint32_t xm = r0 ^ r1;
+            uint32_t code = kPairSingle;
             if (b0 == b1) {
-                const uint32_t r0 = (uint32_t)(atomicAdd(&hist[b0], 2ull + m_a + m_b) & 0xFFFFull);
-                slot[2 * j] = r0;
-                slot[2 * j + 1] = r0 + 1u;
+                if (r1 == r0 + 1u) code = kPairNext;
+                else if ((xm & (xm + 1u)) == 0u && xm != 0u && xm <= 0x1FFFu) code = 31u - (uint32_t)__builtin_clz(xm);
+            }
+            split[j] = code == kPairSingle;
+            if (!split[j]) {
+                // rank inside (tile, bin) + magnitude sums: ONE LDS atomic per pair (|v_a| + |v_b| = |u|)
+                rec_a[j] = pair_pack(r0, u0, u1, wq, code);
+                slot_a[j] = (uint32_t)(atomicAdd(&hist[b0], 1ull | (quant(u0, q0s) << 16) | (quant(u1, q1s) << 40)) & 0xFFFFull);
             } else {
-                slot[2 * j] = (uint32_t)(atomicAdd(&hist[b0], 1ull + m_a) & 0xFFFFull);
-                slot[2 * j + 1] = (uint32_t)(atomicAdd(&hist[b1], 1ull + m_b) & 0xFFFFull);
+                const float a0 = fa * u0, a1 = fa * u1, c0 = fb * u0, c1 = fb * u1;
+                rec_a[j] = pair_pack(r0, a0, a1, 0u, kPairSingle);
+                rec_b[j] = pair_pack(r1, c0, c1, 0u, kPairSingle);
+                slot_a[j] = (uint32_t)(atomicAdd(&hist[b0], 1ull | (quant(a0, q0s) << 16) | (quant(a1, q1s) << 40)) & 0xFFFFull);
+                slot_b[j] = (uint32_t)(atomicAdd(&hist[b1], 1ull | (quant(c0, q0s) << 16) | (quant(c1, q1s) << 40)) & 0xFFFFull);
             }
         }
     }
@@ -1869,25 +1900,36 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     __syncthreads();
     if (live) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            stage[loff[idx[k] / BIN] + slot[k]] = rec_pack(idx[k] % BIN, v0[k], v1[k]);
+        for (uint32_t j = 0; j < 4; ++j) {
+            uint32_t* r = stage + 3u * (loff[bin_a[j]] + slot_a[j]);
+            r[0] = rec_a[j].w0;
+            r[1] = rec_a[j].w1;
+            r[2] = rec_a[j].w2;
+            if (split[j]) {
+                uint32_t* r2 = stage + 3u * (loff[bin_b[j]] + slot_b[j]);
+                r2[0] = rec_b[j].w0;
+                r2[1] = rec_b[j].w1;
+                r2[2] = rec_b[j].w2;
+            }
+        }
     }
     __syncthreads();
     const uint32_t total = total_s;
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(records + ((size_t)blockIdx.y * n_tiles + tile) * kStRecords);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(records + 3u * ((size_t)blockIdx.y * n_tiles + tile) * kStRecords);
     const uint4* src = reinterpret_cast<const uint4*>(stage);
-    for (uint32_t t = threadIdx.x; t < (total + 1u) / 2u; t += kStBlock) dst[t] = src[t];
+    for (uint32_t t = threadIdx.x; t < (3u * total + 3u) / 4u; t += kStBlock) dst[t] = src[t];
 }
 
 template <uint32_t BIN>
 __global__ void __launch_bounds__(kTlBlockP)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
-                  const uint32_t* __restrict__ segl1, const uint2* __restrict__ records, uint32_t n_tiles,
+                  const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
                   uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
     __shared__ float wpart[kWaves][2];
+    __shared__ uint32_t run_incl[kWaves][64], run_base[kWaves][64];  // per wave: the runs of its current tile block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t it = blockIdx.x;
@@ -1922,7 +1964,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             uint4* z = reinterpret_cast<uint4*>(lds_raw);  // one uint4 = two entries
             for (uint32_t e = threadIdx.x; e < (entries + 1u) / 2u; e += kTlBlockP) z[e] = make_uint4(0u, 0u, 0u, 0u);
         }
-        const uint2* __restrict__ rec_lvl = records + (size_t)cur.lvl * n_tiles * tile_records;
+        const uint32_t* __restrict__ rec_lvl = records + 3u * ((size_t)cur.lvl * n_tiles * tile_records);
         const uint32_t n_span = cur.t1 - cur.t0;
         const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
         const uint32_t tile_first = cur.t0 + min(n_span, wib * per_wave);
@@ -1949,16 +1991,25 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             L0 += wpart[w][0];
             L1 += wpart[w][1];
         }
-        // |sum over an entry| <= L; rounding of each add <= 0.5: n <= 2^20 records leave 2^29 + 2^19 < 2^31
+        // |sum over an entry| <= L (a pair's two shares add up to |u|); rounding of each add <= 0.5: n <= 2^20 adds
+        // leave 2^29 + 2^19 < 2^31
         const float s0 = L0 > 0.f ? 536870912.f / L0 : 0.f, s1 = L1 > 0.f ? 536870912.f / L1 : 0.f;
         const float inv0 = L0 * (1.f / 536870912.f), inv1 = L1 * (1.f / 536870912.f);
         bool bad = false;
-        auto add = [&](uint2 r) {
-            const uint32_t rel = (r.x & 0x3Fu) | ((r.y & 0x7Fu) << 6);
-            const int a = __float2int_rn(__uint_as_float(r.x & ~0x3Fu) * s0);
-            const int b = __float2int_rn(__uint_as_float(r.y & ~0x7Fu) * s1);
-            const long long X = (long long)a + ((long long)b << 32);
-            atomicAdd(&acc[rel], (unsigned long long)X);
+        auto add = [&](const PairRec& r) {
+            const uint32_t rel = (r.w0 & 0x3Fu) | ((r.w1 & 0x7Fu) << 6);
+            const uint32_t code = (r.w2 >> 16) & 0xFu;
+            const float u0 = __uint_as_float(r.w0 & ~0x3Fu) * s0, u1 = __uint_as_float(r.w1 & ~0x7Fu) * s1;
+            const float fb = code == kPairSingle ? 0.f : (float)(r.w2 & 0xFFFFu) * (1.f / 65536.f), fa = 1.f - fb;
+            {
+                const long long X = (long long)__float2int_rn(u0 * fa) + ((long long)__float2int_rn(u1 * fa) << 32);
+                atomicAdd(&acc[rel], (unsigned long long)X);
+            }
+            if (code != kPairSingle) {
+                const uint32_t rel_b = code == kPairNext ? rel + 1u : rel ^ ((2u << code) - 1u);
+                const long long X = (long long)__float2int_rn(u0 * fb) + ((long long)__float2int_rn(u1 * fb) << 32);
+                atomicAdd(&acc[rel_b], (unsigned long long)X);
+            }
         };
         TlItem nxt = cur;
         uint32_t segw_next = 0u, l1w_next = 0u;
@@ -1971,26 +2022,22 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t base = (tile_first + j0 + lane) * tile_records + (segw & 0xFFFFu) - (incl - cnt);
-            uint32_t r_s = 0u;  // (scalar) first run that reaches into the current window
-            for (uint32_t q0 = 0; q0 * 64u < total; q0 += kTlWin) {
-                uint2 rec[kTlWin];
+            // record v of the concatenated runs belongs to the first run r with incl[r] > v: a 6-step binary search in
+            // the wave's 64-entry table in LDS, all windows of a pass searched side by side (the dependent readlane
+            // walk over run boundaries this replaces cost as many cycles as the loads and atomics together)
+            run_incl[wib][lane] = incl;
+            run_base[wib][lane] = base;
+            for (uint32_t q0 = 0; q0 * 64u < total; q0 += kTlWinP) {
+                PairRec rec[kTlWinP];
 #pragma unroll
-                for (uint32_t u = 0; u < kTlWin; ++u) {
-                    const uint32_t w0 = (q0 + u) * 64u;  // uniform
-                    const uint32_t v = w0 + lane;
-                    uint32_t my_base = 0u;
-                    if (w0 < total) {
-                        uint32_t end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r_s);
-                        while (end_r <= w0) end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)++r_s);
-                        my_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r_s);
-                        for (uint32_t r = r_s; end_r < w0 + 64u && r < 63u;) {
-                            ++r;
-                            const uint32_t b_r = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r);
-                            my_base = v >= end_r ? b_r : my_base;
-                            end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r);
-                        }
-                    }
-                    rec[u] = rec_lvl[v < total ? my_base + v : 0u];
+                for (uint32_t u = 0; u < kTlWinP; ++u) {
+                    const uint32_t v = (q0 + u) * 64u + lane;
+                    uint32_t r = 0u;
+#pragma unroll
+                    for (uint32_t step = 32u; step >= 1u; step >>= 1) r += run_incl[wib][r + step - 1u] <= v ? step : 0u;
+                    const uint32_t my_base = run_base[wib][min(r, 63u)];
+                    const uint32_t* __restrict__ rw = rec_lvl + 3u * (v < total ? my_base + v : 0u);  // one 12-byte load
+                    rec[u] = PairRec{rw[0], rw[1], rw[2]};
                 }
                 if (!next_requested) {  // the next item's segment / L1 words ride behind this item's loads
                     next_requested = true;
@@ -2000,7 +2047,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < kTlWin; ++u)
+                for (uint32_t u = 0; u < kTlWinP; ++u)
                     if ((q0 + u) * 64u + lane < total) add(rec[u]);
             }
         }
@@ -2747,9 +2794,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     if (st->n_bins == 0) return NVO_OK;
     if (st->tile_local) {
         const size_t tile_records = (size_t)tile * 8;
-        const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * sizeof(uint2), 256);
+        const bool packed = st->acc_bits == 32;  // (12-byte pair records; the 64-bit form keeps 8-byte corner records)
+        const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * (packed ? 12 : sizeof(uint2)), 256);
         const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
-        const bool packed = st->acc_bits == 32;
         const size_t need_tl = rec_bytes_tl + seg_bytes * (packed ? 2 : 1);
         if (int rc = nvo_scratch_reserve(&st->work, need_tl, stream, "grid_bwd_stream records")) return rc;
         unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
@@ -2793,25 +2840,25 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     } while (0)
         if (packed) {
             // two 32-bit fixed-point sums per 64-bit accumulator word, 8192-entry bins (k_tl_scatter_p / k_tl_accumulate_p)
-            NVO_REQUIRE(tile == 512, "grid_bwd_stream: the packed accumulators are built for 512-sample tiles");
+            NVO_REQUIRE(tile == 512 || tile == 1024, "grid_bwd_stream: the packed accumulators take 512- or 1024-sample tiles");
             uint32_t* segl1 = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl + seg_bytes);
-            const size_t lds_p = tile_records * sizeof(uint2) + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
+            const size_t lds_p = tile_records * 12 + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
             const size_t lds_acc_p = sizeof(unsigned long long) * st->bin_entries;
             const uint32_t acc_grid = st->n_tl_slots ? st->n_tl_slots : (st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus);
-#define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_)                                                                      \
+#define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_, TILE_)                                                               \
     do {                                                                                                      \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<512, SOA_, T_, BIN_>,               \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(512 * 64 + 12 * 4096))); \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<TILE_, SOA_, T_, BIN_>,             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TILE_ * 96 + 12 * 4096))); \
             NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p<BIN_>,                           \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * BIN_)));  \
             attr_set = true;                                                                                  \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
-            NVO_LAUNCH((k_tl_scatter_p<512, SOA_, T_, BIN_>), grid_tl, dim3(512), lds_p, stream, g, N, x, (const T_*)dy, \
-                       st->d_levels, st->d_bin_first, seg, segl1, records_tl);                                 \
+            NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
+                       st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl));    \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
@@ -2819,14 +2866,16 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
                 NVO_LAUNCH(k_st_zero_p<BIN_>, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                            st->d_bin_chunks, grad);                                                           \
             NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
-                       (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1, records_tl, n_tiles,         \
+                       (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1,                              \
+                       reinterpret_cast<const uint32_t*>(records_tl), n_tiles,                                \
                        (uint32_t)tile_records, grad, st->owner.nf_flag);                                      \
         }                                                                                                     \
     } while (0)
 #define NVO_LAUNCH_TLP(SOA_, T_)                                                           \
     do {                                                                                   \
-        if (st->bin_entries == kBinP) NVO_LAUNCH_TLP_B(SOA_, T_, kBinP);                   \
-        else NVO_LAUNCH_TLP_B(SOA_, T_, kBinPSmall);                                       \
+        if (st->bin_entries != kBinP) NVO_LAUNCH_TLP_B(SOA_, T_, kBinPSmall, 512);         \
+        else if (tile == 1024) NVO_LAUNCH_TLP_B(SOA_, T_, kBinP, 1024);                    \
+        else NVO_LAUNCH_TLP_B(SOA_, T_, kBinP, 512);                                       \
     } while (0)
             if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
 #undef NVO_LAUNCH_TLP
