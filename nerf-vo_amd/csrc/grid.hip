@@ -1731,7 +1731,10 @@ k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_ite
 constexpr uint32_t kBinP = 8192;   // largest bin of the packed form (13-bit entry index in a record)
 constexpr uint32_t kBinPSmall = 6176;  // (experiment, NVO_TL_BIN=6176: 85 bins per 2^19 table; measured slower)
 constexpr int kTlBlockP = 512;
-constexpr uint32_t kTlWinP = 14;  // wave loads of pair records per pass (a hashed item's 48 runs x ~32 pairs per wave = 24 loads)
+// wave loads of pair records per pass (a hashed item's 48 runs x ~32 pairs per wave = 24 loads).  14 is what 128 VGPRs
+// hold (5 per window); 24 in one pass needs 175 and halves the occupancy (81 us), 256-thread workgroups with 32 windows
+// measured 69.7 us against 52.2
+constexpr uint32_t kTlWinP = 14;
 
 template <uint32_t BIN>
 __device__ __forceinline__ uint32_t st_bin_entries_p(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
@@ -1791,7 +1794,9 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
                uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint32_t* __restrict__ records) {
     constexpr uint32_t kStBlock = TILE;
-    constexpr uint32_t kStRecords = TILE * 8;  // capacity: every pair split into two single-corner records
+    // capacity: every pair split into two single-corner records.  (Staging only TILE * 4 records in LDS -- four workgroups
+    // per CU instead of three -- with the overflow written straight to the region measured SLOWER: 42.5 -> 48.5 us.)
+    constexpr uint32_t kStRecords = TILE * 8;
     constexpr uint32_t kWaves = TILE / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(lds_raw);  // [kStRecords][3]
