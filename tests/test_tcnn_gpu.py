@@ -314,6 +314,55 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0
 
 
+def test_pair_records_that_straddle_two_bins(device):
+    """The record pass of the packed streamed backward carries both x corners of a (y, z) pair in ONE record because they
+    share a bin -- except where they do not: (a) hashed levels finer than the bin size (the occupancy-grid back-end's
+    grid reaches resolution 8192: px = 8191 -> px ^ (px + 1) = 0x3FFF, beyond the 8192-entry bin), (b) a dense level's
+    bin boundary (index % 8192 == 8191).  Such pairs go out as two single-corner records; this test aims samples AT those
+    places and compares with the global-atomic form (rtol 1e-3, atol 1e-5 x max, as test_grid_bwd_lds_matches_atomic_large)."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    ngp = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, max_res=8192)
+    g = torch.Generator().manual_seed(11)
+    for cfg, what in ((ngp, "resolution 8192"), (MAIN, "dense bin boundary")):
+        enc = tcnn.Encoding(3, _enc_cfg(cfg)).to(device)
+        spec = _spec(cfg)
+        n = 8192
+        x = torch.rand(n, 3, generator=g)
+        if cfg is ngp:
+            # finest level: cell x index 8191 (scale * x + 0.5 in [8191, 8192))
+            scale = float(spec.scales[-1])
+            assert abs(scale - 8191.0) < 0.1
+            x[: n // 2, 0] = (8191.0 + torch.rand(n // 2, generator=g) * 0.48 + 0.01 - 0.5) / scale  # upper half-cell: x <= 1
+            assert float(x[:, 0].max()) <= 1.0
+        else:
+            # level 4 (dense, res + 1 = 59): cells whose first corner has index % 8192 == 8191
+            lvl = 4
+            off, size, res, hashed = (int(v) for v in spec.levels[lvl])
+            assert not hashed
+            stride = res + 1
+            cells = []
+            for idx in range(8191, size - stride * stride, 8192):
+                cx, cy, cz = idx % stride, (idx // stride) % stride, idx // (stride * stride)
+                if cx < res and cy < res and cz < res:
+                    cells.append((cx, cy, cz))
+            assert len(cells) >= 8
+            scale = float(spec.scales[lvl])
+            c = torch.tensor(cells, dtype=torch.float32)[torch.randint(0, len(cells), (n // 2,), generator=g)]
+            x[: n // 2] = (c + torch.rand(n // 2, 3, generator=g) * 0.98 + 0.01 - 0.5) / scale
+        x = x.clamp(0.0, 1.0).to(device)
+        dy = torch.randn(n, 2 * cfg["n_levels"], generator=g).to(device)
+        grads = []
+        for mode in (0, 7):
+            _set_bwd_mode(enc, mode)
+            enc.params.grad = None
+            (enc(x).float() * dy).sum().backward()
+            grads.append(enc.params.grad.clone())
+        _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what=f"packed pair records vs atomics ({what})")
+        dy16 = (dy * 128).half().double() / 128
+        assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0
+
+
 def test_spherical_harmonics(device):
     import nerf_vo_amd.tinycudann as tcnn
     from oracle import sh as S
