@@ -107,6 +107,11 @@ class NgpEngine:
         # the coarse (dense) levels that stay slice-owner: int32 accumulators with the L1-derived scale, run-merging scan,
         # chunk table sized for the packed capacity -- what the nerfacto main grid uses (76 -> ~35 us)
         self.density_net.set_option("grid_acc_bits", 32)
+        # every DENSE level stays slice-owner (a hashed 2^19 table is 128 bins of 4096): in an uncontracted scene the samples
+        # crowd into a few cells of the finest dense level, its streamed bins become the record pass's long tail
+        # (tl_accumulate 110 -> 60 us with that level in the owner launch, which grows 33 -> 55 us; step 0.964 -> 0.936 ms).
+        # (The nerfacto main grid is the other way round -- contracted, evenly filled: 116 us streamed vs 126 us owner.)
+        self.density_net.set_option("grid_stream_owner_slices", 127)
         self.density_net.set_option("grid_bwd_runs", 1)
         self.density_net.set_option("grid_bwd_batch", int(cfg.capacity))
         self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
