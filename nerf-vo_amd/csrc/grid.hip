@@ -443,7 +443,7 @@ k_grid_bwd_atomic(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 //              levels a slice receives ~1/26 of the lookups, the kernel is bound by re-deriving the
 //              corner hashes for every (sample, slice) pair, and fewer/larger slices win.
 constexpr uint32_t kSliceFixed = 8192;
-constexpr uint32_t kSliceFloat = 20480;
+constexpr uint32_t kSliceFloat = 20448;  // (160 KiB less 256 B: the item's work counter is static LDS)
 constexpr uint32_t kLdsBwdBytes = 160 * 1024;
 constexpr int kLdsBwdBlock = 1024;
 constexpr float kFixScale = 67108864.f;          // 2^26
@@ -546,8 +546,19 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
         if (chunk >= n_act) return;
     }
 
+    // The item's sample range is handed out to the WAVES in blocks of 64 x 8 (or 64 x 4) consecutive samples from a
+    // counter in LDS: with a fixed stride per wave the waves whose samples happen to hit this slice finish last and the
+    // other fifteen wait at the barrier -- 20-25 % of an item's cycles by the phase clocks.
+    __shared__ uint32_t s_next;
+    if (threadIdx.x == 0) s_next = 0u;
     for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) acc[e] = (typename ACC::T)0;
     __syncthreads();
+    const uint32_t lane_id = threadIdx.x & 63u;
+    auto wave_grab = [&](uint32_t n) -> uint32_t {
+        uint32_t c = 0u;
+        if (lane_id == 0u) c = atomicAdd(&s_next, n);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
 
     // (chunk boundaries on multiples of 8 samples: the run-merging scan loads 8 consecutive samples per lane)
     const uint32_t per_chunk = ((n_scan + n_act - 1) / n_act + 7u) & ~7u;
@@ -627,7 +638,9 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
         if constexpr (SOA && sizeof(DY2) == 4) {
             vec = !listed && (N & 3u) == 0u && (((uintptr_t)dy) & 15u) == 0u && (((uintptr_t)x) & 15u) == 0u;
         }
-        for (uint32_t b0 = begin + threadIdx.x * kRun; b0 < end; b0 += kLdsBwdBlock * kRun) {
+        for (uint32_t c0 = wave_grab(64u * kRun); begin + c0 < end; c0 = wave_grab(64u * kRun)) {
+            const uint32_t b0 = begin + c0 + lane_id * kRun;
+            if (b0 >= end) continue;
             open = false;
             hit = false;
             bool done = false;
@@ -659,13 +672,14 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             if (open && hit) flush();
         }
     } else
-    for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += kUnroll * kLdsBwdBlock) {
+    for (uint32_t c0 = wave_grab(64u * kUnroll); begin + c0 < end; c0 = wave_grab(64u * kUnroll)) {
+        const uint32_t i0 = begin + c0 + lane_id;
         float2 dv[kUnroll];
         float xv[kUnroll][3];
         uint32_t sid[kUnroll];
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; ++u) {  // (one extra round trip per pass when the list is used)
-            const uint32_t j = i0 + u * kLdsBwdBlock;
+            const uint32_t j = i0 + u * 64u;
             sid[u] = j < end ? (listed ? live[j] : j) : 0u;
         }
 #pragma unroll
@@ -673,7 +687,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             const uint32_t i = sid[u];
             dv[u] = make_float2(0.f, 0.f);
             xv[u][0] = xv[u][1] = xv[u][2] = 0.f;
-            if (i0 + u * kLdsBwdBlock < end) {
+            if (i0 + u * 64u < end) {
                 const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
                 dv[u] = dy2f(d2);
                 xv[u][0] = x[3 * (size_t)i + 0];
@@ -3026,7 +3040,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         if (!attr_set) {                                                                      \
             NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_bwd_lds<SOA_, T_>,          \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                              (int)kLdsBwdBytes));                            \
+                                              (int)kLdsBwdBytes - 256)); /* (static: work counter) */ \
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
