@@ -115,6 +115,9 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *                               share a cell (consecutive samples are neighbours on a ray); off = per-sample scan
  *   "grid_bwd_batch"            batch size the backward launches will see (0 = unknown): with "grid_bwd_runs" the
  *                               slices are chunked so that all items of a launch are resident at once
+ *   "grid_bwd_dense_share"      (with "grid_bwd_batch") chunks of a DENSE slice relative to that even split, in percent
+ *                               (default 100; 25..400): 120 when most samples carry a gradient (bf16 gradients, loss
+ *                               scale 65536), where dense-level items are the slower kind
  *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
  *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
  *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges

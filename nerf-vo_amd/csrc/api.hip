@@ -481,6 +481,13 @@ struct GridModule : nvo_module_s {
             slices.batch_hint = stream_bins.owner.batch_hint = (uint32_t)value;
             return NVO_OK;
         }
+        if (!strcmp(key, "grid_bwd_dense_share")) {  // chunks of a dense slice relative to the even one-round split, percent
+            NVO_REQUIRE(value >= 25 && value <= 400, "grid_bwd_dense_share: 25..400 (percent)");
+            nvo_grid_slices_destroy(&slices);
+            nvo_grid_stream_destroy(&stream_bins);
+            slices.dense_share_pct = stream_bins.owner.dense_share_pct = (uint32_t)value;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_bwd_runs")) {  // slice-owner items of dense levels: run-merging scan (on rebuild)
             nvo_grid_slices_destroy(&slices);
             nvo_grid_stream_destroy(&stream_bins);

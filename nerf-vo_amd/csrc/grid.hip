@@ -2418,14 +2418,15 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
     }
     const uint32_t factor = (base_total == 0 || base_total >= target) ? 1u : (target + base_total - 1) / base_total;
     // one-round rule (see NvoGridSlices::batch_hint)
-    uint32_t even_chunks = 0;
+    uint32_t even_chunks = 0, dense_chunks = 0, hashed_chunks = 0;
     if (s->runs && s->batch_hint) {
-        uint32_t n_total = 0;
+        uint32_t n_total = 0, n_dense = 0;
         for (uint32_t l = 0; l < g.n_levels; ++l) {
             if (!((level_mask >> l) & 1u)) continue;
             const uint32_t size = g.offset[l + 1] - g.offset[l];
             const uint32_t se = slice_entries(l);
             n_total += (size + se - 1) / se;
+            if (!g.hashed[l]) n_dense += (size + se - 1) / se;
         }
         int dev = 0, n_cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2435,6 +2436,22 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
             const uint32_t per = (uint32_t)n_cus / n_total;
             const uint32_t k = (uint32_t)((s->batch_hint + pass * per - 1) / (pass * per));
             even_chunks = (uint32_t)((s->batch_hint + pass * k - 1) / (pass * k));
+            dense_chunks = hashed_chunks = even_chunks;
+            // option grid_bwd_dense_share (percent): how the one round is shared between dense and hashed slices.  With
+            // most samples live (bf16 gradients, the reference's loss scale) a dense-level item takes 1.6 x as long as a
+            // hashed-level one (phase clocks): 120 gives the dense slices 12 chunks and the hashed
+            // ones 9 where both had 10; with few samples live it is the other way round and 100 (equal) stays.
+            const uint32_t n_hashed = n_total - n_dense;
+            if (s->dense_share_pct != 100u && n_dense && n_hashed) {
+                uint32_t cd = (even_chunks * s->dense_share_pct + 50u) / 100u;
+                if (cd < 1u) cd = 1u;
+                while (cd > 1u && n_dense * cd + n_hashed > (uint32_t)n_cus) --cd;
+                const uint32_t ch = ((uint32_t)n_cus - n_dense * cd) / n_hashed;
+                if (ch >= 1u) {
+                    dense_chunks = cd;
+                    hashed_chunks = ch;
+                }
+            }
         }
     }
     // Most expensive first: single-chunk items scan all N samples (long), chunked items scan
@@ -2447,7 +2464,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
         const uint32_t se = slice_entries((uint32_t)l);
         for (uint32_t f = 0; f < size; f += se) {
             const uint32_t count = size - f < se ? size - f : se;
-            uint32_t n_chunks = even_chunks ? even_chunks : base_chunks(count, size) * factor;
+            uint32_t n_chunks = even_chunks ? (g.hashed[l] ? hashed_chunks : dense_chunks) : base_chunks(count, size) * factor;
             if (n_chunks > 1024) n_chunks = 1024;
             if (s->deterministic) n_chunks = 1;  // chunks of a slice meet in float atomics: one owner instead
             for (uint32_t c = 0; c < n_chunks; ++c)

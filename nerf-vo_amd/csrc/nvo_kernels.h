@@ -41,6 +41,7 @@ struct NvoGridSlices {
     // and a chunk is a whole number of 8192-sample passes (1024 lanes x 8 consecutive samples): an item costs ~8 us of
     // dispatch, zeroing and flushing whatever it scans, so one round of long items beats several rounds of short ones.
     uint32_t batch_hint = 0;
+    uint32_t dense_share_pct = 100;  // option grid_bwd_dense_share: chunks of a dense slice relative to the even split (percent)
     uint32_t fixed_cap = 0;  // (set before create) entries per 64-bit fixed-point slice of a dense level; 0 = 8192
     // (set before create) deterministic mode: every slice is ONE work item (no chunks meeting in float atomics), integer
     // accumulators on every level (LDS float atomics retire in no fixed order), no live-sample list (its append order

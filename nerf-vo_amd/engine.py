@@ -106,6 +106,9 @@ class EngineConfig:
     overlap_proposal_backward: bool = True
     proposal_backward_streams: int = 1    # 2 = one side stream per proposal network (measured: see DESIGN.md section 5.0)
     proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
+    # chunks of the proposal grids' DENSE slices relative to the even split of the one-round item table, percent;
+    # None = 120 when most samples carry a gradient (bf16 MLPs or dynamic_loss_scale), else 100
+    proposal_dense_share: int | None = None
     # record pass of the main grid's streamed levels (grid_bwd_mode 3): 32 = ONE 64-bit LDS atomic per record on two
     # packed 32-bit fixed-point sums, 8192-entry bins, overflow-proof scale from the scatter's per-(tile, bin) L1 bounds
     # (k_tl_scatter_p / k_tl_accumulate_p: accumulate 83 -> 69 us on the kernel bench); 64 = two 64-bit sums per entry
@@ -236,7 +239,17 @@ class NerfactoEngine:
             m.set_option("grid_bwd_batch", int(cfg.num_rays * per_ray))
         # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
+        # share of the one-round item table that goes to the dense levels: with most proposal samples carrying a gradient
+        # (bf16 keeps what fp16 flushes; so does the reference's loss scale of 65536) their items are the slower kind
+        dense_share = cfg.proposal_dense_share
+        if dense_share is None:
+            # (measured, scannet-shaped bf16 step: 100 / 120 / 140 / 170 / 200 -> 130.7 / 121.8 / 128.3 / 150.5 / 198 us per
+            # launch; fp16 with the static scale, where few samples are live: 70 / 85 / 100 -> 77.8 / 71.0 / 61 us)
+            dense_share = 120 if (self.bf16 or cfg.dynamic_loss_scale) else 100
+            import os
+            dense_share = int(os.environ.get("NVO_PROP_DENSE_SHARE", dense_share))  # measurements
         for m in self.prop_nets:
+            m.set_option("grid_bwd_dense_share", int(dense_share))
             m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
             m.set_option("fuse_encoding", int(cfg.fuse_proposal_encoding))
             # most proposal samples carry an exactly zero gradient after a few hundred steps: scan the live ones only
