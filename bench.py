@@ -350,8 +350,8 @@ def main() -> None:
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src,
-                        # uncorrected counters (FETCH_SIZE under-reports coalesced streams on gfx950; the x2 correction of
-                        # the record pass is an estimate for its access pattern: the truth lies between the two)
+                        # uncorrected counters (FETCH_SIZE counts half of the lines read on gfx950: calibrated for coalesced
+                        # streams and for the record pass's unaligned 384-byte runs, profiles/r3_pmc_probe_run_gather.txt)
                         "traffic_raw": traffic_raw,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
                         "bytes_model": "SURVEY.md 8d per-unit bytes x units per launch (DESIGN.md section 3)",

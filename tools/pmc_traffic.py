@@ -45,9 +45,12 @@ def main():
     # 16 B per lane; calibrated here for 8 B per lane too -- tools/probes/read_bw_probe under --pmc FETCH_SIZE reports
     # 70 688 KB for a 141 312 KB buffer at both widths, profiles/r2_pmc_probe_calibration.txt).  The kernels below read
     # nothing but such streams; every other kernel's reads (4-byte gathers, strided rows) are uncalibrated and stay raw.
-    # (k_tl_accumulate / _p read ~256-512-byte record runs at arbitrary 8-byte offsets plus 4-byte segment words -- NOT
-    # the pattern the probe calibrated.  Their x2 figure is therefore an ESTIMATE; the raw value is reported beside it
-    # -- bench.py: roofline.traffic (estimate) and roofline.traffic_raw -- and the truth lies between the two.)
+    # (k_tl_accumulate_p reads 384-byte runs of 12-byte records at arbitrary record offsets, one dwordx3 per lane.  Round
+    # 3 calibrated THAT pattern too -- tools/probes/run_gather_probe under --pmc FETCH_SIZE, profiles/
+    # r3_pmc_probe_run_gather.txt: a fully coalesced 12-byte stream counts 101 386 KB for 202 752 KB read (x 0.500), the
+    # run gather 67 068 KB for 101 376 KB requested (x 0.662 = 1/2 x 4/3: an unaligned 384-byte run touches four 128-byte
+    # lines).  The x2 figure is therefore the traffic the pass really causes, line over-fetch included; the raw value
+    # stays beside it in bench.py (roofline.traffic_raw).)
     STREAM_READERS = {"k_tl_accumulate", "k_tl_accumulate_p", "k_st_accumulate", "k_adam_groups", "k_adam",
                       "k_nonfinite_flag_ranges", "k_nonfinite_flag", "k_read"}
     for k in kernels:
@@ -83,8 +86,9 @@ def main():
             "per launch = sum / launches.  FETCH_SIZE_KB_corrected = raw x 2 for the kernels whose reads are pure coalesced "
             "streams (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of such reads; calibrated with "
             "tools/probes/read_bw_probe at 8 and 16 B per lane), raw for every other kernel (uncalibrated access widths); "
-            "for k_tl_accumulate(_p) -- record runs at 8-byte granularity, not the calibrated pattern -- the corrected "
-            "figure is an estimate, the raw one a lower bound.")
+            "k_tl_accumulate_p's 384-byte record runs were calibrated separately (tools/probes/run_gather_probe, "
+            "profiles/r3_pmc_probe_run_gather.txt: the counter reports 0.662 of the REQUESTED bytes = half of the 128-byte "
+            "lines an unaligned run touches), so its x2 figure is the traffic it causes, over-fetch included.")
     json.dump({"note": note, "kernels": rows + kernels}, open(out_path, "w"), indent=1)
     for r in rows:
         print(r)
