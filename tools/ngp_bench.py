@@ -84,12 +84,29 @@ def main():
 
         per = {name: total / cnt * 1e-3 for name, cnt, total in rows}  # seconds per launch
         cap = eng.cfg.capacity
+
+        def pmc_traffic(name):
+            """HBM bytes per launch from the committed PMC summary of this command (tools/collect_profile_evidence.sh:
+            separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE corrected as tools/pmc_traffic.py describes)."""
+            import glob
+            import os
+
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            for path in sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_ngp_fetch_write_per_kernel.json")), reverse=True):
+                for k in json.load(open(path)).get("kernels", []):
+                    if k.get("bench_name") == name:
+                        fetch = k.get("FETCH_SIZE_KB_corrected", k["FETCH_SIZE_KB_per_launch"])
+                        return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path)
+            return None, None
+
         roof = None
         for name, bytes_per_sample in (("grid_bwd_stream[L16]", 1100), ("grid_fwd[L16]", 588)):
             if name in per:
                 b = cap * bytes_per_sample
+                traffic, src = pmc_traffic(name)
                 roof = roof or {"kernel": name, "bound": "hbm", "achieved": round(b / per[name] / 1e9, 1), "peak": 8000.0,
-                                "unit": "GB/s", "frac": round(b / per[name] / 1e9 / 8000.0, 4), "traffic": None,
+                                "unit": "GB/s", "frac": round(b / per[name] / 1e9 / 8000.0, 4), "traffic": traffic,
+                                "traffic_source": src,
                                 "avg_launch_us": round(per[name] * 1e6, 1), "algorithmic_bytes_per_launch": b}
         print(json.dumps({"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
                           "unit": "samples/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "rays_per_batch": eng.rays_per_batch,
