@@ -186,6 +186,34 @@ def test_grid_bwd_32bit_accumulators(device, cfg, bwd_mode):
         _assert_close(grads[0][lo:hi], ref[lo:hi], rtol=1e-3, atol_scale=2e-4, what=f"dL/dparams level {l} (32-bit)")
 
 
+@pytest.mark.parametrize("share", [60, 120, 250])
+def test_grid_bwd_item_table_shares_do_not_change_the_gradient(device, share):
+    """grid_bwd_dense_share only redistributes the chunks of the slice-owner item table between dense and hashed slices
+    (what the engine sets to 120 where most proposal samples are live): the gradient must stay the one of the even
+    table -- same integer accumulators per slice, chunks combined with float atomics (rtol 1e-4, atol 1e-6 x max)."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    n = 4096 * 24
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(n, 3, generator=g).to(device)
+    dy = torch.randn(n, 2 * PROP0["n_levels"], generator=g).to(device)
+    grads = []
+    for pct in (100, share):
+        enc = tcnn.Encoding(3, _enc_cfg(PROP0)).to(device)
+        m = enc.native_tcnn_module
+        m.set_option("grid_acc_bits", 32)
+        m.set_option("grid_bwd_runs", 1)
+        m.set_option("grid_bwd_batch", n)
+        m.set_option("grid_bwd_dense_share", pct)
+        m.set_option("grid_bwd_mode", 1)
+        with torch.no_grad():
+            enc.params.copy_(torch.linspace(-1, 1, enc.params.numel(), device=device))
+        (enc(x).float() * dy).sum().backward()
+        grads.append(enc.params.grad.clone())
+    _assert_close(grads[1], grads[0], rtol=1e-4, atol_scale=1e-6, what=f"dense share {share} % vs even item table")
+    assert float(grads[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("bad_value", [float("inf"), float("-inf"), float("nan")], ids=["inf", "-inf", "nan"])
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
 def test_grid_bwd_propagates_nonfinite(device, cfg, bad_value):
