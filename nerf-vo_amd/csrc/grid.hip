@@ -62,6 +62,23 @@ uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_fe
     return offset;
 }
 
+// -DNVO_GRID_PHASE (debugging aid, never in the product build; NVO_EXTRA_CXXFLAGS of nerf_vo_amd/build.py,
+// tools/grid_phase.py): shader-clock sums per phase of the record pass, the slice-owner items and the small-grid
+// forward -- where DESIGN.md section 3.6's "what is this kernel waiting for" figures come from.  One thread per
+// workgroup adds its phase durations with atomics (which disturb the timing of the instrumented launch itself: read the
+// SHARES, not the totals).  Slots: [0..6] k_tl_accumulate_p (zero+L1, records, barrier, flush, end barrier, hashed items,
+// dense items); [8..14] k_tl_scatter_p (loads+max, index+rank, barrier, bin scan, stage, copy-out, workgroups);
+// [16..20] slice-owner dense items, [24..28] hashed items (zero, scan, barrier, flush, items); [32..37] k_grid_fwd_small
+// (staging, loop, issue, LDS levels, consume, workgroups).
+#ifdef NVO_GRID_PHASE
+__device__ unsigned long long nvo_grid_phase_cycles[48];
+#define GP_CLK(v) const unsigned long long v = __builtin_readcyclecounter()
+#define GP_ADD(slot, d) atomicAdd(&nvo_grid_phase_cycles[slot], (unsigned long long)(d))
+#else
+#define GP_CLK(v) do { } while (0)
+#define GP_ADD(slot, d) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kGridBlock = 256;
@@ -289,6 +306,10 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
                  __half2* __restrict__ out, int out_bf16, uint32_t per_block) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
     const uint32_t* __restrict__ tab32 = reinterpret_cast<const uint32_t*>(table);
+    GP_CLK(gf0);
+#ifdef NVO_GRID_PHASE
+    unsigned long long gf_iss = 0, gf_lds = 0, gf_cons = 0;
+#endif
     {   // stage the leading NLDS levels (contiguous from entry 0; level offsets are multiples of 8 entries)
         const uint32_t n4 = g.offset[NLDS] >> 2;
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
@@ -296,6 +317,7 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
         for (uint32_t e = threadIdx.x; e < n4; e += kSmallBlock) dst[e] = src[e];
     }
     __syncthreads();
+    GP_CLK(gf1);
     const uint32_t first = blockIdx.x * per_block;
     const uint32_t last = min(N, first + per_block);
     uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
@@ -311,6 +333,7 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
 #pragma unroll
             for (int k = 0; k < 3; ++k) pos[s][k] = x[3 * (size_t)ic + k];
         }
+        GP_CLK(gfa);
         // ---- global levels first: every gather of the samples is requested before anything is consumed
         Corner cg[SPT][NG];
         uint32_t vg[SPT][NG][8];
@@ -345,6 +368,7 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
                 }
             }
         }
+        GP_CLK(gfb);
         // ---- LDS levels while the gathers fly
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
@@ -367,6 +391,7 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
                 o32[(size_t)l * N + is[s]] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
             }
         }
+        GP_CLK(gfc);
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
             if (is[s] >= last) continue;
@@ -385,7 +410,21 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
                 o32[(size_t)(NLDS + q) * N + is[s]] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
             }
         }
+#ifdef NVO_GRID_PHASE
+        {
+            GP_CLK(gfd);
+            gf_iss += gfb - gfa;
+            gf_lds += gfc - gfb;
+            gf_cons += gfd - gfc;
+        }
+#endif
     }
+#ifdef NVO_GRID_PHASE
+    if (threadIdx.x == 0) {
+        GP_CLK(gfe);
+        GP_ADD(32, gf1 - gf0); GP_ADD(33, gfe - gf1); GP_ADD(34, gf_iss); GP_ADD(35, gf_lds); GP_ADD(36, gf_cons); GP_ADD(37, 1);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,9 +589,11 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     // counter in LDS: with a fixed stride per wave the waves whose samples happen to hit this slice finish last and the
     // other fifteen wait at the barrier -- 20-25 % of an item's cycles by the phase clocks.
     __shared__ uint32_t s_next;
+    GP_CLK(go0);
     if (threadIdx.x == 0) s_next = 0u;
     for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) acc[e] = (typename ACC::T)0;
     __syncthreads();
+    GP_CLK(go1);
     const uint32_t lane_id = threadIdx.x & 63u;
     auto wave_grab = [&](uint32_t n) -> uint32_t {
         uint32_t c = 0u;
@@ -751,7 +792,9 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             }
         }
     }
+    GP_CLK(go2);
     __syncthreads();
+    GP_CLK(go3);
     float* __restrict__ gr = grad + 2 * ((size_t)off + first);
     if (n_chunks == 1) {
         for (uint32_t e = threadIdx.x; e < 2 * count; e += kLdsBwdBlock) gr[e] = ACC::get(acc, e, sc);
@@ -763,6 +806,13 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     }
     // (no LDS to spare for a block-wide vote: one atomic per affected wave, after every plain store has retired)
     __syncthreads();
+#ifdef NVO_GRID_PHASE
+    if (threadIdx.x == 0) {
+        GP_CLK(go4);
+        const int o = hashed ? 24 : 16;
+        GP_ADD(o + 0, go1 - go0); GP_ADD(o + 1, go2 - go1); GP_ADD(o + 2, go3 - go2); GP_ADD(o + 3, go4 - go3); GP_ADD(o + 4, 1);
+    }
+#endif
     if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) {
         atomicAdd(gr, __builtin_nanf(""));
         if (nf_flag) atomicOr(nf_flag, 1u);  // (the optimiser's overflow flag, raised at the source)
@@ -1828,6 +1878,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     float2 d = make_float2(0.f, 0.f);
     float xs[3] = {0.f, 0.f, 0.f};
     bool live = false;
+    GP_CLK(gq0);
     if (i < N) {  // dy and x in one round trip
         live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
         xs[0] = x[3 * (size_t)i + 0];
@@ -1846,6 +1897,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
         }
     }
     __syncthreads();
+    GP_CLK(gq1);
     float M0 = 0.f, M1 = 0.f;
 #pragma unroll
     for (uint32_t w = 0; w < kWaves; ++w) {
@@ -1897,7 +1949,9 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
             }
         }
     }
+    GP_CLK(gq2);
     const uint32_t bad_bit = __syncthreads_or(live && !finite) ? 0x80000000u : 0u;
+    GP_CLK(gq3);
     if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
         uint32_t carry = 0;
         for (uint32_t b0 = 0; b0 < n_slices; b0 += 64) {
@@ -1917,6 +1971,7 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
         if (lane == 0) total_s = carry;
     }
     __syncthreads();
+    GP_CLK(gq4);
     if (live) {
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
@@ -1933,10 +1988,18 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
         }
     }
     __syncthreads();
+    GP_CLK(gq5);
     const uint32_t total = total_s;
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(records + 3u * ((size_t)blockIdx.y * n_tiles + tile) * kStRecords);
     const uint4* src = reinterpret_cast<const uint4*>(stage);
     for (uint32_t t = threadIdx.x; t < (3u * total + 3u) / 4u; t += kStBlock) dst[t] = src[t];
+#ifdef NVO_GRID_PHASE
+    if (threadIdx.x == 64) {
+        GP_CLK(gq6);
+        GP_ADD(8, gq1 - gq0); GP_ADD(9, gq2 - gq1); GP_ADD(10, gq3 - gq2); GP_ADD(11, gq4 - gq3); GP_ADD(12, gq5 - gq4);
+        GP_ADD(13, gq6 - gq5); GP_ADD(14, 1);
+    }
+#endif
 }
 
 template <uint32_t BIN>
@@ -1979,6 +2042,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         }
         const uint32_t entries = st_bin_entries_p<BIN>(g, cur.level, cur.slice);
         float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * BIN);
+        GP_CLK(gp0);
         {
             uint4* z = reinterpret_cast<uint4*>(lds_raw);  // one uint4 = two entries
             for (uint32_t e = threadIdx.x; e < (entries + 1u) / 2u; e += kTlBlockP) z[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -2004,6 +2068,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             }
         }
         __syncthreads();  // accumulators zeroed, L1 partials visible
+        GP_CLK(gp1);
         float L0 = 0.f, L1 = 0.f;
 #pragma unroll
         for (uint32_t w = 0; w < kWaves; ++w) {
@@ -2074,7 +2139,9 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
             nxt = tl_decode(head_next, n_tiles);
             if (nxt.n_chunks) segw_next = words_first(nxt, &l1w_next);
         }
+        GP_CLK(gp2);
         __syncthreads();
+        GP_CLK(gp3);
         {
             // flush: two entries (four gradient scalars) per thread and step: one 16-byte LDS read, one 16-byte store
             const uint32_t n2 = entries >> 1;  // (entries of a bin are a multiple of 8)
@@ -2104,7 +2171,15 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                 }
             }
         }
+        GP_CLK(gp4);
         __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
+#ifdef NVO_GRID_PHASE
+        if (threadIdx.x == 0) {
+            GP_CLK(gp5);
+            GP_ADD(0, gp1 - gp0); GP_ADD(1, gp2 - gp1); GP_ADD(2, gp3 - gp2); GP_ADD(3, gp4 - gp3); GP_ADD(4, gp5 - gp4);
+            GP_ADD(cur.n_chunks == 1u ? 5 : 6, 1);
+        }
+#endif
         if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
             atomicAdd(gr, __builtin_nanf(""));
             if (nf_flag) atomicOr(nf_flag, 1u);
@@ -3138,3 +3213,16 @@ int nvo_grid_bwd_input_launch(const NvoGridLevels& g, hipStream_t stream, uint32
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
+
+#ifdef NVO_GRID_PHASE
+// out48: the phase-clock slots described at the top of this file; reset != 0 clears them afterwards
+extern "C" int nvo_debug_grid_phase(unsigned long long* out48, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(nvo_grid_phase_cycles), sizeof(unsigned long long) * 48) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[48] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nvo_grid_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
