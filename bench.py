@@ -140,6 +140,8 @@ def main() -> None:
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the eager per-kernel HIP-event pass (rocprofv3 runs: only graph-replayed steps in the trace)")
     ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
+    ap.add_argument("--no-pose-overlap", action="store_true",
+                    help="pose optimisation: the main grid's parameter scatter behind the pose chain instead of beside it (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
                     help="GradScaler dynamics (init 65536, x2 / 2000 clean steps, x0.5 on overflow) instead of the static scale 128")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
@@ -219,6 +221,8 @@ def main() -> None:
         cfg.pipeline_single_gpu = True
     if args.dynamic_loss_scale:
         cfg.dynamic_loss_scale = True
+    if args.no_pose_overlap:
+        cfg.overlap_pose_backward = False
     if args.no_overlap:
         cfg.overlap_proposal_backward = False
         cfg.overlap_pose_backward = False
