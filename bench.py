@@ -142,6 +142,7 @@ def main() -> None:
     ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
     ap.add_argument("--no-pose-overlap", action="store_true",
                     help="pose optimisation: the main grid's parameter scatter behind the pose chain instead of beside it (A/B)")
+    ap.add_argument("--no-pair-losses", action="store_true", help="one launch per proposal level's loss kernel (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
                     help="GradScaler dynamics (init 65536, x2 / 2000 clean steps, x0.5 on overflow) instead of the static scale 128")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
@@ -221,6 +222,8 @@ def main() -> None:
         cfg.pipeline_single_gpu = True
     if args.dynamic_loss_scale:
         cfg.dynamic_loss_scale = True
+    if args.no_pair_losses:
+        cfg.pair_proposal_losses = False
     if args.no_pose_overlap:
         cfg.overlap_pose_backward = False
     if args.no_overlap:

@@ -383,6 +383,9 @@ typedef struct nvo_prop_loss_args {
     uint32_t* nonfinite_flag;    /* nullable: as in nvo_main_loss_args */
 } nvo_prop_loss_args;
 int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args);
+/* both proposal levels of a step in ONE launch (the two calls are independent of each other; same results as two
+ * nvo_prop_loss calls -- the loss terms are added to the same shards with float atomics either way) */
+int nvo_prop_loss_pair(nvo_stream_t stream, const nvo_prop_loss_args* args0, const nvo_prop_loss_args* args1);
 
 /* ------------------------------------------------------------------------------------------------
  * D. NerfactoField colour head (nerfstudio fields/nerfacto_field.py get_outputs: concat

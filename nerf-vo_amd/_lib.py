@@ -145,6 +145,7 @@ _SIGNATURES = {
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),
     "nvo_main_render_loss": (_int, [_p, C.POINTER(MainLossArgs)]),
     "nvo_prop_loss": (_int, [_p, C.POINTER(PropLossArgs)]),
+    "nvo_prop_loss_pair": (_int, [_p, _p, _p]),
     # group D
     "nvo_nerfacto_color_fwd": (_int, [_p, C.POINTER(ColorArgs)]),
     "nvo_nerfacto_color_bwd": (_int, [_p, C.POINTER(ColorArgs)]),

@@ -439,11 +439,16 @@ k_main_render_loss(nvo_main_loss_args a) {
 // ------------------------------------------------------------------------------------------------
 // proposal level: interlevel + depth loss and gradient
 // ------------------------------------------------------------------------------------------------
+// Workgroups [0, blocks0) serve a0, the rest a1: both proposal levels of a step in ONE launch (nvo_prop_loss_pair) --
+// each level alone is a single round of 4096 waves that lasts as long as one ray's dependent chain (17-22 us), so two
+// launches cost two chains.
 __global__ void __launch_bounds__(kRayBlock)
-k_prop_loss(nvo_prop_loss_args a) {
+k_prop_loss(nvo_prop_loss_args a0, nvo_prop_loss_args a1, uint32_t blocks0) {
     __shared__ float lds[kRaysPerBlock][5][kMaxS + 4];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t r = blockIdx.x * kRaysPerBlock + wib;
+    const bool second = blockIdx.x >= blocks0;  // (uniform)
+    nvo_prop_loss_args a = second ? a1 : a0;
+    const uint32_t r = (second ? blockIdx.x - blocks0 : blockIdx.x) * kRaysPerBlock + wib;
     if (r >= a.R) return;
     if (a.loss_scale_dev) a.loss_scale = *a.loss_scale_dev;
     float* w = lds[wib][0];
@@ -598,8 +603,25 @@ int nvo_prop_loss(nvo_stream_t stream, const nvo_prop_loss_args* args) {
                 (a.dpre == nullptr || a.dpre_stride >= 1), "prop_loss: NULL input/output");
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "prop_loss[S%u]", a.S);
-    NVO_LAUNCH(k_prop_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,
-                       (hipStream_t)stream, a);
+    const uint32_t blocks = nvo_div_up(a.R, kRaysPerBlock);
+    NVO_LAUNCH(k_prop_loss, dim3(blocks), dim3(kRayBlock), 0, (hipStream_t)stream, a, a, blocks);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_prop_loss_pair(nvo_stream_t stream, const nvo_prop_loss_args* args0, const nvo_prop_loss_args* args1) {
+    NVO_REQUIRE(args0 != nullptr && args1 != nullptr, "prop_loss_pair: args is NULL");
+    for (const nvo_prop_loss_args* p : {args0, args1}) {
+        const nvo_prop_loss_args& a = *p;
+        NVO_REQUIRE(a.S >= 1 && a.S <= (uint32_t)kMaxS && a.S_main >= 1 && a.S_main <= 64,
+                    "prop_loss_pair: S=%u (<=%d) S_main=%u (<=64)", a.S, kMaxS, a.S_main);
+        NVO_REQUIRE(a.pre && a.x01 && a.sbins && a.tbins && a.sbins_main && a.weights_main && a.losses &&
+                    (a.dpre == nullptr || a.dpre_stride >= 1), "prop_loss_pair: NULL input/output");
+    }
+    const uint32_t b0 = nvo_div_up(args0->R, kRaysPerBlock), b1 = nvo_div_up(args1->R, kRaysPerBlock);
+    if (b0 + b1 == 0) return NVO_OK;
+    NVO_PROF(stream, "prop_loss[S%u+S%u]", args0->S, args1->S);
+    NVO_LAUNCH(k_prop_loss, dim3(b0 + b1), dim3(kRayBlock), 0, (hipStream_t)stream, *args0, *args1, b0);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

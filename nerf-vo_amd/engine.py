@@ -125,6 +125,8 @@ class EngineConfig:
     expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
+    # both proposal levels' loss kernels in one launch (nvo_prop_loss_pair)
+    pair_proposal_losses: bool = True
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
     # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
     # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
@@ -868,10 +870,8 @@ class NerfactoEngine:
         R = ws["R"]
         km = len(self.prop_nets)
         inv_rays = 1.0 / (R * self.world_size)
-        for k, net in enumerate(self.prop_nets):
-            if levels is not None and k not in levels:
-                continue
-            pa = _lib.PropLossArgs(
+        def loss_args(k):
+            return _lib.PropLossArgs(
                 R=R, S=self.levels[k], S_main=self.levels[km], pre=ws[f"out{k}"].data_ptr(), pre_stride=1,
                 x01=ws[f"x{k}"].data_ptr(), sbins=ws[f"sbins{k}"].data_ptr(), tbins=ws[f"tbins{k}"].data_ptr(),
                 sbins_main=ws[f"sbins{km}"].data_ptr(), weights_main=ws[f"weights{km}"].data_ptr(),
@@ -882,7 +882,19 @@ class NerfactoEngine:
                 losses=self.losses.data_ptr() + 3 * 4, dpre=None if values_only else ws[f"dout{k}"].data_ptr(),
                 dpre_stride=1, act_bf16=int(self.bf16), loss_scale_dev=self._loss_scale_ptr(),
                 nonfinite_flag=None if values_only else self._flag_ptr("proposal_networks"))
-            _call("nvo_prop_loss", stream, C.byref(pa))
+
+        # both levels' loss kernels are independent of each other (each is one round of 4096 waves that lasts as long as
+        # one ray's dependent chain): ONE launch when both run on this stream
+        paired = levels is None and len(self.prop_nets) == 2 and cfg.pair_proposal_losses
+        if paired:
+            pa0, pa1 = loss_args(0), loss_args(1)
+            _call("nvo_prop_loss_pair", stream, C.byref(pa0), C.byref(pa1))
+        for k, net in enumerate(self.prop_nets):
+            if levels is not None and k not in levels:
+                continue
+            if not paired:
+                pa = loss_args(k)
+                _call("nvo_prop_loss", stream, C.byref(pa))
             if values_only:
                 continue
             _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
