@@ -627,6 +627,12 @@ int nvo_opt_commit(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask,
                    float beta1, float beta2);
 /* bias (nullable): device float [n_groups][2]; a group whose counter advances to t gets {1 - beta1^(t+1),
  * sqrt(1 - beta2^(t+1))} -- what nvo_adam_group::bias_dev of its next step reads. */
+/* nvo_opt_commit and nvo_write_floats(dst, n, host_values) in ONE launch: a graph-replayed step ends with its Adam
+ * launch and the commit rides in the eager launch that writes the next step's scalars. */
+int nvo_opt_commit_write(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                         const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                         float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                         float beta1, float beta2, float* dst, uint32_t n, const float* host_values);
 
 /* ------------------------------------------------------------------------------------------------
  * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of

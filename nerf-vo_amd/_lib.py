@@ -182,6 +182,7 @@ _SIGNATURES = {
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),
+    "nvo_opt_commit_write": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f, _p, _u32, _p]),
     "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f]),
     "nvo_cast_bf16": (_int, [_p, _u64, _p, _p]),
     "nvo_cast_shards": (_int, [_p, _u64, _u32, _u32, _p, _p, _int, _p]),

@@ -372,11 +372,10 @@ k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
 // GradScaler.update() + the optimisers' step counters, on the device (one thread): group i of `active_mask` advances its
 // applied-step counter iff its skip flag is clear; the loss scale backs off when ANY active group saw a non-finite
 // gradient and grows after `interval` clean steps (torch.cuda.amp.GradScaler: init 65536, x2 / 2000 steps, x0.5).
-__global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+__device__ __forceinline__ void opt_commit_thread(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
                              const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
                              uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
                              float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     bool any_bad = false;
     for (uint32_t i = 0; i < n_groups; ++i) {
         const bool bad = skip_flags && skip_flags[i] != 0u;
@@ -404,6 +403,15 @@ __global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t s
         *scale = sc;
         *growth_tracker = tr;
     }
+}
+
+__global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+                             const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
+                             uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
+                             float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    opt_commit_thread(n_groups, active_mask, scale_mask, applied, skip_flags, scale, growth_tracker, growth, backoff, interval,
+                      min_scale, max_scale, bias, beta1, beta2);
 }
 
 constexpr uint32_t kZeroMaxRanges = 24;
@@ -761,6 +769,39 @@ int nvo_write_floats(nvo_stream_t stream, float* dst, uint32_t n, const float* h
     NvoFloats16 vals;
     for (uint32_t i = 0; i < 16; ++i) vals.v[i] = i < n ? host_values[i] : 0.f;
     NVO_LAUNCH(k_write_floats, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n, vals);  // values travel by value
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+// GradScaler.update / step counters of the step that just ran AND the per-step scalars of the next one in ONE tiny
+// launch: a graph-replayed step ends with its Adam launch, the commit rides in the eager launch that every step needs
+// anyway for its scalars (one dependent 5-us launch less per step).
+__global__ void k_opt_commit_write(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+                                   const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
+                                   uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
+                                   float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2,
+                                   float* dst, uint32_t n, NvoFloats16 vals) {
+    if (threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+    if (threadIdx.x == 63)
+        opt_commit_thread(n_groups, active_mask, scale_mask, applied, skip_flags, scale, growth_tracker, growth, backoff, interval,
+                          min_scale, max_scale, bias, beta1, beta2);
+}
+
+int nvo_opt_commit_write(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                         const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                         float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                         float beta1, float beta2, float* dst, uint32_t n, const float* host_values) {
+    NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "opt_commit_write: 1..%u groups (got %u)", kAdamMaxGroups, n_groups);
+    NVO_REQUIRE(applied || scale, "opt_commit_write: nothing to update");
+    NVO_REQUIRE(!scale || (growth_tracker && growth_interval >= 1 && growth_factor >= 1.f && backoff_factor > 0.f &&
+                           backoff_factor <= 1.f && min_scale > 0.f && max_scale >= min_scale),
+                "opt_commit_write: bad loss-scale schedule");
+    NVO_REQUIRE(dst && host_values && n <= 16, "opt_commit_write: bad scalar block (n <= 16)");
+    NvoFloats16 vals;
+    for (uint32_t i = 0; i < 16; ++i) vals.v[i] = i < n ? host_values[i] : 0.f;
+    NVO_LAUNCH(k_opt_commit_write, dim3(1), dim3(64), 0, (hipStream_t)stream, n_groups, active_mask, scale_mask, applied, skip_flags,
+               scale, growth_tracker, growth_factor, backoff_factor, growth_interval, min_scale, max_scale, bias, beta1, beta2,
+               dst, n, vals);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

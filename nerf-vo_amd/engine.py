@@ -127,6 +127,9 @@ class EngineConfig:
     overlap_pose_backward: bool = True
     # both proposal levels' loss kernels in one launch (nvo_prop_loss_pair)
     pair_proposal_losses: bool = True
+    # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
+    # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
+    commit_behind_replay: bool = True
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
     # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
     # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
@@ -322,6 +325,8 @@ class NerfactoEngine:
         self._graphs = {}
         self._side_stream = None
         self._scatter_stream = None
+        self._defer_commit = None   # list while the one-graph step is being captured (optimizer_step appends its masks)
+        self._scalars_step = None   # step whose scalars _commit_and_write has already put into dev_scalars
         self._pix_scale = None
         self.corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
         self.d_corrections = torch.zeros(cfg.num_images, 3, 4, dtype=torch.float32, device=dev)
@@ -1011,10 +1016,28 @@ class NerfactoEngine:
             for g in (step_groups if step_groups is not None else active):
                 if g != "camera_opt" or cfg.optimize_poses:
                     scale_mask |= 1 << order.index(g)
+        if self._defer_commit is not None:
+            # (capture of the one-graph step: the commit rides in the eager launch behind the replay, _commit_and_write)
+            self._defer_commit.append((mask, scale_mask))
+            return
         _call("nvo_opt_commit", stream, len(order), mask, scale_mask, _ptr(self.dev_applied), _ptr(self.skip_flag),
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
               cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
+
+    def _commit_and_write(self, masks, sampling_step: int) -> None:
+        """GradScaler.update + step counters of the step that just replayed AND the scalars of step ``sampling_step`` (=
+        self.step, already advanced) in one eager launch (nvo_opt_commit_write)."""
+        cfg = self.cfg
+        mask, scale_mask = masks
+        vals = self._scalar_values(self.anneal_at(sampling_step), sampling_step)
+        arr = (C.c_float * 16)(*vals)
+        _call("nvo_opt_commit_write", _stream(self.device), len(self._GROUP_ORDER), mask, scale_mask, _ptr(self.dev_applied),
+              _ptr(self.skip_flag), _ptr(self.dev_loss_scale) if scale_mask else None,
+              _ptr(self.dev_growth_tracker) if scale_mask else None, cfg.loss_scale_growth, cfg.loss_scale_backoff,
+              int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max, _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1],
+              _ptr(self.dev_scalars), 16, arr)
+        self._scalars_step = sampling_step
 
     # ------------------------------------------------------------------------------------------
     # hipGraph replay of the step
@@ -1025,16 +1048,23 @@ class NerfactoEngine:
         arr = (C.c_float * 2)(self.anneal_at(step), float(step))
         _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_sampling), 2, arr)
 
-    def _write_step_scalars(self, anneal: float, groups, sampling_step: int | None = None) -> None:
-        """Learning rates of this step -> device memory (read by the captured optimiser; the Adam bias corrections are
-        computed on the device from the applied-step counters).  (Slot 0 mirrors the anneal for inspection; the
-        kernels read dev_sampling.)"""
+    def _scalar_values(self, anneal: float, sampling_step: int | None):
+        """[anneal | lr, -, - per group | ... | anneal, counter of the sampling step] -- functions of self.step alone"""
         vals = [0.0] * 16
         vals[0] = anneal
         for gi, g in enumerate(self._GROUP_ORDER):
             vals[1 + 3 * gi] = self._group_lr(g)
-        if sampling_step is not None:  # (single GPU: the sampling scalars ride in the same launch)
+        if sampling_step is not None:
             vals[14], vals[15] = self.anneal_at(sampling_step), float(sampling_step)
+        return vals
+
+    def _write_step_scalars(self, anneal: float, groups, sampling_step: int | None = None) -> None:
+        """Learning rates of this step -> device memory (read by the captured optimiser; the Adam bias corrections are
+        computed on the device from the applied-step counters).  (Slot 0 mirrors the anneal for inspection; the
+        kernels read dev_sampling.)"""
+        self._scalars_step = None  # (whatever was written ahead by _commit_and_write is overwritten)
+        vals = self._scalar_values(anneal, sampling_step)
+        if sampling_step is not None:  # (single GPU: the sampling scalars ride in the same launch)
             arr = (C.c_float * 16)(*vals)
             _call("nvo_write_floats", _stream(self.device), _ptr(self.dev_scalars), 16, arr)
         else:  # (multi GPU: slots 14-15 belong to the sampling prefix that may already run ahead)
@@ -1100,7 +1130,8 @@ class NerfactoEngine:
             entry = self._graphs[key]
         if all_reduce is None and not entry.get("pipelined"):
             self._pending_head = None
-            self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
+            if self._scalars_step != step:  # (not written ahead: first step, externally set step, eager work in between)
+                self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
             entry["main"].replay()
         elif all_reduce is None:
             # single GPU, pipelined: this graph ends with [Adam of the fields group || sampling prefix of step + 1]
@@ -1128,6 +1159,8 @@ class NerfactoEngine:
             self.steps_since_proposal_update = 0
         self.steps_since_proposal_update += 1
         self.step += 1
+        if all_reduce is None and entry.get("commit") is not None:
+            self._commit_and_write(entry["commit"], self.step)  # (self.step: the NEXT step's learning rates and sampler state)
         return updated
 
     def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False, values=False):
@@ -1337,7 +1370,16 @@ class NerfactoEngine:
                 body_head()
                 body_rest()
                 body_opt(groups_b)
-            entry["main"] = capture(whole)
+            if not cfg.commit_behind_replay:
+                entry["main"] = capture(whole)
+                return entry
+            self._defer_commit = []
+            try:
+                entry["main"] = capture(whole)
+                entry["commit"] = self._defer_commit[0] if len(self._defer_commit) == 1 else None
+            finally:
+                self._defer_commit = None
+            assert entry["commit"] is not None, "the one-graph step runs exactly one optimiser launch"
             return entry
         if pipe1:
             opt_stream = torch.cuda.Stream(device=dev)
