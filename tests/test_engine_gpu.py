@@ -704,6 +704,54 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     _assert_close(g_det, g_def, rtol=1e-3, atol_scale=1e-5, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
+@pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
+def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
+    """EngineConfig.commit_behind_replay: the optimiser's commit (applied-step counters, bias corrections, loss scale)
+    leaves the graph and rides in the eager launch behind the replay that also writes the NEXT step's scalars.  Same
+    seed, deterministic mode: parameters, moments, counters, bias corrections and loss scale must equal those of the
+    commit-in-graph form bit for bit -- across the proposal-update schedule, an externally reset step index and an
+    eager step in between (both of which invalidate the scalars written ahead)."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 512
+    seq = make_sequence(n, H, W, device=device)
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+
+    def run(behind: bool):
+        torch.manual_seed(21)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=True, deterministic=True,
+                                          dynamic_loss_scale=dynamic, loss_scale_interval=7,
+                                          commit_behind_replay=behind), device)
+        gen = torch.Generator(device=device).manual_seed(4)
+        for it in range(30):
+            if it == 12:
+                eng.step = 3  # (a step index set from outside: the scalars written ahead are for step 12)
+            if it == 20:
+                idx = torch.floor(torch.rand(R, 3, device=device, generator=gen) * torch.tensor([n, H, W], device=device)).long()
+                eng.train_step(idx, ds.camera_intrinsics, ds.camera_extrinsics[:, :3, :4].contiguous(), ds.frames_color,
+                               ds.frames_depth, jitters=tuple(torch.rand(R, device=device, generator=gen) for _ in range(3)))
+            eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        if not dynamic:  # (the dynamic scale doubles every 7 steps here and may well run into an overflow: also covered)
+            assert int(eng.skip_flag.sum()) == 0
+        has_commit = any(e.get("commit") is not None for e in eng._graphs.values())
+        return (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.opt_state.clone(), dict(eng.opt_steps),
+                has_commit)
+
+    a, b = run(True), run(False)
+    assert a[5] and not b[5]
+    assert a[4] == b[4], (a[4], b[4])
+    for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "optimiser state"), a[:4], b[:4]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name} differ between the two commit placements"
+    if dynamic:
+        assert float(a[3][4:5].view(torch.float32)) > 65536.0  # the scale really grew (interval 7)
+
+
 def test_pipelined_prefix_is_bit_identical_on_one_gpu(device):
     """EngineConfig.pipeline_single_gpu: the graph ends with [Adam of the fields group || sampling prefix of the NEXT
     step] -- the launch order the multi-GPU step uses around its exchange, on one GPU.  The reordering must not change
