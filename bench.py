@@ -144,6 +144,7 @@ def main() -> None:
                     help="pose optimisation: the main grid's parameter scatter behind the pose chain instead of beside it (A/B)")
     ap.add_argument("--no-pair-losses", action="store_true", help="one launch per proposal level's loss kernel (A/B)")
     ap.add_argument("--commit-in-graph", action="store_true", help="the optimiser's commit as the graph's last node (A/B)")
+    ap.add_argument("--separate-zero", action="store_true", help="the step's zero launch as its own graph node (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
                     help="GradScaler dynamics (init 65536, x2 / 2000 clean steps, x0.5 on overflow) instead of the static scale 128")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
@@ -227,6 +228,8 @@ def main() -> None:
         cfg.pair_proposal_losses = False
     if args.commit_in_graph:
         cfg.commit_behind_replay = False
+    if args.separate_zero:
+        cfg.zero_with_ray_head = False
     if args.no_pose_overlap:
         cfg.overlap_pose_backward = False
     if args.no_overlap:

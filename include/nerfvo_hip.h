@@ -281,6 +281,10 @@ typedef struct nvo_ray_head_args {
     float* x01;                  /* [R*S][3] */
 } nvo_ray_head_args;
 int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args);
+/* the same launch with extra workgroups that clear up to 24 device ranges (as nvo_zero_ranges): the first launch of a
+ * one-graph training step does both */
+int nvo_ray_head_zero(nvo_stream_t stream, const nvo_ray_head_args* args, uint32_t n_ranges, void* const* ptrs,
+                      const uint64_t* bytes);
 /* same with the output format chosen: out_bf16 = 0 -> fp16, 1 -> bfloat16 */
 int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16);
 

@@ -414,30 +414,10 @@ __global__ void k_opt_commit(uint32_t n_groups, uint32_t active_mask, uint32_t s
                       min_scale, max_scale, bias, beta1, beta2);
 }
 
-constexpr uint32_t kZeroMaxRanges = 24;
-struct ZeroRanges {
-    uint32_t n;
-    uint32_t first_block[kZeroMaxRanges + 1];
-    uint32_t* ptr[kZeroMaxRanges];
-    uint64_t words[kZeroMaxRanges];
-};
-// several device ranges cleared by ONE launch (a training step's accumulate-into buffers)
+// several device ranges cleared by ONE launch (a training step's accumulate-into buffers); plan: nvo_common.h
 __global__ void __launch_bounds__(256)
-k_zero_ranges(ZeroRanges r) {
-    uint32_t k = 0;
-    while (k + 1 < r.n && blockIdx.x >= r.first_block[k + 1]) ++k;
-    const uint32_t nb = r.first_block[k + 1] - r.first_block[k];
-    const uint64_t stride = (uint64_t)nb * blockDim.x;
-    uint32_t* __restrict__ p = r.ptr[k];
-    const uint64_t n = r.words[k];
-    const uint64_t tid = (uint64_t)(blockIdx.x - r.first_block[k]) * blockDim.x + threadIdx.x;
-    if ((((uintptr_t)p) & 15u) == 0u) {
-        uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
-        for (uint64_t i = tid; i < n / 4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (uint64_t i = (n / 4) * 4 + tid; i < n; i += stride) p[i] = 0u;
-    } else {
-        for (uint64_t i = tid; i < n; i += stride) p[i] = 0u;
-    }
+k_zero_ranges(NvoZeroPlan r) {
+    nvo_zero_plan_block(r, blockIdx.x);
 }
 
 // ---- deterministic reductions (EngineConfig.deterministic): fixed summation orders instead of float atomics ----
@@ -525,6 +505,38 @@ int nvo_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
     NVO_LAUNCH(k_zero_u32, dim3(blocks), dim3(256), 0, stream, (uint32_t*)ptr, n);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
+}
+
+int nvo_zero_plan_build(uint32_t n_ranges, void* const* ptrs, const uint64_t* bytes, NvoZeroPlan* plan) {
+    if (n_ranges > kZeroMaxRanges) {
+        nvo_set_error("zero_ranges: at most %u ranges (got %u)", kZeroMaxRanges, n_ranges);
+        return -1;
+    }
+    if (n_ranges != 0 && !(ptrs && bytes)) {
+        nvo_set_error("zero_ranges: NULL argument");
+        return -1;
+    }
+    NvoZeroPlan& r = *plan;
+    memset(&r, 0, sizeof(r));
+    uint32_t k = 0, blocks_total = 0;
+    for (uint32_t i = 0; i < n_ranges; ++i) {
+        if (bytes[i] == 0) continue;
+        if (!(ptrs[i] && (bytes[i] & 3u) == 0 && ((uintptr_t)ptrs[i] & 3u) == 0)) {
+            nvo_set_error("zero_ranges: range %u is not 4-byte granular", i);
+            return -1;
+        }
+        r.ptr[k] = (uint32_t*)ptrs[i];
+        r.words[k] = bytes[i] / 4;
+        uint32_t b = nvo_div_up(r.words[k], (uint64_t)256 * 16);  // 16 dwords per thread and pass
+        if (b < 1) b = 1;
+        if (b > 512) b = 512;
+        r.first_block[k] = blocks_total;
+        blocks_total += b;
+        ++k;
+    }
+    r.n = k;
+    for (uint32_t i = k; i <= kZeroMaxRanges; ++i) r.first_block[i] = blocks_total;
+    return (int)blocks_total;
 }
 
 extern "C" {
@@ -849,29 +861,12 @@ int nvo_flag_from_wire(nvo_stream_t stream, const void* wire_slot16, uint32_t* f
 }
 
 int nvo_zero_ranges(nvo_stream_t stream, uint32_t n_ranges, void* const* ptrs, const uint64_t* bytes) {
-    NVO_REQUIRE(n_ranges <= kZeroMaxRanges, "zero_ranges: at most %u ranges (got %u)", kZeroMaxRanges, n_ranges);
-    NVO_REQUIRE(n_ranges == 0 || (ptrs && bytes), "zero_ranges: NULL argument");
-    ZeroRanges r;
-    memset(&r, 0, sizeof(r));
-    uint32_t k = 0, blocks_total = 0;
-    for (uint32_t i = 0; i < n_ranges; ++i) {
-        if (bytes[i] == 0) continue;
-        NVO_REQUIRE(ptrs[i] && (bytes[i] & 3u) == 0 && ((uintptr_t)ptrs[i] & 3u) == 0,
-                    "zero_ranges: range %u is not 4-byte granular", i);
-        r.ptr[k] = (uint32_t*)ptrs[i];
-        r.words[k] = bytes[i] / 4;
-        uint32_t b = nvo_div_up(r.words[k], (uint64_t)256 * 16);  // 16 dwords per thread and pass
-        if (b < 1) b = 1;
-        if (b > 512) b = 512;
-        r.first_block[k] = blocks_total;
-        blocks_total += b;
-        ++k;
-    }
-    if (k == 0) return NVO_OK;
-    r.n = k;
-    for (uint32_t i = k; i <= kZeroMaxRanges; ++i) r.first_block[i] = blocks_total;
+    NvoZeroPlan r;
+    const int blocks_total = nvo_zero_plan_build(n_ranges, ptrs, bytes, &r);
+    if (blocks_total < 0) return NVO_ERR_INVALID;
+    if (blocks_total == 0) return NVO_OK;
     NVO_PROF(stream, "zero_ranges");
-    NVO_LAUNCH(k_zero_ranges, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r);
+    NVO_LAUNCH(k_zero_ranges, dim3((uint32_t)blocks_total), dim3(256), 0, (hipStream_t)stream, r);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

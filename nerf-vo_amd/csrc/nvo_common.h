@@ -122,7 +122,36 @@ uint32_t nvo_grid_levels_init(NvoGridLevels* g, uint32_t n_levels, uint32_t n_fe
                               uint32_t log2_hashmap_size, uint32_t base_resolution,
                               float per_level_scale);
 
+// several device ranges cleared by one launch (a training step's accumulate-into buffers): blocks [first_block[k],
+// first_block[k + 1]) serve range k.  Shared by k_zero_ranges and by the ray head's extra workgroups (nvo_ray_head_zero).
+constexpr uint32_t kZeroMaxRanges = 24;
+struct NvoZeroPlan {
+    uint32_t n;
+    uint32_t first_block[kZeroMaxRanges + 1];
+    uint32_t* ptr[kZeroMaxRanges];
+    uint64_t words[kZeroMaxRanges];
+};
+// host: fills `plan` from (ptrs, bytes); returns the number of 256-thread blocks it needs (0: nothing to clear), < 0 on a
+// bad range (nvo_last_error is set)
+int nvo_zero_plan_build(uint32_t n_ranges, void* const* ptrs, const uint64_t* bytes, NvoZeroPlan* plan);
+
 #ifdef __HIPCC__
+__device__ __forceinline__ void nvo_zero_plan_block(const NvoZeroPlan& r, uint32_t block) {  // blockDim.x == 256
+    uint32_t k = 0;
+    while (k + 1 < r.n && block >= r.first_block[k + 1]) ++k;
+    const uint32_t nb = r.first_block[k + 1] - r.first_block[k];
+    const uint64_t stride = (uint64_t)nb * 256u;
+    uint32_t* __restrict__ p = r.ptr[k];
+    const uint64_t n = r.words[k];
+    const uint64_t tid = (uint64_t)(block - r.first_block[k]) * 256u + threadIdx.x;
+    if ((((uintptr_t)p) & 15u) == 0u) {
+        uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
+        for (uint64_t i = tid; i < n / 4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t i = (n / 4) * 4 + tid; i < n; i += stride) p[i] = 0u;
+    } else {
+        for (uint64_t i = tid; i < n; i += stride) p[i] = 0u;
+    }
+}
 // ---- 16-bit activation storage chosen at run time (wave-uniform flag): fp16 (tcnn's precision) or bfloat16
 // (EngineConfig.mlp_dtype = "bf16", BASELINE configs[4]).  Used by the kernels around the fused MLP, where one
 // select per element is noise; the MLP kernels themselves are compiled per type (mlp_impl.h).

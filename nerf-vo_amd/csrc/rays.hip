@@ -6,6 +6,7 @@
 // 2.4 K8/K12, reference call sites /root/reference/nerf_vo/mapping/nerfstudio_utils.py:286-300.
 // CPU restatement: oracle/rays.py.
 #include "nvo_kernels.h"
+#include <string.h>
 #include "../../include/nerfvo_hip.h"
 
 namespace {
@@ -213,8 +214,14 @@ k_sample_pixels(uint32_t R, uint32_t seed, const float* __restrict__ step_dev, c
 // every thread re-derives its ray (a hash and ~80 flops -- free next to the five launches it replaces, ~6 us each of
 // dispatch + drain for 4096-ray kernels); the thread of sample 0 writes the per-ray outputs.  Same device functions
 // as the separate kernels: the results are bit-identical (tests/test_engine_gpu.py::test_ray_head_matches_separate).
+// Workgroups behind the ray blocks (zero.n != 0: nvo_ray_head_zero) clear the step's accumulate-into buffers: the first
+// launch of a one-graph step does both, a 5 us launch less in front of the main field's forward.
 __global__ void __launch_bounds__(256)
-k_ray_head(nvo_ray_head_args a) {
+k_ray_head(nvo_ray_head_args a, NvoZeroPlan zero, uint32_t ray_blocks) {
+    if (blockIdx.x >= ray_blocks) {  // (uniform)
+        nvo_zero_plan_block(zero, blockIdx.x - ray_blocks);
+        return;
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.R * a.S) return;
     const uint32_t r = i / a.S, j = i - r * a.S;
@@ -477,6 +484,23 @@ int nvo_sh_encode(nvo_stream_t stream, uint32_t R, uint32_t degree, const float*
     return nvo_sh_fwd_launch((hipStream_t)stream, R, degree, dirs01, out_half, 16, 16);
 }
 
+static int ray_head_launch(nvo_stream_t stream, const nvo_ray_head_args& a, uint32_t n_ranges, void* const* ptrs,
+                           const uint64_t* bytes) {
+    NvoZeroPlan zero;
+    memset(&zero, 0, sizeof(zero));
+    int zero_blocks = 0;
+    if (n_ranges) {
+        zero_blocks = nvo_zero_plan_build(n_ranges, ptrs, bytes, &zero);
+        if (zero_blocks < 0) return NVO_ERR_INVALID;
+    }
+    const uint32_t ray_blocks = (uint32_t)nvo_div_up((uint64_t)a.R * a.S, 256);
+    if (ray_blocks + (uint32_t)zero_blocks == 0) return NVO_OK;
+    NVO_PROF(stream, "ray_head[S%u]", a.S);
+    NVO_LAUNCH(k_ray_head, dim3(ray_blocks + (uint32_t)zero_blocks), dim3(256), 0, (hipStream_t)stream, a, zero, ray_blocks);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
 int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args) {
     NVO_REQUIRE(args != nullptr, "ray_head: args is NULL");
     const nvo_ray_head_args a = *args;
@@ -486,11 +510,20 @@ int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args) {
                              a.dirs01 && a.sbins && a.tbins && a.x01), "ray_head: NULL argument");
     NVO_REQUIRE(!a.depths || a.gt_depth, "ray_head: depths without gt_depth");
     NVO_REQUIRE(!a.normals || a.gt_normal, "ray_head: normals without gt_normal");
-    if (a.R == 0) return NVO_OK;
-    NVO_PROF(stream, "ray_head[S%u]", a.S);
-    NVO_LAUNCH(k_ray_head, dim3(nvo_div_up((uint64_t)a.R * a.S, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    NVO_CHECK_LAUNCH();
-    return NVO_OK;
+    return ray_head_launch(stream, a, 0, nullptr, nullptr);
+}
+
+int nvo_ray_head_zero(nvo_stream_t stream, const nvo_ray_head_args* args, uint32_t n_ranges, void* const* ptrs,
+                      const uint64_t* bytes) {
+    NVO_REQUIRE(args != nullptr, "ray_head_zero: args is NULL");
+    const nvo_ray_head_args a = *args;
+    NVO_REQUIRE(a.S >= 1 && a.n_jitter >= 1 && (a.c2w_stride == 12 || a.c2w_stride == 16), "ray_head: bad S / n_jitter / c2w_stride");
+    NVO_REQUIRE(a.R == 0 || (a.step_dev && a.extent_dev && a.intrinsics && a.c2w && a.images && a.ray_indices &&
+                             a.jitter && a.origins && a.directions && a.directions_norm && a.cam_idx && a.gt_rgb &&
+                             a.dirs01 && a.sbins && a.tbins && a.x01), "ray_head: NULL argument");
+    NVO_REQUIRE(!a.depths || a.gt_depth, "ray_head: depths without gt_depth");
+    NVO_REQUIRE(!a.normals || a.gt_normal, "ray_head: normals without gt_normal");
+    return ray_head_launch(stream, a, n_ranges, ptrs, bytes);
 }
 
 int nvo_sh_encode_t(nvo_stream_t stream, uint32_t R, uint32_t degree, const float* dirs01, void* out, int out_bf16) {

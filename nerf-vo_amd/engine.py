@@ -127,6 +127,8 @@ class EngineConfig:
     overlap_pose_backward: bool = True
     # both proposal levels' loss kernels in one launch (nvo_prop_loss_pair)
     pair_proposal_losses: bool = True
+    # one-graph step (single GPU): the step's zero launch rides in extra workgroups of the ray head's launch
+    zero_with_ray_head: bool = True
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
     # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
     commit_behind_replay: bool = True
@@ -760,7 +762,8 @@ class NerfactoEngine:
         # pose gradient by the exp-map backward).  Ranges of groups that do not train this step keep stale values
         # and are neither reduced, checked nor applied.
         pose_active = cfg.optimize_poses and "d_sh" in ws and self._pose_inputs is not None
-        self._zero_step_buffers(ws, bool(update_proposals), bool(pose_active), stream)
+        if not ws.pop("zeroed_by_head", False):  # (one-graph step: the ray head's launch already cleared them)
+            self._zero_step_buffers(ws, bool(update_proposals), bool(pose_active), stream)
         emb_ptr = self._param_ptr("field.embedding", self.params_half).value
         ca = self._forward(ws, True, anneal, jitters, ws["cam_idx"], emb_ptr, stream, anneal_dev=anneal_dev,
                            skip_head=skip_head)
@@ -859,6 +862,8 @@ class NerfactoEngine:
             ranges.append((self.d_corrections.data_ptr(), self.d_corrections.numel() * 4))
         ptrs = (C.c_void_p * len(ranges))(*[p for p, _ in ranges])
         sizes = (C.c_uint64 * len(ranges))(*[b for _, b in ranges])
+        if stream is None:  # (the caller launches: nvo_ray_head_zero)
+            return len(ranges), ptrs, sizes
         _call("nvo_zero_ranges", stream, len(ranges), ptrs, sizes)
 
     def proposal_values_due(self, step: int, updated: bool) -> bool:
@@ -1188,6 +1193,8 @@ class NerfactoEngine:
         step_ptr = C.c_void_p(self.dev_sampling.data_ptr() + 4)
         jits = (jit[0], jit[1], jit[2])
 
+        zero_with_head = False  # set around the capture of the one-graph step (whole())
+
         def body_head(levels=None):
             """Sampling prefix.  levels: None = all of it; (0,) = rays + proposal level 0; (1,) = proposal level 1."""
             first = levels is None or 0 in levels
@@ -1230,7 +1237,14 @@ class NerfactoEngine:
                 cam_idx=ws["cam_idx"].data_ptr(), gt_rgb=ws["gt_rgb"].data_ptr(), gt_depth=ws["gt_depth"].data_ptr(),
                 gt_normal=ws["gt_normal"].data_ptr(), dirs01=ws["dirs01"].data_ptr(), sh=ws["sh"].data_ptr(),
                 sh_bf16=int(self.bf16), sbins=ws["sbins0"].data_ptr(), tbins=ws["tbins0"].data_ptr(), x01=ws["x0"].data_ptr())
-            _call("nvo_ray_head", stream, C.byref(ra))
+            if zero_with_head:
+                # one-graph step: the launch that opens the step also clears its accumulate-into buffers
+                pose_z = cfg.optimize_poses and "d_sh" in ws
+                nz, zp, zs = self._zero_step_buffers(ws, bool(updated), bool(pose_z), None)
+                _call("nvo_ray_head_zero", stream, C.byref(ra), nz, zp, zs)
+                ws["zeroed_by_head"] = True
+            else:
+                _call("nvo_ray_head", stream, C.byref(ra))
             ws["dirs01_ready"] = True
             ws["sh_ready"] = True
             self._forward_head(ws, 1.0, jits, stream, anneal_dev=anneal_ptr, skip_first_level=True, levels=levels)
@@ -1370,6 +1384,7 @@ class NerfactoEngine:
                 body_head()
                 body_rest()
                 body_opt(groups_b)
+            zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
             if not cfg.commit_behind_replay:
                 entry["main"] = capture(whole)
                 return entry
