@@ -146,7 +146,11 @@ def main() -> None:
     ap.add_argument("--commit-in-graph", action="store_true", help="the optimiser's commit as the graph's last node (A/B)")
     ap.add_argument("--separate-zero", action="store_true", help="the step's zero launch as its own graph node (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
-                    help="GradScaler dynamics (init 65536, x2 / 2000 clean steps, x0.5 on overflow) instead of the static scale 128")
+                    help="(the default since round 4) GradScaler dynamics: init 65536, x2 / 2000 clean steps, x0.5 on overflow "
+                         "-- the reference's mixed_precision=True, /root/reference/nerf_vo/mapping/nerfstudio.py:59")
+    ap.add_argument("--static-loss-scale", action="store_true",
+                    help="A/B: tcnn's static loss scale 128 (rounds 1-3's headline regime: most fp16 proposal-loss gradients "
+                         "underflow to exactly zero there and the grid backward skips them)")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
                     help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
@@ -222,8 +226,7 @@ def main() -> None:
         cfg.proposal_backward_streams = args.proposal_streams
     if args.pipeline_single_gpu:
         cfg.pipeline_single_gpu = True
-    if args.dynamic_loss_scale:
-        cfg.dynamic_loss_scale = True
+    cfg.dynamic_loss_scale = not args.static_loss_scale
     if args.no_pair_losses:
         cfg.pair_proposal_losses = False
     if args.commit_in_graph:
@@ -491,6 +494,12 @@ def main() -> None:
                                     if (args.optimize_poses and args.workload == "replica") else
                                     wl["name"] + (", SE3 pose-gradient backprop enabled" if args.optimize_poses else "")),
                        "normal_supervision": use_normals,
+                       # the reference's regime (mixed_precision=True -> torch GradScaler around tcnn's 16-bit networks)
+                       "loss_scale": ("GradScaler 65536 dynamic" if cfg.dynamic_loss_scale else
+                                      "static 128 (tcnn default; A/B only)"),
+                       # orientation / predicted-normal losses have multiplier 0 in the reference's configuration
+                       # (nerfstudio.py:74-75): exactly zero loss and gradient, their heads are not evaluated
+                       "skipped_zero_weight_heads": True,
                        "rays_per_gpu": args.rays, "samples_per_ray": cfg.num_nerf_samples,
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",

@@ -716,9 +716,13 @@ struct NwieModule : nvo_module_s {
         return enc->grid_zero_ranges(dparams ? dparams + net->n_params : nullptr, out);
     }
     hipEvent_t ev_fork = nullptr;  // nvo_bwd_fork: network backward done -> the encoding's parameter backward may start
+    // per-workgroup L1 sums (and live-sample counts) of dL/d(encoded), written by the network's backward and read by the
+    // encoding's 32-bit slice-owner items: NvoMlpArgsT::dx_l1_partial.  [blocks][in_pad] floats | [blocks] uint32
+    NvoScratch l1_scratch;
     ~NwieModule() override {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (d_levels) (void)hipFree(d_levels);
+        nvo_scratch_destroy(&l1_scratch);
     }
     int bwd(hipStream_t s, uint32_t B, const float* in, const void* params, const void* out,
             const void* dout, void* ctx, float* din, float* dparams) override {
@@ -743,6 +747,18 @@ struct NwieModule : nvo_module_s {
         if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         if (int rc0 = net->det_partials(s, B, &a)) return rc0;
+        // the encoding's 32-bit accumulators (slice-owner items) scale by the L1 norm of dL/d(encoded): the network's
+        // backward sums it while it stores those values -- no pass of its own over them
+        static const bool l1_from_mlp = [] { const char* e = getenv("NVO_GRID_L1_FROM_MLP"); return !e || atoi(e) != 0; }();
+        const NvoGridSlices* owner = enc->bwd_mode == 1 ? &enc->slices : enc->bwd_mode == 3 ? &enc->stream_bins.owner : nullptr;
+        const bool want_l1 = l1_from_mlp && dparams && owner && owner->acc_bits == 32;
+        const uint32_t l1_blocks = want_l1 ? nvo_mlp_bwd_blocks(net->in_pad, net->width, net->n_hidden, B) : 0u;
+        if (want_l1) {
+            const size_t bytes = sizeof(float) * (size_t)l1_blocks * (net->in_pad + 1);
+            if (int rc0 = nvo_scratch_reserve(&l1_scratch, bytes, s, "grid L1 partials")) return rc0;
+            a.dx_l1_partial = static_cast<float*>(l1_scratch.ptr);
+            a.dx_live_partial = compact_out ? reinterpret_cast<uint32_t*>(a.dx_l1_partial + (size_t)l1_blocks * net->in_pad) : nullptr;
+        }
         int rc = nvo_mlp_bwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
         if (rc) return rc;
         if (dparams) {
@@ -751,7 +767,18 @@ struct NwieModule : nvo_module_s {
                 NVO_CHECK_HIP(hipEventRecord(ev_fork, s));
                 NVO_CHECK_HIP(hipStreamWaitEvent(sp, ev_fork, 0));
             }
+            if (want_l1) {
+                owner->ext_l1 = a.dx_l1_partial;
+                owner->ext_live = a.dx_live_partial;
+                owner->ext_blocks = l1_blocks;
+                owner->ext_l1_stride = (uint32_t)net->in_pad;
+            }
             rc = enc->bwd_params(sp, B, in, dencoded, true, dparams + net->n_params);
+            if (want_l1) {
+                owner->ext_l1 = nullptr;
+                owner->ext_live = nullptr;
+                owner->ext_blocks = owner->ext_l1_stride = 0u;
+            }
             if (rc) return rc;
         }
         if (din) {

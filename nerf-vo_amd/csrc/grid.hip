@@ -485,6 +485,13 @@ constexpr uint32_t kSliceFixed = 8192;
 constexpr uint32_t kSliceFloat = 20448;  // (160 KiB less 256 B: the item's work counter is static LDS)
 constexpr uint32_t kLdsBwdBytes = 160 * 1024;
 constexpr int kLdsBwdBlock = 1024;
+// Hit queue of the slice-owner scan on HASHED levels (round 4): a (y, z) corner pair of a sample falls into the item's
+// slice with probability 1 / (slices of the level) -- 1/8 for the proposal grids -- so nearly every wave ran the ~26
+// instruction accumulate path 16 times per pass with an eighth of its lanes active.  Each wave now PUSHES its hits into a
+// private ring in the LDS the 32-bit accumulators leave free (128 KiB of the CU's 160) and drains 64 entries at a time
+// with every lane busy.  127 entries of 16 bytes per wave: 16 x 2032 B + 128 KiB = 160 KiB - 256 B.
+constexpr uint32_t kHitCap = 127;
+constexpr uint32_t kHitRingBytes = 16u * kHitCap * (kLdsBwdBlock / 64);
 constexpr float kFixScale = 67108864.f;          // 2^26
 constexpr float kFixInv = 1.0f / 67108864.f;
 
@@ -562,7 +569,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
                                               const uint32_t* __restrict__ live = nullptr, bool merge = false,
                                               uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr,
-                                              const uint32_t* __restrict__ live_n = nullptr) {
+                                              const uint32_t* __restrict__ live_n = nullptr, uint32_t ring_off = 0u) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -712,6 +719,88 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             }
             if (open && hit) flush();
         }
+    } else if (pair_bins && ring_off != 0u) {
+        // HASHED level with a hit queue (kHitCap).  Everything up to the slice test runs for all 64 lanes; the pairs that
+        // fall into this slice (one in `slices of the level` on average) are pushed into the wave's ring -- 16 bytes:
+        // in-slice offset | px << 14, w_y w_z dy_0, w_y w_z dy_1, w_x -- and whenever 64 are waiting the whole wave
+        // splits them into their two x corners and adds them.  The ring is private to the wave (LDS operations of one
+        // wave execute in order: no barrier), head and fill level are wave-uniform scalars, and every push sits in
+        // wave-uniform control flow (a ballot under a lane-divergent branch would let the lanes disagree about them).
+        uint4* const ring = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(lds_raw) + ring_off) +
+                            (threadIdx.x >> 6) * kHitCap;
+        uint32_t q_head = 0u, q_fill = 0u;
+        auto q_drain = [&](uint32_t n) {  // the n <= 64 oldest entries
+            if (lane_id < n) {
+                uint32_t p = q_head + lane_id;
+                if (p >= kHitCap) p -= kHitCap;
+                const uint4 e = ring[p];
+                const uint32_t lo = e.x & (ACC::kEntries - 1u), px = e.x >> 14;
+                const float u0 = __uint_as_float(e.y), u1 = __uint_as_float(e.z), wx = __uint_as_float(e.w);
+                const float wx0 = 1.f - wx;
+                ACC::add(acc, lo ^ px, wx0 * u0, wx0 * u1, sc);
+                ACC::add(acc, lo ^ (px + 1u), wx * u0, wx * u1, sc);
+            }
+            q_head += n;
+            if (q_head >= kHitCap) q_head -= kHitCap;
+            q_fill -= n;
+        };
+        auto q_push = [&](bool hit, uint32_t word, float u0, float u1, float wx) {
+            const unsigned long long m = __ballot(hit);
+            const uint32_t c = (uint32_t)__popcll(m);
+            if (q_fill + c > kHitCap) {  // (cannot happen below 64 waiting entries unless > 63 lanes hit at once)
+                while (q_fill) q_drain(min(q_fill, 64u));
+            }
+            if (hit) {
+                uint32_t p = q_head + q_fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (p >= kHitCap) p -= kHitCap;
+                ring[p] = make_uint4(word, __float_as_uint(u0), __float_as_uint(u1), __float_as_uint(wx));
+            }
+            q_fill += c;
+            if (q_fill >= 64u) q_drain(64u);
+        };
+        for (uint32_t c0 = wave_grab(64u * kUnroll); begin + c0 < end; c0 = wave_grab(64u * kUnroll)) {
+            const uint32_t i0 = begin + c0 + lane_id;
+            float2 dv[kUnroll];
+            float xv[kUnroll][3];
+            uint32_t sid[kUnroll];
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const uint32_t j = i0 + u * 64u;
+                sid[u] = j < end ? (listed ? live[j] : j) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const uint32_t i = sid[u];
+                dv[u] = make_float2(0.f, 0.f);
+                xv[u][0] = xv[u][1] = xv[u][2] = 0.f;
+                if (i0 + u * 64u < end) {
+                    const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
+                    dv[u] = dy2f(d2);
+                    xv[u][0] = x[3 * (size_t)i + 0];
+                    xv[u][1] = x[3 * (size_t)i + 1];
+                    xv[u][2] = x[3 * (size_t)i + 2];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const float2 d = dv[u];
+                bad = bad || !(fabsf(d.x) < INFINITY) || !(fabsf(d.y) < INFINITY);
+                const bool lv = d.x != 0.f || d.y != 0.f;  // (out-of-range slots carry d = 0)
+                const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
+                const float wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+                const float wyz[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
+                const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
+                const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
+                const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t h = a[j] & mask;
+                    q_push(lv && (h & ~(ACC::kEntries - 1u)) == first, (h & (ACC::kEntries - 1u)) | (c.px << 14),
+                           wyz[j] * d.x, wyz[j] * d.y, c.wx);
+                }
+            }
+        }
+        while (q_fill) q_drain(min(q_fill, 64u));
     } else
     for (uint32_t c0 = wave_grab(64u * kUnroll); begin + c0 < end; c0 = wave_grab(64u * kUnroll)) {
         const uint32_t i0 = begin + c0 + lane_id;
@@ -811,6 +900,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
         GP_CLK(go4);
         const int o = hashed ? 24 : 16;
         GP_ADD(o + 0, go1 - go0); GP_ADD(o + 1, go2 - go1); GP_ADD(o + 2, go3 - go2); GP_ADD(o + 3, go4 - go3); GP_ADD(o + 4, 1);
+        if (level < 5u) { GP_ADD(38 + level, go2 - go1); GP_ADD(43 + level, 1); }  // scan cycles / items per level (L <= 5 grids)
     }
 #endif
     if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) {
@@ -880,24 +970,53 @@ __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
                const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
-               const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_n) {
+               const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_n,
+               uint32_t ring_off, const float* __restrict__ ext_l1, uint32_t ext_blocks, uint32_t ext_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
     const bool merge = (item.w >> 29) & 1u;
     const uint32_t level = item.x & 0xFFu, cap = item.x >> 8;  // cap: entries per slice of this level
+    // 32-bit accumulators, L1 norms delivered by the fused-MLP backward that wrote dy (NvoGridSlices::ext_l1): the
+    // workgroups' partial sums are added up in a fixed order (same scale in every item and every run)
+    __shared__ float s_l1[kLdsBwdBlock / 64][2];
+    float l1e[2] = {0.f, 0.f};
+    if (ext_l1 && ((item.w >> 30) & 1u) && !(item.w >> 31)) {
+        float a = 0.f, b = 0.f;
+        for (uint32_t blk = threadIdx.x; blk < ext_blocks; blk += kLdsBwdBlock) {
+            a += ext_l1[(size_t)blk * ext_stride + 2 * level];
+            b += ext_l1[(size_t)blk * ext_stride + 2 * level + 1];
+        }
+        a = nvo_wave_sum(a);
+        b = nvo_wave_sum(b);
+        if ((threadIdx.x & 63u) == 0u) {
+            s_l1[threadIdx.x >> 6][0] = a;
+            s_l1[threadIdx.x >> 6][1] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kLdsBwdBlock / 64; ++w) {
+            l1e[0] += s_l1[w][0];
+            l1e[1] += s_l1[w][1];
+        }
+        // upper bound of the exact sum (fp32 summation error of <= a few thousand terms) -- the 2^29 scale leaves a
+        // factor of four of headroom inside int32 on top of this
+        l1e[0] = l1e[0] * 1.001f + 1e-30f;
+        l1e[1] = l1e[1] * 1.001f + 1e-30f;
+    }
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
                                           AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
     } else if ((item.w >> 30) & 1u) {
-        const float l1x = (float)l1[2 * level] * (1.f / 256.f), l1y = (float)l1[2 * level + 1] * (1.f / 256.f);
+        const float l1x = ext_l1 ? l1e[0] : (float)l1[2 * level] * (1.f / 256.f);
+        const float l1y = ext_l1 ? l1e[1] : (float)l1[2 * level + 1] * (1.f / 256.f);
         AccScale sc;
         sc.s0 = l1x > 0.f ? 536870912.f / l1x : 0.f;  // 2^29 / L1
         sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
         grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge, cap, nf_flag, live_n);
+                                            merge, cap, nf_flag, live_n, ring_off);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
                                           AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
@@ -915,7 +1034,25 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(1024)
 k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ count,
-               uint32_t* __restrict__ out, unsigned long long* __restrict__ l1) {
+               uint32_t* __restrict__ out, unsigned long long* __restrict__ l1, const uint32_t* __restrict__ ext_live,
+               uint32_t ext_blocks) {
+    // ext_live (NvoGridSlices::ext_live): the fused-MLP backward that wrote dy counted the samples with a non-zero
+    // dL/doutput per workgroup.  While at least 3/4 of them are live the items scan all samples anyway (grid_bwd_item:
+    // `listed`): nobody needs the list, every workgroup leaves at once and the length word says "all N".
+    if (ext_live) {
+        __shared__ uint32_t s_cnt[16];
+        uint32_t c = 0u;
+        for (uint32_t b = threadIdx.x; b < ext_blocks; b += 1024u) c += ext_live[b];
+        c = (uint32_t)nvo_wave_sum((float)c);  // (exact: < 2^24 per wave)
+        if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        uint32_t tot = 0u;
+        for (int w = 0; w < 16; ++w) tot += s_cnt[w];
+        if (tot >= N - (N >> 2)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(count, N);
+            return;
+        }
+    }
     // l1 != nullptr (32-bit accumulators, <= 8 levels): the per-level L1 norms of dy that k_dy_l1 computes are summed
     // in the same pass -- both kernels read every dy once, and each cost ~14 us per 1 M-sample launch
     // one workgroup per 4096 consecutive samples, ONE global atomic per workgroup (a wave-level append put 16 K atomics
@@ -3087,7 +3224,19 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                 return rc;
         }
         const dim3 grid(slices->n_slices), block(kLdsBwdBlock);
-        const size_t lds = slices->lds_bytes;
+        size_t lds = slices->lds_bytes;
+        // hit queue of the hashed levels' items (kHitCap): the wave rings sit behind the 32-bit accumulators
+        uint32_t ring_off = 0u;
+        {
+            static const bool hitq = [] { const char* e = getenv("NVO_GRID_HITQ"); return !e || atoi(e) != 0; }();
+            bool any_hashed = false;
+            for (uint32_t l = 0; l < g.n_levels; ++l) any_hashed = any_hashed || (((slices->level_mask >> l) & 1u) && g.hashed[l]);
+            if (hitq && any_hashed && slices->acc_bits == 32 && lds == 2 * AccFixed32::kEntries * sizeof(int) &&
+                lds + kHitRingBytes <= kLdsBwdBytes - 256) {
+                ring_off = (uint32_t)lds;
+                lds += kHitRingBytes;
+            }
+        }
         const uint32_t* live = nullptr;
         bool l1_fused = false;
         if (slices->compact_live && !slices->deterministic) {  // (the list's append order would change the run sums)
@@ -3097,17 +3246,17 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             if (!slices->external_zero)  // (otherwise cleared by the step's zero launch: nvo_grid_slices_zero_ranges)
                 if (int rc = nvo_zero_async(slices->d_live_n, sizeof(uint32_t), stream)) return rc;
             // (32-bit accumulators, <= 8 levels: the L1 norms of dy ride in the same pass)
-            l1_fused = slices->acc_bits == 32 && g.n_levels <= 8 && dy_fmt != NVO_DY_FLOAT;
+            l1_fused = slices->acc_bits == 32 && g.n_levels <= 8 && dy_fmt != NVO_DY_FLOAT && !slices->ext_l1;
             if (l1_fused && !slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
 #define NVO_LAUNCH_LIVE(SOA_, T_)                                                                                    \
     NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, \
-               slices->d_live_n, d_live, l1_fused ? slices->d_l1 : nullptr)
+               slices->d_live_n, d_live, l1_fused ? slices->d_l1 : nullptr, slices->ext_live, slices->ext_blocks)
             if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
 #undef NVO_LAUNCH_LIVE
             live = d_live;
         }
-        if (slices->acc_bits == 32 && !l1_fused) {
+        if (slices->acc_bits == 32 && !l1_fused && !slices->ext_l1) {
             NVO_REQUIRE(dy_fmt != NVO_DY_FLOAT, "grid: 32-bit accumulators need 16-bit dL/dy (set grid_acc_bits to 64)");
             if (!slices->external_zero)
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
@@ -3136,7 +3285,8 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             attr_set = true;                                                                  \
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
-                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag, slices->d_live_n); \
+                           (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag, slices->d_live_n, ring_off, \
+                           slices->ext_l1, slices->ext_blocks, slices->ext_l1_stride); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

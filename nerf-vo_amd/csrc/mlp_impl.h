@@ -634,6 +634,14 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     DwAcc<WIDTH, IN_PAD> dw0;
     DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
     DwAcc<OUT_PAD, WIDTH> dwl;
+    // (level-major dinput) L1 norm of the 16-bit dL/dinput values this lane stores, per column 16 tk + 4 g + j, and the
+    // wave's count of samples with a non-zero dL/doutput: Args::dx_l1_partial / dx_live_partial
+    float l1a[IN_PAD / 16][4];
+    uint32_t live_cnt = 0u;
+#pragma unroll
+    for (int tk = 0; tk < IN_PAD / 16; ++tk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l1a[tk][j] = 0.f;
     dw0.zero();
 #pragma unroll
     for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
@@ -723,7 +731,9 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             // the chain.  (The proposal networks of a nerfacto run: from a few hundred steps on 80-93 % of level 0's
             // tiles and 46-68 % of level 1's -- the interlevel loss is zero wherever the proposal weights stay under
             // the bound and fp16 flushes what is left below 6e-8 -- DESIGN.md section 7.1.)
-            if (__ballot((float)cur.dzl[0][0] != 0.f) == 0ull) {
+            const unsigned long long live_m = __ballot((float)cur.dzl[0][0] != 0.f);  // (lanes g != 0 hold zeros)
+            live_cnt += (uint32_t)__popcll(live_m);
+            if (live_m == 0ull) {
                 if (need_dinput) {
                     T2* __restrict__ p = (T2*)a.dinput;
                     const uint32_t n_lv = a.n_in >> 1;
@@ -867,11 +877,13 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
                 for (int tk = 0; tk < IN_PAD / 16; ++tk) {
                     const uint32_t lv = 8 * tk + 2 * g;
-                    if (lv < n_lv)
-                        p[(size_t)lv * a.batch + row] = T2{(T)acc[tk][0], (T)acc[tk][1]};
-                    if (lv + 1 < n_lv)
-                        p[(size_t)(lv + 1) * a.batch + row] =
-                            T2{(T)acc[tk][2], (T)acc[tk][3]};
+                    const T2 q0 = T2{(T)acc[tk][0], (T)acc[tk][1]}, q1 = T2{(T)acc[tk][2], (T)acc[tk][3]};
+                    if (lv < n_lv) p[(size_t)lv * a.batch + row] = q0;
+                    if (lv + 1 < n_lv) p[(size_t)(lv + 1) * a.batch + row] = q1;
+                    l1a[tk][0] += fabsf((float)q0[0]);  // (columns beyond n_in are never read)
+                    l1a[tk][1] += fabsf((float)q0[1]);
+                    l1a[tk][2] += fabsf((float)q1[0]);
+                    l1a[tk][3] += fabsf((float)q1[1]);
                 }
             } else if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
                 if constexpr (IN_PAD == 64) {
@@ -961,7 +973,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     if (a.dweights) {
         __syncthreads();  // every wave is done with its LDS tiles
         float* red = reinterpret_cast<float*>(lds);
-        constexpr int kLdsFloats = (int)(sizeof(lds) / sizeof(float));
+        constexpr int kLdsFloats = (int)(sizeof(T) * kLdsHalfs / sizeof(float));
         static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
                       "dW block reduction does not fit the LDS tiles");
         float* dW = a.dweights;
@@ -977,6 +989,33 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             if (part) part += WIDTH * WIDTH;
         }
         dwl.flush_block(dW, red, lane, wib, part);
+    }
+    if constexpr (IO == NVO_IO_HALF2_SOA) {
+        if (a.dx_l1_partial && need_dinput) {  // (kernel-uniform)
+            __syncthreads();  // the LDS tiles / the dW reduction buffer are idle
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int tk = 0; tk < IN_PAD / 16; ++tk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = group16_sum(l1a[tk][j]);  // over the 16 sample lanes of this lane group
+                    if (m == 0) red[wib * IN_PAD + 16 * tk + 4 * g + j] = v;
+                }
+            if (lane == 0) reinterpret_cast<uint32_t*>(red)[kWavesPerBlock * IN_PAD + wib] = live_cnt;
+            __syncthreads();
+            if ((int)threadIdx.x < IN_PAD) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; ++w) t += red[w * IN_PAD + threadIdx.x];
+                a.dx_l1_partial[(size_t)blockIdx.x * IN_PAD + threadIdx.x] = t;
+            }
+            if (threadIdx.x == 0 && a.dx_live_partial) {
+                uint32_t c = 0u;
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; ++w) c += reinterpret_cast<uint32_t*>(red)[kWavesPerBlock * IN_PAD + w];
+                a.dx_live_partial[blockIdx.x] = c;
+            }
+        }
     }
 #ifdef NVO_MLP_PHASE
     NVO_PH(11);  // dW flush (block reduction through LDS + float atomics)

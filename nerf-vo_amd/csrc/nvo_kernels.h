@@ -51,6 +51,12 @@ struct NvoGridSlices {
     // gradient entry): the optimiser's overflow flag raised at the source -- the k_tl_accumulate passes of a stream
     // layout use their owner's word
     uint32_t* nf_flag = nullptr;
+    // (set per launch by NetworkWithInputEncoding's backward, cleared afterwards) per-workgroup L1 sums of dL/d(encoded)
+    // written by the fused-MLP backward that produced it: ext_l1[block][ext_l1_stride] floats, column 2 * level + feature;
+    // ext_live[block] = samples with a non-zero dL/doutput (nullable).  See NvoMlpArgsT::dx_l1_partial.
+    mutable const float* ext_l1 = nullptr;
+    mutable const uint32_t* ext_live = nullptr;
+    mutable uint32_t ext_blocks = 0, ext_l1_stride = 0;
 };
 #include <utility>
 #include <vector>
@@ -210,6 +216,13 @@ struct NvoMlpArgsT {
     // tile_partial[tile][48] = {embedding 32 | d_sh 16} instead of float atomics (nvo_color_tile_reduce sums them)
     float* dw_partial;
     float* tile_partial;
+    // NVO_IO_HALF2_SOA backward with dinput (networks behind a hash grid; nullable): every workgroup STORES the L1 norm of
+    // the dL/dinput values it wrote, per input column, to dx_l1_partial[block][IN_PAD] (and, compact_out, the number of
+    // its samples with a non-zero dL/doutput to dx_live_partial[block]).  The grid backward's 32-bit accumulators take
+    // their overflow-proof scale from these sums instead of a pass of their own over dL/d(encoded) (k_dy_l1 / the L1 half
+    // of k_live_samples: ~14 us per 1 M-sample launch), and k_live_samples leaves at once while most samples are live.
+    float* dx_l1_partial;
+    uint32_t* dx_live_partial;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

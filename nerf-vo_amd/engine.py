@@ -78,9 +78,11 @@ class EngineConfig:
     # torch.cuda.amp.GradScaler dynamics (the reference trains with mixed_precision=True,
     # /root/reference/nerf_vo/mapping/nerfstudio.py:59 -- nerfstudio wraps the step in GradScaler(): init 65536, x2 after
     # 2000 consecutive clean steps, x0.5 when any optimiser saw a non-finite gradient).  The state (scale, growth
-    # tracker, per-group applied-step counters) lives on the device, so the captured step stays valid.  False = tcnn's
-    # static loss scale (`loss_scale`) + skip-on-non-finite.
-    dynamic_loss_scale: bool = False
+    # tracker, per-group applied-step counters) lives on the device, so the captured step stays valid.  True is the
+    # DEFAULT since round 4: it is the regime the reference trains in (at the static scale most proposal-loss gradients
+    # underflow fp16 and the grid backward skips them -- a shortcut the reference never gets).  False = tcnn's static
+    # loss scale (`loss_scale`) + skip-on-non-finite.
+    dynamic_loss_scale: bool = True
     loss_scale_init: float = 65536.0
     loss_scale_growth: float = 2.0
     loss_scale_backoff: float = 0.5

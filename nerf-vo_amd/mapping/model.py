@@ -45,9 +45,12 @@ class DepthNerfactoModelConfig:
     should_decay_sigma: bool = False
     eval_num_rays_per_chunk: int = 1 << 15
     mlp_dtype: str = "f16"  # "bf16": fused MLPs on bf16 MFMA, hash tables fp16 + fp32 accumulate (BASELINE configs[4])
-    # EngineConfig.deterministic / .dynamic_loss_scale (GradScaler dynamics of the reference's mixed_precision=True)
+    # EngineConfig.deterministic / .dynamic_loss_scale.  None = follow TrainerConfig.mixed_precision (Trainer.setup):
+    # mixed_precision=True (/root/reference/nerf_vo/mapping/nerfstudio.py:59) means torch's GradScaler() around the step
+    # -- scale 65536, x2 after 2000 clean steps, x0.5 on overflow -- on top of tcnn's 16-bit networks; False = tcnn's own
+    # static scale 128.  A model built without a trainer treats None as True (the reference's regime).
     deterministic: bool = False
-    dynamic_loss_scale: bool = False
+    dynamic_loss_scale: bool | None = None
     camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
 
 
@@ -104,7 +107,8 @@ class ExtendedNerfactoModel:
             depth_sigma=config.depth_sigma, normal_loss_mult=float(config.normal_loss_mult),
             max_num_iterations=max_num_iterations, seed=seed, mlp_dtype=config.mlp_dtype,
             expect_normals=bool(use_normals) and float(config.normal_loss_mult) > 0.0,
-            deterministic=bool(config.deterministic), dynamic_loss_scale=bool(config.dynamic_loss_scale),
+            deterministic=bool(config.deterministic),
+            dynamic_loss_scale=True if config.dynamic_loss_scale is None else bool(config.dynamic_loss_scale),
             optimize_poses=config.camera_optimizer.mode in ("SE3", "SO3xR3"),
             camera_mode=config.camera_optimizer.mode if config.camera_optimizer.mode in ("SE3", "SO3xR3") else "SE3",
             camera_trans_l2_penalty=config.camera_optimizer.trans_l2_penalty,

@@ -55,7 +55,7 @@ class Nerfstudio:
                     is_euclidean_depth=False, depth_sigma=0.001, should_decay_sigma=False,
                     # (not in the reference's argument set: optional switches of this build, off unless given)
                     deterministic=bool(getattr(args, "deterministic", False)),
-                    dynamic_loss_scale=bool(getattr(args, "dynamic_loss_scale", False)),
+                    dynamic_loss_scale=getattr(args, "dynamic_loss_scale", None),  # None: follows mixed_precision
                     **({"camera_optimizer": CameraOptimizerConfig(mode=args.camera_optimizer_mode)}
                        if getattr(args, "camera_optimizer_mode", None) else {}))),
             optimizers={

@@ -207,6 +207,10 @@ class Trainer:
         self.pipeline: VanillaPipeline | None = None
 
     def setup(self, test_mode="val") -> None:
+        # mixed_precision -> GradScaler (/root/reference/nerf_vo/mapping/nerfstudio.py:59; nerfstudio's Trainer builds
+        # GradScaler(enabled=mixed_precision)): the engine's dynamic loss scale, unless the model config pins it
+        if self.config.pipeline.model.dynamic_loss_scale is None:
+            self.config.pipeline.model.dynamic_loss_scale = bool(self.config.mixed_precision)
         self.pipeline = self.config.pipeline.setup(device=self.device, test_mode=test_mode,
                                                    world_size=self.world_size, local_rank=self.local_rank,
                                                    max_num_iterations=self.config.max_num_iterations)

@@ -35,6 +35,9 @@ def main():
                     help="mode 3, tile-local layout: accumulators of the record pass (64 | 32 = packed, 8192-entry bins)")
     ap.add_argument("--show-fwd", action="store_true", help="also print the forward gather's time")
     ap.add_argument("--runs", type=int, default=1, help="run-merging scan of the slice-owner items (grid_bwd_runs)")
+    ap.add_argument("--phase", action="store_true",
+                    help="library built with NVO_EXTRA_CXXFLAGS=-DNVO_GRID_PHASE: shader clocks per phase of the slice-owner items")
+    ap.add_argument("--dead", type=float, default=0.0, help="share of the samples whose dL/dy is exactly zero (ray-coherent runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.lib()
@@ -54,6 +57,9 @@ def main():
         if args.random_x:
             x = torch.rand(n, 3, device=dev)
         dy = torch.randn(n, enc.n_output_dims, device=dev)
+        if args.dead > 0:  # dead samples come in runs along the rays (what the proposal losses produce)
+            runs = (torch.rand((n + 15) // 16, device=dev) < args.dead).repeat_interleave(16)[:n]
+            dy[runs] = 0
         variants = []
         for mode in args.modes:
             if mode == 3:
@@ -75,6 +81,9 @@ def main():
                 if it == 3:
                     torch.cuda.synchronize()
                     lib.nvo_profile_enable(1)
+                    if args.phase:
+                        ph = (C.c_ulonglong * 48)()
+                        assert lib.nvo_debug_grid_phase(ph, 1) == 0
                 enc.params.grad = None
                 y = enc(x)
                 (y.float() * dy).sum().backward()
@@ -89,6 +98,15 @@ def main():
                     continue
                 tag = f"mode={mode}" + (f" tile={tile} owner<={mask} layout={layout} acc={sab}" if mode == 3 else "")
                 print(f"{label:14s} N={n:8d} {tag:32s} {name:24s} avg {float(total) / int(cnt) * 1e3:9.1f} us")
+            if args.phase:
+                assert lib.nvo_debug_grid_phase(ph, 0) == 0
+                v = [int(q) for q in ph]
+                for kind, o in (("dense", 16), ("hashed", 24)):
+                    k = max(v[o + 4], 1)
+                    print(f"{label:14s}   {kind:6s} items/launch {v[o + 4] / args.iters:6.0f}  cycles/item: zero {v[o] / k:8.0f} "
+                          f"scan {v[o + 1] / k:8.0f} barrier {v[o + 2] / k:8.0f} flush {v[o + 3] / k:8.0f}")
+                print(f"{label:14s}   scan cycles per item by level: " + "  ".join(
+                    f"L{l}: {v[38 + l] / max(v[43 + l], 1):.0f} ({v[43 + l] / args.iters:.0f} items)" for l in range(5)))
 
 
 if __name__ == "__main__":

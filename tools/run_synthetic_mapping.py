@@ -21,7 +21,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 
 def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chunk=8, device="cuda:0", quiet=False,
-        out_dir=None, enhancement="depth", log_every=0, deterministic=False, dynamic_loss_scale=False, seed=None,
+        out_dir=None, enhancement="depth", log_every=0, deterministic=False, dynamic_loss_scale=None, seed=None,
         camera_optimizer_mode=None):
     entry.build()
     if seed is not None:  # (the stateless pixel / jitter sampler follows torch's seed)
@@ -101,7 +101,7 @@ def run(keyframes=48, height=240, width=320, iterations=1500, eval_frames=6, chu
         "psnr_reference_uint8wrap": float(np.mean(psnr_ref)), "psnr_float_mse": float(np.mean(psnr_flt)),
         "depth_l1": float(np.mean(depth_l1)), "psnr_float_mse_keyframe_views": float(np.mean(psnr_train)),
         "depth_l1_keyframe_views": float(np.mean(depth_l1_train)), "final_losses": mapper.trainer.pipeline.model.engine.loss_dict(),
-        "snapshot_dir": out_dir, "deterministic": bool(deterministic), "dynamic_loss_scale": bool(dynamic_loss_scale),
+        "snapshot_dir": out_dir, "deterministic": bool(deterministic), "dynamic_loss_scale": bool(mapper.trainer.pipeline.model.engine.cfg.dynamic_loss_scale),
         "seed": seed, "camera_optimizer_mode": camera_optimizer_mode or "SE3",
         "loss_scale_end": mapper.trainer.pipeline.model.engine.current_loss_scale(),
         "opt_steps": mapper.trainer.pipeline.model.engine.opt_steps,
@@ -121,9 +121,10 @@ if __name__ == "__main__":
     ap.add_argument("--eval-frames", type=int, default=6)
     ap.add_argument("--log-every", type=int, default=0)
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--dynamic-loss-scale", action="store_true")
+    ap.add_argument("--dynamic-loss-scale", action="store_true", help="(the default since round 4: GradScaler, as the reference)")
+    ap.add_argument("--static-loss-scale", action="store_true", help="tcnn's static loss scale 128 instead of GradScaler's dynamics")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--camera-optimizer-mode", default=None, help="SE3 (default) | SO3xR3 | off")
     a = ap.parse_args()
     run(a.keyframes, a.height, a.width, a.iterations, a.eval_frames, log_every=a.log_every, deterministic=a.deterministic,
-        dynamic_loss_scale=a.dynamic_loss_scale, seed=a.seed, camera_optimizer_mode=a.camera_optimizer_mode)
+        dynamic_loss_scale=False if a.static_loss_scale else None, seed=a.seed, camera_optimizer_mode=a.camera_optimizer_mode)
