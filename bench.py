@@ -227,6 +227,10 @@ def main() -> None:
     if args.pipeline_single_gpu:
         cfg.pipeline_single_gpu = True
     cfg.dynamic_loss_scale = not args.static_loss_scale
+    if os.environ.get("NVO_EARLY_FIELDS_ADAM") is not None:  # A/B
+        cfg.overlap_fields_adam = os.environ["NVO_EARLY_FIELDS_ADAM"] != "0"
+    if os.environ.get("NVO_PROP_MLP_OVERLAP") is not None:  # A/B
+        cfg.overlap_proposal_mlp = os.environ["NVO_PROP_MLP_OVERLAP"] != "0"
     if args.no_pair_losses:
         cfg.pair_proposal_losses = False
     if args.commit_in_graph:

@@ -143,7 +143,8 @@ int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
  * backward, dL_dinput is produced in `stream` order (complete for later work on `stream` when the call returns)
  * while the parameter backward of the input encoding -- the long scatter -- is enqueued on `params_stream`,
  * forked from `stream` at that point.  The CALLER joins: whatever consumes dL_dparams must wait for
- * `params_stream`.  Lets the consumers of dL_dinput (pose / normal gradient chains) run beside the scatter.
+ * `params_stream`.  Lets the consumers of dL_dinput (pose / normal gradient chains) run beside the scatter, or (dL_dinput
+ * may be NULL) the network backward of one module run beside another module's work that `params_stream` already holds.
  * params_stream == NULL or == stream, or a module without an input encoding: identical to nvo_bwd. */
 int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream, uint32_t batch,
                  const float* input, const void* params, const void* output, const void* dL_doutput, void* ctx,

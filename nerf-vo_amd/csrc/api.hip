@@ -954,7 +954,7 @@ int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream
     NVO_REQUIRE(m && dL_doutput && (input || batch == 0), "bwd_fork: NULL argument");
     NVO_REQUIRE((batch & 15u) == 0, "bwd_fork: batch (%u) must be a multiple of 16", batch);
     auto* n = dynamic_cast<NwieModule*>(m);
-    if (!n || !params_stream || params_stream == stream || !dL_dparams || !dL_dinput)
+    if (!n || !params_stream || params_stream == stream || !dL_dparams)
         return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput, dL_dparams);
     return n->bwd_on((hipStream_t)stream, (hipStream_t)params_stream, batch, input, params, output, dL_doutput, ctx,
                      dL_dinput, dL_dparams);

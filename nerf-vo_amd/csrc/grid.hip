@@ -2666,6 +2666,14 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
             }
         }
     }
+    if (const char* e = getenv("NVO_GRID_CHUNKS")) {  // measurements: "dense,hashed" chunks per slice
+        unsigned d = 0, h = 0;
+        if (sscanf(e, "%u,%u", &d, &h) == 2 && d && h) {
+            even_chunks = d;
+            dense_chunks = d;
+            hashed_chunks = h;
+        }
+    }
     // Most expensive first: single-chunk items scan all N samples (long), chunked items scan
     // N / n_chunks samples with a high hit rate (short but atomic-heavy).
     std::vector<Item> single, chunked;

@@ -129,6 +129,18 @@ class EngineConfig:
     overlap_pose_backward: bool = True
     # both proposal levels' loss kernels in one launch (nvo_prop_loss_pair)
     pair_proposal_losses: bool = True
+    # proposal backward (one side stream): the fused-MLP backward of proposal network 1 runs on a stream of its own beside
+    # network 0's MLP / hash-grid backward (both MLP backwards are latency-bound launches of two waves per SIMD); its
+    # hash-grid backward then follows network 0's on the side stream (nvo_bwd_fork)
+    overlap_proposal_mlp: bool = True
+    # one-graph step, update steps with fixed poses: the fused Adam of the FIELDS group (12.25 M parameters, HBM-bound,
+    # ~63 us) is launched on the main-field backward's stream as soon as that backward is done, beside the rest of the
+    # (longer) proposal chain -- LDS / issue-bound kernels that leave the memory system mostly idle -- instead of behind
+    # the join; the proposal group's Adam follows the join.  Same values: every group still reads its own overflow flag,
+    # and GradScaler.update (nvo_opt_commit) runs once, behind both.
+    # MEASURED SLOWER (0.6157 vs 0.6113 ms per step, two alternating pairs on one box): the Adam stream and the slice-owner
+    # scans compete for the same L2 / fabric path after all (as did Adam beside the sampling prefix); off.
+    overlap_fields_adam: bool = False
     # one-graph step (single GPU): the step's zero launch rides in extra workgroups of the ray head's launch
     zero_with_ray_head: bool = True
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
@@ -746,7 +758,7 @@ class NerfactoEngine:
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
                          anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False,
-                         skip_head: bool = False, proposal_values: bool | None = None):
+                         skip_head: bool = False, proposal_values: bool | None = None, after_main_backward=None):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -780,6 +792,15 @@ class NerfactoEngine:
         la = self._main_loss_args(ws, True, has_depth, normals=normals, has_gt_normal=normals)
         _call("nvo_main_render_loss", stream, C.byref(la))
         side = None
+        # Roles of the two streams on an update step.  The proposal chain (losses, two MLP backwards, two hash-grid
+        # scatters) is the LONGER one; with fixed poses it stays on the origin stream and the main-field backward goes
+        # to the side stream, so that the proposal chain may fork once more (network 1's MLP backward beside network 0's
+        # chain, cfg.overlap_proposal_mlp) -- a fork from a stream that is itself a fork crashes hipStreamEndCapture on
+        # ROCm 7.2.  With pose optimisation the main-field backward forks (its grid scatter beside the pose chain) and
+        # therefore keeps the origin stream, the proposal chain the side stream, unforked.
+        swap = bool(update_proposals and cfg.overlap_proposal_backward and cfg.overlap_proposal_mlp and not pose
+                    and int(cfg.proposal_backward_streams) == 1 and not cfg.deterministic)
+        self._prop_fork_ok = swap
         if update_proposals and cfg.overlap_proposal_backward:
             # fork: everything the proposal backward reads (main-level weights / bins) exists now
             cur = torch.cuda.current_stream(self.device)
@@ -790,28 +811,42 @@ class NerfactoEngine:
                 self._side_stream = [torch.cuda.Stream(device=self.device)
                                      for _ in range(max(1, min(2, int(cfg.proposal_backward_streams))))]
             side = self._side_stream
-            for si, st in enumerate(side):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    self._proposal_backward(ws, has_depth, pose, _stream(self.device),
-                                            levels=None if len(side) == 1 else [si])
-        _call("nvo_nerfacto_color_bwd", stream, C.byref(ca))
-        scatter_stream = None
-        if pose and cfg.overlap_pose_backward:
-            # the pose chain below only needs dL/dx of the main field: the long parameter scatter of its hash grid
-            # runs beside it on another stream (forked inside the call, joined at the end of this function)
-            if self._scatter_stream is None:
-                self._scatter_stream = torch.cuda.Stream(device=self.device)
-            scatter_stream = self._scatter_stream
-            _call("nvo_bwd_fork", self.base_net.handle, stream, C.c_void_p(scatter_stream.cuda_stream),
-                  R * self.levels[km], _ptr(ws[f"x{km}"]), self._param_ptr("field.base", self.params_half),
-                  _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]), _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]),
-                  self._param_ptr("field.base", self.grads))
-        else:
-            _call("nvo_bwd", self.base_net.handle, stream, R * self.levels[km], _ptr(ws[f"x{km}"]),
+            if not swap:
+                for si, st in enumerate(side):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        self._proposal_backward(ws, has_depth, pose, _stream(self.device),
+                                                levels=None if len(side) == 1 else [si])
+
+        def main_backward(st):
+            _call("nvo_nerfacto_color_bwd", st, C.byref(ca))
+            if pose and cfg.overlap_pose_backward:
+                # the pose chain below only needs dL/dx of the main field: the long parameter scatter of its hash grid
+                # runs beside it on another stream (forked inside the call, joined at the end of this function)
+                if self._scatter_stream is None:
+                    self._scatter_stream = torch.cuda.Stream(device=self.device)
+                _call("nvo_bwd_fork", self.base_net.handle, st, C.c_void_p(self._scatter_stream.cuda_stream),
+                      R * self.levels[km], _ptr(ws[f"x{km}"]), self._param_ptr("field.base", self.params_half),
+                      _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]), _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]),
+                      self._param_ptr("field.base", self.grads))
+                return self._scatter_stream
+            _call("nvo_bwd", self.base_net.handle, st, R * self.levels[km], _ptr(ws[f"x{km}"]),
                   self._param_ptr("field.base", self.params_half), _ptr(ws[f"out{km}"]), _ptr(ws[f"dout{km}"]),
                   _ptr(ws[f"ctx{km}"]), _ptr(ws[f"dx{km}"]) if pose else None,
                   self._param_ptr("field.base", self.grads))
+            return None
+
+        if swap:
+            side[0].wait_stream(cur)
+            with torch.cuda.stream(side[0]):
+                scatter_stream = main_backward(_stream(self.device))
+                if after_main_backward is not None:  # (the fields group's optimiser, beside the proposal chain)
+                    after_main_backward()
+            self._proposal_backward(ws, has_depth, pose, stream)
+        else:
+            scatter_stream = main_backward(stream)
+            if after_main_backward is not None:
+                after_main_backward()
         if update_proposals and side is None:
             self._proposal_backward(ws, has_depth, pose, stream)
         if proposal_values and not update_proposals:
@@ -901,7 +936,18 @@ class NerfactoEngine:
         if paired:
             pa0, pa1 = loss_args(0), loss_args(1)
             _call("nvo_prop_loss_pair", stream, C.byref(pa0), C.byref(pa1))
-        for k, net in enumerate(self.prop_nets):
+        # network 1's MLP backward beside network 0's chain: both losses are done (paired launch), the networks share nothing
+        mlp_stream = None
+        if paired and not values_only and getattr(self, "_prop_fork_ok", False):
+            if getattr(self, "_prop_mlp_stream", None) is None:
+                self._prop_mlp_stream = torch.cuda.Stream(device=self.device)
+            mlp_stream = self._prop_mlp_stream
+            mlp_stream.wait_stream(torch.cuda.current_stream(self.device))
+        # (forked form: the SHORT network -- level 1, 393 K samples -- runs its whole backward on `stream` while the long
+        # MLP backward of level 0 -- 1 M samples -- hides beside it on mlp_stream; level 0's scatter then follows)
+        order = [1, 0] if mlp_stream is not None else list(range(len(self.prop_nets)))
+        for k in order:
+            net = self.prop_nets[k]
             if levels is not None and k not in levels:
                 continue
             if not paired:
@@ -909,10 +955,16 @@ class NerfactoEngine:
                 _call("nvo_prop_loss", stream, C.byref(pa))
             if values_only:
                 continue
-            _call("nvo_bwd", net.handle, stream, R * self.levels[k], _ptr(ws[f"x{k}"]),
-                  self._param_ptr(f"proposal.{k}", self.params_half), _ptr(ws[f"out{k}"]),
-                  _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
-                  self._param_ptr(f"proposal.{k}", self.grads))
+            args = (R * self.levels[k], _ptr(ws[f"x{k}"]), self._param_ptr(f"proposal.{k}", self.params_half),
+                    _ptr(ws[f"out{k}"]), _ptr(ws[f"dout{k}"]), _ptr(ws[f"ctx{k}"]), _ptr(ws[f"dx{k}"]) if pose else None,
+                    self._param_ptr(f"proposal.{k}", self.grads))
+            if mlp_stream is not None and k == 0:
+                # (the call forks inside: MLP backward [+ input gradient] on mlp_stream, the grid's parameter scatter on
+                # `stream` behind an event -- i.e. behind network 1's scatter, which is already queued there)
+                _call("nvo_bwd_fork", net.handle, C.c_void_p(mlp_stream.cuda_stream), stream, *args)
+                torch.cuda.current_stream(self.device).wait_stream(mlp_stream)  # join (pose: the input gradient)
+            else:
+                _call("nvo_bwd", net.handle, stream, *args)
 
     def _pose_backward(self, ws, update_proposals: bool, stream) -> None:
         """dL/dx01 of every level that ran backward + the SH direction gradient -> dL/dpose_adjustment
@@ -1382,10 +1434,21 @@ class NerfactoEngine:
             return g
 
         if not split and not pipe1:
+            # update steps: Adam(fields) beside the tail of the proposal chain (cfg.overlap_fields_adam)
+            early_fields = bool(updated and cfg.overlap_fields_adam and cfg.overlap_proposal_backward
+                                and cfg.overlap_proposal_mlp and not cfg.optimize_poses and not cfg.deterministic
+                                and int(cfg.proposal_backward_streams) == 1 and "proposal_networks" in groups_b)
+
             def whole():
                 body_head()
-                body_rest()
-                body_opt(groups_b)
+                if early_fields:
+                    self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
+                                          anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True,
+                                          proposal_values=values, after_main_backward=lambda: body_opt(["fields"]))
+                    body_opt([g for g in groups_b if g != "fields"])
+                else:
+                    body_rest()
+                    body_opt(groups_b)
             zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
             if not cfg.commit_behind_replay:
                 entry["main"] = capture(whole)
@@ -1393,10 +1456,15 @@ class NerfactoEngine:
             self._defer_commit = []
             try:
                 entry["main"] = capture(whole)
-                entry["commit"] = self._defer_commit[0] if len(self._defer_commit) == 1 else None
+                # (one optimiser launch, or two when the fields group is stepped early: ONE commit for the step)
+                mask = scale_mask = 0
+                for m_, s_ in self._defer_commit:  # (disjoint group bits)
+                    mask |= m_
+                    scale_mask |= s_
+                entry["commit"] = (mask, scale_mask) if self._defer_commit else None
             finally:
                 self._defer_commit = None
-            assert entry["commit"] is not None, "the one-graph step runs exactly one optimiser launch"
+            assert entry["commit"] is not None, "the one-graph step runs at least one optimiser launch"
             return entry
         if pipe1:
             opt_stream = torch.cuda.Stream(device=dev)
