@@ -9,8 +9,10 @@ A "step" is ONE full depth-nerfacto training iteration as NeRF-VO's mapping runs
 -> backward -> Adam, on 4096 rays per GPU drawn from a resident synthetic Replica-shaped buffer of
 192 keyframes at 640x480 (BASELINE.json configs[1], fixed poses).  Metric: training ray-samples/s =
 main-field samples whose forward+backward+optimiser update completed per second, whole job.
-Rays shard across ranks (weak scaling); the only exchange is one RCCL all-reduce of the flat
-gradient buffer per step.
+Rays shard across ranks (weak scaling); the exchange per step is the gradient of the flat parameter
+buffer over RCCL: a reduce-scatter of the fields group (Adam on the rank's 1/W slice, all-gather of the
+16-bit working copy) plus, on update steps, an all-reduce of the proposal / pose ranges
+(nerf_vo_amd/parallel.py; NVO_SHARD_OPT=0: one all-reduce, replicated Adam).
 
 Extra JSON objects: "roofline" (dominant kernel, live HIP-event timing) and "cpu_baseline" (the
 torch-CPU oracle of the same step on a bounded sample, rank 0 / N=1 only).

@@ -278,8 +278,11 @@ k_cast_shards(uint64_t n, uint64_t per, uint32_t pad, const float* __restrict__ 
     for (uint64_t q = tid; q < n / 4; q += stride) {
         const uint64_t i = q * 4;
         const float4 v = reinterpret_cast<const float4*>(src)[q];
-        // (what does not survive the cast -- beyond 65504 on an fp16 wire -- counts as an overflow as well)
-        const float lim = BF ? 3.0e38f : 65504.0f;
+        // (what does not survive the cast -- beyond 65504 on an fp16 wire -- counts as an overflow as well; and on that
+        // wire the SUM of `world` finite addends must stay finite too, since nothing scans the reduced shard: a rank
+        // whose own value exceeds 65504 / world raises the flag, which keeps the verdict global -- the flag slots are
+        // summed with the gradient -- and the loss scale identical on all ranks.  bf16 has fp32's range.)
+        const float lim = BF ? 3.0e38f : 65504.0f / (float)(n / per);
         bad = bad || !(fabsf(v.x) <= lim) || !(fabsf(v.y) <= lim) || !(fabsf(v.z) <= lim) || !(fabsf(v.w) <= lim);
         const uint64_t o = (i / per) * (per + pad) + (i % per);
         *reinterpret_cast<uint2*>(dst + o) = make_uint2((uint32_t)cvt(v.x) | ((uint32_t)cvt(v.y) << 16),

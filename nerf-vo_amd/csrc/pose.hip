@@ -94,10 +94,15 @@ __global__ void __launch_bounds__(256)
 k_pose_bwd(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
            const float* __restrict__ c2w, const float* __restrict__ d_origin,
            const float* __restrict__ d_dir, const float* __restrict__ d_dir01,
-           float* __restrict__ d_corr, float* __restrict__ per_ray) {
+           float* __restrict__ d_corr, float* __restrict__ per_ray, uint32_t n_cameras) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int64_t cam = ray_indices[3 * (size_t)r + 0];
+    if (n_cameras && (uint64_t)cam >= (uint64_t)n_cameras) {  // stale / out-of-range index: dropped before any read through it
+        if (per_ray)
+            for (int k = 0; k < 12; ++k) per_ray[12 * (size_t)r + k] = 0.f;
+        return;
+    }
     const float py = (float)ray_indices[3 * (size_t)r + 1] + 0.5f;
     const float px = (float)ray_indices[3 * (size_t)r + 2] + 0.5f;
     const float fx = intrinsics[4 * cam + 0], fy = intrinsics[4 * cam + 1];
@@ -143,7 +148,8 @@ k_pose_bwd_lds(uint32_t R, uint32_t n_cameras, const int64_t* __restrict__ ray_i
     for (uint32_t e = threadIdx.x; e < n_words; e += blockDim.x) pose_acc[e] = 0.f;
     __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < R) {
+    // (a stale or out-of-range camera index is DROPPED before anything is read through it, not just before the adds)
+    if (r < R && (uint64_t)ray_indices[3 * (size_t)r + 0] < (uint64_t)n_cameras) {
         const int64_t cam = ray_indices[3 * (size_t)r + 0];
         const float py = (float)ray_indices[3 * (size_t)r + 1] + 0.5f;
         const float px = (float)ray_indices[3 * (size_t)r + 2] + 0.5f;
@@ -158,7 +164,7 @@ k_pose_bwd_lds(uint32_t R, uint32_t n_cameras, const int64_t* __restrict__ ray_i
             d0[k] /= n0;
             gd[k] = d_dir[3 * (size_t)r + k] + (d_dir01 ? 0.5f * d_dir01[3 * (size_t)r + k] : 0.f);
         }
-        if ((uint64_t)cam < (uint64_t)n_cameras) {
+        {
             float* g = pose_acc + 12 * cam;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -341,17 +347,23 @@ int nvo_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t S, const float* 
     return NVO_OK;
 }
 
-int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
-                 const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
-                 float* d_corrections) {
+static int pose_bwd_plain(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                          const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                          float* d_corrections, uint32_t n_cameras) {
     NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && d_origin && d_dir && d_corrections),
                 "pose_bwd: NULL argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "pose_bwd");
     NVO_LAUNCH(k_pose_bwd, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices,
-               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, (float*)nullptr);
+               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, (float*)nullptr, n_cameras);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
+}
+
+int nvo_pose_bwd(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
+                 const float* c2w, const float* d_origin, const float* d_dir, const float* d_dir01,
+                 float* d_corrections) {
+    return pose_bwd_plain(stream, R, ray_indices, intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, 0u);
 }
 
 int nvo_pose_bwd_cams(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics,
@@ -364,7 +376,7 @@ int nvo_pose_bwd_cams(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
     // cameras 14.8 -> 22.4 us with 1024-ray workgroups, the zeroing and the flush of 2304 words per workgroup cost more than 21 adds per word
     // did): below 64 rays per camera, beyond 1024 cameras (48 KiB) or without a camera count: plain atomics.
     if (n_cameras == 0 || n_cameras > 1024 || R < 64u * n_cameras)
-        return nvo_pose_bwd(stream, R, ray_indices, intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections);
+        return pose_bwd_plain(stream, R, ray_indices, intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, n_cameras);
     NVO_PROF(stream, "pose_bwd");
     static const uint32_t block = [] {
         const char* e = getenv("NVO_POSE_LDS_BLOCK");
@@ -385,7 +397,7 @@ int nvo_pose_bwd_det(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "pose_bwd");
     NVO_LAUNCH(k_pose_bwd, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices,
-               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, per_ray_scratch);
+               intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, per_ray_scratch, n_cameras);
     NVO_CHECK_LAUNCH();
     return nvo_reduce_by_camera((hipStream_t)stream, R, 12, per_ray_scratch, 12, ray_indices, 1, n_cameras, d_corrections);
 }

@@ -1495,7 +1495,15 @@ class NerfactoEngine:
             # capture through its event dependencies): the whole iteration is then ONE graph launch.  thread_local: the
             # process group's watchdog thread polls events with calls a global-mode capture would be invalidated by.
             try:
-                whole_g = {p: capture(lambda p=p: program(p, lambda name, fn: fn()), capture_error_mode="thread_local")
+                def whole_program(p):
+                    # the fused ray head of the graph that ran before (entry["head"] or the previous iteration's
+                    # prefix) already produced dirs01 / SH: without the flags every program captured after the first
+                    # would re-record nvo_dirs01 + nvo_sh_encode_t (two redundant dependent launches per step)
+                    if cfg.fused_ray_head:
+                        ws["dirs01_ready"] = ws["sh_ready"] = True
+                    program(p, lambda name, fn: fn())
+
+                whole_g = {p: capture(lambda p=p: whole_program(p), capture_error_mode="thread_local")
                            for p in (False, True)}
                 entry["captured_collectives"] = True
                 entry["run"] = lambda pipeline: whole_g[bool(pipeline)].replay()
@@ -1515,6 +1523,8 @@ class NerfactoEngine:
             segs[name] = capture(fn)
 
         # capture every compute segment once (the collectives in between run eagerly, here and at replay)
+        if cfg.fused_ray_head:  # (as whole_program above: the head graph already produced dirs01 / SH)
+            ws["dirs01_ready"] = ws["sh_ready"] = True
         program(True, lambda name, fn: (seg_capture(name, fn), segs[name].replay()))
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
@@ -1547,6 +1557,19 @@ class NerfactoEngine:
         self.step += 1
         return updated
 
+    def mean_appearance_embedding(self) -> torch.Tensor:
+        """[1, 32] fp32 mean of the appearance embedding (nerfacto use_average_appearance_embedding), decoded from the
+        16-bit WORKING COPY: with the sharded optimiser only the rank that owns the slice holds current fp32 master
+        values of it, while the working copy is all-gathered every step and complete everywhere."""
+        o, n, _ = self.segments["field.embedding"]
+        raw = self.params_half[o:o + n]
+        vals = raw.view(torch.bfloat16).float() if self.bf16 else raw.float()
+        return vals.view(self.cfg.num_images, -1).mean(dim=0, keepdim=True)
+
+    def layout(self) -> list:
+        """Segment table of the flat parameter buffer: [(name, offset, size, group)] -- what a checkpoint is keyed by."""
+        return [(n, int(o), int(sz), g) for n, (o, sz, g) in self.segments.items()]
+
     def loss_dict(self, totals: torch.Tensor | None = None) -> dict:
         """Loss terms of the last step as Python floats (ONE device sync).  ``totals``: a snapshot taken earlier
         with loss_totals()."""
@@ -1578,8 +1601,7 @@ class NerfactoEngine:
         ws["directions_norm"][:R].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
         if mean_embedding_half is None:
-            emb = self.view("field.embedding").view(self.cfg.num_images, -1)
-            mean_embedding_half = emb.mean(dim=0, keepdim=True)
+            mean_embedding_half = self.mean_appearance_embedding()
         if mean_embedding_half.dtype != self.act_dtype:  # (callers may hand in fp32 / fp16: the colour head reads
             mean_embedding_half = mean_embedding_half.float().to(self.act_dtype)  # its operand format)
         mean_embedding_half = mean_embedding_half.contiguous()

@@ -122,7 +122,9 @@ class DynamicDataset(torch.utils.data.Dataset):
         if self.normalization_matrix is None:
             align = torch.tensor(_WORLD_ALIGN, dtype=extr.dtype, device=extr.device)
             self.normalization_matrix = torch.linalg.solve(extr[0], align)  # inv(E0) @ M
-        extr = self.normalization_matrix.to(extr.device) @ extr
+        # N @ E_k for every pose of the packet, written as the reference writes it (nerfstudio_utils.py:197-199: the double
+        # permute(2, 1, 0) is a batched left-multiply)
+        extr = (self.normalization_matrix.to(extr.device) @ extr.permute(2, 1, 0)).permute(2, 1, 0)
 
         out = {
             "indices": indices, "keyframe_indices": key_idx, "num_active_frames": num_active,
@@ -154,11 +156,23 @@ class DynamicDataset(torch.utils.data.Dataset):
     def _refresh_world_normals(self, frames: torch.Tensor) -> None:
         """(R^-1 n + 1) / 2 for the given frames -- the per-step solve of the reference
         (nerfstudio_utils.py:145-153) hoisted to ingest time."""
-        rot = self.camera_extrinsics[frames, :3, :3]
-        n = self.frames_normal[frames]
-        f, h, w, _ = n.shape
-        world = torch.linalg.solve(rot, n.reshape(f, h * w, 3).transpose(1, 2)).transpose(1, 2)
-        self._normal_world01[frames] = (world.reshape(f, h, w, 3) + 1.0) / 2.0
+        # The reference's own expression on SLICE VIEWS of the buffers, one solve per run of consecutive frames (ingest
+        # touches one or two such runs): torch.linalg.solve takes a different path for a strided view of the 4x4 pose
+        # buffer than for a gathered contiguous copy and the results differ in the last bit -- with views the fixtures
+        # generated by the reference's get_dataset() are reproduced bit for bit (tests/test_dataset_golden_cpu.py).
+        ids = sorted(set(int(i) for i in frames.tolist()))
+        h, w = self.frame_height, self.frame_width
+        lo = 0
+        while lo < len(ids):
+            hi = lo
+            while hi + 1 < len(ids) and ids[hi + 1] == ids[hi] + 1:
+                hi += 1
+            a, b = ids[lo], ids[hi] + 1
+            f = b - a
+            self._normal_world01[a:b] = (torch.linalg.solve(
+                self.camera_extrinsics[a:b, :3, :3],
+                self.frames_normal[a:b].permute(0, 3, 1, 2).reshape(f, 3, h * w)).reshape(f, 3, h, w).permute(0, 2, 3, 1) + 1) / 2
+            lo = hi + 1
 
     # ---- snapshot ------------------------------------------------------------------------------
     def save_dataset(self, dir_prediction: str) -> None:

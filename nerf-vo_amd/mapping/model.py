@@ -133,9 +133,14 @@ class ExtendedNerfactoModel:
         e = self.engine
         return {g: [e.params[lo:hi]] for g, (lo, hi) in e.group_ranges.items()}
 
-    def state_dict(self) -> dict:
+    def state_dict(self, all_reduce=None) -> dict:
+        """``all_reduce``: the step's GradientAllReduce when the optimiser is sharded (multi-GPU): the fp32 master weights
+        and Adam moments of the fields group are current on their owner rank only and are all-gathered first -- a
+        COLLECTIVE, so every rank must call state_dict() (Trainer.save_checkpoint does)."""
         e = self.engine
-        return {"params": e.params.detach().clone(), "exp_avg": e.exp_avg.clone(), "exp_avg_sq": e.exp_avg_sq.clone(),
+        e.sync_sharded_state(all_reduce)
+        return {"layout": e.layout(), "mlp_dtype": e.cfg.mlp_dtype,
+                "params": e.params.detach().clone(), "exp_avg": e.exp_avg.clone(), "exp_avg_sq": e.exp_avg_sq.clone(),
                 "opt_steps": dict(e.opt_steps), "step": e.step,
                 "steps_since_proposal_update": e.steps_since_proposal_update,
                 # GradScaler state (torch: scaler.state_dict() -> scale, _growth_tracker)
@@ -143,6 +148,17 @@ class ExtendedNerfactoModel:
 
     def load_state_dict(self, state: dict) -> None:
         e = self.engine
+        # the flat buffers only mean something together with their segment table (a build with another padding or segment
+        # order would load parameters into the wrong networks, silently when the totals happen to agree)
+        have = [tuple(x) for x in state.get("layout", [])]
+        want = [tuple(x) for x in e.layout()]
+        if have and have != want:
+            diff = next((a, b) for a, b in zip(have + [None] * len(want), want + [None] * len(have)) if a != b)
+            raise ValueError("checkpoint layout does not match this engine's parameter layout: first difference "
+                             f"checkpoint {diff[0]} vs engine {diff[1]}")
+        if not have and int(state["params"].numel()) != e.n_params:
+            raise ValueError(f"checkpoint without a layout table holds {int(state['params'].numel())} parameters, this engine "
+                             f"{e.n_params} (written by an older build: re-train or convert)")
         e.set_params(state["params"])
         e.exp_avg.copy_(state["exp_avg"])
         e.exp_avg_sq.copy_(state["exp_avg_sq"])
@@ -163,8 +179,7 @@ class ExtendedNerfactoModel:
         dnorm = camera_ray_bundle.metadata["directions_norm"].reshape(-1)
         n = origins.shape[0]
         chunk = min(self.config.eval_num_rays_per_chunk, max(n, 1))
-        emb = self.engine.view("field.embedding").view(self.engine.cfg.num_images, -1)
-        mean_emb = emb.mean(dim=0, keepdim=True).contiguous()  # the engine casts it to the colour head's operand format
+        mean_emb = self.engine.mean_appearance_embedding().contiguous()  # (the engine casts it to the operand format)
         outs: dict[str, list] = {}
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)

@@ -246,7 +246,11 @@ class Trainer:
     def save_checkpoint(self, step: int) -> None:
         self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
         path = self.checkpoint_dir / f"step-{step:09d}.ckpt"
-        torch.save({"step": step, "pipeline": self.pipeline.model.state_dict()}, path)
+        # (sharded optimiser: state_dict() all-gathers the fields group's fp32 state -- every rank calls it, rank 0 writes)
+        state = self.pipeline.model.state_dict(all_reduce=self.pipeline.all_reduce)
+        if self.local_rank != 0 and self.world_size > 1:
+            return
+        torch.save({"step": step, "pipeline": state}, path)
         if self.config.save_only_latest_checkpoint:
             for f in self.checkpoint_dir.glob("*.ckpt"):
                 if f != path:

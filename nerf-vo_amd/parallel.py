@@ -1,14 +1,18 @@
 """Multi-GPU data parallelism for the mapping step: one process per MI355X, rays sharded across
 ranks (each rank draws its own 4096 rays from its replica of the keyframe buffer), parameters
-replicated, and exactly ONE exchange per iteration -- a sum all-reduce of the flat gradient buffer
-over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" in the CPU tests).  The
-reference has no distributed path; this is the exchange section 8e specifies.
+replicated, gradients exchanged over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo"
+in the CPU tests).  The reference has no distributed path; this is the
+exchange section 8e specifies.
 
-The flat gradient buffer (13.85 M scalars: 55.4 MB fp32, 27.7 MB as bf16 / fp16) is reduced by as few
-collectives as possible -- adjacent parameter-group ranges are merged and, by default, each merged range is
-ONE all-reduce: xGMI is point-to-point (7 links x ~153 GB/s), the ring cost is per-link-bandwidth bound
-(~0.3 ms for 27.7 MB at 8 GPUs), RCCL pipelines a large message internally, and every extra call only adds
-launch latency (measured at world size 1: four 4 M-element buckets cost ~0.1 ms per step more than one).
+Per iteration (the graph-replayed step, engine.train_step_graphed):
+  * proposal networks + camera poses (1.6 MB as bf16, update steps only): ONE all-reduce, replicated Adam;
+  * fields group (12.25 M of the 13.85 M parameters, 24.5 MB as bf16): with ``shard_optimizer`` (what bench.py uses) a
+    REDUCE-SCATTER, Adam on the rank's 1/W slice, and an ALL-GATHER of the 16-bit working copy -- the same link bytes
+    as an all-reduce (a ring all-reduce IS those two), with the optimiser pass and the overflow check cut to 1/W and
+    both halves overlapped with the next iteration's sampling prefix; without it ONE all-reduce + replicated Adam.
+Adjacent parameter-group ranges are merged and each merged range is one collective: xGMI is point-to-point (7 links
+x ~153 GB/s), a ring is per-link-bandwidth bound, RCCL pipelines a large message internally, and every extra call only
+adds launch latency (measured at world size 1: four 4 M-element buckets cost ~0.1 ms per step more than one).
 """
 from __future__ import annotations
 
