@@ -153,6 +153,8 @@ def main() -> None:
     ap.add_argument("--static-loss-scale", action="store_true",
                     help="A/B: tcnn's static loss scale 128 (rounds 1-3's headline regime: most fp16 proposal-loss gradients "
                          "underflow to exactly zero there and the grid backward skips them)")
+    ap.add_argument("--render-frames", type=int, default=5,
+                    help="timed full-image renders per resolution (1200x680 and the training resolution); 0 = skip")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
                     help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
@@ -429,6 +431,87 @@ def main() -> None:
                 "value": samples_per_step / (t_late / args.late_steps),
                 "note": "proposal networks refreshed every 6th step (schedule past the 5000-step warm-up)"}
 
+    # ---- inference render (the second caller north_star names: NerfstudioRenderer.render_frame,
+    # /root/reference/evaluation/nerf_renderer.py:132-168): full frames at the dataset's native resolution (1200x680 for
+    # Replica: evaluation_frame_* keys absent, /root/reference/run.py:57-66) and at the training resolution, chunks of
+    # 32 768 rays (nerfstudio's eval_num_rays_per_chunk), one hipGraph per image, inputs already on the device
+    render = None
+    if rank == 0 and world == 1 and args.render_frames > 0:
+        from nerf_vo_amd.mapping.cameras import Cameras
+        from nerf_vo_amd.synthetic import replica_intrinsics
+
+        chunk = 1 << 15
+        per_ray = cfg.num_nerf_samples * (16 * 8 * 4 + 12 + 16 * 4) + sum(cfg.num_proposal_samples) * (5 * 8 * 4 + 12 + 5 * 4)
+        render = {"chunk_rays": chunk, "launch": "one hipGraph per image (all chunks; mean appearance embedding once)",
+                  "outputs": "rgb, median depth, expected depth, accumulation (normals on first access only)",
+                  "bytes_model": "SURVEY.md 8d forward bytes: 588 B per main-field sample + 192 B per proposal sample",
+                  "algorithmic_bytes_per_ray": per_ray, "frames": []}
+        pose = ds.camera_extrinsics[:1, :3, :4].clone()
+        for w_, h_ in ((1200, 680), (args.width, args.height)):
+            fx, fy, cx, cy = replica_intrinsics(h_, w_)
+            cams = Cameras(camera_to_worlds=pose, fx=fx, fy=fy, cx=cx, cy=cy, width=w_, height=h_).to(device)
+            n_rays = w_ * h_
+
+            def frame():
+                b = cams.generate_rays(camera_indices=0, keep_shape=True)
+                return engine.render_image(b.origins.reshape(-1, 3), b.directions.reshape(-1, 3),
+                                           b.metadata["directions_norm"].reshape(-1), chunk=chunk)
+
+            frame()  # (captures the graph of this image shape)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tw0 = time.perf_counter()
+            e0.record()
+            for _ in range(args.render_frames):
+                out_img = frame()
+            e1.record()
+            torch.cuda.synchronize(device)
+            wall = (time.perf_counter() - tw0) / args.render_frames
+            ms = e0.elapsed_time(e1) / args.render_frames
+            assert bool(torch.isfinite(out_img["rgb"]).all())
+            render["frames"].append({
+                "resolution": [w_, h_], "rays": n_rays, "chunks": (n_rays + chunk - 1) // chunk,
+                "ms_per_frame": round(ms, 3), "ms_per_frame_wall": round(wall * 1e3, 3),
+                "rays_per_sec": n_rays / (ms * 1e-3),
+                "field_evals_per_sec": n_rays * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples)) / (ms * 1e-3),
+                "roofline": {"bound": "hbm", "achieved": round(n_rays * per_ray / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(n_rays * per_ray / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}})
+        # per-kernel table of one 1200x680 frame, eagerly with HIP events on the launch stream
+        if not args.no_kernel_table:
+            fx, fy, cx, cy = replica_intrinsics(680, 1200)
+            cams = Cameras(camera_to_worlds=pose, fx=fx, fy=fy, cx=cx, cy=cy, width=1200, height=680).to(device)
+            b = cams.generate_rays(camera_indices=0, keep_shape=True)
+            torch.cuda.synchronize(device)
+            lib.nvo_profile_enable(1)
+            engine.render_image(b.origins.reshape(-1, 3), b.directions.reshape(-1, 3), b.metadata["directions_norm"].reshape(-1),
+                                chunk=chunk, use_graph=False)
+            torch.cuda.synchronize(device)
+            need = lib.nvo_profile_summary(None, 0)
+            buf = C.create_string_buffer(int(need) + 16)
+            lib.nvo_profile_summary(buf, len(buf))
+            lib.nvo_profile_enable(0)
+            rows = []
+            for line in buf.value.decode().strip().splitlines():
+                name, cnt, total = line.rsplit(",", 2)
+                rows.append((name, int(cnt), float(total)))
+            rows.sort(key=lambda r: -r[2])
+            tot = sum(r[2] for r in rows)
+            sys.stderr.write(f"[bench] render 1200x680, eager: {tot:.2f} ms in kernels per frame\n")
+            table = []
+            for name, cnt, total in rows:
+                sys.stderr.write(f"[bench]   {name:28s} launches {cnt:5d}  avg {total / cnt * 1e3:9.1f} us  {100 * total / tot:5.1f} %\n")
+                row = {"kernel": name, "launches": cnt, "avg_launch_us": round(total / cnt * 1e3, 2), "share": round(total / tot, 4)}
+                bts = algorithmic_bytes(name, cfg, chunk)
+                if bts is not None and name.startswith("grid_fwd"):
+                    # (launches of the ragged last chunk are smaller: the frame's samples over the frame's time)
+                    # (algorithmic_bytes prices ONE launch -- for the two proposal grids their average)
+                    frame_bytes = bts / chunk * 1200 * 680 * (2 if "L5" in name else 1)
+                    row["roofline"] = {"bound": "hbm", "achieved": round(frame_bytes / (total * 1e-3) / 1e9, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+                    row["roofline"]["frac"] = round(row["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
+                table.append(row)
+            render["kernel_table_1200x680"] = table
+
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
@@ -521,6 +604,7 @@ def main() -> None:
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "render_psnr": render_psnr,
+            "render": render,
         }
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()

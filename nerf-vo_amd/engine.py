@@ -504,9 +504,10 @@ class NerfactoEngine:
             if old is not None and old["R_cap"] >= R:
                 old["R"] = R
                 return old
-            if old is not None:  # grow: nothing captured ever addresses the inference scratch
+            if old is not None:  # grow (a scratch some render_image graph addresses stays alive with that graph)
                 del self._ws["inference"]
-                old.clear()
+                if not old.get("pinned"):
+                    old.clear()
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         f16 = dict(dtype=self.act_dtype, device=dev)  # 16-bit activations / gradients (fp16 | bf16)
@@ -1556,6 +1557,88 @@ class NerfactoEngine:
         self.steps_since_proposal_update += 1
         self.step += 1
         return updated
+
+    # ------------------------------------------------------------------------------------------
+    # inference: a whole image as ONE captured graph
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render_image(self, origins, directions, directions_norm, normals: bool = False, chunk: int = 1 << 15,
+                     use_graph: bool = True) -> dict:
+        """Eval forward of a full-image ray bundle ([N,3] origins / directions, [N] norms): every chunk of
+        ``eval_num_rays_per_chunk`` rays (nerfstudio default 1 << 15; /root/reference/evaluation/nerf_renderer.py:157 goes
+        through model.get_outputs_for_camera_ray_bundle, which chunks) is the same kernel sequence as ``render_rays`` --
+        captured ONCE per (ray count, chunk, normals) with all chunks in one hipGraph: the kernels read the rays from and
+        write the outputs to persistent full-image buffers at the chunk's offset (no per-chunk staging copies, no
+        per-chunk clones), the mean appearance embedding is taken once per image, and a frame costs one graph launch
+        instead of ~20 launches x 25 chunks.  Same values as render_rays chunk by chunk, bit for bit
+        (tests/test_engine_gpu.py::test_render_image_graph_matches_eager_chunks)."""
+        N = int(origins.shape[0])
+        key = (N, int(chunk), bool(normals))
+        if not hasattr(self, "_render_graphs"):
+            self._render_graphs = {}
+        entry = self._render_graphs.get(key)
+        if entry is None:
+            entry = self._render_graphs[key] = self._capture_render(N, int(chunk), bool(normals))
+        entry["origins"].copy_(origins.reshape(N, 3))
+        entry["directions"].copy_(directions.reshape(N, 3))
+        entry["directions_norm"].copy_(directions_norm.reshape(N))
+        if use_graph:
+            entry["graph"].replay()
+        else:  # (per-kernel profiling: the launchers' event hooks only see eager launches)
+            self._render_chunks(entry, entry["ws"], lambda: _stream(self.device))
+        out = {"rgb": entry["out_rgb"].clone(), "depth": entry["out_depth"].clone()[:, None],
+               "expected_depth": entry["out_expected_depth"].clone()[:, None],
+               "accumulation": entry["out_accumulation"].clone()[:, None]}
+        if normals:
+            out["normals"] = entry["out_normals"].clone()
+        return out
+
+    def _render_chunks(self, entry, ws, stream_fn) -> None:
+        """The chunk loop of render_image on the current stream (eagerly for the warm-up, under capture for the graph)."""
+        N, chunk, normals = entry["N"], entry["chunk"], entry["normals"]
+        entry["mean_emb"].copy_(self.mean_appearance_embedding().to(self.act_dtype))  # once per image
+        for lo in range(0, N, chunk):
+            R = min(chunk, N - lo)
+            view = dict(ws)  # same scratch for every chunk; rays / outputs at the chunk's offset of the image buffers
+            view["R"] = R
+            for k in ("origins", "directions", "directions_norm", "out_rgb", "out_depth", "out_expected_depth",
+                      "out_accumulation", "out_normals"):
+                view[k] = entry[k][lo:lo + R]
+            view["dirs01_ready"] = view["sh_ready"] = False
+            stream = stream_fn()
+            self._forward(view, False, 1.0, None, None, entry["mean_emb"].data_ptr(), stream)
+            if normals:
+                self._analytic_normal_grads(view, stream)
+            la = self._main_loss_args(view, False, False, normals=normals)
+            _call("nvo_main_render_loss", stream, C.byref(la))
+        entry["out_rgb"].clamp_(0.0, 1.0)
+
+    def _capture_render(self, N: int, chunk: int, normals: bool) -> dict:
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = self._workspace(min(chunk, N), False)
+        if normals and "dsigma_dx" not in ws:  # (lazily allocated scratch of the analytic-normal pass: before the views)
+            ws["R"] = ws["R_cap"]
+            self._analytic_normal_grads(ws, _stream(dev))
+        ws["pinned"] = True
+        entry = {"N": N, "chunk": chunk, "normals": normals, "ws": ws,  # (ws: kept alive -- the graph addresses it)
+                 "origins": torch.zeros(N, 3, **f32), "directions": torch.zeros(N, 3, **f32),
+                 "directions_norm": torch.ones(N, **f32), "out_rgb": torch.zeros(N, 3, **f32),
+                 "out_depth": torch.zeros(N, **f32), "out_expected_depth": torch.zeros(N, **f32),
+                 "out_accumulation": torch.zeros(N, **f32), "out_normals": torch.zeros(N, 3, **f32),
+                 "mean_emb": torch.zeros(1, self.cfg.appearance_embed_dim, dtype=self.act_dtype, device=dev)}
+        entry["directions"][:, 2] = -1.0  # (finite rays for the warm-up pass)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up: lazy module state, native scratch growth -- none of it may happen under capture
+            self._render_chunks(entry, ws, lambda: _stream(dev))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._render_chunks(entry, ws, lambda: _stream(dev))
+        entry["graph"] = g
+        return entry
 
     def mean_appearance_embedding(self) -> torch.Tensor:
         """[1, 32] fp32 mean of the appearance embedding (nerfacto use_average_appearance_embedding), decoded from the

@@ -68,8 +68,8 @@ class Cameras:
 
     def to(self, device):
         device = torch.device(device)
-        if self.camera_to_worlds.device == device:
-            return self
+        if all(t.device == device for t in (self.camera_to_worlds, self.fx, self.fy, self.cx, self.cy)):
+            return self  # (views of caller-owned buffers stay views)
         return Cameras(self.camera_to_worlds.to(device), self.fx.to(device), self.fy.to(device), self.cx.to(device),
                        self.cy.to(device), self.width, self.height, self.distortion_params, self.camera_type)
 
@@ -99,6 +99,9 @@ class Cameras:
         cam = torch.empty(R, dtype=torch.int32, device=dev)
         intr = self.intrinsics_matrix()
         c2w = self.camera_to_worlds[:, :3, :4].contiguous()
+        if intr.device != dev or (corrections is not None and corrections.device != dev):
+            # (a host pointer handed to the kernel is a GPU memory fault, not an exception)
+            raise RuntimeError("Cameras.generate_rays: intrinsics / corrections are not on the cameras' device; call .to(device)")
         _lib.check(_lib.lib().nvo_raygen(_stream(dev), R, _ptr(idx), _ptr(intr), _ptr(c2w), _ptr(corrections),
                                          _ptr(origins), _ptr(directions), _ptr(dnorm), _ptr(area), _ptr(cam)),
                    "nvo_raygen")

@@ -91,6 +91,23 @@ class CameraOptimizer(torch.nn.Module):
         return self.forward(torch.arange(self.num_cameras, device=self.engine.device))
 
 
+class _LazyOutputs(dict):
+    """Render outputs whose expensive members are computed when somebody asks for them."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            self[key] = self._lazy.pop(key)()
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+
 class ExtendedNerfactoModel:
     def __init__(self, config: ExtendedNerfactoModelConfig, num_train_data: int, device, world_size: int = 1,
                  max_num_iterations: int = 8192, num_rays: int = 4096, seed: int = 1337, rank: int = 0,
@@ -172,28 +189,23 @@ class ExtendedNerfactoModel:
     # ---- inference ---------------------------------------------------------------------------
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> dict:
-        """Chunked eval forward over a full-image bundle ([H,W] shaped); outputs keep that shape."""
+        """Chunked eval forward over a full-image bundle ([H,W] shaped); outputs keep that shape.  The chunks
+        (``eval_num_rays_per_chunk`` rays each, nerfstudio's Model.get_outputs_for_camera_ray_bundle) run as ONE captured
+        graph per image shape (NerfactoEngine.render_image).  ``outputs['normals']`` (predict_normals) costs an extra
+        input-gradient pass of the base network per chunk and is produced on FIRST ACCESS: the reference's renderer
+        reads 'rgb' and 'depth' only (/root/reference/evaluation/nerf_renderer.py:161-167)."""
         shape = camera_ray_bundle.origins.shape[:-1]
         origins = camera_ray_bundle.origins.reshape(-1, 3)
         directions = camera_ray_bundle.directions.reshape(-1, 3)
         dnorm = camera_ray_bundle.metadata["directions_norm"].reshape(-1)
-        n = origins.shape[0]
-        chunk = min(self.config.eval_num_rays_per_chunk, max(n, 1))
-        mean_emb = self.engine.mean_appearance_embedding().contiguous()  # (the engine casts it to the operand format)
-        outs: dict[str, list] = {}
-        for lo in range(0, n, chunk):
-            hi = min(n, lo + chunk)
-            o, d, dn = origins[lo:hi], directions[lo:hi], dnorm[lo:hi]
-            if hi - lo < chunk:  # keep one scratch shape: pad the tail chunk, drop the padding after
-                pad = chunk - (hi - lo)
-                o = torch.cat([o, o[-1:].expand(pad, 3)])
-                d = torch.cat([d, d[-1:].expand(pad, 3)])
-                dn = torch.cat([dn, dn[-1:].expand(pad)])
-            res = self.engine.render_rays(o.contiguous(), d.contiguous(), dn.contiguous(), mean_emb,
-                                          normals=self.config.predict_normals)
-            for k, v in res.items():
-                outs.setdefault(k, []).append(v[: hi - lo].clone())
-        return {k: torch.cat(v).view(*shape, -1) for k, v in outs.items()}
+        chunk = int(self.config.eval_num_rays_per_chunk)
+        eng = self.engine
+        res = eng.render_image(origins, directions, dnorm, normals=False, chunk=chunk)
+        out = _LazyOutputs({k: v.view(*shape, -1) for k, v in res.items()})
+        if self.config.predict_normals:
+            out._lazy["normals"] = lambda: eng.render_image(origins, directions, dnorm, normals=True, chunk=chunk)[
+                "normals"].view(*shape, -1)
+        return out
 
     def get_outputs(self, ray_bundle: RayBundle) -> dict:
         return self.get_outputs_for_camera_ray_bundle(ray_bundle)

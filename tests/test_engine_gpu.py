@@ -1110,3 +1110,30 @@ def test_pixel_sampler_kernel(device):
     idx3, _ = draw(1234, 8)
     idx4, _ = draw(1235, 7)
     assert (idx3 != idx).any(dim=1).double().mean() > 0.99 and (idx4 != idx).any(dim=1).double().mean() > 0.99
+
+
+@pytest.mark.parametrize("normals", [False, True], ids=["rgb-depth", "with-normals"])
+def test_render_image_graph_matches_eager_chunks(device, normals):
+    """NerfactoEngine.render_image -- every chunk of a full-image bundle inside ONE captured graph, rays read from and
+    outputs written to image-sized buffers at the chunk's offset, mean appearance embedding taken once -- against the
+    eager per-chunk render_rays (/root/reference/evaluation/nerf_renderer.py:157 -> get_outputs_for_camera_ray_bundle):
+    bit for bit, including the ragged last chunk, on the first replay and on a second image through the same graph."""
+    eng = _make_engine(device)
+    N, chunk = 5000, 2048  # 2048 + 2048 + 904
+    for seed in (3, 4):
+        origins, directions, dnorm, *_ = _rays(N, seed)
+        o, d, dn = origins.to(device), directions.to(device), dnorm.to(device)
+        got = eng.render_image(o, d, dn, normals=normals, chunk=chunk)
+        ref = {}
+        for lo in range(0, N, chunk):
+            hi = min(N, lo + chunk)
+            res = eng.render_rays(o[lo:hi].contiguous(), d[lo:hi].contiguous(), dn[lo:hi].contiguous(), normals=normals)
+            for k, v in res.items():
+                ref.setdefault(k, []).append(v.clone())
+        torch.cuda.synchronize()
+        assert set(got) == set(ref)
+        for k in ref:
+            want = torch.cat(ref[k])
+            assert got[k].shape == want.shape, k
+            assert torch.equal(got[k].view(torch.int32), want.view(torch.int32)), f"{k}: graphed image render != eager chunks"
+    assert len(eng._render_graphs) == 1
