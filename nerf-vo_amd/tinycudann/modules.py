@@ -103,6 +103,41 @@ class _NativeModule:
         )
         return dx, dp
 
+    def bwd_bwd_input(self, *args, **kwargs):
+        """Second-order backward w.r.t. the input (tcnn's torch binding: Module::bwd_bwd_input).  tiny-cuda-nn itself
+        implements it for encodings and CutlassMLP only -- FullyFusedMLP, the network type every NeRF-VO configuration
+        uses, raises there too -- and nothing on the NeRF-VO path takes a double backward: nerfacto's analytic normals use
+        torch.autograd.grad WITHOUT create_graph.  Kept as the raising stub section 8b of
+        SURVEY.md asks for, so that a double backward fails loudly instead of silently treating the first-order
+        gradient as a constant."""
+        raise NotImplementedError(
+            "nerf_vo_amd tinycudann: bwd_bwd_input (double backward through a tcnn module) is not implemented -- "
+            "FullyFusedMLP has none upstream either; use first-order gradients (torch.autograd.grad without create_graph)")
+
+
+class _module_function_backward(torch.autograd.Function):
+    """The first-order backward as its own autograd node (as in tcnn's bindings/torch/tinycudann/modules.py [UPSTREAM]):
+    differentiating THROUGH it -- a double backward -- reaches ``backward`` below, which is the raising stub."""
+
+    @staticmethod
+    def forward(ctx, ctx_fwd, doutput, x, params, output):
+        ctx.ctx_fwd = ctx_fwd
+        native = ctx_fwd.native
+        scaled = (doutput.to(torch.float32) * ctx_fwd.loss_scale).to(native.out_dtype).contiguous()
+        need_dx = ctx_fwd.needs_input_grad[1]
+        need_dp = ctx_fwd.needs_input_grad[2] and native.n_params > 0
+        with torch.no_grad():
+            dx, dp = native.bwd(ctx_fwd.native_ctx, x, params, output, scaled, need_dx, need_dp)
+            if dx is not None:
+                dx = dx / ctx_fwd.loss_scale
+            if dp is not None:
+                dp = dp / ctx_fwd.loss_scale  # fp32, accumulated in fp32 by the kernels (tcnn hands back fp16 here)
+        return dx, dp
+
+    @staticmethod
+    def backward(ctx, *_grads):
+        return ctx.ctx_fwd.native.bwd_bwd_input()
+
 
 class _module_function(torch.autograd.Function):
     @staticmethod
@@ -126,14 +161,7 @@ class _module_function(torch.autograd.Function):
         x, params, output = ctx.saved_tensors
         if ctx.native_ctx is None:
             raise RuntimeError("tcnn module backward called but forward ran without gradient tracking")
-        scaled = (doutput.to(torch.float32) * ctx.loss_scale).to(ctx.native.out_dtype).contiguous()
-        need_dx = ctx.needs_input_grad[1]
-        need_dp = ctx.needs_input_grad[2] and ctx.native.n_params > 0
-        dx, dp = ctx.native.bwd(ctx.native_ctx, x, params, output, scaled, need_dx, need_dp)
-        if dx is not None:
-            dx = dx / ctx.loss_scale
-        if dp is not None:
-            dp = dp / ctx.loss_scale  # fp32, accumulated in fp32 by the kernels (tcnn hands back fp16 here)
+        dx, dp = _module_function_backward.apply(ctx, doutput, x, params, output)
         return None, dx, dp, None, None
 
 

@@ -700,3 +700,24 @@ def test_run_merged_dense_levels_match_slice_owner(device, cfg, acc_bits, live):
     assert float(res["owner"][n_net:].abs().max()) > 0
     tol = dict(rtol=1e-5, atol_scale=1e-6) if acc_bits == 64 else dict(rtol=1e-3, atol_scale=1e-4)
     _assert_close(res["runs"][n_net:], res["owner"][n_net:], what="grid gradient, run-merged", **tol)
+
+
+def test_double_backward_raises_like_upstream(device):
+    """``bwd_bwd_input`` exists and RAISES (tcnn's FullyFusedMLP has no second-order backward
+    either).  A first-order torch.autograd.grad -- what nerfacto's analytic normals use -- works; differentiating through
+    it (create_graph=True, then backward) must fail loudly instead of silently returning a constant's gradient."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    net = tcnn.NetworkWithInputEncoding(
+        3, 16, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12, "base_resolution": 4,
+                "per_level_scale": 1.5},
+        {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1}).to(device)
+    x = torch.rand(256, 3, device=device, requires_grad=True)
+    y = net(x).float()
+    (g,) = torch.autograd.grad(y[:, 0].sum(), x, retain_graph=True)  # first order: fine
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    (g2,) = torch.autograd.grad(y[:, 0].sum(), x, create_graph=True)
+    with pytest.raises(NotImplementedError, match="bwd_bwd_input"):
+        g2.sum().backward()
+    with pytest.raises(NotImplementedError, match="bwd_bwd_input"):
+        net.native_tcnn_module.bwd_bwd_input()
