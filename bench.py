@@ -537,23 +537,30 @@ def main() -> None:
         # Every run uses the DETERMINISTIC mode with a fixed seed (bitwise reproducible training: DESIGN.md section 3.7), so
         # the figures are the same on every box and every run.  The training THROUGHPUT is the timed region above, not
         # these runs (deterministic mode is ~2x slower).
-        def psnr_run(mode, noise=None):
-            res = run_protocol(quiet=True, deterministic=True, seed=42, camera_optimizer_mode=mode, pose_noise=noise,
+        def psnr_run(mode, noise=None, seed=42):
+            res = run_protocol(quiet=True, deterministic=True, seed=seed, camera_optimizer_mode=mode, pose_noise=noise,
                                keyframe_views=False, **kw)
             ef = res["evaluation_frames"]
             return {"psnr_reference_uint8wrap_db": round(ef["psnr"], 3), "psnr_float_mse_db": round(ef["psnr_float_mse"], 3),
                     "mssim": round(ef["mssim"], 4), "depth_l1": round(ef["absolute_difference"], 4),
                     "depth_delta1": round(ef["delta1"], 4), "scale_pred2gt": round(res["scale_pred2gt"], 5),
                     "pose_rotation_error_rad": round(res["pose_error_after_frame0_alignment"]["rotation_mean_rad"], 6),
-                    "ingested_pose_rotation_error_rad": round(res["pose_error_of_ingested_poses"]["rotation_mean_rad"], 6)}
+                    "ingested_pose_rotation_error_rad": round(res["pose_error_of_ingested_poses"]["rotation_mean_rad"], 6),
+                    "loss_scale_end": res["loss_scale_end"], "seed": seed}
 
-        render_psnr = {**psnr_run("off"), "held_out_views": kw["eval_frames"],
+        # headline = fixed exact poses, MEDIAN run (by float-MSE PSNR) of three fixed seeds, every run listed: one of 29
+        # otherwise identical 8192-step runs measured in round 4 (deterministic, seed 42) ends in an optimisation blow-up --
+        # density pre-activations beyond 15, where trunc_exp's backward multiplies by e^15 -- that the step count does not
+        # recover from (12 dB); a single fixed seed would either hide that or report it as the typical quality
+        seeds = (42, 43, 44) if args.psnr == "replica" else (42,)
+        fixed = sorted((psnr_run("off", seed=sd) for sd in seeds), key=lambda r: r["psnr_float_mse_db"])
+        render_psnr = {**fixed[len(fixed) // 2], "fixed_pose_runs": fixed, "held_out_views": kw["eval_frames"],
                        "protocol": "reference evaluation protocol (frame-0 alignment, median depth scale, JPEG/PNG files, "
                                    "uint8-wrapping PSNR + conventional float-MSE PSNR of the same files)",
                        "config": f'{kw["keyframes"]} keyframes {kw["width"]}x{kw["height"]} (every 2nd dataset frame), '
                                  f'{kw["iterations"]} iterations through the Nerfstudio mapper interface (incremental keyframe '
                                  "ingest), fixed exact poses (BASELINE configs[1]), synthetic textured room; deterministic mode, "
-                                 "seed 42, GradScaler loss scale",
+                                 "GradScaler loss scale; median of the listed seeds",
                        # the mapper exactly as the reference configures it (SE3 refinement on), exact poses
                        "with_se3_pose_refinement": psnr_run("SE3"),
                        # BASELINE configs[2]: tracker-like pose errors (sigma 5e-3 rad / 5e-3 units, frame 0 exact) with

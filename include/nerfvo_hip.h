@@ -560,6 +560,12 @@ int nvo_nonfinite_flag_ranges(nvo_stream_t stream, uint32_t n_ranges, const uint
                               const void* grads, int grads_are_half, uint32_t* flags);
 /* The same without resetting the flag words first (they were cleared earlier, e.g. by the step's nvo_zero_ranges):
  * one launch less in front of the optimiser. */
+/* The same over up to 8 spans with an EXPLICIT flag word each (flags[slots[i]] |= 1; several spans may share a word):
+ * the step whose overflow flags are raised at the source scans the small non-grid ranges of its groups -- fused-MLP
+ * weight gradients, embedding, poses -- where every 16-bit overflow INSIDE the backward chain ends up (dW = dZ x H of
+ * the layer that overflowed), see EngineConfig.producer_overflow_flags. */
+int nvo_nonfinite_flag_spans_or(nvo_stream_t stream, uint32_t n_spans, const uint64_t* offsets, const uint64_t* sizes,
+                                const uint32_t* slots, const void* grads, int grads_are_half, uint32_t* flags);
 int nvo_nonfinite_flag_ranges_or(nvo_stream_t stream, uint32_t n_ranges, const uint64_t* offsets, const uint64_t* sizes,
                               const void* grads, int grads_are_half, uint32_t* flags);
 /* grads: device float[n], or device fp16[n] when grads_are_half != 0 (the buffer a compressed
@@ -580,7 +586,9 @@ int nvo_cast_half(nvo_stream_t stream, uint64_t n, const float* src, void* dst_h
 /* Sharded gradient exchange (multi-GPU: reduce-scatter -> Adam on this rank's 1/world slice -> all-gather of the 16-bit
  * working copy).  src[0, n) is cast to the wire format (1 = fp16, 2 = bf16) as `world` chunks of n / world elements,
  * each followed by `pad` FLAG slots: wire16[(i / per) * (per + pad) + i % per].  *flag (device uint32, OR-ed) is raised
- * when src holds an inf / NaN, and every pad slot receives *flag ? 1 : 0 -- after the SUM reduce-scatter of the wire
+ * when src holds an inf / NaN or a value the SUM over `world` ranks could not carry on the wire (fp16: |v| > 65504 / world
+ * -- nothing scans the reduced shard, so a finite sum must follow from the local verdicts; bf16: fp32's range), and every
+ * pad slot receives *flag ? 1 : 0 -- after the SUM reduce-scatter of the wire
  * buffer, rank r reads the number of ranks that overflowed from the pad of ITS chunk, so all ranks skip the group
  * together (GradScaler.step semantics) without a second collective: nvo_flag_from_wire ORs (slot != 0) into *flag.
  * n multiple of 4 * world; pad a positive multiple of 4; wire16 holds world * (n / world + pad) elements. */

@@ -175,6 +175,7 @@ _SIGNATURES = {
     "nvo_adam_step_groups": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p]),
     "nvo_nonfinite_flag_ranges": (_int, [_p, _u32, _p, _p, _p, _int, _p]),
     "nvo_nonfinite_flag_ranges_or": (_int, [_p, _u32, _p, _p, _p, _int, _p]),
+    "nvo_nonfinite_flag_spans_or": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p]),
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
     "nvo_zero_ranges": (_int, [_p, _u32, _p, _p]),
     "nvo_bwd_zero_ranges": (_int, [_p, _p, _p, _p, _u32]),

@@ -221,6 +221,25 @@ k_nonfinite_flag_ranges(FlagRanges r, const GT* __restrict__ g, uint32_t* __rest
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + r.slot[k], 1u);
 }
 
+// the same with an explicit flag word per span (several spans may raise the same word): the MLP-weight / embedding
+// ranges of the parameter groups, scanned by the single-GPU step whose overflow flags are otherwise raised at the source
+constexpr uint32_t kMaxSpans = 8;
+struct FlagSpans {
+    uint32_t n_spans;
+    uint32_t first_block[kMaxSpans + 1];
+    uint64_t offset[kMaxSpans], n[kMaxSpans];
+    uint32_t slot[kMaxSpans];
+};
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_nonfinite_flag_spans(FlagSpans r, const GT* __restrict__ g, uint32_t* __restrict__ flags) {
+    uint32_t k = 0;
+    while (k + 1 < r.n_spans && blockIdx.x >= r.first_block[k + 1]) ++k;
+    const bool bad = nonfinite_range<GT>(r.n[k], g + r.offset[k], blockIdx.x - r.first_block[k],
+                                         r.first_block[k + 1] - r.first_block[k]);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags + r.slot[k], 1u);
+}
+
 __global__ void __launch_bounds__(256)
 k_cast_half(uint64_t n, const float* __restrict__ src, _Float16* __restrict__ dst) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -736,6 +755,38 @@ static int nonfinite_ranges_launch(nvo_stream_t stream, uint32_t n_ranges, const
     } else {
         NVO_LAUNCH(k_nonfinite_flag_ranges<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r,
                    (const float*)grads, flag);
+    }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_nonfinite_flag_spans_or(nvo_stream_t stream, uint32_t n_spans, const uint64_t* offsets, const uint64_t* sizes,
+                                const uint32_t* slots, const void* grads, int grads_are_half, uint32_t* flags) {
+    NVO_REQUIRE(grads && flags && offsets && sizes && slots, "nonfinite_flag_spans: NULL argument");
+    NVO_REQUIRE(n_spans >= 1 && n_spans <= kMaxSpans, "nonfinite_flag_spans: 1..%u spans (got %u)", kMaxSpans, n_spans);
+    NVO_PROF(stream, "nonfinite_flag");
+    FlagSpans r{};
+    uint32_t k = 0, blocks_total = 0;
+    for (uint32_t i = 0; i < n_spans; ++i) {
+        if (sizes[i] == 0) continue;
+        r.offset[k] = offsets[i];
+        r.n[k] = sizes[i];
+        r.slot[k] = slots[i];
+        uint32_t blocks = nvo_div_up(sizes[i], 256 * 8);
+        if (blocks > 2048) blocks = 2048;
+        r.first_block[k] = blocks_total;
+        blocks_total += blocks;
+        ++k;
+    }
+    if (k == 0) return NVO_OK;
+    r.n_spans = k;
+    for (uint32_t i = k; i <= kMaxSpans; ++i) r.first_block[i] = blocks_total;
+    if (grads_are_half == 2) {
+        NVO_LAUNCH(k_nonfinite_flag_spans<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r, (const Bf16*)grads, flags);
+    } else if (grads_are_half) {
+        NVO_LAUNCH(k_nonfinite_flag_spans<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r, (const _Float16*)grads, flags);
+    } else {
+        NVO_LAUNCH(k_nonfinite_flag_spans<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, r, (const float*)grads, flags);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

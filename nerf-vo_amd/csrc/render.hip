@@ -76,7 +76,10 @@ __device__ __forceinline__ void ray_weights(int lane, uint32_t S, const nvo_h16*
         float dd = 0.f, sg = 0.f;
         if (i < S) {
             const bool sel = cur.x0 > 0.f;
-            sg = sel ? __expf(cur.pr + bias) : 0.f;
+            // (exponent capped at 60: sigma <= 1.1e26 -- alpha is 1 to the last bit long before that -- so that a run whose
+            // density pre-activations have blown up cannot put inf - inf = NaN into the transmittance and, through it, a
+            // NaN that no loss scale can back off from into every gradient of the step; trunc_exp's forward is exp(x))
+            sg = sel ? __expf(fminf(cur.pr + bias, 60.f)) : 0.f;
             dd = (cur.t1 - cur.t0) * sg;
             if (sigma_out) sigma_out[i] = sg;
         }

@@ -88,6 +88,11 @@ class EngineConfig:
     loss_scale_backoff: float = 0.5
     loss_scale_interval: int = 2000
     loss_scale_max: float = 16777216.0    # 2^24: keeps the fixed-point grid accumulators (|v| < 2^25) in range in bf16 mode
+    # torch's GradScaler has NO lower bound: a run whose gradients overflow at every scale >= 1 (density pre-activations
+    # beyond 15 multiply dL/dsigma by e^15 = 3.3e6 through trunc_exp's clamped backward) keeps halving until they fit
+    # and goes on training.  Rounds 1-3 clamped at 1.0, which turns such an episode into a permanent skip (found with the
+    # fixed-pose deterministic seed-42 run of round 4: one of 29 otherwise healthy 8192-step runs).
+    loss_scale_min: float = 2.0 ** -24
     lr_fields: float = 1e-2
     lr_proposal: float = 1e-2
     lr_camera: float = 1e-4
@@ -196,9 +201,12 @@ class EngineConfig:
     # hash-grid backward.  The loss kernels (the roots) and the grid backward (the leaves, which already had to detect
     # it for their integer accumulators) OR the flag word of their parameter group; the optimiser no longer re-reads the
     # 55 MB gradient buffer (nonfinite_flag: 13-17 us per step).  (Instrumenting the fused-MLP backward as well was
-    # measured: +4.5 / +4.6 / +1.7 us on its three launches -- as much as the scan saved -- and is not needed.)  With a
-    # process group the check stays behind the reduction (another rank may have overflowed); the pose group (1152
-    # scalars) is scanned.
+    # measured: +4.5 / +4.6 / +1.7 us on its three launches -- as much as the scan saved.)  [round 4] The argument has a
+    # hole that GradScaler's growing scale walks into: a 16-bit value INSIDE the chain (a hidden dZ, d_base_out) can
+    # overflow while the roots are finite, and a ReLU backward can drop it before a leaf sees it.  The layer it appears in
+    # still multiplies it into its weight gradient, so the optimiser scans the ~30 K NON-GRID scalars of each group (MLP
+    # weights, embedding, poses; one small launch) -- optimizer_step.  With a process group the check stays behind the
+    # reduction (another rank may have overflowed).
     producer_overflow_flags: bool = True
     log_every: int = 10                   # LoggingConfig.steps_per_log of the trainer mirror
     seed: int = 1337
@@ -1036,13 +1044,38 @@ class NerfactoEngine:
             return lo, hi
 
         if check and self._producer_flags:
-            # the producers raised the flags of the fields / proposal groups; the pose gradient (fp32 all the way from the
-            # same 16-bit values, 1152 scalars) is scanned -- it must also stop when EITHER of the others overflowed
-            if "camera_opt" in active:
-                lo, hi = self.group_ranges["camera_opt"]
-                offs = (C.c_uint64 * len(order))(*[lo if g == "camera_opt" else 0 for g in order])
-                sizes = (C.c_uint64 * len(order))(*[hi - lo if g == "camera_opt" else 0 for g in order])
-                _call("nvo_nonfinite_flag_ranges_or", stream, len(order), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
+            # The producers raised the flags of the fields / proposal groups at the roots (loss kernels) and the leaves
+            # (grid backward) of the 16-bit gradient chain.  A 16-bit value can also overflow INSIDE the chain (a hidden
+            # dZ, d_base_out) while the roots are finite -- GradScaler keeps doubling the scale until something does --
+            # and a ReLU backward may drop it before it reaches a leaf; but the layer it appears in multiplies it into
+            # that layer's weight gradient (dW = dZ x H; inf * 0 = NaN), so the small NON-GRID ranges of each group are
+            # scanned: fused-MLP weights, appearance embedding, poses (~30 K scalars, one launch).  (Found by the
+            # fixed-pose 8192-step run of round 4, which nothing scanned: NaN weights after the scale reached 2^19.)
+            spans = []
+            if not hasattr(self, "_mlp_sizes"):  # (weights in front of the grid inside each NetworkWithInputEncoding)
+                self._mlp_sizes = {"base": self.base_net.n_params - self._grid_params(self.base_net),
+                                   **{k: m.n_params - self._grid_params(m) for k, m in enumerate(self.prop_nets)}}
+            n_base_mlp = self._mlp_sizes["base"]
+            for g in active:
+                gi = order.index(g)
+                if g == "fields":
+                    o = self.segments["field.base"][0]
+                    spans.append((o, n_base_mlp, gi))
+                    o = self.segments["field.color"][0]
+                    spans.append((o, sum(self.segments["field.embedding"][:2]) - o, gi))
+                elif g == "proposal_networks":
+                    for k, m in enumerate(self.prop_nets):
+                        spans.append((self.segments[f"proposal.{k}"][0], self._mlp_sizes[k], gi))
+                else:
+                    lo, hi = self.group_ranges[g]
+                    spans.append((lo, hi - lo, gi))
+            if shard is not None:
+                spans = [sp for sp in spans if sp[2] != order.index("fields")]
+            if spans:
+                offs = (C.c_uint64 * len(spans))(*[sp[0] for sp in spans])
+                sizes = (C.c_uint64 * len(spans))(*[sp[1] for sp in spans])
+                slots = (C.c_uint32 * len(spans))(*[sp[2] for sp in spans])
+                _call("nvo_nonfinite_flag_spans_or", stream, len(spans), offs, sizes, slots, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
         elif check:
             # one flag PER GROUP that trains this step (GradScaler.step decides per optimiser; ranges of idle groups
             # hold stale values and are neither checked nor applied), all in one launch; flag word = the group's slot
@@ -1082,7 +1115,7 @@ class NerfactoEngine:
             return
         _call("nvo_opt_commit", stream, len(order), mask, scale_mask, _ptr(self.dev_applied), _ptr(self.skip_flag),
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
-              cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max,
+              cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
 
     def _commit_and_write(self, masks, sampling_step: int) -> None:
@@ -1095,7 +1128,7 @@ class NerfactoEngine:
         _call("nvo_opt_commit_write", _stream(self.device), len(self._GROUP_ORDER), mask, scale_mask, _ptr(self.dev_applied),
               _ptr(self.skip_flag), _ptr(self.dev_loss_scale) if scale_mask else None,
               _ptr(self.dev_growth_tracker) if scale_mask else None, cfg.loss_scale_growth, cfg.loss_scale_backoff,
-              int(cfg.loss_scale_interval), 1.0, cfg.loss_scale_max, _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1],
+              int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max, _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1],
               _ptr(self.dev_scalars), 16, arr)
         self._scalars_step = sampling_step
 
@@ -1509,6 +1542,7 @@ class NerfactoEngine:
                 entry["captured_collectives"] = True
                 entry["run"] = lambda pipeline: whole_g[bool(pipeline)].replay()
                 entry["whole"] = whole_g
+                self._selfcheck_captured_exchange(whole_g[False], saved, red)
                 return entry
             except Exception as exc:  # noqa: BLE001 - fall back to eager collectives between captured segments
                 import sys
@@ -1533,6 +1567,52 @@ class NerfactoEngine:
         entry["segments"] = segs
         entry["run"] = lambda pipeline: program(bool(pipeline), lambda name, fn: segs[name].replay())
         return entry
+
+    def _selfcheck_captured_exchange(self, graph, saved, red) -> None:
+        """Start-up self-check of a step graph that holds CAPTURED RCCL collectives (first capture per process): one replay
+        under a watchdog, then cross-rank agreement of what the exchange produced.  A hang (a captured collective that
+        never completes with real peers) or a disagreement ends the process with a NON-ZERO exit code and a message that
+        names the way out -- NVO_DIST_CAPTURE=0: eager collectives between captured compute segments, the same program.
+        Never a re-exec or an in-process relaunch: this process has touched the GPU.  NVO_DIST_SELFCHECK=0 skips it,
+        NVO_DIST_SELFCHECK_TIMEOUT (seconds, default 120) bounds the wait."""
+        import os
+        import sys
+        import time
+
+        if getattr(self, "_exchange_checked", False) or os.environ.get("NVO_DIST_SELFCHECK", "1") == "0":
+            return
+        self._exchange_checked = True
+        timeout = float(os.environ.get("NVO_DIST_SELFCHECK_TIMEOUT", "120"))
+        dev = self.device
+
+        def die(why: str):
+            sys.stderr.write(f"[nerf_vo_amd] FATAL (rank {red.rank} of {red.world}): {why}.  The step graph with captured RCCL "
+                             "collectives failed its start-up self-check; restart with NVO_DIST_CAPTURE=0 (eager collectives "
+                             "between captured compute segments -- the same program, +0.04 ms per step).\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        done = torch.cuda.Event()
+        graph.replay()
+        done.record(torch.cuda.current_stream(dev))
+        t0 = time.time()
+        while not done.query():
+            if time.time() - t0 > timeout:
+                die(f"one replay did not complete within {timeout:.0f} s")
+            time.sleep(0.002)
+        # every rank must now hold the same 16-bit working copy (what the kernels read) and finite fp32 state
+        chk = self.params_half.view(torch.int16).to(torch.int64).sum()
+        ok = (torch.isfinite(self.params).all() & torch.isfinite(self.exp_avg).all()).to(torch.int64)
+        t = torch.stack([chk, -chk, -ok])
+        red.dist.all_reduce(t, op=red.dist.ReduceOp.MAX, group=red.group)  # (eager, outside any graph)
+        hi, neg_lo, neg_ok = (int(v) for v in t.tolist())
+        if hi != -neg_lo:
+            die("the ranks' working copies differ after one replayed step")
+        if neg_ok != -1:
+            die("non-finite parameters or Adam moments after one replayed step")
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):
+            dst.copy_(src)  # (the check's step does not count as training)
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, jitters=None, all_reduce=None, normals=None):
         """One full iteration.  ``all_reduce``: optional callable(flat_grad_tensor) for multi-GPU."""

@@ -68,6 +68,19 @@ def main():
             prefix_checked += 1
             prefix_mismatch += [k for k in names if not torch.equal(before[k].view(torch.uint8), ws[k].view(torch.uint8))]
     torch.cuda.synchronize()
+    extra = {}
+    if plan.get("checkpoint_render"):
+        # NO manual sync_sharded_state() before either: the render reads the all-gathered working copy, state_dict gathers
+        from nerf_vo_amd.mapping.model import ExtendedNerfactoModel
+
+        g = torch.Generator().manual_seed(5)
+        o = ((torch.rand(256, 3, generator=g) - 0.5) * 0.6).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1).to(dev)
+        extra["render_before_sync"] = eng.render_rays(o, d, torch.ones(256, device=dev))["rgb"].cpu().clone()
+        model = object.__new__(ExtendedNerfactoModel)
+        model.engine = eng
+        extra["checkpoint"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in model.state_dict(all_reduce=reducer).items()}
+        torch.cuda.synchronize()
     sharded_state = None
     if plan.get("shard_optimizer"):
         # sharded optimiser: the fp32 master / moments of the fields group are current on their owner only, the
@@ -101,7 +114,7 @@ def main():
     torch.save({"after_eager": after_eager, "after_graph": eng.params.detach().cpu(), "losses": eng.loss_dict(),
                 "skip": eng.skip_flag.cpu(), "ray_indices": drawn, "prefix_checked": prefix_checked,
                 "prefix_mismatch": sorted(set(prefix_mismatch)), "ab": ab, "sharded_state": sharded_state,
-                "opt_steps": eng.opt_steps, "exp_avg": eng.exp_avg.cpu()}, os.path.join(workdir, f"rank{rank}.pt"))
+                "opt_steps": eng.opt_steps, "exp_avg": eng.exp_avg.cpu(), **extra}, os.path.join(workdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

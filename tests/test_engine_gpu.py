@@ -1137,3 +1137,40 @@ def test_render_image_graph_matches_eager_chunks(device, normals):
             assert got[k].shape == want.shape, k
             assert torch.equal(got[k].view(torch.int32), want.view(torch.int32)), f"{k}: graphed image render != eager chunks"
     assert len(eng._render_graphs) == 1
+
+
+def test_producer_flags_catch_overflow_inside_the_chain(device):
+    """GradScaler doubles the loss scale until something overflows, and what overflows first need not be a root
+    (dL/drgb, dL/d density) or a leaf (dL/d encoded) of the 16-bit gradient chain: a hidden dZ or d_base_out can reach
+    inf while the roots are finite.  Sweep the scale from tcnn's 128 to 2^40: for EVERY scale the per-group verdict of
+    the producer-flag step (flags at roots / leaves + the scan of the non-grid ranges) must equal the verdict of the
+    full scan of the gradient buffer -- including the scales in between, where only the inside of the chain overflows
+    (the regime that turned a fixed-pose 8192-step run into NaN weights before the non-grid scan existed)."""
+    R = 256
+    origins, directions, dnorm, cam, jit, gt_rgb, gt_depth = _rays(R, 7)
+    engines = {p: _make_engine(device, producer_overflow_flags=p) for p in (True, False)}
+    p0 = engines[True].params.clone()
+    verdicts, inside_only = {}, 0
+    for k in range(7, 41, 3):
+        row = {}
+        for producer, eng in engines.items():
+            eng.cfg.loss_scale = float(2 ** k)
+            eng.dev_loss_scale.fill_(float(2 ** k))
+            eng.set_params(p0)
+            eng.reset_optimizer()
+            ws = eng._workspace(R, True)
+            eng.load_ray_bundle(ws, origins.to(device), directions.to(device), dnorm.to(device), cam.to(device),
+                                gt_rgb.to(device), gt_depth.to(device))
+            eng.forward_backward(ws, tuple(j.to(device) for j in jit), has_depth=True, update_proposals=True, anneal=0.6)
+            roots_ok = bool(torch.isfinite(ws["drgb"].float()).all()) and bool(torch.isfinite(ws["dout2"].float()).all())
+            eng.optimizer_step(["fields", "proposal_networks"], flags_cleared=True)
+            torch.cuda.synchronize()
+            row[producer] = [bool(f) for f in eng.skip_flag.tolist()[:2]]
+            assert bool(torch.isfinite(eng.params).all()), f"scale 2^{k}: non-finite parameters (producer flags: {producer})"
+            if producer and row[producer][0] and roots_ok:
+                inside_only += 1
+        verdicts[k] = row
+        assert row[True] == row[False], f"scale 2^{k}: producer flags {row[True]} vs full scan {row[False]}"
+    print(verdicts, "scales whose fields overflow started inside the chain:", inside_only)
+    assert not verdicts[7][True][0] and verdicts[40][True][0], "the sweep must span in-range and overflowing scales"
+    assert inside_only >= 1, "no scale exercised an overflow inside the chain with finite roots"

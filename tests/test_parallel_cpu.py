@@ -1,5 +1,7 @@
-"""Multi-process (gloo, world_size 2, CPU) test of the only collective on the path: the sum
-all-reduce of the flat gradient buffer, plus ray sharding helpers."""
+"""Multi-process (gloo, world_size 2 / 4 / 8, CPU) tests of the exchange of the multi-GPU step:
+sum all-reduce of gradient ranges (fp32 / fp16 / bf16 wire), MAX reduction of the occupancy-grid estimates, and the
+sharded form -- reduce-scatter of a wire buffer of `world` chunks with flag slots, in-place all-gather of the owners'
+slices -- plus the ray-sharding helpers and the bf16 summation drift of an 8-way reduction."""
 import os
 import socket
 
@@ -24,52 +26,54 @@ def _worker(rank, world, port, tmp):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from nerf_vo_amd.parallel import GradientAllReduce
 
+    checks = {}
     red = GradientAllReduce(dist, bucket_numel=1000)
     g = torch.Generator().manual_seed(100 + rank)
     n = 10_007  # not a multiple of the bucket size
     grad = torch.randn(n, generator=g)
     mine = grad.clone()
     red(grad)
-    # every rank must hold the same sum; rank 0 checks it against a locally recomputed reference
+    # every rank must hold the same sum; checked against a locally recomputed reference (summation order differs)
     gathered = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
     ref = sum(gathered)
-    ok = torch.allclose(grad, ref, atol=1e-6)
+    checks["fp32 all-reduce"] = torch.allclose(grad, ref, atol=2e-6 * world)
     # partial reduction: only one segment is reduced, the rest keeps the local value
     grad2 = mine.clone()
     red(grad2, segments=[(100, 2500)])
-    ok = ok and torch.allclose(grad2[100:2600], ref[100:2600], atol=1e-6) and torch.equal(grad2[:100], mine[:100]) \
-        and torch.equal(grad2[2600:], mine[2600:])
-    # fp16-compressed exchange: same sum up to fp16 rounding of each rank's contribution
+    checks["segment all-reduce"] = torch.allclose(grad2[100:2600], ref[100:2600], atol=2e-6 * world) and \
+        torch.equal(grad2[:100], mine[:100]) and torch.equal(grad2[2600:], mine[2600:])
+    # 2-byte wires: every rank's contribution is rounded once, and the collective rounds the running sum to the wire
+    # format after every add -- the bound grows with the number of adds
+    adds = world - 1
     red16 = GradientAllReduce(dist, bucket_numel=3000, compress="fp16")
     grad3 = mine.clone()
     red16(grad3, segments=[(0, 5000), (5000, n - 5000)])
     ref16 = sum(t.half().float() for t in gathered)
-    ok = ok and torch.allclose(grad3, ref16, atol=2e-2, rtol=2e-3)
+    checks["fp16 wire"] = torch.allclose(grad3, ref16, atol=1e-2 * adds, rtol=2e-3 * adds)
     # bf16-compressed exchange (what bench.py uses): 8 significant bits, fp32's exponent range -- tiny values survive
     redb = GradientAllReduce(dist, compress="bf16")
     tiny = mine.clone() * 1e-12
     back = redb(tiny.clone(), keep_half=True)
     refb = sum((t * 1e-12).to(torch.bfloat16).float() for t in gathered)
-    ok = ok and back.dtype == torch.bfloat16 and torch.allclose(back.float(), refb, rtol=2e-2, atol=0.0) \
-        and float((back.float() == 0).float().mean()) < 1e-3
+    checks["bf16 wire keeps tiny values"] = back.dtype == torch.bfloat16 and \
+        torch.allclose(back.float(), refb, rtol=1e-2 * adds, atol=4e-14 * adds) and float((back.float() == 0).float().mean()) < 1e-3
     # asynchronous form (the multi-GPU step overlaps the fields reduction with the next sampling prefix): handles out,
     # same sum after wait(); compressed variant through the caller-owned 2-byte buffer
     grad4 = mine.clone()
     handles = red(grad4, segments=[(0, n)], async_op=True)
-    ok = ok and len(handles) > 0
     red.wait(handles)
-    ok = ok and torch.allclose(grad4, ref, atol=1e-6)
+    checks["async all-reduce"] = len(handles) > 0 and torch.allclose(grad4, ref, atol=2e-6 * world)
     half = mine.to(torch.bfloat16)
     handles = redb.reduce_half(mine, half, [(0, 4000), (6000, n - 6000)], already_cast=True, async_op=True)
     redb.wait(handles)
     refh = sum(t.to(torch.bfloat16).float() for t in gathered)
-    ok = ok and torch.allclose(half[:4000].float(), refh[:4000], rtol=2e-2, atol=1e-2) \
-        and torch.equal(half[4000:6000], mine[4000:6000].to(torch.bfloat16))
+    checks["async bf16 reduce_half"] = torch.allclose(half[:4000].float(), refh[:4000], rtol=1e-2 * adds, atol=4e-2 * adds) and \
+        torch.equal(half[4000:6000], mine[4000:6000].to(torch.bfloat16))
     # MAX reduction of the occupancy-grid density estimates: identical on every rank, elementwise maximum
     dens = mine.abs().clone()
     red.reduce_max(dens)
-    ok = ok and torch.equal(dens, torch.stack([t.abs() for t in gathered]).max(dim=0).values)
+    checks["max reduction"] = torch.equal(dens, torch.stack([t.abs() for t in gathered]).max(dim=0).values)
     # sharded exchange: reduce-scatter of a wire buffer of `world` chunks (+ flag slots), all-gather of the owners' slices
     # IN PLACE (the shard is a slice of the full buffer, as the optimiser writes it)
     reds = GradientAllReduce(dist, compress="bf16", shard_optimizer=True)
@@ -77,32 +81,37 @@ def _worker(rank, world, port, tmp):
     wire = torch.zeros(world * (per + pad), dtype=torch.bfloat16)
     for c in range(world):
         wire[c * (per + pad):c * (per + pad) + per] = mine[c * per:(c + 1) * per].to(torch.bfloat16)
-        wire[c * (per + pad) + per:(c + 1) * (per + pad)] = 1.0 if rank == 1 else 0.0  # rank 1 "overflowed"
+        wire[c * (per + pad) + per:(c + 1) * (per + pad)] = 1.0 if rank % 4 == 1 else 0.0  # ranks 1, 5 "overflowed"
     out = torch.zeros(per + pad, dtype=torch.bfloat16)
     reds.wait(reds.reduce_scatter(out, wire, async_op=True))
     ref_chunk = sum(t[rank * per:(rank + 1) * per].to(torch.bfloat16).float() for t in gathered)
-    ok = ok and torch.allclose(out[:per].float(), ref_chunk, rtol=2e-2, atol=1e-2) and float(out[per]) == 1.0
+    # every rank finds the NUMBER of ranks that overflowed in the flag slots of its own chunk: all ranks skip together
+    n_bad = len([r for r in range(world) if r % 4 == 1])
+    checks["reduce-scatter values"] = torch.allclose(out[:per].float(), ref_chunk, rtol=1e-2 * adds, atol=4e-2 * adds)
+    checks["reduce-scatter flag slots"] = bool((out[per:] == float(n_bad)).all())
     full = torch.zeros(world * per, dtype=torch.bfloat16)
     full[rank * per:(rank + 1) * per] = out[:per]
     reds.wait(reds.all_gather(full, full[rank * per:(rank + 1) * per], async_op=True))
     chunks = [torch.zeros(per, dtype=torch.bfloat16) for _ in range(world)]
     dist.all_gather(chunks, out[:per].clone())
-    ok = ok and torch.equal(full, torch.cat(chunks)) and reds.world == world and reds.rank == rank
+    checks["in-place all-gather"] = torch.equal(full, torch.cat(chunks)) and reds.world == world and reds.rank == rank
     try:
         GradientAllReduce(dist, shard_optimizer=True)
-        ok = False  # the sharded optimiser needs a 2-byte wire format
+        checks["sharding needs a 2-byte wire"] = False
     except ValueError:
-        pass
-    torch.save({"ok": bool(ok)}, os.path.join(tmp, f"r{rank}.pt"))
+        checks["sharding needs a 2-byte wire"] = True
+    torch.save({k: bool(v) for k, v in checks.items()}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_gradient_all_reduce_gloo_world2(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gradient_exchange_gloo(tmp_path, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        assert torch.load(tmp_path / f"r{r}.pt")["ok"], f"rank {r} saw a wrong reduction"
+        checks = torch.load(tmp_path / f"r{r}.pt")
+        bad = [k for k, v in checks.items() if not v]
+        assert len(checks) == 11 and not bad, f"world {world}, rank {r}: {bad}"
 
 
 def test_single_process_world_is_identity():
@@ -120,3 +129,45 @@ def test_single_process_world_is_identity():
     assert torch.equal(x, y)
     assert [shard_ray_count(4096, 8, r) for r in range(8)] == [512] * 8
     assert sum(shard_ray_count(4099, 8, r) for r in range(8)) == 4099
+
+
+def test_fields_shards_split_evenly_for_every_world_size():
+    """Slice arithmetic of the sharded optimiser (engine._capture_step / optimizer_step: per = (f_hi - f_lo) // world,
+    chunks of the wire buffer = per + 8 flag slots): the fields group is padded to a multiple of 512 elements
+    (engine: 'field.pad'), so that for world 1 / 2 / 4 / 8 the shards are equal, 16-byte aligned in the 2-byte wire
+    format and in the fp32 master, and tile the group exactly."""
+    n_base, n_color, n_emb = 12_199_312, 9216, 192 * 32  # base MLP + main grid | colour head | embedding (192 keyframes)
+    off = n_base + n_color + n_emb
+    fields = off + (-off) % 512
+    for world in (1, 2, 4, 8):
+        per = fields // world
+        assert per * world == fields and per % 8 == 0 and (2 * per) % 16 == 0 and (4 * per) % 16 == 0
+        kPad = 8
+        starts = [r * (per + kPad) for r in range(world)]
+        assert all((2 * s) % 16 == 0 for s in starts)  # every chunk of the wire buffer starts 16-byte aligned
+        covered = sum(per for _ in range(world))
+        assert covered == fields
+
+
+def test_bf16_wire_summation_drift_up_to_eight_ranks():
+    """RCCL sums the 2-byte wire format in that format: an 8-rank ring rounds the running sum to bf16's 8 significant bits
+    seven times where two ranks round once.  Emulated here as a sequential bf16 accumulation of per-rank gradients
+    (heavy-tailed magnitudes, as hash-grid gradients are) against the exact sum: the relative L1 error of the reduced
+    gradient grows from 1.9e-3 (W = 2) to 3.2e-3 (W = 8) -- 1.7x, below the 2x at which DESIGN.md section 6 would switch
+    the reduction to fp32 after a bf16 all-gather (which measures 1.5e-3 at every W, also checked)."""
+    g = torch.Generator().manual_seed(0)
+    n = 400_000
+    err = {}
+    for world in (2, 4, 8):
+        grads = [torch.randn(n, generator=g) * torch.rand(n, generator=g).pow(4) * 1e-3 for _ in range(world)]
+        ref = sum(t.double() for t in grads)
+        acc = grads[0].to(torch.bfloat16)
+        for t in grads[1:]:
+            acc = acc + t.to(torch.bfloat16)
+        wide = sum(t.to(torch.bfloat16).float() for t in grads)
+        err[world] = (float((acc.double() - ref).abs().sum() / ref.abs().sum()),
+                      float((wide.double() - ref).abs().sum() / ref.abs().sum()))
+    print({w: tuple(f"{v:.2e}" for v in e) for w, e in err.items()})
+    assert err[2][0] < 2.5e-3 and err[8][0] < 4.5e-3
+    assert err[8][0] < 2.0 * err[2][0], "8-way bf16 addition drifts more than twice the 2-way figure"
+    assert all(e[1] < 2.0e-3 for e in err.values())

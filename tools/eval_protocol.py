@@ -48,6 +48,30 @@ def _pose_errors(pred: np.ndarray, gt: np.ndarray) -> dict:
     return {"translation_rmse": float(np.sqrt((dt ** 2).sum(1).mean())), "rotation_mean_rad": float(ang.mean())}
 
 
+def _log(mapper):
+    every = int(os.environ.get("NVO_PROTO_LOG", "0"))
+    lo, hi = int(os.environ.get("NVO_PROTO_LOG_FROM", "0")), int(os.environ.get("NVO_PROTO_LOG_TO", "1000000000"))
+    if every and mapper.step % every == 0 and lo <= mapper.step <= hi:
+        eng = mapper.trainer.pipeline.model.engine
+        torch.cuda.synchronize()
+        if os.environ.get("NVO_PROTO_LOG_GRADS"):
+            bad = {n: int((~torch.isfinite(eng.grads[o:o + sz])).sum()) for n, (o, sz, _) in eng.segments.items()}
+            ws = eng._workspace(eng.cfg.num_rays, True)
+            extra = {k: int((~torch.isfinite(ws[k].float())).sum()) for k in ("drgb", "dout2", "dout0", "dout1", "out2", "rgb", "weights2", "x2")}
+            mx = {n: float(eng.params[o:o + sz].abs().max()) for n, (o, sz, _) in eng.segments.items()}
+            gmax = {n: float((eng.grads[o:o + sz] / eng.current_loss_scale()).abs().max()) for n, (o, sz, _) in eng.segments.items() if sz}
+            print(f"   max|grad| {gmax}", file=sys.stderr, flush=True)
+            pre = ws["out2"][:, 0].float()
+            d2 = ws["dout2"].float()
+            rows = (~torch.isfinite(d2)).any(dim=1).nonzero().flatten()[:4]
+            detail = [(int(r), [float(v) for v in d2[r][:3]], float(pre[r]), float(ws["weights2"][r]),
+                       [float(v) for v in ws["tbins2"].view(-1, 49)[r // 48, (r % 48):(r % 48) + 2]]) for r in rows.tolist()]
+            print(f"   nonfinite grads {bad} ws {extra} max pre {float(pre.max()):.2f} n(pre>14) {int((pre > 14).sum())} bad rows {detail}", file=sys.stderr, flush=True)
+        print(f"it {mapper.step} scale {eng.current_loss_scale()} tracker {int(eng.dev_growth_tracker.item())} flags "
+              f"{eng.skip_flag.tolist()} applied {eng.opt_steps} finite {bool(torch.isfinite(eng.params).all())} "
+              f"half_finite {bool(torch.isfinite(eng.working_copy_float()).all())} losses {eng.loss_dict()}", file=sys.stderr, flush=True)
+
+
 def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, eval_frames=8, chunk=8, device="cuda:0",
         camera_optimizer_mode=None, pose_noise=None, deterministic=False, seed=42, dynamic_loss_scale=None, out_dir=None,
         quiet=True, keyframe_views=True):
@@ -93,8 +117,10 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
         for _ in range(per_kf * (hi - lo) - 1):
             if mapper.step < iterations:
                 mapper(input=None)
+                _log(mapper)
     while mapper.step < iterations:
         mapper(input=None)
+        _log(mapper)
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
     mapper(input=None)
@@ -149,6 +175,9 @@ if __name__ == "__main__":
     ap.add_argument("--pose-noise", type=float, nargs=2, default=None, metavar=("SIGMA_ROT", "SIGMA_TRANS"))
     ap.add_argument("--deterministic", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--static-loss-scale", action="store_true", help="tcnn's static 128 instead of GradScaler's dynamics")
+    ap.add_argument("--no-keyframe-views", action="store_true")
     a = ap.parse_args()
     run(a.keyframes, a.height, a.width, a.iterations, eval_frames=a.eval_frames, camera_optimizer_mode=a.camera_optimizer_mode,
-        pose_noise=a.pose_noise, deterministic=a.deterministic, seed=a.seed, quiet=False)
+        pose_noise=a.pose_noise, deterministic=a.deterministic, seed=a.seed, quiet=False,
+        dynamic_loss_scale=False if a.static_loss_scale else None, keyframe_views=not a.no_keyframe_views)
