@@ -153,6 +153,8 @@ def main() -> None:
     ap.add_argument("--static-loss-scale", action="store_true",
                     help="A/B: tcnn's static loss scale 128 (rounds 1-3's headline regime: most fp16 proposal-loss gradients "
                          "underflow to exactly zero there and the grid backward skips them)")
+    ap.add_argument("--ngp-steps", type=int, default=200,
+                    help="timed steps of the occupancy-grid back-end (tools/ngp_bench.py) reported as the ngp section; 0 = skip")
     ap.add_argument("--render-frames", type=int, default=5,
                     help="timed full-image renders per resolution (1200x680 and the training resolution); 0 = skip")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
@@ -512,6 +514,16 @@ def main() -> None:
                 table.append(row)
             render["kernel_table_1200x680"] = table
 
+    # ---- the occupancy-grid ("instant-ngp") back-end of the same hot path (SURVEY.md section 8 row a13;
+    # /root/reference/nerf_vo/mapping/instant_ngp.py:104-105 -> Testbed.frame()): step time through the pyngp facade
+    ngp = None
+    if rank == 0 and world == 1 and args.ngp_steps > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ngp_bench
+
+        ngp = ngp_bench.run(argparse.Namespace(steps=args.ngp_steps, warmup=100, keyframes=48, extrinsics=1,
+                                               profile=not args.no_kernel_table), quiet=True)
+
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
@@ -622,6 +634,7 @@ def main() -> None:
             "cpu_baseline": cpu_baseline,
             "render_psnr": render_psnr,
             "render": render,
+            "ngp": ngp,
         }
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()

@@ -26,6 +26,13 @@ def main():
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
     a = ap.parse_args()
+    run(a)
+
+
+def run(a, quiet: bool = False):
+    """a: namespace with steps, warmup, keyframes, extrinsics, profile.  Returns the JSON object of the --profile form
+    (bench.py embeds it as its "ngp" section)."""
+    say = (lambda *x: None) if quiet else print
     dev = torch.device("cuda:0")
     H, W = 272, 480
     seq = make_sequence(a.keyframes, H, W, device=dev, scene_scale=0.2)
@@ -71,12 +78,12 @@ def main():
             rows.append((name, int(cnt), float(total)))
         rows.sort(key=lambda r: -r[2])
         tot = sum(r[2] for r in rows)
-        print(f"kernel time {tot / 32:.3f} ms/step over 32 steps")
+        say(f"kernel time {tot / 32:.3f} ms/step over 32 steps")
         for name, cnt, total in rows[:24]:
-            print(f"  {name:30s} launches {cnt:4d} avg {total / cnt * 1e3:9.1f} us  {100 * total / tot:5.1f} %")
+            say(f"  {name:30s} launches {cnt:4d} avg {total / cnt * 1e3:9.1f} us  {100 * total / tot:5.1f} %")
     n = eng.samples_last_step()
-    print(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
-          f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
+    say(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
+        f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
     if a.profile:
         # one JSON line in the shape of bench.py's (occupancy-grid back-end; SURVEY.md section 8d bytes: 588 B per
         # packed sample for the gather, 1100 B for the scatter)
@@ -108,13 +115,19 @@ def main():
                                 "unit": "GB/s", "frac": round(b / per[name] / 1e9 / 8000.0, 4), "traffic": traffic,
                                 "traffic_source": src,
                                 "avg_launch_us": round(per[name] * 1e6, 1), "algorithmic_bytes_per_launch": b}
-        print(json.dumps({"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
+        out = {"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
                           "unit": "samples/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "rays_per_batch": eng.rays_per_batch,
                           "dtype": "f16", "data": "synthetic",
                           "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H}, aabb_scale 4, "
                                                  f"capacity {cap} packed samples, extrinsics optimisation "
                                                  f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch"},
-                          "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof}))
+                          "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof,
+                          "kernel_ms_per_step": round(tot / 32, 4),
+                          "kernel_table": [{"kernel": nm, "launches_per_step": round(c / 32, 2), "avg_launch_us": round(t / c * 1e3, 1)}
+                                           for nm, c, t in rows[:12]]}
+        say(json.dumps(out))
+        return out
+    return {"ms_per_step": dt * 1e3, "value": n / dt}
 
 
 if __name__ == "__main__":
