@@ -145,7 +145,11 @@ def main() -> None:
     ap.add_argument("--no-pose-overlap", action="store_true",
                     help="pose optimisation: the main grid's parameter scatter behind the pose chain instead of beside it (A/B)")
     ap.add_argument("--no-pair-losses", action="store_true", help="one launch per proposal level's loss kernel (A/B)")
-    ap.add_argument("--commit-in-graph", action="store_true", help="the optimiser's commit as the graph's last node (A/B)")
+    ap.add_argument("--commit-in-graph", action="store_true",
+                    help="the optimiser's commit as the graph's last node, scalars written eagerly BEFORE each replay (A/B)")
+    ap.add_argument("--commit-behind-replay", action="store_true",
+                    help="commit + next step's scalars in ONE eager launch behind each replay (round 3's form; default now: "
+                         "last node of the graph, scalars from a device table) (A/B)")
     ap.add_argument("--separate-zero", action="store_true", help="the step's zero launch as its own graph node (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
                     help="(the default since round 4) GradScaler dynamics: init 65536, x2 / 2000 clean steps, x0.5 on overflow "
@@ -240,7 +244,9 @@ def main() -> None:
     if args.no_pair_losses:
         cfg.pair_proposal_losses = False
     if args.commit_in_graph:
-        cfg.commit_behind_replay = False
+        cfg.commit_behind_replay = cfg.commit_from_table = False
+    if args.commit_behind_replay:
+        cfg.commit_from_table = False
     if args.separate_zero:
         cfg.zero_with_ray_head = False
     if args.no_pose_overlap:

@@ -422,6 +422,8 @@ typedef struct nvo_color_args {
     void* det_scratch;           /* nvo_color_det_scratch_bytes(R, S) */
     uint64_t det_scratch_bytes;
     uint32_t n_cameras;          /* rows of d_embedding (deterministic mode only) */
+    uint32_t* nonfinite_flag;    /* backward; nullable: OR-ed with 1 when a weight-gradient total of the head is not finite
+                                    (an overflow inside its 16-bit chain; d_embedding / d_sh are non-finite only with it) */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
@@ -646,6 +648,14 @@ int nvo_opt_commit_write(nvo_stream_t stream, uint32_t n_groups, uint32_t active
                          const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
                          float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
                          float beta1, float beta2, float* dst, uint32_t n, const float* host_values);
+/* The same as a node INSIDE a captured step: the scalars come from a device table the host fills ahead -- row
+ * (s % table_rows) holds the 16 scalars of step s -- and *next_step (device uint32) names the row to load and is
+ * advanced by one.  Nothing of the launch depends on host values, so every replay of the graph commits and loads the
+ * right row (replaces the eager nvo_opt_commit_write behind each replay: no launch latency behind the graph). */
+int nvo_opt_commit_table(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                         const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                         float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                         float beta1, float beta2, float* dst, const float* table, uint32_t table_rows, uint32_t* next_step);
 
 /* ------------------------------------------------------------------------------------------------
  * G. Keyframe depth alignment (the producer right before the mapping path; replaces the torch-op chain of

@@ -59,7 +59,7 @@ class ColorArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int), ("det_scratch", _p),
-                ("det_scratch_bytes", _u64), ("n_cameras", _u32)]
+                ("det_scratch_bytes", _u64), ("n_cameras", _u32), ("nonfinite_flag", _p)]
 
 
 class RayHeadArgs(C.Structure):
@@ -185,6 +185,7 @@ _SIGNATURES = {
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),
     "nvo_opt_commit_write": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f, _p, _u32, _p]),
+    "nvo_opt_commit_table": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f, _p, _p, _u32, _p]),
     "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f]),
     "nvo_cast_bf16": (_int, [_p, _u64, _p, _p]),
     "nvo_cast_shards": (_int, [_p, _u64, _u32, _u32, _p, _p, _int, _p]),

@@ -872,6 +872,42 @@ int nvo_opt_commit_write(nvo_stream_t stream, uint32_t n_groups, uint32_t active
     return NVO_OK;
 }
 
+// The same commit as a node INSIDE the captured step: the per-step scalars of the next step come from a device table the
+// host fills ahead (row s % table_rows = the 16 scalars of step s) and a device step counter the kernel advances -- no
+// eager launch behind the replay (measured: 8 us of launch latency between the graph's last kernel and the eager one,
+// plus its 5 us, on every step).
+__global__ void k_opt_commit_table(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+                                   const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
+                                   uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
+                                   float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2,
+                                   float* dst, const float* __restrict__ table, uint32_t table_rows,
+                                   uint32_t* __restrict__ next_step) {
+    const uint32_t s = *next_step;
+    if (threadIdx.x < 16) dst[threadIdx.x] = table[(size_t)(s % table_rows) * 16u + threadIdx.x];
+    if (threadIdx.x == 63)
+        opt_commit_thread(n_groups, active_mask, scale_mask, applied, skip_flags, scale, growth_tracker, growth, backoff, interval,
+                          min_scale, max_scale, bias, beta1, beta2);
+    __syncthreads();
+    if (threadIdx.x == 0) *next_step = s + 1u;
+}
+
+int nvo_opt_commit_table(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
+                         const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
+                         float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,
+                         float beta1, float beta2, float* dst, const float* table, uint32_t table_rows, uint32_t* next_step) {
+    NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "opt_commit_table: 1..%u groups (got %u)", kAdamMaxGroups, n_groups);
+    NVO_REQUIRE(applied || scale, "opt_commit_table: nothing to update");
+    NVO_REQUIRE(!scale || (growth_tracker && growth_interval >= 1 && growth_factor >= 1.f && backoff_factor > 0.f &&
+                           backoff_factor <= 1.f && min_scale > 0.f && max_scale >= min_scale),
+                "opt_commit_table: bad loss-scale schedule");
+    NVO_REQUIRE(dst && table && next_step && table_rows >= 1, "opt_commit_table: scalar table missing");
+    NVO_LAUNCH(k_opt_commit_table, dim3(1), dim3(64), 0, (hipStream_t)stream, n_groups, active_mask, scale_mask, applied, skip_flags,
+               scale, growth_tracker, growth_factor, backoff_factor, growth_interval, min_scale, max_scale, bias, beta1, beta2,
+               dst, table, table_rows, next_step);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16) {
     NVO_REQUIRE(src && dst_bf16, "cast_bf16: NULL argument");
     if (n == 0) return NVO_OK;

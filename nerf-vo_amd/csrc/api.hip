@@ -559,6 +559,8 @@ struct MlpModule : nvo_module_s {
     // option "deterministic": the weight gradient is summed over the workgroups in a fixed order (block totals stored
     // to this scratch + a reduce launch) instead of float atomics
     bool deterministic = false;
+    // option "nonfinite_flag_ptr": device uint32 the backward ORs with 1 when a weight-gradient total is not finite
+    uint32_t* nf_flag = nullptr;
     NvoScratch dw_scratch;
     ~MlpModule() override { nvo_scratch_destroy(&dw_scratch); }
     int det_partials(hipStream_t s, uint32_t B, NvoMlpArgs* a) {
@@ -573,6 +575,7 @@ struct MlpModule : nvo_module_s {
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
         if (!strcmp(key, "external_zero")) { external_zero = value != 0; return NVO_OK; }
         if (!strcmp(key, "deterministic")) { deterministic = value != 0; return NVO_OK; }
+        if (!strcmp(key, "nonfinite_flag_ptr")) { nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value); return NVO_OK; }
         return nvo_module_s::set_option(key, value);
     }
 
@@ -631,6 +634,7 @@ struct MlpModule : nvo_module_s {
         a.act = act;
         a.out_act = out_act;
         a.bf16 = bf16;
+        a.nf_flag = nf_flag;
         return a;
     }
     int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
@@ -805,7 +809,10 @@ struct NwieModule : nvo_module_s {
             net->deterministic = value != 0;
             return enc->set_option(key, value);
         }
-        if (!strcmp(key, "nonfinite_flag_ptr")) return enc->set_option(key, value);
+        if (!strcmp(key, "nonfinite_flag_ptr")) {  // leaves (encoding's parameter scatter) and the network's dW flush
+            net->nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value);
+            return enc->set_option(key, value);
+        }
         if (!strcmp(key, "external_zero")) {
             if (int rc = enc->set_external_zero(value != 0)) return rc;
             net->external_zero = value != 0;

@@ -70,6 +70,7 @@ static NvoMlpArgs color_args(const nvo_color_args& c) {
     a.embedding = (const _Float16*)c.embedding;
     a.cam_idx = c.cam_idx;
     a.bf16 = c.act_bf16 != 0;
+    a.nf_flag = c.nonfinite_flag;
     return a;
 }
 

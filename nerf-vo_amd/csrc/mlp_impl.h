@@ -50,6 +50,26 @@ __device__ __forceinline__ f4 mfma16(T4 a, T4 b, f4 c) {
 #endif
 }
 
+// gfx950's K = 32 form, operands given as two K = 16 fragments each: element j < 4 of lane group g pairs feature
+// 16 (2t) + 4g + j of both operands, j >= 4 feature 16 (2t + 1) + 4g + (j - 4) -- the same 32 products as two chained
+// 16x16x16 instructions in HALF the matrix-core time (the K = 16 form runs at the MI300 rate on this chip); the order of
+// the fp32 additions inside differs, which forward and recomputing backward share.
+#ifdef NVO_MLP_K16  // (A/B builds: NVO_EXTRA_CXXFLAGS=-DNVO_MLP_K16)
+constexpr bool kUseK32 = false;
+#else
+constexpr bool kUseK32 = true;
+#endif
+__device__ __forceinline__ f4 mfma32(T4 a_lo, T4 a_hi, T4 b_lo, T4 b_hi, f4 c) {
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    const T8 a = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const T8 b = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#if NVO_MLP_BF16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ float act_fwd(int act, float v) {
     if (act == NVO_ACT_RELU) return fmaxf(v, 0.f);
     if (act == NVO_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
@@ -163,8 +183,13 @@ __device__ __forceinline__ void layer_mm(const WFrag<N_OUT, K_IN>& w, const T4 (
 #pragma unroll
     for (int tn = 0; tn < N_OUT / 16; ++tn) {
         f4 c = {0.f, 0.f, 0.f, 0.f};
+        if constexpr ((K_IN / 16) % 2 == 0 && kUseK32) {
 #pragma unroll
-        for (int tk = 0; tk < K_IN / 16; ++tk) c = mfma16(w.f[tn][tk], in[tk], c);
+            for (int tk = 0; tk < K_IN / 16; tk += 2) c = mfma32(w.f[tn][tk], w.f[tn][tk + 1], in[tk], in[tk + 1], c);
+        } else {
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) c = mfma16(w.f[tn][tk], in[tk], c);
+        }
         acc[tn] = c;
     }
 }
@@ -176,8 +201,13 @@ __device__ __forceinline__ void layer_mm_t(const WTFrag<N_OUT, K_IN>& wt,
 #pragma unroll
     for (int tk = 0; tk < K_IN / 16; ++tk) {
         f4 c = {0.f, 0.f, 0.f, 0.f};
+        if constexpr ((N_OUT / 16) % 2 == 0 && kUseK32) {
 #pragma unroll
-        for (int tn = 0; tn < N_OUT / 16; ++tn) c = mfma16(wt.f[tk][tn], dz[tn], c);
+            for (int tn = 0; tn < N_OUT / 16; tn += 2) c = mfma32(wt.f[tk][tn], wt.f[tk][tn + 1], dz[tn], dz[tn + 1], c);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < N_OUT / 16; ++tn) c = mfma16(wt.f[tk][tn], dz[tn], c);
+        }
         acc[tk] = c;
     }
 }
@@ -514,7 +544,7 @@ struct DwAcc {
     // instruction -- the fast float-atomic shape -- and 4x fewer adds per address).
     // MUST be called by every wave of the block (contains __syncthreads()).
     __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib,
-                                                float* __restrict__ partial = nullptr) const {
+                                                float* __restrict__ partial = nullptr, uint32_t* nf_flag = nullptr) const {
         const int c = lane & 15, g = lane >> 4;
         for (int w = 0; w < kWavesPerBlock; ++w) {
             if (wib == w) {
@@ -532,11 +562,19 @@ struct DwAcc {
         }
         // (every block adds to the same addresses in the same order; starting each block at its own offset was measured
         // SLOWER -- 57.5 vs 56.1 us for the colour head -- the L2 handles the convoy better than a spread)
+        uint32_t chk = 0u;  // exponent bits all ones: inf or NaN
         if (partial) {  // deterministic mode: the block total is STORED; a second launch sums the blocks in order
-            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) partial[e] = red[e];
+            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) {
+                partial[e] = red[e];
+                chk |= (uint32_t)((__float_as_uint(red[e]) & 0x7f800000u) == 0x7f800000u);
+            }
         } else {
-            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) atomicAdd(dW + e, red[e]);
+            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) {
+                atomicAdd(dW + e, red[e]);
+                chk |= (uint32_t)((__float_as_uint(red[e]) & 0x7f800000u) == 0x7f800000u);
+            }
         }
+        if (nf_flag && __ballot(chk != 0u) != 0ull && lane == 0) atomicOr(nf_flag, 1u);
         __syncthreads();
     }
 };
@@ -979,16 +1017,16 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         float* dW = a.dweights;
         constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
         float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
-        dw0.flush_block(dW, red, lane, wib, part);
+        dw0.flush_block(dW, red, lane, wib, part, a.nf_flag);
         dW += WIDTH * IN_PAD;
         if (part) part += WIDTH * IN_PAD;
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            dwh[l].flush_block(dW, red, lane, wib, part);
+            dwh[l].flush_block(dW, red, lane, wib, part, a.nf_flag);
             dW += WIDTH * WIDTH;
             if (part) part += WIDTH * WIDTH;
         }
-        dwl.flush_block(dW, red, lane, wib, part);
+        dwl.flush_block(dW, red, lane, wib, part, a.nf_flag);
     }
     if constexpr (IO == NVO_IO_HALF2_SOA) {
         if (a.dx_l1_partial && need_dinput) {  // (kernel-uniform)

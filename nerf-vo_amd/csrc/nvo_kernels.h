@@ -223,6 +223,10 @@ struct NvoMlpArgsT {
     // of k_live_samples: ~14 us per 1 M-sample launch), and k_live_samples leaves at once while most samples are live.
     float* dx_l1_partial;
     uint32_t* dx_live_partial;
+    // (backward; nullable) OR-ed with 1 when a workgroup's dW total is not finite: an overflow of the 16-bit chain INSIDE
+    // the network (a hidden dZ = inf with finite roots and leaves) always lands in the weight gradient of the layer it
+    // appears in (dW = dZ^T H: inf * h = inf or NaN for every h) -- and in dL/d(embedding), dL/d(SH) only together with it
+    uint32_t* nf_flag;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

@@ -151,6 +151,10 @@ class EngineConfig:
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
     # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
     commit_behind_replay: bool = True
+    # ... or (takes precedence) IS the last node of the graph and takes the next step's scalars from a device table the
+    # host fills 1024 steps ahead (nvo_opt_commit_table): nothing eager behind the replay -- the trace showed 8 us of
+    # launch latency between the graph's last kernel and the eager launch, plus its 5 us, on every step
+    commit_from_table: bool = True
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
     # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
     # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
@@ -668,6 +672,7 @@ class NerfactoEngine:
             d_weights=self._param_ptr("field.color", self.grads).value if training else None,
             act_bf16=int(self.bf16),
             det_scratch=ws["color_det"].data_ptr() if (training and "color_det" in ws) else None,
+            nonfinite_flag=self._flag_ptr("fields") if training else None,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
             n_cameras=self.cfg.num_images)
 
@@ -1044,29 +1049,19 @@ class NerfactoEngine:
             return lo, hi
 
         if check and self._producer_flags:
-            # The producers raised the flags of the fields / proposal groups at the roots (loss kernels) and the leaves
-            # (grid backward) of the 16-bit gradient chain.  A 16-bit value can also overflow INSIDE the chain (a hidden
-            # dZ, d_base_out) while the roots are finite -- GradScaler keeps doubling the scale until something does --
-            # and a ReLU backward may drop it before it reaches a leaf; but the layer it appears in multiplies it into
-            # that layer's weight gradient (dW = dZ x H; inf * 0 = NaN), so the small NON-GRID ranges of each group are
-            # scanned: fused-MLP weights, appearance embedding, poses (~30 K scalars, one launch).  (Found by the
-            # fixed-pose 8192-step run of round 4, which nothing scanned: NaN weights after the scale reached 2^19.)
+            # The producers raised the flags of the fields / proposal groups at the roots (loss kernels), at the leaves
+            # (grid backward) AND inside the 16-bit gradient chain: a hidden dZ or d_base_out can overflow while the roots
+            # are finite -- GradScaler keeps doubling the scale until something does -- and a ReLU backward may drop it
+            # before it reaches a leaf, but the layer it appears in multiplies it into that layer's weight gradient
+            # (dW = dZ^T H; inf * 0 = NaN), so every fused-MLP backward checks the dW totals it flushes
+            # (NvoMlpArgsT::nf_flag; the appearance-embedding gradient is non-finite only together with the colour head's
+            # dW0).  (Found by the fixed-pose 8192-step run of round 4, which nothing checked: NaN weights after the
+            # scale reached 2^19; first fixed with a scan launch over the non-grid ranges, 4.6 us on every step.)  Only
+            # the pose gradients, which no fused MLP produces, are still scanned.
             spans = []
-            if not hasattr(self, "_mlp_sizes"):  # (weights in front of the grid inside each NetworkWithInputEncoding)
-                self._mlp_sizes = {"base": self.base_net.n_params - self._grid_params(self.base_net),
-                                   **{k: m.n_params - self._grid_params(m) for k, m in enumerate(self.prop_nets)}}
-            n_base_mlp = self._mlp_sizes["base"]
             for g in active:
                 gi = order.index(g)
-                if g == "fields":
-                    o = self.segments["field.base"][0]
-                    spans.append((o, n_base_mlp, gi))
-                    o = self.segments["field.color"][0]
-                    spans.append((o, sum(self.segments["field.embedding"][:2]) - o, gi))
-                elif g == "proposal_networks":
-                    for k, m in enumerate(self.prop_nets):
-                        spans.append((self.segments[f"proposal.{k}"][0], self._mlp_sizes[k], gi))
-                else:
+                if g not in ("fields", "proposal_networks"):
                     lo, hi = self.group_ranges[g]
                     spans.append((lo, hi - lo, gi))
             if shard is not None:
@@ -1117,6 +1112,52 @@ class NerfactoEngine:
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
               cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
+
+    _TABLE_ROWS = 1024
+
+    def _scalar_table(self):
+        """Device ring of the per-step scalars (row s % 1024 = _scalar_row(s)) + the step counter nvo_opt_commit_table
+        advances; see EngineConfig.commit_from_table."""
+        if getattr(self, "dev_scalar_table", None) is None:
+            self.dev_scalar_table = torch.zeros(self._TABLE_ROWS, 16, dtype=torch.float32, device=self.device)
+            self.dev_next_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._table_valid = (0, 0, None)  # [lo, hi) steps whose rows are in the ring, stamp of what they depend on
+            self._next_step_host = None
+        return self.dev_scalar_table
+
+    def _scalar_row(self, s: int):
+        """What _commit_and_write puts into dev_scalars for step s (with self.step == s)."""
+        vals = [0.0] * 16
+        vals[0] = self.anneal_at(s)
+        cfg = self.cfg
+        for gi, g in enumerate(self._GROUP_ORDER):
+            vals[1 + 3 * gi] = {"fields": cfg.lr_fields, "proposal_networks": cfg.lr_proposal}.get(g) if g != "camera_opt" \
+                else self.camera_lr(s)
+        vals[14], vals[15] = vals[0], float(s)
+        return vals
+
+    def _fill_scalar_table(self, s: int) -> None:
+        """Makes sure row ``s`` of the ring holds step s's scalars (refilled 1024 steps at a time, in stream order; also
+        when a learning rate or a schedule constant was changed from outside)."""
+        cfg = self.cfg
+        stamp = (cfg.lr_fields, cfg.lr_proposal, cfg.lr_camera, cfg.lr_camera_final, cfg.max_num_iterations,
+                 cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
+        lo, hi, have = self._table_valid
+        if have == stamp and lo <= s < hi:
+            return
+        rows = [None] * self._TABLE_ROWS
+        for t in range(s, s + self._TABLE_ROWS):
+            rows[t % self._TABLE_ROWS] = self._scalar_row(t)
+        self.dev_scalar_table.copy_(torch.tensor(rows, dtype=torch.float32))
+        self._table_valid = (s, s + self._TABLE_ROWS, stamp)
+
+    def _launch_commit_table(self, mask: int, scale_mask: int) -> None:
+        cfg = self.cfg
+        _call("nvo_opt_commit_table", _stream(self.device), len(self._GROUP_ORDER), mask, scale_mask, _ptr(self.dev_applied),
+              _ptr(self.skip_flag), _ptr(self.dev_loss_scale) if scale_mask else None,
+              _ptr(self.dev_growth_tracker) if scale_mask else None, cfg.loss_scale_growth, cfg.loss_scale_backoff,
+              int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max, _ptr(self.dev_bias), cfg.adam_betas[0],
+              cfg.adam_betas[1], _ptr(self.dev_scalars), _ptr(self.dev_scalar_table), self._TABLE_ROWS, _ptr(self.dev_next_step))
 
     def _commit_and_write(self, masks, sampling_step: int) -> None:
         """GradScaler.update + step counters of the step that just replayed AND the scalars of step ``sampling_step`` (=
@@ -1223,9 +1264,17 @@ class NerfactoEngine:
             entry = self._graphs[key]
         if all_reduce is None and not entry.get("pipelined"):
             self._pending_head = None
+            table = bool(entry.get("table_commit"))
+            if table:
+                self._fill_scalar_table(step + 1)  # (the commit node at the end of this replay loads row step + 1)
             if self._scalars_step != step:  # (not written ahead: first step, externally set step, eager work in between)
                 self._write_step_scalars(self.anneal_at(step), groups, sampling_step=step)
+            if table and self._next_step_host != step + 1:
+                self.dev_next_step.fill_(step + 1)
             entry["main"].replay()
+            if table:
+                self._next_step_host = step + 2
+                self._scalars_step = step + 1
         elif all_reduce is None:
             # single GPU, pipelined: this graph ends with [Adam of the fields group || sampling prefix of step + 1]
             stamp = (step, getattr(dataset, "version", 0), extent)
@@ -1484,6 +1533,24 @@ class NerfactoEngine:
                     body_rest()
                     body_opt(groups_b)
             zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
+            if cfg.commit_from_table:
+                def whole_and_commit():
+                    self._defer_commit = []
+                    try:
+                        whole()
+                        mask = scale_mask = 0
+                        for m_, s_ in self._defer_commit:  # (disjoint group bits)
+                            mask |= m_
+                            scale_mask |= s_
+                        assert self._defer_commit, "the one-graph step runs at least one optimiser launch"
+                    finally:
+                        self._defer_commit = None
+                    self._launch_commit_table(mask, scale_mask)
+
+                self._scalar_table()  # (allocated outside the capture)
+                entry["main"] = capture(whole_and_commit)
+                entry["table_commit"] = True
+                return entry
             if not cfg.commit_behind_replay:
                 entry["main"] = capture(whole)
                 return entry

@@ -725,7 +725,9 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
 @pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
 def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
     """EngineConfig.commit_behind_replay: the optimiser's commit (applied-step counters, bias corrections, loss scale)
-    leaves the graph and rides in the eager launch behind the replay that also writes the NEXT step's scalars.  Same
+    leaves the graph and rides in the eager launch behind the replay that also writes the NEXT step's scalars;
+    EngineConfig.commit_from_table (default): it is the graph's last node and loads those scalars from a device ring the
+    host fills ahead.  Same
     seed, deterministic mode: parameters, moments, counters, bias corrections and loss scale must equal those of the
     commit-in-graph form bit for bit -- across the proposal-update schedule, an externally reset step index and an
     eager step in between (both of which invalidate the scalars written ahead)."""
@@ -740,11 +742,14 @@ def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
 
-    def run(behind: bool):
+    def run(placement: str):
         torch.manual_seed(21)
         eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=True, deterministic=True,
                                           dynamic_loss_scale=dynamic, loss_scale_interval=7,
-                                          commit_behind_replay=behind), device)
+                                          commit_from_table=placement == "table",
+                                          commit_behind_replay=placement == "behind"), device)
+        if placement == "table":
+            eng._TABLE_ROWS = 8  # (the ring of per-step scalars wraps and is refilled several times in 30 steps)
         gen = torch.Generator(device=device).manual_seed(4)
         for it in range(30):
             if it == 12:
@@ -758,14 +763,18 @@ def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
         if not dynamic:  # (the dynamic scale doubles every 7 steps here and may well run into an overflow: also covered)
             assert int(eng.skip_flag.sum()) == 0
         has_commit = any(e.get("commit") is not None for e in eng._graphs.values())
+        has_table = any(e.get("table_commit") for e in eng._graphs.values())
         return (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.opt_state.clone(), dict(eng.opt_steps),
-                has_commit)
+                has_commit, has_table, eng.dev_scalars.clone())
 
-    a, b = run(True), run(False)
-    assert a[5] and not b[5]
-    assert a[4] == b[4], (a[4], b[4])
-    for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "optimiser state"), a[:4], b[:4]):
-        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name} differ between the two commit placements"
+    a, b, c = run("behind"), run("graph"), run("table")
+    assert a[5] and not b[5] and not c[5] and c[6] and not a[6] and not b[6]
+    assert a[4] == b[4] == c[4], (a[4], b[4], c[4])
+    for other, what in ((b, "in the graph"), (c, "in the graph with the scalar table")):
+        for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "optimiser state"), a[:4], other[:4]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name}: commit behind the replay vs {what}"
+    # both ahead-of-time forms leave the NEXT step's scalars (learning rates, anneal, sampler counter) on the device
+    assert torch.equal(a[7], c[7]), (a[7], c[7])
     if dynamic:
         assert float(a[3][4:5].view(torch.float32)) > 65536.0  # the scale really grew (interval 7)
 
@@ -1143,7 +1152,7 @@ def test_producer_flags_catch_overflow_inside_the_chain(device):
     """GradScaler doubles the loss scale until something overflows, and what overflows first need not be a root
     (dL/drgb, dL/d density) or a leaf (dL/d encoded) of the 16-bit gradient chain: a hidden dZ or d_base_out can reach
     inf while the roots are finite.  Sweep the scale from tcnn's 128 to 2^40: for EVERY scale the per-group verdict of
-    the producer-flag step (flags at roots / leaves + the scan of the non-grid ranges) must equal the verdict of the
+    the producer-flag step (flags at roots / leaves + the dW totals of every fused-MLP backward) must equal the verdict of the
     full scan of the gradient buffer -- including the scales in between, where only the inside of the chain overflows
     (the regime that turned a fixed-pose 8192-step run into NaN weights before the non-grid scan existed)."""
     R = 256
@@ -1170,31 +1179,6 @@ def test_producer_flags_catch_overflow_inside_the_chain(device):
         assert row[True] == row[False], f"scale 2^{k}: producer flags {row[True]} vs full scan {row[False]}"
     print(verdicts)
     assert not verdicts[7.0][True][0] and verdicts[40.0][True][0], "the sweep must span in-range and overflowing scales"
-    # With these random-init weights the roots overflow first at every scale (fields from 2^29, proposals from 2^35), so
-    # the inside-only case is planted: finite roots and leaves (scale 128, no producer flag raised), and ONE non-finite
-    # value in the weight-gradient range of each fused MLP / the embedding in turn -- where dW = dZ x H of the
-    # overflowing layer would put it.  Only the span scan can see it; the step must be skipped for that group alone.
-    eng = engines[True]
-    n_base_mlp = eng.base_net.n_params - eng._grid_params(eng.base_net)
-    plants = [("field.base", n_base_mlp // 2, 0), ("field.color", 17, 0), ("field.embedding", 3, 0)] + [
-        (f"proposal.{k}", 5, 1) for k in range(len(eng.prop_nets))]
-    for seg, at, group in plants:
-        for bad in (float("inf"), float("nan")):
-            eng.cfg.loss_scale = 128.0
-            eng.dev_loss_scale.fill_(128.0)
-            eng.set_params(p0)
-            eng.reset_optimizer()
-            ws = eng._workspace(R, True)
-            eng.load_ray_bundle(ws, origins.to(device), directions.to(device), dnorm.to(device), cam.to(device),
-                                gt_rgb.to(device), gt_depth.to(device))
-            eng.forward_backward(ws, tuple(j.to(device) for j in jit), has_depth=True, update_proposals=True, anneal=0.6)
-            eng.grads[eng.segments[seg][0] + at] = bad
-            eng.optimizer_step(["fields", "proposal_networks"], flags_cleared=True)
-            torch.cuda.synchronize()
-            flags = [bool(f) for f in eng.skip_flag.tolist()[:2]]
-            assert flags == [group == 0, group == 1], f"{bad} planted in {seg}: flags {flags}"
-            lo, hi = eng.group_ranges["fields" if group == 0 else "proposal_networks"]
-            assert torch.equal(eng.params[lo:hi], p0[lo:hi].to(device)), f"{seg}: the flagged group was stepped"
-            assert bool(torch.isfinite(eng.params).all())
-            olo, ohi = eng.group_ranges["proposal_networks" if group == 0 else "fields"]
-            assert not torch.equal(eng.params[olo:ohi], p0[olo:ohi].to(device)), f"{seg}: the clean group was not stepped"
+    # (With these random-init weights the roots overflow first at every scale -- fields from 2^29, proposals from 2^35.
+    # The inside-only case -- finite roots, a hidden dZ that is not -- is planted at the kernel level:
+    # tests/test_tcnn_gpu.py::test_network_backward_flags_an_overflow_inside_the_chain.)

@@ -470,6 +470,38 @@ def test_network_fwd_bwd(device, shape, dtype):
     _assert_close(net.params.grad, pr.grad, rtol=2e-2 * k, atol_scale=1e-2 * k, what="MLP dL/dparams")
 
 
+@pytest.mark.parametrize("deterministic", [False, True], ids=["atomics", "deterministic"])
+def test_network_backward_flags_an_overflow_inside_the_chain(device, deterministic):
+    """Option "nonfinite_flag_ptr" on a fused MLP: the backward ORs the word with 1 when a weight-gradient total it
+    flushes is not finite.  dL/doutput = 400 * 128 = 51200 is FINITE in fp16 (a clean root), but with weights of 0.5 the
+    hidden dZ = sum over 16 outputs of 0.5 * 51200 = 409600 is not: the overflow exists only inside the 16-bit chain
+    and must raise the flag through dW = dZ^T H (what replaced the optimiser's scan of the non-grid gradient ranges)."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1}
+    net = tcnn.Network(32, 16, cfg).to(device)
+    flags = torch.zeros(4, dtype=torch.int32, device=device)
+    net.native_tcnn_module.set_option("nonfinite_flag_ptr", flags.data_ptr() + 4)
+    net.native_tcnn_module.set_option("deterministic", int(deterministic))
+    with torch.no_grad():
+        net.params.fill_(0.5)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2048, 32, generator=g).to(device).requires_grad_(True)
+    for dy, expect in ((1e-3, 0), (400.0, 1), (1e-3, 1)):  # (the word is OR-ed, never cleared by the kernel)
+        net.params.grad = None
+        x.grad = None
+        (net(x).float() * dy).sum().backward()
+        torch.cuda.synchronize()
+        assert flags.tolist() == [0, expect, 0, 0], (dy, flags.tolist())
+        assert bool(torch.isfinite(net.params.grad).all()) == (dy < 1.0)
+    flags.zero_()
+    net.native_tcnn_module.set_option("nonfinite_flag_ptr", 0)  # detached again: nothing is written
+    net.params.grad = None
+    (net(x).float() * 400.0).sum().backward()
+    torch.cuda.synchronize()
+    assert flags.tolist() == [0, 0, 0, 0]
+
+
 def test_network_identity_layout(device):
     """A = I style check with an ASYMMETRIC weight: catches row/col swaps in the MFMA fragment maps."""
     import nerf_vo_amd.tinycudann as tcnn
