@@ -104,6 +104,17 @@ struct WFrag {
             for (int tk = 0; tk < K_IN / 16; ++tk)
                 f[tn][tk] = *reinterpret_cast<const T4*>(W + (size_t)(16 * tn + r) * K_IN + 16 * tk + 4 * g);
     }
+    // the same fragments from the workgroup's row-major LDS copy of W (row stride K_IN + 4 halfs, see RowStage): the
+    // direct form touches 16 rows x 32 bytes per load instruction -- 16 cache lines for 512 bytes -- and every wave of
+    // the grid pays it for the whole weight set
+    __device__ __forceinline__ void load_staged(const T* stage, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int tn = 0; tn < N_OUT / 16; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk)
+                f[tn][tk] = *reinterpret_cast<const T4*>(stage + (16 * tn + r) * (K_IN + 4) + 16 * tk + 4 * g);
+    }
 };
 
 // A-operand fragments of W^T: f[tk][tn] = W[16tn + 4g + j][16tk + (l&15)]   (strided gather, once)
@@ -387,15 +398,29 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
     WFrag<WIDTH, WIDTH> wh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
     WFrag<OUT_PAD, WIDTH> wl;
     {
+        // The workgroup copies every matrix row-major into LDS with coalesced 8-byte loads (all requested before the
+        // first store waits), each wave takes its fragments from there.  Loading the fragments straight from global
+        // memory made the prologue the cost of a wave (colour head, 18 KB of weights: 21 us at 256 workgroups, 47 us at
+        // 2048), which capped the grid at two waves per SIMD -- too few to hide the latency of the tile inputs.
+        constexpr int kH0 = RowStage<WIDTH, IN_PAD>::kHalfs, kHh = RowStage<WIDTH, WIDTH>::kHalfs;
+        __shared__ __attribute__((aligned(16))) T stage[kH0 + (N_HIDDEN - 1) * kHh + RowStage<OUT_PAD, WIDTH>::kHalfs];
         const T* W = a.weights;
-        w0.load(W, lane);
-        W += WIDTH * IN_PAD;
+        RowStage<WIDTH, IN_PAD> s0;
+        RowStage<WIDTH, WIDTH> sh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+        RowStage<OUT_PAD, WIDTH> sl;
+        s0.issue(W);
 #pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            wh[l].load(W, lane);
-            W += WIDTH * WIDTH;
-        }
-        wl.load(W, lane);
+        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].issue(W + WIDTH * IN_PAD + l * WIDTH * WIDTH);
+        sl.issue(W + WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH);
+        s0.store(stage);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].store(stage + kH0 + l * kHh);
+        sl.store(stage + kH0 + (N_HIDDEN - 1) * kHh);
+        __syncthreads();
+        w0.load_staged(stage, lane);
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l) wh[l].load_staged(stage + kH0 + l * kHh, lane);
+        wl.load_staged(stage + kH0 + (N_HIDDEN - 1) * kHh, lane);
     }
 
     // the next tile's input row is requested before the current tile is computed (see NVO_MLP_NAME(k_mlp_bwd))
@@ -410,6 +435,7 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
     auto load_x = [&](uint32_t tile, T4 (&xo)[IN_PAD / 16], uint32_t cam) {
         load_input<IN_PAD, IO>(a, tile * 16 + m, g, xo, cam);
     };
+    // (requesting TWO tiles ahead measured slower: colour head 17.5 vs 16.6 us, 16-wide 8.7 vs 8.3)
     uint32_t cam_nxt = 0;
     T4 x[IN_PAD / 16];
     if constexpr (IO == NVO_IO_GRID_FUSED) {
@@ -643,22 +669,20 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         RowStage<WIDTH, IN_PAD> s0;
         RowStage<WIDTH, WIDTH> sh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
         RowStage<OUT_PAD, WIDTH> sl;
-        if (need_dinput) s0.issue(W);
+        // (the recomputation's forward fragments come from the same row-major copies: W0 is staged for them alone when
+        // no dL/dinput is wanted)
+        const bool stage_w0 = need_dinput || RECOMP;
+        if (stage_w0) s0.issue(W);
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].issue(W + WIDTH * IN_PAD + l * WIDTH * WIDTH);
         sl.issue(W + WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH);
         if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
             if (a.cam_idx && wave < n_tiles) cam_first = (uint32_t)a.cam_idx[(wave * 16 + m) / a.samples_per_ray];
         }
-        if constexpr (RECOMP) {
-            w0f.load(W, lane);
-#pragma unroll
-            for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load(W + WIDTH * IN_PAD + l * WIDTH * WIDTH, lane);
-        }
         T* stage = lds;  // the wave tiles are idle until the first sample tile
         T* stage_h = stage + RowStage<WIDTH, IN_PAD>::kHalfs;
         T* stage_l = stage_h + (N_HIDDEN - 1) * RowStage<WIDTH, WIDTH>::kHalfs;
-        if (need_dinput) s0.store(stage);
+        if (stage_w0) s0.store(stage);
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].store(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs);
         sl.store(stage_l);
@@ -667,6 +691,11 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
         for (int l = 0; l < N_HIDDEN - 1; ++l) wth[l].read_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
         wtl.read_staged(stage_l, lane);
+        if constexpr (RECOMP) {
+            w0f.load_staged(stage, lane);
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
+        }
         __syncthreads();  // the staging bytes become the wave tiles
     }
     DwAcc<WIDTH, IN_PAD> dw0;
@@ -1230,11 +1259,12 @@ static uint32_t env_blocks(const char* name, uint32_t dflt) {
     return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt;
 }
 
-// Every wave loads the whole weight set into registers before its first tile, so the cap trades that
-// per-wave setup (and, backward, the per-workgroup dW flush) against parallelism.  Measured on MI355X
-// (bench.py per-kernel table, N = 196 608 / 1 M rows): colour head 64-64x2-16 forward 35.7 us at 512
-// workgroups vs 55 us at 2048; base 32-64x1-16 forward 17.8 us at 1024 vs 20.6 us at 2048; the 16-wide
-// proposal MLP wants many forward workgroups (2048+).
+// Every workgroup stages the whole weight set through LDS and every wave takes its fragments into registers before
+// its first tile, so the cap trades that setup (and, backward, the per-workgroup dW flush) against parallelism.
+// Measured on MI355X (bench.py per-kernel table, N = 196 608 / 1 M rows, round 4, weights staged through LDS):
+// colour head 64-64x2-16 forward 18.2 / 16.6 / 18.6 / 22.3 us at 256 / 512 / 1024 / 2048 workgroups (fragments straight
+// from global memory: 21.4 / 22.4 / 30.2 / 46.7); base 32-64x1-16 14.6 / 10.5 / 9.7 / 9.9; the 16-wide proposal MLP
+// 18.9 / 12.5 / 9.6 / 8.3.
 static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
     const int weight_halfs = width * in_pad + (n_hidden - 1) * width * width;
     if (weight_halfs >= 8192) return 512;
