@@ -147,6 +147,8 @@ def main() -> None:
     ap.add_argument("--no-pair-losses", action="store_true", help="one launch per proposal level's loss kernel (A/B)")
     ap.add_argument("--commit-in-graph", action="store_true",
                     help="the optimiser's commit as the graph's last node, scalars written eagerly BEFORE each replay (A/B)")
+    ap.add_argument("--no-fuse-grid-adam", action="store_true",
+                    help="Adam of the main grid's hashed levels in the optimiser launch instead of inside the grid backward (A/B)")
     ap.add_argument("--commit-behind-replay", action="store_true",
                     help="commit + next step's scalars in ONE eager launch behind each replay (round 3's form; default now: "
                          "last node of the graph, scalars from a device table) (A/B)")
@@ -247,6 +249,8 @@ def main() -> None:
         cfg.commit_behind_replay = cfg.commit_from_table = False
     if args.commit_behind_replay:
         cfg.commit_from_table = False
+    if args.no_fuse_grid_adam:
+        cfg.fuse_grid_adam = False
     if args.separate_zero:
         cfg.zero_with_ray_head = False
     if args.no_pose_overlap:

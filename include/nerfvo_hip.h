@@ -146,6 +146,31 @@ int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
  * `params_stream`.  Lets the consumers of dL_dinput (pose / normal gradient chains) run beside the scatter, or (dL_dinput
  * may be NULL) the network backward of one module run beside another module's work that `params_stream` already holds.
  * params_stream == NULL or == stream, or a module without an input encoding: identical to nvo_bwd. */
+/* Optimiser step inside the parameter backward.  The tile-local record pass of a hash grid (grid_bwd_mode 3, 32-bit
+ * accumulators) holds the finished gradient of every entry of its streamed hashed levels in LDS when it flushes: with
+ * nvo_set_fused_adam it applies torch.optim.Adam to those entries right there (same arithmetic as
+ * nvo_adam_step_groups_scaled, bit for bit) instead of storing the gradient -- 8 bytes of HBM traffic per parameter less
+ * (gradient write + the optimiser's read), and the optimiser launch shrinks to the parameters outside
+ * [first_param, first_param + n_params) (nvo_fused_adam_range, relative to the module's first parameter).
+ * Preconditions the caller guarantees: the group's overflow flag word is FINAL when the backward of this module runs
+ * (every kernel that may raise it precedes it in stream order -- true for the producer flags of a nerfacto step), nothing
+ * reads the table between this backward and the end of the step (no gather-form input gradient behind it), and
+ * dL_dparams of that range is not consumed by anyone (it is left untouched).  The settings are read at LAUNCH time:
+ * set, record / run the backward, then switch off (args = NULL) for launches that want the gradient. */
+typedef struct nvo_fused_adam_args {
+    float* params;                 /* fp32 master weights: pointer to THIS MODULE's first parameter */
+    void* params_half;             /* 16-bit working copy, same origin */
+    float* exp_avg;
+    float* exp_avg_sq;
+    const float* hyper_dev;        /* device: [0] = learning rate (NULL: lr below) */
+    const float* bias_dev;         /* device: {1 - beta1^t, sqrt(1 - beta2^t)} of the next applied step (nvo_opt_commit) */
+    const float* loss_scale_dev;   /* device loss scale (NULL: grad_scale below = 1 / loss scale) */
+    const uint32_t* skip_flag;     /* device: the group's overflow flag word; non-zero = no step */
+    float lr, grad_scale, beta1, beta2, eps;
+} nvo_fused_adam_args;
+int nvo_fused_adam_range(nvo_module_t module, uint64_t* first_param, uint64_t* n_params);
+int nvo_set_fused_adam(nvo_module_t module, const nvo_fused_adam_args* args);
+
 int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream, uint32_t batch,
                  const float* input, const void* params, const void* output, const void* dL_doutput, void* ctx,
                  float* dL_dinput, float* dL_dparams);

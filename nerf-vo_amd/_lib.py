@@ -72,6 +72,13 @@ class RayHeadArgs(C.Structure):
                 ("sh", _p), ("sh_bf16", _int), ("sbins", _p), ("tbins", _p), ("x01", _p)]
 
 
+class FusedAdamArgs(C.Structure):
+    """nvo_fused_adam_args (include/nerfvo_hip.h): optimiser step inside a hash grid's parameter backward."""
+    _fields_ = [("params", _p), ("params_half", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("hyper_dev", _p),
+                ("bias_dev", _p), ("loss_scale_dev", _p), ("skip_flag", _p), ("lr", _f), ("grad_scale", _f),
+                ("beta1", _f), ("beta2", _f), ("eps", _f)]
+
+
 class AdamGroup(C.Structure):
     """nvo_adam_group (include/nerfvo_hip.h)"""
     _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
@@ -179,6 +186,8 @@ _SIGNATURES = {
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
     "nvo_zero_ranges": (_int, [_p, _u32, _p, _p]),
     "nvo_bwd_zero_ranges": (_int, [_p, _p, _p, _p, _u32]),
+    "nvo_fused_adam_range": (_int, [_p, _p, _p]),
+    "nvo_set_fused_adam": (_int, [_p, _p]),
     "nvo_ema_update": (_int, [_p, _u64, _p, _p, _p, _f, _u32, _p]),
     "nvo_ema_update_dev": (_int, [_p, _u64, _p, _p, _p, _f, _p, _p]),
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),

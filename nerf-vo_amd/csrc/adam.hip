@@ -26,9 +26,7 @@ __device__ __forceinline__ uint16_t to_bf16(float x) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // round to nearest even
 }
 
-struct AdamHyper {
-    float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale, weight_decay;
-};
+typedef NvoAdamHyper AdamHyper;  // (nvo_common.h: shared with the hash-grid backward's fused step)
 
 // Format of the 16-bit working copy the kernels read: fp16 everywhere except inside up to 4 element ranges
 // [lo, hi) of the flat buffer, which are bfloat16 (bf16 MLP mode: the fused-MLP weights and the appearance
@@ -47,12 +45,7 @@ struct Copy16Fmt {
 };
 
 __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamHyper& h) {
-    float gi = g * h.grad_scale;
-    if (h.weight_decay != 0.f) gi += h.weight_decay * p;
-    m = h.beta1 * m + (1.f - h.beta1) * gi;
-    v = h.beta2 * v + (1.f - h.beta2) * gi * gi;
-    const float denom = sqrtf(v) / h.bias2_sqrt + h.eps;
-    p -= (h.lr / h.bias1) * (m / denom);
+    nvo_adam_one(p, m, v, g, h);
 }
 
 // GT = float (local gradient), _Float16 or Bf16 (the 2-byte buffer a compressed all-reduce leaves behind).

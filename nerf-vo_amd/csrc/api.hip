@@ -308,6 +308,17 @@ struct nvo_module_s {
         nvo_set_error("this module's backward has no externalisable zeroing");
         return NVO_ERR_UNSUPPORTED;
     }
+    // parameter range [first, first + n) of this module whose Adam step the parameter backward can take over
+    // (nvo_fused_adam_range / nvo_set_fused_adam); n = 0: none
+    virtual int fused_adam_range(uint64_t* first, uint64_t* n) {
+        *first = *n = 0;
+        return NVO_OK;
+    }
+    // a: buffers addressed from THIS module's first parameter; NULL switches the fused step off
+    virtual int set_fused_adam(const nvo_fused_adam_args* /*a*/, uint64_t /*param_offset*/) {
+        nvo_set_error("this module's backward cannot take the optimiser step");
+        return NVO_ERR_UNSUPPORTED;
+    }
 };
 
 namespace {
@@ -387,6 +398,45 @@ struct GridModule : nvo_module_s {
         const char* env = getenv("NVO_GRID_BWD_MODE");
         if (env) m->bwd_mode = atoi(env);
         *out = std::move(m);
+        return NVO_OK;
+    }
+    int fused_adam_range(uint64_t* first, uint64_t* n) override {
+        *first = *n = 0;
+        if (bwd_mode != 3) return NVO_OK;
+        if (int rc = ensure_slices()) return rc;
+        uint64_t f = 0, c = 0;
+        nvo_grid_stream_adam_range(g, &stream_bins, &f, &c);
+        *first = 2 * f;  // (entries -> parameters)
+        *n = 2 * c;
+        return NVO_OK;
+    }
+    int set_fused_adam(const nvo_fused_adam_args* a, uint64_t off) override {
+        if (!a) {
+            stream_bins.adam = NvoGridAdam{};
+            return NVO_OK;
+        }
+        uint64_t first = 0, n = 0;
+        if (int rc = fused_adam_range(&first, &n)) return rc;
+        NVO_REQUIRE(n > 0, "set_fused_adam: this grid configuration has no range the backward could step (grid_bwd_mode 3, "
+                           "32-bit tile-local accumulators)");
+        NVO_REQUIRE(a->params && a->params_half && a->exp_avg && a->exp_avg_sq, "set_fused_adam: NULL buffer");
+        NVO_REQUIRE(((((uintptr_t)(a->params + off)) | ((uintptr_t)(a->exp_avg + off)) | ((uintptr_t)(a->exp_avg_sq + off))) & 15u) == 0 &&
+                        (((uintptr_t)a->params_half + 2 * off) & 7u) == 0,
+                    "set_fused_adam: the encoding's parameters must start 16-byte aligned in every buffer");
+        NvoGridAdam& d = stream_bins.adam;
+        d.params = a->params + off;
+        d.params_half = (char*)a->params_half + 2 * off;
+        d.exp_avg = a->exp_avg + off;
+        d.exp_avg_sq = a->exp_avg_sq + off;
+        d.hyper_dev = a->hyper_dev;
+        d.bias_dev = a->bias_dev;
+        d.loss_scale_dev = a->loss_scale_dev;
+        d.skip_flag = a->skip_flag;
+        d.lr = a->lr;
+        d.grad_scale = a->grad_scale;
+        d.beta1 = a->beta1;
+        d.beta2 = a->beta2;
+        d.eps = a->eps;
         return NVO_OK;
     }
     int ensure_slices() {
@@ -676,6 +726,14 @@ struct NwieModule : nvo_module_s {
     int fuse_encoding = 0;
     NvoGridLevels* d_levels = nullptr;  // device copy of enc->g for the fused kernel
 
+    int fused_adam_range(uint64_t* first, uint64_t* n) override {
+        if (int rc = enc->fused_adam_range(first, n)) return rc;
+        if (*n) *first += net->n_params;  // params = [network | encoding]
+        return NVO_OK;
+    }
+    int set_fused_adam(const nvo_fused_adam_args* a, uint64_t off) override {
+        return enc->set_fused_adam(a, off + net->n_params);
+    }
     uint64_t enc_bytes(uint32_t B) const { return nvo_round_up((uint64_t)enc->g.n_levels * B * 4, 256); }
     uint64_t ctx_bytes(uint32_t B) const override {
         // [encoded SoA][d_encoded SoA][mlp hidden][dy/dx of the encoding (option prepare_input_gradients)]
@@ -921,6 +979,16 @@ int nvo_initial_params(nvo_module_t m, uint64_t seed, float* host_out) {
 int nvo_set_option(nvo_module_t m, const char* key, int64_t value) {
     NVO_REQUIRE(m && key, "set_option: NULL argument");
     return m->set_option(key, value);
+}
+
+int nvo_fused_adam_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_params) {
+    NVO_REQUIRE(m && first_param && n_params, "fused_adam_range: NULL argument");
+    return m->fused_adam_range(first_param, n_params);
+}
+
+int nvo_set_fused_adam(nvo_module_t m, const nvo_fused_adam_args* args) {
+    NVO_REQUIRE(m, "set_fused_adam: NULL module");
+    return m->set_fused_adam(args, 0);
 }
 
 int nvo_bwd_zero_ranges(nvo_module_t m, float* dL_dparams, void** ptrs_out, uint64_t* bytes_out, uint32_t capacity) {

@@ -1993,7 +1993,8 @@ template <int TILE, bool SOA, typename DY2, uint32_t BIN>
 __global__ void __launch_bounds__(TILE)
 k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
-               uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint32_t* __restrict__ records) {
+               uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint32_t* __restrict__ records,
+               uint32_t* __restrict__ nf_flag) {
     constexpr uint32_t kStBlock = TILE;
     // capacity: every pair split into two single-corner records.  (Staging only TILE * 4 records in LDS -- four workgroups
     // per CU instead of three -- with the overflow written straight to the region measured SLOWER: 42.5 -> 48.5 us.)
@@ -2088,6 +2089,9 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     }
     GP_CLK(gq2);
     const uint32_t bad_bit = __syncthreads_or(live && !finite) ? 0x80000000u : 0u;
+    // (the accumulate pass poisons the chunk's gradient and raises the flag as well; raised HERE the verdict is final
+    // before that pass starts, which lets it take the optimiser step of the entries it sums -- NvoGridAdam)
+    if (bad_bit && nf_flag && threadIdx.x == 0) atomicOr(nf_flag, 1u);
     GP_CLK(gq3);
     if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
         uint32_t carry = 0;
@@ -2143,10 +2147,22 @@ template <uint32_t BIN>
 __global__ void __launch_bounds__(kTlBlockP)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
-                  uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag) {
+                  uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
+    // fused optimiser step (NvoGridAdam): the scalars of this launch, read once
+    NvoAdamHyper ah{adam.lr, adam.beta1, adam.beta2, adam.eps, 1.f, 1.f, adam.grad_scale, 0.f};
+    bool adam_skip = false;
+    if (adam.params) {
+        if (adam.hyper_dev) ah.lr = adam.hyper_dev[0];
+        if (adam.bias_dev) {
+            ah.bias1 = adam.bias_dev[0];
+            ah.bias2_sqrt = adam.bias_dev[1];
+        }
+        if (adam.loss_scale_dev) ah.grad_scale = 1.0f / *adam.loss_scale_dev;
+        adam_skip = adam.skip_flag && *adam.skip_flag != 0u;
+    }
     __shared__ float wpart[kWaves][2];
     __shared__ uint32_t run_incl[kWaves][64], run_base[kWaves][64];  // per wave: the runs of its current tile block
     const uint32_t lane = threadIdx.x & 63u;
@@ -2291,7 +2307,31 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                 *f0 = (float)lo * inv0;
                 *f1 = (float)hi * inv1;
             };
-            if (cur.n_chunks == 1u) {
+            if (cur.n_chunks == 1u && adam.params && g.hashed[cur.level]) {
+                // the bin's gradient is complete right here: step its entries instead of storing it (skipped step: the
+                // gradient is not needed either)
+                if (!adam_skip) {
+                    const size_t o4 = ((size_t)g.offset[cur.level] + (size_t)cur.slice * BIN) >> 1;  // in float4 units
+                    float4* __restrict__ p4 = reinterpret_cast<float4*>(adam.params) + o4;
+                    float4* __restrict__ m4 = reinterpret_cast<float4*>(adam.exp_avg) + o4;
+                    float4* __restrict__ v4 = reinterpret_cast<float4*>(adam.exp_avg_sq) + o4;
+                    uint2* __restrict__ h4 = reinterpret_cast<uint2*>(adam.params_half) + o4;
+                    for (uint32_t e = threadIdx.x; e < n2; e += kTlBlockP) {
+                        const ulonglong2 w = acc2[e];
+                        float4 gv, pv = p4[e], mv = m4[e], vv = v4[e];
+                        split(w.x, &gv.x, &gv.y);
+                        split(w.y, &gv.z, &gv.w);
+                        nvo_adam_one(pv.x, mv.x, vv.x, gv.x, ah);
+                        nvo_adam_one(pv.y, mv.y, vv.y, gv.y, ah);
+                        nvo_adam_one(pv.z, mv.z, vv.z, gv.z, ah);
+                        nvo_adam_one(pv.w, mv.w, vv.w, gv.w, ah);
+                        p4[e] = pv;
+                        m4[e] = mv;
+                        v4[e] = vv;
+                        h4[e] = make_uint2(nvo_cvt16x2(pv.x, pv.y, false), nvo_cvt16x2(pv.z, pv.w, false));
+                    }
+                }
+            } else if (cur.n_chunks == 1u) {
                 for (uint32_t e = threadIdx.x; e < n2; e += kTlBlockP) {
                     const ulonglong2 w = acc2[e];
                     float4 v;
@@ -2318,7 +2358,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         }
 #endif
         if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
-            atomicAdd(gr, __builtin_nanf(""));
+            if (!(adam.params && g.hashed[cur.level])) atomicAdd(gr, __builtin_nanf(""));  // (fused: no gradient is kept)
             if (nf_flag) atomicOr(nf_flag, 1u);
         }
         if (!has_next) break;
@@ -3021,6 +3061,21 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     nvo_grid_slices_destroy(&st->owner);
 }
 
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n) {
+    *first = 0;
+    *n = 0;
+    if (!st->created || !st->tile_local || st->acc_bits != 32) return;
+    // the streamed hashed levels: one accumulate item per bin (nvo_grid_stream_create); they form the tail of the table
+    uint32_t lo = g.n_levels;
+    for (uint32_t l = 0; l < g.n_levels; ++l)
+        if (((st->streamed_mask >> l) & 1u) && g.hashed[l] && l < lo) lo = l;
+    if (lo == g.n_levels) return;
+    for (uint32_t l = lo; l < g.n_levels; ++l)
+        if (!(((st->streamed_mask >> l) & 1u) && g.hashed[l])) return;  // (not a contiguous tail: leave it to the optimiser)
+    *first = g.offset[lo];
+    *n = (uint64_t)g.offset[g.n_levels] - g.offset[lo];
+}
+
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
                                const float* x, const void* dy, int dy_fmt, bool soa, float* grad) {
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
@@ -3114,7 +3169,8 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
             NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
-                       st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl));    \
+                       st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl),     \
+                       st->owner.nf_flag);                                                                    \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
@@ -3124,7 +3180,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
                        (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1,                              \
                        reinterpret_cast<const uint32_t*>(records_tl), n_tiles,                                \
-                       (uint32_t)tile_records, grad, st->owner.nf_flag);                                      \
+                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam);                            \
         }                                                                                                     \
     } while (0)
 #define NVO_LAUNCH_TLP(SOA_, T_)                                                           \

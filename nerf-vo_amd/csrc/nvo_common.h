@@ -170,6 +170,21 @@ __device__ __forceinline__ nvo_h16 nvo_cvt16(float v, bool bf) {  // round to ne
 __device__ __forceinline__ uint32_t nvo_cvt16x2(float a, float b, bool bf) {
     return (uint32_t)nvo_cvt16(a, bf) | ((uint32_t)nvo_cvt16(b, bf) << 16);
 }
+
+// torch.optim.Adam on one scalar (no AMSGrad, L2 weight decay folded into the gradient); shared by the optimiser launch
+// (adam.hip) and the hash-grid backward that steps the entries it has just finished summing (grid.hip, NvoGridAdam) --
+// ONE definition, so both produce the same bits (the library is built with -ffp-contract=off).
+struct NvoAdamHyper {
+    float lr, beta1, beta2, eps, bias1, bias2_sqrt, grad_scale, weight_decay;
+};
+__device__ __forceinline__ void nvo_adam_one(float& p, float& m, float& v, float g, const NvoAdamHyper& h) {
+    float gi = g * h.grad_scale;
+    if (h.weight_decay != 0.f) gi += h.weight_decay * p;
+    m = h.beta1 * m + (1.f - h.beta1) * gi;
+    v = h.beta2 * v + (1.f - h.beta2) * gi * gi;
+    const float denom = sqrtf(v) / h.bias2_sqrt + h.eps;
+    p -= (h.lr / h.bias1) * (m / denom);
+}
 __device__ __forceinline__ float2 nvo_ld16x2(uint32_t raw, bool bf) {
     if (bf) return make_float2(__uint_as_float(raw << 16), __uint_as_float(raw & 0xFFFF0000u));
     return make_float2((float)__builtin_bit_cast(_Float16, (nvo_h16)(raw & 0xFFFFu)),

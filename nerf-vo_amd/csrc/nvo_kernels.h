@@ -89,6 +89,24 @@ int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStr
 
 // Streamed binned backward (mode 3): levels with many 4K-entry bins go through count / scan / scatter of
 // self-contained 8-byte records / streaming accumulate; the coarse levels keep slice-owner items.
+// Adam fused into the tile-local accumulate pass (k_tl_accumulate_p): the single-item bins of the streamed HASHED levels
+// hold their finished gradient in LDS when they flush, so the optimiser step of those entries happens right there --
+// the gradient is neither written (4 B per parameter) nor read again by the optimiser launch (4 B), and that launch
+// shrinks to the rest of the group.  Legal because the group's overflow verdict is final before the pass starts: every
+// producer of its flag word (loss kernels, fused-MLP backwards, slice-owner items, the scatter pass that marks poisoned
+// records) precedes it in stream order.  Pointers are to the ENCODING's first parameter in each flat buffer.
+struct NvoGridAdam {
+    float* params = nullptr;            // fp32 master weights (nullptr = off: gradients are stored as usual)
+    void* params_half = nullptr;        // 16-bit working copy (fp16 tables)
+    float* exp_avg = nullptr;
+    float* exp_avg_sq = nullptr;
+    const float* hyper_dev = nullptr;   // [0] = learning rate (nullable: lr)
+    const float* bias_dev = nullptr;    // {1 - beta1^t, sqrt(1 - beta2^t)} of the group's next applied step
+    const float* loss_scale_dev = nullptr;  // nullable: grad_scale
+    const uint32_t* skip_flag = nullptr;    // the group's overflow flag word (non-zero: no step)
+    float lr = 0.f, grad_scale = 1.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f;
+};
+
 struct NvoGridStream {
     bool created = false;
     uint32_t n_levels = 0, n_bins = 0, max_slices = 0;
@@ -129,7 +147,11 @@ struct NvoGridStream {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool external_zero = false;  // (tile-local layout only) see NvoGridSlices::external_zero
     bool deterministic = false;  // (set before create) one accumulate item per bin on dense levels too; owner: see there
+    NvoGridAdam adam;            // (packed tile-local layout) optimiser step inside the accumulate pass, see NvoGridAdam
 };
+// entries [first, first + n) of the table (in ENTRIES: two parameters each) whose Adam step NvoGridStream::adam takes over:
+// the streamed hashed levels (one accumulate item per bin); n = 0 when the configuration has none
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n);
 // false: this configuration zeroes data-dependent ranges (globally sorted layout) and cannot hand the zeroing over
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out);
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);

@@ -155,6 +155,11 @@ class EngineConfig:
     # host fills 1024 steps ahead (nvo_opt_commit_table): nothing eager behind the replay -- the trace showed 8 us of
     # launch latency between the graph's last kernel and the eager launch, plus its 5 us, on every step
     commit_from_table: bool = True
+    # one-graph step (single GPU): the tile-local accumulate pass of the main grid applies Adam to the entries of the
+    # hashed levels it has just summed (nvo_set_fused_adam) instead of storing their gradient -- 8 B of HBM traffic per
+    # parameter less (11.5 M of the 12.2 M), and the optimiser launch covers the rest of the fields group only.
+    # Bit-identical to the separate launch.  Needs the producer flags (the group's verdict must be final before the pass).
+    fuse_grid_adam: bool = True
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
     # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
     # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
@@ -1084,13 +1089,21 @@ class NerfactoEngine:
             _call("nvo_nonfinite_flag_ranges_or", stream, len(order), offs, sizes, _ptr(gbuf), ghalf, _ptr(self.skip_flag))
         batch = []
         mask = 0
+        fused = getattr(self, "_fused_adam_range", None)  # (set around the capture of the one-graph step)
         for g in active:
             lo, hi = span(g)
             gi = order.index(g)
             mask |= 1 << gi
             hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None
-            batch.append(_lib.AdamGroup(offset=lo, n=hi - lo, lr=self._group_lr(g), step=0, hyper_dev=hyper,
-                                        bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
+            parts = [(lo, hi)]
+            if g == "fields" and fused is not None:
+                # the main grid's backward has already stepped [fused): the launch covers what lies around it
+                assert shard is None and grads_half is None and lo <= fused[0] < fused[1] <= hi
+                parts = [(lo, fused[0]), (fused[1], hi)]
+            for a_, b_ in parts:
+                if b_ > a_:
+                    batch.append(_lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
+                                                bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
         if not batch:
             return
         arr = (_lib.AdamGroup * len(batch))(*batch)
@@ -1112,6 +1125,44 @@ class NerfactoEngine:
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
               cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
+
+    def _fused_adam_plan(self):
+        """(lo, hi) of the flat parameter buffer whose Adam step the main grid's backward can take over
+        (EngineConfig.fuse_grid_adam), or None."""
+        cfg = self.cfg
+        modes = cfg.grid_bwd_mode if isinstance(cfg.grid_bwd_mode, (tuple, list)) else (cfg.grid_bwd_mode,) * 3
+        flags = bool(cfg.producer_overflow_flags and all(int(m) in (1, 3) for m in modes) and self.world_size == 1
+                     and getattr(self, "_reducer", None) is None)
+        store = cfg.store_input_gradients
+        if store is None:
+            store = bool(cfg.optimize_poses or cfg.expect_normals)
+        # (a gather-form input gradient behind the parameter backward would read the table after its step)
+        if not (cfg.fuse_grid_adam and flags and (store or not (cfg.optimize_poses or cfg.expect_normals))):
+            return None
+        first, n = C.c_uint64(0), C.c_uint64(0)
+        _call("nvo_fused_adam_range", self.base_net.handle, C.byref(first), C.byref(n))
+        if n.value == 0:
+            return None
+        lo = self.segments["field.base"][0] + int(first.value)
+        return lo, lo + int(n.value)
+
+    def _set_fused_adam(self, on: bool) -> None:
+        """Arms / disarms the optimiser step inside the main grid's parameter backward (read at launch time: armed
+        around the capture of the one-graph step only, so that eager steps keep storing the gradient)."""
+        if not on:
+            _call("nvo_set_fused_adam", self.base_net.handle, None)
+            return
+        cfg = self.cfg
+        gi = self._GROUP_ORDER.index("fields")
+        base = self.segments["field.base"][0]
+        a = _lib.FusedAdamArgs(
+            params=self.params.data_ptr() + 4 * base, params_half=self.params_half.data_ptr() + 2 * base,
+            exp_avg=self.exp_avg.data_ptr() + 4 * base, exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * base,
+            hyper_dev=self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi), bias_dev=self.dev_bias.data_ptr() + 8 * gi,
+            loss_scale_dev=self.dev_loss_scale.data_ptr() if cfg.dynamic_loss_scale else None,
+            skip_flag=self.skip_flag.data_ptr() + 4 * gi, lr=self._group_lr("fields"), grad_scale=1.0 / cfg.loss_scale,
+            beta1=cfg.adam_betas[0], beta2=cfg.adam_betas[1], eps=cfg.adam_eps)
+        _call("nvo_set_fused_adam", self.base_net.handle, C.byref(a))
 
     _TABLE_ROWS = 1024
 
@@ -1516,23 +1567,7 @@ class NerfactoEngine:
                 fn()
             return g
 
-        if not split and not pipe1:
-            # update steps: Adam(fields) beside the tail of the proposal chain (cfg.overlap_fields_adam)
-            early_fields = bool(updated and cfg.overlap_fields_adam and cfg.overlap_proposal_backward
-                                and cfg.overlap_proposal_mlp and not cfg.optimize_poses and not cfg.deterministic
-                                and int(cfg.proposal_backward_streams) == 1 and "proposal_networks" in groups_b)
-
-            def whole():
-                body_head()
-                if early_fields:
-                    self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
-                                          anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True,
-                                          proposal_values=values, after_main_backward=lambda: body_opt(["fields"]))
-                    body_opt([g for g in groups_b if g != "fields"])
-                else:
-                    body_rest()
-                    body_opt(groups_b)
-            zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
+        def capture_one_graph():
             if cfg.commit_from_table:
                 def whole_and_commit():
                     self._defer_commit = []
@@ -1567,6 +1602,34 @@ class NerfactoEngine:
                 self._defer_commit = None
             assert entry["commit"] is not None, "the one-graph step runs at least one optimiser launch"
             return entry
+        if not split and not pipe1:
+            # update steps: Adam(fields) beside the tail of the proposal chain (cfg.overlap_fields_adam)
+            early_fields = bool(updated and cfg.overlap_fields_adam and cfg.overlap_proposal_backward
+                                and cfg.overlap_proposal_mlp and not cfg.optimize_poses and not cfg.deterministic
+                                and int(cfg.proposal_backward_streams) == 1 and "proposal_networks" in groups_b)
+
+            def whole():
+                body_head()
+                if early_fields:
+                    self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
+                                          anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True,
+                                          proposal_values=values, after_main_backward=lambda: body_opt(["fields"]))
+                    body_opt([g for g in groups_b if g != "fields"])
+                else:
+                    body_rest()
+                    body_opt(groups_b)
+            zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
+            self._fused_adam_range = self._fused_adam_plan()
+            entry["fused_adam"] = self._fused_adam_range
+            if self._fused_adam_range is not None:
+                self._set_fused_adam(True)
+            try:
+                return capture_one_graph()
+            finally:
+                if self._fused_adam_range is not None:
+                    self._set_fused_adam(False)
+                self._fused_adam_range = None
+
         if pipe1:
             opt_stream = torch.cuda.Stream(device=dev)
 

@@ -779,6 +779,49 @@ def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
         assert float(a[3][4:5].view(torch.float32)) > 65536.0  # the scale really grew (interval 7)
 
 
+@pytest.mark.parametrize("poses", [False, True], ids=["fixed-poses", "se3"])
+def test_adam_inside_the_grid_backward_is_bit_identical(device, poses):
+    """EngineConfig.fuse_grid_adam: the tile-local accumulate pass of the main grid steps the entries of the hashed levels
+    it has just summed instead of storing their gradient, and the optimiser launch covers the rest of the fields group.
+    Same seed, deterministic mode, graph-replayed steps across the proposal-update schedule, a dynamic loss scale that
+    starts at 2^33 and doubles every 2 clean steps (it backs off until the gradients fit, then keeps running into the
+    overflow again: skipped steps occur throughout): parameters, both moments, the 16-bit working copy, step
+    counters and the loss scale must equal those of the separate optimiser launch bit for bit."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 512
+    seq = make_sequence(n, H, W, device=device)
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+
+    def run(fuse: bool):
+        torch.manual_seed(33)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, optimize_poses=poses, deterministic=True,
+                                          dynamic_loss_scale=True, loss_scale_interval=2, loss_scale_init=2.0 ** 33,
+                                          loss_scale_max=2.0 ** 40, fuse_grid_adam=fuse), device)
+        for _ in range(36):
+            eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        fused = [e.get("fused_adam") for e in eng._graphs.values()]
+        return (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.params_half.clone().view(torch.int16),
+                eng.opt_state.clone(), dict(eng.opt_steps), fused, eng.segments["field.base"])
+
+    a, b = run(True), run(False)
+    assert all(f is not None for f in a[6]) and all(f is None for f in b[6])
+    lo, hi = a[6][0]
+    base_lo, base_n, _ = a[7]
+    assert base_lo < lo < hi == base_lo + base_n and hi - lo > 0.8 * base_n  # (the hashed levels: most of the table)
+    assert a[5] == b[5], (a[5], b[5])
+    assert a[5]["fields"] < 36, "the sweep of the loss scale was meant to skip some steps"
+    for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "working copy", "optimiser state"), a[:5], b[:5]):
+        same = x.view(torch.int32) == y.view(torch.int32) if x.dtype != torch.int16 else x == y
+        assert bool(same.all()), f"{name}: {int((~same).sum())} words differ with the step inside the grid backward"
+
+
 def test_pipelined_prefix_is_bit_identical_on_one_gpu(device):
     """EngineConfig.pipeline_single_gpu: the graph ends with [Adam of the fields group || sampling prefix of the NEXT
     step] -- the launch order the multi-GPU step uses around its exchange, on one GPU.  The reordering must not change
