@@ -2316,19 +2316,36 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     float4* __restrict__ m4 = reinterpret_cast<float4*>(adam.exp_avg) + o4;
                     float4* __restrict__ v4 = reinterpret_cast<float4*>(adam.exp_avg_sq) + o4;
                     uint2* __restrict__ h4 = reinterpret_cast<uint2*>(adam.params_half) + o4;
-                    for (uint32_t e = threadIdx.x; e < n2; e += kTlBlockP) {
-                        const ulonglong2 w = acc2[e];
-                        float4 gv, pv = p4[e], mv = m4[e], vv = v4[e];
-                        split(w.x, &gv.x, &gv.y);
-                        split(w.y, &gv.z, &gv.w);
-                        nvo_adam_one(pv.x, mv.x, vv.x, gv.x, ah);
-                        nvo_adam_one(pv.y, mv.y, vv.y, gv.y, ah);
-                        nvo_adam_one(pv.z, mv.z, vv.z, gv.z, ah);
-                        nvo_adam_one(pv.w, mv.w, vv.w, gv.w, ah);
-                        p4[e] = pv;
-                        m4[e] = mv;
-                        v4[e] = vv;
-                        h4[e] = make_uint2(nvo_cvt16x2(pv.x, pv.y, false), nvo_cvt16x2(pv.z, pv.w, false));
+                    // (four steps' loads -- 12 x 16 bytes per thread -- are requested before the first is used: the flush
+                    // of a bin is a pure stream, and with two workgroups per CU only the thread itself hides its latency)
+                    constexpr uint32_t kU = 4;
+                    for (uint32_t e0 = threadIdx.x; e0 < n2; e0 += kU * kTlBlockP) {
+                        float4 pv[kU], mv[kU], vv[kU];
+#pragma unroll
+                        for (uint32_t u = 0; u < kU; ++u) {
+                            const uint32_t e = min(e0 + u * kTlBlockP, n2 - 1u);
+                            pv[u] = p4[e];
+                            mv[u] = m4[e];
+                            vv[u] = v4[e];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < kU; ++u) {
+                            const uint32_t e = e0 + u * kTlBlockP;
+                            if (e < n2) {
+                                const ulonglong2 w = acc2[e];
+                                float4 gv;
+                                split(w.x, &gv.x, &gv.y);
+                                split(w.y, &gv.z, &gv.w);
+                                nvo_adam_one(pv[u].x, mv[u].x, vv[u].x, gv.x, ah);
+                                nvo_adam_one(pv[u].y, mv[u].y, vv[u].y, gv.y, ah);
+                                nvo_adam_one(pv[u].z, mv[u].z, vv[u].z, gv.z, ah);
+                                nvo_adam_one(pv[u].w, mv[u].w, vv[u].w, gv.w, ah);
+                                p4[e] = pv[u];
+                                m4[e] = mv[u];
+                                v4[e] = vv[u];
+                                h4[e] = make_uint2(nvo_cvt16x2(pv[u].x, pv[u].y, false), nvo_cvt16x2(pv[u].z, pv[u].w, false));
+                            }
+                        }
                     }
                 }
             } else if (cur.n_chunks == 1u) {
