@@ -48,7 +48,7 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
+def algorithmic_bytes(name: str, cfg, R: int, fused_adam_params: int = 0) -> float | None:
     """ALGORITHMIC bytes one launch of the named kernel moves (DESIGN.md section 'Kernels'; per-unit
     figures follow SURVEY.md section 8d)."""
     S = {"L16": cfg.num_nerf_samples}
@@ -65,7 +65,12 @@ def algorithmic_bytes(name: str, cfg, R: int) -> float | None:
         # scatter RMW 2 x 512 B (16 levels x 8 corners x 4 B, read + write) + 12 B position
         # + 64 B d(encoded) = 1100 B / sample.  (The kernels accumulate fp32 pairs -- twice the RMW bytes of the
         # fp16 table 8d prices -- which the contract does not credit: see roofline.algorithmic_bytes_fp32_rmw.)
-        return n_main * (16 * 8 * 4 * 2 + 12 + 16 * 4)
+        b = n_main * (16 * 8 * 4 * 2 + 12 + 16 * 4)
+        if name == "grid_bwd_stream[L16]" and fused_adam_params:
+            # the pass also takes the Adam step of the hashed levels' entries (EngineConfig.fuse_grid_adam): SURVEY 8d
+            # prices Adam at 28 B per parameter (the gradient it no longer reads is part of that figure; not deducted)
+            b += 28 * fused_adam_params
+        return b
     if name in tuple(k + "[L5]" for k in bwd_kinds):  # one launch per proposal net: average of the two
         return (n_p0 + n_p1) / 2 * (5 * 8 * 4 * 2 + 12 + 5 * 4)
     if name == "mlp_bwd[64-64x2-16]":
@@ -377,7 +382,9 @@ def main() -> None:
             sys.stderr.write(f"[bench]   {name:28s} launches {cnt:5d}  avg {total / cnt * 1e3:9.1f} us  "
                              f"{100 * total / tot:5.1f} %\n")
         for name, cnt, total in kernel_table:  # dominant kernel with a byte model
-            b = algorithmic_bytes(name, cfg, args.rays)
+            fused_plan = engine._fused_adam_plan() if world == 1 else None
+            fused_n = (fused_plan[1] - fused_plan[0]) if fused_plan else 0
+            b = algorithmic_bytes(name, cfg, args.rays, fused_n)
             if b is None:
                 continue
             avg_s = total / cnt * 1e-3
@@ -390,13 +397,15 @@ def main() -> None:
                         # streams and for the record pass's unaligned 384-byte runs, profiles/r3_pmc_probe_run_gather.txt)
                         "traffic_raw": traffic_raw,
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(b),
-                        "bytes_model": "SURVEY.md 8d per-unit bytes x units per launch (DESIGN.md section 3)",
+                        "bytes_model": "SURVEY.md 8d per-unit bytes x units per launch (DESIGN.md section 3)" + (
+                            f" + 28 B x {fused_n} parameters stepped inside the pass" if (fused_n and name == "grid_bwd_stream[L16]") else ""),
                         "share_of_step_kernel_time": round(total / tot, 4)}
             if name.startswith("grid_bwd"):
                 # informational: what the kernel really read-modify-writes (fp32 gradient pairs, 2x the 8d figure)
                 lv = 16 if name.endswith("[L16]") else 5
-                units = b / (lv * 8 * 4 * 2 + 12 + lv * 4)
-                b32 = units * (lv * 8 * 8 * 2 + 12 + lv * 4)
+                extra = 28 * fused_n if name == "grid_bwd_stream[L16]" else 0  # (the Adam bytes are fp32 already)
+                units = (b - extra) / (lv * 8 * 4 * 2 + 12 + lv * 4)
+                b32 = units * (lv * 8 * 8 * 2 + 12 + lv * 4) + extra
                 roofline["fp32_rmw_variant"] = {"algorithmic_bytes_per_launch": int(b32),
                                                 "achieved": round(b32 / avg_s / 1e9, 2),
                                                 "frac": round(b32 / avg_s / 1e9 / HBM_PEAK_GBS, 5)}

@@ -167,6 +167,15 @@ typedef struct nvo_fused_adam_args {
     const float* loss_scale_dev;   /* device loss scale (NULL: grad_scale below = 1 / loss scale) */
     const uint32_t* skip_flag;     /* device: the group's overflow flag word; non-zero = no step */
     float lr, grad_scale, beta1, beta2, eps;
+    uint32_t step;                 /* bias_dev == NULL: bias corrections of step `step` (counted from 1), computed on the host
+                                      exactly as nvo_adam_step does */
+    /* optional: tcnn EmaOptimizer folded in (nvo_ema_update_dev on the same entries, same arithmetic): the stepped
+     * weights are averaged into ema / ema_half right away.  ema_step_dev is only READ (the caller's
+     * nvo_ema_update_dev launch over the rest of the parameters advances it). */
+    float* ema;                    /* fp32 average, same origin as params; NULL = no averaging */
+    void* ema_half;                /* fp16 copy of the average (nullable) */
+    float ema_decay;
+    const uint32_t* ema_step_dev;  /* device: averages applied so far */
 } nvo_fused_adam_args;
 int nvo_fused_adam_range(nvo_module_t module, uint64_t* first_param, uint64_t* n_params);
 int nvo_set_fused_adam(nvo_module_t module, const nvo_fused_adam_args* args);
@@ -502,6 +511,7 @@ typedef struct nvo_ngp_rgb_args {
     void* d_density_out;         /* bwd: fp16 [capacity][16] (all columns written) */
     const float* d_density_pre;  /* bwd: [capacity], added into column 0; nullable */
     float* d_weights;            /* bwd: accumulated */
+    uint32_t* nonfinite_flag;    /* bwd; nullable: OR-ed with 1 when a weight-gradient total of the head is not finite */
 } nvo_ngp_rgb_args;
 int nvo_ngp_rgb_fwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);
 int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);
@@ -632,6 +642,10 @@ int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* 
                    uint32_t step, const uint32_t* skip_flag);
 /* The same with the step count on the device: *step_dev = averages applied so far; the call uses t = *step_dev + 1 and
  * advances the counter iff the step was not skipped (the debias factor never runs ahead of the average). */
+/* nvo_ema_update_dev without the commit of the step counter: for callers that average the parameters in several
+ * launches (the last one is nvo_ema_update_dev itself). */
+int nvo_ema_update_dev_part(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                            const uint32_t* step_dev, const uint32_t* skip_flag);
 int nvo_ema_update_dev(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
                        uint32_t* step_dev, const uint32_t* skip_flag);
 /* bf16 MLP mode (BASELINE configs[4]: "MFMA bf16 MLP + fp32 hash accumulate"): the 16-bit working copy of the flat

@@ -76,7 +76,8 @@ class FusedAdamArgs(C.Structure):
     """nvo_fused_adam_args (include/nerfvo_hip.h): optimiser step inside a hash grid's parameter backward."""
     _fields_ = [("params", _p), ("params_half", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("hyper_dev", _p),
                 ("bias_dev", _p), ("loss_scale_dev", _p), ("skip_flag", _p), ("lr", _f), ("grad_scale", _f),
-                ("beta1", _f), ("beta2", _f), ("eps", _f)]
+                ("beta1", _f), ("beta2", _f), ("eps", _f), ("step", _u32), ("ema", _p), ("ema_half", _p), ("ema_decay", _f),
+                ("ema_step_dev", _p)]
 
 
 class AdamGroup(C.Structure):
@@ -95,7 +96,8 @@ class DepthAlignArgs(C.Structure):
 class NgpRgbArgs(C.Structure):
     """mirror of nvo_ngp_rgb_args"""
     _fields_ = [("capacity", _u32), ("sh", _p), ("density_out", _p), ("ray_idx", _p), ("weights", _p), ("rgb_out", _p),
-                ("hidden", _p), ("d_rgb_out", _p), ("d_density_out", _p), ("d_density_pre", _p), ("d_weights", _p)]
+                ("hidden", _p), ("d_rgb_out", _p), ("d_density_out", _p), ("d_density_pre", _p), ("d_weights", _p),
+                ("nonfinite_flag", _p)]
 
 
 class NgpLossArgs(C.Structure):
@@ -190,6 +192,7 @@ _SIGNATURES = {
     "nvo_set_fused_adam": (_int, [_p, _p]),
     "nvo_ema_update": (_int, [_p, _u64, _p, _p, _p, _f, _u32, _p]),
     "nvo_ema_update_dev": (_int, [_p, _u64, _p, _p, _p, _f, _p, _p]),
+    "nvo_ema_update_dev_part": (_int, [_p, _u64, _p, _p, _p, _f, _p, _p]),
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),

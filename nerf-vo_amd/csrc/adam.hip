@@ -971,6 +971,20 @@ int nvo_ema_update(nvo_stream_t stream, uint64_t n, const float* params, float* 
     return NVO_OK;
 }
 
+int nvo_ema_update_dev_part(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
+                            const uint32_t* step_dev, const uint32_t* skip_flag) {
+    NVO_REQUIRE(params && ema && step_dev, "ema_update_dev_part: NULL argument");
+    NVO_REQUIRE(decay >= 0.f && decay < 1.f, "ema_update_dev_part: 0 <= decay < 1");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "ema_update");
+    uint32_t blocks = nvo_div_up(n, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    NVO_LAUNCH(k_ema_update_dev, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params, ema, (_Float16*)ema_half, decay,
+               step_dev, skip_flag);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
 int nvo_ema_update_dev(nvo_stream_t stream, uint64_t n, const float* params, float* ema, void* ema_half, float decay,
                        uint32_t* step_dev, const uint32_t* skip_flag) {
     NVO_REQUIRE(params && ema && step_dev, "ema_update_dev: NULL argument");

@@ -437,6 +437,18 @@ struct GridModule : nvo_module_s {
         d.beta1 = a->beta1;
         d.beta2 = a->beta2;
         d.eps = a->eps;
+        if (!a->bias_dev) {  // as nvo_adam_step / nvo_adam_step_groups price a host-side step count
+            NVO_REQUIRE(a->step >= 1, "set_fused_adam: step counts from 1 (or pass bias_dev)");
+            d.bias1 = 1.f - powf(a->beta1, (float)a->step);
+            d.bias2_sqrt = sqrtf(1.f - powf(a->beta2, (float)a->step));
+        }
+        d.ema = a->ema ? a->ema + off : nullptr;
+        d.ema_half = a->ema_half ? (char*)a->ema_half + 2 * off : nullptr;
+        d.ema_decay = a->ema_decay;
+        d.ema_step_dev = a->ema_step_dev;
+        NVO_REQUIRE(!d.ema || (d.ema_step_dev && a->ema_decay >= 0.f && a->ema_decay < 1.f && (((uintptr_t)d.ema) & 15u) == 0 &&
+                               (((uintptr_t)d.ema_half) & 7u) == 0),
+                    "set_fused_adam: bad weight-average arguments");
         return NVO_OK;
     }
     int ensure_slices() {

@@ -2152,8 +2152,15 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
     // fused optimiser step (NvoGridAdam): the scalars of this launch, read once
-    NvoAdamHyper ah{adam.lr, adam.beta1, adam.beta2, adam.eps, 1.f, 1.f, adam.grad_scale, 0.f};
+    NvoAdamHyper ah{adam.lr, adam.beta1, adam.beta2, adam.eps, adam.bias1, adam.bias2_sqrt, adam.grad_scale, 0.f};
     bool adam_skip = false;
+    float ema_keep = 0.f, ema_take = 0.f, ema_inv = 1.f;  // (k_ema_update_dev's factors, same expressions)
+    if (adam.params && adam.ema) {
+        const double d = (double)adam.ema_decay, t = (double)(*adam.ema_step_dev) + 1.0;
+        ema_keep = (float)(d * (1.0 - pow(d, t - 1.0)));
+        ema_inv = (float)(1.0 / (1.0 - pow(d, t)));
+        ema_take = 1.0f - adam.ema_decay;
+    }
     if (adam.params) {
         if (adam.hyper_dev) ah.lr = adam.hyper_dev[0];
         if (adam.bias_dev) {
@@ -2316,6 +2323,8 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     float4* __restrict__ m4 = reinterpret_cast<float4*>(adam.exp_avg) + o4;
                     float4* __restrict__ v4 = reinterpret_cast<float4*>(adam.exp_avg_sq) + o4;
                     uint2* __restrict__ h4 = reinterpret_cast<uint2*>(adam.params_half) + o4;
+                    float4* __restrict__ e4 = adam.ema ? reinterpret_cast<float4*>(adam.ema) + o4 : nullptr;
+                    uint2* __restrict__ eh4 = adam.ema_half ? reinterpret_cast<uint2*>(adam.ema_half) + o4 : nullptr;
                     // (four steps' loads -- 12 x 16 bytes per thread -- are requested before the first is used: the flush
                     // of a bin is a pure stream, and with two workgroups per CU only the thread itself hides its latency)
                     constexpr uint32_t kU = 4;
@@ -2344,6 +2353,15 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                                 m4[e] = mv[u];
                                 v4[e] = vv[u];
                                 h4[e] = make_uint2(nvo_cvt16x2(pv[u].x, pv[u].y, false), nvo_cvt16x2(pv[u].z, pv[u].w, false));
+                                if (e4) {  // the weight average of the entries just stepped (tcnn EmaOptimizer)
+                                    float4 ev = e4[e];
+                                    ev.x = (ev.x * ema_keep + pv[u].x * ema_take) * ema_inv;
+                                    ev.y = (ev.y * ema_keep + pv[u].y * ema_take) * ema_inv;
+                                    ev.z = (ev.z * ema_keep + pv[u].z * ema_take) * ema_inv;
+                                    ev.w = (ev.w * ema_keep + pv[u].w * ema_take) * ema_inv;
+                                    e4[e] = ev;
+                                    if (eh4) eh4[e] = make_uint2(nvo_cvt16x2(ev.x, ev.y, false), nvo_cvt16x2(ev.z, ev.w, false));
+                                }
                             }
                         }
                     }

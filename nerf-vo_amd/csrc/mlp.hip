@@ -103,6 +103,7 @@ static NvoMlpArgs ngp_rgb_args(const nvo_ngp_rgb_args& c) {
     a.sh = (const _Float16*)c.sh;
     a.base_out = (const _Float16*)c.density_out;
     a.sample_ray = c.ray_idx;
+    a.nf_flag = c.nonfinite_flag;
     return a;
 }
 

@@ -105,6 +105,12 @@ struct NvoGridAdam {
     const float* loss_scale_dev = nullptr;  // nullable: grad_scale
     const uint32_t* skip_flag = nullptr;    // the group's overflow flag word (non-zero: no step)
     float lr = 0.f, grad_scale = 1.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f;
+    float bias1 = 1.f, bias2_sqrt = 1.f;    // (bias_dev == nullptr) host-computed corrections
+    // tcnn EmaOptimizer on the same entries (k_ema_update_dev's arithmetic): ema == nullptr = off
+    float* ema = nullptr;
+    void* ema_half = nullptr;
+    float ema_decay = 0.f;
+    const uint32_t* ema_step_dev = nullptr;
 };
 
 struct NvoGridStream {

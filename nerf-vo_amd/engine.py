@@ -1146,7 +1146,7 @@ class NerfactoEngine:
         lo = self.segments["field.base"][0] + int(first.value)
         return lo, lo + int(n.value)
 
-    def _set_fused_adam(self, on: bool) -> None:
+    def _set_fused_adam(self, on: bool, from_device_scalars: bool = True) -> None:
         """Arms / disarms the optimiser step inside the main grid's parameter backward (read at launch time: armed
         around the capture of the one-graph step only, so that eager steps keep storing the gradient)."""
         if not on:
@@ -1158,7 +1158,8 @@ class NerfactoEngine:
         a = _lib.FusedAdamArgs(
             params=self.params.data_ptr() + 4 * base, params_half=self.params_half.data_ptr() + 2 * base,
             exp_avg=self.exp_avg.data_ptr() + 4 * base, exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * base,
-            hyper_dev=self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi), bias_dev=self.dev_bias.data_ptr() + 8 * gi,
+            hyper_dev=self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None,
+            bias_dev=self.dev_bias.data_ptr() + 8 * gi,
             loss_scale_dev=self.dev_loss_scale.data_ptr() if cfg.dynamic_loss_scale else None,
             skip_flag=self.skip_flag.data_ptr() + 4 * gi, lr=self._group_lr("fields"), grad_scale=1.0 / cfg.loss_scale,
             beta1=cfg.adam_betas[0], beta2=cfg.adam_betas[1], eps=cfg.adam_eps)
@@ -1752,9 +1753,24 @@ class NerfactoEngine:
         if jitters is None:
             jitters = tuple(torch.rand(R, device=self.device) for _ in range(3))
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths, normals=normals)
-        updated = self.forward_backward(ws, jitters, has_depth=depths is not None, has_normals=normals is not None)
+        # (single GPU: the main grid's backward takes the Adam step of its hashed levels, as in the captured step --
+        # forward_backward() on its own keeps storing the whole gradient)
+        fused = self._fused_adam_plan() if all_reduce is None else None
+        if fused is not None:
+            self._set_fused_adam(True, from_device_scalars=False)  # (eager: the learning rate travels as an argument)
+        try:
+            updated = self.forward_backward(ws, jitters, has_depth=depths is not None, has_normals=normals is not None)
+        finally:
+            if fused is not None:
+                self._set_fused_adam(False)
         groups = ["fields"] + (["proposal_networks"] if updated else []) + ["camera_opt"]
-        if all_reduce is not None:
+        if fused is not None:
+            self._fused_adam_range = fused
+            try:
+                self.optimizer_step(groups)
+            finally:
+                self._fused_adam_range = None
+        elif all_reduce is not None:
             # one exchange per iteration: the gradient ranges that are non-zero on this step
             active = [g for g in groups if g != "camera_opt" or self.cfg.optimize_poses]
             reduced_half = all_reduce(self.grads, segments=[(lo, hi - lo) for lo, hi in (self.group_ranges[g] for g in active)],

@@ -62,6 +62,9 @@ class NgpConfig:
     # reference loads, instant_ngp.py:45) [UPSTREAM tcnn EmaOptimizer]: inference reads the debiased moving average of
     # the weights, training the raw ones.  0 switches it off.
     ema_decay: float = 0.95
+    # single GPU: the grid backward takes the Adam step + weight average of its streamed hashed levels itself
+    # (nvo_set_fused_adam; bit-identical to the separate launches)
+    fuse_grid_adam: bool = True
     # Testbed::train adapts the rays per batch so that the marched samples meet the target batch (1 << 18):
     # rays <- rays * target / measured, rounded up to the batch granularity (128), every `density_update_every` steps
     # (upstream does it where it reads the loss back, every 16 steps) [UPSTREAM NerfCounters::update_after_training].
@@ -321,7 +324,8 @@ class NgpEngine:
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None,
             d_density_out=ws["d_density_out"].data_ptr() if training else None,
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
-            d_weights=self._pp("rgb", self.grads).value if training else None)
+            d_weights=self._pp("rgb", self.grads).value if training else None,
+            nonfinite_flag=self.skip_flag.data_ptr() if (training and self._leaf_flags) else None)
 
     def _loss_args(self, ws, training: bool, has_depth: bool, background):
         cfg = self.cfg
@@ -340,14 +344,21 @@ class NgpEngine:
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None, d_rgb_stride=16,
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None)
 
-    def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False) -> None:
-        """``leaf_flags`` (single GPU): the hash-grid backward -- the leaf of the 16-bit gradient chain -- raises
-        skip_flag where it meets a non-finite dL/d(encoded); optimizer_step then scans only the two MLPs' weight
-        gradients (where an overflow inside the chain lands: dW = dZ x H) instead of all 12.6 M gradients
-        (nonfinite_flag: 17.6 us per step)."""
+    def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False,
+                         fused_adam=None) -> None:
+        """``leaf_flags`` (single GPU): the producers raise skip_flag themselves -- the hash-grid backward (the leaf of the
+        16-bit gradient chain) where it meets a non-finite dL/d(encoded), the two fused-MLP backwards where a weight-
+        gradient total is not finite (an overflow inside the chain lands in dW = dZ^T H) -- instead of a scan of all
+        12.6 M gradients behind the backward (nonfinite_flag: 17.6 us per step).
+        ``fused_adam``: (lo, hi) from _fused_adam_plan(): the grid backward steps those parameters itself (Adam + weight
+        average, nvo_set_fused_adam) and leaves their gradient unwritten."""
         stream = _stream(self.device)
         cap = self.cfg.capacity
-        self.grads.zero_()
+        if fused_adam is None:
+            self.grads.zero_()
+        else:  # (nothing accumulates into the fused range)
+            self.grads[:fused_adam[0]].zero_()
+            self.grads[fused_adam[1]:].zero_()
         self.losses.zero_()
         if leaf_flags != self._leaf_flags:
             self.density_net.set_option("nonfinite_flag_ptr", self.skip_flag.data_ptr() if leaf_flags else 0)
@@ -360,9 +371,15 @@ class NgpEngine:
         ra = self._rgb_args(ws, True)
         _call("nvo_ngp_rgb_bwd", stream, C.byref(ra))
         pose = self.cfg.optimize_extrinsics and self._pose_inputs is not None and "dx01" in ws
-        _call("nvo_bwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
-              _ptr(ws["density_out"]), _ptr(ws["d_density_out"]), _ptr(ws["ctx"]), _ptr(ws["dx01"]) if pose else None,
-              self._pp("density", self.grads))
+        if fused_adam is not None:
+            self._set_fused_adam(True)
+        try:
+            _call("nvo_bwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self.params_half),
+                  _ptr(ws["density_out"]), _ptr(ws["d_density_out"]), _ptr(ws["ctx"]), _ptr(ws["dx01"]) if pose else None,
+                  self._pp("density", self.grads))
+        finally:
+            if fused_adam is not None:
+                self._set_fused_adam(False)
         if pose:
             self._pose_backward(ws, stream)
 
@@ -385,20 +402,48 @@ class NgpEngine:
               cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, cfg.loss_scale / self.world_size, _ptr(self.pose_grads),
               C.c_void_p(self.losses.data_ptr() + 5 * 4), 1)
 
-    def optimizer_step(self) -> None:
+    def _fused_adam_plan(self):
+        """(lo, hi) of the flat parameter buffer the grid backward can step itself (its streamed hashed levels), or None.
+        Single GPU with producer flags only: the verdict of the step must be final before that backward runs."""
+        if not self.cfg.fuse_grid_adam:
+            return None
+        first, n = C.c_uint64(0), C.c_uint64(0)
+        _call("nvo_fused_adam_range", self.density_net.handle, C.byref(first), C.byref(n))
+        if n.value == 0:
+            return None
+        lo = self.segments["density"][0] + int(first.value)
+        return lo, lo + int(n.value)
+
+    def _set_fused_adam(self, on: bool) -> None:
+        if not on:
+            _call("nvo_set_fused_adam", self.density_net.handle, None)
+            return
+        cfg = self.cfg
+        ema = cfg.ema_decay > 0.0
+        if ema and self.params_ema is None:
+            self.params_ema = torch.zeros_like(self.params)
+            self.params_ema_half = torch.zeros_like(self.params_half)
+        o = self.segments["density"][0]
+        a = _lib.FusedAdamArgs(
+            params=self.params.data_ptr() + 4 * o, params_half=self.params_half.data_ptr() + 2 * o,
+            exp_avg=self.exp_avg.data_ptr() + 4 * o, exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * o, hyper_dev=None,
+            bias_dev=None, loss_scale_dev=None, skip_flag=self.skip_flag.data_ptr(), lr=cfg.lr, grad_scale=1.0 / cfg.loss_scale,
+            beta1=cfg.adam_betas[0], beta2=cfg.adam_betas[1], eps=cfg.adam_eps, step=self.opt_step + 1,
+            ema=self.params_ema.data_ptr() + 4 * o if ema else None,
+            ema_half=self.params_ema_half.data_ptr() + 2 * o if ema else None, ema_decay=cfg.ema_decay,
+            ema_step_dev=self._ema_step_dev.data_ptr() if ema else None)
+        _call("nvo_set_fused_adam", self.density_net.handle, C.byref(a))
+
+    def optimizer_step(self, fused_adam=None) -> None:
         cfg = self.cfg
         stream = _stream(self.device)
         self.opt_step += 1
-        if self._leaf_flags:
-            # the grid backward raised the flag for its own range; every other way a 16-bit overflow can enter the step
-            # ends up in a weight gradient of one of the two MLPs (~7 K scalars, one small launch)
-            offs = (C.c_uint64 * 2)(0, self.density_net.n_params)
-            sizes = (C.c_uint64 * 2)(self.n_density_mlp, self.n_rgb)
-            slots = (C.c_uint32 * 2)(0, 0)
-            _call("nvo_nonfinite_flag_spans_or", stream, 2, offs, sizes, slots, _ptr(self.grads), 0, _ptr(self.skip_flag))
-        else:
+        if not self._leaf_flags:
             _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), 0, _ptr(self.skip_flag))
         n_grid = self.density_net.n_params - self.n_density_mlp
+        if fused_adam is not None:  # (the backward stepped [fused_adam): the tail of the grid's range)
+            assert self.n_density_mlp <= fused_adam[0] and fused_adam[1] == self.density_net.n_params
+            n_grid = fused_adam[0] - self.n_density_mlp
         # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only
         for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
                               (self.density_net.n_params, self.n_rgb, cfg.l2_reg)):
@@ -414,8 +459,16 @@ class NgpEngine:
             # (Should the very first step be skipped, inference would read an all-zero average for one step: instant-ngp
             # has the same window; the debias factor itself is exact -- it follows the device counter.)
             self._ema_started = True
-            _call("nvo_ema_update_dev", stream, self.n_params, _ptr(self.params), _ptr(self.params_ema),
-                  _ptr(self.params_ema_half), cfg.ema_decay, _ptr(self._ema_step_dev), _ptr(self.skip_flag))
+            lo, hi = (0, self.n_params)
+            if fused_adam is not None:
+                # the backward averaged [fused_adam) already (with the counter as it stands): the head here without
+                # committing the counter, the tail below with it
+                _call("nvo_ema_update_dev_part", stream, fused_adam[0], _ptr(self.params), _ptr(self.params_ema),
+                      _ptr(self.params_ema_half), cfg.ema_decay, _ptr(self._ema_step_dev), _ptr(self.skip_flag))
+                lo = fused_adam[1]
+            _call("nvo_ema_update_dev", stream, hi - lo, C.c_void_p(self.params.data_ptr() + 4 * lo),
+                  C.c_void_p(self.params_ema.data_ptr() + 4 * lo), C.c_void_p(self.params_ema_half.data_ptr() + 2 * lo),
+                  cfg.ema_decay, _ptr(self._ema_step_dev), _ptr(self.skip_flag))
         if cfg.optimize_extrinsics and self._pose_inputs is not None:
             n6 = cfg.num_images * 6
             _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
@@ -430,12 +483,14 @@ class NgpEngine:
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
         jitter = torch.rand(R, device=self.device)
         bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
-        self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg, leaf_flags=all_reduce is None)
+        fused = self._fused_adam_plan() if all_reduce is None else None
+        self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg, leaf_flags=all_reduce is None,
+                              fused_adam=fused)
         if all_reduce is not None:
             all_reduce(self.grads)
             if self.cfg.optimize_extrinsics and self._pose_inputs is not None:
                 all_reduce(self.pose_grads)
-        self.optimizer_step()
+        self.optimizer_step(fused_adam=fused)
         self.step += 1
         if self.cfg.adaptive_rays:
             self._adapt_rays(ws, R)

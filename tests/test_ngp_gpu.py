@@ -267,3 +267,64 @@ def test_adaptive_ray_batch_and_ema_inference(device):
     out_raw = eng.render_rays(o, dirs, torch.ones(64, device=device))["rgb"].clone()
     eng.params_ema, eng.params_ema_half = saved
     assert torch.isfinite(out_ema).all() and not torch.equal(out_ema, out_raw)
+
+
+def test_adam_and_ema_inside_the_grid_backward_are_bit_identical(device):
+    """NgpConfig.fuse_grid_adam: the grid backward of the density network applies Adam AND the weight average to the
+    entries of its streamed hashed levels while it still holds their finished gradient in LDS, and leaves that gradient
+    unwritten.  Several steps from identical states (the parameters of the unfused engine are copied into the fused one
+    before every step, because the MLPs' float-atomic weight gradients make two trajectories drift): the fused range's
+    master weights, moments, 16-bit copy, average and its 16-bit copy must equal the separate launches' bit for bit,
+    also on a step whose gradients overflow (huge loss scale: nothing may move)."""
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W = 8, 60, 80
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    c2w = opencv_to_opengl(seq["camera_extrinsics"])
+    c2w[:, :3, 3] += 0.5
+    c2w = c2w[:, :3, :4].contiguous()
+    images = seq["frames_color"].permute(0, 2, 3, 1).contiguous()
+    depths = seq["frames_depth"].permute(0, 2, 3, 1).contiguous()
+    engines = {}
+    for fuse in (True, False):
+        torch.manual_seed(9)
+        # (no extrinsics optimisation: its float-atomic pose gradient would let the two engines' rays drift apart)
+        engines[fuse] = NgpEngine(NgpConfig(num_images=n, num_rays=512, capacity=1 << 18, fuse_grid_adam=fuse,
+                                            optimize_extrinsics=False), device)
+        engines[fuse].update_density_grid()
+    fe, ue = engines[True], engines[False]
+    plan = fe._fused_adam_plan()
+    assert plan is not None and ue._fused_adam_plan() is None
+    lo, hi = plan
+    assert hi == fe.density_net.n_params and hi - lo > 0.5 * fe.density_net.n_params
+    scale = torch.tensor([n, H, W], device=device)
+    state = ("params", "exp_avg", "exp_avg_sq", "params_half", "params_ema", "params_ema_half")
+    for it in range(6):
+        overflow = it == 4
+        for e in (fe, ue):
+            e.cfg.loss_scale = 2.0 ** 60 if overflow else 128.0
+        idx = torch.floor(torch.rand(512, 3, device=device) * scale).long()
+        # identical state, identical random draws (the step takes its jitter / background from the global generator)
+        if it > 0:
+            for name in state:
+                getattr(fe, name).copy_(getattr(ue, name))
+            fe._ema_step_dev.copy_(ue._ema_step_dev)
+        before = {name: getattr(ue, name).clone() for name in state} if it > 0 else None
+        for e in (fe, ue):
+            torch.manual_seed(100 + it)
+            e.train_step(idx, seq["camera_intrinsics"], c2w, images, depths)
+        torch.cuda.synchronize()
+        assert bool(fe.skip_flag.item()) == bool(ue.skip_flag.item()) == overflow, (it, fe.skip_flag.item(), ue.skip_flag.item())
+        assert int(fe._ema_step_dev.item()) == int(ue._ema_step_dev.item())
+        for name in state:
+            x, y = getattr(fe, name)[lo:hi], getattr(ue, name)[lo:hi]
+            x = x.view(torch.int16) if x.dtype == torch.float16 else x.view(torch.int32)
+            y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
+            assert torch.equal(x, y), f"step {it}: {name} of the fused range differs ({int((x != y).sum())} words)"
+            if overflow and before is not None:
+                assert torch.equal(getattr(fe, name), before[name]), f"skipped step moved {name}"
+        # the rest of the parameters went through the same launches in both engines (float atomics in the MLP dW: close)
+        assert torch.allclose(fe.params[:lo], ue.params[:lo], rtol=1e-3, atol=1e-5)
+    assert bool((fe.params[lo:hi] != 0).any()) and bool((fe.params_ema[lo:hi] != 0).any())
