@@ -34,10 +34,15 @@ def main():
     write = load(sys.argv[2], "WRITE_SIZE")
     out_path = sys.argv[3]
     kernels = []
+    # only the kernels of the training step: whatever ran fewer than `min_launches` times in the profiled command is set-up
+    # work (torch's GEMMs of the synthetic scene, the eager warm-up's own launches) and stays out of the summary
+    min_launches = int(sys.argv[4]) // 3 if len(sys.argv) > 4 else 1
     for key in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(key, [0.0, 0])
         w, nw = write.get(key, [0.0, 0])
         n = max(nf, nw, 1)
+        if n < min_launches or key[0].startswith(("k_Ailk", "k_Alik", "k_Ajlk")):
+            continue
         kernels.append({"kernel": key[0], "grid_size": key[1], "launches": n,
                         "FETCH_SIZE_KB_per_launch": round(f / max(nf, 1), 1),
                         "WRITE_SIZE_KB_per_launch": round(w / max(nw, 1), 1)})
@@ -82,7 +87,7 @@ def main():
     commit = os.environ.get("NVO_COMMIT", "")
     note = ((f"commit {commit}; " if commit else "") +
             "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
-            "`python3 bench.py --steps 20 --warmup 5 --psnr off --cpu-baseline off --late-steps 0`; raw counter unit KB; "
+            "`python3 bench.py --steps 20 --warmup 5 --psnr off --cpu-baseline off --late-steps 0 --no-kernel-table --render-frames 0 --ngp-steps 0` (graph-replayed steps; kernels launched fewer than a third as often as the step are left out); raw counter unit KB; "
             "per launch = sum / launches.  FETCH_SIZE_KB_corrected = raw x 2 for the kernels whose reads are pure coalesced "
             "streams (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of such reads; calibrated with "
             "tools/probes/read_bw_probe at 8 and 16 B per lane), raw for every other kernel (uncalibrated access widths); "
