@@ -583,6 +583,10 @@ typedef struct nvo_adam_group {
      * that runs its groups in two launches keeps ONE flag word per group that way) */
     uint32_t flag_slot;
     uint32_t flag_slot_set;
+    /* L2 weight decay of this group (folded into the gradient); used instead of the call's weight_decay when
+     * weight_decay_set != 0 -- instant-ngp decays its MLP weights and leaves the hash table alone, in one launch */
+    float weight_decay;
+    uint32_t weight_decay_set;
 } nvo_adam_group;
 int nvo_adam_step_groups(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
                          void* params_half, const void* grads, int grads_are_half, float* exp_avg, float* exp_avg_sq,

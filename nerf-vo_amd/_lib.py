@@ -84,7 +84,7 @@ class AdamGroup(C.Structure):
     """nvo_adam_group (include/nerfvo_hip.h)"""
     _fields_ = [("offset", C.c_uint64), ("n", C.c_uint64), ("lr", C.c_float), ("step", C.c_uint32),
                 ("hyper_dev", C.c_void_p), ("bias_dev", C.c_void_p), ("flag_slot", C.c_uint32),
-                ("flag_slot_set", C.c_uint32)]
+                ("flag_slot_set", C.c_uint32), ("weight_decay", C.c_float), ("weight_decay_set", C.c_uint32)]
 
 
 class DepthAlignArgs(C.Structure):

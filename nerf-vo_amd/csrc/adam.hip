@@ -118,6 +118,7 @@ struct AdamGroups {
     const float* bias_dev[kAdamMaxGroups];  // {1 - beta1^t, sqrt(1 - beta2^t)} kept by nvo_opt_commit (nvo_adam_group::bias_dev)
     int vec4[kAdamMaxGroups];
     uint32_t slot[kAdamMaxGroups];  // index of the group's skip flag
+    float wd[kAdamMaxGroups];       // L2 weight decay of the group
 };
 
 template <typename GT>
@@ -132,6 +133,7 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
     h.lr = gr.lr[k];
     h.bias1 = gr.bias1[k];
     h.bias2_sqrt = gr.bias2_sqrt[k];
+    h.weight_decay = gr.wd[k];
     if (gr.hyper_dev[k]) {
         h.lr = gr.hyper_dev[k][0];
         h.bias1 = gr.hyper_dev[k][1];
@@ -674,6 +676,7 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
         gr.bias_dev[k] = groups[i].bias_dev;
         // flag word of the group: its index in the caller's array unless the caller pins one (flag_slot + 1)
         gr.slot[k] = groups[i].flag_slot_set ? groups[i].flag_slot : i;
+        gr.wd[k] = groups[i].weight_decay_set ? groups[i].weight_decay : weight_decay;
         const uintptr_t align = (uintptr_t)(params + o) | (uintptr_t)(exp_avg + o) | (uintptr_t)(exp_avg_sq + o);
         gr.vec4[k] = (align & 15u) == 0 && (!params_half || (((uintptr_t)params_half + 2 * o) & 7u) == 0) &&
                      ((((uintptr_t)grads + gsz * o) & (grads_are_half ? 7u : 15u)) == 0);

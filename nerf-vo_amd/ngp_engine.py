@@ -444,14 +444,15 @@ class NgpEngine:
         if fused_adam is not None:  # (the backward stepped [fused_adam): the tail of the grid's range)
             assert self.n_density_mlp <= fused_adam[0] and fused_adam[1] == self.density_net.n_params
             n_grid = fused_adam[0] - self.n_density_mlp
-        # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only
-        for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
-                              (self.density_net.n_params, self.n_rgb, cfg.l2_reg)):
-            _call("nvo_adam_step", stream, size, C.c_void_p(self.params.data_ptr() + 4 * off),
-                  C.c_void_p(self.params_half.data_ptr() + 2 * off), C.c_void_p(self.grads.data_ptr() + 4 * off), 0,
-                  C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
-                  cfg.lr, cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, wd,
-                  _ptr(self.skip_flag), None)
+        # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only; ONE launch
+        batch = [_lib.AdamGroup(offset=off, n=size, lr=cfg.lr, step=self.opt_step, hyper_dev=None, bias_dev=None, flag_slot=0,
+                                flag_slot_set=1, weight_decay=wd, weight_decay_set=1)
+                 for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
+                                       (self.density_net.n_params, self.n_rgb, cfg.l2_reg)) if size > 0]
+        arr = (_lib.AdamGroup * len(batch))(*batch)
+        _call("nvo_adam_step_groups", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(self.grads), 0,
+              _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
         if cfg.ema_decay > 0.0:
             if self.params_ema is None:
                 self.params_ema = torch.zeros_like(self.params)
