@@ -223,6 +223,29 @@ __device__ __forceinline__ void layer_mm_t(const WTFrag<N_OUT, K_IN>& wt,
     }
 }
 
+// layer_mm with the A fragments read from a row-major LDS copy of W (row stride K_IN + 4 halfs, see RowStage) one output
+// tile at a time: same fragments, same instruction sequence, same result as layer_mm on WFrag registers
+template <int N_OUT, int K_IN>
+__device__ __forceinline__ void layer_mm_lds(const T* stage, int lane, const T4 (&in)[K_IN / 16], f4 (&acc)[N_OUT / 16]) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < N_OUT / 16; ++tn) {
+        T4 w[K_IN / 16];
+#pragma unroll
+        for (int tk = 0; tk < K_IN / 16; ++tk)
+            w[tk] = *reinterpret_cast<const T4*>(stage + (16 * tn + r) * (K_IN + 4) + 16 * tk + 4 * g);
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+        if constexpr ((K_IN / 16) % 2 == 0 && kUseK32) {
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; tk += 2) c = mfma32(w[tk], w[tk + 1], in[tk], in[tk + 1], c);
+        } else {
+#pragma unroll
+            for (int tk = 0; tk < K_IN / 16; ++tk) c = mfma16(w[tk], in[tk], c);
+        }
+        acc[tn] = c;
+    }
+}
+
 // Load the B-operand fragments of one 16-sample input tile: x[tk][j] = in[m][16tk + 4g + j]
 template <int IN_PAD, int IO>
 __device__ __forceinline__ void load_input(const Args& a, uint32_t row, int g,
@@ -570,7 +593,9 @@ struct DwAcc {
     // instruction -- the fast float-atomic shape -- and 4x fewer adds per address).
     // MUST be called by every wave of the block (contains __syncthreads()).
     __device__ __forceinline__ void flush_block(float* __restrict__ dW, float* red, int lane, int wib,
-                                                float* __restrict__ partial = nullptr, uint32_t* nf_flag = nullptr) const {
+                                                float* __restrict__ partial = nullptr, uint32_t* nf_flag = nullptr,
+                                                int tid = -1) const {
+        if (tid < 0) tid = (int)threadIdx.x;  // (role kernels pass the index among the kMlpBlock flushing threads)
         const int c = lane & 15, g = lane >> 4;
         for (int w = 0; w < kWavesPerBlock; ++w) {
             if (wib == w) {
@@ -590,12 +615,12 @@ struct DwAcc {
         // SLOWER -- 57.5 vs 56.1 us for the colour head -- the L2 handles the convoy better than a spread)
         uint32_t chk = 0u;  // exponent bits all ones: inf or NaN
         if (partial) {  // deterministic mode: the block total is STORED; a second launch sums the blocks in order
-            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) {
+            for (int e = tid; e < N_OUT * K_IN; e += kMlpBlock) {
                 partial[e] = red[e];
                 chk |= (uint32_t)((__float_as_uint(red[e]) & 0x7f800000u) == 0x7f800000u);
             }
         } else {
-            for (int e = threadIdx.x; e < N_OUT * K_IN; e += kMlpBlock) {
+            for (int e = tid; e < N_OUT * K_IN; e += kMlpBlock) {
                 atomicAdd(dW + e, red[e]);
                 chk |= (uint32_t)((__float_as_uint(red[e]) & 0x7f800000u) == 0x7f800000u);
             }
@@ -624,14 +649,38 @@ __device__ unsigned long long NVO_MLP_NAME(nvo_mlp_phase_cycles)[16];
 #define NVO_PH(k)
 #endif
 
+// LDS halfs of the backward kernel (kernel and launcher): two transposing tiles per wave, or -- roles -- one tile set
+// {dZ_L | H_l | dZ_l | X} per chain wave (8 of them) + the row-major copies of the matrices, which stay
+constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles) {
+    const int maxw = width > in_pad ? (width > out_pad ? width : out_pad) : (in_pad > out_pad ? in_pad : out_pad);
+    const int stage = width * (in_pad + 4) + (n_hidden - 1) * width * (width + 4) + out_pad * (width + 4);
+    const int set = 16 * (out_pad + 4) + 2 * n_hidden * 16 * (width + 4) + 16 * (in_pad + 4);
+    if (roles) return 2 * kWavesPerBlock * set + stage;
+    const int tiles = kWavesPerBlock * 2 * 16 * (maxw + 4);
+    return tiles > stage ? tiles : stage;
+}
+
 // RECOMP (single-hidden-layer ReLU networks): the hidden activation is not read back from memory but
 // recomputed from the input row with the same MFMA sequence and the same fp16 rounding as the forward (so it
 // is bit-identical) -- the forward then does not store it at all.  64..128 bytes per sample less traffic in
 // each direction for one to eight extra MFMAs per 16-sample tile.
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP>
-__global__ void __launch_bounds__(kMlpBlock)
+//
+// ROLES (the 64-wide networks): 12 waves per workgroup.  Waves 0-7 ("chain") hold the transposed weight fragments and run
+// everything that is a chain through the layers -- recomputation, dZ, dX, epilogue; waves 8-11 ("dW") hold the fp32
+// weight-gradient accumulators and do nothing but transposed LDS reads + the dZ^T H products of the tiles the chain waves
+// hand them.  The dW role is MODEL-parallel: wave d owns a quarter of every matrix (36 accumulator registers) and reads
+// all eight tile sets, so the chain role (~150 registers) decides the register count: THREE waves per SIMD where the
+// single-role kernel (280 registers) runs one -- and one chain wave per SIMD is what bounds that kernel (~700
+// instructions per 16-sample tile, half of the cycles stalled on its own dependencies; EXPERIMENTS.md 8.11).
+// Hand-over: ONE tile set {dZ_L | H_l | dZ_l | X} per chain wave in LDS, written as the tiles are produced behind
+// barrier B (after the recomputation: the dW waves are done with the previous contents) and released by barrier A at
+// the end of the step; the dW waves read while the chain waves load and recompute the next tile.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP, bool ROLES = false>
+__global__ void __launch_bounds__(ROLES ? 3 * kMlpBlock : kMlpBlock)
 NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     static_assert(!RECOMP || RELU, "hidden recomputation: ReLU networks");
+    static_assert(!ROLES || (RECOMP && !COMPACT), "roles: recomputing, non-compact networks");
+    constexpr int kChainWaves = ROLES ? 2 * kWavesPerBlock : kWavesPerBlock;
     NVO_PH_START;
     const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
     constexpr int MAXW = (WIDTH > IN_PAD ? (WIDTH > OUT_PAD ? WIDTH : OUT_PAD)
@@ -640,14 +689,24 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     constexpr int kTileHalfs = 16 * (MAXW + 4);
     constexpr int kStageHalfs = RowStage<WIDTH, IN_PAD>::kHalfs + (N_HIDDEN - 1) * RowStage<WIDTH, WIDTH>::kHalfs +
                                 RowStage<OUT_PAD, WIDTH>::kHalfs;
-    constexpr int kLdsHalfs = kWavesPerBlock * 2 * kTileHalfs > kStageHalfs ? kWavesPerBlock * 2 * kTileHalfs : kStageHalfs;
-    __shared__ __attribute__((aligned(16))) T lds[kLdsHalfs];
+    // ROLES: per chain wave ONE set of tiles {dZ_L | H_0..H_{n-1} | dZ_0..dZ_{n-1} | X} (each with its own row stride),
+    // and behind the sets the row-major copies of the matrices, which stay (the chain reads its forward fragments there)
+    constexpr int kHTile = 16 * (WIDTH + 4), kOffH = 16 * (OUT_PAD + 4), kOffDZ = kOffH + N_HIDDEN * kHTile,
+                  kOffX = kOffDZ + N_HIDDEN * kHTile, kSetHalfs = kOffX + 16 * (IN_PAD + 4);
+    constexpr int kTilesHalfs = ROLES ? kChainWaves * kSetHalfs : kWavesPerBlock * 2 * kTileHalfs;
+    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
+    static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES), "launcher and kernel disagree on the LDS size");
+    __shared__ __attribute__((aligned(16))) T lds_static[ROLES ? 8 : kLdsHalfs];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];  // (ROLES: 112 KB, opted in by the launcher)
+    T* const lds = ROLES ? reinterpret_cast<T*>(lds_dyn) : lds_static;
 
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
-    const int wib = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib;
-    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const int wib_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool is_dw = ROLES && wib_all >= kChainWaves;  // waves 8-11
+    const int wib = is_dw ? wib_all - kChainWaves : wib_all;  // chain index 0..7 | dW index 0..3
+    const uint32_t wave = blockIdx.x * kChainWaves + wib;     // (chain role) first tile
+    const uint32_t n_waves = gridDim.x * kChainWaves;
     const uint32_t n_tiles = a.batch >> 4;
     const LdsTile<MAXW> tz{lds + (2 * wib) * kTileHalfs}, th{lds + (2 * wib + 1) * kTileHalfs};
 
@@ -672,35 +731,42 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         // (the recomputation's forward fragments come from the same row-major copies: W0 is staged for them alone when
         // no dL/dinput is wanted)
         const bool stage_w0 = need_dinput || RECOMP;
-        if (stage_w0) s0.issue(W);
-#pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].issue(W + WIDTH * IN_PAD + l * WIDTH * WIDTH);
-        sl.issue(W + WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH);
-        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
-            if (a.cam_idx && wave < n_tiles) cam_first = (uint32_t)a.cam_idx[(wave * 16 + m) / a.samples_per_ray];
-        }
-        T* stage = lds;  // the wave tiles are idle until the first sample tile
+        const bool stager = !ROLES || threadIdx.x < kMlpBlock;  // (RowStage strides by kMlpBlock threads)
+        T* stage = lds + (ROLES ? kTilesHalfs : 0);  // (single role: the wave tiles are idle until the first sample tile)
         T* stage_h = stage + RowStage<WIDTH, IN_PAD>::kHalfs;
         T* stage_l = stage_h + (N_HIDDEN - 1) * RowStage<WIDTH, WIDTH>::kHalfs;
-        if (stage_w0) s0.store(stage);
+        if (stager) {
+            if (stage_w0) s0.issue(W);
 #pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].store(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs);
-        sl.store(stage_l);
+            for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].issue(W + WIDTH * IN_PAD + l * WIDTH * WIDTH);
+            sl.issue(W + WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH);
+        }
+        if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+            if (a.cam_idx && wave < n_tiles && !is_dw) cam_first = (uint32_t)a.cam_idx[(wave * 16 + m) / a.samples_per_ray];
+        }
+        if (stager) {
+            if (stage_w0) s0.store(stage);
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN - 1; ++l) sh[l].store(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs);
+            sl.store(stage_l);
+        }
         __syncthreads();
-        if (need_dinput) wt0.read_staged(stage, lane);
+        if (!is_dw) {
+            if (need_dinput) wt0.read_staged(stage, lane);
 #pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) wth[l].read_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
-        wtl.read_staged(stage_l, lane);
-        if constexpr (RECOMP) {
-            w0f.load_staged(stage, lane);
+            for (int l = 0; l < N_HIDDEN - 1; ++l) wth[l].read_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
+            wtl.read_staged(stage_l, lane);
+            if constexpr (RECOMP && !ROLES) {  // (roles: the forward fragments are read from the copies for every tile)
+                w0f.load_staged(stage, lane);
 #pragma unroll
-            for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
+                for (int l = 0; l < N_HIDDEN - 1; ++l) whf[l].load_staged(stage_h + l * RowStage<WIDTH, WIDTH>::kHalfs, lane);
+            }
         }
         __syncthreads();  // the staging bytes become the wave tiles
     }
-    DwAcc<WIDTH, IN_PAD> dw0;
-    DwAcc<WIDTH, WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
-    DwAcc<OUT_PAD, WIDTH> dwl;
+    DwAcc<ROLES ? 16 : WIDTH, ROLES ? 16 : IN_PAD> dw0;  // (roles: the dW role declares its own, see there)
+    DwAcc<ROLES ? 16 : WIDTH, ROLES ? 16 : WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+    DwAcc<ROLES ? 16 : OUT_PAD, ROLES ? 16 : WIDTH> dwl;
     // (level-major dinput) L1 norm of the 16-bit dL/dinput values this lane stores, per column 16 tk + 4 g + j, and the
     // wave's count of samples with a non-zero dL/doutput: Args::dx_l1_partial / dx_live_partial
     float l1a[IN_PAD / 16][4];
@@ -709,10 +775,12 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     for (int tk = 0; tk < IN_PAD / 16; ++tk)
 #pragma unroll
         for (int j = 0; j < 4; ++j) l1a[tk][j] = 0.f;
-    dw0.zero();
+    if constexpr (!ROLES) {
+        dw0.zero();
 #pragma unroll
-    for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
-    dwl.zero();
+        for (int l = 0; l < N_HIDDEN - 1; ++l) dwh[l].zero();
+        dwl.zero();
+    }
 
     // Every global input of a tile (dL/dout, out, all hidden activations, the input row) is requested in one
     // go, and the NEXT tile's inputs are requested before the current tile is computed: with the dW
@@ -774,7 +842,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     };
     TileIn cur;
     uint32_t cam_nxt = 0;
-    if (wave < n_tiles) {
+    if (wave < n_tiles && !is_dw) {
         load_tile(wave, cur, cam_first);
         cam_nxt = load_cam(min(wave + n_waves, n_tiles - 1u));
     }
@@ -786,7 +854,76 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #ifdef NVO_MLP_PHASE
     ph_[10] = ph_t_ - ph_start_;  // prologue: weight staging, fragment loads, first tile
 #endif
-    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+    // ---- roles: step `it` of chain wave c handles tile blockIdx.x * 8 + c + it * n_waves; every wave of the workgroup
+    // runs n_iter steps (barrier B, barrier A) whether or not its chain wave still has a tile
+    const uint32_t n_iter = ROLES ? (n_tiles + n_waves - 1u) / n_waves : 0u;
+    if (is_dw) {
+        // MODEL-parallel: dW wave d owns rows 16 d .. 16 d + 15 of dW_0 and of every hidden dW, and column tile d of the
+        // output layer's dW -- 36 accumulator registers instead of 144, so the CHAIN role decides the kernel's register
+        // count -- and reads what it needs of ALL chain waves' tile sets (12 transposed fragments per tile).
+        static_assert(!ROLES || (OUT_PAD == 16 && WIDTH == 64), "roles: 64-wide networks with a 16-wide (padded) output");
+        f4 a0[IN_PAD / 16], ah[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][WIDTH / 16], al = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < IN_PAD / 16; ++t) a0[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN - 1; ++l)
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) ah[l][t] = f4{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            __syncthreads();  // B: (this role is done with the previous sets)
+            __syncthreads();  // A: the chain waves have written the sets of step `it`
+            for (int c = 0; c < kChainWaves; ++c) {
+                if (blockIdx.x * kChainWaves + c + it * n_waves >= n_tiles) continue;  // (wave-uniform)
+                T* const set = lds + (size_t)(c * kSetHalfs);
+                // output layer: dW_l[n][16 d + k] += sum_m dZ_L[m][n] H_{n-1}[m][16 d + k]
+                al = mfma16(LdsTile<OUT_PAD>{set}.load_tr(lane, 0), LdsTile<WIDTH>{set + kOffH + (N_HIDDEN - 1) * kHTile}.load_tr(lane, wib), al);
+#pragma unroll
+                for (int l = N_HIDDEN - 1; l >= 1; --l) {  // dW_h[l-1][16 d + r][k] += dZ_l^T H_{l-1}
+                    const T4 zt = LdsTile<WIDTH>{set + kOffDZ + l * kHTile}.load_tr(lane, wib);
+                    const LdsTile<WIDTH> thh{set + kOffH + (l - 1) * kHTile};
+#pragma unroll
+                    for (int t = 0; t < WIDTH / 16; ++t) ah[l - 1][t] = mfma16(zt, thh.load_tr(lane, t), ah[l - 1][t]);
+                }
+                {
+                    const T4 zt = LdsTile<WIDTH>{set + kOffDZ}.load_tr(lane, wib);
+                    const LdsTile<IN_PAD> tx{set + kOffX};
+#pragma unroll
+                    for (int t = 0; t < IN_PAD / 16; ++t) a0[t] = mfma16(zt, tx.load_tr(lane, t), a0[t]);
+                }
+            }
+        }
+        if (a.dweights) {
+            // every entry of dW is owned by ONE wave of the workgroup: no reduction across waves; accumulator (lane, r) =
+            // dW[16 tn + 4 g + r][16 tk + (lane & 15)]
+            constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
+            float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
+            float* dst = part ? part : a.dweights;
+            uint32_t chk = 0u;
+            auto put = [&](float* base, int row, int col, int ld, float v) {
+                chk |= (uint32_t)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
+                if (part) base[row * ld + col] = v; else atomicAdd(base + row * ld + col, v);
+            };
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(dst, 16 * wib + 4 * g + r, 16 * t + m, IN_PAD, a0[t][r]);
+            float* dh = dst + WIDTH * IN_PAD;
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN - 1; ++l) {
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) put(dh, 16 * wib + 4 * g + r, 16 * t + m, WIDTH, ah[l][t][r]);
+                dh += WIDTH * WIDTH;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put(dh, 4 * g + r, 16 * wib + m, WIDTH, al[r]);
+            if (a.nf_flag && __ballot(chk != 0u) != 0ull && lane == 0) atomicOr(a.nf_flag, 1u);
+        }
+    }
+    uint32_t it = 0u;  // (roles: step counter of the chain role)
+    T* const set = lds + (size_t)((ROLES ? wib : 0) * kSetHalfs);  // (roles) this chain wave's tile set
+    for (uint32_t tile = wave; tile < n_tiles && !is_dw; tile += n_waves) {
         const uint32_t row = tile * 16 + m;
         NVO_PH(9);
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
@@ -834,12 +971,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         T4 h[WIDTH / 16];
         if constexpr (RECOMP) {  // forward chain again: identical MFMA order and fp16 rounding
             f4 hacc[WIDTH / 16];
-            layer_mm<WIDTH, IN_PAD>(w0f, cur.x, hacc);
+            const T* const stage_w = lds + (ROLES ? kTilesHalfs : 0);  // (roles) row-major W0 | W_h .. behind the tile sets
+            if constexpr (ROLES) layer_mm_lds<WIDTH, IN_PAD>(stage_w, lane, cur.x, hacc);
+            else layer_mm<WIDTH, IN_PAD>(w0f, cur.x, hacc);
 #pragma unroll
             for (int t = 0; t < WIDTH / 16; ++t) cur.hs[0][t] = pack_act(NVO_ACT_RELU, hacc[t]);
 #pragma unroll
             for (int l = 1; l < N_HIDDEN; ++l) {
-                layer_mm<WIDTH, WIDTH>(whf[l - 1], cur.hs[l - 1], hacc);
+                if constexpr (ROLES)
+                    layer_mm_lds<WIDTH, WIDTH>(stage_w + RowStage<WIDTH, IN_PAD>::kHalfs + (l - 1) * RowStage<WIDTH, WIDTH>::kHalfs,
+                                               lane, cur.hs[l - 1], hacc);
+                else
+                    layer_mm<WIDTH, WIDTH>(whf[l - 1], cur.hs[l - 1], hacc);
 #pragma unroll
                 for (int t = 0; t < WIDTH / 16; ++t) cur.hs[l][t] = pack_act(NVO_ACT_RELU, hacc[t]);
             }
@@ -847,8 +990,28 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
         for (int t = 0; t < WIDTH / 16; ++t) h[t] = cur.hs[N_HIDDEN - 1][t];
         NVO_PH(1);
-        // dW_last += dZ_L^T H
-        {
+        // dW_last += dZ_L^T H   (roles: all dW products belong to the dW waves; the tiles go to this wave's set as they are
+        // produced, behind barrier B: the dW waves are done with the previous step's sets)
+        if constexpr (ROLES) {
+            __syncthreads();  // B
+            const LdsTile<OUT_PAD> tzl{set};
+            const LdsTile<WIDTH> thl{set + kOffH + (N_HIDDEN - 1) * kHTile};
+#pragma unroll
+            for (int t = 0; t < OUT_PAD / 16; ++t) tzl.store(m, g, t, dzl[t]);
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) thl.store(m, g, t, h[t]);
+            // (everything the recomputation produced goes now: the input tile and the lower hidden activations leave the
+            // registers -- H_{l-1} is read back from this wave's own set when its dZ needs it)
+            const LdsTile<IN_PAD> tx{set + kOffX};
+#pragma unroll
+            for (int t = 0; t < IN_PAD / 16; ++t) tx.store(m, g, t, cur.x[t]);
+#pragma unroll
+            for (int l = 0; l < N_HIDDEN - 1; ++l) {
+                const LdsTile<WIDTH> thh{set + kOffH + l * kHTile};
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) thh.store(m, g, t, cur.hs[l][t]);
+            }
+        } else {
 #pragma unroll
             for (int t = 0; t < OUT_PAD / 16; ++t) tz.store(m, g, t, dzl[t]);
 #pragma unroll
@@ -879,24 +1042,36 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
         for (int l = N_HIDDEN - 1; l >= 1; --l) {
             T4 hp_[WIDTH / 16];  // H_{l-1}
-#pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) hp_[t] = cur.hs[l - 1][t];
-#pragma unroll
-            for (int t = 0; t < WIDTH / 16; ++t) {
-                tz.store(m, g, t, dz[t]);
-                th.store(m, g, t, hp_[t]);
-            }
-            wave_lds_sync();
-            {
-                T4 zt[WIDTH / 16], ht[WIDTH / 16];
+            if constexpr (ROLES) {
+                const LdsTile<WIDTH> tzz{set + kOffDZ + l * kHTile};
+                const T* hrow = set + kOffH + (l - 1) * kHTile + m * (WIDTH + 4) + 4 * g;  // (this lane's own stores)
 #pragma unroll
                 for (int t = 0; t < WIDTH / 16; ++t) {
-                    zt[t] = tz.load_tr(lane, t);
-                    ht[t] = th.load_tr(lane, t);
+                    tzz.store(m, g, t, dz[t]);
+                    hp_[t] = *reinterpret_cast<const T4*>(hrow + 16 * t);
                 }
-                dwh[l - 1].accumulate(zt, ht);
+            } else {
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) hp_[t] = cur.hs[l - 1][t];
             }
-            wave_lds_sync();
+            if constexpr (!ROLES) {
+#pragma unroll
+                for (int t = 0; t < WIDTH / 16; ++t) {
+                    tz.store(m, g, t, dz[t]);
+                    th.store(m, g, t, hp_[t]);
+                }
+                wave_lds_sync();
+                {
+                    T4 zt[WIDTH / 16], ht[WIDTH / 16];
+#pragma unroll
+                    for (int t = 0; t < WIDTH / 16; ++t) {
+                        zt[t] = tz.load_tr(lane, t);
+                        ht[t] = th.load_tr(lane, t);
+                    }
+                    dwh[l - 1].accumulate(zt, ht);
+                }
+                wave_lds_sync();
+            }
             f4 acc[WIDTH / 16];
             layer_mm_t<WIDTH, WIDTH>(wth[l - 1], dz, acc);
 #pragma unroll
@@ -907,7 +1082,11 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         }
         NVO_PH(4);
         // ---- first layer: dW0 += dZ_0^T X, dX = W0^T dZ_0
-        {
+        if constexpr (ROLES) {
+            const LdsTile<WIDTH> tz0{set + kOffDZ};
+#pragma unroll
+            for (int t = 0; t < WIDTH / 16; ++t) tz0.store(m, g, t, dz[t]);
+        } else {
             T4 x[IN_PAD / 16];
 #pragma unroll
             for (int t = 0; t < IN_PAD / 16; ++t) x[t] = cur.x[t];
@@ -1033,11 +1212,22 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             }
         }
         NVO_PH(7);
+        if constexpr (ROLES) {
+            __syncthreads();  // A: the sets of step `it` are complete
+            ++it;
+        }
         cur = nxt;
         NVO_PH(8);
     }
+    if constexpr (ROLES) {
+        if (!is_dw)
+            for (; it < n_iter; ++it) {  // (chain waves that ran out of tiles keep the workgroup's step count)
+                __syncthreads();
+                __syncthreads();
+            }
+    }
     // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
-    if (a.dweights) {
+    if (a.dweights && !is_dw && !ROLES) {  // (roles: the dW waves flush what they own themselves, without barriers)
         __syncthreads();  // every wave is done with its LDS tiles
         float* red = reinterpret_cast<float*>(lds);
         constexpr int kLdsFloats = (int)(sizeof(T) * kLdsHalfs / sizeof(float));
@@ -1046,16 +1236,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         float* dW = a.dweights;
         constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
         float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
-        dw0.flush_block(dW, red, lane, wib, part, a.nf_flag);
-        dW += WIDTH * IN_PAD;
-        if (part) part += WIDTH * IN_PAD;
+        if constexpr (!ROLES) {
+            dw0.flush_block(dW, red, lane, wib, part, a.nf_flag);
+            dW += WIDTH * IN_PAD;
+            if (part) part += WIDTH * IN_PAD;
 #pragma unroll
-        for (int l = 0; l < N_HIDDEN - 1; ++l) {
-            dwh[l].flush_block(dW, red, lane, wib, part, a.nf_flag);
-            dW += WIDTH * WIDTH;
-            if (part) part += WIDTH * WIDTH;
+            for (int l = 0; l < N_HIDDEN - 1; ++l) {
+                dwh[l].flush_block(dW, red, lane, wib, part, a.nf_flag);
+                dW += WIDTH * WIDTH;
+                if (part) part += WIDTH * WIDTH;
+            }
+            dwl.flush_block(dW, red, lane, wib, part, a.nf_flag);
         }
-        dwl.flush_block(dW, red, lane, wib, part, a.nf_flag);
     }
     if constexpr (IO == NVO_IO_HALF2_SOA) {
         if (a.dx_l1_partial && need_dinput) {  // (kernel-uniform)
@@ -1066,20 +1258,20 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = group16_sum(l1a[tk][j]);  // over the 16 sample lanes of this lane group
-                    if (m == 0) red[wib * IN_PAD + 16 * tk + 4 * g + j] = v;
+                    if (m == 0 && !is_dw) red[wib * IN_PAD + 16 * tk + 4 * g + j] = v;
                 }
-            if (lane == 0) reinterpret_cast<uint32_t*>(red)[kWavesPerBlock * IN_PAD + wib] = live_cnt;
+            if (lane == 0 && !is_dw) reinterpret_cast<uint32_t*>(red)[kChainWaves * IN_PAD + wib] = live_cnt;
             __syncthreads();
             if ((int)threadIdx.x < IN_PAD) {
                 float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < kWavesPerBlock; ++w) t += red[w * IN_PAD + threadIdx.x];
+                for (int w = 0; w < kChainWaves; ++w) t += red[w * IN_PAD + threadIdx.x];
                 a.dx_l1_partial[(size_t)blockIdx.x * IN_PAD + threadIdx.x] = t;
             }
             if (threadIdx.x == 0 && a.dx_live_partial) {
                 uint32_t c = 0u;
 #pragma unroll
-                for (int w = 0; w < kWavesPerBlock; ++w) c += reinterpret_cast<uint32_t*>(red)[kWavesPerBlock * IN_PAD + w];
+                for (int w = 0; w < kChainWaves; ++w) c += reinterpret_cast<uint32_t*>(red)[kChainWaves * IN_PAD + w];
                 a.dx_live_partial[blockIdx.x] = c;
             }
         }
@@ -1087,7 +1279,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #ifdef NVO_MLP_PHASE
     NVO_PH(11);  // dW flush (block reduction through LDS + float atomics)
     if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
-        if (wave == 0 && lane == 0)
+        if (wave == 0 && lane == 0 && !is_dw)
             for (int k = 0; k < 12; ++k) NVO_MLP_NAME(nvo_mlp_phase_cycles)[k] = ph_[k];
     }
 #endif
@@ -1172,6 +1364,27 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
         if (a.act == NVO_ACT_RELU) {
             if constexpr (kRecompOk) {
                 if (a.recompute_hidden && !a.compact_out) {
+                    if constexpr (WIDTH == 64 && N_HIDDEN == 1) {
+                        // the 64-wide single-hidden-layer networks (base MLP, NGP density network): chain / dW roles, see
+                        // k_mlp_bwd -- base network 30.3 -> 22.9 us.  (The colour head, two hidden layers: 52.3 us against
+                        // 49.5 single-role -- its dW waves need ~2000 cycles per step for 96 transposed reads + 72 MFMAs,
+                        // longer than the chain waves' loads + recomputation in front of barrier B.)
+                        static const bool roles = [] { const char* e = getenv("NVO_MLP_ROLES"); return !e || atoi(e) != 0; }();
+                        if (roles) {
+                            constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true);
+                            static bool attr_set = false;  // (> 64 KiB of dynamic LDS needs an explicit opt-in)
+                            if (!attr_set) {
+                                NVO_CHECK_HIP(hipFuncSetAttribute(
+                                    (const void*)NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytes));
+                                attr_set = true;
+                            }
+                            NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>),
+                                       dim3(blocks), dim3(3 * kMlpBlock), kBytes, stream, a);
+                            NVO_CHECK_LAUNCH();
+                            return NVO_OK;
+                        }
+                    }
                     NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true>), dim3(blocks), dim3(kMlpBlock), 0, stream, a);
                     NVO_CHECK_LAUNCH();
                     return NVO_OK;
