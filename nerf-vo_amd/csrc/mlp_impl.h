@@ -655,7 +655,7 @@ constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bo
     const int maxw = width > in_pad ? (width > out_pad ? width : out_pad) : (in_pad > out_pad ? in_pad : out_pad);
     const int stage = width * (in_pad + 4) + (n_hidden - 1) * width * (width + 4) + out_pad * (width + 4);
     const int set = 16 * (out_pad + 4) + 2 * n_hidden * 16 * (width + 4) + 16 * (in_pad + 4);
-    if (roles) return 2 * kWavesPerBlock * set + stage;
+    if (roles) return 2 * kWavesPerBlock * set + stage + 64;  // (+ 32 hand-over words: full[8], free[8])
     const int tiles = kWavesPerBlock * 2 * 16 * (maxw + 4);
     return tiles > stage ? tiles : stage;
 }
@@ -694,11 +694,22 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     constexpr int kHTile = 16 * (WIDTH + 4), kOffH = 16 * (OUT_PAD + 4), kOffDZ = kOffH + N_HIDDEN * kHTile,
                   kOffX = kOffDZ + N_HIDDEN * kHTile, kSetHalfs = kOffX + 16 * (IN_PAD + 4);
     constexpr int kTilesHalfs = ROLES ? kChainWaves * kSetHalfs : kWavesPerBlock * 2 * kTileHalfs;
-    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
+    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
     static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES), "launcher and kernel disagree on the LDS size");
     __shared__ __attribute__((aligned(16))) T lds_static[ROLES ? 8 : kLdsHalfs];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];  // (ROLES: 112 KB, opted in by the launcher)
     T* const lds = ROLES ? reinterpret_cast<T*>(lds_dyn) : lds_static;
+    // (roles) hand-over of a tile set.  Two hidden layers (kHandFlags): words in LDS -- full[c] = steps chain wave c has
+    // completed writing, free[c] = reads of set c the dW waves have finished (4 per step), release / acquire at workgroup
+    // scope, no barrier inside the tile loop: two workgroup barriers per step kept the eight chain waves in lockstep and
+    // cost ~2500 of a chain wave's 8100 cycles per tile (colour head 52.3 -> 41.4 us).  One hidden layer: the two barriers
+    // (short tiles, light dW role: 22.9 us with barriers, 27.3 with the words).
+    constexpr bool kHandFlags = ROLES && N_HIDDEN >= 2;
+    uint32_t* const hand_full = reinterpret_cast<uint32_t*>(lds + (ROLES ? kTilesHalfs + kStageHalfs : 0));
+    uint32_t* const hand_free = hand_full + 8;
+    if constexpr (ROLES) {
+        if (threadIdx.x < 16) hand_full[threadIdx.x] = 0u;  // (visible behind the prologue's barriers)
+    }
 
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
@@ -855,7 +866,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     ph_[10] = ph_t_ - ph_start_;  // prologue: weight staging, fragment loads, first tile
 #endif
     // ---- roles: step `it` of chain wave c handles tile blockIdx.x * 8 + c + it * n_waves; every wave of the workgroup
-    // runs n_iter steps (barrier B, barrier A) whether or not its chain wave still has a tile
+    // walks n_iter steps; hand-over per tile set through the words hand_full / hand_free (no barrier in the loop)
     const uint32_t n_iter = ROLES ? (n_tiles + n_waves - 1u) / n_waves : 0u;
     if (is_dw) {
         // MODEL-parallel: dW wave d owns rows 16 d .. 16 d + 15 of dW_0 and of every hidden dW, and column tile d of the
@@ -870,10 +881,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
             for (int t = 0; t < WIDTH / 16; ++t) ah[l][t] = f4{0.f, 0.f, 0.f, 0.f};
         for (uint32_t it = 0; it < n_iter; ++it) {
-            __syncthreads();  // B: (this role is done with the previous sets)
-            __syncthreads();  // A: the chain waves have written the sets of step `it`
-            for (int c = 0; c < kChainWaves; ++c) {
+            if constexpr (!kHandFlags) {
+                __syncthreads();  // B: (this role is done with the previous sets)
+                __syncthreads();  // A: the chain waves have written the sets of step `it`
+            }
+            for (int k = 0; k < kChainWaves; ++k) {
+                const int c = (2 * wib + k) & (kChainWaves - 1);  // (every dW wave starts at another set)
                 if (blockIdx.x * kChainWaves + c + it * n_waves >= n_tiles) continue;  // (wave-uniform)
+                if constexpr (kHandFlags) {
+                    // (taking whichever set is ready first instead of this fixed order measured slower: 42.7 vs 41.4 us)
+                    while (__hip_atomic_load(hand_full + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= it)
+                        __builtin_amdgcn_s_sleep(1);
+                }
                 T* const set = lds + (size_t)(c * kSetHalfs);
                 // output layer: dW_l[n][16 d + k] += sum_m dZ_L[m][n] H_{n-1}[m][16 d + k]
                 al = mfma16(LdsTile<OUT_PAD>{set}.load_tr(lane, 0), LdsTile<WIDTH>{set + kOffH + (N_HIDDEN - 1) * kHTile}.load_tr(lane, wib), al);
@@ -890,34 +909,43 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
                     for (int t = 0; t < IN_PAD / 16; ++t) a0[t] = mfma16(zt, tx.load_tr(lane, t), a0[t]);
                 }
+                if constexpr (kHandFlags) {
+                    if (lane == 0) __hip_atomic_fetch_add(hand_free + c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         if (a.dweights) {
-            // every entry of dW is owned by ONE wave of the workgroup: no reduction across waves; accumulator (lane, r) =
-            // dW[16 tn + 4 g + r][16 tk + (lane & 15)]
+            // every entry of dW is owned by ONE wave of the workgroup (no reduction across waves); accumulator (lane, r) =
+            // dW[16 tn + 4 g + r][16 tk + (lane & 15)].  The entries still go through LDS so that the adds leave in ROW
+            // order: 256 contiguous bytes per wave instruction is the fast float-atomic shape, 16 x 64-byte pieces
+            // straight from the accumulator layout are not (the direct form cost as much as the whole tile loop).
             constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
-            float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
-            float* dst = part ? part : a.dweights;
-            uint32_t chk = 0u;
-            auto put = [&](float* base, int row, int col, int ld, float v) {
-                chk |= (uint32_t)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
-                if (part) base[row * ld + col] = v; else atomicAdd(base + row * ld + col, v);
-            };
+            float* red = reinterpret_cast<float*>(lds);  // (the tile sets are idle behind the barrier)
+            static_assert(!ROLES || sizeof(float) * kWeights <= sizeof(T) * (size_t)kTilesHalfs, "dW staging does not fit the tile sets");
+            __syncthreads();
 #pragma unroll
             for (int t = 0; t < IN_PAD / 16; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(dst, 16 * wib + 4 * g + r, 16 * t + m, IN_PAD, a0[t][r]);
-            float* dh = dst + WIDTH * IN_PAD;
+                for (int r = 0; r < 4; ++r) red[(16 * wib + 4 * g + r) * IN_PAD + 16 * t + m] = a0[t][r];
+            float* rh = red + WIDTH * IN_PAD;
 #pragma unroll
             for (int l = 0; l < N_HIDDEN - 1; ++l) {
 #pragma unroll
                 for (int t = 0; t < WIDTH / 16; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) put(dh, 16 * wib + 4 * g + r, 16 * t + m, WIDTH, ah[l][t][r]);
-                dh += WIDTH * WIDTH;
+                    for (int r = 0; r < 4; ++r) rh[(16 * wib + 4 * g + r) * WIDTH + 16 * t + m] = ah[l][t][r];
+                rh += WIDTH * WIDTH;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) put(dh, 4 * g + r, 16 * wib + m, WIDTH, al[r]);
+            for (int r = 0; r < 4; ++r) rh[(4 * g + r) * WIDTH + 16 * wib + m] = al[r];
+            __syncthreads();
+            float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
+            uint32_t chk = 0u;
+            for (int e = (int)threadIdx.x - kChainWaves * 64; e < kWeights; e += kMlpBlock) {  // (the dW waves: threads 512..767)
+                const float v = red[e];
+                chk |= (uint32_t)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
+                if (part) part[e] = v; else atomicAdd(a.dweights + e, v);
+            }
             if (a.nf_flag && __ballot(chk != 0u) != 0ull && lane == 0) atomicOr(a.nf_flag, 1u);
         }
     }
@@ -993,7 +1021,13 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         // dW_last += dZ_L^T H   (roles: all dW products belong to the dW waves; the tiles go to this wave's set as they are
         // produced, behind barrier B: the dW waves are done with the previous step's sets)
         if constexpr (ROLES) {
-            __syncthreads();  // B
+            // B: the four dW waves are done with what step it - 1 left in this wave's set
+            if constexpr (kHandFlags) {
+                while (__hip_atomic_load(hand_free + wib, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * it)
+                    __builtin_amdgcn_s_sleep(1);
+            } else {
+                __syncthreads();
+            }
             const LdsTile<OUT_PAD> tzl{set};
             const LdsTile<WIDTH> thl{set + kOffH + (N_HIDDEN - 1) * kHTile};
 #pragma unroll
@@ -1213,21 +1247,31 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         }
         NVO_PH(7);
         if constexpr (ROLES) {
-            __syncthreads();  // A: the sets of step `it` are complete
-            ++it;
+            ++it;  // A: the set of this step is complete
+            if constexpr (kHandFlags) {
+                if (lane == 0) __hip_atomic_store(hand_full + wib, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __syncthreads();
+            }
         }
         cur = nxt;
         NVO_PH(8);
     }
-    if constexpr (ROLES) {
+    if constexpr (ROLES && !kHandFlags) {
         if (!is_dw)
-            for (; it < n_iter; ++it) {  // (chain waves that ran out of tiles keep the workgroup's step count)
+            for (; it < n_iter; ++it) {  // (chain waves that ran out of tiles keep the workgroup's barrier count)
                 __syncthreads();
                 __syncthreads();
             }
     }
     // ---- flush weight gradients (block-reduced through the now idle LDS tiles)
-    if (a.dweights && !is_dw && !ROLES) {  // (roles: the dW waves flush what they own themselves, without barriers)
+    if constexpr (ROLES) {
+        if (a.dweights && !is_dw) {  // (the two barriers of the dW role's flush)
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+    if (a.dweights && !is_dw && !ROLES) {
         __syncthreads();  // every wave is done with its LDS tiles
         float* red = reinterpret_cast<float*>(lds);
         constexpr int kLdsFloats = (int)(sizeof(T) * kLdsHalfs / sizeof(float));
@@ -1364,11 +1408,9 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
         if (a.act == NVO_ACT_RELU) {
             if constexpr (kRecompOk) {
                 if (a.recompute_hidden && !a.compact_out) {
-                    if constexpr (WIDTH == 64 && N_HIDDEN == 1) {
-                        // the 64-wide single-hidden-layer networks (base MLP, NGP density network): chain / dW roles, see
-                        // k_mlp_bwd -- base network 30.3 -> 22.9 us.  (The colour head, two hidden layers: 52.3 us against
-                        // 49.5 single-role -- its dW waves need ~2000 cycles per step for 96 transposed reads + 72 MFMAs,
-                        // longer than the chain waves' loads + recomputation in front of barrier B.)
+                    if constexpr (WIDTH == 64) {
+                        // the 64-wide networks (base MLP, colour head, the NGP networks): chain / dW roles, see k_mlp_bwd --
+                        // base network 30.3 -> 22.9 us, colour head 49.5 -> 41.4 us
                         static const bool roles = [] { const char* e = getenv("NVO_MLP_ROLES"); return !e || atoi(e) != 0; }();
                         if (roles) {
                             constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true);
