@@ -256,6 +256,8 @@ def main() -> None:
         cfg.commit_from_table = False
     if args.no_fuse_grid_adam:
         cfg.fuse_grid_adam = False
+    if os.environ.get("NVO_DW_REPLICAS") is not None:  # A/B
+        cfg.dw_replicas = int(os.environ["NVO_DW_REPLICAS"])
     if args.separate_zero:
         cfg.zero_with_ray_head = False
     if args.no_pose_overlap:

@@ -458,6 +458,8 @@ typedef struct nvo_color_args {
     uint32_t n_cameras;          /* rows of d_embedding (deterministic mode only) */
     uint32_t* nonfinite_flag;    /* backward; nullable: OR-ed with 1 when a weight-gradient total of the head is not finite
                                     (an overflow inside its 16-bit chain; d_embedding / d_sh are non-finite only with it) */
+    float* dw_replicas;          /* backward; nullable: n_dw_replicas zeroed copies [r][9216] of d_weights the workgroups spread */
+    uint32_t n_dw_replicas;      /* their adds over (module option "dw_replicas"); fold with nvo_fold_replicas */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);
@@ -695,6 +697,12 @@ int nvo_opt_commit_write(nvo_stream_t stream, uint32_t n_groups, uint32_t active
  * (s % table_rows) holds the 16 scalars of step s -- and *next_step (device uint32) names the row to load and is
  * advanced by one.  Nothing of the launch depends on host values, so every replay of the graph commits and loads the
  * right row (replaces the eager nvo_opt_commit_write behind each replay: no launch latency behind the graph). */
+/* Sums the copies a fused-MLP backward spread its weight-gradient adds over (module options "dw_replicas_ptr" /
+ * "dw_replicas", nvo_color_args::dw_replicas) into the gradient buffers and clears the copies: for entry i,
+ * dst[i][e] += sum_r replicas[i][r * n[i] + e], replicas[i][...] = 0.  One launch for up to 8 networks, behind their
+ * backwards and in front of whatever consumes the gradient (exchange, optimiser). */
+int nvo_fold_replicas(nvo_stream_t stream, uint32_t n_entries, float* const* replicas, const uint32_t* n_replicas,
+                      const uint64_t* n, float* const* dst);
 int nvo_opt_commit_table(nvo_stream_t stream, uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* applied,
                          const uint32_t* skip_flags, float* scale, uint32_t* growth_tracker, float growth_factor,
                          float backoff_factor, uint32_t growth_interval, float min_scale, float max_scale, float* bias,

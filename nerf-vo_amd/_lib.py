@@ -59,7 +59,8 @@ class ColorArgs(C.Structure):
     _fields_ = [("R", _u32), ("S", _u32), ("sh", _p), ("base_out", _p), ("embedding", _p), ("cam_idx", _p),
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int), ("det_scratch", _p),
-                ("det_scratch_bytes", _u64), ("n_cameras", _u32), ("nonfinite_flag", _p)]
+                ("det_scratch_bytes", _u64), ("n_cameras", _u32), ("nonfinite_flag", _p), ("dw_replicas", _p),
+                ("n_dw_replicas", _u32)]
 
 
 class RayHeadArgs(C.Structure):
@@ -188,6 +189,7 @@ _SIGNATURES = {
     "nvo_cast_half": (_int, [_p, _u64, _p, _p]),
     "nvo_zero_ranges": (_int, [_p, _u32, _p, _p]),
     "nvo_bwd_zero_ranges": (_int, [_p, _p, _p, _p, _u32]),
+    "nvo_fold_replicas": (_int, [_p, _u32, _p, _p, _p, _p]),
     "nvo_fused_adam_range": (_int, [_p, _p, _p]),
     "nvo_set_fused_adam": (_int, [_p, _p]),
     "nvo_ema_update": (_int, [_p, _u64, _p, _p, _p, _f, _u32, _p]),

@@ -904,6 +904,60 @@ int nvo_opt_commit_table(nvo_stream_t stream, uint32_t n_groups, uint32_t active
     return NVO_OK;
 }
 
+struct FoldEntries {
+    uint32_t n_entries;
+    float* rep[8];
+    float* dst[8];
+    uint32_t n_rep[8];
+    uint64_t n[8], first[9];  // first[i]: index of entry i's first element in the launch's flat index space
+};
+__global__ void __launch_bounds__(256)
+k_fold_replicas(FoldEntries f) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.first[f.n_entries]) return;
+    uint32_t k = 0;
+    while (k + 1 < f.n_entries && i >= f.first[k + 1]) ++k;
+    const uint64_t e = i - f.first[k];
+    // (all copies requested before the first is used: one memory round trip; fixed summation order -- the copies
+    // themselves were filled by float atomics)
+    float acc = f.dst[k][e];
+    for (uint32_t r0 = 0; r0 < f.n_rep[k]; r0 += 8u) {
+        float v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) v[q] = r0 + q < f.n_rep[k] ? f.rep[k][(size_t)(r0 + q) * f.n[k] + e] : 0.f;
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) {
+            acc += v[q];
+            if (r0 + q < f.n_rep[k]) f.rep[k][(size_t)(r0 + q) * f.n[k] + e] = 0.f;
+        }
+    }
+    f.dst[k][e] = acc;
+}
+
+int nvo_fold_replicas(nvo_stream_t stream, uint32_t n_entries, float* const* replicas, const uint32_t* n_replicas,
+                      const uint64_t* n, float* const* dst) {
+    NVO_REQUIRE(n_entries >= 1 && n_entries <= 8 && replicas && n_replicas && n && dst, "fold_replicas: 1..8 entries");
+    FoldEntries f;
+    memset(&f, 0, sizeof(f));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_entries; ++i) {
+        NVO_REQUIRE(replicas[i] && dst[i], "fold_replicas: NULL buffer");
+        f.rep[f.n_entries] = replicas[i];
+        f.dst[f.n_entries] = dst[i];
+        f.n_rep[f.n_entries] = n_replicas[i];
+        f.n[f.n_entries] = n[i];
+        f.first[f.n_entries] = total;
+        total += n[i];
+        ++f.n_entries;
+    }
+    f.first[f.n_entries] = total;
+    if (total == 0) return NVO_OK;
+    NVO_PROF(stream, "fold_replicas");
+    NVO_LAUNCH(k_fold_replicas, dim3((uint32_t)nvo_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, f);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
 int nvo_cast_bf16(nvo_stream_t stream, uint64_t n, const float* src, void* dst_bf16) {
     NVO_REQUIRE(src && dst_bf16, "cast_bf16: NULL argument");
     if (n == 0) return NVO_OK;

@@ -623,6 +623,10 @@ struct MlpModule : nvo_module_s {
     bool deterministic = false;
     // option "nonfinite_flag_ptr": device uint32 the backward ORs with 1 when a weight-gradient total is not finite
     uint32_t* nf_flag = nullptr;
+    // options "dw_replicas_ptr" / "dw_replicas": caller-owned zeroed copies of the weight-gradient buffer the backward's
+    // workgroups spread their adds over (NvoMlpArgsT::dw_replicas; the caller folds them with nvo_fold_replicas)
+    float* dw_replicas = nullptr;
+    uint32_t dw_n_replicas = 0;
     NvoScratch dw_scratch;
     ~MlpModule() override { nvo_scratch_destroy(&dw_scratch); }
     int det_partials(hipStream_t s, uint32_t B, NvoMlpArgs* a) {
@@ -638,6 +642,12 @@ struct MlpModule : nvo_module_s {
         if (!strcmp(key, "external_zero")) { external_zero = value != 0; return NVO_OK; }
         if (!strcmp(key, "deterministic")) { deterministic = value != 0; return NVO_OK; }
         if (!strcmp(key, "nonfinite_flag_ptr")) { nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value); return NVO_OK; }
+        if (!strcmp(key, "dw_replicas_ptr")) { dw_replicas = reinterpret_cast<float*>((uintptr_t)value); return NVO_OK; }
+        if (!strcmp(key, "dw_replicas")) {
+            NVO_REQUIRE(value >= 0 && value <= 63, "dw_replicas: 0..63 copies");
+            dw_n_replicas = (uint32_t)value;
+            return NVO_OK;
+        }
         return nvo_module_s::set_option(key, value);
     }
 
@@ -697,6 +707,10 @@ struct MlpModule : nvo_module_s {
         a.out_act = out_act;
         a.bf16 = bf16;
         a.nf_flag = nf_flag;
+        if (dw_replicas && dw_n_replicas && !deterministic) {
+            a.dw_replicas = dw_replicas;
+            a.dw_n_replicas = dw_n_replicas;
+        }
         return a;
     }
     int fwd(hipStream_t s, uint32_t B, const float* in, const void* params, void* out,
@@ -883,6 +897,7 @@ struct NwieModule : nvo_module_s {
             net->nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value);
             return enc->set_option(key, value);
         }
+        if (!strcmp(key, "dw_replicas_ptr") || !strcmp(key, "dw_replicas")) return net->set_option(key, value);
         if (!strcmp(key, "external_zero")) {
             if (int rc = enc->set_external_zero(value != 0)) return rc;
             net->external_zero = value != 0;

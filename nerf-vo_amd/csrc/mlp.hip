@@ -71,6 +71,10 @@ static NvoMlpArgs color_args(const nvo_color_args& c) {
     a.cam_idx = c.cam_idx;
     a.bf16 = c.act_bf16 != 0;
     a.nf_flag = c.nonfinite_flag;
+    if (c.dw_replicas && c.n_dw_replicas && !c.det_scratch) {
+        a.dw_replicas = c.dw_replicas;
+        a.dw_n_replicas = c.n_dw_replicas;
+    }
     return a;
 }
 

@@ -940,11 +940,16 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             for (int r = 0; r < 4; ++r) rh[(4 * g + r) * WIDTH + 16 * wib + m] = al[r];
             __syncthreads();
             float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
+            float* dW = a.dweights;
+            if (a.dw_replicas) {  // (see NvoMlpArgsT::dw_replicas)
+                const uint32_t r = blockIdx.x % (a.dw_n_replicas + 1u);
+                if (r) dW = a.dw_replicas + (size_t)(r - 1u) * kWeights;
+            }
             uint32_t chk = 0u;
             for (int e = (int)threadIdx.x - kChainWaves * 64; e < kWeights; e += kMlpBlock) {  // (the dW waves: threads 512..767)
                 const float v = red[e];
                 chk |= (uint32_t)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
-                if (part) part[e] = v; else atomicAdd(a.dweights + e, v);
+                if (part) part[e] = v; else atomicAdd(dW + e, v);
             }
             if (a.nf_flag && __ballot(chk != 0u) != 0ull && lane == 0) atomicOr(a.nf_flag, 1u);
         }
@@ -1277,8 +1282,12 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         constexpr int kLdsFloats = (int)(sizeof(T) * kLdsHalfs / sizeof(float));
         static_assert(WIDTH * IN_PAD <= kLdsFloats && WIDTH * WIDTH <= kLdsFloats && OUT_PAD * WIDTH <= kLdsFloats,
                       "dW block reduction does not fit the LDS tiles");
-        float* dW = a.dweights;
         constexpr int kWeights = WIDTH * IN_PAD + (N_HIDDEN - 1) * WIDTH * WIDTH + OUT_PAD * WIDTH;
+        float* dW = a.dweights;
+        if (a.dw_replicas) {  // (spread the workgroups' adds over several copies: see NvoMlpArgsT::dw_replicas)
+            const uint32_t r = blockIdx.x % (a.dw_n_replicas + 1u);
+            if (r) dW = a.dw_replicas + (size_t)(r - 1u) * kWeights;
+        }
         float* part = a.dw_partial ? a.dw_partial + (size_t)blockIdx.x * kWeights : nullptr;
         if constexpr (!ROLES) {
             dw0.flush_block(dW, red, lane, wib, part, a.nf_flag);

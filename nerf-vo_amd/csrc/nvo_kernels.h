@@ -243,6 +243,12 @@ struct NvoMlpArgsT {
     // varies); NVO_IO_NERFACTO_COLOR: the per-tile sums of the embedding / SH-direction gradients go to
     // tile_partial[tile][48] = {embedding 32 | d_sh 16} instead of float atomics (nvo_color_tile_reduce sums them)
     float* dw_partial;
+    // (backward; nullable) dw_n_replicas further copies of the weight-gradient buffer ([r][n_weights] floats, ZERO on
+    // entry): workgroup b adds its block total to copy b % (dw_n_replicas + 1) (0 = dweights itself).  Every workgroup
+    // adding to the same few cache lines serialises at the L2's atomic units -- 7-10 us per launch, a quarter of the
+    // kernels; nvo_fold_replicas sums the copies into dweights (and clears them) once per step.
+    float* dw_replicas;
+    uint32_t dw_n_replicas;
     float* tile_partial;
     // NVO_IO_HALF2_SOA backward with dinput (networks behind a hash grid; nullable): every workgroup STORES the L1 norm of
     // the dL/dinput values it wrote, per input column, to dx_l1_partial[block][IN_PAD] (and, compact_out, the number of

@@ -160,6 +160,10 @@ class EngineConfig:
     # parameter less (11.5 M of the 12.2 M), and the optimiser launch covers the rest of the fields group only.
     # Bit-identical to the separate launch.  Needs the producer flags (the group's verdict must be final before the pass).
     fuse_grid_adam: bool = True
+    # copies of every fused MLP's weight-gradient buffer: the backward's workgroups spread their block totals over
+    # 1 + dw_replicas buffers (256-512 workgroups adding to the same few cache lines serialise at the L2's atomic units:
+    # 7-10 us per launch), ONE launch per step folds the copies (nvo_fold_replicas).  0 = off.
+    dw_replicas: int = 7
     # multi-GPU: launch the next iteration's sampling prefix (rays -> proposal sampling; reads the proposal networks and
     # poses only) inside this iteration's graph, while the fields gradient is still being exchanged (train_step_graphed;
     # bit-identical to the un-pipelined order).  After a step the workspace and the drawn-pixel buffers then already
@@ -377,6 +381,8 @@ class NerfactoEngine:
         self.steps_since_proposal_update = 0
         self._ws = {}  # (ray count, training) -> scratch; never evicted (captured graphs address it by pointer)
         self.init_params(cfg.seed)
+        self._dw_rep = None
+        self._dw_replica_plan()  # (allocated here, never under a graph capture)
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -678,6 +684,8 @@ class NerfactoEngine:
             act_bf16=int(self.bf16),
             det_scratch=ws["color_det"].data_ptr() if (training and "color_det" in ws) else None,
             nonfinite_flag=self._flag_ptr("fields") if training else None,
+            dw_replicas=self._dw_replica_plan()["color"][0] if (training and self._dw_replica_plan()) else None,
+            n_dw_replicas=self._dw_replica_plan()["color"][1] if (training and self._dw_replica_plan()) else 0,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
             n_cameras=self.cfg.num_images)
 
@@ -877,7 +885,41 @@ class NerfactoEngine:
             self._pose_backward(ws, update_proposals, stream)
         if scatter_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(scatter_stream)  # join
+        self._fold_dw_replicas(stream)
         return update_proposals
+
+    def _dw_replica_plan(self):
+        """Zeroed copies of the MLP weight-gradient ranges (EngineConfig.dw_replicas) + the table nvo_fold_replicas takes."""
+        if getattr(self, "_dw_rep", None) is not None:
+            return self._dw_rep
+        cfg = self.cfg
+        G = int(cfg.dw_replicas)
+        if G <= 0 or cfg.deterministic or cfg.overlap_fields_adam:
+            self._dw_rep = False
+            return False
+        nets = [("field.base", self.base_net, self.base_net.n_params - self._grid_params(self.base_net)),
+                ("field.color", None, self.segments["field.color"][1])]
+        nets += [(f"proposal.{k}", m, m.n_params - self._grid_params(m)) for k, m in enumerate(self.prop_nets)]
+        buf = torch.zeros(G * sum(n for _, _, n in nets), dtype=torch.float32, device=self.device)
+        reps, dsts, off = [], [], 0
+        for seg, net, n in nets:
+            ptr = buf.data_ptr() + 4 * off
+            if net is not None:  # (the MLP's weights lead the module's parameter block)
+                net.set_option("dw_replicas_ptr", ptr)
+                net.set_option("dw_replicas", G)
+            reps.append(ptr)
+            dsts.append(self._param_ptr(seg, self.grads).value)
+            off += G * n
+        k = len(nets)
+        self._dw_rep = {"buf": buf, "G": G, "k": k, "color": (reps[1], G),
+                        "reps": (C.c_void_p * k)(*reps), "n_rep": (C.c_uint32 * k)(*([G] * k)),
+                        "n": (C.c_uint64 * k)(*[n for _, _, n in nets]), "dst": (C.c_void_p * k)(*dsts)}
+        return self._dw_rep
+
+    def _fold_dw_replicas(self, stream) -> None:
+        plan = self._dw_replica_plan()
+        if plan:
+            _call("nvo_fold_replicas", stream, plan["k"], plan["reps"], plan["n_rep"], plan["n"], plan["dst"])
 
     def _net_zero_ranges(self, net, seg: str):
         """What nvo_bwd of ``net`` clears before it accumulates (MLP weight gradient, atomically flushed grid ranges,
