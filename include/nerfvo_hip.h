@@ -508,12 +508,15 @@ typedef struct nvo_ngp_rgb_args {
     const int32_t* ray_idx;      /* [capacity] */
     const void* weights;         /* fp16 [64][32], [64][64], [16][64] */
     void* rgb_out;               /* fp16 [capacity][16] */
-    void* hidden;                /* fp16 [2][capacity][64] or NULL */
+    void* hidden;                /* fp16 [2][capacity][64] or NULL: with NULL the forward stores no activations and the
+                                    backward recomputes both hidden layers (bit-identical) */
     const void* d_rgb_out;       /* bwd: fp16 [capacity][16] */
     void* d_density_out;         /* bwd: fp16 [capacity][16] (all columns written) */
     const float* d_density_pre;  /* bwd: [capacity], added into column 0; nullable */
     float* d_weights;            /* bwd: accumulated */
     uint32_t* nonfinite_flag;    /* bwd; nullable: OR-ed with 1 when a weight-gradient total of the head is not finite */
+    float* dw_replicas;          /* bwd; nullable: n_dw_replicas zeroed copies of d_weights (see nvo_color_args) */
+    uint32_t n_dw_replicas;
 } nvo_ngp_rgb_args;
 int nvo_ngp_rgb_fwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);
 int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args);

@@ -98,7 +98,7 @@ class NgpRgbArgs(C.Structure):
     """mirror of nvo_ngp_rgb_args"""
     _fields_ = [("capacity", _u32), ("sh", _p), ("density_out", _p), ("ray_idx", _p), ("weights", _p), ("rgb_out", _p),
                 ("hidden", _p), ("d_rgb_out", _p), ("d_density_out", _p), ("d_density_pre", _p), ("d_weights", _p),
-                ("nonfinite_flag", _p)]
+                ("nonfinite_flag", _p), ("dw_replicas", _p), ("n_dw_replicas", _u32)]
 
 
 class NgpLossArgs(C.Structure):

@@ -108,6 +108,10 @@ static NvoMlpArgs ngp_rgb_args(const nvo_ngp_rgb_args& c) {
     a.base_out = (const _Float16*)c.density_out;
     a.sample_ray = c.ray_idx;
     a.nf_flag = c.nonfinite_flag;
+    if (c.dw_replicas && c.n_dw_replicas) {
+        a.dw_replicas = c.dw_replicas;
+        a.dw_n_replicas = c.n_dw_replicas;
+    }
     return a;
 }
 
@@ -121,7 +125,7 @@ int nvo_ngp_rgb_fwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
 int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
     NVO_REQUIRE(args != nullptr, "ngp_rgb_bwd: args is NULL");
     const nvo_ngp_rgb_args c = *args;
-    NVO_REQUIRE(c.sh && c.density_out && c.ray_idx && c.weights && c.rgb_out && c.hidden && c.d_rgb_out &&
+    NVO_REQUIRE(c.sh && c.density_out && c.ray_idx && c.weights && c.rgb_out && c.d_rgb_out &&
                 c.d_density_out, "ngp_rgb_bwd: NULL argument");
     NvoMlpArgs a = ngp_rgb_args(c);
     a.doutput = (const _Float16*)c.d_rgb_out;
@@ -130,6 +134,7 @@ int nvo_ngp_rgb_bwd(nvo_stream_t stream, const nvo_ngp_rgb_args* args) {
     a.d_base_out = (_Float16*)c.d_density_out;
     a.d_extra_col0 = c.d_density_pre;
     a.dweights = c.d_weights;
+    a.recompute_hidden = c.hidden == nullptr;  // no stored activations: both hidden layers are recomputed (as the colour head)
     return nvo_mlp_bwd_launch(32, 64, 2, 16, a, (hipStream_t)stream);
 }
 

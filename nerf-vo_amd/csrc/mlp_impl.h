@@ -1413,7 +1413,7 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
         // instantiated where the NeRF-VO path uses them: level-major input (networks behind a hash grid; compact
         // only there, recomputation for their single-hidden-layer shapes) and the fused colour head
         constexpr bool kSoa = IO == NVO_IO_HALF2_SOA && OUT_PAD == 16;
-        constexpr bool kRecompOk = (kSoa && N_HIDDEN == 1) || IO == NVO_IO_NERFACTO_COLOR;
+        constexpr bool kRecompOk = (kSoa && N_HIDDEN == 1) || IO == NVO_IO_NERFACTO_COLOR || IO == NVO_IO_NGP_RGB;
         if (a.act == NVO_ACT_RELU) {
             if constexpr (kRecompOk) {
                 if (a.recompute_hidden && !a.compact_out) {

@@ -65,6 +65,9 @@ class NgpConfig:
     # single GPU: the grid backward takes the Adam step + weight average of its streamed hashed levels itself
     # (nvo_set_fused_adam; bit-identical to the separate launches)
     fuse_grid_adam: bool = True
+    # copies of the two MLPs' weight-gradient buffers the backward's workgroups spread their adds over (0 = off;
+    # nvo_fold_replicas sums them once per step)
+    dw_replicas: int = 7
     # Testbed::train adapts the rays per batch so that the marched samples meet the target batch (1 << 18):
     # rays <- rays * target / measured, rounded up to the batch granularity (128), every `density_update_every` steps
     # (upstream does it where it reads the loss back, every 16 steps) [UPSTREAM NerfCounters::update_after_training].
@@ -118,14 +121,28 @@ class NgpEngine:
         self.density_net.set_option("grid_bwd_runs", 1)
         self.density_net.set_option("grid_bwd_batch", int(cfg.capacity))
         self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
+        # neither network stores its hidden activations: the backward recomputes them (bit-identical; less traffic both
+        # ways, and the recomputing backward is the one that runs in chain / dW roles)
+        self.density_net.set_option("recompute_hidden", 1)
         self._leaf_flags = False  # set in forward_backward: the grid backward raises skip_flag itself (single GPU)
         self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
         self.n_density_mlp = 64 * 32 + 16 * 64
         self.segments = {"density": (0, self.density_net.n_params), "rgb": (self.density_net.n_params, self.n_rgb)}
         self.n_params = self.density_net.n_params + self.n_rgb
+        self._dw_rep = None  # (set below, once the gradient buffer exists)
         dev = device
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
         self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(self.n_params), z(self.n_params), z(self.n_params), z(self.n_params)
+        G = int(cfg.dw_replicas)
+        if G > 0:
+            buf = z(G * (self.n_density_mlp + self.n_rgb))
+            self.density_net.set_option("dw_replicas_ptr", buf.data_ptr())
+            self.density_net.set_option("dw_replicas", G)
+            rgb_rep = buf.data_ptr() + 4 * G * self.n_density_mlp
+            self._dw_rep = {"buf": buf, "G": G, "rgb": rgb_rep,
+                            "reps": (C.c_void_p * 2)(buf.data_ptr(), rgb_rep), "n_rep": (C.c_uint32 * 2)(G, G),
+                            "n": (C.c_uint64 * 2)(self.n_density_mlp, self.n_rgb),
+                            "dst": (C.c_void_p * 2)(self.grads.data_ptr(), self.grads.data_ptr() + 4 * self.density_net.n_params)}
         self.params_half = z(self.n_params, torch.float16)
         # moving average of the weights (inference copy) -- allocated on first use
         self.params_ema = None
@@ -220,7 +237,6 @@ class NgpEngine:
         # staging area of the march (ray-major runs of accepted samples): owned here, not by the native side
         ws["march_scratch"] = torch.empty(int(_lib.lib().nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=dev)
         if training:
-            ws["rgb_hidden"] = torch.zeros(2, cap, 64, **f16)
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
             ws["d_density_out"] = torch.zeros(cap, 16, **f16)
             if self.cfg.optimize_extrinsics:
@@ -320,12 +336,14 @@ class NgpEngine:
             capacity=self.cfg.capacity, sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(),
             weights=self._pp("rgb", self.params_half if training else self.inference_params_half()).value,
-            rgb_out=ws["rgb_out"].data_ptr(), hidden=ws["rgb_hidden"].data_ptr() if training else None,
+            rgb_out=ws["rgb_out"].data_ptr(), hidden=None,
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None,
             d_density_out=ws["d_density_out"].data_ptr() if training else None,
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
             d_weights=self._pp("rgb", self.grads).value if training else None,
-            nonfinite_flag=self.skip_flag.data_ptr() if (training and self._leaf_flags) else None)
+            nonfinite_flag=self.skip_flag.data_ptr() if (training and self._leaf_flags) else None,
+            dw_replicas=self._dw_rep["rgb"] if (training and self._dw_rep) else None,
+            n_dw_replicas=self._dw_rep["G"] if (training and self._dw_rep) else 0)
 
     def _loss_args(self, ws, training: bool, has_depth: bool, background):
         cfg = self.cfg
@@ -380,6 +398,8 @@ class NgpEngine:
         finally:
             if fused_adam is not None:
                 self._set_fused_adam(False)
+        if self._dw_rep:
+            _call("nvo_fold_replicas", stream, 2, self._dw_rep["reps"], self._dw_rep["n_rep"], self._dw_rep["n"], self._dw_rep["dst"])
         if pose:
             self._pose_backward(ws, stream)
 
