@@ -316,6 +316,12 @@ typedef struct nvo_ray_head_args {
     float* x01;                  /* [R*S][3] */
 } nvo_ray_head_args;
 int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args);
+/* nvo_raygen + nvo_gather_pixels (colour, depth) + nvo_dirs01 + nvo_sh_encode (degree 4, fp16) for GIVEN pixel indices
+ * in one launch (the occupancy-grid back-end: pyngp.Testbed.frame() draws its pixels itself); same values. */
+int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
+                   const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
+                   float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
+                   float* gt_depth, float* dirs01, void* sh_half);
 /* the same launch with extra workgroups that clear up to 24 device ranges (as nvo_zero_ranges): the first launch of a
  * one-graph training step does both */
 int nvo_ray_head_zero(nvo_stream_t stream, const nvo_ray_head_args* args, uint32_t n_ranges, void* const* ptrs,

@@ -151,6 +151,7 @@ _SIGNATURES = {
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
     "nvo_sh_encode_t": (_int, [_p, _u32, _u32, _p, _p, _int]),
     "nvo_ray_head": (_int, [_p, C.POINTER(RayHeadArgs)]),
+    "nvo_rays_given": (_int, [_p, _u32, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_ray_head_zero": (_int, [_p, C.POINTER(RayHeadArgs), _u32, _p, _p]),
     # group C
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),

@@ -80,6 +80,42 @@ k_raygen(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __res
     cam_idx[r] = (int32_t)cam;
 }
 
+// k_raygen + k_gather_pixels (colour, depth) + the direction-encoding input (d + 1) / 2 + its SH(4) encoding for GIVEN
+// pixel indices, one thread per ray: the occupancy-grid back-end draws its pixels on the host side of pyngp.Testbed and
+// spent five ~6 us launches on what is a microsecond of work.  Same values as the separate kernels, bit for bit.
+__global__ void __launch_bounds__(256)
+k_rays_given(uint32_t R, const int64_t* __restrict__ ray_indices, const float* __restrict__ intrinsics,
+             const float* __restrict__ c2w, const float* __restrict__ corrections, uint32_t H, uint32_t W,
+             const float* __restrict__ images, const float* __restrict__ depths, float* __restrict__ origins,
+             float* __restrict__ directions, float* __restrict__ directions_norm, float* __restrict__ pixel_area,
+             int32_t* __restrict__ cam_idx, float* __restrict__ gt_rgb, float* __restrict__ gt_depth,
+             float* __restrict__ dirs01, nvo_h16* __restrict__ sh) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t cam = ray_indices[3 * (size_t)r + 0], y = ray_indices[3 * (size_t)r + 1], x = ray_indices[3 * (size_t)r + 2];
+    float o[3], d[3], n0, area;
+    raygen_one((float)x + 0.5f, (float)y + 0.5f, intrinsics + 4 * cam, c2w + 12 * cam, corrections ? corrections + 12 * cam : nullptr,
+               o, d, &n0, &area);
+    const size_t pix = ((size_t)cam * H + (size_t)y) * W + (size_t)x;
+    float d01[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[3 * (size_t)r + k] = o[k];
+        directions[3 * (size_t)r + k] = d[k];
+        gt_rgb[3 * (size_t)r + k] = images[3 * pix + k];
+        d01[k] = (d[k] + 1.f) * 0.5f;
+        dirs01[3 * (size_t)r + k] = d01[k];
+    }
+    directions_norm[r] = n0;
+    if (pixel_area) pixel_area[r] = area;
+    cam_idx[r] = (int32_t)cam;
+    if (depths) gt_depth[r] = depths[pix];
+    float c[16];
+    nvo_sh4_eval(d01[0] * 2.f - 1.f, d01[1] * 2.f - 1.f, d01[2] * 2.f - 1.f, 4u, c);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sh[16 * (size_t)r + k] = nvo_cvt16(c[k], false);
+}
+
 // images: [F][H][W][Cn] float -> out [R][Cn]
 __global__ void __launch_bounds__(256)
 k_gather_pixels(uint32_t R, const int64_t* __restrict__ ray_indices, uint32_t H, uint32_t W,
@@ -395,6 +431,21 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
     NVO_LAUNCH(k_raygen, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R,
                        ray_indices, intrinsics, c2w, corrections, origins, directions, directions_norm,
                        pixel_area, cam_idx);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
+                   const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
+                   float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
+                   float* gt_depth, float* dirs01, void* sh_half) {
+    NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && images && origins && directions && directions_norm && cam_idx &&
+                           gt_rgb && dirs01 && sh_half && (!depths || gt_depth)), "rays_given: NULL argument");
+    if (R == 0) return NVO_OK;
+    NVO_PROF(stream, "rays_given");
+    NVO_LAUNCH(k_rays_given, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices, intrinsics, c2w,
+               corrections, H, W, images, depths, origins, directions, directions_norm, pixel_area, cam_idx, gt_rgb, gt_depth,
+               dirs01, (nvo_h16*)sh_half);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

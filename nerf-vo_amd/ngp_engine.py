@@ -305,11 +305,12 @@ class NgpEngine:
             corr = self.corrections
             ws["ray_indices"].copy_(ray_indices)
             self._pose_inputs = (intrinsics, c2w)
-        _call("nvo_raygen", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corr), _ptr(ws["origins"]),
-              _ptr(ws["directions"]), _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]))
-        _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 3, _ptr(images), _ptr(ws["gt_rgb"]))
-        if depths is not None:
-            _call("nvo_gather_pixels", stream, R, _ptr(ray_indices), H, W, 1, _ptr(depths), _ptr(ws["gt_depth"]))
+        # rays, targets, direction-encoding input and its SH encoding in ONE launch (they were five)
+        _call("nvo_rays_given", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corr), H, W, _ptr(images),
+              _ptr(depths) if depths is not None else None, _ptr(ws["origins"]), _ptr(ws["directions"]),
+              _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]), _ptr(ws["gt_rgb"]),
+              _ptr(ws["gt_depth"]), _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+        ws["sh_ready"] = True
 
     def _forward(self, ws, training: bool, jitter, stream) -> None:
         cfg = self.cfg
@@ -326,8 +327,9 @@ class NgpEngine:
               _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
         _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),
               _ptr(ws["density_out"]), _ptr(ws["ctx"]))
-        _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
-        _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+        if not ws.pop("sh_ready", False):  # (rays that did not come through load_rays: inference bundles)
+            _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
+            _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
         ra = self._rgb_args(ws, training)
         _call("nvo_ngp_rgb_fwd", stream, C.byref(ra))
 
