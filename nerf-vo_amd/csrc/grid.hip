@@ -2143,8 +2143,10 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
 #endif
 }
 
+// (second bound: FOUR waves per SIMD, i.e. two of these workgroups per CU -- with the fused optimiser step the allocator
+// otherwise takes 147 registers and only one workgroup fits: half the waves for a pass that is bound by waves x latency)
 template <uint32_t BIN>
-__global__ void __launch_bounds__(kTlBlockP)
+__global__ void __launch_bounds__(kTlBlockP, 4)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
                   uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam) {
