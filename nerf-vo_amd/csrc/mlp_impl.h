@@ -407,7 +407,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 // the proposal sampler produce one number per sample, and a 32-byte row per sample costs 16x the traffic in
 // this kernel, in the per-ray kernels that read it with a 32-byte stride, and again in the backward.
 template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT>
-__global__ void __launch_bounds__(kMlpBlock)
+__global__ void __launch_bounds__(kMlpBlock, 4)  // (four waves per SIMD: the colour head's 130 registers allowed three)
 NVO_MLP_NAME(k_mlp_fwd)(Args a) {
     // hidden activation: compile-time ReLU (every network on the NeRF-VO path) or the run-time switch
     const int hidden_act = RELU ? (int)NVO_ACT_RELU : a.act;
