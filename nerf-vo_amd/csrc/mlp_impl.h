@@ -1536,7 +1536,9 @@ static uint32_t fwd_block_cap(int in_pad, int width, int n_hidden) {
     return 2048;
 }
 static uint32_t bwd_block_cap(int in_pad, int width, int n_hidden) {
-    if (width * in_pad + (n_hidden - 1) * width * width < 2048) return 512;  // 16-wide proposal MLP: 34 vs 37 us
+    // 16-wide proposal MLP: 38.8 / 27.7 / 24.0 / 27.9 us at 256 / 512 / 1024 / 2048 workgroups (with the dW copies; without
+    // them every workgroup more cost 22 ns of serialised adds and 512 was the optimum)
+    if (width * in_pad + (n_hidden - 1) * width * width < 2048) return 1024;
     // one workgroup per CU: with the tile inputs software-pipelined every shape is fastest at 256 (colour head
     // 74 us vs 107 us at 512; base 30.6 vs 37.7; proposal 49.5 vs 53.4) -- fewer dW flushes, and the dW
     // accumulators leave the wide shapes one wave per SIMD anyway
