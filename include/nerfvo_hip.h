@@ -481,7 +481,9 @@ uint64_t nvo_color_det_scratch_bytes(uint32_t R, uint32_t S);
  * ---------------------------------------------------------------------------------------------- */
 /* DDA march of R rays (unit directions) with deterministic packing: counts[R], offsets[R+1]
  * (exclusive scan, offsets[R] = total), then (ray_idx, t, dt)[capacity] written at the offsets.  Rays
- * whose samples would not fit get count 0.  jitter: device float [R] in [0,1) or NULL.
+ * whose samples would not fit get count 0 while offsets keeps their slot range: offsets[R] is the number of samples the
+ * march FOUND (what the adaptive ray batch measures), and a ray with counts[r] == 0 < offsets[r+1] - offsets[r] is a
+ * dropped one.  jitter: device float [R] in [0,1) or NULL.
  * Step size dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 1024).
  * scratch: CALLER-owned device staging area of at least nvo_occ_march_scratch_bytes(R) bytes (ray-major runs of the
  * single march; the native side allocates nothing, so a captured launch never holds a pointer it could lose). */
@@ -498,6 +500,18 @@ int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* 
                    float threshold, uint8_t* bitfield, void* scratch8);
 /* centres (or jittered points, jitter device float [128^3][3]) of cascade `level` cells, Morton order */
 int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, float* positions);
+/* Refresh samples of the density grid PAST the first 256 steps ("all cells first 256 steps";
+ * [UPSTREAM instant-ngp Testbed::update_density_grid_nerf / generate_grid_samples_nerf_nonuniform] -- the call the
+ * reference reaches through pyngp's frame(), /root/reference/nerf_vo/mapping/instant_ngp.py:104-105): samples
+ * first .. first + n - 1 of a pass of n_total.  Sample i takes a cascade uniformly at random and the first of ten
+ * candidate cells ((i + step * n_total) * 56924617 + j * 19349663 + 96925573) mod 128^3 (32-bit wrap-around, j = 0..9)
+ * whose grid value exceeds `thresh` (the tenth stays when none does; thresh < 0 takes every trained cell = the uniform
+ * pass, thresh = the occupancy threshold = the pass over occupied cells), then a uniform point inside the cell.
+ * x01 [n][3]: the point as the density network's input (position in the scene box [aabb_lo, aabb_hi]^3, clamped to
+ * [0, 1]); cell_idx [n]: level * 128^3 + Morton index.  Random numbers are hashes of (seed, stream_id, step, i). */
+int nvo_occ_sample_cells(nvo_stream_t stream, uint32_t n, uint32_t first, uint32_t n_total, uint32_t step, uint32_t seed,
+                         uint32_t stream_id, int n_levels, const float* grid, float thresh, float aabb_lo, float aabb_hi,
+                         float* x01, uint32_t* cell_idx);
 
 /* Occupancy-grid ("instant-ngp") trainer pieces on PACKED samples (capacity slots, ray_idx < 0 = empty):
  *  ngp_positions      : x01 = clamp((o + t d - aabb_lo) / (aabb_hi - aabb_lo), 0, 1) per slot
@@ -505,7 +519,8 @@ int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, 
  *                       output; the logistic is applied by the compositing kernel, as upstream)
  *  ngp_composite_loss : per ray (counts/offsets from nvo_occ_march) front-to-back compositing with
  *                       density = exp(pre), rgb = sigmoid(y), background blend; L2 rgb + L2 depth
- *                       losses; per-sample gradients (d_rgb_out fp16 rows, d_density_pre float)
+ *                       losses; per-sample gradients (d_rgb_out fp16 rows, d_density_pre float); rays the march
+ *                       dropped at the packed capacity are rendered (background) but add nothing to the losses
  *  ngp_thickness      : exp(pre) * sqrt(3)/1024 * 2^level for the density-grid update */
 typedef struct nvo_ngp_rgb_args {
     uint32_t capacity;           /* multiple of 16 */
@@ -563,6 +578,10 @@ int nvo_ngp_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t capacity, co
 int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args);
 int nvo_ngp_thickness(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride, int level,
                       float* out);
+/* The same for scattered samples: fresh[cell_idx[i]] = max(fresh[cell_idx[i]], thickness_i) with the cascade taken from the
+ * cell index (atomic; fresh zero-initialised by the caller) [UPSTREAM splat_grid_samples_nerf_max_nearest_neighbor]. */
+int nvo_ngp_thickness_splat(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride,
+                            const uint32_t* cell_idx, float* fresh);
 int nvo_fill_i32(nvo_stream_t stream, uint32_t n, int32_t* ptr, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------

@@ -169,6 +169,7 @@ _SIGNATURES = {
     "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64]),
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
+    "nvo_occ_sample_cells": (_int, [_p, _u32, _u32, _u32, _u32, _u32, _u32, _int, _p, _f, _f, _f, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
     "nvo_depth_align_scratch_bytes": (_u64, [_u32, _u32]),
     "nvo_depth_align": (_int, [_p, C.POINTER(DepthAlignArgs)]),
@@ -177,6 +178,7 @@ _SIGNATURES = {
     "nvo_ngp_rgb_bwd": (_int, [_p, C.POINTER(NgpRgbArgs)]),
     "nvo_ngp_composite_loss": (_int, [_p, C.POINTER(NgpLossArgs)]),
     "nvo_ngp_thickness": (_int, [_p, _u32, _p, _u32, _int, _p]),
+    "nvo_ngp_thickness_splat": (_int, [_p, _u32, _p, _u32, _p, _p]),
     "nvo_fill_i32": (_int, [_p, _u32, _p, _i32]),
     # group E
     "nvo_adam_step": (_int, [_p, _u64, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _u32, _f, _f, _p, _p]),

@@ -137,6 +137,9 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         if (a.out_accumulation) a.out_accumulation[r] = acc;
     }
     if (!a.d_rgb_out) return;
+    // a ray the scan dropped at the packed capacity (count zeroed, its slot range in `offsets` kept) leaves no trace in
+    // the losses [UPSTREAM generate_training_samples_nerf: an overflowing ray returns before it is counted]
+    if (n == 0u && a.offsets[r + 1] != base) return;
 
     // ---- losses (means over the global ray count)
     float g_pix[3], l_rgb = 0.f;
@@ -248,6 +251,19 @@ k_ngp_thickness(uint32_t n, const _Float16* __restrict__ density_out, uint32_t s
     out[i] = __expf((float)density_out[(size_t)i * stride]) * scalbnf(1.7320508075688772f / 1024.0f, level);
 }
 
+// the same for scattered refresh samples (nvo_occ_sample_cells): the cell keeps the LARGEST thickness any of its samples
+// saw [UPSTREAM splat_grid_samples_nerf_max_nearest_neighbor] -- non-negative floats order like their bit patterns
+__global__ void __launch_bounds__(256)
+k_ngp_thickness_splat(uint32_t n, const _Float16* __restrict__ density_out, uint32_t stride,
+                      const uint32_t* __restrict__ cell_idx, float* __restrict__ fresh) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = cell_idx[i];
+    const float v = __expf((float)density_out[(size_t)i * stride]) * scalbnf(1.7320508075688772f / 1024.0f, (int)(cell >> 21));
+    if (!(v >= 0.0f)) return;  // (NaN)
+    atomicMax(reinterpret_cast<unsigned int*>(fresh) + cell, __float_as_uint(v));
+}
+
 __global__ void __launch_bounds__(256)
 k_fill_i32(uint32_t n, int32_t* __restrict__ p, int32_t v) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,6 +315,17 @@ int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args) {
         NVO_CHECK_LAUNCH();
     }
     NVO_LAUNCH(k_ngp_composite_loss, dim3(nvo_div_up(a.R, 4)), dim3(256), 0, s, a);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ngp_thickness_splat(nvo_stream_t stream, uint32_t n, const void* density_out, uint32_t stride,
+                            const uint32_t* cell_idx, float* fresh) {
+    NVO_REQUIRE(n == 0 || (density_out && cell_idx && fresh && stride >= 1), "ngp_thickness_splat: bad argument");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "ngp_thickness_splat");
+    NVO_LAUNCH(k_ngp_thickness_splat, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+               (const _Float16*)density_out, stride, cell_idx, fresh);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

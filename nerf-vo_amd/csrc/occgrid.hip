@@ -370,6 +370,60 @@ k_occ_maxpool(int l, uint8_t* __restrict__ bitfield) {
     }
 }
 
+// Counter-based generator of the density-grid refresh samples: every value is a hash of (seed, stream, step, element), so
+// the launch is stateless (the same generator as the pixel sampler of rays.hip).
+__device__ __forceinline__ uint32_t occ_pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float occ_hash_uniform(uint32_t seed, uint32_t step, uint32_t stream, uint32_t i) {
+    const uint32_t h = occ_pcg_hash(occ_pcg_hash(occ_pcg_hash(seed ^ (stream * 0x9E3779B9u)) + step) + i);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+// Refresh samples of the density grid past the warm-up [UPSTREAM instant-ngp testbed_nerf.cu,
+// generate_grid_samples_nerf_nonuniform]: sample i takes a cascade at random and the first of ten candidate cells
+//   idx_j = ((i + step * n_total) * 56924617 + j * 19349663 + 96925573) mod 128^3        (32-bit wrap-around)
+// whose grid value exceeds `thresh` (the tenth stays when none does), then a uniform point inside that cell.  Writes the
+// point as the density network's input (position in the scene box, clamped to [0, 1]) and the cell it belongs to.
+__global__ void __launch_bounds__(256)
+k_occ_sample_cells(uint32_t n, uint32_t first, uint32_t n_total, uint32_t step, uint32_t seed, uint32_t stream_id,
+                   int n_levels, const float* __restrict__ grid, float thresh, float aabb_lo, float aabb_hi,
+                   float* __restrict__ x01, uint32_t* __restrict__ cell_idx) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = first + k;
+    uint32_t level = (uint32_t)(occ_hash_uniform(seed, step, 4u * stream_id + 0u, i) * (float)n_levels);
+    if (level >= (uint32_t)n_levels) level = (uint32_t)n_levels - 1u;
+    const uint32_t base = (i + step * n_total) * 56924617u + 96925573u;
+    uint32_t idx = 0;
+    for (uint32_t j = 0; j < 10u; ++j) {
+        idx = (base + j * 19349663u) & (kCells - 1u);
+        if (grid[(size_t)level * kCells + idx] > thresh) break;
+    }
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // inverse Morton
+        uint32_t v = (idx >> a) & 0x49249249u;
+        v = (v ^ (v >> 2)) & 0xC30C30C3u;
+        v = (v ^ (v >> 4)) & 0x0F00F00Fu;
+        v = (v ^ (v >> 8)) & 0xFF0000FFu;
+        v = (v ^ (v >> 16)) & 0x0000FFFFu;
+        c[a] = v;
+    }
+    const float scale = scalbnf(1.0f, (int)level);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float u = ((float)c[a] + occ_hash_uniform(seed, step, 4u * stream_id + 1u + (uint32_t)a, i)) / (float)kG;
+        const float p = (u - 0.5f) * scale + 0.5f;
+        float q = (p - aabb_lo) / (aabb_hi - aabb_lo);
+        q = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q);
+        x01[3 * (size_t)k + a] = q;
+    }
+    cell_idx[k] = level * kCells + idx;
+}
+
 // cell centres of one cascade in Morton order, normalised frame; jitter [cells][3] in [0,1) or null
 __global__ void __launch_bounds__(256)
 k_occ_cell_positions(int level, const float* __restrict__ jitter, float* __restrict__ pos) {
@@ -468,6 +522,19 @@ int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, 
     NVO_REQUIRE(level >= 0 && level < 8 && positions, "occ_cell_positions: bad argument");
     NVO_PROF(stream, "occ_cell_positions");
     NVO_LAUNCH(k_occ_cell_positions, dim3(kCells / 256), dim3(256), 0, (hipStream_t)stream, level, jitter, positions);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_occ_sample_cells(nvo_stream_t stream, uint32_t n, uint32_t first, uint32_t n_total, uint32_t step, uint32_t seed,
+                         uint32_t stream_id, int n_levels, const float* grid, float thresh, float aabb_lo, float aabb_hi,
+                         float* x01, uint32_t* cell_idx) {
+    NVO_REQUIRE(n_levels >= 1 && n_levels <= 8 && grid && x01 && cell_idx && aabb_hi > aabb_lo && (uint64_t)first + n <= n_total,
+                "occ_sample_cells: bad argument");
+    if (n == 0) return NVO_OK;
+    NVO_PROF(stream, "occ_sample_cells");
+    NVO_LAUNCH(k_occ_sample_cells, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, first, n_total, step, seed,
+               stream_id, n_levels, grid, thresh, aabb_lo, aabb_hi, x01, cell_idx);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import math
+import time
 from dataclasses import dataclass, field
 
 import torch
@@ -41,6 +42,11 @@ class NgpConfig:
     near_distance: float = 0.1
     desired_resolution: int = 2048
     density_update_every: int = 16
+    # Past the first `density_warmup_steps` steps a refresh no longer visits every cell: cells / 4 per cascade drawn
+    # uniformly + as many among the cells the grid already holds above the occupancy threshold (half the network
+    # evaluations of a full sweep) [UPSTREAM Testbed::training_prep_nerf: `m_training_step < 256` -> all cells, else
+    # n_cells / 4 * n_cascades uniform + the same number non-uniform; SURVEY.md section 2.4 K16]
+    density_warmup_steps: int = 256
     density_decay: float = 0.95
     occupancy_threshold: float = 0.01
     rgb_loss_mult: float = 1.0
@@ -73,6 +79,10 @@ class NgpConfig:
     # (upstream does it where it reads the loss back, every 16 steps) [UPSTREAM NerfCounters::update_after_training].
     # num_rays is the first batch; rays beyond the packed capacity are dropped for that step, as upstream.
     adaptive_rays: bool = True
+    # single GPU: the whole step (ray set-up ... optimiser + step counter) is captured once per ray count and replayed as
+    # ONE hipGraph; the caller's ray indices and the march jitter are copied / drawn into fixed buffers in front of the
+    # replay, the Adam bias corrections follow a device counter (nvo_opt_commit), the density-grid refresh stays eager.
+    graph_step: bool = True
     min_rays: int = 128
     max_rays: int = 1 << 16               # (upstream clamps at 1 << 18; the march scratch is rays x 1024 steps x 8 B)
     seed: int = 1337
@@ -160,6 +170,18 @@ class NgpEngine:
         self._scratch8 = z(8, torch.uint8)
         self.step = 0
         self.opt_step = 0
+        # device side of the optimiser's step count: [0] = extrinsic learning rate, [1..2] = {1 - beta1^t, sqrt(1 - beta2^t)}
+        # of the NEXT applied step (nvo_adam_step's hyper_dev layout; [1..2] alone = nvo_adam_group::bias_dev), advanced by
+        # nvo_opt_commit behind the optimiser launches iff the step was not skipped -- nothing of a step depends on a host
+        # scalar, so a captured step can be replayed
+        self._opt_dev = z(4)
+        self._applied_dev = z(1, torch.int32)
+        self._dev_synced = None   # the host opt_step the two buffers above were written for
+        self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
+        self._kernels_loaded = False
+        self.graph_captures, self.graph_capture_seconds = 0, 0.0  # (diagnostics: tools/ngp_bench.py)
+        self._measured_acc = torch.zeros(1, dtype=torch.int64, device=dev)  # marched samples since the last adaptation
+        self._measured_n = 0
         self._ws = None
         # camera offsets [F][6] = (translation, rotation vector) and their optimiser state
         F6 = cfg.num_images * 6
@@ -239,17 +261,23 @@ class NgpEngine:
         if training:
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
             ws["d_density_out"] = torch.zeros(cap, 16, **f16)
+            # fixed homes of the per-step inputs (a captured step reads them by address)
+            ws["ray_indices"] = torch.zeros(R, 3, dtype=torch.int64, device=dev)
+            ws["jitter"] = torch.zeros(R, **f32)
+            if self.cfg.random_background:
+                ws["background"] = torch.zeros(R, 3, **f32)
             if self.cfg.optimize_extrinsics:
                 ws["dx01"] = torch.zeros(cap, 3, **f32)
                 ws["d_origin"] = torch.zeros(R, 3, **f32)
                 ws["d_dir"] = torch.zeros(R, 3, **f32)
-                ws["ray_indices"] = torch.zeros(R, 3, dtype=torch.int64, device=dev)
         ws["_per_ray"] = {k: ws[k] for k in self._PER_RAY if k in ws}
+        self._graphs.clear()  # (captured steps address the old buffers)
         self._ws = ws
         return self._ray_views(ws, R_req)
 
     _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "dirs01", "out_rgb",
-                "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices")
+                "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices",
+                "jitter", "background")
 
     @staticmethod
     def _ray_views(ws, R: int):
@@ -262,8 +290,10 @@ class NgpEngine:
     # ---- density grid ------------------------------------------------------------------------
     @torch.no_grad()
     def update_density_grid(self, jitter: bool = True, all_reduce=None) -> None:
-        """update_density_grid_nerf: sample every cell of every cascade (jittered), evaluate the density
-        network, EMA the optical thickness into the grid, rebuild bitfield + cascade max-pool.
+        """update_density_grid_nerf: during the first `density_warmup_steps` steps sample every cell of every cascade
+        (jittered), afterwards cells / 4 per cascade uniformly + as many among the occupied cells (nvo_occ_sample_cells);
+        evaluate the density network, EMA the optical thickness into the grid (cells without a sample only decay),
+        rebuild bitfield + cascade max-pool.
         ``all_reduce`` (multi-GPU): the fresh estimates are MAX-reduced over the ranks before the update, so the
         density grid and bitfield stay identical everywhere (parallel.GradientAllReduce.reduce_max)."""
         # (The density network is evaluated with the RAW training weights, not the EMA copy inference reads: upstream's
@@ -274,20 +304,35 @@ class NgpEngine:
         stream = _stream(self.device)
         lo, hi = cfg.aabb
         chunk = 1 << 19
-        fresh = torch.empty(cfg.n_levels * CELLS, device=self.device)
-        pos = torch.empty(CELLS, 3, device=self.device)
         x01 = torch.empty(chunk, 3, device=self.device)
         out = torch.empty(chunk, 16, dtype=torch.float16, device=self.device)
         ctx = torch.empty(self.density_net.ctx_bytes(chunk), dtype=torch.uint8, device=self.device)
-        for level in range(cfg.n_levels):
-            jit = torch.rand(CELLS, 3, device=self.device) if jitter else None
-            _call("nvo_occ_cell_positions", stream, level, _ptr(jit), _ptr(pos))
-            for c0 in range(0, CELLS, chunk):
-                x01.copy_(((pos[c0:c0 + chunk] - lo) / (hi - lo)).clamp_(0.0, 1.0))
-                _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
-                      _ptr(out), _ptr(ctx))
-                _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 16, level,
-                      C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
+        if self.step >= cfg.density_warmup_steps:
+            # scattered refresh: a uniform pass (every trained cell qualifies) and a pass over occupied cells
+            fresh = torch.zeros(cfg.n_levels * CELLS, device=self.device)
+            cells = torch.empty(chunk, dtype=torch.int32, device=self.device)
+            n_pass = CELLS // 4 * cfg.n_levels
+            for pass_id, thresh in ((0, -0.01), (1, cfg.occupancy_threshold)):
+                for c0 in range(0, n_pass, chunk):
+                    m = min(chunk, n_pass - c0)
+                    _call("nvo_occ_sample_cells", stream, m, c0, n_pass, self.step, cfg.seed & 0xFFFFFFFF, pass_id,
+                          cfg.n_levels, _ptr(self.density_grid), thresh, lo, hi, _ptr(x01), _ptr(cells))
+                    # (the network runs on whole chunks: rows past m hold an earlier chunk's points and are not splatted)
+                    _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
+                          _ptr(out), _ptr(ctx))
+                    _call("nvo_ngp_thickness_splat", stream, m, _ptr(out), 16, _ptr(cells), _ptr(fresh))
+        else:
+            fresh = torch.empty(cfg.n_levels * CELLS, device=self.device)
+            pos = torch.empty(CELLS, 3, device=self.device)
+            for level in range(cfg.n_levels):
+                jit = torch.rand(CELLS, 3, device=self.device) if jitter else None
+                _call("nvo_occ_cell_positions", stream, level, _ptr(jit), _ptr(pos))
+                for c0 in range(0, CELLS, chunk):
+                    x01.copy_(((pos[c0:c0 + chunk] - lo) / (hi - lo)).clamp_(0.0, 1.0))
+                    _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
+                          _ptr(out), _ptr(ctx))
+                    _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 16, level,
+                          C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
         if all_reduce is not None:
             all_reduce.reduce_max(fresh)
         _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
@@ -300,10 +345,11 @@ class NgpEngine:
         H, W = images.shape[1], images.shape[2]
         corr = None
         self._pose_inputs = None
-        if self.cfg.optimize_extrinsics and "ray_indices" in ws:
+        if self.cfg.optimize_extrinsics and "dx01" in ws:
             _call("nvo_pose_exp_map", stream, self.cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.corrections), 1)
             corr = self.corrections
-            ws["ray_indices"].copy_(ray_indices)
+            if ray_indices.data_ptr() != ws["ray_indices"].data_ptr():  # (the graphed step has copied them already)
+                ws["ray_indices"].copy_(ray_indices)
             self._pose_inputs = (intrinsics, c2w)
         # rays, targets, direction-encoding input and its SH encoding in ONE launch (they were five)
         _call("nvo_rays_given", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corr), H, W, _ptr(images),
@@ -374,17 +420,24 @@ class NgpEngine:
         average, nvo_set_fused_adam) and leaves their gradient unwritten."""
         stream = _stream(self.device)
         cap = self.cfg.capacity
-        if fused_adam is None:
-            self.grads.zero_()
-        else:  # (nothing accumulates into the fused range)
-            self.grads[:fused_adam[0]].zero_()
-            self.grads[fused_adam[1]:].zero_()
-        self.losses.zero_()
         if leaf_flags != self._leaf_flags:
             self.density_net.set_option("nonfinite_flag_ptr", self.skip_flag.data_ptr() if leaf_flags else 0)
             self._leaf_flags = leaf_flags
+        # everything the step accumulates into, cleared by ONE launch (they were six fills): the gradient outside the
+        # range the grid backward steps itself (nothing accumulates there), the loss slots, the overflow flag, the pose
+        # gradients
+        g0 = self.grads.data_ptr()
+        spans = [(g0, 4 * self.n_params)] if fused_adam is None else \
+            [(g0, 4 * fused_adam[0]), (g0 + 4 * fused_adam[1], 4 * (self.n_params - fused_adam[1]))]
+        spans.append((self.losses.data_ptr(), 4 * self.losses.numel()))
         if leaf_flags:
-            self.skip_flag.zero_()
+            spans.append((self.skip_flag.data_ptr(), 4))
+        if self.cfg.optimize_extrinsics and self._pose_inputs is not None and "dx01" in ws:
+            spans += [(self.d_corrections.data_ptr(), 4 * self.d_corrections.numel()),
+                      (self.pose_grads.data_ptr(), 4 * self.pose_grads.numel())]
+        spans = [sp for sp in spans if sp[1] > 0]
+        _call("nvo_zero_ranges", stream, len(spans), (C.c_void_p * len(spans))(*[a for a, _ in spans]),
+              (C.c_uint64 * len(spans))(*[b for _, b in spans]))
         self._forward(ws, True, jitter, stream)
         la = self._loss_args(ws, True, has_depth, background)
         _call("nvo_ngp_composite_loss", stream, C.byref(la))
@@ -415,11 +468,9 @@ class NgpEngine:
         _call("nvo_ngp_positions_bwd", stream, R, cfg.capacity, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["t"]),
               _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["dx01"]), _ptr(ws["d_origin"]),
               _ptr(ws["d_dir"]))
-        self.d_corrections.zero_()
         intr, c2w = self._pose_inputs
         _call("nvo_pose_bwd_cams", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
               _ptr(ws["d_dir"]), None, _ptr(self.d_corrections), cfg.num_images)
-        self.pose_grads.zero_()
         _call("nvo_se3_exp_map_bwd", stream, cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.d_corrections),
               cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, cfg.loss_scale / self.world_size, _ptr(self.pose_grads),
               C.c_void_p(self.losses.data_ptr() + 5 * 4), 1)
@@ -440,6 +491,7 @@ class NgpEngine:
         if not on:
             _call("nvo_set_fused_adam", self.density_net.handle, None)
             return
+        self._sync_opt_dev()
         cfg = self.cfg
         ema = cfg.ema_decay > 0.0
         if ema and self.params_ema is None:
@@ -449,17 +501,39 @@ class NgpEngine:
         a = _lib.FusedAdamArgs(
             params=self.params.data_ptr() + 4 * o, params_half=self.params_half.data_ptr() + 2 * o,
             exp_avg=self.exp_avg.data_ptr() + 4 * o, exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * o, hyper_dev=None,
-            bias_dev=None, loss_scale_dev=None, skip_flag=self.skip_flag.data_ptr(), lr=cfg.lr, grad_scale=1.0 / cfg.loss_scale,
-            beta1=cfg.adam_betas[0], beta2=cfg.adam_betas[1], eps=cfg.adam_eps, step=self.opt_step + 1,
+            bias_dev=self._opt_dev.data_ptr() + 4, loss_scale_dev=None, skip_flag=self.skip_flag.data_ptr(), lr=cfg.lr,
+            grad_scale=1.0 / cfg.loss_scale, beta1=cfg.adam_betas[0], beta2=cfg.adam_betas[1], eps=cfg.adam_eps, step=0,
             ema=self.params_ema.data_ptr() + 4 * o if ema else None,
             ema_half=self.params_ema_half.data_ptr() + 2 * o if ema else None, ema_decay=cfg.ema_decay,
             ema_step_dev=self._ema_step_dev.data_ptr() if ema else None)
         _call("nvo_set_fused_adam", self.density_net.handle, C.byref(a))
 
+    def _sync_opt_dev(self) -> None:
+        """Writes the device side of the step count (self._opt_dev, self._applied_dev) for the host's ``opt_step`` -- at
+        the first step and whenever ``opt_step`` was set from outside (snapshot load); otherwise nvo_opt_commit keeps it."""
+        if self._dev_synced == self.opt_step:
+            return
+        b1, b2 = self.cfg.adam_betas
+        t = float(self.opt_step + 1)
+        self._opt_dev.copy_(torch.tensor([self.cfg.extrinsic_lr, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0],
+                                         dtype=torch.float64).float())
+        self._applied_dev.fill_(int(self.opt_step))
+        self._dev_synced = self.opt_step
+
+    @property
+    def applied_steps(self) -> int:
+        """Optimiser steps actually applied (a step whose gradients overflowed is skipped and does not count; device
+        counter, reading it synchronises)."""
+        self._sync_opt_dev()
+        return int(self._applied_dev.item())
+
     def optimizer_step(self, fused_adam=None) -> None:
+        """Adam of the three parameter ranges (one launch), weight average, Adam of the camera offsets, step counter.
+        The bias corrections come from the device (self._opt_dev): t = applied steps + 1."""
         cfg = self.cfg
         stream = _stream(self.device)
-        self.opt_step += 1
+        self._sync_opt_dev()
+        bias_dev = self._opt_dev.data_ptr() + 4
         if not self._leaf_flags:
             _call("nvo_nonfinite_flag", stream, self.n_params, _ptr(self.grads), 0, _ptr(self.skip_flag))
         n_grid = self.density_net.n_params - self.n_density_mlp
@@ -467,7 +541,7 @@ class NgpEngine:
             assert self.n_density_mlp <= fused_adam[0] and fused_adam[1] == self.density_net.n_params
             n_grid = fused_adam[0] - self.n_density_mlp
         # (offset, size, weight decay): density MLP | hash grid | rgb MLP -- l2_reg on MLP weights only; ONE launch
-        batch = [_lib.AdamGroup(offset=off, n=size, lr=cfg.lr, step=self.opt_step, hyper_dev=None, bias_dev=None, flag_slot=0,
+        batch = [_lib.AdamGroup(offset=off, n=size, lr=cfg.lr, step=0, hyper_dev=None, bias_dev=bias_dev, flag_slot=0,
                                 flag_slot_set=1, weight_decay=wd, weight_decay_set=1)
                  for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
                                        (self.density_net.n_params, self.n_rgb, cfg.l2_reg)) if size > 0]
@@ -496,16 +570,33 @@ class NgpEngine:
             n6 = cfg.num_images * 6
             _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
                   _ptr(self.pose_exp_avg), _ptr(self.pose_exp_avg_sq), cfg.extrinsic_lr, cfg.adam_betas[0],
-                  cfg.adam_betas[1], cfg.adam_eps, self.opt_step, 1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), None)
+                  cfg.adam_betas[1], cfg.adam_eps, 1, 1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), _ptr(self._opt_dev))
+            # (hyper_dev = self._opt_dev overrides the by-value learning rate and step)
+        # the step counter and the next step's bias corrections, behind every launch that read them
+        _call("nvo_opt_commit", stream, 1, 1, 0, _ptr(self._applied_dev), _ptr(self.skip_flag), None, None, 2.0, 0.5, 2000,
+              0.0, 0.0, C.c_void_p(bias_dev), cfg.adam_betas[0], cfg.adam_betas[1])
 
     def train_step(self, ray_indices, intrinsics, c2w, images, depths, all_reduce=None):
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
         if self.step % self.cfg.density_update_every == 0:
             self.update_density_grid(all_reduce=all_reduce)
+        self._sync_opt_dev()
+        if self.cfg.graph_step and all_reduce is None:
+            self._train_step_graphed(ws, ray_indices, intrinsics, c2w, images, depths)
+        else:
+            jitter = torch.rand(R, device=self.device)
+            bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
+            self._step_body(ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce)
+        self.opt_step += 1
+        self._dev_synced = self.opt_step  # (the host mirror counts attempts; the device follows the applied steps)
+        self.step += 1
+        if self.cfg.adaptive_rays:
+            self._adapt_rays(ws, R)
+
+    def _step_body(self, ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce=None) -> None:
+        """Every launch of one step, in order (eager, or recorded into a hipGraph by _train_step_graphed)."""
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
-        jitter = torch.rand(R, device=self.device)
-        bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
         fused = self._fused_adam_plan() if all_reduce is None else None
         self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg, leaf_flags=all_reduce is None,
                               fused_adam=fused)
@@ -514,19 +605,71 @@ class NgpEngine:
             if self.cfg.optimize_extrinsics and self._pose_inputs is not None:
                 all_reduce(self.pose_grads)
         self.optimizer_step(fused_adam=fused)
-        self.step += 1
         if self.cfg.adaptive_rays:
-            self._adapt_rays(ws, R)
+            # samples the march found in this step, BEFORE rays were dropped at the packed capacity (the scan's total):
+            # a capped measure could never exceed the target, so the batch would only ever grow
+            self._measured_acc.add_(ws["offsets"][-1:])
+
+    _MAX_GRAPHS = 48
+
+    def _train_step_graphed(self, ws, ray_indices, intrinsics, c2w, images, depths) -> None:
+        """The step as ONE hipGraph replay (NgpConfig.graph_step).  In front of it, eager: the caller's ray indices are
+        copied and the march jitter is drawn into the workspace's fixed buffers (same generator calls as the eager step).
+        Captured once per ray count (the adaptive batch moves it every `density_update_every` steps, usually between a
+        few neighbouring values) and set of input buffers; the very first step of an engine runs eagerly so that every
+        kernel's code object is loaded before anything is recorded."""
+        cfg = self.cfg
+        R = ws["R"]
+        ws["ray_indices"].copy_(ray_indices)
+        ws["jitter"].uniform_()
+        bg = None
+        if cfg.random_background:
+            bg = ws["background"]
+            bg.uniform_()
+        if not self._kernels_loaded:
+            self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
+            self._kernels_loaded = True
+            return
+        key = (R, ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
+               None if depths is None else depths.data_ptr(), bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
+               self._fused_adam_plan(),
+               # every by-value scalar of the step's launches
+               (cfg.loss_scale, cfg.lr, cfg.rgb_loss_mult, cfg.depth_loss_mult, cfg.l2_reg, cfg.extrinsic_l2_reg, cfg.ema_decay,
+                cfg.cone_angle, cfg.near_distance, tuple(cfg.adam_betas), cfg.adam_eps, bool(cfg.random_background),
+                int(cfg.dw_replicas), self.world_size),
+               self.params_ema is None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) >= self._MAX_GRAPHS:
+                self._graphs.clear()
+            if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
+                self.params_ema = torch.zeros_like(self.params)
+                self.params_ema_half = torch.zeros_like(self.params_half)
+                key = key[:-1] + (False,)
+            t0 = time.perf_counter()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
+            self.graph_captures += 1
+            self.graph_capture_seconds += time.perf_counter() - t0
+            # the graph addresses these buffers: they must stay alive as long as it does
+            entry = {"graph": g, "keep": (intrinsics, c2w, images, depths, ws), "pose_inputs": self._pose_inputs}
+            self._graphs[key] = entry
+        entry["graph"].replay()
+        self._pose_inputs = entry["pose_inputs"]
+        if cfg.ema_decay > 0.0:
+            self._ema_started = True
 
     def _adapt_rays(self, ws, R: int) -> None:
         """rays_per_batch <- rays * target / measured samples per step (mean since the last adaptation), rounded up to
         128, every `density_update_every` steps -- ONE host read-back per 16 steps, where upstream reads its loss."""
         cfg = self.cfg
-        self._measured.append(ws["counts"].sum())  # marched (uncapped) samples of this step, device scalar
+        self._measured_n += 1
         if self.step % cfg.density_update_every != 0:
             return
-        measured = float(torch.stack(self._measured).float().mean().item())
-        self._measured = []
+        measured = float(self._measured_acc.item()) / self._measured_n
+        self._measured_acc.zero_()
+        self._measured_n = 0
         if measured <= 0.0:
             return
         want = int(math.ceil(R * cfg.capacity / measured / 128.0)) * 128

@@ -162,6 +162,7 @@ class Testbed:
         self._engine: NgpEngine | None = None
         self._camera = np.eye(4)[:3][_TO_NGP_ROWS]
         self._generator = torch.Generator(device=self.device)
+        self._draw_scale = None
         self._generator.manual_seed(42)
 
     # ---- dataset / network set-up ------------------------------------------------------------------------
@@ -231,11 +232,13 @@ class Testbed:
         eng = self._engine
         eng.cfg.optimize_extrinsics = bool(self.nerf.training.optimize_extrinsics)
         h, w = self._resolution
-        scale = torch.tensor([n, h, w], device=self.device)
+        if self._draw_scale is None or self._draw_scale[0] != (n, h, w):  # (one upload per change, not per frame)
+            self._draw_scale = ((n, h, w), torch.tensor([n, h, w], device=self.device, dtype=torch.float32))
         # (Testbed::train adapts the rays per batch to the marched-sample target; NgpEngine.rays_per_batch)
         u = torch.rand((eng.rays_per_batch if eng.cfg.adaptive_rays else eng.cfg.num_rays, 3), device=self.device,
                        generator=self._generator)
-        eng.train_step(torch.floor(u * scale).long(), self._intrinsics, self._poses, self._images, self._depths)
+        # (image, row, column) = floor(u * (n, h, w)): the int64 conversion of the non-negative products truncates
+        eng.train_step(u.mul_(self._draw_scale[1]).long(), self._intrinsics, self._poses, self._images, self._depths)
         self.training_step = eng.step
         return True
 

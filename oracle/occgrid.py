@@ -74,3 +74,58 @@ def ema_update(grid, new_values, decay=0.95):
     """instant-ngp ema_grid_samples_nerf: negative (never-visible) cells stay, others max(decay*old, new)."""
     g = np.asarray(grid, np.float32)
     return np.where(g < 0, g, np.maximum(g * np.float32(decay), np.asarray(new_values, np.float32)))
+
+
+def _pcg_hash(v):
+    """PCG output permutation on uint32 arrays (the product's counter-based generator)."""
+    v = np.asarray(v, np.uint32)
+    state = v * np.uint32(747796405) + np.uint32(2891336453)
+    word = ((state >> ((state >> np.uint32(28)) + np.uint32(4))) ^ state) * np.uint32(277803737)
+    return (word >> np.uint32(22)) ^ word
+
+
+def _hash_uniform(seed, step, stream, i):
+    with np.errstate(over="ignore"):
+        a = _pcg_hash(np.uint32(seed) ^ (np.uint32(stream) * np.uint32(0x9E3779B9)))
+        h = _pcg_hash(_pcg_hash(a + np.uint32(step)) + np.asarray(i, np.uint32))
+    return (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def morton3d_invert_numpy(idx):
+    idx = np.asarray(idx, np.uint32)
+    out = []
+    for a in range(3):
+        v = np.zeros_like(idx)
+        for b in range(10):
+            v |= ((idx >> np.uint32(3 * b + a)) & np.uint32(1)) << np.uint32(b)
+        out.append(v)
+    return out
+
+
+def refresh_samples(n, first, n_total, step, seed, stream_id, n_levels, grid, thresh, aabb_lo, aabb_hi):
+    """Samples first .. first + n - 1 of one pass of the density-grid refresh past the warm-up [UPSTREAM instant-ngp
+    testbed_nerf.cu generate_grid_samples_nerf_nonuniform; SURVEY.md section 2.4 K16]: a random cascade, the first of ten
+    candidate cells ((i + step * n_total) * 56924617 + j * 19349663 + 96925573) mod 128^3 (uint32 wrap-around) whose grid
+    value exceeds `thresh` (the tenth when none does), a uniform point inside the cell.  float32 operations in the
+    kernel's order.  Returns (cell_idx [n] = level * 128^3 + Morton index, x01 [n,3])."""
+    g = np.ascontiguousarray(grid, np.float32).reshape(n_levels, CELLS)
+    i = (np.uint32(first) + np.arange(n, dtype=np.uint32)).astype(np.uint32)
+    level = (_hash_uniform(seed, step, 4 * stream_id, i) * np.float32(n_levels)).astype(np.uint32)
+    level = np.minimum(level, np.uint32(n_levels - 1))
+    with np.errstate(over="ignore"):
+        base = (i + np.uint32(step) * np.uint32(n_total)) * np.uint32(56924617) + np.uint32(96925573)
+        idx = np.zeros(n, np.uint32)
+        done = np.zeros(n, bool)
+        for j in range(10):
+            cand = (base + np.uint32(j) * np.uint32(19349663)) & np.uint32(CELLS - 1)
+            idx = np.where(done, idx, cand)
+            done |= g[level, idx] > np.float32(thresh)
+    c = morton3d_invert_numpy(idx)
+    scale = np.ldexp(np.float32(1.0), level.astype(np.int32)).astype(np.float32)
+    x01 = np.zeros((n, 3), np.float32)
+    lo, hi = np.float32(aabb_lo), np.float32(aabb_hi)
+    for a in range(3):
+        u = (c[a].astype(np.float32) + _hash_uniform(seed, step, 4 * stream_id + 1 + a, i)) / np.float32(GRID)
+        p = (u - np.float32(0.5)) * scale + np.float32(0.5)
+        x01[:, a] = np.clip((p - lo) / (hi - lo), np.float32(0.0), np.float32(1.0))
+    return level * np.uint32(CELLS) + idx, x01

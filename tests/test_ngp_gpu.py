@@ -328,3 +328,158 @@ def test_adam_and_ema_inside_the_grid_backward_are_bit_identical(device):
         # the rest of the parameters went through the same launches in both engines (float atomics in the MLP dW: close)
         assert torch.allclose(fe.params[:lo], ue.params[:lo], rtol=1e-3, atol=1e-5)
     assert bool((fe.params[lo:hi] != 0).any()) and bool((fe.params_ema[lo:hi] != 0).any())
+
+
+def test_graphed_step_matches_eager_step(device):
+    """NgpConfig.graph_step: the step replayed from ONE hipGraph against the same launches issued eagerly.  Both engines
+    start every step from the eager engine's state and the same generator seed (the MLPs' float-atomic weight gradients
+    would let two free-running trajectories drift): the hash grid's range -- deterministic backward, Adam and weight
+    average inside it -- must agree bit for bit, the rest closely; covered on the way: the first (eager) step of the graphed
+    engine, density-grid refreshes between replays, a ray count the adaptive batch moves (a second capture), an overflowing
+    step (nothing moves, the applied-step counter stands still) and the camera offsets' optimiser."""
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W = 8, 60, 80
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    c2w = opencv_to_opengl(seq["camera_extrinsics"])
+    c2w[:, :3, 3] += 0.5
+    c2w = c2w[:, :3, :4].contiguous()
+    images = seq["frames_color"].permute(0, 2, 3, 1).contiguous()
+    depths = seq["frames_depth"].permute(0, 2, 3, 1).contiguous()
+    engines = {}
+    for graphed in (True, False):
+        torch.manual_seed(9)
+        engines[graphed] = NgpEngine(NgpConfig(num_images=n, num_rays=512, capacity=1 << 16, graph_step=graphed,
+                                               density_update_every=4, optimize_extrinsics=True), device)
+    ge, ee = engines[True], engines[False]
+    lo, hi = ge._fused_adam_plan()
+    scale = torch.tensor([n, H, W], device=device)
+    state = ("params", "exp_avg", "exp_avg_sq", "params_half", "params_ema", "params_ema_half", "pose_adjustment",
+             "pose_exp_avg", "pose_exp_avg_sq", "density_grid", "bitfield", "_ema_step_dev", "_applied_dev", "_opt_dev")
+    ray_counts = set()
+    for it in range(11):
+        overflow = it == 6
+        for e in (ge, ee):
+            e.cfg.loss_scale = 2.0 ** 60 if overflow else 128.0
+        assert ge.rays_per_batch == ee.rays_per_batch
+        R = ge.rays_per_batch
+        ray_counts.add(R)
+        idx = torch.floor(torch.rand(R, 3, device=device) * scale).long()
+        if it > 0:
+            for name in state:
+                getattr(ge, name).copy_(getattr(ee, name))
+        before = ee.params.clone()
+        for e in (ge, ee):
+            torch.manual_seed(100 + it)
+            e.train_step(idx, seq["camera_intrinsics"], c2w, images, depths)
+        torch.cuda.synchronize()
+        assert bool(ge.skip_flag.item()) == bool(ee.skip_flag.item()) == overflow
+        assert ge.applied_steps == ee.applied_steps == it + 1 - (1 if it >= 6 else 0)
+        assert torch.equal(ge._ws["counts"][:R], ee._ws["counts"][:R])
+        for name in ("params", "exp_avg", "exp_avg_sq", "params_half", "params_ema", "params_ema_half"):
+            x, y = getattr(ge, name)[lo:hi], getattr(ee, name)[lo:hi]
+            x = x.view(torch.int16) if x.dtype == torch.float16 else x.view(torch.int32)
+            y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
+            assert torch.equal(x, y), f"step {it}: {name} of the hash grid differs ({int((x != y).sum())} words)"
+        assert torch.equal(ge._opt_dev, ee._opt_dev) and torch.equal(ge.density_grid, ee.density_grid)
+        assert torch.allclose(ge.params[:lo], ee.params[:lo], rtol=1e-3, atol=1e-5)
+        assert torch.allclose(ge.pose_adjustment, ee.pose_adjustment, rtol=1e-3, atol=1e-6)
+        assert torch.allclose(ge.losses.sum(0), ee.losses.sum(0), rtol=1e-4, atol=1e-7)
+        if overflow:
+            assert torch.equal(ge.params, before) and torch.equal(ee.params, before)
+        else:
+            assert not torch.equal(ge.params[lo:hi], before[lo:hi])
+    assert len(ray_counts) >= 2 and len(ge._graphs) >= 2 and not ee._graphs
+    assert bool((ge.pose_adjustment != 0).any())
+
+
+def test_scattered_density_refresh_past_the_warmup(device):
+    """Past NgpConfig.density_warmup_steps a refresh evaluates cells / 4 per cascade drawn uniformly + as many among the
+    occupied cells instead of every cell: cells no sample fell into decay by exactly `density_decay`
+    (the EMA with a zero estimate), sampled ones take max(decayed, estimate) >= decayed, never-visible (negative) cells
+    stay, the bitfield follows the oracle's threshold + max-pool of the new grid, and half the density-network
+    evaluations of a full sweep are issued."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.ngp_engine import CELLS, NgpConfig, NgpEngine
+    from oracle import occgrid as O
+
+    eng = NgpEngine(NgpConfig(num_images=4, num_rays=512, capacity=1 << 15, density_warmup_steps=0), device)
+    L = eng.cfg.n_levels
+    rng = np.random.default_rng(11)
+    grid = (rng.random((L, CELLS), dtype=np.float32) ** 8) * 0.2
+    grid[1, 5000:9000] = -1.0
+    eng.density_grid.copy_(torch.from_numpy(grid.reshape(-1)).to(device))
+    eng.step = 48
+    lib = _lib.lib()
+    lib.nvo_profile_enable(1)
+    eng.update_density_grid()
+    torch.cuda.synchronize()
+    need = lib.nvo_profile_summary(None, 0)
+    buf = C.create_string_buffer(int(need) + 16)
+    lib.nvo_profile_summary(buf, len(buf))
+    lib.nvo_profile_enable(0)
+    launches = {ln.rsplit(",", 2)[0]: int(ln.rsplit(",", 2)[1]) for ln in buf.value.decode().strip().splitlines()}
+    assert launches.get("occ_sample_cells") == 2 * (L * CELLS // 4) // (1 << 19) == launches.get("ngp_thickness_splat")
+    assert "occ_cell_positions" not in launches
+    new = eng.density_grid.cpu().numpy().reshape(L, CELLS)
+    decayed = np.where(grid < 0, grid, grid * np.float32(eng.cfg.density_decay))
+    assert (new[grid < 0] == grid[grid < 0]).all()
+    assert (new >= decayed).all()
+    untouched = new == decayed
+    # 2 x (L x cells / 4) samples over L x cells cells, the second pass crowding into the occupied ones (and an estimate
+    # below the decayed value changes nothing): well over a third of the cells, not all, stay at the decayed value
+    assert 0.3 < untouched.mean() < 0.95, untouched.mean()
+    assert (new > decayed).mean() > 0.05
+    bf = eng.bitfield.cpu().numpy().reshape(L, -1)
+    assert (bf == O.grid_to_bitfield(new, L, eng.cfg.occupancy_threshold)).all()
+    # the same step and seed draw the same cells: a second engine from the same state lands on the same grid
+    eng2 = NgpEngine(NgpConfig(num_images=4, num_rays=512, capacity=1 << 15, density_warmup_steps=0), device)
+    eng2.set_params(eng.params.cpu())
+    eng2.density_grid.copy_(torch.from_numpy(grid.reshape(-1)).to(device))
+    eng2.step = 48
+    eng2.update_density_grid()
+    assert torch.equal(eng2.density_grid, eng.density_grid) and torch.equal(eng2.bitfield, eng.bitfield)
+
+
+def test_rays_dropped_at_the_capacity_leave_the_losses_alone(device):
+    """Rays whose samples do not fit the packed capacity are dropped by the march (count 0, slot range kept in the scan).
+    They must not enter the losses as empty rays (black against their target): the loss sums of a batch with dropped rays
+    equal those of the kept rays alone, rescaled by the ray counts of the two means; the scan's total still reports every
+    sample the march found (what the adaptive batch measures)."""
+    eng = _engine(device)
+    cap = eng.cfg.capacity
+    g = torch.Generator().manual_seed(4)
+    R = 1024
+    origins = ((torch.rand(R, 3, generator=g) - 0.5) * 0.6 + 0.5).to(device)
+    directions = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    jitter = torch.rand(R, generator=g).to(device)
+    gt_rgb, gt_depth = torch.rand(R, 3, generator=g).to(device), (torch.rand(R, generator=g) * 0.8).to(device)
+    eng.bitfield.fill_(255)  # everything occupied: ~100 samples per ray, 1024 rays overflow 2^15 slots
+
+    def run(sel):
+        n = int(sel.numel())
+        ws = eng._workspace(n, True)
+        ws["origins"].copy_(origins[sel])
+        ws["directions"].copy_(directions[sel])
+        ws["directions_norm"].fill_(1.0)
+        ws["gt_rgb"].copy_(gt_rgb[sel])
+        ws["gt_depth"].copy_(gt_depth[sel])
+        eng.forward_backward(ws, jitter[sel].contiguous(), has_depth=True)
+        torch.cuda.synchronize()
+        return ws["counts"][:n].clone(), ws["offsets"][:n + 1].clone(), eng.losses.sum(0)[:2].clone(), eng.grads.clone()
+
+    counts, offsets, loss_all, grads_all = run(torch.arange(R, device=device))
+    found = (offsets[1:] - offsets[:-1])
+    dropped = (counts == 0) & (found > 0)
+    assert int(dropped.sum()) > 100 and int(offsets[-1]) > cap >= int(counts.sum()) > 0.9 * cap
+    kept = torch.nonzero(~dropped).flatten()
+    counts_k, _, loss_kept, grads_kept = run(kept)
+    assert torch.equal(counts_k, counts[kept])
+    ratio = kept.numel() / R
+    assert torch.allclose(loss_all, loss_kept * ratio, rtol=2e-3, atol=1e-8), (loss_all, loss_kept * ratio)
+    ref = grads_kept * ratio
+    assert float((grads_all - ref).abs().sum()) <= 2e-2 * float(ref.abs().sum())

@@ -137,3 +137,80 @@ def test_cell_positions_invert_the_index(device):
         u = (p[sel] - 0.5) / (2.0 ** level) + 0.5
         ijk = np.floor(u * 128).astype(np.uint32)
         assert (O.morton3d_numpy(ijk[:, 0], ijk[:, 1], ijk[:, 2]) == sel).all()
+
+
+@pytest.mark.parametrize("n_levels,thresh", [(3, -0.01), (3, 0.01), (1, 0.01), (5, 0.01)])
+def test_refresh_samples_bit_exact(device, n_levels, thresh):
+    """nvo_occ_sample_cells (scattered density-grid refresh past the warm-up) == the numpy restatement:
+    cascade, candidate-cell sequence with the rejection against the grid, point inside the cell -- uint32 / float32 bit
+    for bit; the uniform pass (thresh < 0) skips only untrained (negative) cells, the occupied pass lands on cells above
+    the threshold whenever one of its ten candidates is."""
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    grid = _scene_grid(n_levels, 5)
+    h = 0.5 * (1 << (n_levels - 1))
+    lo, hi = 0.5 - h, 0.5 + h
+    g_dev = torch.from_numpy(grid.reshape(-1)).to(device)
+    n_total, first, n, step, seed, sid = 3 * (1 << 17), 70001, 50000, 4321, 1337, 1
+    x01 = torch.full((n, 3), -7.0, device=device)
+    cells = torch.zeros(n, dtype=torch.int32, device=device)
+    rc = lib.nvo_occ_sample_cells(_stream(), n, first, n_total, step, seed, sid, n_levels, _p(g_dev), thresh, lo, hi,
+                                  _p(x01), _p(cells))
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    want_cells, want_x = O.refresh_samples(n, first, n_total, step, seed, sid, n_levels, grid, thresh, lo, hi)
+    got_cells = cells.cpu().numpy().view(np.uint32)
+    assert (got_cells == want_cells).all()
+    assert (x01.cpu().numpy().view(np.uint32) == want_x.view(np.uint32)).all()
+    vals = grid.reshape(-1)[got_cells]
+    if thresh < 0:
+        assert (vals >= 0).mean() > 0.999  # (1000 untrained cells of 2 M: ten candidates in a row is out of reach)
+    else:
+        assert (vals > thresh).mean() > 0.9 and (grid > thresh).mean() < 0.5
+    # every cascade is drawn, points stay inside the scene box and inside their cell
+    lev = got_cells >> 21
+    assert set(np.unique(lev)) == set(range(n_levels))
+    xs = x01.cpu().numpy()
+    assert xs.min() >= 0.0 and xs.max() <= 1.0
+    cx, cy, cz = O.morton3d_invert_numpy(got_cells & (O.CELLS - 1))
+    p = xs.astype(np.float64) * (hi - lo) + lo
+    for a, c in enumerate((cx, cy, cz)):
+        u = ((p[:, a] - 0.5) / np.ldexp(1.0, lev.astype(np.int32)) + 0.5) * O.GRID
+        assert (np.floor(u + 1e-4) >= c).all() and (u <= c + 1 + 1e-4).all()
+    # bad arguments are refused before any launch
+    assert lib.nvo_occ_sample_cells(_stream(), n, n_total - 10, n_total, step, seed, sid, n_levels, _p(g_dev), thresh, lo, hi,
+                                    _p(x01), _p(cells)) != 0
+
+
+def test_thickness_splat_keeps_the_cell_maximum(device):
+    """nvo_ngp_thickness_splat: fresh[cell] = max over the cell's samples of the thickness nvo_ngp_thickness computes for
+    that sample in the cell's cascade -- bit for bit (same expression), cells without a sample stay 0, NaN is dropped."""
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    n, n_levels = 40000, 3
+    g = torch.Generator().manual_seed(3)
+    out = (torch.randn(n, 16, generator=g) * 3).half()
+    out[17, 0] = float("nan")
+    cells_np = np.random.default_rng(8).integers(0, 5000, n).astype(np.uint32) * 1237 % (n_levels * O.CELLS)
+    cells_np[0:13000] = cells_np[13000:26000]  # duplicates
+    cells = torch.from_numpy(cells_np.view(np.int32)).to(device)
+    out_d = out.to(device)
+    fresh = torch.zeros(n_levels * O.CELLS, device=device)
+    assert lib.nvo_ngp_thickness_splat(_stream(), n, _p(out_d), 16, _p(cells), _p(fresh)) == 0, _lib.last_error()
+    per_level = []
+    for level in range(n_levels):
+        tmp = torch.empty(n, device=device)
+        assert lib.nvo_ngp_thickness(_stream(), n, _p(out_d), 16, level, _p(tmp)) == 0
+        per_level.append(tmp.cpu().numpy())
+    torch.cuda.synchronize()
+    per = np.stack(per_level)[cells_np >> 21, np.arange(n)]
+    want = np.zeros(n_levels * O.CELLS, np.float32)
+    ok = ~np.isnan(per)
+    np.maximum.at(want, cells_np[ok], per[ok])
+    got = fresh.cpu().numpy()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    assert (got > 0).sum() == len(np.unique(cells_np[ok]))

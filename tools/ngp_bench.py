@@ -53,21 +53,29 @@ def run(a, quiet: bool = False):
     for _ in range(a.warmup):
         tb.frame()
     torch.cuda.synchronize()
+    eng = tb._engine
+    cap0 = (eng.graph_captures, eng.graph_capture_seconds)
+    batches = set()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        batches.add(eng.rays_per_batch)
         tb.frame()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    eng = tb._engine
+    say(f"timed window: {a.steps} steps from step {eng.step - a.steps}, ray batches {sorted(batches)}, "
+        f"{eng.graph_captures - cap0[0]} graph captures taking {(eng.graph_capture_seconds - cap0[1]) * 1e3:.1f} ms in all")
     if a.profile:
         import ctypes as C
 
         from nerf_vo_amd import _lib
         lib = _lib.lib()
         lib.nvo_profile_enable(1)
+        graphed = eng.cfg.graph_step
+        eng.cfg.graph_step = False  # (the per-kernel clocks bracket eager launches)
         for _ in range(32):
             tb.frame()
         torch.cuda.synchronize()
+        eng.cfg.graph_step = graphed
         need = lib.nvo_profile_summary(None, 0)
         buf = C.create_string_buffer(int(need) + 16)
         lib.nvo_profile_summary(buf, len(buf))
@@ -120,7 +128,9 @@ def run(a, quiet: bool = False):
                           "dtype": "f16", "data": "synthetic",
                           "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H}, aabb_scale 4, "
                                                  f"capacity {cap} packed samples, extrinsics optimisation "
-                                                 f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch"},
+                                                 f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch",
+                                     "launch": "hipGraph replay: ONE graph per step (per ray count), density-grid refresh "
+                                               "eager every 16th step" if eng.cfg.graph_step else "eager"},
                           "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof,
                           "kernel_ms_per_step": round(tot / 32, 4),
                           "kernel_table": [{"kernel": nm, "launches_per_step": round(c / 32, 2), "avg_launch_us": round(t / c * 1e3, 1)}
