@@ -500,6 +500,18 @@ int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* 
                    float threshold, uint8_t* bitfield, void* scratch8);
 /* centres (or jittered points, jitter device float [128^3][3]) of cascade `level` cells, Morton order */
 int nvo_occ_cell_positions(nvo_stream_t stream, int level, const float* jitter, float* positions);
+/* Cells no training camera sees are taken out of training (SURVEY.md section 2.4 K16 `mark_untrained_density_grid`
+ * [UPSTREAM instant-ngp testbed_nerf.cu]; reached through pyngp's frame(), /root/reference/nerf_vo/mapping/instant_ngp.py:
+ * 104-105, at step 0 and whenever training images were added): a cell of any cascade stays trainable iff one of its
+ * eight corners lies in front of one of the first n_images cameras (cosine to the viewing axis >= 1e-4) and projects
+ * strictly inside its H x W image -- grown on every side by `margin` projected cell diagonals (margin * f * sqrt(3) *
+ * cell size / depth pixels; 0 = upstream's rule, which also excludes cells the frustum clips without containing one of
+ * their corners: on small images that blanks the border rows of a view no other camera shares).  intrinsics [F][4] = (fx, fy, cx, cy) in pixels, c2w [F][3][4] (OpenGL axes, the
+ * engine's normalised frame; the cameras nvo_rays_given takes).  A trainable cell that was marked becomes 0, a cell without
+ * a view -1 (never occupied: nvo_occ_update keeps negative values, nvo_occ_sample_cells passes them over); others keep
+ * their value. */
+int nvo_occ_mark_untrained(nvo_stream_t stream, int n_levels, float* grid, uint32_t n_images, const float* intrinsics,
+                           const float* c2w, uint32_t H, uint32_t W, float margin);
 /* Refresh samples of the density grid PAST the first 256 steps ("all cells first 256 steps";
  * [UPSTREAM instant-ngp Testbed::update_density_grid_nerf / generate_grid_samples_nerf_nonuniform] -- the call the
  * reference reaches through pyngp's frame(), /root/reference/nerf_vo/mapping/instant_ngp.py:104-105): samples

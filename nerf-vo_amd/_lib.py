@@ -169,6 +169,7 @@ _SIGNATURES = {
     "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64]),
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
+    "nvo_occ_mark_untrained": (_int, [_p, _int, _p, _u32, _p, _p, _u32, _u32, _f]),
     "nvo_occ_sample_cells": (_int, [_p, _u32, _u32, _u32, _u32, _u32, _u32, _int, _p, _f, _f, _f, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
     "nvo_depth_align_scratch_bytes": (_u64, [_u32, _u32]),

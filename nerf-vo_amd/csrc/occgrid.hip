@@ -424,6 +424,59 @@ k_occ_sample_cells(uint32_t n, uint32_t first, uint32_t n_total, uint32_t step, 
     cell_idx[k] = level * kCells + idx;
 }
 
+// Cells no training camera sees are taken out of training [UPSTREAM instant-ngp mark_untrained_density_grid]: a cell of
+// any cascade stays trainable iff one of its eight corners lies in front of some camera (cos of the angle to the viewing
+// axis >= 1e-4) and projects strictly inside that camera's image.  Pinhole cameras in the engine's convention (OpenGL
+// axes: pixel (px, py) looks along R ((px - cx) / fx, -(py - cy) / fy, -1), nvo_rays_given).  margin = 0 is upstream's
+// rule; see the projection below for margin > 0.  grid: trainable cells that
+// were marked come back as 0, cells that lose their last view become -1 (never occupied, never refreshed); all others keep
+// their value.
+__global__ void __launch_bounds__(256)
+k_occ_mark_untrained(uint64_t n, float* __restrict__ grid, uint32_t n_images, const float* __restrict__ intrinsics,
+                     const float* __restrict__ c2w, float W, float H, float margin) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t level = (uint32_t)(i / kCells), idx = (uint32_t)(i % kCells);
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // inverse Morton
+        uint32_t v = (idx >> a) & 0x49249249u;
+        v = (v ^ (v >> 2)) & 0xC30C30C3u;
+        v = (v ^ (v >> 4)) & 0x0F00F00Fu;
+        v = (v ^ (v >> 8)) & 0xFF0000FFu;
+        v = (v ^ (v >> 16)) & 0x0000FFFFu;
+        c[a] = v;
+    }
+    const float scale = scalbnf(1.0f, (int)level);
+    const float size = scalbnf(1.0f / (float)kG, (int)level);
+    float p0[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p0[a] = ((float)c[a] / (float)kG - 0.5f) * scale + 0.5f;
+    bool seen = false;
+    for (uint32_t j = 0; j < n_images && !seen; ++j) {
+        const float* __restrict__ m = c2w + 12 * (size_t)j;
+        const float fx = intrinsics[4 * j + 0], fy = intrinsics[4 * j + 1], cx = intrinsics[4 * j + 2], cy = intrinsics[4 * j + 3];
+        for (uint32_t k = 0; k < 8u && !seen; ++k) {
+            const float d[3] = {p0[0] + ((k & 1u) ? size : 0.f) - m[3], p0[1] + ((k & 2u) ? size : 0.f) - m[7],
+                                p0[2] + ((k & 4u) ? size : 0.f) - m[11]};
+            // camera frame: q = R^T d
+            const float qx = m[0] * d[0] + m[4] * d[1] + m[8] * d[2];
+            const float qy = m[1] * d[0] + m[5] * d[1] + m[9] * d[2];
+            const float qz = m[2] * d[0] + m[6] * d[1] + m[10] * d[2];
+            const float depth = -qz;
+            const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            if (!(depth >= 1e-4f * len) || !(depth > 0.f)) continue;
+            const float px = cx + fx * (qx / depth), py = cy - fy * (qy / depth);
+            // margin > 0: the image grows by `margin` projected cell diagonals on every side, so that a cell the
+            // frustum only clips (no corner inside it) keeps its view
+            const float mx = margin * (fx * (size * 1.7320508f / depth)), my = margin * (fy * (size * 1.7320508f / depth));
+            seen = px > -mx && py > -my && px < W + mx && py < H + my;
+        }
+    }
+    const float g = grid[i];
+    if ((g < 0.f) != !seen) grid[i] = seen ? 0.f : -1.f;
+}
+
 // cell centres of one cascade in Morton order, normalised frame; jitter [cells][3] in [0,1) or null
 __global__ void __launch_bounds__(256)
 k_occ_cell_positions(int level, const float* __restrict__ jitter, float* __restrict__ pos) {
@@ -535,6 +588,18 @@ int nvo_occ_sample_cells(nvo_stream_t stream, uint32_t n, uint32_t first, uint32
     NVO_PROF(stream, "occ_sample_cells");
     NVO_LAUNCH(k_occ_sample_cells, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, first, n_total, step, seed,
                stream_id, n_levels, grid, thresh, aabb_lo, aabb_hi, x01, cell_idx);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_occ_mark_untrained(nvo_stream_t stream, int n_levels, float* grid, uint32_t n_images, const float* intrinsics,
+                           const float* c2w, uint32_t H, uint32_t W, float margin) {
+    NVO_REQUIRE(n_levels >= 1 && n_levels <= 8 && grid && (n_images == 0 || (intrinsics && c2w)) && H > 0 && W > 0 && margin >= 0.f,
+                "occ_mark_untrained: bad argument");
+    NVO_PROF(stream, "occ_mark_untrained");
+    const uint64_t n = (uint64_t)n_levels * kCells;
+    NVO_LAUNCH(k_occ_mark_untrained, dim3(nvo_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, grid, n_images, intrinsics,
+               c2w, (float)W, (float)H, margin);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -16,7 +16,9 @@ so that a multi-GPU step needs exactly one RCCL all-reduce and one optimiser pas
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import gc
 import json
 import math
 from dataclasses import dataclass, field
@@ -26,6 +28,21 @@ import torch
 
 from . import _lib
 from .tinycudann.modules import _NativeModule, _create, _ptr, _stream
+
+
+@contextlib.contextmanager
+def capture_graph(graph: "torch.cuda.CUDAGraph", **kw):
+    """torch.cuda.graph(graph) with the cyclic garbage collector held off while the stream records: a finaliser that frees
+    device memory or destroys another graph in the middle of a capture invalidates it (hipErrorStreamCaptureInvalidated --
+    seen when engines of earlier runs were still waiting for the collector)."""
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 @dataclass
@@ -1606,7 +1623,7 @@ class NerfactoEngine:
 
         def capture(fn, **kw):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **kw):
+            with capture_graph(g, **kw):
                 fn()
             return g
 
@@ -1903,7 +1920,7 @@ class NerfactoEngine:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with capture_graph(g):
             self._render_chunks(entry, ws, lambda: _stream(dev))
         entry["graph"] = g
         return entry

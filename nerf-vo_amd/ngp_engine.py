@@ -26,7 +26,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _lib
-from .engine import GridConfig, _call
+from .engine import GridConfig, _call, capture_graph
 from .tinycudann.modules import _create, _ptr, _stream
 
 CELLS = 128 ** 3
@@ -47,6 +47,14 @@ class NgpConfig:
     # evaluations of a full sweep) [UPSTREAM Testbed::training_prep_nerf: `m_training_step < 256` -> all cells, else
     # n_cells / 4 * n_cascades uniform + the same number non-uniform; SURVEY.md section 2.4 K16]
     density_warmup_steps: int = 256
+    # cells no training camera sees are excluded from training (grid value -1: never occupied, never refreshed), at step 0
+    # and whenever images were added [UPSTREAM mark_untrained_density_grid; SURVEY.md section 2.4 K16]
+    mark_untrained: bool = True
+    # upstream keeps a cell iff one of its CORNERS projects inside an image, which also drops cells a frustum merely clips
+    # (on the 120 x 68 test images the border rows of a view no other camera shares rendered black: 17 -> 14.9 dB); the
+    # image is therefore grown by this many projected cell diagonals -- a superset of upstream's trainable cells (0 =
+    # upstream's rule)
+    mark_untrained_margin: float = 1.0
     density_decay: float = 0.95
     occupancy_threshold: float = 0.01
     rgb_loss_mult: float = 1.0
@@ -180,9 +188,12 @@ class NgpEngine:
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
         self._kernels_loaded = False
         self.graph_captures, self.graph_capture_seconds = 0, 0.0  # (diagnostics: tools/ngp_bench.py)
+        self.n_training_images = None   # images in use (pyngp: nerf.training.n_images_for_training); None = all slots
+        self._marked_images = None      # the image count the untrained cells were last marked for
         self._measured_acc = torch.zeros(1, dtype=torch.int64, device=dev)  # marched samples since the last adaptation
         self._measured_n = 0
-        self._ws = None
+        self._ws = None                      # the workspace used last
+        self._wss = {True: None, False: None}  # one for training, one for inference (switching keeps both, and the captured steps)
         # camera offsets [F][6] = (translation, rotation vector) and their optimiser state
         F6 = cfg.num_images * 6
         self.pose_adjustment, self.pose_grads = z(F6), z(F6)
@@ -233,8 +244,9 @@ class NgpEngine:
     def _workspace(self, R: int, training: bool):
         """Scratch for up to R_cap >= R rays (power of two: the adaptive batch changes R every few steps; the kernels
         take R as an argument and only touch the first R rows)."""
-        ws = self._ws
-        if ws is not None and ws["training"] == training and R <= ws["R_cap"]:
+        ws = self._wss[training]
+        if ws is not None and R <= ws["R_cap"] and ("dx01" in ws or not (training and self.cfg.optimize_extrinsics)):
+            self._ws = ws
             return self._ray_views(ws, R)
         R_req, R = R, max(4096, 1 << max(0, (R - 1).bit_length()))
         key = (R, training)
@@ -271,7 +283,9 @@ class NgpEngine:
                 ws["d_origin"] = torch.zeros(R, 3, **f32)
                 ws["d_dir"] = torch.zeros(R, 3, **f32)
         ws["_per_ray"] = {k: ws[k] for k in self._PER_RAY if k in ws}
-        self._graphs.clear()  # (captured steps address the old buffers)
+        if training:
+            self._graphs.clear()  # (captured steps address the old buffers)
+        self._wss[training] = ws
         self._ws = ws
         return self._ray_views(ws, R_req)
 
@@ -338,6 +352,14 @@ class NgpEngine:
         _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
               cfg.occupancy_threshold, _ptr(self.bitfield), _ptr(self._scratch8))
 
+    @torch.no_grad()
+    def mark_untrained_cells(self, intrinsics, c2w, n_images: int, H: int, W: int) -> None:
+        """mark_untrained_density_grid: cells none of the first ``n_images`` cameras sees get -1 (excluded from training and
+        from the bitfield), cells that gained a view come back as 0.  Takes effect with the next update_density_grid()."""
+        _call("nvo_occ_mark_untrained", _stream(self.device), self.cfg.n_levels, _ptr(self.density_grid), int(n_images),
+              _ptr(intrinsics), _ptr(c2w), int(H), int(W), float(self.cfg.mark_untrained_margin))
+        self._marked_images = int(n_images)
+
     # ---- forward / backward ------------------------------------------------------------------
     def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths) -> None:
         stream = _stream(self.device)
@@ -359,16 +381,26 @@ class NgpEngine:
         ws["sh_ready"] = True
 
     def _forward(self, ws, training: bool, jitter, stream) -> None:
+        self._march(ws, jitter, stream)
+        self._shade(ws, training, stream)
+
+    def _march(self, ws, jitter, stream) -> None:
+        """Packed samples of the workspace's rays: counts / offsets (offsets[R] = samples found, before rays were dropped
+        at the capacity), ray_idx / t / dt."""
         cfg = self.cfg
         R, cap = ws["R"], cfg.capacity
-        lo, hi = cfg.aabb
-        # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
-        self._fwd_half = self.params_half if training else self.inference_params_half()
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
               _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), _ptr(ws["march_scratch"]),
               ws["march_scratch"].numel())
+
+    def _shade(self, ws, training: bool, stream) -> None:
+        cfg = self.cfg
+        R, cap = ws["R"], cfg.capacity
+        lo, hi = cfg.aabb
+        # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
+        self._fwd_half = self.params_half if training else self.inference_params_half()
         _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
               _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
         _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),
@@ -580,6 +612,9 @@ class NgpEngine:
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
         if self.step % self.cfg.density_update_every == 0:
+            n_train = int(self.n_training_images) if self.n_training_images else int(images.shape[0])
+            if self.cfg.mark_untrained and (self.step == 0 or n_train != self._marked_images):
+                self.mark_untrained_cells(intrinsics, c2w, n_train, int(images.shape[1]), int(images.shape[2]))
             self.update_density_grid(all_reduce=all_reduce)
         self._sync_opt_dev()
         if self.cfg.graph_step and all_reduce is None:
@@ -648,7 +683,7 @@ class NgpEngine:
                 key = key[:-1] + (False,)
             t0 = time.perf_counter()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):  # (no cyclic garbage collection while the stream records)
                 self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
             self.graph_captures += 1
             self.graph_capture_seconds += time.perf_counter() - t0
@@ -721,13 +756,23 @@ class NgpEngine:
 
     @torch.no_grad()
     def render_rays(self, origins, directions, directions_norm):
+        """rgb / depth / accumulation of a ray bundle with the inference weights.  Every sample the march finds is shaded
+        (no early termination), so a bundle may hold more samples than the packed capacity: the march's total is read
+        back (one synchronisation per call) and an overflowing bundle is rendered as two halves -- no ray is dropped."""
         R = origins.shape[0]
         ws = self._workspace(R, False)
         ws["origins"].copy_(origins)
         ws["directions"].copy_(directions)
         ws["directions_norm"].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
-        self._forward(ws, False, None, stream)
+        self._march(ws, None, stream)
+        if R > 1 and int(ws["offsets"][-1].item()) > self.cfg.capacity:
+            h = R // 2
+            dn = directions_norm.reshape(-1)
+            a = self.render_rays(origins[:h].contiguous(), directions[:h].contiguous(), dn[:h].contiguous())
+            b = self.render_rays(origins[h:].contiguous(), directions[h:].contiguous(), dn[h:].contiguous())
+            return {k: torch.cat([a[k], b[k]]) for k in a}
+        self._shade(ws, False, stream)
         la = self._loss_args(ws, False, False, None)
         _call("nvo_ngp_composite_loss", stream, C.byref(la))
         return {"rgb": ws["out_rgb"].clamp(0, 1), "depth": ws["out_depth"].clone()[:, None],

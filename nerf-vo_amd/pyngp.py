@@ -231,6 +231,7 @@ class Testbed:
             return True
         eng = self._engine
         eng.cfg.optimize_extrinsics = bool(self.nerf.training.optimize_extrinsics)
+        eng.n_training_images = n
         h, w = self._resolution
         if self._draw_scale is None or self._draw_scale[0] != (n, h, w):  # (one upload per change, not per frame)
             self._draw_scale = ((n, h, w), torch.tensor([n, h, w], device=self.device, dtype=torch.float32))
@@ -328,8 +329,8 @@ class Testbed:
         """float32 [height, width, 4].  Shade: alpha-premultiplied linear RGB + alpha (the reference divides by
         alpha, nerf_renderer.py:274-277); Depth: z-depth in every channel (it reads channel 0, :296).  Pinhole with
         the focal length of ``fov`` along ``fov_axis``, square pixels and a centred principal point, like the
-        testbed's free camera.  (2048 rays per launch: the engine's packed-sample capacity of 2^18 then leaves 128
-        marched samples per ray; rays beyond the capacity would be dropped whole.)"""
+        testbed's free camera.  (2048 rays per launch: 128 marched samples per ray fill the engine's packed-sample capacity of
+        2^18; a bundle that finds more is rendered in halves by NgpEngine.render_rays, no ray is dropped.)"""
         if self._engine is None:
             raise RuntimeError("render: no network has been trained or loaded")
         if not linear:

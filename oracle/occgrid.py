@@ -129,3 +129,38 @@ def refresh_samples(n, first, n_total, step, seed, stream_id, n_levels, grid, th
         p = (u - np.float32(0.5)) * scale + np.float32(0.5)
         x01[:, a] = np.clip((p - lo) / (hi - lo), np.float32(0.0), np.float32(1.0))
     return level * np.uint32(CELLS) + idx, x01
+
+
+def cells_seen(cell_idx, n_levels, intrinsics, c2w, H, W, margin=0.0):
+    """Which cells (level * 128^3 + Morton index) some camera sees [UPSTREAM instant-ngp mark_untrained_density_grid;
+    SURVEY.md section 2.4 K16]: one of the eight corners in front of a camera (cosine to the viewing axis >= 1e-4) and
+    projecting strictly inside its image (grown by `margin` projected cell diagonals on every side; 0 = upstream).  Pinhole cameras, OpenGL axes: c2w [F,3,4], intrinsics [F,4] = fx, fy, cx, cy.
+    float32 operations in the kernel's order."""
+    f32 = np.float32
+    cell_idx = np.asarray(cell_idx, np.uint32)
+    level = (cell_idx // np.uint32(CELLS)).astype(np.int32)
+    c = morton3d_invert_numpy(cell_idx % np.uint32(CELLS))
+    scale = np.ldexp(f32(1.0), level).astype(f32)
+    size = np.ldexp(f32(1.0 / GRID), level).astype(f32)
+    p0 = [((c[a].astype(f32) / f32(GRID) - f32(0.5)) * scale + f32(0.5)).astype(f32) for a in range(3)]
+    seen = np.zeros(cell_idx.shape, bool)
+    K = np.asarray(intrinsics, f32)
+    M = np.asarray(c2w, f32).reshape(-1, 12)
+    for j in range(M.shape[0]):
+        m = M[j]
+        fx, fy, cx, cy = K[j]
+        for k in range(8):
+            d = [(p0[a] + (size if (k >> a) & 1 else f32(0.0))).astype(f32) - m[4 * a + 3] for a in range(3)]
+            qx = (m[0] * d[0] + m[4] * d[1]) + m[8] * d[2]
+            qy = (m[1] * d[0] + m[5] * d[1]) + m[9] * d[2]
+            qz = (m[2] * d[0] + m[6] * d[1]) + m[10] * d[2]
+            depth = -qz
+            ln = np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]).astype(f32)
+            front = (depth >= f32(1e-4) * ln) & (depth > 0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                px = cx + fx * (qx / depth)
+                py = cy - fy * (qy / depth)
+                mx = f32(margin) * (fx * (size * f32(1.7320508) / depth))
+                my = f32(margin) * (fy * (size * f32(1.7320508) / depth))
+            seen |= front & (px > -mx) & (py > -my) & (px < f32(W) + mx) & (py < f32(H) + my)
+    return seen

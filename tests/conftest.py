@@ -42,3 +42,22 @@ def _poisoned_allocator(request):
                       for n in (1 << 8, 1 << 12, 1 << 16, 1 << 19, 1 << 22, 1 << 24, 1 << 26) for _ in range(3)]
             del blocks
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity margins of the session: for every float comparison against the oracle (test_tcnn_gpu._assert_close), the
+    largest error in units of the stated bound, the relative L1 error and the share of elements outside the bound --
+    written next to the run's other outputs (NVO_PARITY_MARGINS, default gpurun_out/parity_margins.json)."""
+    mod = sys.modules.get("test_tcnn_gpu")
+    rows = getattr(mod, "MARGINS", None) if mod is not None else None
+    if not rows:
+        return
+    import json
+
+    path = os.environ.get("NVO_PARITY_MARGINS", os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(rows, fh, indent=0)
+    except OSError:
+        pass

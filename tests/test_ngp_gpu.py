@@ -196,6 +196,11 @@ def test_density_grid_update_and_training(device):
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-10:])
     assert int(eng.skip_flag.item()) == 0
+    # the first step marked the cells no camera sees (NgpConfig.mark_untrained): they stay negative and unoccupied
+    unseen = (eng.density_grid < 0).cpu().numpy()
+    assert eng._marked_images == n and 0.05 < unseen.mean() < 0.99
+    bits = np.unpackbits(eng.bitfield.cpu().numpy(), bitorder="little").astype(bool)
+    assert not bits[: unseen.size // eng.cfg.n_levels][unseen[: unseen.size // eng.cfg.n_levels]].any()
 
 
 def test_weight_ema_matches_tcnn_formula(device):
@@ -325,8 +330,10 @@ def test_adam_and_ema_inside_the_grid_backward_are_bit_identical(device):
             assert torch.equal(x, y), f"step {it}: {name} of the fused range differs ({int((x != y).sum())} words)"
             if overflow and before is not None:
                 assert torch.equal(getattr(fe, name), before[name]), f"skipped step moved {name}"
-        # the rest of the parameters went through the same launches in both engines (float atomics in the MLP dW: close)
-        assert torch.allclose(fe.params[:lo], ue.params[:lo], rtol=1e-3, atol=1e-5)
+        # the rest of the parameters went through the same launches in both engines: close, except where the float atomics
+        # of the MLP dW leave a near-zero total with either sign (Adam turns that into +- lr): a handful of entries
+        d = (fe.params[:lo] - ue.params[:lo]).abs()
+        assert float((d > 1e-5 + 1e-3 * ue.params[:lo].abs()).float().mean()) < 0.02
     assert bool((fe.params[lo:hi] != 0).any()) and bool((fe.params_ema[lo:hi] != 0).any())
 
 
@@ -384,7 +391,8 @@ def test_graphed_step_matches_eager_step(device):
             y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
             assert torch.equal(x, y), f"step {it}: {name} of the hash grid differs ({int((x != y).sum())} words)"
         assert torch.equal(ge._opt_dev, ee._opt_dev) and torch.equal(ge.density_grid, ee.density_grid)
-        assert torch.allclose(ge.params[:lo], ee.params[:lo], rtol=1e-3, atol=1e-5)
+        d = (ge.params[:lo] - ee.params[:lo]).abs()  # (MLP weights: float-atomic dW totals, see the test above)
+        assert float((d > 1e-5 + 1e-3 * ee.params[:lo].abs()).float().mean()) < 0.02
         assert torch.allclose(ge.pose_adjustment, ee.pose_adjustment, rtol=1e-3, atol=1e-6)
         assert torch.allclose(ge.losses.sum(0), ee.losses.sum(0), rtol=1e-4, atol=1e-7)
         if overflow:
@@ -483,3 +491,30 @@ def test_rays_dropped_at_the_capacity_leave_the_losses_alone(device):
     assert torch.allclose(loss_all, loss_kept * ratio, rtol=2e-3, atol=1e-8), (loss_all, loss_kept * ratio)
     ref = grads_kept * ratio
     assert float((grads_all - ref).abs().sum()) <= 2e-2 * float(ref.abs().sum())
+
+
+def test_render_splits_bundles_that_overflow_the_capacity(device):
+    """NgpEngine.render_rays shades every sample the march finds; a bundle with more samples than the packed capacity
+    must come out exactly as from an engine whose capacity holds it whole (rendered in halves, no ray dropped -- dropped
+    rays used to come back black), and switching between training and rendering keeps both workspaces."""
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+
+    small = _engine(device)                                   # capacity 2^15
+    big = NgpEngine(NgpConfig(num_images=4, capacity=1 << 18), device)
+    big.set_params(small.params.cpu())
+    for e in (small, big):
+        e.bitfield.fill_(255)                                 # every cell occupied: hundreds of samples per ray
+    g = torch.Generator().manual_seed(12)
+    R = 256
+    origins = ((torch.rand(R, 3, generator=g) - 0.5) * 0.6 + 0.5).to(device)
+    directions = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    dnorm = torch.ones(R, device=device)
+    ws_train = small._workspace(64, True)
+    a = small.render_rays(origins, directions, dnorm)
+    b = big.render_rays(origins, directions, dnorm)
+    total = int(big._ws["offsets"][-1].item())
+    assert small.cfg.capacity * 4 < total <= big.cfg.capacity
+    for k in ("rgb", "depth", "accumulation"):
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    assert float(b["accumulation"].min()) > 0.0
+    assert small._workspace(64, True) is ws_train and small._wss[False] is not None

@@ -214,3 +214,47 @@ def test_thickness_splat_keeps_the_cell_maximum(device):
     got = fresh.cpu().numpy()
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
     assert (got > 0).sum() == len(np.unique(cells_np[ok]))
+
+
+@pytest.mark.parametrize("margin", [0.0, 1.0])
+def test_mark_untrained_cells_matches_the_oracle(device, margin):
+    """nvo_occ_mark_untrained (SURVEY.md 2.4 K16 mark_untrained_density_grid): the seen / unseen verdict of every sampled
+    cell equals the numpy restatement's; unseen cells become -1, seen cells that were marked come back as 0, every other
+    value is kept; with more cameras no cell loses its view."""
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    n_levels, F, H, W = 3, 6, 60, 80
+    seq = make_sequence(F, H, W, device=device, scene_scale=0.2)
+    c2w = opencv_to_opengl(seq["camera_extrinsics"])
+    c2w[:, :3, 3] += 0.5
+    c2w = c2w[:, :3, :4].contiguous()
+    K = seq["camera_intrinsics"].contiguous()
+    rng = np.random.default_rng(2)
+    grid = rng.random(n_levels * O.CELLS, dtype=np.float32) * 0.05
+    grid[::5] = -1.0
+    g = torch.from_numpy(grid).to(device)
+    assert lib.nvo_occ_mark_untrained(_stream(), n_levels, _p(g), 3, _p(K), _p(c2w), H, W, margin) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    got = g.cpu().numpy()
+    cells = rng.integers(0, n_levels * O.CELLS, 150000).astype(np.uint32)
+    seen = O.cells_seen(cells, n_levels, K.cpu().numpy()[:3], c2w.cpu().numpy()[:3], H, W, margin)
+    if margin > 0:  # a superset of upstream's trainable cells
+        strict = O.cells_seen(cells, n_levels, K.cpu().numpy()[:3], c2w.cpu().numpy()[:3], H, W, 0.0)
+        assert (seen | ~strict).all() and seen.sum() > strict.sum()
+    assert 0.02 < seen.mean() < 0.98
+    was_marked = grid[cells] < 0
+    want = np.where(seen, np.where(was_marked, np.float32(0.0), grid[cells]), np.float32(-1.0))
+    assert (got[cells].view(np.uint32) == want.view(np.uint32)).all(), int((got[cells] != want).sum())
+    # the coarser the cascade, the larger the share of cells outside every frustum; more cameras only add views
+    g6 = torch.from_numpy(grid).to(device)
+    assert lib.nvo_occ_mark_untrained(_stream(), n_levels, _p(g6), F, _p(K), _p(c2w), H, W, margin) == 0
+    got6 = g6.cpu().numpy()
+    assert ((got6 >= 0) | (got < 0)).all() and (got6 >= 0).sum() > (got >= 0).sum()
+    # marking again with the same cameras changes nothing
+    g6b = g6.clone()
+    assert lib.nvo_occ_mark_untrained(_stream(), n_levels, _p(g6b), F, _p(K), _p(c2w), H, W, margin) == 0
+    assert torch.equal(g6b, g6)

@@ -9,6 +9,7 @@ Tolerances (stated per north_star: fp32 tolerance for outputs, bit-exact for has
   * gradients: fp32 accumulation of fp16 products over the batch -> rtol 2e-2 / atol 2e-2*scale.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -56,6 +57,9 @@ def _points(n, seed, edge_cases=True):
 BF16_K = 8.0
 
 
+MARGINS = []  # one record per _assert_close call of the session
+
+
 def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0, max_outlier=0.05):
     """|got-ref| <= atol_scale*max|ref| + rtol*|ref| elementwise.  max_outlier_frac > 0 is only used
     for gradients that pass through ReLU kinks: a hidden unit whose pre-activation is within fp16
@@ -68,6 +72,13 @@ def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0, max_ou
     err = (got - ref).abs()
     bound = atol_scale * scale + rtol * ref.abs()
     bad = err > bound
+    # how much of each stated tolerance the comparison actually used (conftest writes the session's table:
+    # profiles/*_parity_margins.json)
+    MARGINS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "what": what, "elements": int(bad.numel()),
+                    "rtol": rtol, "atol_scale": atol_scale, "worst_error_over_bound": float((err / bound.clamp_min(1e-300)).max()),
+                    "rel_l1": float(err.sum() / max(ref.abs().sum().item(), 1e-300)),
+                    "outlier_frac_allowed": max_outlier_frac, "outlier_frac": float(bad.sum()) / max(1, bad.numel()),
+                    "max_error_over_scale": float(err.max()) / scale})
     if max_outlier_frac > 0 and bad.sum().item() <= max_outlier_frac * bad.numel():
         assert err.max().item() <= max_outlier * scale, f"{what}: outlier too large {err.max().item():.3e} (scale {scale:.3e})"
         return
