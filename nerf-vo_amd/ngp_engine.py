@@ -665,6 +665,9 @@ class NgpEngine:
             self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
             self._kernels_loaded = True
             return
+        if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
+            self.params_ema = torch.zeros_like(self.params)
+            self.params_ema_half = torch.zeros_like(self.params_half)
         key = (R, ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
                None if depths is None else depths.data_ptr(), bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
                self._fused_adam_plan(),
@@ -672,15 +675,11 @@ class NgpEngine:
                (cfg.loss_scale, cfg.lr, cfg.rgb_loss_mult, cfg.depth_loss_mult, cfg.l2_reg, cfg.extrinsic_l2_reg, cfg.ema_decay,
                 cfg.cone_angle, cfg.near_distance, tuple(cfg.adam_betas), cfg.adam_eps, bool(cfg.random_background),
                 int(cfg.dw_replicas), self.world_size),
-               self.params_ema is None)
+               0 if self.params_ema is None else self.params_ema.data_ptr())
         entry = self._graphs.get(key)
         if entry is None:
             if len(self._graphs) >= self._MAX_GRAPHS:
                 self._graphs.clear()
-            if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
-                self.params_ema = torch.zeros_like(self.params)
-                self.params_ema_half = torch.zeros_like(self.params_half)
-                key = key[:-1] + (False,)
             t0 = time.perf_counter()
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):  # (no cyclic garbage collection while the stream records)

@@ -119,14 +119,25 @@ def run(a, quiet: bool = False):
             return None, None
 
         roof = None
+        plan = eng._fused_adam_plan()
+        fused_n = (plan[1] - plan[0]) if plan else 0
+        # the record pass steps the parameters of its streamed hashed levels itself: Adam at 28 B per parameter (bench.py's
+        # figure) + the weight average folded in (fp32 average read + written, 16-bit copy: 10 B)
+        per_param = 28 + (10 if eng.cfg.ema_decay > 0.0 else 0)
         for name, bytes_per_sample in (("grid_bwd_stream[L16]", 1100), ("grid_fwd[L16]", 588)):
             if name in per:
-                b = cap * bytes_per_sample
+                scatter = cap * bytes_per_sample
+                b = scatter + (per_param * fused_n if name == "grid_bwd_stream[L16]" else 0)
                 traffic, src = pmc_traffic(name)
                 roof = roof or {"kernel": name, "bound": "hbm", "achieved": round(b / per[name] / 1e9, 1), "peak": 8000.0,
                                 "unit": "GB/s", "frac": round(b / per[name] / 1e9 / 8000.0, 4), "traffic": traffic,
                                 "traffic_source": src,
-                                "avg_launch_us": round(per[name] * 1e6, 1), "algorithmic_bytes_per_launch": b}
+                                "avg_launch_us": round(per[name] * 1e6, 1), "algorithmic_bytes_per_launch": b,
+                                "bytes_model": f"SURVEY.md 8d: {bytes_per_sample} B x {cap} packed samples" + (
+                                    f" + {per_param} B x {fused_n} parameters stepped and averaged inside the pass"
+                                    if (fused_n and name == "grid_bwd_stream[L16]") else ""),
+                                "samples_only": {"algorithmic_bytes_per_launch": scatter,
+                                                 "frac": round(scatter / per[name] / 1e9 / 8000.0, 4)}}
         out = {"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
                           "unit": "samples/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "rays_per_batch": eng.rays_per_batch,
                           "dtype": "f16", "data": "synthetic",
