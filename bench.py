@@ -542,7 +542,7 @@ def main() -> None:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import ngp_bench
 
-        ngp = ngp_bench.run(argparse.Namespace(steps=args.ngp_steps, warmup=300, keyframes=48, extrinsics=1,
+        ngp = ngp_bench.run(argparse.Namespace(steps=args.ngp_steps, warmup=300, keyframes=48, extrinsics=1, render_frames=3,
                                                profile=not args.no_kernel_table), quiet=True)
 
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)

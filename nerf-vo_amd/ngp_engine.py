@@ -188,6 +188,7 @@ class NgpEngine:
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
         self._kernels_loaded = False
         self.graph_captures, self.graph_capture_seconds = 0, 0.0  # (diagnostics: tools/ngp_bench.py)
+        self.params_version = 0         # bumped whenever the weights inference reads may have changed (render caches)
         self.n_training_images = None   # images in use (pyngp: nerf.training.n_images_for_training); None = all slots
         self._marked_images = None      # the image count the untrained cells were last marked for
         self._measured_acc = torch.zeros(1, dtype=torch.int64, device=dev)  # marched samples since the last adaptation
@@ -220,6 +221,7 @@ class NgpEngine:
         _call("nvo_cast_half", _stream(self.device), self.n_params, _ptr(self.params), _ptr(self.params_half))
         self.params_ema = self.params_ema_half = None  # the average restarts from the new weights
         self.ema_step = 0
+        self.params_version += 1
 
     def inference_params_half(self) -> torch.Tensor:
         """The 16-bit weights inference reads: the moving average once it exists (tcnn: the optimiser's
@@ -235,6 +237,7 @@ class NgpEngine:
     def ema_step(self, value: int) -> None:
         self._ema_step_dev.fill_(int(value))
         self._ema_started = int(value) > 0
+        self.params_version = getattr(self, "params_version", 0) + 1
 
     def _pp(self, name: str, buf: torch.Tensor):
         o, _ = self.segments[name]
@@ -351,6 +354,7 @@ class NgpEngine:
             all_reduce.reduce_max(fresh)
         _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
               cfg.occupancy_threshold, _ptr(self.bitfield), _ptr(self._scratch8))
+        self.params_version += 1  # (the bitfield inference marches through)
 
     @torch.no_grad()
     def mark_untrained_cells(self, intrinsics, c2w, n_images: int, H: int, W: int) -> None:
@@ -626,6 +630,7 @@ class NgpEngine:
         self.opt_step += 1
         self._dev_synced = self.opt_step  # (the host mirror counts attempts; the device follows the applied steps)
         self.step += 1
+        self.params_version += 1
         if self.cfg.adaptive_rays:
             self._adapt_rays(ws, R)
 

@@ -163,6 +163,7 @@ class Testbed:
         self._camera = np.eye(4)[:3][_TO_NGP_ROWS]
         self._generator = torch.Generator(device=self.device)
         self._draw_scale = None
+        self._render_cache = None  # (key, rgba [n,4], z-depth [n]) of the last rendered view
         self._generator.manual_seed(42)
 
     # ---- dataset / network set-up ------------------------------------------------------------------------
@@ -213,6 +214,7 @@ class Testbed:
         if self.nerf.training.depth_loss_type != LossType.L2:
             raise NotImplementedError("only LossType.L2 depth supervision is built (instant_ngp.py:48)")
         self._engine = NgpEngine(self._config(), self.device)
+        self._render_cache = None
         self._resolution = (height, width)
         f32 = dict(dtype=torch.float32, device=self.device)
         n = self._n_images
@@ -315,6 +317,8 @@ class Testbed:
             for name in ("exp_avg", "exp_avg_sq", "pose_exp_avg", "pose_exp_avg_sq"):
                 put(getattr(e, name), snap["optimizer"][name])
         e.step, e.opt_step = int(snap["step"]), int(snap["opt_step"])
+        e.params_version += 1
+        self._render_cache = None
         self.training_step = e.step
         self.nerf.training.n_images_for_training = int(snap["n_images_for_training"])
 
@@ -335,33 +339,43 @@ class Testbed:
             raise RuntimeError("render: no network has been trained or loaded")
         if not linear:
             raise NotImplementedError("render(linear=False): the reference always asks for linear output")
-        focal = 0.5 * (width if self.fov_axis == 0 else height) / math.tan(0.5 * math.radians(self.fov))
-        c2w = torch.tensor(self._camera[_FROM_NGP_ROWS], dtype=torch.float32).unsqueeze(0)
-        cams = Cameras(fx=focal, fy=focal, cx=0.5 * width, cy=0.5 * height, height=height, width=width,
-                       camera_to_worlds=c2w, camera_type=CameraType.PERSPECTIVE).to(self.device)
-        bundle = cams.generate_rays(camera_indices=0, keep_shape=True)
-        o = bundle.origins.reshape(-1, 3)
-        d = bundle.directions.reshape(-1, 3)
-        dn = bundle.metadata["directions_norm"].reshape(-1)
-        chunks = []
-        for lo in range(0, o.shape[0], rays_per_chunk):
-            hi = min(o.shape[0], lo + rays_per_chunk)
-            oo, dd, nn = o[lo:hi], d[lo:hi], dn[lo:hi]
-            if hi - lo < rays_per_chunk:  # one scratch shape: pad the tail chunk
-                pad = rays_per_chunk - (hi - lo)
-                oo = torch.cat([oo, oo[-1:].expand(pad, 3)])
-                dd = torch.cat([dd, dd[-1:].expand(pad, 3)])
-                nn = torch.cat([nn, nn[-1:].expand(pad)])
-            out = self._engine.render_rays(oo.contiguous(), dd.contiguous(), nn.contiguous())
-            if self.render_mode == Depth:
-                z = (out["depth"][: hi - lo, 0] / nn[: hi - lo])[:, None]  # distance along the ray -> z-depth
-                chunks.append(z.expand(-1, 4).clone())
-            elif self.render_mode == Shade:
-                rgb = out["rgb"][: hi - lo] * (2.0 ** self.exposure)
-                chunks.append(torch.cat([rgb, out["accumulation"][: hi - lo]], dim=1))
-            else:
-                raise NotImplementedError(f"render_mode {self.render_mode}: the reference uses Shade and Depth")
-        return torch.cat(chunks).view(height, width, 4).cpu().numpy()
+        if self.render_mode not in (Shade, Depth):
+            raise NotImplementedError(f"render_mode {self.render_mode}: the reference uses Shade and Depth")
+        # The reference renders every frame twice, once per mode (evaluation/nerf_renderer.py:259-300): both modes come
+        # from ONE pass over the rays, kept until the camera, the image size or the weights change.
+        eng = self._engine
+        key = (self._camera.tobytes(), float(self.fov), int(self.fov_axis), int(width), int(height), int(rays_per_chunk),
+               id(eng), eng.params_version)
+        if self._render_cache is None or self._render_cache[0] != key:
+            focal = 0.5 * (width if self.fov_axis == 0 else height) / math.tan(0.5 * math.radians(self.fov))
+            c2w = torch.tensor(self._camera[_FROM_NGP_ROWS], dtype=torch.float32).unsqueeze(0)
+            cams = Cameras(fx=focal, fy=focal, cx=0.5 * width, cy=0.5 * height, height=height, width=width,
+                           camera_to_worlds=c2w, camera_type=CameraType.PERSPECTIVE).to(self.device)
+            bundle = cams.generate_rays(camera_indices=0, keep_shape=True)
+            o = bundle.origins.reshape(-1, 3)
+            d = bundle.directions.reshape(-1, 3)
+            dn = bundle.metadata["directions_norm"].reshape(-1)
+            n = o.shape[0]
+            rgba = torch.empty(n, 4, device=self.device)
+            z = torch.empty(n, device=self.device)
+            for lo in range(0, n, rays_per_chunk):
+                hi = min(n, lo + rays_per_chunk)
+                oo, dd, nn = o[lo:hi], d[lo:hi], dn[lo:hi]
+                if hi - lo < rays_per_chunk:  # one scratch shape: pad the tail chunk
+                    pad = rays_per_chunk - (hi - lo)
+                    oo = torch.cat([oo, oo[-1:].expand(pad, 3)])
+                    dd = torch.cat([dd, dd[-1:].expand(pad, 3)])
+                    nn = torch.cat([nn, nn[-1:].expand(pad)])
+                out = eng.render_rays(oo.contiguous(), dd.contiguous(), nn.contiguous())
+                rgba[lo:hi, :3] = out["rgb"][: hi - lo]
+                rgba[lo:hi, 3:] = out["accumulation"][: hi - lo]
+                z[lo:hi] = out["depth"][: hi - lo, 0] / nn[: hi - lo]  # distance along the ray -> z-depth
+            self._render_cache = (key, rgba, z)
+        _, rgba, z = self._render_cache
+        if self.render_mode == Depth:
+            return z[:, None].expand(-1, 4).reshape(height, width, 4).cpu().numpy()
+        shade = torch.cat([rgba[:, :3] * (2.0 ** self.exposure), rgba[:, 3:]], dim=1)
+        return shade.view(height, width, 4).cpu().numpy()
 
     def compute_and_save_marching_cubes_mesh(self, filename: str, resolution=(256, 256, 256), aabb: BoundingBox | None = None,
                                              thresh: float = 2.5, generate_uvs_for_obj_file: bool = False) -> None:

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--keyframes", type=int, default=48)
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--render-frames", type=int, default=0, help="1200x680 views rendered through Testbed.render after training")
     a = ap.parse_args()
     run(a)
 
@@ -93,6 +94,31 @@ def run(a, quiet: bool = False):
         say(f"kernel time {tot / 32:.3f} ms/step over 32 steps")
         for name, cnt, total in rows[:24]:
             say(f"  {name:30s} launches {cnt:4d} avg {total / cnt * 1e3:9.1f} us  {100 * total / tot:5.1f} %")
+    # inference through the facade, as evaluation/nerf_renderer.py drives it (colour + depth of one 1200x680 view)
+    render = None
+    if getattr(a, "render_frames", 0) > 0:
+        import math
+
+        fx = float(seq["camera_intrinsics"][0, 0]) * 1200.0 / W
+        tb.fov_axis, tb.fov, tb.exposure = 0, 2.0 * math.degrees(math.atan(0.5 * 1200.0 / fx)), 0.0
+        times = []
+        for f in range(a.render_frames + 1):
+            m = poses[f % a.keyframes].detach().cpu().numpy().astype(np.float64).copy()
+            m[0:3, 1:3] *= -1
+            tb.set_nerf_camera_matrix(m[[2, 0, 1]])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tb.render_mode = pyngp.Shade
+            shade = tb.render(width=1200, height=680, spp=1, linear=True)
+            tb.render_mode = pyngp.Depth
+            depth = tb.render(width=1200, height=680, spp=1, linear=True)
+            times.append(time.perf_counter() - t1)
+        ms = 1e3 * float(np.mean(times[1:]))
+        render = {"resolution": [1200, 680], "frames": a.render_frames, "ms_per_frame_colour_and_depth": round(ms, 2),
+                  "rays_per_sec": round(1200 * 680 / (ms * 1e-3)), "coverage": round(float((shade[..., 3] > 0.5).mean()), 4),
+                  "launch": "eager, 2048 rays per bundle, both modes from one pass (host copies of both images included)"}
+        say(f"render 1200x680 (colour + depth): {ms:.1f} ms per frame, {render['rays_per_sec'] / 1e6:.1f} M rays/s, "
+            f"coverage {render['coverage']}, depth median {float(np.median(depth[..., 0])):.3f}")
     n = eng.samples_last_step()
     say(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
         f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
@@ -146,13 +172,13 @@ def run(a, quiet: bool = False):
                                                  f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch",
                                      "launch": "hipGraph replay: ONE graph per step (per ray count), density-grid refresh "
                                                "eager every 16th step" if eng.cfg.graph_step else "eager"},
-                          "window": window, "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof,
+                          "window": window, "render": render, "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof,
                           "kernel_ms_per_step": round(tot / 32, 4),
                           "kernel_table": [{"kernel": nm, "launches_per_step": round(c / 32, 2), "avg_launch_us": round(t / c * 1e3, 1)}
                                            for nm, c, t in rows[:12]]}
         say(json.dumps(out))
         return out
-    return {"ms_per_step": dt * 1e3, "value": n / dt}
+    return {"ms_per_step": dt * 1e3, "value": n / dt, "render": render}
 
 
 if __name__ == "__main__":
