@@ -37,6 +37,9 @@ class NgpConfig:
     num_images: int = 192
     num_rays: int = 4096
     capacity: int = 1 << 18               # packed sample slots per step (instant-ngp's target batch)
+    # packed sample slots of an INFERENCE launch (its own workspace): every sample the march finds is shaded, ~110 per ray
+    # in a trained room, so 2^21 slots take ~16 K rays per launch instead of 2 K (0 = the training capacity)
+    render_capacity: int = 1 << 21
     aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
     cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
     near_distance: float = 0.1
@@ -253,11 +256,12 @@ class NgpEngine:
             return self._ray_views(ws, R)
         R_req, R = R, max(4096, 1 << max(0, (R - 1).bit_length()))
         key = (R, training)
-        dev, cap = self.device, self.cfg.capacity
+        dev = self.device
+        cap = int(self.cfg.capacity if (training or not self.cfg.render_capacity) else self.cfg.render_capacity)
         f32 = dict(dtype=torch.float32, device=dev)
         f16 = dict(dtype=torch.float16, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        ws = {"key": key, "R": R_req, "R_cap": R, "training": training}
+        ws = {"key": key, "R": R_req, "R_cap": R, "training": training, "cap": cap}
         for name, shape in (("origins", (R, 3)), ("directions", (R, 3)), ("directions_norm", (R,)), ("pixel_area", (R,)),
                             ("gt_rgb", (R, 3)), ("gt_depth", (R,)), ("dirs01", (R, 3)), ("out_rgb", (R, 3)),
                             ("out_depth", (R,)), ("out_accumulation", (R,)), ("t", (cap,)), ("dt", (cap,)),
@@ -392,7 +396,7 @@ class NgpEngine:
         """Packed samples of the workspace's rays: counts / offsets (offsets[R] = samples found, before rays were dropped
         at the capacity), ray_idx / t / dt."""
         cfg = self.cfg
-        R, cap = ws["R"], cfg.capacity
+        R, cap = ws["R"], ws["cap"]
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
@@ -401,14 +405,22 @@ class NgpEngine:
 
     def _shade(self, ws, training: bool, stream) -> None:
         cfg = self.cfg
-        R, cap = ws["R"], cfg.capacity
+        R, cap = ws["R"], ws["cap"]
         lo, hi = cfg.aabb
         # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
         self._fwd_half = self.params_half if training else self.inference_params_half()
         _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
               _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
-        _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),
-              _ptr(ws["density_out"]), _ptr(ws["ctx"]))
+        # (inference needs no d(encoded)/d(position) from the forward; the option is read at launch time)
+        no_dydx = (not training) and bool(cfg.optimize_extrinsics)
+        if no_dydx:
+            self.density_net.set_option("prepare_input_gradients", 0)
+        try:
+            _call("nvo_fwd", self.density_net.handle, stream, cap, _ptr(ws["x01"]), self._pp("density", self._fwd_half),
+                  _ptr(ws["density_out"]), _ptr(ws["ctx"]))
+        finally:
+            if no_dydx:
+                self.density_net.set_option("prepare_input_gradients", 1)
         if not ws.pop("sh_ready", False):  # (rays that did not come through load_rays: inference bundles)
             _call("nvo_dirs01", stream, 3 * R, _ptr(ws["directions"]), _ptr(ws["dirs01"]))
             _call("nvo_sh_encode", stream, R, 4, _ptr(ws["dirs01"]), _ptr(ws["sh"]))
@@ -417,7 +429,7 @@ class NgpEngine:
 
     def _rgb_args(self, ws, training: bool):
         return _lib.NgpRgbArgs(
-            capacity=self.cfg.capacity, sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
+            capacity=ws["cap"], sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(),
             weights=self._pp("rgb", self.params_half if training else self.inference_params_half()).value,
             rgb_out=ws["rgb_out"].data_ptr(), hidden=None,
@@ -433,7 +445,7 @@ class NgpEngine:
         cfg = self.cfg
         R = ws["R"]
         return _lib.NgpLossArgs(
-            R=R, capacity=cfg.capacity, counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
+            R=R, capacity=ws["cap"], counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(), t=ws["t"].data_ptr(), dt=ws["dt"].data_ptr(),
             density_out=ws["density_out"].data_ptr(), density_stride=16, rgb_out=ws["rgb_out"].data_ptr(), rgb_stride=16,
             background=None if background is None else background.data_ptr(),
@@ -755,8 +767,8 @@ class NgpEngine:
         return d
 
     def samples_last_step(self) -> int:
-        ws = self._ws
-        return int(min(int(ws["offsets"][-1].item()), self.cfg.capacity)) if ws is not None else 0
+        ws = self._wss[True]  # (the training workspace: an inference call in between has its own)
+        return int(min(int(ws["offsets"][-1].item()), ws["cap"])) if ws is not None else 0
 
     @torch.no_grad()
     def render_rays(self, origins, directions, directions_norm):
@@ -770,7 +782,7 @@ class NgpEngine:
         ws["directions_norm"].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
         self._march(ws, None, stream)
-        if R > 1 and int(ws["offsets"][-1].item()) > self.cfg.capacity:
+        if R > 1 and int(ws["offsets"][-1].item()) > ws["cap"]:
             h = R // 2
             dn = directions_norm.reshape(-1)
             a = self.render_rays(origins[:h].contiguous(), directions[:h].contiguous(), dn[:h].contiguous())

@@ -329,12 +329,13 @@ class Testbed:
             raise RuntimeError(f"set_nerf_camera_matrix expects a 3x4 matrix, got {m.shape}")
         self._camera = m.copy()
 
-    def render(self, width: int, height: int, spp: int = 1, linear: bool = True, rays_per_chunk: int = 2048) -> np.ndarray:
+    def render(self, width: int, height: int, spp: int = 1, linear: bool = True, rays_per_chunk: int = 0) -> np.ndarray:
         """float32 [height, width, 4].  Shade: alpha-premultiplied linear RGB + alpha (the reference divides by
         alpha, nerf_renderer.py:274-277); Depth: z-depth in every channel (it reads channel 0, :296).  Pinhole with
         the focal length of ``fov`` along ``fov_axis``, square pixels and a centred principal point, like the
-        testbed's free camera.  (2048 rays per launch: 128 marched samples per ray fill the engine's packed-sample capacity of
-        2^18; a bundle that finds more is rendered in halves by NgpEngine.render_rays, no ray is dropped.)"""
+        testbed's free camera.  (rays_per_chunk = 0: the inference capacity / 128 -- 16 K rays per launch at 2^21 packed
+        samples; a bundle that finds more samples than fit is rendered in halves by NgpEngine.render_rays, no ray is
+        dropped.)"""
         if self._engine is None:
             raise RuntimeError("render: no network has been trained or loaded")
         if not linear:
@@ -344,6 +345,8 @@ class Testbed:
         # The reference renders every frame twice, once per mode (evaluation/nerf_renderer.py:259-300): both modes come
         # from ONE pass over the rays, kept until the camera, the image size or the weights change.
         eng = self._engine
+        if rays_per_chunk <= 0:
+            rays_per_chunk = max(256, int(eng.cfg.render_capacity or eng.cfg.capacity) // 128)
         key = (self._camera.tobytes(), float(self.fov), int(self.fov_axis), int(width), int(height), int(rays_per_chunk),
                id(eng), eng.params_version)
         if self._render_cache is None or self._render_cache[0] != key:

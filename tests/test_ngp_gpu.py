@@ -499,8 +499,8 @@ def test_render_splits_bundles_that_overflow_the_capacity(device):
     rays used to come back black), and switching between training and rendering keeps both workspaces."""
     from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
 
-    small = _engine(device)                                   # capacity 2^15
-    big = NgpEngine(NgpConfig(num_images=4, capacity=1 << 18), device)
+    small = _engine(device, render_capacity=1 << 15)         # inference capacity 2^15
+    big = NgpEngine(NgpConfig(num_images=4, capacity=1 << 15, render_capacity=1 << 18), device)
     big.set_params(small.params.cpu())
     for e in (small, big):
         e.bitfield.fill_(255)                                 # every cell occupied: hundreds of samples per ray
@@ -513,7 +513,7 @@ def test_render_splits_bundles_that_overflow_the_capacity(device):
     a = small.render_rays(origins, directions, dnorm)
     b = big.render_rays(origins, directions, dnorm)
     total = int(big._ws["offsets"][-1].item())
-    assert small.cfg.capacity * 4 < total <= big.cfg.capacity
+    assert small.cfg.render_capacity * 4 < total <= big.cfg.render_capacity
     for k in ("rgb", "depth", "accumulation"):
         assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
     assert float(b["accumulation"].min()) > 0.0
