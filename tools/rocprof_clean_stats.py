@@ -7,7 +7,7 @@ kernel-trace CSV instead, keeps the dispatches of THIS library's kernels (k_*) t
 (= after the last graph capture warm-up: the first k_ray_head whose successor k_ray_head is < 5 ms away marks steady
 state) and prints name, calls, total / average / min / max duration and share.
 
-Usage: python tools/rocprof_clean_stats.py <rocprof-output-dir> [--skip-first N] > stats.csv"""
+Usage: python tools/rocprof_clean_stats.py <rocprof-output-dir> [--skip-first N] [--head k_rays_given] > stats.csv"""
 import csv
 import glob
 import os
@@ -28,7 +28,8 @@ def main():
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    heads = [t0 for t0, _, n in rows if "k_ray_head" in n]
+    head = sys.argv[sys.argv.index("--head") + 1] if "--head" in sys.argv else "k_ray_head"  # (first kernel of a step)
+    heads = [t0 for t0, _, n in rows if head in n]
     # steady state: the first step start followed by >= 20 further starts all < 5 ms apart
     start = heads[0] if heads else rows[0][0]
     for i in range(len(heads) - 20):
