@@ -329,13 +329,17 @@ k_occ_ema(uint64_t n, float* __restrict__ grid, const float* __restrict__ fresh,
 // sum of max(v, 0) over cascade 0 (fixed-point so the mean is order independent / reproducible)
 __global__ void __launch_bounds__(256)
 k_occ_sum(const float* __restrict__ grid, unsigned long long* __restrict__ acc) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float v = i < kCells ? fmaxf(grid[i], 0.f) : 0.f;
-    // 2^-20 resolution fixed point, block-reduced in LDS integer atomics (fast on gfx950)
+    // 2^-20 resolution fixed point: per-thread partial over a grid-stride range, wave reduction, one LDS add per wave and
+    // ONE global add per workgroup (512 workgroups; it was one same-address atomic from each of 8192: 103 us)
+    unsigned long long part = 0ull;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kCells; i += gridDim.x * blockDim.x)
+        part += (unsigned long long)(long long)llrintf(fmaxf(grid[i], 0.f) * 1048576.0f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     __shared__ unsigned long long s;
     if (threadIdx.x == 0) s = 0ull;
     __syncthreads();
-    atomicAdd(&s, (unsigned long long)(long long)llrintf(v * 1048576.0f));
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&s, part);
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, s);
 }
@@ -559,7 +563,7 @@ int nvo_occ_update(nvo_stream_t stream, int n_levels, float* grid, const float* 
         NVO_CHECK_LAUNCH();
     }
     if (int rc = nvo_zero_async(scratch8, 8, s)) return rc;
-    NVO_LAUNCH(k_occ_sum, dim3(kCells / 256), dim3(256), 0, s, grid, (unsigned long long*)scratch8);
+    NVO_LAUNCH(k_occ_sum, dim3(512), dim3(256), 0, s, grid, (unsigned long long*)scratch8);
     NVO_CHECK_LAUNCH();
     NVO_LAUNCH(k_occ_bitfield, dim3(nvo_div_up(n / 8, 256)), dim3(256), 0, s, grid, n_levels, threshold,
                (const unsigned long long*)scratch8, bitfield);
