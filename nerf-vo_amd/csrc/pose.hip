@@ -374,8 +374,12 @@ int nvo_pose_bwd_cams(nvo_stream_t stream, uint32_t R, const int64_t* ray_indice
     if (R == 0) return NVO_OK;
     // The table pays when many rays meet on a camera (measured: 7552 rays / 48 cameras 60 -> 10 us; 4096 rays / 192
     // cameras 14.8 -> 22.4 us with 1024-ray workgroups, the zeroing and the flush of 2304 words per workgroup cost more than 21 adds per word
-    // did): below 64 rays per camera, beyond 1024 cameras (48 KiB) or without a camera count: plain atomics.
-    if (n_cameras == 0 || n_cameras > 1024 || R < 64u * n_cameras)
+    // did): below 32 rays per camera, beyond 1024 cameras (48 KiB) or without a camera count: plain atomics.
+    static const uint32_t min_per_cam = [] {
+        const char* e = getenv("NVO_POSE_LDS_MIN_RAYS_PER_CAM");
+        return e ? (uint32_t)atoi(e) : 32u;  // (2432 rays / 48 cameras = 50 per camera: 24.8 us plain, 9.5 us through the table)
+    }();
+    if (n_cameras == 0 || n_cameras > 1024 || R < min_per_cam * n_cameras)
         return pose_bwd_plain(stream, R, ray_indices, intrinsics, c2w, d_origin, d_dir, d_dir01, d_corrections, n_cameras);
     NVO_PROF(stream, "pose_bwd");
     static const uint32_t block = [] {
