@@ -393,7 +393,9 @@ def test_graphed_step_matches_eager_step(device):
         assert torch.equal(ge._opt_dev, ee._opt_dev) and torch.equal(ge.density_grid, ee.density_grid)
         d = (ge.params[:lo] - ee.params[:lo]).abs()  # (MLP weights: float-atomic dW totals, see the test above)
         assert float((d > 1e-5 + 1e-3 * ee.params[:lo].abs()).float().mean()) < 0.02
-        assert torch.allclose(ge.pose_adjustment, ee.pose_adjustment, rtol=1e-3, atol=1e-6)
+        # (camera offsets: float-atomic gradient totals; a near-zero total of either sign moves an entry by +- lr)
+        dp = (ge.pose_adjustment - ee.pose_adjustment).abs()
+        assert int((dp > 1e-6 + 1e-3 * ee.pose_adjustment.abs()).sum()) <= 2
         assert torch.allclose(ge.losses.sum(0), ee.losses.sum(0), rtol=1e-4, atol=1e-7)
         if overflow:
             assert torch.equal(ge.params, before) and torch.equal(ee.params, before)
