@@ -150,3 +150,84 @@ def test_instant_ngp_mapper_end_to_end(device, tmp_path):
             frame_ids=[n], poses=opencv_to_opengl(poses)[:1, :3], images=torch.zeros(1, H, W, 4), depths=torch.zeros(1, H, W, 1),
             depths_cov=torch.ones(1, H, W, 1), resolution=np.array([W, H]), principal_point=np.array([cx, cy]),
             focal_length=np.array([fx, fy]))
+
+
+def test_pyngp_incremental_keyframes_snapshot_and_render(device, tmp_path):
+    """The facade the way a SLAM run drives it: keyframes arrive in batches between training iterations (the image count
+    the rays are drawn from grows, untrained cells are re-marked, the captured steps keep addressing the same buffers), a
+    view is rendered between two training steps (its own workspace: the captured steps survive), a snapshot is written,
+    read back by a fresh testbed and trained on."""
+    import torch
+
+    from nerf_vo_amd import pyngp
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W = 12, 68, 120
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    poses = seq["camera_extrinsics"].clone()
+    poses[:, :3, 3] += 0.5
+    gl = opencv_to_opengl(poses)[:, :3]
+    color = seq["frames_color"].permute(0, 2, 3, 1)
+    color = torch.cat([color, torch.ones_like(color[..., :1])], dim=3).contiguous()
+    depth = seq["frames_depth"].permute(0, 2, 3, 1).contiguous()
+
+    def make():
+        tb = pyngp.Testbed(pyngp.TestbedMode.Nerf, 0)
+        tb.create_empty_nerf_dataset(n_images=n, nerf_scale=1.0, nerf_offset=np.zeros(3), aabb_scale=4)
+        tb.reload_network_from_file("")
+        tb.shall_train = True
+        tb.nerf.training.optimize_extrinsics = True
+        return tb
+
+    def add(tb, ids):
+        tb.nerf.training.update_training_images(
+            frame_ids=ids, poses=gl[ids], images=color[ids], depths=depth[ids], depths_cov=torch.ones_like(depth[ids]),
+            resolution=np.array([W, H]), principal_point=seq["camera_intrinsics"][0, 2:].cpu().numpy(),
+            focal_length=seq["camera_intrinsics"][0, :2].cpu().numpy())
+
+    tb = make()
+    unseen, losses = [], []
+    for batch in ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]):
+        add(tb, batch)
+        for _ in range(48):
+            tb.frame()
+        eng = tb._engine
+        assert eng._marked_images == batch[-1] + 1 == tb.nerf.training.n_images_for_training
+        unseen.append(float((eng.density_grid < 0).float().mean()))
+        losses.append(eng.loss_dict()["rgb_loss"])
+    assert unseen[0] > unseen[1] > unseen[2] > 0.0, unseen     # every batch of cameras adds views
+    assert all(np.isfinite(losses)) and eng.graph_captures >= 1 and int(eng.skip_flag.item()) == 0
+    captures = eng.graph_captures
+    graphs = dict(eng._graphs)
+    m = poses[5].cpu().numpy().astype(np.float64).copy()
+    m[0:3, 1:3] *= -1
+    tb.set_nerf_camera_matrix(m[[2, 0, 1]])
+    tb.fov_axis, tb.fov = 0, 2.0 * np.degrees(np.arctan(0.5 * W / float(seq["camera_intrinsics"][0, 0])))
+    tb.render_mode = pyngp.Shade
+    shade = tb.render(width=W, height=H, spp=1, linear=True)
+    tb.render_mode = pyngp.Depth
+    z = tb.render(width=W, height=H, spp=1, linear=True)
+    assert shade.shape == (H, W, 4) and np.isfinite(shade).all() and (shade[..., 3] > 0.5).mean() > 0.9
+    assert np.abs(z[..., 0] - seq["frames_depth"][5, 0].cpu().numpy()).mean() < 0.2
+    assert all(eng._graphs.get(k) is v for k, v in graphs.items())  # the render left the captured steps alone
+    last_batch = eng._wss[True]["R"]  # (a new capture is due only if the adaptive batch has just moved)
+    tb.frame()
+    assert eng.graph_captures == captures + (0 if eng._wss[True]["R"] == last_batch else 1)
+    path = str(tmp_path / "snap.msgpack")
+    tb.save_snapshot(path, include_optimizer_state=True)
+    tb2 = make()
+    tb2.load_snapshot(path)
+    assert tb2.training_step == tb.training_step and tb2.nerf.training.n_images_for_training == n
+    tb2._images.copy_(tb._images)  # (snapshots hold the model, not the training images: as upstream)
+    tb2._depths.copy_(tb._depths)
+    tb2.render_mode = pyngp.Shade
+    tb2.set_nerf_camera_matrix(m[[2, 0, 1]])
+    tb2.fov_axis, tb2.fov = tb.fov_axis, tb.fov
+    tb.render_mode = pyngp.Shade
+    np.testing.assert_array_equal(tb2.render(width=W, height=H, spp=1, linear=True),
+                                  tb.render(width=W, height=H, spp=1, linear=True))
+    for _ in range(20):
+        tb2.frame()
+    assert np.isfinite(tb2._engine.loss_dict()["rgb_loss"]) and int(tb2._engine.skip_flag.item()) == 0
+    assert tb2._engine.applied_steps == tb2._engine.opt_step == tb.training_step + 20
