@@ -676,6 +676,9 @@ class NgpEngine:
         ws["jitter"].uniform_()
         bg = None
         if cfg.random_background:
+            if "background" not in ws:  # (switched on after the workspace was made)
+                ws["_per_ray"]["background"] = torch.zeros(ws["R_cap"], 3, dtype=torch.float32, device=self.device)
+                self._ray_views(ws, R)
             bg = ws["background"]
             bg.uniform_()
         if not self._kernels_loaded:

@@ -99,6 +99,11 @@ class _Training:
         self._tb = testbed
         self.n_images_for_training = 0
         self.optimize_extrinsics = False  # instant-ngp's default; the reference switches it on
+        # instant-ngp's default [UPSTREAM testbed.h Nerf::Training::random_bg_color = true; scripts/run.py switches it off
+        # only for --nerf_compatibility]; the reference leaves it alone (nerf_vo/mapping/instant_ngp.py:33-50): every
+        # training ray is composited over a random colour, and so is its target (alpha 1 everywhere: unchanged), which
+        # pushes the transmittance left at the end of a ray to zero
+        self.random_bg_color = True
         self.depth_loss_type = LossType.L2
         self.depth_supervision_lambda = 1.0
 
@@ -193,7 +198,8 @@ class Testbed:
     def _config(self) -> NgpConfig:
         cfg = NgpConfig(num_images=self._n_images, aabb_scale=self._aabb_scale,
                         depth_loss_mult=self.nerf.training.depth_supervision_lambda,
-                        optimize_extrinsics=bool(self.nerf.training.optimize_extrinsics))
+                        optimize_extrinsics=bool(self.nerf.training.optimize_extrinsics),
+                        random_background=bool(self.nerf.training.random_bg_color))
         opt = self._network_config.get("optimizer", {})
         while "nested" in opt:  # base.json wraps Adam in ExponentialDecay / Ema
             opt = opt["nested"]
@@ -233,6 +239,7 @@ class Testbed:
             return True
         eng = self._engine
         eng.cfg.optimize_extrinsics = bool(self.nerf.training.optimize_extrinsics)
+        eng.cfg.random_background = bool(self.nerf.training.random_bg_color)
         eng.n_training_images = n
         h, w = self._resolution
         if self._draw_scale is None or self._draw_scale[0] != (n, h, w):  # (one upload per change, not per frame)

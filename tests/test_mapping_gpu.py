@@ -121,9 +121,10 @@ def test_instant_ngp_mapper_end_to_end(device, tmp_path):
     color, depth = renderer.render_frame(intr, pose3)
     gt = (seq["frames_color"][3].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
     assert color.shape == (H, W, 3) and color.dtype == np.uint8
-    # (24-26 dB over a dozen runs; it was 15-18 while pyngp.render dropped the rays of a chunk whose samples overflowed
-    # the packed capacity -- they came back black)
-    assert calculate_psnr_float(color, gt) > 20.0
+    # (21-27 dB over two dozen runs of this 400-step training -- float atomics make it non-deterministic; 14-18 dB while
+    # pyngp.render dropped the rays of a chunk whose samples overflowed the packed capacity: they came back black --
+    # tests/test_ngp_gpu.py::test_render_splits_bundles_that_overflow_the_capacity is the guard for that)
+    assert calculate_psnr_float(color, gt) > 18.5
     gt_depth = seq["frames_depth"][3, 0].cpu().numpy()
     assert np.abs(depth - gt_depth).mean() < 0.15
     # offline: a fresh testbed restored from the snapshot renders the same frame bit for bit

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry  # noqa: E402
 
 entry.build()
-from nerf_vo_amd import ngp_engine  # noqa: E402
+from nerf_vo_amd import ngp_engine, pyngp  # noqa: E402
 from nerf_vo_amd.mapping.dataset import opencv_to_opengl  # noqa: E402
 from nerf_vo_amd.mapping.instant_ngp_mapper import InstantNGP, InstantNGPRenderer  # noqa: E402
 from nerf_vo_amd.mapping.renderer import calculate_psnr_float  # noqa: E402
@@ -24,12 +24,12 @@ n, H, W, iters = 12, 68, 120, 400
 seq = make_sequence(n, H, W, device=dev, scene_scale=0.2)
 poses = seq["camera_extrinsics"].clone()
 poses[:, :3, 3] += 0.5
-_init = ngp_engine.NgpEngine.__init__
-for mark, margin, warm in ((False, 0.0, 256), (True, 1.0, 256), (True, 4.0, 256)):
-    def patched(self, config, device, world_size=1, _m=mark, _g=margin, _w=warm):
-        config.mark_untrained, config.mark_untrained_margin, config.density_warmup_steps = _m, _g, _w
-        _init(self, config, device, world_size)
-    ngp_engine.NgpEngine.__init__ = patched
+_tinit = pyngp._Training.__init__
+for mark, margin, warm, rbg in ((True, 1.0, 256, False), (True, 1.0, 256, True)):
+    def tpatched(self, testbed, _r=rbg):
+        _tinit(self, testbed)
+        self.random_bg_color = _r
+    pyngp._Training.__init__ = tpatched
     res = []
     for run in range(3):
         with tempfile.TemporaryDirectory() as tmp:
@@ -58,4 +58,4 @@ for mark, margin, warm in ((False, 0.0, 256), (True, 1.0, 256), (True, 4.0, 256)
                         [round(float((g3[l] < 0).float().mean()), 3) for l in range(3)],
                         [round(float(b3[l].float().mean()), 4) for l in range(3)],
                         round(float(g3[0].clamp_min(0).mean()), 5), eng.loss_dict()))
-    print(f"mark_untrained={mark} margin={margin} density_warmup_steps={warm}: (psnr frame 3, mean of 4 frames, rays/batch, unseen share per cascade, occupied share per cascade, mean of cascade 0, losses) {res}", flush=True)
+    print(f"mark_untrained={mark} margin={margin} density_warmup_steps={warm} random_bg={rbg}: (psnr frame 3, mean of 4 frames, rays/batch, unseen share per cascade, occupied share per cascade, mean of cascade 0, losses) {res}", flush=True)
