@@ -145,6 +145,7 @@ class NgpEngine:
         # neither network stores its hidden activations: the backward recomputes them (bit-identical; less traffic both
         # ways, and the recomputing backward is the one that runs in chain / dW roles)
         self.density_net.set_option("recompute_hidden", 1)
+        self._bwd_zero_plan = None
         self._leaf_flags = False  # set in forward_backward: the grid backward raises skip_flag itself (single GPU)
         self.n_rgb = 64 * 32 + 64 * 64 + 16 * 64
         self.n_density_mlp = 64 * 32 + 16 * 64
@@ -483,6 +484,7 @@ class NgpEngine:
         if self.cfg.optimize_extrinsics and self._pose_inputs is not None and "dx01" in ws:
             spans += [(self.d_corrections.data_ptr(), 4 * self.d_corrections.numel()),
                       (self.pose_grads.data_ptr(), 4 * self.pose_grads.numel())]
+        spans += self._bwd_zero_spans()
         spans = [sp for sp in spans if sp[1] > 0]
         _call("nvo_zero_ranges", stream, len(spans), (C.c_void_p * len(spans))(*[a for a, _ in spans]),
               (C.c_uint64 * len(spans))(*[b for _, b in spans]))
@@ -505,6 +507,21 @@ class NgpEngine:
             _call("nvo_fold_replicas", stream, 2, self._dw_rep["reps"], self._dw_rep["n_rep"], self._dw_rep["n"], self._dw_rep["dst"])
         if pose:
             self._pose_backward(ws, stream)
+
+    def _bwd_zero_spans(self):
+        """What the density network's nvo_bwd clears before it accumulates (MLP weight gradient, atomically flushed grid
+        ranges, scale scratch), handed to the step's single zero launch (module option external_zero: two launches less
+        per step).  From here on every nvo_bwd of that network must come through forward_backward."""
+        if self._bwd_zero_plan is None:
+            cap = 16
+            ptrs = (C.c_void_p * cap)()
+            sizes = (C.c_uint64 * cap)()
+            n = _lib.lib().nvo_bwd_zero_ranges(self.density_net.handle, self._pp("density", self.grads), ptrs, sizes, cap)
+            if n < 0:
+                raise RuntimeError(f"nvo_bwd_zero_ranges: {_lib.lib().nvo_last_error().decode()}")
+            self.density_net.set_option("external_zero", 1)
+            self._bwd_zero_plan = [(int(ptrs[i]), int(sizes[i])) for i in range(n)]
+        return list(self._bwd_zero_plan)
 
     def _pose_backward(self, ws, stream) -> None:
         """Position gradients of the packed samples -> per-ray dL/do, dL/dd -> per-camera correction gradient ->
