@@ -192,6 +192,7 @@ class NgpEngine:
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
         self._kernels_loaded = False
         self.graph_captures, self.graph_capture_seconds = 0, 0.0  # (diagnostics: tools/ngp_bench.py)
+        self.last_render_samples = 0    # samples the march found for the last render_rays bundle
         self.params_version = 0         # bumped whenever the weights inference reads may have changed (render caches)
         self.n_training_images = None   # images in use (pyngp: nerf.training.n_images_for_training); None = all slots
         self._marked_images = None      # the image count the untrained cells were last marked for
@@ -802,11 +803,14 @@ class NgpEngine:
         ws["directions_norm"].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
         self._march(ws, None, stream)
-        if R > 1 and int(ws["offsets"][-1].item()) > ws["cap"]:
+        found = int(ws["offsets"][-1].item())
+        self.last_render_samples = found  # (callers size their next bundle from it: pyngp.Testbed.render)
+        if R > 1 and found > ws["cap"]:
             h = R // 2
             dn = directions_norm.reshape(-1)
             a = self.render_rays(origins[:h].contiguous(), directions[:h].contiguous(), dn[:h].contiguous())
             b = self.render_rays(origins[h:].contiguous(), directions[h:].contiguous(), dn[h:].contiguous())
+            self.last_render_samples = found
             return {k: torch.cat([a[k], b[k]]) for k in a}
         self._shade(ws, False, stream)
         la = self._loss_args(ws, False, False, None)

@@ -340,9 +340,9 @@ class Testbed:
         """float32 [height, width, 4].  Shade: alpha-premultiplied linear RGB + alpha (the reference divides by
         alpha, nerf_renderer.py:274-277); Depth: z-depth in every channel (it reads channel 0, :296).  Pinhole with
         the focal length of ``fov`` along ``fov_axis``, square pixels and a centred principal point, like the
-        testbed's free camera.  (rays_per_chunk = 0: the inference capacity / 128 -- 16 K rays per launch at 2^21 packed
-        samples; a bundle that finds more samples than fit is rendered in halves by NgpEngine.render_rays, no ray is
-        dropped.)"""
+        testbed's free camera.  (rays_per_chunk = 0: bundles sized so that the samples their rays find fill ~85 % of the
+        inference capacity -- from the training batches' samples per ray at first, from the previous bundle's afterwards; a
+        bundle that still finds more than fit is rendered in halves by NgpEngine.render_rays, no ray is dropped.)"""
         if self._engine is None:
             raise RuntimeError("render: no network has been trained or loaded")
         if not linear:
@@ -352,8 +352,11 @@ class Testbed:
         # The reference renders every frame twice, once per mode (evaluation/nerf_renderer.py:259-300): both modes come
         # from ONE pass over the rays, kept until the camera, the image size or the weights change.
         eng = self._engine
-        if rays_per_chunk <= 0:
-            rays_per_chunk = max(256, int(eng.cfg.render_capacity or eng.cfg.capacity) // 128)
+        cap = int(eng.cfg.render_capacity or eng.cfg.capacity)
+        adaptive = rays_per_chunk <= 0
+        if adaptive:  # first bundle: sized from the samples per ray the training batches find
+            per_ray = max(16.0, eng.cfg.capacity / max(1, eng.rays_per_batch))
+            rays_per_chunk = max(256, min(1 << 15, int(0.8 * cap / per_ray) // 256 * 256))
         key = (self._camera.tobytes(), float(self.fov), int(self.fov_axis), int(width), int(height), int(rays_per_chunk),
                id(eng), eng.params_version)
         if self._render_cache is None or self._render_cache[0] != key:
@@ -368,18 +371,18 @@ class Testbed:
             n = o.shape[0]
             rgba = torch.empty(n, 4, device=self.device)
             z = torch.empty(n, device=self.device)
-            for lo in range(0, n, rays_per_chunk):
+            lo = 0
+            while lo < n:
                 hi = min(n, lo + rays_per_chunk)
-                oo, dd, nn = o[lo:hi], d[lo:hi], dn[lo:hi]
-                if hi - lo < rays_per_chunk:  # one scratch shape: pad the tail chunk
-                    pad = rays_per_chunk - (hi - lo)
-                    oo = torch.cat([oo, oo[-1:].expand(pad, 3)])
-                    dd = torch.cat([dd, dd[-1:].expand(pad, 3)])
-                    nn = torch.cat([nn, nn[-1:].expand(pad)])
-                out = eng.render_rays(oo.contiguous(), dd.contiguous(), nn.contiguous())
-                rgba[lo:hi, :3] = out["rgb"][: hi - lo]
-                rgba[lo:hi, 3:] = out["accumulation"][: hi - lo]
-                z[lo:hi] = out["depth"][: hi - lo, 0] / nn[: hi - lo]  # distance along the ray -> z-depth
+                nn = dn[lo:hi]
+                out = eng.render_rays(o[lo:hi].contiguous(), d[lo:hi].contiguous(), nn.contiguous())
+                rgba[lo:hi, :3] = out["rgb"]
+                rgba[lo:hi, 3:] = out["accumulation"]
+                z[lo:hi] = out["depth"][:, 0] / nn  # distance along the ray -> z-depth
+                if adaptive:  # the next bundle aims at 85 % of the capacity with this bundle's samples per ray
+                    per_ray = max(16.0, eng.last_render_samples / (hi - lo))
+                    rays_per_chunk = max(256, min(1 << 15, int(0.85 * cap / per_ray) // 256 * 256))
+                lo = hi
             self._render_cache = (key, rgba, z)
         _, rgba, z = self._render_cache
         if self.render_mode == Depth:

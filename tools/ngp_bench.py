@@ -116,7 +116,7 @@ def run(a, quiet: bool = False):
         ms = 1e3 * float(np.mean(times[1:]))
         render = {"resolution": [1200, 680], "frames": a.render_frames, "ms_per_frame_colour_and_depth": round(ms, 2),
                   "rays_per_sec": round(1200 * 680 / (ms * 1e-3)), "coverage": round(float((shade[..., 3] > 0.5).mean()), 4),
-                  "launch": f"eager, {max(256, int(eng.cfg.render_capacity or eng.cfg.capacity) // 128)} rays per bundle, both modes from one pass (host copies of both images included)"}
+                  "launch": f"eager, bundles sized to ~85 % of {int(eng.cfg.render_capacity or eng.cfg.capacity)} packed samples, both modes from one pass (host copies of both images included)"}
         say(f"render 1200x680 (colour + depth): {ms:.1f} ms per frame, {render['rays_per_sec'] / 1e6:.1f} M rays/s, "
             f"coverage {render['coverage']}, depth median {float(np.median(depth[..., 0])):.3f}")
     n = eng.samples_last_step()
