@@ -407,7 +407,7 @@ class NgpEngine:
 
     def _shade(self, ws, training: bool, stream) -> None:
         cfg = self.cfg
-        R, cap = ws["R"], ws["cap"]
+        R, cap = ws["R"], ws.get("n_launch", ws["cap"])
         lo, hi = cfg.aabb
         # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
         self._fwd_half = self.params_half if training else self.inference_params_half()
@@ -431,7 +431,7 @@ class NgpEngine:
 
     def _rgb_args(self, ws, training: bool):
         return _lib.NgpRgbArgs(
-            capacity=ws["cap"], sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
+            capacity=ws.get("n_launch", ws["cap"]), sh=ws["sh"].data_ptr(), density_out=ws["density_out"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(),
             weights=self._pp("rgb", self.params_half if training else self.inference_params_half()).value,
             rgb_out=ws["rgb_out"].data_ptr(), hidden=None,
@@ -447,7 +447,7 @@ class NgpEngine:
         cfg = self.cfg
         R = ws["R"]
         return _lib.NgpLossArgs(
-            R=R, capacity=ws["cap"], counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
+            R=R, capacity=ws.get("n_launch", ws["cap"]), counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(), t=ws["t"].data_ptr(), dt=ws["dt"].data_ptr(),
             density_out=ws["density_out"].data_ptr(), density_stride=16, rgb_out=ws["rgb_out"].data_ptr(), rgb_stride=16,
             background=None if background is None else background.data_ptr(),
@@ -812,8 +812,13 @@ class NgpEngine:
             b = self.render_rays(origins[h:].contiguous(), directions[h:].contiguous(), dn[h:].contiguous())
             self.last_render_samples = found
             return {k: torch.cat([a[k], b[k]]) for k in a}
-        self._shade(ws, False, stream)
-        la = self._loss_args(ws, False, False, None)
-        _call("nvo_ngp_composite_loss", stream, C.byref(la))
+        # the packed samples sit at the front of the workspace: the shading launches cover them, not the whole capacity
+        ws["n_launch"] = min(ws["cap"], max(4096, (found + 4095) // 4096 * 4096))
+        try:
+            self._shade(ws, False, stream)
+            la = self._loss_args(ws, False, False, None)
+            _call("nvo_ngp_composite_loss", stream, C.byref(la))
+        finally:
+            del ws["n_launch"]
         return {"rgb": ws["out_rgb"].clamp(0, 1), "depth": ws["out_depth"].clone()[:, None],
                 "accumulation": ws["out_accumulation"].clone()[:, None]}
