@@ -114,11 +114,32 @@ def run(a, quiet: bool = False):
             depth = tb.render(width=1200, height=680, spp=1, linear=True)
             times.append(time.perf_counter() - t1)
         ms = 1e3 * float(np.mean(times[1:]))
+        # quality of what was trained so far: views halfway between training cameras (the same trajectory sampled twice
+        # as densely: odd frames) and training views, at the training resolution, float-MSE PSNR of the colour image
+        def view_psnr(pose_cv, gt_chw):
+            mm = pose_cv.detach().cpu().numpy().astype(np.float64).copy()
+            mm[0:3, 1:3] *= -1
+            tb.set_nerf_camera_matrix(mm[[2, 0, 1]])
+            tb.fov = 2.0 * math.degrees(math.atan(0.5 * W / float(seq["camera_intrinsics"][0, 0])))
+            tb.render_mode = pyngp.Shade
+            img = np.clip(tb.render(width=W, height=H, spp=1, linear=True)[..., :3], 0.0, 1.0)
+            mse = float(np.mean((img - gt_chw.permute(1, 2, 0).cpu().numpy()) ** 2))
+            return 10.0 * math.log10(1.0 / max(mse, 1e-12))
+
+        dense = make_sequence(2 * a.keyframes, H, W, device=dev, scene_scale=0.2)
+        dposes = dense["camera_extrinsics"].clone()
+        dposes[:, :3, 3] += 0.5
+        same_path = bool(torch.allclose(dposes[::2], poses, atol=1e-5))
+        held = [view_psnr(dposes[i], dense["frames_color"][i]) for i in range(1, 2 * a.keyframes, 2 * a.keyframes // 4)] if same_path else []
+        seen = [view_psnr(poses[i], seq["frames_color"][i]) for i in range(0, a.keyframes, a.keyframes // 4)]
         render = {"resolution": [1200, 680], "frames": a.render_frames, "ms_per_frame_colour_and_depth": round(ms, 2),
                   "rays_per_sec": round(1200 * 680 / (ms * 1e-3)), "coverage": round(float((shade[..., 3] > 0.5).mean()), 4),
+                  "psnr_after_steps": int(eng.step), "psnr_training_views_db": round(float(np.mean(seen)), 2),
+                  "psnr_heldout_views_db": round(float(np.mean(held)), 2) if held else None,
                   "launch": f"eager, bundles sized to ~85 % of {int(eng.cfg.render_capacity or eng.cfg.capacity)} packed samples, both modes from one pass (host copies of both images included)"}
         say(f"render 1200x680 (colour + depth): {ms:.1f} ms per frame, {render['rays_per_sec'] / 1e6:.1f} M rays/s, "
-            f"coverage {render['coverage']}, depth median {float(np.median(depth[..., 0])):.3f}")
+            f"coverage {render['coverage']}, depth median {float(np.median(depth[..., 0])):.3f}; after {eng.step} steps PSNR "
+            f"{render['psnr_training_views_db']} dB on training views, {render['psnr_heldout_views_db']} dB on views between them")
     n = eng.samples_last_step()
     say(f"extrinsics={a.extrinsics}: {dt * 1e3:.3f} ms/step, {n} packed samples in the last step "
         f"({n / dt / 1e6:.1f} M samples/s), losses {eng.loss_dict()}")
