@@ -75,6 +75,15 @@ class NgpConfig:
     optimize_extrinsics: bool = True
     extrinsic_lr: float = 1e-3
     extrinsic_l2_reg: float = 1e-4
+    # The camera optimiser does not step with the network [UPSTREAM Testbed::train_nerf, unpinned]: the per-camera gradient
+    # is ACCUMULATED over n_steps_between_cam_updates = 16 training steps, then scaled by n_images / 16 (the mean over the
+    # window of a camera's share of the batch), the L2 pull is added and Adam -- with its own step count -- moves the
+    # offsets with a learning rate extrinsic_lr * 0.33^(camera step / 128), not below lr / 1000.  (Stepping the offsets with
+    # every batch at a constant 1e-3 lets Adam's normalised steps jitter exact poses by ~2e-3: 33 -> 27 dB on the bench
+    # scene, EXPERIMENTS 8.17.)  1 = every step (the former behaviour, with the constant rate).
+    extrinsic_update_every: int = 16
+    extrinsic_lr_decay: float = 0.33
+    extrinsic_lr_decay_steps: int = 128
     # "optimizer": {"otype": "Ema", "decay": 0.95, "nested": Adam} of instant-ngp's configs/nerf/base.json (the file the
     # reference loads, instant_ngp.py:45) [UPSTREAM tcnn EmaOptimizer]: inference reads the debiased moving average of
     # the weights, training the raw ones.  0 switches it off.
@@ -187,6 +196,14 @@ class NgpEngine:
         # nvo_opt_commit behind the optimiser launches iff the step was not skipped -- nothing of a step depends on a host
         # scalar, so a captured step can be replayed
         self._opt_dev = z(4)
+        # the camera optimiser's own device scalars (same layout: [0] = its current learning rate, [1..2] = bias corrections
+        # of ITS next applied step), step counter, overflow verdict of the accumulated gradient
+        self._cam_dev = z(4)
+        self._cam_applied_dev = z(1, torch.int32)
+        self._cam_flag = z(1, torch.int32)
+        self.cam_step = 0          # camera-optimiser steps attempted (host mirror; drives the learning-rate schedule)
+        self._cam_synced = None    # (cam_step, lr) the device scalars were written for
+        self._cam_window = 0       # training steps accumulated into d_corrections since the last camera update
         self._applied_dev = z(1, torch.int32)
         self._dev_synced = None   # the host opt_step the two buffers above were written for
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
@@ -482,9 +499,7 @@ class NgpEngine:
         spans.append((self.losses.data_ptr(), 4 * self.losses.numel()))
         if leaf_flags:
             spans.append((self.skip_flag.data_ptr(), 4))
-        if self.cfg.optimize_extrinsics and self._pose_inputs is not None and "dx01" in ws:
-            spans += [(self.d_corrections.data_ptr(), 4 * self.d_corrections.numel()),
-                      (self.pose_grads.data_ptr(), 4 * self.pose_grads.numel())]
+        # (the per-camera gradient d_corrections accumulates across the camera optimiser's window: cleared behind its step)
         spans += self._bwd_zero_spans()
         spans = [sp for sp in spans if sp[1] > 0]
         _call("nvo_zero_ranges", stream, len(spans), (C.c_void_p * len(spans))(*[a for a, _ in spans]),
@@ -536,10 +551,68 @@ class NgpEngine:
               _ptr(ws["d_dir"]))
         intr, c2w = self._pose_inputs
         _call("nvo_pose_bwd_cams", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
-              _ptr(ws["d_dir"]), None, _ptr(self.d_corrections), cfg.num_images)
+              _ptr(ws["d_dir"]), None, _ptr(self.d_corrections), cfg.num_images)  # (adds into the window's total)
+
+    @torch.no_grad()
+    def camera_gradient(self) -> torch.Tensor:
+        """dL/d(camera offsets) [F * 6] of what the current window has accumulated: the loss-scaled SUM over its training
+        steps, without the L2 pull (tests; the optimiser's own step adds the pull and the window / camera scaling)."""
+        _call("nvo_se3_exp_map_bwd", _stream(self.device), self.cfg.num_images, _ptr(self.pose_adjustment),
+              _ptr(self.d_corrections), 0.0, 0.0, 0.0, _ptr(self.pose_grads), C.c_void_p(self.losses.data_ptr() + 6 * 4), 1)
+        return self.pose_grads.clone()
+
+    def _camera_update_due(self) -> bool:
+        """Does the step about to run end a window of the camera optimiser?"""
+        return self._cam_window + 1 >= max(1, int(self.cfg.extrinsic_update_every))
+
+    def _camera_grad_scale(self) -> float:
+        """What turns the window's accumulated, loss-scaled gradient into upstream's per-camera figure: the mean over the
+        window, times the number of cameras the batch is spread over."""
+        n = int(self.n_training_images) if self.n_training_images else int(self.cfg.num_images)
+        return float(n) / (self.cfg.loss_scale * max(1, int(self.cfg.extrinsic_update_every)))
+
+    def _camera_lr(self) -> float:
+        cfg = self.cfg
+        if int(cfg.extrinsic_update_every) <= 1:
+            return float(cfg.extrinsic_lr)
+        return max(cfg.extrinsic_lr * cfg.extrinsic_lr_decay ** (self.cam_step // max(1, int(cfg.extrinsic_lr_decay_steps))),
+                   cfg.lr / 1000.0)
+
+    def _sync_cam_dev(self) -> None:
+        """Device scalars of the camera optimiser for the host's ``cam_step`` and the scheduled learning rate (written when
+        either moved from outside the optimiser's own commit: first use, snapshot load, a decay boundary)."""
+        lr = self._camera_lr()
+        if self._cam_synced == (self.cam_step, lr):
+            return
+        b1, b2 = self.cfg.adam_betas
+        if self._cam_synced is None or self._cam_synced[0] != self.cam_step:
+            t = float(self.cam_step + 1)
+            self._cam_dev.copy_(torch.tensor([lr, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0], dtype=torch.float64).float())
+            self._cam_applied_dev.fill_(int(self.cam_step))
+        else:  # (only the rate moved: the optimiser's commit keeps the bias corrections)
+            self._cam_dev[0:1].fill_(lr)
+        self._cam_synced = (self.cam_step, lr)
+
+    def _camera_optimizer_step(self, stream, all_reduce=None) -> None:
+        """End of a window: accumulated per-camera gradient -> dL/d(offset) + L2 pull -> Adam with the camera optimiser's own
+        step count and rate; the window's total is cleared behind it.  An overflow anywhere in the window skips the step."""
+        cfg = self.cfg
+        scale = self._camera_grad_scale()
         _call("nvo_se3_exp_map_bwd", stream, cfg.num_images, _ptr(self.pose_adjustment), _ptr(self.d_corrections),
-              cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, cfg.loss_scale / self.world_size, _ptr(self.pose_grads),
+              cfg.extrinsic_l2_reg, cfg.extrinsic_l2_reg, 1.0 / (scale * self.world_size), _ptr(self.pose_grads),
               C.c_void_p(self.losses.data_ptr() + 5 * 4), 1)
+        if all_reduce is not None:
+            all_reduce(self.pose_grads)
+        n6 = cfg.num_images * 6
+        _call("nvo_nonfinite_flag", stream, n6, _ptr(self.pose_grads), 0, _ptr(self._cam_flag))
+        _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
+              _ptr(self.pose_exp_avg), _ptr(self.pose_exp_avg_sq), cfg.extrinsic_lr, cfg.adam_betas[0],
+              cfg.adam_betas[1], cfg.adam_eps, 1, scale, 0.0, _ptr(self._cam_flag), _ptr(self._cam_dev))
+        # (hyper_dev = self._cam_dev overrides the by-value learning rate and step)
+        _call("nvo_opt_commit", stream, 1, 1, 0, _ptr(self._cam_applied_dev), _ptr(self._cam_flag), None, None, 2.0, 0.5,
+              2000, 0.0, 0.0, C.c_void_p(self._cam_dev.data_ptr() + 4), cfg.adam_betas[0], cfg.adam_betas[1])
+        _call("nvo_zero_ranges", stream, 1, (C.c_void_p * 1)(self.d_corrections.data_ptr()),
+              (C.c_uint64 * 1)(4 * self.d_corrections.numel()))
 
     def _fused_adam_plan(self):
         """(lo, hi) of the flat parameter buffer the grid backward can step itself (its streamed hashed levels), or None.
@@ -593,7 +666,7 @@ class NgpEngine:
         self._sync_opt_dev()
         return int(self._applied_dev.item())
 
-    def optimizer_step(self, fused_adam=None) -> None:
+    def optimizer_step(self, fused_adam=None, camera_update: bool = True, all_reduce=None) -> None:
         """Adam of the three parameter ranges (one launch), weight average, Adam of the camera offsets, step counter.
         The bias corrections come from the device (self._opt_dev): t = applied steps + 1."""
         cfg = self.cfg
@@ -632,12 +705,9 @@ class NgpEngine:
             _call("nvo_ema_update_dev", stream, hi - lo, C.c_void_p(self.params.data_ptr() + 4 * lo),
                   C.c_void_p(self.params_ema.data_ptr() + 4 * lo), C.c_void_p(self.params_ema_half.data_ptr() + 2 * lo),
                   cfg.ema_decay, _ptr(self._ema_step_dev), _ptr(self.skip_flag))
-        if cfg.optimize_extrinsics and self._pose_inputs is not None:
-            n6 = cfg.num_images * 6
-            _call("nvo_adam_step", stream, n6, _ptr(self.pose_adjustment), _ptr(self._pose_half), _ptr(self.pose_grads), 0,
-                  _ptr(self.pose_exp_avg), _ptr(self.pose_exp_avg_sq), cfg.extrinsic_lr, cfg.adam_betas[0],
-                  cfg.adam_betas[1], cfg.adam_eps, 1, 1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), _ptr(self._opt_dev))
-            # (hyper_dev = self._opt_dev overrides the by-value learning rate and step)
+        if camera_update and cfg.optimize_extrinsics and self._pose_inputs is not None:
+            self._sync_cam_dev()  # (a no-op once train_step has written them: nothing is uploaded inside a capture)
+            self._camera_optimizer_step(stream, all_reduce)
         # the step counter and the next step's bias corrections, behind every launch that read them
         _call("nvo_opt_commit", stream, 1, 1, 0, _ptr(self._applied_dev), _ptr(self.skip_flag), None, None, 2.0, 0.5, 2000,
               0.0, 0.0, C.c_void_p(bias_dev), cfg.adam_betas[0], cfg.adam_betas[1])
@@ -651,12 +721,21 @@ class NgpEngine:
                 self.mark_untrained_cells(intrinsics, c2w, n_train, int(images.shape[1]), int(images.shape[2]))
             self.update_density_grid(all_reduce=all_reduce)
         self._sync_opt_dev()
+        pose = bool(self.cfg.optimize_extrinsics) and "dx01" in ws
+        cam_update = pose and self._camera_update_due()
+        if cam_update:
+            self._sync_cam_dev()
         if self.cfg.graph_step and all_reduce is None:
-            self._train_step_graphed(ws, ray_indices, intrinsics, c2w, images, depths)
+            self._train_step_graphed(ws, ray_indices, intrinsics, c2w, images, depths, cam_update)
         else:
             jitter = torch.rand(R, device=self.device)
             bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
-            self._step_body(ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce)
+            self._step_body(ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce, cam_update)
+        if pose:
+            self._cam_window = 0 if cam_update else self._cam_window + 1
+            if cam_update:
+                self.cam_step += 1
+                self._cam_synced = (self.cam_step, self._cam_synced[1])  # (the commit advanced the device side)
         self.opt_step += 1
         self._dev_synced = self.opt_step  # (the host mirror counts attempts; the device follows the applied steps)
         self.step += 1
@@ -664,7 +743,8 @@ class NgpEngine:
         if self.cfg.adaptive_rays:
             self._adapt_rays(ws, R)
 
-    def _step_body(self, ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce=None) -> None:
+    def _step_body(self, ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce=None,
+                   camera_update: bool = True) -> None:
         """Every launch of one step, in order (eager, or recorded into a hipGraph by _train_step_graphed)."""
         self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
         fused = self._fused_adam_plan() if all_reduce is None else None
@@ -672,9 +752,7 @@ class NgpEngine:
                               fused_adam=fused)
         if all_reduce is not None:
             all_reduce(self.grads)
-            if self.cfg.optimize_extrinsics and self._pose_inputs is not None:
-                all_reduce(self.pose_grads)
-        self.optimizer_step(fused_adam=fused)
+        self.optimizer_step(fused_adam=fused, camera_update=camera_update, all_reduce=all_reduce)
         if self.cfg.adaptive_rays:
             # samples the march found in this step, BEFORE rays were dropped at the packed capacity (the scan's total):
             # a capped measure could never exceed the target, so the batch would only ever grow
@@ -682,7 +760,7 @@ class NgpEngine:
 
     _MAX_GRAPHS = 48
 
-    def _train_step_graphed(self, ws, ray_indices, intrinsics, c2w, images, depths) -> None:
+    def _train_step_graphed(self, ws, ray_indices, intrinsics, c2w, images, depths, cam_update: bool = True) -> None:
         """The step as ONE hipGraph replay (NgpConfig.graph_step).  In front of it, eager: the caller's ray indices are
         copied and the march jitter is drawn into the workspace's fixed buffers (same generator calls as the eager step).
         Captured once per ray count (the adaptive batch moves it every `density_update_every` steps, usually between a
@@ -700,7 +778,7 @@ class NgpEngine:
             bg = ws["background"]
             bg.uniform_()
         if not self._kernels_loaded:
-            self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
+            self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update)
             self._kernels_loaded = True
             return
         if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
@@ -708,11 +786,11 @@ class NgpEngine:
             self.params_ema_half = torch.zeros_like(self.params_half)
         key = (R, ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
                None if depths is None else depths.data_ptr(), bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
-               self._fused_adam_plan(),
+               bool(cam_update), self._camera_grad_scale() if cam_update else 0.0, self._fused_adam_plan(),
                # every by-value scalar of the step's launches
                (cfg.loss_scale, cfg.lr, cfg.rgb_loss_mult, cfg.depth_loss_mult, cfg.l2_reg, cfg.extrinsic_l2_reg, cfg.ema_decay,
                 cfg.cone_angle, cfg.near_distance, tuple(cfg.adam_betas), cfg.adam_eps, bool(cfg.random_background),
-                int(cfg.dw_replicas), self.world_size),
+                int(cfg.dw_replicas), self.world_size, cfg.extrinsic_lr),
                0 if self.params_ema is None else self.params_ema.data_ptr())
         entry = self._graphs.get(key)
         if entry is None:
@@ -721,7 +799,7 @@ class NgpEngine:
             t0 = time.perf_counter()
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):  # (no cyclic garbage collection while the stream records)
-                self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg)
+                self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update)
             self.graph_captures += 1
             self.graph_capture_seconds += time.perf_counter() - t0
             # the graph addresses these buffers: they must stay alive as long as it does

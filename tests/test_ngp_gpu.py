@@ -137,9 +137,10 @@ def test_ngp_extrinsics_gradient_matches_oracle(device):
 
     ws = eng._workspace(R, True)
     eng.load_rays(ws, idx.to(device), intr.to(device), c2w.to(device).contiguous(), images.to(device), depths.to(device))
+    eng.d_corrections.zero_()  # (a fresh window of the camera optimiser: the per-camera gradient accumulates across steps)
     eng.forward_backward(ws, jitter.to(device), has_depth=True, background=None)
     torch.cuda.synchronize()
-    got = (eng.pose_grads / eng.cfg.loss_scale).view(F, 6).double().cpu()
+    got = (eng.camera_gradient() / eng.cfg.loss_scale).view(F, 6).double().cpu()
 
     orc = _oracle(eng)
     pose_r = pose.double().requires_grad_(True)
@@ -257,7 +258,8 @@ def test_adaptive_ray_batch_and_ema_inference(device):
             idx = torch.floor(torch.rand(R, 3, device=device) * scale).long()
             eng.train_step(idx, seq["camera_intrinsics"], c2w, images, depths)
             seen.append((R, int(eng._ws["counts"].sum().item())))
-        assert eng.rays_per_batch != start, "the batch never adapted"
+        # (in the first hundred steps a ray of this scene still finds 250-600 samples: 2^16 slots take 128-256 rays)
+        assert eng.rays_per_batch <= 512, "the batch never adapted"
         tail = np.mean([m for _, m in seen[-16:]])
         assert 0.75 * eng.cfg.capacity <= tail <= 1.25 * eng.cfg.capacity, (start, seen[-16:])
         assert int(eng.skip_flag.item()) == 0
@@ -359,12 +361,14 @@ def test_graphed_step_matches_eager_step(device):
     for graphed in (True, False):
         torch.manual_seed(9)
         engines[graphed] = NgpEngine(NgpConfig(num_images=n, num_rays=512, capacity=1 << 16, graph_step=graphed,
-                                               density_update_every=4, optimize_extrinsics=True), device)
+                                               density_update_every=4, optimize_extrinsics=True,
+                                               extrinsic_update_every=3), device)
     ge, ee = engines[True], engines[False]
     lo, hi = ge._fused_adam_plan()
     scale = torch.tensor([n, H, W], device=device)
     state = ("params", "exp_avg", "exp_avg_sq", "params_half", "params_ema", "params_ema_half", "pose_adjustment",
-             "pose_exp_avg", "pose_exp_avg_sq", "density_grid", "bitfield", "_ema_step_dev", "_applied_dev", "_opt_dev")
+             "pose_exp_avg", "pose_exp_avg_sq", "density_grid", "bitfield", "_ema_step_dev", "_applied_dev", "_opt_dev",
+             "d_corrections", "_cam_dev", "_cam_applied_dev")
     ray_counts = set()
     for it in range(11):
         overflow = it == 6
@@ -391,6 +395,11 @@ def test_graphed_step_matches_eager_step(device):
             y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
             assert torch.equal(x, y), f"step {it}: {name} of the hash grid differs ({int((x != y).sum())} words)"
         assert torch.equal(ge._opt_dev, ee._opt_dev) and torch.equal(ge.density_grid, ee.density_grid)
+        # the camera optimiser steps at the end of every third training step, with its own count and rate
+        assert ge.cam_step == ee.cam_step == (it + 1) // 3 and ge._cam_window == ee._cam_window == (it + 1) % 3
+        assert torch.equal(ge._cam_dev, ee._cam_dev) and torch.equal(ge._cam_applied_dev, ee._cam_applied_dev)
+        if (it + 1) % 3 == 0:
+            assert float(ge.d_corrections.abs().max()) == 0.0 == float(ee.d_corrections.abs().max())
         d = (ge.params[:lo] - ee.params[:lo]).abs()  # (MLP weights: float-atomic dW totals, see the test above)
         assert float((d > 1e-5 + 1e-3 * ee.params[:lo].abs()).float().mean()) < 0.02
         # (camera offsets: float-atomic gradient totals; a near-zero total of either sign moves an entry by +- lr)
