@@ -43,7 +43,6 @@ import numpy as np
 import torch
 
 from .mapping.cameras import Cameras, CameraType
-from .mapping.model import multiply
 from .ngp_engine import NgpConfig, NgpEngine
 
 _TO_NGP_ROWS = [2, 0, 1]    # OpenGL c2w rows -> "NGP" row order
@@ -139,7 +138,11 @@ class _Training:
             raise RuntimeError("get_camera_extrinsics: no training images have been set")
         pose = tb._poses[frame_idx]
         if self.optimize_extrinsics:
-            pose = multiply(tb._engine.camera_corrections()[frame_idx], pose)
+            # as the training rays see the camera (nvo_rays_given: direction = R_c d, origin = t + t_c) and as upstream's
+            # update_transforms composes it [UPSTREAM: rotation offset times the camera's rotation, position offset ADDED]:
+            # [R_c R | t + t_c] -- not the 4x4 product, whose translation R_c t + t_c is off by (R_c - 1) t
+            corr = tb._engine.camera_corrections()[frame_idx]
+            pose = torch.cat([corr[:3, :3] @ pose[:3, :3], pose[:3, 3:] + corr[:3, 3:]], dim=1)
         return pose.detach().cpu().numpy().astype(np.float64)[_TO_NGP_ROWS]
 
 

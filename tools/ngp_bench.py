@@ -116,10 +116,13 @@ def run(a, quiet: bool = False):
         ms = 1e3 * float(np.mean(times[1:]))
         # quality of what was trained so far: views halfway between training cameras (the same trajectory sampled twice
         # as densely: odd frames) and training views, at the training resolution, float-MSE PSNR of the colour image
-        def view_psnr(pose_cv, gt_chw):
-            mm = pose_cv.detach().cpu().numpy().astype(np.float64).copy()
-            mm[0:3, 1:3] *= -1
-            tb.set_nerf_camera_matrix(mm[[2, 0, 1]])
+        def view_psnr(pose_cv, gt_chw, keyframe=None):
+            if keyframe is not None:  # a training view: at the model's own (optimised) pose, as the reference renders keyframes
+                tb.set_nerf_camera_matrix(tb.nerf.training.get_camera_extrinsics(keyframe))
+            else:
+                mm = pose_cv.detach().cpu().numpy().astype(np.float64).copy()
+                mm[0:3, 1:3] *= -1
+                tb.set_nerf_camera_matrix(mm[[2, 0, 1]])
             tb.fov = 2.0 * math.degrees(math.atan(0.5 * W / float(seq["camera_intrinsics"][0, 0])))
             tb.render_mode = pyngp.Shade
             img = np.clip(tb.render(width=W, height=H, spp=1, linear=True)[..., :3], 0.0, 1.0)
@@ -131,7 +134,7 @@ def run(a, quiet: bool = False):
         dposes[:, :3, 3] += 0.5
         same_path = bool(torch.allclose(dposes[::2], poses, atol=1e-5))
         held = [view_psnr(dposes[i], dense["frames_color"][i]) for i in range(1, 2 * a.keyframes, 2 * a.keyframes // 4)] if same_path else []
-        seen = [view_psnr(poses[i], seq["frames_color"][i]) for i in range(0, a.keyframes, a.keyframes // 4)]
+        seen = [view_psnr(poses[i], seq["frames_color"][i], keyframe=i) for i in range(0, a.keyframes, a.keyframes // 4)]
         render = {"resolution": [1200, 680], "frames": a.render_frames, "ms_per_frame_colour_and_depth": round(ms, 2),
                   "rays_per_sec": round(1200 * 680 / (ms * 1e-3)), "coverage": round(float((shade[..., 3] > 0.5).mean()), 4),
                   "psnr_after_steps": int(eng.step), "psnr_training_views_db": round(float(np.mean(seen)), 2),

@@ -51,9 +51,12 @@ tb.nerf.training.update_training_images(
 
 
 def view_psnr(i):
-    mm = dposes[i].detach().cpu().numpy().astype(np.float64).copy()
-    mm[0:3, 1:3] *= -1
-    tb.set_nerf_camera_matrix(mm[[2, 0, 1]])
+    if i % 2 == 0:  # a training view: at the model's own (optimised) pose, as the reference's evaluation renders keyframes
+        tb.set_nerf_camera_matrix(tb.nerf.training.get_camera_extrinsics(i // 2))
+    else:           # a view between two training cameras: at its dataset pose
+        mm = dposes[i].detach().cpu().numpy().astype(np.float64).copy()
+        mm[0:3, 1:3] *= -1
+        tb.set_nerf_camera_matrix(mm[[2, 0, 1]])
     tb.fov_axis, tb.fov = 0, 2.0 * math.degrees(math.atan(0.5 * W / float(dense["camera_intrinsics"][0, 0])))
     tb.render_mode = pyngp.Shade
     img = np.clip(tb.render(width=W, height=H, spp=1, linear=True)[..., :3], 0.0, 1.0)
