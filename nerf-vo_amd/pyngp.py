@@ -280,6 +280,7 @@ class Testbed:
             snap["params_ema"] = raw(e.params_ema)
             snap["ema_step"] = e.ema_step
         snap["rays_per_batch"] = e.rays_per_batch
+        snap["cam_step"] = e.cam_step  # (the camera optimiser's own step count: its learning-rate schedule resumes)
         if include_optimizer_state:
             snap["optimizer"] = {"exp_avg": raw(e.exp_avg), "exp_avg_sq": raw(e.exp_avg_sq),
                                  "pose_exp_avg": raw(e.pose_exp_avg), "pose_exp_avg_sq": raw(e.pose_exp_avg_sq)}
@@ -318,6 +319,7 @@ class Testbed:
             e.params_ema_half = e.params_ema.to(torch.float16)
             e.ema_step = int(snap["ema_step"])
         e.rays_per_batch = int(snap.get("rays_per_batch", e.cfg.num_rays))
+        e.cam_step = int(snap.get("cam_step", 0))
         put(e.density_grid, snap["density_grid"])
         put(e.bitfield, snap["bitfield"])
         put(self._poses, snap["poses"])

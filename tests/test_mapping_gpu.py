@@ -220,6 +220,7 @@ def test_pyngp_incremental_keyframes_snapshot_and_render(device, tmp_path):
     tb2 = make()
     tb2.load_snapshot(path)
     assert tb2.training_step == tb.training_step and tb2.nerf.training.n_images_for_training == n
+    assert tb2._engine.cam_step == tb._engine.cam_step == tb.training_step // 16  # (the camera optimiser's schedule resumes)
     tb2._images.copy_(tb._images)  # (snapshots hold the model, not the training images: as upstream)
     tb2._depths.copy_(tb._depths)
     tb2.render_mode = pyngp.Shade
