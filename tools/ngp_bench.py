@@ -193,7 +193,9 @@ def run(a, quiet: bool = False):
                           "dtype": "f16", "data": "synthetic",
                           "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H}, aabb_scale 4, "
                                                  f"capacity {cap} packed samples, extrinsics optimisation "
-                                                 f"{'on' if a.extrinsics else 'off'}, weight EMA, adaptive ray batch",
+                                                 f"{'on' if a.extrinsics else 'off'} (camera step every {eng.cfg.extrinsic_update_every} training steps), weight EMA, "
+                                                 f"adaptive ray batch, random background {'on' if eng.cfg.random_background else 'off'}, "
+                                                 f"untrained cells marked",
                                      "launch": "hipGraph replay: ONE graph per step (per ray count), density-grid refresh "
                                                "eager every 16th step" if eng.cfg.graph_step else "eager"},
                           "window": window, "render": render, "march_us": round(per.get("occ_march", 0.0) * 1e6, 1), "roofline": roof,
