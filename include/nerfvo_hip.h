@@ -492,6 +492,16 @@ int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const f
                   const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                   uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
                   float* dt_out, void* scratch, uint64_t scratch_bytes);
+/* The same march in ROUNDS (inference with early termination: `render_min_transmittance`, which the reference sets to 1e-4,
+ * /root/reference/evaluation/nerf_renderer.py:154): ray r takes up its progression at candidate t_resume[r] (NULL: a fresh
+ * march from t_near with jitter; a negative entry: the ray is not alive, 0 samples), accepts at most max_new samples and
+ * writes to t_next[r] (nullable) the candidate it stopped in front of, -1 once it has left the scene box.  The step
+ * recurrence depends on t alone, so the rounds of a ray concatenate to exactly the samples of one uninterrupted march. */
+int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                         const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                         uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
+                         float* dt_out, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
+                         float* t_next);
 /* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
  * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
  * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.
@@ -577,6 +587,12 @@ typedef struct nvo_ngp_loss_args {
     void* d_rgb_out;             /* fp16 [capacity][d_rgb_stride]; NULL -> inference */
     uint32_t d_rgb_stride;
     float* d_density_pre;        /* [capacity] */
+    /* inference in rounds (nvo_occ_march_resume): the optical depth the ray has gathered in earlier rounds (NULL: none),
+     * where to leave the total (nullable), and whether out_rgb / out_depth / out_accumulation are ADDED to (a later round)
+     * or overwritten.  Training ignores the three. */
+    const float* carry_in;       /* [R] */
+    float* carry_out;            /* [R] */
+    uint32_t accumulate_outputs;
 } nvo_ngp_loss_args;
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);

@@ -108,7 +108,7 @@ class NgpLossArgs(C.Structure):
                 ("background", _p), ("gt_rgb", _p), ("gt_depth", _p), ("directions_norm", _p), ("rgb_mult", _f),
                 ("depth_mult", _f), ("inv_rays", _f), ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p),
                 ("out_accumulation", _p), ("losses", _p), ("d_rgb_out", _p), ("d_rgb_stride", _u32),
-                ("d_density_pre", _p)]
+                ("d_density_pre", _p), ("carry_in", _p), ("carry_out", _p), ("accumulate_outputs", _u32)]
 
 
 _SIGNATURES = {
@@ -167,6 +167,7 @@ _SIGNATURES = {
     # group F
     "nvo_occ_march_scratch_bytes": (_u64, [_u32]),
     "nvo_occ_march": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64]),
+    "nvo_occ_march_resume": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _u32, _p, _p, _p, _p, _p, _p, _u64, _p, _u32, _p]),
     "nvo_occ_update": (_int, [_p, _int, _p, _p, _f, _f, _p, _p]),
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_occ_mark_untrained": (_int, [_p, _int, _p, _u32, _p, _p, _u32, _u32, _f]),

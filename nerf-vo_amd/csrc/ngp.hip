@@ -86,6 +86,12 @@ k_ngp_positions_bwd(uint32_t R, uint32_t capacity, const int32_t* __restrict__ c
 
 namespace {
 
+// Optical depth of one sample, density x step, capped at 128: beyond it alpha = 1 - exp(-dd) is exactly 1 and the
+// transmittance behind the sample exactly 0 in fp32 either way, but an uncapped huge value (a pre-activation of 30 is
+// 1e13 x dt) wipes the smaller terms out of the prefix sum the transmittances are read from (T = exp(-(incl - dd)):
+// accumulations above 1 were observed with pre-activations of +-70) and turns 0 x inf into NaN in the gradient.
+__device__ __forceinline__ float ngp_optical_step(float sigma, float dt) { return fminf(sigma * dt, 128.f); }
+
 __global__ void __launch_bounds__(256)
 k_ngp_composite_loss(nvo_ngp_loss_args a) {
     const int lane = threadIdx.x & 63;
@@ -97,7 +103,8 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     const _Float16* col = (const _Float16*)a.rgb_out;
 
     // ---- pass 1: composite front to back (T = prod (1 - alpha) through a log-space additive scan)
-    float carry = 0.f;  // sum of density * dt of all previous samples
+    // sum of density * dt of all previous samples (inference in rounds: what earlier rounds of this ray have gathered)
+    float carry = (a.carry_in && !a.d_rgb_out) ? a.carry_in[r] : 0.f;
     float pix[3] = {0.f, 0.f, 0.f};
     float depth = 0.f, acc = 0.f;
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -106,7 +113,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         if (j < n) {
             const size_t s = base + j;
             const float sigma = __expf((float)den[s * a.density_stride]);
-            dd = sigma * a.dt[s];
+            dd = ngp_optical_step(sigma, a.dt[s]);
             tj = a.t[s];
 #pragma unroll
             for (int k = 0; k < 3; ++k) rgb[k] = 1.f / (1.f + __expf(-(float)col[s * a.rgb_stride + k]));
@@ -129,12 +136,14 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) pix[k] += T_final * bg[k];
     if (lane == 0) {
+        const bool add = a.accumulate_outputs != 0u && !a.d_rgb_out;
         if (a.out_rgb) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.out_rgb[3 * (size_t)r + k] = pix[k];
+            for (int k = 0; k < 3; ++k) a.out_rgb[3 * (size_t)r + k] = (add ? a.out_rgb[3 * (size_t)r + k] : 0.f) + pix[k];
         }
-        if (a.out_depth) a.out_depth[r] = depth;
-        if (a.out_accumulation) a.out_accumulation[r] = acc;
+        if (a.out_depth) a.out_depth[r] = (add ? a.out_depth[r] : 0.f) + depth;
+        if (a.out_accumulation) a.out_accumulation[r] = (add ? a.out_accumulation[r] : 0.f) + acc;
+        if (a.carry_out && !a.d_rgb_out) a.carry_out[r] = carry;
     }
     if (!a.d_rgb_out) return;
     // a ray the scan dropped at the packed capacity (count zeroed, its slot range in `offsets` kept) leaves no trace in
@@ -175,7 +184,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         float dd = 0.f, q = 0.f;
         if (j < n) {
             const size_t s = base + j;
-            dd = __expf((float)den[s * a.density_stride]) * a.dt[s];
+            dd = ngp_optical_step(__expf((float)den[s * a.density_stride]), a.dt[s]);
         }
         const float incl = wave_incl_scan(dd, lane) + carry;
         if (j < n) {
@@ -200,7 +209,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         if (j < n) {
             const size_t s = base + j;
             sigma = __expf((float)den[s * a.density_stride]);
-            dd = sigma * a.dt[s];
+            dd = ngp_optical_step(sigma, a.dt[s]);
         }
         const float incl = wave_incl_scan(dd, lane) + carry;
         if (j < n) {

@@ -186,10 +186,25 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
 __global__ void __launch_bounds__(256)
 k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __restrict__ directions,
                  const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
-                 const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch) {
+                 const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch,
+                 const float* __restrict__ t_resume, uint32_t max_new, float* __restrict__ t_next) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     if (r >= R) return;
+    // RESUMABLE form (inference in rounds): the ray takes up its progression at candidate t_resume[r] (a value an earlier
+    // launch handed out through t_next: the recurrence depends on t alone, so the samples are the ones a single march
+    // would have found), accepts at most max_new samples and reports the candidate it stopped in front of (-1: the ray
+    // has left the scene box, or was not alive: t_resume[r] < 0)
+    const uint32_t budget = max_new < kMaxSteps ? max_new : kMaxSteps;
+    const float resume = t_resume ? t_resume[r] : 0.f;
+    if (t_resume && !(resume >= 0.f)) {
+        if (lane == 0u) {
+            counts[r] = 0u;
+            if (t_next) t_next[r] = -1.f;
+        }
+        return;
+    }
+    float next = -1.f;  // (uniform)
     const int max_mip = n_levels - 1;
     const float half = 0.5f * (float)(1 << max_mip);
     const float lo = 0.5f - half, hi = 0.5f + half;
@@ -208,7 +223,7 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
     float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
     uint32_t j = 0;  // accepted so far (uniform)
     if (tmax > tmin) {
-        float t = tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);  // candidate 0 of the current block
+        float t = t_resume ? resume : tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);  // candidate 0 of the current block
         float skip_to = -3.0e38f;  // (uniform) candidates before this ray parameter are stepped over
         bool done = false;
         // (16384 blocks = 2^20 candidates: an exit every wave reaches even for a degenerate ray whose skip target is
@@ -238,7 +253,12 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
                 const unsigned long long cand = __ballot(my_t >= skip_to) & (~0ull << pos);
                 if (cand == 0ull) break;  // the rest of the block is stepped over
                 const uint32_t k = (uint32_t)__builtin_ctzll(cand);
-                if (!((in_mask >> k) & 1ull) || j >= kMaxSteps) {  // left the box / sample budget of the ray spent
+                if (!((in_mask >> k) & 1ull)) {  // left the box
+                    done = true;
+                    break;
+                }
+                if (j >= budget) {  // sample budget of the ray (of this round) spent: candidate k is where it resumes
+                    next = nvo_wave_bcast(my_t, (int)k);
                     done = true;
                     break;
                 }
@@ -246,7 +266,7 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
                     // an occupied candidate steps to its successor: the whole run of occupied candidates is visited
                     const unsigned long long stop = ~occ_mask & (~0ull << k);
                     uint32_t u = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                    const uint32_t room = kMaxSteps - j;
+                    const uint32_t room = budget - j;
                     if (u - k > room) u = k + room;
                     accept |= (u >= 64u ? ~0ull : ((1ull << u) - 1ull)) & (~0ull << k);
                     j += u - k;
@@ -264,7 +284,10 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
             }
         }
     }
-    if (lane == 0u) counts[r] = j;
+    if (lane == 0u) {
+        counts[r] = j;
+        if (t_next) t_next[r] = next;
+    }
 }
 
 // one wave per ray: scratch run -> packed arrays at the scanned offset (rays dropped by the capacity clamp have
@@ -515,7 +538,17 @@ int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const f
                   const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                   uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
                   float* dt_out, void* scratch, uint64_t scratch_bytes) {
+    return nvo_occ_march_resume(stream, R, origins, directions, bitfield, n_levels, cone_angle, t_near, jitter, capacity, counts,
+                                offsets, ray_idx, t_out, dt_out, scratch, scratch_bytes, nullptr, kMaxSteps, nullptr);
+}
+
+int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                         const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                         uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
+                         float* dt_out, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
+                         float* t_next) {
     NVO_REQUIRE(n_levels >= 1 && n_levels <= 8, "occ_march: n_levels %d not in 1..8", n_levels);
+    NVO_REQUIRE(max_new >= 1, "occ_march: max_new must be positive");
     NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts && offsets && ray_idx && t_out && dt_out),
                 "occ_march: NULL argument");
     if (R == 0) return NVO_OK;
@@ -529,12 +562,12 @@ int nvo_occ_march(nvo_stream_t stream, uint32_t R, const float* origins, const f
     {
         NVO_PROF(stream, "occ_march");
         static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
-        if (ray_per_lane) {  // (A/B switch: the sequential form, one ray per lane)
+        if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps) {  // (A/B switch: the sequential form, one ray per lane)
             NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
                        n_levels, cone_angle, t_near, jitter, counts, march_scratch);
         } else {
             NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
-                       n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+                       n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next);
         }
         NVO_CHECK_LAUNCH();
     }

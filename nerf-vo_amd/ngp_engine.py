@@ -40,6 +40,12 @@ class NgpConfig:
     # packed sample slots of an INFERENCE launch (its own workspace): every sample the march finds is shaded, ~110 per ray
     # in a trained room, so 2^21 slots take ~16 K rays per launch instead of 2 K (0 = the training capacity)
     render_capacity: int = 1 << 21
+    # Inference stops a ray where its transmittance has fallen below this (instant-ngp's render_min_transmittance; the
+    # reference sets 1e-4, evaluation/nerf_renderer.py:154): render_rays shades the first `render_first_round` samples of
+    # every ray, then only the rays still alive take up their march where it stopped (nvo_occ_march_resume).  0 = one pass
+    # over every sample up to the scene box.
+    render_min_transmittance: float = 1e-4
+    render_first_round: int = 48
     aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
     cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
     near_distance: float = 0.1
@@ -209,7 +215,8 @@ class NgpEngine:
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
         self._kernels_loaded = False
         self.graph_captures, self.graph_capture_seconds = 0, 0.0  # (diagnostics: tools/ngp_bench.py)
-        self.last_render_samples = 0    # samples the march found for the last render_rays bundle
+        self.last_render_samples = 0    # samples the march found for the last render_rays bundle (its largest round)
+        self.render_shaded_total = 0
         self.params_version = 0         # bumped whenever the weights inference reads may have changed (render caches)
         self.n_training_images = None   # images in use (pyngp: nerf.training.n_images_for_training); None = all slots
         self._marked_images = None      # the image count the untrained cells were last marked for
@@ -286,6 +293,9 @@ class NgpEngine:
                             ("out_depth", (R,)), ("out_accumulation", (R,)), ("t", (cap,)), ("dt", (cap,)),
                             ("x01", (cap, 3)), ("d_density_pre", (cap,))):
             ws[name] = torch.zeros(*shape, **f32)
+        if not training:
+            for name in ("t_next", "t_resume", "carry"):
+                ws[name] = torch.zeros(R, **f32)
         ws["cam_idx"] = torch.zeros(R, **i32)
         ws["counts"] = torch.zeros(R, **i32)
         ws["offsets"] = torch.zeros(R + 1, **i32)
@@ -317,7 +327,7 @@ class NgpEngine:
 
     _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "dirs01", "out_rgb",
                 "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices",
-                "jitter", "background")
+                "jitter", "background", "t_next", "t_resume", "carry")
 
     @staticmethod
     def _ray_views(ws, R: int):
@@ -411,16 +421,17 @@ class NgpEngine:
         self._march(ws, jitter, stream)
         self._shade(ws, training, stream)
 
-    def _march(self, ws, jitter, stream) -> None:
+    def _march(self, ws, jitter, stream, t_resume=None, max_new: int = 1024, t_next=None) -> None:
         """Packed samples of the workspace's rays: counts / offsets (offsets[R] = samples found, before rays were dropped
-        at the capacity), ray_idx / t / dt."""
+        at the capacity), ray_idx / t / dt.  ``t_resume`` / ``max_new`` / ``t_next``: one round of a march in rounds
+        (nvo_occ_march_resume)."""
         cfg = self.cfg
         R, cap = ws["R"], ws["cap"]
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
-        _call("nvo_occ_march", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
+        _call("nvo_occ_march_resume", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
               _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), _ptr(ws["march_scratch"]),
-              ws["march_scratch"].numel())
+              ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next))
 
     def _shade(self, ws, training: bool, stream) -> None:
         cfg = self.cfg
@@ -460,7 +471,8 @@ class NgpEngine:
             dw_replicas=self._dw_rep["rgb"] if (training and self._dw_rep) else None,
             n_dw_replicas=self._dw_rep["G"] if (training and self._dw_rep) else 0)
 
-    def _loss_args(self, ws, training: bool, has_depth: bool, background):
+    def _loss_args(self, ws, training: bool, has_depth: bool, background, carry_in=None, carry_out=None,
+                   accumulate: bool = False):
         cfg = self.cfg
         R = ws["R"]
         return _lib.NgpLossArgs(
@@ -475,7 +487,9 @@ class NgpEngine:
             loss_scale=cfg.loss_scale, out_rgb=ws["out_rgb"].data_ptr(), out_depth=ws["out_depth"].data_ptr(),
             out_accumulation=ws["out_accumulation"].data_ptr(), losses=self.losses.data_ptr() if training else None,
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None, d_rgb_stride=16,
-            d_density_pre=ws["d_density_pre"].data_ptr() if training else None)
+            d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
+            carry_in=None if carry_in is None else carry_in.data_ptr(),
+            carry_out=None if carry_out is None else carry_out.data_ptr(), accumulate_outputs=int(bool(accumulate)))
 
     def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False,
                          fused_adam=None) -> None:
@@ -870,33 +884,68 @@ class NgpEngine:
         return int(min(int(ws["offsets"][-1].item()), ws["cap"])) if ws is not None else 0
 
     @torch.no_grad()
-    def render_rays(self, origins, directions, directions_norm):
-        """rgb / depth / accumulation of a ray bundle with the inference weights.  Every sample the march finds is shaded
-        (no early termination), so a bundle may hold more samples than the packed capacity: the march's total is read
-        back (one synchronisation per call) and an overflowing bundle is rendered as two halves -- no ray is dropped."""
+    def render_rays(self, origins, directions, directions_norm, min_transmittance=None):
+        """rgb / depth / accumulation of a ray bundle with the inference weights.
+
+        ``min_transmittance`` (default NgpConfig.render_min_transmittance) > 0: two rounds -- the first
+        ``render_first_round`` samples of every ray are shaded and composited, then only the rays whose transmittance is
+        still above the threshold (and that have not left the scene box) take up their march where it stopped; the rounds of
+        a ray are exactly the samples one uninterrupted march finds.  0: one pass over every sample.
+        A round may hold more samples than the packed capacity: the march's total is read back (one synchronisation per
+        round) and an overflowing round is rendered over halves of the rays -- no ray is dropped."""
+        cfg = self.cfg
         R = origins.shape[0]
         ws = self._workspace(R, False)
         ws["origins"].copy_(origins)
         ws["directions"].copy_(directions)
         ws["directions_norm"].copy_(directions_norm.reshape(-1))
         stream = _stream(self.device)
-        self._march(ws, None, stream)
+        min_t = float(cfg.render_min_transmittance if min_transmittance is None else min_transmittance)
+        first = int(cfg.render_first_round) if min_t > 0.0 else 1024
+        self._march(ws, None, stream, None, first, ws["t_next"] if min_t > 0.0 else None)
         found = int(ws["offsets"][-1].item())
         self.last_render_samples = found  # (callers size their next bundle from it: pyngp.Testbed.render)
         if R > 1 and found > ws["cap"]:
             h = R // 2
             dn = directions_norm.reshape(-1)
-            a = self.render_rays(origins[:h].contiguous(), directions[:h].contiguous(), dn[:h].contiguous())
-            b = self.render_rays(origins[h:].contiguous(), directions[h:].contiguous(), dn[h:].contiguous())
+            a = self.render_rays(origins[:h].contiguous(), directions[:h].contiguous(), dn[:h].contiguous(), min_t)
+            b = self.render_rays(origins[h:].contiguous(), directions[h:].contiguous(), dn[h:].contiguous(), min_t)
             self.last_render_samples = found
             return {k: torch.cat([a[k], b[k]]) for k in a}
+        self._shade_and_composite(ws, found, stream, None, ws["carry"] if min_t > 0.0 else None, False)
+        if min_t > 0.0:
+            # the rays that go on: not yet opaque, still inside the scene box
+            alive = (ws["t_next"] >= 0.0) & (ws["carry"] < -math.log(min_t))
+            resume = torch.where(alive, ws["t_next"], torch.full_like(ws["t_next"], -1.0))
+            if bool(alive.any().item()):
+                self.last_render_samples = max(found, self._render_second_round(ws, resume, 0, R, stream))
+        return {"rgb": ws["out_rgb"].clamp(0, 1), "depth": ws["out_depth"].clone()[:, None],
+                "accumulation": ws["out_accumulation"].clone()[:, None]}
+
+    def _shade_and_composite(self, ws, found: int, stream, carry_in, carry_out, accumulate: bool) -> None:
         # the packed samples sit at the front of the workspace: the shading launches cover them, not the whole capacity
         ws["n_launch"] = min(ws["cap"], max(4096, (found + 4095) // 4096 * 4096))
+        self.render_shaded_total += found  # (running count of the samples inference has shaded: diagnostics, tests)
         try:
             self._shade(ws, False, stream)
-            la = self._loss_args(ws, False, False, None)
+            la = self._loss_args(ws, False, False, None, carry_in, carry_out, accumulate)
             _call("nvo_ngp_composite_loss", stream, C.byref(la))
         finally:
             del ws["n_launch"]
-        return {"rgb": ws["out_rgb"].clamp(0, 1), "depth": ws["out_depth"].clone()[:, None],
-                "accumulation": ws["out_accumulation"].clone()[:, None]}
+
+    def _render_second_round(self, ws, resume, lo: int, hi: int, stream) -> int:
+        """The rest of the march for the alive rays lo .. hi - 1 of the bundle (the others sit the launch out), added to the
+        first round's outputs; halves of the range when the samples do not fit.  Returns the largest sample count a launch
+        of this round held."""
+        tr = ws["t_resume"]
+        tr.fill_(-1.0)
+        tr[lo:hi] = resume[lo:hi]
+        self._march(ws, None, stream, tr, 1024, None)
+        found = int(ws["offsets"][-1].item())
+        if found > ws["cap"] and hi - lo > 1:
+            mid = (lo + hi) // 2
+            return max(self._render_second_round(ws, resume, lo, mid, stream),
+                       self._render_second_round(ws, resume, mid, hi, stream))
+        if found > 0:
+            self._shade_and_composite(ws, found, stream, ws["carry"], None, True)
+        return found

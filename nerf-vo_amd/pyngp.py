@@ -362,8 +362,9 @@ class Testbed:
         if adaptive:  # first bundle: sized from the samples per ray the training batches find
             per_ray = max(16.0, eng.cfg.capacity / max(1, eng.rays_per_batch))
             rays_per_chunk = max(256, min(1 << 15, int(0.8 * cap / per_ray) // 256 * 256))
+        min_t = float(self.nerf.render_min_transmittance)  # (upstream default 0.01; the reference sets 1e-4)
         key = (self._camera.tobytes(), float(self.fov), int(self.fov_axis), int(width), int(height), int(rays_per_chunk),
-               id(eng), eng.params_version)
+               id(eng), eng.params_version, min_t)
         if self._render_cache is None or self._render_cache[0] != key:
             focal = 0.5 * (width if self.fov_axis == 0 else height) / math.tan(0.5 * math.radians(self.fov))
             c2w = torch.tensor(self._camera[_FROM_NGP_ROWS], dtype=torch.float32).unsqueeze(0)
@@ -380,7 +381,7 @@ class Testbed:
             while lo < n:
                 hi = min(n, lo + rays_per_chunk)
                 nn = dn[lo:hi]
-                out = eng.render_rays(o[lo:hi].contiguous(), d[lo:hi].contiguous(), nn.contiguous())
+                out = eng.render_rays(o[lo:hi].contiguous(), d[lo:hi].contiguous(), nn.contiguous(), min_t)
                 rgba[lo:hi, :3] = out["rgb"]
                 rgba[lo:hi, 3:] = out["accumulation"]
                 z[lo:hi] = out["depth"][:, 0] / nn  # distance along the ray -> z-depth

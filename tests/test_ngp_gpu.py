@@ -529,3 +529,45 @@ def test_render_splits_bundles_that_overflow_the_capacity(device):
         assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
     assert float(b["accumulation"].min()) > 0.0
     assert small._workspace(64, True) is ws_train and small._wss[False] is not None
+
+
+def test_render_in_rounds_matches_the_single_pass(device):
+    """NgpEngine.render_rays with a transmittance threshold (two rounds, nvo_occ_march_resume + the compositing kernel's
+    carried optical depth): with a threshold nothing can reach (1e-30) every ray goes through both rounds and the result
+    must equal the single pass up to the order of the float sums; with the reference's 1e-4 the images differ by less than
+    the light the cut-off tail could still have contributed, and far fewer samples are shaded."""
+    eng = _engine(device, render_capacity=1 << 18)
+    rng = np.random.default_rng(3)
+    grid = (rng.random((eng.cfg.n_levels, 128 ** 3), dtype=np.float32) ** 4) * 0.3
+    eng.density_grid.copy_(torch.from_numpy(grid.reshape(-1)).to(device))
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+    _call("nvo_occ_update", _stream(device), eng.cfg.n_levels, _ptr(eng.density_grid), None, 0.95, 0.01,
+          _ptr(eng.bitfield), _ptr(eng._scratch8))
+    g = torch.Generator().manual_seed(5)
+    R = 700
+    origins = ((torch.rand(R, 3, generator=g) - 0.5) * 0.6 + 0.5).to(device)
+    directions = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    dnorm = torch.ones(R, device=device)
+    # much denser than the random initialisation (both layers of the density MLP x 16: pre-activations of +-70, i.e.
+    # densities up to 1e30 -- the compositing caps a sample's optical depth, so weights still sum to at most 1), so that
+    # rays do become opaque on their way
+    flat = eng.params.clone()
+    flat[:eng.n_density_mlp] *= 16.0
+    eng.set_params(flat.cpu())
+    s0 = eng.render_shaded_total
+    single = eng.render_rays(origins, directions, dnorm, 0.0)
+    n_single = eng.render_shaded_total - s0
+    rounds = eng.render_rays(origins, directions, dnorm, 1e-30)
+    # (in two rounds; only rays already blacker than 1e-30 -- a capped sample of optical depth 128 does that -- stop early)
+    assert n_single < eng.render_shaded_total - s0 <= 2 * n_single
+    for k in ("rgb", "depth", "accumulation"):
+        assert torch.allclose(rounds[k], single[k], rtol=1e-4, atol=2e-5), k
+    s1 = eng.render_shaded_total
+    cut = eng.render_rays(origins, directions, dnorm, 1e-4)
+    n_cut = eng.render_shaded_total - s1
+    assert float((cut["rgb"] - single["rgb"]).abs().max()) < 2e-3
+    assert float((cut["accumulation"] - single["accumulation"]).abs().max()) < 2e-3
+    assert float(single["accumulation"].max()) <= 1.0 + 1e-4   # (2.7 before the cap; __expf rounding is what is left)
+    opaque = float((single["accumulation"] > 0.999).float().mean())
+    assert opaque > 0.2 and n_cut < 0.8 * n_single, (opaque, n_cut, n_single)

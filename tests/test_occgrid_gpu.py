@@ -258,3 +258,52 @@ def test_mark_untrained_cells_matches_the_oracle(device, margin):
     g6b = g6.clone()
     assert lib.nvo_occ_mark_untrained(_stream(), n_levels, _p(g6b), F, _p(K), _p(c2w), H, W, margin) == 0
     assert torch.equal(g6b, g6)
+
+
+@pytest.mark.parametrize("first", [1, 37, 64, 200])
+def test_march_in_rounds_concatenates_to_the_single_march(device, first):
+    """nvo_occ_march_resume: a ray marched in rounds (at most `first` samples, then the rest from the candidate t_next handed
+    out) yields exactly the (t, dt) sequence of one uninterrupted march -- bit for bit; rays that left the box or whose
+    resume value is negative produce nothing."""
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    n_levels, cone, R, cap = 3, 1.0 / 256.0, 384, 1 << 19
+    grid = _scene_grid(n_levels, 1)
+    bf = torch.from_numpy(O.grid_to_bitfield(grid, n_levels)).to(device)
+    rng = np.random.default_rng(21)
+    o = torch.from_numpy(((rng.random((R, 3), dtype=np.float32) - 0.5) * 0.8 + 0.5)).to(device)
+    d = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((R, 3)).astype(np.float32)), dim=-1).to(device)
+    jit = torch.from_numpy(rng.random(R, dtype=np.float32)).to(device)
+    scratch = torch.empty(int(lib.nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=device)
+
+    def march(t_resume, max_new, want_next):
+        counts = torch.zeros(R, dtype=torch.int32, device=device)
+        offsets = torch.zeros(R + 1, dtype=torch.int32, device=device)
+        ray_idx = torch.full((cap,), -1, dtype=torch.int32, device=device)
+        t = torch.zeros(cap, device=device)
+        dt = torch.zeros(cap, device=device)
+        nxt = torch.full((R,), 7.0, device=device) if want_next else None
+        rc = lib.nvo_occ_march_resume(_stream(), R, _p(o), _p(d), _p(bf), n_levels, cone, 0.1, _p(jit), cap, _p(counts),
+                                      _p(offsets), _p(ray_idx), _p(t), _p(dt), _p(scratch), scratch.numel(), _p(t_resume),
+                                      max_new, _p(nxt))
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        c, off = counts.cpu().numpy(), offsets.cpu().numpy()
+        tt, dd = t.cpu().numpy(), dt.cpu().numpy()
+        return c, [np.stack([tt[off[r]:off[r] + c[r]], dd[off[r]:off[r] + c[r]]]) for r in range(R)], \
+            (nxt.cpu().numpy() if want_next else None)
+
+    c_all, runs_all, _ = march(None, 1024, False)
+    assert c_all.sum() > 20000 and c_all.max() > first
+    c1, runs1, nxt = march(None, first, True)
+    assert (c1 == np.minimum(c_all, first)).all()
+    assert ((nxt >= 0) | (c_all <= first)).all()          # a ray with samples left hands out where it goes on
+    resume = torch.from_numpy(nxt).to(device)
+    c2, runs2, nxt2 = march(resume, 1024, True)
+    assert (c1 + c2 == c_all).all() and (nxt2 < 0).all()
+    for r in range(R):
+        both = np.concatenate([runs1[r], runs2[r]], axis=1)
+        assert (both.view(np.uint32) == runs_all[r].view(np.uint32)).all(), r
+    assert (c2[nxt < 0] == 0).all()
