@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--render-frames", type=int, default=0, help="1200x680 views rendered through Testbed.render after training")
+    ap.add_argument("--first-round", type=int, default=0, help="samples per ray of the first inference round (0: NgpConfig.render_first_round)")
     a = ap.parse_args()
     run(a)
 
@@ -99,6 +100,8 @@ def run(a, quiet: bool = False):
     if getattr(a, "render_frames", 0) > 0:
         import math
 
+        if getattr(a, "first_round", 0):
+            eng.cfg.render_first_round = int(a.first_round)
         fx = float(seq["camera_intrinsics"][0, 0]) * 1200.0 / W
         tb.fov_axis, tb.fov, tb.exposure = 0, 2.0 * math.degrees(math.atan(0.5 * 1200.0 / fx)), 0.0
         times = []
