@@ -593,6 +593,10 @@ typedef struct nvo_ngp_loss_args {
     const float* carry_in;       /* [R] */
     float* carry_out;            /* [R] */
     uint32_t accumulate_outputs;
+    /* training: samples a ray reaches with a transmittance below this get EXACTLY zero gradients (0 = off) -- upstream's
+     * loss kernel stops a ray there and trains on the samples in front (`if (T < EPSILON) break`, EPSILON = 1e-4); the
+     * zero rows then cost the fused-MLP and hash-grid backwards nothing (they skip zero-gradient samples) */
+    float train_min_transmittance;
 } nvo_ngp_loss_args;
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);

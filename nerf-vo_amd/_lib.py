@@ -108,7 +108,8 @@ class NgpLossArgs(C.Structure):
                 ("background", _p), ("gt_rgb", _p), ("gt_depth", _p), ("directions_norm", _p), ("rgb_mult", _f),
                 ("depth_mult", _f), ("inv_rays", _f), ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p),
                 ("out_accumulation", _p), ("losses", _p), ("d_rgb_out", _p), ("d_rgb_stride", _u32),
-                ("d_density_pre", _p), ("carry_in", _p), ("carry_out", _p), ("accumulate_outputs", _u32)]
+                ("d_density_pre", _p), ("carry_in", _p), ("carry_out", _p), ("accumulate_outputs", _u32),
+                ("train_min_transmittance", _f)]
 
 
 _SIGNATURES = {

@@ -228,12 +228,15 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
         if (j < n) {
             const size_t s = base + j;
             const float suffix = total_q - incl_q;
+            // a sample the ray reaches with less than train_min_transmittance left trains nothing (upstream stops the ray
+            // there): exact zeros, which the backwards behind this kernel skip
+            const bool dead = T < a.train_min_transmittance;
             const float dsigma = a.dt[s] * (T * __expf(-dd) * dot - suffix - g_bg);
             // density = exp(x): dsigma/dx = sigma (clamped like tcnn's Exponential activation backward)
-            a.d_density_pre[s] = dsigma * fminf(sigma, 3.2690173e6f) * a.loss_scale;
+            a.d_density_pre[s] = dead ? 0.f : dsigma * fminf(sigma, 3.2690173e6f) * a.loss_scale;
 #pragma unroll
             for (int k = 0; k < 3; ++k)  // rgb = sigmoid(y): drgb/dy = rgb (1 - rgb)
-                d_rgb[s * a.d_rgb_stride + k] = (_Float16)(w * g_pix[k] * rgb[k] * (1.f - rgb[k]) * a.loss_scale);
+                d_rgb[s * a.d_rgb_stride + k] = dead ? (_Float16)0.f : (_Float16)(w * g_pix[k] * rgb[k] * (1.f - rgb[k]) * a.loss_scale);
             for (uint32_t k = 3; k < a.d_rgb_stride; ++k) d_rgb[s * a.d_rgb_stride + k] = (_Float16)0.f;
         }
         carry = nvo_wave_bcast(incl, 63);

@@ -45,6 +45,10 @@ class NgpConfig:
     # every ray, then only the rays still alive take up their march where it stopped (nvo_occ_march_resume).  0 = one pass
     # over every sample up to the scene box.
     render_min_transmittance: float = 1e-4
+    # training: samples behind the point where a ray's transmittance falls below this get exactly zero gradients (upstream
+    # stops the ray there, EPSILON = 1e-4 in compute_loss_kernel_train_nerf, and trains on the samples in front); the
+    # backwards skip zero-gradient samples, so late in training most of a batch costs the backward nothing.  0 = off.
+    train_min_transmittance: float = 1e-4
     render_first_round: int = 48
     aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
     cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
@@ -489,7 +493,8 @@ class NgpEngine:
             d_rgb_out=ws["d_rgb_out"].data_ptr() if training else None, d_rgb_stride=16,
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
             carry_in=None if carry_in is None else carry_in.data_ptr(),
-            carry_out=None if carry_out is None else carry_out.data_ptr(), accumulate_outputs=int(bool(accumulate)))
+            carry_out=None if carry_out is None else carry_out.data_ptr(), accumulate_outputs=int(bool(accumulate)),
+            train_min_transmittance=float(cfg.train_min_transmittance) if training else 0.0)
 
     def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False,
                          fused_adam=None) -> None:
@@ -804,7 +809,7 @@ class NgpEngine:
                # every by-value scalar of the step's launches
                (cfg.loss_scale, cfg.lr, cfg.rgb_loss_mult, cfg.depth_loss_mult, cfg.l2_reg, cfg.extrinsic_l2_reg, cfg.ema_decay,
                 cfg.cone_angle, cfg.near_distance, tuple(cfg.adam_betas), cfg.adam_eps, bool(cfg.random_background),
-                int(cfg.dw_replicas), self.world_size, cfg.extrinsic_lr),
+                int(cfg.dw_replicas), self.world_size, cfg.extrinsic_lr, cfg.train_min_transmittance),
                0 if self.params_ema is None else self.params_ema.data_ptr())
         entry = self._graphs.get(key)
         if entry is None:

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--render-frames", type=int, default=0, help="1200x680 views rendered through Testbed.render after training")
+    ap.add_argument("--train-min-t", type=float, default=None, help="NgpConfig.train_min_transmittance (default 1e-4; 0 = every sample trains)")
     ap.add_argument("--first-round", type=int, default=0, help="samples per ray of the first inference round (0: NgpConfig.render_first_round)")
     a = ap.parse_args()
     run(a)
@@ -52,6 +53,9 @@ def run(a, quiet: bool = False):
         frame_ids=list(range(a.keyframes)), poses=opencv_to_opengl(poses)[:, :3], images=color.contiguous(),
         depths=depth.contiguous(), depths_cov=torch.ones_like(depth), resolution=np.array([W, H]),
         principal_point=seq["camera_intrinsics"][0, 2:].cpu().numpy(), focal_length=seq["camera_intrinsics"][0, :2].cpu().numpy())
+    if getattr(a, "train_min_t", None) is not None:
+        tb.frame()
+        tb._engine.cfg.train_min_transmittance = float(a.train_min_t)
     for _ in range(a.warmup):
         tb.frame()
     torch.cuda.synchronize()
