@@ -193,7 +193,6 @@ class NgpEngine:
         self._ema_step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._ema_started = False
         self.rays_per_batch = int(cfg.num_rays)
-        self._measured = []  # device scalars: marched samples of the steps since the last adaptation
         self.losses = torch.zeros(64, 8, dtype=torch.float32, device=dev)
         self.skip_flag = z(1, torch.int32)
         self.density_grid = z(cfg.n_levels * CELLS)
@@ -201,8 +200,8 @@ class NgpEngine:
         self._scratch8 = z(8, torch.uint8)
         self.step = 0
         self.opt_step = 0
-        # device side of the optimiser's step count: [0] = extrinsic learning rate, [1..2] = {1 - beta1^t, sqrt(1 - beta2^t)}
-        # of the NEXT applied step (nvo_adam_step's hyper_dev layout; [1..2] alone = nvo_adam_group::bias_dev), advanced by
+        # device side of the optimiser's step count: [0] = learning rate (unused: by value), [1..2] = {1 - beta1^t,
+        # sqrt(1 - beta2^t)} of the NEXT applied step (nvo_adam_step's hyper_dev layout; [1..2] alone = nvo_adam_group::bias_dev), advanced by
         # nvo_opt_commit behind the optimiser launches iff the step was not skipped -- nothing of a step depends on a host
         # scalar, so a captured step can be replayed
         self._opt_dev = z(4)
@@ -509,9 +508,9 @@ class NgpEngine:
         if leaf_flags != self._leaf_flags:
             self.density_net.set_option("nonfinite_flag_ptr", self.skip_flag.data_ptr() if leaf_flags else 0)
             self._leaf_flags = leaf_flags
-        # everything the step accumulates into, cleared by ONE launch (they were six fills): the gradient outside the
-        # range the grid backward steps itself (nothing accumulates there), the loss slots, the overflow flag, the pose
-        # gradients
+        # everything the step accumulates into, cleared by ONE launch (they were six fills + two inside nvo_bwd): the
+        # gradient outside the range the grid backward steps itself (nothing accumulates there), the loss slots, the
+        # overflow flag, what the density network's backward used to clear itself
         g0 = self.grads.data_ptr()
         spans = [(g0, 4 * self.n_params)] if fused_adam is None else \
             [(g0, 4 * fused_adam[0]), (g0 + 4 * fused_adam[1], 4 * (self.n_params - fused_adam[1]))]
@@ -673,7 +672,8 @@ class NgpEngine:
             return
         b1, b2 = self.cfg.adam_betas
         t = float(self.opt_step + 1)
-        self._opt_dev.copy_(torch.tensor([self.cfg.extrinsic_lr, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0],
+        # ([0] is unused here: the camera optimiser keeps its own scalars, self._cam_dev)
+        self._opt_dev.copy_(torch.tensor([self.cfg.lr, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0],
                                          dtype=torch.float64).float())
         self._applied_dev.fill_(int(self.opt_step))
         self._dev_synced = self.opt_step
