@@ -105,20 +105,26 @@ class SyntheticEvaluationDataset:
     (every frame that is not a keyframe stride), and ``frames_color`` / ``frames_depth`` per mode."""
 
     def __init__(self, num_frames: int = 96, height: int = 120, width: int = 160, evaluation_stride: int = 5,
-                 depth_scale: float = 6553.5, device="cpu"):
+                 depth_scale: float = 6553.5, device="cpu", scene_scale: float = 1.0):
         self.device = torch.device(device)  # where the ground-truth frames are ray-cast (values are the same)
         fx, fy, cx, cy = replica_intrinsics(height, width)
         self.camera_intrinsics = {"fx": fx, "fy": fy, "cx": cx, "cy": cy, "height": height, "width": width,
                                   "depth_scale": depth_scale}
         self.num_frames = num_frames
-        self.camera_extrinsics = orbit_poses_opencv(num_frames).double().numpy()
+        # scene_scale shrinks room and orbit together (the occupancy-grid back-end takes poses as they come: the room has
+        # to lie inside its scene box [-1.5, 2.5]^3)
+        self.scene_scale = float(scene_scale)
+        poses = orbit_poses_opencv(num_frames)
+        poses[:, :3, 3] *= self.scene_scale
+        self.camera_extrinsics = poses.double().numpy()
         self.evaluation_frames = list(range(2, num_frames, evaluation_stride))
 
     def render(self, pose_cv) -> tuple:
         """(uint8 [H,W,3] colour, float [H,W] z-depth) of the room from a standard-convention c2w pose."""
         ci = self.camera_intrinsics
         pose = torch.as_tensor(pose_cv, dtype=torch.float32)[None].to(self.device)
-        color, depth, _ = render_room(pose, ci["height"], ci["width"], (ci["fx"], ci["fy"], ci["cx"], ci["cy"]))
+        color, depth, _ = render_room(pose, ci["height"], ci["width"], (ci["fx"], ci["fy"], ci["cx"], ci["cy"]),
+                                      half_extent=2.0 * self.scene_scale)
         return ((color[0].permute(1, 2, 0).cpu().numpy() * 255).astype("uint8"), depth[0, 0].double().cpu().numpy())
 
     def _indices(self, mode: str, keyframes) -> list:

@@ -74,7 +74,10 @@ def _log(mapper):
 
 def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, eval_frames=8, chunk=8, device="cuda:0",
         camera_optimizer_mode=None, pose_noise=None, deterministic=False, seed=42, dynamic_loss_scale=None, out_dir=None,
-        quiet=True, keyframe_views=True):
+        quiet=True, keyframe_views=True, method="nerfstudio", scene_scale=None):
+    """``method``: 'nerfstudio' (the default mapper) or 'instant-ngp' (the occupancy-grid back-end through the pyngp facade,
+    /root/reference/nerf_vo/mapping/instant_ngp.py + evaluation/nerf_renderer.py:221-320; the room is shrunk by
+    ``scene_scale``, default 0.5, so that it lies inside that back-end's scene box: it takes poses as they come)."""
     entry.build()
     from nerf_vo_amd.evaluation import (EvaluationRenderer, Evaluator2D, read_color, transform_matrices_pred2gt)
     from nerf_vo_amd.mapping.dataset import opencv_to_opengl
@@ -86,7 +89,13 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
     dev = torch.device(device)
     out_dir = out_dir or tempfile.mkdtemp(prefix="nvo_eval_")
     n_frames = keyframes * frame_stride  # dataset frames; every frame_stride-th one is a keyframe (configs: frame_stride 2)
-    ds = SyntheticEvaluationDataset(num_frames=n_frames, height=height, width=width, device=dev)
+    ngp = method == "instant-ngp"
+    if ngp and abs(width / height - 1200.0 / 680.0) > 0.01:
+        # (the testbed's free camera has ONE focal length, evaluation/nerf_renderer.py:152: Replica's intrinsics have square
+        # pixels only at its own aspect -- 160 x 120 renders with fx != fy come out at 13 dB)
+        raise SystemExit("--method instant-ngp needs Replica's aspect ratio (e.g. --width 240 --height 136)")
+    ds = SyntheticEvaluationDataset(num_frames=n_frames, height=height, width=width, device=dev,
+                                    scene_scale=float(scene_scale) if scene_scale else (0.5 if ngp else 1.0))
     kf = list(range(0, n_frames, frame_stride))
     held_out = [i for i in range(n_frames) if i % frame_stride != 0]
     ds.evaluation_frames = [held_out[int(j * len(held_out) / eval_frames)] for j in range(eval_frames)]
@@ -94,7 +103,11 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
                               mapping_iterations=iterations, num_keyframes=keyframes, frame_height=height, frame_width=width,
                               enhancement_module="depth", deterministic=deterministic, dynamic_loss_scale=dynamic_loss_scale,
                               camera_optimizer_mode=camera_optimizer_mode)
-    mapper = Nerfstudio(args, device=dev)
+    if ngp:
+        from nerf_vo_amd.mapping.instant_ngp_mapper import InstantNGP, InstantNGPRenderer
+        mapper = InstantNGP(args, device=dev)
+    else:
+        mapper = Nerfstudio(args, device=dev)
     ci = ds.camera_intrinsics
     intr = torch.tensor([ci["fx"], ci["fy"], ci["cx"], ci["cy"]])
     poses = torch.from_numpy(ds.camera_extrinsics[kf]).float()
@@ -111,8 +124,9 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
         frames = [ds.render(ds.camera_extrinsics[i]) for i in kf[lo:hi]]
         color = torch.stack([torch.from_numpy(c) for c, _ in frames]).permute(0, 3, 1, 2).float() / 255.0
         depth = torch.stack([torch.from_numpy(d) for _, d in frames])[:, None].float().clamp(0.0, 5.0)
+        gl = opencv_to_opengl(poses[lo:hi].to(dev))
         mapper(input={"keyframe_indices": torch.arange(lo, hi), "camera_intrinsics": intr.repeat(hi - lo, 1).to(dev),
-                      "camera_extrinsics": opencv_to_opengl(poses[lo:hi].to(dev)), "frames_color": color.to(dev),
+                      "camera_extrinsics": gl, "frames_color": color.to(dev),
                       "frames_depth": depth.to(dev), "last_frame": hi == keyframes})
         for _ in range(per_kf * (hi - lo) - 1):
             if mapper.step < iterations:
@@ -126,7 +140,7 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
     mapper(input=None)
     assert mapper.is_shut_down
 
-    nerf = NerfstudioRenderer(mapping_model=mapper)
+    nerf = InstantNGPRenderer(mapping_model=mapper) if ngp else NerfstudioRenderer(mapping_model=mapper)
     renderer = EvaluationRenderer(dataset=ds, nerf=nerf, keyframes=kf, dir_prediction=args.dir_prediction)
     renderer.render_frames(mode="evaluation_frames")
     exported = renderer.export_keyframe_poses()
@@ -149,16 +163,20 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
     # the same for the poses as INGESTED (no camera-optimiser correction): what the optimiser had to improve on
     ing = poses.double().numpy()
     ing = np.asarray(gt_kf[0])[None] @ np.linalg.inv(ing[0])[None] @ ing  # frame-0 anchored, as the protocol does
-    eng = mapper.trainer.pipeline.model.engine
-    res = {"keyframes": keyframes, "resolution": [width, height], "iterations": iterations, "train_seconds": train_s,
+    eng = mapper.ngp._engine if ngp else mapper.trainer.pipeline.model.engine
+    res = {"method": method, "scene_scale": ds.scene_scale, "keyframes": keyframes, "resolution": [width, height], "iterations": iterations, "train_seconds": train_s,
            "camera_optimizer_mode": camera_optimizer_mode or "SE3", "pose_noise": list(pose_noise) if pose_noise else None,
            "scale_pred2gt": float(t["scale_pred2gt"]),
            "evaluation_frames": {**{k: float(v) for k, v in m_eval.items()}, "psnr_float_mse": psnr_float, "frames": len(files)},
            "keyframe_views": {k: float(v) for k, v in m_kf.items()},
            "pose_error_after_frame0_alignment": pose_err, "pose_error_of_ingested_poses": _pose_errors(ing, gt_kf),
-           "pose_adjustment_rms": float(eng.view("camera_opt.pose_adjustment").pow(2).mean().sqrt()),
-           "deterministic": bool(deterministic), "dynamic_loss_scale": bool(eng.cfg.dynamic_loss_scale),
-           "loss_scale_end": eng.current_loss_scale(), "seed": seed, "exported_poses": int(exported.shape[0])}
+           "pose_adjustment_rms": float((eng.pose_adjustment if ngp else eng.view("camera_opt.pose_adjustment")).pow(2).mean().sqrt()),
+           "deterministic": bool(deterministic), "seed": seed, "exported_poses": int(exported.shape[0])}
+    if ngp:
+        res.update({"camera_optimizer_mode": "instant-ngp extrinsics", "ms_per_step_incl_ingest": 1e3 * train_s / iterations,
+                    "rays_per_batch": eng.rays_per_batch, "applied_steps": eng.applied_steps})
+    else:
+        res.update({"dynamic_loss_scale": bool(eng.cfg.dynamic_loss_scale), "loss_scale_end": eng.current_loss_scale()})
     if not quiet:
         print(json.dumps(res))
     return res
@@ -177,7 +195,10 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--static-loss-scale", action="store_true", help="tcnn's static 128 instead of GradScaler's dynamics")
     ap.add_argument("--no-keyframe-views", action="store_true")
+    ap.add_argument("--method", default="nerfstudio", choices=["nerfstudio", "instant-ngp"])
+    ap.add_argument("--scene-scale", type=float, default=None)
     a = ap.parse_args()
     run(a.keyframes, a.height, a.width, a.iterations, eval_frames=a.eval_frames, camera_optimizer_mode=a.camera_optimizer_mode,
         pose_noise=a.pose_noise, deterministic=a.deterministic, seed=a.seed, quiet=False,
-        dynamic_loss_scale=False if a.static_loss_scale else None, keyframe_views=not a.no_keyframe_views)
+        dynamic_loss_scale=False if a.static_loss_scale else None, keyframe_views=not a.no_keyframe_views,
+        method=a.method, scene_scale=a.scene_scale)
