@@ -317,11 +317,13 @@ typedef struct nvo_ray_head_args {
 } nvo_ray_head_args;
 int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args);
 /* nvo_raygen + nvo_gather_pixels (colour, depth) + nvo_dirs01 + nvo_sh_encode (degree 4, fp16) for GIVEN pixel indices
- * in one launch (the occupancy-grid back-end: pyngp.Testbed.frame() draws its pixels itself); same values. */
+ * in one launch (the occupancy-grid back-end: pyngp.Testbed.frame() draws its pixels itself); same values.
+ * depths_cov [F][H][W] (nullable) -> gt_depth_cov [R]: the per-pixel depth variance update_training_images received
+ * (/root/reference/nerf_vo/mapping/instant_ngp.py:77-86,93-94), gathered like the depth. */
 int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
                    const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
                    float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
-                   float* gt_depth, float* dirs01, void* sh_half);
+                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov);
 /* the same launch with extra workgroups that clear up to 24 device ranges (as nvo_zero_ranges): the first launch of a
  * one-graph training step does both */
 int nvo_ray_head_zero(nvo_stream_t stream, const nvo_ray_head_args* args, uint32_t n_ranges, void* const* ptrs,
@@ -597,6 +599,12 @@ typedef struct nvo_ngp_loss_args {
      * loss kernel stops a ray there and trains on the samples in front (`if (T < EPSILON) break`, EPSILON = 1e-4); the
      * zero rows then cost the fused-MLP and hash-grid backwards nothing (they skip zero-gradient samples) */
     float train_min_transmittance;
+    /* [R] or NULL: variance of the ray's depth target (NeRF-SLAM's covariance-weighted depth term, spec by paper
+     * [UPSTREAM]: L_D = ||D - D*||^2_Sigma = (D - D*)^2 / Sigma_D per pixel).  The depth residual of ray r is weighted by
+     * 1 / gt_depth_cov[r]; a variance that is not a positive finite number switches the ray's depth term off.  NULL or
+     * all ones: the plain L2 term, bit for bit.  The reference supplies it on every instant-ngp configuration
+     * (/root/reference/nerf_vo/enhancement/enhancement_module.py:105-111, configs/nerf_slam_*.yaml: compute_covariances) */
+    const float* gt_depth_cov;
 } nvo_ngp_loss_args;
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);

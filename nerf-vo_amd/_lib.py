@@ -109,7 +109,7 @@ class NgpLossArgs(C.Structure):
                 ("depth_mult", _f), ("inv_rays", _f), ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p),
                 ("out_accumulation", _p), ("losses", _p), ("d_rgb_out", _p), ("d_rgb_stride", _u32),
                 ("d_density_pre", _p), ("carry_in", _p), ("carry_out", _p), ("accumulate_outputs", _u32),
-                ("train_min_transmittance", _f)]
+                ("train_min_transmittance", _f), ("gt_depth_cov", _p)]
 
 
 _SIGNATURES = {
@@ -152,7 +152,7 @@ _SIGNATURES = {
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
     "nvo_sh_encode_t": (_int, [_p, _u32, _u32, _p, _p, _int]),
     "nvo_ray_head": (_int, [_p, C.POINTER(RayHeadArgs)]),
-    "nvo_rays_given": (_int, [_p, _u32, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_rays_given": (_int, [_p, _u32, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_ray_head_zero": (_int, [_p, C.POINTER(RayHeadArgs), _u32, _p, _p]),
     # group C
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),

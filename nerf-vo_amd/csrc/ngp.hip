@@ -162,10 +162,16 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     float g_depth = 0.f, l_depth = 0.f;
     if (a.gt_depth && a.depth_mult != 0.f) {
         const float z = a.gt_depth[r] * (a.directions_norm ? a.directions_norm[r] : 1.f);
+        // covariance-weighted residual (gt_depth_cov: variance of the target; 1 -> the plain L2 term, exactly)
+        float wgt = 1.f;
+        if (a.gt_depth_cov) {
+            const float var = a.gt_depth_cov[r];
+            wgt = (var > 0.f && var < __builtin_inff()) ? 1.f / var : 0.f;
+        }
         if (z > 0.f) {
             const float e = depth - z;
-            l_depth = e * e * a.inv_rays * a.depth_mult;
-            g_depth = 2.f * e * a.inv_rays * a.depth_mult;
+            l_depth = e * e * wgt * a.inv_rays * a.depth_mult;
+            g_depth = 2.f * e * wgt * a.inv_rays * a.depth_mult;
         }
     }
     if (lane == 0) {

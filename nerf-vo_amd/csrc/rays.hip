@@ -89,7 +89,8 @@ k_rays_given(uint32_t R, const int64_t* __restrict__ ray_indices, const float* _
              const float* __restrict__ images, const float* __restrict__ depths, float* __restrict__ origins,
              float* __restrict__ directions, float* __restrict__ directions_norm, float* __restrict__ pixel_area,
              int32_t* __restrict__ cam_idx, float* __restrict__ gt_rgb, float* __restrict__ gt_depth,
-             float* __restrict__ dirs01, nvo_h16* __restrict__ sh) {
+             float* __restrict__ dirs01, nvo_h16* __restrict__ sh, const float* __restrict__ depths_cov,
+             float* __restrict__ gt_depth_cov) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int64_t cam = ray_indices[3 * (size_t)r + 0], y = ray_indices[3 * (size_t)r + 1], x = ray_indices[3 * (size_t)r + 2];
@@ -110,6 +111,7 @@ k_rays_given(uint32_t R, const int64_t* __restrict__ ray_indices, const float* _
     if (pixel_area) pixel_area[r] = area;
     cam_idx[r] = (int32_t)cam;
     if (depths) gt_depth[r] = depths[pix];
+    if (depths_cov) gt_depth_cov[r] = depths_cov[pix];
     float c[16];
     nvo_sh4_eval(d01[0] * 2.f - 1.f, d01[1] * 2.f - 1.f, d01[2] * 2.f - 1.f, 4u, c);
 #pragma unroll
@@ -438,14 +440,15 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
 int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
                    const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
                    float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
-                   float* gt_depth, float* dirs01, void* sh_half) {
+                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov) {
     NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && images && origins && directions && directions_norm && cam_idx &&
-                           gt_rgb && dirs01 && sh_half && (!depths || gt_depth)), "rays_given: NULL argument");
+                           gt_rgb && dirs01 && sh_half && (!depths || gt_depth) && (!depths_cov || gt_depth_cov)),
+                "rays_given: NULL argument");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "rays_given");
     NVO_LAUNCH(k_rays_given, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices, intrinsics, c2w,
                corrections, H, W, images, depths, origins, directions, directions_norm, pixel_area, cam_idx, gt_rgb, gt_depth,
-               dirs01, (nvo_h16*)sh_half);
+               dirs01, (nvo_h16*)sh_half, depths_cov, gt_depth_cov);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

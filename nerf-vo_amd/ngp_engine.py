@@ -292,7 +292,7 @@ class NgpEngine:
         i32 = dict(dtype=torch.int32, device=dev)
         ws = {"key": key, "R": R_req, "R_cap": R, "training": training, "cap": cap}
         for name, shape in (("origins", (R, 3)), ("directions", (R, 3)), ("directions_norm", (R,)), ("pixel_area", (R,)),
-                            ("gt_rgb", (R, 3)), ("gt_depth", (R,)), ("dirs01", (R, 3)), ("out_rgb", (R, 3)),
+                            ("gt_rgb", (R, 3)), ("gt_depth", (R,)), ("gt_depth_cov", (R,)), ("dirs01", (R, 3)), ("out_rgb", (R, 3)),
                             ("out_depth", (R,)), ("out_accumulation", (R,)), ("t", (cap,)), ("dt", (cap,)),
                             ("x01", (cap, 3)), ("d_density_pre", (cap,))):
             ws[name] = torch.zeros(*shape, **f32)
@@ -328,7 +328,7 @@ class NgpEngine:
         self._ws = ws
         return self._ray_views(ws, R_req)
 
-    _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "dirs01", "out_rgb",
+    _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "gt_depth_cov", "dirs01", "out_rgb",
                 "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices",
                 "jitter", "background", "t_next", "t_resume", "carry")
 
@@ -401,7 +401,10 @@ class NgpEngine:
         self._marked_images = int(n_images)
 
     # ---- forward / backward ------------------------------------------------------------------
-    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths) -> None:
+    def load_rays(self, ws, ray_indices, intrinsics, c2w, images, depths, depths_cov=None) -> None:
+        """``depths_cov`` [F,H,W,1] (optional): per-pixel variance of the depth targets, what the reference hands to
+        update_training_images on every instant-ngp configuration (nerf_vo/mapping/instant_ngp.py:77-86,93-94); the
+        depth residual of a ray is weighted by its inverse (nvo_ngp_loss_args::gt_depth_cov)."""
         stream = _stream(self.device)
         R = ws["R"]
         H, W = images.shape[1], images.shape[2]
@@ -417,7 +420,9 @@ class NgpEngine:
         _call("nvo_rays_given", stream, R, _ptr(ray_indices), _ptr(intrinsics), _ptr(c2w), _ptr(corr), H, W, _ptr(images),
               _ptr(depths) if depths is not None else None, _ptr(ws["origins"]), _ptr(ws["directions"]),
               _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]), _ptr(ws["gt_rgb"]),
-              _ptr(ws["gt_depth"]), _ptr(ws["dirs01"]), _ptr(ws["sh"]))
+              _ptr(ws["gt_depth"]), _ptr(ws["dirs01"]), _ptr(ws["sh"]),
+              _ptr(depths_cov) if (depths is not None and depths_cov is not None) else None, _ptr(ws["gt_depth_cov"]))
+        ws["has_depth_cov"] = depths is not None and depths_cov is not None
         ws["sh_ready"] = True
 
     def _forward(self, ws, training: bool, jitter, stream) -> None:
@@ -493,7 +498,8 @@ class NgpEngine:
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
             carry_in=None if carry_in is None else carry_in.data_ptr(),
             carry_out=None if carry_out is None else carry_out.data_ptr(), accumulate_outputs=int(bool(accumulate)),
-            train_min_transmittance=float(cfg.train_min_transmittance) if training else 0.0)
+            train_min_transmittance=float(cfg.train_min_transmittance) if training else 0.0,
+            gt_depth_cov=ws["gt_depth_cov"].data_ptr() if (training and has_depth and ws.get("has_depth_cov")) else None)
 
     def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False,
                          fused_adam=None) -> None:
@@ -731,7 +737,7 @@ class NgpEngine:
         _call("nvo_opt_commit", stream, 1, 1, 0, _ptr(self._applied_dev), _ptr(self.skip_flag), None, None, 2.0, 0.5, 2000,
               0.0, 0.0, C.c_void_p(bias_dev), cfg.adam_betas[0], cfg.adam_betas[1])
 
-    def train_step(self, ray_indices, intrinsics, c2w, images, depths, all_reduce=None):
+    def train_step(self, ray_indices, intrinsics, c2w, images, depths, all_reduce=None, depths_cov=None):
         R = ray_indices.shape[0]
         ws = self._workspace(R, True)
         if self.step % self.cfg.density_update_every == 0:
@@ -745,11 +751,11 @@ class NgpEngine:
         if cam_update:
             self._sync_cam_dev()
         if self.cfg.graph_step and all_reduce is None:
-            self._train_step_graphed(ws, ray_indices, intrinsics, c2w, images, depths, cam_update)
+            self._train_step_graphed(ws, ray_indices, intrinsics, c2w, images, depths, cam_update, depths_cov)
         else:
             jitter = torch.rand(R, device=self.device)
             bg = torch.rand(R, 3, device=self.device) if self.cfg.random_background else None
-            self._step_body(ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce, cam_update)
+            self._step_body(ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce, cam_update, depths_cov)
         if pose:
             self._cam_window = 0 if cam_update else self._cam_window + 1
             if cam_update:
@@ -763,9 +769,9 @@ class NgpEngine:
             self._adapt_rays(ws, R)
 
     def _step_body(self, ws, ray_indices, intrinsics, c2w, images, depths, jitter, bg, all_reduce=None,
-                   camera_update: bool = True) -> None:
+                   camera_update: bool = True, depths_cov=None) -> None:
         """Every launch of one step, in order (eager, or recorded into a hipGraph by _train_step_graphed)."""
-        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths)
+        self.load_rays(ws, ray_indices, intrinsics, c2w, images, depths, depths_cov)
         fused = self._fused_adam_plan() if all_reduce is None else None
         self.forward_backward(ws, jitter, has_depth=depths is not None, background=bg, leaf_flags=all_reduce is None,
                               fused_adam=fused)
@@ -779,7 +785,8 @@ class NgpEngine:
 
     _MAX_GRAPHS = 48
 
-    def _train_step_graphed(self, ws, ray_indices, intrinsics, c2w, images, depths, cam_update: bool = True) -> None:
+    def _train_step_graphed(self, ws, ray_indices, intrinsics, c2w, images, depths, cam_update: bool = True,
+                            depths_cov=None) -> None:
         """The step as ONE hipGraph replay (NgpConfig.graph_step).  In front of it, eager: the caller's ray indices are
         copied and the march jitter is drawn into the workspace's fixed buffers (same generator calls as the eager step).
         Captured once per ray count (the adaptive batch moves it every `density_update_every` steps, usually between a
@@ -797,14 +804,16 @@ class NgpEngine:
             bg = ws["background"]
             bg.uniform_()
         if not self._kernels_loaded:
-            self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update)
+            self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update,
+                            depths_cov)
             self._kernels_loaded = True
             return
         if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
             self.params_ema = torch.zeros_like(self.params)
             self.params_ema_half = torch.zeros_like(self.params_half)
         key = (R, ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
-               None if depths is None else depths.data_ptr(), bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
+               None if depths is None else depths.data_ptr(), None if depths_cov is None else depths_cov.data_ptr(),
+               bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
                bool(cam_update), self._camera_grad_scale() if cam_update else 0.0, self._fused_adam_plan(),
                # every by-value scalar of the step's launches
                (cfg.loss_scale, cfg.lr, cfg.rgb_loss_mult, cfg.depth_loss_mult, cfg.l2_reg, cfg.extrinsic_l2_reg, cfg.ema_decay,
@@ -818,11 +827,12 @@ class NgpEngine:
             t0 = time.perf_counter()
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):  # (no cyclic garbage collection while the stream records)
-                self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update)
+                self._step_body(ws, ws["ray_indices"], intrinsics, c2w, images, depths, ws["jitter"], bg, None, cam_update,
+                                depths_cov)
             self.graph_captures += 1
             self.graph_capture_seconds += time.perf_counter() - t0
             # the graph addresses these buffers: they must stay alive as long as it does
-            entry = {"graph": g, "keep": (intrinsics, c2w, images, depths, ws), "pose_inputs": self._pose_inputs}
+            entry = {"graph": g, "keep": (intrinsics, c2w, images, depths, depths_cov, ws), "pose_inputs": self._pose_inputs}
             self._graphs[key] = entry
         entry["graph"].replay()
         self._pose_inputs = entry["pose_inputs"]

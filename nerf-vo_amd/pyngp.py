@@ -122,7 +122,11 @@ class _Training:
             raise RuntimeError(f"update_training_images: images are {tuple(rgba.shape[1:3])}, resolution says {(height, width)}")
         tb._images[idx] = rgba[..., :3]  # linear RGB; the alpha the reference appends is 1 everywhere
         tb._depths[idx] = _as_device_tensor(depths, dev).reshape(-1, height, width, 1) * float(depth_scale)
-        tb._depths_cov[idx] = _as_device_tensor(depths_cov, dev).reshape(-1, height, width, 1) * float(depth_cov_scale)
+        cov = _as_device_tensor(depths_cov, dev).reshape(-1, height, width, 1) * float(depth_cov_scale)
+        tb._depths_cov[idx] = cov
+        # (a dataset that only ever received ones -- the reference's fallback without DROID-SLAM's covariances,
+        # instant_ngp.py:80-85 -- trains on the plain L2 term without the extra gather)
+        tb._has_depths_cov = tb._has_depths_cov or bool((cov != 1.0).any().item())
         pose = _as_device_tensor(poses, dev)[:, :3, :4]
         pose = pose.clone()
         pose[:, :, 3] = pose[:, :, 3] * tb._nerf_scale + torch.as_tensor(tb._nerf_offset, dtype=torch.float32, device=dev)
@@ -230,6 +234,7 @@ class Testbed:
         self._images = torch.zeros(n, height, width, 3, **f32)
         self._depths = torch.zeros(n, height, width, 1, **f32)
         self._depths_cov = torch.ones(n, height, width, 1, **f32)
+        self._has_depths_cov = False
         self._poses = torch.eye(4, **f32)[:3].repeat(n, 1, 1)
         self._intrinsics = torch.zeros(n, 4, **f32)
 
@@ -251,7 +256,9 @@ class Testbed:
         u = torch.rand((eng.rays_per_batch if eng.cfg.adaptive_rays else eng.cfg.num_rays, 3), device=self.device,
                        generator=self._generator)
         # (image, row, column) = floor(u * (n, h, w)): the int64 conversion of the non-negative products truncates
-        eng.train_step(u.mul_(self._draw_scale[1]).long(), self._intrinsics, self._poses, self._images, self._depths)
+        # the per-pixel depth variance weights the depth term (all ones until update_training_images supplied one: plain L2)
+        eng.train_step(u.mul_(self._draw_scale[1]).long(), self._intrinsics, self._poses, self._images, self._depths,
+                       depths_cov=self._depths_cov if self._has_depths_cov else None)
         self.training_step = eng.step
         return True
 

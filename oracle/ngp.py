@@ -75,10 +75,21 @@ class NgpOracle:
             out_acc.append(w.sum())
         return torch.stack(out_rgb), torch.stack(out_depth), torch.stack(out_acc)
 
-    def loss_dict(self, rgb, depth, gt_rgb, gt_depth, directions_norm):
+    def loss_dict(self, rgb, depth, gt_rgb, gt_depth, directions_norm, gt_depth_cov=None):
+        """L2 rgb + depth term.  ``gt_depth_cov`` (per ray; what update_training_images received as ``depths_cov`` times
+        ``depth_cov_scale``, /root/reference/nerf_vo/mapping/instant_ngp.py:77-100): the VARIANCE of the depth target
+        (DROID-SLAM's marginal depth covariance, /root/reference/nerf_vo/tracking/droid_slam.py:716-725: z_cov / idepth^4).
+        Form chosen [UPSTREAM NeRF-SLAM fork of instant-ngp, not vendored -- spec by the paper's mapping loss
+        L_D = ||D - D*||^2_{Sigma_D}, the Mahalanobis norm]:
+            depth_loss = depth_mult * mean_r( [z_r > 0] * (D_r - z_r)^2 / Sigma_r ),
+        a variance that is not positive and finite drops the ray's depth term; Sigma = 1 is the plain L2 term."""
         d = {"rgb_loss": self.rgb_mult * torch.mean((rgb - gt_rgb) ** 2)}
         if gt_depth is not None:
             z = gt_depth * directions_norm
             mask = (z > 0).double()
+            if gt_depth_cov is not None:
+                var = gt_depth_cov.double()
+                ok = (var > 0) & torch.isfinite(var)
+                mask = mask * torch.where(ok, 1.0 / torch.where(ok, var, torch.ones_like(var)), torch.zeros_like(var))
             d["depth_loss"] = self.depth_mult * torch.mean(((depth - z) ** 2) * mask)
         return d

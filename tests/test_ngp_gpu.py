@@ -40,7 +40,11 @@ def _oracle(eng):
     return orc
 
 
-def test_ngp_step_matches_oracle(device):
+@pytest.mark.parametrize("cov", ["none", "ones", "varying"])
+def test_ngp_step_matches_oracle(device, cov):
+    """``cov``: the per-ray variance of the depth target (nvo_ngp_loss_args::gt_depth_cov) -- absent, all ones (must be
+    the absent case bit for bit) or spread over three decades with zeros, negatives and inf mixed in (rays whose depth
+    term is dropped)."""
     from oracle import occgrid as O
 
     eng = _engine(device)
@@ -71,8 +75,23 @@ def test_ngp_step_matches_oracle(device):
     ws["directions_norm"].copy_(dnorm)
     ws["gt_rgb"].copy_(gt_rgb)
     ws["gt_depth"].copy_(gt_depth)
+    gt_cov = None
+    if cov != "none":
+        gt_cov = torch.ones(R) if cov == "ones" else 10.0 ** (torch.rand(R, generator=g) * 3 - 1.5)
+        if cov == "varying":
+            gt_cov[3::11] = 0.0
+            gt_cov[4::13] = -1.0
+            gt_cov[6::17] = float("inf")
+        ws["gt_depth_cov"].copy_(gt_cov)
+        ws["has_depth_cov"] = True
     eng.forward_backward(ws, jitter.to(device), has_depth=True, background=bg.to(device))
     torch.cuda.synchronize()
+    if cov == "ones":  # the plain L2 term, bit for bit
+        got_g, got_l = eng.grads.clone(), eng.losses.clone()
+        ws["has_depth_cov"] = False
+        eng.forward_backward(ws, jitter.to(device), has_depth=True, background=bg.to(device))
+        torch.cuda.synchronize()
+        assert torch.equal(got_g, eng.grads) and torch.equal(got_l, eng.losses)
 
     orc = _oracle(eng)
     counts, t, dt = orc.march(origins, directions, bf, jitter)
@@ -86,7 +105,8 @@ def test_ngp_step_matches_oracle(device):
         assert (tt[off[r]:off[r] + n].view(np.uint32) == t[r, :n].view(np.uint32)).all()
 
     rgb, depth, acc = orc.forward(origins.double(), directions.double(), counts, t, dt, background=bg.double())
-    ld = orc.loss_dict(rgb, depth, gt_rgb.double(), gt_depth.double(), dnorm.double())
+    ld = orc.loss_dict(rgb, depth, gt_rgb.double(), gt_depth.double(), dnorm.double(),
+                       None if gt_cov is None else gt_cov.double())
     sum(ld.values()).backward()
     _assert_close(ws["out_rgb"], rgb.detach(), rtol=1e-2, atol_scale=5e-3, what="ngp rgb")
     _assert_close(ws["out_depth"], depth.detach(), rtol=1e-2, atol_scale=5e-3, what="ngp depth")
