@@ -156,7 +156,11 @@ int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
  * (every kernel that may raise it precedes it in stream order -- true for the producer flags of a nerfacto step), nothing
  * reads the table between this backward and the end of the step (no gather-form input gradient behind it), and
  * dL_dparams of that range is not consumed by anyone (it is left untouched).  The settings are read at LAUNCH time:
- * set, record / run the backward, then switch off (args = NULL) for launches that want the gradient. */
+ * set, record / run the backward, then switch off (args = NULL) for launches that want the gradient.
+ * The fused step applies NO weight decay (there is no such field): both engines decay MLP weights only, never a hash
+ * table (instant-ngp's l2_reg, nvo_adam_group::weight_decay); a caller whose optimiser decays the grid range must keep
+ * that range in its own nvo_adam_step_groups launch.  While a step is armed the slice-owner items of the coarse levels
+ * run IN stream order in front of the accumulate pass (option grid_stream_overlap is ignored): they may raise the flag. */
 typedef struct nvo_fused_adam_args {
     float* params;                 /* fp32 master weights: pointer to THIS MODULE's first parameter */
     void* params_half;             /* 16-bit working copy, same origin */

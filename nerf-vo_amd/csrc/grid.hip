@@ -3128,7 +3128,11 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
     const uint32_t n_tiles = nvo_div_up(N, tile);
     // fork: with the per-kernel profiler on, everything stays on the caller's stream (its events live there)
-    const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !(nvo_prof_enabled() && nvo_prof_detail());
+    // ... and with the optimiser step armed (st->adam.params): k_tl_accumulate_p reads *adam.skip_flag once, so every
+    // producer of that word -- the slice-owner items included -- must precede it in stream order; an owner item raising
+    // the flag beside it would leave the group half stepped (GradScaler steps all of a group or nothing)
+    const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !st->adam.params &&
+                      !(nvo_prof_enabled() && nvo_prof_detail());
     if (st->owner.n_slices) {  // coarse levels: slice-owner items (disjoint gradient ranges)
         NvoProfMute mute;
         if (fork) {
