@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the mapping hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or plainly -- it then
+                                                          starts its N ranks itself, launch_ranks())
 
 A "step" is ONE full depth-nerfacto training iteration as NeRF-VO's mapping runs it
 (/root/reference/nerf_vo/mapping/nerfstudio.py:151): pixel sampling -> rays -> proposal sampling
@@ -109,6 +110,74 @@ def pmc_traffic(name: str):
     return None, None, None
 
 
+def launch_ranks(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a child job
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`,
+    one rank per GPU), relay rank 0's single JSON line to stdout, return the job's exit code.  Runs BEFORE anything
+    initialises the GPU in this process (`import torch` and device_count() do not), and nothing is exec'd: the ranks
+    are children.  NVO_BENCH_DRY=1 (tests): the ranks only rendezvous over gloo and print a stub line."""
+    import socket
+    import subprocess
+
+    dry = os.environ.get("NVO_BENCH_DRY") == "1"
+    if not dry:
+        have = torch.cuda.device_count()  # (counts devices without creating a context on this image)
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} asked for, this node exposes {have} GPU(s): nothing was run "
+                             f"(error: not-enough-gpus)\n")
+            return 3
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL across processes needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    sys.stderr.write(f"[bench] launching {n} ranks: {' '.join(cmd)}\n")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else on the ranks' stdout goes to stderr
+        text = out.strip()
+        if text.startswith("{") and text.endswith("}") and line is None:
+            try:
+                json.loads(text)
+                line = text
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly without a result line (error: no-result)\n")
+        rc = 4
+    return rc
+
+
+def dry_run(args) -> int:
+    """NVO_BENCH_DRY=1: the launch path without a GPU -- rendezvous over gloo, the max-over-ranks timing reduction,
+    rank 0's single line (tests/test_parallel_cpu.py runs `python bench.py --gpus 2` this way)."""
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}\n")
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "training ray-samples/sec", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "max_over_ranks": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +240,11 @@ def main() -> None:
     ap.add_argument("--pipeline-single-gpu", action="store_true",
                     help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher -- it never touches a GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("NVO_BENCH_DRY") == "1":
+        raise SystemExit(dry_run(args))
     wl = WORKLOADS[args.workload]
     args.keyframes = args.keyframes or wl["keyframes"]
     args.height = args.height or wl["height"]
@@ -191,8 +265,8 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus} (launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or plainly as `python bench.py --gpus {args.gpus}`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -643,7 +717,14 @@ def main() -> None:
                        "proposal_samples": list(cfg.num_proposal_samples), "keyframes": args.keyframes,
                        "resolution": [args.width, args.height], "sampler": "proposal-network (nerfacto)",
                        "grid_bwd": [{0: "atomic", 1: "lds", 2: "binned", 3: "stream"}[int(m)] for m in bwd_modes],
-                       "launch": launch_desc, "parallelism": parallelism},
+                       "launch": launch_desc, "parallelism": parallelism,
+                       # which form of the optimiser ran (the Adam step of the main grid's hashed levels inside the grid
+                       # backward needs the step's overflow verdict before the exchange: single GPU only)
+                       "optimizer": ("fused grid Adam: on (hashed levels stepped inside the grid backward; one launch for the rest)"
+                                     if (world == 1 and engine._fused_adam_plan()) else
+                                     "fused grid Adam: off" + (" under a process group (verdict travels with the exchange); " +
+                                                               ("sharded Adam on 1/%d of the fields group" % world if shard_opt
+                                                                else "replicated Adam") if dist is not None else ""))},
             "rays_per_sec": args.rays * world / (elapsed / args.steps),
             # main + both proposal levels: every field evaluation a ray costs
             "field_evals_per_sec": args.rays * world * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples))

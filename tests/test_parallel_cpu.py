@@ -171,3 +171,37 @@ def test_bf16_wire_summation_drift_up_to_eight_ranks():
     assert err[2][0] < 2.5e-3 and err[8][0] < 4.5e-3
     assert err[8][0] < 2.0 * err[2][0], "8-way bf16 addition drifts more than twice the 2-way figure"
     assert all(e[1] < 2.0e-3 for e in err.values())
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver types it for N = 1 (no launcher around it): the process starts its two
+    ranks itself, relays rank 0's single JSON line and returns the job's exit code.  NVO_BENCH_DRY=1 keeps the ranks
+    off the GPU (gloo rendezvous + the max-over-ranks reduction only), so the whole entry path runs here."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NVO_BENCH_DRY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["max_over_ranks"] == 2.0
+
+
+def test_bench_names_the_error_when_the_node_has_too_few_gpus(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NVO_BENCH_DRY")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
+                         env=env, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 3 and "not-enough-gpus" in res.stderr and res.stdout.strip() == ""
