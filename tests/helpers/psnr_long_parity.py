@@ -12,6 +12,7 @@ Three phases, because the oracle needs CPU-hours and the GPU box grants 20-minut
   --phase oracle  (any CPU)  loads init.pt, trains the float64 oracle on the same ray / jitter stream (torch CPU generator,
                              seed fixed), renders the same views -> <dir>/oracle.pt   (resumable: --resume)
   --phase report             reads both, prints the table
+  --phase summary            over --seeds: mean +- spread of both sides' end points and the paired differences
 
 Sizes: main grid 16 levels x 2^14, proposal grids 5 levels x 2^12 (the oracle has to finish), production kernels,
 MLP shapes, samplers, losses and Adam."""
@@ -27,7 +28,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-N_IMG, N_HELD, H, W = 6, 2, 48, 64
+# 12 training views, 15 degrees apart along the orbit, and 4 held-out views half way BETWEEN training views (the 64x48
+# frames see 90 degrees, so every held-out pixel is covered by several training views): a 96-frame orbit, training frames
+# 0, 4, ..., 44, held-out frames 6, 18, 30, 42.  Buffer order: training views first, then the held-out ones.
+N_IMG, N_HELD, H, W = 12, 4, 48, 64
+ORBIT, TRAIN_FRAMES, HELD_FRAMES = 96, list(range(0, 48, 4)), [6, 18, 30, 42]
 GRIDS = dict(main=(16, 14, 16, 512), props=((5, 12, 16, 64), (5, 12, 16, 128)))
 
 
@@ -40,9 +45,9 @@ def _views(view_ids, stride):
     return torch.stack([cams, ys, xs], dim=-1).reshape(-1, 3)
 
 
-def _ray_stream(steps, rays):
+def _ray_stream(steps, rays, seed=0):
     """The injected (pixel, jitter) stream both phases consume: ONE CPU generator, same draws in the same order."""
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(5 + 7919 * int(seed))
     for _ in range(steps):
         idx = torch.stack([torch.randint(0, N_IMG, (rays,), generator=g), torch.randint(0, H, (rays,), generator=g),
                            torch.randint(0, W, (rays,), generator=g)], dim=1)
@@ -58,8 +63,10 @@ def phase_hip(a):
     from nerf_vo_amd.synthetic import make_sequence
 
     dev = torch.device("cuda:0")
-    torch.manual_seed(11)
-    seq = make_sequence(N_IMG + N_HELD, H, W, device=dev)  # the last views are held out
+    torch.manual_seed(11 + a.seed)
+    seq = make_sequence(ORBIT, H, W, device=dev)
+    pick = torch.tensor(TRAIN_FRAMES + HELD_FRAMES, device=dev)  # (the last views of the buffer are held out)
+    seq = {k: v[pick] for k, v in seq.items()}
     ds = DynamicDataset(num_frames=N_IMG + N_HELD, frame_height=H, frame_width=W, device=dev, use_normals=False)
     ds.update({"keyframe_indices": torch.arange(N_IMG + N_HELD), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
@@ -68,11 +75,11 @@ def phase_hip(a):
     images, depths = ds.frames_color, ds.frames_depth
     eng = NerfactoEngine(EngineConfig(num_images=N_IMG, num_rays=a.rays, main_grid=GridConfig(*GRIDS["main"]),
                                       proposal_grids=tuple(GridConfig(*g) for g in GRIDS["props"]),
-                                      dynamic_loss_scale=not a.static_loss_scale), dev)
+                                      dynamic_loss_scale=not a.static_loss_scale, seed=1337 + a.seed), dev)
     torch.save({"params": eng.params.detach().cpu(), "segments": dict(eng.segments), "intr": intr.cpu(), "c2w": c2w.cpu(),
                 "images": images.cpu(), "depths": depths.cpu(), "density_bias": eng.cfg.density_bias,
                 "lr": (eng.cfg.lr_fields, eng.cfg.lr_proposal), "betas": eng.cfg.adam_betas, "eps": eng.cfg.adam_eps,
-                "anneal": [eng.anneal_at(s) for s in range(a.steps)], "rays": a.rays, "steps": a.steps},
+                "anneal": [eng.anneal_at(s) for s in range(a.steps)], "rays": a.rays, "steps": a.steps, "seed": a.seed},
                os.path.join(a.dir, "init.pt"))
     from oracle import rays as Rr  # (the view rays of both phases come from the same CPU ray generator)
 
@@ -86,7 +93,7 @@ def phase_hip(a):
 
     out = {"checkpoints": {}, "loss": [], "updated": []}
     t0 = time.time()
-    for step, (idx, jit) in enumerate(_ray_stream(a.steps, a.rays)):
+    for step, (idx, jit) in enumerate(_ray_stream(a.steps, a.rays, a.seed)):
         upd = eng.train_step(idx.to(dev), intr, c2w, images, depths, jitters=tuple(j.to(dev) for j in jit))
         out["updated"].append(bool(upd))
         if step % 25 == 24 or step + 1 == a.steps:
@@ -150,7 +157,7 @@ def phase_oracle(a):
         out, start = st["out"], st["step"]
         print(f"[oracle] resumed at step {start}", flush=True)
     t0 = time.time()
-    for step, (idx, jit) in enumerate(_ray_stream(steps, rays)):
+    for step, (idx, jit) in enumerate(_ray_stream(steps, rays, init.get("seed", 0))):
         if step < start:
             continue
         ro, rd, rn, _ = Rr.generate_rays(idx, intr, c2w)
@@ -199,10 +206,45 @@ def phase_report(a):
     print(json.dumps({"rows": rows}))
 
 
+def _end_points(d, last=4):
+    """mean PSNR of the last checkpoints of one seed's pair of runs: (held HIP, held oracle, train HIP, train oracle)"""
+    init = torch.load(os.path.join(d, "init.pt"))
+    hip, orc = torch.load(os.path.join(d, "hip.pt")), torch.load(os.path.join(d, "oracle.pt"))
+    images = init["images"]
+    held, train = _views(list(range(N_IMG, N_IMG + N_HELD)), 1), _views(list(range(N_IMG)), 2)
+    gt_h, gt_t = images[held[:, 0], held[:, 1], held[:, 2]], images[train[:, 0], train[:, 1], train[:, 2]]
+    steps = sorted(set(hip["checkpoints"]) & set(orc["checkpoints"]))[-last:]
+    rows = np.array([[_psnr(hip["checkpoints"][s]["held"], gt_h), _psnr(orc["checkpoints"][s]["held"], gt_h),
+                      _psnr(hip["checkpoints"][s]["train"], gt_t), _psnr(orc["checkpoints"][s]["train"], gt_t)] for s in steps])
+    return rows.mean(axis=0), steps
+
+
+def phase_summary(a):
+    """Over the seeds: mean +- sample standard deviation of each side's end point, and the paired differences."""
+    base = a.dir.rsplit("_s", 1)[0]
+    pts = []
+    for sd in a.seeds:
+        e, steps = _end_points(f"{base}_s{sd}")
+        pts.append(e)
+        print(f"seed {sd}: held-out HIP {e[0]:.3f} / oracle {e[1]:.3f} dB (delta {e[0] - e[1]:+.3f}); training views HIP {e[2]:.3f} / "
+              f"oracle {e[3]:.3f} dB (delta {e[2] - e[3]:+.3f})   [mean of checkpoints {steps}]")
+    pts = np.array(pts)
+    m, sdv = pts.mean(axis=0), pts.std(axis=0, ddof=1) if len(pts) > 1 else np.zeros(4)
+    dh, dt = pts[:, 0] - pts[:, 1], pts[:, 2] - pts[:, 3]
+    print(f"held-out:        HIP {m[0]:.3f} +- {sdv[0]:.3f} dB, oracle {m[1]:.3f} +- {sdv[1]:.3f} dB over {len(pts)} seeds; "
+          f"paired delta {dh.mean():+.3f} +- {dh.std(ddof=1) if len(dh) > 1 else 0.0:.3f} dB")
+    print(f"training views:  HIP {m[2]:.3f} +- {sdv[2]:.3f} dB, oracle {m[3]:.3f} +- {sdv[3]:.3f} dB; "
+          f"paired delta {dt.mean():+.3f} +- {dt.std(ddof=1) if len(dt) > 1 else 0.0:.3f} dB")
+    print(json.dumps({"seeds": list(a.seeds), "end_points": pts.tolist(), "mean": m.tolist(), "std": sdv.tolist(),
+                      "held_delta": dh.tolist(), "train_delta": dt.tolist()}))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--phase", choices=("hip", "oracle", "report"), required=True)
-    ap.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "psnr_long"))
+    ap.add_argument("--phase", choices=("hip", "oracle", "report", "summary"), required=True)
+    ap.add_argument("--seed", type=int, default=0, help="initial parameters (1337 + seed) and ray / jitter stream")
+    ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2], help="(summary) the seeds to combine")
+    ap.add_argument("--dir", default=None)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--every", type=int, default=250)
@@ -210,5 +252,7 @@ if __name__ == "__main__":
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--static-loss-scale", action="store_true")
     args = ap.parse_args()
+    if args.dir is None:
+        args.dir = os.path.join(ROOT, "gpurun_out", f"psnr_long_s{args.seed}")
     os.makedirs(args.dir, exist_ok=True)
-    {"hip": phase_hip, "oracle": phase_oracle, "report": phase_report}[args.phase](args)
+    {"hip": phase_hip, "oracle": phase_oracle, "report": phase_report, "summary": phase_summary}[args.phase](args)
