@@ -323,11 +323,13 @@ int nvo_ray_head(nvo_stream_t stream, const nvo_ray_head_args* args);
 /* nvo_raygen + nvo_gather_pixels (colour, depth) + nvo_dirs01 + nvo_sh_encode (degree 4, fp16) for GIVEN pixel indices
  * in one launch (the occupancy-grid back-end: pyngp.Testbed.frame() draws its pixels itself); same values.
  * depths_cov [F][H][W] (nullable) -> gt_depth_cov [R]: the per-pixel depth variance update_training_images received
- * (/root/reference/nerf_vo/mapping/instant_ngp.py:77-86,93-94), gathered like the depth. */
+ * (/root/reference/nerf_vo/mapping/instant_ngp.py:77-86,93-94), gathered like the depth.
+ * R_dev (nullable): device uint32, rays in use (the launch covers R rows, rows from *R_dev on are left alone). */
 int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
                    const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
                    float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
-                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov);
+                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov,
+                   const uint32_t* R_dev);
 /* the same launch with extra workgroups that clear up to 24 device ranges (as nvo_zero_ranges): the first launch of a
  * one-graph training step does both */
 int nvo_ray_head_zero(nvo_stream_t stream, const nvo_ray_head_args* args, uint32_t n_ranges, void* const* ptrs,
@@ -508,6 +510,23 @@ int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, 
                          uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
                          float* dt_out, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
                          float* t_next);
+/* The two halves of nvo_occ_march_resume as calls of their own (the training step of the occupancy-grid back-end packs a
+ * ray's run twice: everything the march found for the pass that finds where each ray ends, then the samples in front of
+ * that point for the batch that is trained on).
+ *  nvo_occ_march_runs : the march alone -- counts[r] and the ray-major runs in `scratch` ([R][1024] (t, dt) pairs).
+ *  nvo_occ_pack       : exclusive scan of counts_in[R] with the capacity rule (a ray whose samples would pass `capacity`
+ *                       gets counts_out 0 and keeps its slot range in offsets; counts_out may alias counts_in), then the
+ *                       first counts_out[r] samples of every run are copied to (ray_idx, t, dt) at offsets[r].
+ *                       totals (nullable): device uint32[2] = {sum of counts_in, min(that, capacity)}.
+ * R_dev (nullable): device uint32, the number of rays in use -- the launch covers R rows, rows from *R_dev on are left
+ * alone (a captured step is replayed while the adaptive ray batch moves). */
+int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                       const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                       uint32_t* counts, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
+                       float* t_next, const uint32_t* R_dev);
+int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
+                 uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
+                 float* t_out, float* dt_out, const uint32_t* R_dev);
 /* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
  * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
  * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.
@@ -609,7 +628,42 @@ typedef struct nvo_ngp_loss_args {
      * all ones: the plain L2 term, bit for bit.  The reference supplies it on every instant-ngp configuration
      * (/root/reference/nerf_vo/enhancement/enhancement_module.py:105-111, configs/nerf_slam_*.yaml: compute_covariances) */
     const float* gt_depth_cov;
+    /* training on the samples in front of the point where a ray's transmittance falls below the threshold
+     * (nvo_ngp_count_alive; counts / offsets then describe the COMPACTED batch): ray_state [R] (nullable) -- 1: the ray was
+     * cut (no background term), 2: it was dropped where the march was packed (no trace in the losses). */
+    const uint32_t* ray_state;
+    /* R_dev (nullable): device uint32, rays in use; the launch covers R rows, inv_rays is then taken as
+     * 1 / (*R_dev * max(world_size, 1)) */
+    const uint32_t* R_dev;
+    uint32_t world_size;
 } nvo_ngp_loss_args;
+/* Where each ray ends for training: kept[r] = index of the first of its packed samples reached with a transmittance
+ * T = exp(-sum of min(exp(pre) dt, 128) over the samples in front) below min_transmittance (its count when none is),
+ * state[r] = 0 (kept everything) | 1 (cut) | 2 (the ray was dropped where the march was packed: kept 0)
+ * [UPSTREAM instant-ngp compute_loss_kernel_train_nerf `if (T < EPSILON) break`, EPSILON = 1e-4; the testbed the
+ * reference drives through pyngp's frame(), /root/reference/nerf_vo/mapping/instant_ngp.py:104-105]. */
+typedef struct nvo_ngp_alive_args {
+    uint32_t R;
+    const uint32_t* counts;      /* [R] packed samples per ray (0 for a dropped ray) */
+    const uint32_t* offsets;     /* [R+1] */
+    const float* dt;             /* [capacity] */
+    const void* density_out;     /* fp16 [capacity][density_stride], pre-activation in column 0 (stride 1: compact) */
+    uint32_t density_stride;
+    float min_transmittance;
+    uint32_t* kept;              /* [R] */
+    uint32_t* state;             /* [R] */
+    const uint32_t* R_dev;       /* nullable: device ray count */
+} nvo_ngp_alive_args;
+int nvo_ngp_count_alive(nvo_stream_t stream, const nvo_ngp_alive_args* args);
+/* nvo_ngp_positions with the number of slots in use on the device (n_live, nullable): slots from the next multiple of
+ * 4096 on are left alone; nvo_ngp_positions_bwd with a device ray count (rows from *R_dev on receive zeros). */
+int nvo_ngp_positions_live(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
+                           const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01,
+                           const uint32_t* n_live);
+int nvo_ngp_positions_bwd_dev(nvo_stream_t stream, uint32_t R, uint32_t capacity, const int32_t* counts,
+                              const int32_t* offsets, const float* t, const float* origins, const float* directions,
+                              float aabb_lo, float aabb_hi, const float* dx01, float* d_origin, float* d_dir,
+                              const uint32_t* R_dev);
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);
 /* Extrinsics optimisation of the occupancy-grid back-end (`optimize_extrinsics = True`,

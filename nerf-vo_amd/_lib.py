@@ -109,7 +109,13 @@ class NgpLossArgs(C.Structure):
                 ("depth_mult", _f), ("inv_rays", _f), ("loss_scale", _f), ("out_rgb", _p), ("out_depth", _p),
                 ("out_accumulation", _p), ("losses", _p), ("d_rgb_out", _p), ("d_rgb_stride", _u32),
                 ("d_density_pre", _p), ("carry_in", _p), ("carry_out", _p), ("accumulate_outputs", _u32),
-                ("train_min_transmittance", _f), ("gt_depth_cov", _p)]
+                ("train_min_transmittance", _f), ("gt_depth_cov", _p), ("ray_state", _p), ("R_dev", _p), ("world_size", _u32)]
+
+
+class NgpAliveArgs(C.Structure):
+    """mirror of nvo_ngp_alive_args"""
+    _fields_ = [("R", _u32), ("counts", _p), ("offsets", _p), ("dt", _p), ("density_out", _p), ("density_stride", _u32),
+                ("min_transmittance", _f), ("kept", _p), ("state", _p), ("R_dev", _p)]
 
 
 _SIGNATURES = {
@@ -152,7 +158,7 @@ _SIGNATURES = {
     "nvo_sh_encode": (_int, [_p, _u32, _u32, _p, _p]),
     "nvo_sh_encode_t": (_int, [_p, _u32, _u32, _p, _p, _int]),
     "nvo_ray_head": (_int, [_p, C.POINTER(RayHeadArgs)]),
-    "nvo_rays_given": (_int, [_p, _u32, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nvo_rays_given": (_int, [_p, _u32, _p, _p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_ray_head_zero": (_int, [_p, C.POINTER(RayHeadArgs), _u32, _p, _p]),
     # group C
     "nvo_weights_pdf": (_int, [_p, C.POINTER(WeightsPdfArgs)]),
@@ -173,6 +179,11 @@ _SIGNATURES = {
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_occ_mark_untrained": (_int, [_p, _int, _p, _u32, _p, _p, _u32, _u32, _f]),
     "nvo_occ_sample_cells": (_int, [_p, _u32, _u32, _u32, _u32, _u32, _u32, _int, _p, _f, _f, _f, _p, _p]),
+    "nvo_occ_march_runs": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _p, _p, _u64, _p, _u32, _p, _p]),
+    "nvo_occ_pack": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p]),
+    "nvo_ngp_count_alive": (_int, [_p, C.POINTER(NgpAliveArgs)]),
+    "nvo_ngp_positions_live": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p, _p]),
+    "nvo_ngp_positions_bwd_dev": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
     "nvo_ngp_positions": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p]),
     "nvo_depth_align_scratch_bytes": (_u64, [_u32, _u32]),
     "nvo_depth_align": (_int, [_p, C.POINTER(DepthAlignArgs)]),

@@ -343,6 +343,7 @@ struct GridModule : nvo_module_s {
         nvo_scratch_destroy(&input_scratch);
     }
     bool external_zero = false;
+    const uint32_t* n_live = nullptr;  // option "n_live_ptr": device count of the rows a FORWARD evaluates (0 = all)
     int grid_zero_ranges(float* dparams, NvoZeroRanges* out) {
         int rc = ensure_slices();
         if (rc) return rc;
@@ -474,7 +475,7 @@ struct GridModule : nvo_module_s {
     int fwd_encode(hipStream_t s, uint32_t B, const float* in, const void* table, void* out, bool soa, void* dydx) {
         dydx_valid = dydx != nullptr;
         dydx_batch = B;
-        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16);
+        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16, n_live);
     }
     int bwd_input(hipStream_t s, uint32_t B, const float* in, const void* table, const void* dout, bool soa,
                   float* din, const void* dydx) {
@@ -513,6 +514,7 @@ struct GridModule : nvo_module_s {
             return NVO_OK;
         }
         if (!strcmp(key, "bf16")) { bf16 = value != 0; return NVO_OK; }
+        if (!strcmp(key, "n_live_ptr")) { n_live = reinterpret_cast<const uint32_t*>((uintptr_t)value); return NVO_OK; }
         if (!strcmp(key, "nonfinite_flag_ptr")) {  // device address of the overflow flag the backward raises (0 = none)
             slices.nf_flag = stream_bins.owner.nf_flag = reinterpret_cast<uint32_t*>((uintptr_t)value);
             return NVO_OK;
@@ -779,7 +781,7 @@ struct NwieModule : nvo_module_s {
         void* hidden = c + 2 * enc_bytes(B);
         const _Float16* p = (const _Float16*)params;
         void* dydx = enc->prepare_input_gradients ? c + dydx_offset(B) : nullptr;
-        if (fuse_encoding && !dydx && net->n_hidden == 1 && net->in_pad <= 32 && net->out_pad == 16) {
+        if (fuse_encoding && !dydx && !enc->n_live && net->n_hidden == 1 && net->in_pad <= 32 && net->out_pad == 16) {
             if (!d_levels) {  // (first call = an eager warm-up step, never under graph capture)
                 NVO_CHECK_HIP(hipMalloc((void**)&d_levels, sizeof(NvoGridLevels)));
                 NVO_CHECK_HIP(hipMemcpy(d_levels, &enc->g, sizeof(NvoGridLevels), hipMemcpyHostToDevice));
@@ -797,6 +799,7 @@ struct NwieModule : nvo_module_s {
         NvoMlpArgs a = net->make_args(B, encoded, NVO_IO_HALF2_SOA, enc->n_out, p, out, hidden);
         a.compact_out = compact_out;
         if (recompute_hidden) a.hidden = nullptr;
+        a.n_live = enc->n_live;  // (option "n_live_ptr": both kernels stop at the rows in use)
         return nvo_mlp_fwd_launch(net->in_pad, net->width, net->n_hidden, net->out_pad, a, s);
     }
     int zero_ranges(float* dparams, NvoZeroRanges* out) override {

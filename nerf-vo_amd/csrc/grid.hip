@@ -178,13 +178,16 @@ template <bool SOA, bool DYDX, int SPT>
 __global__ void __launch_bounds__(kGridBlock)
 k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
            const __half2* __restrict__ table, __half2* __restrict__ out,
-           uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16, GridFwdPlan plan) {
+           uint32_t* __restrict__ indices, __half2* __restrict__ dydx, int out_bf16, GridFwdPlan plan,
+           const uint32_t* __restrict__ n_live) {
     uint32_t tile, level;
     if (plan.enabled) {
         if (!grid_plan_map(plan, blockIdx.x, &tile, &level)) return;
     } else {
         grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
     }
+    // (rows in use known on the device only: tiles past them leave at once; N stays the stride of the level-major output)
+    if (n_live && tile * (kGridBlock * SPT) >= *n_live) return;
     const uint32_t i_first = tile * (kGridBlock * SPT) + threadIdx.x;
     if (i_first >= N) return;
 
@@ -2597,14 +2600,14 @@ static uint32_t grid_fwd_plan_build(const NvoGridLevels& g, uint32_t tiles, Grid
 
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half,
-                        bool out_bf16) {
+                        bool out_bf16, const uint32_t* n_live) {
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     // small grids (the proposal networks): the two coarsest dense levels from LDS, a thread per sample (k_grid_fwd_small)
     static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 1; }();  // 0 off | 1 | 2 samples per thread (2 measured slower: 35.0 vs 33.6 us)
-    if (small_env && soa && !indices && !dydx_half && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
+    if (small_env && soa && !indices && !dydx_half && !n_live && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
         (size_t)g.offset[2] * 4 <= 152 * 1024 && (g.offset[2] & 3u) == 0u && (((uintptr_t)table_half) & 15u) == 0u) {
         static const uint32_t n_cus = [] {
             int dev = 0, n = 256;
@@ -2645,7 +2648,7 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     }
 #define NVO_LAUNCH_FWD_S(SOA_, DYDX_, SPT_)                                                                  \
     NVO_LAUNCH((k_grid_fwd<SOA_, DYDX_, SPT_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
-               (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0, plan)
+               (__half2*)out_half, indices, (__half2*)dydx_half, out_bf16 ? 1 : 0, plan, n_live)
 #define NVO_LAUNCH_FWD(SOA_, DYDX_)                                        \
     do {                                                                   \
         if (DYDX_ || spt == 1) NVO_LAUNCH_FWD_S(SOA_, DYDX_, 1);           \

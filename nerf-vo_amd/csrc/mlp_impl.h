@@ -415,7 +415,7 @@ NVO_MLP_NAME(k_mlp_fwd)(Args a) {
     const int m = lane & 15, g = lane >> 4;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_tiles = a.batch >> 4;
+    const uint32_t n_tiles = (a.n_live ? min(a.batch, (*a.n_live + 15u) & ~15u) : a.batch) >> 4;
 
     WFrag<WIDTH, IN_PAD> w0;
     WFrag<WIDTH, WIDTH> wh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];

@@ -22,9 +22,12 @@ __device__ __forceinline__ float wave_incl_scan(float v, int) { return nvo_wave_
 __global__ void __launch_bounds__(256)
 k_ngp_positions(uint32_t capacity, const int32_t* __restrict__ ray_idx, const float* __restrict__ t,
                 const float* __restrict__ origins, const float* __restrict__ directions, float aabb_lo,
-                float aabb_inv_size, float* __restrict__ x01) {
+                float aabb_inv_size, float* __restrict__ x01, const uint32_t* __restrict__ n_live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
+    // (slots in use known on the device: the network launches behind this one stop at the tile that holds the last of
+    // them, rows up to the next multiple of 4096 are kept finite for that tile)
+    if (n_live && i >= ((*n_live + 4095u) & ~4095u)) return;
     const int32_t r = ray_idx[i];
     float p[3] = {0.f, 0.f, 0.f};
     if (r >= 0) {
@@ -46,10 +49,17 @@ k_ngp_positions_bwd(uint32_t R, uint32_t capacity, const int32_t* __restrict__ c
                     const int32_t* __restrict__ offsets, const float* __restrict__ t,
                     const float* __restrict__ origins, const float* __restrict__ directions, float aabb_lo,
                     float aabb_inv_size, const float* __restrict__ dx01, float* __restrict__ d_origin,
-                    float* __restrict__ d_dir) {
+                    float* __restrict__ d_dir, const uint32_t* __restrict__ R_dev) {
     const int lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
+    if (R_dev && r >= *R_dev) {  // rows past the batch: zero gradients (the per-camera sum behind this covers all R rows)
+        if (lane < 3) {
+            d_origin[3 * (size_t)r + lane] = 0.f;
+            d_dir[3 * (size_t)r + lane] = 0.f;
+        }
+        return;
+    }
     const uint32_t off = (uint32_t)offsets[r];
     uint32_t n = (uint32_t)counts[r];
     if (off >= capacity) n = 0;
@@ -97,6 +107,14 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     const int lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= a.R) return;
+    if (a.R_dev) {  // the batch is the first *R_dev rows; the losses are means over them (times the ranks)
+        const uint32_t R = *a.R_dev;
+        if (r >= R) return;
+        a.inv_rays = 1.f / (float)(R * (a.world_size ? a.world_size : 1u));
+    }
+    // 0: the ray's samples reach the end of its march; 1: they stop where the transmittance fell below the training
+    // threshold (nvo_ngp_count_alive); 2: dropped where the march was packed (no trace in the losses)
+    const uint32_t state = a.ray_state ? a.ray_state[r] : 0u;
     const uint32_t n = a.counts[r];
     const uint32_t base = a.offsets[r];
     const _Float16* den = (const _Float16*)a.density_out;
@@ -129,7 +147,9 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     }
     const float T_final = __expf(-carry);
     float bg[3] = {0.f, 0.f, 0.f};
-    if (a.background) {
+    // (a ray that was cut at the threshold sees no background: what is left of it, < 1e-4, belongs to the samples behind
+    // the cut [UPSTREAM compute_loss_kernel_train_nerf: `if (compacted_numsteps == numsteps) rgb_ray += T * background`])
+    if (a.background && state == 0u) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) bg[k] = a.background[3 * (size_t)r + k];
     }
@@ -149,6 +169,7 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     // a ray the scan dropped at the packed capacity (count zeroed, its slot range in `offsets` kept) leaves no trace in
     // the losses [UPSTREAM generate_training_samples_nerf: an overflowing ray returns before it is counted]
     if (n == 0u && a.offsets[r + 1] != base) return;
+    if (state == 2u) return;
 
     // ---- losses (means over the global ray count)
     float g_pix[3], l_rgb = 0.f;
@@ -250,6 +271,53 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     }
 }
 
+// Where each ray ends for TRAINING [UPSTREAM compute_loss_kernel_train_nerf: the loop over a ray's samples opens with
+// `if (T < EPSILON) break`, EPSILON = 1e-4; the samples in front of that point are the ones compacted into the batch
+// that is trained on]: kept[r] = index of the first sample the ray reaches with a transmittance below `min_t` (its
+// sample count when there is none).  Same arithmetic as the compositing pass of k_ngp_composite_loss (capped optical
+// step, wave scan with a carry), density pre-activations in COMPACT form (one 16-bit value per slot) or with a stride.
+// state[r]: 0 = kept everything, 1 = cut, 2 = the ray was dropped where the march was packed (kept 0).
+__global__ void __launch_bounds__(256)
+k_ngp_count_alive(nvo_ngp_alive_args a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t R = a.R;
+    if (a.R_dev) R = min(R, *a.R_dev);
+    if (r >= R) return;
+    const uint32_t n = a.counts[r];
+    const uint32_t base = a.offsets[r];
+    if (n == 0u) {
+        if (lane == 0) {
+            a.kept[r] = 0u;
+            a.state[r] = (a.offsets[r + 1] != base) ? 2u : 0u;
+        }
+        return;
+    }
+    const _Float16* den = (const _Float16*)a.density_out;
+    float carry = 0.f;
+    uint32_t kept = n;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t j = c0 + lane;
+        float dd = 0.f;
+        if (j < n) {
+            const size_t s = base + j;
+            dd = ngp_optical_step(__expf((float)den[s * a.density_stride]), a.dt[s]);
+        }
+        const float incl = wave_incl_scan(dd, lane) + carry;
+        const float T = __expf(-(incl - dd));
+        const unsigned long long below = __ballot(j < n && T < a.min_transmittance);
+        if (below) {
+            kept = c0 + (uint32_t)__builtin_ctzll(below);
+            break;
+        }
+        carry = nvo_wave_bcast(incl, 63);
+    }
+    if (lane == 0) {
+        a.kept[r] = kept;
+        a.state[r] = kept < n ? 1u : 0u;
+    }
+}
+
 // zero the gradient rows of packed slots that belong to no ray (beyond the last offset / dropped rays)
 __global__ void __launch_bounds__(256)
 k_ngp_clear_invalid(uint32_t capacity, const int32_t* __restrict__ ray_idx, _Float16* __restrict__ d_rgb,
@@ -294,12 +362,31 @@ extern "C" {
 
 int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01) {
+    return nvo_ngp_positions_live(stream, capacity, ray_idx, t, origins, directions, aabb_lo, aabb_hi, x01, nullptr);
+}
+
+int nvo_ngp_positions_live(nvo_stream_t stream, uint32_t capacity, const int32_t* ray_idx, const float* t,
+                           const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01,
+                           const uint32_t* n_live) {
     NVO_REQUIRE(capacity == 0 || (ray_idx && t && origins && directions && x01), "ngp_positions: NULL argument");
     NVO_REQUIRE(aabb_hi > aabb_lo, "ngp_positions: empty aabb");
     if (capacity == 0) return NVO_OK;
     NVO_PROF(stream, "ngp_positions");
     NVO_LAUNCH(k_ngp_positions, dim3(nvo_div_up(capacity, 256)), dim3(256), 0, (hipStream_t)stream, capacity, ray_idx,
-               t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), x01);
+               t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), x01, n_live);
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_ngp_count_alive(nvo_stream_t stream, const nvo_ngp_alive_args* args) {
+    NVO_REQUIRE(args != nullptr, "ngp_count_alive: args is NULL");
+    const nvo_ngp_alive_args a = *args;
+    NVO_REQUIRE(a.R == 0 || (a.counts && a.offsets && a.dt && a.density_out && a.kept && a.state && a.density_stride >= 1),
+                "ngp_count_alive: NULL argument");
+    NVO_REQUIRE(a.min_transmittance >= 0.f && a.min_transmittance < 1.f, "ngp_count_alive: threshold outside [0, 1)");
+    if (a.R == 0) return NVO_OK;
+    NVO_PROF(stream, "ngp_count_alive");
+    NVO_LAUNCH(k_ngp_count_alive, dim3(nvo_div_up(a.R, 4)), dim3(256), 0, (hipStream_t)stream, a);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }
@@ -307,13 +394,21 @@ int nvo_ngp_positions(nvo_stream_t stream, uint32_t capacity, const int32_t* ray
 int nvo_ngp_positions_bwd(nvo_stream_t stream, uint32_t R, uint32_t capacity, const int32_t* counts,
                           const int32_t* offsets, const float* t, const float* origins, const float* directions,
                           float aabb_lo, float aabb_hi, const float* dx01, float* d_origin, float* d_dir) {
+    return nvo_ngp_positions_bwd_dev(stream, R, capacity, counts, offsets, t, origins, directions, aabb_lo, aabb_hi, dx01, d_origin,
+                                     d_dir, nullptr);
+}
+
+int nvo_ngp_positions_bwd_dev(nvo_stream_t stream, uint32_t R, uint32_t capacity, const int32_t* counts,
+                              const int32_t* offsets, const float* t, const float* origins, const float* directions,
+                              float aabb_lo, float aabb_hi, const float* dx01, float* d_origin, float* d_dir,
+                              const uint32_t* R_dev) {
     NVO_REQUIRE(R == 0 || (counts && offsets && t && origins && directions && dx01 && d_origin && d_dir),
                 "ngp_positions_bwd: NULL argument");
     NVO_REQUIRE(aabb_hi > aabb_lo, "ngp_positions_bwd: empty box");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "ngp_positions_bwd");
     NVO_LAUNCH(k_ngp_positions_bwd, dim3(nvo_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, R, capacity, counts,
-               offsets, t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), dx01, d_origin, d_dir);
+               offsets, t, origins, directions, aabb_lo, 1.0f / (aabb_hi - aabb_lo), dx01, d_origin, d_dir, R_dev);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -169,7 +169,7 @@ void nvo_grid_slices_destroy(NvoGridSlices* s);
 // out_bf16: the encoded features leave as bfloat16 pairs instead of fp16 pairs (bf16 MLP mode)
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices,
-                        void* dydx_half = nullptr, bool out_bf16 = false);
+                        void* dydx_half = nullptr, bool out_bf16 = false, const uint32_t* n_live = nullptr);
 int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
                                    const void* dy, int dy_fmt, bool soa, float* dx, bool zero_dx);
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,
@@ -261,6 +261,9 @@ struct NvoMlpArgsT {
     // the network (a hidden dZ = inf with finite roots and leaves) always lands in the weight gradient of the layer it
     // appears in (dW = dZ^T H: inf * h = inf or NaN for every h) -- and in dL/d(embedding), dL/d(SH) only together with it
     uint32_t* nf_flag;
+    // (forward; nullable) device count of the rows in use: tiles past it are not evaluated (`batch` stays the stride of
+    // the level-major input) -- the pass of the occupancy-grid back-end that finds where each ray ends
+    const uint32_t* n_live;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

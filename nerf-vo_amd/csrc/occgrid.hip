@@ -187,9 +187,11 @@ __global__ void __launch_bounds__(256)
 k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __restrict__ directions,
                  const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
                  const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch,
-                 const float* __restrict__ t_resume, uint32_t max_new, float* __restrict__ t_next) {
+                 const float* __restrict__ t_resume, uint32_t max_new, float* __restrict__ t_next,
+                 const uint32_t* __restrict__ R_dev) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (R_dev) R = min(R, *R_dev);  // the launch covers the buffers' rows, the batch is the first *R_dev of them
     if (r >= R) return;
     // RESUMABLE form (inference in rounds): the ray takes up its progression at candidate t_resume[r] (a value an earlier
     // launch handed out through t_next: the recurrence depends on t alone, so the samples are the ones a single march
@@ -295,8 +297,9 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
 __global__ void __launch_bounds__(256)
 k_occ_compact(uint32_t R, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
               const float2* __restrict__ scratch, int32_t* __restrict__ ray_idx, float* __restrict__ t_out,
-              float* __restrict__ dt_out) {
+              float* __restrict__ dt_out, const uint32_t* __restrict__ R_dev) {
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (R_dev) R = min(R, *R_dev);
     if (r >= R) return;
     const uint32_t n = counts[r], base = offsets[r];
     const float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
@@ -310,18 +313,21 @@ k_occ_compact(uint32_t R, const uint32_t* __restrict__ counts, const uint32_t* _
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return nvo_wave_incl_scan(v); }  // DPP
 
-// Single-workgroup exclusive scan of counts[n] -> offsets[n], total in offsets[n]; entries that would
-// push the running total beyond `capacity` are treated as 0 (and zeroed in counts).
+// Single-workgroup exclusive scan of counts_in[n] -> offsets[n], total in offsets[n]; entries that would
+// push the running total beyond `capacity` are treated as 0 in counts_out (counts_out == counts_in: in place).
+// totals (nullable): [0] = the total BEFORE the clamp, [1] = min(total, capacity) = the packed slots in use.
 __global__ void __launch_bounds__(1024)
-k_scan_counts(uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t capacity) {
+k_scan_counts(uint32_t n, const uint32_t* counts_in, uint32_t* counts_out, uint32_t* __restrict__ offsets,
+              uint32_t capacity, uint32_t* __restrict__ totals, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
+    if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t c = i < n ? counts[i] : 0u;
+        const uint32_t c = i < n ? counts_in[i] : 0u;
         const uint32_t incl = wave_incl_scan_u32(c, lane);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
@@ -335,9 +341,17 @@ k_scan_counts(uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ 
     }
     // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024)
-        if (offsets[i] + counts[i] > capacity) counts[i] = 0;
-    if (threadIdx.x == 0) offsets[n] = carry_s;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t c = counts_in[i];
+        counts_out[i] = (offsets[i] + c > capacity) ? 0u : c;
+    }
+    if (threadIdx.x == 0) {
+        offsets[n] = carry_s;
+        if (totals) {
+            totals[0] = carry_s;
+            totals[1] = carry_s < capacity ? carry_s : capacity;
+        }
+    }
 }
 
 // instant-ngp ema_grid_samples_nerf: never-seen cells (negative) stay; others max(decay * old, new)
@@ -547,10 +561,21 @@ int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, 
                          uint32_t capacity, uint32_t* counts, uint32_t* offsets, int32_t* ray_idx, float* t_out,
                          float* dt_out, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
                          float* t_next) {
+    NVO_REQUIRE(R == 0 || (counts && offsets && ray_idx && t_out && dt_out), "occ_march: NULL argument");
+    if (int rc = nvo_occ_march_runs(stream, R, origins, directions, bitfield, n_levels, cone_angle, t_near, jitter, counts,
+                                    scratch, scratch_bytes, t_resume, max_new, t_next, nullptr))
+        return rc;
+    return nvo_occ_pack(stream, R, counts, capacity, counts, offsets, nullptr, scratch, scratch_bytes, ray_idx, t_out, dt_out,
+                        nullptr);
+}
+
+int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
+                       const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
+                       uint32_t* counts, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
+                       float* t_next, const uint32_t* R_dev) {
     NVO_REQUIRE(n_levels >= 1 && n_levels <= 8, "occ_march: n_levels %d not in 1..8", n_levels);
     NVO_REQUIRE(max_new >= 1, "occ_march: max_new must be positive");
-    NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts && offsets && ray_idx && t_out && dt_out),
-                "occ_march: NULL argument");
+    NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts), "occ_march: NULL argument");
     if (R == 0) return NVO_OK;
     // ray-major staging area of the single march: CALLER-owned (it used to be a process-global block that was freed
     // and re-allocated whenever a larger R arrived -- a captured graph would have kept the dangling pointer)
@@ -559,27 +584,35 @@ int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, 
                 (unsigned long long)scratch_bytes, R, (unsigned long long)nvo_occ_march_scratch_bytes(R));
     hipStream_t s = (hipStream_t)stream;
     float2* march_scratch = static_cast<float2*>(scratch);
-    {
-        NVO_PROF(stream, "occ_march");
-        static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
-        if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps) {  // (A/B switch: the sequential form, one ray per lane)
-            NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
-                       n_levels, cone_angle, t_near, jitter, counts, march_scratch);
-        } else {
-            NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
-                       n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next);
-        }
-        NVO_CHECK_LAUNCH();
+    NVO_PROF(stream, "occ_march");
+    static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
+    if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps && !R_dev) {  // (A/B switch: the sequential form, one ray per lane)
+        NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
+                   n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+    } else {
+        NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
+                   n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next, R_dev);
     }
+    NVO_CHECK_LAUNCH();
+    return NVO_OK;
+}
+
+int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
+                 uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
+                 float* t_out, float* dt_out, const uint32_t* R_dev) {
+    NVO_REQUIRE(R == 0 || (counts_in && counts_out && offsets && scratch && ray_idx && t_out && dt_out), "occ_pack: NULL argument");
+    NVO_REQUIRE(scratch_bytes >= nvo_occ_march_scratch_bytes(R), "occ_pack: scratch too small for %u rays", R);
+    if (R == 0) return NVO_OK;
+    hipStream_t s = (hipStream_t)stream;
     {
         NVO_PROF(stream, "occ_scan");
-        NVO_LAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, R, counts, offsets, capacity);
+        NVO_LAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
         NVO_CHECK_LAUNCH();
     }
     {
         NVO_PROF(stream, "occ_compact");
-        NVO_LAUNCH(k_occ_compact, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, counts, offsets, march_scratch, ray_idx,
-                   t_out, dt_out);
+        NVO_LAUNCH(k_occ_compact, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, counts_out, offsets,
+                   static_cast<const float2*>(scratch), ray_idx, t_out, dt_out, R_dev);
         NVO_CHECK_LAUNCH();
     }
     return NVO_OK;

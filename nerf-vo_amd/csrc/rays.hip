@@ -90,8 +90,9 @@ k_rays_given(uint32_t R, const int64_t* __restrict__ ray_indices, const float* _
              float* __restrict__ directions, float* __restrict__ directions_norm, float* __restrict__ pixel_area,
              int32_t* __restrict__ cam_idx, float* __restrict__ gt_rgb, float* __restrict__ gt_depth,
              float* __restrict__ dirs01, nvo_h16* __restrict__ sh, const float* __restrict__ depths_cov,
-             float* __restrict__ gt_depth_cov) {
+             float* __restrict__ gt_depth_cov, const uint32_t* __restrict__ R_dev) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) R = min(R, *R_dev);
     if (r >= R) return;
     const int64_t cam = ray_indices[3 * (size_t)r + 0], y = ray_indices[3 * (size_t)r + 1], x = ray_indices[3 * (size_t)r + 2];
     float o[3], d[3], n0, area;
@@ -440,7 +441,8 @@ int nvo_raygen(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, cons
 int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, const float* intrinsics, const float* c2w,
                    const float* corrections, uint32_t H, uint32_t W, const float* images, const float* depths, float* origins,
                    float* directions, float* directions_norm, float* pixel_area, int32_t* cam_idx, float* gt_rgb,
-                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov) {
+                   float* gt_depth, float* dirs01, void* sh_half, const float* depths_cov, float* gt_depth_cov,
+                   const uint32_t* R_dev) {
     NVO_REQUIRE(R == 0 || (ray_indices && intrinsics && c2w && images && origins && directions && directions_norm && cam_idx &&
                            gt_rgb && dirs01 && sh_half && (!depths || gt_depth) && (!depths_cov || gt_depth_cov)),
                 "rays_given: NULL argument");
@@ -448,7 +450,7 @@ int nvo_rays_given(nvo_stream_t stream, uint32_t R, const int64_t* ray_indices, 
     NVO_PROF(stream, "rays_given");
     NVO_LAUNCH(k_rays_given, dim3(nvo_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, R, ray_indices, intrinsics, c2w,
                corrections, H, W, images, depths, origins, directions, directions_norm, pixel_area, cam_idx, gt_rgb, gt_depth,
-               dirs01, (nvo_h16*)sh_half, depths_cov, gt_depth_cov);
+               dirs01, (nvo_h16*)sh_half, depths_cov, gt_depth_cov, R_dev);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -49,6 +49,15 @@ class NgpConfig:
     # stops the ray there, EPSILON = 1e-4 in compute_loss_kernel_train_nerf, and trains on the samples in front); the
     # backwards skip zero-gradient samples, so late in training most of a batch costs the backward nothing.  0 = off.
     train_min_transmittance: float = 1e-4
+    # Training batch = the samples IN FRONT of that point [UPSTREAM Testbed::train_nerf_step: generate_training_samples_nerf
+    # marches up to 16 x the target batch, the network is evaluated on everything marched, compute_loss_kernel_train_nerf
+    # stops each ray at T < 1e-4 and compacts the samples in front into the 2^18-sample batch that is trained on; the rays
+    # per batch adapt to the samples AFTER compaction].  Here: march (ray-major runs) -> pack everything found into
+    # `march_capacity` slots -> density network alone, on the slots in use (the count stays on the device) ->
+    # nvo_ngp_count_alive -> pack the first kept[r] samples of every run into `capacity` slots -> the training pass.
+    # False: every marched sample is trained on, the ones behind the threshold with zero gradients (rounds 1-4).
+    compact_training: bool = True
+    march_capacity: int = 1 << 22         # upstream: max_samples = target_batch_size * 16
     render_first_round: int = 48
     aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
     cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
@@ -160,7 +169,8 @@ class NgpEngine:
         self.density_net.set_option("grid_stream_owner_slices", 127)
         self.density_net.set_option("grid_bwd_runs", 1)
         self.density_net.set_option("grid_bwd_batch", int(cfg.capacity))
-        self.density_net.set_option("prepare_input_gradients", int(bool(cfg.optimize_extrinsics)))
+        self._pig = int(bool(cfg.optimize_extrinsics))  # (the option's value as constructed; launches toggle it around themselves)
+        self.density_net.set_option("prepare_input_gradients", self._pig)
         # neither network stores its hidden activations: the backward recomputes them (bit-identical; less traffic both
         # ways, and the recomputing backward is the one that runs in chain / dW roles)
         self.density_net.set_option("recompute_hidden", 1)
@@ -223,7 +233,11 @@ class NgpEngine:
         self.params_version = 0         # bumped whenever the weights inference reads may have changed (render caches)
         self.n_training_images = None   # images in use (pyngp: nerf.training.n_images_for_training); None = all slots
         self._marked_images = None      # the image count the untrained cells were last marked for
-        self._measured_acc = torch.zeros(1, dtype=torch.int64, device=dev)  # marched samples since the last adaptation
+        self._measured_acc = torch.zeros(1, dtype=torch.int64, device=dev)  # samples per step (after compaction) since the last adaptation
+        # rays in use, ON THE DEVICE: a captured step covers the workspace's rows and reads the batch size here, so the
+        # adaptive ray batch moves without a new capture
+        self._R_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._R_dev_host = -1
         self._measured_n = 0
         self._ws = None                      # the workspace used last
         self._wss = {True: None, False: None}  # one for training, one for inference (switching keeps both, and the captured steps)
@@ -309,6 +323,25 @@ class NgpEngine:
         ws["ctx"] = torch.empty(self.density_net.ctx_bytes(cap), dtype=torch.uint8, device=dev)
         # staging area of the march (ray-major runs of accepted samples): owned here, not by the native side
         ws["march_scratch"] = torch.empty(int(_lib.lib().nvo_occ_march_scratch_bytes(R)), dtype=torch.uint8, device=dev)
+        ws["totals"] = torch.zeros(2, **i32)   # {samples to pack, slots in use} of the last nvo_occ_pack
+        if training and self.cfg.compact_training:
+            # the pass that finds where each ray ends: everything the march found, density network only
+            cap_m = int(max(self.cfg.march_capacity, cap))
+            ws["cap_m"] = cap_m
+            for name, shape in (("t_m", (cap_m,)), ("dt_m", (cap_m,)), ("x01_m", (cap_m, 3))):
+                ws[name] = torch.zeros(*shape, **f32)
+            ws["ray_idx_m"] = torch.full((cap_m,), -1, **i32)
+            ws["density_m"] = torch.zeros(cap_m, **f16)  # (compact output: column 0 alone)
+            if self._pig:
+                self.density_net.set_option("prepare_input_gradients", 0)  # (sizes the ctx without the dy/dx block)
+            ws["ctx_m"] = torch.empty(self.density_net.ctx_bytes(cap_m), dtype=torch.uint8, device=dev)
+            if self._pig:
+                self.density_net.set_option("prepare_input_gradients", 1)
+            ws["counts_m"] = torch.zeros(R, **i32)
+            ws["offsets_m"] = torch.zeros(R + 1, **i32)
+            ws["ray_state"] = torch.zeros(R, **i32)
+            ws["kept"] = torch.zeros(R, **i32)
+            ws["totals_m"] = torch.zeros(2, **i32)
         if training:
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
             ws["d_density_out"] = torch.zeros(cap, 16, **f16)
@@ -330,14 +363,14 @@ class NgpEngine:
 
     _PER_RAY = ("origins", "directions", "directions_norm", "pixel_area", "gt_rgb", "gt_depth", "gt_depth_cov", "dirs01", "out_rgb",
                 "out_depth", "out_accumulation", "cam_idx", "counts", "offsets", "sh", "d_origin", "d_dir", "ray_indices",
-                "jitter", "background", "t_next", "t_resume", "carry")
+                "jitter", "background", "t_next", "t_resume", "carry", "counts_m", "offsets_m", "ray_state", "kept")
 
     @staticmethod
     def _ray_views(ws, R: int):
         """ws[name] = the first R rows of every per-ray buffer (same storage, same base address)."""
         ws["R"] = R
         for k, full in ws["_per_ray"].items():
-            ws[k] = full[:R + 1] if k == "offsets" else full[:R]
+            ws[k] = full[:R + 1] if k in ("offsets", "offsets_m") else full[:R]
         return ws
 
     # ---- density grid ------------------------------------------------------------------------
@@ -406,7 +439,7 @@ class NgpEngine:
         update_training_images on every instant-ngp configuration (nerf_vo/mapping/instant_ngp.py:77-86,93-94); the
         depth residual of a ray is weighted by its inverse (nvo_ngp_loss_args::gt_depth_cov)."""
         stream = _stream(self.device)
-        R = ws["R"]
+        R = ws.get("R_launch", ws["R"])
         H, W = images.shape[1], images.shape[2]
         corr = None
         self._pose_inputs = None
@@ -421,25 +454,81 @@ class NgpEngine:
               _ptr(depths) if depths is not None else None, _ptr(ws["origins"]), _ptr(ws["directions"]),
               _ptr(ws["directions_norm"]), _ptr(ws["pixel_area"]), _ptr(ws["cam_idx"]), _ptr(ws["gt_rgb"]),
               _ptr(ws["gt_depth"]), _ptr(ws["dirs01"]), _ptr(ws["sh"]),
-              _ptr(depths_cov) if (depths is not None and depths_cov is not None) else None, _ptr(ws["gt_depth_cov"]))
+              _ptr(depths_cov) if (depths is not None and depths_cov is not None) else None, _ptr(ws["gt_depth_cov"]),
+              self._rdev(ws))
         ws["has_depth_cov"] = depths is not None and depths_cov is not None
         ws["sh_ready"] = True
 
+    def _rdev(self, ws):
+        """Device ray count of a launch that covers the workspace's rows (graphed steps), or None."""
+        return _ptr(self._R_dev) if ws.get("R_launch") else None
+
     def _forward(self, ws, training: bool, jitter, stream) -> None:
-        self._march(ws, jitter, stream)
+        if training and self.cfg.compact_training and "cap_m" in ws:
+            self._march_compact(ws, jitter, stream)
+        else:
+            self._march(ws, jitter, stream)
         self._shade(ws, training, stream)
 
     def _march(self, ws, jitter, stream, t_resume=None, max_new: int = 1024, t_next=None) -> None:
-        """Packed samples of the workspace's rays: counts / offsets (offsets[R] = samples found, before rays were dropped
-        at the capacity), ray_idx / t / dt.  ``t_resume`` / ``max_new`` / ``t_next``: one round of a march in rounds
+        """Packed samples of the workspace's rays: counts / offsets (offsets[R] = totals[0] = samples found, before rays were
+        dropped at the capacity), ray_idx / t / dt.  ``t_resume`` / ``max_new`` / ``t_next``: one round of a march in rounds
         (nvo_occ_march_resume)."""
         cfg = self.cfg
-        R, cap = ws["R"], ws["cap"]
+        R, cap = ws.get("R_launch", ws["R"]), ws["cap"]
+        rdev = self._rdev(ws)
+        ws.pop("ray_state_on", None)
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
-        _call("nvo_occ_march_resume", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
-              cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), cap, _ptr(ws["counts"]),
-              _ptr(ws["offsets"]), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), _ptr(ws["march_scratch"]),
-              ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next))
+        _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
+              cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts"]), _ptr(ws["march_scratch"]),
+              ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next), rdev)
+        _call("nvo_occ_pack", stream, R, _ptr(ws["counts"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
+              _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev)
+
+    def _march_compact(self, ws, jitter, stream) -> None:
+        """The training batch as upstream builds it (NgpConfig.compact_training): march -> everything found packed into the
+        `march_capacity` slots -> density network on the slots in use -> where each ray's transmittance falls below
+        train_min_transmittance (kept[r], ray_state[r]) -> the first kept[r] samples of every run packed into the training
+        slots.  Leaves counts / offsets / ray_idx / t / dt of the COMPACTED batch (totals[0] = its size before rays were
+        dropped at the capacity: what the adaptive ray batch measures) and ray_state for the loss kernel."""
+        cfg = self.cfg
+        R, cap, cap_m = ws.get("R_launch", ws["R"]), ws["cap"], ws["cap_m"]
+        rdev = self._rdev(ws)
+        lo, hi = cfg.aabb
+        nscr = ws["march_scratch"].numel()
+        n_live = C.c_void_p(ws["totals_m"].data_ptr() + 4)
+        _call("nvo_fill_i32", stream, cap_m, _ptr(ws["ray_idx_m"]), -1)
+        _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
+              cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts_m"]), _ptr(ws["march_scratch"]),
+              nscr, None, 1024, None, rdev)
+        _call("nvo_occ_pack", stream, R, _ptr(ws["counts_m"]), cap_m, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
+              _ptr(ws["totals_m"]), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev)
+        _call("nvo_ngp_positions_live", stream, cap_m, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["origins"]),
+              _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]), n_live)
+        # density alone (column 0, compact), no d(encoded)/d(position), tiles past the slots in use skipped; the raw weights
+        # (the training pass behind this evaluates the same ones)
+        net = self.density_net
+        net.set_option("n_live_ptr", n_live.value)
+        net.set_option("compact_output", 1)
+        if self._pig:
+            net.set_option("prepare_input_gradients", 0)
+        try:
+            _call("nvo_fwd", net.handle, stream, cap_m, _ptr(ws["x01_m"]), self._pp("density", self.params_half),
+                  _ptr(ws["density_m"]), _ptr(ws["ctx_m"]))
+        finally:
+            net.set_option("n_live_ptr", 0)
+            net.set_option("compact_output", 0)
+            if self._pig:
+                net.set_option("prepare_input_gradients", 1)
+        aa = _lib.NgpAliveArgs(R=R, counts=ws["counts_m"].data_ptr(), offsets=ws["offsets_m"].data_ptr(),
+                               dt=ws["dt_m"].data_ptr(), density_out=ws["density_m"].data_ptr(), density_stride=1,
+                               min_transmittance=float(cfg.train_min_transmittance), kept=ws["kept"].data_ptr(),
+                               state=ws["ray_state"].data_ptr(), R_dev=None if rdev is None else rdev.value)
+        _call("nvo_ngp_count_alive", stream, C.byref(aa))
+        _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
+        _call("nvo_occ_pack", stream, R, _ptr(ws["kept"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
+              _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev)
+        ws["ray_state_on"] = True
 
     def _shade(self, ws, training: bool, stream) -> None:
         cfg = self.cfg
@@ -483,8 +572,11 @@ class NgpEngine:
                    accumulate: bool = False):
         cfg = self.cfg
         R = ws["R"]
+        R_launch = ws.get("R_launch", R) if training else R
+        rdev = self._rdev(ws) if training else None
+        compact = bool(training and ws.get("ray_state_on"))
         return _lib.NgpLossArgs(
-            R=R, capacity=ws.get("n_launch", ws["cap"]), counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
+            R=R_launch, capacity=ws.get("n_launch", ws["cap"]), counts=ws["counts"].data_ptr(), offsets=ws["offsets"].data_ptr(),
             ray_idx=ws["ray_idx"].data_ptr(), t=ws["t"].data_ptr(), dt=ws["dt"].data_ptr(),
             density_out=ws["density_out"].data_ptr(), density_stride=16, rgb_out=ws["rgb_out"].data_ptr(), rgb_stride=16,
             background=None if background is None else background.data_ptr(),
@@ -498,8 +590,11 @@ class NgpEngine:
             d_density_pre=ws["d_density_pre"].data_ptr() if training else None,
             carry_in=None if carry_in is None else carry_in.data_ptr(),
             carry_out=None if carry_out is None else carry_out.data_ptr(), accumulate_outputs=int(bool(accumulate)),
-            train_min_transmittance=float(cfg.train_min_transmittance) if training else 0.0,
-            gt_depth_cov=ws["gt_depth_cov"].data_ptr() if (training and has_depth and ws.get("has_depth_cov")) else None)
+            # (a compacted batch holds no sample behind the threshold: nothing to switch off)
+            train_min_transmittance=float(cfg.train_min_transmittance) if (training and not compact) else 0.0,
+            gt_depth_cov=ws["gt_depth_cov"].data_ptr() if (training and has_depth and ws.get("has_depth_cov")) else None,
+            ray_state=ws["ray_state"].data_ptr() if compact else None, R_dev=None if rdev is None else rdev.value,
+            world_size=int(self.world_size))
 
     def forward_backward(self, ws, jitter, has_depth: bool = True, background=None, leaf_flags: bool = False,
                          fused_adam=None) -> None:
@@ -569,10 +664,10 @@ class NgpEngine:
         trains the extrinsics from the position gradient alone)."""
         cfg = self.cfg
         lo, hi = cfg.aabb
-        R = ws["R"]
-        _call("nvo_ngp_positions_bwd", stream, R, cfg.capacity, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["t"]),
+        R = ws.get("R_launch", ws["R"])
+        _call("nvo_ngp_positions_bwd_dev", stream, R, cfg.capacity, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["t"]),
               _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["dx01"]), _ptr(ws["d_origin"]),
-              _ptr(ws["d_dir"]))
+              _ptr(ws["d_dir"]), self._rdev(ws))
         intr, c2w = self._pose_inputs
         _call("nvo_pose_bwd_cams", stream, R, _ptr(ws["ray_indices"]), _ptr(intr), _ptr(c2w), _ptr(ws["d_origin"]),
               _ptr(ws["d_dir"]), None, _ptr(self.d_corrections), cfg.num_images)  # (adds into the window's total)
@@ -781,7 +876,7 @@ class NgpEngine:
         if self.cfg.adaptive_rays:
             # samples the march found in this step, BEFORE rays were dropped at the packed capacity (the scan's total):
             # a capped measure could never exceed the target, so the batch would only ever grow
-            self._measured_acc.add_(ws["offsets"][-1:])
+            self._measured_acc.add_(ws["totals"][:1])
 
     _MAX_GRAPHS = 48
 
@@ -789,9 +884,10 @@ class NgpEngine:
                             depths_cov=None) -> None:
         """The step as ONE hipGraph replay (NgpConfig.graph_step).  In front of it, eager: the caller's ray indices are
         copied and the march jitter is drawn into the workspace's fixed buffers (same generator calls as the eager step).
-        Captured once per ray count (the adaptive batch moves it every `density_update_every` steps, usually between a
-        few neighbouring values) and set of input buffers; the very first step of an engine runs eagerly so that every
-        kernel's code object is loaded before anything is recorded."""
+        Captured once per WORKSPACE SIZE (rows: the next power of two above the ray count) and set of input buffers: the
+        per-ray launches cover the workspace's rows and read the batch size from the device (self._R_dev), so the adaptive
+        ray batch moves without a new capture; the very first step of an engine runs eagerly so that every kernel's code
+        object is loaded before anything is recorded."""
         cfg = self.cfg
         R = ws["R"]
         ws["ray_indices"].copy_(ray_indices)
@@ -811,7 +907,18 @@ class NgpEngine:
         if cfg.ema_decay > 0.0 and self.params_ema is None:  # (allocated outside the capture)
             self.params_ema = torch.zeros_like(self.params)
             self.params_ema_half = torch.zeros_like(self.params_half)
-        key = (R, ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
+        if self._R_dev_host != R:
+            self._R_dev.fill_(R)
+            self._R_dev_host = R
+        ws["R_launch"] = ws["R_cap"]
+        try:
+            self._replay_step(ws, intrinsics, c2w, images, depths, cam_update, depths_cov, bg)
+        finally:
+            del ws["R_launch"]
+
+    def _replay_step(self, ws, intrinsics, c2w, images, depths, cam_update, depths_cov, bg) -> None:
+        cfg = self.cfg
+        key = (ws["R_cap"], bool(cfg.compact_training), int(cfg.march_capacity), ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
                None if depths is None else depths.data_ptr(), None if depths_cov is None else depths_cov.data_ptr(),
                bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
                bool(cam_update), self._camera_grad_scale() if cam_update else 0.0, self._fused_adam_plan(),
@@ -896,7 +1003,7 @@ class NgpEngine:
 
     def samples_last_step(self) -> int:
         ws = self._wss[True]  # (the training workspace: an inference call in between has its own)
-        return int(min(int(ws["offsets"][-1].item()), ws["cap"])) if ws is not None else 0
+        return int(ws["totals"][1].item()) if ws is not None else 0
 
     @torch.no_grad()
     def render_rays(self, origins, directions, directions_norm, min_transmittance=None):
@@ -918,7 +1025,7 @@ class NgpEngine:
         min_t = float(cfg.render_min_transmittance if min_transmittance is None else min_transmittance)
         first = int(cfg.render_first_round) if min_t > 0.0 else 1024
         self._march(ws, None, stream, None, first, ws["t_next"] if min_t > 0.0 else None)
-        found = int(ws["offsets"][-1].item())
+        found = int(ws["totals"][0].item())
         self.last_render_samples = found  # (callers size their next bundle from it: pyngp.Testbed.render)
         if R > 1 and found > ws["cap"]:
             h = R // 2
@@ -955,8 +1062,8 @@ class NgpEngine:
         tr = ws["t_resume"]
         tr.fill_(-1.0)
         tr[lo:hi] = resume[lo:hi]
-        self._march(ws, None, stream, tr, 1024, None)
-        found = int(ws["offsets"][-1].item())
+        self._march(ws, None, stream, tr, 1024 - int(self.cfg.render_first_round), None)
+        found = int(ws["totals"][0].item())
         if found > ws["cap"] and hi - lo > 1:
             mid = (lo + hi) // 2
             return max(self._render_second_round(ws, resume, lo, mid, stream),

@@ -35,10 +35,17 @@ class NgpOracle:
         return O.march_rays(origins.float().numpy(), directions.float().numpy(), bitfield, self.n_levels,
                             self.cone_angle, self.near, np.zeros(len(origins)) if jitter is None else jitter.numpy())
 
-    def forward(self, origins, directions, counts, t, dt, background=None, sh_directions=None):
+    def forward(self, origins, directions, counts, t, dt, background=None, sh_directions=None, kept=None):
         """Packed forward for the samples found by march().  Returns per-ray rgb, depth, accumulation.
         ``sh_directions``: directions used for the SH encoding (default: ``directions``); the extrinsics
-        optimiser differentiates the sample positions only, its test passes a detached copy here."""
+        optimiser differentiates the sample positions only, its test passes a detached copy here.
+        ``kept`` [R] (training on the compacted batch, alive_counts() below): ray r is composited over its first kept[r]
+        samples only, and sees the background only when nothing was cut (kept[r] == counts[r])
+        [UPSTREAM compute_loss_kernel_train_nerf: `if (T < EPSILON) break` / `if (compacted_numsteps == numsteps)
+        rgb_ray += T * background_color`]."""
+        full_counts = counts
+        if kept is not None:
+            counts = np.asarray(kept).astype(counts.dtype)
         P = self.params
         R = origins.shape[0]
         ray_idx = np.repeat(np.arange(R), counts.astype(np.int64))
@@ -70,6 +77,8 @@ class NgpOracle:
             w = (1 - torch.exp(-ddens)) * T
             Tf = torch.exp(-ddens.sum()) if n else torch.ones((), dtype=torch.float64)
             bg = background[r] if background is not None else torch.zeros(3, dtype=torch.float64)
+            if int(full_counts[r]) != n:  # (cut at the transmittance threshold)
+                bg = torch.zeros(3, dtype=torch.float64)
             out_rgb.append((w[:, None] * c).sum(0) + Tf * bg)
             out_depth.append((w * ts).sum())
             out_acc.append(w.sum())
@@ -93,3 +102,34 @@ class NgpOracle:
                 mask = mask * torch.where(ok, 1.0 / torch.where(ok, var, torch.ones_like(var)), torch.zeros_like(var))
             d["depth_loss"] = self.depth_mult * torch.mean(((depth - z) ** 2) * mask)
         return d
+
+
+def alive_counts(counts, dt, density_pre, min_transmittance=1e-4):
+    """numpy restatement of nvo_ngp_count_alive [UPSTREAM instant-ngp compute_loss_kernel_train_nerf: the loop over a
+    ray's samples opens with `if (T < EPSILON) break`, EPSILON = 1e-4]: kept[r] = index of the first sample ray r reaches
+    with a transmittance T_j = exp(-sum_{i<j} min(exp(pre_i) dt_i, 128)) below the threshold (counts[r] when none is).
+    counts [R]; dt, density_pre: ray-major lists / [R, max] arrays of the marched samples.  Also returns, per ray, how close
+    the deciding transmittances came to the threshold (min |T / thr - 1| over its samples): a ray whose margin is below the
+    kernel's fp32 rounding (~1e-5) is a tie that may legitimately fall either way."""
+    R = len(counts)
+    kept = np.zeros(R, dtype=np.int64)
+    margin = np.full(R, np.inf)
+    for r in range(R):
+        n = int(counts[r])
+        if n == 0:
+            continue
+        dd = np.minimum(np.exp(np.asarray(density_pre[r][:n], dtype=np.float64)) * np.asarray(dt[r][:n], dtype=np.float64), 128.0)
+        T = np.exp(-(np.cumsum(dd) - dd))
+        below = np.nonzero(T < min_transmittance)[0]
+        kept[r] = below[0] if len(below) else n
+        margin[r] = np.min(np.abs(T / min_transmittance - 1.0))
+    return kept, margin
+
+
+def compact_offsets(kept, capacity):
+    """The packing rule of nvo_occ_pack: exclusive scan of kept[R]; a ray whose samples would pass ``capacity`` is dropped
+    (count 0) and keeps its slot range.  Returns (counts, offsets [R+1], total)."""
+    kept = np.asarray(kept, dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(kept)])
+    counts = np.where(offsets[:-1] + kept > capacity, 0, kept)
+    return counts, offsets, int(offsets[-1])

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 def _engine(device, **kw):
     from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
 
+    kw.setdefault("march_capacity", 1 << 17)
     cfg = NgpConfig(num_images=4, capacity=1 << 15, **kw)
     eng = NgpEngine(cfg, device)
     g = torch.Generator().manual_seed(9)
@@ -40,14 +41,23 @@ def _oracle(eng):
     return orc
 
 
-@pytest.mark.parametrize("cov", ["none", "ones", "varying"])
-def test_ngp_step_matches_oracle(device, cov):
+@pytest.mark.parametrize("cov,compact", [("none", True), ("ones", True), ("varying", True), ("none", False)])
+def test_ngp_step_matches_oracle(device, cov, compact):
     """``cov``: the per-ray variance of the depth target (nvo_ngp_loss_args::gt_depth_cov) -- absent, all ones (must be
     the absent case bit for bit) or spread over three decades with zeros, negatives and inf mixed in (rays whose depth
-    term is dropped)."""
+    term is dropped).  ``compact``: the batch that is trained on holds the samples in front of T < 1e-4 only
+    (NgpConfig.compact_training, upstream's training-batch compaction): marched samples bit for bit, kept counts against the
+    numpy restatement on the kernel's own density outputs, packing rule, then the step against the oracle composited over
+    the kept samples."""
     from oracle import occgrid as O
+    from oracle import ngp as ON
 
-    eng = _engine(device)
+    eng = _engine(device, compact_training=compact)
+    if compact:  # denser medium: a good share of the rays must end in front of their last sample
+        nd = eng.n_density_mlp
+        boosted = eng.params.clone()
+        boosted[:nd] *= 3.0
+        eng.set_params(boosted)
     # a structured occupancy grid (independent of the network) so that rays see gaps and hits
     rng = np.random.default_rng(3)
     grid = (rng.random((eng.cfg.n_levels, O.CELLS), dtype=np.float32) ** 8) * 0.05
@@ -86,6 +96,16 @@ def test_ngp_step_matches_oracle(device, cov):
         ws["has_depth_cov"] = True
     eng.forward_backward(ws, jitter.to(device), has_depth=True, background=bg.to(device))
     torch.cuda.synchronize()
+    if compact:
+        # the threshold of THIS test: the median of the transmittance the rays end with, so that about half of them are cut
+        # (with random weights next to no ray reaches the production 1e-4)
+        om, cm = ws["offsets_m"].cpu().numpy(), ws["counts_m"].cpu().numpy()
+        dm, dtm = ws["density_m"].float().cpu().numpy().astype(np.float64), ws["dt_m"].cpu().numpy().astype(np.float64)
+        t_end = np.array([np.exp(-np.sum(np.minimum(np.exp(dm[om[r]:om[r] + cm[r]]) * dtm[om[r]:om[r] + cm[r]], 128.0))) for r in range(R)])
+        eng.cfg.train_min_transmittance = float(np.median(t_end[cm > 0]))
+        assert 1e-6 < eng.cfg.train_min_transmittance < 0.999
+        eng.forward_backward(ws, jitter.to(device), has_depth=True, background=bg.to(device))
+        torch.cuda.synchronize()
     if cov == "ones":
         # the plain L2 term, bit for bit: the per-sample gradients the loss kernel writes (the parameter gradients behind
         # them and the loss shards are sums of float atomics, whose order varies from launch to launch)
@@ -100,16 +120,36 @@ def test_ngp_step_matches_oracle(device, cov):
 
     orc = _oracle(eng)
     counts, t, dt = orc.march(origins, directions, bf, jitter)
-    got_counts = ws["counts"].cpu().numpy().astype(np.uint32)
+    sfx = "_m" if compact else ""
+    got_counts = ws["counts" + sfx].cpu().numpy().astype(np.uint32)
     assert int(counts.sum()) <= eng.cfg.capacity and counts.sum() > 500
     assert (got_counts == counts).all()
-    off = ws["offsets"].cpu().numpy()
-    tt = ws["t"].cpu().numpy()
+    off = ws["offsets" + sfx].cpu().numpy()
+    tt = ws["t" + sfx].cpu().numpy()
     for r in range(R):
         n = int(counts[r])
         assert (tt[off[r]:off[r] + n].view(np.uint32) == t[r, :n].view(np.uint32)).all()
+    kept = None
+    if compact:
+        dens = ws["density_m"].float().cpu().numpy()
+        thr = eng.cfg.train_min_transmittance
+        kept_ref, margin = ON.alive_counts(counts, [dt[r] for r in range(R)], [dens[off[r]:off[r] + int(counts[r])] for r in range(R)], thr)
+        kept = ws["kept"].cpu().numpy().astype(np.int64)
+        tie = margin < 1e-5  # (a transmittance within the kernel's fp32 rounding of the threshold may fall either way)
+        assert (kept == kept_ref)[~tie].all() and (np.abs(kept - kept_ref) <= 1).all() and tie.sum() <= R // 4
+        cut = kept < counts
+        assert cut.sum() >= 10 and (~cut & (counts > 0)).sum() >= 10, (cut.sum(), (~cut).sum())
+        assert (ws["ray_state"].cpu().numpy() == cut.astype(np.int32)).all()
+        c2, o2, total = ON.compact_offsets(kept, eng.cfg.capacity)
+        assert (ws["counts"].cpu().numpy() == c2).all() and (ws["offsets"].cpu().numpy() == o2).all()
+        assert ws["totals"].cpu().tolist() == [total, min(total, eng.cfg.capacity)] and total == int(kept.sum())
+        tc, rc = ws["t"].cpu().numpy(), ws["ray_idx"].cpu().numpy()
+        for r in range(R):
+            n = int(kept[r])
+            assert (tc[o2[r]:o2[r] + n].view(np.uint32) == t[r, :n].view(np.uint32)).all() and (rc[o2[r]:o2[r] + n] == r).all()
+        assert (rc[total:] == -1).all()
 
-    rgb, depth, acc = orc.forward(origins.double(), directions.double(), counts, t, dt, background=bg.double())
+    rgb, depth, acc = orc.forward(origins.double(), directions.double(), counts, t, dt, background=bg.double(), kept=kept)
     ld = orc.loss_dict(rgb, depth, gt_rgb.double(), gt_depth.double(), dnorm.double(),
                        None if gt_cov is None else gt_cov.double())
     sum(ld.values()).backward()
