@@ -519,14 +519,16 @@ int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, 
  *                       first counts_out[r] samples of every run are copied to (ray_idx, t, dt) at offsets[r].
  *                       totals (nullable): device uint32[2] = {sum of counts_in, min(that, capacity)}.
  * R_dev (nullable): device uint32, the number of rays in use -- the launch covers R rows, rows from *R_dev on are left
- * alone (a captured step is replayed while the adaptive ray batch moves). */
+ * alone (a captured step is replayed while the adaptive ray batch moves).
+ * run_offset: a march in rounds appends a later round behind the samples the earlier rounds left in the ray's run (the
+ * march writes from run[run_offset] on, the pack reads from there): run_offset + max_new <= 1024. */
 int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
                        const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                        uint32_t* counts, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
-                       float* t_next, const uint32_t* R_dev);
+                       float* t_next, const uint32_t* R_dev, uint32_t run_offset);
 int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
                  uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
-                 float* t_out, float* dt_out, const uint32_t* R_dev);
+                 float* t_out, float* dt_out, const uint32_t* R_dev, uint32_t run_offset);
 /* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
  * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
  * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.
@@ -653,6 +655,18 @@ typedef struct nvo_ngp_alive_args {
     uint32_t* kept;              /* [R] */
     uint32_t* state;             /* [R] */
     const uint32_t* R_dev;       /* nullable: device ray count */
+    /* In ROUNDS (the march of nvo_occ_march_runs with max_new / t_next / t_resume): a round looks at the samples its march
+     * added.  resume_in (nullable) [R]: rays with a negative entry are not part of this round (kept / state stay);
+     * carry_in (nullable) [R]: optical depth the ray gathered in earlier rounds; kept_base: samples of the earlier rounds
+     * (kept = kept_base + index inside this round).  A ray that is neither cut nor dropped and whose march stopped at
+     * its sample budget (t_next[r] >= 0) goes on: resume_out[r] = t_next[r], carry_out[r] = its optical depth so far;
+     * every other ray gets resume_out[r] = -1.  t_next / resume_out / carry_out NULL: a single round. */
+    const float* resume_in;
+    const float* carry_in;
+    uint32_t kept_base;
+    const float* t_next;
+    float* resume_out;
+    float* carry_out;
 } nvo_ngp_alive_args;
 int nvo_ngp_count_alive(nvo_stream_t stream, const nvo_ngp_alive_args* args);
 /* nvo_ngp_positions with the number of slots in use on the device (n_live, nullable): slots from the next multiple of

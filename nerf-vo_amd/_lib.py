@@ -115,7 +115,8 @@ class NgpLossArgs(C.Structure):
 class NgpAliveArgs(C.Structure):
     """mirror of nvo_ngp_alive_args"""
     _fields_ = [("R", _u32), ("counts", _p), ("offsets", _p), ("dt", _p), ("density_out", _p), ("density_stride", _u32),
-                ("min_transmittance", _f), ("kept", _p), ("state", _p), ("R_dev", _p)]
+                ("min_transmittance", _f), ("kept", _p), ("state", _p), ("R_dev", _p), ("resume_in", _p), ("carry_in", _p),
+                ("kept_base", _u32), ("t_next", _p), ("resume_out", _p), ("carry_out", _p)]
 
 
 _SIGNATURES = {
@@ -179,8 +180,8 @@ _SIGNATURES = {
     "nvo_occ_cell_positions": (_int, [_p, _int, _p, _p]),
     "nvo_occ_mark_untrained": (_int, [_p, _int, _p, _u32, _p, _p, _u32, _u32, _f]),
     "nvo_occ_sample_cells": (_int, [_p, _u32, _u32, _u32, _u32, _u32, _u32, _int, _p, _f, _f, _f, _p, _p]),
-    "nvo_occ_march_runs": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _p, _p, _u64, _p, _u32, _p, _p]),
-    "nvo_occ_pack": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p]),
+    "nvo_occ_march_runs": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _p, _p, _u64, _p, _u32, _p, _p, _u32]),
+    "nvo_occ_pack": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p, _u32]),
     "nvo_ngp_count_alive": (_int, [_p, C.POINTER(NgpAliveArgs)]),
     "nvo_ngp_positions_live": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p, _p]),
     "nvo_ngp_positions_bwd_dev": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p]),

@@ -284,17 +284,15 @@ k_ngp_count_alive(nvo_ngp_alive_args a) {
     uint32_t R = a.R;
     if (a.R_dev) R = min(R, *a.R_dev);
     if (r >= R) return;
-    const uint32_t n = a.counts[r];
-    const uint32_t base = a.offsets[r];
-    if (n == 0u) {
-        if (lane == 0) {
-            a.kept[r] = 0u;
-            a.state[r] = (a.offsets[r + 1] != base) ? 2u : 0u;
-        }
+    if (a.resume_in && !(a.resume_in[r] >= 0.f)) {  // not part of this round: the earlier rounds settled it
+        if (lane == 0 && a.resume_out) a.resume_out[r] = -1.f;
         return;
     }
+    const uint32_t n = a.counts[r];
+    const uint32_t base = a.offsets[r];
+    const bool dropped = n == 0u && a.offsets[r + 1] != base;
     const _Float16* den = (const _Float16*)a.density_out;
-    float carry = 0.f;
+    float carry = a.carry_in ? a.carry_in[r] : 0.f;
     uint32_t kept = n;
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
         const uint32_t j = c0 + lane;
@@ -313,8 +311,17 @@ k_ngp_count_alive(nvo_ngp_alive_args a) {
         carry = nvo_wave_bcast(incl, 63);
     }
     if (lane == 0) {
-        a.kept[r] = kept;
-        a.state[r] = kept < n ? 1u : 0u;
+        const bool cut = kept < n;
+        a.kept[r] = dropped ? 0u : a.kept_base + kept;
+        a.state[r] = dropped ? 2u : (cut ? 1u : 0u);
+        if (a.resume_out) {
+            // goes on: every sample of this round kept, and the march stopped at its budget, not at the scene box.
+            // (A ray whose transmittance falls below the threshold exactly BEHIND the round's last sample is found in the
+            // next round, at its first sample: kept = kept_base' + 0, cut.)
+            const bool more = !dropped && !cut && a.t_next && a.t_next[r] >= 0.f;
+            a.resume_out[r] = more ? a.t_next[r] : -1.f;
+            if (a.carry_out) a.carry_out[r] = carry;
+        }
     }
 }
 

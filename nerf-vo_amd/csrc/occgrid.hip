@@ -188,7 +188,7 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
                  const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
                  const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch,
                  const float* __restrict__ t_resume, uint32_t max_new, float* __restrict__ t_next,
-                 const uint32_t* __restrict__ R_dev) {
+                 const uint32_t* __restrict__ R_dev, uint32_t run_offset) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     if (R_dev) R = min(R, *R_dev);  // the launch covers the buffers' rows, the batch is the first *R_dev of them
@@ -222,7 +222,8 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
         if (t0 > tmin) tmin = t0;
         if (t1 < tmax) tmax = t1;
     }
-    float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
+    // (run_offset: a later round appends behind the samples the ray's earlier rounds left in its run)
+    float2* __restrict__ run = scratch + (size_t)r * kMaxSteps + run_offset;
     uint32_t j = 0;  // accepted so far (uniform)
     if (tmax > tmin) {
         float t = t_resume ? resume : tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);  // candidate 0 of the current block
@@ -297,12 +298,12 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
 __global__ void __launch_bounds__(256)
 k_occ_compact(uint32_t R, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
               const float2* __restrict__ scratch, int32_t* __restrict__ ray_idx, float* __restrict__ t_out,
-              float* __restrict__ dt_out, const uint32_t* __restrict__ R_dev) {
+              float* __restrict__ dt_out, const uint32_t* __restrict__ R_dev, uint32_t run_offset) {
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (R_dev) R = min(R, *R_dev);
     if (r >= R) return;
     const uint32_t n = counts[r], base = offsets[r];
-    const float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
+    const float2* __restrict__ run = scratch + (size_t)r * kMaxSteps + run_offset;
     for (uint32_t k = threadIdx.x & 63u; k < n; k += 64u) {
         const float2 v = run[k];
         ray_idx[base + k] = (int32_t)r;
@@ -316,40 +317,51 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return
 // Single-workgroup exclusive scan of counts_in[n] -> offsets[n], total in offsets[n]; entries that would
 // push the running total beyond `capacity` are treated as 0 in counts_out (counts_out == counts_in: in place).
 // totals (nullable): [0] = the total BEFORE the clamp, [1] = min(total, capacity) = the packed slots in use.
+template <int PER>
 __global__ void __launch_bounds__(1024)
 k_scan_counts(uint32_t n, const uint32_t* counts_in, uint32_t* counts_out, uint32_t* __restrict__ offsets,
               uint32_t capacity, uint32_t* __restrict__ totals, const uint32_t* __restrict__ n_dev) {
+    // One pass: thread i owns the PER consecutive entries [i * PER, (i + 1) * PER), all requested before the first is used
+    // (the first form walked the array in 1024-entry rounds with three barriers each, the second read its entries one
+    // dependent load after the other: 19-21 us for 13 K rays either way, three launches per step), then ONE scan of the
+    // 1024 sums across the workgroup and the prefixes from registers.
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t c = i < n ? counts_in[i] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(c, lane);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t prefix = carry_s;
-        for (int w = 0; w < wave; ++w) prefix += wave_tot[w];
-        uint32_t excl = prefix + incl - c;
-        if (i < n) offsets[i] = excl;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = prefix + incl;
-        __syncthreads();
+    const uint32_t first = threadIdx.x * PER;
+    uint32_t c[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) c[k] = counts_in[min(first + (uint32_t)k, n ? n - 1u : 0u)];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (first + (uint32_t)k >= n) c[k] = 0u;
+        sum += c[k];
     }
-    // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t c = counts_in[i];
-        counts_out[i] = (offsets[i] + c > capacity) ? 0u : c;
+    uint32_t prefix = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) prefix += wave_tot[w];
+        total += wave_tot[w];
+    }
+    uint32_t run = prefix + incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = first + (uint32_t)k;
+        if (i < n) {
+            offsets[i] = run;
+            // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
+            counts_out[i] = (run + c[k] > capacity) ? 0u : c[k];
+            run += c[k];
+        }
     }
     if (threadIdx.x == 0) {
-        offsets[n] = carry_s;
+        offsets[n] = total;
         if (totals) {
-            totals[0] = carry_s;
-            totals[1] = carry_s < capacity ? carry_s : capacity;
+            totals[0] = total;
+            totals[1] = total < capacity ? total : capacity;
         }
     }
 }
@@ -563,18 +575,20 @@ int nvo_occ_march_resume(nvo_stream_t stream, uint32_t R, const float* origins, 
                          float* t_next) {
     NVO_REQUIRE(R == 0 || (counts && offsets && ray_idx && t_out && dt_out), "occ_march: NULL argument");
     if (int rc = nvo_occ_march_runs(stream, R, origins, directions, bitfield, n_levels, cone_angle, t_near, jitter, counts,
-                                    scratch, scratch_bytes, t_resume, max_new, t_next, nullptr))
+                                    scratch, scratch_bytes, t_resume, max_new, t_next, nullptr, 0u))
         return rc;
     return nvo_occ_pack(stream, R, counts, capacity, counts, offsets, nullptr, scratch, scratch_bytes, ray_idx, t_out, dt_out,
-                        nullptr);
+                        nullptr, 0u);
 }
 
 int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, const float* directions,
                        const uint8_t* bitfield, int n_levels, float cone_angle, float t_near, const float* jitter,
                        uint32_t* counts, void* scratch, uint64_t scratch_bytes, const float* t_resume, uint32_t max_new,
-                       float* t_next, const uint32_t* R_dev) {
+                       float* t_next, const uint32_t* R_dev, uint32_t run_offset) {
     NVO_REQUIRE(n_levels >= 1 && n_levels <= 8, "occ_march: n_levels %d not in 1..8", n_levels);
     NVO_REQUIRE(max_new >= 1, "occ_march: max_new must be positive");
+    NVO_REQUIRE((uint64_t)run_offset + (max_new < kMaxSteps ? max_new : kMaxSteps) <= kMaxSteps,
+                "occ_march: run_offset %u + max_new %u pass the %u samples a run holds", run_offset, max_new, kMaxSteps);
     NVO_REQUIRE(R == 0 || (origins && directions && bitfield && counts), "occ_march: NULL argument");
     if (R == 0) return NVO_OK;
     // ray-major staging area of the single march: CALLER-owned (it used to be a process-global block that was freed
@@ -586,12 +600,12 @@ int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, co
     float2* march_scratch = static_cast<float2*>(scratch);
     NVO_PROF(stream, "occ_march");
     static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
-    if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps && !R_dev) {  // (A/B switch: the sequential form, one ray per lane)
+    if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps && !R_dev && !run_offset) {  // (A/B switch: the sequential form, one ray per lane)
         NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
                    n_levels, cone_angle, t_near, jitter, counts, march_scratch);
     } else {
         NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
-                   n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next, R_dev);
+                   n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next, R_dev, run_offset);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;
@@ -599,20 +613,24 @@ int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, co
 
 int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
                  uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
-                 float* t_out, float* dt_out, const uint32_t* R_dev) {
+                 float* t_out, float* dt_out, const uint32_t* R_dev, uint32_t run_offset) {
+    NVO_REQUIRE(run_offset < kMaxSteps, "occ_pack: run_offset %u outside a run", run_offset);
     NVO_REQUIRE(R == 0 || (counts_in && counts_out && offsets && scratch && ray_idx && t_out && dt_out), "occ_pack: NULL argument");
     NVO_REQUIRE(scratch_bytes >= nvo_occ_march_scratch_bytes(R), "occ_pack: scratch too small for %u rays", R);
     if (R == 0) return NVO_OK;
     hipStream_t s = (hipStream_t)stream;
     {
         NVO_PROF(stream, "occ_scan");
-        NVO_LAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        NVO_REQUIRE(R <= 65536u, "occ_pack: at most 65536 rays per launch (got %u)", R);
+        if (R <= 4096u) NVO_LAUNCH(k_scan_counts<4>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        else if (R <= 16384u) NVO_LAUNCH(k_scan_counts<16>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        else NVO_LAUNCH(k_scan_counts<64>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
         NVO_CHECK_LAUNCH();
     }
     {
         NVO_PROF(stream, "occ_compact");
         NVO_LAUNCH(k_occ_compact, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, counts_out, offsets,
-                   static_cast<const float2*>(scratch), ray_idx, t_out, dt_out, R_dev);
+                   static_cast<const float2*>(scratch), ray_idx, t_out, dt_out, R_dev, run_offset);
         NVO_CHECK_LAUNCH();
     }
     return NVO_OK;

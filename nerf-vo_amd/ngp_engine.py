@@ -58,6 +58,13 @@ class NgpConfig:
     # False: every marched sample is trained on, the ones behind the threshold with zero gradients (rounds 1-4).
     compact_training: bool = True
     march_capacity: int = 1 << 22         # upstream: max_samples = target_batch_size * 16
+    # The pass that finds where the rays end runs in ROUNDS: the first train_rounds[0] samples of every ray, then the next
+    # train_rounds[1] of the rays that are neither cut nor out of the scene box yet, ..., at last the rest of the march of
+    # those still going (late in training a ray keeps ~20 of the ~230 samples its march finds: the density network sees a
+    # sixth of them, and most rays never march past their first 32 samples; measured at step 5000 of the bench
+    # scene: one round 1.34 ms/step, (32,) 0.95, (24, 24) 0.98, (16, 16, 32) 1.05 -- a round costs ~40 us whatever it holds).  Same kept counts as one pass up to
+    # transmittances within fp32 rounding of the threshold; everything stays on the device.  () = one round.
+    train_rounds: tuple = (32,)
     render_first_round: int = 48
     aabb_scale: int = 4                   # /root/reference/nerf_vo/mapping/instant_ngp.py:41
     cone_angle: float = 1.0 / 256.0       # instant-ngp: 0 for aabb_scale <= 1, else 1/256
@@ -341,7 +348,9 @@ class NgpEngine:
             ws["offsets_m"] = torch.zeros(R + 1, **i32)
             ws["ray_state"] = torch.zeros(R, **i32)
             ws["kept"] = torch.zeros(R, **i32)
-            ws["totals_m"] = torch.zeros(2, **i32)
+            ws["totals_m"] = torch.zeros(8, 2, **i32)   # per round: {samples found, slots in use}
+            for name in ("t_next", "t_resume", "carry"):
+                ws[name] = torch.zeros(R, **f32)
         if training:
             ws["d_rgb_out"] = torch.zeros(cap, 16, **f16)
             ws["d_density_out"] = torch.zeros(cap, 16, **f16)
@@ -481,9 +490,9 @@ class NgpEngine:
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts"]), _ptr(ws["march_scratch"]),
-              ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next), rdev)
+              ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next), rdev, 0)
         _call("nvo_occ_pack", stream, R, _ptr(ws["counts"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
-              _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev)
+              _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0)
 
     def _march_compact(self, ws, jitter, stream) -> None:
         """The training batch as upstream builds it (NgpConfig.compact_training): march -> everything found packed into the
@@ -496,38 +505,54 @@ class NgpEngine:
         rdev = self._rdev(ws)
         lo, hi = cfg.aabb
         nscr = ws["march_scratch"].numel()
-        n_live = C.c_void_p(ws["totals_m"].data_ptr() + 4)
-        _call("nvo_fill_i32", stream, cap_m, _ptr(ws["ray_idx_m"]), -1)
-        _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
-              cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts_m"]), _ptr(ws["march_scratch"]),
-              nscr, None, 1024, None, rdev)
-        _call("nvo_occ_pack", stream, R, _ptr(ws["counts_m"]), cap_m, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
-              _ptr(ws["totals_m"]), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev)
-        _call("nvo_ngp_positions_live", stream, cap_m, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["origins"]),
-              _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]), n_live)
-        # density alone (column 0, compact), no d(encoded)/d(position), tiles past the slots in use skipped; the raw weights
-        # (the training pass behind this evaluates the same ones)
         net = self.density_net
-        net.set_option("n_live_ptr", n_live.value)
-        net.set_option("compact_output", 1)
-        if self._pig:
-            net.set_option("prepare_input_gradients", 0)
-        try:
-            _call("nvo_fwd", net.handle, stream, cap_m, _ptr(ws["x01_m"]), self._pp("density", self.params_half),
-                  _ptr(ws["density_m"]), _ptr(ws["ctx_m"]))
-        finally:
-            net.set_option("n_live_ptr", 0)
-            net.set_option("compact_output", 0)
+        budgets = [int(b) for b in cfg.train_rounds if int(b) > 0][:7]
+        assert sum(budgets) < 1024, "NgpConfig.train_rounds: the rounds in front of the last one must leave it samples"
+        budgets.append(1024 - sum(budgets))
+        base = 0
+        for k, budget in enumerate(budgets):
+            last = k + 1 == len(budgets)
+            resume = ws["t_resume"] if k else None
+            tot_ptr = ws["totals_m"].data_ptr() + 8 * k
+            n_live = C.c_void_p(tot_ptr + 4)
+            # slots this round can fill at most: its budget per ray
+            B = min(cap_m, (R * budget + 4095) // 4096 * 4096)
+            _call("nvo_fill_i32", stream, B, _ptr(ws["ray_idx_m"]), -1)
+            _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
+                  cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts_m"]), _ptr(ws["march_scratch"]),
+                  nscr, _ptr(resume), budget, None if last else _ptr(ws["t_next"]), rdev, base)
+            _call("nvo_occ_pack", stream, R, _ptr(ws["counts_m"]), B, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
+                  C.c_void_p(tot_ptr), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev, base)
+            _call("nvo_ngp_positions_live", stream, B, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["origins"]),
+                  _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]), n_live)
+            # density alone (column 0, compact), no d(encoded)/d(position), tiles past the slots in use skipped; the raw
+            # weights (the training pass behind this evaluates the same ones)
+            net.set_option("n_live_ptr", n_live.value)
+            net.set_option("compact_output", 1)
             if self._pig:
-                net.set_option("prepare_input_gradients", 1)
-        aa = _lib.NgpAliveArgs(R=R, counts=ws["counts_m"].data_ptr(), offsets=ws["offsets_m"].data_ptr(),
-                               dt=ws["dt_m"].data_ptr(), density_out=ws["density_m"].data_ptr(), density_stride=1,
-                               min_transmittance=float(cfg.train_min_transmittance), kept=ws["kept"].data_ptr(),
-                               state=ws["ray_state"].data_ptr(), R_dev=None if rdev is None else rdev.value)
-        _call("nvo_ngp_count_alive", stream, C.byref(aa))
+                net.set_option("prepare_input_gradients", 0)
+            try:
+                _call("nvo_fwd", net.handle, stream, B, _ptr(ws["x01_m"]), self._pp("density", self.params_half),
+                      _ptr(ws["density_m"]), _ptr(ws["ctx_m"]))
+            finally:
+                net.set_option("n_live_ptr", 0)
+                net.set_option("compact_output", 0)
+                if self._pig:
+                    net.set_option("prepare_input_gradients", 1)
+            aa = _lib.NgpAliveArgs(R=R, counts=ws["counts_m"].data_ptr(), offsets=ws["offsets_m"].data_ptr(),
+                                   dt=ws["dt_m"].data_ptr(), density_out=ws["density_m"].data_ptr(), density_stride=1,
+                                   min_transmittance=float(cfg.train_min_transmittance), kept=ws["kept"].data_ptr(),
+                                   state=ws["ray_state"].data_ptr(), R_dev=None if rdev is None else rdev.value,
+                                   resume_in=None if resume is None else resume.data_ptr(),
+                                   carry_in=None if resume is None else ws["carry"].data_ptr(), kept_base=base,
+                                   t_next=None if last else ws["t_next"].data_ptr(),
+                                   resume_out=None if last else ws["t_resume"].data_ptr(),
+                                   carry_out=None if last else ws["carry"].data_ptr())
+            _call("nvo_ngp_count_alive", stream, C.byref(aa))
+            base += budget
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_pack", stream, R, _ptr(ws["kept"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
-              _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev)
+              _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0)
         ws["ray_state_on"] = True
 
     def _shade(self, ws, training: bool, stream) -> None:
@@ -918,7 +943,7 @@ class NgpEngine:
 
     def _replay_step(self, ws, intrinsics, c2w, images, depths, cam_update, depths_cov, bg) -> None:
         cfg = self.cfg
-        key = (ws["R_cap"], bool(cfg.compact_training), int(cfg.march_capacity), ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
+        key = (ws["R_cap"], bool(cfg.compact_training), int(cfg.march_capacity), tuple(cfg.train_rounds), ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
                None if depths is None else depths.data_ptr(), None if depths_cov is None else depths_cov.data_ptr(),
                bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
                bool(cam_update), self._camera_grad_scale() if cam_update else 0.0, self._fused_adam_plan(),

@@ -41,18 +41,20 @@ def _oracle(eng):
     return orc
 
 
-@pytest.mark.parametrize("cov,compact", [("none", True), ("ones", True), ("varying", True), ("none", False)])
-def test_ngp_step_matches_oracle(device, cov, compact):
+@pytest.mark.parametrize("cov,compact,rounds", [("none", True, 0), ("ones", True, 0), ("varying", True, 0), ("none", False, 0),
+                                                ("none", True, 128)])
+def test_ngp_step_matches_oracle(device, cov, compact, rounds):
     """``cov``: the per-ray variance of the depth target (nvo_ngp_loss_args::gt_depth_cov) -- absent, all ones (must be
     the absent case bit for bit) or spread over three decades with zeros, negatives and inf mixed in (rays whose depth
     term is dropped).  ``compact``: the batch that is trained on holds the samples in front of T < 1e-4 only
     (NgpConfig.compact_training, upstream's training-batch compaction): marched samples bit for bit, kept counts against the
     numpy restatement on the kernel's own density outputs, packing rule, then the step against the oracle composited over
-    the kept samples."""
+    the kept samples.  ``rounds`` > 0: the pass that finds the kept counts runs in three rounds (NgpConfig.train_rounds),
+    its counts must be the single pass's."""
     from oracle import occgrid as O
     from oracle import ngp as ON
 
-    eng = _engine(device, compact_training=compact)
+    eng = _engine(device, compact_training=compact, train_rounds=())
     if compact:  # denser medium: a good share of the rays must end in front of their last sample
         nd = eng.n_density_mlp
         boosted = eng.params.clone()
@@ -143,6 +145,20 @@ def test_ngp_step_matches_oracle(device, cov, compact):
         c2, o2, total = ON.compact_offsets(kept, eng.cfg.capacity)
         assert (ws["counts"].cpu().numpy() == c2).all() and (ws["offsets"].cpu().numpy() == o2).all()
         assert ws["totals"].cpu().tolist() == [total, min(total, eng.cfg.capacity)] and total == int(kept.sum())
+        if rounds:
+            # the same step with the counts found in two rounds: same counts (ties aside), same packed batch
+            single = {k: ws[k].clone() for k in ("kept", "ray_state", "counts", "offsets", "t", "dt", "ray_idx")}
+            eng.cfg.train_rounds = (rounds, rounds // 2)
+            assert (kept < rounds).sum() >= 5 and (kept > rounds).sum() >= 5 and (kept > rounds + rounds // 2).sum() >= 2
+            eng.forward_backward(ws, jitter.to(device), has_depth=True, background=bg.to(device))
+            torch.cuda.synchronize()
+            k2 = ws["kept"].cpu().numpy().astype(np.int64)
+            assert (k2 == kept)[~tie].all() and (np.abs(k2 - kept) <= 1).all()
+            if (k2 == kept).all():
+                for k, v in single.items():
+                    assert torch.equal(v, ws[k]), k
+            kept = k2
+            c2, o2, total = ON.compact_offsets(kept, eng.cfg.capacity)
         tc, rc = ws["t"].cpu().numpy(), ws["ray_idx"].cpu().numpy()
         for r in range(R):
             n = int(kept[r])
