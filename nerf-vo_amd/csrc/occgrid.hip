@@ -317,21 +317,31 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return
 // Single-workgroup exclusive scan of counts_in[n] -> offsets[n], total in offsets[n]; entries that would
 // push the running total beyond `capacity` are treated as 0 in counts_out (counts_out == counts_in: in place).
 // totals (nullable): [0] = the total BEFORE the clamp, [1] = min(total, capacity) = the packed slots in use.
-template <int PER>
+// LDS form (n <= kScanLds entries): the counts come in and the results leave with coalesced accesses; between them
+// thread i owns the PER consecutive entries [i * PER, (i + 1) * PER) of the staged array -- one scan of the 1024 thread sums
+// across the workgroup, no round structure.  (History: rounds of 1024 entries with three barriers each, then a thread's
+// entries straight from global memory -- 64 different lines per wave instruction on ONE CU: 19-21 us for 13 K rays either
+// way, three launches per step.)
+constexpr uint32_t kScanLds = 16384;
+template <int PER, bool LDS>
 __global__ void __launch_bounds__(1024)
 k_scan_counts(uint32_t n, const uint32_t* counts_in, uint32_t* counts_out, uint32_t* __restrict__ offsets,
               uint32_t capacity, uint32_t* __restrict__ totals, const uint32_t* __restrict__ n_dev) {
-    // One pass: thread i owns the PER consecutive entries [i * PER, (i + 1) * PER), all requested before the first is used
-    // (the first form walked the array in 1024-entry rounds with three barriers each, the second read its entries one
-    // dependent load after the other: 19-21 us for 13 K rays either way, three launches per step), then ONE scan of the
-    // 1024 sums across the workgroup and the prefixes from registers.
+    extern __shared__ uint32_t stage[];  // LDS: [n] counts -> offsets, [n] counts_out behind them
     __shared__ uint32_t wave_tot[16];
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t first = threadIdx.x * PER;
     uint32_t c[PER];
+    if constexpr (LDS) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) stage[i] = counts_in[i];
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PER; ++k) c[k] = counts_in[min(first + (uint32_t)k, n ? n - 1u : 0u)];
+        for (int k = 0; k < PER; ++k) c[k] = (first + (uint32_t)k < n) ? stage[first + k] : 0u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) c[k] = counts_in[min(first + (uint32_t)k, n ? n - 1u : 0u)];
+    }
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -351,10 +361,23 @@ k_scan_counts(uint32_t n, const uint32_t* counts_in, uint32_t* counts_out, uint3
     for (int k = 0; k < PER; ++k) {
         const uint32_t i = first + (uint32_t)k;
         if (i < n) {
-            offsets[i] = run;
             // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
-            counts_out[i] = (run + c[k] > capacity) ? 0u : c[k];
+            const uint32_t kept = (run + c[k] > capacity) ? 0u : c[k];
+            if constexpr (LDS) {
+                stage[i] = run;
+                stage[kScanLds + i] = kept;
+            } else {
+                offsets[i] = run;
+                counts_out[i] = kept;
+            }
             run += c[k];
+        }
+    }
+    if constexpr (LDS) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            offsets[i] = stage[i];
+            counts_out[i] = stage[kScanLds + i];
         }
     }
     if (threadIdx.x == 0) {
@@ -622,9 +645,16 @@ int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uin
     {
         NVO_PROF(stream, "occ_scan");
         NVO_REQUIRE(R <= 65536u, "occ_pack: at most 65536 rays per launch (got %u)", R);
-        if (R <= 4096u) NVO_LAUNCH(k_scan_counts<4>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
-        else if (R <= 16384u) NVO_LAUNCH(k_scan_counts<16>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
-        else NVO_LAUNCH(k_scan_counts<64>, dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        const size_t lds = 2 * kScanLds * sizeof(uint32_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_scan_counts<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_scan_counts<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        if (R <= 4096u) NVO_LAUNCH((k_scan_counts<4, true>), dim3(1), dim3(1024), lds, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        else if (R <= kScanLds) NVO_LAUNCH((k_scan_counts<16, true>), dim3(1), dim3(1024), lds, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
+        else NVO_LAUNCH((k_scan_counts<64, false>), dim3(1), dim3(1024), 0, s, R, counts_in, counts_out, offsets, capacity, totals, R_dev);
         NVO_CHECK_LAUNCH();
     }
     {

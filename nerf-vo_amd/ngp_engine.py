@@ -304,7 +304,9 @@ class NgpEngine:
         if ws is not None and R <= ws["R_cap"] and ("dx01" in ws or not (training and self.cfg.optimize_extrinsics)):
             self._ws = ws
             return self._ray_views(ws, R)
-        R_req, R = R, max(4096, 1 << max(0, (R - 1).bit_length()))
+        # (training: at least 16384 rows -- the adaptive batch ends between 10 K and 16 K rays on a carved scene, and a
+        # workspace that grows clears the captured steps)
+        R_req, R = R, max(16384 if training else 4096, 1 << max(0, (R - 1).bit_length()))
         key = (R, training)
         dev = self.device
         cap = int(self.cfg.capacity if (training or not self.cfg.render_capacity) else self.cfg.render_capacity)

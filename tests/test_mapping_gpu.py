@@ -212,9 +212,9 @@ def test_pyngp_incremental_keyframes_snapshot_and_render(device, tmp_path):
     assert shade.shape == (H, W, 4) and np.isfinite(shade).all() and (shade[..., 3] > 0.5).mean() > 0.9
     assert np.abs(z[..., 0] - seq["frames_depth"][5, 0].cpu().numpy()).mean() < 0.2
     assert all(eng._graphs.get(k) is v for k, v in graphs.items())  # the render left the captured steps alone
-    last_batch = eng._wss[True]["R"]  # (a new capture is due only if the adaptive batch has just moved)
+    rows = eng._wss[True]["R_cap"]  # (the ray count lives on the device: a new capture is due only when the workspace grows)
     tb.frame()
-    assert eng.graph_captures == captures + (0 if eng._wss[True]["R"] == last_batch else 1)
+    assert eng.graph_captures == captures + (0 if eng._wss[True]["R_cap"] == rows else 1)
     path = str(tmp_path / "snap.msgpack")
     tb.save_snapshot(path, include_optimizer_state=True)
     tb2 = make()
