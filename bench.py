@@ -215,10 +215,8 @@ def main() -> None:
                     help="proposal backward on the main stream instead of a side stream (profiling: every kernel alone)")
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the eager per-kernel HIP-event pass (rocprofv3 runs: only graph-replayed steps in the trace)")
-    ap.add_argument("--proposal-streams", type=int, default=None, help="side streams of the proposal backward (1 | 2)")
     ap.add_argument("--no-pose-overlap", action="store_true",
                     help="pose optimisation: the main grid's parameter scatter behind the pose chain instead of beside it (A/B)")
-    ap.add_argument("--no-pair-losses", action="store_true", help="one launch per proposal level's loss kernel (A/B)")
     ap.add_argument("--commit-in-graph", action="store_true",
                     help="the optimiser's commit as the graph's last node, scalars written eagerly BEFORE each replay (A/B)")
     ap.add_argument("--no-fuse-grid-adam", action="store_true",
@@ -226,7 +224,6 @@ def main() -> None:
     ap.add_argument("--commit-behind-replay", action="store_true",
                     help="commit + next step's scalars in ONE eager launch behind each replay (round 3's form; default now: "
                          "last node of the graph, scalars from a device table) (A/B)")
-    ap.add_argument("--separate-zero", action="store_true", help="the step's zero launch as its own graph node (A/B)")
     ap.add_argument("--dynamic-loss-scale", action="store_true",
                     help="(the default since round 4) GradScaler dynamics: init 65536, x2 / 2000 clean steps, x0.5 on overflow "
                          "-- the reference's mixed_precision=True, /root/reference/nerf_vo/mapping/nerfstudio.py:59")
@@ -313,17 +310,9 @@ def main() -> None:
 
     cfg = EngineConfig(num_images=args.keyframes, num_rays=args.rays, optimize_poses=args.optimize_poses,
                        mlp_dtype=args.mlp_dtype, expect_normals=use_normals)
-    if args.proposal_streams is not None:
-        cfg.proposal_backward_streams = args.proposal_streams
     if args.pipeline_single_gpu:
         cfg.pipeline_single_gpu = True
     cfg.dynamic_loss_scale = not args.static_loss_scale
-    if os.environ.get("NVO_EARLY_FIELDS_ADAM") is not None:  # A/B
-        cfg.overlap_fields_adam = os.environ["NVO_EARLY_FIELDS_ADAM"] != "0"
-    if os.environ.get("NVO_PROP_MLP_OVERLAP") is not None:  # A/B
-        cfg.overlap_proposal_mlp = os.environ["NVO_PROP_MLP_OVERLAP"] != "0"
-    if args.no_pair_losses:
-        cfg.pair_proposal_losses = False
     if args.commit_in_graph:
         cfg.commit_behind_replay = cfg.commit_from_table = False
     if args.commit_behind_replay:
@@ -332,8 +321,6 @@ def main() -> None:
         cfg.fuse_grid_adam = False
     if os.environ.get("NVO_DW_REPLICAS") is not None:  # A/B
         cfg.dw_replicas = int(os.environ["NVO_DW_REPLICAS"])
-    if args.separate_zero:
-        cfg.zero_with_ray_head = False
     if args.no_pose_overlap:
         cfg.overlap_pose_backward = False
     if args.no_overlap:

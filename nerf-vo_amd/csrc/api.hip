@@ -326,10 +326,9 @@ namespace {
 struct GridModule : nvo_module_s {
     NvoGridLevels g;
     NvoGridSlices slices;
-    NvoGridBins bins;
     NvoGridStream stream_bins;
     NvoGridInputScratch input_scratch;  // per-level partials of the input backward (allocated at first use)
-    int bwd_mode = 1;  // 0 global atomics, 1 LDS slice owner (default, fastest), 2 binned hashed levels + slice owner
+    int bwd_mode = 1;  // 0 global atomics (the readable reference form), 1 LDS slice owner (default), 3 streamed pair records + slice owner
     bool soa_out = false;  // standalone Encoding: [B][L*F] rows (tcnn API); inside NWIE: SoA
     // option "bf16": the encoded features and their gradient are bfloat16 instead of fp16 (the format of the network
     // behind the encoding).  The table itself stays fp16, interpolation and gradient accumulation stay fp32.
@@ -338,7 +337,6 @@ struct GridModule : nvo_module_s {
 
     ~GridModule() override {
         nvo_grid_slices_destroy(&slices);
-        nvo_grid_bins_destroy(&bins);
         nvo_grid_stream_destroy(&stream_bins);
         nvo_scratch_destroy(&input_scratch);
     }
@@ -370,7 +368,6 @@ struct GridModule : nvo_module_s {
     int bwd_params(hipStream_t s, uint32_t B, const float* in, const void* dout, bool soa, float* dparams) {
         int rc = ensure_slices();
         if (rc) return rc;
-        if (bwd_mode == 2) return nvo_grid_bwd_binned_launch(g, &bins, s, B, in, dout, dy_fmt(), soa, dparams);
         if (bwd_mode == 3) return nvo_grid_bwd_stream_launch(g, &stream_bins, s, B, in, dout, dy_fmt(), soa, dparams);
         return nvo_grid_bwd_launch(g, &slices, s, B, in, dout, dy_fmt(), soa, dparams, bwd_mode);
     }
@@ -459,7 +456,6 @@ struct GridModule : nvo_module_s {
             // launch against 79.6 us for 256-448 and 89.5 us for <= 100)
             return nvo_grid_slices_create(g, &slices, 0xFFFFFFFFu,
                                           slices.acc_bits == 32 ? (slices.runs ? 160u : 512u) : 1024u);
-        if (bwd_mode == 2 && bins.n_bins == 0 && bins.dense.n_slices == 0) return nvo_grid_bins_create(g, &bins);
         if (bwd_mode == 3 && !stream_bins.created) return nvo_grid_stream_create(g, &stream_bins);
         return NVO_OK;
     }
@@ -507,7 +503,11 @@ struct GridModule : nvo_module_s {
         return NVO_OK;
     }
     int set_option(const char* key, int64_t value) override {
-        if (!strcmp(key, "grid_bwd_mode")) { bwd_mode = (int)value; return NVO_OK; }
+        if (!strcmp(key, "grid_bwd_mode")) {
+            NVO_REQUIRE(value == 0 || value == 1 || value == 3, "grid_bwd_mode: 0 (global atomics), 1 (slice owner) or 3 (streamed records)");
+            bwd_mode = (int)value;
+            return NVO_OK;
+        }
         if (!strcmp(key, "external_zero")) return set_external_zero(value != 0);
         if (!strcmp(key, "grid_compact_live")) {  // slice-owner items scan only the samples with a non-zero gradient
             slices.compact_live = value != 0;
@@ -558,20 +558,13 @@ struct GridModule : nvo_module_s {
             slices.runs = stream_bins.owner.runs = value != 0;
             return NVO_OK;
         }
-        if (!strcmp(key, "grid_stream_layout")) {  // 0: globally bin-sorted records (count/scan/scatter), 1: tile-local
-            nvo_grid_stream_destroy(&stream_bins);
-            stream_bins.tile_local = value != 0;
-            return NVO_OK;
-        }
         if (!strcmp(key, "grid_stream_overlap")) {  // 0: slice-owner levels and record pipeline back to back
             nvo_grid_stream_destroy(&stream_bins);  // (the owner's slice size depends on it)
             stream_bins.overlap = value != 0;
             return NVO_OK;
         }
-        if (!strcmp(key, "grid_stream_acc_bits")) {  // record pass of the streamed levels: 64 | 32 (packed, 8192-entry bins)
-            NVO_REQUIRE(value == 32 || value == 64, "grid_stream_acc_bits must be 32 or 64");
-            nvo_grid_stream_destroy(&stream_bins);
-            stream_bins.acc_bits = (uint32_t)value;
+        if (!strcmp(key, "grid_stream_acc_bits")) {  // (the record pass has one form left: packed 2 x 32-bit sums)
+            NVO_REQUIRE(value == 32, "grid_stream_acc_bits: only the packed 32-bit record pass exists (got %lld)", (long long)value);
             return NVO_OK;
         }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built

@@ -1137,24 +1137,16 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
-// backward w.r.t. parameters, BINNED form for hashed levels (mode 2)
+// backward w.r.t. parameters, STREAMED form (mode 3): pair records sorted by bin inside each tile, streaming accumulate
 // ------------------------------------------------------------------------------------------
-// The slice-owner kernel above re-derives every sample's corner hashes once per slice of a level
-// (26-64x redundancy).  The binned form derives them a constant three times instead:
-//   k_bin_count   : per (sample, hashed level) count the corner lookups per kBinSlice-entry slice (LDS
-//                   integer histogram per workgroup, one global add per non-empty bin)
-//   k_bin_scan    : exclusive scan of the <= 2048 bin totals (one workgroup)
-//   k_bin_scatter : same histogram -> one range reservation per (workgroup, bin) -> 4-byte records
-//                   (sample << 3 | corner) written in short contiguous runs
-//   k_bin_accumulate: one workgroup per bin walks ITS records only, re-derives weight and entry of
-//                   that single corner, accumulates in 64-bit fixed point in LDS (integer atomics),
-//                   and writes the slice with plain stores -> bitwise reproducible gradients.
-// Entries per bin of the binned / streamed forms.  4096 (64 KiB of 64-bit accumulator pairs) since the end of round 2:
-// TWO accumulate workgroups fit a CU, and while one of them only loads its records the other one converts / adds /
-// flushes -- with 8192-entry bins (one 128 KiB workgroup per CU) every CU of the chip was in the same phase at the same
-// time (k_tl_accumulate 77 -> 70 us).
+// The slice-owner kernel above re-derives every sample's corner hashes once per slice of a level (26-64x redundancy on a
+// 2^19-entry table).  The streamed form derives them once: a scatter pass over (tile, level) writes self-contained records,
+// an accumulate pass streams the records of one bin into LDS and writes the slice with plain stores.  (History, removed in
+// round 5: mode 2 -- count / scan / scatter of 4-byte (sample, corner) records and an accumulate pass bound by the
+// dependent gathers behind every record; globally bin-sorted 8-byte records with count / scan passes; tile-local 8-byte
+// records with 64-bit accumulators over 4096-entry bins.  What is left is the fastest of them.)
+// Slice size the streamed / owner split is decided in (nvo_grid_stream_create: levels with few such bins stay slice-owner).
 constexpr uint32_t kBinSlice = 4096;
-constexpr int kBinBlock = 256;
 
 template <bool SOA, typename DY2>
 __device__ __forceinline__ bool load_dy_nonzero(const NvoGridLevels& g, const DY2* __restrict__ dy, uint32_t N,
@@ -1168,600 +1160,12 @@ __device__ __forceinline__ uint32_t hashed_corner(const Corner& c, uint32_t k, u
     return ((c.px + (k & 1u)) ^ ((c.py + ((k >> 1) & 1u)) * 2654435761u) ^ ((c.pz + ((k >> 2) & 1u)) * 805459861u)) & mask;
 }
 
-// grid = (ceil(N / 256), n_binned_levels).  bin ids of level j start at bin_first[j].
-template <bool SCATTER, bool SOA, typename DY2>
-__global__ void __launch_bounds__(kBinBlock)
-k_bin_count_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
-                    const uint32_t* __restrict__ binned_levels, const uint32_t* __restrict__ bin_first,
-                    uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t* __restrict__ records) {
-    extern __shared__ uint32_t hist[];  // [n_slices] histogram, then [n_slices] block bases (scatter)
-    const uint32_t level = binned_levels[blockIdx.y];
-    const uint32_t bin0 = bin_first[blockIdx.y];
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    const uint32_t n_slices = size / kBinSlice;
-    const uint32_t mask = size - 1u;
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock) hist[b] = 0u;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * kBinBlock + threadIdx.x;
-    uint32_t idx[8];
-    bool live = false;
-    if (i < N) {
-        float2 d;
-        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
-        if (live) {
-            const Corner c = grid_cell(g.scale[level], x[3 * (size_t)i + 0], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                idx[k] = hashed_corner(c, k, mask);
-                atomicAdd(&hist[idx[k] / kBinSlice], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    if (!SCATTER) {
-        for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock)
-            if (hist[b]) atomicAdd(&counts[bin0 + b], hist[b]);
-        return;
-    }
-    // reserve one contiguous range per bin for this workgroup, then hand out slots inside it
-    uint32_t* block_base = hist + n_slices;
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kBinBlock) {
-        const uint32_t c = hist[b];
-        block_base[b] = c ? atomicAdd(&cursor[bin0 + b], c) : 0u;
-        hist[b] = 0u;
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t b = idx[k] / kBinSlice;
-            const uint32_t slot = atomicAdd(&hist[b], 1u);
-            records[block_base[b] + slot] = (i << 3) | k;
-        }
-    }
-}
-
-// counts[n] -> base[n] (exclusive), cursor[n] = base[n]; base[n] = total.  One workgroup.
-__global__ void __launch_bounds__(1024)
-k_bin_scan(uint32_t n, const uint32_t* __restrict__ counts, uint32_t* __restrict__ base,
-           uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(n, lo + per);
-    uint32_t s = 0;
-    for (uint32_t b = lo; b < hi; ++b) s += counts[b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 1024; ++t) {
-            const uint32_t v = part[t];
-            part[t] = run;
-            run += v;
-        }
-        base[n] = run;
-    }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (uint32_t b = lo; b < hi; ++b) {
-        base[b] = run;
-        cursor[b] = run;
-        run += counts[b];
-    }
-}
-
-// grid = (n_bins, n_chunks): a workgroup walks chunk `blockIdx.y` of ITS bin's records.  Loads are
-// unconditional (indices clamped into the bin) and issued kUnroll deep, so that the record ->
-// (x, dy) dependent chain is paid once per kUnroll records instead of once per record.
-template <bool SOA, typename DY2>
-__global__ void __launch_bounds__(kLdsBwdBlock)
-k_bin_accumulate(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
-                 const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
-                 const uint32_t* __restrict__ base, const uint32_t* __restrict__ records,
-                 float* __restrict__ grad) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
-    const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    const uint32_t mask = size - 1u;
-    const float scale = g.scale[level];
-    const uint32_t n_chunks = gridDim.y;
-    const uint32_t bin_begin = base[blockIdx.x], bin_end = base[blockIdx.x + 1];
-    const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
-    const uint32_t begin = bin_begin + blockIdx.y * per_chunk;
-    const uint32_t end = min(bin_end, begin + per_chunk);
-    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
-    if (begin >= end) {
-        if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
-            for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = 0.f;
-        return;
-    }
-    for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) acc[e] = 0ull;
-    __syncthreads();
-    constexpr uint32_t kUnroll = 8;
-    bool bad = false;  // non-finite dy: see grid_bwd_item
-    for (uint32_t r0 = begin + threadIdx.x; r0 < end; r0 += kUnroll * kLdsBwdBlock) {
-        uint32_t rec[kUnroll];
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; ++u) rec[u] = records[min(r0 + u * kLdsBwdBlock, end - 1u)];
-        float2 dv[kUnroll];
-        float xv[kUnroll][3];
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; ++u) {
-            const uint32_t i = rec[u] >> 3;
-            const DY2 d2 = SOA ? dy[(size_t)level * N + i] : dy[(size_t)i * g.n_levels + level];
-            dv[u] = dy2f(d2);
-            xv[u][0] = x[3 * (size_t)i + 0];
-            xv[u][1] = x[3 * (size_t)i + 1];
-            xv[u][2] = x[3 * (size_t)i + 2];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; ++u) {
-            const uint32_t k = rec[u] & 7u;
-            const Corner c = grid_cell(scale, xv[u][0], xv[u][1], xv[u][2]);
-            const uint32_t idx = hashed_corner(c, k, mask);
-            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                            ((k & 4u) ? c.wz : 1.f - c.wz);
-            if (r0 + u * kLdsBwdBlock < end) {  // idx / kBinSlice == slice by construction of the bins
-                bad = bad || !(fabsf(dv[u].x) < INFINITY) || !(fabsf(dv[u].y) < INFINITY);
-                AccFixed::add(acc, idx & (kBinSlice - 1u), w * dv[u].x, w * dv[u].y, AccScale{});
-            }
-        }
-    }
-    __syncthreads();
-    if (n_chunks == 1) {
-        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e, AccScale{});
-    } else {
-        for (uint32_t e = threadIdx.x; e < 2 * kBinSlice; e += kLdsBwdBlock) {
-            const float v = AccFixed::get(acc, e, AccScale{});
-            if (v != 0.f) atomicAdd(gr + e, v);
-        }
-    }
-    __syncthreads();
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));
-}
-
-// ------------------------------------------------------------------------------------------
-// backward w.r.t. parameters, STREAMED binned form (mode 3) -- every level, no global atomics in the
-// sort, no gathers and no hash re-derivation in the accumulate
-// ------------------------------------------------------------------------------------------
-// Mode 2's accumulate pass is bound by the dependent random gathers of x / dy behind every 4-byte
-// record, mode 1 by re-deriving every corner hash once per slice.  Here:
-//   k_st_count   : tile of 1024 samples x one level -> LDS histogram over the level's kBinSlice-entry bins ->
-//                  counts[bin][tile] with plain stores
-//   k_st_scan_tiles : per bin, exclusive scan over the tiles (in place) + bin total
-//   k_st_scan_bins  : exclusive scan of the bin totals -> base[]; builds the accumulate work items
-//                  (bin, chunk, n_chunks) from the ACTUAL record counts, so a heavily hit bin (dense coarse
-//                  levels, clustered samples) is split over several workgroups
-//   k_st_scatter : same tile decomposition; the pass that holds x, dy and the interpolation weights in
-//                  registers writes SELF-CONTAINED 8-byte records {entry-in-bin (13 bit), w*dy.x, w*dy.y}.
-//                  The index bits ride in the low mantissa bits of the two fp32 values (6 + 7), which keep
-//                  17 / 16 mantissa bits after round-to-nearest -- 64x finer than the fp16 dy they are
-//                  computed from (tcnn forms the same product in fp16).  Records are staged in LDS sorted
-//                  by bin and leave the workgroup in runs that are contiguous per bin.
-//   k_st_zero    : zero the slices of multi-chunk bins (their chunks combine with float atomics)
-//   k_st_accumulate : a pure stream -- coalesced record loads + LDS 64-bit integer atomics, then plain
-//                  stores (single-chunk bins: bitwise reproducible) or row-contiguous float atomics.
-// samples per tile = threads per workgroup (template parameter TILE of count / scatter; both passes
-// must use the same value: the scatter offsets are the scanned per-tile counts)
-constexpr uint32_t kStChunkRecords = 32768;        // target records per accumulate work item
-constexpr uint32_t kStMaxChunks = 256;
-
-__device__ __forceinline__ uint2 rec_pack(uint32_t rel, float v0, float v1) {
-    const uint32_t a = __float_as_uint(v0) + 0x20u;  // round to nearest at bit 6
-    const uint32_t b = __float_as_uint(v1) + 0x40u;  // ... at bit 7
-    return make_uint2((a & ~0x3Fu) | (rel & 0x3Fu), (b & ~0x7Fu) | (rel >> 6));
-}
-
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int) { return nvo_wave_incl_scan(v); }  // DPP
 
-// grid = (n_tiles, n_levels).  counts[(bin_first[level] + b) * n_tiles + tile]
-template <int TILE, bool SOA, typename DY2>
-__global__ void __launch_bounds__(TILE)
-k_st_count(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
-           const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
-           uint32_t* __restrict__ counts) {
-    constexpr uint32_t kStBlock = TILE;
-    extern __shared__ uint32_t hist[];
-    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
-    const uint32_t bin0 = bin_first[blockIdx.y];
-    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
-    const uint32_t i = tile * kStBlock + threadIdx.x;
-    float2 d = make_float2(0.f, 0.f);
-    float xs[3] = {0.f, 0.f, 0.f};
-    bool live = false;
-    if (i < N) {  // dy and x in one round trip (see k_st_scatter)
-        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
-        xs[0] = x[3 * (size_t)i + 0];
-        xs[1] = x[3 * (size_t)i + 1];
-        xs[2] = x[3 * (size_t)i + 2];
-    }
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) hist[b] = 0u;
-    __syncthreads();
-    {
-        if (live) {
-            const Corner c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
-            // the two x corners of a (y, z) pair almost always share a bin (hashed levels: x only touches the
-            // index bits below the bin bits; dense levels: neighbouring entries): one LDS atomic for both
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t b0 = nvo_grid_index(hashed, size, res, c.px, c.py + (j & 1u), c.pz + (j >> 1)) / kBinSlice;
-                const uint32_t b1 = nvo_grid_index(hashed, size, res, c.px + 1u, c.py + (j & 1u), c.pz + (j >> 1)) / kBinSlice;
-                if (b0 == b1) {
-                    atomicAdd(&hist[b0], 2u);
-                } else {
-                    atomicAdd(&hist[b0], 1u);
-                    atomicAdd(&hist[b1], 1u);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) counts[(size_t)(bin0 + b) * n_tiles + tile] = hist[b];
-}
-
-// grid = n_bins, block = 256: counts[bin][0..n_tiles) -> exclusive offsets in place, totals[bin]
-__global__ void __launch_bounds__(256)
-k_st_scan_tiles(uint32_t n_tiles, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals) {
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t carry_s;
-    uint32_t* row = counts + (size_t)blockIdx.x * n_tiles;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0u;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 256) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t c = t < n_tiles ? row[t] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(c, lane);
-        if (lane == 63) wave_tot[wib] = incl;
-        __syncthreads();
-        uint32_t pre = carry_s;
-        for (int w = 0; w < wib; ++w) pre += wave_tot[w];
-        if (t < n_tiles) row[t] = pre + incl - c;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = pre + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
-}
-
-// One workgroup.  totals[n] -> base[n + 1] (exclusive; base[n] = grand total); item list from the actual
-// counts: items[j] = {bin, chunk, n_chunks, 0}; n_items[0] = number of items.
-__global__ void __launch_bounds__(1024)
-k_st_scan_bins(uint32_t n, const uint32_t* __restrict__ totals, uint32_t* __restrict__ base,
-               uint4* __restrict__ items, uint32_t* __restrict__ n_items, uint32_t* __restrict__ bin_chunks,
-               uint32_t max_items) {
-    __shared__ uint32_t wtot[16], wtot2[16];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
-    uint32_t s = 0, s2 = 0;
-    for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t c = totals[b];
-        s += c;
-        s2 += min(kStMaxChunks, max(1u, (c + kStChunkRecords - 1u) / kStChunkRecords));
-    }
-    const uint32_t incl = wave_incl_scan_u32(s, lane), incl2 = wave_incl_scan_u32(s2, lane);
-    if (lane == 63) {
-        wtot[wib] = incl;
-        wtot2[wib] = incl2;
-    }
-    __syncthreads();
-    uint32_t run = incl - s, run2 = incl2 - s2;
-    for (int w = 0; w < wib; ++w) {
-        run += wtot[w];
-        run2 += wtot2[w];
-    }
-    if (threadIdx.x == 1023) {
-        base[n] = run + s;
-        n_items[0] = min(run2 + s2, max_items);
-    }
-    for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t c = totals[b];
-        base[b] = run;
-        run += c;
-        const uint32_t nc = min(kStMaxChunks, max(1u, (c + kStChunkRecords - 1u) / kStChunkRecords));
-        bin_chunks[b] = nc;
-        for (uint32_t j = 0; j < nc; ++j)
-            if (run2 + j < max_items) items[run2 + j] = make_uint4(b, j, nc, 0u);
-        run2 += nc;
-    }
-}
-
-// grid = (n_tiles, n_levels); LDS: stage[8192] uint2 | dst[8192] u32 | hist | loff | gbase
-template <int TILE, bool SOA, typename DY2>
-__global__ void __launch_bounds__(TILE)
-k_st_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
-             const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
-             const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ base,
-             uint2* __restrict__ records) {
-    constexpr uint32_t kStBlock = TILE;
-    constexpr uint32_t kStRecords = TILE * 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(stage + kStRecords);
-    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
-    const uint32_t bin0 = bin_first[blockIdx.y];
-    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
-    uint32_t* hist = dst + kStRecords;
-    uint32_t* loff = hist + n_slices;
-    uint32_t* gbase = loff + n_slices;
-    __shared__ uint32_t total_s;
-    // every global input of the workgroup is requested up front, in ONE round trip: dy and x of this thread's
-    // sample (x unconditionally -- loading it only for dy != 0 chains two latencies) and the global offset of
-    // this tile's run in every bin, which does not depend on the histogram
-    const uint32_t i = tile * kStBlock + threadIdx.x;
-    float2 d = make_float2(0.f, 0.f);
-    float xs[3] = {0.f, 0.f, 0.f};
-    bool live = false;
-    if (i < N) {
-        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
-        xs[0] = x[3 * (size_t)i + 0];
-        xs[1] = x[3 * (size_t)i + 1];
-        xs[2] = x[3 * (size_t)i + 2];
-    }
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) {
-        hist[b] = 0u;
-        gbase[b] = base[bin0 + b] + tile_off[(size_t)(bin0 + b) * n_tiles + tile];
-    }
-    __syncthreads();
-    uint32_t idx[8], slot[8];
-    Corner c = {};
-    {
-        if (live) {
-            c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u),
-                                        c.pz + ((k >> 2) & 1u));
-            // rank inside (tile, bin); one LDS atomic per x-corner pair when both corners share the bin
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t b0 = idx[2 * j] / kBinSlice, b1 = idx[2 * j + 1] / kBinSlice;
-                if (b0 == b1) {
-                    const uint32_t r0 = atomicAdd(&hist[b0], 2u);
-                    slot[2 * j] = r0;
-                    slot[2 * j + 1] = r0 + 1u;
-                } else {
-                    slot[2 * j] = atomicAdd(&hist[b0], 1u);
-                    slot[2 * j + 1] = atomicAdd(&hist[b1], 1u);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
-        const int lane = (int)threadIdx.x;
-        uint32_t carry = 0;
-        for (uint32_t b0 = 0; b0 < n_slices; b0 += 64) {
-            const uint32_t b = b0 + lane;
-            const uint32_t cnt = b < n_slices ? hist[b] : 0u;
-            const uint32_t incl = wave_incl_scan_u32(cnt, lane);
-            if (b < n_slices) loff[b] = carry + incl - cnt;
-            carry += nvo_wave_bcast(incl, 63);
-        }
-        if (lane == 0) total_s = carry;
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t b = idx[k] / kBinSlice;
-            const uint32_t pos = loff[b] + slot[k];
-            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                            ((k & 4u) ? c.wz : 1.f - c.wz);
-            stage[pos] = rec_pack(idx[k] & (kBinSlice - 1u), w * d.x, w * d.y);
-            dst[pos] = gbase[b] + slot[k];
-        }
-    }
-    __syncthreads();
-    const uint32_t total = total_s;
-    for (uint32_t t = threadIdx.x; t < total; t += kStBlock) records[dst[t]] = stage[t];
-}
-
-// entries of the slice a bin owns
-__device__ __forceinline__ uint32_t st_bin_entries(const NvoGridLevels& g, uint32_t level, uint32_t slice) {
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    return min(kBinSlice, size - slice * kBinSlice);
-}
-
-// grid = n_bins: slices of multi-chunk bins are combined with float atomics and must start at zero
-__global__ void __launch_bounds__(256)
-k_st_zero(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
-          const uint32_t* __restrict__ bin_chunks, float* __restrict__ grad) {
-    if (bin_chunks[blockIdx.x] <= 1u) return;
-    const uint32_t level = bin_level[blockIdx.x], slice = bin_slice[blockIdx.x];
-    const uint32_t n = 2 * st_bin_entries(g, level, slice);
-    float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
-    for (uint32_t e = threadIdx.x; e < n; e += 256) gr[e] = 0.f;
-}
-
-// PERSISTENT: grid = one workgroup per CU, each loops over the work items (blockIdx.x, + gridDim.x, ...).
-// A 1024-thread workgroup with 128 KiB of LDS has a CU to itself and costs ~6 us just to be dispatched
-// and drained on MI355X (measured: the kernel with an empty body took 44 us for 1775 workgroups), so
-// one-item-per-workgroup launches were dispatch-bound.
-__global__ void __launch_bounds__(kLdsBwdBlock)
-k_st_accumulate(NvoGridLevels g, const uint32_t* __restrict__ bin_level, const uint32_t* __restrict__ bin_slice,
-                const uint32_t* __restrict__ base, const uint4* __restrict__ items,
-                const uint32_t* __restrict__ n_items, const uint2* __restrict__ records, float* __restrict__ grad) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
-    const uint4* __restrict__ rec2 = reinterpret_cast<const uint4*>(records);
-    const uint32_t total_items = n_items[0];
-    for (uint32_t it = blockIdx.x; it < total_items; it += gridDim.x) {
-        const uint4 item = items[it];
-        const uint32_t bin = item.x, chunk = item.y, n_chunks = item.z;
-        const uint32_t level = bin_level[bin], slice = bin_slice[bin];
-        const uint32_t entries = st_bin_entries(g, level, slice);
-        const uint32_t bin_begin = base[bin], bin_end = base[bin + 1];
-        const uint32_t per_chunk = (bin_end - bin_begin + n_chunks - 1) / n_chunks;
-        const uint32_t begin = bin_begin + chunk * per_chunk;
-        const uint32_t end = min(bin_end, begin + per_chunk);
-        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[level] + (size_t)slice * kBinSlice);
-        if (begin >= end) {  // uniform per workgroup
-            if (n_chunks == 1)  // an empty bin still owns its slice: write zeros
-                for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = 0.f;
-            continue;
-        }
-        {
-            uint4* z = reinterpret_cast<uint4*>(lds_raw);
-            for (uint32_t e = threadIdx.x; e < entries; e += kLdsBwdBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        __syncthreads();
-        // Record pairs (16-byte loads), kUnroll of them per thread in flight at once: a chunk of <= 32K
-        // records is requested in one round trip.
-        constexpr uint32_t kUnroll = 16;
-        bool bad = false;  // a record of a non-finite w * dy has an all-ones exponent whatever rides in its mantissa
-        const uint32_t pair_begin = begin >> 1, pair_end = (end + 1u) >> 1;
-        for (uint32_t p0 = pair_begin + threadIdx.x; p0 < pair_end; p0 += kUnroll * kLdsBwdBlock) {
-            uint4 rec[kUnroll];
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; ++u) {
-                const uint32_t p = p0 + u * kLdsBwdBlock;
-                rec[u] = p < pair_end ? rec2[p] : make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; ++u) {
-                const uint32_t r = 2u * (p0 + u * kLdsBwdBlock);
-                if (r >= begin && r < end) {
-                    const uint32_t rel = (rec[u].x & 0x3Fu) | ((rec[u].y & 0x7Fu) << 6);
-                    bad |= ((rec[u].x & 0x7F800000u) == 0x7F800000u) | ((rec[u].y & 0x7F800000u) == 0x7F800000u);
-                    AccFixed::add(acc, rel, __uint_as_float(rec[u].x & ~0x3Fu), __uint_as_float(rec[u].y & ~0x7Fu), AccScale{});
-                }
-                if (r + 1u >= begin && r + 1u < end) {
-                    const uint32_t rel = (rec[u].z & 0x3Fu) | ((rec[u].w & 0x7Fu) << 6);
-                    bad |= ((rec[u].z & 0x7F800000u) == 0x7F800000u) | ((rec[u].w & 0x7F800000u) == 0x7F800000u);
-                    AccFixed::add(acc, rel, __uint_as_float(rec[u].z & ~0x3Fu), __uint_as_float(rec[u].w & ~0x7Fu), AccScale{});
-                }
-            }
-        }
-        __syncthreads();
-        if (n_chunks == 1) {
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) gr[e] = AccFixed::get(acc, e, AccScale{});
-        } else {
-            for (uint32_t e = threadIdx.x; e < 2 * entries; e += kLdsBwdBlock) {
-                const float v = AccFixed::get(acc, e, AccScale{});
-                if (v != 0.f) atomicAdd(gr + e, v);
-            }
-        }
-        __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
-        if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(gr, __builtin_nanf(""));  // poisoned chunk
-    }
-}
-
-// ---- tile-local record layout (NvoGridStream::tile_local) -------------------------------------------------
-// The count / scan passes above exist only to give every (tile, bin) run its place in ONE globally bin-sorted
-// record array.  Here the runs stay where they are produced: tile t of streamed level j owns the fixed region
-// records[(j * n_tiles + t) * TILE * 8 ...], sorted by bin inside, and seg[bin][tile] = start | count << 16 (| bit 31:
-// the tile saw a non-finite dy) says
-// where bin's run sits in it.  The scatter is then a single pass whose output is a straight copy of its LDS
-// staging area (no per-record destination), and the accumulate work items (bin, tile range) are STATIC: a bin's
-// workgroup walks its ~58-record (464-byte) runs, one wave per run, several runs in flight per wave.
-// Removes k_st_count (22 us), both scans (10 us) and the 16 KiB destination array of the scatter.
-template <int TILE, bool SOA, typename DY2>
-__global__ void __launch_bounds__(TILE)
-k_tl_scatter(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
-             const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
-             uint32_t* __restrict__ seg, uint2* __restrict__ records) {
-    constexpr uint32_t kStBlock = TILE;
-    constexpr uint32_t kStRecords = TILE * 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
-    const uint32_t level = st_levels[blockIdx.y], tile = blockIdx.x, n_tiles = gridDim.x;
-    const uint32_t bin0 = bin_first[blockIdx.y];
-    const uint32_t n_slices = bin_first[blockIdx.y + 1] - bin0;
-    const uint32_t size = g.offset[level + 1] - g.offset[level];
-    const uint32_t res = g.resolution[level], hashed = g.hashed[level];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(stage + kStRecords);
-    uint32_t* loff = hist + n_slices;
-    __shared__ uint32_t total_s;
-    const uint32_t i = tile * kStBlock + threadIdx.x;
-    float2 d = make_float2(0.f, 0.f);
-    float xs[3] = {0.f, 0.f, 0.f};
-    bool live = false;
-    if (i < N) {  // dy and x in one round trip
-        live = load_dy_nonzero<SOA, DY2>(g, dy, N, level, i, &d);
-        xs[0] = x[3 * (size_t)i + 0];
-        xs[1] = x[3 * (size_t)i + 1];
-        xs[2] = x[3 * (size_t)i + 2];
-    }
-    for (uint32_t b = threadIdx.x; b < n_slices; b += kStBlock) hist[b] = 0u;
-    __syncthreads();
-    uint32_t idx[8], slot[8];
-    Corner c = {};
-    if (live) {
-        c = grid_cell(g.scale[level], xs[0], xs[1], xs[2]);
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            idx[k] = nvo_grid_index(hashed, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {  // rank inside (tile, bin); one LDS atomic per x-corner pair sharing a bin
-            const uint32_t b0 = idx[2 * j] / kBinSlice, b1 = idx[2 * j + 1] / kBinSlice;
-            if (b0 == b1) {
-                const uint32_t r0 = atomicAdd(&hist[b0], 2u);
-                slot[2 * j] = r0;
-                slot[2 * j + 1] = r0 + 1u;
-            } else {
-                slot[2 * j] = atomicAdd(&hist[b0], 1u);
-                slot[2 * j + 1] = atomicAdd(&hist[b1], 1u);
-            }
-        }
-    }
-    // Integer accumulators cannot carry inf / NaN: a non-finite dy of this (tile, level) is flagged in bit 31 of every
-    // segment word the tile writes, and the accumulate pass poisons the slices that see the flag (the optimiser's
-    // non-finite check decides per parameter group, so the whole level being poisoned changes nothing)
-    const uint32_t bad_bit =
-        __syncthreads_or(live && !(fabsf(d.x) < INFINITY && fabsf(d.y) < INFINITY)) ? 0x80000000u : 0u;
-    if (threadIdx.x < 64) {  // wave 0: exclusive scan over the bins of this level
-        const int lane = (int)threadIdx.x;
-        uint32_t carry = 0;
-        for (uint32_t b0 = 0; b0 < n_slices; b0 += 64) {
-            const uint32_t b = b0 + lane;
-            const uint32_t cnt = b < n_slices ? hist[b] : 0u;
-            const uint32_t incl = wave_incl_scan_u32(cnt, lane);
-            if (b < n_slices) {
-                loff[b] = carry + incl - cnt;
-                seg[(size_t)(bin0 + b) * n_tiles + tile] = (carry + incl - cnt) | (cnt << 16) | bad_bit;
-            }
-            carry += nvo_wave_bcast(incl, 63);
-        }
-        if (lane == 0) total_s = carry;
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t b = idx[k] / kBinSlice;
-            const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
-                            ((k & 4u) ? c.wz : 1.f - c.wz);
-            stage[loff[b] + slot[k]] = rec_pack(idx[k] & (kBinSlice - 1u), w * d.x, w * d.y);
-        }
-    }
-    __syncthreads();
-    // the sorted staging area leaves as ONE contiguous run (16-byte stores)
-    const uint32_t total = total_s;
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(records + ((size_t)blockIdx.y * n_tiles + tile) * kStRecords);
-    const uint4* src = reinterpret_cast<const uint4*>(stage);
-    for (uint32_t t = threadIdx.x; t < (total + 1u) / 2u; t += kStBlock) dst[t] = src[t];
-}
-
-// PERSISTENT like k_st_accumulate; items = {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}:
-// the chunk walks tiles [chunk * per, (chunk + 1) * per) of its bin.
-//
-// One 1024-thread workgroup with 128 KiB of accumulators has a CU to itself, so nothing hides a dependent round trip
-// but the workgroup's own loads: measured with the loads alone (atomics off), a straightforward item -- header ->
-// bin tables -> segment words -> runs in two batches, the second half of every run in a serial tail -- cost 28 us.
-// Hence: the header is self-contained (no bin-table hop); the NEXT item's header and segment words are requested
-// while the current item streams; every wave owns a contiguous block of the item's tiles (all waves stream, whatever
-// the tile count, and a wave's segment words are one contiguous read); and a wave reads its runs as one
-// concatenated record stream, all of whose loads are in flight at once (see the loop).
-constexpr uint32_t kTlWin = 26;  // wave loads per pass: 24 runs x 64 records of a hashed level + slack
-constexpr int kTlBlock = 512;  // two workgroups per CU (2 x 64 KiB of accumulators): their phases overlap
-
+// Work items of the accumulate pass = {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}: the chunk
+// walks tiles [chunk * per, (chunk + 1) * per) of its bin.  The header is self-contained (no bin-table hop), the NEXT
+// item's header and segment words are requested while the current item streams, every wave owns a contiguous block of the
+// item's tiles and reads its runs as one concatenated record stream, all of whose loads are in flight at once.
 struct TlItem {
     uint32_t bin, chunk, n_chunks, lvl, level, slice, t0, t1;
 };
@@ -1777,144 +1181,6 @@ __device__ __forceinline__ TlItem tl_decode(uint4 h, uint32_t n_tiles) {
     I.t0 = min(n_tiles, I.chunk * per);
     I.t1 = min(n_tiles, I.t0 + per);
     return I;
-}
-
-__global__ void __launch_bounds__(kTlBlock)
-k_tl_accumulate(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
-                const uint2* __restrict__ records, uint32_t n_tiles, uint32_t tile_records, float* __restrict__ grad,
-                uint32_t* __restrict__ nf_flag) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
-    const uint32_t lane = threadIdx.x & 63u;
-    // the wave index as a SCALAR: everything derived from it (tile block, run counts, loop bounds, the lane a segment
-    // word is read from) then lives in SGPRs -- left in a VGPR, the compiler treated the run loops as divergent
-    // (exec-masked loops, ds_bpermute for every segment word, 64-bit vector address arithmetic per run)
-    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    constexpr uint32_t kWaves = kTlBlock / 64;
-    uint32_t it = blockIdx.x;
-    if (it >= n_items) return;
-    // Wave w owns the contiguous tile block [t0 + w * per_wave, ...) of an item: its segment words (lane j: the wave's
-    // j-th tile; first block of 64 tiles) are one contiguous read.
-    auto seg_first = [&](const TlItem& I) -> uint32_t {
-        const uint32_t n_span = I.t1 - I.t0;
-        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
-        const uint32_t first = min(n_span, wib * per_wave);
-        const uint32_t n_mine = min(per_wave, n_span - first);
-        return lane < min(64u, n_mine) ? seg[(size_t)I.bin * n_tiles + I.t0 + first + lane] : 0u;
-    };
-    TlItem cur = tl_decode(items[it], n_tiles);
-    uint32_t segw = seg_first(cur);
-    for (;;) {
-        const uint32_t it_next = it + gridDim.x;
-        const bool has_next = it_next < n_items;
-        const uint4 head_next = items[has_next ? it_next : it];  // in flight while the accumulators are zeroed
-        const uint32_t entries = st_bin_entries(g, cur.level, cur.slice);
-        float* __restrict__ gr = grad + 2 * ((size_t)g.offset[cur.level] + (size_t)cur.slice * kBinSlice);
-        {
-            uint4* z = reinterpret_cast<uint4*>(lds_raw);
-            for (uint32_t e = threadIdx.x; e < entries; e += kTlBlock) z[e] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        __syncthreads();
-        const uint2* __restrict__ rec_lvl = records + (size_t)cur.lvl * n_tiles * tile_records;
-        const uint32_t n_span = cur.t1 - cur.t0;
-        const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
-        const uint32_t tile_first = cur.t0 + min(n_span, wib * per_wave);
-        const uint32_t n_mine = min(per_wave, cur.t1 - tile_first);
-        bool bad = false;  // (flagged by the scatter pass in bit 31 of the segment words)
-        auto add = [&](uint2 r) {
-            const uint32_t rel = (r.x & 0x3Fu) | ((r.y & 0x7Fu) << 6);
-            AccFixed::add(acc, rel, __uint_as_float(r.x & ~0x3Fu), __uint_as_float(r.y & ~0x7Fu), AccScale{});
-        };
-        TlItem nxt = cur;
-        uint32_t segw_next = 0u;
-        bool next_requested = false;
-        for (uint32_t j0 = 0; j0 < n_mine; j0 += 64u) {
-            const uint32_t n_here = min(64u, n_mine - j0);
-            if (j0 > 0u)  // (more than 64 tiles per wave: > 1024 tiles in the chunk)
-                segw = lane < n_here ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
-            // The wave's runs (lane j: run of its j-th tile) are read as ONE concatenated stream of `total` records:
-            // wave load q fetches virtual records [64 q, 64 q + 64), whichever runs they fall in.  Every load is full
-            // (no per-run tails, no masked half loads) and all kTlWin loads of a pass -- a whole item's share for this
-            // wave when the level is hashed -- are requested back to back with UNCONDITIONAL loads (straight-line code:
-            // the compiler waits with counted vmcnt(N); loads behind `lane < count` branches made it wait for vmcnt(0)
-            // at every join).
-            const uint32_t cnt = lane < n_here ? (segw >> 16) & 0x7FFFu : 0u;
-            bad |= lane < n_here && (segw >> 31) != 0u;
-            const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            // index (in records, from rec_lvl) of the run's first record minus its position in the stream: a lane whose
-            // virtual record v lies in run j reads rec_lvl[base_j + v]   (mod 2^32 arithmetic)
-            const uint32_t base = (tile_first + j0 + lane) * tile_records + (segw & 0xFFFFu) - (incl - cnt);
-            uint32_t r_s = 0u;  // (scalar) first run that reaches into the current window
-            for (uint32_t q0 = 0; q0 * 64u < total; q0 += kTlWin) {
-                uint2 rec[kTlWin];
-#pragma unroll
-                for (uint32_t u = 0; u < kTlWin; ++u) {
-                    const uint32_t w0 = (q0 + u) * 64u;  // uniform
-                    const uint32_t v = w0 + lane;
-                    uint32_t my_base = 0u;
-                    if (w0 < total) {
-                        // ~9 vector instructions per window: the run index lives in an SGPR, the lanes only compare
-                        // against the (scalar) start of each further run that begins inside the window
-                        uint32_t end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r_s);
-                        while (end_r <= w0) end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)++r_s);
-                        my_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r_s);
-                        for (uint32_t r = r_s; end_r < w0 + 64u && r < 63u;) {
-                            ++r;
-                            const uint32_t b_r = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)r);
-                            my_base = v >= end_r ? b_r : my_base;  // (end of run r - 1 = start of run r)
-                            end_r = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)r);
-                        }
-                    }
-                    rec[u] = rec_lvl[v < total ? my_base + v : 0u];
-                }
-                if (!next_requested) {  // the next item's segment words ride behind this item's loads
-                    next_requested = true;
-                    if (has_next) {
-                        nxt = tl_decode(head_next, n_tiles);
-                        segw_next = seg_first(nxt);
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kTlWin; ++u)
-                    if ((q0 + u) * 64u + lane < total) add(rec[u]);
-            }
-        }
-        if (!next_requested && has_next) {  // (a wave without records in this item)
-            nxt = tl_decode(head_next, n_tiles);
-            segw_next = seg_first(nxt);
-        }
-        __syncthreads();
-        {
-            // flush: 4 consecutive gradient scalars per thread and step (two 16-byte LDS reads, one 16-byte store)
-            const uint32_t n4 = entries >> 1;  // 2 * entries scalars / 4
-            float4* __restrict__ gr4 = reinterpret_cast<float4*>(gr);
-            if (cur.n_chunks == 1u) {
-                for (uint32_t e = threadIdx.x; e < n4; e += kTlBlock) {
-                    float4 v;
-                    v.x = AccFixed::get(acc, 4 * e + 0, AccScale{});
-                    v.y = AccFixed::get(acc, 4 * e + 1, AccScale{});
-                    v.z = AccFixed::get(acc, 4 * e + 2, AccScale{});
-                    v.w = AccFixed::get(acc, 4 * e + 3, AccScale{});
-                    gr4[e] = v;
-                }
-            } else {
-                for (uint32_t e = threadIdx.x; e < 2 * entries; e += kTlBlock) {
-                    const float v = AccFixed::get(acc, e, AccScale{});
-                    if (v != 0.f) atomicAdd(gr + e, v);
-                }
-            }
-        }
-        __syncthreads();  // the next item zeroes the accumulators; the plain stores above have retired
-        if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
-            atomicAdd(gr, __builtin_nanf(""));
-            if (nf_flag) atomicOr(nf_flag, 1u);
-        }
-        if (!has_next) break;
-        it = it_next;
-        cur = nxt;
-        segw = segw_next;
-    }
 }
 
 // ---- tile-local layout, PACKED accumulators (NvoGridStream::acc_bits == 32; round 3) ---------------------------
@@ -2821,7 +2087,6 @@ void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s,
 }
 
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out) {
-    if (!st->tile_local) return false;  // the sorted layout decides per launch which bins are chunked
     nvo_grid_slices_zero_ranges(g, &st->owner, grad, out);
     // streamed DENSE levels: their bins are split into tile ranges that combine with float atomics (k_st_zero)
     if (st->dense_chunks > 1)
@@ -2829,109 +2094,6 @@ bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st
             if (((st->streamed_mask >> l) & 1u) && !g.hashed[l])
                 out->push_back({grad + 2 * (size_t)g.offset[l], sizeof(float) * 2 * (size_t)(g.offset[l + 1] - g.offset[l])});
     return true;
-}
-
-int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b) {
-    std::vector<uint32_t> levels, first, bin_level, bin_slice;
-    b->binned_mask = 0;
-    b->max_slices = 0;
-    for (uint32_t l = 0; l < g.n_levels; ++l) {
-        const uint32_t size = g.offset[l + 1] - g.offset[l];
-        if (!g.hashed[l] || size < kBinSlice || (size & (size - 1u))) continue;
-        levels.push_back(l);
-        first.push_back((uint32_t)bin_level.size());
-        const uint32_t n_slices = size / kBinSlice;
-        if (n_slices > b->max_slices) b->max_slices = n_slices;
-        for (uint32_t s = 0; s < n_slices; ++s) {
-            bin_level.push_back(l);
-            bin_slice.push_back(s);
-        }
-        b->binned_mask |= 1u << l;
-    }
-    b->n_binned_levels = (uint32_t)levels.size();
-    b->n_bins = (uint32_t)bin_level.size();
-    if (b->n_bins) {
-        const size_t words = 2 * levels.size() + 2 * bin_level.size() + 3 * bin_level.size() + 1;
-        NVO_CHECK_HIP(hipMalloc((void**)&b->d_binned_levels, sizeof(uint32_t) * words));
-        uint32_t* p = b->d_binned_levels;
-        b->d_bin_first = p + levels.size();
-        b->d_bin_level = b->d_bin_first + levels.size();
-        b->d_bin_slice = b->d_bin_level + bin_level.size();
-        b->d_counts = b->d_bin_slice + bin_level.size();
-        b->d_base = b->d_counts + bin_level.size();
-        b->d_cursor = b->d_base + bin_level.size() + 1;
-        NVO_CHECK_HIP(hipMemcpy(b->d_binned_levels, levels.data(), 4 * levels.size(), hipMemcpyHostToDevice));
-        NVO_CHECK_HIP(hipMemcpy(b->d_bin_first, first.data(), 4 * first.size(), hipMemcpyHostToDevice));
-        NVO_CHECK_HIP(hipMemcpy(b->d_bin_level, bin_level.data(), 4 * bin_level.size(), hipMemcpyHostToDevice));
-        NVO_CHECK_HIP(hipMemcpy(b->d_bin_slice, bin_slice.data(), 4 * bin_slice.size(), hipMemcpyHostToDevice));
-    }
-    const uint32_t all = g.n_levels >= 32 ? 0xFFFFFFFFu : ((1u << g.n_levels) - 1u);
-    return nvo_grid_slices_create(g, &b->dense, all & ~b->binned_mask);
-}
-
-void nvo_grid_bins_destroy(NvoGridBins* b) {
-    if (b->d_binned_levels) (void)hipFree(b->d_binned_levels);
-    nvo_scratch_destroy(&b->records);
-    b->d_binned_levels = nullptr;
-    b->n_bins = b->n_binned_levels = 0;
-    nvo_grid_slices_destroy(&b->dense);
-}
-
-// mode 2: binned scatter for hashed levels + slice-owner items for the rest
-int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad) {
-    NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported");
-    NVO_REQUIRE(N < (1u << 29), "grid_bwd_binned: batch too large for 29-bit sample ids");
-    NVO_REQUIRE((uint64_t)N * 8 * bins->n_binned_levels < 0xFFFFFFFFull, "grid_bwd_binned: too many records");
-    NVO_PROF(stream, "grid_bwd_binned[L%u]", g.n_levels);
-    if (bins->n_bins) {
-        const size_t need = (size_t)N * 8 * bins->n_binned_levels;
-        if (int rc = nvo_scratch_reserve(&bins->records, sizeof(uint32_t) * need, stream, "grid_bwd_binned records")) return rc;
-        uint32_t* const d_records = static_cast<uint32_t*>(bins->records.ptr);
-        if (int rc = nvo_zero_async(bins->d_counts, sizeof(uint32_t) * bins->n_bins, stream)) return rc;
-        const dim3 grid(nvo_div_up(N, kBinBlock), bins->n_binned_levels), block(kBinBlock);
-        // few bins (small tables): several workgroups per bin, combined with contiguous float atomics
-        uint32_t acc_chunks = 1;
-        while (bins->n_bins * acc_chunks < 512u && acc_chunks < 64u) acc_chunks *= 2;
-        if (acc_chunks > 1) {
-            for (uint32_t j = 0; j < 32; ++j) {
-                if (!((bins->binned_mask >> j) & 1u)) continue;
-                if (int rc = nvo_zero_async(grad + 2 * (size_t)g.offset[j],
-                                            sizeof(float) * 2 * (size_t)(g.offset[j + 1] - g.offset[j]), stream))
-                    return rc;
-            }
-        }
-        const size_t lds_hist = sizeof(uint32_t) * 2 * bins->max_slices;
-        const size_t lds_acc = sizeof(unsigned long long) * 2 * kBinSlice;
-#define NVO_LAUNCH_BIN(SOA_, T_)                                                                             \
-    do {                                                                                                     \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_bin_accumulate<SOA_, T_>,                       \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));   \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
-        NVO_LAUNCH((k_bin_count_scatter<false, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy, \
-                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, d_records); \
-        NVO_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, stream, bins->n_bins, bins->d_counts, bins->d_base,   \
-                   bins->d_cursor);                                                                          \
-        NVO_LAUNCH((k_bin_count_scatter<true, SOA_, T_>), grid, block, lds_hist, stream, g, N, x, (const T_*)dy,  \
-                   bins->d_binned_levels, bins->d_bin_first, bins->d_counts, bins->d_cursor, d_records); \
-        NVO_LAUNCH((k_bin_accumulate<SOA_, T_>), dim3(bins->n_bins, acc_chunks), dim3(kLdsBwdBlock), lds_acc, stream, g, N, x, \
-                   (const T_*)dy, bins->d_bin_level, bins->d_bin_slice, bins->d_base, d_records, grad); \
-    } while (0)
-        if (soa) {
-            NVO_DY_DISPATCH(NVO_LAUNCH_BIN, true);
-        } else {
-            NVO_DY_DISPATCH(NVO_LAUNCH_BIN, false);
-        }
-#undef NVO_LAUNCH_BIN
-        NVO_CHECK_LAUNCH();
-    }
-    if (bins->dense.n_slices) {
-        return nvo_grid_bwd_launch(g, &bins->dense, stream, N, x, dy, dy_fmt, soa, grad, 1);
-    }
-    return NVO_OK;
 }
 
 // ---- mode 3 host side ---------------------------------------------------------------------------
@@ -2944,16 +2106,13 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     st->streamed_mask = 0;
     if (const char* e = getenv("NVO_GRID_STREAM_OVERLAP")) st->overlap = atoi(e) != 0;  // A/B switch for measurements
     if (const char* e = getenv("NVO_GRID_OWNER_SLICES")) st->owner_max_slices = (uint32_t)atoi(e);  // measurements
-    if (const char* e = getenv("NVO_TL_ACC_BITS")) st->acc_bits = (uint32_t)atoi(e);  // A/B switch for measurements
-    if (const char* e = getenv("NVO_GRID_STREAM_LAYOUT")) st->tile_local = atoi(e) != 0;  // A/B switch for measurements
-    if (!st->tile_local) st->acc_bits = 64;  // (the packed accumulators exist for the tile-local layout only)
-    // entries per bin: 4096 x 16 B (two 64-bit sums per entry) or 8192 x 8 B (two 32-bit sums in one word) = 64 KiB
+    // entries per bin: 8192 x 8 B (two 32-bit fixed-point sums in one 64-bit word) = 64 KiB
     // (6176-entry bins -- 85 per 2^19 table, 935 hashed items = two even rounds of 512 workgroups on paper -- measured
     // SLOWER: 139.0 / 146.1 us for the stage against 132.8 / 127.3 with 8192-entry bins (dealt / balanced work list):
     // the shorter runs cost more than the evener rounds save)
     uint32_t bin_p = kBinP;
     if (const char* e = getenv("NVO_TL_BIN")) bin_p = (uint32_t)atoi(e) == kBinPSmall ? kBinPSmall : kBinP;  // measurements
-    const uint32_t bin_entries = st->acc_bits == 32 ? bin_p : kBinSlice;
+    const uint32_t bin_entries = bin_p;
     st->bin_entries = bin_entries;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offset[l + 1] - g.offset[l];
@@ -2974,22 +2133,19 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
     st->n_bins = (uint32_t)bin_level.size();
     const size_t nb = st->n_bins;
     if (nb) {
-        const size_t words = levels.size() + first.size() + 2 * nb + nb /*totals*/ + (nb + 1) /*base*/ + nb /*chunks*/ + 4;
+        const size_t words = levels.size() + first.size() + 2 * nb + nb /*chunks*/ + 4;
         NVO_CHECK_HIP(hipMalloc((void**)&st->d_meta, sizeof(uint32_t) * words));
         st->d_levels = st->d_meta;
         st->d_bin_first = st->d_levels + levels.size();
         st->d_bin_level = st->d_bin_first + first.size();
         st->d_bin_slice = st->d_bin_level + nb;
-        st->d_totals = st->d_bin_slice + nb;
-        st->d_base = st->d_totals + nb;
-        st->d_bin_chunks = st->d_base + nb + 1;
-        st->d_n_items = st->d_bin_chunks + nb;
+        st->d_bin_chunks = st->d_bin_slice + nb;
         NVO_CHECK_HIP(hipMemcpy(st->d_levels, levels.data(), 4 * levels.size(), hipMemcpyHostToDevice));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_first, first.data(), 4 * first.size(), hipMemcpyHostToDevice));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_level, bin_level.data(), 4 * nb, hipMemcpyHostToDevice));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_slice, bin_slice.data(), 4 * nb, hipMemcpyHostToDevice));
     }
-    if (st->tile_local && nb) {
+    if (nb) {
         // static work list: hashed levels spread their records evenly over the bins (one item per bin); a streamed
         // DENSE level sees clustered samples, so its bins are split into tile ranges
         std::vector<uint32_t> items, chunks(nb, 1u);
@@ -3017,7 +2173,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
             }
         }
         st->n_tl_slots = 0;
-        if (st->acc_bits == 32 && !(getenv("NVO_TL_BALANCE") && atoi(getenv("NVO_TL_BALANCE")) == 0)) {
+        if (!(getenv("NVO_TL_BALANCE") && atoi(getenv("NVO_TL_BALANCE")) == 0)) {
             // BALANCED work list for the persistent accumulate (2 workgroups per CU, workgroup w walks items w, w + slots,
             // ...).  Dealt round-robin, 704 hashed-level items + 208 cheap dense-level chunks gave some workgroups two
             // hashed items and a chunk, others one hashed item: the launch lasted as long as the former (132.8 -> 127.3
@@ -3104,7 +2260,7 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
 void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n) {
     *first = 0;
     *n = 0;
-    if (!st->created || !st->tile_local || st->acc_bits != 32) return;
+    if (!st->created) return;
     // the streamed hashed levels: one accumulate item per bin (nvo_grid_stream_create); they form the tail of the table
     uint32_t lo = g.n_levels;
     for (uint32_t l = 0; l < g.n_levels; ++l)
@@ -3128,7 +2284,6 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         return (uint32_t)(n > 0 ? n : 256);
     }();
     const uint32_t tile = st->tile;
-    NVO_REQUIRE(tile == 256 || tile == 512 || tile == 1024, "grid_stream_tile must be 256, 512 or 1024");
     const uint32_t n_tiles = nvo_div_up(N, tile);
     // fork: with the per-kernel profiler on, everything stays on the caller's stream (its events live there)
     // ... and with the optimiser step armed (st->adam.params): k_tl_accumulate_p reads *adam.skip_flag once, so every
@@ -3147,59 +2302,23 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         if (fork) NVO_CHECK_HIP(hipEventRecord(st->ev_join, st->aux));
     }
     if (st->n_bins == 0) return NVO_OK;
-    if (st->tile_local) {
-        const size_t tile_records = (size_t)tile * 8;
-        const bool packed = st->acc_bits == 32;  // (12-byte pair records; the 64-bit form keeps 8-byte corner records)
-        const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * (packed ? 12 : sizeof(uint2)), 256);
-        const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
-        const size_t need_tl = rec_bytes_tl + seg_bytes * (packed ? 2 : 1);
-        if (int rc = nvo_scratch_reserve(&st->work, need_tl, stream, "grid_bwd_stream records")) return rc;
-        unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
-        uint2* records_tl = reinterpret_cast<uint2*>(d_work);
-        uint32_t* seg = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl);
-        const dim3 grid_tl(n_tiles, st->n_levels);
-        const size_t lds_tl = tile_records * sizeof(uint2) + sizeof(uint32_t) * 2 * st->max_slices;
-        const size_t lds_acc_tl = sizeof(unsigned long long) * 2 * kBinSlice;
-        NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
-#define NVO_LAUNCH_TL(TILE_, SOA_, T_)                                                                       \
-    do {                                                                                                     \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter<TILE_, SOA_, T_>,                    \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                                              (int)((size_t)TILE_ * 64 + 8 * 4096)));                        \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate,                                  \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc_tl)); \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                             \
-            NVO_LAUNCH((k_tl_scatter<TILE_, SOA_, T_>), grid_tl, dim3(TILE_), lds_tl, stream, g, N, x, (const T_*)dy, \
-                       st->d_levels, st->d_bin_first, seg, records_tl);                                       \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                          \
-            if (!st->external_zero)                                                                          \
-                NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
-                           st->d_bin_chunks, grad);                                                          \
-            NVO_LAUNCH(k_tl_accumulate, dim3(st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus), dim3(kTlBlock), \
-                       lds_acc_tl, stream, g, (const uint4*)st->d_tl_items, st->n_tl_items, seg, records_tl, \
-                       n_tiles, (uint32_t)tile_records, grad, st->owner.nf_flag);                            \
-        }                                                                                                    \
-    } while (0)
-#define NVO_LAUNCH_TL_T(SOA_, T_)                                                 \
-    do {                                                                          \
-        if (tile == 256) NVO_LAUNCH_TL(256, SOA_, T_);                            \
-        else if (tile == 512) NVO_LAUNCH_TL(512, SOA_, T_);                       \
-        else NVO_LAUNCH_TL(1024, SOA_, T_);                                       \
-    } while (0)
-        if (packed) {
-            // two 32-bit fixed-point sums per 64-bit accumulator word, 8192-entry bins (k_tl_scatter_p / k_tl_accumulate_p)
-            NVO_REQUIRE(tile == 512 || tile == 1024, "grid_bwd_stream: the packed accumulators take 512- or 1024-sample tiles");
-            uint32_t* segl1 = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl + seg_bytes);
-            const size_t lds_p = tile_records * 12 + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
-            const size_t lds_acc_p = sizeof(unsigned long long) * st->bin_entries;
-            const uint32_t acc_grid = st->n_tl_slots ? st->n_tl_slots : (st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus);
+    // tile-local 12-byte pair records, two 32-bit fixed-point sums per 64-bit accumulator word, 8192-entry bins
+    // (k_tl_scatter_p / k_tl_accumulate_p)
+    const size_t tile_records = (size_t)tile * 8;
+    const size_t rec_bytes_tl = nvo_round_up((size_t)st->n_levels * n_tiles * tile_records * 12, 256);
+    const size_t seg_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
+    const size_t need_tl = rec_bytes_tl + seg_bytes * 2;
+    if (int rc = nvo_scratch_reserve(&st->work, need_tl, stream, "grid_bwd_stream records")) return rc;
+    unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
+    uint2* records_tl = reinterpret_cast<uint2*>(d_work);
+    uint32_t* seg = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl);
+    const dim3 grid_tl(n_tiles, st->n_levels);
+    NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
+    NVO_REQUIRE(tile == 512 || tile == 1024, "grid_bwd_stream: the packed accumulators take 512- or 1024-sample tiles");
+    uint32_t* segl1 = reinterpret_cast<uint32_t*>(d_work + rec_bytes_tl + seg_bytes);
+    const size_t lds_p = tile_records * 12 + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
+    const size_t lds_acc_p = sizeof(unsigned long long) * st->bin_entries;
+    const uint32_t acc_grid = st->n_tl_slots ? st->n_tl_slots : (st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus);
 #define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_, TILE_)                                                               \
     do {                                                                                                      \
         static bool attr_set = false;                                                                         \
@@ -3233,81 +2352,9 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
         else if (tile == 1024) NVO_LAUNCH_TLP_B(SOA_, T_, kBinP, 1024);                    \
         else NVO_LAUNCH_TLP_B(SOA_, T_, kBinP, 512);                                       \
     } while (0)
-            if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
+    if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
 #undef NVO_LAUNCH_TLP
 #undef NVO_LAUNCH_TLP_B
-        } else if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TL_T, false);
-#undef NVO_LAUNCH_TL_T
-#undef NVO_LAUNCH_TL
-        NVO_CHECK_LAUNCH();
-        if (fork) NVO_CHECK_HIP(hipStreamWaitEvent(stream, st->ev_join, 0));  // join
-        return NVO_OK;
-    }
-    const size_t n_records = (size_t)N * 8 * st->n_levels;
-    const uint32_t max_items = st->n_bins + (uint32_t)(n_records / kStChunkRecords) + 1u;
-    // scratch: records | counts[n_bins][n_tiles] | items[max_items]   (graph-safe growth: NvoScratch)
-    const size_t rec_bytes = nvo_round_up(n_records * sizeof(uint2), 256);
-    const size_t cnt_bytes = nvo_round_up((size_t)st->n_bins * n_tiles * sizeof(uint32_t), 256);
-    const size_t item_bytes = (size_t)max_items * sizeof(uint4);
-    const size_t need = rec_bytes + cnt_bytes + item_bytes;
-    if (int rc = nvo_scratch_reserve(&st->work, need, stream, "grid_bwd_stream records")) return rc;
-    unsigned char* d_work = static_cast<unsigned char*>(st->work.ptr);
-    uint2* records = reinterpret_cast<uint2*>(d_work);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(d_work + rec_bytes);
-    uint4* items = reinterpret_cast<uint4*>(d_work + rec_bytes + cnt_bytes);
-    const dim3 grid(n_tiles, st->n_levels);
-    const size_t lds_hist = sizeof(uint32_t) * st->max_slices;
-    const size_t lds_stage = (size_t)tile * 8 * 12 + sizeof(uint32_t) * 3 * st->max_slices;
-    const size_t lds_acc = sizeof(unsigned long long) * 2 * kBinSlice;
-#define NVO_LAUNCH_ST(TILE_, SOA_, T_)                                                                       \
-    do {                                                                                                     \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_st_scatter<TILE_, SOA_, T_>,                    \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                                              (int)((size_t)TILE_ * 96 + 12 * 4096)));                       \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_st_accumulate,                                  \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));   \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "st_count[L%u]", g.n_levels);                                               \
-            NVO_LAUNCH((k_st_count<TILE_, SOA_, T_>), grid, dim3(TILE_), lds_hist, stream, g, N, x, (const T_*)dy, \
-                       st->d_levels, st->d_bin_first, counts);                                                 \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "st_scan[L%u]", g.n_levels);                                                \
-            NVO_LAUNCH(k_st_scan_tiles, dim3(st->n_bins), dim3(256), 0, stream, n_tiles, counts, st->d_totals); \
-            NVO_LAUNCH(k_st_scan_bins, dim3(1), dim3(1024), 0, stream, st->n_bins, st->d_totals, st->d_base, \
-                       items, st->d_n_items, st->d_bin_chunks, max_items);                                   \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "st_scatter[L%u]", g.n_levels);                                             \
-            NVO_LAUNCH((k_st_scatter<TILE_, SOA_, T_>), grid, dim3(TILE_), lds_stage, stream, g, N, x, (const T_*)dy, \
-                       st->d_levels, st->d_bin_first, counts, st->d_base, records);                            \
-        }                                                                                                    \
-        {                                                                                                    \
-            NVO_PROF_SUB(stream, "st_accumulate[L%u]", g.n_levels);                                          \
-            NVO_LAUNCH(k_st_zero, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
-                       st->d_bin_chunks, grad);                                                              \
-            NVO_LAUNCH(k_st_accumulate, dim3(max_items < n_cus ? max_items : n_cus), dim3(kLdsBwdBlock), lds_acc, \
-                       stream, g, st->d_bin_level, st->d_bin_slice, st->d_base, items, st->d_n_items, records, grad); \
-        }                                                                                                    \
-    } while (0)
-#define NVO_LAUNCH_ST_T(SOA_, T_)                                                 \
-    do {                                                                          \
-        if (tile == 256) NVO_LAUNCH_ST(256, SOA_, T_);                            \
-        else if (tile == 512) NVO_LAUNCH_ST(512, SOA_, T_);                       \
-        else NVO_LAUNCH_ST(1024, SOA_, T_);                                       \
-    } while (0)
-    NVO_REQUIRE(st->max_slices <= 4096, "grid_bwd_stream: level too large (%u bins)", st->max_slices);
-    if (soa) {
-        NVO_DY_DISPATCH(NVO_LAUNCH_ST_T, true);
-    } else {
-        NVO_DY_DISPATCH(NVO_LAUNCH_ST_T, false);
-    }
-#undef NVO_LAUNCH_ST_T
-#undef NVO_LAUNCH_ST
     NVO_CHECK_LAUNCH();
     if (fork) NVO_CHECK_HIP(hipStreamWaitEvent(stream, st->ev_join, 0));  // join
     return NVO_OK;

@@ -67,28 +67,9 @@ void nvo_grid_slices_zero_ranges(const NvoGridLevels& g, const NvoGridSlices* s,
 int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t level_mask = 0xFFFFFFFFu,
                            uint32_t target_items = 1024, bool env_items = true);
 
-// Binned backward (mode 2): hashed levels go through count/scan/scatter/accumulate, the remaining
-// (dense, small) levels through the slice-owner items in `dense`.
-struct NvoGridBins {
-    uint32_t n_binned_levels = 0, n_bins = 0, max_slices = 0;
-    uint32_t binned_mask = 0;
-    uint32_t* d_binned_levels = nullptr;  // [n_binned_levels]
-    uint32_t* d_bin_first = nullptr;      // [n_binned_levels]
-    uint32_t* d_bin_level = nullptr;      // [n_bins]
-    uint32_t* d_bin_slice = nullptr;      // [n_bins]
-    uint32_t* d_counts = nullptr;         // [n_bins]
-    uint32_t* d_base = nullptr;           // [n_bins + 1]
-    uint32_t* d_cursor = nullptr;         // [n_bins]
-    NvoScratch records;                   // [N * 8 * n_binned_levels] uint32 (grows with N; graph-safe)
-    NvoGridSlices dense;
-};
-int nvo_grid_bins_create(const NvoGridLevels& g, NvoGridBins* b);
-void nvo_grid_bins_destroy(NvoGridBins* b);
-int nvo_grid_bwd_binned_launch(const NvoGridLevels& g, NvoGridBins* bins, hipStream_t stream, uint32_t N,
-                               const float* x, const void* dy, int dy_fmt, bool soa, float* grad);
-
-// Streamed binned backward (mode 3): levels with many 4K-entry bins go through count / scan / scatter of
-// self-contained 8-byte records / streaming accumulate; the coarse levels keep slice-owner items.
+// Streamed backward (mode 3): levels with many 4K-entry bins go through a scatter of self-contained 12-byte pair records,
+// bin-sorted inside each tile, and a streaming accumulate into packed 2 x 32-bit LDS sums; the coarse levels keep
+// slice-owner items.
 // Adam fused into the tile-local accumulate pass (k_tl_accumulate_p): the single-item bins of the streamed HASHED levels
 // hold their finished gradient in LDS when they flush, so the optimiser step of those entries happens right there --
 // the gradient is neither written (4 B per parameter) nor read again by the optimiser launch (4 B), and that launch
@@ -118,17 +99,14 @@ struct NvoGridStream {
     uint32_t n_levels = 0, n_bins = 0, max_slices = 0;
     uint32_t streamed_mask = 0;
     uint32_t owner_max_slices = 24;   // levels with at most this many 4K-entry bins stay slice-owner (measured optimum: levels 0-3 of the main grid)
-    uint32_t tile = 512;              // samples per count / scatter workgroup (256 | 512 | 1024)
+    uint32_t tile = 512;              // samples per scatter workgroup (512 | 1024)
     uint32_t* d_meta = nullptr;       // one allocation holding the arrays below
     uint32_t* d_levels = nullptr;     // [n_levels] streamed level ids
     uint32_t* d_bin_first = nullptr;  // [n_levels + 1]
     uint32_t* d_bin_level = nullptr;  // [n_bins]
     uint32_t* d_bin_slice = nullptr;  // [n_bins]
-    uint32_t* d_totals = nullptr;     // [n_bins]
-    uint32_t* d_base = nullptr;       // [n_bins + 1]
     uint32_t* d_bin_chunks = nullptr; // [n_bins]
-    uint32_t* d_n_items = nullptr;    // [1]
-    NvoScratch work;                  // records | counts | items (sized for the largest batch seen; graph-safe growth)
+    NvoScratch work;                  // records | segment tables (sized for the largest batch seen; graph-safe growth)
     NvoGridSlices owner;
     // The slice-owner items of the coarse levels and the record pipeline of the streamed levels touch disjoint
     // gradient ranges, so they CAN run side by side (the former on this auxiliary stream, forked from / joined to the
@@ -136,14 +114,11 @@ struct NvoGridStream {
     // 0.778 / 0.775 ms back to back -- the 512 slice-owner items already fill the CUs -- so the default is off
     // (option grid_stream_overlap / NVO_GRID_STREAM_OVERLAP=1).
     bool overlap = false;
-    // Tile-local record layout (option grid_stream_layout = 1, the default; 0 = globally bin-sorted records with
-    // count / scan passes): every (tile, level) keeps its bin-sorted records in a fixed region + a [bin][tile] segment
-    // table; accumulate items are static (grid.hip).  Measured on the full step: 0.744 vs 0.769 ms.
-    bool tile_local = true;
-    // (tile-local layout) accumulators of the record pass: 64 = two 64-bit fixed-point sums per entry, 4096-entry bins;
-    // 32 = two 32-bit fixed-point sums in ONE 64-bit word (one LDS atomic per record), 8192-entry bins, overflow-proof
-    // scale from per-(tile, bin) L1 bounds the scatter delivers with its rank atomics (grid.hip, k_tl_scatter_p)
-    uint32_t acc_bits = 64;
+    // Record layout: every (tile, level) keeps its bin-sorted 12-byte pair records in a fixed region + a [bin][tile]
+    // segment table; accumulate items are static (grid.hip).  Accumulators of the record pass: two 32-bit fixed-point sums
+    // in ONE 64-bit word (one LDS atomic per record), 8192-entry bins, overflow-proof scale from per-(tile, bin) L1 bounds
+    // the scatter delivers with its rank atomics (k_tl_scatter_p).  (Rounds 2-3 also carried a globally bin-sorted layout
+    // with count / scan passes and 64-bit accumulators over 4096-entry bins: 0.769 vs 0.744 ms per step, removed.)
     uint32_t bin_entries = 4096;      // (set by create)
     uint32_t dense_chunks = 8;        // tile-range chunks per bin of a streamed DENSE level (clustered samples)
     uint32_t* d_tl_items = nullptr;   // uint4 {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}
@@ -151,9 +126,9 @@ struct NvoGridStream {
     uint32_t n_tl_slots = 0;          // (packed form) persistent workgroups the balanced item list was laid out for; 0 = dealt
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool external_zero = false;  // (tile-local layout only) see NvoGridSlices::external_zero
+    bool external_zero = false;  // see NvoGridSlices::external_zero
     bool deterministic = false;  // (set before create) one accumulate item per bin on dense levels too; owner: see there
-    NvoGridAdam adam;            // (packed tile-local layout) optimiser step inside the accumulate pass, see NvoGridAdam
+    NvoGridAdam adam;            // optimiser step inside the accumulate pass, see NvoGridAdam
 };
 // entries [first, first + n) of the table (in ENTRIES: two parameters each) whose Adam step NvoGridStream::adam takes over:
 // the streamed hashed levels (one accumulate item per bin); n = 0 when the configuration has none

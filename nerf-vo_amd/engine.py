@@ -128,18 +128,9 @@ class EngineConfig:
     # run the proposal-network losses + backward on a second HIP stream beside the main-field backward
     # (they only share read-only inputs; forked after the render/loss kernel, joined before the optimiser)
     overlap_proposal_backward: bool = True
-    proposal_backward_streams: int = 1    # 2 = one side stream per proposal network (measured: see DESIGN.md section 5.0)
-    proposal_grid_acc_bits: int = 32      # 64 = 2^26 fixed point in int64 (as the main grid uses)
     # chunks of the proposal grids' DENSE slices relative to the even split of the one-round item table, percent;
     # None = 120 when most samples carry a gradient (bf16 MLPs or dynamic_loss_scale), else 100
     proposal_dense_share: int | None = None
-    # record pass of the main grid's streamed levels (grid_bwd_mode 3): 32 = ONE 64-bit LDS atomic per record on two
-    # packed 32-bit fixed-point sums, 8192-entry bins, overflow-proof scale from the scatter's per-(tile, bin) L1 bounds
-    # (k_tl_scatter_p / k_tl_accumulate_p: accumulate 83 -> 69 us on the kernel bench); 64 = two 64-bit sums per entry
-    main_grid_stream_acc_bits: int = 32
-    main_grid_owner_acc_bits: int = 32    # accumulators of the main grid's slice-owner (coarse) levels: 32 | 64
-    # dense levels of (main, proposal 0, proposal 1): run-merging scan in the slice-owner items (option grid_bwd_runs)
-    grid_bwd_runs: tuple = (True, True, True)
     # Main grid: the forward also stores d(encoded)/d(position) (tcnn's prepare_input_gradients) whenever positions
     # need gradients (pose optimisation, analytic normals); the input backward then streams it (112 -> ~20 us) instead
     # of gathering the corners again.  None = on iff optimize_poses or expect_normals.
@@ -149,22 +140,6 @@ class EngineConfig:
     expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
-    # both proposal levels' loss kernels in one launch (nvo_prop_loss_pair)
-    pair_proposal_losses: bool = True
-    # proposal backward (one side stream): the fused-MLP backward of proposal network 1 runs on a stream of its own beside
-    # network 0's MLP / hash-grid backward (both MLP backwards are latency-bound launches of two waves per SIMD); its
-    # hash-grid backward then follows network 0's on the side stream (nvo_bwd_fork)
-    overlap_proposal_mlp: bool = True
-    # one-graph step, update steps with fixed poses: the fused Adam of the FIELDS group (12.25 M parameters, HBM-bound,
-    # ~63 us) is launched on the main-field backward's stream as soon as that backward is done, beside the rest of the
-    # (longer) proposal chain -- LDS / issue-bound kernels that leave the memory system mostly idle -- instead of behind
-    # the join; the proposal group's Adam follows the join.  Same values: every group still reads its own overflow flag,
-    # and GradScaler.update (nvo_opt_commit) runs once, behind both.
-    # MEASURED SLOWER (0.6157 vs 0.6113 ms per step, two alternating pairs on one box): the Adam stream and the slice-owner
-    # scans compete for the same L2 / fabric path after all (as did Adam beside the sampling prefix); off.
-    overlap_fields_adam: bool = False
-    # one-graph step (single GPU): the step's zero launch rides in extra workgroups of the ray head's launch
-    zero_with_ray_head: bool = True
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
     # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
     commit_behind_replay: bool = True
@@ -191,19 +166,6 @@ class EngineConfig:
     # gains only 2 %): the Adam stream saturates HBM and the prefix's gathers then wait longer for their misses -- the
     # chip has no idle resource for a second kernel to use.  Off by default; kept for the test of the launch order.
     pipeline_single_gpu: bool = False
-    # graph-replayed step: pixel sampling, ray generation, target gather, SH and the first sampler level in ONE launch
-    # (nvo_ray_head) instead of five 4096-ray kernels of ~6 us dispatch + drain each; bit-identical
-    fused_ray_head: bool = True
-    # proposal networks: evaluate the hash grid inside the MLP kernel's operand load (module option fuse_encoding:
-    # one launch per level instead of two, no feature round trip between them; bit-identical).  MEASURED SLOWER and
-    # therefore off: 51.5 us per launch against 35 + 8.2 us for the two kernels (0.760 vs 0.740 ms per step) -- a lane
-    # group of the MFMA operand layout owns two levels, so with 5 levels the groups gather 2 / 2 / 1 / 0 levels, and
-    # the stand-alone gather has a thread per (sample, level).  (Never for the main field: its 16 level tables, 24 MiB,
-    # only stay L2-resident because k_grid_fwd pins each level to one XCD.)
-    fuse_proposal_encoding: bool = False
-    # proposal grids: the slice-owner scatter scans a list of the samples with a non-zero gradient instead of all of
-    # them (option grid_compact_live; 87-98 % of the proposal samples have dL/dy == 0 from a few hundred steps on)
-    compact_live_proposal_samples: bool = True
     # 16-bit format of everything the fused MLPs stream (weights, encoded features, hidden activations, outputs and
     # their gradients): "f16" = tcnn's precision (BASELINE configs[1-3]); "bf16" = v_mfma_f32_16x16x16_bf16 with
     # the hash tables kept fp16 + fp32 interpolation / fp32 gradient accumulation (BASELINE configs[4]:
@@ -288,13 +250,14 @@ class NerfactoEngine:
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
             m.set_option("deterministic", int(bool(cfg.deterministic)))
-        self.base_net.set_option("grid_stream_acc_bits", int(cfg.main_grid_stream_acc_bits))
-        # the four coarse levels that stay slice-owner: int32 accumulators with the L1-derived scale as the proposal grids
-        # (the L1 pre-pass now reads those four levels only: 130.3 -> 128.3 us for the stage)
-        self.base_net.set_option("grid_acc_bits", int(cfg.main_grid_owner_acc_bits))
+        # Settled by measurement in rounds 2-4 (EXPERIMENTS.md), no longer switches: the main grid's four coarse levels stay
+        # slice-owner with int32 accumulators and the L1-derived scale, as the proposal grids (half the slices per level,
+        # a cheaper conversion: 1 M-sample grid 298 -> 227 us); dense levels use the run-merging scan; the record pass of
+        # the streamed levels is the packed 2 x 32-bit form (the only one left in grid.hip).
+        self.base_net.set_option("grid_acc_bits", 32)
         batches = (cfg.num_nerf_samples, *cfg.num_proposal_samples)
-        for m, runs, per_ray in zip((self.base_net, *self.prop_nets), cfg.grid_bwd_runs, batches):
-            m.set_option("grid_bwd_runs", int(bool(runs)))
+        for m, per_ray in zip((self.base_net, *self.prop_nets), batches):
+            m.set_option("grid_bwd_runs", 1)
             m.set_option("grid_bwd_batch", int(cfg.num_rays * per_ray))
         # proposal grids (slice-owner form): int32 accumulators with the overflow-proof L1-derived scale -- half
         # the slices per level and a cheaper conversion (1 M-sample grid 298 -> 227 us, 393 K-sample grid 157 -> 126 us)
@@ -309,10 +272,12 @@ class NerfactoEngine:
             dense_share = int(os.environ.get("NVO_PROP_DENSE_SHARE", dense_share))  # measurements
         for m in self.prop_nets:
             m.set_option("grid_bwd_dense_share", int(dense_share))
-            m.set_option("grid_acc_bits", int(cfg.proposal_grid_acc_bits))
-            m.set_option("fuse_encoding", int(cfg.fuse_proposal_encoding))
-            # most proposal samples carry an exactly zero gradient after a few hundred steps: scan the live ones only
-            m.set_option("grid_compact_live", int(cfg.compact_live_proposal_samples))
+            m.set_option("grid_acc_bits", 32)
+            # (module option fuse_encoding -- the hash grid inside the MLP kernel's operand load -- stays off: measured
+            # 51.5 us per launch against 35 + 8.2 us for the two kernels)
+            # under tcnn's static loss scale most proposal samples carry an exactly zero gradient after a few hundred steps:
+            # scan the live ones only (the launch leaves at once while >= 3/4 of the samples are live)
+            m.set_option("grid_compact_live", 1)
         store = cfg.store_input_gradients
         if store is None:
             store = bool(cfg.optimize_poses or cfg.expect_normals)
@@ -802,7 +767,7 @@ class NerfactoEngine:
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
                          anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False,
-                         skip_head: bool = False, proposal_values: bool | None = None, after_main_backward=None):
+                         skip_head: bool = False, proposal_values: bool | None = None):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
         loss_scale) and self.losses; does NOT touch the parameters."""
         cfg = self.cfg
@@ -839,21 +804,18 @@ class NerfactoEngine:
         # Roles of the two streams on an update step.  The proposal chain (losses, two MLP backwards, two hash-grid
         # scatters) is the LONGER one; with fixed poses it stays on the origin stream and the main-field backward goes
         # to the side stream, so that the proposal chain may fork once more (network 1's MLP backward beside network 0's
-        # chain, cfg.overlap_proposal_mlp) -- a fork from a stream that is itself a fork crashes hipStreamEndCapture on
+        # chain) -- a fork from a stream that is itself a fork crashes hipStreamEndCapture on
         # ROCm 7.2.  With pose optimisation the main-field backward forks (its grid scatter beside the pose chain) and
         # therefore keeps the origin stream, the proposal chain the side stream, unforked.
-        swap = bool(update_proposals and cfg.overlap_proposal_backward and cfg.overlap_proposal_mlp and not pose
-                    and int(cfg.proposal_backward_streams) == 1 and not cfg.deterministic)
+        swap = bool(update_proposals and cfg.overlap_proposal_backward and not pose and not cfg.deterministic)
         self._prop_fork_ok = swap
         if update_proposals and cfg.overlap_proposal_backward:
             # fork: everything the proposal backward reads (main-level weights / bins) exists now
             cur = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 # ONE side stream for both proposal networks (round 1: a stream each measured slower, 1.10 vs 1.01
-                # ms/step -- three LDS-heavy scatter kernels at once thrash); cfg.proposal_backward_streams = 2 keeps
-                # the experiment available
-                self._side_stream = [torch.cuda.Stream(device=self.device)
-                                     for _ in range(max(1, min(2, int(cfg.proposal_backward_streams))))]
+                # ms/step -- three LDS-heavy scatter kernels at once thrash)
+                self._side_stream = [torch.cuda.Stream(device=self.device)]
             side = self._side_stream
             if not swap:
                 for si, st in enumerate(side):
@@ -884,13 +846,9 @@ class NerfactoEngine:
             side[0].wait_stream(cur)
             with torch.cuda.stream(side[0]):
                 scatter_stream = main_backward(_stream(self.device))
-                if after_main_backward is not None:  # (the fields group's optimiser, beside the proposal chain)
-                    after_main_backward()
             self._proposal_backward(ws, has_depth, pose, stream)
         else:
             scatter_stream = main_backward(stream)
-            if after_main_backward is not None:
-                after_main_backward()
         if update_proposals and side is None:
             self._proposal_backward(ws, has_depth, pose, stream)
         if proposal_values and not update_proposals:
@@ -911,7 +869,7 @@ class NerfactoEngine:
             return self._dw_rep
         cfg = self.cfg
         G = int(cfg.dw_replicas)
-        if G <= 0 or cfg.deterministic or cfg.overlap_fields_adam:
+        if G <= 0 or cfg.deterministic:
             self._dw_rep = False
             return False
         nets = [("field.base", self.base_net, self.base_net.n_params - self._grid_params(self.base_net)),
@@ -1010,7 +968,7 @@ class NerfactoEngine:
 
         # both levels' loss kernels are independent of each other (each is one round of 4096 waves that lasts as long as
         # one ray's dependent chain): ONE launch when both run on this stream
-        paired = levels is None and len(self.prop_nets) == 2 and cfg.pair_proposal_losses
+        paired = levels is None and len(self.prop_nets) == 2
         if paired:
             pa0, pa1 = loss_args(0), loss_args(1)
             _call("nvo_prop_loss_pair", stream, C.byref(pa0), C.byref(pa1))
@@ -1446,15 +1404,7 @@ class NerfactoEngine:
         def body_head(levels=None):
             """Sampling prefix.  levels: None = all of it; (0,) = rays + proposal level 0; (1,) = proposal level 1."""
             first = levels is None or 0 in levels
-            if cfg.fused_ray_head:
-                return body_head_fused(levels, first)
-            if first:
-                # pixel sampling + the three sampler jitters: one stateless kernel (step counter in device memory)
-                _call("nvo_sample_pixels", _stream(dev), R, rng_seed, step_ptr, _ptr(scale), _ptr(ray_indices), _ptr(jit), 3)
-                c2w.copy_(c2w_full[:, :3, :4])  # poses may have been refreshed in place by the tracker
-                self.load_rays(ws, ray_indices, intr, c2w, dataset.frames_color, dataset.frames_depth if has_depth else None,
-                               normals=dataset.world_normals01() if has_normals else None)
-            self._forward_head(ws, 1.0, jits, _stream(dev), anneal_dev=anneal_ptr, skip_first_level=not first, levels=levels)
+            return body_head_fused(levels, first)
 
         def body_head_fused(levels, first):
             # everything per ray up to the first sampler level in ONE launch (nvo_ray_head)
@@ -1617,7 +1567,7 @@ class NerfactoEngine:
             dst.copy_(src)  # the warm-up steps must not count as training (nor as applied optimiser steps)
         # the graphs address these buffers by pointer: they must outlive this call (a freed block would be handed
         # to the next small allocation and every replay would scribble over it)
-        drawn = ws["ray_indices"] if (cfg.fused_ray_head and cfg.optimize_poses and "ray_indices" in ws) else ray_indices
+        drawn = ws["ray_indices"] if (cfg.optimize_poses and "ray_indices" in ws) else ray_indices
         entry = {"half": half, "buffers": (c2w, drawn, jit, scale, ray_indices), "ws": ws, "sharded": sharded,
                  "captured_collectives": False}
 
@@ -1663,22 +1613,11 @@ class NerfactoEngine:
             assert entry["commit"] is not None, "the one-graph step runs at least one optimiser launch"
             return entry
         if not split and not pipe1:
-            # update steps: Adam(fields) beside the tail of the proposal chain (cfg.overlap_fields_adam)
-            early_fields = bool(updated and cfg.overlap_fields_adam and cfg.overlap_proposal_backward
-                                and cfg.overlap_proposal_mlp and not cfg.optimize_poses and not cfg.deterministic
-                                and int(cfg.proposal_backward_streams) == 1 and "proposal_networks" in groups_b)
-
             def whole():
                 body_head()
-                if early_fields:
-                    self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
-                                          anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True,
-                                          proposal_values=values, after_main_backward=lambda: body_opt(["fields"]))
-                    body_opt([g for g in groups_b if g != "fields"])
-                else:
-                    body_rest()
-                    body_opt(groups_b)
-            zero_with_head = bool(cfg.zero_with_ray_head and cfg.fused_ray_head)
+                body_rest()
+                body_opt(groups_b)
+            zero_with_head = True  # (the launch that opens the step also clears its accumulate-into buffers)
             self._fused_adam_range = self._fused_adam_plan()
             entry["fused_adam"] = self._fused_adam_range
             if self._fused_adam_range is not None:
@@ -1723,8 +1662,7 @@ class NerfactoEngine:
                     # the fused ray head of the graph that ran before (entry["head"] or the previous iteration's
                     # prefix) already produced dirs01 / SH: without the flags every program captured after the first
                     # would re-record nvo_dirs01 + nvo_sh_encode_t (two redundant dependent launches per step)
-                    if cfg.fused_ray_head:
-                        ws["dirs01_ready"] = ws["sh_ready"] = True
+                    ws["dirs01_ready"] = ws["sh_ready"] = True
                     program(p, lambda name, fn: fn())
 
                 whole_g = {p: capture(lambda p=p: whole_program(p), capture_error_mode="thread_local")
@@ -1748,8 +1686,7 @@ class NerfactoEngine:
             segs[name] = capture(fn)
 
         # capture every compute segment once (the collectives in between run eagerly, here and at replay)
-        if cfg.fused_ray_head:  # (as whole_program above: the head graph already produced dirs01 / SH)
-            ws["dirs01_ready"] = ws["sh_ready"] = True
+        ws["dirs01_ready"] = ws["sh_ready"] = True  # (as whole_program above: the head graph already produced dirs01 / SH)
         program(True, lambda name, fn: (seg_capture(name, fn), segs[name].replay()))
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.params_half, self.opt_state), saved):

@@ -109,20 +109,17 @@ def test_grid_indices_bit_exact(device, cfg):
 
 
 def _set_bwd_mode(enc, bwd_mode):
-    """0 atomics | 1 slice owner | 2 binned | 3 streamed (globally sorted records) | 4 streamed, tile-local records |
-    5 slice owner with run-merged dense levels | 6 streamed tile-local with run-merged coarse levels"""
+    """The three backward forms of the hash grid (+ the run-merging variant of the second, which the proposal grids run):
+    0 global atomics (the readable reference form) | 1 slice owner | 5 slice owner with run-merged dense levels |
+    7 streamed: tile-local pair records accumulated as two 32-bit fixed-point sums per 64-bit word, 8192-entry bins, the
+    coarse levels slice-owner with run merging (what the main grid runs)."""
     m = enc.native_tcnn_module
-    m.set_option("grid_bwd_runs", int(bwd_mode in (5, 6, 7)))
-    m.set_option("grid_bwd_mode", {5: 1, 6: 3, 7: 3}.get(bwd_mode, min(bwd_mode, 3)))
-    if bwd_mode >= 3 and bwd_mode != 5:
-        m.set_option("grid_stream_layout", int(bwd_mode in (4, 6, 7)))
-        # 7: tile-local records accumulated as two 32-bit fixed-point sums per 64-bit word, 8192-entry bins (round 3)
-        m.set_option("grid_stream_acc_bits", 32 if bwd_mode == 7 else 64)
+    m.set_option("grid_bwd_runs", int(bwd_mode in (5, 7)))
+    m.set_option("grid_bwd_mode", {5: 1, 7: 3}.get(bwd_mode, bwd_mode))
 
 
-BWD_MODES = [0, 1, 2, 3, 4, 5, 6, 7]
-BWD_MODE_IDS = ["atomic", "lds", "binned", "streamed", "streamed-tile-local", "lds-runs", "streamed-tile-local-runs",
-                "streamed-tile-local-packed32"]
+BWD_MODES = [0, 1, 5, 7]
+BWD_MODE_IDS = ["atomic", "lds", "lds-runs", "streamed-packed32"]
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
@@ -241,7 +238,7 @@ def test_grid_bwd_propagates_nonfinite(device, cfg, bad_value):
     for level in (0, spec.n_levels - 1):
         dy = torch.randn(n, 2 * spec.n_levels, generator=g).to(device)
         dy[12345, 2 * level + 1] = bad_value
-        for mode, bits in ((0, 64), (1, 64), (1, 32), (2, 64), (3, 64), (3, 32)):
+        for mode, bits in ((0, 64), (1, 64), (1, 32), (3, 64), (3, 32)):
             enc.native_tcnn_module.set_option("grid_bwd_mode", mode)
             enc.native_tcnn_module.set_option("grid_acc_bits", bits)
             enc.params.grad = None
@@ -306,13 +303,13 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     g = torch.Generator().manual_seed(7)
     x = torch.rand(n, 3, generator=g).to(device)
     dy = torch.randn(n, 32, generator=g).to(device)
-    grads = []
-    for mode in (0, 1, 2, 3, 4, 5, 6, 7):
+    grads = {}
+    for mode in BWD_MODES:
         _set_bwd_mode(enc, mode)
         enc.params.grad = None
         y = enc(x)
         (y.float() * dy).sum().backward()
-        grads.append(enc.params.grad.clone())
+        grads[mode] = enc.params.grad.clone()
     torch.cuda.synchronize()
     # packed 32-bit fixed-point accumulators (one 64-bit LDS atomic per record, scale 2^29 / L1 of the bin): each add
     # rounds to L1(bin) / 2^29 -- finer than the 16-17 mantissa bits the records carry -- and the sums are integers
@@ -324,30 +321,7 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     assert torch.equal(enc.params.grad[hashed7:], grads[7][hashed7:]), "packed form is not bitwise reproducible"
     # run-merged coarse levels (uniform random points are the worst case: no two consecutive samples share a cell)
     _assert_close(grads[5], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds + run-merged dense levels vs atomic dL/dparams")
-    _assert_close(grads[6], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed + run-merged coarse levels vs atomic")
-    assert torch.equal(grads[6][2 * (4096 + 12168 + 29792 + 79512 + 205384):],
-                       grads[4][2 * (4096 + 12168 + 29792 + 79512 + 205384):]), "hashed levels must not change"
-    # tile-local record layout: the same records summed in 64-bit fixed point -> bit-identical to the sorted layout
-    # wherever a bin has a single accumulate item (every hashed level)
-    hashed0 = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
-    assert torch.equal(grads[4][hashed0:], grads[3][hashed0:]), "tile-local layout differs from the sorted layout"
-    _assert_close(grads[4], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed (tile-local) vs atomic dL/dparams")
-    _set_bwd_mode(enc, 3)
     _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
-    _assert_close(grads[2], grads[0], rtol=1e-3, atol_scale=1e-5, what="binned vs atomic dL/dparams")
-    # streamed records carry w*dy rounded to 16-17 mantissa bits (2^-17 relative per contribution)
-    _assert_close(grads[3], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed vs atomic dL/dparams")
-    enc.native_tcnn_module.set_option("grid_bwd_mode", 3)
-    enc.params.grad = None
-    (enc(x).float() * dy).sum().backward()
-    assert torch.equal(enc.params.grad[2 * (4096 + 12168 + 29792 + 79512 + 205384):],
-                       grads[3][2 * (4096 + 12168 + 29792 + 79512 + 205384):]), "streamed form is not reproducible"
-    # the binned form accumulates hashed levels in fixed point with a single owner per slice: bitwise reproducible
-    enc.native_tcnn_module.set_option("grid_bwd_mode", 2)
-    enc.params.grad = None
-    (enc(x).float() * dy).sum().backward()
-    hashed_lo = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
-    assert torch.equal(enc.params.grad[hashed_lo:], grads[2][hashed_lo:])
     # every sample distributes a total weight of 1 per level/feature: sum of grads == sum of dy16
     dy16 = (dy * 128).half().double() / 128
     assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0

@@ -35,7 +35,7 @@ def main():
                              "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]),
                              "frames_color": seq["frames_color"], "frames_depth": seq["frames_depth"]})
     ds = dm.train_dataset
-    cfg = EngineConfig(num_images=a.kf, optimize_poses=bool(a.poses), proposal_grid_acc_bits=a.acc, max_num_iterations=a.iters)
+    cfg = EngineConfig(num_images=a.kf, optimize_poses=bool(a.poses), max_num_iterations=a.iters)
     eng = NerfactoEngine(cfg, dev)
     scale = torch.tensor([a.kf, a.h, a.w], device=dev)
     for it in range(a.iters):

@@ -28,11 +28,8 @@ def main():
     ap.add_argument("--tiles", type=int, nargs="+", default=[512], help="mode 3: samples per count/scatter tile")
     ap.add_argument("--masks", type=str, nargs="+", default=["12"], help="mode 3: owner_max_slices values")
     ap.add_argument("--cases", type=int, nargs="+", default=[0, 1, 2])
-    ap.add_argument("--layouts", type=int, nargs="+", default=[0, 1], help="mode 3: record layout (0 sorted, 1 tile-local)")
     ap.add_argument("--acc-bits", type=int, default=64, help="accumulators of the slice-owner items (32 | 64)")
     ap.add_argument("--random-x", action="store_true", help="uniform random positions instead of ray-coherent ones")
-    ap.add_argument("--stream-acc-bits", type=int, nargs="+", default=[64],
-                    help="mode 3, tile-local layout: accumulators of the record pass (64 | 32 = packed, 8192-entry bins)")
     ap.add_argument("--show-fwd", action="store_true", help="also print the forward gather's time")
     ap.add_argument("--runs", type=int, default=1, help="run-merging scan of the slice-owner items (grid_bwd_runs)")
     ap.add_argument("--phase", action="store_true",
@@ -63,8 +60,7 @@ def main():
         variants = []
         for mode in args.modes:
             if mode == 3:
-                variants += [(3, t, int(m, 0), lay, ab) for t in args.tiles for m in args.masks for lay in args.layouts
-                             for ab in (args.stream_acc_bits if lay == 1 else [64])]
+                variants += [(3, t, int(m, 0), 1, 32) for t in args.tiles for m in args.masks]
             else:
                 variants.append((mode, 0, 0xFFFFFFFF, 0, 64))
         enc.native_tcnn_module.set_option("grid_acc_bits", args.acc_bits)
@@ -75,8 +71,6 @@ def main():
             if mode == 3:
                 enc.native_tcnn_module.set_option("grid_stream_tile", tile)
                 enc.native_tcnn_module.set_option("grid_stream_owner_slices", mask)
-                enc.native_tcnn_module.set_option("grid_stream_layout", layout)
-                enc.native_tcnn_module.set_option("grid_stream_acc_bits", sab)
             for it in range(args.iters + 3):
                 if it == 3:
                     torch.cuda.synchronize()

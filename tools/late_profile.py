@@ -31,7 +31,7 @@ def main():
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
-    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, compact_live_proposal_samples=bool(a.compact)), dev)
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R), dev)
     for _ in range(a.train):
         eng.train_step_graphed(ds)
     torch.cuda.synchronize()
