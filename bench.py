@@ -88,7 +88,7 @@ def algorithmic_bytes(name: str, cfg, R: int, fused_adam_params: int = 0) -> flo
     return None
 
 
-def pmc_traffic(name: str):
+def pmc_traffic(name: str, live_path: str | None = None):
     """HBM bytes per launch of the named kernel from the committed rocprofv3 PMC summary
     (profiles/*_pmc_fetch_write_per_kernel.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of
     this same command; (FETCH_SIZE corrected for gfx950's half-counted coalesced streaming reads + WRITE_SIZE) *
@@ -97,7 +97,8 @@ def pmc_traffic(name: str):
     source file.  None when no PMC summary covers the kernel."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")), reverse=True):
+    committed = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")), reverse=True)
+    for path in ([live_path] if live_path else []) + committed:
         try:
             data = json.load(open(path))
         except Exception:
@@ -106,8 +107,57 @@ def pmc_traffic(name: str):
             if k.get("bench_name") == name:
                 fetch = k.get("FETCH_SIZE_KB_corrected", k["FETCH_SIZE_KB_per_launch"])  # gfx950 streaming-read correction
                 raw = int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024)
-                return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), os.path.basename(path), raw
+                src = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench process" if path == live_path
+                       else os.path.basename(path))
+                return int((fetch + k["WRITE_SIZE_KB_per_launch"]) * 1024), src, raw
     return None, None, None
+
+
+def live_pmc_summary(steps: int = 20, warmup: int = 5, timeout_s: int = 240):
+    """HBM traffic counters of THIS build in THIS session: two child runs of the bench command under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md's HBM section prescribes; the counters serialise the kernels, so they cannot ride in the timed
+    run), summarised by tools/pmc_traffic.py.  Children, never an exec: this process has initialised the GPU.  Returns
+    (path of the summary JSON, None) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="nvo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        rev = ""
+    env["NVO_COMMIT"] = (rev or "unknown") + " (collected by the bench run that printed the line)"
+    cmd_tail = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--psnr", "off",
+                "--cpu-baseline", "off", "--late-steps", "0", "--no-kernel-table", "--render-frames", "0", "--ngp-steps", "0",
+                "--pmc-traffic", "off"]
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, sub), "--", *cmd_tail]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                 timeout=timeout_s)
+        except (OSError, subprocess.TimeoutExpired) as exc:
+            return None, f"{counter} pass: {type(exc).__name__}"
+        if res.returncode != 0:
+            return None, f"{counter} pass exited {res.returncode}: {res.stderr[-300:]}"
+    out = os.path.join(work, "pmc_fetch_write_per_kernel.json")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(work, "fetch"),
+                          os.path.join(work, "write"), out, str(steps + warmup)], env=env, capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(out):
+        return None, f"pmc_traffic.py: {res.stderr[-300:]}"
+    try:  # keep the summary next to the run's other outputs (copied to profiles/ by hand when it is to be judged)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        shutil.copy(out, os.path.join(ROOT, "gpurun_out", "live_pmc_fetch_write_per_kernel.json"))
+    except OSError:
+        pass
+    return out, None
 
 
 def launch_ranks(n: int, argv: list) -> int:
@@ -194,8 +244,8 @@ def main() -> None:
     ap.add_argument("--mlp-dtype", choices=("f16", "bf16"), default=None)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--cpu-baseline", choices=("configs0", "sample", "off"), default="configs0",
-                    help="configs0 = BASELINE configs[0] as written: one 640x480 keyframe, 4096 rays, fp32 torch-CPU, all "
-                         "host cores, 3 timed steps after 1 warm-up (about 1-2 min of CPU); sample = 256-ray sample (about 12 s)")
+                    help="configs0 = BASELINE configs[0] as written: one 640x480 keyframe, 4096 rays, fp32 torch-CPU, calibrated "
+                         "thread count, median of 20 timed steps after 3 warm-ups (about 1 min of CPU); sample = 256-ray sample (about 12 s)")
     ap.add_argument("--cpu-baseline-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--psnr", choices=("off", "small", "replica"), default="replica",
@@ -234,6 +284,10 @@ def main() -> None:
                     help="timed steps of the occupancy-grid back-end (tools/ngp_bench.py) reported as the ngp section; 0 = skip")
     ap.add_argument("--render-frames", type=int, default=5,
                     help="timed full-image renders per resolution (1200x680 and the training resolution); 0 = skip")
+    ap.add_argument("--pmc-traffic", choices=("live", "committed", "off"), default="live",
+                    help="roofline.traffic: live = two child runs of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                         "(about a minute; falls back to the committed summary and says so), committed = the latest "
+                         "profiles/*_pmc_fetch_write_per_kernel.json, off = null")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
                     help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
@@ -452,7 +506,14 @@ def main() -> None:
                 continue
             avg_s = total / cnt * 1e-3
             achieved = b / avg_s / 1e9
-            traffic, traffic_src, traffic_raw = pmc_traffic(name)
+            live_path = live_err = None
+            if args.pmc_traffic == "live" and world == 1:
+                live_path, live_err = live_pmc_summary()
+                if live_err:
+                    sys.stderr.write(f"[bench] live PMC passes failed ({live_err}); using the committed summary\n")
+            traffic, traffic_src, traffic_raw = (None, None, None) if args.pmc_traffic == "off" else pmc_traffic(name, live_path)
+            if live_err and traffic_src:
+                traffic_src += f" (live passes failed: {live_err[:80]})"
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src,
@@ -612,7 +673,8 @@ def main() -> None:
         from oracle.bench_cpu import time_cpu_step
 
         if args.cpu_baseline == "configs0":  # BASELINE configs[0] as written
-            cpu_baseline = time_cpu_step(num_rays=4096, num_images=1, steps=3, warmup=1, keyframe=(480, 640),
+            # median of >= 20 steps after 3 warm-ups (2.7 s per step on the GPU box's host: ~1 min)
+            cpu_baseline = time_cpu_step(num_rays=4096, num_images=1, steps=20, warmup=3, keyframe=(480, 640),
                                          max_threads=None)
         else:  # explicitly labelled fallback: a 256-ray sample of the same step
             cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)

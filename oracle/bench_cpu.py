@@ -4,7 +4,7 @@ step (forward + losses + autograd backward + Adam on every parameter) on the GPU
 The reference's own CPU path (nerfstudio ``implementation="torch"``) cannot be imported here
 (SURVEY.md section 8c), so this is kind "port".  Two forms:
   * BASELINE.json configs[0] as written (bench.py default): ONE 640x480 keyframe, 4096 rays drawn from it, fp32,
-    3 timed steps after 1 warm-up.  Thread count: torch-CPU gets SLOWER past a few dozen threads on these
+    the MEDIAN of 20 timed steps after 3 warm-ups (SURVEY.md section 8d's protocol; about a minute).  Thread count: torch-CPU gets SLOWER past a few dozen threads on these
     gather/scatter-heavy ops (256 threads on the GPU box's host measured 40x slower than 16), so the count is
     calibrated on a 128-ray forward+backward (8, 16, 32, ... up to every host core, stopping at the first count that
     is slower) and the best one is used; both the threads used and the host's core count are reported.
@@ -112,15 +112,21 @@ def time_cpu_step(num_rays: int = 256, num_images: int = 8, steps: int = 8, warm
 
     for i in range(warmup):
         one_step(i)
-    t0 = time.perf_counter()
+    per_step = []
     for i in range(steps):
+        t0 = time.perf_counter()
         one_step(warmup + i)
-    dt = (time.perf_counter() - t0) / steps
+        per_step.append(time.perf_counter() - t0)
+    per_step.sort()
+    dt = per_step[len(per_step) // 2]  # MEDIAN step (median of >= 20 steps after 3 warm-ups)
+    mean_dt = sum(per_step) / len(per_step)
     samples = num_rays * cfg.num_nerf_samples
     what = (f"BASELINE configs[0]: one {keyframe[1]}x{keyframe[0]} keyframe, " if keyframe is not None else
             "256-ray SAMPLE of the step (fallback form), ")
     return {"value": samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": what + f"{steps} timed steps after {warmup} warm-up x {num_rays} rays (256/96/48 samples per ray, "
+            "sample": what + f"median of {steps} timed steps after {warmup} warm-ups x {num_rays} rays (256/96/48 samples per ray, "
                       f"full {sum(p.numel() for p in orc.params.values()) / 1e6:.1f} M-parameter model, float32 torch-CPU "
-                      f"oracle incl. autograd backward + Adam), {dt:.2f} s/step, {cores} threads of {host_cores} host cores",
-            "seconds_per_step": dt, "host_cores": host_cores, "thread_calibration": calib}
+                      f"oracle incl. autograd backward + Adam), {dt:.2f} s/step (mean {mean_dt:.2f}), {cores} threads of "
+                      f"{host_cores} host cores (calibrated: torch-CPU gets slower past a few dozen threads on these ops)",
+            "seconds_per_step": dt, "seconds_per_step_mean": mean_dt, "steps": steps, "warmup": warmup,
+            "host_cores": host_cores, "thread_calibration": calib}

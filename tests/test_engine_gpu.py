@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_tcnn_gpu import BF16_K, _assert_close
+from test_tcnn_gpu import BF16_K, _assert_close, _assert_close_chain
 
 pytestmark = pytest.mark.gpu
 
@@ -128,16 +128,16 @@ def test_full_step_matches_oracle(device, dtype, gradscaler):
 
     # ---- sampling / rendering
     for k in range(3):
-        _assert_close(ws[f"sbins{k}"], out["sbins_list"][k], rtol=2e-3 * K, atol_scale=2e-4 * K, what=f"sbins level {k}",
+        _assert_close(ws[f"sbins{k}"], out["sbins_list"][k], rtol=1.5e-4 * K, atol_scale=1.5e-5 * K, what=f"sbins level {k}",
                       max_outlier_frac=2e-3 * K)
-        _assert_close(ws[f"tbins{k}"], out["tbins_list"][k], rtol=5e-3 * K, atol_scale=1e-6 * K, what=f"tbins level {k}",
+        _assert_close(ws[f"tbins{k}"], out["tbins_list"][k], rtol=3.5e-4 * K, atol_scale=7e-8 * K, what=f"tbins level {k}",
                       max_outlier_frac=2e-3 * K)
         _assert_close(ws[f"weights{k}"].view(R, -1), out["weights_list"][k], rtol=2e-2 * K, atol_scale=3e-3 * K,
                       what=f"weights level {k}", max_outlier_frac=2e-3 * K)
-    _assert_close(ws["rgb"][:, :3].view(R, -1, 3), out["rgb_samples"], rtol=1e-2 * K, atol_scale=5e-3 * K,
+    _assert_close(ws["rgb"][:, :3].view(R, -1, 3), out["rgb_samples"], rtol=5e-3 * K, atol_scale=2.5e-3 * K,
                   what="per-sample rgb", max_outlier_frac=1e-3 * K)
-    _assert_close(ws["out_rgb"], out["rgb"], rtol=1e-2 * K, atol_scale=5e-3 * K, what="rendered rgb")
-    _assert_close(ws["out_accumulation"], out["accumulation"].reshape(-1), rtol=1e-2 * K, atol_scale=5e-3 * K,
+    _assert_close(ws["out_rgb"], out["rgb"], rtol=2e-4 * K, atol_scale=1e-4 * K, what="rendered rgb")
+    _assert_close(ws["out_accumulation"], out["accumulation"].reshape(-1), rtol=5e-5 * K, atol_scale=2.5e-5 * K,
                   what="accumulation")
 
     # ---- losses
@@ -154,16 +154,21 @@ def test_full_step_matches_oracle(device, dtype, gradscaler):
         return eng.grads[o:o + s] / ls
 
     nb = _mlp_count("field.base")
-    tol = dict(rtol=3e-2 * K, atol_scale=1.5e-2 * K, max_outlier_frac=1e-4 * K, max_outlier=0.05 if K == 1.0 else 0.2)
+    # (bounds = 2-3x the errors the suite measures, profiles/r5_parity_margins.md; the base network's gradient passes
+    # through the colour head's 16-bit d(geo features) first and carries ~10x the error of the heads')
+    tol = dict(rtol=1.5e-3 * K, atol_scale=7.5e-4 * K, max_outlier_frac=1e-4 * K, max_outlier=0.05 if K == 1.0 else 0.2)
+    tol_base = dict(tol, rtol=1.2e-2 * K, atol_scale=6e-3 * K)
     _assert_close(gseg("field.color"), orc.params["color_mlp"].grad, what="d colour MLP", **tol)
     _assert_close(gseg("field.embedding"), orc.params["embedding"].grad.reshape(-1), what="d embedding", **tol)
-    _assert_close(gseg("field.base")[:nb], orc.params["base_mlp"].grad, what="d base MLP", **tol)
-    _assert_close(gseg("field.base")[nb:], orc.params["base_grid"].grad.reshape(-1), what="d main grid", **tol)
+    _assert_close(gseg("field.base")[:nb], orc.params["base_mlp"].grad, what="d base MLP", **tol_base)
+    # hash-grid gradients: reached through the 16-bit chain (_assert_close_chain: relative L1 error + largest error)
+    chain = {"main": (1.5e-2, 0.10), 0: (1.4e-2, 0.04), 1: (5.5e-3, 0.01)} if K == 1.0 else \
+        {"main": (5e-2, 0.22), 0: (1.6e-2, 0.10), 1: (8e-3, 0.055)}
+    _assert_close_chain(gseg("field.base")[nb:], orc.params["base_grid"].grad, "d main grid", *chain["main"])
     for k in range(2):
         npk = _mlp_count(f"proposal.{k}")
         _assert_close(gseg(f"proposal.{k}")[:npk], orc.params[f"prop{k}_mlp"].grad, what=f"d prop{k} MLP", **tol)
-        _assert_close(gseg(f"proposal.{k}")[npk:], orc.params[f"prop{k}_grid"].grad.reshape(-1),
-                      what=f"d prop{k} grid", **tol)
+        _assert_close_chain(gseg(f"proposal.{k}")[npk:], orc.params[f"prop{k}_grid"].grad, f"d prop{k} grid", *chain[k])
 
 
 @pytest.mark.parametrize("stride,poses,fmt", [(16, False, 0), (12, True, 1)], ids=["4x4-fixed-f16", "3x4-corrected-bf16"])
@@ -257,10 +262,10 @@ def test_raygen_and_gather(device):
         ro, rd, rn, rpa = Rr.generate_rays(idx, intr.double(), c2w.double())
         if use_corr:
             ro, rd = Rr.apply_pose_correction(ro, rd, corr.double()[idx[:, 0]])
-        _assert_close(o, ro, rtol=1e-5, atol_scale=1e-6, what="origins")
-        _assert_close(dr, rd, rtol=1e-5, atol_scale=1e-6, what="directions")
-        _assert_close(dn, rn.reshape(-1), rtol=1e-5, atol_scale=1e-6, what="directions_norm")
-        _assert_close(pa, rpa.reshape(-1), rtol=2e-3, atol_scale=1e-4, what="pixel_area")
+        _assert_close(o, ro, rtol=7.5e-8, atol_scale=7.5e-9, what="origins")  # (fp32 against float64: one rounding)
+        _assert_close(dr, rd, rtol=1e-6, atol_scale=1e-7, what="directions")
+        _assert_close(dn, rn.reshape(-1), rtol=2.7e-7, atol_scale=2.7e-8, what="directions_norm")
+        _assert_close(pa, rpa.reshape(-1), rtol=1.8e-5, atol_scale=9e-7, what="pixel_area")
         assert (ci.cpu() == idx[:, 0].int()).all()
     _call("nvo_gather_pixels", st, R, _ptr(idx_d), H, W, 3, _ptr(img_d), _ptr(px))
     torch.cuda.synchronize()
@@ -280,8 +285,8 @@ def test_lindisp_bins(device):
               _ptr(sb), _ptr(tb))
         torch.cuda.synchronize()
         rs, rt = Rr.sample_uniform_lindisp(R, S, 0.05, 1000.0, None if j is None else j.double().reshape(R, 1))
-        _assert_close(sb, rs, rtol=1e-5, atol_scale=1e-6, what="lindisp sbins")
-        _assert_close(tb, rt, rtol=2e-3, atol_scale=1e-6, what="lindisp tbins")
+        _assert_close(sb, rs, rtol=1.1e-7, atol_scale=1.1e-8, what="lindisp sbins")
+        _assert_close(tb, rt, rtol=3.2e-4, atol_scale=1.6e-7, what="lindisp tbins")
 
 
 def test_adam_matches_torch_semantics(device):
@@ -303,7 +308,7 @@ def test_adam_matches_torch_semantics(device):
               1e-15, step, 1.0 / 128.0, 0.0, _ptr(flag), None)
         pr, mr, vr = adam_reference(pr, grad.double() / 128.0, mr, vr, 1e-2, step)
     torch.cuda.synchronize()
-    _assert_close(pd, pr, rtol=1e-5, atol_scale=1e-6, what="adam params")
+    _assert_close(pd, pr, rtol=4.2e-7, atol_scale=4.2e-8, what="adam params")
     assert torch.equal(p16.cpu(), pd.cpu().half())
     # a non-finite gradient anywhere skips the whole step (GradScaler semantics)
     before = pd.clone()
@@ -483,7 +488,8 @@ def test_normal_supervision_matches_oracle(device, dtype):
     tol = dict(rtol=3e-2 * K, atol_scale=1.5e-2 * K, max_outlier_frac=1e-4 * K, max_outlier=0.05 if K == 1.0 else 0.2)
     assert orc.params["base_mlp"].grad.abs().max() > 0
     _assert_close(gb[:nb], orc.params["base_mlp"].grad, what="d base MLP (normal loss)", **tol)
-    _assert_close(gb[nb:], orc.params["base_grid"].grad.reshape(-1), what="d main grid (normal loss)", **tol)
+    _assert_close_chain(gb[nb:], orc.params["base_grid"].grad, "d main grid (normal loss)",
+                        *((1.1e-2, 0.085) if K == 1.0 else (2.5e-2, 0.08)))
 
     # inference output: outputs['normals'] of the eval forward
     res = eng.render_rays(origins.to(device), directions.to(device), dnorm.to(device), normals=True)
@@ -509,8 +515,8 @@ def test_eval_render_matches_oracle(device):
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = orc.forward(origins.double(), directions.double(), dnorm.double(), cam, None, anneal=1.0, training=False)
-    _assert_close(out["rgb"], ref["rgb"], rtol=1e-2, atol_scale=5e-3, what="eval rgb")
-    _assert_close(out["accumulation"], ref["accumulation"], rtol=1e-2, atol_scale=5e-3, what="eval accumulation")
+    _assert_close(out["rgb"], ref["rgb"], rtol=2.9e-4, atol_scale=1.45e-4, what="eval rgb")
+    _assert_close(out["accumulation"], ref["accumulation"], rtol=1.3e-5, atol_scale=6.5e-6, what="eval accumulation")
     # median depth is a discrete pick: allow a small fraction of neighbouring-sample picks
     d_err = (out["depth"].double().cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp(min=1e-6)
     assert (d_err < 5e-3).double().mean() > 0.95, f"median depth agrees on only {(d_err < 5e-3).double().mean():.3f}"
@@ -678,7 +684,7 @@ def test_gradscaler_step_and_update_semantics(device):
         flags = eng.skip_flag.tolist()
         assert [bool(flags[eng._GROUP_ORDER.index(k)]) for k in eng._GROUP_ORDER] == [k in found for k in eng._GROUP_ORDER]
     for k, (lo, hi) in eng.group_ranges.items():
-        _assert_close(eng.params[lo:hi], ref_p[k].detach(), rtol=2e-5, atol_scale=2e-6, what=f"params of group {k}")
+        _assert_close(eng.params[lo:hi], ref_p[k].detach(), rtol=1e-6, atol_scale=1e-7, what=f"params of group {k}")
     assert bool(torch.isfinite(eng.params).all()) and bool(torch.isfinite(eng.exp_avg_sq).all())
 
 
@@ -719,7 +725,7 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     assert abs(np.log(a[3]["rgb_loss"] / c[3]["rgb_loss"])) < 0.3, (a[3], c[3])
     # one step from the same initial state: same gradient up to summation order
     g_det, g_def = run(True, 1)[4], run(False, 1)[4]
-    _assert_close(g_det, g_def, rtol=1e-3, atol_scale=1e-5, what="deterministic vs default gradient", max_outlier_frac=1e-4)
+    _assert_close(g_det, g_def, rtol=2e-6, atol_scale=2e-8, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
 @pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
@@ -1053,8 +1059,8 @@ def test_pose_gradients_match_oracle(device, mode):
     ref = pose_r.grad
 
     # forward sanity: the corrected rays the kernels used are the oracle's
-    _assert_close(ws["origins"], ro2.detach(), rtol=1e-5, atol_scale=1e-6, what="corrected origins")
-    _assert_close(ws["directions"], rd2.detach(), rtol=1e-5, atol_scale=1e-6, what="corrected directions")
+    _assert_close(ws["origins"], ro2.detach(), rtol=2.2e-7, atol_scale=2.2e-8, what="corrected origins")
+    _assert_close(ws["directions"], rd2.detach(), rtol=4.5e-7, atol_scale=4.5e-8, what="corrected directions")
     assert eng.loss_dict()["camera_opt_regularizer"] == pytest.approx(float(ld["camera_opt_regularizer"]), rel=1e-4)
     _assert_close(got, ref, rtol=5e-2, atol_scale=4e-2, what=f"dL/dpose_adjustment ({mode})")
     # and the Adam step on the camera group moves the poses

@@ -88,6 +88,29 @@ def _assert_close(got, ref, rtol, atol_scale, what, max_outlier_frac=0.0, max_ou
         f"ref {ref[bad][0].item():.6e}")
 
 
+def _assert_close_chain(got, ref, what, rel_l1, cap):
+    """Hash-grid gradients that arrive through a 16-bit gradient chain (loss kernels -> fused-MLP backward -> 16-bit
+    dL/d(encoded) -> scatter).  No per-entry RELATIVE bound exists for them: dL/d(encoded) = W^T dZ is a sum whose terms
+    are rounded to 16 bits one by one, so an entry fed by a few samples whose terms cancel carries an error set by the
+    terms, not by the result; and a hidden unit whose pre-activation lies within rounding of 0 takes the other ReLU
+    branch in the kernel than in the float64 oracle, which moves the few entries its sample touches by a finite amount.
+    What the format does guarantee, and what this asserts -- both without any outlier allowance:
+        (a) aggregate accuracy:  sum |got - ref|  <=  rel_l1 x sum |ref|
+        (b) no entry is far off: max |got - ref|  <=  cap x max |ref|
+    with rel_l1 / cap set to 2-2.5x what the suite measures (profiles/r5_parity_margins.md)."""
+    got, ref = got.double().cpu().reshape(-1), ref.double().cpu().reshape(-1)
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs()
+    l1 = float(err.sum() / max(ref.abs().sum().item(), 1e-300))
+    worst = float(err.max()) / scale
+    MARGINS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "what": what, "elements": int(err.numel()),
+                    "rtol": f"relative L1 <= {rel_l1:g}", "atol_scale": f"max error <= {cap:g} x max|ref|",
+                    "worst_error_over_bound": max(l1 / rel_l1, worst / cap), "rel_l1": l1, "outlier_frac_allowed": 0.0,
+                    "outlier_frac": 0.0, "max_error_over_scale": worst})
+    assert l1 <= rel_l1, f"{what}: relative L1 error {l1:.3e} > {rel_l1:g}"
+    assert worst <= cap, f"{what}: max error {worst:.3e} x max|ref| > {cap:g} (idx {int(err.argmax())})"
+
+
 @pytest.mark.parametrize("cfg", [MAIN, PROP0, PROP1], ids=["main", "prop0", "prop1"])
 def test_grid_indices_bit_exact(device, cfg):
     import nerf_vo_amd.tinycudann as tcnn
@@ -150,9 +173,9 @@ def test_grid_encoding_fwd_bwd(device, cfg, bwd_mode):
     dy16 = (dy.cpu().float() * 128.0).to(torch.float16).double() / 128.0  # kernel sees fp16(dy*loss_scale)
     (yr * dy16).sum().backward()
 
-    _assert_close(y, yr, rtol=1e-3, atol_scale=1e-3, what="encoded features")
+    _assert_close(y, yr, rtol=4e-4, atol_scale=4e-4, what="encoded features")
     _assert_close(enc.params.grad, table.grad.reshape(-1), rtol=1e-3, atol_scale=1e-4, what="dL/dparams")
-    _assert_close(x.grad, xr.grad, rtol=2e-3, atol_scale=2e-4, what="dL/dx")
+    _assert_close(x.grad, xr.grad, rtol=1.1e-3, atol_scale=1.1e-4, what="dL/dx")
 
 
 @pytest.mark.parametrize("cfg", [MAIN, PROP0], ids=["main", "prop0"])
@@ -191,7 +214,7 @@ def test_grid_bwd_32bit_accumulators(device, cfg, bwd_mode):
     # per level: the resolution scales with that level's own L1, so compare level by level
     for l in range(spec.n_levels):
         lo, hi = 2 * int(spec.levels[l, 0]), 2 * int(spec.levels[l, 0] + spec.levels[l, 1])
-        _assert_close(grads[0][lo:hi], ref[lo:hi], rtol=1e-3, atol_scale=2e-4, what=f"dL/dparams level {l} (32-bit)")
+        _assert_close(grads[0][lo:hi], ref[lo:hi], rtol=4.7e-4, atol_scale=9.4e-5, what=f"dL/dparams level {l} (32-bit)")
 
 
 @pytest.mark.parametrize("share", [60, 120, 250])
@@ -218,7 +241,7 @@ def test_grid_bwd_item_table_shares_do_not_change_the_gradient(device, share):
             enc.params.copy_(torch.linspace(-1, 1, enc.params.numel(), device=device))
         (enc(x).float() * dy).sum().backward()
         grads.append(enc.params.grad.clone())
-    _assert_close(grads[1], grads[0], rtol=1e-4, atol_scale=1e-6, what=f"dense share {share} % vs even item table")
+    _assert_close(grads[1], grads[0], rtol=8e-6, atol_scale=8e-8, what=f"dense share {share} % vs even item table")
     assert float(grads[0].abs().max()) > 0
 
 
@@ -288,9 +311,9 @@ def test_stored_input_gradients_match_gather(device, cfg, kind):
     (y0, dx0, dp0), (y1, dx1, dp1), (y2, dx2, _) = res
     assert torch.equal(y0, y1), "the option must not change the forward output"
     # (parameter gradients: same kernels; the default slice-owner scatter is reproducible to fp32 rounding only)
-    _assert_close(dp1, dp0, rtol=1e-3, atol_scale=2e-4, what="dL/dparams with the option on")
+    _assert_close(dp1, dp0, rtol=2.6e-6, atol_scale=5.2e-7, what="dL/dparams with the option on")
     assert torch.equal(dx0, dx2), "switching the option off again must restore the gather form exactly"
-    _assert_close(dx1, dx0, rtol=2e-3, atol_scale=2e-3, what="dL/dx from stored dy/dx vs gather")
+    _assert_close(dx1, dx0, rtol=4.8e-4, atol_scale=4.8e-4, what="dL/dx from stored dy/dx vs gather")
     assert float(dx0.abs().max()) > 0
 
 
@@ -313,15 +336,15 @@ def test_grid_bwd_lds_matches_atomic_large(device):
     torch.cuda.synchronize()
     # packed 32-bit fixed-point accumulators (one 64-bit LDS atomic per record, scale 2^29 / L1 of the bin): each add
     # rounds to L1(bin) / 2^29 -- finer than the 16-17 mantissa bits the records carry -- and the sums are integers
-    _assert_close(grads[7], grads[0], rtol=1e-3, atol_scale=1e-5, what="streamed (tile-local, packed 32-bit) vs atomic")
+    _assert_close(grads[7], grads[0], rtol=4.1e-4, atol_scale=4.1e-6, what="streamed (tile-local, packed 32-bit) vs atomic")
     _set_bwd_mode(enc, 7)
     enc.params.grad = None
     (enc(x).float() * dy).sum().backward()
     hashed7 = 2 * (4096 + 12168 + 29792 + 79512 + 205384)
     assert torch.equal(enc.params.grad[hashed7:], grads[7][hashed7:]), "packed form is not bitwise reproducible"
     # run-merged coarse levels (uniform random points are the worst case: no two consecutive samples share a cell)
-    _assert_close(grads[5], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds + run-merged dense levels vs atomic dL/dparams")
-    _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what="lds vs atomic dL/dparams")
+    _assert_close(grads[5], grads[0], rtol=3e-5, atol_scale=3e-7, what="lds + run-merged dense levels vs atomic dL/dparams")
+    _assert_close(grads[1], grads[0], rtol=3e-5, atol_scale=3e-7, what="lds vs atomic dL/dparams")
     # every sample distributes a total weight of 1 per level/feature: sum of grads == sum of dy16
     dy16 = (dy * 128).half().double() / 128
     assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0
@@ -371,7 +394,8 @@ def test_pair_records_that_straddle_two_bins(device):
             enc.params.grad = None
             (enc(x).float() * dy).sum().backward()
             grads.append(enc.params.grad.clone())
-        _assert_close(grads[1], grads[0], rtol=1e-3, atol_scale=1e-5, what=f"packed pair records vs atomics ({what})")
+        _assert_close(grads[1], grads[0], rtol=1e-3 if cfg is ngp else 4.2e-4, atol_scale=1e-5 if cfg is ngp else 4.2e-6,
+                      what=f"packed pair records vs atomics ({what})")
         dy16 = (dy * 128).half().double() / 128
         assert abs(grads[1].double().sum().item() - dy16.sum().item()) <= 1e-2 * dy16.abs().sum().item() ** 0.5 + 1.0
 
@@ -392,12 +416,12 @@ def test_spherical_harmonics(device):
         dr = d01.detach().double().cpu().requires_grad_(True)
         yr = S.sh_encode(dr, degree)
         dy16 = (dy.cpu() * 128).half().double() / 128
-        _assert_close(y, yr, rtol=1e-3, atol_scale=1e-3, what=f"SH degree {degree}")
+        _assert_close(y, yr, rtol=4.7e-4, atol_scale=4.7e-4, what=f"SH degree {degree}")
         if degree == 1:  # constant encoding: the gradient is exactly zero
             assert (d01.grad == 0).all()
             continue
         (yr * dy16).sum().backward()
-        _assert_close(d01.grad, dr.grad, rtol=2e-3, atol_scale=1e-3, what=f"SH degree {degree} dL/dd")
+        _assert_close(d01.grad, dr.grad, rtol=4.4e-7, atol_scale=2.2e-7, what=f"SH degree {degree} dL/dd")
 
 
 MLP_SHAPES = [
@@ -450,9 +474,9 @@ def test_network_fwd_bwd(device, shape, dtype):
         dy16 = q16(dy.cpu().double() * 128) / 128  # the kernel sees dy * loss_scale in its 16-bit format
         (yr * dy16).sum().backward()
 
-    _assert_close(y, yr, rtol=1e-2 * k, atol_scale=5e-3 * k, what="MLP output")
-    _assert_close(x.grad, xr.grad, rtol=2e-2 * k, atol_scale=1e-2 * k, what="MLP dL/dinput", max_outlier_frac=1e-3 if k > 1 else 0.0)
-    _assert_close(net.params.grad, pr.grad, rtol=2e-2 * k, atol_scale=1e-2 * k, what="MLP dL/dparams")
+    _assert_close(y, yr, rtol=1e-3 * k, atol_scale=5e-4 * k, what="MLP output")
+    _assert_close(x.grad, xr.grad, rtol=1.9e-3 * k, atol_scale=9.3e-4 * k, what="MLP dL/dinput", max_outlier_frac=1e-3 if k > 1 else 0.0)
+    _assert_close(net.params.grad, pr.grad, rtol=3.1e-3 * k, atol_scale=1.55e-3 * k, what="MLP dL/dparams")
 
 
 @pytest.mark.parametrize("deterministic", [False, True], ids=["atomics", "deterministic"])
@@ -549,11 +573,11 @@ def test_network_with_input_encoding(device, cfg, width, dtype):
         dy16 = q16(dy.cpu().double() * 128) / 128
         (yr * dy16).sum().backward()
 
-    _assert_close(y, yr, rtol=1e-2 * k, atol_scale=5e-3 * k, what="NWIE output")
-    _assert_close(model.params.grad[:n_net], pr.grad[:n_net], rtol=2e-2 * k, atol_scale=1e-2 * k, what="NWIE dW")
-    # the encoding gradient passes through a 16-bit d(encoded) buffer: tolerance 1 ulp of the scale
-    _assert_close(model.params.grad[n_net:], pr.grad[n_net:], rtol=2e-2 * k, atol_scale=2e-3 * k, what="NWIE dgrid",
-                  max_outlier_frac=1e-5 * k)
+    _assert_close(y, yr, rtol=1.2e-3 * k, atol_scale=6e-4 * k, what="NWIE output")
+    _assert_close(model.params.grad[:n_net], pr.grad[:n_net], rtol=4e-3 * k, atol_scale=2e-3 * k, what="NWIE dW")
+    # the encoding gradient passes through a 16-bit d(encoded) buffer (_assert_close_chain: aggregate + cap)
+    chain = {(64, "f16"): (7e-4, 9e-3), (64, "bf16"): (5.5e-3, 9e-2), (16, "f16"): (6e-4, 6.5e-4), (16, "bf16"): (5e-3, 4e-3)}
+    _assert_close_chain(model.params.grad[n_net:], pr.grad[n_net:], "NWIE dgrid", *chain[(width, dtype)])
     _assert_close(x.grad, xr.grad, rtol=3e-2 * k, atol_scale=1e-2 * k, what="NWIE dL/dx")
 
 
@@ -596,7 +620,7 @@ def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dt
     assert torch.equal(res[0][2], res[1][2]), "dL/dx differs (the encoded features left in ctx differ)"
     # the weight gradient is flushed with float atomics (order-dependent in the last bits); the grid gradient of the
     # default slice-owner scatter is deterministic for single-chunk slices -- both must agree to rounding
-    _assert_close(res[1][1], res[0][1], rtol=1e-4, atol_scale=1e-6, what="dL/dparams, fused vs two-kernel forward")
+    _assert_close(res[1][1], res[0][1], rtol=2.3e-5, atol_scale=2.3e-7, what="dL/dparams, fused vs two-kernel forward")
 
 
 def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0, runs=0):
@@ -660,8 +684,8 @@ def test_zero_gradient_samples_are_skipped_exactly(device, zero_frac):
     # grid gradient accumulates in int32 with the scale 2^29 / L1(dy): with the live list the L1 norms are summed inside
     # k_live_samples, without it by k_dy_l1 -- another summation order, a scale that differs in its last bits, hence
     # every addend rounded to the integer grid independently in the two runs: quantum L1 / 2^29 per addend.)
-    _assert_close(res["skip"][2][n_net:], res["ref"][2][n_net:], rtol=1e-3, atol_scale=2e-5, what="grid gradient, live list")
-    _assert_close(res["skip"][2][:n_net], res["ref"][2][:n_net], rtol=1e-4, atol_scale=1e-6, what="dW with skipped tiles")
+    _assert_close(res["skip"][2][n_net:], res["ref"][2][n_net:], rtol=2.7e-6, atol_scale=5.4e-8, what="grid gradient, live list")
+    _assert_close(res["skip"][2][:n_net], res["ref"][2][:n_net], rtol=5.5e-6, atol_scale=5.5e-8, what="dW with skipped tiles")
     if zero_frac == 1.0:
         assert float(res["skip"][2].abs().max()) == 0.0 and float(res["skip"][1].abs().max()) == 0.0
 
@@ -715,7 +739,7 @@ def test_run_merged_dense_levels_match_slice_owner(device, cfg, acc_bits, live):
         res[tag] = dp.clone()
     n_net = 16 * 16 + 16 * 16
     assert float(res["owner"][n_net:].abs().max()) > 0
-    tol = dict(rtol=1e-5, atol_scale=1e-6) if acc_bits == 64 else dict(rtol=1e-3, atol_scale=1e-4)
+    tol = dict(rtol=2.2e-6, atol_scale=2.2e-7) if acc_bits == 64 else dict(rtol=2.2e-4, atol_scale=2.2e-5)
     _assert_close(res["runs"][n_net:], res["owner"][n_net:], what="grid gradient, run-merged", **tol)
 
 

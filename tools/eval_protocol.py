@@ -48,6 +48,37 @@ def _pose_errors(pred: np.ndarray, gt: np.ndarray) -> dict:
     return {"translation_rmse": float(np.sqrt((dt ** 2).sum(1).mean())), "rotation_mean_rad": float(ang.mean())}
 
 
+def _gauge_split(pred: np.ndarray, gt: np.ndarray) -> dict:
+    """The pose error split into what a common rigid motion of ALL cameras explains (a gauge: the field absorbs it, and
+    the protocol's alignment pins it on frame 0 alone) and what is left.  D_i = pred_i gt_i^-1 is camera i's error as a
+    world-frame motion; G = their mean (rotation vectors and translations averaged: the errors are ~1e-3); the residual of
+    camera i is G^-1 D_i."""
+    n = pred.shape[0]
+    P4, G4 = np.tile(np.eye(4), (n, 1, 1)), np.tile(np.eye(4), (n, 1, 1))
+    P4[:, :3, :4], G4[:, :3, :4] = pred[:, :3, :4], gt[:, :3, :4]
+    D = P4 @ np.linalg.inv(G4)
+
+    def log_so3(R):
+        ang = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+        w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        return w * (0.5 if ang < 1e-8 else ang / (2 * np.sin(ang)))
+
+    def exp_so3(w):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        return np.eye(3) + K if th < 1e-8 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+    w = np.stack([log_so3(D[i, :3, :3]) for i in range(n)])
+    Gm = np.eye(4)
+    Gm[:3, :3], Gm[:3, 3] = exp_so3(w.mean(0)), D[:, :3, 3].mean(0)
+    Res = np.linalg.inv(Gm)[None] @ D
+    res_ang = np.array([np.linalg.norm(log_so3(Res[i, :3, :3])) for i in range(n)])
+    return {"mean_rigid_rotation_rad": float(np.linalg.norm(w.mean(0))), "mean_rigid_translation": float(np.linalg.norm(Gm[:3, 3])),
+            "residual_rotation_mean_rad": float(res_ang.mean()),
+            "residual_translation_rmse": float(np.sqrt((Res[:, :3, 3] ** 2).sum(1).mean())),
+            "raw_rotation_mean_rad": float(np.linalg.norm(w, axis=1).mean())}
+
+
 def _log(mapper):
     every = int(os.environ.get("NVO_PROTO_LOG", "0"))
     lo, hi = int(os.environ.get("NVO_PROTO_LOG_FROM", "0")), int(os.environ.get("NVO_PROTO_LOG_TO", "1000000000"))
@@ -170,6 +201,8 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
            "evaluation_frames": {**{k: float(v) for k, v in m_eval.items()}, "psnr_float_mse": psnr_float, "frames": len(files)},
            "keyframe_views": {k: float(v) for k, v in m_kf.items()},
            "pose_error_after_frame0_alignment": pose_err, "pose_error_of_ingested_poses": _pose_errors(ing, gt_kf),
+           # the same error split into the cameras' common rigid motion (gauge) and the residual
+           "pose_error_gauge_split": _gauge_split(traj, gt_kf),
            "pose_adjustment_rms": float((eng.pose_adjustment if ngp else eng.view("camera_opt.pose_adjustment")).pow(2).mean().sqrt()),
            "deterministic": bool(deterministic), "seed": seed, "exported_poses": int(exported.shape[0])}
     if ngp:
