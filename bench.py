@@ -702,6 +702,9 @@ def main() -> None:
                     "depth_delta1": round(ef["delta1"], 4), "scale_pred2gt": round(res["scale_pred2gt"], 5),
                     "pose_rotation_error_rad": round(res["pose_error_after_frame0_alignment"]["rotation_mean_rad"], 6),
                     "ingested_pose_rotation_error_rad": round(res["pose_error_of_ingested_poses"]["rotation_mean_rad"], 6),
+                    # the same pose error split into the cameras' common rigid motion (a gauge the field absorbs; the
+                    # protocol's alignment pins it on frame 0 alone) and what is left per camera
+                    "pose_error_gauge_split": {k: round(v, 6) for k, v in res["pose_error_gauge_split"].items()},
                     "loss_scale_end": res["loss_scale_end"], "seed": seed}
 
         # headline = fixed exact poses, MEDIAN run (by float-MSE PSNR) of three fixed seeds, every run listed: one of 29

@@ -107,6 +107,34 @@ class _LazyOutputs(dict):
     def __contains__(self, key):
         return dict.__contains__(self, key) or key in self._lazy
 
+    # everything that enumerates the outputs sees the lazy members too (nerfstudio-style per-key loops: metrics, image
+    # writers, the viewer): they are computed at that point
+    def _materialise(self):
+        for key in list(self._lazy):
+            self[key] = self._lazy.pop(key)()
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
 
 class ExtendedNerfactoModel:
     def __init__(self, config: ExtendedNerfactoModelConfig, num_train_data: int, device, world_size: int = 1,
