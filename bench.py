@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md, L2 (per XCD): 4 MiB per XCD, 32 MiB aggregate, ~34.5 TB/s
 
 WORKLOADS = {
     "replica": dict(keyframes=192, height=480, width=640, mlp_dtype="f16", normals=False,
@@ -619,8 +620,14 @@ def main() -> None:
                 "ms_per_frame": round(ms, 3), "ms_per_frame_wall": round(wall * 1e3, 3),
                 "rays_per_sec": n_rays / (ms * 1e-3),
                 "field_evals_per_sec": n_rays * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples)) / (ms * 1e-3),
-                "roofline": {"bound": "hbm", "achieved": round(n_rays * per_ray / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(n_rays * per_ray / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}})
+                # The frame's algorithmic bytes are table GATHERS (588 B of 600 per main-field sample, 160 of 192 per proposal
+                # sample), and the tables -- 24.4 MB main, 1.5 + 1.7 MB proposal, fp16 -- stay in the 32 MiB of L2 (k_grid_fwd
+                # pins a level to one XCD; the PMC counters of the training step show 8.7-12.1 MB fetched per grid_fwd[L5] launch
+                # against 201 MB of algorithmic gathers).  The bound that applies is the L2 gather rate, not HBM.
+                "roofline": {"bound": "l2", "achieved": round(n_rays * per_ray / (ms * 1e-3) / 1e9, 1), "peak": L2_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(n_rays * per_ray / (ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
+                             "note": "algorithmic gather bytes over the L2 aggregate rate; HBM traffic is a small fraction of "
+                                     "these bytes (tables L2-resident), so no HBM fraction is quoted"}})
         # per-kernel table of one 1200x680 frame, eagerly with HIP events on the launch stream
         if not args.no_kernel_table:
             fx, fy, cx, cy = replica_intrinsics(680, 1200)
@@ -651,9 +658,10 @@ def main() -> None:
                     # (launches of the ragged last chunk are smaller: the frame's samples over the frame's time)
                     # (algorithmic_bytes prices ONE launch -- for the two proposal grids their average)
                     frame_bytes = bts / chunk * 1200 * 680 * (2 if "L5" in name else 1)
-                    row["roofline"] = {"bound": "hbm", "achieved": round(frame_bytes / (total * 1e-3) / 1e9, 1),
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-                    row["roofline"]["frac"] = round(row["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
+                    # (cache-resident tables: priced against the L2 gather rate, see the frame's roofline above)
+                    row["roofline"] = {"bound": "l2", "achieved": round(frame_bytes / (total * 1e-3) / 1e9, 1),
+                                       "peak": L2_PEAK_GBS, "unit": "GB/s"}
+                    row["roofline"]["frac"] = round(row["roofline"]["achieved"] / L2_PEAK_GBS, 4)
                 table.append(row)
             render["kernel_table_1200x680"] = table
 
