@@ -245,6 +245,8 @@ class NgpEngine:
         # adaptive ray batch moves without a new capture
         self._R_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._R_dev_host = -1
+        # epoch block of nvo_occ_pack_fused (scan + compact + positions in one launch): zeroed once, the kernels' own from then on
+        self._pack_state = torch.zeros(int(_lib.lib().nvo_occ_pack_state_bytes()), dtype=torch.uint8, device=dev)
         self._measured_n = 0
         self._ws = None                      # the workspace used last
         self._wss = {True: None, False: None}  # one for training, one for inference (switching keeps both, and the captured steps)
@@ -493,8 +495,11 @@ class NgpEngine:
         _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
               cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts"]), _ptr(ws["march_scratch"]),
               ws["march_scratch"].numel(), _ptr(t_resume), int(max_new), _ptr(t_next), rdev, 0)
-        _call("nvo_occ_pack", stream, R, _ptr(ws["counts"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
-              _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0)
+        lo, hi = cfg.aabb
+        _call("nvo_occ_pack_fused", stream, R, _ptr(ws["counts"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
+              _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0,
+              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
+        ws["x01_ready"] = True  # (the pack wrote the network input of every packed sample)
 
     def _march_compact(self, ws, jitter, stream) -> None:
         """The training batch as upstream builds it (NgpConfig.compact_training): march -> everything found packed into the
@@ -523,10 +528,9 @@ class NgpEngine:
             _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
                   cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts_m"]), _ptr(ws["march_scratch"]),
                   nscr, _ptr(resume), budget, None if last else _ptr(ws["t_next"]), rdev, base)
-            _call("nvo_occ_pack", stream, R, _ptr(ws["counts_m"]), B, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
-                  C.c_void_p(tot_ptr), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev, base)
-            _call("nvo_ngp_positions_live", stream, B, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["origins"]),
-                  _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]), n_live)
+            _call("nvo_occ_pack_fused", stream, R, _ptr(ws["counts_m"]), B, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
+                  C.c_void_p(tot_ptr), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev, base,
+                  _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]))
             # density alone (column 0, compact), no d(encoded)/d(position), tiles past the slots in use skipped; the raw
             # weights (the training pass behind this evaluates the same ones)
             net.set_option("n_live_ptr", n_live.value)
@@ -553,9 +557,11 @@ class NgpEngine:
             _call("nvo_ngp_count_alive", stream, C.byref(aa))
             base += budget
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
-        _call("nvo_occ_pack", stream, R, _ptr(ws["kept"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
-              _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0)
+        _call("nvo_occ_pack_fused", stream, R, _ptr(ws["kept"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
+              _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0,
+              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
         ws["ray_state_on"] = True
+        ws["x01_ready"] = True
 
     def _shade(self, ws, training: bool, stream) -> None:
         cfg = self.cfg
@@ -563,8 +569,9 @@ class NgpEngine:
         lo, hi = cfg.aabb
         # training evaluates the raw weights, inference the moving average (tcnn Trainer: params vs. params_inference)
         self._fwd_half = self.params_half if training else self.inference_params_half()
-        _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
-              _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
+        if not ws.pop("x01_ready", False):  # (the pack in front of this wrote them; callers that fill the packed arrays themselves)
+            _call("nvo_ngp_positions", stream, cap, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["origins"]),
+                  _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
         # (inference needs no d(encoded)/d(position) from the forward; the option is read at launch time)
         no_dydx = (not training) and bool(cfg.optimize_extrinsics)
         if no_dydx:

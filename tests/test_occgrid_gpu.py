@@ -307,3 +307,52 @@ def test_march_in_rounds_concatenates_to_the_single_march(device, first):
         both = np.concatenate([runs1[r], runs2[r]], axis=1)
         assert (both.view(np.uint32) == runs_all[r].view(np.uint32)).all(), r
     assert (c2[nxt < 0] == 0).all()
+
+
+@pytest.mark.parametrize("R,R_used,cap", [(65536, 65536, 1 << 22), (65536, 13312, 1 << 18), (16384, 12345, 1 << 18), (4096, 100, 1 << 15),
+                                          (64, 64, 1 << 10), (1, 1, 64)])
+def test_pack_in_one_launch_matches_the_three_launch_pack(device, R, R_used, cap):
+    """nvo_occ_pack_fused (scan by decoupled look-back between 64-ray workgroups + copy + network input of every copied
+    sample) against nvo_occ_pack + nvo_ngp_positions: counts, offsets, totals, ray_idx, t, dt and x01 bit for bit, with
+    the ray count on the device, rays dropped at the capacity, a run offset, and 40 launches in a row on one state block
+    (every launch runs in a new epoch of it) -- up to 1024 workgroups waiting on each other's totals."""
+    from nerf_vo_amd import _lib
+    from oracle import ngp as ON
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(R + R_used)
+    n_scr = int(lib.nvo_occ_march_scratch_bytes(R))
+    scratch = torch.rand(n_scr // 4, generator=g).to(device)  # (t, dt) pairs of every run slot
+    origins = (torch.rand(R, 3, generator=g) - 0.5).to(device)
+    directions = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    state = torch.zeros(int(lib.nvo_occ_pack_state_bytes()), dtype=torch.uint8, device=device)
+    r_dev = torch.tensor([R_used], dtype=torch.int32, device=device)
+    i32 = dict(dtype=torch.int32, device=device)
+    for it in range(40):
+        run_offset = 0 if it % 2 == 0 else 17
+        hi = max(2, min(1024 - run_offset, (3 * cap) // max(R_used, 1)))  # about a third of the launches overflow the capacity
+        counts = torch.randint(0, hi, (R,), generator=g, dtype=torch.int32)
+        counts[torch.rand(R, generator=g) < 0.2] = 0
+        counts = counts.to(device)
+        out = {}
+        for fused in (False, True):
+            c_out, offs, tot = torch.full((R,), -7, **i32), torch.full((R + 1,), -7, **i32), torch.full((2,), -7, **i32)
+            ridx = torch.full((cap,), -1, **i32)
+            t, dt = torch.zeros(cap, device=device), torch.zeros(cap, device=device)
+            x01 = torch.zeros(cap, 3, device=device)
+            if fused:
+                _lib.check(lib.nvo_occ_pack_fused(_stream(), R, _p(counts), cap, _p(c_out), _p(offs), _p(tot), _p(scratch), n_scr,
+                                                  _p(ridx), _p(t), _p(dt), _p(r_dev), run_offset, _p(state), _p(origins),
+                                                  _p(directions), -1.5, 2.5, _p(x01)), "nvo_occ_pack_fused")
+            else:
+                _lib.check(lib.nvo_occ_pack(_stream(), R, _p(counts), cap, _p(c_out), _p(offs), _p(tot), _p(scratch), n_scr,
+                                            _p(ridx), _p(t), _p(dt), _p(r_dev), run_offset), "nvo_occ_pack")
+                _lib.check(lib.nvo_ngp_positions(_stream(), cap, _p(ridx), _p(t), _p(origins), _p(directions), -1.5, 2.5, _p(x01)),
+                           "nvo_ngp_positions")
+            torch.cuda.synchronize()
+            out[fused] = (c_out[:R_used], offs[:R_used + 1], tot, ridx, t, dt, x01)
+        for a, b, name in zip(out[False], out[True], ("counts", "offsets", "totals", "ray_idx", "t", "dt", "x01")):
+            assert torch.equal(a, b), (name, it)
+        kept, offsets, total = ON.compact_offsets(counts[:R_used].cpu().numpy(), cap)
+        assert (out[True][0].cpu().numpy() == kept).all() and (out[True][1].cpu().numpy() == offsets).all()
+        assert out[True][2].cpu().tolist() == [total, min(total, cap)]
