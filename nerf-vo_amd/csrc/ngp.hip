@@ -120,6 +120,98 @@ k_ngp_composite_loss(nvo_ngp_loss_args a) {
     const _Float16* den = (const _Float16*)a.density_out;
     const _Float16* col = (const _Float16*)a.rgb_out;
 
+    // ---- training, a ray of at most 64 samples (with the compacted batch: nearly every ray -- a ray keeps ~20 samples):
+    // ONE pass with everything in registers.  Same operations in the same order as the chunked passes below (their carries
+    // are exact zeros for a single chunk), so the values are theirs bit for bit; the chunked form loads every sample three
+    // times and evaluates its four exponentials three times.
+    if (a.d_rgb_out && n <= 64u) {
+        const uint32_t j = (uint32_t)lane;
+        const bool valid = j < n;
+        const size_t s = base + j;
+        float sigma = 0.f, dd = 0.f, tj = 0.f, dts = 0.f, rgb[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            sigma = __expf((float)den[s * a.density_stride]);
+            dts = a.dt[s];
+            dd = ngp_optical_step(sigma, dts);
+            tj = a.t[s];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb[k] = 1.f / (1.f + __expf(-(float)col[s * a.rgb_stride + k]));
+        }
+        const float incl = wave_incl_scan(dd, lane) + 0.f;
+        const float T = __expf(-(incl - dd));
+        const float w = valid ? (1.f - __expf(-dd)) * T : 0.f;
+        float pix[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pix[k] = 0.f + wave_sum(w * rgb[k]);
+        const float depth = 0.f + wave_sum(w * tj);
+        const float acc = 0.f + wave_sum(w);
+        const float carry1 = nvo_wave_bcast(incl, 63);
+        const float T_final = __expf(-carry1);
+        float bg[3] = {0.f, 0.f, 0.f};
+        if (a.background && state == 0u) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bg[k] = a.background[3 * (size_t)r + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pix[k] += T_final * bg[k];
+        if (lane == 0) {
+            if (a.out_rgb) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.out_rgb[3 * (size_t)r + k] = 0.f + pix[k];
+            }
+            if (a.out_depth) a.out_depth[r] = 0.f + depth;
+            if (a.out_accumulation) a.out_accumulation[r] = 0.f + acc;
+        }
+        if (n == 0u && a.offsets[r + 1] != base) return;
+        if (state == 2u) return;
+        float g_pix[3], l_rgb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = pix[k] - a.gt_rgb[3 * (size_t)r + k];
+            l_rgb += e * e;
+            g_pix[k] = 2.f * e * a.inv_rays * (1.f / 3.f) * a.rgb_mult;
+        }
+        l_rgb *= a.inv_rays * (1.f / 3.f) * a.rgb_mult;
+        float g_depth = 0.f, l_depth = 0.f;
+        if (a.gt_depth && a.depth_mult != 0.f) {
+            const float z = a.gt_depth[r] * (a.directions_norm ? a.directions_norm[r] : 1.f);
+            float wgt = 1.f;
+            if (a.gt_depth_cov) {
+                const float var = a.gt_depth_cov[r];
+                wgt = (var > 0.f && var < __builtin_inff()) ? 1.f / var : 0.f;
+            }
+            if (z > 0.f) {
+                const float e = depth - z;
+                l_depth = e * e * wgt * a.inv_rays * a.depth_mult;
+                g_depth = 2.f * e * wgt * a.inv_rays * a.depth_mult;
+            }
+        }
+        if (lane == 0) {
+            float* shard = a.losses + 8 * (r & 63u);
+            atomicAdd(shard + 0, l_rgb);
+            atomicAdd(shard + 1, l_depth);
+        }
+        float dot = g_depth * tj;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dot += g_pix[k] * rgb[k];
+        const float q = valid ? w * dot : 0.f;
+        const float total_q = 0.f + wave_sum(q);
+        const float g_bg = T_final * (g_pix[0] * bg[0] + g_pix[1] * bg[1] + g_pix[2] * bg[2]);
+        const float incl_q = wave_incl_scan(q, lane) + 0.f;
+        if (valid) {
+            const float suffix = total_q - incl_q;
+            const bool dead = T < a.train_min_transmittance;
+            const float dsigma = dts * (T * __expf(-dd) * dot - suffix - g_bg);
+            a.d_density_pre[s] = dead ? 0.f : dsigma * fminf(sigma, 3.2690173e6f) * a.loss_scale;
+            _Float16* d_rgb = (_Float16*)a.d_rgb_out;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                d_rgb[s * a.d_rgb_stride + k] = dead ? (_Float16)0.f : (_Float16)(w * g_pix[k] * rgb[k] * (1.f - rgb[k]) * a.loss_scale);
+            for (uint32_t k = 3; k < a.d_rgb_stride; ++k) d_rgb[s * a.d_rgb_stride + k] = (_Float16)0.f;
+        }
+        return;
+    }
+
     // ---- pass 1: composite front to back (T = prod (1 - alpha) through a log-space additive scan)
     // sum of density * dt of all previous samples (inference in rounds: what earlier rounds of this ray have gathered)
     float carry = (a.carry_in && !a.d_rgb_out) ? a.carry_in[r] : 0.f;

@@ -524,7 +524,8 @@ class NgpEngine:
             n_live = C.c_void_p(tot_ptr + 4)
             # slots this round can fill at most: its budget per ray
             B = min(cap_m, (R * budget + 4095) // 4096 * 4096)
-            _call("nvo_fill_i32", stream, B, _ptr(ws["ray_idx_m"]), -1)
+            # (no clearing of ray_idx_m: nothing of this pass reads the slots no ray owns -- the pack writes position, t and
+            # dt of the slots in use, the network stops at their count, the count kernel walks the rays' own ranges)
             _call("nvo_occ_march_runs", stream, R, _ptr(ws["origins"]), _ptr(ws["directions"]), _ptr(self.bitfield),
                   cfg.n_levels, cfg.cone_angle, cfg.near_distance, _ptr(jitter), _ptr(ws["counts_m"]), _ptr(ws["march_scratch"]),
                   nscr, _ptr(resume), budget, None if last else _ptr(ws["t_next"]), rdev, base)
