@@ -529,7 +529,7 @@ int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, co
 int nvo_occ_pack(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
                  uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
                  float* t_out, float* dt_out, const uint32_t* R_dev, uint32_t run_offset);
-/* nvo_occ_pack in ONE launch (scan by decoupled look-back between 64-ray workgroups, copy, and -- x01 != NULL -- the
+/* nvo_occ_pack in ONE launch (scan by decoupled look-back between 16- or 64-ray workgroups, copy, and -- x01 != NULL -- the
  * network input of every copied sample, nvo_ngp_positions' values: clamp((o + t d - aabb_lo) / (aabb_hi - aabb_lo), 0, 1)).
  * Same counts_out / offsets / totals / ray_idx / t / dt as nvo_occ_pack, bit for bit.  `state`: caller-owned device block of
  * nvo_occ_pack_state_bytes() bytes, 8-byte aligned, ZEROED once when it is allocated and never touched by the caller again
@@ -538,7 +538,8 @@ uint64_t nvo_occ_pack_state_bytes(void);
 int nvo_occ_pack_fused(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
                        uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
                        float* t_out, float* dt_out, const uint32_t* R_dev, uint32_t run_offset, void* state,
-                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01);
+                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01,
+                       uint32_t rays_per_group /* 16 | 64: rays a workgroup owns (speed only) */);
 /* grid: device float [n_levels][128^3]; fresh (nullable): same shape, the new optical thickness per
  * cell -> grid = grid < 0 ? grid : max(grid * decay, fresh); then bitfield = grid > min(threshold,
  * mean(max(grid[0], 0))) and every coarser cascade ORs in the 2x2x2 max-pool of the next finer one.

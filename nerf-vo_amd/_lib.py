@@ -183,7 +183,7 @@ _SIGNATURES = {
     "nvo_occ_march_runs": (_int, [_p, _u32, _p, _p, _p, _int, _f, _f, _p, _p, _p, _u64, _p, _u32, _p, _p, _u32]),
     "nvo_occ_pack": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p, _u32]),
     "nvo_occ_pack_state_bytes": (_u64, []),
-    "nvo_occ_pack_fused": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p, _u32, _p, _p, _p, _f, _f, _p]),
+    "nvo_occ_pack_fused": (_int, [_p, _u32, _p, _u32, _p, _p, _p, _p, _u64, _p, _p, _p, _p, _u32, _p, _p, _p, _f, _f, _p, _u32]),
     "nvo_ngp_count_alive": (_int, [_p, C.POINTER(NgpAliveArgs)]),
     "nvo_ngp_positions_live": (_int, [_p, _u32, _p, _p, _p, _p, _f, _f, _p, _p]),
     "nvo_ngp_positions_bwd_dev": (_int, [_p, _u32, _u32, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p]),

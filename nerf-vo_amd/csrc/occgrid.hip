@@ -392,59 +392,83 @@ k_scan_counts(uint32_t n, const uint32_t* counts_in, uint32_t* counts_out, uint3
 // ---- scan + compact (+ positions) in ONE launch ----------------------------------------------------------------
 // nvo_occ_pack spends three launches on what is a few microseconds of work: a single-workgroup scan (10-17 us for
 // 4-13 K rays: one CU, latency all the way), the copy of the runs, and -- in the training step of the occupancy-grid
-// back-end -- the network input of every packed slot; three such sequences per step.  Here a workgroup owns 64 rays:
+// back-end -- the network input of every packed slot; three such sequences per step.  Here a workgroup owns 16 rays (64 left
+// 47 workgroups for a 3 K-ray batch whose runs are hundreds of samples long):
 // it scans their counts, PUBLISHES its total, reads the totals of the workgroups in front of it (a decoupled look-back
-// without aggregation: at most 1023 eight-byte words), and goes on to copy its rays' runs and write their positions.
+// without aggregation: at most 4095 eight-byte words, 16 per thread), and goes on to copy its rays' runs and write their positions.
 // Cross-workgroup hand-off (MI355X_MICROARCH.md, "8-B agent atomics both sides"): a total travels as ONE 64-bit word
 // {epoch + 1, total} written with an agent-scope atomic store and polled with agent-scope atomic loads -- no payload
 // behind a flag, nothing that needs a release / acquire pair.  The epoch lives in the caller's state block and is advanced
 // by the LAST workgroup to finish (a second counter), so the words of this launch are stale for the next one without
 // anybody clearing them; launches that share a state block must be ordered (same stream).
 // Forward progress: a workgroup only waits for workgroups with a LOWER index, which the dispatcher has started before it;
-// at most 1024 workgroups of 256 threads, all resident at once on this chip.
+// (workgroups are dispatched in index order: whatever a resident workgroup waits for is resident or done).
 struct OccPackState {
-    unsigned long long sums[1024];
+    unsigned long long sums[65536 / 16];
     uint32_t epoch, done;
 };
 
+template <uint32_t kPackRays, int kPackRaysLog2>
 __global__ void __launch_bounds__(256)
 k_occ_pack_fused(uint32_t R, const uint32_t* counts_in, uint32_t* counts_out, uint32_t* __restrict__ offsets,
                  uint32_t capacity, uint32_t* __restrict__ totals, const float2* __restrict__ scratch, uint32_t run_offset,
                  int32_t* __restrict__ ray_idx, float* __restrict__ t_out, float* __restrict__ dt_out,
                  const uint32_t* __restrict__ R_dev, OccPackState* __restrict__ st, const float* __restrict__ origins,
                  const float* __restrict__ directions, float aabb_lo, float aabb_inv_size, float* __restrict__ x01) {
-    __shared__ uint32_t s_off[64], s_cnt[64], s_c[64], s_part[4];
-    __shared__ float s_od[64][6];  // origin | direction of the workgroup's rays
+    __shared__ uint32_t s_off[kPackRays], s_cnt[kPackRays], s_c[kPackRays], s_part[4];
+    __shared__ float s_od[kPackRays][6];  // origin | direction of the workgroup's rays
     __shared__ uint32_t s_prefix;
     if (R_dev) R = min(R, *R_dev);
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t tag = epoch + 1u;
-    const uint32_t r0 = b * 64u;
+    const uint32_t r0 = b * kPackRays;
+    if (r0 >= R && b != 0u) {
+        // past the batch (the launch covers the workspace's rows): nothing to scan, publish or copy -- only the check-in
+        // that lets the last workgroup retire the epoch
+        if (threadIdx.x == 0u) {
+            const uint32_t before = __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == gridDim.x - 1u) {
+                __hip_atomic_store(&st->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    const uint32_t b_last = R ? (R - 1u) / kPackRays : 0u;  // the workgroup that holds the last ray in use
     // ---- this workgroup's 64 counts: exclusive scan in wave 0, total published
     uint32_t c = 0, excl = 0;
     if (wave == 0u) {
         const uint32_t r = r0 + lane;
-        c = r < R ? counts_in[r] : 0u;
+        c = (lane < kPackRays && r < R) ? counts_in[r] : 0u;
         const uint32_t incl = nvo_wave_incl_scan(c);
         excl = incl - c;
         if (lane == 63u)
             __hip_atomic_store(&st->sums[b], ((unsigned long long)tag << 32) | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (x01) {
-        for (uint32_t i = threadIdx.x; i < 64u * 6u; i += 256u) {
+        for (uint32_t i = threadIdx.x; i < kPackRays * 6u; i += 256u) {
             const uint32_t q = i / 6u, a = i - q * 6u, r = r0 + q;
             s_od[q][a] = r < R ? (a < 3u ? origins[3 * (size_t)r + a] : directions[3 * (size_t)r + a - 3u]) : 0.f;
         }
     }
     // ---- totals of the workgroups in front: every thread polls its share
+    // (four words per thread requested at once -- they are all there when the workgroups of a launch start together --
+    // then the stragglers one by one: a thread that polled its words one after the other spent a round trip on each)
     uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < b; j += 256u) {
-        unsigned long long v;
-        do {
-            v = __hip_atomic_load(&st->sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((uint32_t)(v >> 32) != tag);
-        part += (uint32_t)v;
+    for (uint32_t j0 = threadIdx.x; j0 < b; j0 += 4u * 256u) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * 256u;
+            v[u] = j < b ? __hip_atomic_load(&st->sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * 256u;
+            while ((uint32_t)(v[u] >> 32) != tag) v[u] = __hip_atomic_load(&st->sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            part += (uint32_t)v[u];
+        }
     }
     part = nvo_wave_bcast(nvo_wave_incl_scan(part), 63);
     if (lane == 0u) s_part[wave] = part;
@@ -457,14 +481,16 @@ k_occ_pack_fused(uint32_t R, const uint32_t* counts_in, uint32_t* counts_out, ui
         const uint32_t off = prefix + excl;
         // capacity clamp: rays whose samples do not fit are dropped (count 0); offsets stay monotone
         const uint32_t kept = (off + c > capacity) ? 0u : c;
-        s_off[lane] = off;
-        s_cnt[lane] = kept;
-        s_c[lane] = c;
-        if (r < R) {
-            offsets[r] = off;
-            counts_out[r] = kept;
+        if (lane < kPackRays) {
+            s_off[lane] = off;
+            s_cnt[lane] = kept;
+            s_c[lane] = c;
+            if (r < R) {
+                offsets[r] = off;
+                counts_out[r] = kept;
+            }
         }
-        if (lane == 63u && b == gridDim.x - 1u) {  // (the launch covers ceil(R_arg / 64) workgroups: the last one ends the scan)
+        if (lane == 63u && b == b_last) {  // (the workgroup of the last ray in use ends the scan)
             const uint32_t total = off + c;
             offsets[R] = total;
             if (totals) {
@@ -478,7 +504,7 @@ k_occ_pack_fused(uint32_t R, const uint32_t* counts_in, uint32_t* counts_out, ui
     // total) are dealt to the threads one by one (a wave per ray left half the lanes idle on 20-32-sample runs and walked
     // its 16 rays one dependent load -> store after the other: 18.6 us per launch); a slot finds its ray by a 6-step
     // search of the 64 offsets in LDS
-    const uint32_t blk_total = s_off[63] + s_c[63] - prefix;
+    const uint32_t blk_total = s_off[kPackRays - 1u] + s_c[kPackRays - 1u] - prefix;
     for (uint32_t p0 = threadIdx.x; p0 < blk_total; p0 += 4u * 256u) {
         uint32_t slot[4], q[4], k[4];
         float2 v[4];
@@ -487,9 +513,9 @@ k_occ_pack_fused(uint32_t R, const uint32_t* counts_in, uint32_t* counts_out, ui
         for (int u = 0; u < 4; ++u) {
             const uint32_t p = p0 + (uint32_t)u * 256u;
             slot[u] = prefix + p;
-            uint32_t lo_ = 0u, hi_ = 64u;  // largest q with s_off[q] <= slot
+            uint32_t lo_ = 0u, hi_ = kPackRays;  // largest q with s_off[q] <= slot
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
+            for (int it = 0; it < kPackRaysLog2; ++it) {
                 const uint32_t mid = (lo_ + hi_) >> 1;
                 if (s_off[mid] <= slot[u]) lo_ = mid; else hi_ = mid;
             }
@@ -808,7 +834,9 @@ uint64_t nvo_occ_pack_state_bytes(void) { return sizeof(OccPackState); }
 int nvo_occ_pack_fused(nvo_stream_t stream, uint32_t R, const uint32_t* counts_in, uint32_t capacity, uint32_t* counts_out,
                        uint32_t* offsets, uint32_t* totals, const void* scratch, uint64_t scratch_bytes, int32_t* ray_idx,
                        float* t_out, float* dt_out, const uint32_t* R_dev, uint32_t run_offset, void* state,
-                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01) {
+                       const float* origins, const float* directions, float aabb_lo, float aabb_hi, float* x01,
+                       uint32_t rays_per_group) {
+    NVO_REQUIRE(rays_per_group == 16u || rays_per_group == 64u, "occ_pack_fused: rays_per_group is 16 or 64 (got %u)", rays_per_group);
     NVO_REQUIRE(R == 0 || (counts_in && counts_out && offsets && scratch && ray_idx && t_out && dt_out && state),
                 "occ_pack_fused: NULL argument");
     NVO_REQUIRE(scratch_bytes >= nvo_occ_march_scratch_bytes(R), "occ_pack_fused: scratch too small for %u rays", R);
@@ -818,9 +846,17 @@ int nvo_occ_pack_fused(nvo_stream_t stream, uint32_t R, const uint32_t* counts_i
     NVO_REQUIRE((((uintptr_t)state) & 7u) == 0u, "occ_pack_fused: the state block must be 8-byte aligned");
     if (R == 0) return NVO_OK;
     NVO_PROF(stream, "occ_pack");
-    NVO_LAUNCH(k_occ_pack_fused, dim3(nvo_div_up(R, 64)), dim3(256), 0, (hipStream_t)stream, R, counts_in, counts_out, offsets,
-               capacity, totals, static_cast<const float2*>(scratch), run_offset, ray_idx, t_out, dt_out, R_dev,
-               static_cast<OccPackState*>(state), origins, directions, aabb_lo, x01 ? 1.0f / (aabb_hi - aabb_lo) : 0.f, x01);
+    // 16 rays per workgroup while the batch is small (a 3 K-ray batch of early training has runs of hundreds of samples:
+    // 64-ray workgroups would leave 47 of them to copy everything), 64 once it is large (856 workgroups polling each
+    // other's 8-byte words hammer a few L2 channels: 19 us per launch against 13)
+    if (rays_per_group == 16u)
+        NVO_LAUNCH((k_occ_pack_fused<16, 4>), dim3(nvo_div_up(R, 16)), dim3(256), 0, (hipStream_t)stream, R, counts_in, counts_out,
+                   offsets, capacity, totals, static_cast<const float2*>(scratch), run_offset, ray_idx, t_out, dt_out, R_dev,
+                   static_cast<OccPackState*>(state), origins, directions, aabb_lo, x01 ? 1.0f / (aabb_hi - aabb_lo) : 0.f, x01);
+    else
+        NVO_LAUNCH((k_occ_pack_fused<64, 6>), dim3(nvo_div_up(R, 64)), dim3(256), 0, (hipStream_t)stream, R, counts_in, counts_out,
+                   offsets, capacity, totals, static_cast<const float2*>(scratch), run_offset, ray_idx, t_out, dt_out, R_dev,
+                   static_cast<OccPackState*>(state), origins, directions, aabb_lo, x01 ? 1.0f / (aabb_hi - aabb_lo) : 0.f, x01);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

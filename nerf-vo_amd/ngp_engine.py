@@ -476,6 +476,11 @@ class NgpEngine:
         """Device ray count of a launch that covers the workspace's rows (graphed steps), or None."""
         return _ptr(self._R_dev) if ws.get("R_launch") else None
 
+    @staticmethod
+    def _pack_group(ws) -> int:
+        """Rays a workgroup of nvo_occ_pack_fused owns: 16 for a small batch, 64 for a large one (speed only)."""
+        return 64 if int(ws["R"]) >= 6144 else 16
+
     def _forward(self, ws, training: bool, jitter, stream) -> None:
         if training and self.cfg.compact_training and "cap_m" in ws:
             self._march_compact(ws, jitter, stream)
@@ -498,7 +503,7 @@ class NgpEngine:
         lo, hi = cfg.aabb
         _call("nvo_occ_pack_fused", stream, R, _ptr(ws["counts"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
               _ptr(ws["march_scratch"]), ws["march_scratch"].numel(), _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0,
-              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
+              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]), self._pack_group(ws))
         ws["x01_ready"] = True  # (the pack wrote the network input of every packed sample)
 
     def _march_compact(self, ws, jitter, stream) -> None:
@@ -531,7 +536,7 @@ class NgpEngine:
                   nscr, _ptr(resume), budget, None if last else _ptr(ws["t_next"]), rdev, base)
             _call("nvo_occ_pack_fused", stream, R, _ptr(ws["counts_m"]), B, _ptr(ws["counts_m"]), _ptr(ws["offsets_m"]),
                   C.c_void_p(tot_ptr), _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx_m"]), _ptr(ws["t_m"]), _ptr(ws["dt_m"]), rdev, base,
-                  _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]))
+                  _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01_m"]), self._pack_group(ws))
             # density alone (column 0, compact), no d(encoded)/d(position), tiles past the slots in use skipped; the raw
             # weights (the training pass behind this evaluates the same ones)
             net.set_option("n_live_ptr", n_live.value)
@@ -560,7 +565,7 @@ class NgpEngine:
         _call("nvo_fill_i32", stream, cap, _ptr(ws["ray_idx"]), -1)
         _call("nvo_occ_pack_fused", stream, R, _ptr(ws["kept"]), cap, _ptr(ws["counts"]), _ptr(ws["offsets"]), _ptr(ws["totals"]),
               _ptr(ws["march_scratch"]), nscr, _ptr(ws["ray_idx"]), _ptr(ws["t"]), _ptr(ws["dt"]), rdev, 0,
-              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]))
+              _ptr(self._pack_state), _ptr(ws["origins"]), _ptr(ws["directions"]), lo, hi, _ptr(ws["x01"]), self._pack_group(ws))
         ws["ray_state_on"] = True
         ws["x01_ready"] = True
 
@@ -953,7 +958,8 @@ class NgpEngine:
 
     def _replay_step(self, ws, intrinsics, c2w, images, depths, cam_update, depths_cov, bg) -> None:
         cfg = self.cfg
-        key = (ws["R_cap"], bool(cfg.compact_training), int(cfg.march_capacity), tuple(cfg.train_rounds), ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
+        key = (ws["R_cap"], self._pack_group(ws), bool(cfg.compact_training), int(cfg.march_capacity), tuple(cfg.train_rounds),
+               ws["origins"].data_ptr(), intrinsics.data_ptr(), c2w.data_ptr(), images.data_ptr(), tuple(images.shape),
                None if depths is None else depths.data_ptr(), None if depths_cov is None else depths_cov.data_ptr(),
                bool(cfg.optimize_extrinsics), bool(cfg.adaptive_rays),
                bool(cam_update), self._camera_grad_scale() if cam_update else 0.0, self._fused_adam_plan(),

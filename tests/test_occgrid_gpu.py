@@ -312,10 +312,10 @@ def test_march_in_rounds_concatenates_to_the_single_march(device, first):
 @pytest.mark.parametrize("R,R_used,cap", [(65536, 65536, 1 << 22), (65536, 13312, 1 << 18), (16384, 12345, 1 << 18), (4096, 100, 1 << 15),
                                           (64, 64, 1 << 10), (1, 1, 64)])
 def test_pack_in_one_launch_matches_the_three_launch_pack(device, R, R_used, cap):
-    """nvo_occ_pack_fused (scan by decoupled look-back between 64-ray workgroups + copy + network input of every copied
+    """nvo_occ_pack_fused (scan by decoupled look-back between 16-ray workgroups + copy + network input of every copied
     sample) against nvo_occ_pack + nvo_ngp_positions: counts, offsets, totals, ray_idx, t, dt and x01 bit for bit, with
     the ray count on the device, rays dropped at the capacity, a run offset, and 40 launches in a row on one state block
-    (every launch runs in a new epoch of it) -- up to 1024 workgroups waiting on each other's totals."""
+    (every launch runs in a new epoch of it) -- up to 4096 workgroups waiting on each other's totals."""
     from nerf_vo_amd import _lib
     from oracle import ngp as ON
 
@@ -343,7 +343,7 @@ def test_pack_in_one_launch_matches_the_three_launch_pack(device, R, R_used, cap
             if fused:
                 _lib.check(lib.nvo_occ_pack_fused(_stream(), R, _p(counts), cap, _p(c_out), _p(offs), _p(tot), _p(scratch), n_scr,
                                                   _p(ridx), _p(t), _p(dt), _p(r_dev), run_offset, _p(state), _p(origins),
-                                                  _p(directions), -1.5, 2.5, _p(x01)), "nvo_occ_pack_fused")
+                                                  _p(directions), -1.5, 2.5, _p(x01), 16 if it % 4 < 2 else 64), "nvo_occ_pack_fused")
             else:
                 _lib.check(lib.nvo_occ_pack(_stream(), R, _p(counts), cap, _p(c_out), _p(offs), _p(tot), _p(scratch), n_scr,
                                             _p(ridx), _p(t), _p(dt), _p(r_dev), run_offset), "nvo_occ_pack")
