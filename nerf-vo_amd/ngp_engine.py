@@ -404,34 +404,46 @@ class NgpEngine:
         lo, hi = cfg.aabb
         chunk = 1 << 19
         x01 = torch.empty(chunk, 3, device=self.device)
-        out = torch.empty(chunk, 16, dtype=torch.float16, device=self.device)
-        ctx = torch.empty(self.density_net.ctx_bytes(chunk), dtype=torch.uint8, device=self.device)
-        if self.step >= cfg.density_warmup_steps:
-            # scattered refresh: a uniform pass (every trained cell qualifies) and a pass over occupied cells
-            fresh = torch.zeros(cfg.n_levels * CELLS, device=self.device)
-            cells = torch.empty(chunk, dtype=torch.int32, device=self.device)
-            n_pass = CELLS // 4 * cfg.n_levels
-            for pass_id, thresh in ((0, -0.01), (1, cfg.occupancy_threshold)):
-                for c0 in range(0, n_pass, chunk):
-                    m = min(chunk, n_pass - c0)
-                    _call("nvo_occ_sample_cells", stream, m, c0, n_pass, self.step, cfg.seed & 0xFFFFFFFF, pass_id,
-                          cfg.n_levels, _ptr(self.density_grid), thresh, lo, hi, _ptr(x01), _ptr(cells))
-                    # (the network runs on whole chunks: rows past m hold an earlier chunk's points and are not splatted)
-                    _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
-                          _ptr(out), _ptr(ctx))
-                    _call("nvo_ngp_thickness_splat", stream, m, _ptr(out), 16, _ptr(cells), _ptr(fresh))
-        else:
-            fresh = torch.empty(cfg.n_levels * CELLS, device=self.device)
-            pos = torch.empty(CELLS, 3, device=self.device)
-            for level in range(cfg.n_levels):
-                jit = torch.rand(CELLS, 3, device=self.device) if jitter else None
-                _call("nvo_occ_cell_positions", stream, level, _ptr(jit), _ptr(pos))
-                for c0 in range(0, CELLS, chunk):
-                    x01.copy_(((pos[c0:c0 + chunk] - lo) / (hi - lo)).clamp_(0.0, 1.0))
-                    _call("nvo_fwd", self.density_net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
-                          _ptr(out), _ptr(ctx))
-                    _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 16, level,
-                          C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
+        out = torch.empty(chunk, dtype=torch.float16, device=self.device)  # (compact: the density column alone)
+        net = self.density_net
+        # density alone, no d(encoded)/d(position): the refresh evaluates 3.1 M cell samples every 16 steps -- as many
+        # network evaluations per step as the training batch -- and ran them as TRAINING forwards until round 5 (16-column
+        # rows, 192 B of dy/dx per sample nobody read: 164 us per 2^19 samples against 116)
+        net.set_option("compact_output", 1)
+        if self._pig:
+            net.set_option("prepare_input_gradients", 0)
+        try:
+            ctx = torch.empty(net.ctx_bytes(chunk), dtype=torch.uint8, device=self.device)
+            if self.step >= cfg.density_warmup_steps:
+                # scattered refresh: a uniform pass (every trained cell qualifies) and a pass over occupied cells
+                fresh = torch.zeros(cfg.n_levels * CELLS, device=self.device)
+                cells = torch.empty(chunk, dtype=torch.int32, device=self.device)
+                n_pass = CELLS // 4 * cfg.n_levels
+                for pass_id, thresh in ((0, -0.01), (1, cfg.occupancy_threshold)):
+                    for c0 in range(0, n_pass, chunk):
+                        m = min(chunk, n_pass - c0)
+                        _call("nvo_occ_sample_cells", stream, m, c0, n_pass, self.step, cfg.seed & 0xFFFFFFFF, pass_id,
+                              cfg.n_levels, _ptr(self.density_grid), thresh, lo, hi, _ptr(x01), _ptr(cells))
+                        # (the network runs on whole chunks: rows past m hold an earlier chunk's points and are not splatted)
+                        _call("nvo_fwd", net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
+                              _ptr(out), _ptr(ctx))
+                        _call("nvo_ngp_thickness_splat", stream, m, _ptr(out), 1, _ptr(cells), _ptr(fresh))
+            else:
+                fresh = torch.empty(cfg.n_levels * CELLS, device=self.device)
+                pos = torch.empty(CELLS, 3, device=self.device)
+                for level in range(cfg.n_levels):
+                    jit = torch.rand(CELLS, 3, device=self.device) if jitter else None
+                    _call("nvo_occ_cell_positions", stream, level, _ptr(jit), _ptr(pos))
+                    for c0 in range(0, CELLS, chunk):
+                        x01.copy_(((pos[c0:c0 + chunk] - lo) / (hi - lo)).clamp_(0.0, 1.0))
+                        _call("nvo_fwd", net.handle, stream, chunk, _ptr(x01), self._pp("density", self.params_half),
+                              _ptr(out), _ptr(ctx))
+                        _call("nvo_ngp_thickness", stream, chunk, _ptr(out), 1, level,
+                              C.c_void_p(fresh.data_ptr() + 4 * (level * CELLS + c0)))
+        finally:
+            net.set_option("compact_output", 0)
+            if self._pig:
+                net.set_option("prepare_input_gradients", 1)
         if all_reduce is not None:
             all_reduce.reduce_max(fresh)
         _call("nvo_occ_update", stream, cfg.n_levels, _ptr(self.density_grid), _ptr(fresh), cfg.density_decay,
