@@ -725,7 +725,8 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     assert abs(np.log(a[3]["rgb_loss"] / c[3]["rgb_loss"])) < 0.3, (a[3], c[3])
     # one step from the same initial state: same gradient up to summation order
     g_det, g_def = run(True, 1)[4], run(False, 1)[4]
-    _assert_close(g_det, g_def, rtol=2e-6, atol_scale=2e-8, what="deterministic vs default gradient", max_outlier_frac=1e-4)
+    # (two summation orders of the same float terms: the difference moves by an order of magnitude from run to run)
+    _assert_close(g_det, g_def, rtol=1e-5, atol_scale=1e-7, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
 @pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
