@@ -232,35 +232,11 @@ k_occ_march_wave(uint32_t R, const float* __restrict__ origins, const float* __r
         // (16384 blocks = 2^20 candidates: an exit every wave reaches even for a degenerate ray whose skip target is
         // not finite -- a regular ray leaves a cascade-2 box after ~1000 candidates)
         for (uint32_t block = 0; !done && block < 16384u; ++block) {
-            // lane k keeps the k-th value of the progression.  In general every lane evaluates the same 64-step recurrence
-            // (64 x 5 dependent vector instructions per block: three quarters of the kernel's instruction count).  While the
-            // step is the constant minimum (t x cone_angle <= sqrt(3)/1024, i.e. t < 0.433 at cone_angle 1/256, any t at 0)
-            // AND the block stays inside one binade, the recurrence has a closed form that is exact: t_k lies on the
-            // binade's grid of spacing u = ulp(t), so fl(t_k + m) = t_k + delta with delta = rne(m / u) u whatever t_k is
-            // (no k-dependence unless m / u ends in exactly .5: for m = 0x3ADDB3D7 the bits below the grid are 010111,
-            // 1010111, 11010111 in the binades [2^-4, 2^-1) -- never a tie), every add is exact, and t_k = t_0 + k delta
-            // with k delta < 2^24 u.  Taken only for t in [2^-4, 2^-1) (near plane 0.1 and up); outside it, at a binade
-            // crossing and once the step grows with t, the sequential form runs.  Bit-identical either way
-            // (tests/test_occgrid_gpu.py: every sample's t against the C oracle).
-            // (in segments of 16 candidates: 64 steps of the minimum span 0.108, wider than the binade [2^-4, 2^-3))
+            // lane k keeps the k-th value of the progression; every lane evaluates the same recurrence
             float my_t = t;
-#pragma unroll
-            for (uint32_t seg = 0; seg < 4u; ++seg) {
-                const uint32_t tb = __float_as_uint(t);
-                const float delta = (t + min_step()) - t;
-                const float c16 = t + 16.0f * delta;
-                const float c15 = t + 15.0f * delta;
-                const bool closed = tb >= 0x3D800000u && tb < 0x3F000000u && (__float_as_uint(c16) >> 23) == (tb >> 23) &&
-                                    c15 * cone_angle <= min_step();
-                if (closed) {
-                    if ((lane >> 4) == seg) my_t = t + (float)(lane & 15u) * delta;
-                    t = c16;
-                } else {
-                    for (uint32_t k = 0; k < 16u; ++k) {
-                        if (lane == seg * 16u + k) my_t = t;
-                        t += calc_dt(t, cone_angle);
-                    }
-                }
+            for (uint32_t k = 0; k < 64u; ++k) {
+                if (lane == k) my_t = t;
+                t += calc_dt(t, cone_angle);
             }
             float p[3];
             bool inside = true;
