@@ -310,7 +310,7 @@ def test_march_in_rounds_concatenates_to_the_single_march(device, first):
 
 
 @pytest.mark.parametrize("R,R_used,cap", [(65536, 65536, 1 << 22), (65536, 13312, 1 << 18), (16384, 12345, 1 << 18), (4096, 100, 1 << 15),
-                                          (64, 64, 1 << 10), (1, 1, 64)])
+                                          (64, 64, 1 << 10), (1, 1, 64), (256, 0, 1 << 10)])
 def test_pack_in_one_launch_matches_the_three_launch_pack(device, R, R_used, cap):
     """nvo_occ_pack_fused (scan by decoupled look-back between 16-ray workgroups + copy + network input of every copied
     sample) against nvo_occ_pack + nvo_ngp_positions: counts, offsets, totals, ray_idx, t, dt and x01 bit for bit, with
