@@ -294,8 +294,9 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 // k_grid_fwd on a proposal grid runs at the L1's tag-lookup rate, not at any bandwidth: 27 M line accesses per 1 M-sample
 // launch, 90 % of them hits (profiles/r2_pmc_grid_fwd.txt) -- a random gather costs the vector L1 one tag look-up per
-// DISTINCT LINE of the instruction whatever it hits (lanes in one line are one look-up: EXPERIMENTS.md 9.6b).  The two coarsest levels (16 KiB + 79 / 128 KiB) fit a CU's 160 KiB of LDS, whose banked
-// gather costs ~8 cycles per wave instruction instead of 64.  One 1024-thread workgroup per CU stages them once and
+// DISTINCT LINE of the instruction whatever it hits (lanes in one line are one look-up: EXPERIMENTS.md 9.6b).  The
+// two coarsest levels (16 KiB + 79 / 128 KiB) fit a CU's 160 KiB of LDS, whose banked gather costs ~8 cycles per wave
+// instruction instead of 64.  One 1024-thread workgroup per CU stages them once and
 // walks its share of the samples with a thread per SAMPLE (all levels: the position is loaded once instead of once per
 // level, and a lane keeps 16-20 global gathers of the remaining levels in flight); on the hashed levels the two x
 // corners of a (y, z) pair are ONE aligned 8-byte load whenever the cell's x index is even (then idx1 == idx0 ^ 1).
