@@ -824,6 +824,39 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
                                 float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
                                 float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
                                 const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev);
+/* nvo_adam_step_groups_scaled with a TAIL in the same launch (the occupancy-grid trainer's step: four launches less):
+ *  - the weight average of exactly the elements the launch steps (nvo_ema_update_dev's arithmetic on the value just
+ *    written; a skipped group is not averaged), and
+ *  - by the LAST workgroup of the grid, once every other workgroup has checked in (each has then read the scalars a
+ *    commit changes), the step's commit: nvo_opt_commit (applied / scale / bias) and the average's counter (ema_commit
+ *    != 0: *ema_step_dev += 1 iff skip_flags[ema_flag_slot] == 0, what nvo_ema_update_dev does behind its launch).
+ * done_counter: a device word, zero before the first launch; the launch leaves it zero (graph replay safe).  Each part is
+ * optional (NULL pointers = not requested); tail == NULL is nvo_adam_step_groups_scaled.  Measured (EXPERIMENTS.md
+ * 9.11): -6 us on the occupancy-grid step; the nerfacto step, whose average-free tail is one commit launch, gains
+ * nothing from it and keeps nvo_opt_commit_table. */
+typedef struct nvo_adam_tail {
+    float* ema;                 /* fp32 average, same origin as params (NULL: no averaging) */
+    void* ema_half;             /* fp16 copy of the average (nullable) */
+    float ema_decay;
+    uint32_t* ema_step_dev;     /* device: averages applied so far */
+    uint32_t ema_flag_slot;     /* word of skip_flags that gates the counter */
+    uint32_t ema_commit;        /* != 0: advance *ema_step_dev behind the launch */
+    uint32_t* done_counter;
+    uint32_t n_commit_groups, active_mask, scale_mask;   /* as nvo_opt_commit */
+    uint32_t* applied;
+    float* scale;
+    uint32_t* growth_tracker;
+    float growth_factor, backoff_factor;
+    uint32_t growth_interval;
+    float min_scale, max_scale;
+    float* bias;
+} nvo_adam_tail;
+int nvo_adam_step_groups_tail(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                              void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                              float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                              float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                              const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev,
+                              const nvo_adam_tail* tail);
 /* What GradScaler.step / GradScaler.update leave behind, on the device (one tiny launch behind the optimiser launches
  * of a step, capturable): for every group i in active_mask (bit i), applied[i] += 1 iff skip_flags[i] == 0; and, when
  * scale != NULL, the loss scale backs off (x backoff_factor, not below min_scale) if ANY group of scale_mask was

@@ -88,6 +88,16 @@ class AdamGroup(C.Structure):
                 ("flag_slot_set", C.c_uint32), ("weight_decay", C.c_float), ("weight_decay_set", C.c_uint32)]
 
 
+class AdamTail(C.Structure):
+    """nvo_adam_tail (include/nerfvo_hip.h)"""
+    _fields_ = [("ema", C.c_void_p), ("ema_half", C.c_void_p), ("ema_decay", C.c_float), ("ema_step_dev", C.c_void_p),
+                ("ema_flag_slot", C.c_uint32), ("ema_commit", C.c_uint32), ("done_counter", C.c_void_p),
+                ("n_commit_groups", C.c_uint32), ("active_mask", C.c_uint32), ("scale_mask", C.c_uint32),
+                ("applied", C.c_void_p), ("scale", C.c_void_p), ("growth_tracker", C.c_void_p),
+                ("growth_factor", C.c_float), ("backoff_factor", C.c_float), ("growth_interval", C.c_uint32),
+                ("min_scale", C.c_float), ("max_scale", C.c_float), ("bias", C.c_void_p)]
+
+
 class DepthAlignArgs(C.Structure):
     """mirror of nvo_depth_align_args"""
     _fields_ = [("K", _u32), ("M", _u32), ("P", _u32), ("H", _u32), ("W", _u32), ("patches", _p), ("noise", _p),
@@ -218,6 +228,7 @@ _SIGNATURES = {
     "nvo_cast_working_copy": (_int, [_p, _u64, _p, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_mixed": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p]),
     "nvo_adam_step_groups_scaled": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p]),
+    "nvo_adam_step_groups_tail": (_int, [_p, _u32, _p, _p, _p, _p, _int, _p, _p, _f, _f, _f, _f, _f, _p, _u32, _p, _p, _p, _p]),
     "nvo_opt_commit_write": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f, _p, _u32, _p]),
     "nvo_opt_commit_table": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f, _p, _p, _u32, _p]),
     "nvo_opt_commit": (_int, [_p, _u32, _u32, _u32, _p, _p, _p, _p, _f, _f, _u32, _f, _f, _p, _f, _f]),

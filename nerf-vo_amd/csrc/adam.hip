@@ -52,11 +52,18 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, 
 // The body works on 4 consecutive parameters per thread through 16-byte accesses when the range is
 // 16-byte aligned (HBM-bound kernel: 28 B + 2 B per parameter), scalar otherwise / for the tail.
 // base: index of p[0] in the flat buffer (what Copy16Fmt's ranges refer to)
+// Optional weight average of the stepped elements (tcnn EmaOptimizer; k_ema_update_dev's arithmetic on the value just
+// written, term for term): ema / ema16 start at the range like p does; the 16-byte form needs them aligned like p / p16.
+struct AdamEma {
+    float* ema;
+    nvo_h16* ema16;
+    float keep, take, inv_debias;
+};
 template <typename GT>
 __device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, nvo_h16* __restrict__ p16,
                                            const GT* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                            const AdamHyper& h, int vec4, uint32_t block_id, uint32_t n_blocks,
-                                           const Copy16Fmt& fmt, uint64_t base) {
+                                           const Copy16Fmt& fmt, uint64_t base, const AdamEma& ea = AdamEma{}) {
     const uint64_t stride = (uint64_t)n_blocks * blockDim.x;
     const uint64_t tid = (uint64_t)block_id * blockDim.x + threadIdx.x;
     uint64_t done = 0;
@@ -78,6 +85,17 @@ __device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, nv
                 const bool bf = fmt.is_bf16(base + i);
                 *reinterpret_cast<uint2*>(p16 + i) = make_uint2(nvo_cvt16x2(pv.x, pv.y, bf), nvo_cvt16x2(pv.z, pv.w, bf));
             }
+            if (ea.ema) {
+                float4 ev = reinterpret_cast<float4*>(ea.ema)[q];
+                ev.x = (ev.x * ea.keep + pv.x * ea.take) * ea.inv_debias;
+                ev.y = (ev.y * ea.keep + pv.y * ea.take) * ea.inv_debias;
+                ev.z = (ev.z * ea.keep + pv.z * ea.take) * ea.inv_debias;
+                ev.w = (ev.w * ea.keep + pv.w * ea.take) * ea.inv_debias;
+                reinterpret_cast<float4*>(ea.ema)[q] = ev;
+                if (ea.ema16)
+                    *reinterpret_cast<uint2*>(ea.ema16 + i) =
+                        make_uint2(nvo_cvt16x2(ev.x, ev.y, false), nvo_cvt16x2(ev.z, ev.w, false));
+            }
         }
         done = n4 << 2;
     }
@@ -88,6 +106,11 @@ __device__ __forceinline__ void adam_range(uint64_t n, float* __restrict__ p, nv
         m[i] = mi;
         v[i] = vi;
         if (p16) p16[i] = nvo_cvt16(pi, fmt.is_bf16(base + i));
+        if (ea.ema) {
+            const float e = (ea.ema[i] * ea.keep + pi * ea.take) * ea.inv_debias;
+            ea.ema[i] = e;
+            if (ea.ema16) ea.ema16[i] = nvo_cvt16(e, false);
+        }
     }
 }
 
@@ -121,35 +144,98 @@ struct AdamGroups {
     float wd[kAdamMaxGroups];       // L2 weight decay of the group
 };
 
+// What may ride behind the groups' step in the SAME launch (nvo_adam_tail): the weight average of the stepped elements
+// and, by the last workgroup of the grid once the others have checked in, the commit of the step (nvo_opt_commit /
+// k_ema_commit) -- every workgroup has read the scalars the commit changes before it checks in.
+struct AdamTail {
+    float* ema;
+    nvo_h16* ema16;
+    float decay;
+    uint32_t* ema_step;
+    uint32_t ema_slot, ema_commit;
+    uint32_t* done;  // nullable: no commit
+    uint32_t n_groups, active_mask, scale_mask;
+    uint32_t* applied;
+    float* scale;
+    uint32_t* growth_tracker;
+    float growth, backoff;
+    uint32_t interval;
+    float min_scale, max_scale;
+    float* bias;
+};
+
+__device__ void opt_commit_thread(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+                                  const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
+                                  uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
+                                  float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2);
+
 template <typename GT>
 __global__ void __launch_bounds__(256)
 k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, const GT* __restrict__ g,
               float* __restrict__ m, float* __restrict__ v, AdamHyper h, const uint32_t* __restrict__ skip_flags,
-              Copy16Fmt fmt, const float* __restrict__ loss_scale_dev) {
+              Copy16Fmt fmt, const float* __restrict__ loss_scale_dev, AdamTail t) {
     uint32_t k = 0;
     while (k + 1 < gr.n_groups && blockIdx.x >= gr.first_block[k + 1]) ++k;
+    __shared__ float fac[2];
+    if (t.ema) {  // (uniform) the factors of k_ema_update_dev, from the counter as it stands
+        if (threadIdx.x == 0) {
+            const double d = (double)t.decay, st = (double)(*t.ema_step) + 1.0;
+            fac[0] = (float)(d * (1.0 - pow(d, st - 1.0)));
+            fac[1] = (float)(1.0 / (1.0 - pow(d, st)));
+        }
+        __syncthreads();
+    }
     // GradScaler.step decides per optimiser: a group is skipped iff ITS gradients held a non-finite value
-    if (skip_flags && skip_flags[gr.slot[k]]) return;
-    h.lr = gr.lr[k];
-    h.bias1 = gr.bias1[k];
-    h.bias2_sqrt = gr.bias2_sqrt[k];
-    h.weight_decay = gr.wd[k];
-    if (gr.hyper_dev[k]) {
-        h.lr = gr.hyper_dev[k][0];
-        h.bias1 = gr.hyper_dev[k][1];
-        h.bias2_sqrt = gr.hyper_dev[k][2];
+    if (!(skip_flags && skip_flags[gr.slot[k]])) {
+        h.lr = gr.lr[k];
+        h.bias1 = gr.bias1[k];
+        h.bias2_sqrt = gr.bias2_sqrt[k];
+        h.weight_decay = gr.wd[k];
+        if (gr.hyper_dev[k]) {
+            h.lr = gr.hyper_dev[k][0];
+            h.bias1 = gr.hyper_dev[k][1];
+            h.bias2_sqrt = gr.hyper_dev[k][2];
+        }
+        if (gr.bias_dev[k]) {
+            // torch.optim.Adam under GradScaler.step: state['step'] counts the APPLIED steps only -- the counter and the
+            // bias corrections of the NEXT applied step live on the device; the commit advances them behind this launch
+            // (or as its last act: AdamTail) iff the group was not skipped
+            h.bias1 = gr.bias_dev[k][0];
+            h.bias2_sqrt = gr.bias_dev[k][1];
+        }
+        if (loss_scale_dev) h.grad_scale = 1.0f / *loss_scale_dev;  // dynamic loss scale (GradScaler state on the device)
+        const uint64_t o = gr.offset[k];
+        AdamEma ea{};
+        if (t.ema) ea = AdamEma{t.ema + o, t.ema16 ? t.ema16 + o : nullptr, fac[0], 1.0f - t.decay, fac[1]};
+        adam_range<GT>(gr.n[k], p + o, p16 ? p16 + o : nullptr, g + o, m + o, v + o, h, gr.vec4[k],
+                       blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k], fmt, o, ea);
     }
-    if (gr.bias_dev[k]) {
-        // torch.optim.Adam under GradScaler.step: state['step'] counts the APPLIED steps only -- the counter and the
-        // bias corrections of the NEXT applied step live on the device; nvo_opt_commit advances them behind this launch
-        // iff the group was not skipped
-        h.bias1 = gr.bias_dev[k][0];
-        h.bias2_sqrt = gr.bias_dev[k][1];
+    if (!t.done) return;  // (uniform)
+    // Check-in without a round trip: every workgroup adds one to the counter (fire and forget -- a RETURNING atomic per
+    // workgroup on one address cost 75 ns each, +90 us on a 1200-workgroup launch), the LAST workgroup of the grid waits
+    // for the others and commits.  Workgroups are dispatched in index order, so everything it waits for is resident or
+    // done: no deadlock.  What the ordering has to guarantee is only that every READ of the scalars the commit changes
+    // (bias corrections, loss scale, learning rates, average counter) precedes it: those loads were consumed before the
+    // workgroup's first store, long before its check-in -- so relaxed atomics at agent scope do (they act at the coherent
+    // level; a release / __threadfence() per workgroup is an L2 write-back on this multi-XCD part, and nothing here needs
+    // another workgroup's WRITES).
+    __syncthreads();
+    if (blockIdx.x != gridDim.x - 1u) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(t.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
-    if (loss_scale_dev) h.grad_scale = 1.0f / *loss_scale_dev;  // dynamic loss scale (GradScaler state on the device)
-    const uint64_t o = gr.offset[k];
-    adam_range<GT>(gr.n[k], p + o, p16 ? p16 + o : nullptr, g + o, m + o, v + o, h, gr.vec4[k],
-                   blockIdx.x - gr.first_block[k], gr.first_block[k + 1] - gr.first_block[k], fmt, o);
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(t.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1u)
+            __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (t.applied || t.scale)
+            opt_commit_thread(t.n_groups, t.active_mask, t.scale_mask, t.applied, skip_flags, t.scale, t.growth_tracker, t.growth,
+                              t.backoff, t.interval, t.min_scale, t.max_scale, t.bias, h.beta1, h.beta2);
+        if (t.ema_commit && !(skip_flags && skip_flags[t.ema_slot] != 0u)) *t.ema_step += 1u;  // (k_ema_commit)
+        *t.done = 0u;  // (the next launch / replay counts from zero again)
+    }
 }
 
 // A pure streaming read: 16-byte loads, four of them in flight per thread (the scalar grid-stride form ran at
@@ -389,7 +475,7 @@ k_zero_u32(uint32_t* __restrict__ p, uint64_t n) {
 // GradScaler.update() + the optimisers' step counters, on the device (one thread): group i of `active_mask` advances its
 // applied-step counter iff its skip flag is clear; the loss scale backs off when ANY active group saw a non-finite
 // gradient and grows after `interval` clean steps (torch.cuda.amp.GradScaler: init 65536, x2 / 2000 steps, x0.5).
-__device__ __forceinline__ void opt_commit_thread(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
+__device__ void opt_commit_thread(uint32_t n_groups, uint32_t active_mask, uint32_t scale_mask, uint32_t* __restrict__ applied,
                              const uint32_t* __restrict__ skip_flags, float* __restrict__ scale,
                              uint32_t* __restrict__ growth_tracker, float growth, float backoff, uint32_t interval,
                              float min_scale, float max_scale, float* __restrict__ bias, float beta1, float beta2) {
@@ -653,7 +739,51 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
                                 float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
                                 float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
                                 const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev) {
+    return nvo_adam_step_groups_tail(stream, n_groups, groups, params, params_half, grads, grads_are_half, exp_avg, exp_avg_sq,
+                                     beta1, beta2, eps, grad_scale, weight_decay, skip_flags, n_bf16_ranges, bf16_lo, bf16_hi,
+                                     loss_scale_dev, nullptr);
+}
+
+int nvo_adam_step_groups_tail(nvo_stream_t stream, uint32_t n_groups, const nvo_adam_group* groups, float* params,
+                              void* params_half, const void* grads, int grads_are_half, float* exp_avg,
+                              float* exp_avg_sq, float beta1, float beta2, float eps, float grad_scale,
+                              float weight_decay, const uint32_t* skip_flags, uint32_t n_bf16_ranges,
+                              const uint64_t* bf16_lo, const uint64_t* bf16_hi, const float* loss_scale_dev,
+                              const nvo_adam_tail* tail) {
     NVO_REQUIRE(params && grads && exp_avg && exp_avg_sq && groups, "adam_step_groups: NULL argument");
+    AdamTail t{};
+    if (tail) {
+        NVO_REQUIRE(!tail->ema || (tail->ema_step_dev && tail->ema_decay >= 0.f && tail->ema_decay < 1.f &&
+                                   tail->ema_flag_slot < kAdamMaxGroups),
+                    "adam_step_groups_tail: weight average needs its step counter, 0 <= decay < 1");
+        const bool commit = tail->applied || tail->scale || (tail->ema && tail->ema_commit);
+        NVO_REQUIRE(!commit || tail->done_counter, "adam_step_groups_tail: the commit needs done_counter (a zeroed device word)");
+        NVO_REQUIRE(!(tail->applied || tail->scale) || (tail->n_commit_groups >= 1 && tail->n_commit_groups <= kAdamMaxGroups),
+                    "adam_step_groups_tail: 1..%u commit groups (got %u)", kAdamMaxGroups, tail->n_commit_groups);
+        NVO_REQUIRE(!tail->scale || (tail->growth_tracker && tail->growth_interval >= 1 && tail->growth_factor >= 1.f &&
+                                     tail->backoff_factor > 0.f && tail->backoff_factor <= 1.f && tail->min_scale > 0.f &&
+                                     tail->max_scale >= tail->min_scale),
+                    "adam_step_groups_tail: bad loss-scale schedule");
+        t.ema = tail->ema;
+        t.ema16 = (nvo_h16*)tail->ema_half;
+        t.decay = tail->ema_decay;
+        t.ema_step = tail->ema ? tail->ema_step_dev : nullptr;
+        t.ema_slot = tail->ema_flag_slot;
+        t.ema_commit = (tail->ema && tail->ema_commit) ? 1u : 0u;
+        t.done = commit ? tail->done_counter : nullptr;
+        t.n_groups = tail->n_commit_groups;
+        t.active_mask = tail->active_mask;
+        t.scale_mask = tail->scale_mask;
+        t.applied = tail->applied;
+        t.scale = tail->scale;
+        t.growth_tracker = tail->growth_tracker;
+        t.growth = tail->growth_factor;
+        t.backoff = tail->backoff_factor;
+        t.interval = tail->growth_interval;
+        t.min_scale = tail->min_scale;
+        t.max_scale = tail->max_scale;
+        t.bias = tail->bias;
+    }
     Copy16Fmt fmt;
     if (int rc = make_copy_fmt(n_bf16_ranges, bf16_lo, bf16_hi, &fmt)) return rc;
     NVO_REQUIRE(n_groups >= 1 && n_groups <= kAdamMaxGroups, "adam_step_groups: 1..%u groups (got %u)", kAdamMaxGroups,
@@ -686,19 +816,27 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
         blocks_total += blocks;
         ++k;
     }
+    NVO_REQUIRE(k > 0 || !(t.done || t.ema), "adam_step_groups_tail: a tail needs at least one non-empty group");
     if (k == 0) return NVO_OK;
     gr.n_groups = k;
     for (uint32_t i = k; i <= kAdamMaxGroups; ++i) gr.first_block[i] = blocks_total;
+    if (t.ema) {
+        // (the 16-byte form of a group reads the average like the parameters: same alignment or the scalar form)
+        for (uint32_t i = 0; i < k; ++i) {
+            const uintptr_t al = (uintptr_t)(t.ema + gr.offset[i]);
+            if ((al & 15u) != 0 || (t.ema16 && (((uintptr_t)t.ema16 + 2 * gr.offset[i]) & 7u) != 0)) gr.vec4[i] = 0;
+        }
+    }
     AdamHyper h{0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, weight_decay};
     if (grads_are_half == 2) {
         NVO_LAUNCH(k_adam_groups<Bf16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
+                   (nvo_h16*)params_half, (const Bf16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev, t);
     } else if (grads_are_half) {
         NVO_LAUNCH(k_adam_groups<_Float16>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
+                   (nvo_h16*)params_half, (const _Float16*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev, t);
     } else {
         NVO_LAUNCH(k_adam_groups<float>, dim3(blocks_total), dim3(256), 0, (hipStream_t)stream, gr, params,
-                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev);
+                   (nvo_h16*)params_half, (const float*)grads, exp_avg, exp_avg_sq, h, skip_flags, fmt, loss_scale_dev, t);
     }
     NVO_CHECK_LAUNCH();
     return NVO_OK;

@@ -103,7 +103,17 @@ namespace {
 __device__ __forceinline__ float ngp_optical_step(float sigma, float dt) { return fminf(sigma * dt, 128.f); }
 
 __global__ void __launch_bounds__(256)
-k_ngp_composite_loss(nvo_ngp_loss_args a) {
+k_ngp_composite_loss(nvo_ngp_loss_args a, uint32_t ray_blocks) {
+    if (blockIdx.x >= ray_blocks) {
+        // (uniform) workgroups behind the rays' zero the gradient rows of packed slots that belong to no ray (beyond the last
+        // offset / dropped rays) -- rows no ray writes: a launch of its own before
+        const uint32_t i = (blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x;
+        if (i >= a.capacity || a.ray_idx[i] >= 0) return;
+        _Float16* __restrict__ d_rgb = (_Float16*)a.d_rgb_out;
+        for (uint32_t k = 0; k < a.d_rgb_stride; ++k) d_rgb[(size_t)i * a.d_rgb_stride + k] = (_Float16)0.f;
+        a.d_density_pre[i] = 0.f;
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= a.R) return;
@@ -417,16 +427,6 @@ k_ngp_count_alive(nvo_ngp_alive_args a) {
     }
 }
 
-// zero the gradient rows of packed slots that belong to no ray (beyond the last offset / dropped rays)
-__global__ void __launch_bounds__(256)
-k_ngp_clear_invalid(uint32_t capacity, const int32_t* __restrict__ ray_idx, _Float16* __restrict__ d_rgb,
-                    uint32_t d_rgb_stride, float* __restrict__ d_density_pre) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity || ray_idx[i] >= 0) return;
-    for (uint32_t k = 0; k < d_rgb_stride; ++k) d_rgb[(size_t)i * d_rgb_stride + k] = (_Float16)0.f;
-    d_density_pre[i] = 0.f;
-}
-
 // optical thickness of a density-grid cell sample: exp(pre) * sqrt(3)/1024 * 2^level
 __global__ void __launch_bounds__(256)
 k_ngp_thickness(uint32_t n, const _Float16* __restrict__ density_out, uint32_t stride, int level,
@@ -521,12 +521,9 @@ int nvo_ngp_composite_loss(nvo_stream_t stream, const nvo_ngp_loss_args* args) {
     if (a.R == 0) return NVO_OK;
     hipStream_t s = (hipStream_t)stream;
     NVO_PROF(stream, "ngp_composite_loss");
-    if (a.d_rgb_out) {
-        NVO_LAUNCH(k_ngp_clear_invalid, dim3(nvo_div_up(a.capacity, 256)), dim3(256), 0, s, a.capacity, a.ray_idx,
-                   (_Float16*)a.d_rgb_out, a.d_rgb_stride, a.d_density_pre);
-        NVO_CHECK_LAUNCH();
-    }
-    NVO_LAUNCH(k_ngp_composite_loss, dim3(nvo_div_up(a.R, 4)), dim3(256), 0, s, a);
+    const uint32_t ray_blocks = nvo_div_up(a.R, 4);
+    const uint32_t clear_blocks = a.d_rgb_out ? nvo_div_up(a.capacity, 256) : 0u;
+    NVO_LAUNCH(k_ngp_composite_loss, dim3(ray_blocks + clear_blocks), dim3(256), 0, s, a, ray_blocks);
     NVO_CHECK_LAUNCH();
     return NVO_OK;
 }

@@ -117,6 +117,9 @@ class NgpConfig:
     # single GPU: the grid backward takes the Adam step + weight average of its streamed hashed levels itself
     # (nvo_set_fused_adam; bit-identical to the separate launches)
     fuse_grid_adam: bool = True
+    # the weight average and the step's commit ride in the Adam launch (nvo_adam_step_groups_tail; bit-identical to the
+    # four launches it replaces: two nvo_ema_update_dev, k_ema_commit, nvo_opt_commit)
+    fuse_optimizer_tail: bool = True
     # copies of the two MLPs' weight-gradient buffers the backward's workgroups spread their adds over (0 = off;
     # nvo_fold_replicas sums them once per step)
     dw_replicas: int = 7
@@ -231,6 +234,7 @@ class NgpEngine:
         self._cam_synced = None    # (cam_step, lr) the device scalars were written for
         self._cam_window = 0       # training steps accumulated into d_corrections since the last camera update
         self._applied_dev = z(1, torch.int32)
+        self._tail_done = z(1, torch.int32)  # check-in counter of nvo_adam_step_groups_tail (the launch leaves it zero)
         self._dev_synced = None   # the host opt_step the two buffers above were written for
         self._graphs = {}         # captured steps by (ray count, inputs' addresses, ...)
         self._kernels_loaded = False
@@ -857,9 +861,6 @@ class NgpEngine:
                  for off, size, wd in ((0, self.n_density_mlp, cfg.l2_reg), (self.n_density_mlp, n_grid, 0.0),
                                        (self.density_net.n_params, self.n_rgb, cfg.l2_reg)) if size > 0]
         arr = (_lib.AdamGroup * len(batch))(*batch)
-        _call("nvo_adam_step_groups", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(self.grads), 0,
-              _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
-              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
         if cfg.ema_decay > 0.0:
             if self.params_ema is None:
                 self.params_ema = torch.zeros_like(self.params)
@@ -867,6 +868,27 @@ class NgpEngine:
             # (Should the very first step be skipped, inference would read an all-zero average for one step: instant-ngp
             # has the same window; the debias factor itself is exact -- it follows the device counter.)
             self._ema_started = True
+        if cfg.fuse_optimizer_tail:
+            # ONE launch: Adam of the three ranges, the weight average of the same elements and -- by its last workgroup --
+            # both counters with the next step's bias corrections (nvo_adam_step_groups_tail)
+            ema = cfg.ema_decay > 0.0
+            tail = _lib.AdamTail(ema=self.params_ema.data_ptr() if ema else None,
+                                 ema_half=self.params_ema_half.data_ptr() if ema else None, ema_decay=cfg.ema_decay,
+                                 ema_step_dev=self._ema_step_dev.data_ptr() if ema else None, ema_flag_slot=0, ema_commit=1,
+                                 done_counter=self._tail_done.data_ptr(), n_commit_groups=1, active_mask=1, scale_mask=0,
+                                 applied=self._applied_dev.data_ptr(), scale=None, growth_tracker=None, growth_factor=2.0,
+                                 backoff_factor=0.5, growth_interval=2000, min_scale=0.0, max_scale=0.0, bias=bias_dev)
+            _call("nvo_adam_step_groups_tail", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half),
+                  _ptr(self.grads), 0, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1],
+                  cfg.adam_eps, 1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), 0, None, None, None, C.byref(tail))
+            if camera_update and cfg.optimize_extrinsics and self._pose_inputs is not None:
+                self._sync_cam_dev()
+                self._camera_optimizer_step(stream, all_reduce)
+            return
+        _call("nvo_adam_step_groups", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(self.grads), 0,
+              _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag))
+        if cfg.ema_decay > 0.0:
             lo, hi = (0, self.n_params)
             if fused_adam is not None:
                 # the backward averaged [fused_adam) already (with the counter as it stands): the head here without

@@ -314,6 +314,76 @@ def test_weight_ema_matches_tcnn_formula(device):
     assert torch.equal(before, ema)
 
 
+def test_adam_tail_in_one_launch_is_bit_identical(device):
+    """nvo_adam_step_groups_tail (Adam + weight average + both commits in ONE launch, the commit by the last workgroup to
+    finish) against the launches it replaces -- nvo_adam_step_groups, nvo_ema_update_dev_part, nvo_ema_update_dev (with
+    its k_ema_commit) and nvo_opt_commit -- from identical states over several steps, one of them skipped: master weights,
+    moments, 16-bit copy, average and its 16-bit copy, both counters, the bias corrections and the check-in counter (back
+    at zero after every launch).  Three groups at offsets that make one of them take the scalar form, own weight decay."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    n = 300_007
+    groups = ((0, 4096, 1e-6), (4096, 250_001, 0.0), (4096 + 250_001, n - 4096 - 250_001, 1e-6))
+    g = torch.Generator().manual_seed(21)
+    b1, b2, eps, decay, lr = 0.9, 0.99, 1e-15, 0.95, 1e-2
+
+    def state():
+        return {"p": torch.randn(n, generator=torch.Generator().manual_seed(5)).to(device),
+                "p16": torch.zeros(n, dtype=torch.float16, device=device), "m": torch.zeros(n, device=device),
+                "v": torch.zeros(n, device=device), "ema": torch.zeros(n, device=device),
+                "ema16": torch.zeros(n, dtype=torch.float16, device=device),
+                "ema_step": torch.zeros(1, dtype=torch.int32, device=device),
+                "applied": torch.zeros(1, dtype=torch.int32, device=device),
+                "bias": torch.tensor([1.0 - b1, (1.0 - b2) ** 0.5], device=device),
+                "done": torch.zeros(1, dtype=torch.int32, device=device)}
+
+    a, b = state(), state()
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    stream = _stream(device)
+
+    def batch(st):
+        arr = [_lib.AdamGroup(offset=o, n=m, lr=lr, step=0, hyper_dev=None, bias_dev=st["bias"].data_ptr(), flag_slot=0,
+                              flag_slot_set=1, weight_decay=wd, weight_decay_set=1) for o, m, wd in groups]
+        return (_lib.AdamGroup * len(arr))(*arr)
+
+    for it in range(5):
+        grads = (torch.randn(n, generator=g) * 128.0).to(device)
+        flag.fill_(1 if it == 3 else 0)
+        # --- separate launches
+        _call("nvo_adam_step_groups", stream, 3, batch(a), _ptr(a["p"]), _ptr(a["p16"]), _ptr(grads), 0, _ptr(a["m"]), _ptr(a["v"]),
+              b1, b2, eps, 1.0 / 128.0, 0.0, _ptr(flag))
+        head = groups[1][0] + groups[1][1]
+        _call("nvo_ema_update_dev_part", stream, head, _ptr(a["p"]), _ptr(a["ema"]), _ptr(a["ema16"]), decay, _ptr(a["ema_step"]),
+              _ptr(flag))
+        _call("nvo_ema_update_dev", stream, n - head, C.c_void_p(a["p"].data_ptr() + 4 * head),
+              C.c_void_p(a["ema"].data_ptr() + 4 * head), C.c_void_p(a["ema16"].data_ptr() + 2 * head), decay,
+              _ptr(a["ema_step"]), _ptr(flag))
+        _call("nvo_opt_commit", stream, 1, 1, 0, _ptr(a["applied"]), _ptr(flag), None, None, 2.0, 0.5, 2000, 0.0, 0.0,
+              _ptr(a["bias"]), b1, b2)
+        # --- one launch
+        tail = _lib.AdamTail(ema=b["ema"].data_ptr(), ema_half=b["ema16"].data_ptr(), ema_decay=decay,
+                             ema_step_dev=b["ema_step"].data_ptr(), ema_flag_slot=0, ema_commit=1,
+                             done_counter=b["done"].data_ptr(), n_commit_groups=1, active_mask=1, scale_mask=0,
+                             applied=b["applied"].data_ptr(), scale=None, growth_tracker=None, growth_factor=2.0,
+                             backoff_factor=0.5, growth_interval=2000, min_scale=0.0, max_scale=0.0,
+                             bias=b["bias"].data_ptr())
+        _call("nvo_adam_step_groups_tail", stream, 3, batch(b), _ptr(b["p"]), _ptr(b["p16"]), _ptr(grads), 0, _ptr(b["m"]),
+              _ptr(b["v"]), b1, b2, eps, 1.0 / 128.0, 0.0, _ptr(flag), 0, None, None, None, C.byref(tail))
+        torch.cuda.synchronize()
+        for name in a:
+            x, y = a[name], b[name]
+            x = x.view(torch.int16) if x.dtype == torch.float16 else x.view(torch.int32)
+            y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
+            assert torch.equal(x, y), f"step {it}: {name} differs ({int((x != y).sum())} words)"
+        expect = it + 1 - (1 if it >= 3 else 0)
+        assert int(b["applied"].item()) == expect and int(b["ema_step"].item()) == expect and int(b["done"].item()) == 0
+    assert bool((b["ema"] != 0).all()) and bool((b["p16"] != 0).any())
+
+
 def test_adaptive_ray_batch_and_ema_inference(device):
     """The ray batch adapts toward the packed-sample target (NerfCounters::update_after_training [UPSTREAM]): after a
     few adaptations the marched samples per step sit within 25 % of the capacity, whatever batch the run started
