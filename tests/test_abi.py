@@ -29,6 +29,47 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.exported_symbols())
 
 
+def test_struct_mirrors_match_the_header(tmp_path):
+    """Every ctypes.Structure of nerf_vo_amd/_lib.py against the C struct it mirrors: include/nerfvo_hip.h is compiled
+    as plain C (gcc -- what a cgo / JNI / ctypes binding of a maintainer would do), and sizeof + every
+    field's offsetof must agree.  A field added on one side only would otherwise show up as a wrong kernel argument."""
+    import shutil
+    import subprocess
+
+    from nerf_vo_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    mirrors = {}
+    for name in dir(_lib):
+        cls = getattr(_lib, name)
+        if isinstance(cls, type) and issubclass(cls, C.Structure) and cls is not C.Structure:
+            m = re.search(r"(nvo_\w+)", cls.__doc__ or "")
+            assert m, f"{name}: the docstring names the C struct it mirrors"
+            mirrors[name] = (cls, m.group(1))
+    text = (ROOT / "include" / "nerfvo_hip.h").read_text()
+    declared = set(re.findall(r"^}\s*(nvo_\w+);", text, flags=re.M))
+    assert declared == {c for _, c in mirrors.values()}, "every argument struct of the header has a mirror"
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "nerfvo_hip.h"', "int main(void) {"]
+    for name, (cls, cname) in sorted(mirrors.items()):
+        src.append(f'  printf("{name} %zu", sizeof({cname}));')
+        src += [f'  printf(" %zu", offsetof({cname}, {f[0]}));' for f in cls._fields_]
+        src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(tmp_path / "layout.c"), "-o",
+                    str(tmp_path / "layout")], check=True, capture_output=True, text=True)
+    out = subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        name, *nums = line.split()
+        cls = mirrors[name][0]
+        expect = [C.sizeof(cls)] + [getattr(cls, f[0]).offset for f in cls._fields_]
+        assert [int(v) for v in nums] == expect, f"{name} vs {mirrors[name][1]}: [sizeof, offsets...] {nums} != {expect}"
+        seen += 1
+    assert seen == len(mirrors) >= 12
+
+
 def _create_encoding(cfg):
     from nerf_vo_amd import _lib
 
