@@ -80,10 +80,10 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  * them so).
  *   "grid_bwd_mode"   parameter-gradient kernel of a hash-grid encoding:
  *                       0 = global float atomics, 1 = LDS slice-owner scatter (module default),
- *                       2 = binned scatter for hashed levels with gathers (count / scan / scatter / accumulate),
- *                       3 = streamed binned scatter of self-contained 8-byte records, coarse levels slice-owner
- *                           (what the engine selects for the main field)
- *   "grid_stream_layout"        (mode 3) 1 = tile-local records, no count / scan passes (default); 0 = globally sorted
+ *                       3 = streamed scatter of self-contained tile-local records (no count / scan passes), coarse
+ *                           levels slice-owner (what the engine selects for the main field)
+ *                       (2 -- binned with gathers -- and the globally sorted record layout were removed in round 5:
+ *                       nothing shipped them)
  *   "grid_stream_tile"          (mode 3) samples per scatter workgroup: 256 | 512 (default) | 1024
  *   "grid_stream_owner_slices"  (mode 3) levels with at most this many 4K-entry bins stay slice-owner (default 24)
  *   "grid_stream_overlap"       (mode 3) 1 = coarse-level launch on an auxiliary stream beside the record pipeline
@@ -99,10 +99,10 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *                               a lane's 8 list-consecutive samples then depend on that order, so results are NOT
  *                               bitwise reproducible (without it only the chunk a sample falls in changes, which
  *                               integer accumulation does not see); "deterministic" switches the list off
- *   "grid_stream_acc_bits"      (mode 3, tile-local layout) accumulators of the record pass: 64 = two 64-bit fixed-point
- *                               sums per entry, 4096-entry bins; 32 = two 32-bit fixed-point sums in ONE 64-bit word
- *                               (one LDS atomic per record), 8192-entry bins, scale 2^29 / L1(bin) from bounds the
- *                               scatter delivers with its rank atomics; both bitwise reproducible on hashed levels
+ *   "grid_stream_acc_bits"      (mode 3) accumulators of the record pass: 32 only -- two 32-bit fixed-point sums in
+ *                               ONE 64-bit word (one LDS atomic per record), 8192-entry bins, scale 2^29 / L1(bin) from
+ *                               bounds the scatter delivers with its rank atomics; bitwise reproducible on hashed levels
+ *                               (the 64-bit form with 4096-entry bins was removed in round 5)
  *   "deterministic"             bitwise reproducible gradients: every slice / bin has ONE owner work item (no sample
  *                               chunks meeting in float atomics), integer accumulators on every level, no live list;
  *                               networks sum their weight gradient over the workgroups in a fixed order.  Several
