@@ -118,6 +118,9 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *   "grid_bwd_dense_share"      (with "grid_bwd_batch") chunks of a DENSE slice relative to that even split, in percent
  *                               (default 100; 25..400): 120 when most samples carry a gradient (bf16 gradients, loss
  *                               scale 65536), where dense-level items are the slower kind
+ *   "grid_fwd_runs"             the level-major forward (no input gradients requested) walks runs of four consecutive
+ *                               samples per thread and gathers only where the cell changes: pays on ray-ordered samples
+ *                               of a trained field (inference), costs ~8 % on uniform ones; bit-identical; default 0
  *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
  *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
  *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges

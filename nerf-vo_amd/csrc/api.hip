@@ -464,6 +464,7 @@ struct GridModule : nvo_module_s {
     // gathering the 8 corners of every (sample, level) again.  The ctx of a forward run with the option off (or
     // with another batch size) is never read as dy/dx: the matching backward then takes the gather form.
     int prepare_input_gradients = 0;
+    bool fwd_runs = false;  // option "grid_fwd_runs": the forward walks runs of four consecutive samples (k_grid_fwd_runs)
     bool dydx_valid = false;
     uint32_t dydx_batch = 0;
     uint64_t dydx_bytes(uint32_t B) const { return nvo_round_up((uint64_t)g.n_levels * 3 * B * 4, 256); }
@@ -471,7 +472,7 @@ struct GridModule : nvo_module_s {
     int fwd_encode(hipStream_t s, uint32_t B, const float* in, const void* table, void* out, bool soa, void* dydx) {
         dydx_valid = dydx != nullptr;
         dydx_batch = B;
-        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16, n_live);
+        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16, n_live, fwd_runs);
     }
     int bwd_input(hipStream_t s, uint32_t B, const float* in, const void* table, const void* dout, bool soa,
                   float* din, const void* dydx) {
@@ -509,6 +510,10 @@ struct GridModule : nvo_module_s {
             return NVO_OK;
         }
         if (!strcmp(key, "external_zero")) return set_external_zero(value != 0);
+        if (!strcmp(key, "grid_fwd_runs")) {
+            fwd_runs = value != 0;
+            return NVO_OK;
+        }
         if (!strcmp(key, "grid_compact_live")) {  // slice-owner items scan only the samples with a non-zero gradient
             slices.compact_live = value != 0;
             return NVO_OK;

@@ -290,6 +290,100 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------
+// forward over RUNS of four consecutive samples (level-major output; option "grid_fwd_runs")
+// ------------------------------------------------------------------------------------------
+// Samples arrive in ray order, and a TRAINED field concentrates a ray's samples at the surface: on every level whose
+// cell is wider than their spacing, neighbours in memory fall into the same cell and repeat the gather instructions of
+// the sample before.  A thread here walks four consecutive samples of one level and gathers only where the cell changes;
+// positions are 3 x 16-byte loads per thread, the four results leave as one 16-byte store.  Pays where runs exist --
+// full-image inference of a trained field: grid_fwd[L16] 301 -> 253 us per 32 768-ray chunk -- and costs 8 % where they
+// do not (uniform samples of an untrained field: the 48-byte position stride, fewer waves per sample), so it is an
+// option the inference path switches on (EXPERIMENTS.md 9.6b).  Same fp32 interpolation, same order, one rounding:
+// bit-identical to k_grid_fwd.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_grid_fwd_runs(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                __half2* __restrict__ out, int out_bf16, GridFwdPlan plan, const uint32_t* __restrict__ n_live) {
+    constexpr int RUN = 4;
+    uint32_t tile, level;
+    if (plan.enabled) {
+        if (!grid_plan_map(plan, blockIdx.x, &tile, &level)) return;
+    } else {
+        grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    }
+    if (n_live && tile * (BLOCK * RUN) >= *n_live) return;
+    const uint32_t i0 = tile * (BLOCK * RUN) + threadIdx.x * RUN;
+    if (i0 >= N) return;  // (N is a multiple of RUN: a run is in range as a whole)
+
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const uint32_t* __restrict__ tab = reinterpret_cast<const uint32_t*>(table) + off;
+    const float scale = g.scale[level];
+
+    float p[RUN * 3];
+    {
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(x + 3 * (size_t)i0);
+#pragma unroll
+        for (int q = 0; q < RUN * 3 / 4; ++q) {
+            const float4 f = xp[q];
+            p[4 * q] = f.x; p[4 * q + 1] = f.y; p[4 * q + 2] = f.z; p[4 * q + 3] = f.w;
+        }
+    }
+    Corner c[RUN];
+    bool need[RUN];
+#pragma unroll
+    for (int s = 0; s < RUN; ++s) {
+        c[s] = grid_cell(scale, p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+        need[s] = s == 0 || c[s].px != c[s - 1].px || c[s].py != c[s - 1].py || c[s].pz != c[s - 1].pz;
+    }
+    // every gather of the run is requested before anything is consumed
+    uint32_t v[RUN][8];
+#pragma unroll
+    for (int s = 0; s < RUN; ++s) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[s][k] = 0u;
+        if (!need[s]) continue;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t cy = c[s].py + (j & 1u), cz = c[s].pz + (j >> 1);
+            const uint32_t a = nvo_grid_index(hashed, size, res, c[s].px, cy, cz);
+            const uint32_t b = nvo_grid_index(hashed, size, res, c[s].px + 1u, cy, cz);
+            if (!hashed && b == a + 1u) {
+                // dense level: the two x corners are neighbours in memory (dword alignment suffices)
+                const uint2 q = *reinterpret_cast<const uint2*>(tab + a);
+                v[s][2 * j] = q.x;
+                v[s][2 * j + 1] = q.y;
+            } else {
+                v[s][2 * j] = tab[a];
+                v[s][2 * j + 1] = tab[b];
+            }
+        }
+    }
+    uint32_t cur[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t r[RUN];
+#pragma unroll
+    for (int s = 0; s < RUN; ++s) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) cur[k] = need[s] ? v[s][k] : cur[k];
+        const Corner& cc = c[s];
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const float w = ((k & 1u) ? cc.wx : 1.f - cc.wx) * ((k & 2u) ? cc.wy : 1.f - cc.wy) *
+                            ((k & 4u) ? cc.wz : 1.f - cc.wz);
+            const float2 f = __half22float2(__builtin_bit_cast(__half2, cur[k]));
+            r0 = fmaf(w, f.x, r0);
+            r1 = fmaf(w, f.y, r1);
+        }
+        r[s] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+    }
+    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
+    *reinterpret_cast<uint4*>(o32 + (size_t)level * N + i0) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// ------------------------------------------------------------------------------------------
 // forward for SMALL grids (the proposal networks: 5 levels, 2^17-entry tables): coarse dense levels served from LDS
 // ------------------------------------------------------------------------------------------
 // k_grid_fwd on a proposal grid runs at the L1's tag-lookup rate, not at any bandwidth: 27 M line accesses per 1 M-sample
@@ -429,6 +523,121 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
         GP_ADD(32, gf1 - gf0); GP_ADD(33, gfe - gf1); GP_ADD(34, gf_iss); GP_ADD(35, gf_lds); GP_ADD(36, gf_cons); GP_ADD(37, 1);
     }
 #endif
+}
+
+// The same over RUNS of four consecutive samples per thread (see k_grid_fwd_runs): the first proposal level's samples are
+// 256 per ray at uniform lin-disp spacing whatever the state of training -- 3.8 / 2.2 / 1.3 samples per cell on its three
+// global levels -- so a thread that walks four neighbours gathers once per cell change.  Level by level (the values of
+// four samples of ONE level are 32 registers; all three at once would spill at 1024 threads per workgroup), with an LDS
+// level evaluated while each global level's gathers fly.  Bit-identical to k_grid_fwd_small.
+template <int NLDS, int NG>
+__global__ void __launch_bounds__(kSmallBlock)
+k_grid_fwd_small_runs(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                      __half2* __restrict__ out, int out_bf16, uint32_t per_block) {
+    constexpr int RUN = 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const uint32_t* __restrict__ tab32 = reinterpret_cast<const uint32_t*>(table);
+    {
+        const uint32_t n4 = g.offset[NLDS] >> 2;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+        for (uint32_t e = threadIdx.x; e < n4; e += kSmallBlock) dst[e] = src[e];
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.x * per_block;
+    const uint32_t last = min(N, first + per_block);  // (both multiples of RUN)
+    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
+    auto lds_level = [&](int l, const float (&p)[RUN * 3], uint32_t i0) {
+        const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+        const uint32_t* tl = lds_tab + off;
+        uint32_t r[RUN];
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            const Corner c = grid_cell(g.scale[l], p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                ((k & 4u) ? c.wz : 1.f - c.wz);
+                const float2 f = __half22float2(__builtin_bit_cast(__half2, tl[idx]));
+                r0 = fmaf(w, f.x, r0);
+                r1 = fmaf(w, f.y, r1);
+            }
+            r[s] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+        }
+        *reinterpret_cast<uint4*>(o32 + (size_t)l * N + i0) = make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    for (uint32_t i0 = first + threadIdx.x * RUN; i0 < last; i0 += kSmallBlock * RUN) {
+        float p[RUN * 3];
+        {
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(x + 3 * (size_t)i0);
+#pragma unroll
+            for (int q = 0; q < RUN * 3 / 4; ++q) {
+                const float4 f = xp[q];
+                p[4 * q] = f.x; p[4 * q + 1] = f.y; p[4 * q + 2] = f.z; p[4 * q + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const uint32_t level = NLDS + q;
+            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+            const uint32_t hashed = g.hashed[level];
+            const uint32_t* __restrict__ tl = tab32 + off;
+            Corner c[RUN];
+            bool need[RUN];
+            uint32_t v[RUN][8];
+#pragma unroll
+            for (int s = 0; s < RUN; ++s) {
+                c[s] = grid_cell(g.scale[level], p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+                need[s] = s == 0 || c[s].px != c[s - 1].px || c[s].py != c[s - 1].py || c[s].pz != c[s - 1].pz;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) v[s][k] = 0u;
+                if (!need[s]) continue;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t cy = c[s].py + (j & 1u), cz = c[s].pz + (j >> 1);
+                    const uint32_t a = nvo_grid_index(hashed, size, res, c[s].px, cy, cz);
+                    const uint32_t b = nvo_grid_index(hashed, size, res, c[s].px + 1u, cy, cz);
+                    if (hashed ? ((c[s].px & 1u) == 0u) : false) {
+                        // even cell x: idx1 == idx0 ^ 1 -- both corners sit in one aligned 8-byte pair
+                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + (a & ~1u));
+                        v[s][2 * j] = (a & 1u) ? pr.y : pr.x;
+                        v[s][2 * j + 1] = (a & 1u) ? pr.x : pr.y;
+                    } else if (!hashed && b == a + 1u) {
+                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + a);
+                        v[s][2 * j] = pr.x;
+                        v[s][2 * j + 1] = pr.y;
+                    } else {
+                        v[s][2 * j] = tl[a];
+                        v[s][2 * j + 1] = tl[b];
+                    }
+                }
+            }
+            // an LDS level while the gathers fly
+            if (q < NLDS) lds_level(q, p, i0);
+            uint32_t cur[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            uint32_t r[RUN];
+#pragma unroll
+            for (int s = 0; s < RUN; ++s) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) cur[k] = need[s] ? v[s][k] : cur[k];
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const float w = ((k & 1u) ? c[s].wx : 1.f - c[s].wx) * ((k & 2u) ? c[s].wy : 1.f - c[s].wy) *
+                                    ((k & 4u) ? c[s].wz : 1.f - c[s].wz);
+                    const float2 f = __half22float2(__builtin_bit_cast(__half2, cur[k]));
+                    r0 = fmaf(w, f.x, r0);
+                    r1 = fmaf(w, f.y, r1);
+                }
+                r[s] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+            }
+            *reinterpret_cast<uint4*>(o32 + (size_t)level * N + i0) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+#pragma unroll
+        for (int l = NG; l < NLDS; ++l) lds_level(l, p, i0);  // (more LDS levels than global ones: the rest)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1867,7 +2076,7 @@ static uint32_t grid_fwd_plan_build(const NvoGridLevels& g, uint32_t tiles, Grid
 
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half,
-                        bool out_bf16, const uint32_t* n_live) {
+                        bool out_bf16, const uint32_t* n_live, bool runs) {
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
@@ -1890,6 +2099,21 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
                                               152 * 1024));
             attr_set = true;
         }
+        if (runs && (N & 3u) == 0u && (((uintptr_t)x) & 15u) == 0u && (((uintptr_t)out_half) & 15u) == 0u) {
+            // option "grid_fwd_runs" (inference: 8 M samples per chunk -- 175 -> 158 us; on a training batch of 0.4-1 M
+            // samples a 1024-thread workgroup of four-sample runs has one pass or less to do and loses 8 us)
+            static bool attr_runs = false;
+            if (!attr_runs) {
+                NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small_runs<2, 3>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+                attr_runs = true;
+            }
+            const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock * 4);
+            NVO_LAUNCH((k_grid_fwd_small_runs<2, 3>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
+                       (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
+            NVO_CHECK_LAUNCH();
+            return NVO_OK;
+        }
         // one workgroup per CU, a whole number of passes each
         const uint32_t spt = small_env >= 2 ? 2u : 1u;
         const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock * spt);
@@ -1903,7 +2127,10 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
         return NVO_OK;
     }
     static const int spt_env = [] { const char* e = getenv("NVO_GRID_FWD_SPT"); return e ? atoi(e) : 2; }();
-    const int spt = (dydx_half || spt_env < 2) ? 1 : (spt_env >= 4 ? 4 : 2);  // samples per thread
+    // option "grid_fwd_runs": four consecutive samples per thread (k_grid_fwd_runs) wherever its 16-byte accesses line up
+    runs = runs && soa && !indices && !dydx_half && (N & 3u) == 0u && (((uintptr_t)x) & 15u) == 0u &&
+           (((uintptr_t)out_half) & 15u) == 0u;
+    const int spt = runs ? 4 : (dydx_half || spt_env < 2) ? 1 : (spt_env >= 4 ? 4 : 2);  // samples per thread
     const uint32_t tiles = nvo_div_up(N, kGridBlock * spt);
     dim3 grid(tiles * g.n_levels), block(kGridBlock);
     GridFwdPlan plan;
@@ -1922,7 +2149,10 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
         else if (spt == 2) NVO_LAUNCH_FWD_S(SOA_, false, 2);               \
         else NVO_LAUNCH_FWD_S(SOA_, false, 4);                             \
     } while (0)
-    if (soa) {
+    if (runs) {
+        NVO_LAUNCH((k_grid_fwd_runs<kGridBlock>), grid, block, 0, stream, g, N, x, (const __half2*)table_half,
+                   (__half2*)out_half, out_bf16 ? 1 : 0, plan, n_live);
+    } else if (soa) {
         if (dydx_half) NVO_LAUNCH_FWD(true, true); else NVO_LAUNCH_FWD(true, false);
     } else {
         if (dydx_half) NVO_LAUNCH_FWD(false, true); else NVO_LAUNCH_FWD(false, false);

@@ -144,7 +144,8 @@ void nvo_grid_slices_destroy(NvoGridSlices* s);
 // out_bf16: the encoded features leave as bfloat16 pairs instead of fp16 pairs (bf16 MLP mode)
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices,
-                        void* dydx_half = nullptr, bool out_bf16 = false, const uint32_t* n_live = nullptr);
+                        void* dydx_half = nullptr, bool out_bf16 = false, const uint32_t* n_live = nullptr,
+                        bool runs = false);
 int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
                                    const void* dy, int dy_fmt, bool soa, float* dx, bool zero_dx);
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,

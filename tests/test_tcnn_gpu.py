@@ -623,6 +623,47 @@ def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dt
     _assert_close(res[1][1], res[0][1], rtol=5e-5, atol_scale=5e-7, what="dL/dparams, fused vs two-kernel forward")
 
 
+@pytest.mark.parametrize("coherent", [True, False], ids=["ray-ordered", "random"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg,width", [(MAIN, 64), (PROP0, 16), (PROP1, 16)], ids=["main", "prop0", "prop1"])
+def test_forward_over_runs_is_bit_identical(device, coherent, dtype, cfg, width):
+    """option grid_fwd_runs (what the inference path switches on): a thread walks four consecutive samples of a level and
+    gathers only where the cell changes -- the SAME bits as the thread-per-sample forward, on ray-ordered samples (runs of
+    equal cells on the coarse levels, none on the fine ones) and on random ones (no runs at all), both domain faces
+    included.  The proposal grids take the form with the two coarsest levels in LDS (k_grid_fwd_small_runs)."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width,
+               "n_hidden_layers": 1}
+    g = torch.Generator().manual_seed(33)
+    rays, per_ray = 96, 48
+    n = rays * per_ray  # 4608 = 36 x 128
+    if coherent:
+        o = torch.rand(rays, 1, 3, generator=g) * 0.5 + 0.25
+        d = torch.nn.functional.normalize(torch.randn(rays, 1, 3, generator=g), dim=-1)
+        t = (torch.arange(per_ray).float()[None, :, None] * 2.0e-3) * (1.0 + torch.rand(rays, 1, 1, generator=g))
+        x = (o + d * t).clamp(0.0, 1.0).reshape(n, 3)
+    else:
+        x = torch.from_numpy(_points(n, 4))
+    x[0] = 0.0
+    x[1] = 1.0  # both domain faces (dense-index wrap)
+    x = x.contiguous().to(device)
+    res = []
+    params = None
+    for runs in (0, 1):
+        model = tcnn.NetworkWithInputEncoding(3, 16 if width == 64 else 1, _enc_cfg(cfg), net_cfg, dtype=tdt).to(device)
+        if params is None:
+            params = (torch.randn(model.params.numel(), generator=g) * 0.3).to(device)
+        with torch.no_grad():
+            model.params.copy_(params)
+            model.native_tcnn_module.set_option("grid_fwd_runs", runs)
+            res.append(model(x).clone())
+    torch.cuda.synchronize()
+    assert bool((res[0].float().abs() > 0).any())
+    assert torch.equal(res[0].view(torch.int16), res[1].view(torch.int16)), "forward over runs differs from the per-sample forward"
+
+
 def _raw_nwie(device, cfg, compact, acc_bits=32, compact_live=0, runs=0):
     """A proposal-shaped NetworkWithInputEncoding driven through the raw C-ABI the way the engine drives it."""
     import json
