@@ -225,7 +225,10 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
         return;
     }
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(t.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1u)
+        // (">=" and a bounded wait of a few seconds: a counter someone left dirty must not turn into a
+        // wave that never finishes)
+        for (uint32_t spin = 0; spin < (1u << 24) &&
+                                __hip_atomic_load(t.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x - 1u; ++spin)
             __builtin_amdgcn_s_sleep(16);
     }
     __syncthreads();
