@@ -133,7 +133,9 @@ int nvo_bwd_zero_ranges(nvo_module_t m, float* dL_dparams, void** ptrs_out, uint
 /* input  : device float [batch][n_input_dims]
  * params : device fp16 [n_params]   (NetworkWithInputEncoding: network weights first, then grid)
  * output : device fp16 [batch][padded_output_dims]
- * ctx    : device scratch of nvo_ctx_bytes() bytes, or NULL for inference (nothing is saved) */
+ * ctx    : device scratch of nvo_ctx_bytes() bytes, or NULL for inference (nothing is saved)
+ * batch  : a multiple of 16; 0 is a no-op (buffers may be NULL), and nvo_bwd of an empty batch writes zeros to
+ *          dL_dparams */
 int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
             const void* params, void* output, void* ctx);
 /* dL_doutput: device fp16 [batch][padded_output_dims] (already multiplied by the loss scale)

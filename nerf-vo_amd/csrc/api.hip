@@ -1036,7 +1036,9 @@ int nvo_bwd_zero_ranges(nvo_module_t m, float* dL_dparams, void** ptrs_out, uint
 
 int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
             const void* params, void* output, void* ctx) {
-    NVO_REQUIRE(m && output && (input || batch == 0), "fwd: NULL argument");
+    NVO_REQUIRE(m, "fwd: NULL module");
+    if (batch == 0) return NVO_OK;  // an empty batch has no rows to write (its buffers may be NULL: torch's empty tensors)
+    NVO_REQUIRE(output && input, "fwd: NULL argument");
     NVO_REQUIRE(params || m->n_params == 0, "fwd: params is NULL");
     NVO_REQUIRE((batch & 15u) == 0, "fwd: batch (%u) must be a multiple of 16", batch);
     return m->fwd((hipStream_t)stream, batch, input, params, output, ctx);
@@ -1045,7 +1047,12 @@ int nvo_fwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* in
 int nvo_bwd(nvo_module_t m, nvo_stream_t stream, uint32_t batch, const float* input,
             const void* params, const void* output, const void* dL_doutput, void* ctx,
             float* dL_dinput, float* dL_dparams) {
-    NVO_REQUIRE(m && dL_doutput && (input || batch == 0), "bwd: NULL argument");
+    NVO_REQUIRE(m, "bwd: NULL module");
+    if (batch == 0) {  // the gradient of an empty batch: zeros (dL_dinput has no rows)
+        if (dL_dparams && m->n_params) return nvo_zero_async(dL_dparams, sizeof(float) * m->n_params, (hipStream_t)stream);
+        return NVO_OK;
+    }
+    NVO_REQUIRE(dL_doutput && input, "bwd: NULL argument");
     NVO_REQUIRE((batch & 15u) == 0, "bwd: batch (%u) must be a multiple of 16", batch);
     return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput,
                   dL_dparams);

@@ -623,6 +623,50 @@ def test_fused_encoding_forward_is_bit_identical(device, cfg, width, compact, dt
     _assert_close(res[1][1], res[0][1], rtol=5e-5, atol_scale=5e-7, what="dL/dparams, fused vs two-kernel forward")
 
 
+@pytest.mark.parametrize("kind", ["encoding", "network", "network_with_input_encoding"])
+def test_empty_and_ragged_batches(device, kind):
+    """Batches the 128-row granularity does not divide, and none at all: an EMPTY batch is a no-op with an empty output
+    and zero gradients (torch hands NULL pointers for empty tensors -- nvo_fwd / nvo_bwd take them for batch 0), a
+    ragged batch gives the rows of the padded one bit for bit (forward) and the same input gradient rows."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+               "n_hidden_layers": 1}
+    if kind == "encoding":
+        m = tcnn.Encoding(3, _enc_cfg(PROP0)).to(device)
+    elif kind == "network":
+        m = tcnn.Network(32, 16, net_cfg).to(device)
+    else:
+        m = tcnn.NetworkWithInputEncoding(3, 16, _enc_cfg(PROP0), net_cfg).to(device)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        m.params.copy_((torch.randn(m.params.numel(), generator=g) * 0.3).to(device))
+    x0 = torch.zeros(0, m.n_input_dims, device=device, requires_grad=True)
+    y0 = m(x0)
+    assert tuple(y0.shape) == (0, m.n_output_dims) and y0.dtype == m.dtype
+    y0.float().sum().backward()
+    torch.cuda.synchronize()
+    assert tuple(x0.grad.shape) == (0, m.n_input_dims)
+    assert m.params.grad is not None and float(m.params.grad.abs().max()) == 0.0
+    m.params.grad = None
+    full = torch.rand(256, m.n_input_dims, generator=g).to(device)
+    dy = torch.randn(256, m.n_output_dims, generator=g).to(device)
+    xf = full.clone().requires_grad_(True)
+    yf = m(xf)
+    (yf.float() * dy).sum().backward()
+    m.params.grad = None
+    for B in (1, 127, 129):
+        xb = full[:B].clone().requires_grad_(True)
+        yb = m(xb)
+        assert tuple(yb.shape) == (B, m.n_output_dims)
+        assert torch.equal(yb.view(torch.int16), yf[:B].view(torch.int16)), f"batch {B}: rows differ from the padded batch"
+        (yb.float() * dy[:B]).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(xb.grad, xf.grad[:B]), f"batch {B}: input gradient rows differ"
+        assert bool(torch.isfinite(m.params.grad).all())
+        m.params.grad = None
+
+
 @pytest.mark.parametrize("coherent", [True, False], ids=["ray-ordered", "random"])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("cfg,width", [(MAIN, 64), (PROP0, 16), (PROP1, 16)], ids=["main", "prop0", "prop1"])
