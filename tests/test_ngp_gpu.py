@@ -655,6 +655,44 @@ def test_rays_dropped_at_the_capacity_leave_the_losses_alone(device):
     assert float((grads_all - ref).abs().sum()) <= 2e-2 * float(ref.abs().sum())
 
 
+@pytest.mark.parametrize("compact", [False, True], ids=["plain", "compact"])
+def test_step_on_an_empty_occupancy_grid(device, compact):
+    """No occupied cell at all (a grid decayed to nothing, a camera looking out of the scene): the march finds no sample, every
+    ray renders its background, the packed batch is empty -- the step must run (no kernel is handed a zero-sized grid it
+    cannot launch), report finite losses, leave every gradient exactly zero and let the optimiser and the adaptive ray
+    batch pass through; inference of the same rays returns the background with zero accumulation."""
+    eng = _engine(device, compact_training=compact)
+    g = torch.Generator().manual_seed(8)
+    R = 256
+    origins = ((torch.rand(R, 3, generator=g) - 0.5) * 0.6 + 0.5).to(device)
+    directions = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(device)
+    jitter = torch.rand(R, generator=g).to(device)
+    eng.bitfield.zero_()
+    ws = eng._workspace(R, True)
+    ws["origins"].copy_(origins)
+    ws["directions"].copy_(directions)
+    ws["directions_norm"].fill_(1.0)
+    ws["gt_rgb"].copy_(torch.rand(R, 3, generator=g).to(device))
+    ws["gt_depth"].copy_((torch.rand(R, generator=g) * 0.8).to(device))
+    before = eng.params.clone()
+    eng.forward_backward(ws, jitter, has_depth=True)
+    torch.cuda.synchronize()
+    assert int(ws["totals"][0]) == 0 and int(ws["counts"][:R].sum()) == 0
+    assert bool(torch.isfinite(eng.losses).all())
+    assert float(eng.grads.abs().max()) == 0.0
+    eng.optimizer_step(camera_update=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.params).all()) and int(eng.skip_flag.item()) == 0
+    # the hash table (zero gradient, zero moments, no decay) stays where it was bit for bit; the MLP weights see their L2
+    # decay as the only gradient, which Adam turns into one learning-rate step
+    nd, nden = eng.n_density_mlp, eng.density_net.n_params
+    assert torch.equal(eng.params[nd:nden], before[nd:nden])
+    assert float((eng.params - before).abs().max()) <= eng.cfg.lr * 1.001
+    out = eng.render_rays(origins, directions, torch.ones(R, device=device))
+    torch.cuda.synchronize()
+    assert float(out["accumulation"].abs().max()) == 0.0 and bool(torch.isfinite(out["rgb"]).all())
+
+
 def test_render_splits_bundles_that_overflow_the_capacity(device):
     """NgpEngine.render_rays shades every sample the march finds; a bundle with more samples than the packed capacity
     must come out exactly as from an engine whose capacity holds it whole (rendered in halves, no ray dropped -- dropped
