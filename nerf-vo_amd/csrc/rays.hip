@@ -261,22 +261,50 @@ k_ray_head(nvo_ray_head_args a, NvoZeroPlan zero, uint32_t ray_blocks) {
         nvo_zero_plan_block(zero, blockIdx.x - ray_blocks);
         return;
     }
+    // A workgroup's 256 samples belong to a handful of rays (ONE at 256 samples per ray): the first lanes derive them --
+    // three hashes, ~30 loads of intrinsics / pose / correction, ~200 flops each -- and the workgroup takes them from LDS
+    // (18.7 -> 17.4 us: most of the launch is its 25-31 MB of stores and the zero plan).  Same
+    // device functions on the same inputs: the values do not change.
+    constexpr uint32_t kHeadRays = 8;
+    struct HeadRay {
+        int32_t idx[3];
+        float jit0, o[3], d[3], n0, area;
+    };
+    __shared__ HeadRay s_ray[kHeadRays];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.R * a.S) return;
-    const uint32_t r = i / a.S, j = i - r * a.S;
+    const uint32_t total = a.R * a.S;
+    const uint32_t i_first = blockIdx.x * blockDim.x;
+    const uint32_t i_last = min(total, i_first + blockDim.x) - 1u;  // (i_first < total: the grid covers exactly the samples)
+    const uint32_t r_first = i_first / a.S, n_rays = i_last / a.S - r_first + 1u;
+    const bool shared_rays = n_rays <= kHeadRays;  // (uniform)
     const uint32_t step = (uint32_t)a.step_dev[0];
-    int64_t idx[3];
+    auto derive = [&](uint32_t r, HeadRay& h) {
+        int64_t idx[3];
 #pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
-        const float e = a.extent_dev[c];
-        const float v = floorf(hash_uniform(a.seed, step, c, r) * e);
-        idx[c] = (int64_t)fminf(v, e - 1.f);
+        for (uint32_t c = 0; c < 3; ++c) {
+            const float e = a.extent_dev[c];
+            const float v = floorf(hash_uniform(a.seed, step, c, r) * e);
+            idx[c] = (int64_t)fminf(v, e - 1.f);
+            h.idx[c] = (int32_t)idx[c];
+        }
+        h.jit0 = hash_uniform(a.seed, step, 3u, r);
+        const int64_t cam = idx[0];
+        raygen_one((float)idx[2] + 0.5f, (float)idx[1] + 0.5f, a.intrinsics + 4 * cam, a.c2w + (size_t)a.c2w_stride * cam,
+                   a.corrections ? a.corrections + 12 * cam : nullptr, h.o, h.d, &h.n0, &h.area);
+    };
+    if (shared_rays) {
+        if (threadIdx.x < n_rays) derive(r_first + threadIdx.x, s_ray[threadIdx.x]);
+        __syncthreads();
     }
-    const float jit0 = hash_uniform(a.seed, step, 3u, r);
+    if (i >= total) return;
+    const uint32_t r = i / a.S, j = i - r * a.S;
+    HeadRay hr;
+    if (shared_rays) hr = s_ray[r - r_first]; else derive(r, hr);
+    const int64_t idx[3] = {hr.idx[0], hr.idx[1], hr.idx[2]};
+    const float jit0 = hr.jit0;
     const int64_t cam = idx[0];
-    float o[3], d[3], n0, area;
-    raygen_one((float)idx[2] + 0.5f, (float)idx[1] + 0.5f, a.intrinsics + 4 * cam, a.c2w + (size_t)a.c2w_stride * cam,
-               a.corrections ? a.corrections + 12 * cam : nullptr, o, d, &n0, &area);
+    float o[3] = {hr.o[0], hr.o[1], hr.o[2]}, d[3] = {hr.d[0], hr.d[1], hr.d[2]};
+    const float n0 = hr.n0, area = hr.area;
     // ---- first sampler level (k_lindisp_positions)
     const float s_near = spacing_fn(a.near_plane), s_far = spacing_fn(a.far_plane);
     const float b0 = lindisp_bin(j, a.S, &jit0, 0), b1 = lindisp_bin(j + 1, a.S, &jit0, 0);
