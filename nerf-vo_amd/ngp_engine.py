@@ -38,8 +38,9 @@ class NgpConfig:
     num_rays: int = 4096
     capacity: int = 1 << 18               # packed sample slots per step (instant-ngp's target batch)
     # packed sample slots of an INFERENCE launch (its own workspace): every sample the march finds is shaded, ~110 per ray
-    # in a trained room, so 2^21 slots take ~16 K rays per launch instead of 2 K (0 = the training capacity)
-    render_capacity: int = 1 << 21
+    # in a trained room, so 2^22 slots take ~30 K rays per launch instead of 2 K (0 = the training capacity; ~300 B of
+    # workspace per slot)
+    render_capacity: int = 1 << 22
     # Inference stops a ray where its transmittance has fallen below this (instant-ngp's render_min_transmittance; the
     # reference sets 1e-4, evaluation/nerf_renderer.py:154): render_rays shades the first `render_first_round` samples of
     # every ray, then only the rays still alive take up their march where it stopped (nvo_occ_march_resume).  0 = one pass

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--keyframes", type=int, default=48)
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--render-capacity", type=int, default=0, help="packed sample slots of an inference launch (0: NgpConfig)")
+    ap.add_argument("--profile-render", action="store_true", help="per-kernel device time of the rendered frames")
     ap.add_argument("--render-frames", type=int, default=0, help="1200x680 views rendered through Testbed.render after training")
     ap.add_argument("--train-min-t", type=float, default=None, help="NgpConfig.train_min_transmittance (default 1e-4; 0 = every sample trains)")
     ap.add_argument("--first-round", type=int, default=0, help="samples per ray of the first inference round (0: NgpConfig.render_first_round)")
@@ -106,6 +108,8 @@ def run(a, quiet: bool = False):
 
         if getattr(a, "first_round", 0):
             eng.cfg.render_first_round = int(a.first_round)
+        if getattr(a, "render_capacity", 0):
+            eng.cfg.render_capacity = int(a.render_capacity)
         fx = float(seq["camera_intrinsics"][0, 0]) * 1200.0 / W
         tb.fov_axis, tb.fov, tb.exposure = 0, 2.0 * math.degrees(math.atan(0.5 * 1200.0 / fx)), 0.0
         times = []
@@ -121,6 +125,35 @@ def run(a, quiet: bool = False):
             depth = tb.render(width=1200, height=680, spp=1, linear=True)
             times.append(time.perf_counter() - t1)
         ms = 1e3 * float(np.mean(times[1:]))
+        if getattr(a, "profile_render", False):
+            # per-kernel device time of two more frames (HIP events around every launch: the frame itself gets slower)
+            import ctypes as C
+
+            from nerf_vo_amd import _lib
+            lib = _lib.lib()
+            lib.nvo_profile_enable(1)
+            for f in range(2):
+                m = poses[(a.render_frames + 1 + f) % a.keyframes].detach().cpu().numpy().astype(np.float64).copy()
+                m[0:3, 1:3] *= -1
+                tb.set_nerf_camera_matrix(m[[2, 0, 1]])  # (a new view: the facade keeps the last pass)
+                tb.render_mode = pyngp.Shade
+                tb.render(width=1200, height=680, spp=1, linear=True)
+                tb.render_mode = pyngp.Depth
+                tb.render(width=1200, height=680, spp=1, linear=True)
+            torch.cuda.synchronize()
+            need = lib.nvo_profile_summary(None, 0)
+            buf = C.create_string_buffer(int(need) + 16)
+            lib.nvo_profile_summary(buf, len(buf))
+            lib.nvo_profile_enable(0)
+            rows = []
+            for line in buf.value.decode().strip().splitlines():
+                name, cnt, total = line.rsplit(",", 2)
+                rows.append((name, int(cnt), float(total)))
+            rows.sort(key=lambda r: -r[2])
+            tot = sum(r[2] for r in rows)
+            say(f"render kernel time {tot / 2:.2f} ms per frame (colour + depth) against {ms:.1f} ms wall")
+            for name, cnt, total in rows[:16]:
+                say(f"  {name:30s} launches/frame {cnt / 2:6.1f} avg {total / cnt * 1e3:9.1f} us  {100 * total / max(tot, 1e-12):5.1f} %")
         # quality of what was trained so far: views halfway between training cameras (the same trajectory sampled twice
         # as densely: odd frames) and training views, at the training resolution, float-MSE PSNR of the colour image
         def view_psnr(pose_cv, gt_chw, keyframe=None):
