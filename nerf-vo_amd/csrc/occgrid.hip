@@ -112,12 +112,27 @@ __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle
 // step share one in-order counter (vmcnt), so a store per accepted sample made every following occupancy test wait for
 // that store to reach memory (measured: 5.2 ms with per-sample stores against 0.37 ms without any).  With staging
 // a wave stalls once per kStage accepted samples.
+// Resumable like k_occ_march_wave (t_resume / max_new / t_next / run_offset, same meaning, same samples).  This form is
+// what LARGE launches take (inference: >= 49 152 rays): a candidate costs one lane ~25 instructions here and one WAVE ~11
+// there (every lane of a ray's wave evaluates the same fp32 recurrence), so with enough rays to fill the chip it is the
+// cheaper one by far -- 816 000 rays marched to the end: 9.5 ms wave-per-ray whatever the launch size, ray-per-lane 13.5 ms
+// in launches of 16 K rays, 3.6 ms at 65 K, 1.6 ms at 262 K (tools/probes/march_forms.py) -- while a training batch of 2-16 K
+// rays leaves most SIMDs without a wave and is a chain of ~1000 dependent loads per ray.
 __global__ void __launch_bounds__(256)
 k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restrict__ directions,
             const uint8_t* __restrict__ bitfield, int n_levels, float cone_angle, float t_near,
-            const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch) {
+            const float* __restrict__ jitter, uint32_t* __restrict__ counts, float2* __restrict__ scratch,
+            const float* __restrict__ t_resume, uint32_t max_new, float* __restrict__ t_next,
+            const uint32_t* __restrict__ R_dev, uint32_t run_offset) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
+    if (R_dev) R = min(R, *R_dev);
+    // (no early return: the staging flush below is a wave-wide vote -- lanes without a ray simply have nothing to march)
+    const bool has_ray = r < R;
+    const uint32_t rc = has_ray ? r : 0u;
+    const uint32_t budget = max_new < kMaxSteps ? max_new : kMaxSteps;
+    const float resume = (t_resume && has_ray) ? t_resume[rc] : 0.f;
+    const bool alive = has_ray && !(t_resume && !(resume >= 0.f));
+    float next = -1.f;
     const int max_mip = n_levels - 1;
     const float half = 0.5f * (float)(1 << max_mip);
     const float lo = 0.5f - half, hi = 0.5f + half;
@@ -125,8 +140,8 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
     float tmin = t_near, tmax = 3.0e38f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        o[k] = origins[3 * (size_t)r + k];
-        d[k] = directions[3 * (size_t)r + k];
+        o[k] = origins[3 * (size_t)rc + k];
+        d[k] = directions[3 * (size_t)rc + k];
         idir[k] = 1.0f / d[k];
         float t0 = (lo - o[k]) * idir[k], t1 = (hi - o[k]) * idir[k];
         if (t0 > t1) { const float tt = t0; t0 = t1; t1 = tt; }
@@ -135,7 +150,7 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
     }
     constexpr uint32_t kStage = 16;
     __shared__ float2 stage[kStage][256];
-    float2* __restrict__ run = scratch + (size_t)r * kMaxSteps;
+    float2* __restrict__ run = scratch + (size_t)rc * kMaxSteps + run_offset;
     uint32_t staged = 0;
     auto flush = [&](uint32_t j_now) {
         const uint32_t first = j_now - staged;
@@ -145,9 +160,12 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
         staged = 0;
     };
     uint32_t j = 0;
-    if (tmax > tmin) {
-        float t = tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[r] : 0.f);
-        for (;;) {
+    if (alive && tmax > tmin) {
+        float t = t_resume ? resume : tmin + calc_dt(tmin, cone_angle) * (jitter ? jitter[rc] : 0.f);
+        // (2^20 candidates: an exit every lane reaches even for a degenerate ray whose skip target is not finite -- the
+        // bound of k_occ_march_wave's block loop)
+        uint32_t guard = 1u << 20;
+        while (guard) {
             float p[3];
             bool inside = true;
 #pragma unroll
@@ -155,7 +173,11 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
                 p[k] = o[k] + d[k] * t;
                 inside = inside && p[k] >= lo && p[k] <= hi;
             }
-            if (!inside || j >= kMaxSteps) break;
+            if (!inside) break;  // left the box
+            if (j >= budget) {   // sample budget of the ray (of this round) spent: this candidate is where it resumes
+                next = t;
+                break;
+            }
             const float dt = calc_dt(t, cone_angle);
             const int mip = mip_from_dt(dt, p, max_mip);
             if (occupied(p, bitfield, mip)) {
@@ -163,15 +185,23 @@ k_occ_march(uint32_t R, const float* __restrict__ origins, const float* __restri
                 ++staged;
                 ++j;
                 t += dt;
+                --guard;
             } else {
-                t = advance_to_next_voxel(t, cone_angle, p, d, idir, mip);
+                const float t_target = voxel_exit_target(t, p, d, idir, mip);
+                do {  // (advance_to_next_voxel, with the guard)
+                    t += calc_dt(t, cone_angle);
+                    --guard;
+                } while (t < t_target && guard);
             }
             // every lane still marching empties its stage when ANY of them is full: one burst, one stall
             if (__any(staged == kStage)) flush(j);
         }
     }
     if (staged) flush(j);
-    counts[r] = j;
+    if (has_ray) {
+        counts[r] = j;
+        if (t_next) t_next[r] = next;
+    }
 }
 
 // ONE WAVE PER RAY (the default).  A ray's candidate positions are the fixed progression t_0, t_1 = t_0 + calc_dt(t_0), ...
@@ -785,10 +815,13 @@ int nvo_occ_march_runs(nvo_stream_t stream, uint32_t R, const float* origins, co
     hipStream_t s = (hipStream_t)stream;
     float2* march_scratch = static_cast<float2*>(scratch);
     NVO_PROF(stream, "occ_march");
-    static const bool ray_per_lane = getenv("NVO_OCC_MARCH_LANES") && atoi(getenv("NVO_OCC_MARCH_LANES")) != 0;
-    if (ray_per_lane && !t_resume && !t_next && max_new >= kMaxSteps && !R_dev && !run_offset) {  // (A/B switch: the sequential form, one ray per lane)
+    // ray-per-lane for launches that fill the chip with rays (inference bundles), wave-per-ray for training batches;
+    // NVO_OCC_MARCH_LANES = 0 | 1 forces one form (A/B, tests)
+    static const int lanes_env = [] { const char* e = getenv("NVO_OCC_MARCH_LANES"); return e ? atoi(e) : -1; }();
+    const bool ray_per_lane = lanes_env >= 0 ? lanes_env != 0 : R >= 49152u;
+    if (ray_per_lane) {
         NVO_LAUNCH(k_occ_march, dim3(nvo_div_up(R, 256)), dim3(256), 0, s, R, origins, directions, bitfield,
-                   n_levels, cone_angle, t_near, jitter, counts, march_scratch);
+                   n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next, R_dev, run_offset);
     } else {
         NVO_LAUNCH(k_occ_march_wave, dim3(nvo_div_up(R, 4)), dim3(256), 0, s, R, origins, directions, bitfield,
                    n_levels, cone_angle, t_near, jitter, counts, march_scratch, t_resume, max_new, t_next, R_dev, run_offset);
@@ -841,7 +874,8 @@ int nvo_occ_pack_fused(nvo_stream_t stream, uint32_t R, const uint32_t* counts_i
                 "occ_pack_fused: NULL argument");
     NVO_REQUIRE(scratch_bytes >= nvo_occ_march_scratch_bytes(R), "occ_pack_fused: scratch too small for %u rays", R);
     NVO_REQUIRE(run_offset < kMaxSteps, "occ_pack_fused: run_offset %u outside a run", run_offset);
-    NVO_REQUIRE(R <= 65536u, "occ_pack_fused: at most 65536 rays per launch (got %u)", R);
+    NVO_REQUIRE(nvo_div_up(R, rays_per_group) <= 4096u, "occ_pack_fused: at most %u rays per launch with %u rays per workgroup (got %u)",
+                4096u * rays_per_group, rays_per_group, R);
     NVO_REQUIRE(!x01 || (origins && directions && aabb_hi > aabb_lo), "occ_pack_fused: positions need origins, directions and a box");
     NVO_REQUIRE((((uintptr_t)state) & 7u) == 0u, "occ_pack_fused: the state block must be 8-byte aligned");
     if (R == 0) return NVO_OK;

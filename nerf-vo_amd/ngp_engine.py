@@ -38,9 +38,10 @@ class NgpConfig:
     num_rays: int = 4096
     capacity: int = 1 << 18               # packed sample slots per step (instant-ngp's target batch)
     # packed sample slots of an INFERENCE launch (its own workspace): every sample the march finds is shaded, ~110 per ray
-    # in a trained room, so 2^22 slots take ~30 K rays per launch instead of 2 K (0 = the training capacity; ~300 B of
-    # workspace per slot)
-    render_capacity: int = 1 << 22
+    # in a trained room, so the slots decide how many rays a launch takes (0 = the training capacity).  2^23 slots (~300 B
+    # of workspace each: 2.5 GB, plus 8 KB of march scratch per ray of the bundle) hold the first round of 131 072 rays --
+    # sized for 288 GB of HBM, and for the ray-per-lane march large launches take (pyngp._MAX_BUNDLE_RAYS)
+    render_capacity: int = 1 << 23
     # Inference stops a ray where its transmittance has fallen below this (instant-ngp's render_min_transmittance; the
     # reference sets 1e-4, evaluation/nerf_renderer.py:154): render_rays shades the first `render_first_round` samples of
     # every ray, then only the rays still alive take up their march where it stopped (nvo_occ_march_resume).  0 = one pass

@@ -49,9 +49,11 @@ _TO_NGP_ROWS = [2, 0, 1]    # OpenGL c2w rows -> "NGP" row order
 _FROM_NGP_ROWS = [1, 2, 0]  # and back
 
 
-# rays per inference bundle, at most (nvo_occ_pack_fused takes 65 536 rays per launch; 2^15 rays / 2^21 slots measured
-# 28.5 ms per 1200x680 frame against 26.6 ms: the march and the scans are launched half as often)
-_MAX_BUNDLE_RAYS = 1 << 16
+# rays per inference bundle, at most.  Large bundles are what the ray-per-lane march needs (nvo_occ_march_runs takes it
+# from 49 152 rays on: a 1200x680 image marched in 26 launches of 65 536 rays costs 4.1 ms, in 14 of 131 072 2.3 ms) and
+# they halve the scans; 1200x680 colour + depth on one box: 2^15 rays / 2^21 slots 30.0-31.6 ms, 2^16 / 2^22 25.7-26.2 (still
+# wave-per-ray), 2^16 / 2^23 24.0-24.4, 2^17 / 2^23 20.8-21.9, 2^18 / 2^24 20.5-21.2.
+_MAX_BUNDLE_RAYS = 1 << 17
 
 
 class TestbedMode(enum.Enum):

@@ -71,6 +71,71 @@ def test_march_bit_exact(device, n_levels, cone):
         assert (dtt[sl].view(np.uint32) == rdt[r, :n].view(np.uint32)).all(), f"ray {r}: dt differs"
 
 
+@pytest.mark.parametrize("n_levels,cone", [(3, 1.0 / 256.0), (1, 0.0)])
+def test_ray_per_lane_march_matches_wave_per_ray(device, n_levels, cone):
+    """A launch of >= 49 152 rays (an inference bundle) takes the ray-per-lane march, a training batch the wave-per-ray one
+    (pinned to the C oracle by test_march_bit_exact): the same 65 536 rays through both -- one launch against four of
+    16 384 -- must give the same counts and the same (t, dt) of every sample bit for bit, in one pass and in rounds (48
+    samples, then the rest from where the first round stopped, appended to the ray's run: t_resume / t_next / run_offset),
+    rays outside every cascade, an axis-aligned ray and rays that sit a round out included."""
+    from nerf_vo_amd import _lib
+    from oracle import occgrid as O
+
+    lib = _lib.lib()
+    bf = O.grid_to_bitfield(_scene_grid(n_levels, 1), n_levels)
+    rng = np.random.default_rng(5)
+    R, chunk = 65536, 16384
+    o = (rng.random((R, 3), dtype=np.float32) - 0.5) * 0.9 + 0.5
+    o[:64] = rng.random((64, 3), dtype=np.float32) * 6 - 2.5
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[64] = (0.0, 1.0, 0.0)
+    jit = rng.random(R).astype(np.float32)
+    od, dd, jd = (torch.from_numpy(a).to(device) for a in (o, d, jit))
+    bfd = torch.from_numpy(bf).to(device)
+    nscr = int(lib.nvo_occ_march_scratch_bytes(R))
+
+    def march(rays_per_launch, rounds):
+        scratch = torch.zeros(nscr, dtype=torch.uint8, device=device)
+        counts = [torch.zeros(R, dtype=torch.int32, device=device) for _ in rounds]
+        t_next = torch.full((R,), -2.0, device=device)
+        t_resume = None
+        base = 0
+        for k, budget in enumerate(rounds):
+            last = k + 1 == len(rounds)
+            for lo in range(0, R, rays_per_launch):
+                n = min(rays_per_launch, R - lo)
+                at = lambda t, w: None if t is None else C.c_void_p(t.data_ptr() + w * lo)  # noqa: E731
+                _lib.check(lib.nvo_occ_march_runs(
+                    _stream(), n, at(od, 12), at(dd, 12), _p(bfd), n_levels, cone, 0.0, at(jd, 4), at(counts[k], 4),
+                    C.c_void_p(scratch.data_ptr() + 8 * 1024 * lo), nscr - 8 * 1024 * lo, at(t_resume, 4), budget,
+                    None if last else at(t_next, 4), None, base), "occ_march_runs")
+            if not last:
+                t_resume = t_next.clone()
+                t_resume[::5] = -1.0  # (every fifth ray sits the next round out)
+            base += budget
+        torch.cuda.synchronize()
+        return [c.cpu().numpy() for c in counts], scratch.cpu().numpy().view(np.uint32).reshape(R, 1024, 2), t_next.cpu().numpy()
+
+    for rounds in ([1024], [48, 976]):
+        c_lane, runs_lane, next_lane = march(R, rounds)
+        c_wave, runs_wave, next_wave = march(chunk, rounds)
+        total = np.zeros(R, np.int64)
+        for k in range(len(rounds)):
+            assert (c_lane[k] == c_wave[k]).all(), f"rounds {rounds}, round {k}: {int((c_lane[k] != c_wave[k]).sum())} counts differ"
+            total += c_lane[k]
+        assert total.sum() > 100 * R / 4 and (total == 0).any()
+        if len(rounds) > 1:
+            assert (next_lane.view(np.uint32) == next_wave.view(np.uint32)).all(), "t_next differs"
+            assert (c_lane[1][::5] == 0).all() and (c_lane[1] > 0).any()
+            # (a later round appends at run_offset: the run is contiguous only where the first round filled its budget)
+            used = (np.arange(1024)[None, :] < c_lane[0][:, None]) | \
+                   ((np.arange(1024)[None, :] >= rounds[0]) & (np.arange(1024)[None, :] < rounds[0] + c_lane[1][:, None]))
+        else:
+            used = np.arange(1024)[None, :] < total[:, None]
+        assert (runs_lane[used] == runs_wave[used]).all(), f"rounds {rounds}: (t, dt) differ"
+
+
 def test_capacity_drops_whole_rays(device):
     from nerf_vo_amd import _lib
     from oracle import occgrid as O
