@@ -114,7 +114,21 @@ def pmc_traffic(name: str, live_path: str | None = None):
     return None, None, None
 
 
-def live_pmc_summary(steps: int = 20, warmup: int = 5, timeout_s: int = 240):
+def workload_argv(args) -> list:
+    """The flags that DEFINE the measured configuration (not what is reported about it), as a child bench process must
+    receive them to measure the same thing."""
+    out = ["--workload", args.workload, "--keyframes", str(args.keyframes), "--height", str(args.height), "--width", str(args.width),
+           "--mlp-dtype", args.mlp_dtype, "--rays", str(args.rays)]
+    for flag in ("optimize_poses", "static_loss_scale", "no_fuse_grid_adam", "no_graph", "no_overlap", "no_pose_overlap",
+                 "commit_in_graph", "commit_behind_replay", "pipeline_single_gpu"):
+        if getattr(args, flag, False):
+            out.append("--" + flag.replace("_", "-"))
+    if args.grid_bwd_mode is not None:
+        out += ["--grid-bwd-mode", *[str(m) for m in args.grid_bwd_mode]]
+    return out
+
+
+def live_pmc_summary(config_argv: list, steps: int = 20, warmup: int = 5, timeout_s: int = 240):
     """HBM traffic counters of THIS build in THIS session: two child runs of the bench command under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
     MI355X_MICROARCH.md's HBM section prescribes; the counters serialise the kernels, so they cannot ride in the timed
@@ -136,23 +150,44 @@ def live_pmc_summary(steps: int = 20, warmup: int = 5, timeout_s: int = 240):
     except OSError:
         rev = ""
     env["NVO_COMMIT"] = (rev or "unknown") + " (collected by the bench run that printed the line)"
-    cmd_tail = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--psnr", "off",
-                "--cpu-baseline", "off", "--late-steps", "0", "--no-kernel-table", "--render-frames", "0", "--ngp-steps", "0",
-                "--pmc-traffic", "off"]
+    # the child measures the SAME configuration as this process (workload, dtype, rays, pose optimisation, loss scale,
+    # optimiser form ...): only the reporting sections are switched off
+    cmd_tail = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), *config_argv,
+                "--psnr", "off", "--cpu-baseline", "off", "--late-steps", "0", "--no-kernel-table", "--render-frames", "0",
+                "--ngp-steps", "0", "--mapping-loop", "off", "--pmc-traffic", "off"]
+    import signal
+
     for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, sub), "--", *cmd_tail]
         try:
-            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
-                                 timeout=timeout_s)
-        except (OSError, subprocess.TimeoutExpired) as exc:
+            # own process group: on a timeout the WHOLE group goes (rocprofv3 is a wrapper; killing it alone would leave
+            # its python child on the GPU)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+        except OSError as exc:
             return None, f"{counter} pass: {type(exc).__name__}"
-        if res.returncode != 0:
-            return None, f"{counter} pass exited {res.returncode}: {res.stderr[-300:]}"
+        try:
+            _, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)  # (the exact group this call started)
+            except OSError:
+                pass
+            proc.communicate()
+            return None, f"{counter} pass: timed out after {timeout_s} s (process group killed)"
+        if proc.returncode != 0:
+            return None, f"{counter} pass exited {proc.returncode}: {(err or '')[-300:]}"
     out = os.path.join(work, "pmc_fetch_write_per_kernel.json")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(work, "fetch"),
                           os.path.join(work, "write"), out, str(steps + warmup)], env=env, capture_output=True, text=True)
     if res.returncode != 0 or not os.path.exists(out):
         return None, f"pmc_traffic.py: {res.stderr[-300:]}"
+    try:  # the summary names the configuration it was collected on
+        data = json.load(open(out))
+        data["bench_argv"] = config_argv
+        json.dump(data, open(out, "w"), indent=1)
+    except (OSError, ValueError):
+        pass
     try:  # keep the summary next to the run's other outputs (copied to profiles/ by hand when it is to be judged)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         shutil.copy(out, os.path.join(ROOT, "gpurun_out", "live_pmc_fetch_write_per_kernel.json"))
@@ -289,6 +324,10 @@ def main() -> None:
                     help="roofline.traffic: live = two child runs of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "(about a minute; falls back to the committed summary and says so), committed = the latest "
                          "profiles/*_pmc_fetch_write_per_kernel.json, off = null")
+    ap.add_argument("--mapping-loop", choices=("on", "off"), default="on",
+                    help="the reference's whole mapping run (BASELINE configs[1] 'full mapping loop'): 8192 iterations through the "
+                         "MappingModule / Nerfstudio mirrors with the ingest cadence, default kernels, fixed exact poses; wall seconds, "
+                         "timed windows as the field trains, kernel table of the trained-field step (tools/mapping_loop.py; ~8 s)")
     ap.add_argument("--pipeline-single-gpu", action="store_true",
                     help="run the next step's sampling prefix beside the fields Adam inside this step's graph (A/B; measured neutral)")
     args = ap.parse_args()
@@ -297,11 +336,14 @@ def main() -> None:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if os.environ.get("NVO_BENCH_DRY") == "1":
         raise SystemExit(dry_run(args))
+    default_args = ap.parse_args([])  # (what the committed PMC summaries were collected on)
+    for a_ in (args, default_args):
+        wl = WORKLOADS[a_.workload]
+        a_.keyframes = a_.keyframes or wl["keyframes"]
+        a_.height = a_.height or wl["height"]
+        a_.width = a_.width or wl["width"]
+        a_.mlp_dtype = a_.mlp_dtype or wl["mlp_dtype"]
     wl = WORKLOADS[args.workload]
-    args.keyframes = args.keyframes or wl["keyframes"]
-    args.height = args.height or wl["height"]
-    args.width = args.width or wl["width"]
-    args.mlp_dtype = args.mlp_dtype or wl["mlp_dtype"]
     use_normals = wl["normals"]
     if args.no_cpu_baseline:
         args.cpu_baseline = "off"
@@ -509,10 +551,15 @@ def main() -> None:
             achieved = b / avg_s / 1e9
             live_path = live_err = None
             if args.pmc_traffic == "live" and world == 1:
-                live_path, live_err = live_pmc_summary()
+                live_path, live_err = live_pmc_summary(workload_argv(args))
                 if live_err:
                     sys.stderr.write(f"[bench] live PMC passes failed ({live_err}); using the committed summary\n")
-            traffic, traffic_src, traffic_raw = (None, None, None) if args.pmc_traffic == "off" else pmc_traffic(name, live_path)
+            # a COMMITTED summary was collected on the default command line: it says nothing about another configuration
+            default_cfg = workload_argv(args) == workload_argv(default_args)
+            if args.pmc_traffic == "off" or (live_path is None and not default_cfg):
+                traffic, traffic_src, traffic_raw = None, ("no PMC summary for this configuration" if args.pmc_traffic != "off" else None), None
+            else:
+                traffic, traffic_src, traffic_raw = pmc_traffic(name, live_path)
             if live_err and traffic_src:
                 traffic_src += f" (live passes failed: {live_err[:80]})"
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -687,6 +734,17 @@ def main() -> None:
         else:  # explicitly labelled fallback: a 256-ray sample of the same step
             cpu_baseline = time_cpu_step(num_rays=args.cpu_baseline_rays, num_images=8)
 
+    # ---- the reference's whole mapping run (BASELINE configs[1]: "full mapping loop"): MappingModule.step -> Nerfstudio(update |
+    # train), 8192 iterations with the ingest cadence, default (non-deterministic) kernels, fixed exact poses
+    mapping_loop = None
+    if rank == 0 and world == 1 and args.mapping_loop == "on" and args.workload in ("replica", "replica360"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import mapping_loop as mapping_loop_mod
+
+        mapping_loop = mapping_loop_mod.run(keyframes=args.keyframes, height=args.height, width=args.width, iterations=8192,
+                                            profile_steps=0 if args.no_kernel_table else 60,
+                                            camera_optimizer_mode="SE3" if args.optimize_poses else "off")
+
     # ---- render PSNR (rank 0, N=1): outside the timed region, separate end-to-end mapping runs scored by the reference's
     # PUBLISHED protocol (tools/eval_protocol.py: frame-0 pose alignment + median depth scale, evaluation frames at
     # ground-truth poses carried into the model's world, JPEG / 16-bit PNG files, the reference's metrics --
@@ -794,6 +852,7 @@ def main() -> None:
             "late_schedule": late,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "mapping_loop": mapping_loop,
             "render_psnr": render_psnr,
             "render": render,
             "ngp": ngp,

@@ -465,6 +465,7 @@ struct GridModule : nvo_module_s {
     // with another batch size) is never read as dy/dx: the matching backward then takes the gather form.
     int prepare_input_gradients = 0;
     bool fwd_runs = false;  // option "grid_fwd_runs": the forward walks runs of four consecutive samples (k_grid_fwd_runs)
+    int fwd_small_form = -1;  // option "grid_fwd_small_form": form of the small-grid forward (nvo_grid_fwd_launch), -1 = default
     bool dydx_valid = false;
     uint32_t dydx_batch = 0;
     uint64_t dydx_bytes(uint32_t B) const { return nvo_round_up((uint64_t)g.n_levels * 3 * B * 4, 256); }
@@ -472,7 +473,7 @@ struct GridModule : nvo_module_s {
     int fwd_encode(hipStream_t s, uint32_t B, const float* in, const void* table, void* out, bool soa, void* dydx) {
         dydx_valid = dydx != nullptr;
         dydx_batch = B;
-        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16, n_live, fwd_runs);
+        return nvo_grid_fwd_launch(g, s, B, in, table, out, soa, nullptr, dydx, bf16, n_live, fwd_runs, fwd_small_form);
     }
     int bwd_input(hipStream_t s, uint32_t B, const float* in, const void* table, const void* dout, bool soa,
                   float* din, const void* dydx) {
@@ -512,6 +513,11 @@ struct GridModule : nvo_module_s {
         if (!strcmp(key, "external_zero")) return set_external_zero(value != 0);
         if (!strcmp(key, "grid_fwd_runs")) {
             fwd_runs = value != 0;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "grid_fwd_small_form")) {
+            NVO_REQUIRE(value >= -1 && value <= 4, "grid_fwd_small_form: -1 (default) or 0..4");
+            fwd_small_form = (int)value;
             return NVO_OK;
         }
         if (!strcmp(key, "grid_compact_live")) {  // slice-owner items scan only the samples with a non-zero gradient

@@ -525,6 +525,401 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
 #endif
 }
 
+// k_grid_fwd_small, SOFTWARE-PIPELINED (round 6).  A fit of the two training launches (1 M samples 33 us, 393 K samples
+// 26 us) puts ~22 us of every launch into what does not scale with the samples: the LDS staging ran as ~10 dependent
+// L2 round trips (one 16-byte load -> store per thread and iteration), and every pass of a workgroup exposed its own
+// position load and gather latencies one after the other.  Here (a) all staging loads of a thread are in flight at once
+// (<= kStageMax x 16 bytes in registers), (b) the first pass's positions and global-level gathers are requested BEFORE the
+// staging loads are waited for, (c) pass p + 2's positions and pass p + 1's gathers are in flight while pass p is consumed
+// (loads return in issue order, so each wait only covers what was issued before it).  Same arithmetic, same order, one
+// rounding: bit-identical to k_grid_fwd_small.
+constexpr int kStageMax = 10;  // 10 x 16 B x 1024 threads = 160 KiB >= the 152 KiB the launcher admits
+
+template <int NLDS, int NG>
+__global__ void __launch_bounds__(kSmallBlock)
+k_grid_fwd_small_pipe(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                      __half2* __restrict__ out, int out_bf16, uint32_t per_block) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const uint32_t* __restrict__ tab32 = reinterpret_cast<const uint32_t*>(table);
+    const uint32_t first = blockIdx.x * per_block;
+    const uint32_t last = min(N, first + per_block);
+    if (first >= last) return;  // (uniform)
+    const uint32_t n_pass = (last - first + kSmallBlock - 1u) / kSmallBlock;
+    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out);
+
+    struct Pos { float v[3]; };
+    auto load_pos = [&](uint32_t pass) {  // (unconditional; a slot past the end re-reads the last sample and stores nothing)
+        const uint32_t ic = min(first + pass * kSmallBlock + threadIdx.x, last - 1u);
+        Pos p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.v[k] = x[3 * (size_t)ic + k];
+        return p;
+    };
+    // What a gather leaves in registers is consumed a pass later, and NOTHING is computed from a loaded value next to its
+    // load: a select or convert behind a load inside a lane-divergent branch makes the compiler wait for that load right
+    // there (the value must exist at the join), which serialised the twelve gathers of a sample into twelve L2 round trips
+    // in the first form of this kernel.  Per (y, z) pair: `pr` = the aligned 8-byte pair that holds corner x (hashed levels;
+    // on dense levels the 8 bytes at corner x), `ex` = corner x + 1 where `pr` does not hold it -- requested under a
+    // branch that contains the load alone, so only the lanes that need it reach the L1.
+    Corner cg[NG];
+    uint2 pr[NG][4];
+    uint32_t ex[NG][4];
+    uint32_t sel[NG];  // bit j: corner x of pair j is pr.y (hashed, odd index); bit 4 + j: corner x + 1 comes from ex
+    auto issue = [&](const Pos& p) {  // cells of the global levels + every gather of the sample
+        // index arithmetic of ALL pairs first (the dense levels' modulo sits behind a branch), then nothing but loads: a
+        // register written between two loads can collide with an outstanding load's destination and wait for it
+        uint32_t a0[NG][4], a1[NG][4];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const uint32_t level = NLDS + q;
+            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+            const uint32_t hashed = g.hashed[level];
+            cg[q] = grid_cell(g.scale[level], p.v[0], p.v[1], p.v[2]);
+            sel[q] = 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t cy = cg[q].py + (j & 1u), cz = cg[q].pz + (j >> 1);
+                const uint32_t i0c = nvo_grid_index(hashed, size, res, cg[q].px, cy, cz);
+                const uint32_t i1c = nvo_grid_index(hashed, size, res, cg[q].px + 1u, cy, cz);
+                // hashed: idx1 == idx0 ^ 1 when the cell's x is even -- both corners in one aligned pair; dense: x neighbours
+                // are neighbours in memory unless the pair straddles the table's wrap (dword alignment suffices; the last
+                // entry's pair would reach past the level: taken one entry lower and read from .y)
+                const bool hi = hashed ? (i0c & 1u) != 0u : (i0c + 1u >= size);
+                const bool extra = hashed ? (cg[q].px & 1u) != 0u : (i1c != i0c + 1u);
+                a0[q][j] = off + (hashed ? (i0c & ~1u) : (hi ? i0c - 1u : i0c));
+                a1[q][j] = off + i1c;
+                sel[q] |= (hi ? 1u : 0u) << j | (extra ? 16u : 0u) << j;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                pr[q][j] = *reinterpret_cast<const uint2*>(tab32 + a0[q][j]);
+                ex[q][j] = 0u;
+                if ((sel[q] >> (4u + j)) & 1u) ex[q][j] = tab32[a1[q][j]];
+            }
+        }
+    };
+    auto corner = [&](int q, uint32_t k) -> uint32_t {  // raw half2 of corner k (bit 0: x, bit 1: y, bit 2: z)
+        const uint32_t j = k >> 1;
+        const bool hi = (sel[q] >> j) & 1u, extra = (sel[q] >> (4u + j)) & 1u;
+        if ((k & 1u) == 0u) return hi ? pr[q][j].y : pr[q][j].x;
+        return extra ? ex[q][j] : (hi ? pr[q][j].x : pr[q][j].y);
+    };
+
+    Pos p0 = load_pos(0u);
+    {   // staging: every load of the thread requested before the first is stored
+        const uint32_t n4 = g.offset[NLDS] >> 2;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+        uint4 st[kStageMax];
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) st[k] = src[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)];
+        issue(p0);  // (the first pass's gathers fly with the staging loads)
+        // (branch-free: a slot past the end re-writes the last vector's own value -- a store under `if (e < n4)` lets the
+        // compiler sink each load into its branch, which is the load -> wait -> store chain this form is there to avoid)
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) dst[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)] = st[k];
+    }
+    __syncthreads();
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+        const uint32_t i = first + pass * kSmallBlock + threadIdx.x;
+        // (a value carried into the next iteration while its load is still in flight would be waited for at the loop's
+        // register copies together with everything requested after it: the next positions are requested here, have arrived
+        // by the time the gathers have, and only then take p0's place)
+        const Pos p1 = load_pos(min(pass + 1u, n_pass - 1u));
+        const bool live = i < last;
+        // ---- LDS levels while the gathers fly
+        if (live) {
+#pragma unroll
+            for (int l = 0; l < NLDS; ++l) {
+                const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+                const uint32_t* tl = lds_tab + off;
+                const Corner c = grid_cell(g.scale[l], p0.v[0], p0.v[1], p0.v[2]);
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t idx = nvo_grid_index(0u, size, res, c.px + (k & 1u), c.py + ((k >> 1) & 1u), c.pz + ((k >> 2) & 1u));
+                    const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                    ((k & 4u) ? c.wz : 1.f - c.wz);
+                    const float2 f = __half22float2(__builtin_bit_cast(__half2, tl[idx]));
+                    r0 = fmaf(w, f.x, r0);
+                    r1 = fmaf(w, f.y, r1);
+                }
+                o32[(size_t)l * N + i] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+            }
+        }
+        // ---- consume this pass's gathers
+        uint32_t rg[NG];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Corner& c = cg[q];
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const float w = ((k & 1u) ? c.wx : 1.f - c.wx) * ((k & 2u) ? c.wy : 1.f - c.wy) *
+                                ((k & 4u) ? c.wz : 1.f - c.wz);
+                const float2 f = __half22float2(__builtin_bit_cast(__half2, corner(q, k)));
+                r0 = fmaf(w, f.x, r0);
+                r1 = fmaf(w, f.y, r1);
+            }
+            rg[q] = nvo_cvt16x2(r0, r1, out_bf16 != 0);
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q) o32[(size_t)(NLDS + q) * N + i] = rg[q];
+        }
+        // ---- next pass's gathers
+        if (pass + 1u < n_pass) issue(p1);  // (uniform)
+        p0 = p1;
+    }
+}
+
+// k_grid_fwd_small, INSTRUCTION-LEAN (round 6).  The phase clocks (profiles/r6_grid_phase_fwd_small.txt) and an A/B of
+// the pipelined form above against the plain one (no gain with every gather in flight) say what bounds this kernel: not a
+// memory system rate but the vector ALU -- a wave64 instruction occupies its SIMD for 4 cycles (16 for the quarter-rate
+// 32-bit multiplies), four waves share a SIMD, and the first form spent ~900 issue slots per sample on 40 corners: every
+// corner's index from scratch (v_mad_u64_u32 / v_mul_lo_u32: the compiler neither knows that cell coordinates fit 24
+// bits nor that (py + 1) P = py P + P), 64-bit address arithmetic per load, both index rules compiled into every level
+// and chosen at run time, both 16-bit output formats computed and selected.  Here:
+//   * which global levels are hashed (HMASK) and the output format (BF) are template parameters;
+//   * dense levels: ONE base index per sample from 24-bit multiplies (exact: coordinates <= resolution <= 2^12, checked
+//     against the level's resolution first), corners = base + per-level constants; a sample whose cell touches the upper
+//     domain faces (an index may wrap) or lies outside the level (positions outside [0, 1]) takes the generic rule,
+//     corner by corner -- the same values, behind a branch that training batches never take;
+//   * hashed levels: two 32-bit multiplies per sample and level, the 4 (y, z) combinations by xor, both x corners from
+//     them; the aligned 8-byte pair where the cell's x is even (as before);
+//   * 32-bit byte offsets against scalar base pointers (saddr loads / stores) instead of 64-bit pointer arithmetic;
+//   * corner weights as (wx' wy') wz' exactly as the reference order has them, 12 multiplies per level;
+//   * waves past the workgroup's last sample leave the pass loop, and the workgroups' shares are wave-granular (the
+//     second proposal level's 393 216 samples are 1.5 passes per workgroup: the first form ran 2 on 192 of the 256 CUs);
+//   * the software pipeline of k_grid_fwd_small_pipe (staging loads in flight, next positions / gathers requested early).
+// Same fp32 interpolation, same order, one rounding: bit-identical to k_grid_fwd_small (tools/probes/fwd_small_ab.py).
+struct __attribute__((packed, aligned(4))) NvoU2A4 {  // two dwords at dword alignment (x neighbours of a dense level)
+    uint32_t x, y;
+};
+
+template <bool BF>
+__device__ __forceinline__ uint32_t lean_cvt16x2(float a, float b) {
+    asm("" : "+v"(a));  // (as nvo_cvt16: fp32 first, then ONE rounding to 16 bits, whatever the surrounding code)
+    asm("" : "+v"(b));
+    if constexpr (BF)
+        return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+    else
+        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+}
+
+// weights of the 4 (y, z) pairs: [j][0] = x-even corner, [j][1] = x-odd corner; (wx' * wy') * wz' as k_grid_fwd.  Written on
+// two-float vectors: the x-even / x-odd halves of every product are one v_pk_mul_f32 (6 instead of 12 multiplies a level).
+typedef float nvo_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lean_weights(const Corner& c, float (&w)[4][2]) {
+    const float wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+    const nvo_v2f wxp = {1.f - c.wx, c.wx};
+    const nvo_v2f a0 = wxp * wy0, a1 = wxp * c.wy;
+    const nvo_v2f w0 = a0 * wz0, w1 = a1 * wz0, w2 = a0 * c.wz, w3 = a1 * c.wz;
+    w[0][0] = w0.x; w[0][1] = w0.y;
+    w[1][0] = w1.x; w[1][1] = w1.y;
+    w[2][0] = w2.x; w[2][1] = w2.y;
+    w[3][0] = w3.x; w[3][1] = w3.y;
+}
+
+template <bool BF>
+__device__ __forceinline__ uint32_t lean_interp(const float (&w)[4][2], const uint32_t (&even)[4], const uint32_t (&odd)[4]) {
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 fe = __half22float2(__builtin_bit_cast(__half2, even[j]));
+        const float2 fo = __half22float2(__builtin_bit_cast(__half2, odd[j]));
+        r0 = fmaf(w[j][0], fe.x, r0);
+        r1 = fmaf(w[j][0], fe.y, r1);
+        r0 = fmaf(w[j][1], fo.x, r0);
+        r1 = fmaf(w[j][1], fo.y, r1);
+    }
+    return lean_cvt16x2<BF>(r0, r1);
+}
+
+template <int NLDS, int NG, uint32_t HMASK, bool BF>
+__global__ void __launch_bounds__(kSmallBlock)
+k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                      __half2* __restrict__ out, uint32_t per_block) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const unsigned char* __restrict__ tab8 = reinterpret_cast<const unsigned char*>(table);
+    const unsigned char* __restrict__ x8 = reinterpret_cast<const unsigned char*>(x);
+    unsigned char* __restrict__ o8 = reinterpret_cast<unsigned char*>(out);
+    const uint32_t first = blockIdx.x * per_block;
+    const uint32_t last = min(N, first + per_block);
+    if (first >= last) return;  // (uniform)
+    const uint32_t n_pass = (last - first + kSmallBlock - 1u) / kSmallBlock;
+    const uint32_t wave_first = first + (threadIdx.x & ~63u);  // first sample of this wave in pass 0
+
+    struct Pos { float v[3]; };
+    auto load_pos = [&](uint32_t pass) {  // (unconditional; a slot past the end re-reads the last sample and stores nothing)
+        const uint32_t ic = min(first + pass * kSmallBlock + threadIdx.x, last - 1u);
+        const float* p = reinterpret_cast<const float*>(x8 + ic * 12u);  // (32-bit byte offset: N < 2^32 / 12, launcher)
+        Pos r;
+        r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2];
+        return r;
+    };
+
+    // Per global level and (y, z) pair j, what a gather leaves in registers (nothing is computed from a loaded value next to
+    // its load, see k_grid_fwd_small_pipe):
+    //   hashed level: with pe = px & ~1, the entries of x = pe and x = pe + 1 differ in index bit 0 only -- `pr` = that aligned
+    //     8-byte pair (it holds corner px whatever its parity, and corner px + 1 when px is even), `ex` = corner px + 1 when px
+    //     is odd.  Which half of the pair is x = pe: bit 0 of the (y, z) hash = (py ^ pz ^ j ^ (j >> 1)) & 1 (both primes are
+    //     odd) -- TWO lane predicates per level (parity of px, parity of py ^ pz) decide every select of the level.
+    //   dense level: `pr` = corner px and its memory neighbour px + 1 (the generic rule for a cell on the upper domain faces
+    //     loads the two corners separately into the same registers).
+    Corner cg[NG];
+    uint2 pr[NG][4];
+    uint32_t ex[NG][4];
+    auto issue = [&](const Pos& p) {
+        uint32_t a0[NG][4], a1[NG][4];  // BYTE offsets from the table's base
+        bool split[NG];                 // dense level: this sample takes the generic rule
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const uint32_t level = NLDS + q;
+            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+            cg[q] = grid_cell(g.scale[level], p.v[0], p.v[1], p.v[2]);
+            const Corner& c = cg[q];
+            split[q] = false;
+            if ((HMASK >> q) & 1u) {  // (a constant once the loop is unrolled)
+                const uint32_t mask = size - 1u;
+                const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
+                const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
+                const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    a0[q][j] = (off + ((c.px ^ a[j]) & mask & ~1u)) << 2;
+                    a1[q][j] = (off + (((c.px + 1u) ^ a[j]) & mask)) << 2;
+                }
+            } else {
+                const uint32_t res2 = res * res;  // (scalar)
+                // fast rule: cell inside the level and no corner index reaches the table's end => index = base + constant
+                const uint32_t base = c.px + __umul24(c.py, res) + __umul24(c.pz, res2);
+                split[q] = !(max(max(c.px, c.py), c.pz) < res && base + res2 + res + 1u < size);
+                const uint32_t dj[4] = {0u, res, res2, res2 + res};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    uint32_t i0c = base + dj[j], i1c = i0c + 1u;
+                    if (split[q]) {  // the generic rule, corner by corner (upper domain faces; positions outside [0, 1])
+                        const uint32_t cy = c.py + (j & 1u), cz = c.pz + (j >> 1);
+                        i0c = nvo_grid_index(0u, size, res, c.px, cy, cz);
+                        i1c = nvo_grid_index(0u, size, res, c.px + 1u, cy, cz);
+                    }
+                    a0[q][j] = (off + i0c) << 2;
+                    a1[q][j] = (off + i1c) << 2;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if ((HMASK >> q) & 1u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    pr[q][j] = *reinterpret_cast<const uint2*>(tab8 + a0[q][j]);
+                    ex[q][j] = 0u;
+                }
+                if (cg[q].px & 1u) {  // (the branch holds the four loads alone)
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) ex[q][j] = *reinterpret_cast<const uint32_t*>(tab8 + a1[q][j]);
+                }
+            } else {
+                if (!split[q]) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const NvoU2A4 v = *reinterpret_cast<const NvoU2A4*>(tab8 + a0[q][j]);
+                        pr[q][j] = make_uint2(v.x, v.y);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        pr[q][j].x = *reinterpret_cast<const uint32_t*>(tab8 + a0[q][j]);
+                        pr[q][j].y = *reinterpret_cast<const uint32_t*>(tab8 + a1[q][j]);
+                    }
+                }
+            }
+        }
+    };
+
+    Pos p0 = load_pos(0u);
+    {   // staging: every load of the thread requested before the first is stored
+        const uint32_t n4 = g.offset[NLDS] >> 2;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+        uint4 st[kStageMax];
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) st[k] = src[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)];
+        issue(p0);  // (the first pass's gathers fly with the staging loads)
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) dst[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)] = st[k];
+    }
+    __syncthreads();
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+        if (wave_first + pass * kSmallBlock >= last) break;  // (wave-uniform: nothing of this wave is left; no barrier below)
+        const uint32_t i = first + pass * kSmallBlock + threadIdx.x;
+        const Pos p1 = load_pos(min(pass + 1u, n_pass - 1u));
+        const bool live = i < last;
+        // ---- LDS levels while the gathers fly
+#pragma unroll
+        for (int l = 0; l < NLDS; ++l) {
+            const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+            const uint32_t res2 = res * res;
+            const Corner c = grid_cell(g.scale[l], p0.v[0], p0.v[1], p0.v[2]);
+            const uint32_t base = c.px + __umul24(c.py, res) + __umul24(c.pz, res2);
+            const bool fast = max(max(c.px, c.py), c.pz) < res && base + res2 + res + 1u < size;
+            const uint32_t* tl = lds_tab + off;
+            uint32_t even[4], odd[4];
+            if (fast) {
+                const uint32_t* b = tl + base;
+                even[0] = b[0]; odd[0] = b[1];
+                even[1] = b[res]; odd[1] = b[res + 1u];
+                even[2] = b[res2]; odd[2] = b[res2 + 1u];
+                even[3] = b[res2 + res]; odd[3] = b[res2 + res + 1u];
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t cy = c.py + (j & 1u), cz = c.pz + (j >> 1);
+                    even[j] = tl[nvo_grid_index(0u, size, res, c.px, cy, cz)];
+                    odd[j] = tl[nvo_grid_index(0u, size, res, c.px + 1u, cy, cz)];
+                }
+            }
+            float w[4][2];
+            lean_weights(c, w);
+            const uint32_t r = lean_interp<BF>(w, even, odd);
+            if (live) *reinterpret_cast<uint32_t*>(o8 + (((uint32_t)l * N + i) << 2)) = r;
+        }
+        // ---- consume this pass's gathers
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            uint32_t even[4], odd[4];
+            if ((HMASK >> q) & 1u) {
+                const bool px_odd = (cg[q].px & 1u) != 0u;
+                const bool t = (((cg[q].py ^ cg[q].pz) & 1u) != 0u) != px_odd;  // corner px sits in pr.y for j = 0, 3 (pr.x for 1, 2)
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const bool hi = (j == 0u || j == 3u) ? t : !t;
+                    even[j] = hi ? pr[q][j].y : pr[q][j].x;
+                    odd[j] = px_odd ? ex[q][j] : (hi ? pr[q][j].x : pr[q][j].y);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    even[j] = pr[q][j].x;
+                    odd[j] = pr[q][j].y;
+                }
+            }
+            float w[4][2];
+            lean_weights(cg[q], w);
+            const uint32_t r = lean_interp<BF>(w, even, odd);
+            if (live) *reinterpret_cast<uint32_t*>(o8 + (((uint32_t)(NLDS + q) * N + i) << 2)) = r;
+        }
+        // ---- next pass's gathers
+        if (wave_first + (pass + 1u) * kSmallBlock < last) issue(p1);  // (wave-uniform)
+        p0 = p1;
+    }
+}
+
 // The same over RUNS of four consecutive samples per thread (see k_grid_fwd_runs): the first proposal level's samples are
 // 256 per ray at uniform lin-disp spacing whatever the state of training -- 3.8 / 2.2 / 1.3 samples per cell on its three
 // global levels -- so a thread that walks four neighbours gathers once per cell change.  Level by level (the values of
@@ -2076,13 +2471,16 @@ static uint32_t grid_fwd_plan_build(const NvoGridLevels& g, uint32_t tiles, Grid
 
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices, void* dydx_half,
-                        bool out_bf16, const uint32_t* n_live, bool runs) {
+                        bool out_bf16, const uint32_t* n_live, bool runs, int small_form) {
     if (N == 0) return NVO_OK;
     NVO_REQUIRE(g.n_features == 2, "grid: only n_features_per_level == 2 is supported (got %u)",
                 g.n_features);
     NVO_PROF(stream, "grid_fwd[L%u]", g.n_levels);
     // small grids (the proposal networks): the two coarsest dense levels from LDS, a thread per sample (k_grid_fwd_small)
-    static const int small_env = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 1; }();  // 0 off | 1 | 2 samples per thread (2 measured slower: 35.0 vs 33.6 us)
+    // 0 off | 1 plain | 2 two samples per thread (measured slower: 35.0 vs 33.6 us) | 3 software-pipelined (round 6: no gain,
+    // the kernel is bound by vector-instruction issue) | 4 instruction-lean + pipelined (round 6, default)
+    static const int small_default = [] { const char* e = getenv("NVO_GRID_FWD_SMALL"); return e ? atoi(e) : 4; }();
+    const int small_env = small_form >= 0 ? small_form : small_default;  // (module option grid_fwd_small_form: tests, A/B)
     if (small_env && soa && !indices && !dydx_half && !n_live && g.n_levels == 5 && !g.hashed[0] && !g.hashed[1] &&
         (size_t)g.offset[2] * 4 <= 152 * 1024 && (g.offset[2] & 3u) == 0u && (((uintptr_t)table_half) & 15u) == 0u) {
         static const uint32_t n_cus = [] {
@@ -2096,6 +2494,8 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
             NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               152 * 1024));
             NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              152 * 1024));
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small_pipe<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               152 * 1024));
             attr_set = true;
         }
@@ -2115,9 +2515,36 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
             return NVO_OK;
         }
         // one workgroup per CU, a whole number of passes each
-        const uint32_t spt = small_env >= 2 ? 2u : 1u;
+        const uint32_t spt = small_env == 2 ? 2u : 1u;
+        const uint32_t hmask = (g.hashed[2] ? 1u : 0u) | (g.hashed[3] ? 2u : 0u) | (g.hashed[4] ? 4u : 0u);
+        if (small_env >= 4 && (hmask == 6u || hmask == 7u || hmask == 4u) && (uint64_t)N * 20u < (1ull << 32) &&
+            g.resolution[0] <= 4096u && g.resolution[1] <= 4096u && g.resolution[2] <= 4096u) {
+            // the instruction-lean form: wave-granular shares (a workgroup's last pass may be partly empty: its idle waves leave)
+            const uint32_t per_lean = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), 64u);
+            const dim3 gl(nvo_div_up(N, per_lean));
+#define NVO_LAUNCH_LEAN(HM_, BF_)                                                                                          \
+    do {                                                                                                                   \
+        static bool attr_lean = false;                                                                                     \
+        if (!attr_lean) {                                                                                                  \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small_lean<2, 3, HM_, BF_>,                          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));                    \
+            attr_lean = true;                                                                                              \
+        }                                                                                                                  \
+        NVO_LAUNCH((k_grid_fwd_small_lean<2, 3, HM_, BF_>), gl, dim3(kSmallBlock), lds, stream, g, N, x,                   \
+                   (const __half2*)table_half, (__half2*)out_half, per_lean);                                              \
+    } while (0)
+            if (hmask == 6u) { if (out_bf16) NVO_LAUNCH_LEAN(6u, true); else NVO_LAUNCH_LEAN(6u, false); }
+            else if (hmask == 7u) { if (out_bf16) NVO_LAUNCH_LEAN(7u, true); else NVO_LAUNCH_LEAN(7u, false); }
+            else { if (out_bf16) NVO_LAUNCH_LEAN(4u, true); else NVO_LAUNCH_LEAN(4u, false); }
+#undef NVO_LAUNCH_LEAN
+            NVO_CHECK_LAUNCH();
+            return NVO_OK;
+        }
         const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock * spt);
-        if (spt == 2)
+        if (small_env >= 3)
+            NVO_LAUNCH((k_grid_fwd_small_pipe<2, 3>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
+                       (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
+        else if (spt == 2)
             NVO_LAUNCH((k_grid_fwd_small<2, 3, 2>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
                        (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
         else

@@ -145,7 +145,10 @@ void nvo_grid_slices_destroy(NvoGridSlices* s);
 int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const float* x,
                         const void* table_half, void* out_half, bool soa, uint32_t* indices,
                         void* dydx_half = nullptr, bool out_bf16 = false, const uint32_t* n_live = nullptr,
-                        bool runs = false);
+                        bool runs = false, int small_form = -1);
+// small_form: form of the small-grid forward (5-level grids whose two coarsest levels fit the LDS): -1 = the default
+// (NVO_GRID_FWD_SMALL, else the instruction-lean form), 0 = the generic kernel, 1 plain, 2 two samples per thread,
+// 3 software-pipelined, 4 instruction-lean + pipelined.  All forms produce the same bits.
 int nvo_grid_bwd_input_dydx_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, const void* dydx_half,
                                    const void* dy, int dy_fmt, bool soa, float* dx, bool zero_dx);
 int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hipStream_t stream,

@@ -847,3 +847,48 @@ def test_double_backward_raises_like_upstream(device):
         g2.sum().backward()
     with pytest.raises(NotImplementedError, match="bwd_bwd_input"):
         net.native_tcnn_module.bwd_bwd_input()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [PROP0, PROP1], ids=["prop0", "prop1"])
+def test_small_grid_forward_forms_are_bit_identical(device, cfg, dtype):
+    """The proposal grids' forward has several forms of ONE arithmetic (module option grid_fwd_small_form: 0 the generic
+    thread-per-(sample, level) kernel, 1 coarse levels from LDS, 3 software-pipelined, 4 instruction-lean -- the default):
+    same fp32 interpolation in the same order, one rounding.  Their outputs must agree bit for bit, on ray-coherent
+    samples, on cells at the domain faces (the dense levels' wrap takes the lean form's generic branch), on positions
+    outside [0, 1] (memory-safe garbage in every form, the SAME garbage), and for batches that end inside a pass."""
+    import nerf_vo_amd.tinycudann as tcnn
+
+    net = tcnn.NetworkWithInputEncoding(3, 1, _enc_cfg(cfg), {"otype": "FullyFusedMLP", "activation": "ReLU",
+                                                              "output_activation": "None", "n_neurons": 16,
+                                                              "n_hidden_layers": 1}).to(device)
+    m = net.native_tcnn_module
+    m.set_option("bf16", int(dtype == "bf16"))
+    with torch.no_grad():
+        net.params.uniform_(-1, 1)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n, S in ((4096 * 96, 96), (1024 * 256 + 640, 256), (131 * 128, 96)):
+        R = (n + S - 1) // S
+        o = (torch.rand(R, 1, 3, generator=g) - 0.5) * 1.2
+        d = torch.nn.functional.normalize(torch.randn(R, 1, 3, generator=g), dim=-1)
+        t = 1.0 / torch.linspace(1.0 / 0.05, 1.0 / 30.0, S).view(1, S, 1)
+        p = o + d * t
+        mag = p.abs().amax(dim=-1, keepdim=True).clamp_min(1e-9)
+        p = torch.where(mag > 1, (2 - 1 / mag) * (p / mag), p)
+        x = ((p + 2) / 4).reshape(-1, 3)[:n].contiguous()
+        x[:7] = torch.from_numpy(_points(16, 3)[:7])          # faces, corners, one ulp inside them
+        x[7:71] = torch.rand(64, 3, generator=g).round()       # every lane of a wave on a face / edge / corner
+        x[71] = torch.tensor([1.5, -0.25, 0.5])                # outside the unit cube
+        x[72] = torch.tensor([-3.0, 7.0, 2.0])
+        x = x.to(device)
+        outs = {}
+        for form in (0, 1, 3, 4):
+            m.set_option("grid_fwd_small_form", form)
+            with torch.no_grad():
+                y = net(x)
+            torch.cuda.synchronize()
+            outs[form] = y.view(torch.int16).cpu()
+        m.set_option("grid_fwd_small_form", -1)
+        for form in (0, 3, 4):
+            diff = int((outs[form] != outs[1]).sum())
+            assert diff == 0, f"form {form} differs from form 1 in {diff} of {outs[1].numel()} outputs (n={n})"

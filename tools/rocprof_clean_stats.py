@@ -7,7 +7,9 @@ kernel-trace CSV instead, keeps the dispatches of THIS library's kernels (k_*) t
 (= after the last graph capture warm-up: the first k_ray_head whose successor k_ray_head is < 5 ms away marks steady
 state) and prints name, calls, total / average / min / max duration and share.
 
-Usage: python tools/rocprof_clean_stats.py <rocprof-output-dir> [--skip-first N] [--head k_rays_given] > stats.csv"""
+`--last N`: only the last N steps of the trace (e.g. the trained-field end of a full mapping run, tools/mapping_loop.py).
+
+Usage: python tools/rocprof_clean_stats.py <rocprof-output-dir> [--skip-first N] [--last N] [--head k_rays_given] > stats.csv"""
 import csv
 import glob
 import os
@@ -36,6 +38,11 @@ def main():
         if all(heads[j + 1] - heads[j] < 5_000_000 for j in range(i, i + 20)):
             start = heads[min(i + skip, len(heads) - 1)]
             break
+    if "--last" in sys.argv:
+        last = int(sys.argv[sys.argv.index("--last") + 1])
+        later = [h for h in heads if h >= start]
+        if len(later) > last:
+            start = later[-last]
     agg = defaultdict(list)
     for t0, t1, n in rows:
         if t0 < start:
