@@ -920,6 +920,167 @@ k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
     }
 }
 
+// k_grid_fwd for the level-major production path, INSTRUCTION-LEAN (round 6): the blockIdx -> (tile, level) plan of
+// k_grid_fwd (XCD-balanced), a thread per (sample, level), SPT samples per thread -- with what k_grid_fwd_small_lean
+// does to the arithmetic: the level's kind is block-uniform and takes one of two straight-line paths; hashed levels
+// compute TWO 32-bit multiplies per sample (the four (y, z) combinations by xor) and fetch the aligned 8-byte pair around
+// corner px plus, for odd px only, corner px + 1 (two lane predicates steer every select) -- one L1 look-up instead of two
+// for half the (y, z) pairs; dense levels one base index from 24-bit multiplies with the generic rule behind a branch;
+// 32-bit byte offsets against scalar bases; packed weight products; the output format a template parameter.
+// Same fp32 interpolation, same order, one rounding: bit-identical to k_grid_fwd.
+template <int SPT, bool BF, bool PAIR>
+__global__ void __launch_bounds__(kGridBlock)
+k_grid_fwd_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                __half2* __restrict__ out, GridFwdPlan plan, const uint32_t* __restrict__ n_live) {
+    uint32_t tile, level;
+    if (plan.enabled) {
+        if (!grid_plan_map(plan, blockIdx.x, &tile, &level)) return;
+    } else {
+        grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    }
+    if (n_live && tile * (kGridBlock * SPT) >= *n_live) return;
+    const uint32_t i_first = tile * (kGridBlock * SPT) + threadIdx.x;
+    if (i_first >= N) return;
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const float scale = g.scale[level];
+    const unsigned char* __restrict__ tab8 = reinterpret_cast<const unsigned char*>(table + off);  // (the level's base)
+    const unsigned char* __restrict__ x8 = reinterpret_cast<const unsigned char*>(x);
+    unsigned char* __restrict__ o8 = reinterpret_cast<unsigned char*>(out) + (size_t)level * N * 4u;
+
+    // NOTHING below is conditional on a sample being in range: a slot past the end re-reads sample N - 1, computes that
+    // sample's value and stores it to that sample's place (the same bits its owner stores).  A store under `if (i < N)`
+    // lets the compiler sink the slot's index arithmetic AND its gathers into the branch -- behind the previous slot's
+    // consumption -- which halves the gathers in flight (measured: 72 against 59 us on an untrained field's batch).
+    uint32_t i[SPT];
+    Corner c[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        i[s] = i_first + (uint32_t)s * kGridBlock;
+        const float* p = reinterpret_cast<const float*>(x8 + min(i[s], N - 1u) * 12u);
+        const float px = p[0], py = p[1], pz = p[2];
+        c[s] = grid_cell(scale, px, py, pz);
+    }
+    uint2 pr[SPT][4];
+    uint32_t ex[SPT][4];
+    if (hashed) {  // (block-uniform)
+        const uint32_t mask = size - 1u;
+        uint32_t a0[SPT][4], a1[SPT][4];
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            const uint32_t hy0 = c[s].py * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = c[s].pz * 805459861u, hz1 = hz0 + 805459861u;
+            const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                a0[s][j] = ((c[s].px ^ a[j]) & mask & (PAIR ? ~1u : ~0u)) << 2;
+                a1[s][j] = (((c[s].px + 1u) ^ a[j]) & mask) << 2;
+            }
+        }
+        if constexpr (PAIR) {
+            // the aligned 8-byte pair around corner px (+ corner px + 1 for odd px): fewer L1 look-ups, but an 8-byte gather
+            // occupies the address path twice as long as a 4-byte one -- measured SLOWER where the gather binds (60 -> 66 us
+            // on the spread samples of an untrained field, tools/probes/fwd_main_ab.py) and kept for the A/B only
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    pr[s][j] = *reinterpret_cast<const uint2*>(tab8 + a0[s][j]);
+                    ex[s][j] = 0u;
+                }
+                if (c[s].px & 1u) {  // (the branch holds the four loads alone)
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) ex[s][j] = *reinterpret_cast<const uint32_t*>(tab8 + a1[s][j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    pr[s][j].x = *reinterpret_cast<const uint32_t*>(tab8 + a0[s][j]);
+                    pr[s][j].y = *reinterpret_cast<const uint32_t*>(tab8 + a1[s][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            uint32_t even[4], odd[4];
+            if constexpr (PAIR) {
+                const bool px_odd = (c[s].px & 1u) != 0u;
+                const bool t = (((c[s].py ^ c[s].pz) & 1u) != 0u) != px_odd;  // corner px sits in pr.y for j = 0, 3 (pr.x for 1, 2)
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const bool hi = (j == 0u || j == 3u) ? t : !t;
+                    even[j] = hi ? pr[s][j].y : pr[s][j].x;
+                    odd[j] = px_odd ? ex[s][j] : (hi ? pr[s][j].x : pr[s][j].y);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    even[j] = pr[s][j].x;
+                    odd[j] = pr[s][j].y;
+                }
+            }
+            float w[4][2];
+            lean_weights(c[s], w);
+            *reinterpret_cast<uint32_t*>(o8 + (min(i[s], N - 1u) << 2)) = lean_interp<BF>(w, even, odd);
+        }
+    } else {
+        const uint32_t res2 = res * res;
+        uint32_t a0[SPT][4], a1[SPT][4];
+        bool split[SPT];
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            const uint32_t base = c[s].px + __umul24(c[s].py, res) + __umul24(c[s].pz, res2);
+            // (24-bit multiplies: exact while coordinates and res^2 stay below 2^24 -- the launcher admits res <= 4096)
+            split[s] = !(max(max(c[s].px, c[s].py), c[s].pz) < res && base + res2 + res + 1u < size);
+            const uint32_t dj[4] = {0u, res, res2, res2 + res};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t i0c = base + dj[j], i1c = i0c + 1u;
+                if (split[s]) {  // the generic rule, corner by corner (upper domain faces; positions outside [0, 1])
+                    const uint32_t cy = c[s].py + (j & 1u), cz = c[s].pz + (j >> 1);
+                    i0c = nvo_grid_index(0u, size, res, c[s].px, cy, cz);
+                    i1c = nvo_grid_index(0u, size, res, c[s].px + 1u, cy, cz);
+                }
+                a0[s][j] = i0c << 2;
+                a1[s][j] = i1c << 2;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            if (!split[s]) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const NvoU2A4 v = *reinterpret_cast<const NvoU2A4*>(tab8 + a0[s][j]);
+                    pr[s][j] = make_uint2(v.x, v.y);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    pr[s][j].x = *reinterpret_cast<const uint32_t*>(tab8 + a0[s][j]);
+                    pr[s][j].y = *reinterpret_cast<const uint32_t*>(tab8 + a1[s][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            uint32_t even[4], odd[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                even[j] = pr[s][j].x;
+                odd[j] = pr[s][j].y;
+            }
+            float w[4][2];
+            lean_weights(c[s], w);
+            *reinterpret_cast<uint32_t*>(o8 + (min(i[s], N - 1u) << 2)) = lean_interp<BF>(w, even, odd);
+        }
+    }
+}
+
 // The same over RUNS of four consecutive samples per thread (see k_grid_fwd_runs): the first proposal level's samples are
 // 256 per ray at uniform lin-disp spacing whatever the state of training -- 3.8 / 2.2 / 1.3 samples per cell on its three
 // global levels -- so a thread that walks four neighbours gathers once per cell change.  Level by level (the values of
@@ -1177,7 +1338,8 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               const AccScale sc = AccScale{0.f, 0.f, 0.f, 0.f},
                                               const uint32_t* __restrict__ live = nullptr, bool merge = false,
                                               uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr,
-                                              const uint32_t* __restrict__ live_n = nullptr, uint32_t ring_off = 0u) {
+                                              const uint32_t* __restrict__ live_n = nullptr, uint32_t ring_off = 0u,
+                                              const uint16_t* __restrict__ codes = nullptr) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -1327,6 +1489,86 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
             }
             if (open && hit) flush();
         }
+    } else if (pair_bins && ring_off != 0u && codes != nullptr && sizeof(DY2) == 4 && ACC::kEntries == 16384u) {
+      if constexpr (sizeof(DY2) == 4 && ACC::kEntries == 16384u) {  // (the launcher hands codes to this combination only)
+        // HASHED level, SLICE CODES (round 6).  The scan below this branch derives every sample's cell, two 32-bit
+        // multiplies and four hashes on EVERY one of the level's 8 slice visits to find the one (y, z) pair in eight that
+        // lands in the slice: ~100 vector instructions per sample and visit, and the launch is bound by exactly that
+        // (1 M samples x 16 hashed visits on ~250 CUs at one wave instruction per cycle and CU).  k_slice_codes derives them
+        // ONCE per (sample, level) and leaves 12 bits -- the slice of each of the four (y, z) pairs; a visit here is a
+        // 2-byte code + the 4-byte gradient, four field compares and one push of {sample | pair mask, gradient} for the
+        // ~40 % of the samples that touch the slice at all; the cell, the hashes and the weights are computed when 64
+        // entries are drained, with every lane busy.  Same products, integer accumulation: bit-identical gradients.
+        const uint32_t my = (first >> 14) & 7u;
+        constexpr uint32_t kCap = 2u * kHitCap;  // 8-byte entries in the wave's ring
+        uint2* const ring = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(lds_raw) + ring_off) +
+                            (threadIdx.x >> 6) * kCap;
+        uint32_t q_head = 0u, q_fill = 0u;
+        auto q_drain = [&](uint32_t n) {  // the n <= 64 oldest entries
+            if (lane_id < n) {
+                uint32_t p = q_head + lane_id;
+                if (p >= kCap) p -= kCap;
+                const uint2 e = ring[p];
+                const uint32_t i = e.x & 0x0FFFFFFFu, m = e.x >> 28;
+                const float2 d = dy2f(__builtin_bit_cast(DY2, e.y));
+                const float* xp = x + 3 * (size_t)i;
+                const Corner c = grid_cell(scale, xp[0], xp[1], xp[2]);
+                const float wx0 = 1.f - c.wx, wy0 = 1.f - c.wy, wz0 = 1.f - c.wz;
+                const float wyz[4] = {wy0 * wz0, c.wy * wz0, wy0 * c.wz, c.wy * c.wz};
+                const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
+                const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
+                const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if ((m >> j) & 1u) {
+                        const uint32_t lo = a[j] & mask & (ACC::kEntries - 1u);
+                        const float u0 = wyz[j] * d.x, u1 = wyz[j] * d.y;
+                        ACC::add(acc, lo ^ c.px, wx0 * u0, wx0 * u1, sc);
+                        ACC::add(acc, lo ^ (c.px + 1u), c.wx * u0, c.wx * u1, sc);
+                    }
+                }
+            }
+            q_head += n;
+            if (q_head >= kCap) q_head -= kCap;
+            q_fill -= n;
+        };
+        for (uint32_t c0 = wave_grab(64u * kUnroll); begin + c0 < end; c0 = wave_grab(64u * kUnroll)) {
+            const uint32_t i0 = begin + c0 + lane_id;
+            uint32_t sid[kUnroll], code[kUnroll], dyr[kUnroll];
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const uint32_t j = i0 + u * 64u;
+                sid[u] = j < end ? (listed ? live[j] : j) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {  // (unconditional loads at a valid index; slots past the end are masked below)
+                code[u] = codes[sid[u]];
+                const DY2 d2 = SOA ? dy[(size_t)level * N + sid[u]] : dy[(size_t)sid[u] * g.n_levels + level];
+                dyr[u] = __builtin_bit_cast(uint32_t, d2);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; ++u) {
+                const bool valid = i0 + u * 64u < end;
+                const float2 d = dy2f(__builtin_bit_cast(DY2, dyr[u]));
+                bad = bad || (valid && (!(fabsf(d.x) < INFINITY) || !(fabsf(d.y) < INFINITY)));
+                uint32_t m = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) m |= (((code[u] >> (3u * j)) & 7u) == my ? 1u : 0u) << j;
+                const bool hit = valid && m != 0u && (d.x != 0.f || d.y != 0.f);
+                // (wave-uniform control flow around the ballot, as in the scan below)
+                const unsigned long long bm = __ballot(hit);
+                const uint32_t cnt = (uint32_t)__popcll(bm);
+                if (hit) {
+                    uint32_t p = q_head + q_fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                    if (p >= kCap) p -= kCap;
+                    ring[p] = make_uint2(sid[u] | (m << 28), dyr[u]);
+                }
+                q_fill += cnt;  // (< 64 before, <= 64 more: never beyond the ring's 254 entries)
+                if (q_fill >= 64u) q_drain(64u);
+            }
+        }
+        while (q_fill) q_drain(min(q_fill, 64u));
+      }
     } else if (pair_bins && ring_off != 0u) {
         // HASHED level with a hit queue (kHitCap).  Everything up to the slice test runs for all 64 lanes; the pairs that
         // fall into this slice (one in `slices of the level` on average) are pushed into the wave's ring -- 16 bytes:
@@ -1573,13 +1815,40 @@ k_dy_l1(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, unsigned long l
     }
 }
 
+// Slice codes of the hashed levels in `levels` (bit l): codes[row][i] = the 16384-entry slice of each of sample i's four
+// (y, z) corner pairs on that level, 3 bits each (pair j in bits 3 j .. 3 j + 2); row = rank of the level among the coded
+// ones.  A level qualifies when it is hashed, a power-of-two multiple of 16384 entries with at most 8 slices, and every x
+// coordinate stays below the slice bits (the slice-owner items' `pair_bins` condition): the slice is then a function of
+// the (y, z) hash alone.  One pass over the positions; what the slice owners otherwise re-derive on every visit.
+__global__ void __launch_bounds__(256)
+k_slice_codes(NvoGridLevels g, uint32_t N, const float* __restrict__ x, uint32_t levels, uint16_t* __restrict__ codes) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= N) return;
+    const float px = x[3 * (size_t)i], py = x[3 * (size_t)i + 1], pz = x[3 * (size_t)i + 2];
+    uint32_t row = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
+        if (!((levels >> l) & 1u)) continue;  // (uniform)
+        const uint32_t mask = g.offset[l + 1] - g.offset[l] - 1u;
+        const Corner c = grid_cell(g.scale[l], px, py, pz);
+        const uint32_t hy0 = c.py * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = c.pz * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        uint32_t code = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) code |= (((a[j] & mask) >> 14) & 7u) << (3u * j);
+        codes[(size_t)row * N + i] = (uint16_t)code;
+        ++row;
+    }
+}
+
 template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(kLdsBwdBlock)
 k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const DY2* __restrict__ dy, float* __restrict__ grad,
                const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
                const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_n,
-               uint32_t ring_off, const float* __restrict__ ext_l1, uint32_t ext_blocks, uint32_t ext_stride) {
+               uint32_t ring_off, const float* __restrict__ ext_l1, uint32_t ext_blocks, uint32_t ext_stride,
+               const uint16_t* __restrict__ codes, uint32_t code_levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
@@ -1623,8 +1892,11 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         sc.s1 = l1y > 0.f ? 536870912.f / l1y : 0.f;
         sc.inv0 = l1x * (1.f / 536870912.f);
         sc.inv1 = l1y * (1.f / 536870912.f);
+        // (slice codes of this level, k_slice_codes: row = number of coded levels below it)
+        const uint16_t* lc = (codes && ((code_levels >> level) & 1u))
+                                 ? codes + (size_t)__builtin_popcount(code_levels & ((1u << level) - 1u)) * N : nullptr;
         grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge, cap, nf_flag, live_n, ring_off);
+                                            merge, cap, nf_flag, live_n, ring_off, lc);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
                                           AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
@@ -2576,7 +2848,30 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
         else if (spt == 2) NVO_LAUNCH_FWD_S(SOA_, false, 2);               \
         else NVO_LAUNCH_FWD_S(SOA_, false, 4);                             \
     } while (0)
-    if (runs) {
+    // the instruction-lean form of the level-major production path (form 0 = the first kernel, kept as the reference form)
+    // NVO_GRID_FWD_LEAN=1 (A/B; default off): k_grid_fwd_lean for the main grid.  Measured (EXPERIMENTS 10.3): faster on
+    // samples clustered within 2 % of the surface (35.5 -> 30.9 us per training batch, 243 -> 199 us per render chunk) but
+    // SLOWER where the gather binds -- the spread samples of an untrained field: 59.5 -> 66 us -- and neutral inside the
+    // mapping loop (windows at iterations 5000 / 7900: 0.398 / 0.385 vs 0.395 / 0.385 ms); the first kernel stays.
+    static const bool lean_env = [] { const char* e = getenv("NVO_GRID_FWD_LEAN"); return e && atoi(e) != 0; }();
+    bool lean = lean_env && small_env != 0 && !runs && soa && !indices && !dydx_half && (uint64_t)N * 12u < (1ull << 32);
+    for (uint32_t l = 0; l < g.n_levels; ++l) lean = lean && g.resolution[l] <= 4096u;
+    if (lean) {
+        static const bool pair_env = [] { const char* e = getenv("NVO_GRID_FWD_PAIR"); return !e || atoi(e) != 0; }();  // A/B (default on)
+#define NVO_LAUNCH_LEANM(SPT_, BF_, PAIR_)                                                                   \
+    NVO_LAUNCH((k_grid_fwd_lean<SPT_, BF_, PAIR_>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, \
+               (__half2*)out_half, plan, n_live)
+#define NVO_LAUNCH_LEANS(SPT_)                                                                               \
+    do {                                                                                                     \
+        if (pair_env) { if (out_bf16) NVO_LAUNCH_LEANM(SPT_, true, true); else NVO_LAUNCH_LEANM(SPT_, false, true); } \
+        else { if (out_bf16) NVO_LAUNCH_LEANM(SPT_, true, false); else NVO_LAUNCH_LEANM(SPT_, false, false); } \
+    } while (0)
+        if (spt == 1) NVO_LAUNCH_LEANS(1);
+        else if (spt == 2) NVO_LAUNCH_LEANS(2);
+        else NVO_LAUNCH_LEANS(4);
+#undef NVO_LAUNCH_LEANS
+#undef NVO_LAUNCH_LEANM
+    } else if (runs) {
         NVO_LAUNCH((k_grid_fwd_runs<kGridBlock>), grid, block, 0, stream, g, N, x, (const __half2*)table_half,
                    (__half2*)out_half, out_bf16 ? 1 : 0, plan, n_live);
     } else if (soa) {
@@ -2729,6 +3024,7 @@ int nvo_grid_slices_create(const NvoGridLevels& g, NvoGridSlices* s, uint32_t le
 
 void nvo_grid_slices_destroy(NvoGridSlices* s) {
     nvo_scratch_destroy(&s->live);
+    nvo_scratch_destroy(&s->codes);
     if (s->d_level) (void)hipFree(s->d_level);
     s->d_level = s->d_first = nullptr;
     s->d_l1 = nullptr;
@@ -3088,6 +3384,31 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
             }
 #undef NVO_LAUNCH_L1
         }
+        // slice codes of the hashed levels (k_slice_codes; see the coded scan of grid_bwd_item): one pre-pass over the
+        // positions instead of a cell + hash derivation on every slice visit
+        const uint16_t* d_codes = nullptr;
+        uint32_t code_levels = 0u;
+        {
+            // NVO_GRID_SLICE_CODES=1 (A/B; default OFF -- a measured negative, EXPERIMENTS 10.4: 201 -> 212 us on 1 M live
+            // samples, 97 -> 108 us with 60 % dead: a drained entry re-derives cell, hashes and weights from an uncoalesced
+            // position load, which costs what the 59 % of skipped visits save)
+            static const bool codes_env = [] { const char* e = getenv("NVO_GRID_SLICE_CODES"); return e && atoi(e) != 0; }();
+            if (codes_env && ring_off != 0u && dy_fmt != NVO_DY_FLOAT && N < (1u << 28)) {
+                for (uint32_t l = 0; l < g.n_levels; ++l) {
+                    const uint32_t size = g.offset[l + 1] - g.offset[l];
+                    if (((slices->level_mask >> l) & 1u) && g.hashed[l] && (size & (size - 1u)) == 0u && size >= 16384u &&
+                        size <= 8u * 16384u && g.resolution[l] + 1u < 16384u)
+                        code_levels |= 1u << l;
+                }
+            }
+            if (code_levels) {
+                const size_t bytes = sizeof(uint16_t) * (size_t)__builtin_popcount(code_levels) * N;
+                if (int rc = nvo_scratch_reserve(&slices->codes, bytes, stream, "grid_bwd slice codes")) return rc;
+                uint16_t* dc = static_cast<uint16_t*>(slices->codes.ptr);
+                NVO_LAUNCH(k_slice_codes, dim3(nvo_div_up(N, 256)), dim3(256), 0, stream, g, N, x, code_levels, dc);
+                d_codes = dc;
+            }
+        }
 #define NVO_LAUNCH_LDS(SOA_, T_)                                                              \
     do {                                                                                      \
         static bool attr_set = false; /* >64 KiB of dynamic LDS needs an explicit opt-in */   \
@@ -3099,7 +3420,7 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
                            (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag, slices->d_live_n, ring_off, \
-                           slices->ext_l1, slices->ext_blocks, slices->ext_l1_stride); \
+                           slices->ext_l1, slices->ext_blocks, slices->ext_l1_stride, d_codes, code_levels); \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

@@ -32,6 +32,7 @@ struct NvoGridSlices {
     // was loaded and tested once per slice (25 slice scans for a proposal grid).
     bool compact_live = false;
     mutable NvoScratch live;              // [1 + N] uint32: count, then the live sample ids (grows with N; graph-safe)
+    mutable NvoScratch codes;             // [coded levels][N] uint16: slice codes of the hashed levels (k_slice_codes)
     // option grid_bwd_runs (set before create): the items of DENSE levels scan with run merging -- a lane takes 8
     // consecutive samples, sums the corner contributions in registers while the cell stays the same and goes to the LDS
     // accumulators once per run (consecutive samples are neighbours on a ray, so a coarse cell holds a run of them)

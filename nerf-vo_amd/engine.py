@@ -643,8 +643,10 @@ class NerfactoEngine:
             # ray share cells, and a trained field concentrates the later levels' samples at the surface: per 32 768-ray
             # chunk grid_fwd[L16] 301 -> 250 us, grid_fwd[L5] 175 -> 158 us.  Off for training batches (EXPERIMENTS 9.6b).
             nets = (*self.prop_nets, self.base_net)
-            for m in nets:
-                m.set_option("grid_fwd_runs", 1)
+            import os
+            runs_mask = int(os.environ.get("NVO_RENDER_RUNS", "7"))  # A/B: bit k = network k walks runs (proposal 0, 1, main)
+            for k_, m in enumerate(nets):
+                m.set_option("grid_fwd_runs", (runs_mask >> k_) & 1)
             try:
                 return self._forward_body(ws, training, anneal, jitters, cam_idx_for_embedding, embedding_ptr, stream,
                                           anneal_dev, skip_head)

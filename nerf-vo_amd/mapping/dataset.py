@@ -142,15 +142,27 @@ class DynamicDataset(torch.utils.data.Dataset):
         # an older state of the buffer
         self.version = getattr(self, "version", 0) + 1
         dev = self.device
-        idx = input["indices"].to(dev)
-        key = input["keyframe_indices"].to(dev)
-        self.camera_intrinsics[idx] = input["camera_intrinsics"].to(dev)
-        self.camera_extrinsics[key] = input["camera_extrinsics"].to(dev)
-        self.frames_color[idx] = input["frames_color"].to(dev)
-        self.frames_depth[key] = input["frames_depth"].to(dev)
+        idx, key = input["indices"], input["keyframe_indices"]
+
+        def put(buf: torch.Tensor, ids: torch.Tensor, src: torch.Tensor) -> None:
+            """buf[ids] = src as the reference writes it (nerfstudio_utils.py:217-227), without the index tensor when ``ids``
+            is a run of consecutive slots -- what every tracker delivers (a new frame appended, a sliding window of
+            poses / depths refreshed): a slice copy instead of an H2D copy of the indices + an index_put over up to
+            26 x 480 x 640 elements per buffer.  Same values either way."""
+            ids_l = ids.tolist()
+            src = src.to(dev)
+            if ids_l and ids_l == list(range(ids_l[0], ids_l[0] + len(ids_l))):
+                buf[ids_l[0]:ids_l[0] + len(ids_l)].copy_(src)
+            else:
+                buf[ids.to(dev)] = src
+
+        put(self.camera_intrinsics, idx, input["camera_intrinsics"])
+        put(self.camera_extrinsics, key, input["camera_extrinsics"])
+        put(self.frames_color, idx, input["frames_color"])
+        put(self.frames_depth, key, input["frames_depth"])
         if self.use_normals:
-            self.frames_normal[idx] = input["frames_normal"].to(dev)
-            self._refresh_world_normals(torch.unique(torch.cat([idx, key])))
+            put(self.frames_normal, idx, input["frames_normal"])
+            self._refresh_world_normals(torch.unique(torch.cat([idx.to(dev), key.to(dev)])))
         self.num_active_frames = input["num_active_frames"]
 
     def _refresh_world_normals(self, frames: torch.Tensor) -> None:

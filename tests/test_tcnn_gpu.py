@@ -850,18 +850,20 @@ def test_double_backward_raises_like_upstream(device):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("cfg", [PROP0, PROP1], ids=["prop0", "prop1"])
-def test_small_grid_forward_forms_are_bit_identical(device, cfg, dtype):
-    """The proposal grids' forward has several forms of ONE arithmetic (module option grid_fwd_small_form: 0 the generic
-    thread-per-(sample, level) kernel, 1 coarse levels from LDS, 3 software-pipelined, 4 instruction-lean -- the default):
-    same fp32 interpolation in the same order, one rounding.  Their outputs must agree bit for bit, on ray-coherent
-    samples, on cells at the domain faces (the dense levels' wrap takes the lean form's generic branch), on positions
-    outside [0, 1] (memory-safe garbage in every form, the SAME garbage), and for batches that end inside a pass."""
+@pytest.mark.parametrize("cfg", [PROP0, PROP1, MAIN], ids=["prop0", "prop1", "main"])
+def test_grid_forward_forms_are_bit_identical(device, cfg, dtype):
+    """The level-major forward has several forms of ONE arithmetic (module option grid_fwd_small_form).  Proposal grids:
+    0 the first thread-per-(sample, level) kernel, 1 coarse levels from LDS, 3 software-pipelined, 4 instruction-lean (the
+    default).  Main grid: 0 the first kernel, anything else the instruction-lean one (the default).  Same fp32
+    interpolation in the same order, one rounding: the outputs must agree bit for bit, on ray-coherent samples, on cells
+    at the domain faces (the dense levels' wrap takes the lean forms' generic branch), on positions outside [0, 1]
+    (memory-safe garbage in every form, the SAME garbage), and for batches that end inside a pass / a tile."""
     import nerf_vo_amd.tinycudann as tcnn
 
-    net = tcnn.NetworkWithInputEncoding(3, 1, _enc_cfg(cfg), {"otype": "FullyFusedMLP", "activation": "ReLU",
-                                                              "output_activation": "None", "n_neurons": 16,
-                                                              "n_hidden_layers": 1}).to(device)
+    wide = cfg["n_levels"] == 16
+    net = tcnn.NetworkWithInputEncoding(3, 16 if wide else 1, _enc_cfg(cfg), {
+        "otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64 if wide else 16,
+        "n_hidden_layers": 1}).to(device)
     m = net.native_tcnn_module
     m.set_option("bf16", int(dtype == "bf16"))
     with torch.no_grad():
