@@ -719,7 +719,10 @@ def main() -> None:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import ngp_bench
 
-        ngp = ngp_bench.run(argparse.Namespace(steps=args.ngp_steps, warmup=300, keyframes=48, extrinsics=1, render_frames=3,
+        # on the reference's own configuration of this back-end (configs/nerf_slam_replica.yaml:14-19: 192 keyframes 360x640,
+        # compute_covariances: True -> a non-constant per-pixel depth variance, so the variance gather runs)
+        ngp = ngp_bench.run(argparse.Namespace(steps=args.ngp_steps, warmup=300, keyframes=192, height=360, width=640,
+                                               cov="varying", extrinsics=1, render_frames=3,
                                                profile=not args.no_kernel_table), quiet=True)
 
     # ---- CPU baseline: the torch-CPU oracle of the same step on a bounded sample (rank 0, N=1)

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Step time of the occupancy-grid ("instant-ngp") trainer through the pyngp facade on the synthetic room.
-python tools/ngp_bench.py [--steps 300] [--extrinsics 0|1]"""
+"""Step time of the occupancy-grid ("instant-ngp") trainer through the pyngp facade on the synthetic room, on the
+configuration the reference runs this back-end on (/root/reference/configs/nerf_slam_replica.yaml:6-19: 192 keyframes at
+360x640, DROID-SLAM tracking with compute_covariances: True -- every keyframe arrives with a per-pixel depth VARIANCE,
+/root/reference/nerf_vo/mapping/instant_ngp.py:77-100): `--cov varying` (the default) hands a smooth, non-constant variance
+to update_training_images, so the variance gather and the Mahalanobis depth term run; `--cov ones` is the reference's
+fallback without DROID-SLAM (plain L2 depth term, gather skipped).
+python tools/ngp_bench.py [--steps 300] [--extrinsics 0|1] [--keyframes 192 --height 360 --width 640] [--cov varying|ones]"""
 import argparse
 import os
 import sys
@@ -22,7 +27,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=300)  # (past the 256 steps of full density-grid sweeps)
-    ap.add_argument("--keyframes", type=int, default=48)
+    ap.add_argument("--keyframes", type=int, default=192)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--cov", choices=("varying", "ones"), default="varying",
+                    help="per-pixel depth variance handed to update_training_images (varying: (0.02 + 0.03 depth)^2 with a smooth "
+                         "image-space modulation -- the gather and the covariance-weighted depth term run; ones: plain L2)")
     ap.add_argument("--extrinsics", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--render-capacity", type=int, default=0, help="packed sample slots of an inference launch (0: NgpConfig)")
@@ -39,7 +49,8 @@ def run(a, quiet: bool = False):
     (bench.py embeds it as its "ngp" section)."""
     say = (lambda *x: None) if quiet else print
     dev = torch.device("cuda:0")
-    H, W = 272, 480
+    H, W = int(getattr(a, "height", 360)), int(getattr(a, "width", 640))
+    cov_mode = getattr(a, "cov", "varying")
     seq = make_sequence(a.keyframes, H, W, device=dev, scene_scale=0.2)
     poses = seq["camera_extrinsics"].clone()
     poses[:, :3, 3] += 0.5
@@ -51,9 +62,17 @@ def run(a, quiet: bool = False):
     color = seq["frames_color"].permute(0, 2, 3, 1)
     color = torch.cat([color, torch.ones_like(color[..., :1])], dim=3)
     depth = seq["frames_depth"].permute(0, 2, 3, 1)
+    if cov_mode == "ones":
+        depths_cov = torch.ones_like(depth)
+    else:
+        # what a tracker's depth covariance looks like in shape: grows with depth, varies smoothly over the image, positive
+        ys = torch.linspace(0.0, 3.14159, H, device=dev).view(1, H, 1, 1)
+        xs = torch.linspace(0.0, 6.28318, W, device=dev).view(1, 1, W, 1)
+        sigma = (0.02 + 0.03 * depth) * (1.0 + 0.25 * torch.sin(xs) * torch.cos(ys))
+        depths_cov = (sigma * sigma).contiguous()
     tb.nerf.training.update_training_images(
         frame_ids=list(range(a.keyframes)), poses=opencv_to_opengl(poses)[:, :3], images=color.contiguous(),
-        depths=depth.contiguous(), depths_cov=torch.ones_like(depth), resolution=np.array([W, H]),
+        depths=depth.contiguous(), depths_cov=depths_cov, resolution=np.array([W, H]),
         principal_point=seq["camera_intrinsics"][0, 2:].cpu().numpy(), focal_length=seq["camera_intrinsics"][0, :2].cpu().numpy())
     if getattr(a, "train_min_t", None) is not None:
         tb.frame()
@@ -231,7 +250,8 @@ def run(a, quiet: bool = False):
         out = {"metric": "packed training samples/sec (occupancy-grid back-end)", "value": n / dt,
                           "unit": "samples/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "rays_per_batch": eng.rays_per_batch,
                           "dtype": "f16", "data": "synthetic",
-                          "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H}, aabb_scale 4, "
+                          "config": {"workload": f"pyngp.Testbed.frame(): {a.keyframes} keyframes {W}x{H} (configs/nerf_slam_replica.yaml:14-19), "
+                                                 f"per-pixel depth variance {'non-constant: the covariance-weighted depth term and its gather run' if cov_mode != 'ones' else 'all ones (plain L2)'}, aabb_scale 4, "
                                                  f"capacity {cap} packed samples, extrinsics optimisation "
                                                  f"{'on' if a.extrinsics else 'off'} (camera step every {eng.cfg.extrinsic_update_every} training steps), weight EMA, "
                                                  f"adaptive ray batch, random background {'on' if eng.cfg.random_background else 'off'}, "
