@@ -128,6 +128,49 @@ def workload_argv(args) -> list:
     return out
 
 
+def gather_roofline(kernel_table: list, cfg, R: int, summary_path: str | None):
+    """`roofline_gather`: the main grid's hash gather (north_star: "rocprof HBM GB/s on the hash gather") priced three
+    ways per launch -- the ALGORITHMIC gather bytes (588 B per main-field sample), the HBM traffic the PMC
+    counters saw (FETCH_SIZE + WRITE_SIZE of the same launch: small, the 24 MB table lives in the L2s), and the read
+    REQUESTS the vector L1s sent to the L2 (TCP_TCC_READ_REQ; each asks for one cache line -- 64 B counted, a 128-byte
+    line filled): the figure the kernel is really bound by.  None without a kernel table."""
+    row = next((r for r in kernel_table if r[0] == "grid_fwd[L16]"), None)
+    if row is None:
+        return None
+    avg_s = row[2] / row[1] * 1e-3
+    alg = algorithmic_bytes("grid_fwd[L16]", cfg, R)
+    out = {"kernel": "grid_fwd[L16]", "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(alg),
+           "algorithmic": {"achieved": round(alg / avg_s / 1e9, 1), "unit": "GB/s", "frac_of_hbm_peak": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_of_l2_peak": round(alg / avg_s / 1e9 / L2_PEAK_GBS, 4)},
+           "hbm": None, "l2_requests": None}
+    paths = ([summary_path] if summary_path else []) + sorted(
+        __import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")), reverse=True)
+    for path in paths:
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        k = next((k for k in data.get("kernels", []) if k.get("kernel") == "k_grid_fwd"), None)
+        if k is None:
+            continue
+        src = "live passes of this bench process" if path == summary_path else os.path.basename(path)
+        hbm = int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024)
+        out["hbm"] = {"traffic_bytes_per_launch": hbm, "achieved": round(hbm / avg_s / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                      "frac": round(hbm / avg_s / 1e9 / HBM_PEAK_GBS, 4), "source": src,
+                      "note": "raw FETCH_SIZE + WRITE_SIZE (gathers: no streaming-read correction); the table is L2-resident, "
+                              "most of this is the positions read and the encoded features written"}
+        if "L2_READ_REQ_per_launch" in k:
+            req = k["L2_READ_REQ_per_launch"]
+            out["l2_requests"] = {"read_requests_per_launch": int(req), "requests_per_sample_level": round(req / (R * cfg.num_nerf_samples * 16), 2),
+                                  "bytes_at_64": int(req * 64), "bytes_at_128": int(req * 128), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                                  "achieved_at_64": round(req * 64 / avg_s / 1e9, 1), "achieved_at_128": round(req * 128 / avg_s / 1e9, 1),
+                                  "frac_at_64": round(req * 64 / avg_s / 1e9 / L2_PEAK_GBS, 4),
+                                  "frac_at_128": round(req * 128 / avg_s / 1e9 / L2_PEAK_GBS, 4),
+                                  "amplification_over_algorithmic": [round(req * 64 / alg, 2), round(req * 128 / alg, 2)], "source": src}
+        break
+    return out
+
+
 def live_pmc_summary(config_argv: list, steps: int = 20, warmup: int = 5, timeout_s: int = 240):
     """HBM traffic counters of THIS build in THIS session: two child runs of the bench command under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
@@ -157,7 +200,8 @@ def live_pmc_summary(config_argv: list, steps: int = 20, warmup: int = 5, timeou
                 "--ngp-steps", "0", "--mapping-loop", "off", "--pmc-traffic", "off"]
     import signal
 
-    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    # (third pass: read requests of the vector L1s to the L2 -- what the hash gathers are served by, roofline_gather)
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("TCP_TCC_READ_REQ_sum", "l2req")):
         cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, sub), "--", *cmd_tail]
         try:
             # own process group: on a timeout the WHOLE group goes (rocprofv3 is a wrapper; killing it alone would leave
@@ -166,6 +210,7 @@ def live_pmc_summary(config_argv: list, steps: int = 20, warmup: int = 5, timeou
                                     start_new_session=True)
         except OSError as exc:
             return None, f"{counter} pass: {type(exc).__name__}"
+        optional = sub == "l2req"  # (the HBM counters are the contract; the L2 request pass only feeds roofline_gather)
         try:
             _, err = proc.communicate(timeout=timeout_s)
         except subprocess.TimeoutExpired:
@@ -174,12 +219,19 @@ def live_pmc_summary(config_argv: list, steps: int = 20, warmup: int = 5, timeou
             except OSError:
                 pass
             proc.communicate()
+            if optional:
+                shutil.rmtree(os.path.join(work, sub), ignore_errors=True)
+                continue
             return None, f"{counter} pass: timed out after {timeout_s} s (process group killed)"
         if proc.returncode != 0:
+            if optional:
+                shutil.rmtree(os.path.join(work, sub), ignore_errors=True)
+                continue
             return None, f"{counter} pass exited {proc.returncode}: {(err or '')[-300:]}"
     out = os.path.join(work, "pmc_fetch_write_per_kernel.json")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(work, "fetch"),
-                          os.path.join(work, "write"), out, str(steps + warmup)], env=env, capture_output=True, text=True)
+                          os.path.join(work, "write"), out, str(steps + warmup), os.path.join(work, "l2req")], env=env,
+                         capture_output=True, text=True)
     if res.returncode != 0 or not os.path.exists(out):
         return None, f"pmc_traffic.py: {res.stderr[-300:]}"
     try:  # the summary names the configuration it was collected on
@@ -490,6 +542,7 @@ def main() -> None:
 
     # ---- roofline: same K steps again with per-launch HIP events on the launch stream
     roofline = None
+    live_summary_path = None
     kernel_table = []
     lib = _lib.lib()
     prof_steps = 0 if args.no_kernel_table else min(args.steps, 50)
@@ -552,6 +605,7 @@ def main() -> None:
             live_path = live_err = None
             if args.pmc_traffic == "live" and world == 1:
                 live_path, live_err = live_pmc_summary(workload_argv(args))
+                live_summary_path = live_path
                 if live_err:
                     sys.stderr.write(f"[bench] live PMC passes failed ({live_err}); using the committed summary\n")
             # a COMMITTED summary was collected on the default command line: it says nothing about another configuration
@@ -582,6 +636,7 @@ def main() -> None:
                                                 "achieved": round(b32 / avg_s / 1e9, 2),
                                                 "frac": round(b32 / avg_s / 1e9 / HBM_PEAK_GBS, 5)}
             break
+    roofline_gather = gather_roofline(kernel_table, cfg, args.rays, live_summary_path) if rank == 0 else None
     # MFMA utilisation of the fused-MLP kernels alone: FLOP model 2*N*(I*W + (H-1)*W*W + W*O)
     # for a forward; a backward = input gradient + weight gradient + (these networks store no hidden activations)
     # the recomputed forward = 3x.  N = main-field samples per launch; dense fp16 MFMA peak 2.5 PFLOP/s.
@@ -851,6 +906,7 @@ def main() -> None:
             "field_evals_per_sec": args.rays * world * (cfg.num_nerf_samples + sum(cfg.num_proposal_samples))
             / (elapsed / args.steps),
             "mlp_mfma": mlp_mfma,
+            "roofline_gather": roofline_gather,
             "final_losses": losses,
             "late_schedule": late,
             "roofline": roofline,

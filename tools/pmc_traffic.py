@@ -3,7 +3,11 @@
 bench command into profiles/<round>_pmc_fetch_write_per_kernel.json: HBM-side KB per launch for every
 kernel of the library, plus the sums bench.py's `roofline.traffic` reads (`bench_name` rows).
 
-Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [steps_profiled]"""
+An optional third pass (`--pmc TCP_TCC_READ_REQ_sum`: read requests the vector L1s send to the L2, one per cache line a
+wave instruction misses) adds `L2_READ_REQ_per_launch` to every kernel: what a gather kernel is really served by when
+its tables are cache-resident (bench.py's `roofline_gather`).
+
+Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [steps_profiled] [l2_read_req_dir]"""
 import csv
 import glob
 import json
@@ -18,7 +22,7 @@ def load(path, counter):
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter:
+                if row["Counter_Name"] != counter and not row["Counter_Name"].startswith(counter):
                     continue
                 m = re.search(r"(k_\w+)", row["Kernel_Name"])
                 if not m:
@@ -33,6 +37,7 @@ def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     out_path = sys.argv[3]
+    l2req = load(sys.argv[5], "TCP_TCC_READ_REQ") if len(sys.argv) > 5 and sys.argv[5] else {}
     kernels = []
     # only the kernels of the training step: whatever ran fewer than `min_launches` times in the profiled command is set-up
     # work (torch's GEMMs of the synthetic scene, the eager warm-up's own launches) and stays out of the summary
@@ -46,6 +51,8 @@ def main():
         kernels.append({"kernel": key[0], "grid_size": key[1], "launches": n,
                         "FETCH_SIZE_KB_per_launch": round(f / max(nf, 1), 1),
                         "WRITE_SIZE_KB_per_launch": round(w / max(nw, 1), 1)})
+        if key in l2req and l2req[key][1]:
+            kernels[-1]["L2_READ_REQ_per_launch"] = round(l2req[key][0] / l2req[key][1], 1)
     # gfx950: FETCH_SIZE reports exactly HALF the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section:
     # 16 B per lane; calibrated here for 8 B per lane too -- tools/probes/read_bw_probe under --pmc FETCH_SIZE reports
     # 70 688 KB for a 141 312 KB buffer at both widths, profiles/r2_pmc_probe_calibration.txt).  The kernels below read
