@@ -835,7 +835,10 @@ int nvo_adam_step_groups_scaled(nvo_stream_t stream, uint32_t n_groups, const nv
  *  - by the LAST workgroup of the grid, once every other workgroup has checked in (each has then read the scalars a
  *    commit changes), the step's commit: nvo_opt_commit (applied / scale / bias) and the average's counter (ema_commit
  *    != 0: *ema_step_dev += 1 iff skip_flags[ema_flag_slot] == 0, what nvo_ema_update_dev does behind its launch).
- * done_counter: a device word, zero before the first launch; the launch leaves it zero (graph replay safe).  Each part is
+ * done_counter: a device word, zero before the first launch; the launch leaves it zero (graph replay safe).  Should the
+ * check-in not arrive at exactly the grid size (a counter left dirty, a stall of ~0.5 s) the launch does NOT commit and
+ * sets bit 31 of the word, for good: the host checks it where it reads the step's results (a non-zero word after a
+ * synchronised launch = the optimiser state can no longer be trusted).  Each part is
  * optional (NULL pointers = not requested); tail == NULL is nvo_adam_step_groups_scaled.  Measured (EXPERIMENTS.md
  * 9.11): -6 us on the occupancy-grid step; the nerfacto step, whose average-free tail is one commit launch, gains
  * nothing from it and keeps nvo_opt_commit_table. */

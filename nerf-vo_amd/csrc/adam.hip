@@ -213,7 +213,7 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
     if (!t.done) return;  // (uniform)
     // Check-in without a round trip: every workgroup adds one to the counter (fire and forget -- a RETURNING atomic per
     // workgroup on one address cost 75 ns each, +90 us on a 1200-workgroup launch), the LAST workgroup of the grid waits
-    // for the others and commits.  Workgroups are dispatched in index order, so everything it waits for is resident or
+    // for the others and commits (the final load is an acquire).  Workgroups are dispatched in index order, so everything it waits for is resident or
     // done: no deadlock.  What the ordering has to guarantee is only that every READ of the scalars the commit changes
     // (bias corrections, loss scale, learning rates, average counter) precedes it: those loads were consumed before the
     // workgroup's first store, long before its check-in -- so relaxed atomics at agent scope do (they act at the coherent
@@ -224,15 +224,29 @@ k_adam_groups(AdamGroups gr, float* __restrict__ p, nvo_h16* __restrict__ p16, c
         if (threadIdx.x == 0) __hip_atomic_fetch_add(t.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    // The counter must arrive at EXACTLY gridDim.x - 1.  A counter someone left dirty (an aborted launch, a caller that
+    // did not zero it) ends above that and a stall ends below: either way the wait runs out (~0.5 s) and the launch raises
+    // a STICKY error instead of committing -- bit 31 of the counter, which the host checks wherever it reads the step's
+    // results (nvo_adam_tail::done_counter) -- and neither commits nor resets: committing on a dirty counter could run
+    // before every workgroup has read the scalars the commit changes, i.e. silent optimiser-state corruption.
+    __shared__ uint32_t s_commit;
     if (threadIdx.x == 0) {
-        // (">=" and a bounded wait of a few seconds: a counter someone left dirty must not turn into a
-        // wave that never finishes)
-        for (uint32_t spin = 0; spin < (1u << 24) &&
-                                __hip_atomic_load(t.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x - 1u; ++spin)
+        uint32_t ok = 0u;
+        for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+            const uint32_t v = __hip_atomic_load(t.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (v & 0x80000000u) break;  // (an earlier launch already failed: stay failed)
+            if (v == gridDim.x - 1u) {
+                ok = 1u;
+                break;
+            }
+            if (v > gridDim.x - 1u) break;  // (dirty: it can only grow)
             __builtin_amdgcn_s_sleep(16);
+        }
+        if (!ok) __hip_atomic_fetch_or(t.done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_commit = ok;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && s_commit) {
         if (t.applied || t.scale)
             opt_commit_thread(t.n_groups, t.active_mask, t.scale_mask, t.applied, skip_flags, t.scale, t.growth_tracker, t.growth,
                               t.backoff, t.interval, t.min_scale, t.max_scale, t.bias, h.beta1, h.beta2);

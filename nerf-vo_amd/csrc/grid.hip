@@ -83,6 +83,17 @@ namespace {
 
 constexpr int kGridBlock = 256;
 
+// Two dwords at DWORD alignment (the x neighbours of a dense level start at any entry): loaded through a packed type, so
+// that the 8-byte access is well defined at 4-byte alignment -- it still compiles to one global_load_dwordx2 (unaligned
+// access mode is on for this target) -- instead of a uint2 reinterpretation that promises the compiler 8-byte alignment.
+struct __attribute__((packed, aligned(4))) NvoU2A4 {
+    uint32_t x, y;
+};
+__device__ __forceinline__ uint2 nvo_ld_u2_a4(const uint32_t* p) {
+    const NvoU2A4 v = *reinterpret_cast<const NvoU2A4*>(p);
+    return make_uint2(v.x, v.y);
+}
+
 // blockIdx -> (tile, level).  With n_levels a multiple of 8 the blocks that share blockIdx % 8
 // (one XCD under round-robin placement) get levels {xcd, xcd + 8, ...}.
 __device__ __forceinline__ void grid_block_map(uint32_t bid, uint32_t n_levels, uint32_t* tile,
@@ -228,7 +239,7 @@ k_grid_fwd(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 if (idx[s][2 * j + 1] == idx[s][2 * j] + 1u) {
-                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(tab) + idx[s][2 * j]);
+                    const uint2 q = nvo_ld_u2_a4(reinterpret_cast<const uint32_t*>(tab) + idx[s][2 * j]);
                     v[s][2 * j] = __builtin_bit_cast(__half2, q.x);
                     v[s][2 * j + 1] = __builtin_bit_cast(__half2, q.y);
                 } else {
@@ -352,7 +363,7 @@ k_grid_fwd_runs(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const 
             const uint32_t b = nvo_grid_index(hashed, size, res, c[s].px + 1u, cy, cz);
             if (!hashed && b == a + 1u) {
                 // dense level: the two x corners are neighbours in memory (dword alignment suffices)
-                const uint2 q = *reinterpret_cast<const uint2*>(tab + a);
+                const uint2 q = nvo_ld_u2_a4(tab + a);
                 v[s][2 * j] = q.x;
                 v[s][2 * j + 1] = q.y;
             } else {
@@ -456,7 +467,7 @@ k_grid_fwd_small(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const
                         vg[s][q][2 * j + 1] = (i0c & 1u) ? pr.x : pr.y;
                     } else if (!hashed && i1c == i0c + 1u) {
                         // dense level: x neighbours are neighbours in memory (dword alignment suffices)
-                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + i0c);
+                        const uint2 pr = nvo_ld_u2_a4(tl + i0c);
                         vg[s][q][2 * j] = pr.x;
                         vg[s][q][2 * j + 1] = pr.y;
                     } else {
@@ -595,7 +606,7 @@ k_grid_fwd_small_pipe(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
         for (int q = 0; q < NG; ++q) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                pr[q][j] = *reinterpret_cast<const uint2*>(tab32 + a0[q][j]);
+                pr[q][j] = nvo_ld_u2_a4(tab32 + a0[q][j]);
                 ex[q][j] = 0u;
                 if ((sel[q] >> (4u + j)) & 1u) ex[q][j] = tab32[a1[q][j]];
             }
@@ -696,10 +707,6 @@ k_grid_fwd_small_pipe(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
 //     second proposal level's 393 216 samples are 1.5 passes per workgroup: the first form ran 2 on 192 of the 256 CUs);
 //   * the software pipeline of k_grid_fwd_small_pipe (staging loads in flight, next positions / gathers requested early).
 // Same fp32 interpolation, same order, one rounding: bit-identical to k_grid_fwd_small (tools/probes/fwd_small_ab.py).
-struct __attribute__((packed, aligned(4))) NvoU2A4 {  // two dwords at dword alignment (x neighbours of a dense level)
-    uint32_t x, y;
-};
-
 template <bool BF>
 __device__ __forceinline__ uint32_t lean_cvt16x2(float a, float b) {
     asm("" : "+v"(a));  // (as nvo_cvt16: fp32 first, then ONE rounding to 16 bits, whatever the surrounding code)
@@ -1161,7 +1168,7 @@ k_grid_fwd_small_runs(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
                         v[s][2 * j] = (a & 1u) ? pr.y : pr.x;
                         v[s][2 * j + 1] = (a & 1u) ? pr.x : pr.y;
                     } else if (!hashed && b == a + 1u) {
-                        const uint2 pr = *reinterpret_cast<const uint2*>(tl + a);
+                        const uint2 pr = nvo_ld_u2_a4(tl + a);
                         v[s][2 * j] = pr.x;
                         v[s][2 * j + 1] = pr.y;
                     } else {

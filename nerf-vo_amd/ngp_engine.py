@@ -1073,6 +1073,9 @@ class NgpEngine:
 
     def loss_dict(self) -> dict:
         vals = self.losses.sum(dim=0).tolist()
+        if int(self._tail_done.item()) & 0x80000000:  # (nvo_adam_tail::done_counter: the fused optimiser tail refused to commit)
+            raise RuntimeError("the optimiser launch's commit failed its check-in (counter left dirty or a stalled launch): "
+                               "step counters and weight average are no longer consistent -- restart from a snapshot")
         d = {"rgb_loss": vals[0], "depth_loss": vals[1]}
         if self.cfg.optimize_extrinsics and vals[5] != 0.0:
             d["extrinsic_regularizer"] = vals[5]

@@ -384,6 +384,49 @@ def test_adam_tail_in_one_launch_is_bit_identical(device):
     assert bool((b["ema"] != 0).all()) and bool((b["p16"] != 0).any())
 
 
+def test_adam_tail_refuses_to_commit_on_a_dirty_counter(device):
+    """The fused optimiser tail commits when its check-in counter arrives at EXACTLY the grid size.  A counter somebody
+    left dirty never does: the launch must then neither commit (step counter, bias corrections, average counter stay as
+    they were) nor reset the counter, and raise the sticky error bit (bit 31) that the host checks -- instead of
+    committing before every workgroup has read the scalars the commit rewrites."""
+    import ctypes as C
+
+    from nerf_vo_amd import _lib
+    from nerf_vo_amd.engine import _call
+    from nerf_vo_amd.tinycudann.modules import _ptr, _stream
+
+    n = 200_000
+    b1, b2 = 0.9, 0.99
+    p = torch.randn(n, device=device)
+    p16 = torch.zeros(n, dtype=torch.float16, device=device)
+    m, v = torch.zeros(n, device=device), torch.zeros(n, device=device)
+    grads = torch.randn(n, device=device)
+    applied = torch.zeros(1, dtype=torch.int32, device=device)
+    bias = torch.tensor([1.0 - b1, (1.0 - b2) ** 0.5], device=device)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    done = torch.full((1,), 3, dtype=torch.int32, device=device)  # dirty
+    group = (_lib.AdamGroup * 1)(_lib.AdamGroup(offset=0, n=n, lr=1e-2, step=0, hyper_dev=None, bias_dev=bias.data_ptr(),
+                                                flag_slot=0, flag_slot_set=1, weight_decay=0.0, weight_decay_set=1))
+    tail = _lib.AdamTail(ema=None, ema_half=None, ema_decay=0.0, ema_step_dev=None, ema_flag_slot=0, ema_commit=0,
+                         done_counter=done.data_ptr(), n_commit_groups=1, active_mask=1, scale_mask=0,
+                         applied=applied.data_ptr(), scale=None, growth_tracker=None, growth_factor=2.0, backoff_factor=0.5,
+                         growth_interval=2000, min_scale=0.0, max_scale=0.0, bias=bias.data_ptr())
+    bias0 = bias.clone()
+    for _ in range(2):  # (the second launch meets the sticky bit and must stay failed)
+        _call("nvo_adam_step_groups_tail", _stream(device), 1, group, _ptr(p), _ptr(p16), _ptr(grads), 0, _ptr(m), _ptr(v), b1, b2,
+              1e-15, 1.0, 0.0, _ptr(flag), 0, None, None, None, C.byref(tail))
+        torch.cuda.synchronize()
+        word = int(done.item()) & 0xFFFFFFFF
+        assert word & 0x80000000, f"no error bit on a dirty counter (word {word:#x})"
+        assert int(applied.item()) == 0 and torch.equal(bias, bias0), "the launch committed on a dirty counter"
+    # a clean counter commits and is left at zero
+    done.zero_()
+    _call("nvo_adam_step_groups_tail", _stream(device), 1, group, _ptr(p), _ptr(p16), _ptr(grads), 0, _ptr(m), _ptr(v), b1, b2,
+          1e-15, 1.0, 0.0, _ptr(flag), 0, None, None, None, C.byref(tail))
+    torch.cuda.synchronize()
+    assert int(done.item()) == 0 and int(applied.item()) == 1 and not torch.equal(bias, bias0)
+
+
 def test_adaptive_ray_batch_and_ema_inference(device):
     """The ray batch adapts toward the packed-sample target (NerfCounters::update_after_training [UPSTREAM]): after a
     few adaptations the marched samples per step sit within 25 % of the capacity, whatever batch the run started
@@ -563,6 +606,66 @@ def test_graphed_step_matches_eager_step(device):
             assert not torch.equal(ge.params[lo:hi], before[lo:hi])
     assert len(ray_counts) >= 2 and len(ge._graphs) >= 2 and not ee._graphs
     assert bool((ge.pose_adjustment != 0).any())
+
+
+def test_rows_past_the_live_count_do_not_influence_the_step(device):
+    """The packed position buffers (x01 of the training slots, x01_m of the marched candidates) are written for the LIVE
+    slots only; the rows between the live count and the next tile boundary (16 rows for the fused MLPs, 4096 for the
+    launches that stop at n_live) keep whatever an earlier step left there, and the kernels DO evaluate them: a tile is
+    computed whole, its dead rows carry dL/dout = 0.  The invariant that makes this safe has two halves: (1) those rows
+    are always FINITE -- the buffers start zeroed and every writer clamps positions into [0, 1] (a NaN there would turn
+    0 x NaN into a NaN weight gradient) -- and (2) nothing of the step depends on them.  This pins (2): with both buffers
+    overwritten with fresh random positions before every step the run must be the run without them, bit for bit on the
+    hash grid, no overflow flag."""
+    from nerf_vo_amd.mapping.dataset import opencv_to_opengl
+    from nerf_vo_amd.ngp_engine import NgpConfig, NgpEngine
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W = 8, 60, 80
+    seq = make_sequence(n, H, W, device=device, scene_scale=0.2)
+    c2w = opencv_to_opengl(seq["camera_extrinsics"])
+    c2w[:, :3, 3] += 0.5
+    c2w = c2w[:, :3, :4].contiguous()
+    images = seq["frames_color"].permute(0, 2, 3, 1).contiguous()
+    depths = seq["frames_depth"].permute(0, 2, 3, 1).contiguous()
+    engines = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        engines.append(NgpEngine(NgpConfig(num_images=n, num_rays=512, capacity=1 << 16, graph_step=False,
+                                           density_update_every=4), device))
+    clean, poisoned = engines
+    lo, hi = clean._fused_adam_plan()
+    scale = torch.tensor([n, H, W], device=device)
+    state = ("params", "exp_avg", "exp_avg_sq", "params_half", "params_ema", "params_ema_half", "density_grid", "bitfield",
+             "_ema_step_dev", "_applied_dev", "_opt_dev")
+    hit = 0
+    for it in range(8):
+        assert clean.rays_per_batch == poisoned.rays_per_batch
+        R = clean.rays_per_batch
+        idx = torch.floor(torch.rand(R, 3, device=device) * scale).long()
+        if it > 0:
+            for name in state:  # (the MLPs' float-atomic weight gradients would let two free-running trajectories drift)
+                getattr(poisoned, name).copy_(getattr(clean, name))
+            for key in ("x01", "x01_m"):
+                if poisoned._ws is not None and key in poisoned._ws:
+                    poisoned._ws[key].copy_(torch.rand_like(poisoned._ws[key]))
+                    hit += 1
+        for e in (clean, poisoned):
+            torch.manual_seed(100 + it)
+            e.train_step(idx, seq["camera_intrinsics"], c2w, images, depths)
+        torch.cuda.synchronize()
+        assert int(poisoned.skip_flag.item()) == 0 == int(clean.skip_flag.item()), f"step {it}: overflow flag raised"
+        for key in ("x01", "x01_m"):  # (1): whatever the step left in the buffers is finite and inside the unit cube
+            buf = poisoned._ws[key]
+            assert bool(torch.isfinite(buf).all()) and float(buf.min()) >= 0.0 and float(buf.max()) <= 1.0
+        for name in ("params", "exp_avg", "exp_avg_sq", "params_half"):
+            x, y = getattr(clean, name)[lo:hi], getattr(poisoned, name)[lo:hi]
+            x = x.view(torch.int16) if x.dtype == torch.float16 else x.view(torch.int32)
+            y = y.view(torch.int16) if y.dtype == torch.float16 else y.view(torch.int32)
+            assert torch.equal(x, y), f"step {it}: {name} depends on the stale rows ({int((x != y).sum())} words)"
+        assert bool(torch.isfinite(poisoned.params).all())
+        assert torch.allclose(clean.losses.sum(0), poisoned.losses.sum(0), rtol=1e-4, atol=1e-7)
+    assert hit >= 7, "the position buffers were never poisoned (workspace keys changed?)"
 
 
 def test_scattered_density_refresh_past_the_warmup(device):

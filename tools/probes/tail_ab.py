@@ -1,5 +1,6 @@
-"""A/B of the optimiser tails (commit inside the Adam launch; NGP: + weight average) on one box:
-python tools/probes/tail_ab.py {on|off} -- bench args"""
+"""A/B of the occupancy-grid back-end's fused optimiser tail (Adam + weight average + commit in ONE launch,
+NgpConfig.fuse_optimizer_tail) on one box: python tools/probes/tail_ab.py {on|off} -- bench args
+(The nerfacto engine's commit is a node of its own, nvo_opt_commit_table: there is no switch to flip for it.)"""
 import runpy
 import sys
 
@@ -7,18 +8,13 @@ sys.path.insert(0, ".")
 mode = sys.argv[1]
 sys.argv = ["bench.py"] + sys.argv[2:]
 if mode == "off":
-    import nerf_vo_amd.engine as e
     import nerf_vo_amd.ngp_engine as n
 
-    def patch(cls, **defaults):
-        init = cls.__init__
+    init = n.NgpConfig.__init__
 
-        def wrapped(self, *a, **kw):
-            for k, v in defaults.items():
-                kw.setdefault(k, v)
-            init(self, *a, **kw)
-        cls.__init__ = wrapped
+    def wrapped(self, *a, **kw):
+        kw.setdefault("fuse_optimizer_tail", False)
+        init(self, *a, **kw)
 
-    patch(e.EngineConfig, commit_in_adam=False)
-    patch(n.NgpConfig, fuse_optimizer_tail=False)
+    n.NgpConfig.__init__ = wrapped
 runpy.run_path("bench.py", run_name="__main__")
