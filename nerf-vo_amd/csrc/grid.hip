@@ -1203,6 +1203,281 @@ k_grid_fwd_small_runs(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
     }
 }
 
+// k_grid_fwd_runs, INSTRUCTION-LEAN (round 6): the run-walking inference form of the main grid's forward (plan and tile
+// shape of k_grid_fwd_runs: a thread walks four consecutive samples of ONE level, block-uniform) with the arithmetic of
+// k_grid_fwd_lean.  Bit-identical to k_grid_fwd.
+template <int BLOCK, bool BF>
+__global__ void __launch_bounds__(BLOCK)
+k_grid_fwd_runs_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                     __half2* __restrict__ out, GridFwdPlan plan, const uint32_t* __restrict__ n_live) {
+    constexpr int RUN = 4;
+    uint32_t tile, level;
+    if (plan.enabled) {
+        if (!grid_plan_map(plan, blockIdx.x, &tile, &level)) return;
+    } else {
+        grid_block_map(blockIdx.x, g.n_levels, &tile, &level);
+    }
+    if (n_live && tile * (BLOCK * RUN) >= *n_live) return;
+    const uint32_t i0 = tile * (BLOCK * RUN) + threadIdx.x * RUN;
+    if (i0 >= N) return;  // (N is a multiple of RUN: a run is in range as a whole)
+    const uint32_t off = g.offset[level];
+    const uint32_t size = g.offset[level + 1] - off;
+    const uint32_t res = g.resolution[level];
+    const uint32_t hashed = g.hashed[level];
+    const float scale = g.scale[level];
+    const unsigned char* __restrict__ tab8 = reinterpret_cast<const unsigned char*>(table + off);
+    float p[RUN * 3];
+    {
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(x) + i0 * 12u);
+#pragma unroll
+        for (int q = 0; q < RUN * 3 / 4; ++q) {
+            const float4 f = xp[q];
+            p[4 * q] = f.x; p[4 * q + 1] = f.y; p[4 * q + 2] = f.z; p[4 * q + 3] = f.w;
+        }
+    }
+    Corner c[RUN];
+    bool need[RUN];
+    uint2 pr[RUN][4];
+    uint32_t ex[RUN][4];
+#pragma unroll
+    for (int s = 0; s < RUN; ++s) {
+        c[s] = grid_cell(scale, p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+        need[s] = s == 0 || c[s].px != c[s - 1].px || c[s].py != c[s - 1].py || c[s].pz != c[s - 1].pz;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            pr[s][j] = make_uint2(0u, 0u);
+            ex[s][j] = 0u;
+        }
+    }
+    uint32_t r[RUN];
+    uint32_t even[4] = {0u, 0u, 0u, 0u}, odd[4] = {0u, 0u, 0u, 0u};
+    if (hashed) {  // (block-uniform)
+        const uint32_t mask = size - 1u;
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            if (!need[s]) continue;  // (the branch holds index arithmetic and loads alone)
+            const uint32_t hy0 = c[s].py * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = c[s].pz * 805459861u, hz1 = hz0 + 805459861u;
+            const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                pr[s][j] = *reinterpret_cast<const uint2*>(tab8 + (((c[s].px ^ a[j]) & mask & ~1u) << 2));
+            if (c[s].px & 1u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j)
+                    ex[s][j] = *reinterpret_cast<const uint32_t*>(tab8 + ((((c[s].px + 1u) ^ a[j]) & mask) << 2));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            const bool px_odd = (c[s].px & 1u) != 0u;
+            const bool t = (((c[s].py ^ c[s].pz) & 1u) != 0u) != px_odd;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const bool hi = (j == 0u || j == 3u) ? t : !t;
+                const uint32_t e = hi ? pr[s][j].y : pr[s][j].x;
+                const uint32_t o = px_odd ? ex[s][j] : (hi ? pr[s][j].x : pr[s][j].y);
+                even[j] = need[s] ? e : even[j];
+                odd[j] = need[s] ? o : odd[j];
+            }
+            float w[4][2];
+            lean_weights(c[s], w);
+            r[s] = lean_interp<BF>(w, even, odd);
+        }
+    } else {
+        const uint32_t res2 = res * res;
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            if (!need[s]) continue;
+            const uint32_t base = c[s].px + __umul24(c[s].py, res) + __umul24(c[s].pz, res2);
+            const bool split = !(max(max(c[s].px, c[s].py), c[s].pz) < res && base + res2 + res + 1u < size);
+            const uint32_t dj[4] = {0u, res, res2, res2 + res};
+            if (!split) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) pr[s][j] = nvo_ld_u2_a4(reinterpret_cast<const uint32_t*>(tab8 + ((base + dj[j]) << 2)));
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t cy = c[s].py + (j & 1u), cz = c[s].pz + (j >> 1);
+                    pr[s][j].x = *reinterpret_cast<const uint32_t*>(tab8 + (nvo_grid_index(0u, size, res, c[s].px, cy, cz) << 2));
+                    pr[s][j].y = *reinterpret_cast<const uint32_t*>(tab8 + (nvo_grid_index(0u, size, res, c[s].px + 1u, cy, cz) << 2));
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                even[j] = need[s] ? pr[s][j].x : even[j];
+                odd[j] = need[s] ? pr[s][j].y : odd[j];
+            }
+            float w[4][2];
+            lean_weights(c[s], w);
+            r[s] = lean_interp<BF>(w, even, odd);
+        }
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + (((size_t)level * N + i0) << 2)) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// k_grid_fwd_small_runs, INSTRUCTION-LEAN (round 6): the run-walking inference form of the small-grid forward (a thread
+// takes four consecutive samples of a ray and gathers only where the cell changes) with the arithmetic of
+// k_grid_fwd_small_lean -- level kinds and output format as template parameters, dense levels from ONE base index per
+// sample (24-bit multiplies, the generic rule behind a branch), hashed levels from two 32-bit multiplies with the aligned
+// 8-byte pair around corner px (+ corner px + 1 for odd px, two lane predicates steering every select), 32-bit byte
+// offsets against scalar bases, packed weight products, and nothing computed from a loaded value next to its load.
+// Level by level (the raw gathers of four samples of one level are 48 registers).  Bit-identical to k_grid_fwd_small.
+template <int NLDS, int NG, uint32_t HMASK, bool BF>
+__global__ void __launch_bounds__(kSmallBlock)
+k_grid_fwd_small_runs_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const __half2* __restrict__ table,
+                           __half2* __restrict__ out, uint32_t per_block) {
+    constexpr int RUN = 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const unsigned char* __restrict__ tab8 = reinterpret_cast<const unsigned char*>(table);
+    unsigned char* __restrict__ o8 = reinterpret_cast<unsigned char*>(out);
+    {   // staging: every load of the thread requested before the first is stored
+        const uint32_t n4 = g.offset[NLDS] >> 2;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+        uint4 st[kStageMax];
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) st[k] = src[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)];
+#pragma unroll
+        for (int k = 0; k < kStageMax; ++k) dst[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)] = st[k];
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.x * per_block;
+    const uint32_t last = min(N, first + per_block);  // (both multiples of RUN)
+    auto lds_level = [&](int l, const float (&p)[RUN * 3], uint32_t i0) {
+        const uint32_t off = g.offset[l], size = g.offset[l + 1] - off, res = g.resolution[l];
+        const uint32_t res2 = res * res;
+        const uint32_t* tl = lds_tab + off;
+        uint32_t r[RUN];
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            const Corner c = grid_cell(g.scale[l], p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+            const uint32_t base = c.px + __umul24(c.py, res) + __umul24(c.pz, res2);
+            const bool fast = max(max(c.px, c.py), c.pz) < res && base + res2 + res + 1u < size;
+            uint32_t even[4], odd[4];
+            if (fast) {
+                const uint32_t* b = tl + base;
+                even[0] = b[0]; odd[0] = b[1];
+                even[1] = b[res]; odd[1] = b[res + 1u];
+                even[2] = b[res2]; odd[2] = b[res2 + 1u];
+                even[3] = b[res2 + res]; odd[3] = b[res2 + res + 1u];
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t cy = c.py + (j & 1u), cz = c.pz + (j >> 1);
+                    even[j] = tl[nvo_grid_index(0u, size, res, c.px, cy, cz)];
+                    odd[j] = tl[nvo_grid_index(0u, size, res, c.px + 1u, cy, cz)];
+                }
+            }
+            float w[4][2];
+            lean_weights(c, w);
+            r[s] = lean_interp<BF>(w, even, odd);
+        }
+        *reinterpret_cast<uint4*>(o8 + (((uint32_t)l * N + i0) << 2)) = make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    for (uint32_t i0 = first + threadIdx.x * RUN; i0 < last; i0 += kSmallBlock * RUN) {
+        float p[RUN * 3];
+        {
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(x) + i0 * 12u);
+#pragma unroll
+            for (int q = 0; q < RUN * 3 / 4; ++q) {
+                const float4 f = xp[q];
+                p[4 * q] = f.x; p[4 * q + 1] = f.y; p[4 * q + 2] = f.z; p[4 * q + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const uint32_t level = NLDS + q;
+            const uint32_t off = g.offset[level], size = g.offset[level + 1] - off, res = g.resolution[level];
+            Corner c[RUN];
+            bool need[RUN];
+            uint2 pr[RUN][4];
+            uint32_t ex[RUN][4];
+            bool split[RUN];
+#pragma unroll
+            for (int s = 0; s < RUN; ++s) {
+                c[s] = grid_cell(g.scale[level], p[3 * s], p[3 * s + 1], p[3 * s + 2]);
+                need[s] = s == 0 || c[s].px != c[s - 1].px || c[s].py != c[s - 1].py || c[s].pz != c[s - 1].pz;
+                split[s] = false;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    pr[s][j] = make_uint2(0u, 0u);
+                    ex[s][j] = 0u;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < RUN; ++s) {
+                if (!need[s]) continue;  // (the branch holds index arithmetic and loads alone)
+                if ((HMASK >> q) & 1u) {
+                    const uint32_t mask = size - 1u;
+                    const uint32_t hy0 = c[s].py * 2654435761u, hy1 = hy0 + 2654435761u;
+                    const uint32_t hz0 = c[s].pz * 805459861u, hz1 = hz0 + 805459861u;
+                    const uint32_t a[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j)
+                        pr[s][j] = *reinterpret_cast<const uint2*>(tab8 + ((off + ((c[s].px ^ a[j]) & mask & ~1u)) << 2));
+                    if (c[s].px & 1u) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j)
+                            ex[s][j] = *reinterpret_cast<const uint32_t*>(tab8 + ((off + (((c[s].px + 1u) ^ a[j]) & mask)) << 2));
+                    }
+                } else {
+                    const uint32_t res2 = res * res;
+                    const uint32_t base = c[s].px + __umul24(c[s].py, res) + __umul24(c[s].pz, res2);
+                    split[s] = !(max(max(c[s].px, c[s].py), c[s].pz) < res && base + res2 + res + 1u < size);
+                    const uint32_t dj[4] = {0u, res, res2, res2 + res};
+                    if (!split[s]) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j)
+                            pr[s][j] = nvo_ld_u2_a4(reinterpret_cast<const uint32_t*>(tab8 + ((off + base + dj[j]) << 2)));
+                    } else {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const uint32_t cy = c[s].py + (j & 1u), cz = c[s].pz + (j >> 1);
+                            pr[s][j].x = *reinterpret_cast<const uint32_t*>(tab8 + ((off + nvo_grid_index(0u, size, res, c[s].px, cy, cz)) << 2));
+                            pr[s][j].y = *reinterpret_cast<const uint32_t*>(tab8 + ((off + nvo_grid_index(0u, size, res, c[s].px + 1u, cy, cz)) << 2));
+                        }
+                    }
+                }
+            }
+            // an LDS level while the gathers fly
+            if (q < NLDS) lds_level(q, p, i0);
+            uint32_t even[4] = {0u, 0u, 0u, 0u}, odd[4] = {0u, 0u, 0u, 0u};
+            uint32_t r[RUN];
+#pragma unroll
+            for (int s = 0; s < RUN; ++s) {
+                if ((HMASK >> q) & 1u) {
+                    const bool px_odd = (c[s].px & 1u) != 0u;
+                    const bool t = (((c[s].py ^ c[s].pz) & 1u) != 0u) != px_odd;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const bool hi = (j == 0u || j == 3u) ? t : !t;
+                        const uint32_t e = hi ? pr[s][j].y : pr[s][j].x;
+                        const uint32_t o = px_odd ? ex[s][j] : (hi ? pr[s][j].x : pr[s][j].y);
+                        even[j] = need[s] ? e : even[j];
+                        odd[j] = need[s] ? o : odd[j];
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        even[j] = need[s] ? pr[s][j].x : even[j];
+                        odd[j] = need[s] ? pr[s][j].y : odd[j];
+                    }
+                }
+                float w[4][2];
+                lean_weights(c[s], w);
+                r[s] = lean_interp<BF>(w, even, odd);
+            }
+            *reinterpret_cast<uint4*>(o8 + (((uint32_t)level * N + i0) << 2)) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+#pragma unroll
+        for (int l = NG; l < NLDS; ++l) lds_level(l, p, i0);  // (more LDS levels than global ones: the rest)
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward w.r.t. parameters, global-atomic form
 // ------------------------------------------------------------------------------------------
@@ -2788,6 +3063,26 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
                 attr_runs = true;
             }
             const uint32_t per_block = (uint32_t)nvo_round_up(nvo_div_up(N, n_cus), kSmallBlock * 4);
+            const uint32_t hm = (g.hashed[2] ? 1u : 0u) | (g.hashed[3] ? 2u : 0u) | (g.hashed[4] ? 4u : 0u);
+            if (small_env >= 4 && (hm == 6u || hm == 7u) && (uint64_t)N * 20u < (1ull << 32) && g.resolution[0] <= 4096u &&
+                g.resolution[1] <= 4096u && g.resolution[2] <= 4096u) {
+#define NVO_LAUNCH_RL(HM_, BF_)                                                                                           \
+    do {                                                                                                                   \
+        static bool attr_rl = false;                                                                                       \
+        if (!attr_rl) {                                                                                                    \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_grid_fwd_small_runs_lean<2, 3, HM_, BF_>,                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));                    \
+            attr_rl = true;                                                                                                \
+        }                                                                                                                  \
+        NVO_LAUNCH((k_grid_fwd_small_runs_lean<2, 3, HM_, BF_>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds,   \
+                   stream, g, N, x, (const __half2*)table_half, (__half2*)out_half, per_block);                            \
+    } while (0)
+                if (hm == 6u) { if (out_bf16) NVO_LAUNCH_RL(6u, true); else NVO_LAUNCH_RL(6u, false); }
+                else { if (out_bf16) NVO_LAUNCH_RL(7u, true); else NVO_LAUNCH_RL(7u, false); }
+#undef NVO_LAUNCH_RL
+                NVO_CHECK_LAUNCH();
+                return NVO_OK;
+            }
             NVO_LAUNCH((k_grid_fwd_small_runs<2, 3>), dim3(nvo_div_up(N, per_block)), dim3(kSmallBlock), lds, stream, g, N, x,
                        (const __half2*)table_half, (__half2*)out_half, out_bf16 ? 1 : 0, per_block);
             NVO_CHECK_LAUNCH();
@@ -2863,6 +3158,10 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
     static const bool lean_env = [] { const char* e = getenv("NVO_GRID_FWD_LEAN"); return e && atoi(e) != 0; }();
     bool lean = lean_env && small_env != 0 && !runs && soa && !indices && !dydx_half && (uint64_t)N * 12u < (1ull << 32);
     for (uint32_t l = 0; l < g.n_levels; ++l) lean = lean && g.resolution[l] <= 4096u;
+    // the run-walking inference form has a lean counterpart as well (form 0 = the first kernel)
+    static const bool lean_runs_env = [] { const char* e = getenv("NVO_GRID_FWD_RUNS_LEAN"); return !e || atoi(e) != 0; }();  // A/B
+    bool lean_runs = lean_runs_env && small_env != 0 && runs && (uint64_t)N * 12u < (1ull << 32);
+    for (uint32_t l = 0; l < g.n_levels; ++l) lean_runs = lean_runs && g.resolution[l] <= 4096u;
     if (lean) {
         static const bool pair_env = [] { const char* e = getenv("NVO_GRID_FWD_PAIR"); return !e || atoi(e) != 0; }();  // A/B (default on)
 #define NVO_LAUNCH_LEANM(SPT_, BF_, PAIR_)                                                                   \
@@ -2878,6 +3177,9 @@ int nvo_grid_fwd_launch(const NvoGridLevels& g, hipStream_t stream, uint32_t N, 
         else NVO_LAUNCH_LEANS(4);
 #undef NVO_LAUNCH_LEANS
 #undef NVO_LAUNCH_LEANM
+    } else if (runs && lean_runs) {
+        if (out_bf16) NVO_LAUNCH((k_grid_fwd_runs_lean<kGridBlock, true>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, (__half2*)out_half, plan, n_live);
+        else NVO_LAUNCH((k_grid_fwd_runs_lean<kGridBlock, false>), grid, block, 0, stream, g, N, x, (const __half2*)table_half, (__half2*)out_half, plan, n_live);
     } else if (runs) {
         NVO_LAUNCH((k_grid_fwd_runs<kGridBlock>), grid, block, 0, stream, g, N, x, (const __half2*)table_half,
                    (__half2*)out_half, out_bf16 ? 1 : 0, plan, n_live);

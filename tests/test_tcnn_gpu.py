@@ -890,7 +890,17 @@ def test_grid_forward_forms_are_bit_identical(device, cfg, dtype):
                 y = net(x)
             torch.cuda.synchronize()
             outs[form] = y.view(torch.int16).cpu()
+        # the run-walking inference forms (option grid_fwd_runs: four consecutive samples per thread, gathers only where
+        # the cell changes): the first kernels (form 1) and the instruction-lean one of the small grids (form 4)
+        m.set_option("grid_fwd_runs", 1)
+        for form in (1, 4):
+            m.set_option("grid_fwd_small_form", form)
+            with torch.no_grad():
+                y = net(x)
+            torch.cuda.synchronize()
+            outs[("runs", form)] = y.view(torch.int16).cpu()
+        m.set_option("grid_fwd_runs", 0)
         m.set_option("grid_fwd_small_form", -1)
-        for form in (0, 3, 4):
+        for form in (0, 3, 4, ("runs", 1), ("runs", 4)):
             diff = int((outs[form] != outs[1]).sum())
             assert diff == 0, f"form {form} differs from form 1 in {diff} of {outs[1].numel()} outputs (n={n})"

@@ -78,7 +78,7 @@ def kernel_table(lib, engine, step_fn, steps: int, ms_per_step: float, device) -
 
 def run(keyframes=192, height=480, width=640, iterations=8192, window_steps=200, window_starts=WINDOW_STARTS,
         tracker_window=26, profile_steps=60, camera_optimizer_mode="off", seed=42, device="cuda:0", quiet=True,
-        out_dir=None):
+        out_dir=None, render_frames=3):
     entry.build()
     from nerf_vo_amd import _lib
     from nerf_vo_amd.mapping.dataset import opencv_to_opengl
@@ -188,6 +188,33 @@ def run(keyframes=192, height=480, width=640, iterations=8192, window_steps=200,
             table.append({"kernel": name, "launches_per_step": round(cnt / profile_steps, 3), "avg_launch_us": round(total / cnt * 1e3, 2),
                           "us_per_step": round(total / profile_steps * 1e3, 2), "share": round(total / tot, 4)})
     # (no shut_down tick: the snapshot -- a 0.9 GB dataset.pt at this size -- is outside the measured path)
+    # ---- inference on the field this run trained (what evaluation/nerf_renderer.py does after mapping): full frames at the
+    # dataset's native 1200x680 and at the training resolution, one hipGraph per image shape, HIP-event timed
+    rendered = []
+    if render_frames > 0:
+        from nerf_vo_amd.mapping.cameras import Cameras
+        from nerf_vo_amd.synthetic import replica_intrinsics
+
+        pose = ds.camera_extrinsics[keyframes // 2:keyframes // 2 + 1, :3, :4].clone()
+        for w_, h_ in ((1200, 680), (width, height)):
+            fx, fy, cx, cy = replica_intrinsics(h_, w_)
+            cams = Cameras(camera_to_worlds=pose, fx=fx, fy=fy, cx=cx, cy=cy, width=w_, height=h_).to(dev)
+
+            def frame():
+                b = cams.generate_rays(camera_indices=0, keep_shape=True)
+                return eng.render_image(b.origins.reshape(-1, 3), b.directions.reshape(-1, 3),
+                                        b.metadata["directions_norm"].reshape(-1), chunk=1 << 15)
+
+            frame()  # (captures the graph of this image shape)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(render_frames):
+                img = frame()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            rendered.append({"resolution": [w_, h_], "ms_per_frame": round(e0.elapsed_time(e1) / render_frames, 3),
+                             "finite": bool(torch.isfinite(img["rgb"]).all()), "mean_accumulation": round(float(img["accumulation"].mean()), 4)})
     res = {
         "what": "the reference's mapping run end to end: MappingModule.step -> Nerfstudio(update | train) with its ingest cadence "
                 "(one DPVO-shaped item per keyframe: new colour frame + refreshed poses / depths of the tracker window, then "
@@ -198,6 +225,7 @@ def run(keyframes=192, height=480, width=640, iterations=8192, window_steps=200,
         "ticks": ticks, "skipped_ticks": skipped, "ingests": len(ingest_events), "ingest_gpu_ms_total": ingest_ms,
         "ingest_gpu_ms_each": ingest_ms / max(len(ingest_events), 1),
         "windows": windows, "final_losses": losses, "loss_scale_end": eng.current_loss_scale(),
+        "render_of_the_trained_field": rendered,
         "trained_field_kernel_table": table,
         "trained_field_kernel_us_per_step": round(sum(r["us_per_step"] for r in table), 2),
         "trained_field_note": f"{profile_steps} eager steps after iteration {done}, HIP-event pair per launch, every kernel alone on "
@@ -218,6 +246,7 @@ if __name__ == "__main__":
     ap.add_argument("--profile-steps", type=int, default=60)
     ap.add_argument("--camera-optimizer-mode", default="off", help="off (BASELINE configs[1], fixed poses) | SE3 | SO3xR3")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--render-frames", type=int, default=3, help="timed full-frame renders of the trained field per resolution (0 = skip)")
     a = ap.parse_args()
     run(a.keyframes, a.height, a.width, a.iterations, window_steps=a.window_steps, profile_steps=a.profile_steps,
-        camera_optimizer_mode=a.camera_optimizer_mode, seed=a.seed, quiet=False)
+        camera_optimizer_mode=a.camera_optimizer_mode, seed=a.seed, quiet=False, render_frames=a.render_frames)
