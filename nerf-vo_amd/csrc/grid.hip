@@ -757,6 +757,7 @@ k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
     const uint32_t first = blockIdx.x * per_block;
     const uint32_t last = min(N, first + per_block);
     if (first >= last) return;  // (uniform)
+    GP_CLK(gl0);
     const uint32_t n_pass = (last - first + kSmallBlock - 1u) / kSmallBlock;
     const uint32_t wave_first = first + (threadIdx.x & ~63u);  // first sample of this wave in pass 0
 
@@ -862,6 +863,7 @@ k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
         for (int k = 0; k < kStageMax; ++k) dst[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)] = st[k];
     }
     __syncthreads();
+    GP_CLK(gl1);
     for (uint32_t pass = 0; pass < n_pass; ++pass) {
         if (wave_first + pass * kSmallBlock >= last) break;  // (wave-uniform: nothing of this wave is left; no barrier below)
         const uint32_t i = first + pass * kSmallBlock + threadIdx.x;
@@ -925,6 +927,12 @@ k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
         if (wave_first + (pass + 1u) * kSmallBlock < last) issue(p1);  // (wave-uniform)
         p0 = p1;
     }
+#ifdef NVO_GRID_PHASE
+    if (threadIdx.x == 0) {  // (slots of k_grid_fwd_small: staging [+ the first pass's gather issue here], sample loop, workgroups)
+        GP_CLK(gl2);
+        GP_ADD(32, gl1 - gl0); GP_ADD(33, gl2 - gl1); GP_ADD(37, 1);
+    }
+#endif
 }
 
 // k_grid_fwd for the level-major production path, INSTRUCTION-LEAN (round 6): the blockIdx -> (tile, level) plan of
