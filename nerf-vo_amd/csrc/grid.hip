@@ -850,20 +850,44 @@ k_grid_fwd_small_lean(NvoGridLevels g, uint32_t N, const float* __restrict__ x, 
         }
     };
 
+#ifndef NVO_LEAN_STAGE
+#define NVO_LEAN_STAGE 1
+#endif
     Pos p0 = load_pos(0u);
-    {   // staging: every load of the thread requested before the first is stored
+    {   // staging
         const uint32_t n4 = g.offset[NLDS] >> 2;
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(table);
         uint4* dst = reinterpret_cast<uint4*>(lds_tab);
+#if NVO_LEAN_STAGE == 0
+        for (uint32_t e = threadIdx.x; e < n4; e += kSmallBlock) dst[e] = src[e];
+#elif NVO_LEAN_STAGE == 2
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 st[kStageMax / 2];
+#pragma unroll
+            for (int k = 0; k < kStageMax / 2; ++k) st[k] = src[min(threadIdx.x + (uint32_t)(h * (kStageMax / 2) + k) * kSmallBlock, n4 - 1u)];
+#pragma unroll
+            for (int k = 0; k < kStageMax / 2; ++k) dst[min(threadIdx.x + (uint32_t)(h * (kStageMax / 2) + k) * kSmallBlock, n4 - 1u)] = st[k];
+        }
+#else
         uint4 st[kStageMax];
 #pragma unroll
         for (int k = 0; k < kStageMax; ++k) st[k] = src[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)];
-        issue(p0);  // (the first pass's gathers fly with the staging loads)
 #pragma unroll
         for (int k = 0; k < kStageMax; ++k) dst[min(threadIdx.x + (uint32_t)k * kSmallBlock, n4 - 1u)] = st[k];
+#endif
     }
+#ifdef NVO_GRID_PHASE
+    GP_CLK(gls);
+    if (threadIdx.x == 0) GP_ADD(34, gls - gl0);  // (staging alone, before the first pass's index arithmetic)
+#endif
+    // The kernel's ONE barrier sits directly behind the staging stores and the first pass's gathers are requested behind
+    // IT: the waves of a workgroup move through a gather-issue phase very unevenly (the address path serves 16 waves x 24
+    // divergent gathers; phase clocks: the last wave reaches the end of that phase ~20 K cycles after the first), and
+    // with the phase in front of the barrier every wave waited for the slowest one -- 25 K of a workgroup's 40 K cycles.
     __syncthreads();
     GP_CLK(gl1);
+    issue(p0);
     for (uint32_t pass = 0; pass < n_pass; ++pass) {
         if (wave_first + pass * kSmallBlock >= last) break;  // (wave-uniform: nothing of this wave is left; no barrier below)
         const uint32_t i = first + pass * kSmallBlock + threadIdx.x;

@@ -68,8 +68,9 @@ def main():
     table("slice-owner items of DENSE levels", ["zero + barrier", "scan", "barrier behind slowest wave", "flush"], v[16:20], v[20], "items")
     table("slice-owner items of HASHED levels", ["zero + barrier", "scan", "barrier behind slowest wave", "flush"], v[24:28], v[28], "items")
     table("k_grid_fwd_small, per workgroup", ["LDS staging + barrier", "sample loop"], v[32:34], v[37], "workgroups")
-    table("  sample loop of k_grid_fwd_small", ["cells, hashes, gather issue", "LDS levels", "gather wait + interpolation + stores"],
-          v[34:37], v[37], "workgroups")
+    table("  sample loop of k_grid_fwd_small (lean form: slot 0 = staging alone, before the first pass's index arithmetic)",
+          ["cells, hashes, gather issue", "LDS levels", "gather wait + interpolation + stores"], v[34:37], v[37], "workgroups")
+
 
 
 if __name__ == "__main__":
