@@ -865,6 +865,8 @@ struct NwieModule : nvo_module_s {
             if (want_l1) {
                 owner->ext_l1 = a.dx_l1_partial;
                 owner->ext_live = a.dx_live_partial;
+                static const bool live_dout = [] { const char* e = getenv("NVO_LIVE_FROM_DOUT"); return !e || atoi(e) != 0; }();  // A/B
+                owner->ext_dout = (live_dout && compact_out && a.dx_live_partial) ? reinterpret_cast<const uint16_t*>(dout) : nullptr;
                 owner->ext_blocks = l1_blocks;
                 owner->ext_l1_stride = (uint32_t)net->in_pad;
             }
@@ -872,6 +874,7 @@ struct NwieModule : nvo_module_s {
             if (want_l1) {
                 owner->ext_l1 = nullptr;
                 owner->ext_live = nullptr;
+                owner->ext_dout = nullptr;
                 owner->ext_blocks = owner->ext_l1_stride = 0u;
             }
             if (rc) return rc;

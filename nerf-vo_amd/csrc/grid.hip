@@ -2229,7 +2229,7 @@ template <bool SOA, typename DY2>
 __global__ void __launch_bounds__(1024)
 k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t* __restrict__ count,
                uint32_t* __restrict__ out, unsigned long long* __restrict__ l1, const uint32_t* __restrict__ ext_live,
-               uint32_t ext_blocks) {
+               uint32_t ext_blocks, const uint16_t* __restrict__ ext_dout) {
     // ext_live (NvoGridSlices::ext_live): the fused-MLP backward that wrote dy counted the samples with a non-zero
     // dL/doutput per workgroup.  While at least 3/4 of them are live the items scan all samples anyway (grid_bwd_item:
     // `listed`): nobody needs the list, every workgroup leaves at once and the length word says "all N".
@@ -2268,7 +2268,13 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
         const uint32_t i = first + q * 1024u + threadIdx.x;
         live[q] = false;
         if (i < N) {
-            if (l1) {
+            if (ext_dout && !l1) {
+                // (NvoGridSlices::ext_dout: dL/doutput of the network in front, one 16-bit value per sample -- dy = W^T dZ is
+                // exactly zero on every level where it is zero, so the list built from it holds every sample the level-wise
+                // test would list (and the few whose products all underflowed, which the scans skip): 2 bytes per sample
+                // instead of 4 per sample and level)
+                live[q] = (ext_dout[i] & 0x7FFFu) != 0u;
+            } else if (l1) {
 #pragma unroll
                 for (uint32_t l = 0; l < kL1Levels; ++l) {
                     if (l < g.n_levels) {
@@ -3701,7 +3707,8 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                 if (int rc = nvo_zero_async(slices->d_l1, sizeof(unsigned long long) * 2 * g.n_levels, stream)) return rc;
 #define NVO_LAUNCH_LIVE(SOA_, T_)                                                                                    \
     NVO_LAUNCH((k_live_samples<SOA_, T_>), dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, g, N, (const T_*)dy, \
-               slices->d_live_n, d_live, l1_fused ? slices->d_l1 : nullptr, slices->ext_live, slices->ext_blocks)
+               slices->d_live_n, d_live, l1_fused ? slices->d_l1 : nullptr, slices->ext_live, slices->ext_blocks, \
+               (soa && !l1_fused) ? slices->ext_dout : nullptr)
             if (soa) { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, true); } else { NVO_DY_DISPATCH(NVO_LAUNCH_LIVE, false); }
 #undef NVO_LAUNCH_LIVE
             live = d_live;

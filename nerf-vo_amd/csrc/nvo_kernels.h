@@ -57,6 +57,9 @@ struct NvoGridSlices {
     // ext_live[block] = samples with a non-zero dL/doutput (nullable).  See NvoMlpArgsT::dx_l1_partial.
     mutable const float* ext_l1 = nullptr;
     mutable const uint32_t* ext_live = nullptr;
+    // (set per launch with ext_live) dL/doutput of that network when it is ONE 16-bit value per sample (compact output):
+    // k_live_samples lists the samples from it instead of reading dL/d(encoded) of every level
+    mutable const uint16_t* ext_dout = nullptr;
     mutable uint32_t ext_blocks = 0, ext_l1_stride = 0;
 };
 #include <utility>

@@ -64,8 +64,10 @@ ngp)
     grep -v "^{" $OUT/${R}_ngp_bench.txt | tail -45 ;;
 probes)
     { for v in 1 3 4; do NVO_GRID_FWD_SMALL=$v python3 $ROOT/tools/probes/fwd_small_ab.py /tmp/ab_small.pt 2>&1 | grep -E "back to back|grid_fwd|identical"; done; } > $OUT/${R}_probe_fwd_small_forms.txt
-    { python3 $ROOT/tools/probes/fwd_main_ab.py 2>&1 | grep -E "form|identical"; echo "--- NVO_GRID_FWD_LEAN=1 NVO_GRID_FWD_PAIR=0 (plain 4-byte gathers in the lean form)";
-      NVO_GRID_FWD_PAIR=0 python3 $ROOT/tools/probes/fwd_main_ab.py 2>&1 | grep -E "form 4"; } > $OUT/${R}_probe_fwd_main_forms.txt
+    { echo "--- NVO_GRID_FWD_LEAN=1 (form 4 = k_grid_fwd_lean with the aligned 8-byte pair on hashed levels; form 0 = k_grid_fwd, the default)";
+      NVO_GRID_FWD_LEAN=1 python3 $ROOT/tools/probes/fwd_main_ab.py 2>&1 | grep -E "form|identical"
+      echo "--- NVO_GRID_FWD_LEAN=1 NVO_GRID_FWD_PAIR=0 (plain 4-byte gathers in the lean form)"
+      NVO_GRID_FWD_LEAN=1 NVO_GRID_FWD_PAIR=0 python3 $ROOT/tools/probes/fwd_main_ab.py 2>&1 | grep -E "form 4"; } > $OUT/${R}_probe_fwd_main_forms.txt
     { for v in 0 1; do NVO_GRID_SLICE_CODES=$v python3 $ROOT/tools/probes/bwd_codes_ab.py /tmp/ab_codes.pt 2>&1 | grep -E "grid_bwd|identical|saved"; done; } > $OUT/${R}_probe_bwd_slice_codes.txt
     $ROOT/tools/probes/launch_probe > $OUT/${R}_probe_launch_staging.txt 2>&1
     tail -n +1 $OUT/${R}_probe_*.txt | cut -c1-170 ;;
