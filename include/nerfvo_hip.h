@@ -121,6 +121,11 @@ uint64_t nvo_ctx_bytes(nvo_module_t m, uint32_t batch);
  *   "grid_fwd_runs"             the level-major forward (no input gradients requested) walks runs of four consecutive
  *                               samples per thread and gathers only where the cell changes: pays on ray-ordered samples
  *                               of a trained field (inference), costs ~8 % on uniform ones; bit-identical; default 0
+ *   "grid_fwd_small_form"       form of the level-major forward: -1 = default; for 5-level grids whose two coarsest levels fit
+ *                               the LDS: 0 the first thread-per-(sample, level) kernel, 1 coarse levels from LDS, 2 two
+ *                               samples per thread, 3 software-pipelined, 4 instruction-lean + pipelined (the default);
+ *                               other grids: 0 the first kernel, else the default.  Every form produces the same bits
+ *                               (tests, A/B); with "grid_fwd_runs" the choice is between the first and the lean run forms
  *   "fuse_encoding"             (NetworkWithInputEncoding) the forward evaluates the hash grid inside the MLP kernel
  *   "external_zero"             1 = nvo_bwd does not clear what it accumulates into (MLP weight gradient, atomically
  *                               flushed grid ranges, scale scratch): the caller clears the ranges nvo_bwd_zero_ranges
