@@ -421,6 +421,11 @@ typedef struct nvo_main_loss_args {
                                     GradScaler state lives on the device so that a captured step stays valid) */
     uint32_t* nonfinite_flag;    /* nullable: OR-ed with 1 when a gradient stored to dpre / drgb overflows the 16-bit
                                     format (inf / NaN / > 65504 in fp16): the overflow check at its source */
+    uint8_t* tile_live;          /* nullable (training, S % 16 == 0, S <= 64): [R*S/16] one byte per 16-sample tile --
+                                    bit 0: some stored drgb value of the tile is non-zero, bit 1: some stored dpre value
+                                    is.  The MLP backwards behind this kernel walk only the live tiles
+                                    (nvo_color_args::tile_live, module option "bwd_tile_live_ptr"); slot 7 of the loss
+                                    shards then receives the number of tiles with a non-zero byte */
 } nvo_main_loss_args;
 int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args);
 
@@ -484,6 +489,10 @@ typedef struct nvo_color_args {
                                     (an overflow inside its 16-bit chain; d_embedding / d_sh are non-finite only with it) */
     float* dw_replicas;          /* backward; nullable: n_dw_replicas zeroed copies [r][9216] of d_weights the workgroups spread */
     uint32_t n_dw_replicas;      /* their adds over (module option "dw_replicas"); fold with nvo_fold_replicas */
+    const uint8_t* tile_live;    /* backward; nullable: nvo_main_loss_args::tile_live of the kernel that wrote drgb -- tiles
+                                    without bit 0 are not evaluated, their d_base_out columns 1..15 are stored as zeros */
+    const float* tile_live_count;/* nullable: the loss shards' slot 7 (64 floats, 8 apart; nvo_main_loss_args::tile_live) --
+                                    while 3/4 of the tiles or more are live the kernel does not build its list */
 } nvo_color_args;
 int nvo_nerfacto_color_fwd(nvo_stream_t stream, const nvo_color_args* args);
 int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args);

@@ -41,7 +41,8 @@ class MainLossArgs(C.Structure):
                 ("out_accumulation", _p), ("weights", _p), ("losses", _p), ("dpre", _p), ("dpre_stride", _u32),
                 ("drgb", _p), ("drgb_stride", _u32),
                 ("dsigma_dx", _p), ("dsigma_inv_scale", _f), ("gt_normal", _p), ("normal_mult", _f),
-                ("out_normals", _p), ("act_bf16", _int), ("loss_scale_dev", _p), ("nonfinite_flag", _p)]
+                ("out_normals", _p), ("act_bf16", _int), ("loss_scale_dev", _p), ("nonfinite_flag", _p),
+                ("tile_live", _p)]
 
 
 class PropLossArgs(C.Structure):
@@ -60,7 +61,7 @@ class ColorArgs(C.Structure):
                 ("weights", _p), ("rgb", _p), ("hidden", _p), ("drgb", _p), ("d_base_out", _p),
                 ("d_embedding", _p), ("d_sh", _p), ("d_weights", _p), ("act_bf16", _int), ("det_scratch", _p),
                 ("det_scratch_bytes", _u64), ("n_cameras", _u32), ("nonfinite_flag", _p), ("dw_replicas", _p),
-                ("n_dw_replicas", _u32)]
+                ("n_dw_replicas", _u32), ("tile_live", _p), ("tile_live_count", _p)]
 
 
 class RayHeadArgs(C.Structure):

@@ -751,6 +751,11 @@ struct NwieModule : nvo_module_s {
     std::unique_ptr<MlpModule> net;
     int compact_out = 0;  // option "compact_output": output / dL_doutput are [B] halfs (column 0 only)
     int recompute_hidden = 0;  // option "recompute_hidden": the forward does not store the hidden layer
+    // options "bwd_tile_live_ptr" / "bwd_tile_live_bits": NvoMlpArgsT::tile_live of the backwards that follow (the caller
+    // clears the pointer when its dL/doutput no longer comes with such bytes)
+    const uint8_t* bwd_tile_live = nullptr;
+    uint32_t bwd_tile_live_bits = 0xffu;
+    const float* bwd_tile_live_count = nullptr;  // option "bwd_tile_live_count_ptr"
     // option "fuse_encoding": the forward evaluates the hash grid inside the MLP kernel's operand load
     // (NVO_IO_GRID_FUSED) -- one launch, no feature round trip between two kernels.  Meant for grids whose tables fit
     // every XCD's L2 (the proposal networks: 1.5 MB): the stand-alone k_grid_fwd keeps a level's table on ONE XCD,
@@ -839,6 +844,11 @@ struct NwieModule : nvo_module_s {
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
+        if (bwd_tile_live && !compact_out) {  // (module option "bwd_tile_live_ptr": the caller's promise about `dout`)
+            a.tile_live = bwd_tile_live;
+            a.tile_live_bits = bwd_tile_live_bits;
+            a.tile_live_count = bwd_tile_live_count;
+        }
         if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         if (int rc0 = net->det_partials(s, B, &a)) return rc0;
@@ -870,7 +880,23 @@ struct NwieModule : nvo_module_s {
                 owner->ext_blocks = l1_blocks;
                 owner->ext_l1_stride = (uint32_t)net->in_pad;
             }
+            // the samples behind dead tiles carry no gradient: the encoding lists the others from `dout` (k_live_rows)
+            const char* const e_rows = getenv("NVO_GRID_LIVE_ROWS");  // A/B, tests (per launch; a graph keeps its capture's)
+            const bool live_rows = !e_rows || atoi(e_rows) != 0;
+            const bool list_rows = live_rows && a.tile_live && owner && enc->bwd_mode == 3 && net->out_pad == 16;
+            if (list_rows) {
+                owner->ext_tile_live = a.tile_live;
+                owner->ext_tile_bits = a.tile_live_bits;
+                owner->ext_rows = dout;
+                owner->ext_tile_count = bwd_tile_live_count;
+            }
             rc = enc->bwd_params(sp, B, in, dencoded, true, dparams + net->n_params);
+            if (list_rows) {
+                owner->ext_tile_live = nullptr;
+                owner->ext_rows = nullptr;
+                owner->ext_tile_count = nullptr;
+                owner->ext_tile_bits = 0u;
+            }
             if (want_l1) {
                 owner->ext_l1 = nullptr;
                 owner->ext_live = nullptr;
@@ -911,6 +937,24 @@ struct NwieModule : nvo_module_s {
         if (!strcmp(key, "external_zero")) {
             if (int rc = enc->set_external_zero(value != 0)) return rc;
             net->external_zero = value != 0;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "bwd_tile_live_ptr")) {  // device bytes, one per 16 samples of the NEXT backwards' dL/doutput (0 = none)
+            bwd_tile_live = reinterpret_cast<const uint8_t*>((uintptr_t)value);
+            return NVO_OK;
+        }
+        if (!strcmp(key, "bwd_tile_live_bits")) {
+            bwd_tile_live_bits = (uint32_t)value;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "debug_copy_grid_live_n")) {  // (tests) length word of the encoding's live-sample list -> *value (device u32)
+            const NvoGridSlices* owner = enc->bwd_mode == 1 ? &enc->slices : enc->bwd_mode == 3 ? &enc->stream_bins.owner : nullptr;
+            NVO_REQUIRE(owner && owner->d_live_n && value, "debug_copy_grid_live_n: no slice-owner state");
+            NVO_CHECK_HIP(hipMemcpy(reinterpret_cast<void*>((uintptr_t)value), owner->d_live_n, sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            return NVO_OK;
+        }
+        if (!strcmp(key, "bwd_tile_live_count_ptr")) {  // 64 float shards, 8 floats apart: their sum = number of live tiles (0 = none)
+            bwd_tile_live_count = reinterpret_cast<const float*>((uintptr_t)value);
             return NVO_OK;
         }
         if (!strcmp(key, "recompute_hidden")) {

@@ -1653,7 +1653,7 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                                               const uint32_t* __restrict__ live = nullptr, bool merge = false,
                                               uint32_t slice_cap = ACC::kEntries, uint32_t* __restrict__ nf_flag = nullptr,
                                               const uint32_t* __restrict__ live_n = nullptr, uint32_t ring_off = 0u,
-                                              const uint16_t* __restrict__ codes = nullptr) {
+                                              const uint16_t* __restrict__ codes = nullptr, uint32_t list_pass = 4096u) {
     typename ACC::T* acc = reinterpret_cast<typename ACC::T*>(lds_raw);
     const uint32_t off = g.offset[level];
     const uint32_t size = g.offset[level + 1] - off;
@@ -1668,11 +1668,14 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
     const uint32_t n_scan = listed ? n_live : N;
     // A short list does not need all of a slice's chunks: an item costs ~10 us of zeroing / flushing / barriers
     // whatever it scans (measured: with 95 % of the samples dead the launch only got 15 % faster), so only as many
-    // chunks stay active as have a full pass (4096 samples) to scan; the others leave at once.  The slice of a
-    // chunked item is flushed with atomics into a pre-zeroed range, which any number of active chunks satisfies.
+    // chunks stay active as have a full pass (list_pass = 4096 samples) to scan; the others leave at once.  The slice of
+    // a chunked item is flushed with atomics into a pre-zeroed range, which any number of active chunks satisfies.
+    // (list_pass = 1024, a stream layout's coarse levels behind k_live_rows: EVERY listed sample carries a gradient there
+    // and it is their visits that cost, not the scan -- 31 K listed samples on 7 of a slice's 28 chunks took 25 us where the
+    // full scan of 1.5 M mostly dead ones on all 28 takes 12.)
     uint32_t n_act = n_chunks;
     if (listed && n_chunks > 1u) {
-        n_act = max(1u, min(n_chunks, n_scan / 4096u));
+        n_act = max(1u, min(n_chunks, n_scan / list_pass));
         if (chunk >= n_act) return;
     }
 
@@ -1770,8 +1773,14 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
         if constexpr (SOA && sizeof(DY2) == 4) {
             vec = !listed && (N & 3u) == 0u && (((uintptr_t)dy) & 15u) == 0u && (((uintptr_t)x) & 15u) == 0u;
         }
-        for (uint32_t c0 = wave_grab(64u * kRun); begin + c0 < end; c0 = wave_grab(64u * kRun)) {
-            const uint32_t b0 = begin + c0 + lane_id * kRun;
+        // (a list of samples that ALL carry a gradient -- list_pass < 4096, k_live_rows on a trained field, one sample per
+        // ray: a lane takes ONE sample of a 64-sample block; list neighbours are not neighbours in space, there is nothing
+        // to merge, and a short list then reaches every wave: 1.1 K samples per item are 17 blocks of 64 but only 3 of 512)
+        const bool single = listed && list_pass < 4096u;
+        const uint32_t kGrab = single ? 64u : 64u * kRun;
+        const uint32_t kLaneRun = single ? 1u : kRun;
+        for (uint32_t c0 = wave_grab(kGrab); begin + c0 < end; c0 = wave_grab(kGrab)) {
+            const uint32_t b0 = begin + c0 + lane_id * kLaneRun;
             if (b0 >= end) continue;
             open = false;
             hit = false;
@@ -1792,6 +1801,12 @@ __device__ __forceinline__ void grid_bwd_item(const NvoGridLevels& g, uint32_t N
                     visit(p5.y, p5.z, p5.w, dy2f(__builtin_bit_cast(DY2, q1.w)));
                     done = true;
                 }
+            }
+            if (!done && single) {
+                const uint32_t id = live[b0];
+                const DY2 dd = SOA ? dy[(size_t)level * N + id] : dy[(size_t)id * g.n_levels + level];
+                visit(x[3 * (size_t)id + 0], x[3 * (size_t)id + 1], x[3 * (size_t)id + 2], dy2f(dd));
+                done = true;
             }
             if (!done) {
                 const uint32_t stop = min(end, b0 + kRun);
@@ -2162,7 +2177,7 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
                const uint4* __restrict__ items, const unsigned long long* __restrict__ l1,
                const uint32_t* __restrict__ live, uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_n,
                uint32_t ring_off, const float* __restrict__ ext_l1, uint32_t ext_blocks, uint32_t ext_stride,
-               const uint16_t* __restrict__ codes, uint32_t code_levels) {
+               const uint16_t* __restrict__ codes, uint32_t code_levels, uint32_t list_pass) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 item = items[blockIdx.x];  // {level, first entry, chunk, n_chunks | accumulator-kind flags}
     const uint32_t n_chunks = item.w & 0x1FFFFFFFu;
@@ -2197,7 +2212,7 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
     }
     if (item.w >> 31) {
         grid_bwd_item<AccFloat, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n, 0u, nullptr, list_pass);
     } else if ((item.w >> 30) & 1u) {
         const float l1x = ext_l1 ? l1e[0] : (float)l1[2 * level] * (1.f / 256.f);
         const float l1y = ext_l1 ? l1e[1] : (float)l1[2 * level + 1] * (1.f / 256.f);
@@ -2210,10 +2225,10 @@ k_grid_bwd_lds(NvoGridLevels g, uint32_t N, const float* __restrict__ x,
         const uint16_t* lc = (codes && ((code_levels >> level) & 1u))
                                  ? codes + (size_t)__builtin_popcount(code_levels & ((1u << level) - 1u)) * N : nullptr;
         grid_bwd_item<AccFixed32, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw, sc, live,
-                                            merge, cap, nf_flag, live_n, ring_off, lc);
+                                            merge, cap, nf_flag, live_n, ring_off, lc, list_pass);
     } else {
         grid_bwd_item<AccFixed, SOA, DY2>(g, N, x, dy, grad, level, item.y, item.z, n_chunks, lds_raw,
-                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n);
+                                          AccScale{0.f, 0.f, 0.f, 0.f}, live, merge, cap, nf_flag, live_n, 0u, nullptr, list_pass);
     }
 }
 
@@ -2314,6 +2329,59 @@ k_live_samples(NvoGridLevels g, uint32_t N, const DY2* __restrict__ dy, uint32_t
         // round UP to the 2^-8 grid: the sum must not under-estimate (it bounds every accumulator) -- as k_dy_l1
         atomicAdd(&l1[2 * l + f], (unsigned long long)ceilf(t * 256.f) + 1ull);
     }
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = wave_cnt[w];
+            wave_cnt[w] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = block_base + wave_cnt[wib];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const unsigned long long m = __ballot(live[q]);
+        if (live[q]) out[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = first + q * 1024u + threadIdx.x;
+        pos += (uint32_t)__popcll(m);
+    }
+}
+
+// The same list from the dL/doutput ROWS of the network in front (16 16-bit values per sample) and the tile bytes of the
+// kernel that wrote them (NvoGridSlices::ext_tile_live): a sample whose row is all zero has dL/d(encoded) = W^T dZ = 0 on
+// every level, and a tile without its bits holds only such rows and is not read at all.  On a trained field one sample
+// of a ray's 48 carries the weight: a third of the main level's tiles are live, 2 % of its samples, and the record
+// scatter below spends its time on workgroups of 512 samples of which ten do anything.
+__global__ void __launch_bounds__(1024)
+k_live_rows(uint32_t N, const uint8_t* __restrict__ tile_live, uint32_t bits, const uint4* __restrict__ rows,
+            const float* __restrict__ tile_count, uint32_t* __restrict__ count, uint32_t* __restrict__ out) {
+    constexpr uint32_t kPer = 4;
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t block_base;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    if (tile_count) {  // (uniform over the launch: every workgroup sums the same 64 words)
+        const float c = nvo_wave_sum(tile_count[8u * lane]);
+        if (c >= (float)((N >> 4) - (N >> 6))) {  // (3/4 of the tiles, as the consumers' rule for the list itself)
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(count, N);  // "all N": the consumers scan every sample
+            return;
+        }
+    }
+    const uint32_t first = blockIdx.x * (1024u * kPer);
+    bool live[kPer];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t i = first + q * 1024u + threadIdx.x;
+        live[q] = false;
+        if (i < N && (tile_live[i >> 4] & bits) != 0u) {
+            const uint4 a = rows[2 * (size_t)i], b = rows[2 * (size_t)i + 1];
+            live[q] = ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) & 0x7FFF7FFFu) != 0u;
+        }
+        mine += (uint32_t)__popcll(__ballot(live[q]));
+    }
+    if (lane == 0u) wave_cnt[wib] = mine;
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < 16; ++w) {
@@ -2460,7 +2528,7 @@ __global__ void __launch_bounds__(TILE)
 k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
                uint32_t* __restrict__ seg, uint32_t* __restrict__ segl1, uint32_t* __restrict__ records,
-               uint32_t* __restrict__ nf_flag) {
+               uint32_t* __restrict__ nf_flag, const uint32_t* __restrict__ live_list, const uint32_t* __restrict__ live_n) {
     constexpr uint32_t kStBlock = TILE;
     // capacity: every pair split into two single-corner records.  (Staging only TILE * 4 records in LDS -- four workgroups
     // per CU instead of three -- with the overflow written straight to the region measured SLOWER: 42.5 -> 48.5 us.)
@@ -2477,7 +2545,14 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     uint32_t* loff = reinterpret_cast<uint32_t*>(hist + n_slices);
     __shared__ uint32_t total_s;
     __shared__ float wmax[kWaves][2];
-    const uint32_t i = tile * kStBlock + threadIdx.x;
+    // live_list (k_live_rows / k_live_samples): the tiles are cut from the list of samples that carry a gradient -- as the
+    // slice-owner items, only while it is shorter than 3/4 N; tiles past its end write empty segments and leave
+    const uint32_t n_listed = live_list ? *live_n : N;
+    const bool listed = live_list != nullptr && n_listed < N - (N >> 2);
+    const uint32_t n_scan = listed ? n_listed : N;
+    if (tile * kStBlock >= n_scan) return;  // (workgroup-uniform, before any barrier; k_tl_accumulate_p skips these tiles' words)
+    const uint32_t j_scan = tile * kStBlock + threadIdx.x;
+    const uint32_t i = j_scan < n_scan ? (listed ? live_list[j_scan] : j_scan) : N;
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     float2 d = make_float2(0.f, 0.f);
     float xs[3] = {0.f, 0.f, 0.f};
@@ -2615,7 +2690,8 @@ template <uint32_t BIN>
 __global__ void __launch_bounds__(kTlBlockP, 4)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
-                  uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam) {
+                  uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam,
+                  const uint32_t* __restrict__ live_n, uint32_t N) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
@@ -2644,12 +2720,19 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t it = blockIdx.x;
     if (it >= n_items) return;
+    // (live_n: the scatter cut its tiles from a list of that many samples -- k_tl_scatter_p's rule -- and tiles past the
+    // list's end wrote nothing: their words are stale and count as empty)
+    uint32_t n_used = n_tiles;
+    if (live_n) {
+        const uint32_t n_listed = *live_n;
+        if (n_listed < N - (N >> 2)) n_used = (n_listed + (tile_records >> 3) - 1u) / (tile_records >> 3);  // (tile = tile_records / 8 samples)
+    }
     auto words_first = [&](const TlItem& I, uint32_t* l1w) -> uint32_t {
         const uint32_t n_span = I.t1 - I.t0;
         const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
         const uint32_t first = min(n_span, wib * per_wave);
         const uint32_t n_mine = min(per_wave, n_span - first);
-        const bool mine = lane < min(64u, n_mine);
+        const bool mine = lane < min(64u, n_mine) && I.t0 + first + lane < n_used;
         const size_t o = (size_t)I.bin * n_tiles + I.t0 + first + lane;
         *l1w = mine ? segl1[o] : 0u;
         return mine ? seg[o] : 0u;
@@ -2684,7 +2767,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         {
             float a0 = __uint_as_float(l1w << 16), a1 = __uint_as_float(l1w & 0xFFFF0000u);
             for (uint32_t j0 = 64u; j0 < n_mine; j0 += 64u) {
-                const uint32_t w2 = lane < min(64u, n_mine - j0) ? segl1[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+                const uint32_t w2 = (lane < min(64u, n_mine - j0) && tile_first + j0 + lane < n_used) ? segl1[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
                 a0 += __uint_as_float(w2 << 16);
                 a1 += __uint_as_float(w2 & 0xFFFF0000u);
             }
@@ -2728,7 +2811,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         bool next_requested = false;
         for (uint32_t j0 = 0; j0 < n_mine; j0 += 64u) {
             const uint32_t n_here = min(64u, n_mine - j0);
-            if (j0 > 0u) segw = lane < n_here ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+            if (j0 > 0u) segw = (lane < n_here && tile_first + j0 + lane < n_used) ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
             const uint32_t cnt = lane < n_here ? (segw >> 16) & 0x7FFFu : 0u;
             bad |= lane < n_here && (segw >> 31) != 0u;
             const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
@@ -3592,6 +3675,25 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     // the flag beside it would leave the group half stepped (GradScaler steps all of a group or nothing)
     const bool fork = st->overlap && st->aux && st->owner.n_slices && st->n_bins && !st->adam.params &&
                       !(nvo_prof_enabled() && nvo_prof_detail());
+    // the samples that carry a gradient, listed from the network's dL/doutput rows (NvoGridSlices::ext_tile_live)
+    const uint32_t* live_list = nullptr;
+    const uint32_t* live_n = nullptr;
+    if (st->owner.ext_tile_live && st->owner.ext_rows && st->owner.d_live_n && !st->owner.deterministic && (N & 15u) == 0u) {
+        NvoProfMute mute;
+        if (int rc = nvo_scratch_reserve(&st->owner.live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list")) return rc;
+        uint32_t* const d_live = static_cast<uint32_t*>(st->owner.live.ptr);
+        if (!st->owner.external_zero)  // (otherwise cleared by the step's zero launch: nvo_grid_slices_zero_ranges)
+            if (int rc = nvo_zero_async(st->owner.d_live_n, sizeof(uint32_t), stream)) return rc;
+        NVO_LAUNCH(k_live_rows, dim3(nvo_div_up(N, 4096)), dim3(1024), 0, stream, N, st->owner.ext_tile_live, st->owner.ext_tile_bits,
+                   static_cast<const uint4*>(st->owner.ext_rows), st->owner.ext_tile_count, st->owner.d_live_n, d_live);
+        live_list = d_live;
+        live_n = st->owner.d_live_n;
+    }
+    struct ListGuard {  // (the owner launch below reads ext_list; nobody else may)
+        const NvoGridSlices* s;
+        ~ListGuard() { s->ext_list = nullptr; }
+    } list_guard{&st->owner};
+    st->owner.ext_list = live_list;
     if (st->owner.n_slices) {  // coarse levels: slice-owner items (disjoint gradient ranges)
         NvoProfMute mute;
         if (fork) {
@@ -3634,7 +3736,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
             NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
                        st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl),     \
-                       st->owner.nf_flag);                                                                    \
+                       st->owner.nf_flag, live_list, live_n);                                                 \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
@@ -3644,7 +3746,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
                        (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1,                              \
                        reinterpret_cast<const uint32_t*>(records_tl), n_tiles,                                \
-                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam);                            \
+                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam, live_n, N);                 \
         }                                                                                                     \
     } while (0)
 #define NVO_LAUNCH_TLP(SOA_, T_)                                                           \
@@ -3693,9 +3795,9 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
                 lds += kHitRingBytes;
             }
         }
-        const uint32_t* live = nullptr;
+        const uint32_t* live = slices->ext_list;  // (a stream layout's launcher has listed them already: k_live_rows)
         bool l1_fused = false;
-        if (slices->compact_live && !slices->deterministic) {  // (the list's append order would change the run sums)
+        if (!live && slices->compact_live && !slices->deterministic) {  // (the list's append order would change the run sums)
             if (int rc = nvo_scratch_reserve(&slices->live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list"))
                 return rc;
             uint32_t* const d_live = static_cast<uint32_t*>(slices->live.ptr);
@@ -3768,7 +3870,8 @@ int nvo_grid_bwd_launch(const NvoGridLevels& g, const NvoGridSlices* slices, hip
         }                                                                                     \
         NVO_LAUNCH((k_grid_bwd_lds<SOA_, T_>), grid, block, lds, stream, g, N, x,     \
                            (const T_*)dy, grad, (const uint4*)slices->d_level, slices->d_l1, live, slices->nf_flag, slices->d_live_n, ring_off, \
-                           slices->ext_l1, slices->ext_blocks, slices->ext_l1_stride, d_codes, code_levels); \
+                           slices->ext_l1, slices->ext_blocks, slices->ext_l1_stride, d_codes, code_levels,         \
+                           slices->ext_list ? 1024u : 4096u);                                                   \
     } while (0)
         if (soa) {
             NVO_DY_DISPATCH(NVO_LAUNCH_LDS, true);

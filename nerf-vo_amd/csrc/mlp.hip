@@ -152,6 +152,11 @@ int nvo_nerfacto_color_bwd(nvo_stream_t stream, const nvo_color_args* args) {
     a.d_sh = c.d_sh;
     a.dweights = c.d_weights;
     a.recompute_hidden = c.hidden == nullptr;  // no stored activations: both hidden layers are recomputed
+    if (c.tile_live && (c.S & 15u) == 0) {  // (bit 0: the tile's drgb rows are not all zero -- nvo_main_loss_args::tile_live)
+        a.tile_live = c.tile_live;
+        a.tile_live_bits = 1u;
+        a.tile_live_count = c.tile_live_count;
+    }
     if (c.det_scratch) {
         // deterministic mode: [dW block totals | per-tile embedding / SH sums | per-ray sums], all summed in fixed orders
         NVO_REQUIRE((c.S & 15u) == 0 && c.cam_idx && c.d_weights, "color_bwd: the deterministic form needs S %% 16 == 0, cam_idx, d_weights");

@@ -651,11 +651,13 @@ __device__ unsigned long long NVO_MLP_NAME(nvo_mlp_phase_cycles)[16];
 
 // LDS halfs of the backward kernel (kernel and launcher): two transposing tiles per wave, or -- roles -- one tile set
 // {dZ_L | H_l | dZ_l | X} per chain wave (8 of them) + the row-major copies of the matrices, which stay
+constexpr int kLiveListCap = 2048;  // (roles) entries of a workgroup's live-tile list (16-bit codes)
 constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles) {
     const int maxw = width > in_pad ? (width > out_pad ? width : out_pad) : (in_pad > out_pad ? in_pad : out_pad);
     const int stage = width * (in_pad + 4) + (n_hidden - 1) * width * (width + 4) + out_pad * (width + 4);
     const int set = 16 * (out_pad + 4) + 2 * n_hidden * 16 * (width + 4) + 16 * (in_pad + 4);
-    if (roles) return 2 * kWavesPerBlock * set + stage + 64;  // (+ 32 hand-over words: full[8], free[8])
+    // (+ 32 hand-over / list words: full[8], free[8], live and dead counts, 12 per-wave counts; + the live-tile list)
+    if (roles) return 2 * kWavesPerBlock * set + stage + 64 + kLiveListCap;
     const int tiles = kWavesPerBlock * 2 * 16 * (maxw + 4);
     return tiles > stage ? tiles : stage;
 }
@@ -694,7 +696,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     constexpr int kHTile = 16 * (WIDTH + 4), kOffH = 16 * (OUT_PAD + 4), kOffDZ = kOffH + N_HIDDEN * kHTile,
                   kOffX = kOffDZ + N_HIDDEN * kHTile, kSetHalfs = kOffX + 16 * (IN_PAD + 4);
     constexpr int kTilesHalfs = ROLES ? kChainWaves * kSetHalfs : kWavesPerBlock * 2 * kTileHalfs;
-    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
+    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 + kLiveListCap : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
     static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES), "launcher and kernel disagree on the LDS size");
     __shared__ __attribute__((aligned(16))) T lds_static[ROLES ? 8 : kLdsHalfs];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];  // (ROLES: 112 KB, opted in by the launcher)
@@ -710,6 +712,16 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     if constexpr (ROLES) {
         if (threadIdx.x < 16) hand_full[threadIdx.x] = 0u;  // (visible behind the prologue's barriers)
     }
+    // (roles) LIVE-TILE LIST (round 6).  On a trained field one sample of a ray's 48 carries the weight: 98 % of the main
+    // field's dL/d(rgb) rows and two of a ray's three 16-sample tiles are exactly zero (tools/probes/dead_tiles.py), and
+    // testing for that inside the tile loop costs a memory round trip per dead tile (the next tile's inputs are not there
+    // yet; measured: colour head 36.9 -> 32.7 us only).  The kernel that WRITES dL/doutput knows: Args::tile_live, one
+    // byte per tile.  The workgroup compacts the live ones of the tiles it owns (code = 8 step + chain wave, in order,
+    // so that the deterministic mode keeps a fixed order) into live_list, every chain wave takes list entry 8 s + c in its
+    // step s -- all eight stay busy, the hand-over is untouched, only the number of steps shrinks -- and the dead tiles'
+    // dX is stored as zeros up front.
+    uint32_t* const list_words = hand_full + 16;  // [0] per-wave counts of a round: live | dead << 16 (12 words)
+    uint16_t* const live_list = reinterpret_cast<uint16_t*>(hand_full + 32);  // live codes from the front, dead ones from the back
 
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
@@ -722,6 +734,27 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     const LdsTile<MAXW> tz{lds + (2 * wib) * kTileHalfs}, th{lds + (2 * wib + 1) * kTileHalfs};
 
     const bool need_dinput = a.dinput != nullptr;
+    // (roles) the tiles this workgroup owns: code = 8 step + chain wave <-> tile blockIdx.x * 8 + (code & 7) + (code >> 3) * n_waves
+    const uint32_t n_iter_all = ROLES ? (n_tiles + n_waves - 1u) / n_waves : 0u;
+    const uint32_t n_own = n_iter_all * kChainWaves;
+    constexpr bool kListIo = ROLES && (IO == NVO_IO_HALF2_SOA || (IO == NVO_IO_NERFACTO_COLOR && IN_PAD == 64));
+    // (kernel-uniform; decided behind the prologue's round trip: Args::tile_live_count is requested with the matrices)
+    const bool list_pre = kListIo && a.tile_live != nullptr && n_own <= (uint32_t)kLiveListCap;
+    bool use_list = list_pre;
+    float live_tiles_part = 0.f;
+    if constexpr (kListIo) {
+        if (list_pre && a.tile_live_count) live_tiles_part = a.tile_live_count[8 * lane];
+    }
+    auto own_tile = [&](uint32_t code) -> uint32_t { return blockIdx.x * kChainWaves + (code & (kChainWaves - 1u)) + (code >> 3) * n_waves; };
+    auto tile_flag = [&](uint32_t code) -> uint32_t {  // 0 not a tile | 1 live | 2 dead
+        const uint32_t t = own_tile(code);
+        if (code >= n_own || t >= n_tiles) return 0u;
+        return (a.tile_live[t] & a.tile_live_bits) != 0u ? 1u : 2u;
+    };
+    uint32_t flag0 = 0u;  // (the first round's bytes are requested with the matrices: one round trip)
+    if constexpr (kListIo) {
+        if (list_pre) flag0 = tile_flag(threadIdx.x);
+    }
 
     // transposed weights for the dH chain (layer 0's only if dL/dinput is wanted)
     WTFrag<WIDTH, IN_PAD> wt0;
@@ -774,6 +807,64 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             }
         }
         __syncthreads();  // the staging bytes become the wave tiles
+    }
+    uint32_t n_live = 0u;  // (list) live tiles of this workgroup
+    if constexpr (kListIo) {
+        if (list_pre && a.tile_live_count) {  // while 3/4 of the tiles or more are live: no list, every tile in its turn
+            float c = live_tiles_part;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+            use_list = c < (float)(n_tiles - (n_tiles >> 2));
+        }
+        if (use_list) {
+            uint32_t n_dead = 0u;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (uint32_t base = 0; base < n_own; base += 3 * kMlpBlock) {
+                const uint32_t code = base + threadIdx.x;
+                const uint32_t flag = base == 0u ? flag0 : tile_flag(code);
+                const unsigned long long bl = __ballot(flag == 1u), bd = __ballot(flag == 2u);
+                if (lane == 0) list_words[wib_all] = (uint32_t)__popcll(bl) | ((uint32_t)__popcll(bd) << 16);
+                __syncthreads();
+                uint32_t pl = n_live, pd = n_dead;
+#pragma unroll
+                for (int w = 0; w < 3 * kWavesPerBlock; ++w) {
+                    const uint32_t c = list_words[w];
+                    if (w < wib_all) {
+                        pl += c & 0xffffu;
+                        pd += c >> 16;
+                    }
+                    n_live += c & 0xffffu;
+                    n_dead += c >> 16;
+                }
+                if (flag == 1u) live_list[pl + (uint32_t)__popcll(bl & lt)] = (uint16_t)code;
+                if (flag == 2u) live_list[kLiveListCap - 1u - (pd + (uint32_t)__popcll(bd & lt))] = (uint16_t)code;
+                __syncthreads();  // the list is complete up to here; the count words are free again
+            }
+            // dX of the dead tiles: zeros (all twelve waves, a tile per wave and turn; stores only)
+            if (need_dinput) {
+                const T z = (T)0.f;
+                for (uint32_t d = (uint32_t)wib_all; d < n_dead; d += 3u * kWavesPerBlock) {
+                    const uint32_t tile = own_tile(live_list[kLiveListCap - 1u - d]);
+                    const uint32_t row = tile * 16 + m;
+                    if constexpr (IO == NVO_IO_HALF2_SOA) {
+                        T2* __restrict__ p = (T2*)a.dinput;
+                        const uint32_t n_lv = a.n_in >> 1;
+#pragma unroll
+                        for (int tk = 0; tk < IN_PAD / 16; ++tk) {
+                            const uint32_t lv = 8 * tk + 2 * g;
+                            if (lv < n_lv) p[(size_t)lv * a.batch + row] = T2{z, z};
+                            if (lv + 1 < n_lv) p[(size_t)(lv + 1) * a.batch + row] = T2{z, z};
+                        }
+                    } else {
+                        T* __restrict__ dbo = a.d_base_out + (size_t)row * 16;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4 * g + j < 15) dbo[1 + 4 * g + j] = z;
+                        if (a.tile_partial && lane < 48) a.tile_partial[(size_t)tile * 48 + lane] = 0.f;  // (deterministic mode)
+                    }
+                }
+            }
+        }
     }
     DwAcc<ROLES ? 16 : WIDTH, ROLES ? 16 : IN_PAD> dw0;  // (roles: the dW role declares its own, see there)
     DwAcc<ROLES ? 16 : WIDTH, ROLES ? 16 : WIDTH> dwh[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
@@ -851,11 +942,25 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         }
         load_input<IN_PAD, IO>(a, row, g, t.x, cam);
     };
+    // step s of this (chain) wave: its s-th tile, clamped to a tile that exists (prefetches past the end)
+    auto step_tile = [&](uint32_t st) -> uint32_t {
+        if constexpr (kListIo) {
+            if (use_list)
+                return own_tile((uint32_t)__builtin_amdgcn_readfirstlane((int)live_list[min(st * kChainWaves + (uint32_t)wib, n_live - 1u)]));
+        }
+        return min(wave + st * n_waves, n_tiles - 1u);
+    };
+    const uint32_t my_steps = is_dw ? 0u
+                              : use_list ? (n_live > (uint32_t)wib ? (n_live - (uint32_t)wib + kChainWaves - 1u) / kChainWaves : 0u)
+                                         : (wave < n_tiles ? (n_tiles - wave + n_waves - 1u) / n_waves : 0u);
     TileIn cur;
     uint32_t cam_nxt = 0;
-    if (wave < n_tiles && !is_dw) {
-        load_tile(wave, cur, cam_first);
-        cam_nxt = load_cam(min(wave + n_waves, n_tiles - 1u));
+    uint32_t t_cur = 0u, t_nxt = 0u;
+    if (my_steps) {
+        t_cur = step_tile(0u);
+        t_nxt = step_tile(1u);
+        load_tile(t_cur, cur, use_list ? load_cam(t_cur) : cam_first);
+        cam_nxt = load_cam(t_nxt);
     }
     // Nothing issued before the loop may still be pending when it starts: the compiler's waits for such loads (weight
     // fragments, the first tile) would sit INSIDE the loop as s_waitcnt vmcnt(N) with N counted along the entry path,
@@ -867,7 +972,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #endif
     // ---- roles: step `it` of chain wave c handles tile blockIdx.x * 8 + c + it * n_waves; every wave of the workgroup
     // walks n_iter steps; hand-over per tile set through the words hand_full / hand_free (no barrier in the loop)
-    const uint32_t n_iter = ROLES ? (n_tiles + n_waves - 1u) / n_waves : 0u;
+    const uint32_t n_iter = use_list ? (n_live + kChainWaves - 1u) / kChainWaves : n_iter_all;
     if (is_dw) {
         // MODEL-parallel: dW wave d owns rows 16 d .. 16 d + 15 of dW_0 and of every hidden dW, and column tile d of the
         // output layer's dW -- 36 accumulator registers instead of 144, so the CHAIN role decides the kernel's register
@@ -887,7 +992,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             }
             for (int k = 0; k < kChainWaves; ++k) {
                 const int c = (2 * wib + k) & (kChainWaves - 1);  // (every dW wave starts at another set)
-                if (blockIdx.x * kChainWaves + c + it * n_waves >= n_tiles) continue;  // (wave-uniform)
+                if (use_list ? it * kChainWaves + c >= n_live : blockIdx.x * kChainWaves + c + it * n_waves >= n_tiles) continue;  // (wave-uniform)
                 if constexpr (kHandFlags) {
                     // (taking whichever set is ready first instead of this fixed order measured slower: 42.7 vs 41.4 us)
                     while (__hip_atomic_load(hand_full + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= it)
@@ -956,12 +1061,15 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     }
     uint32_t it = 0u;  // (roles: step counter of the chain role)
     T* const set = lds + (size_t)((ROLES ? wib : 0) * kSetHalfs);  // (roles) this chain wave's tile set
-    for (uint32_t tile = wave; tile < n_tiles && !is_dw; tile += n_waves) {
+    for (uint32_t st = 0; st < my_steps; ++st) {
+        const uint32_t tile = t_cur;
         const uint32_t row = tile * 16 + m;
         NVO_PH(9);
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
-        load_tile(min(tile + n_waves, n_tiles - 1u), nxt, cam_nxt);
-        cam_nxt = load_cam(min(tile + 2u * n_waves, n_tiles - 1u));
+        load_tile(t_nxt, nxt, cam_nxt);
+        t_cur = t_nxt;
+        t_nxt = step_tile(st + 2u);
+        cam_nxt = load_cam(t_nxt);
         NVO_PH(0);
         if constexpr (COMPACT && IO == NVO_IO_HALF2_SOA) {
             // A tile whose 16 dL/dout values are all EXACTLY zero contributes nothing to any dW and its dX is zero: skip
@@ -1430,8 +1538,13 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytes));
                                 attr_set = true;
                             }
+                            // (A/B and tests: NVO_MLP_SKIP_DEAD=0 walks every tile; read per launch -- a graph keeps what
+                            // its capture saw -- so that one process can compare the two)
+                            const char* const e_dead = getenv("NVO_MLP_SKIP_DEAD");
+                            Args ar = a;
+                            if (e_dead && atoi(e_dead) == 0) ar.tile_live = nullptr;
                             NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>),
-                                       dim3(blocks), dim3(3 * kMlpBlock), kBytes, stream, a);
+                                       dim3(blocks), dim3(3 * kMlpBlock), kBytes, stream, ar);
                             NVO_CHECK_LAUNCH();
                             return NVO_OK;
                         }

@@ -61,6 +61,17 @@ struct NvoGridSlices {
     // k_live_samples lists the samples from it instead of reading dL/d(encoded) of every level
     mutable const uint16_t* ext_dout = nullptr;
     mutable uint32_t ext_blocks = 0, ext_l1_stride = 0;
+    // (set per launch by NetworkWithInputEncoding's backward -- module option "bwd_tile_live_ptr" -- and cleared afterwards;
+    // streamed layouts, non-deterministic mode) the network's dL/doutput as rows of 16 16-bit values with one byte per
+    // 16-sample tile that promises all-zero rows where (byte & ext_tile_bits) == 0: k_live_rows lists the samples with a
+    // non-zero row reading only the live tiles, and both the slice-owner items and the record scatter walk that list.
+    // ext_tile_count (nullable): 64 shards, 8 floats apart, whose sum is the number of live tiles -- while 3/4 of the
+    // tiles or more are live nobody needs the list and the pass leaves at once.
+    mutable const uint8_t* ext_tile_live = nullptr;
+    mutable uint32_t ext_tile_bits = 0;
+    mutable const void* ext_rows = nullptr;
+    mutable const float* ext_tile_count = nullptr;
+    mutable const uint32_t* ext_list = nullptr;  // (set by the stream launcher around its owner launch) the list to walk
 };
 #include <utility>
 #include <vector>
@@ -247,6 +258,15 @@ struct NvoMlpArgsT {
     // (forward; nullable) device count of the rows in use: tiles past it are not evaluated (`batch` stays the stride of
     // the level-major input) -- the pass of the occupancy-grid back-end that finds where each ray ends
     const uint32_t* n_live;
+    // (backward, chain / dW roles, level-major and colour-head layouts; nullable) one byte per 16-sample tile, written by the
+    // kernel that produced dL/doutput: (tile_live[t] & tile_live_bits) == 0 promises that all 16 x out_pad values of tile t
+    // are exactly zero.  Such a tile adds nothing to any dW and its dX is zero: the workgroup compacts the live ones of
+    // its tiles into a list, walks only those, and stores zeros as the dead tiles' dX (k_mlp_bwd, "LIVE-TILE LIST").
+    const uint8_t* tile_live;
+    uint32_t tile_live_bits;
+    // (nullable) 64 shards, 8 floats apart, whose sum is the number of tiles with a non-zero byte (an upper bound of the
+    // live ones): while 3/4 of the tiles or more are live the list is not built at all
+    const float* tile_live_count;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);

@@ -102,7 +102,9 @@ __device__ __forceinline__ bool ray_weights_bwd(int lane, uint32_t S, const nvo_
                                                 const float* __restrict__ tb, float bias,
                                                 const float* w, const float* Tr, const float* g,
                                                 float loss_scale, nvo_h16* __restrict__ dpre,
-                                                uint32_t dpre_stride, bool zero_row = false) {
+                                                uint32_t dpre_stride, bool zero_row = false,
+                                                unsigned long long* live = nullptr) {
+    // (live, S <= 64: lanes whose STORED 16-bit gradient is not zero)
     bool overflow = false;
     const float fmt_max = bf ? 3.0e38f : 65504.0f;
     // total of g_i w_i, then inclusive prefix per chunk -> suffix (exclusive) = total - incl
@@ -127,15 +129,17 @@ __device__ __forceinline__ bool ray_weights_bwd(int lane, uint32_t S, const nvo_
                 d = dsig * __expf(fminf(fmaxf(x, -15.f), 15.f));
             }
             overflow = overflow || !(fabsf(d * loss_scale) <= fmt_max);
+            const nvo_h16 d16 = nvo_cvt16(d * loss_scale, bf);
+            if (live) *live = __ballot((d16 & 0x7fffu) != 0u);
             if (zero_row && dpre_stride == 16) {
                 // whole 32-byte row {d, 0 x 15} as two 16-byte stores (the MLP backward reads all 16 columns)
                 uint4 lo = make_uint4(0u, 0u, 0u, 0u);
-                lo.x = (uint32_t)nvo_cvt16(d * loss_scale, bf);
+                lo.x = (uint32_t)d16;
                 uint4* row = reinterpret_cast<uint4*>(dpre + (size_t)i * 16);
                 row[0] = lo;
                 row[1] = make_uint4(0u, 0u, 0u, 0u);
             } else {
-                dpre[(size_t)i * dpre_stride] = nvo_cvt16(d * loss_scale, bf);
+                dpre[(size_t)i * dpre_stride] = d16;
             }
         }
         carry = nvo_wave_bcast(incl, 63);
@@ -415,14 +419,16 @@ k_main_render_loss(nvo_main_loss_args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned long long pre_live = 0ull;
     bool overflow = ray_weights_bwd(lane, S, pre, bf, a.pre_stride, x01, tb, a.density_bias, w, Tr, g, a.loss_scale,
-                                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride);
+                                    (nvo_h16*)a.dpre + so * a.dpre_stride, a.dpre_stride, false, &pre_live);
     if (act) {
         const float fmt_max = bf ? 3.0e38f : 65504.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) overflow = overflow || !(fabsf(dc[k] * a.loss_scale) <= fmt_max);
     }
     if (a.nonfinite_flag && __ballot(overflow) != 0ull && lane == 0) atomicOr(a.nonfinite_flag, 1u);
+    bool rgb_nz = false;
     if (act && a.drgb_stride == 16) {
         // the colour MLP backward reads all 16 columns: one 32-byte row {dr, dg, db, 0 x 13} as two 16-byte stores
         uint4 lo = make_uint4(0u, 0u, 0u, 0u);
@@ -431,11 +437,28 @@ k_main_render_loss(nvo_main_loss_args a) {
         uint4* row = reinterpret_cast<uint4*>((nvo_h16*)a.drgb + (so + lane) * 16);
         row[0] = lo;
         row[1] = make_uint4(0u, 0u, 0u, 0u);
+        rgb_nz = ((lo.x | lo.y) & 0x7fff7fffu) != 0u;
     } else if (act) {
         nvo_h16* dp = (nvo_h16*)a.drgb + (so + lane) * a.drgb_stride;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dp[k] = nvo_cvt16(dc[k] * a.loss_scale, bf);
+        for (int k = 0; k < 3; ++k) {
+            dp[k] = nvo_cvt16(dc[k] * a.loss_scale, bf);
+            rgb_nz = rgb_nz || (dp[k] & 0x7fffu) != 0u;
+        }
         for (uint32_t k = 3; k < a.drgb_stride; ++k) dp[k] = (nvo_h16)0;
+    }
+    if (a.tile_live) {  // (the launcher: S % 16 == 0, S <= 64) what the stored 16-bit gradients of each 16-sample tile hold
+        const unsigned long long rgb_live = __ballot(rgb_nz);
+        uint32_t byte = 0u;
+        if (lane < (int)(S >> 4)) {
+            const uint32_t sh = 16u * (uint32_t)lane;
+            byte = (((rgb_live >> sh) & 0xffffull) != 0ull ? 1u : 0u) | (((pre_live >> sh) & 0xffffull) != 0ull ? 2u : 0u);
+            a.tile_live[(so >> 4) + lane] = (uint8_t)byte;
+        }
+        // slot 7 of the loss shards: the number of tiles that carry any gradient (exact in fp32 up to 2^24) -- what tells the
+        // hash grid's backward whether listing the live samples pays (k_live_rows)
+        const uint32_t n_live_tiles = (uint32_t)__popcll(__ballot(byte != 0u));
+        if (lane == 0 && n_live_tiles) atomicAdd(a.losses + 8 * (r & 63u) + 7, (float)n_live_tiles);
     }
 }
 
@@ -589,6 +612,7 @@ int nvo_main_render_loss(nvo_stream_t stream, const nvo_main_loss_args* args) {
                 a.out_accumulation, "main_render_loss: NULL input/output");
     NVO_REQUIRE(!a.dpre || (a.drgb && a.losses && a.gt_rgb && a.drgb_stride >= 3),
                 "main_render_loss: training mode needs drgb, losses, gt_rgb");
+    NVO_REQUIRE(!a.tile_live || (a.dpre && (a.S & 15u) == 0u), "main_render_loss: tile_live needs training mode and S %% 16 == 0 (S = %u)", a.S);
     if (a.R == 0) return NVO_OK;
     NVO_PROF(stream, "main_render_loss");
     NVO_LAUNCH(k_main_render_loss, dim3(nvo_div_up(a.R, kRaysPerBlock)), dim3(kRayBlock), 0,

@@ -80,6 +80,7 @@ class EngineConfig:
     geo_feat_dim: int = 15
     appearance_embed_dim: int = 32
     density_bias: float = -1.0            # sigma = trunc_exp(h0 - 1)
+    skip_dead_tiles: bool = True          # the MLP backwards of the main field walk only tiles that carry a gradient
     histogram_padding: float = 0.01
     proposal_weights_anneal_slope: float = 10.0
     proposal_weights_anneal_max_num_iters: int = 1000
@@ -558,6 +559,11 @@ class NerfactoEngine:
         if training:
             # colour head: no stored hidden activations (recomputed in the backward)
             ws["drgb"] = torch.empty(Nm, 16, **f16)
+            if self.levels[-1] % 16 == 0 and self.cfg.skip_dead_tiles:
+                # one byte per 16-sample tile of the main level, written by the render / loss kernel: which tiles carry
+                # any gradient at all.  The two MLP backwards behind it walk only those (two of three tiles of a trained
+                # field carry none: nvo_main_loss_args::tile_live)
+                ws["tile_live"] = torch.zeros(Nm // 16, dtype=torch.uint8, device=dev)
             if self.cfg.deterministic:  # scratch of the fixed-order reductions (colour head, pose gradient)
                 ws["color_det"] = torch.empty(int(_lib.lib().nvo_color_det_scratch_bytes(R, self.levels[-1])),
                                               dtype=torch.uint8, device=dev)
@@ -691,7 +697,9 @@ class NerfactoEngine:
             dw_replicas=self._dw_replica_plan()["color"][0] if (training and self._dw_replica_plan()) else None,
             n_dw_replicas=self._dw_replica_plan()["color"][1] if (training and self._dw_replica_plan()) else 0,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
-            n_cameras=self.cfg.num_images)
+            n_cameras=self.cfg.num_images,
+            tile_live=ws["tile_live"].data_ptr() if (training and "tile_live" in ws) else None,
+            tile_live_count=(self.losses.data_ptr() + 7 * 4) if (training and "tile_live" in ws) else None)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -719,7 +727,8 @@ class NerfactoEngine:
             normal_mult=cfg.normal_loss_mult if (normals and has_gt_normal) else 0.0,
             out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16),
             loss_scale_dev=self._loss_scale_ptr() if training else None,
-            nonfinite_flag=self._flag_ptr("fields") if training else None)
+            nonfinite_flag=self._flag_ptr("fields") if training else None,
+            tile_live=ws["tile_live"].data_ptr() if (training and "tile_live" in ws) else None)
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -848,6 +857,19 @@ class NerfactoEngine:
 
         def main_backward(st):
             _call("nvo_nerfacto_color_bwd", st, C.byref(ca))
+            if "tile_live" in ws:
+                # the base network's dL/doutput = {dpre | the colour head's dX}: zero wherever neither bit is set.  Only for
+                # THIS backward (the analytic-normal pass runs the same module on another dL/doutput)
+                self.base_net.set_option("bwd_tile_live_ptr", ws["tile_live"].data_ptr())
+                self.base_net.set_option("bwd_tile_live_bits", 3)
+                self.base_net.set_option("bwd_tile_live_count_ptr", self.losses.data_ptr() + 7 * 4)
+            try:
+                return main_backward_base(st)
+            finally:
+                if "tile_live" in ws:
+                    self.base_net.set_option("bwd_tile_live_ptr", 0)
+
+        def main_backward_base(st):
             if pose and cfg.overlap_pose_backward:
                 # the pose chain below only needs dL/dx of the main field: the long parameter scatter of its hash grid
                 # runs beside it on another stream (forked inside the call, joined at the end of this function)

@@ -729,6 +729,118 @@ def test_deterministic_mode_is_bitwise_reproducible(device, dtype):
     _assert_close(g_det, g_def, rtol=1e-5, atol_scale=1e-7, what="deterministic vs default gradient", max_outlier_frac=1e-4)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_dead_tiles_of_the_mlp_backward_are_skipped_exactly(device, dtype, monkeypatch):
+    """The render / loss kernel marks every 16-sample tile of the main level whose stored dL/d(rgb) and dL/d(density) are
+    all zero (nvo_main_loss_args::tile_live); the role-split backwards of the colour head and of the base network walk
+    only the live tiles of a workgroup (mlp_impl.h, "LIVE-TILE LIST") and store zeros as the dead tiles' dX.  With a
+    density bias of +12 the first sample inside the box takes a ray's whole weight (T = exp(-sigma delta) underflows to
+    0 behind it), which is the state a trained field reaches: most tiles are dead.  Deterministic steps from the same
+    state with the list on and off (NVO_MLP_SKIP_DEAD=0 walks every tile): the bytes must be a sound promise (a tile
+    without its bit holds only zeros), what the colour head hands the base network must be the same values, and the
+    gradients must agree up to the order of the fp32 sums (the live tiles meet the dW accumulators in another order once
+    the dead ones between them are gone; the hash grid's fixed-point sums are order-free up to their scale)."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 1024
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    seq = make_sequence(n, H, W, device=device)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+
+    def run(skip: bool, steps: int):
+        if skip:
+            monkeypatch.delenv("NVO_MLP_SKIP_DEAD", raising=False)
+        else:
+            monkeypatch.setenv("NVO_MLP_SKIP_DEAD", "0")
+        torch.manual_seed(5)
+        # (bf16 keeps its range and flushes less: a larger bias, so that T itself underflows behind the first sample)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, mlp_dtype=dtype, deterministic=True,
+                                          dynamic_loss_scale=False, density_bias=12.0 if dtype == "f16" else 17.0), device)
+        for _ in range(steps):
+            eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        assert int(eng.skip_flag.sum()) == 0
+        ws = eng._workspace(R, True)
+        return eng, eng.grads.clone(), eng.params.clone(), ws["drgb"].float().clone(), ws["dout2"].float().clone(), \
+            ws["tile_live"].clone()
+
+    eng, g_on, _, drgb, dbo, live = run(True, 1)
+    _, g_off, _, drgb_off, dbo_off, _ = run(False, 1)
+    # the promise of the bytes
+    rgb_nz = (drgb.abs().sum(1) != 0).view(-1, 16).any(1)
+    pre_nz = (dbo[:, 0] != 0).view(-1, 16).any(1)
+    assert torch.equal((live & 1).bool(), rgb_nz) and torch.equal((live & 2).bool(), pre_nz)
+    dead_rgb, dead_base = ~rgb_nz, ~(rgb_nz | pre_nz)
+    # both kinds of tile in both kernels, and fewer than 3/4 of them live: above that the kernels do not build their lists
+    assert 0.25 < float(dead_rgb.float().mean()) < 0.999 and 0.25 < float(dead_base.float().mean()) < 0.999, \
+        (float(dead_rgb.float().mean()), float(dead_base.float().mean()))
+    # what the colour head left as the base network's dL/doutput: the same values, zeros behind its dead tiles
+    assert torch.equal(drgb, drgb_off) and torch.equal(dbo, dbo_off)
+    assert float(dbo.view(-1, 16, 16)[dead_rgb][:, :, 1:].abs().max()) == 0.0
+    assert bool(torch.isfinite(g_on).all()) and float(g_on.abs().max()) > 0
+    o, sz, _ = eng.segments["field.base"]
+    n_mlp = _mlp_count("field.base")
+    assert float(g_on[o + n_mlp:o + sz].abs().max()) > 0
+    # (fixed-point sums of the same dX values; their scale comes from per-workgroup L1 sums, whose grouping changed)
+    _assert_close(g_on[o + n_mlp:o + sz], g_off[o + n_mlp:o + sz], rtol=1e-6, atol_scale=1e-7, what="hash-grid gradient of the main field")
+    _assert_close(g_on, g_off, rtol=1e-5, atol_scale=1e-7, what="gradient with / without the live-tile list", max_outlier_frac=1e-4)
+    # and a few steps on: the same trajectory up to that noise
+    p_on, p_off = run(True, 4)[2], run(False, 4)[2]
+    _assert_close(p_on, p_off, rtol=1e-3, atol_scale=1e-5, what="parameters after 4 steps", max_outlier_frac=1e-3)
+
+
+def test_grid_backward_walks_the_live_rows_of_a_trained_field(device, monkeypatch):
+    """Default (non-deterministic) kernels, the state of a trained field (density bias +12: a ray's first sample inside
+    the box takes its whole weight): the main hash grid's backward lists the samples whose dL/doutput row is non-zero from
+    the tile bytes of the render / loss kernel (k_live_rows) and both its slice-owner items and its record scatter walk
+    that list.  The list must hold exactly those samples, and the gradient must agree with the full scan's
+    (NVO_GRID_LIVE_ROWS=0) -- the table part up to the fixed-point scale (order-free sums; the per-tile L1 bounds that set
+    the scale follow the tile composition), the network weights up to the order of their float atomics."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 2048
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    seq = make_sequence(n, H, W, device=device)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+
+    def run(listed: bool):
+        if listed:
+            monkeypatch.delenv("NVO_GRID_LIVE_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("NVO_GRID_LIVE_ROWS", "0")
+        torch.manual_seed(5)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, dynamic_loss_scale=False, density_bias=12.0,
+                                          fuse_grid_adam=False), device)
+        eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        assert int(eng.skip_flag.sum()) == 0
+        ws = eng._workspace(R, True)
+        word = torch.zeros(1, dtype=torch.int32, device=device)
+        eng.base_net.set_option("debug_copy_grid_live_n", word.data_ptr())
+        return eng, eng.grads.clone(), ws["dout2"].float().clone(), ws["tile_live"].clone(), int(word.item())
+
+    eng, g_on, dbo, live, n_listed = run(True)
+    _, g_off, dbo_off, _, n_off = run(False)
+    rows_nz = dbo.abs().sum(1) != 0
+    assert float((live != 0).float().mean()) < 0.75, "the state must be one where the list is built"
+    assert n_listed == int(rows_nz.sum()) and 0 < n_listed < 0.75 * rows_nz.numel(), (n_listed, int(rows_nz.sum()))
+    assert n_off == 0, "the full scan does not build a list"
+    assert torch.equal(dbo, dbo_off)
+    o, sz, _ = eng.segments["field.base"]
+    n_mlp = _mlp_count("field.base")
+    assert float(g_on[o + n_mlp:o + sz].abs().max()) > 0
+    _assert_close(g_on[o + n_mlp:o + sz], g_off[o + n_mlp:o + sz], rtol=1e-6, atol_scale=1e-7, what="main hash grid gradient, listed vs full scan")
+    _assert_close(g_on, g_off, rtol=1e-4, atol_scale=1e-6, what="gradient, listed vs full scan", max_outlier_frac=1e-4)
+
+
 @pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
 def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
     """EngineConfig.commit_behind_replay: the optimiser's commit (applied-step counters, bias corrections, loss scale)
