@@ -422,6 +422,10 @@ struct GridModule : nvo_module_s {
                         (((uintptr_t)a->params_half + 2 * off) & 7u) == 0,
                     "set_fused_adam: the encoding's parameters must start 16-byte aligned in every buffer");
         NvoGridAdam& d = stream_bins.adam;
+        {
+            uint64_t f_ = 0, c_ = 0;
+            nvo_grid_stream_adam_range(g, &stream_bins, &f_, &c_, &d.first_level);
+        }
         d.params = a->params + off;
         d.params_half = (char*)a->params_half + 2 * off;
         d.exp_avg = a->exp_avg + off;
@@ -576,6 +580,12 @@ struct GridModule : nvo_module_s {
         }
         if (!strcmp(key, "grid_stream_acc_bits")) {  // (the record pass has one form left: packed 2 x 32-bit sums)
             NVO_REQUIRE(value == 32, "grid_stream_acc_bits: only the packed 32-bit record pass exists (got %lld)", (long long)value);
+            return NVO_OK;
+        }
+        if (!strcmp(key, "grid_stream_dense_chunks")) {  // tile-range chunks per bin of a streamed DENSE level (on rebuild)
+            NVO_REQUIRE(value >= 1 && value <= 64, "grid_stream_dense_chunks: 1..64 (got %lld)", (long long)value);
+            nvo_grid_stream_destroy(&stream_bins);
+            stream_bins.dense_chunks = (uint32_t)value;
             return NVO_OK;
         }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
@@ -852,6 +862,25 @@ struct NwieModule : nvo_module_s {
         if (dparams && !net->external_zero)
             if (int rc0 = nvo_zero_async(dparams, sizeof(float) * net->n_params, s)) return rc0;
         if (int rc0 = net->det_partials(s, B, &a)) return rc0;
+        // the samples behind dead tiles carry no gradient: the encoding walks a LIST of the others, which this network's
+        // backward writes while it walks its live tiles (NvoMlpArgsT::live_rows) -- or, where it cannot, a pass of the
+        // encoding's own over `dout` (k_live_rows)
+        const char* const e_rows = getenv("NVO_GRID_LIVE_ROWS");  // A/B, tests (per launch; a graph keeps its capture's)
+        const NvoGridSlices* const row_owner = enc->bwd_mode == 3 ? &enc->stream_bins.owner : nullptr;
+        const bool list_rows = (!e_rows || atoi(e_rows) != 0) && a.tile_live && dparams && row_owner && row_owner->d_live_n &&
+                               !row_owner->deterministic && net->out_pad == 16 && recompute_hidden && (B & 15u) == 0u;
+        bool rows_by_mlp = false;
+        if (list_rows && nvo_mlp_bwd_lists_rows(net->in_pad, net->width, net->n_hidden, B)) {
+            const char* const e_mlp = getenv("NVO_MLP_LISTS_ROWS");  // (A/B: 0 = the encoding's own pass)
+            rows_by_mlp = !e_mlp || atoi(e_mlp) != 0;
+        }
+        if (rows_by_mlp) {
+            if (int rc0 = nvo_scratch_reserve(&row_owner->live, sizeof(uint32_t) * ((size_t)B + 1), s, "grid_bwd live list")) return rc0;
+            if (!row_owner->external_zero)  // (otherwise cleared by the step's zero launch: nvo_grid_slices_zero_ranges)
+                if (int rc0 = nvo_zero_async(row_owner->d_live_n, sizeof(uint32_t), s)) return rc0;
+            a.live_rows = static_cast<uint32_t*>(row_owner->live.ptr);
+            a.live_rows_n = row_owner->d_live_n;
+        }
         // the encoding's 32-bit accumulators (slice-owner items) scale by the L1 norm of dL/d(encoded): the network's
         // backward sums it while it stores those values -- no pass of its own over them
         static const bool l1_from_mlp = [] { const char* e = getenv("NVO_GRID_L1_FROM_MLP"); return !e || atoi(e) != 0; }();
@@ -880,22 +909,21 @@ struct NwieModule : nvo_module_s {
                 owner->ext_blocks = l1_blocks;
                 owner->ext_l1_stride = (uint32_t)net->in_pad;
             }
-            // the samples behind dead tiles carry no gradient: the encoding lists the others from `dout` (k_live_rows)
-            const char* const e_rows = getenv("NVO_GRID_LIVE_ROWS");  // A/B, tests (per launch; a graph keeps its capture's)
-            const bool live_rows = !e_rows || atoi(e_rows) != 0;
-            const bool list_rows = live_rows && a.tile_live && owner && enc->bwd_mode == 3 && net->out_pad == 16;
-            if (list_rows) {
-                owner->ext_tile_live = a.tile_live;
-                owner->ext_tile_bits = a.tile_live_bits;
-                owner->ext_rows = dout;
-                owner->ext_tile_count = bwd_tile_live_count;
+            if (rows_by_mlp) {
+                row_owner->ext_list_given = true;  // (the list and its length word are in place: a.live_rows above)
+            } else if (list_rows) {
+                row_owner->ext_tile_live = a.tile_live;
+                row_owner->ext_tile_bits = a.tile_live_bits;
+                row_owner->ext_rows = dout;
+                row_owner->ext_tile_count = bwd_tile_live_count;
             }
             rc = enc->bwd_params(sp, B, in, dencoded, true, dparams + net->n_params);
             if (list_rows) {
-                owner->ext_tile_live = nullptr;
-                owner->ext_rows = nullptr;
-                owner->ext_tile_count = nullptr;
-                owner->ext_tile_bits = 0u;
+                row_owner->ext_list_given = false;
+                row_owner->ext_tile_live = nullptr;
+                row_owner->ext_rows = nullptr;
+                row_owner->ext_tile_count = nullptr;
+                row_owner->ext_tile_bits = 0u;
             }
             if (want_l1) {
                 owner->ext_l1 = nullptr;
@@ -945,6 +973,12 @@ struct NwieModule : nvo_module_s {
         }
         if (!strcmp(key, "bwd_tile_live_bits")) {
             bwd_tile_live_bits = (uint32_t)value;
+            return NVO_OK;
+        }
+        if (!strcmp(key, "bwd_mark_fork_point")) {  // see nvo_wait_fork_point
+            NVO_REQUIRE(enc->bwd_mode == 3 || value == 0, "bwd_mark_fork_point: the streamed parameter backward (grid_bwd_mode 3) only");
+            enc->stream_bins.mark_pre_acc = value != 0;
+            enc->stream_bins.pre_acc_recorded = false;
             return NVO_OK;
         }
         if (!strcmp(key, "debug_copy_grid_live_n")) {  // (tests) length word of the encoding's live-sample list -> *value (device u32)
@@ -1121,6 +1155,16 @@ int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream
         return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput, dL_dparams);
     return n->bwd_on((hipStream_t)stream, (hipStream_t)params_stream, batch, input, params, output, dL_doutput, ctx,
                      dL_dinput, dL_dparams);
+}
+
+int nvo_wait_fork_point(nvo_module_t m, nvo_stream_t waiting_stream) {
+    NVO_REQUIRE(m, "wait_fork_point: NULL module");
+    auto* n = dynamic_cast<NwieModule*>(m);
+    NVO_REQUIRE(n && n->enc->bwd_mode == 3 && n->enc->stream_bins.mark_pre_acc && n->enc->stream_bins.pre_acc_recorded &&
+                    n->enc->stream_bins.ev_pre_acc,
+                "wait_fork_point: no fork point recorded (option bwd_mark_fork_point, streamed parameter backward, a backward since)");
+    NVO_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiting_stream, n->enc->stream_bins.ev_pre_acc, 0));
+    return NVO_OK;
 }
 
 static GridModule* as_grid(nvo_module_t m) {

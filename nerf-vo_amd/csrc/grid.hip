@@ -2865,7 +2865,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                 *f0 = (float)lo * inv0;
                 *f1 = (float)hi * inv1;
             };
-            if (cur.n_chunks == 1u && adam.params && g.hashed[cur.level]) {
+            if (cur.n_chunks == 1u && adam.params && cur.level >= adam.first_level) {
                 // the bin's gradient is complete right here: step its entries instead of storing it (skipped step: the
                 // gradient is not needed either)
                 if (!adam_skip) {
@@ -2944,7 +2944,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         }
 #endif
         if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
-            if (!(adam.params && g.hashed[cur.level])) atomicAdd(gr, __builtin_nanf(""));  // (fused: no gradient is kept)
+            if (!(adam.params && cur.level >= adam.first_level)) atomicAdd(gr, __builtin_nanf(""));  // (fused: no gradient is kept)
             if (nf_flag) atomicOr(nf_flag, 1u);
         }
         if (!has_next) break;
@@ -3630,6 +3630,11 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     st->d_meta = nullptr;
     st->n_bins = 0;
     st->created = false;
+    if (st->ev_pre_acc) {
+        (void)hipEventDestroy(st->ev_pre_acc);
+        st->ev_pre_acc = nullptr;
+        st->pre_acc_recorded = false;
+    }
     if (st->aux) {
         (void)hipStreamSynchronize(st->aux);
         (void)hipStreamDestroy(st->aux);
@@ -3641,19 +3646,23 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     nvo_grid_slices_destroy(&st->owner);
 }
 
-void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n) {
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n, uint32_t* first_level) {
+    if (first_level) *first_level = 0xFFFFFFFFu;
     *first = 0;
     *n = 0;
     if (!st->created) return;
-    // the streamed hashed levels: one accumulate item per bin (nvo_grid_stream_create); they form the tail of the table
+    // the streamed levels whose bins are ONE accumulate item each (nvo_grid_stream_create: the hashed ones, and the dense
+    // ones with option grid_stream_dense_chunks = 1); they form the tail of the table
+    auto single = [&](uint32_t l) { return ((st->streamed_mask >> l) & 1u) && (g.hashed[l] || st->dense_chunks == 1u); };
     uint32_t lo = g.n_levels;
     for (uint32_t l = 0; l < g.n_levels; ++l)
-        if (((st->streamed_mask >> l) & 1u) && g.hashed[l] && l < lo) lo = l;
+        if (single(l) && l < lo) lo = l;
     if (lo == g.n_levels) return;
     for (uint32_t l = lo; l < g.n_levels; ++l)
-        if (!(((st->streamed_mask >> l) & 1u) && g.hashed[l])) return;  // (not a contiguous tail: leave it to the optimiser)
+        if (!single(l)) return;  // (not a contiguous tail: leave it to the optimiser)
     *first = g.offset[lo];
     *n = (uint64_t)g.offset[g.n_levels] - g.offset[lo];
+    if (first_level) *first_level = lo;
 }
 
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
@@ -3678,7 +3687,10 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     // the samples that carry a gradient, listed from the network's dL/doutput rows (NvoGridSlices::ext_tile_live)
     const uint32_t* live_list = nullptr;
     const uint32_t* live_n = nullptr;
-    if (st->owner.ext_tile_live && st->owner.ext_rows && st->owner.d_live_n && !st->owner.deterministic && (N & 15u) == 0u) {
+    if (st->owner.ext_list_given && st->owner.live.ptr && st->owner.d_live_n) {  // (listed by the network's backward)
+        live_list = static_cast<const uint32_t*>(st->owner.live.ptr);
+        live_n = st->owner.d_live_n;
+    } else if (st->owner.ext_tile_live && st->owner.ext_rows && st->owner.d_live_n && !st->owner.deterministic && (N & 15u) == 0u) {
         NvoProfMute mute;
         if (int rc = nvo_scratch_reserve(&st->owner.live, sizeof(uint32_t) * ((size_t)N + 1), stream, "grid_bwd live list")) return rc;
         uint32_t* const d_live = static_cast<uint32_t*>(st->owner.live.ptr);
@@ -3737,6 +3749,11 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
                        st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl),     \
                        st->owner.nf_flag, live_list, live_n);                                                 \
+        }                                                                                                     \
+        if (st->mark_pre_acc) { /* nvo_wait_fork_point: what follows only the verdict may start here */       \
+            if (!st->ev_pre_acc) NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_pre_acc, hipEventDisableTiming)); \
+            NVO_CHECK_HIP(hipEventRecord(st->ev_pre_acc, stream));                                            \
+            st->pre_acc_recorded = true;                                                                      \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \

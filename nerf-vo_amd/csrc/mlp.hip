@@ -46,6 +46,14 @@ uint32_t nvo_mlp_bwd_blocks(int in_pad, int width, int n_hidden, uint32_t batch)
     const uint32_t cap = env_blocks("NVO_MLP_BWD_BLOCKS", bwd_block_cap(in_pad, width, n_hidden));
     return blocks > cap ? cap : blocks;
 }
+bool nvo_mlp_bwd_lists_rows(int in_pad, int width, int n_hidden, uint32_t batch) {
+    const char* e = getenv("NVO_MLP_ROLES");
+    if (width != 64 || n_hidden != 1 || (e && atoi(e) == 0) || (batch & 15u)) return false;  // (the role-split form of launch_bwd_io_kernel)
+    const uint32_t n_tiles = batch >> 4, blocks = nvo_mlp_bwd_blocks(in_pad, width, n_hidden, batch);
+    if (!blocks) return false;
+    const uint32_t n_own = nvo_div_up(n_tiles, blocks * 2u * kWavesPerBlock) * 2u * kWavesPerBlock;
+    return n_own * 16u <= (uint32_t)kLiveRowCap;
+}
 uint64_t nvo_mlp_n_weights(int in_pad, int width, int n_hidden, int out_pad) {
     return (uint64_t)width * in_pad + (uint64_t)(n_hidden - 1) * width * width + (uint64_t)out_pad * width;
 }

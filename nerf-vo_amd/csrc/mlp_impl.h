@@ -652,12 +652,13 @@ __device__ unsigned long long NVO_MLP_NAME(nvo_mlp_phase_cycles)[16];
 // LDS halfs of the backward kernel (kernel and launcher): two transposing tiles per wave, or -- roles -- one tile set
 // {dZ_L | H_l | dZ_l | X} per chain wave (8 of them) + the row-major copies of the matrices, which stay
 constexpr int kLiveListCap = 2048;  // (roles) entries of a workgroup's live-tile list (16-bit codes)
-constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles) {
+constexpr int kLiveRowCap = 8192;   // (roles, level-major input) sample ids a workgroup collects for Args::live_rows
+constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles, bool rows = false) {
     const int maxw = width > in_pad ? (width > out_pad ? width : out_pad) : (in_pad > out_pad ? in_pad : out_pad);
     const int stage = width * (in_pad + 4) + (n_hidden - 1) * width * (width + 4) + out_pad * (width + 4);
     const int set = 16 * (out_pad + 4) + 2 * n_hidden * 16 * (width + 4) + 16 * (in_pad + 4);
     // (+ 32 hand-over / list words: full[8], free[8], live and dead counts, 12 per-wave counts; + the live-tile list)
-    if (roles) return 2 * kWavesPerBlock * set + stage + 64 + kLiveListCap;
+    if (roles) return 2 * kWavesPerBlock * set + stage + 64 + kLiveListCap + (rows ? 2 * kLiveRowCap : 0);
     const int tiles = kWavesPerBlock * 2 * 16 * (maxw + 4);
     return tiles > stage ? tiles : stage;
 }
@@ -696,8 +697,10 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     constexpr int kHTile = 16 * (WIDTH + 4), kOffH = 16 * (OUT_PAD + 4), kOffDZ = kOffH + N_HIDDEN * kHTile,
                   kOffX = kOffDZ + N_HIDDEN * kHTile, kSetHalfs = kOffX + 16 * (IN_PAD + 4);
     constexpr int kTilesHalfs = ROLES ? kChainWaves * kSetHalfs : kWavesPerBlock * 2 * kTileHalfs;
-    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 + kLiveListCap : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
-    static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES), "launcher and kernel disagree on the LDS size");
+    constexpr bool kRowsIo = ROLES && IO == NVO_IO_HALF2_SOA;  // (the kernels that may list live rows: Args::live_rows)
+    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 + kLiveListCap + (kRowsIo ? 2 * kLiveRowCap : 0)
+                                    : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
+    static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES, kRowsIo), "launcher and kernel disagree on the LDS size");
     __shared__ __attribute__((aligned(16))) T lds_static[ROLES ? 8 : kLdsHalfs];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];  // (ROLES: 112 KB, opted in by the launcher)
     T* const lds = ROLES ? reinterpret_cast<T*>(lds_dyn) : lds_static;
@@ -710,7 +713,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     uint32_t* const hand_full = reinterpret_cast<uint32_t*>(lds + (ROLES ? kTilesHalfs + kStageHalfs : 0));
     uint32_t* const hand_free = hand_full + 8;
     if constexpr (ROLES) {
-        if (threadIdx.x < 16) hand_full[threadIdx.x] = 0u;  // (visible behind the prologue's barriers)
+        if (threadIdx.x < 32) hand_full[threadIdx.x] = 0u;  // (visible behind the prologue's barriers)
     }
     // (roles) LIVE-TILE LIST (round 6).  On a trained field one sample of a ray's 48 carries the weight: 98 % of the main
     // field's dL/d(rgb) rows and two of a ray's three 16-sample tiles are exactly zero (tools/probes/dead_tiles.py), and
@@ -722,6 +725,9 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     // dX is stored as zeros up front.
     uint32_t* const list_words = hand_full + 16;  // [0] per-wave counts of a round: live | dead << 16 (12 words)
     uint16_t* const live_list = reinterpret_cast<uint16_t*>(hand_full + 32);  // live codes from the front, dead ones from the back
+    // (level-major input) Args::live_rows: ids of the samples with a non-zero dL/doutput row, collected here and appended to
+    // the global list with ONE atomic per workgroup at the end; list_words[12] = their number, [13] = the reserved position
+    uint32_t* const wg_rows = reinterpret_cast<uint32_t*>(live_list + kLiveListCap);
 
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
@@ -816,6 +822,9 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
             use_list = c < (float)(n_tiles - (n_tiles >> 2));
         }
+        if constexpr (kRowsIo) {
+            if (a.live_rows && !use_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.live_rows_n, a.batch);  // "all samples"
+        }
         if (use_list) {
             uint32_t n_dead = 0u;
             const unsigned long long lt = (1ull << lane) - 1ull;
@@ -841,7 +850,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                 __syncthreads();  // the list is complete up to here; the count words are free again
             }
             // dX of the dead tiles: zeros (all twelve waves, a tile per wave and turn; stores only)
-            if (need_dinput) {
+            if (need_dinput && !(a.tile_live_bits & 0x100u)) {
                 const T z = (T)0.f;
                 for (uint32_t d = (uint32_t)wib_all; d < n_dead; d += 3u * kWavesPerBlock) {
                     const uint32_t tile = own_tile(live_list[kLiveListCap - 1u - d]);
@@ -1071,6 +1080,22 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         t_nxt = step_tile(st + 2u);
         cam_nxt = load_cam(t_nxt);
         NVO_PH(0);
+        if constexpr (kRowsIo) {
+            if (a.live_rows && use_list) {  // (kernel-uniform) list this tile's samples with a non-zero dL/doutput row
+                bool nz = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nz = nz || (float)cur.dzl[0][j] != 0.f;  // (NaN != 0: non-finite rows stay listed)
+                const unsigned long long b = __ballot(nz);
+                const uint32_t m16 = (uint32_t)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);  // row m: any of its 4 lanes
+                const uint32_t cnt = (uint32_t)__popc(m16);
+                if (cnt) {
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(&list_words[12], cnt);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (g == 0 && ((m16 >> m) & 1u)) wg_rows[base + (uint32_t)__popc(m16 & ((1u << m) - 1u))] = row;
+                }
+            }
+        }
         if constexpr (COMPACT && IO == NVO_IO_HALF2_SOA) {
             // A tile whose 16 dL/dout values are all EXACTLY zero contributes nothing to any dW and its dX is zero: skip
             // the chain.  (The proposal networks of a nerfacto run: from a few hundred steps on 80-93 % of level 0's
@@ -1437,6 +1462,16 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
             }
         }
     }
+    if constexpr (kRowsIo) {
+        if (a.live_rows && use_list) {  // (kernel-uniform) this workgroup's rows -> the global list
+            __syncthreads();
+            const uint32_t total = list_words[12];
+            if (threadIdx.x == 0) list_words[13] = total ? atomicAdd(a.live_rows_n, total) : 0u;
+            __syncthreads();
+            const uint32_t gbase = list_words[13];
+            for (uint32_t i = threadIdx.x; i < total; i += 3 * kMlpBlock) a.live_rows[gbase + i] = wg_rows[i];
+        }
+    }
 #ifdef NVO_MLP_PHASE
     NVO_PH(11);  // dW flush (block reduction through LDS + float atomics)
     if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
@@ -1530,7 +1565,7 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
                         // base network 30.3 -> 22.9 us, colour head 49.5 -> 41.4 us
                         static const bool roles = [] { const char* e = getenv("NVO_MLP_ROLES"); return !e || atoi(e) != 0; }();
                         if (roles) {
-                            constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true);
+                            constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true, IO == NVO_IO_HALF2_SOA);
                             static bool attr_set = false;  // (> 64 KiB of dynamic LDS needs an explicit opt-in)
                             if (!attr_set) {
                                 NVO_CHECK_HIP(hipFuncSetAttribute(
@@ -1543,6 +1578,18 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
                             const char* const e_dead = getenv("NVO_MLP_SKIP_DEAD");
                             Args ar = a;
                             if (e_dead && atoi(e_dead) == 0) ar.tile_live = nullptr;
+                            if (getenv("NVO_MLP_NOZERO_EXPERIMENT")) ar.tile_live_bits |= 0x100u;  // (timing experiment: WRONG results)
+                            if constexpr (IO == NVO_IO_HALF2_SOA) {
+                                // (the caller asked nvo_mlp_bwd_lists_rows first; a workgroup's tiles must fit its row buffer)
+                                const uint32_t n_tiles_l = a.batch >> 4;
+                                const uint32_t n_own_l = nvo_div_up(n_tiles_l, blocks * 2u * kWavesPerBlock) * 2u * kWavesPerBlock;
+                                if (ar.live_rows && n_own_l * 16u > (uint32_t)kLiveRowCap) {
+                                    nvo_set_error("mlp: live_rows with %u tiles per workgroup (> %d rows)", n_own_l, kLiveRowCap);
+                                    return NVO_ERR_UNSUPPORTED;
+                                }
+                            } else {
+                                ar.live_rows = nullptr;
+                            }
                             NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>),
                                        dim3(blocks), dim3(3 * kMlpBlock), kBytes, stream, ar);
                             NVO_CHECK_LAUNCH();

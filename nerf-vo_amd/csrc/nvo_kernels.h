@@ -72,6 +72,9 @@ struct NvoGridSlices {
     mutable const void* ext_rows = nullptr;
     mutable const float* ext_tile_count = nullptr;
     mutable const uint32_t* ext_list = nullptr;  // (set by the stream launcher around its owner launch) the list to walk
+    // (set per launch) the network's backward has written the list itself (NvoMlpArgsT::live_rows): `live` holds it, d_live_n
+    // its length -- no k_live_rows pass
+    mutable bool ext_list_given = false;
 };
 #include <utility>
 #include <vector>
@@ -107,6 +110,9 @@ struct NvoGridAdam {
     void* ema_half = nullptr;
     float ema_decay = 0.f;
     const uint32_t* ema_step_dev = nullptr;
+    // (set by the module: nvo_grid_stream_adam_range) the first level of the range the accumulate pass steps; every bin
+    // of that level and of those behind it is ONE accumulate item
+    uint32_t first_level = 0xFFFFFFFFu;
 };
 
 struct NvoGridStream {
@@ -141,13 +147,20 @@ struct NvoGridStream {
     uint32_t n_tl_slots = 0;          // (packed form) persistent workgroups the balanced item list was laid out for; 0 = dealt
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // option "bwd_mark_fork_point": an event recorded in front of the accumulate pass.  With the optimiser step armed
+    // (adam.params) every producer of the step's overflow verdict precedes that pass, so whatever else only waits for the
+    // verdict -- the optimiser launch of the other parameters -- may run BESIDE it on another stream (nvo_wait_fork_point)
+    bool mark_pre_acc = false;
+    mutable hipEvent_t ev_pre_acc = nullptr;
+    mutable bool pre_acc_recorded = false;
     bool external_zero = false;  // see NvoGridSlices::external_zero
     bool deterministic = false;  // (set before create) one accumulate item per bin on dense levels too; owner: see there
     NvoGridAdam adam;            // optimiser step inside the accumulate pass, see NvoGridAdam
 };
 // entries [first, first + n) of the table (in ENTRIES: two parameters each) whose Adam step NvoGridStream::adam takes over:
 // the streamed hashed levels (one accumulate item per bin); n = 0 when the configuration has none
-void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n);
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n,
+                                uint32_t* first_level = nullptr);
 // false: this configuration zeroes data-dependent ranges (globally sorted layout) and cannot hand the zeroing over
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out);
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);
@@ -267,6 +280,13 @@ struct NvoMlpArgsT {
     // (nullable) 64 shards, 8 floats apart, whose sum is the number of tiles with a non-zero byte (an upper bound of the
     // live ones): while 3/4 of the tiles or more are live the list is not built at all
     const float* tile_live_count;
+    // (backward, chain / dW roles, level-major layout; nullable -- the launcher has checked nvo_mlp_bwd_lists_rows) the
+    // kernel LISTS the samples whose dL/doutput row is not all zero while it walks its live tiles: live_rows[k] = sample id,
+    // *live_rows_n += their number (one atomic per workgroup; the order of the workgroups is not deterministic).  Without
+    // a tile list (no bytes, or most tiles live) it adds `batch` to the word instead: "all samples".  What the hash grid's
+    // backward behind this network walks (NvoGridSlices::ext_list) -- without a pass of its own over the rows.
+    uint32_t* live_rows;
+    uint32_t* live_rows_n;
 };
 typedef NvoMlpArgsT<_Float16> NvoMlpArgs;
 bool nvo_mlp_shape_supported(int in_pad, int width, int n_hidden, int out_pad);
@@ -281,6 +301,9 @@ int nvo_mlp_bwd_launch(int in_pad, int width, int n_hidden, int out_pad, const N
                        hipStream_t stream);
 // workgroups the backward of this shape launches for `batch` rows (rows of dw_partial) and its weight count
 uint32_t nvo_mlp_bwd_blocks(int in_pad, int width, int n_hidden, uint32_t batch);
+// true when the backward of this shape and batch can list the live rows itself (NvoMlpArgsT::live_rows): role-split form,
+// and a workgroup's tiles fit its LDS row buffer
+bool nvo_mlp_bwd_lists_rows(int in_pad, int width, int n_hidden, uint32_t batch);
 uint64_t nvo_mlp_n_weights(int in_pad, int width, int n_hidden, int out_pad);
 
 // ---- deterministic reductions (adam.hip) ---------------------------------------------------------

@@ -141,6 +141,12 @@ class EngineConfig:
     expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
+    # one-graph step with the main grid's optimiser step fused into its backward (fuse_grid_adam): the optimiser launch of
+    # the OTHER parameters (and the fold of the weight-gradient copies in front of it) runs beside the accumulate pass of that
+    # backward instead of behind it -- by then every producer of the step's overflow verdict has run (nvo_wait_fork_point).
+    # The accumulate pass is a stream of the whole table through Adam (HBM-bound, ~60-85 us); the two small launches
+    # are ~15 us of dependent dispatch that hide in it.
+    overlap_optimizer_tail: bool = True
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
     # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
     commit_behind_replay: bool = True
@@ -251,6 +257,12 @@ class NerfactoEngine:
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
             m.set_option("deterministic", int(bool(cfg.deterministic)))
+        if int(modes[0]) == 3 and cfg.fuse_grid_adam and cfg.overlap_optimizer_tail:
+            # the streamed DENSE level of the main grid (level 4) as ONE accumulate item per bin, like the hashed ones: the
+            # accumulate pass then steps it too, and nothing the optimiser launch covers comes out of that pass any more
+            # -- which is what lets the launch run beside it (overlap_optimizer_tail).  Eight tile-range chunks per bin
+            # measured 1 us faster per step on their own (0.5636 vs 0.5648 ms, tools/probes/bench_dense_chunks_ab.sh).
+            self.base_net.set_option("grid_stream_dense_chunks", 1)
         # Settled by measurement in rounds 2-4 (EXPERIMENTS.md), no longer switches: the main grid's four coarse levels stay
         # slice-owner with int32 accumulators and the L1-derived scale, as the proposal grids (half the slices per level,
         # a cheaper conversion: 1 M-sample grid 298 -> 227 us); dense levels use the run-merging scan; the record pass of
@@ -897,13 +909,40 @@ class NerfactoEngine:
             self._proposal_backward(ws, has_depth, pose, stream)
         if proposal_values and not update_proposals:
             self._proposal_backward(ws, has_depth, False, stream, values_only=True)
+        # EngineConfig.overlap_optimizer_tail: what is left of the step -- the fold of the dW copies, the optimiser launch of
+        # the parameters the main grid's backward has not stepped itself -- waits for the FORK POINT in front of that
+        # backward's accumulate pass instead of its end (armed around the capture of the one-graph step only)
+        self._tail_join = None
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_fork_point_armed", False) and not pose and scatter_stream is None and \
+                getattr(self, "_fused_adam_range", None) is not None:
+            if swap:
+                # the main-field backward runs on the side stream: this (origin) stream, behind the proposal chain, waits for
+                # the fork point only; the side stream itself is joined behind the optimiser launch (optimizer_step)
+                _call("nvo_wait_fork_point", self.base_net.handle, stream)
+                self._fold_dw_replicas(stream)
+                self._tail_join = ("origin", list(side))
+                return update_proposals
+            if side is None:
+                # everything ran on this stream: a tail stream forks at the fork point, this stream goes on into the
+                # accumulate pass; joined behind the optimiser launch
+                if getattr(self, "_tail_stream", None) is None:
+                    # (default priority: a graph captured across a priority stream crashed hipGraphLaunch -- hip::Graph::
+                    # UpdateStreams -- on ROCm 7.2)
+                    self._tail_stream = torch.cuda.Stream(device=self.device)
+                tail = self._tail_stream
+                _call("nvo_wait_fork_point", self.base_net.handle, C.c_void_p(tail.cuda_stream))
+                with torch.cuda.stream(tail):
+                    self._fold_dw_replicas(_stream(self.device))
+                self._tail_join = ("tail", [tail])
+                return update_proposals
         if side is not None:
             for st in side:
-                torch.cuda.current_stream(self.device).wait_stream(st)  # join
+                cur.wait_stream(st)  # join
         if pose:
             self._pose_backward(ws, update_proposals, stream)
         if scatter_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(scatter_stream)  # join
+            cur.wait_stream(scatter_stream)  # join
         self._fold_dw_replicas(stream)
         return update_proposals
 
@@ -1165,14 +1204,31 @@ class NerfactoEngine:
                 if b_ > a_:
                     batch.append(_lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
                                                 bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
+        tail_join, self._tail_join = getattr(self, "_tail_join", None), None
         if not batch:
+            if tail_join is not None:
+                for st_ in tail_join[1]:
+                    torch.cuda.current_stream(self.device).wait_stream(st_)
             return
         arr = (_lib.AdamGroup * len(batch))(*batch)
         dyn = cfg.dynamic_loss_scale
-        _call("nvo_adam_step_groups_scaled", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
-              ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
-              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
-              _ptr(self.dev_loss_scale) if dyn else None)
+
+        def launch_adam(st):
+            _call("nvo_adam_step_groups_scaled", st, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+                  ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
+                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
+                  _ptr(self.dev_loss_scale) if dyn else None)
+
+        if tail_join is not None and tail_join[0] == "tail":
+            # (forward_backward left a tail stream waiting at the fork point of the main grid's backward: the launch goes
+            # there, beside the accumulate pass this stream is in)
+            with torch.cuda.stream(tail_join[1][0]):
+                launch_adam(_stream(self.device))
+        else:
+            launch_adam(stream)
+        if tail_join is not None:
+            for st_ in tail_join[1]:
+                torch.cuda.current_stream(self.device).wait_stream(st_)  # join: the commit below is the step's last launch
         scale_mask = 0
         if dyn and "fields" in active:  # the fields group is stepped last in every launch order
             for g in (step_groups if step_groups is not None else active):
@@ -1212,8 +1268,15 @@ class NerfactoEngine:
         around the capture of the one-graph step only, so that eager steps keep storing the gradient)."""
         if not on:
             _call("nvo_set_fused_adam", self.base_net.handle, None)
+            if getattr(self, "_fork_point_armed", False):
+                self.base_net.set_option("bwd_mark_fork_point", 0)
+                self._fork_point_armed = False
             return
         cfg = self.cfg
+        import os
+        if cfg.overlap_optimizer_tail and int(os.environ.get("NVO_OVERLAP_TAIL", "1")):  # (A/B switch for measurements)
+            self.base_net.set_option("bwd_mark_fork_point", 1)
+            self._fork_point_armed = True
         gi = self._GROUP_ORDER.index("fields")
         base = self.segments["field.base"][0]
         a = _lib.FusedAdamArgs(

@@ -793,11 +793,14 @@ def test_dead_tiles_of_the_mlp_backward_are_skipped_exactly(device, dtype, monke
     _assert_close(p_on, p_off, rtol=1e-3, atol_scale=1e-5, what="parameters after 4 steps", max_outlier_frac=1e-3)
 
 
-def test_grid_backward_walks_the_live_rows_of_a_trained_field(device, monkeypatch):
+@pytest.mark.parametrize("lister", ["mlp-backward", "grid-pass"])
+def test_grid_backward_walks_the_live_rows_of_a_trained_field(device, monkeypatch, lister):
     """Default (non-deterministic) kernels, the state of a trained field (density bias +12: a ray's first sample inside
     the box takes its whole weight): the main hash grid's backward lists the samples whose dL/doutput row is non-zero from
-    the tile bytes of the render / loss kernel (k_live_rows) and both its slice-owner items and its record scatter walk
-    that list.  The list must hold exactly those samples, and the gradient must agree with the full scan's
+    the tile bytes of the render / loss kernel -- written by the base network's backward while it walks its live tiles
+    (NvoMlpArgsT::live_rows, the default) or by a pass of the encoding's own (k_live_rows, NVO_MLP_LISTS_ROWS=0: what
+    batches too large for the network's row buffer get) -- and both its slice-owner items and its record scatter walk that
+    list.  The list must hold exactly those samples, and the gradient must agree with the full scan's
     (NVO_GRID_LIVE_ROWS=0) -- the table part up to the fixed-point scale (order-free sums; the per-tile L1 bounds that set
     the scale follow the tile composition), the network weights up to the order of their float atomics."""
     from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
@@ -810,6 +813,8 @@ def test_grid_backward_walks_the_live_rows_of_a_trained_field(device, monkeypatc
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
+
+    monkeypatch.setenv("NVO_MLP_LISTS_ROWS", "1" if lister == "mlp-backward" else "0")
 
     def run(listed: bool):
         if listed:

@@ -32,7 +32,9 @@ def main():
     ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
                "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
                "frames_depth": seq["frames_depth"]})
-    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R), dev)
+    # NVO_PHASE_DENSITY_BIAS=12: the state of a trained field (a ray's first sample takes its whole weight, most tiles dead)
+    bias = float(os.environ.get("NVO_PHASE_DENSITY_BIAS", "-1"))
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, density_bias=bias, dynamic_loss_scale=bias < 0), dev)
     for _ in range(60):
         eng.train_step_graphed(ds)
     torch.cuda.synchronize()
@@ -40,6 +42,9 @@ def main():
     out = (C.c_ulonglong * 16)()
     rc = raw.nvo_debug_mlp_phase(out)
     assert rc == 0, "library was not built with -DNVO_MLP_PHASE"
+    if "tile_live" in eng._workspace(R, True):
+        live = eng._workspace(R, True)["tile_live"]
+        print(f"tiles with an rgb gradient {float((live & 1).bool().float().mean()):.3f}, with any {float((live != 0).float().mean()):.3f}")
     tot = sum(out[k] for k in range(10))
     tiles = R * 48 // 16 // 1024
     print(f"wave 0: {tot} cycles in the tile loop, {tiles} tiles -> {tot / tiles:.0f} cycles per tile")

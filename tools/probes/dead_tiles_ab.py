@@ -29,19 +29,22 @@ eng, ds = captured["eng"], captured["ds"]
 E.NerfactoEngine.train_step_graphed = _old
 
 
+GRAPHS = {}
 SCALE = float(os.environ.get("NVO_AB_LOSS_SCALE", "0"))  # > 0: pin the GradScaler's scale for the blocks (64 = the underflow regime)
 
 
-def block(skip: bool, rows: bool, steps: int = 300) -> float:
+def block(skip: bool, rows: bool, tail: bool = True, steps: int = 300) -> float:
     if SCALE > 0:
         eng.dev_loss_scale.fill_(SCALE)
         eng.dev_growth_tracker.zero_()
-    for key, on in (("NVO_MLP_SKIP_DEAD", skip), ("NVO_GRID_LIVE_ROWS", rows)):
+    for key, on in (("NVO_MLP_SKIP_DEAD", skip), ("NVO_GRID_LIVE_ROWS", rows), ("NVO_OVERLAP_TAIL", tail)):
         if on:
             os.environ.pop(key, None)
         else:
             os.environ[key] = "0"
-    eng._graphs.clear()
+    # one set of step graphs per setting, all kept alive (dropping the graphs of a setting and capturing again crashed a
+    # later replay -- tools/probes/recapture_repro.py; not a flow the mapper has)
+    eng._graphs = GRAPHS.setdefault((skip, rows, tail), {})
     for _ in range(12):  # warm-up: eager step + captures of the variants the schedule uses here
         eng.train_step_graphed(ds)
     torch.cuda.synchronize()
@@ -52,11 +55,12 @@ def block(skip: bool, rows: bool, steps: int = 300) -> float:
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-ORDER = [(c[0] == "1", c[1] == "1") for c in os.environ.get("NVO_AB_ORDER", "11,10,01,00").split(",")]  # (MLP list, grid list)
+# (MLP live-tile list, grid live-row list[, optimiser tail beside the accumulate pass])
+ORDER = [(c[0] == "1", c[1] == "1", c[2:3] != "0") for c in os.environ.get("NVO_AB_ORDER", "11,10,01,00").split(",")]
 for rep in range(int(os.environ.get("NVO_AB_REPS", "3"))):
-    for skip, rows in ORDER:
-        ms = block(skip, rows)
+    for skip, rows, tail in ORDER:
+        ms = block(skip, rows, tail)
         ws = eng._workspace(eng.cfg.num_rays, True)
         live = ws["tile_live"]
-        print(f"rep {rep} MLP live-tile list {'on ' if skip else 'off'} grid live-row list {'on ' if rows else 'off'}: {ms:.4f} ms/step  loss scale {eng.current_loss_scale():g}  "
+        print(f"rep {rep} MLP live-tile list {'on ' if skip else 'off'} grid live-row list {'on ' if rows else 'off'} tail {'beside' if tail else 'behind'}: {ms:.4f} ms/step  loss scale {eng.current_loss_scale():g}  "
               f"tiles with rgb gradient {float((live & 1).bool().float().mean()):.3f}  with any {float((live != 0).float().mean()):.3f}", flush=True)
