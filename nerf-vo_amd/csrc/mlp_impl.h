@@ -757,9 +757,11 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         if (code >= n_own || t >= n_tiles) return 0u;
         return (a.tile_live[t] & a.tile_live_bits) != 0u ? 1u : 2u;
     };
-    uint32_t flag0 = 0u;  // (the first round's bytes are requested with the matrices: one round trip)
+    // (the bytes of the first round are requested with the matrices -- one round trip -- unless a count of the live tiles
+    // is at hand: then they wait for the decision, and the untrained field, every tile live, never loads them)
+    uint32_t flag0 = 0u;
     if constexpr (kListIo) {
-        if (list_pre) flag0 = tile_flag(threadIdx.x);
+        if (list_pre && !a.tile_live_count) flag0 = tile_flag(threadIdx.x);
     }
 
     // transposed weights for the dH chain (layer 0's only if dL/dinput is wanted)
@@ -821,6 +823,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
             use_list = c < (float)(n_tiles - (n_tiles >> 2));
+            if (use_list) flag0 = tile_flag(threadIdx.x);
         }
         if constexpr (kRowsIo) {
             if (a.live_rows && !use_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.live_rows_n, a.batch);  // "all samples"
