@@ -24,6 +24,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -637,6 +638,8 @@ def main() -> None:
                                                 "frac": round(b32 / avg_s / 1e9 / HBM_PEAK_GBS, 5)}
             break
     roofline_gather = gather_roofline(kernel_table, cfg, args.rays, live_summary_path) if rank == 0 else None
+    if live_summary_path and os.path.basename(os.path.dirname(live_summary_path)).startswith("nvo_pmc_"):
+        shutil.rmtree(os.path.dirname(live_summary_path), ignore_errors=True)  # (the passes' traces: 25 MB per run; a copy of the summary is in gpurun_out/)
     # MFMA utilisation of the fused-MLP kernels alone: FLOP model 2*N*(I*W + (H-1)*W*W + W*O)
     # for a forward; a backward = input gradient + weight gradient + (these networks store no hidden activations)
     # the recomputed forward = 3x.  N = main-field samples per launch; dense fp16 MFMA peak 2.5 PFLOP/s.

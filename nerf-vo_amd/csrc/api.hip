@@ -408,6 +408,19 @@ struct GridModule : nvo_module_s {
         *n = 2 * c;
         return NVO_OK;
     }
+    // parameters whose gradient comes out of the streamed accumulate pass (the contiguous tail of streamed levels)
+    int streamed_range(uint64_t* first, uint64_t* n) {
+        *first = *n = 0;
+        if (bwd_mode != 3) return NVO_OK;
+        if (int rc = ensure_slices()) return rc;
+        uint32_t lo = g.n_levels;
+        for (uint32_t l = 0; l < g.n_levels; ++l)
+            if (((stream_bins.streamed_mask >> l) & 1u) && l < lo) lo = l;
+        if (lo == g.n_levels) return NVO_OK;
+        *first = 2 * (uint64_t)g.offset[lo];
+        *n = 2 * ((uint64_t)g.offset[g.n_levels] - g.offset[lo]);
+        return NVO_OK;
+    }
     int set_fused_adam(const nvo_fused_adam_args* a, uint64_t off) override {
         if (!a) {
             stream_bins.adam = NvoGridAdam{};
@@ -1099,6 +1112,17 @@ int nvo_set_option(nvo_module_t m, const char* key, int64_t value) {
 int nvo_fused_adam_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_params) {
     NVO_REQUIRE(m && first_param && n_params, "fused_adam_range: NULL argument");
     return m->fused_adam_range(first_param, n_params);
+}
+
+int nvo_streamed_grad_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_params) {
+    NVO_REQUIRE(m && first_param && n_params, "streamed_grad_range: NULL argument");
+    *first_param = *n_params = 0;
+    auto* n = dynamic_cast<NwieModule*>(m);
+    GridModule* g = n ? n->enc.get() : dynamic_cast<GridModule*>(m);
+    if (!g) return NVO_OK;
+    if (int rc = g->streamed_range(first_param, n_params)) return rc;
+    if (n && *n_params) *first_param += n->net->n_params;  // params = [network | encoding]
+    return NVO_OK;
 }
 
 int nvo_set_fused_adam(nvo_module_t m, const nvo_fused_adam_args* args) {

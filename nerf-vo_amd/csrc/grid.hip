@@ -2691,7 +2691,7 @@ __global__ void __launch_bounds__(kTlBlockP, 4)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
                   uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam,
-                  const uint32_t* __restrict__ live_n, uint32_t N) {
+                  const uint32_t* __restrict__ live_n, uint32_t N, uint32_t* __restrict__ bin_done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
@@ -2896,6 +2896,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                                 float4 gv;
                                 split(w.x, &gv.x, &gv.y);
                                 split(w.y, &gv.z, &gv.w);
+                                if (!g.hashed[cur.level]) gr4[e] = gv;  // (a dense level as single items: the deterministic mode, whose tests read the gradient)
                                 nvo_adam_one(pv[u].x, mv[u].x, vv[u].x, gv.x, ah);
                                 nvo_adam_one(pv[u].y, mv[u].y, vv[u].y, gv.y, ah);
                                 nvo_adam_one(pv[u].z, mv[u].z, vv[u].z, gv.z, ah);
@@ -2931,6 +2932,75 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     split(acc[e], &f0, &f1);
                     if (f0 != 0.f) atomicAdd(gr + 2 * e, f0);
                     if (f1 != 0.f) atomicAdd(gr + 2 * e + 1, f1);
+                }
+                if (adam.params && cur.level >= adam.first_level && bin_done) {
+                    // The bin's chunks meet in the float atomics above; the LAST of them to check in finds the complete
+                    // sums in `gr` and steps the bin (the pattern of the optimiser launch's tail commit, adam.hip).  Every
+                    // chunk's adds are performed before its check-in, the reader takes the sums with agent-scope loads, and the
+                    // counter goes back to zero for the next launch.  The adds, the counter and the reader's loads are all
+                    // agent-scope accesses, performed where the XCDs meet: what the check-in has to wait for is only that
+                    // the workgroup's own adds have been acknowledged (vmcnt(0), then the barrier) -- NOT __threadfence(),
+                    // whose agent-scope release writes back this XCD's L2, full of the pass's own Adam output: with it on
+                    // each of the 208 chunk items the launch took 258 us instead of 149.
+                    __shared__ uint32_t s_last;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        const uint32_t prev = atomicAdd(&bin_done[cur.bin], 1u);
+                        s_last = prev + 1u == cur.n_chunks ? 1u : 0u;
+                        if (s_last) bin_done[cur.bin] = 0u;
+                    }
+                    __syncthreads();
+                    if (s_last != 0u && !adam_skip) {
+                        const size_t o4 = ((size_t)g.offset[cur.level] + (size_t)cur.slice * BIN) >> 1;  // in float4 units
+                        float4* __restrict__ p4 = reinterpret_cast<float4*>(adam.params) + o4;
+                        float4* __restrict__ m4 = reinterpret_cast<float4*>(adam.exp_avg) + o4;
+                        float4* __restrict__ v4 = reinterpret_cast<float4*>(adam.exp_avg_sq) + o4;
+                        uint2* __restrict__ h4 = reinterpret_cast<uint2*>(adam.params_half) + o4;
+                        float4* __restrict__ e4 = adam.ema ? reinterpret_cast<float4*>(adam.ema) + o4 : nullptr;
+                        uint2* __restrict__ eh4 = adam.ema_half ? reinterpret_cast<uint2*>(adam.ema_half) + o4 : nullptr;
+                        const unsigned long long* g64 = reinterpret_cast<const unsigned long long*>(gr);
+                        constexpr uint32_t kU = 2;  // (two steps' loads in flight: this branch must not set the kernel's register count)
+                        for (uint32_t e0 = threadIdx.x; e0 < n2; e0 += kU * kTlBlockP) {
+                            float4 pv[kU], mv[kU], vv[kU];
+                            unsigned long long ga[kU], gb[kU];
+#pragma unroll
+                            for (uint32_t u = 0; u < kU; ++u) {
+                                const uint32_t e = min(e0 + u * kTlBlockP, n2 - 1u);
+                                pv[u] = p4[e];
+                                mv[u] = m4[e];
+                                vv[u] = v4[e];
+                                ga[u] = __hip_atomic_load(g64 + 2 * (size_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gb[u] = __hip_atomic_load(g64 + 2 * (size_t)e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < kU; ++u) {
+                                const uint32_t e = e0 + u * kTlBlockP;
+                                if (e < n2) {
+                                    const float gx = __uint_as_float((uint32_t)ga[u]), gy = __uint_as_float((uint32_t)(ga[u] >> 32));
+                                    const float gz = __uint_as_float((uint32_t)gb[u]), gw = __uint_as_float((uint32_t)(gb[u] >> 32));
+                                    nvo_adam_one(pv[u].x, mv[u].x, vv[u].x, gx, ah);
+                                    nvo_adam_one(pv[u].y, mv[u].y, vv[u].y, gy, ah);
+                                    nvo_adam_one(pv[u].z, mv[u].z, vv[u].z, gz, ah);
+                                    nvo_adam_one(pv[u].w, mv[u].w, vv[u].w, gw, ah);
+                                    p4[e] = pv[u];
+                                    m4[e] = mv[u];
+                                    v4[e] = vv[u];
+                                    h4[e] = make_uint2(nvo_cvt16x2(pv[u].x, pv[u].y, false), nvo_cvt16x2(pv[u].z, pv[u].w, false));
+                                    if (e4) {
+                                        float4 ev = e4[e];
+                                        ev.x = (ev.x * ema_keep + pv[u].x * ema_take) * ema_inv;
+                                        ev.y = (ev.y * ema_keep + pv[u].y * ema_take) * ema_inv;
+                                        ev.z = (ev.z * ema_keep + pv[u].z * ema_take) * ema_inv;
+                                        ev.w = (ev.w * ema_keep + pv[u].w * ema_take) * ema_inv;
+                                        e4[e] = ev;
+                                        if (eh4) eh4[e] = make_uint2(nvo_cvt16x2(ev.x, ev.y, false), nvo_cvt16x2(ev.z, ev.w, false));
+                                    }
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -3600,6 +3670,8 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         st->n_tl_items = (uint32_t)(items.size() / 4);
         NVO_CHECK_HIP(hipMalloc((void**)&st->d_tl_items, 4 * items.size()));
         NVO_CHECK_HIP(hipMemcpy(st->d_tl_items, items.data(), 4 * items.size(), hipMemcpyHostToDevice));
+        NVO_CHECK_HIP(hipMalloc((void**)&st->d_bin_done, 4 * (size_t)nb));
+        NVO_CHECK_HIP(hipMemset(st->d_bin_done, 0, 4 * (size_t)nb));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_chunks, chunks.data(), 4 * nb, hipMemcpyHostToDevice));
     }
     st->created = true;
@@ -3626,6 +3698,8 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     nvo_scratch_destroy(&st->work);
     if (st->d_tl_items) (void)hipFree(st->d_tl_items);
     st->d_tl_items = nullptr;
+    if (st->d_bin_done) (void)hipFree(st->d_bin_done);
+    st->d_bin_done = nullptr;
     st->n_tl_items = 0;
     st->d_meta = nullptr;
     st->n_bins = 0;
@@ -3651,9 +3725,13 @@ void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st,
     *first = 0;
     *n = 0;
     if (!st->created) return;
-    // the streamed levels whose bins are ONE accumulate item each (nvo_grid_stream_create: the hashed ones, and the dense
-    // ones with option grid_stream_dense_chunks = 1); they form the tail of the table
-    auto single = [&](uint32_t l) { return ((st->streamed_mask >> l) & 1u) && (g.hashed[l] || st->dense_chunks == 1u); };
+    // the streamed levels; they form the tail of the table.  A hashed level's bin is one accumulate item, which steps it
+    // from its LDS sums; a streamed DENSE level sees clustered samples and its bins are split into tile ranges that meet
+    // in float atomics -- the LAST of a bin's chunks to check in steps it from the summed gradient (k_tl_accumulate_p,
+    // d_bin_done).  (Single items for the dense bins too -- option grid_stream_dense_chunks = 1 -- put most of the level's
+    // records on a few workgroups in a run's early iterations, few keyframes: +55 us per step at iteration 500 of the
+    // mapping run, tools/probes/loop_early_ab.sh.)
+    auto single = [&](uint32_t l) { return ((st->streamed_mask >> l) & 1u) != 0u && (g.hashed[l] || st->d_bin_done != nullptr); };
     uint32_t lo = g.n_levels;
     for (uint32_t l = 0; l < g.n_levels; ++l)
         if (single(l) && l < lo) lo = l;
@@ -3763,7 +3841,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
             NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
                        (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1,                              \
                        reinterpret_cast<const uint32_t*>(records_tl), n_tiles,                                \
-                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam, live_n, N);                 \
+                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam, live_n, N, st->d_bin_done); \
         }                                                                                                     \
     } while (0)
 #define NVO_LAUNCH_TLP(SOA_, T_)                                                           \

@@ -143,6 +143,7 @@ struct NvoGridStream {
     uint32_t bin_entries = 4096;      // (set by create)
     uint32_t dense_chunks = 8;        // tile-range chunks per bin of a streamed DENSE level (clustered samples)
     uint32_t* d_tl_items = nullptr;   // uint4 {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}
+    uint32_t* d_bin_done = nullptr;   // [n_bins] check-in counters of the chunked bins (the LAST chunk steps the bin; self-resetting)
     uint32_t n_tl_items = 0;
     uint32_t n_tl_slots = 0;          // (packed form) persistent workgroups the balanced item list was laid out for; 0 = dealt
     hipStream_t aux = nullptr;

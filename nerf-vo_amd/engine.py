@@ -257,12 +257,6 @@ class NerfactoEngine:
             m.set_option("grid_bwd_mode", int(mode))
             m.set_option("bf16", int(self.bf16))
             m.set_option("deterministic", int(bool(cfg.deterministic)))
-        if int(modes[0]) == 3 and cfg.fuse_grid_adam and cfg.overlap_optimizer_tail:
-            # the streamed DENSE level of the main grid (level 4) as ONE accumulate item per bin, like the hashed ones: the
-            # accumulate pass then steps it too, and nothing the optimiser launch covers comes out of that pass any more
-            # -- which is what lets the launch run beside it (overlap_optimizer_tail).  Eight tile-range chunks per bin
-            # measured 1 us faster per step on their own (0.5636 vs 0.5648 ms, tools/probes/bench_dense_chunks_ab.sh).
-            self.base_net.set_option("grid_stream_dense_chunks", 1)
         # Settled by measurement in rounds 2-4 (EXPERIMENTS.md), no longer switches: the main grid's four coarse levels stay
         # slice-owner with int32 accumulators and the L1-derived scale, as the proposal grids (half the slices per level,
         # a cheaper conversion: 1 M-sample grid 298 -> 227 us); dense levels use the run-merging scan; the record pass of
@@ -923,7 +917,10 @@ class NerfactoEngine:
                 self._fold_dw_replicas(stream)
                 self._tail_join = ("origin", list(side))
                 return update_proposals
-            if side is None:
+            if side is None and int(__import__("os").environ.get("NVO_OVERLAP_TAIL_PLAIN", "0")):
+                # (measurement only, default OFF: a step without a side stream.  The accumulate pass alone fills every CU
+                # -- two 512-thread workgroups each -- and the two small launches of a forked tail stream get their turn
+                # when its workgroups retire: 4 us of 13, less than the extra launch of the late range below costs.)
                 # everything ran on this stream: a tail stream forks at the fork point, this stream goes on into the
                 # accumulate pass; joined behind the optimiser launch
                 if getattr(self, "_tail_stream", None) is None:
@@ -1190,21 +1187,29 @@ class NerfactoEngine:
         batch = []
         mask = 0
         fused = getattr(self, "_fused_adam_range", None)  # (set around the capture of the one-graph step)
+        tail_join, self._tail_join = getattr(self, "_tail_join", None), None
+        late = []  # (overlap_optimizer_tail) ranges whose gradient comes out of the pass the launch runs beside: stepped behind the join
         for g in active:
             lo, hi = span(g)
             gi = order.index(g)
             mask |= 1 << gi
             hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None
-            parts = [(lo, hi)]
+            parts = [(lo, hi, False)]
             if g == "fields" and fused is not None:
                 # the main grid's backward has already stepped [fused): the launch covers what lies around it
                 assert shard is None and grads_half is None and lo <= fused[0] < fused[1] <= hi
-                parts = [(lo, fused[0]), (fused[1], hi)]
-            for a_, b_ in parts:
+                parts = [(lo, fused[0], False), (fused[1], hi, False)]
+                if tail_join is not None:
+                    # ... and the streamed levels in front of [fused) -- the main grid's dense level 4, whose bins meet in
+                    # float atomics and are therefore not stepped by the pass -- get their gradient from it
+                    s_lo = self._streamed_grad_lo()
+                    assert lo <= s_lo <= fused[0]
+                    parts = [(lo, s_lo, False), (s_lo, fused[0], True), (fused[1], hi, False)]
+            for a_, b_, late_ in parts:
                 if b_ > a_:
-                    batch.append(_lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
-                                                bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
-        tail_join, self._tail_join = getattr(self, "_tail_join", None), None
+                    (late if late_ else batch).append(
+                        _lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
+                                       bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
         if not batch:
             if tail_join is not None:
                 for st_ in tail_join[1]:
@@ -1213,8 +1218,8 @@ class NerfactoEngine:
         arr = (_lib.AdamGroup * len(batch))(*batch)
         dyn = cfg.dynamic_loss_scale
 
-        def launch_adam(st):
-            _call("nvo_adam_step_groups_scaled", st, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+        def launch_adam(st, arr=arr, n=len(batch)):
+            _call("nvo_adam_step_groups_scaled", st, n, arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
                   ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
                   1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
                   _ptr(self.dev_loss_scale) if dyn else None)
@@ -1229,6 +1234,8 @@ class NerfactoEngine:
         if tail_join is not None:
             for st_ in tail_join[1]:
                 torch.cuda.current_stream(self.device).wait_stream(st_)  # join: the commit below is the step's last launch
+            if late:
+                launch_adam(stream, (_lib.AdamGroup * len(late))(*late), len(late))
         scale_mask = 0
         if dyn and "fields" in active:  # the fields group is stepped last in every launch order
             for g in (step_groups if step_groups is not None else active):
@@ -1242,6 +1249,15 @@ class NerfactoEngine:
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
               cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
+
+    def _streamed_grad_lo(self) -> int:
+        """First element of the flat buffer whose gradient comes out of the main grid's accumulate pass (nvo_streamed_grad_range)."""
+        if getattr(self, "_streamed_lo", None) is None:
+            first, n = C.c_uint64(0), C.c_uint64(0)
+            _call("nvo_streamed_grad_range", self.base_net.handle, C.byref(first), C.byref(n))
+            assert n.value > 0
+            self._streamed_lo = self.segments["field.base"][0] + int(first.value)
+        return self._streamed_lo
 
     def _fused_adam_plan(self):
         """(lo, hi) of the flat parameter buffer whose Adam step the main grid's backward can take over

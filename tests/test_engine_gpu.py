@@ -946,6 +946,72 @@ def test_adam_inside_the_grid_backward_is_bit_identical(device, poses):
         assert bool(same.all()), f"{name}: {int((~same).sum())} words differ with the step inside the grid backward"
 
 
+def test_chunked_dense_bins_are_stepped_by_their_last_chunk(device):
+    """Default (non-deterministic) kernels: the streamed DENSE level of the main grid (level 4) splits its bins into tile-range
+    chunks that meet in float atomics; with the optimiser step inside the accumulate pass the LAST chunk of a bin to check
+    in steps it from the summed gradient (k_tl_accumulate_p, d_bin_done).  Three graph-replayed steps from the same seed
+    with the step inside the backward and with the separate optimiser launch: that level's parameters and both moments
+    must agree up to the order of the float atomics, must have moved, and the check-in counters must be back at zero
+    (the next launch counts from there)."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 2048
+    seq = make_sequence(n, H, W, device=device)
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+
+    def run(fuse: bool):
+        torch.manual_seed(33)
+        eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, fuse_grid_adam=fuse, dynamic_loss_scale=False), device)
+        p0 = eng.params.clone()
+        for _ in range(3):
+            eng.train_step_graphed(ds)
+        torch.cuda.synchronize()
+        assert int(eng.skip_flag.sum()) == 0
+        fused = [e.get("fused_adam") for e in eng._graphs.values()]
+        return eng, p0, eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), fused
+
+    eng, p0, pa, ma, va, fused = run(True)
+    _, _, pb, mb, vb, fused_b = run(False)
+    _, _, pc, mc, vc, _ = run(False)  # the noise floor: the separate launch twice (float atomics in another order)
+    assert all(f is not None for f in fused) and all(f is None for f in fused_b)
+    lo, hi = fused[0]
+    s_lo = eng._streamed_grad_lo()
+    base_lo, base_n, _ = eng.segments["field.base"]
+    assert lo == s_lo < hi == base_lo + base_n, "the stepped range starts at the first streamed level"
+    # level 4: from the first streamed entry to the first hashed level (2^19 entries each from there on)
+    l4_hi = hi - 2 * 11 * (1 << 19)
+    assert lo < l4_hi < hi and (l4_hi - lo) // 2 > 100000, (lo, l4_hi, hi)
+    sl = slice(lo, l4_hi)
+    assert float((pa[sl] - p0[sl]).abs().max()) > 0, "level 4 must have been stepped"
+
+    def noise(x, y):
+        """(fraction of entries beyond rtol 2e-3 / atol 2e-5 x scale, largest difference / scale, relative L1)"""
+        x, y = x.double(), y.double()
+        scale = float(y.abs().max())
+        d = (x - y).abs()
+        return float((d > 2e-3 * y.abs() + 2e-5 * scale).double().mean()), float(d.max()) / scale, float(d.sum() / y.abs().sum())
+
+    # Adam divides by sqrt(v): an entry whose gradient is rounding noise of the float atomics moves by +- lr whichever way the
+    # noise falls, so ANY two default-mode runs differ in a few entries by a sizeable fraction of the largest parameter.
+    # A chunk's adds missing from the sums its bin's last chunk read would show as whole bins of 8192 entries off and in
+    # the second moment: the fused form must sit at the noise floor of the separate launch against itself.
+    for name, xa, xb, xc in (("parameters", pa[sl], pb[sl], pc[sl]), ("first moment", ma[sl], mb[sl], mc[sl]),
+                             ("second moment", va[sl], vb[sl], vc[sl])):
+        f_ab, m_ab, l_ab = noise(xa, xb)
+        f_bc, m_bc, l_bc = noise(xc, xb)
+        assert f_ab <= 3.0 * f_bc + 2e-4, f"level-4 {name}: {f_ab:.2e} of the entries differ (floor {f_bc:.2e})"
+        assert l_ab <= 3.0 * l_bc + 1e-5, f"level-4 {name}: relative L1 difference {l_ab:.2e} (floor {l_bc:.2e})"
+        assert m_ab <= 3.0 * m_bc + 0.02, f"level-4 {name}: largest difference {m_ab:.2e} of the scale (floor {m_bc:.2e})"
+    f_ab, _, l_ab = noise(pa[base_lo:lo], pb[base_lo:lo])
+    f_bc, _, l_bc = noise(pc[base_lo:lo], pb[base_lo:lo])
+    assert f_ab <= 3.0 * f_bc + 2e-4 and l_ab <= 3.0 * l_bc + 1e-5, (f_ab, f_bc, l_ab, l_bc)  # (base network + slice-owner levels)
+
+
 def test_pipelined_prefix_is_bit_identical_on_one_gpu(device):
     """EngineConfig.pipeline_single_gpu: the graph ends with [Adam of the fields group || sampling prefix of the NEXT
     step] -- the launch order the multi-GPU step uses around its exchange, on one GPU.  The reordering must not change

@@ -118,6 +118,7 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
 
     torch.manual_seed(int(seed))
     dev = torch.device(device)
+    own_dir = out_dir is None  # (a directory of our own making is removed again: 1.1 GB of frames and snapshots per run)
     out_dir = out_dir or tempfile.mkdtemp(prefix="nvo_eval_")
     n_frames = keyframes * frame_stride  # dataset frames; every frame_stride-th one is a keyframe (configs: frame_stride 2)
     ngp = method == "instant-ngp"
@@ -212,6 +213,9 @@ def run(keyframes=48, height=120, width=160, iterations=1500, frame_stride=2, ev
         res.update({"dynamic_loss_scale": bool(eng.cfg.dynamic_loss_scale), "loss_scale_end": eng.current_loss_scale()})
     if not quiet:
         print(json.dumps(res))
+    if own_dir:
+        import shutil
+        shutil.rmtree(out_dir, ignore_errors=True)
     return res
 
 
