@@ -197,16 +197,6 @@ int nvo_set_fused_adam(nvo_module_t module, const nvo_fused_adam_args* args);
 int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream, uint32_t batch,
                  const float* input, const void* params, const void* output, const void* dL_doutput, void* ctx,
                  float* dL_dinput, float* dL_dparams);
-/* Module option "bwd_mark_fork_point" (NetworkWithInputEncoding, streamed parameter backward): every nvo_bwd records an
- * event in front of the encoding's accumulate pass -- the last, HBM-bound third of that backward.  With the optimiser step
- * armed (nvo_set_fused_adam) every producer of the step's overflow verdict precedes that pass, so the optimiser launch of
- * the OTHER parameters, which waits for nothing but the verdict and its own gradients, may run beside it:
- * nvo_wait_fork_point makes `waiting_stream` wait for the event of the last nvo_bwd (a capture-safe fork; the caller
- * joins the streams again).  Error when no fork point has been recorded. */
-int nvo_wait_fork_point(nvo_module_t m, nvo_stream_t waiting_stream);
-/* The parameters (offsets from the module's first) whose gradient -- or, armed, whose optimiser step -- comes out of the
- * accumulate pass behind that fork point: whatever runs beside the pass must leave them alone.  n = 0: none. */
-int nvo_streamed_grad_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_params);
 
 /* Parity/debug: the per-level table geometry and the 8 corner indices the encoder uses.
  * levels_out: host uint32 [n_levels][4] = {offset, size, resolution, hashed}; scales_out: host

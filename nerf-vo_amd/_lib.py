@@ -149,8 +149,6 @@ _SIGNATURES = {
     "nvo_fwd": (_int, [_p, _p, _u32, _p, _p, _p, _p]),
     "nvo_bwd": (_int, [_p, _p, _u32, _p, _p, _p, _p, _p, _p, _p]),
     "nvo_bwd_fork": (_int, [_p, _p, _p, _u32, _p, _p, _p, _p, _p, _p, _p]),
-    "nvo_wait_fork_point": (_int, [_p, _p]),
-    "nvo_streamed_grad_range": (_int, [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nvo_grid_describe": (_int, [_p, _p, _p]),
     "nvo_grid_indices": (_int, [_p, _p, _u32, _p, _p]),
     # group B

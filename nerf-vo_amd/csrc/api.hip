@@ -408,19 +408,6 @@ struct GridModule : nvo_module_s {
         *n = 2 * c;
         return NVO_OK;
     }
-    // parameters whose gradient comes out of the streamed accumulate pass (the contiguous tail of streamed levels)
-    int streamed_range(uint64_t* first, uint64_t* n) {
-        *first = *n = 0;
-        if (bwd_mode != 3) return NVO_OK;
-        if (int rc = ensure_slices()) return rc;
-        uint32_t lo = g.n_levels;
-        for (uint32_t l = 0; l < g.n_levels; ++l)
-            if (((stream_bins.streamed_mask >> l) & 1u) && l < lo) lo = l;
-        if (lo == g.n_levels) return NVO_OK;
-        *first = 2 * (uint64_t)g.offset[lo];
-        *n = 2 * ((uint64_t)g.offset[g.n_levels] - g.offset[lo]);
-        return NVO_OK;
-    }
     int set_fused_adam(const nvo_fused_adam_args* a, uint64_t off) override {
         if (!a) {
             stream_bins.adam = NvoGridAdam{};
@@ -435,10 +422,6 @@ struct GridModule : nvo_module_s {
                         (((uintptr_t)a->params_half + 2 * off) & 7u) == 0,
                     "set_fused_adam: the encoding's parameters must start 16-byte aligned in every buffer");
         NvoGridAdam& d = stream_bins.adam;
-        {
-            uint64_t f_ = 0, c_ = 0;
-            nvo_grid_stream_adam_range(g, &stream_bins, &f_, &c_, &d.first_level);
-        }
         d.params = a->params + off;
         d.params_half = (char*)a->params_half + 2 * off;
         d.exp_avg = a->exp_avg + off;
@@ -593,12 +576,6 @@ struct GridModule : nvo_module_s {
         }
         if (!strcmp(key, "grid_stream_acc_bits")) {  // (the record pass has one form left: packed 2 x 32-bit sums)
             NVO_REQUIRE(value == 32, "grid_stream_acc_bits: only the packed 32-bit record pass exists (got %lld)", (long long)value);
-            return NVO_OK;
-        }
-        if (!strcmp(key, "grid_stream_dense_chunks")) {  // tile-range chunks per bin of a streamed DENSE level (on rebuild)
-            NVO_REQUIRE(value >= 1 && value <= 64, "grid_stream_dense_chunks: 1..64 (got %lld)", (long long)value);
-            nvo_grid_stream_destroy(&stream_bins);
-            stream_bins.dense_chunks = (uint32_t)value;
             return NVO_OK;
         }
         if (!strcmp(key, "grid_stream_owner_slices")) {  // takes effect when the tables are (re)built
@@ -867,7 +844,8 @@ struct NwieModule : nvo_module_s {
         a.dinput = dencoded;
         a.din_mode = NVO_IO_HALF2_SOA;
         a.dweights = dparams;
-        if (bwd_tile_live && !compact_out) {  // (module option "bwd_tile_live_ptr": the caller's promise about `dout`)
+        const char* const e_dead = getenv("NVO_MLP_SKIP_DEAD");  // (A/B, tests: 0 = every tile in its turn; per launch)
+        if (bwd_tile_live && !compact_out && !(e_dead && atoi(e_dead) == 0)) {  // (module option "bwd_tile_live_ptr": the caller's promise about `dout`)
             a.tile_live = bwd_tile_live;
             a.tile_live_bits = bwd_tile_live_bits;
             a.tile_live_count = bwd_tile_live_count;
@@ -986,12 +964,6 @@ struct NwieModule : nvo_module_s {
         }
         if (!strcmp(key, "bwd_tile_live_bits")) {
             bwd_tile_live_bits = (uint32_t)value;
-            return NVO_OK;
-        }
-        if (!strcmp(key, "bwd_mark_fork_point")) {  // see nvo_wait_fork_point
-            NVO_REQUIRE(enc->bwd_mode == 3 || value == 0, "bwd_mark_fork_point: the streamed parameter backward (grid_bwd_mode 3) only");
-            enc->stream_bins.mark_pre_acc = value != 0;
-            enc->stream_bins.pre_acc_recorded = false;
             return NVO_OK;
         }
         if (!strcmp(key, "debug_copy_grid_live_n")) {  // (tests) length word of the encoding's live-sample list -> *value (device u32)
@@ -1114,17 +1086,6 @@ int nvo_fused_adam_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_para
     return m->fused_adam_range(first_param, n_params);
 }
 
-int nvo_streamed_grad_range(nvo_module_t m, uint64_t* first_param, uint64_t* n_params) {
-    NVO_REQUIRE(m && first_param && n_params, "streamed_grad_range: NULL argument");
-    *first_param = *n_params = 0;
-    auto* n = dynamic_cast<NwieModule*>(m);
-    GridModule* g = n ? n->enc.get() : dynamic_cast<GridModule*>(m);
-    if (!g) return NVO_OK;
-    if (int rc = g->streamed_range(first_param, n_params)) return rc;
-    if (n && *n_params) *first_param += n->net->n_params;  // params = [network | encoding]
-    return NVO_OK;
-}
-
 int nvo_set_fused_adam(nvo_module_t m, const nvo_fused_adam_args* args) {
     NVO_REQUIRE(m, "set_fused_adam: NULL module");
     return m->set_fused_adam(args, 0);
@@ -1179,16 +1140,6 @@ int nvo_bwd_fork(nvo_module_t m, nvo_stream_t stream, nvo_stream_t params_stream
         return m->bwd((hipStream_t)stream, batch, input, params, output, dL_doutput, ctx, dL_dinput, dL_dparams);
     return n->bwd_on((hipStream_t)stream, (hipStream_t)params_stream, batch, input, params, output, dL_doutput, ctx,
                      dL_dinput, dL_dparams);
-}
-
-int nvo_wait_fork_point(nvo_module_t m, nvo_stream_t waiting_stream) {
-    NVO_REQUIRE(m, "wait_fork_point: NULL module");
-    auto* n = dynamic_cast<NwieModule*>(m);
-    NVO_REQUIRE(n && n->enc->bwd_mode == 3 && n->enc->stream_bins.mark_pre_acc && n->enc->stream_bins.pre_acc_recorded &&
-                    n->enc->stream_bins.ev_pre_acc,
-                "wait_fork_point: no fork point recorded (option bwd_mark_fork_point, streamed parameter backward, a backward since)");
-    NVO_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiting_stream, n->enc->stream_bins.ev_pre_acc, 0));
-    return NVO_OK;
 }
 
 static GridModule* as_grid(nvo_module_t m) {

@@ -2523,7 +2523,7 @@ __device__ __forceinline__ PairRec pair_pack(uint32_t rel, float u0, float u1, u
     return PairRec{(a & ~0x3Fu) | (rel & 0x3Fu), (b & ~0x7Fu) | (rel >> 6), (wq & 0xFFFFu) | (code << 16)};
 }
 
-template <int TILE, bool SOA, typename DY2, uint32_t BIN>
+template <int TILE, bool SOA, typename DY2, uint32_t BIN, bool LISTED>
 __global__ void __launch_bounds__(TILE)
 k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const DY2* __restrict__ dy,
                const uint32_t* __restrict__ st_levels, const uint32_t* __restrict__ bin_first,
@@ -2545,14 +2545,17 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
     uint32_t* loff = reinterpret_cast<uint32_t*>(hist + n_slices);
     __shared__ uint32_t total_s;
     __shared__ float wmax[kWaves][2];
-    // live_list (k_live_rows / k_live_samples): the tiles are cut from the list of samples that carry a gradient -- as the
-    // slice-owner items, only while it is shorter than 3/4 N; tiles past its end write empty segments and leave
-    const uint32_t n_listed = live_list ? *live_n : N;
-    const bool listed = live_list != nullptr && n_listed < N - (N >> 2);
-    const uint32_t n_scan = listed ? n_listed : N;
-    if (tile * kStBlock >= n_scan) return;  // (workgroup-uniform, before any barrier; k_tl_accumulate_p skips these tiles' words)
-    const uint32_t j_scan = tile * kStBlock + threadIdx.x;
-    const uint32_t i = j_scan < n_scan ? (listed ? live_list[j_scan] : j_scan) : N;
+    // LISTED (live_list: k_live_rows / the network's backward / k_live_samples): the tiles are cut from the list of samples
+    // that carry a gradient -- as the slice-owner items, only while it is shorter than 3/4 N; tiles past its end write
+    // nothing and leave (k_tl_accumulate_p<.., true> skips their words).  A separate instantiation (see there).
+    uint32_t i = tile * kStBlock + threadIdx.x;
+    if constexpr (LISTED) {
+        const uint32_t n_listed = *live_n;
+        const bool listed = n_listed < N - (N >> 2);
+        const uint32_t n_scan = listed ? n_listed : N;
+        if (tile * kStBlock >= n_scan) return;  // (workgroup-uniform, before any barrier)
+        i = i < n_scan ? (listed ? live_list[i] : i) : N;
+    }
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     float2 d = make_float2(0.f, 0.f);
     float xs[3] = {0.f, 0.f, 0.f};
@@ -2686,12 +2689,16 @@ k_tl_scatter_p(NvoGridLevels g, uint32_t N, const float* __restrict__ x, const D
 
 // (second bound: FOUR waves per SIMD, i.e. two of these workgroups per CU -- with the fused optimiser step the allocator
 // otherwise takes 147 registers and only one workgroup fits: half the waves for a pass that is bound by waves x latency)
-template <uint32_t BIN>
+// LISTED: the scatter cut its tiles from a list of `*live_n` samples (k_tl_scatter_p<..., true>) and tiles past the list's end
+// wrote nothing -- their words are stale and count as empty.  A separate instantiation: the pass runs at its scalar-register
+// limit (24 v_writelane in the plain form), and the three values the bound needs, kept through the item loop, tripled
+// the spills and cost every launch 12 us (86 -> 99 us alone) -- whether a list was in use or not.
+template <uint32_t BIN, bool LISTED>
 __global__ void __launch_bounds__(kTlBlockP, 4)
 k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_items, const uint32_t* __restrict__ seg,
                   const uint32_t* __restrict__ segl1, const uint32_t* __restrict__ records, uint32_t n_tiles,
                   uint32_t tile_records, float* __restrict__ grad, uint32_t* __restrict__ nf_flag, NvoGridAdam adam,
-                  const uint32_t* __restrict__ live_n, uint32_t N, uint32_t* __restrict__ bin_done) {
+                  const uint32_t* __restrict__ live_n, uint32_t N) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds_raw);
     constexpr uint32_t kWaves = kTlBlockP / 64;
@@ -2720,11 +2727,9 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t it = blockIdx.x;
     if (it >= n_items) return;
-    // (live_n: the scatter cut its tiles from a list of that many samples -- k_tl_scatter_p's rule -- and tiles past the
-    // list's end wrote nothing: their words are stale and count as empty)
     uint32_t n_used = n_tiles;
-    if (live_n) {
-        const uint32_t n_listed = *live_n;
+    if constexpr (LISTED) {
+        const uint32_t n_listed = *live_n;  // (k_tl_scatter_p's rule for the list)
         if (n_listed < N - (N >> 2)) n_used = (n_listed + (tile_records >> 3) - 1u) / (tile_records >> 3);  // (tile = tile_records / 8 samples)
     }
     auto words_first = [&](const TlItem& I, uint32_t* l1w) -> uint32_t {
@@ -2732,7 +2737,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         const uint32_t per_wave = (n_span + kWaves - 1u) / kWaves;
         const uint32_t first = min(n_span, wib * per_wave);
         const uint32_t n_mine = min(per_wave, n_span - first);
-        const bool mine = lane < min(64u, n_mine) && I.t0 + first + lane < n_used;
+        const bool mine = lane < min(64u, n_mine) && (!LISTED || I.t0 + first + lane < n_used);
         const size_t o = (size_t)I.bin * n_tiles + I.t0 + first + lane;
         *l1w = mine ? segl1[o] : 0u;
         return mine ? seg[o] : 0u;
@@ -2767,7 +2772,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         {
             float a0 = __uint_as_float(l1w << 16), a1 = __uint_as_float(l1w & 0xFFFF0000u);
             for (uint32_t j0 = 64u; j0 < n_mine; j0 += 64u) {
-                const uint32_t w2 = (lane < min(64u, n_mine - j0) && tile_first + j0 + lane < n_used) ? segl1[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+                const uint32_t w2 = (lane < min(64u, n_mine - j0) && (!LISTED || tile_first + j0 + lane < n_used)) ? segl1[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
                 a0 += __uint_as_float(w2 << 16);
                 a1 += __uint_as_float(w2 & 0xFFFF0000u);
             }
@@ -2811,7 +2816,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         bool next_requested = false;
         for (uint32_t j0 = 0; j0 < n_mine; j0 += 64u) {
             const uint32_t n_here = min(64u, n_mine - j0);
-            if (j0 > 0u) segw = (lane < n_here && tile_first + j0 + lane < n_used) ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
+            if (j0 > 0u) segw = (lane < n_here && (!LISTED || tile_first + j0 + lane < n_used)) ? seg[(size_t)cur.bin * n_tiles + tile_first + j0 + lane] : 0u;
             const uint32_t cnt = lane < n_here ? (segw >> 16) & 0x7FFFu : 0u;
             bad |= lane < n_here && (segw >> 31) != 0u;
             const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
@@ -2865,7 +2870,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                 *f0 = (float)lo * inv0;
                 *f1 = (float)hi * inv1;
             };
-            if (cur.n_chunks == 1u && adam.params && cur.level >= adam.first_level) {
+            if (cur.n_chunks == 1u && adam.params && g.hashed[cur.level]) {
                 // the bin's gradient is complete right here: step its entries instead of storing it (skipped step: the
                 // gradient is not needed either)
                 if (!adam_skip) {
@@ -2896,7 +2901,6 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                                 float4 gv;
                                 split(w.x, &gv.x, &gv.y);
                                 split(w.y, &gv.z, &gv.w);
-                                if (!g.hashed[cur.level]) gr4[e] = gv;  // (a dense level as single items: the deterministic mode, whose tests read the gradient)
                                 nvo_adam_one(pv[u].x, mv[u].x, vv[u].x, gv.x, ah);
                                 nvo_adam_one(pv[u].y, mv[u].y, vv[u].y, gv.y, ah);
                                 nvo_adam_one(pv[u].z, mv[u].z, vv[u].z, gv.z, ah);
@@ -2933,75 +2937,6 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
                     if (f0 != 0.f) atomicAdd(gr + 2 * e, f0);
                     if (f1 != 0.f) atomicAdd(gr + 2 * e + 1, f1);
                 }
-                if (adam.params && cur.level >= adam.first_level && bin_done) {
-                    // The bin's chunks meet in the float atomics above; the LAST of them to check in finds the complete
-                    // sums in `gr` and steps the bin (the pattern of the optimiser launch's tail commit, adam.hip).  Every
-                    // chunk's adds are performed before its check-in, the reader takes the sums with agent-scope loads, and the
-                    // counter goes back to zero for the next launch.  The adds, the counter and the reader's loads are all
-                    // agent-scope accesses, performed where the XCDs meet: what the check-in has to wait for is only that
-                    // the workgroup's own adds have been acknowledged (vmcnt(0), then the barrier) -- NOT __threadfence(),
-                    // whose agent-scope release writes back this XCD's L2, full of the pass's own Adam output: with it on
-                    // each of the 208 chunk items the launch took 258 us instead of 149.
-                    __shared__ uint32_t s_last;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        const uint32_t prev = atomicAdd(&bin_done[cur.bin], 1u);
-                        s_last = prev + 1u == cur.n_chunks ? 1u : 0u;
-                        if (s_last) bin_done[cur.bin] = 0u;
-                    }
-                    __syncthreads();
-                    if (s_last != 0u && !adam_skip) {
-                        const size_t o4 = ((size_t)g.offset[cur.level] + (size_t)cur.slice * BIN) >> 1;  // in float4 units
-                        float4* __restrict__ p4 = reinterpret_cast<float4*>(adam.params) + o4;
-                        float4* __restrict__ m4 = reinterpret_cast<float4*>(adam.exp_avg) + o4;
-                        float4* __restrict__ v4 = reinterpret_cast<float4*>(adam.exp_avg_sq) + o4;
-                        uint2* __restrict__ h4 = reinterpret_cast<uint2*>(adam.params_half) + o4;
-                        float4* __restrict__ e4 = adam.ema ? reinterpret_cast<float4*>(adam.ema) + o4 : nullptr;
-                        uint2* __restrict__ eh4 = adam.ema_half ? reinterpret_cast<uint2*>(adam.ema_half) + o4 : nullptr;
-                        const unsigned long long* g64 = reinterpret_cast<const unsigned long long*>(gr);
-                        constexpr uint32_t kU = 2;  // (two steps' loads in flight: this branch must not set the kernel's register count)
-                        for (uint32_t e0 = threadIdx.x; e0 < n2; e0 += kU * kTlBlockP) {
-                            float4 pv[kU], mv[kU], vv[kU];
-                            unsigned long long ga[kU], gb[kU];
-#pragma unroll
-                            for (uint32_t u = 0; u < kU; ++u) {
-                                const uint32_t e = min(e0 + u * kTlBlockP, n2 - 1u);
-                                pv[u] = p4[e];
-                                mv[u] = m4[e];
-                                vv[u] = v4[e];
-                                ga[u] = __hip_atomic_load(g64 + 2 * (size_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                gb[u] = __hip_atomic_load(g64 + 2 * (size_t)e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-#pragma unroll
-                            for (uint32_t u = 0; u < kU; ++u) {
-                                const uint32_t e = e0 + u * kTlBlockP;
-                                if (e < n2) {
-                                    const float gx = __uint_as_float((uint32_t)ga[u]), gy = __uint_as_float((uint32_t)(ga[u] >> 32));
-                                    const float gz = __uint_as_float((uint32_t)gb[u]), gw = __uint_as_float((uint32_t)(gb[u] >> 32));
-                                    nvo_adam_one(pv[u].x, mv[u].x, vv[u].x, gx, ah);
-                                    nvo_adam_one(pv[u].y, mv[u].y, vv[u].y, gy, ah);
-                                    nvo_adam_one(pv[u].z, mv[u].z, vv[u].z, gz, ah);
-                                    nvo_adam_one(pv[u].w, mv[u].w, vv[u].w, gw, ah);
-                                    p4[e] = pv[u];
-                                    m4[e] = mv[u];
-                                    v4[e] = vv[u];
-                                    h4[e] = make_uint2(nvo_cvt16x2(pv[u].x, pv[u].y, false), nvo_cvt16x2(pv[u].z, pv[u].w, false));
-                                    if (e4) {
-                                        float4 ev = e4[e];
-                                        ev.x = (ev.x * ema_keep + pv[u].x * ema_take) * ema_inv;
-                                        ev.y = (ev.y * ema_keep + pv[u].y * ema_take) * ema_inv;
-                                        ev.z = (ev.z * ema_keep + pv[u].z * ema_take) * ema_inv;
-                                        ev.w = (ev.w * ema_keep + pv[u].w * ema_take) * ema_inv;
-                                        e4[e] = ev;
-                                        if (eh4) eh4[e] = make_uint2(nvo_cvt16x2(ev.x, ev.y, false), nvo_cvt16x2(ev.z, ev.w, false));
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
             }
         }
         GP_CLK(gp4);
@@ -3014,7 +2949,7 @@ k_tl_accumulate_p(NvoGridLevels g, const uint4* __restrict__ items, uint32_t n_i
         }
 #endif
         if (__ballot(bad) != 0ull && lane == 0u) {  // poisoned chunk
-            if (!(adam.params && cur.level >= adam.first_level)) atomicAdd(gr, __builtin_nanf(""));  // (fused: no gradient is kept)
+            if (!(adam.params && g.hashed[cur.level])) atomicAdd(gr, __builtin_nanf(""));  // (fused: no gradient is kept)
             if (nf_flag) atomicOr(nf_flag, 1u);
         }
         if (!has_next) break;
@@ -3660,6 +3595,7 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
             }
             size_t rounds = 0;
             for (const auto& m : mine) rounds = m.size() > rounds ? m.size() : rounds;
+            NVO_REQUIRE(rounds <= 32, "grid_bwd_stream: %zu items per accumulate workgroup (k_tl_accumulate_p keeps 32 pending bins)", rounds);
             std::vector<uint32_t> laid(4 * rounds * slots, 0u);  // all-zero header = padding (n_chunks == 0)
             for (uint32_t w = 0; w < slots; ++w)
                 for (size_t r = 0; r < mine[w].size(); ++r)
@@ -3670,8 +3606,6 @@ int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st) {
         st->n_tl_items = (uint32_t)(items.size() / 4);
         NVO_CHECK_HIP(hipMalloc((void**)&st->d_tl_items, 4 * items.size()));
         NVO_CHECK_HIP(hipMemcpy(st->d_tl_items, items.data(), 4 * items.size(), hipMemcpyHostToDevice));
-        NVO_CHECK_HIP(hipMalloc((void**)&st->d_bin_done, 4 * (size_t)nb));
-        NVO_CHECK_HIP(hipMemset(st->d_bin_done, 0, 4 * (size_t)nb));
         NVO_CHECK_HIP(hipMemcpy(st->d_bin_chunks, chunks.data(), 4 * nb, hipMemcpyHostToDevice));
     }
     st->created = true;
@@ -3698,17 +3632,10 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     nvo_scratch_destroy(&st->work);
     if (st->d_tl_items) (void)hipFree(st->d_tl_items);
     st->d_tl_items = nullptr;
-    if (st->d_bin_done) (void)hipFree(st->d_bin_done);
-    st->d_bin_done = nullptr;
     st->n_tl_items = 0;
     st->d_meta = nullptr;
     st->n_bins = 0;
     st->created = false;
-    if (st->ev_pre_acc) {
-        (void)hipEventDestroy(st->ev_pre_acc);
-        st->ev_pre_acc = nullptr;
-        st->pre_acc_recorded = false;
-    }
     if (st->aux) {
         (void)hipStreamSynchronize(st->aux);
         (void)hipStreamDestroy(st->aux);
@@ -3720,27 +3647,23 @@ void nvo_grid_stream_destroy(NvoGridStream* st) {
     nvo_grid_slices_destroy(&st->owner);
 }
 
-void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n, uint32_t* first_level) {
-    if (first_level) *first_level = 0xFFFFFFFFu;
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n) {
     *first = 0;
     *n = 0;
     if (!st->created) return;
-    // the streamed levels; they form the tail of the table.  A hashed level's bin is one accumulate item, which steps it
-    // from its LDS sums; a streamed DENSE level sees clustered samples and its bins are split into tile ranges that meet
-    // in float atomics -- the LAST of a bin's chunks to check in steps it from the summed gradient (k_tl_accumulate_p,
-    // d_bin_done).  (Single items for the dense bins too -- option grid_stream_dense_chunks = 1 -- put most of the level's
-    // records on a few workgroups in a run's early iterations, few keyframes: +55 us per step at iteration 500 of the
-    // mapping run, tools/probes/loop_early_ab.sh.)
-    auto single = [&](uint32_t l) { return ((st->streamed_mask >> l) & 1u) != 0u && (g.hashed[l] || st->d_bin_done != nullptr); };
+    // the streamed hashed levels: one accumulate item per bin (nvo_grid_stream_create); they form the tail of the table.
+    // (A streamed DENSE level sees clustered samples and its bins are split into tile ranges that meet in float atomics.
+    // Round 6 tried both ways of stepping it inside the pass as well -- single items per bin, and the last chunk to check
+    // in stepping the bin from the summed gradient -- so that the optimiser launch of the other parameters could run
+    // beside the pass: EXPERIMENTS.md 10.9, both measured slower overall.)
     uint32_t lo = g.n_levels;
     for (uint32_t l = 0; l < g.n_levels; ++l)
-        if (single(l) && l < lo) lo = l;
+        if (((st->streamed_mask >> l) & 1u) && g.hashed[l] && l < lo) lo = l;
     if (lo == g.n_levels) return;
     for (uint32_t l = lo; l < g.n_levels; ++l)
-        if (!single(l)) return;  // (not a contiguous tail: leave it to the optimiser)
+        if (!(((st->streamed_mask >> l) & 1u) && g.hashed[l])) return;  // (not a contiguous tail: leave it to the optimiser)
     *first = g.offset[lo];
     *n = (uint64_t)g.offset[g.n_levels] - g.offset[lo];
-    if (first_level) *first_level = lo;
 }
 
 int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStream_t stream, uint32_t N,
@@ -3812,37 +3735,38 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     const size_t lds_p = tile_records * 12 + (sizeof(unsigned long long) + sizeof(uint32_t)) * st->max_slices;
     const size_t lds_acc_p = sizeof(unsigned long long) * st->bin_entries;
     const uint32_t acc_grid = st->n_tl_slots ? st->n_tl_slots : (st->n_tl_items < 2 * n_cus ? st->n_tl_items : 2 * n_cus);
-#define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_, TILE_)                                                               \
+#define NVO_LAUNCH_TLP_L(SOA_, T_, BIN_, TILE_, LISTED_)                                                      \
     do {                                                                                                      \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<TILE_, SOA_, T_, BIN_>,             \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_scatter_p<TILE_, SOA_, T_, BIN_, LISTED_>,    \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TILE_ * 96 + 12 * 4096))); \
-            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p<BIN_>,                           \
+            NVO_CHECK_HIP(hipFuncSetAttribute((const void*)k_tl_accumulate_p<BIN_, LISTED_>,                  \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * BIN_)));  \
             attr_set = true;                                                                                  \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_scatter[L%u]", g.n_levels);                                              \
-            NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
+            NVO_LAUNCH((k_tl_scatter_p<TILE_, SOA_, T_, BIN_, LISTED_>), grid_tl, dim3(TILE_), lds_p, stream, g, N, x, (const T_*)dy, \
                        st->d_levels, st->d_bin_first, seg, segl1, reinterpret_cast<uint32_t*>(records_tl),     \
                        st->owner.nf_flag, live_list, live_n);                                                 \
-        }                                                                                                     \
-        if (st->mark_pre_acc) { /* nvo_wait_fork_point: what follows only the verdict may start here */       \
-            if (!st->ev_pre_acc) NVO_CHECK_HIP(hipEventCreateWithFlags(&st->ev_pre_acc, hipEventDisableTiming)); \
-            NVO_CHECK_HIP(hipEventRecord(st->ev_pre_acc, stream));                                            \
-            st->pre_acc_recorded = true;                                                                      \
         }                                                                                                     \
         {                                                                                                     \
             NVO_PROF_SUB(stream, "tl_accumulate[L%u]", g.n_levels);                                           \
             if (!st->external_zero)                                                                           \
                 NVO_LAUNCH(k_st_zero_p<BIN_>, dim3(st->n_bins), dim3(256), 0, stream, g, st->d_bin_level, st->d_bin_slice, \
                            st->d_bin_chunks, grad);                                                           \
-            NVO_LAUNCH(k_tl_accumulate_p<BIN_>, dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g,        \
+            NVO_LAUNCH((k_tl_accumulate_p<BIN_, LISTED_>), dim3(acc_grid), dim3(kTlBlockP), lds_acc_p, stream, g, \
                        (const uint4*)st->d_tl_items, st->n_tl_items, seg, segl1,                              \
                        reinterpret_cast<const uint32_t*>(records_tl), n_tiles,                                \
-                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam, live_n, N, st->d_bin_done); \
+                       (uint32_t)tile_records, grad, st->owner.nf_flag, st->adam, live_n, N);                 \
         }                                                                                                     \
+    } while (0)
+/* (the listed forms are separate instantiations: see k_tl_accumulate_p) */                                   
+#define NVO_LAUNCH_TLP_B(SOA_, T_, BIN_, TILE_)                                                               \
+    do {                                                                                                      \
+        if (live_list) NVO_LAUNCH_TLP_L(SOA_, T_, BIN_, TILE_, true);                                         \
+        else NVO_LAUNCH_TLP_L(SOA_, T_, BIN_, TILE_, false);                                                  \
     } while (0)
 #define NVO_LAUNCH_TLP(SOA_, T_)                                                           \
     do {                                                                                   \
@@ -3853,6 +3777,7 @@ int nvo_grid_bwd_stream_launch(const NvoGridLevels& g, NvoGridStream* st, hipStr
     if (soa) NVO_DY_DISPATCH(NVO_LAUNCH_TLP, true); else NVO_DY_DISPATCH(NVO_LAUNCH_TLP, false);
 #undef NVO_LAUNCH_TLP
 #undef NVO_LAUNCH_TLP_B
+#undef NVO_LAUNCH_TLP_L
     NVO_CHECK_LAUNCH();
     if (fork) NVO_CHECK_HIP(hipStreamWaitEvent(stream, st->ev_join, 0));  // join
     return NVO_OK;

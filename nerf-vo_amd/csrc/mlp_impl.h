@@ -4,6 +4,7 @@
 // Everything the network streams -- weights, inputs from the encoding, hidden activations, outputs and all of
 // their gradients -- is T in memory; accumulation is fp32 in both.  See mlp.hip for the design notes.
 #pragma once
+#include <type_traits>
 #include "nvo_kernels.h"
 
 #include <stdlib.h>
@@ -653,12 +654,12 @@ __device__ unsigned long long NVO_MLP_NAME(nvo_mlp_phase_cycles)[16];
 // {dZ_L | H_l | dZ_l | X} per chain wave (8 of them) + the row-major copies of the matrices, which stay
 constexpr int kLiveListCap = 2048;  // (roles) entries of a workgroup's live-tile list (16-bit codes)
 constexpr int kLiveRowCap = 8192;   // (roles, level-major input) sample ids a workgroup collects for Args::live_rows
-constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles, bool rows = false) {
+constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bool roles, bool rows = false, bool lists = false) {
     const int maxw = width > in_pad ? (width > out_pad ? width : out_pad) : (in_pad > out_pad ? in_pad : out_pad);
     const int stage = width * (in_pad + 4) + (n_hidden - 1) * width * (width + 4) + out_pad * (width + 4);
     const int set = 16 * (out_pad + 4) + 2 * n_hidden * 16 * (width + 4) + 16 * (in_pad + 4);
     // (+ 32 hand-over / list words: full[8], free[8], live and dead counts, 12 per-wave counts; + the live-tile list)
-    if (roles) return 2 * kWavesPerBlock * set + stage + 64 + kLiveListCap + (rows ? 2 * kLiveRowCap : 0);
+    if (roles) return 2 * kWavesPerBlock * set + stage + 64 + (lists ? kLiveListCap + (rows ? 2 * kLiveRowCap : 0) : 0);
     const int tiles = kWavesPerBlock * 2 * 16 * (maxw + 4);
     return tiles > stage ? tiles : stage;
 }
@@ -678,9 +679,13 @@ constexpr int bwd_lds_halfs(int in_pad, int width, int n_hidden, int out_pad, bo
 // Hand-over: ONE tile set {dZ_L | H_l | dZ_l | X} per chain wave in LDS, written as the tiles are produced behind
 // barrier B (after the recomputation: the dW waves are done with the previous contents) and released by barrier A at
 // the end of the step; the dW waves read while the chain waves load and recompute the next tile.
-template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP, bool ROLES = false>
+// LISTS (roles only): the live-tile list of a trained field, see "LIVE-TILE LIST" below -- a separate instantiation, picked by
+// the launcher when Args::tile_live is given: with the list code compiled in, the plain tile loop spilled scalar registers
+// and lost 10-15 % on every launch (colour head 37.9 -> 44.4 us, base network 19.8 -> 22.3 us), list or no list.
+template <int IN_PAD, int WIDTH, int N_HIDDEN, int OUT_PAD, int IO, bool RELU, bool COMPACT, bool RECOMP, bool ROLES = false, bool LISTS = false>
 __global__ void __launch_bounds__(ROLES ? 3 * kMlpBlock : kMlpBlock)
 NVO_MLP_NAME(k_mlp_bwd)(Args a) {
+    static_assert(!LISTS || ROLES, "lists: the role-split form only");
     static_assert(!RECOMP || RELU, "hidden recomputation: ReLU networks");
     static_assert(!ROLES || (RECOMP && !COMPACT), "roles: recomputing, non-compact networks");
     constexpr int kChainWaves = ROLES ? 2 * kWavesPerBlock : kWavesPerBlock;
@@ -697,10 +702,10 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     constexpr int kHTile = 16 * (WIDTH + 4), kOffH = 16 * (OUT_PAD + 4), kOffDZ = kOffH + N_HIDDEN * kHTile,
                   kOffX = kOffDZ + N_HIDDEN * kHTile, kSetHalfs = kOffX + 16 * (IN_PAD + 4);
     constexpr int kTilesHalfs = ROLES ? kChainWaves * kSetHalfs : kWavesPerBlock * 2 * kTileHalfs;
-    constexpr bool kRowsIo = ROLES && IO == NVO_IO_HALF2_SOA;  // (the kernels that may list live rows: Args::live_rows)
-    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 + kLiveListCap + (kRowsIo ? 2 * kLiveRowCap : 0)
+    constexpr bool kRowsIo = LISTS && IO == NVO_IO_HALF2_SOA;  // (the kernels that may list live rows: Args::live_rows)
+    constexpr int kLdsHalfs = ROLES ? kTilesHalfs + kStageHalfs + 64 + (LISTS ? kLiveListCap + (kRowsIo ? 2 * kLiveRowCap : 0) : 0)
                                     : (kTilesHalfs > kStageHalfs ? kTilesHalfs : kStageHalfs);
-    static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES, kRowsIo), "launcher and kernel disagree on the LDS size");
+    static_assert(kLdsHalfs == bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, ROLES, kRowsIo, LISTS), "launcher and kernel disagree on the LDS size");
     __shared__ __attribute__((aligned(16))) T lds_static[ROLES ? 8 : kLdsHalfs];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];  // (ROLES: 112 KB, opted in by the launcher)
     T* const lds = ROLES ? reinterpret_cast<T*>(lds_dyn) : lds_static;
@@ -743,7 +748,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     // (roles) the tiles this workgroup owns: code = 8 step + chain wave <-> tile blockIdx.x * 8 + (code & 7) + (code >> 3) * n_waves
     const uint32_t n_iter_all = ROLES ? (n_tiles + n_waves - 1u) / n_waves : 0u;
     const uint32_t n_own = n_iter_all * kChainWaves;
-    constexpr bool kListIo = ROLES && (IO == NVO_IO_HALF2_SOA || (IO == NVO_IO_NERFACTO_COLOR && IN_PAD == 64));
+    constexpr bool kListIo = LISTS && (IO == NVO_IO_HALF2_SOA || (IO == NVO_IO_NERFACTO_COLOR && IN_PAD == 64));
     // (kernel-uniform; decided behind the prologue's round trip: Args::tile_live_count is requested with the matrices)
     const bool list_pre = kListIo && a.tile_live != nullptr && n_own <= (uint32_t)kLiveListCap;
     bool use_list = list_pre;
@@ -1073,6 +1078,18 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     }
     uint32_t it = 0u;  // (roles: step counter of the chain role)
     T* const set = lds + (size_t)((ROLES ? wib : 0) * kSetHalfs);  // (roles) this chain wave's tile set
+    // The tile loop, instantiated TWICE for the kernels that can walk a live-tile list: the list form carries the list state
+    // (its length, the tile codes in LDS, the row buffer of Args::live_rows) through the loop, and with it in ONE loop the
+    // plain form -- every tile live, the untrained field, every step of the headline measurement -- spilled scalar registers
+    // (35 v_writelane / 53 v_readlane in the colour head: 37.9 -> 44.4 us; base network 19.8 -> 22.3 us).
+    auto step_tile_c = [&](auto list_c, uint32_t st_) -> uint32_t {
+        if constexpr (decltype(list_c)::value)
+            return own_tile((uint32_t)__builtin_amdgcn_readfirstlane((int)live_list[min(st_ * kChainWaves + (uint32_t)wib, n_live - 1u)]));
+        else
+            return min(wave + st_ * n_waves, n_tiles - 1u);
+    };
+    auto chain_loop = [&](auto list_c) __attribute__((always_inline)) {
+    constexpr bool kList = decltype(list_c)::value;
     for (uint32_t st = 0; st < my_steps; ++st) {
         const uint32_t tile = t_cur;
         const uint32_t row = tile * 16 + m;
@@ -1080,11 +1097,11 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
         load_tile(t_nxt, nxt, cam_nxt);
         t_cur = t_nxt;
-        t_nxt = step_tile(st + 2u);
+        t_nxt = step_tile_c(list_c, st + 2u);
         cam_nxt = load_cam(t_nxt);
         NVO_PH(0);
         if constexpr (kRowsIo) {
-            if (a.live_rows && use_list) {  // (kernel-uniform) list this tile's samples with a non-zero dL/doutput row
+            if (kList && a.live_rows) {  // (kernel-uniform) list this tile's samples with a non-zero dL/doutput row
                 bool nz = false;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nz = nz || (float)cur.dzl[0][j] != 0.f;  // (NaN != 0: non-finite rows stay listed)
@@ -1398,6 +1415,13 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         cur = nxt;
         NVO_PH(8);
     }
+    };
+    if constexpr (kListIo) {
+        if (use_list) chain_loop(std::true_type{});
+        else chain_loop(std::false_type{});
+    } else {
+        chain_loop(std::false_type{});
+    }
     if constexpr (ROLES && !kHandFlags) {
         if (!is_dw)
             for (; it < n_iter; ++it) {  // (chain waves that ran out of tiles keep the workgroup's barrier count)
@@ -1568,20 +1592,14 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
                         // base network 30.3 -> 22.9 us, colour head 49.5 -> 41.4 us
                         static const bool roles = [] { const char* e = getenv("NVO_MLP_ROLES"); return !e || atoi(e) != 0; }();
                         if (roles) {
-                            constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true, IO == NVO_IO_HALF2_SOA);
-                            static bool attr_set = false;  // (> 64 KiB of dynamic LDS needs an explicit opt-in)
-                            if (!attr_set) {
-                                NVO_CHECK_HIP(hipFuncSetAttribute(
-                                    (const void*)NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytes));
-                                attr_set = true;
-                            }
                             // (A/B and tests: NVO_MLP_SKIP_DEAD=0 walks every tile; read per launch -- a graph keeps what
                             // its capture saw -- so that one process can compare the two)
                             const char* const e_dead = getenv("NVO_MLP_SKIP_DEAD");
                             Args ar = a;
                             if (e_dead && atoi(e_dead) == 0) ar.tile_live = nullptr;
-                            if (getenv("NVO_MLP_NOZERO_EXPERIMENT")) ar.tile_live_bits |= 0x100u;  // (timing experiment: WRONG results)
+                            constexpr bool kCanList = IO == NVO_IO_HALF2_SOA || (IO == NVO_IO_NERFACTO_COLOR && IN_PAD == 64);
+                            if constexpr (!kCanList) ar.tile_live = nullptr;
+                            if (!ar.tile_live) ar.live_rows = nullptr;  // (the plain form lists nothing: the caller's fallback is k_live_rows)
                             if constexpr (IO == NVO_IO_HALF2_SOA) {
                                 // (the caller asked nvo_mlp_bwd_lists_rows first; a workgroup's tiles must fit its row buffer)
                                 const uint32_t n_tiles_l = a.batch >> 4;
@@ -1593,7 +1611,32 @@ int launch_bwd_io_kernel(const Args& a, hipStream_t stream, uint32_t blocks) {
                             } else {
                                 ar.live_rows = nullptr;
                             }
-                            NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true>),
+                            // (> 64 KiB of dynamic LDS needs an explicit opt-in, per instantiation)
+                            if constexpr (kCanList) {
+                                if (ar.tile_live) {
+                                    constexpr size_t kBytesL = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true, IO == NVO_IO_HALF2_SOA, true);
+                                    static bool attr_set_l = false;
+                                    if (!attr_set_l) {
+                                        NVO_CHECK_HIP(hipFuncSetAttribute(
+                                            (const void*)NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytesL));
+                                        attr_set_l = true;
+                                    }
+                                    NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true, true>),
+                                               dim3(blocks), dim3(3 * kMlpBlock), kBytesL, stream, ar);
+                                    NVO_CHECK_LAUNCH();
+                                    return NVO_OK;
+                                }
+                            }
+                            constexpr size_t kBytes = sizeof(T) * (size_t)bwd_lds_halfs(IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, true);
+                            static bool attr_set = false;
+                            if (!attr_set) {
+                                NVO_CHECK_HIP(hipFuncSetAttribute(
+                                    (const void*)NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytes));
+                                attr_set = true;
+                            }
+                            NVO_LAUNCH((NVO_MLP_NAME(k_mlp_bwd)<IN_PAD, WIDTH, N_HIDDEN, OUT_PAD, IO, true, false, true, true, false>),
                                        dim3(blocks), dim3(3 * kMlpBlock), kBytes, stream, ar);
                             NVO_CHECK_LAUNCH();
                             return NVO_OK;

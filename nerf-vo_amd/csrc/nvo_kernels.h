@@ -110,9 +110,6 @@ struct NvoGridAdam {
     void* ema_half = nullptr;
     float ema_decay = 0.f;
     const uint32_t* ema_step_dev = nullptr;
-    // (set by the module: nvo_grid_stream_adam_range) the first level of the range the accumulate pass steps; every bin
-    // of that level and of those behind it is ONE accumulate item
-    uint32_t first_level = 0xFFFFFFFFu;
 };
 
 struct NvoGridStream {
@@ -143,25 +140,17 @@ struct NvoGridStream {
     uint32_t bin_entries = 4096;      // (set by create)
     uint32_t dense_chunks = 8;        // tile-range chunks per bin of a streamed DENSE level (clustered samples)
     uint32_t* d_tl_items = nullptr;   // uint4 {bin, chunk | n_chunks << 16, streamed-level index | level << 8, slice}
-    uint32_t* d_bin_done = nullptr;   // [n_bins] check-in counters of the chunked bins (the LAST chunk steps the bin; self-resetting)
     uint32_t n_tl_items = 0;
     uint32_t n_tl_slots = 0;          // (packed form) persistent workgroups the balanced item list was laid out for; 0 = dealt
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // option "bwd_mark_fork_point": an event recorded in front of the accumulate pass.  With the optimiser step armed
-    // (adam.params) every producer of the step's overflow verdict precedes that pass, so whatever else only waits for the
-    // verdict -- the optimiser launch of the other parameters -- may run BESIDE it on another stream (nvo_wait_fork_point)
-    bool mark_pre_acc = false;
-    mutable hipEvent_t ev_pre_acc = nullptr;
-    mutable bool pre_acc_recorded = false;
     bool external_zero = false;  // see NvoGridSlices::external_zero
     bool deterministic = false;  // (set before create) one accumulate item per bin on dense levels too; owner: see there
     NvoGridAdam adam;            // optimiser step inside the accumulate pass, see NvoGridAdam
 };
 // entries [first, first + n) of the table (in ENTRIES: two parameters each) whose Adam step NvoGridStream::adam takes over:
 // the streamed hashed levels (one accumulate item per bin); n = 0 when the configuration has none
-void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n,
-                                uint32_t* first_level = nullptr);
+void nvo_grid_stream_adam_range(const NvoGridLevels& g, const NvoGridStream* st, uint64_t* first, uint64_t* n);
 // false: this configuration zeroes data-dependent ranges (globally sorted layout) and cannot hand the zeroing over
 bool nvo_grid_stream_zero_ranges(const NvoGridLevels& g, const NvoGridStream* st, float* grad, NvoZeroRanges* out);
 int nvo_grid_stream_create(const NvoGridLevels& g, NvoGridStream* st);

@@ -80,7 +80,15 @@ class EngineConfig:
     geo_feat_dim: int = 15
     appearance_embed_dim: int = 32
     density_bias: float = -1.0            # sigma = trunc_exp(h0 - 1)
-    skip_dead_tiles: bool = True          # the MLP backwards of the main field walk only tiles that carry a gradient
+    # The backward of a TRAINED field: one sample of a ray's 48 carries the weight, two of its three 16-sample tiles carry no
+    # gradient at all.  "sparse" steps have the render / loss kernel mark the tiles (nvo_main_loss_args::tile_live), the two
+    # MLP backwards of the main field walk only the live ones and the hash grid's backward only the listed live rows
+    # (-8 % per step on the trained field of the mapping run).  The list-capable kernels are separate instantiations -- with
+    # the list code compiled in, the plain forms lost 10-15 % to scalar-register spills -- so WHICH step graph runs is
+    # decided on the host: "auto" runs a sparse step every 64th step, reads the live-tile count it leaves behind
+    # (asynchronously) and switches all steps to the sparse graphs while fewer than 60 % of the tiles are live (back above
+    # 75 %); "on" / "off" pin it.  Either kind of step is correct on any field.
+    sparse_backward: str = "auto"
     histogram_padding: float = 0.01
     proposal_weights_anneal_slope: float = 10.0
     proposal_weights_anneal_max_num_iters: int = 1000
@@ -141,12 +149,6 @@ class EngineConfig:
     expect_normals: bool = False
     # pose optimisation: the main grid's parameter scatter runs on a second stream beside the pose-gradient chain
     overlap_pose_backward: bool = True
-    # one-graph step with the main grid's optimiser step fused into its backward (fuse_grid_adam): the optimiser launch of
-    # the OTHER parameters (and the fold of the weight-gradient copies in front of it) runs beside the accumulate pass of that
-    # backward instead of behind it -- by then every producer of the step's overflow verdict has run (nvo_wait_fork_point).
-    # The accumulate pass is a stream of the whole table through Adam (HBM-bound, ~60-85 us); the two small launches
-    # are ~15 us of dependent dispatch that hide in it.
-    overlap_optimizer_tail: bool = True
     # one-graph step (single GPU): the optimiser's commit (step counters, bias corrections, loss scale) is not a node of
     # the graph but rides in the eager launch behind the replay that also writes the NEXT step's scalars
     commit_behind_replay: bool = True
@@ -237,6 +239,14 @@ class NerfactoEngine:
             raise ValueError(f"mlp_dtype must be 'f16' or 'bf16' (got {cfg.mlp_dtype!r})")
         self.bf16 = cfg.mlp_dtype == "bf16"
         self.act_dtype = torch.bfloat16 if self.bf16 else torch.float16
+        import os
+        if os.environ.get("NVO_SPARSE_BACKWARD"):  # (A/B switch for measurements: auto | on | off)
+            cfg.sparse_backward = os.environ["NVO_SPARSE_BACKWARD"]
+        assert cfg.sparse_backward in ("auto", "on", "off"), cfg.sparse_backward
+        if cfg.sparse_backward == "auto" and world_size > 1:
+            # (the probe's answer arrives when the copy has landed -- a host-side race the ranks would each decide for
+            # themselves; data-parallel ranks run the same kind of step: pin it explicitly to get the sparse one)
+            cfg.sparse_backward = "off"
 
         # ---- native modules (tcnn NetworkWithInputEncoding: params = [mlp | grid])
         self.prop_nets = [
@@ -565,7 +575,7 @@ class NerfactoEngine:
         if training:
             # colour head: no stored hidden activations (recomputed in the backward)
             ws["drgb"] = torch.empty(Nm, 16, **f16)
-            if self.levels[-1] % 16 == 0 and self.cfg.skip_dead_tiles:
+            if self.levels[-1] % 16 == 0 and self.cfg.sparse_backward != "off":
                 # one byte per 16-sample tile of the main level, written by the render / loss kernel: which tiles carry
                 # any gradient at all.  The two MLP backwards behind it walk only those (two of three tiles of a trained
                 # field carry none: nvo_main_loss_args::tile_live)
@@ -704,8 +714,8 @@ class NerfactoEngine:
             n_dw_replicas=self._dw_replica_plan()["color"][1] if (training and self._dw_replica_plan()) else 0,
             det_scratch_bytes=ws["color_det"].numel() if (training and "color_det" in ws) else 0,
             n_cameras=self.cfg.num_images,
-            tile_live=ws["tile_live"].data_ptr() if (training and "tile_live" in ws) else None,
-            tile_live_count=(self.losses.data_ptr() + 7 * 4) if (training and "tile_live" in ws) else None)
+            tile_live=ws["tile_live"].data_ptr() if (training and ws.get("sparse")) else None,
+            tile_live_count=(self.losses.data_ptr() + 7 * 4) if (training and ws.get("sparse")) else None)
 
     def _main_loss_args(self, ws, training: bool, has_depth: bool, normals: bool = False,
                         has_gt_normal: bool = False):
@@ -734,7 +744,7 @@ class NerfactoEngine:
             out_normals=ws["out_normals"].data_ptr() if normals else None, act_bf16=int(self.bf16),
             loss_scale_dev=self._loss_scale_ptr() if training else None,
             nonfinite_flag=self._flag_ptr("fields") if training else None,
-            tile_live=ws["tile_live"].data_ptr() if (training and "tile_live" in ws) else None)
+            tile_live=ws["tile_live"].data_ptr() if (training and ws.get("sparse")) else None)
 
     # ------------------------------------------------------------------------------------------
     # schedules (nerfacto callbacks)
@@ -804,12 +814,14 @@ class NerfactoEngine:
 
     def forward_backward(self, ws, jitters, has_depth: bool = True, update_proposals: bool | None = None,
                          anneal: float | None = None, anneal_dev: int | None = None, has_normals: bool = False,
-                         skip_head: bool = False, proposal_values: bool | None = None):
+                         skip_head: bool = False, proposal_values: bool | None = None, sparse: bool | None = None):
         """Forward + losses + backward for the rays loaded into ``ws``.  Fills self.grads (scaled by
-        loss_scale) and self.losses; does NOT touch the parameters."""
+        loss_scale) and self.losses; does NOT touch the parameters.  ``sparse``: EngineConfig.sparse_backward's kind of
+        step (None: what the configuration / the last probe says)."""
         cfg = self.cfg
         stream = _stream(self.device)
         step = self.step
+        ws["sparse"] = bool(self._sparse_default() if sparse is None else sparse) and "tile_live" in ws
         self._use_producer_flags(self.world_size == 1 and getattr(self, "_reducer", None) is None)
         if anneal is None:
             anneal = self.anneal_at(step)
@@ -863,7 +875,7 @@ class NerfactoEngine:
 
         def main_backward(st):
             _call("nvo_nerfacto_color_bwd", st, C.byref(ca))
-            if "tile_live" in ws:
+            if ws.get("sparse"):
                 # the base network's dL/doutput = {dpre | the colour head's dX}: zero wherever neither bit is set.  Only for
                 # THIS backward (the analytic-normal pass runs the same module on another dL/doutput)
                 self.base_net.set_option("bwd_tile_live_ptr", ws["tile_live"].data_ptr())
@@ -872,7 +884,7 @@ class NerfactoEngine:
             try:
                 return main_backward_base(st)
             finally:
-                if "tile_live" in ws:
+                if ws.get("sparse"):
                     self.base_net.set_option("bwd_tile_live_ptr", 0)
 
         def main_backward_base(st):
@@ -903,36 +915,7 @@ class NerfactoEngine:
             self._proposal_backward(ws, has_depth, pose, stream)
         if proposal_values and not update_proposals:
             self._proposal_backward(ws, has_depth, False, stream, values_only=True)
-        # EngineConfig.overlap_optimizer_tail: what is left of the step -- the fold of the dW copies, the optimiser launch of
-        # the parameters the main grid's backward has not stepped itself -- waits for the FORK POINT in front of that
-        # backward's accumulate pass instead of its end (armed around the capture of the one-graph step only)
-        self._tail_join = None
         cur = torch.cuda.current_stream(self.device)
-        if getattr(self, "_fork_point_armed", False) and not pose and scatter_stream is None and \
-                getattr(self, "_fused_adam_range", None) is not None:
-            if swap:
-                # the main-field backward runs on the side stream: this (origin) stream, behind the proposal chain, waits for
-                # the fork point only; the side stream itself is joined behind the optimiser launch (optimizer_step)
-                _call("nvo_wait_fork_point", self.base_net.handle, stream)
-                self._fold_dw_replicas(stream)
-                self._tail_join = ("origin", list(side))
-                return update_proposals
-            if side is None and int(__import__("os").environ.get("NVO_OVERLAP_TAIL_PLAIN", "0")):
-                # (measurement only, default OFF: a step without a side stream.  The accumulate pass alone fills every CU
-                # -- two 512-thread workgroups each -- and the two small launches of a forked tail stream get their turn
-                # when its workgroups retire: 4 us of 13, less than the extra launch of the late range below costs.)
-                # everything ran on this stream: a tail stream forks at the fork point, this stream goes on into the
-                # accumulate pass; joined behind the optimiser launch
-                if getattr(self, "_tail_stream", None) is None:
-                    # (default priority: a graph captured across a priority stream crashed hipGraphLaunch -- hip::Graph::
-                    # UpdateStreams -- on ROCm 7.2)
-                    self._tail_stream = torch.cuda.Stream(device=self.device)
-                tail = self._tail_stream
-                _call("nvo_wait_fork_point", self.base_net.handle, C.c_void_p(tail.cuda_stream))
-                with torch.cuda.stream(tail):
-                    self._fold_dw_replicas(_stream(self.device))
-                self._tail_join = ("tail", [tail])
-                return update_proposals
         if side is not None:
             for st in side:
                 cur.wait_stream(st)  # join
@@ -942,6 +925,44 @@ class NerfactoEngine:
             cur.wait_stream(scatter_stream)  # join
         self._fold_dw_replicas(stream)
         return update_proposals
+
+    # ---- EngineConfig.sparse_backward -----------------------------------------------------------------------------------
+    _SPARSE_PROBE_EVERY = 64
+
+    def _sparse_default(self) -> bool:
+        mode = self.cfg.sparse_backward
+        return mode == "on" or (mode == "auto" and bool(getattr(self, "_sparse_mode", False)))
+
+    def _sparse_for_step(self, step: int) -> bool:
+        """Kind of the step about to run ("auto": every 64th step is a sparse one whatever the mode -- the probe)."""
+        mode = self.cfg.sparse_backward
+        if mode != "auto":
+            return mode == "on"
+        self._sparse_poll()
+        return bool(getattr(self, "_sparse_mode", False)) or step % self._SPARSE_PROBE_EVERY == 0
+
+    def _sparse_probe_after(self, step: int, R: int) -> None:
+        """Behind a sparse step of the "auto" mode: ask (asynchronously) how many of its tiles were live."""
+        if self.cfg.sparse_backward != "auto" or step % self._SPARSE_PROBE_EVERY != 0 or getattr(self, "_sparse_pending", None):
+            return
+        if getattr(self, "_sparse_host", None) is None:
+            self._sparse_host = torch.zeros(64, dtype=torch.float32).pin_memory()
+            self._sparse_event = torch.cuda.Event()
+        self._sparse_host.copy_(self.losses[:, 7], non_blocking=True)  # (slot 7 of the loss shards: nvo_main_loss_args::tile_live)
+        self._sparse_event.record()
+        self._sparse_pending = R * self.levels[-1] // 16
+
+    def _sparse_poll(self) -> None:
+        n_tiles = getattr(self, "_sparse_pending", None)
+        if not n_tiles or not self._sparse_event.query():
+            return
+        frac = float(self._sparse_host.sum()) / n_tiles
+        self._sparse_pending = None
+        self._sparse_live_frac = frac
+        if frac < 0.60:
+            self._sparse_mode = True
+        elif frac > 0.75:
+            self._sparse_mode = False
 
     def _dw_replica_plan(self):
         """Zeroed copies of the MLP weight-gradient ranges (EngineConfig.dw_replicas) + the table nvo_fold_replicas takes."""
@@ -1187,55 +1208,28 @@ class NerfactoEngine:
         batch = []
         mask = 0
         fused = getattr(self, "_fused_adam_range", None)  # (set around the capture of the one-graph step)
-        tail_join, self._tail_join = getattr(self, "_tail_join", None), None
-        late = []  # (overlap_optimizer_tail) ranges whose gradient comes out of the pass the launch runs beside: stepped behind the join
         for g in active:
             lo, hi = span(g)
             gi = order.index(g)
             mask |= 1 << gi
             hyper = self.dev_scalars.data_ptr() + 4 * (1 + 3 * gi) if from_device_scalars else None
-            parts = [(lo, hi, False)]
+            parts = [(lo, hi)]
             if g == "fields" and fused is not None:
                 # the main grid's backward has already stepped [fused): the launch covers what lies around it
                 assert shard is None and grads_half is None and lo <= fused[0] < fused[1] <= hi
-                parts = [(lo, fused[0], False), (fused[1], hi, False)]
-                if tail_join is not None:
-                    # ... and the streamed levels in front of [fused) -- the main grid's dense level 4, whose bins meet in
-                    # float atomics and are therefore not stepped by the pass -- get their gradient from it
-                    s_lo = self._streamed_grad_lo()
-                    assert lo <= s_lo <= fused[0]
-                    parts = [(lo, s_lo, False), (s_lo, fused[0], True), (fused[1], hi, False)]
-            for a_, b_, late_ in parts:
+                parts = [(lo, fused[0]), (fused[1], hi)]
+            for a_, b_ in parts:
                 if b_ > a_:
-                    (late if late_ else batch).append(
-                        _lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
-                                       bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
+                    batch.append(_lib.AdamGroup(offset=a_, n=b_ - a_, lr=self._group_lr(g), step=0, hyper_dev=hyper,
+                                                bias_dev=self.dev_bias.data_ptr() + 8 * gi, flag_slot=gi, flag_slot_set=1))
         if not batch:
-            if tail_join is not None:
-                for st_ in tail_join[1]:
-                    torch.cuda.current_stream(self.device).wait_stream(st_)
             return
         arr = (_lib.AdamGroup * len(batch))(*batch)
         dyn = cfg.dynamic_loss_scale
-
-        def launch_adam(st, arr=arr, n=len(batch)):
-            _call("nvo_adam_step_groups_scaled", st, n, arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
-                  ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
-                  1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
-                  _ptr(self.dev_loss_scale) if dyn else None)
-
-        if tail_join is not None and tail_join[0] == "tail":
-            # (forward_backward left a tail stream waiting at the fork point of the main grid's backward: the launch goes
-            # there, beside the accumulate pass this stream is in)
-            with torch.cuda.stream(tail_join[1][0]):
-                launch_adam(_stream(self.device))
-        else:
-            launch_adam(stream)
-        if tail_join is not None:
-            for st_ in tail_join[1]:
-                torch.cuda.current_stream(self.device).wait_stream(st_)  # join: the commit below is the step's last launch
-            if late:
-                launch_adam(stream, (_lib.AdamGroup * len(late))(*late), len(late))
+        _call("nvo_adam_step_groups_scaled", stream, len(batch), arr, _ptr(self.params), _ptr(self.params_half), _ptr(gbuf),
+              ghalf, _ptr(self.exp_avg), _ptr(self.exp_avg_sq), cfg.adam_betas[0], cfg.adam_betas[1], cfg.adam_eps,
+              1.0 / cfg.loss_scale, 0.0, _ptr(self.skip_flag), len(self.bf16_ranges), self._bf16_lo, self._bf16_hi,
+              _ptr(self.dev_loss_scale) if dyn else None)
         scale_mask = 0
         if dyn and "fields" in active:  # the fields group is stepped last in every launch order
             for g in (step_groups if step_groups is not None else active):
@@ -1249,15 +1243,6 @@ class NerfactoEngine:
               _ptr(self.dev_loss_scale) if scale_mask else None, _ptr(self.dev_growth_tracker) if scale_mask else None,
               cfg.loss_scale_growth, cfg.loss_scale_backoff, int(cfg.loss_scale_interval), cfg.loss_scale_min, cfg.loss_scale_max,
               _ptr(self.dev_bias), cfg.adam_betas[0], cfg.adam_betas[1])
-
-    def _streamed_grad_lo(self) -> int:
-        """First element of the flat buffer whose gradient comes out of the main grid's accumulate pass (nvo_streamed_grad_range)."""
-        if getattr(self, "_streamed_lo", None) is None:
-            first, n = C.c_uint64(0), C.c_uint64(0)
-            _call("nvo_streamed_grad_range", self.base_net.handle, C.byref(first), C.byref(n))
-            assert n.value > 0
-            self._streamed_lo = self.segments["field.base"][0] + int(first.value)
-        return self._streamed_lo
 
     def _fused_adam_plan(self):
         """(lo, hi) of the flat parameter buffer whose Adam step the main grid's backward can take over
@@ -1284,15 +1269,8 @@ class NerfactoEngine:
         around the capture of the one-graph step only, so that eager steps keep storing the gradient)."""
         if not on:
             _call("nvo_set_fused_adam", self.base_net.handle, None)
-            if getattr(self, "_fork_point_armed", False):
-                self.base_net.set_option("bwd_mark_fork_point", 0)
-                self._fork_point_armed = False
             return
         cfg = self.cfg
-        import os
-        if cfg.overlap_optimizer_tail and int(os.environ.get("NVO_OVERLAP_TAIL", "1")):  # (A/B switch for measurements)
-            self.base_net.set_option("bwd_mark_fork_point", 1)
-            self._fork_point_armed = True
         gi = self._GROUP_ORDER.index("fields")
         base = self.segments["field.base"][0]
         a = _lib.FusedAdamArgs(
@@ -1427,7 +1405,8 @@ class NerfactoEngine:
         has_depth = dataset.frames_depth is not None
         has_normals = bool(getattr(dataset, "use_normals", False)) and cfg.normal_loss_mult > 0.0
         values = self.proposal_values_due(step, updated)
-        key = (R, updated, has_depth, all_reduce is not None, has_normals, values)
+        sparse = self._sparse_for_step(step) and self.levels[-1] % 16 == 0
+        key = (R, updated, has_depth, all_reduce is not None, has_normals, values, sparse)
         self._reducer = all_reduce
         if self._pix_scale is None:
             self._pix_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -1445,14 +1424,18 @@ class NerfactoEngine:
             mode = cfg.proposal_loss_values
             variants = [(True, False)] + ([(False, False)] if mode != "always" else []) + (
                 [(False, True)] if mode != "never" else [])
+            # (... and, EngineConfig.sparse_backward "auto", both kinds of every variant: the probe runs a sparse step every
+            # 64th step from the start, and the switch to sparse steps comes in the middle of a run)
+            kinds = [False, True] if (cfg.sparse_backward == "auto" and self.levels[-1] % 16 == 0) else [sparse]
             for v_upd, v_val in variants:
-                vkey = (R, v_upd, has_depth, all_reduce is not None, has_normals, v_val)
-                if vkey in self._graphs:
-                    continue
-                v_groups = ["fields"] + (["proposal_networks"] if v_upd else []) + (
-                    ["camera_opt"] if cfg.optimize_poses else [])
-                self._graphs[vkey] = self._capture_step(dataset, R, v_upd, has_depth, v_groups, all_reduce is not None,
-                                                        has_normals, v_val)
+                for v_sparse in kinds:
+                    vkey = (R, v_upd, has_depth, all_reduce is not None, has_normals, v_val, v_sparse)
+                    if vkey in self._graphs:
+                        continue
+                    v_groups = ["fields"] + (["proposal_networks"] if v_upd else []) + (
+                        ["camera_opt"] if cfg.optimize_poses else [])
+                    self._graphs[vkey] = self._capture_step(dataset, R, v_upd, has_depth, v_groups, all_reduce is not None,
+                                                            has_normals, v_val, sparse=v_sparse)
             entry = self._graphs[key]
         if all_reduce is None and not entry.get("pipelined"):
             self._pending_head = None
@@ -1489,6 +1472,8 @@ class NerfactoEngine:
             entry["run"](pipeline)
             if pipeline:
                 self._pending_head = (step + 1, getattr(dataset, "version", 0), extent)
+        if sparse:
+            self._sparse_probe_after(step, R)  # (reads the loss shards: before anything of the next step clears them)
         if updated:
             self.steps_since_proposal_update = 0
         self.steps_since_proposal_update += 1
@@ -1497,7 +1482,7 @@ class NerfactoEngine:
             self._commit_and_write(entry["commit"], self.step)  # (self.step: the NEXT step's learning rates and sampler state)
         return updated
 
-    def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False, values=False):
+    def _capture_step(self, dataset, R, updated, has_depth, groups, split, has_normals=False, values=False, sparse=False):
         dev = self.device
         cfg = self.cfg
         ws = self._workspace(R, True)
@@ -1600,7 +1585,8 @@ class NerfactoEngine:
 
         def body_rest():
             self.forward_backward(ws, jits, has_depth=has_depth, update_proposals=updated, anneal=1.0,
-                                  anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True, proposal_values=values)
+                                  anneal_dev=anneal_ptr, has_normals=has_normals, skip_head=True, proposal_values=values,
+                                  sparse=sparse)
             if half is None:
                 return
             cast = "nvo_cast_bf16" if half.dtype == torch.bfloat16 else "nvo_cast_half"

@@ -2,5 +2,5 @@
 F="--mapping-loop off --pmc-traffic off --no-cpu-baseline --psnr off --ngp-steps 0 --render-frames 0"
 for i in 1 2; do
 for v in 8 1 2; do
-NVO_OVERLAP_TAIL=0 NVO_TL_DENSE_CHUNKS=$v python bench.py $F 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dense chunks $v', r['ms_per_step'])"
+NVO_TL_DENSE_CHUNKS=$v python bench.py $F 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dense chunks $v', r['ms_per_step'])"
 done; done

@@ -1,5 +1,5 @@
-"""Same-state A/B of the live-tile list of the main field's MLP backwards (NVO_MLP_SKIP_DEAD) and of the hash grid's
-live-row list (NVO_GRID_LIVE_ROWS): run the mapping loop once,
+"""Same-state A/B of EngineConfig.sparse_backward (the live-tile lists of the main field's MLP backwards) and of the hash
+grid's live-row list (NVO_GRID_LIVE_ROWS): run the mapping loop once,
 then time blocks of graph-replayed steps on the trained field with the step graphs re-captured under either setting,
 alternating, in one process.  Prints ms/step per block and the loss scale (which sets how much of dL/d(rgb) underflows)."""
 import os
@@ -33,18 +33,18 @@ GRAPHS = {}
 SCALE = float(os.environ.get("NVO_AB_LOSS_SCALE", "0"))  # > 0: pin the GradScaler's scale for the blocks (64 = the underflow regime)
 
 
-def block(skip: bool, rows: bool, tail: bool = True, steps: int = 300) -> float:
+def block(sparse: bool, rows: bool, steps: int = 300) -> float:
     if SCALE > 0:
         eng.dev_loss_scale.fill_(SCALE)
         eng.dev_growth_tracker.zero_()
-    for key, on in (("NVO_MLP_SKIP_DEAD", skip), ("NVO_GRID_LIVE_ROWS", rows), ("NVO_OVERLAP_TAIL", tail)):
-        if on:
-            os.environ.pop(key, None)
-        else:
-            os.environ[key] = "0"
+    eng.cfg.sparse_backward = "on" if sparse else "off"  # (EngineConfig.sparse_backward: which kind of step graph runs)
+    if rows:
+        os.environ.pop("NVO_GRID_LIVE_ROWS", None)
+    else:
+        os.environ["NVO_GRID_LIVE_ROWS"] = "0"  # (read when a graph is captured: the MLP backwards keep their tile lists)
     # one set of step graphs per setting, all kept alive (dropping the graphs of a setting and capturing again crashed a
     # later replay -- tools/probes/recapture_repro.py; not a flow the mapper has)
-    eng._graphs = GRAPHS.setdefault((skip, rows, tail), {})
+    eng._graphs = GRAPHS.setdefault((sparse, rows), {})
     for _ in range(12):  # warm-up: eager step + captures of the variants the schedule uses here
         eng.train_step_graphed(ds)
     torch.cuda.synchronize()
@@ -55,12 +55,12 @@ def block(skip: bool, rows: bool, tail: bool = True, steps: int = 300) -> float:
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-# (MLP live-tile list, grid live-row list[, optimiser tail beside the accumulate pass])
-ORDER = [(c[0] == "1", c[1] == "1", c[2:3] != "0") for c in os.environ.get("NVO_AB_ORDER", "11,10,01,00").split(",")]
+# (sparse steps, grid live-row list)
+ORDER = [(c[0] == "1", c[1:2] != "0") for c in os.environ.get("NVO_AB_ORDER", "11,10,00").split(",")]
 for rep in range(int(os.environ.get("NVO_AB_REPS", "3"))):
-    for skip, rows, tail in ORDER:
-        ms = block(skip, rows, tail)
+    for sparse, rows in ORDER:
+        ms = block(sparse, rows)
         ws = eng._workspace(eng.cfg.num_rays, True)
         live = ws["tile_live"]
-        print(f"rep {rep} MLP live-tile list {'on ' if skip else 'off'} grid live-row list {'on ' if rows else 'off'} tail {'beside' if tail else 'behind'}: {ms:.4f} ms/step  loss scale {eng.current_loss_scale():g}  "
+        print(f"rep {rep} sparse steps {'on ' if sparse else 'off'} grid live-row list {'on ' if rows else 'off'}: {ms:.4f} ms/step  loss scale {eng.current_loss_scale():g}  "
               f"tiles with rgb gradient {float((live & 1).bool().float().mean()):.3f}  with any {float((live != 0).float().mean()):.3f}", flush=True)
