@@ -1681,6 +1681,11 @@ class NerfactoEngine:
                  "captured_collectives": False}
 
         def capture(fn, **kw):
+            if split:
+                # (a process group is up: its watchdog thread polls events, which a GLOBAL-mode capture on this thread
+                # forbids -- "operation not permitted when stream is capturing", seen once the sparse / dense kinds doubled
+                # the number of captures; thread-local mode confines the restriction to this thread)
+                kw.setdefault("capture_error_mode", "thread_local")
             g = torch.cuda.CUDAGraph()
             with capture_graph(g, **kw):
                 fn()

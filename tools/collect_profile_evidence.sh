@@ -71,26 +71,25 @@ probes)
     { for v in 0 1; do NVO_GRID_SLICE_CODES=$v python3 $ROOT/tools/probes/bwd_codes_ab.py /tmp/ab_codes.pt 2>&1 | grep -E "grid_bwd|identical|saved"; done; } > $OUT/${R}_probe_bwd_slice_codes.txt
     $ROOT/tools/probes/launch_probe > $OUT/${R}_probe_launch_staging.txt 2>&1
     tail -n +1 $OUT/${R}_probe_*.txt | cut -c1-170 ;;
-lists)   # round 6: what a trained field's dead tiles buy (same-state A/B), the optimiser tail beside the accumulate pass
-    { echo "--- tools/probes/dead_tiles_ab.py, loss scale pinned to 64 (the underflow regime of the run): MLP live-tile list | grid live-row list | tail"
-      NVO_AB_LOSS_SCALE=64 NVO_AB_ORDER=111,110,100,010,000 python3 $ROOT/tools/probes/dead_tiles_ab.py 2>/dev/null | grep "^rep"
-      echo "--- tools/probes/bench_tail_ab.sh (driver-style workload, every step an update step)"
-      (cd $ROOT && bash tools/probes/bench_tail_ab.sh)
-      echo "--- tools/probes/bench_lists_ab.sh (driver-style workload: every tile live, the lists are not built)"
+lists)   # round 6: what a trained field's dead tiles buy (EngineConfig.sparse_backward), and what the probe costs where none are dead
+    { echo "--- tools/probes/dead_tiles_ab.py (one trained state, loss scale pinned to 64): sparse steps | grid live-row list"
+      NVO_AB_LOSS_SCALE=64 NVO_AB_ORDER=11,10,00 python3 $ROOT/tools/probes/dead_tiles_ab.py 2>/dev/null | grep "^rep"
+      echo "--- tools/probes/bench_lists_ab.sh (driver-style workload: every tile live; auto = a sparse step every 64th step)"
       (cd $ROOT && bash tools/probes/bench_lists_ab.sh)
+      echo "--- tools/probes/loop_early_ab.sh"
+      (cd $ROOT && bash tools/probes/loop_early_ab.sh)
       echo "--- tools/probes/live_fraction.py"
       python3 $ROOT/tools/probes/live_fraction.py 2>/dev/null | grep "^step"; } > $OUT/${R}_probe_dead_tiles.txt
-    # kernel statistics of the last 240 iterations of the whole mapping run, lists + tail armed / not armed (one capture per
-    # process: rocprofv3 around a process that captures a second set of step graphs crashed in hipGraphLaunch)
-    for o in 111 000; do
+    # kernel statistics of the last 240 iterations of the whole mapping run, sparse steps armed (auto) / off (one capture set
+    # per process: rocprofv3 around a process that captures a second set of step graphs crashed in hipGraphLaunch)
+    for o in auto off; do
         rm -rf /tmp/pp_$o
-        if [ $o = 000 ]; then export NVO_MLP_SKIP_DEAD=0 NVO_GRID_LIVE_ROWS=0 NVO_OVERLAP_TAIL=0; fi
-        rocprofv3 --kernel-trace --output-format csv -d /tmp/pp_$o -- python3 $ROOT/tools/mapping_loop.py --profile-steps 0 --render-frames 0 2> /dev/null | grep "^{" > $OUT/${R}_mapping_loop_lists_$o.json
-        python3 $ROOT/tools/rocprof_clean_stats.py /tmp/pp_$o --last 240 > $OUT/${R}_trained_field_kernel_stats_lists_$o.csv 2>/dev/null
-        python3 -c "import json,sys; d=json.load(open('$OUT/${R}_mapping_loop_lists_$o.json')); print('lists/tail $o: loop', round(d['wall_seconds'],3), 's; windows', [(w['first_iteration'], round(w['ms_per_iteration'],4), w['loss_scale']) for w in d['windows']])" >> $OUT/${R}_probe_dead_tiles.txt
+        NVO_SPARSE_BACKWARD=$o rocprofv3 --kernel-trace --output-format csv -d /tmp/pp_$o -- python3 $ROOT/tools/mapping_loop.py --profile-steps 0 --render-frames 0 2> /dev/null | grep "^{" > $OUT/${R}_mapping_loop_sparse_$o.json
+        python3 $ROOT/tools/rocprof_clean_stats.py /tmp/pp_$o --last 240 > $OUT/${R}_trained_field_kernel_stats_sparse_$o.csv 2>/dev/null
+        python3 -c "import json,sys; d=json.load(open('$OUT/${R}_mapping_loop_sparse_$o.json')); print('sparse_backward $o: loop', round(d['wall_seconds'],3), 's; windows', [(w['first_iteration'], round(w['ms_per_iteration'],4), w['loss_scale']) for w in d['windows']])" >> $OUT/${R}_probe_dead_tiles.txt
+        rm -rf /tmp/pp_$o
     done
-    unset NVO_MLP_SKIP_DEAD NVO_GRID_LIVE_ROWS NVO_OVERLAP_TAIL
-    cat $OUT/${R}_probe_dead_tiles.txt; head -14 $OUT/${R}_trained_field_kernel_stats_lists_111.csv ;;
+    cat $OUT/${R}_probe_dead_tiles.txt; head -14 $OUT/${R}_trained_field_kernel_stats_sparse_auto.csv ;;
 phase)   # shader-clock shares of the grid kernels (an instrumented build: the product library is rebuilt afterwards)
     for v in 1 4; do
         NVO_EXTRA_CXXFLAGS=-DNVO_GRID_PHASE NVO_GRID_FWD_SMALL=$v python3 $ROOT/tools/grid_phase.py --steps 60 --dynamic-loss-scale 2>&1 | grep -A8 "k_grid_fwd_small, per workgroup" | sed "s/^/[NVO_GRID_FWD_SMALL=$v] /"
