@@ -763,7 +763,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
         return (a.tile_live[t] & a.tile_live_bits) != 0u ? 1u : 2u;
     };
     // (the bytes of the first round are requested with the matrices -- one round trip -- unless a count of the live tiles
-    // is at hand: then they wait for the decision, and the untrained field, every tile live, never loads them)
+    // is at hand: then they wait for the decision; requesting them early regardless measured the same)
     uint32_t flag0 = 0u;
     if constexpr (kListIo) {
         if (list_pre && !a.tile_live_count) flag0 = tile_flag(threadIdx.x);
@@ -857,8 +857,14 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
                 if (flag == 2u) live_list[kLiveListCap - 1u - (pd + (uint32_t)__popcll(bd & lt))] = (uint16_t)code;
                 __syncthreads();  // the list is complete up to here; the count words are free again
             }
+            // (colour head) the camera index of this chain wave's first listed tile heads a dependent chain -- index ->
+            // embedding row -> the tile's loads: requested here, it arrives while the zeros below are stored
+            if constexpr (IO == NVO_IO_NERFACTO_COLOR) {
+                if (a.cam_idx && !is_dw && n_live > (uint32_t)wib)
+                    cam_first = (uint32_t)a.cam_idx[(own_tile(live_list[wib]) * 16 + m) / a.samples_per_ray];
+            }
             // dX of the dead tiles: zeros (all twelve waves, a tile per wave and turn; stores only)
-            if (need_dinput && !(a.tile_live_bits & 0x100u)) {
+            if (need_dinput) {
                 const T z = (T)0.f;
                 for (uint32_t d = (uint32_t)wib_all; d < n_dead; d += 3u * kWavesPerBlock) {
                     const uint32_t tile = own_tile(live_list[kLiveListCap - 1u - d]);
@@ -976,7 +982,7 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     if (my_steps) {
         t_cur = step_tile(0u);
         t_nxt = step_tile(1u);
-        load_tile(t_cur, cur, use_list ? load_cam(t_cur) : cam_first);
+        load_tile(t_cur, cur, cam_first);  // (list form: cam_first was re-requested for the first LISTED tile, see there)
         cam_nxt = load_cam(t_nxt);
     }
     // Nothing issued before the loop may still be pending when it starts: the compiler's waits for such loads (weight
