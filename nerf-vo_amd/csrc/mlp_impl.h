@@ -1096,15 +1096,22 @@ NVO_MLP_NAME(k_mlp_bwd)(Args a) {
     };
     auto chain_loop = [&](auto list_c) __attribute__((always_inline)) {
     constexpr bool kList = decltype(list_c)::value;
-    for (uint32_t st = 0; st < my_steps; ++st) {
-        const uint32_t tile = t_cur;
+    // (the plain form keeps the loop it always had -- a tile index striding by the wave count: the list form's step
+    // counter and carried tile indices cost the base network's plain kernel 1 us of its 19)
+    for (uint32_t st = 0, tile_p = wave; kList ? st < my_steps : (tile_p < n_tiles && !is_dw); ++st, tile_p += n_waves) {
+        const uint32_t tile = kList ? t_cur : tile_p;
         const uint32_t row = tile * 16 + m;
         NVO_PH(9);
         TileIn nxt;  // unconditional (clamped) so that no join forces the loads to complete here
-        load_tile(t_nxt, nxt, cam_nxt);
-        t_cur = t_nxt;
-        t_nxt = step_tile_c(list_c, st + 2u);
-        cam_nxt = load_cam(t_nxt);
+        if constexpr (kList) {
+            load_tile(t_nxt, nxt, cam_nxt);
+            t_cur = t_nxt;
+            t_nxt = step_tile_c(list_c, st + 2u);
+            cam_nxt = load_cam(t_nxt);
+        } else {
+            load_tile(min(tile + n_waves, n_tiles - 1u), nxt, cam_nxt);
+            cam_nxt = load_cam(min(tile + 2u * n_waves, n_tiles - 1u));
+        }
         NVO_PH(0);
         if constexpr (kRowsIo) {
             if (kList && a.live_rows) {  // (kernel-uniform) list this tile's samples with a non-zero dL/doutput row
