@@ -135,7 +135,8 @@ def run(keyframes=192, height=480, width=640, iterations=8192, window_steps=200,
             open_w.update({"iterations": n, "ms_per_iteration": dt / n * 1e3, "ray_samples_per_sec": n * eng.cfg.num_rays * eng.cfg.num_nerf_samples / dt,
                            "ingests_inside": open_w["ingests_inside"], "proposal_updates": updates_in_window,
                            "keyframes_active_at_end": int(mapper.trainer.pipeline.datamanager.train_dataset.num_active_frames),
-                           "loss_scale": eng.current_loss_scale()})
+                           "loss_scale": eng.current_loss_scale(),
+                           "sparse_steps": bool(getattr(eng, "_sparse_mode", False))})
             windows.append(open_w)
             open_w = None
         if open_w is None and starts and mapper.step >= starts[0]:
@@ -225,6 +226,10 @@ def run(keyframes=192, height=480, width=640, iterations=8192, window_steps=200,
         "ticks": ticks, "skipped_ticks": skipped, "ingests": len(ingest_events), "ingest_gpu_ms_total": ingest_ms,
         "ingest_gpu_ms_each": ingest_ms / max(len(ingest_events), 1),
         "windows": windows, "final_losses": losses, "loss_scale_end": eng.current_loss_scale(),
+        # EngineConfig.sparse_backward: which kind of step the run ended on, and the live-tile fraction its
+        # last probe read (one of a ray's three tiles on a trained field; 1.0 while GradScaler's scale keeps everything live)
+        "sparse_backward": {"config": eng.cfg.sparse_backward, "sparse_steps_at_the_end": bool(getattr(eng, "_sparse_mode", False)),
+                            "live_tile_fraction_last_probe": getattr(eng, "_sparse_live_frac", None)},
         "render_of_the_trained_field": rendered,
         "trained_field_kernel_table": table,
         "trained_field_kernel_us_per_step": round(sum(r["us_per_step"] for r in table), 2),
