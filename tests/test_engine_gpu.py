@@ -848,6 +848,40 @@ def test_grid_backward_walks_the_live_rows_of_a_trained_field(device, monkeypatc
     _assert_close(g_on, g_off, rtol=1e-4, atol_scale=1e-6, what="gradient, listed vs full scan", max_outlier_frac=1e-4)
 
 
+@pytest.mark.parametrize("bias,expect_sparse", [(-1.0, False), (12.0, True)], ids=["untrained-field", "hard-surfaces"])
+def test_sparse_backward_auto_follows_the_field(device, bias, expect_sparse):
+    """EngineConfig.sparse_backward = "auto": every 64th step is a sparse one (the probe), the live-tile count it leaves in
+    slot 7 of the loss shards is read back asynchronously, and all steps switch to the sparse graphs while fewer than 60 %
+    of the tiles are live.  An untrained field (every tile live) must stay on dense steps, a field whose first sample takes
+    the ray's weight (density bias +12: about half of the tiles live) must switch -- and both kinds of every step variant
+    are captured up front, so the switch never captures in the middle of a run."""
+    from nerf_vo_amd.engine import EngineConfig, NerfactoEngine
+    from nerf_vo_amd.mapping.dataset import DynamicDataset, opencv_to_opengl
+    from nerf_vo_amd.synthetic import make_sequence
+
+    n, H, W, R = 6, 60, 80, 1024
+    ds = DynamicDataset(num_frames=n, frame_height=H, frame_width=W, device=device, use_normals=False)
+    seq = make_sequence(n, H, W, device=device)
+    ds.update({"keyframe_indices": torch.arange(n), "camera_intrinsics": seq["camera_intrinsics"],
+               "camera_extrinsics": opencv_to_opengl(seq["camera_extrinsics"]), "frames_color": seq["frames_color"],
+               "frames_depth": seq["frames_depth"]})
+    torch.manual_seed(5)
+    eng = NerfactoEngine(EngineConfig(num_images=n, num_rays=R, dynamic_loss_scale=False, density_bias=bias), device)
+    assert eng.cfg.sparse_backward == "auto"
+    eng.train_step_graphed(ds)  # step 0: a probe
+    n_graphs = len(eng._graphs)
+    assert n_graphs == 6 and sum(1 for k in eng._graphs if k[-1]) == 3
+    torch.cuda.synchronize()    # (the copy has landed: the next step polls it)
+    for _ in range(70):
+        eng.train_step_graphed(ds)
+    torch.cuda.synchronize()
+    assert len(eng._graphs) == n_graphs, "no capture after the first step"
+    frac = eng._sparse_live_frac
+    assert (frac < 0.60) == expect_sparse and 0.0 < frac <= 1.0, frac
+    assert bool(getattr(eng, "_sparse_mode", False)) == expect_sparse
+    assert int(eng.skip_flag.sum()) == 0 and bool(torch.isfinite(eng.params).all())
+
+
 @pytest.mark.parametrize("dynamic", [False, True], ids=["static-scale", "dynamic-scale"])
 def test_commit_behind_the_replay_is_bit_identical(device, dynamic):
     """EngineConfig.commit_behind_replay: the optimiser's commit (applied-step counters, bias corrections, loss scale)
