@@ -1,4 +1,6 @@
 # rocprofv3 kernel trace of graph-replayed driver-style steps: this tree against the baseline worktree (_basetree)
+# (the baseline: `git worktree add -f _basetree <commit> && (cd _basetree && python -c "import __graft_entry__ as g; g.build()")`;
+#  _basetree/ is git-ignored, travels to the GPU box with the snapshot, and is removed again with `git worktree remove --force _basetree`)
 export TMPDIR=/tmp
 ROOT=$(pwd)
 F="--mapping-loop off --pmc-traffic off --no-cpu-baseline --psnr off --ngp-steps 0 --render-frames 0 --steps 100 --warmup 20 --late-steps 0 --no-kernel-table"
